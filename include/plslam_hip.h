@@ -1,0 +1,209 @@
+/*
+ * plslam_hip.h -- C ABI of the MI355X-native PL-SLAM front end (libplslam_hip.so).
+ *
+ * This is the drop-in boundary for the per-frame hot path of HarborC/PL-SLAM:
+ *   ORBextractor::operator()      reference src/ORBextractor.cc:1043-1105
+ *   LINEextractor::operator()     reference src/LineExtractor.cpp:26-93
+ *   ORBmatcher  Hamming searches  reference src/ORBmatcher.cc:187-327, 455-572, 1764-1780
+ *   LSDmatcher  brute-force 2-NN  reference src/LSDmatcher.cpp:375-486, 627-670
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch / OpenCV types cross this boundary.
+ *   - every function returns a plh_status (0 = ok); nothing throws.
+ *   - "_dev" entry points take DEVICE pointers and a HIP stream (void* = hipStream_t) and
+ *     enqueue work asynchronously on that stream; the caller synchronises.  The non-"_dev"
+ *     entry points take HOST buffers, stage them over PCIe and block until results are back:
+ *     they are the direct replacement for one reference call (see pl-slam_amd/adaptor/).
+ *   - batch layout is "frame-major": B frames, each a contiguous rows*cols u8 plane at
+ *     stride `frame_stride` bytes; results are fixed-stride records (capacity per frame is
+ *     queried from the handle) plus an int32 count per frame.
+ *   - a handle is NOT re-entrant (same rule as the reference's ORBextractor, which keeps
+ *     mvImagePyramid); different handles may be used concurrently from different host
+ *     threads (Frame.cc:224-225 runs the ORB and line extractors on two threads).
+ */
+#ifndef PLSLAM_HIP_H
+#define PLSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLH_API __attribute__((visibility("default")))
+
+typedef enum plh_status {
+  PLH_OK = 0,
+  PLH_ERR_INVALID = 1,    /* bad argument (null, size out of the handle's plan, ...) */
+  PLH_ERR_NO_DEVICE = 2,  /* no HIP device / hipSetDevice failed */
+  PLH_ERR_HIP = 3,        /* a HIP runtime call failed; see plh_last_error() */
+  PLH_ERR_CAPACITY = 4,   /* an internal fixed-capacity buffer overflowed (reported, never silent) */
+  PLH_ERR_ALLOC = 5
+} plh_status;
+
+/* Layout-identical to cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct plh_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} plh_keypoint;
+
+/* Layout-identical to cv::line_descriptor::KeyLine (68 bytes),
+ * field order per Thirdparty/line_descriptor/include/line_descriptor/descriptor_custom.hpp:105-175. */
+typedef struct plh_keyline {
+  float angle;
+  int32_t class_id, octave;
+  float pt_x, pt_y;
+  float response, size;
+  float startPointX, startPointY, endPointX, endPointY;
+  float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+  float lineLength;
+  int32_t numOfPixels;
+} plh_keyline;
+
+PLH_API const char* plh_last_error(void);     /* thread-local message of the last failing call */
+PLH_API const char* plh_version(void);
+PLH_API int plh_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * ORB extractor  (replaces ORB_SLAM2::ORBextractor, include/ORBextractor.h:45-111)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct plh_orb plh_orb;
+
+typedef struct plh_orb_params {    /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) */
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels;
+  int32_t ini_th_fast;
+  int32_t min_th_fast;
+} plh_orb_params;
+
+/* Plan a handle for images of exactly rows x cols and up to max_batch frames per call. */
+PLH_API plh_status plh_orb_create(const plh_orb_params* p, int device, int rows, int cols, int max_batch, plh_orb** out);
+PLH_API plh_status plh_orb_destroy(plh_orb* h);
+
+/* Scale tables, as the reference getters return them (GetScaleFactors() etc., ORBextractor.h:62-84).
+ * which: 0 = mvScaleFactor, 1 = mvInvScaleFactor, 2 = mvLevelSigma2, 3 = mvInvLevelSigma2. out[nlevels]. */
+PLH_API plh_status plh_orb_scale_table(const plh_orb* h, int which, float* out);
+PLH_API int plh_orb_levels(const plh_orb* h);
+/* Features-per-level split (mnFeaturesPerLevel, ORBextractor.cc:435-446). out[nlevels]. */
+PLH_API plh_status plh_orb_features_per_level(const plh_orb* h, int32_t* out);
+/* Per-frame record capacity: sum over levels of max(N_l + 3, 4*nIni) (the quad-tree can overshoot N_l by <= 2). */
+PLH_API int plh_orb_capacity(const plh_orb* h);
+
+/* One frame, host buffers: the ORBextractor::operator() replacement (ORBextractor.cc:1043-1105).
+ * img: rows x cols u8, `step` bytes per row. kps[cap], desc[cap*32]; *n_out = number of keypoints.
+ * rows==0 || cols==0 is the reference's "empty image -> silent return": *n_out = 0, PLH_OK. */
+PLH_API plh_status plh_orb_extract(plh_orb* h, const uint8_t* img, int rows, int cols, size_t step,
+                                   plh_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Batch, host buffers (frames contiguous, frame_stride bytes apart, rows tightly packed at `cols`). */
+PLH_API plh_status plh_orb_extract_batch(plh_orb* h, const uint8_t* imgs, int batch, size_t frame_stride,
+                                         plh_keypoint* kps, uint8_t* desc, int32_t* n_out);
+
+/* Batch, device buffers, asynchronous on `stream`.
+ *   d_imgs : batch planes of rows*cols u8 (row pitch = cols), frame_stride bytes apart
+ *   d_kps  : batch * capacity plh_keypoint records
+ *   d_desc : batch * capacity * 32 bytes
+ *   d_n    : batch int32 counts
+ * Records of frame b start at b*capacity; order inside a frame is the reference's (level-major,
+ * quad-tree list order). */
+PLH_API plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batch, size_t frame_stride,
+                                             plh_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, void* stream);
+
+/* After an extract call: geometry and DEVICE pointer of pyramid level `level` of frame `b`
+ * (mvImagePyramid[level] of the reference; border-less). */
+PLH_API plh_status plh_orb_pyramid_dev(const plh_orb* h, int b, int level, const uint8_t** d_ptr,
+                                       int* rows, int* cols, size_t* pitch);
+/* Debug/parity taps (device -> host copies, synchronous):
+ *   pyramid level pixels (tightly packed rows*cols), and the FAST candidates of a level in
+ *   the order they enter the quad-tree (x, y in level-image coordinates, response). */
+PLH_API plh_status plh_orb_read_level(plh_orb* h, int b, int level, uint8_t* out, size_t out_bytes);
+PLH_API plh_status plh_orb_read_candidates(plh_orb* h, int b, int level, plh_keypoint* out, int cap, int* n_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hamming matching  (ORBmatcher / LSDmatcher inner loops)
+ * ------------------------------------------------------------------------------------------- */
+
+/* 256-bit Hamming distance of two 32-byte rows: ORBmatcher::DescriptorDistance (ORBmatcher.cc:1764-1780),
+ * LSDmatcher::DescriptorDistance (LSDmatcher.cpp:654-670).  Host helper (scalar). */
+PLH_API int plh_descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+/* Brute-force 2-NN, cv::BFMatcher(NORM_HAMMING,false).knnMatch(q,t,k=2) semantics (LSDmatcher.cpp:468-469):
+ * for each query row the two smallest distances, ties -> lower train index first.
+ * idx/dist are nq x 2 int32 (idx = -1, dist = 256+ when nt < 2 leaves a slot empty). */
+PLH_API plh_status plh_hamming_knn2_dev(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                                        int32_t* d_idx, int32_t* d_dist, void* stream);
+PLH_API plh_status plh_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt,
+                                    int32_t* idx, int32_t* dist, int device);
+
+/* Batched form: P independent (query set, train set) pairs at fixed strides (sets padded to
+ * q_cap / t_cap rows; nq[p], nt[p] give the live row counts). */
+PLH_API plh_status plh_hamming_knn2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, int q_cap,
+                                              const uint8_t* d_t, const int32_t* d_nt, int t_cap,
+                                              int pairs, int32_t* d_idx, int32_t* d_dist, void* stream);
+
+/* LSDmatcher::FrameBFMatch + lineDescriptorMAD (LSDmatcher.cpp:462-486, 627-652) on top of a knn2 table:
+ * matches12[nq] = train index or -1.  th = TH_LOW (50), nnratio = mfNNratio. Batched over pairs. */
+PLH_API plh_status plh_line_bfmatch_batch_dev(const int32_t* d_idx, const int32_t* d_dist, const int32_t* d_nq,
+                                              const int32_t* d_nt, int q_cap, int pairs, float th, float nnratio,
+                                              int32_t* d_matches, void* stream);
+/* LSDmatcher::SearchDouble(Frame&,Frame&,vector<int>&) (LSDmatcher.cpp:427-460): both directions + mutual check.
+ * d_desc1/d_desc2: pairs x cap x 32; matches12: pairs x cap (train index in set 2 or -1); nmatches[pairs]. */
+PLH_API plh_status plh_line_search_double_batch_dev(const uint8_t* d_desc1, const int32_t* d_n1,
+                                                    const uint8_t* d_desc2, const int32_t* d_n2, int cap, int pairs,
+                                                    float th, float nnratio, int32_t* d_matches12,
+                                                    int32_t* d_nmatches, void* d_workspace, size_t workspace_bytes,
+                                                    void* stream);
+PLH_API size_t plh_line_search_double_workspace(int cap, int pairs);
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:187-327) on flat arrays.
+ * Per pair p: set 1 (the KeyFrame) and set 2 (the Frame), each `cap` rows of 32-byte descriptors with
+ * angle[] (degrees) and node[] (DBoW2 FeatureVector node id of the row, ascending groups are NOT required:
+ * rows are grouped by the kernel exactly like std::map<node, vector<idx>> iteration: node ascending, row
+ * index ascending inside a node).  valid1[] != 0 marks KeyFrame rows that carry a live MapPoint.
+ * matches21[cap]: for Frame row j the matched KeyFrame row or -1 (the reference stores the MapPoint*).
+ * th_low = TH_LOW (50), nnratio = mfNNratio, check_ori = mbCheckOrientation. */
+PLH_API plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const float* d_angle1, const int32_t* d_node1,
+                                                   const uint8_t* d_valid1, const int32_t* d_n1,
+                                                   const uint8_t* d_desc2, const float* d_angle2, const int32_t* d_node2,
+                                                   const int32_t* d_n2, int cap, int pairs, int th_low, float nnratio,
+                                                   int check_ori, int32_t* d_matches21, int32_t* d_nmatches,
+                                                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Line extractor  (replaces ORB_SLAM2::LINEextractor, include/LineExtractor.h:20-62)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct plh_line plh_line;
+
+typedef struct plh_line_params {   /* LINEextractor(numOctaves, scale, nLSDFeature, min_line_length) */
+  int32_t num_octaves;             /* only 1 is supported (the reference's int scale truncates 1.2 -> 1) */
+  float scale;
+  uint32_t n_lsd_feature;
+  double min_line_length;
+} plh_line_params;
+
+PLH_API plh_status plh_line_create(const plh_line_params* p, int device, int rows, int cols, int max_batch, plh_line** out);
+PLH_API plh_status plh_line_destroy(plh_line* h);
+PLH_API int plh_line_capacity(const plh_line* h);   /* n_lsd_feature + 1 (LineExtractor.cpp:64 keeps index+1) */
+
+/* Optional per-frame undistortion in front of LSD (Frame.cc:220-222): K = fx,fy,cx,cy ; D = k1,k2,p1,p2,k3.
+ * Maps are built once here (the reference rebuilds them every frame). Pass NULL D or all-zero D to disable. */
+PLH_API plh_status plh_line_set_undistort(plh_line* h, const float K[4], const float D[5]);
+
+/* One frame, host buffers: LINEextractor::operator() (LineExtractor.cpp:26-93).
+ * mask may be NULL (no filtering); a non-NULL mask must be rows x cols u8 (size mismatch is the
+ * reference's std::runtime_error -> PLH_ERR_INVALID). keylines[cap], desc[cap*32], linefn[cap*3] (double). */
+PLH_API plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, int cols, size_t step,
+                                    const uint8_t* mask, plh_keyline* keylines, uint8_t* desc, double* linefn,
+                                    int cap, int* n_out);
+PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride,
+                                              const uint8_t* d_mask, plh_keyline* d_keylines, uint8_t* d_desc,
+                                              double* d_linefn, int32_t* d_n, void* stream);
+/* parity taps */
+PLH_API plh_status plh_line_read_segments(plh_line* h, int b, float* out_xyxy, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSLAM_HIP_H */

@@ -1,0 +1,99 @@
+/*
+ * plo.h -- CPU ORACLE for the PL-SLAM front end.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A dependency-free C++17 restatement of the reference's per-frame hot path, used by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the CHECKER.  Nothing in the
+ * product path (pl-slam_amd/) may include, link or call this.
+ *
+ * PARITY UNPINNED: the reference (HarborC/PL-SLAM) ships no tests, golden vectors or fixtures
+ * for this path, and its sources cannot be built here: every file on the
+ * path needs OpenCV 3.x (+ opencv_contrib line_descriptor) and Eigen3, none of which exist in
+ * this image.  OpenCV version is un-pinned upstream (CMakeLists.txt:29-35).  The arithmetic of
+ * the OpenCV primitives below is restated from the published OpenCV 3.2-3.4.0 algorithms and is
+ * THE definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions").
+ *
+ * Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off: no FMA contraction, IEEE float32).
+ */
+#ifndef PLO_H
+#define PLO_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plo_keypoint {   /* == cv::KeyPoint, 28 bytes */
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} plo_keypoint;
+
+typedef struct plo_keyline {    /* == cv::line_descriptor::KeyLine, 68 bytes */
+  float angle;
+  int32_t class_id, octave;
+  float pt_x, pt_y;
+  float response, size;
+  float startPointX, startPointY, endPointX, endPointY;
+  float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+  float lineLength;
+  int32_t numOfPixels;
+} plo_keyline;
+
+/* ---- OpenCV primitives (restated; not under /root/reference) ---- */
+int   plo_cv_round_f(float v);                                    /* cvRound: round-half-even */
+float plo_fast_atan2(float y, float x);                           /* cv::fastAtan2, degrees */
+void  plo_resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstep,
+                           uint8_t* dst, int dw, int dh, size_t dstep);       /* cv::resize INTER_LINEAR 8UC1 */
+void  plo_gaussian_kernel_q8(int ksize, double sigma, int32_t* out);          /* cvRound(getGaussianKernel*256) */
+void  plo_gaussian_blur_u8(const uint8_t* src, int w, int h, size_t sstep,
+                           uint8_t* dst, size_t dstep, int ksize, double sigma); /* 8U classic path, REFLECT_101 */
+int   plo_fast_score(const uint8_t* center, size_t step, int threshold);      /* cornerScore<16> */
+int   plo_fast9_16(const uint8_t* img, int w, int h, size_t step, int threshold, int nonmax,
+                   plo_keypoint* out, int cap);                               /* cv::FAST TYPE_9_16; returns count */
+void  plo_sobel3_s16(const uint8_t* src, int w, int h, size_t sstep, int16_t* dx, int16_t* dy); /* cv::Sobel ksize 3 */
+void  plo_undistort_maps(const float K[4], const float D[5], int w, int h, float* mapx, float* mapy);
+void  plo_remap_linear_u8(const uint8_t* src, int w, int h, size_t sstep, const float* mapx, const float* mapy,
+                          uint8_t* dst, size_t dstep);                        /* cv::remap INTER_LINEAR, BORDER_CONSTANT 0 */
+
+/* ---- ORB extractor (reference src/ORBextractor.cc) ---- */
+typedef struct plo_orb plo_orb;
+plo_orb* plo_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
+void     plo_orb_destroy(plo_orb*);
+int      plo_orb_levels(const plo_orb*);
+void     plo_orb_scale_table(const plo_orb*, int which, float* out);          /* 0 sf, 1 inv sf, 2 sigma2, 3 inv sigma2 */
+void     plo_orb_features_per_level(const plo_orb*, int32_t* out);
+void     plo_orb_umax(const plo_orb*, int32_t* out16);
+/* operator(): returns number of keypoints (<= cap, -1 if cap too small) */
+int      plo_orb_extract(plo_orb*, const uint8_t* img, int rows, int cols, size_t step,
+                         plo_keypoint* kps, uint8_t* desc, int cap);
+/* taps into the last extract call */
+int      plo_orb_level_size(const plo_orb*, int level, int* rows, int* cols);
+int      plo_orb_read_level(const plo_orb*, int level, uint8_t* out);         /* tightly packed */
+int      plo_orb_read_blurred(const plo_orb*, int level, uint8_t* out);
+int      plo_orb_read_candidates(const plo_orb*, int level, plo_keypoint* out, int cap); /* level-image coords */
+
+/* ---- Hamming matching (reference src/ORBmatcher.cc, src/LSDmatcher.cpp) ---- */
+int  plo_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void plo_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist);
+void plo_line_mad(const int32_t* dist, int nq, double* nn_mad, double* nn12_mad);
+void plo_line_bfmatch(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float th, float nnratio, int32_t* matches);
+int  plo_line_search_double(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float th, float nnratio,
+                            int32_t* matches12);
+int  plo_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
+                           const uint8_t* desc2, const float* angle2, const int32_t* node2, int n2,
+                           int th_low, float nnratio, int check_ori, int32_t* matches21);
+
+/* ---- Line extractor (reference src/LineExtractor.cpp + contrib LSDDetector / BinaryDescriptor) ---- */
+int  plo_lsd_detect(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap);  /* cv::LineSegmentDetector (STD) */
+int  plo_keylines_from_segments(const float* segs, int n, int w, int h, const uint8_t* mask, size_t mstep,
+                                plo_keyline* out);                                              /* LSDDetector::detectImpl */
+void plo_lbd_compute(const uint8_t* img, int w, int h, size_t step, const plo_keyline* kl, int n, uint8_t* desc32,
+                     float* desc_float72);                                                      /* BinaryDescriptor::compute */
+int  plo_line_extract(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask,
+                      unsigned n_lsd_feature, double min_line_length,
+                      plo_keyline* keylines, uint8_t* desc, double* linefn, int cap);           /* LINEextractor::operator() */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
