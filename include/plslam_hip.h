@@ -111,6 +111,12 @@ PLH_API plh_status plh_orb_extract_batch(plh_orb* h, const uint8_t* imgs, int ba
 PLH_API plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batch, size_t frame_stride,
                                              plh_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, void* stream);
 
+/* Per-kernel device time, measured with HIP events recorded on the caller's stream around each launch
+ * group.  kernel: 0 = pyramid (all levels), 1 = FAST cells, 2 = quad-tree, 3 = orientation+rBRIEF.
+ * Call plh_orb_kernel_ms only after synchronising the stream; it folds and clears the pending events. */
+PLH_API plh_status plh_orb_set_profiling(plh_orb* h, int on);
+PLH_API plh_status plh_orb_kernel_ms(plh_orb* h, int kernel, double* total_ms, int* intervals);
+
 /* After an extract call: geometry and DEVICE pointer of pyramid level `level` of frame `b`
  * (mvImagePyramid[level] of the reference; border-less). */
 PLH_API plh_status plh_orb_pyramid_dev(const plh_orb* h, int b, int level, const uint8_t** d_ptr,

@@ -1,0 +1,700 @@
+// HIP kernels of the ORB extractor hot path (gfx950 / CDNA4, wave64).  Batch-first: every kernel
+// takes the frame index from the grid, because one 640x480 frame is ~1 us of HBM time and can
+// never fill 256 CUs by itself (DESIGN.md "batch-first").
+//
+//   k_pyr_down      cv::resize(INTER_LINEAR) level l-1 -> l      ORBextractor::ComputePyramid   (ORBextractor.cc:1107-1132)
+//   k_fast_cells    per-cell cv::FAST 9/16 + 3x3 NMS + fallback   ComputeKeyPointsOctTree        (ORBextractor.cc:789-829)
+//   k_octree        quad-tree keypoint distribution               DistributeOctTree / DivideNode (ORBextractor.cc:481-763)
+//   k_orient_brief  IC_Angle + 7x7 blur + steered rBRIEF          IC_Angle / GaussianBlur / computeOrbDescriptor
+//                                                                 (ORBextractor.cc:77-147, 1085-1101)
+//
+// All integer work is exact; the only floating point on the path is float32 with no FMA
+// contraction (this file is compiled with -ffp-contract=off) so results are bit-identical to
+// the CPU oracle's pinned definition.
+#include "orb_plan.h"
+#include "plh_common.h"
+
+namespace plh {
+
+// rBRIEF sampling pattern (data): 256 pairs, row i = descriptor byte i.
+__device__ const signed char c_orb_pattern[1024] = {
+#include "../../include/plh_orb_pattern.inc"
+};
+
+// u_max of the circular 31-px patch; the host asserts this equals the reference's construction
+// (ORBextractor.cc:454-469).
+__device__ const signed char c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// 7x7 sigma=2 Gaussian in Q8 (cvRound(getGaussianKernel(7,2)*256)); host asserts against its own
+// float evaluation at create time.
+__device__ const int c_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
+
+__device__ __forceinline__ const uint8_t* level_ptr(const OrbDeviceArgs& a, const OrbLevel& lv, int level, int b) {
+  return level == 0 ? a.img0 + (long long)b * a.stride0 : a.pyr + (long long)b * a.pyrFrameBytes + lv.off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pyramid: one level-to-level bilinear downscale, OpenCV fixed-point semantics.
+// grid (ceil(pitch/256), ceil(h/4), batch), block (64,4); each thread produces 4 pixels = one
+// aligned 32-bit store.  Coefficient tables are built on the host in float exactly as cv::resize
+// does, so the device does integer work only.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
+  const OrbLevel S = a.levels[l - 1];
+  const OrbLevel D = a.levels[l];
+  const int b = blockIdx.z;
+  const int x4 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
+  const int y = (int)blockIdx.y * 4 + (int)threadIdx.y;
+  if (y >= D.h || x4 >= D.pitch) return;
+  const uint8_t* src = level_ptr(a, S, l - 1, b);
+  uint8_t* dst = a.pyr + (long long)b * a.pyrFrameBytes + D.off;
+  const ResizeTap ty = a.ytab[D.ytabOff + y];
+  const int sy0 = min(max((int)ty.ofs, 0), S.h - 1);
+  const int sy1 = min(max((int)ty.ofs + 1, 0), S.h - 1);
+  const uint8_t* r0 = src + (long long)sy0 * S.pitch;
+  const uint8_t* r1 = src + (long long)sy1 * S.pitch;
+  const int b0 = ty.a0, b1 = ty.a1;
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int x = x4 + k;
+    if (x < D.w) {
+      const ResizeTap tx = a.xtab[D.xtabOff + x];
+      int s0 = r0[tx.ofs] * tx.a0, s1 = r1[tx.ofs] * tx.a0;
+      if (tx.a1) {
+        s0 += r0[tx.ofs + 1] * tx.a1;
+        s1 += r1[tx.ofs + 1] * tx.a1;
+      }
+      const int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 255) << (8 * k);
+    }
+  }
+  *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + x4) = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9/16 corner measure.  For ring differences d[i] = v - p[i]:
+//   M = max( max_i min(d[i..i+8]),  max_i min(-d[i..i+8]) )
+// pixel is a corner at threshold t  <=>  M > t ; cornerScore<16>() = M - 1 for any corner
+// (the `threshold` floor inside cornerScore only matters for non-corners).  The sliding 9-window
+// min/max over the circular 16-ring is built by doubling (2,4,8,+1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_arc_measure(int v, const int p[16]) {
+  int d[16], lo2[16], lo4[16], lo8[16], hi2[16], hi4[16], hi8[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) d[i] = v - p[i];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo2[i] = min(d[i], d[(i + 1) & 15]);
+    hi2[i] = max(d[i], d[(i + 1) & 15]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo4[i] = min(lo2[i], lo2[(i + 2) & 15]);
+    hi4[i] = max(hi2[i], hi2[(i + 2) & 15]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo8[i] = min(lo4[i], lo4[(i + 4) & 15]);
+    hi8[i] = max(hi4[i], hi4[(i + 4) & 15]);
+  }
+  int dark = -512, bright = 512;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    dark = max(dark, min(lo8[i], d[(i + 8) & 15]));
+    bright = min(bright, max(hi8[i], d[(i + 8) & 15]));
+  }
+  return max(dark, -bright);
+}
+
+// One block per (cell, frame).  The cell sub-image (<= 66x66) is staged in LDS; scores for the
+// evaluated window go to an LDS score tile; NMS treats everything outside the cell's window as
+// score 0 exactly like a per-cell cv::FAST call; wave 0 then emits survivors in raster order.
+// If no survivor reaches iniThFAST the cell falls back to minThFAST (ORBextractor.cc:808-816).
+__global__ void __launch_bounds__(256) k_fast_cells(OrbDeviceArgs a) {
+  __shared__ uint8_t tile[ORB_CELL_MAX * (ORB_CELL_MAX + 2)];
+  __shared__ uint8_t sc[60 * 60];
+  __shared__ uint8_t fl[60 * 60];
+  __shared__ int s_hi;
+  constexpr int TP = ORB_CELL_MAX + 2;
+
+  // XCD-aware decode: block L runs on XCD (L % 8); keep all cells of a frame on one XCD so the
+  // overlapping cell halos and the level rows are served from that XCD's L2.
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q = L >> 3;
+  const int cell = q % a.nCellsTotal;
+  const int b = (q / a.nCellsTotal) * 8 + xcd;
+  if (b >= a.batch) return;
+
+  const OrbCell c = a.cells[cell];
+  const OrbLevel lv = a.levels[c.level];
+  const uint8_t* src = level_ptr(a, lv, c.level, b);
+  const int tid = threadIdx.x;
+  const int cw = c.cw, ch = c.ch;
+
+  for (int i = tid; i < cw * ch; i += 256) {
+    const int r = i / cw, col = i - r * cw;
+    tile[r * TP + col] = src[(long long)(c.y0 + r) * lv.pitch + c.x0 + col];
+  }
+  if (tid == 0) s_hi = 0;
+  __syncthreads();
+
+  const int ew = cw - 6, eh = ch - 6;
+  const int npx = (ew > 0 && eh > 0) ? ew * eh : 0;
+  const int tlo = min(a.iniTh, a.minTh);
+
+  for (int i = tid; i < npx; i += 256) {
+    const int ey = i / ew, ex = i - ey * ew;
+    const uint8_t* t = &tile[(ey + 3) * TP + ex + 3];
+    const int v = t[0];
+    int S = 0;
+    // antipodal quick reject: every 9-arc contains one pixel of each antipodal pair
+    const int p0 = t[3 * TP], p8 = t[-3 * TP], p4 = t[3], p12 = t[-3];
+    const bool q0 = (abs(v - p0) > tlo) || (abs(v - p8) > tlo);
+    const bool q4 = (abs(v - p4) > tlo) || (abs(v - p12) > tlo);
+    if (q0 && q4) {
+      int p[16];
+      p[0] = p0;              p[1] = t[3 * TP + 1];   p[2] = t[2 * TP + 2];   p[3] = t[TP + 3];
+      p[4] = p4;              p[5] = t[-TP + 3];      p[6] = t[-2 * TP + 2];  p[7] = t[-3 * TP + 1];
+      p[8] = p8;              p[9] = t[-3 * TP - 1];  p[10] = t[-2 * TP - 2]; p[11] = t[-TP - 3];
+      p[12] = p12;            p[13] = t[TP - 3];      p[14] = t[2 * TP - 2];  p[15] = t[3 * TP - 1];
+      const int M = fast_arc_measure(v, p);
+      if (M > tlo) S = M - 1;
+    }
+    sc[i] = (uint8_t)S;
+  }
+  __syncthreads();
+
+  int myhi = 0;
+  for (int i = tid; i < npx; i += 256) {
+    const int ey = i / ew, ex = i - ey * ew;
+    const int s = sc[i];
+    int f = 0;
+    if (s > 0 && s >= tlo) {
+      int m = 0;
+      const bool l = ex > 0, r = ex < ew - 1, u = ey > 0, d = ey < eh - 1;
+      if (l) m = max(m, (int)sc[i - 1]);
+      if (r) m = max(m, (int)sc[i + 1]);
+      if (u) {
+        m = max(m, (int)sc[i - ew]);
+        if (l) m = max(m, (int)sc[i - ew - 1]);
+        if (r) m = max(m, (int)sc[i - ew + 1]);
+      }
+      if (d) {
+        m = max(m, (int)sc[i + ew]);
+        if (l) m = max(m, (int)sc[i + ew - 1]);
+        if (r) m = max(m, (int)sc[i + ew + 1]);
+      }
+      if (s > m) f = (s >= a.iniTh) ? 2 : (s >= a.minTh ? 1 : 0);
+    }
+    fl[i] = (uint8_t)f;
+    myhi += (f == 2);
+  }
+  if (myhi) atomicAdd(&s_hi, myhi);
+  __syncthreads();
+
+  if (tid < 64) {
+    const int need = s_hi > 0 ? 2 : 1;
+    uint32_t* out = a.slots + (long long)b * a.slotsPerFrame + c.slotOff;
+    int cnt = 0;
+    for (int base = 0; base < npx; base += 64) {
+      const int i = base + tid;
+      const int f = i < npx ? fl[i] : 0;
+      const bool keep = f >= need;
+      const unsigned long long mask = __ballot(keep);
+      if (keep) {
+        const int pos = cnt + __popcll(mask & lanemask_lt());
+        const int ey = i / ew, ex = i - ey * ew;
+        if (pos < c.slotCap)
+          out[pos] = ((uint32_t)(c.x0 + 3 + ex) << 20) | ((uint32_t)(c.y0 + 3 + ey) << 8) | sc[i];
+      }
+      cnt += __popcll(mask);
+    }
+    if (tid == 0) {
+      if (cnt > c.slotCap) { atomicOr(a.status, 1); cnt = c.slotCap; }
+      a.cellCount[(long long)b * a.nCellsTotal + cell] = (uint32_t)cnt;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quad-tree distribution.  One wavefront per (level, frame).  The reference algorithm is a
+// sequential std::list manipulation whose OUTPUT ORDER is the final list order, so it is kept
+// sequential: lane 0 runs the list logic on node arrays in LDS; the whole wave services the two
+// data-parallel steps it asks for -- the stable 4-way key partition of DivideNode and the
+// (size, creation-id) sort of the "largest first" phase.  Parallelism comes from the batch:
+// batch x levels independent wavefronts.
+//   list order  == descending creation id (children are always push_front'ed)
+//   tie-break   == creation order (PINNED; the reference's is a heap address)
+// ---------------------------------------------------------------------------------------------
+enum { OCT_DONE = 0, OCT_SPLIT = 1, OCT_SORT = 2 };
+enum { S_P1_BEGIN, S_P1_SCAN, S_P1_AFTER, S_P2_BEGIN, S_P2_SORTED, S_P2_NEXT, S_P2_AFTER, S_P2_END };
+
+struct OctLds {
+  short *x0, *x1, *y0, *y1, *next, *prev, *freeStack, *order;
+  int *start, *cnt, *id;
+  uint8_t* buf;
+  int* evSize[2];
+  int* evId[2];
+  short* evSlot[2];
+  int* req;   // [0] op [1] slot/prevIdx [2] n
+};
+
+__device__ __forceinline__ int key_x(uint32_t k) { return (int)(k >> 20); }
+__device__ __forceinline__ int key_y(uint32_t k) { return (int)((k >> 8) & 0xfff); }
+__device__ __forceinline__ int key_resp(uint32_t k) { return (int)(k & 0xff); }
+
+__global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  const int level = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x;
+  const OrbLevel lv = a.levels[level];
+  const int cap = nodeCapMax;
+
+  OctLds n;
+  {
+    unsigned char* p = smem;
+    n.start = (int*)p;      p += 4 * cap;
+    n.cnt = (int*)p;        p += 4 * cap;
+    n.id = (int*)p;         p += 4 * cap;
+    for (int k = 0; k < 2; k++) { n.evSize[k] = (int*)p; p += 4 * cap; n.evId[k] = (int*)p; p += 4 * cap; }
+    n.req = (int*)p;        p += 4 * 16;
+    n.x0 = (short*)p;       p += 2 * cap;
+    n.x1 = (short*)p;       p += 2 * cap;
+    n.y0 = (short*)p;       p += 2 * cap;
+    n.y1 = (short*)p;       p += 2 * cap;
+    n.next = (short*)p;     p += 2 * cap;
+    n.prev = (short*)p;     p += 2 * cap;
+    n.freeStack = (short*)p; p += 2 * cap;
+    n.order = (short*)p;    p += 2 * cap;
+    for (int k = 0; k < 2; k++) { n.evSlot[k] = (short*)p; p += 2 * cap; }
+    n.buf = (uint8_t*)p;
+  }
+
+  uint32_t* kbuf[2];
+  kbuf[0] = a.keys + ((long long)b * 2 + 0) * a.slotsPerFrame + lv.slotOff;
+  kbuf[1] = a.keys + ((long long)b * 2 + 1) * a.slotsPerFrame + lv.slotOff;
+  const uint32_t* slots = a.slots + (long long)b * a.slotsPerFrame;
+  const uint32_t* ccount = a.cellCount + (long long)b * a.nCellsTotal + lv.cellBase;
+
+  // ---- gather the level's candidates in cell order (== vToDistributeKeys order) into kbuf[0] ----
+  int K = 0;
+  for (int cb = 0; cb < lv.nCells; cb += 64) {
+    const int ci = cb + lane;
+    const int cnt = ci < lv.nCells ? (int)ccount[ci] : 0;
+    // inclusive scan over the wave
+    int incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    const int excl = incl - cnt;
+    if (cnt > 0) {
+      const uint32_t* s = slots + a.cells[lv.cellBase + ci].slotOff;
+      for (int k = 0; k < cnt; k++) kbuf[0][K + excl + k] = s[k];
+    }
+    K += __shfl(incl, 63);
+  }
+  __syncthreads();
+
+  const int N = lv.nFeat;
+  int* selCount = a.selCount + (long long)b * a.nlevels + level;
+  uint32_t* sel = a.sel + (long long)b * a.selPerFrame + lv.selOff;
+
+  // ---- initial nodes: stable compaction of kbuf[0] by vpIniNodes[kp.pt.x / hX] into kbuf[1] ----
+  // lane-0 list state (registers; only lane 0's copies are meaningful)
+  int head = -1, tail = -1, lsize = 0, nextId = 0, freeTop = 0;
+  if (lane == 0) {
+    for (int s = 0; s < cap; s++) n.freeStack[s] = (short)(cap - 1 - s);
+    freeTop = cap;
+  }
+  {
+    int off = 0;
+    for (int j = 0; j < lv.nIni; j++) {
+      int cj = 0;
+      for (int base = 0; base < K; base += 64) {
+        const int i = base + lane;
+        uint32_t key = 0;
+        bool mine = false;
+        if (i < K) {
+          key = kbuf[0][i];
+          const float xw = (float)(key_x(key) - lv.minBX);
+          mine = (int)(xw / lv.hX) == j;
+        }
+        const unsigned long long mask = __ballot(mine);
+        if (mine) kbuf[1][off + cj + __popcll(mask & lanemask_lt())] = key;
+        cj += __popcll(mask);
+      }
+      if (lane == 0 && cj > 0) {
+        const int s = n.freeStack[--freeTop];
+        n.x0[s] = (short)(int)(lv.hX * (float)j);
+        n.x1[s] = (short)(int)(lv.hX * (float)(j + 1));
+        n.y0[s] = 0;
+        n.y1[s] = (short)(lv.maxBY - lv.minBY);
+        n.start[s] = off;
+        n.cnt[s] = cj;
+        n.buf[s] = 1;
+        n.id[s] = nextId++;
+        // push_back
+        n.next[s] = -1;
+        n.prev[s] = (short)tail;
+        if (tail >= 0) n.next[tail] = (short)s; else head = s;
+        tail = s;
+        lsize++;
+      }
+      off += cj;
+    }
+  }
+  __syncthreads();
+
+  // ---- lane-0 state machine + wave services ----
+  int state = S_P1_BEGIN, cursor = -1, savedNext = -1, prevSize = 0, nToExpand = 0, jdx = 0, evCur = 0, prevIdx = 0;
+  int evN[2] = {0, 0};
+  int c4[4] = {0, 0, 0, 0};   // child counts of the last split (uniform)
+  int splitSlot = -1;
+
+  for (;;) {
+    if (lane == 0) {
+      int op = -1;
+      while (op < 0) {
+        switch (state) {
+          case S_P1_BEGIN:
+            prevSize = lsize; nToExpand = 0; evN[evCur] = 0; cursor = head;
+            state = S_P1_SCAN;
+            break;
+          case S_P1_SCAN:
+            while (cursor >= 0 && n.cnt[cursor] == 1) cursor = n.next[cursor];
+            if (cursor >= 0) {
+              savedNext = n.next[cursor];
+              splitSlot = cursor;
+              op = OCT_SPLIT;
+              state = S_P1_AFTER;
+            } else if (lsize >= N || lsize == prevSize) {
+              op = OCT_DONE;
+            } else if (lsize + nToExpand * 3 > N) {
+              state = S_P2_BEGIN;
+            } else {
+              state = S_P1_BEGIN;
+            }
+            break;
+          case S_P1_AFTER:
+          case S_P2_AFTER: {
+            // create the non-empty children n1..n4 (push_front each), then erase the parent
+            const int sp = splitSlot;
+            const int px0 = n.x0[sp], px1 = n.x1[sp], py0 = n.y0[sp], py1 = n.y1[sp];
+            const int hx = (px1 - px0 + 1) >> 1, hy = (py1 - py0 + 1) >> 1;   // ceil(d/2.f)
+            const int db = n.buf[sp] ^ 1;
+            int st = n.start[sp];
+            for (int k = 0; k < 4; k++) {
+              const int ck = c4[k];
+              if (ck > 0) {
+                const int s = n.freeStack[--freeTop];
+                n.x0[s] = (short)((k & 1) ? px0 + hx : px0);
+                n.x1[s] = (short)((k & 1) ? px1 : px0 + hx);
+                n.y0[s] = (short)((k & 2) ? py0 + hy : py0);
+                n.y1[s] = (short)((k & 2) ? py1 : py0 + hy);
+                n.start[s] = st;
+                n.cnt[s] = ck;
+                n.buf[s] = (uint8_t)db;
+                n.id[s] = nextId++;
+                n.prev[s] = -1;
+                n.next[s] = (short)head;
+                if (head >= 0) n.prev[head] = (short)s; else tail = s;
+                head = s;
+                lsize++;
+                if (ck > 1) {
+                  if (state == S_P1_AFTER) nToExpand++;
+                  const int e = evN[evCur]++;
+                  n.evSize[evCur][e] = ck;
+                  n.evId[evCur][e] = n.id[s];
+                  n.evSlot[evCur][e] = (short)s;
+                }
+              }
+              st += ck;
+            }
+            {  // erase parent
+              const int p = n.prev[sp], q = n.next[sp];
+              if (p >= 0) n.next[p] = (short)q; else head = q;
+              if (q >= 0) n.prev[q] = (short)p; else tail = p;
+              lsize--;
+              n.freeStack[freeTop++] = (short)sp;
+            }
+            if (state == S_P1_AFTER) {
+              cursor = savedNext;
+              state = S_P1_SCAN;
+            } else if (lsize >= N) {
+              state = S_P2_END;
+            } else {
+              jdx--;
+              state = S_P2_NEXT;
+            }
+            break;
+          }
+          case S_P2_BEGIN:
+            prevSize = lsize;
+            prevIdx = evCur;
+            evCur ^= 1;
+            evN[evCur] = 0;
+            op = OCT_SORT;
+            state = S_P2_SORTED;
+            break;
+          case S_P2_SORTED:
+            jdx = evN[prevIdx] - 1;
+            state = S_P2_NEXT;
+            break;
+          case S_P2_NEXT:
+            if (jdx < 0) {
+              state = S_P2_END;
+            } else {
+              splitSlot = n.evSlot[prevIdx][n.order[jdx]];
+              op = OCT_SPLIT;
+              state = S_P2_AFTER;
+            }
+            break;
+          case S_P2_END:
+            if (lsize >= N || lsize == prevSize) op = OCT_DONE;
+            else state = S_P2_BEGIN;
+            break;
+        }
+      }
+      n.req[0] = op;
+      if (op == OCT_SPLIT) {
+        const int sp = splitSlot;
+        n.req[1] = n.buf[sp];
+        n.req[2] = n.start[sp];
+        n.req[3] = n.cnt[sp];
+        n.req[4] = n.x0[sp] + ((n.x1[sp] - n.x0[sp] + 1) >> 1);   // n1.UR.x
+        n.req[5] = n.y0[sp] + ((n.y1[sp] - n.y0[sp] + 1) >> 1);   // n1.BR.y
+      } else if (op == OCT_SORT) {
+        n.req[1] = prevIdx;
+        n.req[2] = evN[prevIdx];
+      }
+    }
+    __syncthreads();
+    const int op = n.req[0];
+    if (op == OCT_DONE) break;
+    if (op == OCT_SPLIT) {
+      // stable 4-way partition of the node's keys into the other key buffer (DivideNode)
+      const int sb = n.req[1], st = n.req[2], cnt = n.req[3], bx = n.req[4], by = n.req[5];
+      const uint32_t* src = kbuf[sb] + st;
+      uint32_t* dst = kbuf[sb ^ 1] + st;
+      int tot[4] = {0, 0, 0, 0};
+      for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        int cls = -1;
+        if (i < cnt) {
+          const uint32_t key = src[i];
+          const int xw = key_x(key) - lv.minBX, yw = key_y(key) - lv.minBY;
+          cls = (xw < bx) ? (yw < by ? 0 : 2) : (yw < by ? 1 : 3);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) tot[k] += __popcll(__ballot(cls == k));
+      }
+      int run[4];
+      run[0] = 0; run[1] = tot[0]; run[2] = tot[0] + tot[1]; run[3] = tot[0] + tot[1] + tot[2];
+      for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        int cls = -1;
+        uint32_t key = 0;
+        if (i < cnt) {
+          key = src[i];
+          const int xw = key_x(key) - lv.minBX, yw = key_y(key) - lv.minBY;
+          cls = (xw < bx) ? (yw < by ? 0 : 2) : (yw < by ? 1 : 3);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned long long m = __ballot(cls == k);
+          if (cls == k) dst[run[k] + __popcll(m & lanemask_lt())] = key;
+          run[k] += __popcll(m);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) c4[k] = tot[k];
+    } else {
+      // rank sort of the expand vector by (size, creation id) ascending -> order[rank] = entry
+      const int pi = n.req[1], cntE = n.req[2];
+      for (int e = lane; e < cntE; e += 64) {
+        const int sz = n.evSize[pi][e], id = n.evId[pi][e];
+        int rank = 0;
+        for (int f = 0; f < cntE; f++) {
+          const int sf = n.evSize[pi][f], idf = n.evId[pi][f];
+          rank += (sf < sz) || (sf == sz && idf < id);
+        }
+        n.order[rank] = (short)e;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- retain the best point of each leaf, in list order (ORBextractor.cc:744-760) ----
+  if (lane == 0) {
+    int i = 0;
+    for (int s = head; s >= 0; s = n.next[s]) n.order[i++] = (short)s;
+    n.req[1] = lsize;
+    *selCount = min(lsize, lv.selCap);
+    if (lsize > lv.selCap) atomicOr(a.status, 2);
+  }
+  __syncthreads();
+  const int nleaf = min(n.req[1], lv.selCap);
+  for (int i = lane; i < nleaf; i += 64) {
+    const int s = n.order[i];
+    const uint32_t* kk = kbuf[n.buf[s]] + n.start[s];
+    uint32_t best = kk[0];
+    const int cnt = n.cnt[s];
+    for (int k = 1; k < cnt; k++) {
+      const uint32_t key = kk[k];
+      if (key_resp(key) > key_resp(best)) best = key;
+    }
+    sel[i] = best;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Orientation + descriptor.  One wavefront per selected keypoint.  The 43x43 neighbourhood of the
+// (un-blurred) level image is staged in LDS once; IC_Angle runs on its central 31x31 disc, the
+// separable 7x7 sigma=2 Gaussian (Q8 integer, REFLECT_101 at the level's own edges as the
+// reference blurs a border-less clone) is evaluated for the central 37x37 region only, and the
+// 512 steered rBRIEF samples are gathered from that LDS tile.  No blurred pyramid is ever
+// written to HBM.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int nn) {
+  if (p < 0) p = -p;
+  if (p >= nn) p = 2 * nn - 2 - p;
+  return p;
+}
+
+__global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoint* kps, uint8_t* desc, int* nOut,
+                                                     int cap) {
+  constexpr int PR = 21, PW = 43, PP = 44;   // patch radius / width / pitch
+  constexpr int BR = 18, BW = 37, BP = 40;   // blurred radius / width / pitch
+  __shared__ uint8_t patch[PW * PP];
+  __shared__ unsigned short hbuf[PW * BP];
+  __shared__ uint8_t blur[BW * BP];
+
+  const int slot = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int* selCount = a.selCount + (long long)b * a.nlevels;
+
+  int level = 0, outBase = 0;
+  {
+    int l = 0, base = 0;
+    for (; l < a.nlevels; l++) {
+      const int so = a.levels[l].selOff, sc = a.levels[l].selCap;
+      if (slot >= so && slot < so + sc) break;
+      base += selCount[l];
+    }
+    level = l;
+    outBase = base;
+  }
+  if (slot == 0 && lane == 0) {
+    int tot = 0;
+    for (int l = 0; l < a.nlevels; l++) tot += selCount[l];
+    nOut[b] = tot;
+  }
+  if (level >= a.nlevels) return;
+  const OrbLevel lv = a.levels[level];
+  const int idx = slot - lv.selOff;
+  if (idx >= selCount[level]) return;
+  const int outIdx = outBase + idx;
+  if (outIdx >= cap) return;
+
+  const uint32_t key = a.sel[(long long)b * a.selPerFrame + slot];
+  const int kx = key_x(key), ky = key_y(key);
+  const uint8_t* img = level_ptr(a, lv, level, b);
+
+  for (int i = lane; i < PW * PW; i += 64) {
+    const int r = i / PW, c = i - r * PW;
+    const int yy = reflect101(ky - PR + r, lv.h), xx = reflect101(kx - PR + c, lv.w);
+    patch[r * PP + c] = img[(long long)yy * lv.pitch + xx];
+  }
+  __syncthreads();
+
+  // IC_Angle: integer moments over the circular patch
+  int m10 = 0, m01 = 0;
+  for (int i = lane; i < 31 * 31; i += 64) {
+    const int r = i / 31, c = i - r * 31;
+    const int v = r - 15, u = c - 15;
+    const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+    if (au <= c_umax[av]) {
+      const int val = patch[(PR + v) * PP + PR + u];
+      m10 += u * val;
+      m01 += v * val;
+    }
+  }
+  m10 = wave_sum(m10);
+  m01 = wave_sum(m01);
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // horizontal pass: rows 0..42, output columns 3..39 (37 wide)
+  for (int i = lane; i < PW * BW; i += 64) {
+    const int r = i / BW, c = i - r * BW;
+    const uint8_t* p = &patch[r * PP + c];
+    const int s = c_gauss7[0] * (p[0] + p[6]) + c_gauss7[1] * (p[1] + p[5]) + c_gauss7[2] * (p[2] + p[4]) + c_gauss7[3] * p[3];
+    hbuf[r * BP + c] = (unsigned short)s;
+  }
+  __syncthreads();
+  for (int i = lane; i < BW * BW; i += 64) {
+    const int r = i / BW, c = i - r * BW;
+    const unsigned short* p = &hbuf[r * BP + c];
+    const int s = c_gauss7[0] * (p[0] + p[6 * BP]) + c_gauss7[1] * (p[BP] + p[5 * BP]) + c_gauss7[2] * (p[2 * BP] + p[4 * BP]) +
+                  c_gauss7[3] * p[3 * BP];
+    int v = (s + (1 << 15)) >> 16;
+    blur[r * BP + c] = (uint8_t)(v > 255 ? 255 : v);
+  }
+  __syncthreads();
+
+  // steered rBRIEF: lane -> 4 pairs (one nibble)
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float ang = angle * factorPI;
+  const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
+  const signed char* pat = c_orb_pattern + lane * 16;
+  int nib = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float x0 = (float)pat[k * 4 + 0], y0 = (float)pat[k * 4 + 1];
+    const float x1 = (float)pat[k * 4 + 2], y1 = (float)pat[k * 4 + 3];
+    const int t0 = blur[(BR + cv_round(x0 * sa + y0 * ca)) * BP + BR + cv_round(x0 * ca - y0 * sa)];
+    const int t1 = blur[(BR + cv_round(x1 * sa + y1 * ca)) * BP + BR + cv_round(x1 * ca - y1 * sa)];
+    nib |= (t0 < t1) << k;
+  }
+  const int hiNib = __shfl_down(nib, 1);
+  uint8_t* dptr = desc + ((long long)b * cap + outIdx) * 32;
+  if ((lane & 1) == 0) dptr[lane >> 1] = (uint8_t)(nib | (hiNib << 4));
+
+  if (lane == 0) {
+    plh_keypoint o;
+    o.x = (float)kx;
+    o.y = (float)ky;
+    if (level != 0) { o.x *= lv.scale; o.y *= lv.scale; }
+    o.size = lv.kpSize;
+    o.angle = angle;
+    o.response = (float)key_resp(key);
+    o.octave = level;
+    o.class_id = -1;
+    kps[(long long)b * cap + outIdx] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launchers (kept in this translation unit so the kernels stay file-local)
+// ---------------------------------------------------------------------------------------------
+void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, hipStream_t s) {
+  dim3 grid((pitch / 4 + 63) / 64, (h + 3) / 4, a.batch), block(64, 4);
+  hipLaunchKernelGGL(k_pyr_down, grid, block, 0, s, a, l);
+}
+void launch_fast_cells(const OrbDeviceArgs& a, hipStream_t s) {
+  const int groups = (a.batch + 7) / 8;
+  dim3 grid((unsigned)((long long)a.nCellsTotal * groups * 8)), block(256);
+  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, a);
+}
+size_t octree_lds_bytes(int nodeCap) { return (size_t)nodeCap * (4 * 7 + 2 * 10 + 1) + 64 + 64; }
+void launch_octree(const OrbDeviceArgs& a, int nodeCapMax, hipStream_t s) {
+  dim3 grid(a.nlevels, a.batch), block(64);
+  hipLaunchKernelGGL(k_octree, grid, block, octree_lds_bytes(nodeCapMax), s, a, nodeCapMax);
+}
+void launch_orient_brief(const OrbDeviceArgs& a, plh_keypoint* kps, uint8_t* desc, int* nOut, int cap, hipStream_t s) {
+  dim3 grid(a.selPerFrame, a.batch), block(64);
+  hipLaunchKernelGGL(k_orient_brief, grid, block, 0, s, a, kps, desc, nOut, cap);
+}
+
+}  // namespace plh

@@ -1,0 +1,67 @@
+// ORB extractor plan: geometry tables shared by host planning code and the HIP kernels.
+// Everything here is derived from the reference's constructor / per-level setup
+// (reference src/ORBextractor.cc:410-470, 765-806, 1107-1113).
+#pragma once
+#include <cstdint>
+
+namespace plh {
+
+constexpr int ORB_MAX_LEVELS = 16;
+constexpr int ORB_PATCH_SIZE = 31;        // ORBextractor.cc:72
+constexpr int ORB_HALF_PATCH = 15;        // ORBextractor.cc:73
+constexpr int ORB_EDGE_THRESHOLD = 19;    // ORBextractor.cc:74
+constexpr int ORB_CELL_MAX = 66;          // max cell sub-image side (wCell <= 60, +6)
+constexpr int ORB_KEY_XY_BITS = 12;       // packed candidate key: x:12 | y:12 | response:8
+
+struct OrbLevel {
+  int w, h, pitch;             // level image; pitch in bytes (level 0 uses the caller's pitch = cols)
+  long long off;               // byte offset inside one frame's pyramid block (levels >= 1)
+  int minBX, minBY, maxBX, maxBY;   // FAST window  [16, w-16) x [16, h-16)
+  int cellBase, nCells;        // this level's cells in the cell table (reference loop order: row-major)
+  int slotOff, slotCap;        // candidate slots of the level inside one frame's slot array
+  int nFeat;                   // mnFeaturesPerLevel[l]
+  int nIni;                    // initial quad-tree nodes = round(W/H)
+  float hX;                    // W / nIni
+  int selOff, selCap;          // selected-keypoint slots of the level inside one frame's record array
+  int nodeCap;                 // quad-tree node slots
+  int xtabOff, ytabOff;        // resize tables (levels >= 1)
+  int xmax;                    // first dx using the single-tap path (cv::resize)
+  float scale;                 // mvScaleFactor[l]
+  float kpSize;                // (int)(31 * mvScaleFactor[l])
+};
+
+struct OrbCell {               // one FAST cell = one cv::FAST call on a sub-image (ORBextractor.cc:789-829)
+  short level;
+  short x0, y0;                // sub-image origin in level-image coordinates
+  short cw, ch;                // sub-image size (evaluated window is [3,cw-3) x [3,ch-3))
+  short pad;
+  int slotOff;                 // first candidate slot of this cell (inside the frame's slot array)
+  int slotCap;                 // ceil(ew/2)*ceil(eh/2): hard upper bound of 3x3-NMS survivors
+};
+
+struct ResizeTap {             // one entry of the cv::resize coefficient tables
+  short ofs, a0, a1, pad;
+};
+
+struct OrbDeviceArgs {         // kernel argument block (passed by value)
+  const uint8_t* img0;         // batch input (level 0)
+  long long stride0;           // bytes between frames of the input
+  uint8_t* pyr;                // levels >= 1, frame-major
+  long long pyrFrameBytes;
+  const OrbLevel* levels;
+  const OrbCell* cells;
+  const ResizeTap* xtab;
+  const ResizeTap* ytab;
+  uint32_t* slots;             // candidate slots [frame][slot]
+  long long slotsPerFrame;
+  uint32_t* cellCount;         // [frame][cell]
+  uint32_t* keys;              // quad-tree key scratch: [frame][2][slotsPerFrame]
+  uint32_t* sel;               // selected keys [frame][selPerFrame]
+  int* selCount;               // [frame][nlevels]
+  int selPerFrame;
+  int nlevels, nCellsTotal, batch;
+  int iniTh, minTh;
+  int* status;                 // device-side error flag (capacity overflow etc.)
+};
+
+}  // namespace plh

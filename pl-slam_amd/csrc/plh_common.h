@@ -1,0 +1,84 @@
+// Shared host/device helpers of libplslam_hip (MI355X / gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/plslam_hip.h"
+
+#define PLH_WAVE 64
+
+namespace plh {
+
+char* tls_error();
+void set_error(const char* fmt, ...);
+
+#define PLH_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      plh::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__));    \
+      return PLH_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+#define PLH_LAUNCH_CHECK()                                                                    \
+  do {                                                                                        \
+    hipError_t e__ = hipGetLastError();                                                       \
+    if (e__ != hipSuccess) {                                                                  \
+      plh::set_error("%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return PLH_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+template <typename T>
+static inline T align_up(T v, T a) { return (v + a - 1) / a * a; }
+
+// ---- device helpers ----
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// cvRound: round-half-to-even (v_cvt_i32_f32 with the default RNE mode / v_rndne)
+__device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  return (1ull << lane_id()) - 1ull;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// cv::fastAtan2 (degrees), float32 Horner evaluation, no FMA (translation unit is built with
+// -ffp-contract=off); used by IC_Angle (reference src/ORBextractor.cc:103) and by LSD.
+__host__ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + 2.2204460492503131e-16f);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + 2.2204460492503131e-16f);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// 256-bit Hamming distance of two 32-byte rows held as 4 x u64.
+__device__ __forceinline__ int hamming256(const unsigned long long a[4], const unsigned long long b[4]) {
+  return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+}  // namespace plh
