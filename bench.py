@@ -47,29 +47,27 @@ def cpu_baseline(O, frames, nfeatures, nlevels, budget_s=15.0):
     """Oracle (port) on all host cores, one frame per task (ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     cores = os.cpu_count() or 1
-    n = len(frames)
     handles = [O.OrbOracle(nfeatures, 1.2, nlevels, 20, 7) for _ in range(cores)]
 
-    def work(t):
-        cnt = 0
-        for i in range(t, n, cores):
-            handles[t].extract(frames[i])
-            cnt += 1
-        return cnt
-
-    # calibrate on a few frames, then size the sample to the budget
+    # calibrate on one frame, then size the sample (frames are cycled) to the time budget
     t0 = time.perf_counter()
     handles[0].extract(frames[0])
     per = time.perf_counter() - t0
-    want = int(max(cores, min(n, budget_s / max(per, 1e-4) * cores)))
-    want = max(cores, (want // cores) * cores)
-    n = min(n, want)
+    per_thread = int(max(2, min(64, budget_s / max(per, 1e-4))))
+    total = per_thread * cores
+    nf = len(frames)
+
+    def work(t):
+        for k in range(per_thread):
+            handles[t].extract(frames[(t * per_thread + k) % nf])
+        return per_thread
+
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": round(done / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic 640x480 frames, ORB extract (oracle/ restatement, g++ -O2, %d threads, 1 frame/task)" % (done, cores)}
+            "sample": "%d synthetic 640x480 frame extractions (ORB, oracle/ restatement, g++ -O2 -ffp-contract=off), %d host threads x %d frames" % (done, cores, per_thread)}
 
 
 def main():

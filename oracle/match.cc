@@ -1,0 +1,192 @@
+// ORACLE (test infrastructure) -- CPU restatement of the Hamming matching on the hot path:
+//   ORBmatcher::DescriptorDistance        reference src/ORBmatcher.cc:1764-1780
+//   ORBmatcher::SearchByBoW(KF, F, ...)   reference src/ORBmatcher.cc:187-327 (+ ComputeThreeMaxima :1718-1759)
+//   LSDmatcher::FrameBFMatch              reference src/LSDmatcher.cpp:462-486
+//   LSDmatcher::lineDescriptorMAD         reference src/LSDmatcher.cpp:627-652
+//   LSDmatcher::SearchDouble(F, F, ...)   reference src/LSDmatcher.cpp:427-460
+//   cv::BFMatcher(NORM_HAMMING).knnMatch  (OpenCV, not in tree)
+// Frame / KeyFrame / MapPoint objects are replaced by flat arrays (descriptors, angles, DBoW2 node id per
+// feature, "has a live MapPoint" flags); the selection logic is restated statement by statement.
+// PARITY UNPINNED, see oracle/plo.h.
+#include "plo.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+namespace {
+const int TH_LOW_ORB = 50, HISTO_LENGTH = 30;
+
+// ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:1718-1759
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+}  // namespace
+
+extern "C" {
+
+// Bit-set count from the Stanford bithacks page, as the reference writes it.
+int plo_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  int32_t pa[8], pb[8];
+  memcpy(pa, a, 32);
+  memcpy(pb, b, 32);
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    unsigned int v = (unsigned)(pa[i] ^ pb[i]);
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+// knnMatch(q, t, k=2): exhaustive, insertion with strict '<' (ties keep the lower train index first).
+// Empty slots (nt < 2): idx -1, dist INT_MAX.
+void plo_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) {
+  for (int i = 0; i < nq; i++) {
+    int b0 = INT_MAX, b1 = INT_MAX, i0 = -1, i1 = -1;
+    for (int j = 0; j < nt; j++) {
+      const int d = plo_descriptor_distance(q + (size_t)i * 32, t + (size_t)j * 32);
+      if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
+      else if (d < b1) { b1 = d; i1 = j; }
+    }
+    idx[i * 2] = i0; idx[i * 2 + 1] = i1;
+    dist[i * 2] = b0; dist[i * 2 + 1] = b1;
+  }
+}
+
+// lineDescriptorMAD on a knn2 distance table (nq x 2, distances as the float the reference stores).
+void plo_line_mad(const int32_t* dist, int nq, double* nn_mad, double* nn12_mad) {
+  *nn_mad = 0; *nn12_mad = 0;
+  if (nq <= 0) return;
+  std::vector<float> d0(nq), gap(nq);
+  for (int i = 0; i < nq; i++) { d0[i] = (float)dist[i * 2]; gap[i] = (float)dist[i * 2 + 1] - (float)dist[i * 2]; }
+  std::vector<float> a = d0;
+  std::sort(a.begin(), a.end());
+  double nn_dist_median = a[nq / 2];
+  for (int i = 0; i < nq; i++) a[i] = fabsf((float)(d0[i] - nn_dist_median));
+  std::sort(a.begin(), a.end());
+  *nn_mad = 1.4826 * a[nq / 2];
+  std::vector<float> g = gap;
+  std::sort(g.begin(), g.end(), [](float x, float y) { return x > y; });   // conpare_descriptor_by_NN12_dist: descending gap
+  double nn12_dist_median = g[nq / 2];
+  for (int i = 0; i < nq; i++) g[i] = fabsf((float)(gap[i] - nn12_dist_median));
+  std::sort(g.begin(), g.end());
+  *nn12_mad = 1.4826 * g[nq / 2];
+}
+
+// LSDmatcher::FrameBFMatch.  Guards: the reference indexes lmatches[i][1] (UB when ldesc2 has < 2 rows) and
+// matches[size/2] (UB when empty) -> no matches in those cases.
+void plo_line_bfmatch(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float TH, float nnratio, int32_t* matches) {
+  for (int i = 0; i < n1; i++) matches[i] = -1;
+  if (n1 <= 0 || n2 < 2) return;
+  std::vector<int32_t> idx((size_t)n1 * 2), dist((size_t)n1 * 2);
+  plo_knn2(d1, n1, d2, n2, idx.data(), dist.data());
+  double nn_mad, nn12_mad;
+  plo_line_mad(dist.data(), n1, &nn_mad, &nn12_mad);
+  const double nn12_dist_th = nn12_mad * 0.5;
+  for (int i = 0; i < n1; i++) {
+    const float m0 = (float)dist[i * 2], m1 = (float)dist[i * 2 + 1];
+    const double dist_12 = m1 - m0;
+    if (dist_12 > nn12_dist_th && m0 < TH && m0 < nnratio * m1) matches[i] = idx[i * 2];
+  }
+}
+
+// LSDmatcher::SearchDouble(Frame&, Frame&, vector<int>&): both directions + mutual consistency.
+int plo_line_search_double(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float TH, float nnratio,
+                           int32_t* matches12) {
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n1 == 0 || n2 == 0) return 0;
+  std::vector<int32_t> m1(std::max(n1, 1)), m2(std::max(n2, 1));
+  plo_line_bfmatch(d1, n1, d2, n2, TH, nnratio, m1.data());
+  plo_line_bfmatch(d2, n2, d1, n1, TH, nnratio, m2.data());
+  int nmatches = 0;
+  for (int i = 0; i < n1; i++) {
+    const int j = m1[i];
+    if (j >= 0) {
+      if (m2[j] != i) m1[i] = -1;
+      else nmatches++;
+    }
+  }
+  for (int i = 0; i < n1; i++) matches12[i] = m1[i];
+  return nmatches;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches).
+// set 1 = KeyFrame (desc1, angle1 = mvKeysUn[].angle, node1 = FeatureVector node of each feature,
+// valid1 = feature has a non-bad MapPoint); set 2 = Frame.  matches21[j] = KeyFrame index whose MapPoint is
+// assigned to Frame feature j, or -1.  Returns nmatches.
+int plo_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
+                          const uint8_t* desc2, const float* angle2, const int32_t* node2, int n2, int th_low,
+                          float nnratio, int check_ori, int32_t* matches21) {
+  for (int j = 0; j < n2; j++) matches21[j] = -1;
+  // DBoW2::FeatureVector = std::map<NodeId, std::vector<unsigned>>, features appended in index order
+  std::map<int, std::vector<unsigned>> fv1, fv2;
+  for (int i = 0; i < n1; i++) if (node1[i] >= 0) fv1[node1[i]].push_back((unsigned)i);
+  for (int j = 0; j < n2; j++) if (node2[j] >= 0) fv2[node2[j]].push_back((unsigned)j);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  auto KFit = fv1.begin(), KFend = fv1.end();
+  auto Fit = fv2.begin(), Fend = fv2.end();
+  while (KFit != KFend && Fit != Fend) {
+    if (KFit->first == Fit->first) {
+      const std::vector<unsigned>& vKF = KFit->second;
+      const std::vector<unsigned>& vF = Fit->second;
+      for (size_t iKF = 0; iKF < vKF.size(); iKF++) {
+        const unsigned realIdxKF = vKF[iKF];
+        if (!valid1[realIdxKF]) continue;
+        const uint8_t* dKF = desc1 + (size_t)realIdxKF * 32;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (size_t iF = 0; iF < vF.size(); iF++) {
+          const unsigned realIdxF = vF[iF];
+          if (matches21[realIdxF] >= 0) continue;
+          const int dist = plo_descriptor_distance(dKF, desc2 + (size_t)realIdxF * 32);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+          else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist1 <= th_low) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches21[bestIdxF] = (int32_t)realIdxKF;
+            if (check_ori) {
+              float rot = angle1[realIdxKF] - angle2[bestIdxF];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)roundf(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin].push_back(bestIdxF);
+            }
+            nmatches++;
+          }
+        }
+      }
+      ++KFit; ++Fit;
+    } else if (KFit->first < Fit->first) {
+      KFit = fv1.lower_bound(Fit->first);
+    } else {
+      Fit = fv2.lower_bound(KFit->first);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) { matches21[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  (void)TH_LOW_ORB;
+  return nmatches;
+}
+
+}  // extern "C"

@@ -112,7 +112,9 @@ def test_full_size_properties(plslam, synth):
     ex = plslam.ORBextractor(1000, 1.2, 8, 20, 7, rows=480, cols=640, max_batch=B)
     k1, d1, n1 = ex.extract_batch(frames)
     k2, d2, n2 = ex.extract_batch(frames)
-    assert (n1 == n2).all() and k1.tobytes() == k2.tobytes() and d1.tobytes() == d2.tobytes()   # idempotent
+    assert (n1 == n2).all()
+    for b in range(B):   # idempotent (rows past n[b] are unspecified)
+        assert k1[b, :n1[b]].tobytes() == k2[b, :n1[b]].tobytes() and d1[b, :n1[b]].tobytes() == d2[b, :n1[b]].tobytes()
     per = ex.features_per_level()
     sf = ex.GetScaleFactors()
     for b in range(B):
@@ -125,5 +127,8 @@ def test_full_size_properties(plslam, synth):
     # permuting the batch permutes the results
     perm = np.random.default_rng(0).permutation(B)
     k3, d3, n3 = ex.extract_batch(frames[perm])
-    assert (n3 == n1[perm]).all() and d3.tobytes() == d1[perm].tobytes()
+    assert (n3 == n1[perm]).all()
+    for b in range(B):
+        assert d3[b, :n3[b]].tobytes() == d1[perm[b], :n3[b]].tobytes()
+        assert k3[b, :n3[b]].tobytes() == k1[perm[b], :n3[b]].tobytes()
     ex.close()
