@@ -228,3 +228,184 @@ class ORBextractor:
         n = C.c_int(0)
         _check(self.lib, self.lib.plh_orb_read_candidates(self.h, b, level, _p(out), cap, C.byref(n)), "plh_orb_read_candidates")
         return out[:n.value].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# device buffers: torch tensors on the GPU (PyTorch is only the allocator / stream provider);
+# under the hipemu test build "device" memory is host memory, so numpy arrays are passed directly.
+# ------------------------------------------------------------------------------------------------
+def is_emulated(lib):
+    return b"hipemu" in lib.plh_version()
+
+
+class _Dev:
+    def __init__(self, lib, device=0):
+        self.emu = is_emulated(lib)
+        self.device = device
+        if not self.emu:
+            import torch
+            if not torch.cuda.is_available():
+                raise PlhError("no GPU visible and no CPU fallback exists")
+            self.torch = torch
+            self.dev = torch.device("cuda", device)
+
+    def put(self, a):
+        a = np.ascontiguousarray(a)
+        if self.emu:
+            return a.copy()
+        return self.torch.from_numpy(a.view(np.uint8).reshape(-1) if a.dtype.names else a).to(self.dev)
+
+    def empty(self, shape, dtype):
+        if self.emu:
+            return np.zeros(shape, dtype)
+        tmap = {np.int32: self.torch.int32, np.uint8: self.torch.uint8, np.float32: self.torch.float32,
+                np.float64: self.torch.float64}
+        return self.torch.zeros(shape, dtype=tmap[dtype], device=self.dev)
+
+    def get(self, d):
+        if self.emu:
+            return d
+        self.torch.cuda.synchronize(self.dev)
+        return d.cpu().numpy()
+
+    def stream(self):
+        return 0 if self.emu else self.torch.cuda.current_stream(self.dev).cuda_stream
+
+
+def descriptor_distance(a, b, lib=None):
+    """ORBmatcher::DescriptorDistance / LSDmatcher::DescriptorDistance (256-bit Hamming)."""
+    L = load(lib)
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return L.plh_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_knn2(q, t, device=0, lib=None):
+    """cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2) -> (idx[nq,2], dist[nq,2])."""
+    L = load(lib)
+    D = _Dev(L, device)
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    nq, nt = len(q), len(t)
+    if nq == 0:
+        return np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32)
+    dq, dt = D.put(q), D.put(t if nt else np.zeros((1, 32), np.uint8))
+    di, dd = D.empty((nq, 2), np.int32), D.empty((nq, 2), np.int32)
+    _check(L, L.plh_hamming_knn2_dev(_p(dq), nq, _p(dt), nt, _p(di), _p(dd), C.c_void_p(D.stream())), "plh_hamming_knn2_dev")
+    return D.get(di), D.get(dd)
+
+
+def _pad_sets(sets, cap, width, dtype):
+    out = np.zeros((len(sets), cap) + ((width,) if width else ()), dtype)
+    n = np.zeros(len(sets), np.int32)
+    for i, s in enumerate(sets):
+        s = np.asarray(s, dtype)
+        n[i] = len(s)
+        if len(s):
+            out[i, :len(s)] = s
+    return out, n
+
+
+class LSDmatcher:
+    """ORB_SLAM2::LSDmatcher(nnratio=0.7, checkOri=true) -- the brute-force descriptor searches
+    (reference include/LSDmatcher.h:22-76, src/LSDmatcher.cpp:12-14).  Frames are given by their LBD
+    descriptor matrices (mLdesc)."""
+    TH_HIGH = 80
+    TH_LOW = 50
+
+    def __init__(self, nnratio=0.7, checkOri=True, device=0, lib=None):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self.lib = load(lib)
+        self.D = _Dev(self.lib, device)
+
+    def SearchDoubleBatch(self, descs1, descs2):
+        """SearchDouble(Frame&, Frame&, vector<int>&) for P independent frame pairs.
+        Returns (matches12[P, cap] (-1 = unmatched), nmatches[P])."""
+        P = len(descs1)
+        assert P == len(descs2) and P > 0
+        cap = max(1, max(len(d) for d in list(descs1) + list(descs2)))
+        a, n1 = _pad_sets(descs1, cap, 32, np.uint8)
+        b, n2 = _pad_sets(descs2, cap, 32, np.uint8)
+        D, L = self.D, self.lib
+        da, db, dn1, dn2 = D.put(a), D.put(b), D.put(n1), D.put(n2)
+        dm, dc = D.empty((P, cap), np.int32), D.empty((P,), np.int32)
+        wsb = L.plh_line_search_double_workspace(cap, P)
+        ws = D.empty((wsb,), np.uint8)
+        _check(L, L.plh_line_search_double_batch_dev(_p(da), _p(dn1), _p(db), _p(dn2), cap, P, float(self.TH_LOW),
+                                                     self.mfNNratio, _p(dm), _p(dc), _p(ws), wsb, C.c_void_p(D.stream())),
+               "plh_line_search_double_batch_dev")
+        return D.get(dm), D.get(dc)
+
+    def SearchDouble(self, ldesc1, ldesc2):
+        """Returns (nmatches, LineMatches[NL1]) like the reference's out-parameter version (LSDmatcher.cpp:427-460)."""
+        ldesc1 = np.asarray(ldesc1, np.uint8).reshape(-1, 32)
+        ldesc2 = np.asarray(ldesc2, np.uint8).reshape(-1, 32)
+        if len(ldesc1) == 0 or len(ldesc2) == 0:
+            return 0, np.full(len(ldesc1), -1, np.int32)
+        m, c = self.SearchDoubleBatch([ldesc1], [ldesc2])
+        return int(c[0]), m[0, :len(ldesc1)].copy()
+
+    def FrameBFMatch(self, ldesc1, ldesc2, TH=None):
+        """LSDmatcher::FrameBFMatch (LSDmatcher.cpp:462-486): LineMatches[NL1]."""
+        ldesc1 = np.asarray(ldesc1, np.uint8).reshape(-1, 32)
+        ldesc2 = np.asarray(ldesc2, np.uint8).reshape(-1, 32)
+        n1, n2 = len(ldesc1), len(ldesc2)
+        if n1 == 0:
+            return np.zeros(0, np.int32)
+        D, L = self.D, self.lib
+        cap = max(n1, n2, 1)
+        a, na = _pad_sets([ldesc1], cap, 32, np.uint8)
+        b, nb = _pad_sets([ldesc2], cap, 32, np.uint8)
+        da, db, dna, dnb = D.put(a), D.put(b), D.put(na), D.put(nb)
+        di, dd = D.empty((1, cap, 2), np.int32), D.empty((1, cap, 2), np.int32)
+        dm = D.empty((1, cap), np.int32)
+        s = C.c_void_p(D.stream())
+        _check(L, L.plh_hamming_knn2_batch_dev(_p(da), _p(dna), cap, _p(db), _p(dnb), cap, 1, _p(di), _p(dd), s), "knn2")
+        _check(L, L.plh_line_bfmatch_batch_dev(_p(di), _p(dd), _p(dna), _p(dnb), cap, 1,
+                                               float(self.TH_LOW if TH is None else TH), self.mfNNratio, _p(dm), s), "bfmatch")
+        return D.get(dm)[0, :n1].copy()
+
+
+class ORBmatcher:
+    """ORB_SLAM2::ORBmatcher(nnratio=0.6, checkOri=true) -- Hamming searches on flat arrays
+    (reference include/ORBmatcher.h:37-102, src/ORBmatcher.cc:37-39)."""
+    TH_HIGH = 100
+    TH_LOW = 50
+    HISTO_LENGTH = 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0, lib=None):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self.lib = load(lib)
+        self.D = _Dev(self.lib, device)
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        return descriptor_distance(a, b)
+
+    def SearchByBoWBatch(self, kf_sets, f_sets):
+        """SearchByBoW(KeyFrame*, Frame&, ...) for P pairs.  Each kf set = dict(desc[n,32], angle[n], node[n], valid[n]);
+        each frame set = dict(desc, angle, node).  Returns (matches21[P, cap], nmatches[P])."""
+        P = len(kf_sets)
+        cap = max(1, max(len(s["desc"]) for s in list(kf_sets) + list(f_sets)))
+        d1, n1 = _pad_sets([s["desc"] for s in kf_sets], cap, 32, np.uint8)
+        a1, _ = _pad_sets([s["angle"] for s in kf_sets], cap, 0, np.float32)
+        k1, _ = _pad_sets([s["node"] for s in kf_sets], cap, 0, np.int32)
+        v1, _ = _pad_sets([s["valid"] for s in kf_sets], cap, 0, np.uint8)
+        d2, n2 = _pad_sets([s["desc"] for s in f_sets], cap, 32, np.uint8)
+        a2, _ = _pad_sets([s["angle"] for s in f_sets], cap, 0, np.float32)
+        k2, _ = _pad_sets([s["node"] for s in f_sets], cap, 0, np.int32)
+        D, L = self.D, self.lib
+        bufs = [D.put(x) for x in (d1, a1, k1, v1, n1, d2, a2, k2, n2)]
+        dm, dc = D.empty((P, cap), np.int32), D.empty((P,), np.int32)
+        _check(L, L.plh_orb_search_by_bow_batch_dev(*[_p(x) for x in bufs], cap, P, self.TH_LOW, self.mfNNratio,
+                                                    int(self.mbCheckOrientation), _p(dm), _p(dc), C.c_void_p(D.stream())),
+               "plh_orb_search_by_bow_batch_dev")
+        return D.get(dm), D.get(dc)
+
+    def SearchByBoW(self, kf, frame):
+        """Returns (nmatches, matches21[N_F]): for each Frame feature the matched KeyFrame feature (the reference
+        stores that feature's MapPoint*) or -1."""
+        m, c = self.SearchByBoWBatch([kf], [frame])
+        return int(c[0]), m[0, :len(frame["desc"])].copy()

@@ -1,0 +1,410 @@
+// Hamming matching kernels (gfx950, wave64) + C ABI.  No MFMA: 256-bit XOR + popcount on the VALU.
+//
+//   k_knn2            cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)        (LSDmatcher.cpp:468-469)
+//   k_line_bfmatch    LSDmatcher::FrameBFMatch + lineDescriptorMAD      (LSDmatcher.cpp:462-486, 627-652)
+//   k_line_mutual     LSDmatcher::SearchDouble mutual check             (LSDmatcher.cpp:445-455)
+//   k_search_by_bow   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...)   (ORBmatcher.cc:187-327, 1718-1759)
+//
+// All results are integer / index valued and bit-exact against the oracle.
+#include <climits>
+#include <vector>
+
+#include "plh_common.h"
+
+namespace plh {
+
+#if defined(HIPEMU)
+#define PLH_WAVE_SYNC() hipemu::wave_barrier()
+#else
+#define PLH_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+struct Desc256 {
+  unsigned long long w[4];
+};
+
+__device__ __forceinline__ Desc256 load_desc(const uint8_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  Desc256 d;
+  d.w[0] = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+  d.w[1] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
+  d.w[2] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
+  d.w[3] = (unsigned long long)b.z | ((unsigned long long)b.w << 32);
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Brute-force 2-NN.  grid (ceil(q_cap/256), pairs); each thread owns one query row in registers;
+// train rows stream through an 8 KiB LDS tile and are read as wave-wide broadcasts.
+// Scan order is ascending train index with strict '<', i.e. ties keep the lower index (BFMatcher).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_knn2(const uint8_t* q, const int* nqArr, int nqConst, int qCap, const uint8_t* t,
+                                              const int* ntArr, int ntConst, int tCap, int32_t* idx, int32_t* dist) {
+  __shared__ unsigned long long tile[256 * 4];
+  const int pair = blockIdx.y;
+  const int nq = nqArr ? nqArr[pair] : nqConst;
+  const int nt = ntArr ? ntArr[pair] : ntConst;
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  if (blockIdx.x * 256 >= max(nq, 1) && blockIdx.x > 0) return;
+  const uint8_t* qp = q + (long long)pair * qCap * 32;
+  const uint8_t* tp = t + (long long)pair * tCap * 32;
+  Desc256 me;
+  me.w[0] = me.w[1] = me.w[2] = me.w[3] = 0;
+  if (i < nq) me = load_desc(qp + (long long)i * 32);
+  int b0 = INT_MAX, b1 = INT_MAX, i0 = -1, i1 = -1;
+  for (int base = 0; base < nt; base += 256) {
+    const int cnt = min(256, nt - base);
+    __syncthreads();
+    if (tid < cnt) {
+      const Desc256 d = load_desc(tp + (long long)(base + tid) * 32);
+      tile[tid * 4 + 0] = d.w[0]; tile[tid * 4 + 1] = d.w[1]; tile[tid * 4 + 2] = d.w[2]; tile[tid * 4 + 3] = d.w[3];
+    }
+    __syncthreads();
+    for (int j = 0; j < cnt; j++) {
+      const int d = __popcll(me.w[0] ^ tile[j * 4]) + __popcll(me.w[1] ^ tile[j * 4 + 1]) +
+                    __popcll(me.w[2] ^ tile[j * 4 + 2]) + __popcll(me.w[3] ^ tile[j * 4 + 3]);
+      if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = base + j; }
+      else if (d < b1) { b1 = d; i1 = base + j; }
+    }
+  }
+  if (i < nq) {
+    const long long o = ((long long)pair * qCap + i) * 2;
+    idx[o] = i0; idx[o + 1] = i1;
+    dist[o] = b0; dist[o + 1] = b1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FrameBFMatch on a knn2 table.  One block per pair.  The two medians of lineDescriptorMAD are
+// order statistics of integer gaps in [0,256] -> exact via 257-bin histograms, no sort needed.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_line_bfmatch(const int32_t* idx, const int32_t* dist, const int* nqArr,
+                                                      const int* ntArr, int qCap, float TH, float nnratio,
+                                                      int32_t* matches) {
+  __shared__ int hist[260];
+  __shared__ int s_med;
+  __shared__ double s_th;
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int nq = nqArr[pair], nt = ntArr[pair];
+  const int32_t* D = dist + (long long)pair * qCap * 2;
+  const int32_t* I = idx + (long long)pair * qCap * 2;
+  int32_t* M = matches + (long long)pair * qCap;
+  const bool live = nq > 0 && nt >= 2;   // the reference is UB otherwise (lmatches[i][1], matches[size/2])
+  for (int k = tid; k < 260; k += 256) hist[k] = 0;
+  __syncthreads();
+  if (live)
+    for (int i = tid; i < nq; i += 256) atomicAdd(&hist[D[i * 2 + 1] - D[i * 2]], 1);
+  __syncthreads();
+  if (tid == 0 && live) {   // element [nq/2] of the gaps sorted DESCENDING
+    int cum = 0, g = 256;
+    for (; g >= 0; g--) { cum += hist[g]; if (cum > nq / 2) break; }
+    s_med = g;
+  }
+  __syncthreads();
+  for (int k = tid; k < 260; k += 256) hist[k] = 0;
+  __syncthreads();
+  if (live) {
+    const int med = s_med;
+    for (int i = tid; i < nq; i += 256) atomicAdd(&hist[abs(D[i * 2 + 1] - D[i * 2] - med)], 1);
+  }
+  __syncthreads();
+  if (tid == 0 && live) {   // element [nq/2] of the absolute deviations sorted ASCENDING
+    int cum = 0, g = 0;
+    for (; g <= 256; g++) { cum += hist[g]; if (cum > nq / 2) break; }
+    const double nn12_mad = 1.4826 * (double)(float)g;
+    s_th = nn12_mad * 0.5;
+  }
+  __syncthreads();
+  for (int i = tid; i < qCap; i += 256) {
+    int m = -1;
+    if (live && i < nq) {
+      const float m0 = (float)D[i * 2], m1 = (float)D[i * 2 + 1];
+      const double dist_12 = m1 - m0;
+      if (dist_12 > s_th && m0 < TH && m0 < nnratio * m1) m = I[i * 2];
+    }
+    M[i] = m;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_line_mutual(const int32_t* m1, const int32_t* m2, const int* n1Arr, const int* n2Arr,
+                                                     int cap, int32_t* out, int32_t* nmatches) {
+  __shared__ int s_cnt;
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int n1 = n1Arr[pair], n2 = n2Arr[pair];
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = tid; i < cap; i += 256) {
+    int j = -1;
+    if (i < n1 && n1 > 0 && n2 > 0) {
+      j = m1[(long long)pair * cap + i];
+      if (j >= 0) {
+        if (m2[(long long)pair * cap + j] != i) j = -1;
+        else c++;
+      }
+    }
+    out[(long long)pair * cap + i] = j;
+  }
+  if (c) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (tid == 0) nmatches[pair] = s_cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SearchByBoW.  One block per pair.  Phase A (256 threads): stable rank-sort of both feature sets
+// by (node id, feature index) == iteration order of DBoW2::FeatureVector (std::map<node, vector<idx>>).
+// Phase B (wave 0): KeyFrame features in that order, strictly sequential because of the greedy
+// "already matched" skip (ORBmatcher.cc:240); the 64 lanes scan the Frame candidates of the node.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1,
+                                                       const uint8_t* valid1, const int* n1Arr, const uint8_t* desc2,
+                                                       const float* angle2, const int32_t* node2, const int* n2Arr, int cap,
+                                                       int thLow, float nnratio, int checkOri, int32_t* matches21,
+                                                       int32_t* nmatchesOut) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  int* nd1 = (int*)smem;                 // node id per feature
+  int* nd2 = nd1 + cap;
+  int* snode2 = nd2 + cap;               // node id by sorted position (set 2)
+  int* m2 = snode2 + cap;                // Frame feature -> KeyFrame feature
+  unsigned short* ord1 = (unsigned short*)(m2 + cap);
+  unsigned short* ord2 = ord1 + cap;
+  unsigned char* bin2 = (unsigned char*)(ord2 + cap);
+
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int n1 = n1Arr[pair], n2 = n2Arr[pair];
+  const long long o = (long long)pair * cap;
+  for (int i = tid; i < cap; i += 256) {
+    nd1[i] = i < n1 ? node1[o + i] : -1;
+    nd2[i] = i < n2 ? node2[o + i] : -1;
+    m2[i] = -1;
+    bin2[i] = 255;
+  }
+  __syncthreads();
+  // invalid nodes (< 0) sort to the end: key = node<0 ? INT_MAX : node
+  for (int i = tid; i < n1; i += 256) {
+    const int k = nd1[i] < 0 ? INT_MAX : nd1[i];
+    int r = 0;
+    for (int j = 0; j < n1; j++) {
+      const int kj = nd1[j] < 0 ? INT_MAX : nd1[j];
+      r += (kj < k) || (kj == k && j < i);
+    }
+    ord1[r] = (unsigned short)i;
+  }
+  for (int i = tid; i < n2; i += 256) {
+    const int k = nd2[i] < 0 ? INT_MAX : nd2[i];
+    int r = 0;
+    for (int j = 0; j < n2; j++) {
+      const int kj = nd2[j] < 0 ? INT_MAX : nd2[j];
+      r += (kj < k) || (kj == k && j < i);
+    }
+    ord2[r] = (unsigned short)i;
+    snode2[r] = k;
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+
+  const int lane = tid;
+  const float factor = 1.0f / 30;
+  int myHist = 0;      // lane b < 30 holds rotHist[b].size()
+  int nmatches = 0;
+  const uint8_t* D1 = desc1 + o * 32;
+  const uint8_t* D2 = desc2 + o * 32;
+  for (int r1 = 0; r1 < n1; r1++) {
+    const int i = ord1[r1];
+    const int nd = nd1[i];
+    if (nd < 0) break;                       // sorted: only invalid nodes follow
+    if (!valid1[o + i]) continue;
+    // [lo, hi) = sorted positions of set 2 with node == nd
+    int lo = 0, hi = n2;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (snode2[mid] < nd) lo = mid + 1; else hi = mid; }
+    int hi2 = lo, top = n2;
+    while (hi2 < top) { const int mid = (hi2 + top) >> 1; if (snode2[mid] <= nd) hi2 = mid + 1; else top = mid; }
+    if (lo >= hi2) continue;
+    const Desc256 dk = load_desc(D1 + (long long)i * 32);
+    int b1 = 256, b2 = 256, p1 = 0x7fffffff;
+    for (int c = lo + lane; c < hi2; c += 64) {
+      const int f = ord2[c];
+      if (m2[f] >= 0) continue;
+      const Desc256 df = load_desc(D2 + (long long)f * 32);
+      const int d = hamming256(dk.w, df.w);
+      if (d < b1) { b2 = b1; b1 = d; p1 = c; }
+      else if (d < b2) { b2 = d; }
+    }
+    // wave reduction: best = min (dist, position); second = min over everything except the winning element
+    int key = b1 < 256 ? ((b1 << 20) | (p1 - lo)) : 0x7fffffff;
+    int kmin = key;
+    for (int s = 32; s >= 1; s >>= 1) kmin = min(kmin, __shfl_xor(kmin, s));
+    const bool winner = (key == kmin) && b1 < 256;
+    int second = winner ? b2 : b1;
+    for (int s = 32; s >= 1; s >>= 1) second = min(second, __shfl_xor(second, s));
+    if (kmin == 0x7fffffff) continue;
+    const int bestDist1 = kmin >> 20, bestPos = (kmin & 0xfffff) + lo, bestDist2 = second;
+    if (bestDist1 <= thLow && (float)bestDist1 < nnratio * (float)bestDist2) {
+      const int bestF = ord2[bestPos];
+      int bin = 255;
+      if (checkOri) {
+        float rot = angle1[o + i] - angle2[o + bestF];
+        if (rot < 0.0f) rot += 360.0f;
+        bin = (int)roundf(rot * factor);
+        if (bin == 30) bin = 0;
+        if (lane == bin) myHist++;
+      }
+      // every lane performs the same store (uniform values): later reads by any lane see it
+      m2[bestF] = i;
+      bin2[bestF] = (unsigned char)bin;
+      nmatches++;
+    }
+  }
+  PLH_WAVE_SYNC();
+  if (checkOri) {   // ComputeThreeMaxima over the 30 bins
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int b = 0; b < 30; b++) {
+      const int s = __shfl(myHist, b);
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+      else if (s > max3) { max3 = s; ind3 = b; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    int removed = 0;
+    for (int f = lane; f < n2; f += 64) {
+      const int b = bin2[f];
+      if (m2[f] >= 0 && b != ind1 && b != ind2 && b != ind3) { m2[f] = -1; removed++; }
+    }
+    removed = wave_sum(removed);
+    nmatches -= removed;
+  }
+  for (int f = lane; f < cap; f += 64) matches21[o + f] = f < n2 ? m2[f] : -1;
+  if (lane == 0) nmatchesOut[pair] = nmatches;
+}
+
+static size_t bow_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
+
+}  // namespace plh
+
+using namespace plh;
+
+extern "C" {
+
+int plh_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  int d = 0;
+  for (int i = 0; i < 4; i++) {
+    unsigned long long x, y;
+    memcpy(&x, a + 8 * i, 8);
+    memcpy(&y, b + 8 * i, 8);
+    d += __builtin_popcountll(x ^ y);
+  }
+  return d;
+}
+
+plh_status plh_hamming_knn2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, int q_cap, const uint8_t* d_t,
+                                      const int32_t* d_nt, int t_cap, int pairs, int32_t* d_idx, int32_t* d_dist,
+                                      void* stream) {
+  if (!d_q || !d_t || !d_idx || !d_dist || !d_nq || !d_nt || q_cap <= 0 || t_cap <= 0 || pairs <= 0) {
+    set_error("plh_hamming_knn2_batch_dev: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  dim3 grid((q_cap + 255) / 256, pairs), block(256);
+  hipLaunchKernelGGL(k_knn2, grid, block, 0, (hipStream_t)stream, d_q, (const int*)d_nq, 0, q_cap, d_t, (const int*)d_nt, 0,
+                     t_cap, d_idx, d_dist);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_hamming_knn2_dev(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, int32_t* d_dist,
+                                void* stream) {
+  if (nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist)) || (nt > 0 && !d_t)) {
+    set_error("plh_hamming_knn2_dev: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  if (nq == 0) return PLH_OK;
+  dim3 grid((nq + 255) / 256, 1), block(256);
+  hipLaunchKernelGGL(k_knn2, grid, block, 0, (hipStream_t)stream, d_q, (const int*)nullptr, nq, nq, d_t, (const int*)nullptr,
+                     nt, std::max(nt, 1), d_idx, d_dist);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist, int device) {
+  if (nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) return PLH_ERR_INVALID;
+  if (nq == 0) return PLH_OK;
+  PLH_HIP(hipSetDevice(device));
+  uint8_t *dq = nullptr, *dt = nullptr;
+  int32_t *di = nullptr, *dd = nullptr;
+  PLH_HIP(hipMalloc((void**)&dq, (size_t)nq * 32));
+  PLH_HIP(hipMalloc((void**)&dt, (size_t)std::max(nt, 1) * 32));
+  PLH_HIP(hipMalloc((void**)&di, (size_t)nq * 8));
+  PLH_HIP(hipMalloc((void**)&dd, (size_t)nq * 8));
+  PLH_HIP(hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice));
+  if (nt) PLH_HIP(hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice));
+  plh_status st = plh_hamming_knn2_dev(dq, nq, dt, nt, di, dd, nullptr);
+  if (st == PLH_OK) {
+    PLH_HIP(hipDeviceSynchronize());
+    PLH_HIP(hipMemcpy(idx, di, (size_t)nq * 8, hipMemcpyDeviceToHost));
+    PLH_HIP(hipMemcpy(dist, dd, (size_t)nq * 8, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(di); (void)hipFree(dd);
+  return st;
+}
+
+plh_status plh_line_bfmatch_batch_dev(const int32_t* d_idx, const int32_t* d_dist, const int32_t* d_nq, const int32_t* d_nt,
+                                      int q_cap, int pairs, float th, float nnratio, int32_t* d_matches, void* stream) {
+  if (!d_idx || !d_dist || !d_nq || !d_nt || !d_matches || q_cap <= 0 || pairs <= 0) return PLH_ERR_INVALID;
+  hipLaunchKernelGGL(k_line_bfmatch, dim3(pairs), dim3(256), 0, (hipStream_t)stream, d_idx, d_dist, (const int*)d_nq,
+                     (const int*)d_nt, q_cap, th, nnratio, d_matches);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+size_t plh_line_search_double_workspace(int cap, int pairs) {
+  // 2 x (idx + dist tables: cap x 2 int32) + 2 x matches (cap int32), per pair
+  return (size_t)pairs * cap * (2 * 2 * 2 * 4 + 2 * 4) + 256;
+}
+
+plh_status plh_line_search_double_batch_dev(const uint8_t* d_desc1, const int32_t* d_n1, const uint8_t* d_desc2,
+                                            const int32_t* d_n2, int cap, int pairs, float th, float nnratio,
+                                            int32_t* d_matches12, int32_t* d_nmatches, void* d_workspace,
+                                            size_t workspace_bytes, void* stream) {
+  if (!d_desc1 || !d_desc2 || !d_n1 || !d_n2 || !d_matches12 || !d_nmatches || !d_workspace || cap <= 0 || pairs <= 0 ||
+      workspace_bytes < plh_line_search_double_workspace(cap, pairs)) {
+    set_error("plh_line_search_double_batch_dev: invalid argument / workspace too small");
+    return PLH_ERR_INVALID;
+  }
+  const size_t tab = (size_t)pairs * cap * 2;
+  int32_t* idx12 = (int32_t*)d_workspace;
+  int32_t* dist12 = idx12 + tab;
+  int32_t* idx21 = dist12 + tab;
+  int32_t* dist21 = idx21 + tab;
+  int32_t* m1 = dist21 + tab;
+  int32_t* m2 = m1 + (size_t)pairs * cap;
+  plh_status st;
+  if ((st = plh_hamming_knn2_batch_dev(d_desc1, d_n1, cap, d_desc2, d_n2, cap, pairs, idx12, dist12, stream)) != PLH_OK) return st;
+  if ((st = plh_hamming_knn2_batch_dev(d_desc2, d_n2, cap, d_desc1, d_n1, cap, pairs, idx21, dist21, stream)) != PLH_OK) return st;
+  if ((st = plh_line_bfmatch_batch_dev(idx12, dist12, d_n1, d_n2, cap, pairs, th, nnratio, m1, stream)) != PLH_OK) return st;
+  if ((st = plh_line_bfmatch_batch_dev(idx21, dist21, d_n2, d_n1, cap, pairs, th, nnratio, m2, stream)) != PLH_OK) return st;
+  hipLaunchKernelGGL(k_line_mutual, dim3(pairs), dim3(256), 0, (hipStream_t)stream, (const int32_t*)m1, (const int32_t*)m2,
+                     (const int*)d_n1, (const int*)d_n2, cap, d_matches12, d_nmatches);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const float* d_angle1, const int32_t* d_node1,
+                                           const uint8_t* d_valid1, const int32_t* d_n1, const uint8_t* d_desc2,
+                                           const float* d_angle2, const int32_t* d_node2, const int32_t* d_n2, int cap,
+                                           int pairs, int th_low, float nnratio, int check_ori, int32_t* d_matches21,
+                                           int32_t* d_nmatches, void* stream) {
+  if (!d_desc1 || !d_angle1 || !d_node1 || !d_valid1 || !d_n1 || !d_desc2 || !d_angle2 || !d_node2 || !d_n2 ||
+      !d_matches21 || !d_nmatches || cap <= 0 || cap > 6000 || pairs <= 0) {
+    set_error("plh_orb_search_by_bow_batch_dev: invalid argument (cap must be in 1..6000)");
+    return PLH_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1, d_angle1,
+                     d_node1, d_valid1, (const int*)d_n1, d_desc2, d_angle2, d_node2, (const int*)d_n2, cap, th_low, nnratio,
+                     check_ori, d_matches21, d_nmatches);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+}  // extern "C"

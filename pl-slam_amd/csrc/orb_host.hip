@@ -247,7 +247,13 @@ plh_status upload(const std::vector<T>& v, T** d) {
 extern "C" {
 
 const char* plh_last_error(void) { return plh::tls_error(); }
-const char* plh_version(void) { return "plslam_hip 0.1 (gfx950)"; }
+const char* plh_version(void) {
+#if defined(HIPEMU)
+  return "plslam_hip 0.1 (hipemu CPU emulation -- test infrastructure, not the product)";
+#else
+  return "plslam_hip 0.1 (gfx950)";
+#endif
+}
 int plh_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

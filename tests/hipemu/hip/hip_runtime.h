@@ -33,6 +33,8 @@ struct dim3 {
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint3e { unsigned x, y, z; };
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 
 typedef int hipError_t;
 typedef void* hipStream_t;

@@ -1,0 +1,160 @@
+"""Hamming matching: oracle known answers (CPU), kernel sources under hipemu (CPU), and GPU parity."""
+import numpy as np
+import pytest
+
+import _util
+
+
+def _cases(synth, seed, n1, n2, flip=0.08):
+    a, b, perm = synth.make_descriptor_sets(seed, max(n1, n2), flip)
+    return a[:n1].copy(), b[:n2].copy()
+
+
+def _bow_sets(synth, seed, n, nodes=100, valid_p=0.8):
+    a, b, perm = synth.make_descriptor_sets(seed, n, 0.06)
+    rng = synth.SplitMix64(seed + 7)
+    node_a = rng.randint(n, 0, nodes).astype(np.int32)
+    node_b = node_a[perm].copy()
+    # a few features land in other nodes / have no word
+    flip = rng.uniform(n) < 0.1
+    node_b[flip] = rng.randint(int(flip.sum()), 0, nodes).astype(np.int32)
+    node_b[rng.uniform(n) < 0.02] = -1
+    ang_a = rng.uniform(n, 0, 360).astype(np.float32)
+    ang_b = ((ang_a[perm] + 12.0 + rng.uniform(n, -3, 3)) % 360).astype(np.float32)
+    wrong = rng.uniform(n) < 0.15
+    ang_b[wrong] = rng.uniform(int(wrong.sum()), 0, 360).astype(np.float32)
+    valid = (rng.uniform(n) < valid_p).astype(np.uint8)
+    kf = dict(desc=a, angle=ang_a, node=node_a, valid=valid)
+    fr = dict(desc=b, angle=ang_b, node=node_b)
+    return kf, fr
+
+
+def _oracle_bow(O, kf, fr, th_low, nnratio, check):
+    n1, n2 = len(kf["desc"]), len(fr["desc"])
+    out = np.zeros(max(n2, 1), np.int32)
+    p = O._p
+    c = O.lib().plo_orb_search_by_bow(p(kf["desc"]), p(kf["angle"]), p(kf["node"]), p(kf["valid"]), n1, p(fr["desc"]),
+                                      p(fr["angle"]), p(fr["node"]), n2, th_low, nnratio, int(check), p(out))
+    return c, out[:n2]
+
+
+def _oracle_double(O, d1, d2, th, ratio):
+    m = np.zeros(max(len(d1), 1), np.int32)
+    c = O.lib().plo_line_search_double(O._p(d1), len(d1), O._p(d2), len(d2), th, ratio, O._p(m))
+    return c, m[:len(d1)]
+
+
+# ------------------------------------------------------------------ oracle known answers (CPU)
+def test_descriptor_distance_known(oracle):
+    L = oracle.lib()
+    z, f = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert L.plo_descriptor_distance(oracle._p(z), oracle._p(f)) == 256
+    assert L.plo_descriptor_distance(oracle._p(z), oracle._p(z)) == 0
+    a = np.zeros(32, np.uint8); a[3] = 0b10110000; a[31] = 1
+    assert L.plo_descriptor_distance(oracle._p(a), oracle._p(z)) == 4
+    rng = np.random.default_rng(0)
+    x, y = rng.integers(0, 256, (2, 32)).astype(np.uint8)
+    assert L.plo_descriptor_distance(oracle._p(x), oracle._p(y)) == int(np.unpackbits(x ^ y).sum())
+
+
+def test_knn2_ties_and_bruteforce(oracle):
+    q = np.zeros((1, 32), np.uint8)
+    t = np.zeros((4, 32), np.uint8); t[0, 0] = 3; t[1, 0] = 1; t[2, 0] = 2; t[3, 0] = 4   # distances 2,1,1,1
+    idx, dist = oracle.knn2(q, t)
+    assert idx.tolist() == [[1, 2]] and dist.tolist() == [[1, 1]]     # ties keep the lower train index first
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (50, 32)).astype(np.uint8); t = rng.integers(0, 256, (70, 32)).astype(np.uint8)
+    idx, dist = oracle.knn2(q, t)
+    full = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2)
+    assert (np.sort(full, axis=1)[:, :2] == dist).all()
+    assert (full[np.arange(50), idx[:, 0]] == dist[:, 0]).all()
+
+
+def test_search_double_recovers_permutation(oracle, synth):
+    a, b, perm = synth.make_descriptor_sets(103, 200, 0.08)
+    c, m = _oracle_double(oracle, a, b, 50.0, 0.7)
+    inv = np.empty(200, np.int64); inv[perm] = np.arange(200)      # a[i] corresponds to b[inv[i]]
+    ok = m >= 0
+    assert c == ok.sum() and c > 100
+    assert (m[ok] == inv[ok]).all()
+
+
+# ------------------------------------------------------------------ HIP sources under hipemu (CPU)
+def test_emu_knn2(plslam, oracle, synth, emu_lib):
+    a, b = _cases(synth, 100, 300, 333)
+    idx, dist = plslam.hamming_knn2(a, b, lib=emu_lib)
+    ri, rd = oracle.knn2(a, b)
+    assert (idx == ri).all() and (dist == rd).all()
+    idx, dist = plslam.hamming_knn2(a[:5], b[:1], lib=emu_lib)       # nt < 2: second slot empty
+    assert (idx[:, 1] == -1).all() and (dist[:, 1] == 2**31 - 1).all()
+
+
+def test_emu_line_search_double(plslam, oracle, synth, emu_lib):
+    m = plslam.LSDmatcher(0.7, True, lib=emu_lib)
+    sets1, sets2 = [], []
+    for k, (n1, n2) in enumerate([(200, 201), (57, 120), (3, 2), (0, 10), (10, 0), (1, 1)]):
+        a, b = _cases(synth, 110 + k, n1, n2)
+        sets1.append(a); sets2.append(b)
+    got, cnt = m.SearchDoubleBatch(sets1, sets2)
+    for p, (a, b) in enumerate(zip(sets1, sets2)):
+        c, ref = _oracle_double(oracle, a, b, 50.0, 0.7)
+        assert cnt[p] == c and (got[p, :len(a)] == ref).all(), p
+    a, b = _cases(synth, 130, 64, 80)
+    ref = np.zeros(64, np.int32)
+    oracle.lib().plo_line_bfmatch(oracle._p(a), 64, oracle._p(b), 80, 50.0, 0.7, oracle._p(ref))
+    assert (m.FrameBFMatch(a, b) == ref).all()
+
+
+def test_emu_search_by_bow(plslam, oracle, synth, emu_lib):
+    om = plslam.ORBmatcher(0.7, True, lib=emu_lib)
+    for seed, n, nodes in [(200, 300, 20), (201, 150, 5), (202, 64, 64)]:
+        kf, fr = _bow_sets(synth, seed, n, nodes)
+        c, got = om.SearchByBoW(kf, fr)
+        rc, ref = _oracle_bow(oracle, kf, fr, 50, 0.7, True)
+        assert c == rc and (got == ref).all() and c > 10
+    om2 = plslam.ORBmatcher(0.9, False, lib=emu_lib)
+    kf, fr = _bow_sets(synth, 203, 200, 10)
+    c, got = om2.SearchByBoW(kf, fr)
+    rc, ref = _oracle_bow(oracle, kf, fr, 50, 0.9, False)
+    assert c == rc and (got == ref).all()
+
+
+# ------------------------------------------------------------------ GPU parity (config 4: 2 x 2000 descriptors)
+@pytest.mark.gpu
+def test_gpu_knn2_2000(plslam, oracle, synth):
+    a, b, _ = synth.make_descriptor_sets(100, 2000)
+    idx, dist = plslam.hamming_knn2(a, b)
+    ri, rd = oracle.knn2(a, b)
+    assert (idx == ri).all() and (dist == rd).all()
+    # ties: many duplicate rows
+    t = np.repeat(b[:50], 8, axis=0)
+    idx, dist = plslam.hamming_knn2(a[:300], t)
+    ri, rd = oracle.knn2(a[:300], t)
+    assert (idx == ri).all() and (dist == rd).all()
+
+
+@pytest.mark.gpu
+def test_gpu_line_search_double(plslam, oracle, synth):
+    m = plslam.LSDmatcher(0.7, True)
+    sets1, sets2 = [], []
+    for k, (n1, n2) in enumerate([(200, 201), (201, 200), (57, 120), (3, 2), (0, 10), (10, 0), (1, 1), (199, 64)] * 4):
+        a, b = _cases(synth, 103 + k, n1, n2, flip=0.05 + 0.01 * (k % 5))
+        sets1.append(a); sets2.append(b)
+    got, cnt = m.SearchDoubleBatch(sets1, sets2)
+    for p, (a, b) in enumerate(zip(sets1, sets2)):
+        c, ref = _oracle_double(oracle, a, b, 50.0, 0.7)
+        assert cnt[p] == c and (got[p, :len(a)] == ref).all(), p
+
+
+@pytest.mark.gpu
+def test_gpu_search_by_bow_2000(plslam, oracle, synth):
+    om = plslam.ORBmatcher(0.7, True)
+    kfs, frs = [], []
+    for seed, n, nodes in [(300, 2000, 100), (301, 2000, 1000), (302, 1500, 10), (303, 64, 3), (304, 1, 1)]:
+        kf, fr = _bow_sets(synth, seed, n, nodes)
+        kfs.append(kf); frs.append(fr)
+    got, cnt = om.SearchByBoWBatch(kfs, frs)
+    for p, (kf, fr) in enumerate(zip(kfs, frs)):
+        rc, ref = _oracle_bow(oracle, kf, fr, 50, 0.7, True)
+        assert cnt[p] == rc and (got[p, :len(fr["desc"])] == ref).all(), p
+    assert cnt[0] > 500
