@@ -60,10 +60,13 @@ float plo_fast_atan2(float y, float x) {
 
 // cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for CV_8UC1 -- ORBextractor.cc:1120 (pyramid) and
 // LSD's internal 0.8x rescale.  Fixed point: 11-bit coefficients, >>4 / >>16 / (+2)>>2 vertical pass.
-void plo_resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
-                          size_t dstep) {
-  const double scale_x = 1.0 / ((double)dw / sw);
-  const double scale_y = 1.0 / ((double)dh / sh);
+// inv_scale_* > 0: the fx/fy form (dsize = Size(), scale = 1/fx exactly, as LSD calls it); <= 0: derive from dsize.
+void plo_resize_linear_u8_scale(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
+                                size_t dstep, double inv_scale_x, double inv_scale_y) {
+  if (inv_scale_x <= 0) inv_scale_x = (double)dw / sw;
+  if (inv_scale_y <= 0) inv_scale_y = (double)dh / sh;
+  const double scale_x = 1.0 / inv_scale_x;
+  const double scale_y = 1.0 / inv_scale_y;
   std::vector<int> xofs(dw), yofs(dh);
   std::vector<short> ialpha(dw * 2), ibeta(dh * 2);
   int xmax = dw;
@@ -107,6 +110,11 @@ void plo_resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstep, uint
     for (int x = 0; x < dw; x++)
       D[x] = (uint8_t)((((b0 * (r0[x] >> 4)) >> 16) + ((b1 * (r1[x] >> 4)) >> 16) + 2) >> 2);
   }
+}
+
+void plo_resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
+                          size_t dstep) {
+  plo_resize_linear_u8_scale(src, sw, sh, sstep, dst, dw, dh, dstep, 0, 0);
 }
 
 // getGaussianKernel(ksize, sigma, CV_32F) then convertTo(CV_32S, 256): the 8-bit "classic" separable path

@@ -44,6 +44,8 @@ int   plo_cv_round_f(float v);                                    /* cvRound: ro
 float plo_fast_atan2(float y, float x);                           /* cv::fastAtan2, degrees */
 void  plo_resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstep,
                            uint8_t* dst, int dw, int dh, size_t dstep);       /* cv::resize INTER_LINEAR 8UC1 */
+void  plo_resize_linear_u8_scale(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
+                                 size_t dstep, double inv_scale_x, double inv_scale_y);    /* fx/fy form (LSD) */
 void  plo_gaussian_kernel_q8(int ksize, double sigma, int32_t* out);          /* cvRound(getGaussianKernel*256) */
 void  plo_gaussian_blur_u8(const uint8_t* src, int w, int h, size_t sstep,
                            uint8_t* dst, size_t dstep, int ksize, double sigma); /* 8U classic path, REFLECT_101 */
@@ -85,6 +87,8 @@ int  plo_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int3
 
 /* ---- Line extractor (reference src/LineExtractor.cpp + contrib LSDDetector / BinaryDescriptor) ---- */
 int  plo_lsd_detect(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap);  /* cv::LineSegmentDetector (STD) */
+int  plo_lsd_stage_taps(const uint8_t* img, int w, int h, size_t step, uint8_t* scaled, double* angles, double* modgrad,
+                        int32_t* ordered, int* sw_out, int* sh_out);
 int  plo_keylines_from_segments(const float* segs, int n, int w, int h, const uint8_t* mask, size_t mstep,
                                 plo_keyline* out);                                              /* LSDDetector::detectImpl */
 void plo_lbd_compute(const uint8_t* img, int w, int h, size_t step, const plo_keyline* kl, int n, uint8_t* desc32,

@@ -178,3 +178,56 @@ def knn2(q, t):
     dist = np.zeros((len(q), 2), np.int32)
     lib().plo_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
     return idx, dist
+
+
+def lsd_detect(img, cap=20000):
+    """cv::LineSegmentDetector(LSD_REFINE_STD).detect -> float32 [n,4] (x1,y1,x2,y2)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    segs = np.zeros((cap, 4), np.float32)
+    n = lib().plo_lsd_detect(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(segs), cap)
+    return segs[:min(n, cap)].copy()
+
+
+def lsd_stage_taps(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    sw, sh = int(np.rint(w * 0.8)), int(np.rint(h * 0.8))
+    scaled = np.zeros((sh, sw), np.uint8)
+    ang = np.zeros((sh, sw), np.float64)
+    mod = np.zeros((sh, sw), np.float64)
+    order = np.zeros((sh - 1) * (sw - 1), np.int32)
+    a, b = C.c_int(), C.c_int()
+    _SIGS_L = lib().plo_lsd_stage_taps
+    _SIGS_L.argtypes = [_V, _I, _I, _Z, _V, _V, _V, _V, _V, _V]
+    _SIGS_L.restype = _I
+    n = _SIGS_L(_p(img), w, h, w, _p(scaled), _p(ang), _p(mod), _p(order), C.byref(a), C.byref(b))
+    assert (a.value, b.value) == (sw, sh) and n == len(order)
+    return scaled, ang, mod, order
+
+
+def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None):
+    """LINEextractor::operator() -> (keylines[KL_DTYPE], desc[n,32], linefn[n,3])."""
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = n_lsd_feature + 1
+    kl = np.zeros(cap, KL_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    fn = np.zeros((cap, 3), np.float64)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8)
+        if mask.shape != img.shape:
+            raise ValueError("Mask error while detecting lines")
+    n = lib().plo_line_extract(_p(img), img.shape[0], img.shape[1], img.shape[1], _p(mask), n_lsd_feature,
+                               float(min_line_length), _p(kl), _p(desc), _p(fn), cap)
+    if n < 0:
+        raise RuntimeError("oracle line capacity")
+    return kl[:n].copy(), desc[:n].copy(), fn[:n].copy()
+
+
+def lbd_compute(img, keylines):
+    img = np.ascontiguousarray(img, np.uint8)
+    keylines = np.ascontiguousarray(keylines)
+    n = len(keylines)
+    desc = np.zeros((n, 32), np.uint8)
+    f72 = np.zeros((n, 72), np.float32)
+    lib().plo_lbd_compute(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(keylines), n, _p(desc), _p(f72))
+    return desc, f72

@@ -409,3 +409,93 @@ class ORBmatcher:
         stores that feature's MapPoint*) or -1."""
         m, c = self.SearchByBoWBatch([kf], [frame])
         return int(c[0]), m[0, :len(frame["desc"])].copy()
+
+
+class LINEextractor:
+    """ORB_SLAM2::LINEextractor(numOctaves, scale, nLSDFeature, min_line_length) on the GPU
+    (reference include/LineExtractor.h:20-62).  `__call__(image, mask)` is operator()
+    (src/LineExtractor.cpp:26-93): returns (keylines[KL_DTYPE], descriptors[n,32] u8, lineVec2d[n,3] f64)."""
+
+    def __init__(self, numOctaves, scale, nLSDFeature, min_line_length, rows=480, cols=640, max_batch=1, device=0,
+                 lib=None, K=None, D=None):
+        self.lib = load(lib)
+        self.params = LineParams(numOctaves, scale, nLSDFeature, min_line_length)
+        self.rows, self.cols, self.max_batch, self.device = rows, cols, max_batch, device
+        h = C.c_void_p()
+        _check(self.lib, self.lib.plh_line_create(C.byref(self.params), device, rows, cols, max_batch, C.byref(h)),
+               "plh_line_create")
+        self.h = h
+        self.capacity = self.lib.plh_line_capacity(self.h)
+        # the reference's scale tables (LineExtractor.cpp:7-23); numOctaves is 1 on this path
+        self.mvScaleFactor = np.ones(numOctaves, np.float32)
+        for i in range(1, numOctaves):
+            self.mvScaleFactor[i] = np.float32(self.mvScaleFactor[i - 1] * np.float32(scale))
+        if K is not None:
+            self.set_undistort(K, D)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.plh_line_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def GetLevels(self):
+        return int(self.params.num_octaves)
+
+    def GetScaleFactor(self):
+        return float(self.params.scale)
+
+    def GetScaleFactors(self):
+        return self.mvScaleFactor.copy()
+
+    def GetInverseScaleFactors(self):
+        return (np.float32(1.0) / self.mvScaleFactor).astype(np.float32)
+
+    def GetScaleSigmaSquares(self):
+        return (self.mvScaleFactor * self.mvScaleFactor).astype(np.float32)
+
+    def GetInverseScaleSigmaSquares(self):
+        return (np.float32(1.0) / (self.mvScaleFactor * self.mvScaleFactor)).astype(np.float32)
+
+    def set_undistort(self, K, D):
+        """Frame.cc:220-222: undistort the grey image in front of LSD (maps built once, not per frame)."""
+        K = np.ascontiguousarray(K, np.float32)
+        D = np.ascontiguousarray(D if D is not None else np.zeros(5), np.float32)
+        _check(self.lib, self.lib.plh_line_set_undistort(self.h, _p(K), _p(D)), "plh_line_set_undistort")
+
+    def __call__(self, image, mask=None):
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, KL_DTYPE), np.zeros((0, 32), np.uint8), np.zeros((0, 3), np.float64)
+        assert image.dtype == np.uint8 and image.ndim == 2, "image.type() == CV_8UC1"
+        image = np.ascontiguousarray(image)
+        if mask is not None and np.asarray(mask).size:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            if mask.shape != image.shape:
+                raise PlhError("Mask error while detecting lines: please check its dimensions and that data type is CV_8UC1")
+        else:
+            mask = None
+        cap = self.capacity
+        kl = np.zeros(cap, KL_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        fn = np.zeros((cap, 3), np.float64)
+        n = C.c_int(0)
+        _check(self.lib, self.lib.plh_line_extract(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0], _p(mask),
+                                                   _p(kl), _p(desc), _p(fn), cap, C.byref(n)), "plh_line_extract")
+        return kl[:n.value].copy(), desc[:n.value].copy(), fn[:n.value].copy()
+
+    def extract_batch_dev(self, d_imgs, batch, frame_stride, d_keylines, d_desc, d_linefn, d_n, stream=0, d_mask=None):
+        _check(self.lib, self.lib.plh_line_extract_batch_dev(self.h, _p(d_imgs), batch, frame_stride, _p(d_mask), _p(d_keylines),
+                                                             _p(d_desc), _p(d_linefn), _p(d_n), C.c_void_p(stream)),
+               "plh_line_extract_batch_dev")
+
+    def read_segments(self, b=0, cap=20000):
+        out = np.zeros((cap, 4), np.float32)
+        n = C.c_int(0)
+        _check(self.lib, self.lib.plh_line_read_segments(self.h, b, _p(out), cap, C.byref(n)), "plh_line_read_segments")
+        return out[:min(n.value, cap)].copy()

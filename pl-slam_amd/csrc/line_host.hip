@@ -1,0 +1,343 @@
+// Host side of the line extractor: plan (LSD constants computed in double exactly as flsd() does),
+// workspace, launch sequence and the C ABI (include/plslam_hip.h, plh_line_*).
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "line_plan.h"
+#include "plh_common.h"
+
+namespace plh {
+void launch_remap(const LineDeviceArgs& a, hipStream_t s);
+void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst, long long dStride, int dPitch, int w, int h,
+                  int batch, const int taps[7], hipStream_t s);
+void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst, long long dStride, int dPitch, int dw,
+                   int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, hipStream_t s);
+void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s);
+void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s);
+void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s);
+void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s);
+void launch_sobel(const LineDeviceArgs& a, hipStream_t s);
+void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, const float* coef, uint8_t* desc, hipStream_t s);
+size_t lsd_grow_lds_bytes(int spitch, int sh);
+}  // namespace plh
+
+using namespace plh;
+
+struct plh_line {
+  plh_line_params p;
+  int device, rows, cols, maxBatch;
+  LineDeviceArgs a;   // template (pointers filled at create)
+  int taps075[7], taps1[7];
+  // device buffers
+  uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dUsed = nullptr, *dMask = nullptr;
+  uint32_t *dGxgy = nullptr, *dOrdered = nullptr, *dReg = nullptr, *dDxdy = nullptr;
+  unsigned int* dQmax = nullptr;
+  int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
+  float *dSegs = nullptr, *dMap = nullptr, *dCoef = nullptr;
+  ResizeTap *dXtab = nullptr, *dYtab = nullptr;
+  // staging (host-buffer entry points)
+  uint8_t *dImgs = nullptr, *dDesc = nullptr;
+  plh_keyline* dKl = nullptr;
+  double* dFn = nullptr;
+  int* dN = nullptr;
+  hipStream_t stream = nullptr;
+  bool hasUndistort = false;
+};
+
+namespace {
+
+inline int cv_round_h(float v) { return (int)lrintf(v); }
+inline int cv_floor_h(float v) { int i = (int)v; return i - (i > v); }
+
+// getGaussianKernel(n, sigma, CV_32F) -> cvRound(k*256), centred in a 7-tap array (classic 8-bit path).
+void gaussian_q8_7(int n, double sigma, int out[7]) {
+  float cf[7];
+  const double scale2X = -0.5 / (sigma * sigma);
+  double sum = 0;
+  for (int i = 0; i < n; i++) {
+    const double x = i - (n - 1) * 0.5;
+    cf[i] = (float)std::exp(scale2X * x * x);
+    sum += cf[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < 7; i++) out[i] = 0;
+  const int off = (7 - n) / 2;
+  for (int i = 0; i < n; i++) {
+    cf[i] = (float)(cf[i] * sum);
+    out[off + i] = cv_round_h(cf[i] * 256.f);
+  }
+}
+
+// cv::resize(..., Size(), fx, fy, INTER_LINEAR): scale = 1/fx exactly.
+void resize_axis_scale(int ssize, int dsize, double inv_scale, bool isX, std::vector<ResizeTap>& out) {
+  const double scale = 1.0 / inv_scale;
+  int xmax = dsize;
+  for (int d = 0; d < dsize; d++) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = cv_floor_h(f);
+    f -= s;
+    if (isX) {
+      if (s < 0) { f = 0; s = 0; }
+      if (s + 1 >= ssize) {
+        xmax = std::min(xmax, d);
+        if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+      }
+    }
+    ResizeTap t;
+    t.ofs = (short)s;
+    t.a0 = (short)cv_round_h((1.f - f) * 2048.f);
+    t.a1 = (short)cv_round_h(f * 2048.f);
+    t.pad = 0;
+    if (isX && d >= xmax) { t.a0 = 2048; t.a1 = 0; }
+    out.push_back(t);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+plh_status plh_line_destroy(plh_line* h) {
+  if (!h) return PLH_OK;
+  (void)hipSetDevice(h->device);
+  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dUsed, h->dMask, h->dGxgy, h->dOrdered, h->dReg, h->dDxdy, h->dQmax,
+                  h->dNOrdered, h->dNSegs, h->dStatus, h->dSegs, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
+                  h->dKl, h->dFn, h->dN};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PLH_OK;
+}
+
+plh_status plh_line_create(const plh_line_params* p, int device, int rows, int cols, int max_batch, plh_line** out) {
+  if (!p || !out || rows < 16 || cols < 16 || max_batch <= 0 || rows > 8192 || cols > 8192) {
+    set_error("plh_line_create: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  if (p->num_octaves != 1) {
+    set_error("plh_line_create: only numOctaves == 1 is supported (the reference's int scale truncates to 1)");
+    return PLH_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    set_error("plh_line_create: no HIP device %d", device);
+    return PLH_ERR_NO_DEVICE;
+  }
+  PLH_HIP(hipSetDevice(device));
+  plh_line* h = new (std::nothrow) plh_line();
+  if (!h) return PLH_ERR_ALLOC;
+  h->p = *p; h->device = device; h->rows = rows; h->cols = cols; h->maxBatch = max_batch;
+  LineDeviceArgs& a = h->a;
+  memset(&a, 0, sizeof(a));
+  a.w = cols; a.h = rows;
+  a.sw = (int)lrint(cols * 0.8); a.sh = (int)lrint(rows * 0.8);
+  a.spitch = align_up(a.sw, 64);
+  a.fullStride = align_up<long long>((long long)cols * rows, 256);
+  a.scaledStride = align_up<long long>((long long)a.spitch * a.sh, 256);
+  // flsd() constants
+  const double ANG_TH = 22.5, QUANT = 2.0;
+  a.prec = M_PI * ANG_TH / 180;
+  a.p = ANG_TH / 180;
+  a.densityTh = 0.7;
+  const double rho = QUANT / std::sin(a.prec);
+  unsigned q = 0;
+  while (std::sqrt((double)(int)(q + 1) / 4.0) <= rho) q++;   // largest q with norm <= rho  (NOTDEF)
+  a.qThresh = q;
+  const double LOG_NT = 5 * (std::log10(double(a.sw)) + std::log10(double(a.sh))) / 2 + std::log10(11.0);
+  a.minRegSize = (int)(size_t)(-LOG_NT / std::log10(a.p));
+  a.segCap = (a.sw * a.sh) / std::max(a.minRegSize, 1) + 16;
+  a.nFeature = (int)p->n_lsd_feature;
+  a.minLineLength = p->min_line_length;
+  a.outCap = a.nFeature + 1;
+  gaussian_q8_7(7, 0.6 / 0.8, h->taps075);
+  gaussian_q8_7(5, 1.0, h->taps1);
+  if (lsd_grow_lds_bytes(a.spitch, a.sh) > 150 * 1024) {
+    set_error("plh_line_create: image too large for the LDS `used` bitmap (%d x %d scaled)", a.sw, a.sh);
+    delete h;
+    return PLH_ERR_INVALID;
+  }
+  std::vector<ResizeTap> xt, yt;
+  resize_axis_scale(cols, a.sw, 0.8, true, xt);
+  resize_axis_scale(rows, a.sh, 0.8, false, yt);
+  // LBD weights: BinaryDescriptor ctor, binary_descriptor_custom.cpp:217-259 (integer divisions as written there)
+  std::vector<float> coef(21 + 63);
+  {
+    double u = (LBD_BAND_WIDTH * 3 - 1) / 2;
+    double sigma = (LBD_BAND_WIDTH * 2 + 1) / 2;
+    double invsigma2 = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < 21; i++) { double dis = i - u; coef[i] = (float)std::exp(dis * dis * invsigma2); }
+    u = (LBD_NUM_BANDS * LBD_BAND_WIDTH - 1) / 2;
+    sigma = u;
+    invsigma2 = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < 63; i++) { double dis = i - u; coef[21 + i] = (float)std::exp(dis * dis * invsigma2); }
+  }
+  const size_t B = (size_t)max_batch;
+#define TRYHIP(x) do { if ((x) != hipSuccess) { set_error("plh_line_create: %s failed (batch %d)", #x, max_batch); plh_line_destroy(h); return PLH_ERR_ALLOC; } } while (0)
+  TRYHIP(hipMalloc((void**)&h->dTmpA, B * a.fullStride));
+  TRYHIP(hipMalloc((void**)&h->dScaled, B * a.scaledStride));
+  TRYHIP(hipMalloc((void**)&h->dGxgy, B * a.scaledStride * 4));
+  TRYHIP(hipMalloc((void**)&h->dOrdered, B * a.scaledStride * 4));
+  TRYHIP(hipMalloc((void**)&h->dReg, B * a.scaledStride * 4));
+  TRYHIP(hipMalloc((void**)&h->dDxdy, B * a.fullStride * 4));
+  TRYHIP(hipMalloc((void**)&h->dSegs, B * a.segCap * 16));
+  TRYHIP(hipMalloc((void**)&h->dQmax, B * 4));
+  TRYHIP(hipMalloc((void**)&h->dNOrdered, B * 4));
+  TRYHIP(hipMalloc((void**)&h->dNSegs, B * 4));
+  TRYHIP(hipMalloc((void**)&h->dStatus, 64));
+  TRYHIP(hipMemset(h->dStatus, 0, 64));
+  TRYHIP(hipMalloc((void**)&h->dXtab, xt.size() * sizeof(ResizeTap)));
+  TRYHIP(hipMalloc((void**)&h->dYtab, yt.size() * sizeof(ResizeTap)));
+  TRYHIP(hipMemcpy(h->dXtab, xt.data(), xt.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+  TRYHIP(hipMemcpy(h->dYtab, yt.data(), yt.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+  TRYHIP(hipMalloc((void**)&h->dCoef, coef.size() * 4));
+  TRYHIP(hipMemcpy(h->dCoef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
+  TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+#undef TRYHIP
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.gxgy = h->dGxgy; a.used = nullptr; a.ordered = h->dOrdered; a.reg = h->dReg;
+  a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = h->dSegs; a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
+  a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
+  *out = h;
+  return PLH_OK;
+}
+
+int plh_line_capacity(const plh_line* h) { return h ? h->a.outCap : 0; }
+
+plh_status plh_line_set_undistort(plh_line* h, const float K[4], const float D[5]) {
+  if (!h || !K) return PLH_ERR_INVALID;
+  PLH_HIP(hipSetDevice(h->device));
+  bool any = false;
+  if (D)
+    for (int i = 0; i < 5; i++) any |= D[i] != 0.f;
+  if (!any) { h->hasUndistort = false; return PLH_OK; }
+  const int w = h->cols, hh = h->rows;
+  std::vector<float> map((size_t)w * hh * 2);
+  // cv::initUndistortRectifyMap(K, D, I, K, size, CV_32F) (Frame.cc:221), evaluated per pixel in double (pinned)
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+  for (int v = 0; v < hh; v++)
+    for (int u = 0; u < w; u++) {
+      const double x = (u - cx) / fx, y = (v - cy) / fy;
+      const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+      const double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
+      const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+      const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+      map[((size_t)v * w + u) * 2] = (float)(fx * xd + cx);
+      map[((size_t)v * w + u) * 2 + 1] = (float)(fy * yd + cy);
+    }
+  if (!h->dMap) PLH_HIP(hipMalloc((void**)&h->dMap, map.size() * 4));
+  if (!h->dUndist) PLH_HIP(hipMalloc((void**)&h->dUndist, (size_t)h->maxBatch * h->a.fullStride));
+  PLH_HIP(hipMemcpy(h->dMap, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+  h->hasUndistort = true;
+  return PLH_OK;
+}
+
+plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride, const uint8_t* d_mask,
+                                      plh_keyline* d_keylines, uint8_t* d_desc, double* d_linefn, int32_t* d_n, void* stream) {
+  if (!h || !d_imgs || !d_keylines || !d_desc || !d_linefn || !d_n || batch <= 0 || batch > h->maxBatch ||
+      frame_stride < (size_t)h->rows * h->cols) {
+    set_error("plh_line_extract_batch_dev: invalid argument (batch %d, plan max %d)", batch, h ? h->maxBatch : 0);
+    return PLH_ERR_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  LineDeviceArgs a = h->a;
+  a.batch = batch;
+  a.img = d_imgs; a.imgStride = (long long)frame_stride;
+  a.mask = d_mask;
+  const uint8_t* src = d_imgs;
+  long long srcStride = (long long)frame_stride;
+  if (h->hasUndistort) {
+    a.mapxy = h->dMap; a.undist = h->dUndist;
+    launch_remap(a, s);
+    PLH_LAUNCH_CHECK();
+    src = h->dUndist; srcStride = a.fullStride;
+  }
+  // LSD: 7x7 sigma 0.75 blur -> 0.8x resize -> level-line field -> seed order -> region growing
+  launch_blur7(src, srcStride, a.w, h->dTmpA, a.fullStride, a.w, a.w, a.h, batch, h->taps075, s);
+  PLH_LAUNCH_CHECK();
+  launch_resize(h->dTmpA, a.fullStride, a.w, a.h, h->dScaled, a.scaledStride, a.spitch, a.sw, a.sh, batch, h->dXtab, h->dYtab, s);
+  PLH_LAUNCH_CHECK();
+  PLH_HIP(hipMemsetAsync(h->dQmax, 0, (size_t)batch * 4, s));
+  launch_lsd_grad(a, s);
+  PLH_LAUNCH_CHECK();
+  launch_lsd_order(a, s);
+  PLH_LAUNCH_CHECK();
+  launch_lsd_grow(a, s);
+  PLH_LAUNCH_CHECK();
+  launch_keylines(a, d_keylines, d_linefn, d_n, s);
+  PLH_LAUNCH_CHECK();
+  // LBD: 5x5 sigma 1 blur -> Sobel -> band descriptor
+  launch_blur7(src, srcStride, a.w, h->dTmpA, a.fullStride, a.w, a.w, a.h, batch, h->taps1, s);
+  PLH_LAUNCH_CHECK();
+  launch_sobel(a, s);
+  PLH_LAUNCH_CHECK();
+  launch_lbd(a, d_keylines, d_n, h->dCoef, d_desc, s);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask,
+                            plh_keyline* keylines, uint8_t* desc, double* linefn, int cap, int* n_out) {
+  if (!h || !n_out) return PLH_ERR_INVALID;
+  if (rows == 0 || cols == 0 || !img) {   // reference: empty image -> silent return (LineExtractor.cpp:29-30)
+    *n_out = 0;
+    return PLH_OK;
+  }
+  if (rows != h->rows || cols != h->cols || step < (size_t)cols || !keylines || !desc || !linefn) {
+    set_error("plh_line_extract: image %dx%d does not match the plan %dx%d", rows, cols, h->rows, h->cols);
+    return PLH_ERR_INVALID;
+  }
+  PLH_HIP(hipSetDevice(h->device));
+  const size_t B = (size_t)h->maxBatch, ocap = h->a.outCap;
+  if (!h->dImgs) {
+    PLH_HIP(hipMalloc((void**)&h->dImgs, B * rows * cols));
+    PLH_HIP(hipMalloc((void**)&h->dKl, B * ocap * sizeof(plh_keyline)));
+    PLH_HIP(hipMalloc((void**)&h->dDesc, B * ocap * 32));
+    PLH_HIP(hipMalloc((void**)&h->dFn, B * ocap * 24));
+    PLH_HIP(hipMalloc((void**)&h->dN, B * 4));
+  }
+  PLH_HIP(hipMemcpy2DAsync(h->dImgs, cols, img, step, cols, rows, hipMemcpyHostToDevice, h->stream));
+  const uint8_t* dmask = nullptr;
+  if (mask) {
+    if (!h->dMask) PLH_HIP(hipMalloc((void**)&h->dMask, (size_t)rows * cols));
+    PLH_HIP(hipMemcpyAsync(h->dMask, mask, (size_t)rows * cols, hipMemcpyHostToDevice, h->stream));
+    dmask = h->dMask;
+  }
+  plh_status st = plh_line_extract_batch_dev(h, h->dImgs, 1, (size_t)rows * cols, dmask, h->dKl, h->dDesc, h->dFn, h->dN, h->stream);
+  if (st != PLH_OK) return st;
+  int n = 0;
+  PLH_HIP(hipMemcpyAsync(&n, h->dN, 4, hipMemcpyDeviceToHost, h->stream));
+  PLH_HIP(hipStreamSynchronize(h->stream));
+  if (n > cap) {
+    set_error("plh_line_extract: %d keylines exceed the caller's capacity %d", n, cap);
+    return PLH_ERR_CAPACITY;
+  }
+  PLH_HIP(hipMemcpy(keylines, h->dKl, (size_t)n * sizeof(plh_keyline), hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(desc, h->dDesc, (size_t)n * 32, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(linefn, h->dFn, (size_t)n * 24, hipMemcpyDeviceToHost));
+  *n_out = n;
+  int stf = 0;
+  PLH_HIP(hipMemcpy(&stf, h->dStatus, 4, hipMemcpyDeviceToHost));
+  if (stf) {
+    (void)hipMemset(h->dStatus, 0, 4);
+    set_error("line kernels reported a capacity overflow (flags 0x%x)", stf);
+    return PLH_ERR_CAPACITY;
+  }
+  return PLH_OK;
+}
+
+plh_status plh_line_read_segments(plh_line* h, int b, float* out_xyxy, int cap, int* n_out) {
+  if (!h || b < 0 || b >= h->maxBatch || !n_out) return PLH_ERR_INVALID;
+  PLH_HIP(hipSetDevice(h->device));
+  PLH_HIP(hipDeviceSynchronize());
+  int n = 0;
+  PLH_HIP(hipMemcpy(&n, h->dNSegs + b, 4, hipMemcpyDeviceToHost));
+  *n_out = n;
+  const int m = std::min(n, std::min(cap, h->a.segCap));
+  if (out_xyxy && m > 0)
+    PLH_HIP(hipMemcpy(out_xyxy, h->dSegs + (size_t)b * h->a.segCap * 4, (size_t)m * 16, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+// HIP kernels of the line half of the front end (gfx950 / CDNA4, wave64), batch-first.
+//
+//   k_remap_u8      cv::remap(INTER_LINEAR) with prebuilt undistortion maps     Frame.cc:220-222
+//   k_blur7_u8      8-bit separable Gaussian (Q8, REFLECT_101), 5 or 7 taps     LSD internal 7x7 s=0.75; LBD 5x5 s=1
+//   k_resize_u8     cv::resize(INTER_LINEAR) fixed point                        LSD internal 0.8x
+//   k_lsd_grad      ll_angle(): 2x2 gradient, NOTDEF threshold, max gradient    SURVEY.md B.7
+//   k_lsd_order     ll_angle(): 1024-bin pseudo-ordering of seeds (stable)      SURVEY.md B.7 / 8c pin (6)
+//   k_lsd_grow      flsd(): region_grow / region2rect / refine / reduce_region_radius
+//   k_keylines      LSDDetector::detectImpl KeyLine fill + mask; LINEextractor sort/keep/class_id/line equation
+//                                                                              LSDDetector_custom.cpp:162-213, LineExtractor.cpp:43-90
+//   k_sobel_pack    cv::Sobel 3x3 dx,dy -> packed int16x2                       binary_descriptor_custom.cpp:395-396
+//   k_lbd           BinaryDescriptor::computeLBD + binaryConversion             binary_descriptor_custom.cpp:1026-1372, 401-412
+//
+// LSD's region growing is inherently sequential per frame (global `used` map, seed order, running mean
+// angle): it runs as ONE WAVEFRONT PER FRAME with the sequential semantics kept, the 3x3 neighbourhood
+// fetched by 9 lanes, the `used` map as a bitmap in LDS and the region queue mirrored in an LDS ring.
+// Throughput comes from the batch (thousands of frames = thousands of independent wavefronts).
+// Float32 / float64 arithmetic follows the oracle's operation order exactly (-ffp-contract=off).
+#include "line_dev.h"
+
+namespace plh {
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= a.w) return;
+  const uint8_t* src = a.img + (long long)b * a.imgStride;
+  const float mx = a.mapxy[((long long)y * a.w + x) * 2], my = a.mapxy[((long long)y * a.w + x) * 2 + 1];
+  const int sx = cv_round(mx * 32.f), sy = cv_round(my * 32.f);
+  const int ix = sx >> 5, iy = sy >> 5, ax = sx & 31, ay = sy & 31;
+  auto P = [&](int yy, int xx) -> int {
+    return (xx >= 0 && xx < a.w && yy >= 0 && yy < a.h) ? (int)src[(long long)yy * a.w + xx] : 0;
+  };
+  const int s = (32 - ax) * (32 - ay) * 32 * P(iy, ix) + ax * (32 - ay) * 32 * P(iy, ix + 1) +
+                (32 - ax) * ay * 32 * P(iy + 1, ix) + ax * ay * 32 * P(iy + 1, ix + 1);
+  int v = (s + (1 << 14)) >> 15;
+  a.undist[(long long)b * a.fullStride + (long long)y * a.w + x] = (uint8_t)(v > 255 ? 255 : v);
+}
+
+// Separable 7-tap Q8 blur; 64x16 output tile per block, input tile (+3 halo, REFLECT_101) staged in LDS.
+__global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst,
+                                                  long long dStride, int dPitch, int w, int h, Taps7 t) {
+  constexpr int TW = 64, TH = 16, IW = TW + 6, IH = TH + 6, IP = IW + 2;
+  __shared__ uint8_t tin[IH * IP];
+  __shared__ unsigned short hb[IH * TW];
+  const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+  const uint8_t* S = src + (long long)b * sStride;
+  for (int i = tid; i < IH * IW; i += 256) {
+    const int r = i / IW, c = i - r * IW;
+    tin[r * IP + c] = S[(long long)refl101(y0 - 3 + r, h) * sPitch + refl101(x0 - 3 + c, w)];
+  }
+  __syncthreads();
+  for (int i = tid; i < IH * TW; i += 256) {
+    const int r = i / TW, c = i - r * TW;
+    const uint8_t* p = &tin[r * IP + c];
+    hb[i] = (unsigned short)(t.k[0] * p[0] + t.k[1] * p[1] + t.k[2] * p[2] + t.k[3] * p[3] + t.k[4] * p[4] + t.k[5] * p[5] +
+                             t.k[6] * p[6]);
+  }
+  __syncthreads();
+  uint8_t* D = dst + (long long)b * dStride;
+  for (int i = tid; i < TH * TW; i += 256) {
+    const int r = i / TW, c = i - r * TW;
+    const int x = x0 + c, y = y0 + r;
+    if (x < w && y < h) {
+      const unsigned short* p = &hb[r * TW + c];
+      const int s = t.k[0] * p[0] + t.k[1] * p[TW] + t.k[2] * p[2 * TW] + t.k[3] * p[3 * TW] + t.k[4] * p[4 * TW] +
+                    t.k[5] * p[5 * TW] + t.k[6] * p[6 * TW];
+      const int v = (s + (1 << 15)) >> 16;
+      D[(long long)y * dPitch + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+  }
+}
+
+// cv::resize INTER_LINEAR (fixed point), one thread per 4 output pixels.  dPitch must be a multiple of 4.
+__global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst,
+                                                   long long dStride, int dPitch, int dw, int dh, const ResizeTap* xtab,
+                                                   const ResizeTap* ytab) {
+  const int b = blockIdx.z;
+  const int x4 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
+  const int y = (int)blockIdx.y * 4 + (int)threadIdx.y;
+  if (y >= dh || x4 >= dPitch) return;
+  const uint8_t* S = src + (long long)b * sStride;
+  const ResizeTap ty = ytab[y];
+  const int sy0 = min(max((int)ty.ofs, 0), sh - 1), sy1 = min(max((int)ty.ofs + 1, 0), sh - 1);
+  const uint8_t* r0 = S + (long long)sy0 * sPitch;
+  const uint8_t* r1 = S + (long long)sy1 * sPitch;
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int x = x4 + k;
+    if (x < dw) {
+      const ResizeTap tx = xtab[x];
+      int s0 = r0[tx.ofs] * tx.a0, s1 = r1[tx.ofs] * tx.a0;
+      if (tx.a1) { s0 += r0[tx.ofs + 1] * tx.a1; s1 += r1[tx.ofs + 1] * tx.a1; }
+      const int v = ((((int)ty.a0 * (s0 >> 4)) >> 16) + (((int)ty.a1 * (s1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 255) << (8 * k);
+    }
+  }
+  *reinterpret_cast<uint32_t*>(dst + (long long)b * dStride + (long long)y * dPitch + x4) = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ll_angle(): level-line field (packed gx,gy, see line_dev.h), padding columns cleared, per-frame max gradient.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
+  __shared__ unsigned s_max;
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
+  if (x < a.spitch) {
+    const uint8_t* I = a.scaled + (long long)b * a.scaledStride;
+    uint32_t g = 0;
+    if (x < a.sw - 1 && y < a.sh - 1) {
+      const int p00 = I[(long long)y * a.spitch + x], p01 = I[(long long)y * a.spitch + x + 1];
+      const int p10 = I[(long long)(y + 1) * a.spitch + x], p11 = I[(long long)(y + 1) * a.spitch + x + 1];
+      const int DA = p11 - p00, BC = p01 - p10;
+      g = pack_g(DA + BC, DA - BC);
+      const unsigned q = g_q(g);
+      if (q > a.qThresh) atomicMax(&s_max, q);
+    }
+    a.gxgy[(long long)b * a.scaledStride + (long long)y * a.spitch + x] = g;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);
+}
+
+// One 1024-thread block per frame: stable counting sort of the DEFINED pixels by bin (descending), raster
+// order inside a bin.  16 waves own contiguous raster chunks; per-(wave,bin) counters live in LDS.
+__global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  int* hist = (int*)smem;                 // [16][1024] counts, then running offsets
+  int* scan = hist + 16 * LSD_NBINS;      // [1024]
+  const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const uint32_t* G = a.gxgy + (long long)b * a.scaledStride;
+  uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
+  const unsigned qmax = a.qmax[b];
+  const double bin_coef = qmax > 0 ? (double)(LSD_NBINS - 1) / sqrt((double)(int)qmax / 4.0) : 0.0;
+  const int npix = a.spitch * a.sh;
+  const int chunk = ((npix + 15) / 16 + 63) / 64 * 64;
+  const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
+  for (int i = tid; i < 16 * LSD_NBINS; i += 1024) hist[i] = 0;
+  __syncthreads();
+  for (int base = c0; base < c1; base += 64) {
+    const int i = base + lane;
+    if (i < c1) {
+      const uint32_t g = G[i];
+      if (g_q(g) > a.qThresh) atomicAdd(&hist[wv * LSD_NBINS + (int)(g_modgrad(g) * bin_coef)], 1);
+    }
+  }
+  __syncthreads();
+  {   // thread t owns bin 1023 - t (descending bins first)
+    const int bin = LSD_NBINS - 1 - tid;
+    int tot = 0;
+    for (int w = 0; w < 16; w++) tot += hist[w * LSD_NBINS + bin];
+    scan[tid] = tot;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int v = tid >= d ? scan[tid - d] : 0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    int run = scan[tid] - tot;
+    for (int w = 0; w < 16; w++) {
+      const int c = hist[w * LSD_NBINS + bin];
+      hist[w * LSD_NBINS + bin] = run;
+      run += c;
+    }
+    if (tid == 1023) a.nOrdered[b] = scan[1023];
+  }
+  __syncthreads();
+  for (int base = c0; base < c1; base += 64) {
+    const int i = base + lane;
+    bool active = false;
+    int bin = 0;
+    if (i < c1) {
+      const uint32_t g = G[i];
+      if (g_q(g) > a.qThresh) { active = true; bin = (int)(g_modgrad(g) * bin_coef); }
+    }
+    for (;;) {
+      const unsigned long long m = __ballot(active);
+      if (!m) break;
+      const int leader = __ffsll((long long)m) - 1;
+      const int lb = __shfl(bin, leader);
+      const unsigned long long same = __ballot(active && bin == lb);
+      int basep = 0;
+      if (lane == leader) basep = hist[wv * LSD_NBINS + lb];
+      basep = __shfl(basep, leader);
+      if (lane == leader) hist[wv * LSD_NBINS + lb] = basep + __popcll(same);
+      if (active && bin == lb) {
+        ord[basep + __popcll(same & lanemask_lt())] = (uint32_t)i;
+        active = false;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launchers (stage 1: image preparation + level-line field + seed ordering)
+// ---------------------------------------------------------------------------------------------
+void launch_remap(const LineDeviceArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_remap_u8, dim3((a.w + 255) / 256, a.h, a.batch), dim3(256), 0, s, a);
+}
+void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst, long long dStride, int dPitch, int w, int h,
+                  int batch, const int taps[7], hipStream_t s) {
+  Taps7 t;
+  for (int i = 0; i < 7; i++) t.k[i] = taps[i];
+  hipLaunchKernelGGL(k_blur7_u8, dim3((w + 63) / 64, (h + 15) / 16, batch), dim3(256), 0, s, src, sStride, sPitch, dst, dStride,
+                     dPitch, w, h, t);
+}
+void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst, long long dStride, int dPitch, int dw,
+                   int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, hipStream_t s) {
+  hipLaunchKernelGGL(k_resize_u8, dim3((dPitch / 4 + 63) / 64, (dh + 3) / 4, batch), dim3(64, 4), 0, s, src, sStride, sPitch, sh,
+                     dst, dStride, dPitch, dw, dh, xtab, ytab);
+}
+void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_lsd_grad, dim3((a.spitch + 255) / 256, a.sh, a.batch), dim3(256), 0, s, a);
+}
+void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_lsd_order, dim3(a.batch), dim3(1024), (size_t)(16 * LSD_NBINS + 1024) * 4, s, a);
+}
+
+}  // namespace plh
+

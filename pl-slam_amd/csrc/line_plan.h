@@ -1,0 +1,55 @@
+// Line extractor plan: geometry and workspace layout shared by host code and the HIP kernels.
+// Constants follow cv::LineSegmentDetector's defaults (LSD_REFINE_STD) and cv::line_descriptor::BinaryDescriptor's
+// parameters as used by LINEextractor::operator() (reference src/LineExtractor.cpp:39-40,77-78).
+#pragma once
+#include <cstdint>
+
+#include "orb_plan.h"   // ResizeTap
+
+namespace plh {
+
+constexpr int LBD_NUM_BANDS = 9;      // NUM_OF_BANDS, binary_descriptor_custom.cpp:57
+constexpr int LBD_BAND_WIDTH = 7;     // Params::widthOfBand_, binary_descriptor_custom.cpp:112
+constexpr int LBD_ROWS = LBD_NUM_BANDS * LBD_BAND_WIDTH;   // 63 rows of the line support region
+constexpr int LSD_NBINS = 1024;
+
+struct LineDeviceArgs {
+  // geometry
+  int w, h;                 // full-resolution image
+  int sw, sh, spitch;       // LSD's 0.8x image
+  int batch;
+  // per-frame strides (elements)
+  long long fullStride;     // w*h rounded up (u8 planes at full resolution)
+  long long scaledStride;   // spitch*sh rounded up
+  // inputs / intermediates (frame-major)
+  const uint8_t* img;       // caller's frames (pitch = w)
+  long long imgStride;
+  const float* mapxy;       // undistortion maps (x,y interleaved) or null
+  uint8_t* undist;          // remapped frames (== img when no undistortion), pitch w
+  uint8_t* tmpA;            // full-res scratch plane (blur output), pitch w
+  uint8_t* scaled;          // 0.8x image, pitch spitch
+  uint32_t* gxgy;           // packed (gx:int16 | gy:int16 << 16) per scaled pixel, pitch spitch
+  uint8_t* used;            // region-growing marks, pitch spitch
+  uint32_t* ordered;        // seed list (pixel index y*spitch+x), bins descending / raster inside a bin
+  uint32_t* reg;            // region point queue
+  unsigned int* qmax;       // per frame max(gx^2+gy^2) over defined pixels
+  int* nOrdered;            // per frame
+  float* segs;              // [frame][segCap][4]
+  int* nSegs;               // per frame
+  int segCap;
+  uint32_t* dxdy;           // Sobel (dx:int16 | dy:int16 << 16) of the 5x5-blurred full-res frame, pitch w
+  const ResizeTap* xtab;
+  const ResizeTap* ytab;
+  const uint8_t* mask;      // optional w*h mask shared by all frames, or null
+  // LSD constants (computed on the host in double exactly as flsd() does)
+  double prec, p, densityTh;
+  unsigned int qThresh;     // pixel is NOTDEF  <=>  gx^2+gy^2 <= qThresh  (<=> sqrt(q/4) <= rho)
+  int minRegSize;
+  // selection
+  int nFeature;             // nLSDFeature
+  double minLineLength;
+  int outCap;               // nFeature + 1
+  int* status;
+};
+
+}  // namespace plh

@@ -1,0 +1,542 @@
+// Line kernels, stage 2: LSD region growing / rectangle fit, KeyLine selection, Sobel pack, LBD.
+// See line_kernels.hip for the overview and the reference citations.
+#include "line_dev.h"
+
+namespace plh {
+
+struct LsdRect {
+  double x1, y1, x2, y2, width;
+};
+
+struct GrowCtx {
+  const uint32_t* G;   // packed gx,gy of the scaled image
+  uint32_t* reg;       // region queue (global memory)
+  uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
+  uint32_t* bm;        // LDS `used` bitmap
+  int spitch, sw, sh, lane;
+  unsigned qThresh;
+};
+constexpr int LSD_RING = 2048;
+
+__device__ __forceinline__ uint32_t reg_get(const GrowCtx& c, int i, int cnt) {
+  return (cnt - i <= LSD_RING) ? c.ring[i & (LSD_RING - 1)] : c.reg[i];
+}
+
+// region_grow(): BFS over reg[] used as a queue; lanes 0..8 fetch the 3x3 neighbourhood (yy outer, xx inner),
+// acceptance is resolved in that order because every accepted pixel moves the running region angle.
+// Returns the region size; *regAngleOut = final reg_angle.  All lanes hold identical (uniform) state.
+__device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, double* regAngleOut) {
+  const int lane = c.lane;
+  double reg_angle = g_angle(c.G[seed]);
+  float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+  PLH_WAVE_SYNC();   // every lane has finished reading the seed's `used` bit before it is set
+  if (lane == 0) {
+    c.reg[0] = seed;
+    c.ring[0] = seed;
+    atomicOr(&c.bm[seed >> 5], 1u << (seed & 31));
+  }
+  int cnt = 1;
+  const int dy = lane / 3 - 1, dx = lane - (lane / 3) * 3 - 1;
+  for (int i = 0; i < cnt; i++) {
+    PLH_WAVE_SYNC();
+    const uint32_t p = reg_get(c, i, cnt);
+    const int px = (int)(p % (uint32_t)c.spitch), py = (int)(p / (uint32_t)c.spitch);
+    bool cand = false;
+    uint32_t nidx = 0;
+    double ang = 0;
+    if (lane < 9) {
+      const int xx = px + dx, yy = py + dy;
+      if (xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
+        nidx = (uint32_t)(yy * c.spitch + xx);
+        if (!((c.bm[nidx >> 5] >> (nidx & 31)) & 1u)) {
+          const uint32_t g = c.G[nidx];
+          if (g_q(g) > c.qThresh) {   // angle != NOTDEF
+            cand = true;
+            ang = g_angle(g);
+          }
+        }
+      }
+    }
+    unsigned long long cm = __ballot(cand);
+    while (cm) {
+      const int k = __ffsll((long long)cm) - 1;
+      cm &= cm - 1;
+      const double a = __shfl(ang, k);
+      double n_theta = reg_angle - a;   // isAligned()
+      if (n_theta < 0) n_theta = -n_theta;
+      if (n_theta > k3_2PI) {
+        n_theta -= k2PI;
+        if (n_theta < 0) n_theta = -n_theta;
+      }
+      if (n_theta <= prec) {
+        if (lane == k) {
+          atomicOr(&c.bm[nidx >> 5], 1u << (nidx & 31));
+          c.reg[cnt] = nidx;
+          c.ring[cnt & (LSD_RING - 1)] = nidx;
+        }
+        const float af = (float)a;
+        sumdx += (float)cos((double)af);
+        sumdy += (float)sin((double)af);
+        reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * kDegToRads;
+        cnt++;
+      }
+    }
+  }
+  *regAngleOut = reg_angle;
+  return cnt;
+}
+
+__device__ __forceinline__ double angle_diff_signed(double a, double b) {
+  double diff = a - b;
+  while (diff <= -kPI) diff += k2PI;
+  while (diff > kPI) diff -= k2PI;
+  return diff;
+}
+
+// region2rect() + get_theta().  The weighted sums are accumulated in region order (sequentially, via lane
+// broadcasts) so the doubles are bit-identical to the sequential reference; the extents are min/max (exact).
+__device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, double prec, LsdRect* rec) {
+  const int lane = c.lane;
+  double x = 0, y = 0, sum = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    double w = 0, wx = 0, wy = 0;
+    if (i < cnt) {
+      const uint32_t p = c.reg[i];
+      w = g_modgrad(c.G[p]);
+      wx = (double)(int)(p % (uint32_t)c.spitch) * w;
+      wy = (double)(int)(p / (uint32_t)c.spitch) * w;
+    }
+    const int n = min(64, cnt - base);
+    for (int l = 0; l < n; l++) {
+      x += __shfl(wx, l);
+      y += __shfl(wy, l);
+      sum += __shfl(w, l);
+    }
+  }
+  x /= sum;
+  y /= sum;
+  double Ixx = 0, Iyy = 0, Ixy = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    double a = 0, b = 0, cc = 0;
+    if (i < cnt) {
+      const uint32_t p = c.reg[i];
+      const double w = g_modgrad(c.G[p]);
+      const double ddx = (double)(int)(p % (uint32_t)c.spitch) - x, ddy = (double)(int)(p / (uint32_t)c.spitch) - y;
+      a = ddy * ddy * w;
+      b = ddx * ddx * w;
+      cc = ddx * ddy * w;
+    }
+    const int n = min(64, cnt - base);
+    for (int l = 0; l < n; l++) {
+      Ixx += __shfl(a, l);
+      Iyy += __shfl(b, l);
+      Ixy -= __shfl(cc, l);
+    }
+  }
+  const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+  double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                         : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+  theta *= kDegToRads;
+  if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += kPI;
+  const double dx = cos(theta), dy = sin(theta);
+  double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+  for (int i = lane; i < cnt; i += 64) {
+    const uint32_t p = c.reg[i];
+    const double rdx = (double)(int)(p % (uint32_t)c.spitch) - x, rdy = (double)(int)(p / (uint32_t)c.spitch) - y;
+    const double l = rdx * dx + rdy * dy;
+    const double w = -rdx * dy + rdy * dx;
+    l_max = fmax(l_max, l); l_min = fmin(l_min, l);
+    w_max = fmax(w_max, w); w_min = fmin(w_min, w);
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    l_max = fmax(l_max, __shfl_xor(l_max, m)); l_min = fmin(l_min, __shfl_xor(l_min, m));
+    w_max = fmax(w_max, __shfl_xor(w_max, m)); w_min = fmin(w_min, __shfl_xor(w_min, m));
+  }
+  rec->x1 = x + l_min * dx; rec->y1 = y + l_min * dy;
+  rec->x2 = x + l_max * dx; rec->y2 = y + l_max * dy;
+  rec->width = w_max - w_min;
+  if (rec->width < 1.0) rec->width = 1.0;
+}
+
+__device__ __forceinline__ double dist_sq(double x1, double y1, double x2, double y2) {
+  return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+}
+__device__ __forceinline__ double rect_density(int cnt, const LsdRect& r) {
+  return (double)cnt / (sqrt(dist_sq(r.x1, r.y1, r.x2, r.y2)) * r.width);
+}
+
+// flsd(): one wavefront per frame, seeds in pseudo-order, sequential semantics.
+__global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nWords = (a.spitch * a.sh + 31) / 32;
+  GrowCtx c;
+  c.bm = (uint32_t*)smem;
+  c.ring = c.bm + nWords;
+  c.G = a.gxgy + (long long)b * a.scaledStride;
+  c.reg = a.reg + (long long)b * a.scaledStride;
+  c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
+  const uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
+  float* segs = a.segs + (long long)b * a.segCap * 4;
+  for (int i = lane; i < nWords; i += 64) c.bm[i] = 0;
+  __syncthreads();
+  const int nOrd = a.nOrdered[b];
+  int nseg = 0;
+  for (int s = 0; s < nOrd; s++) {
+    const uint32_t seed = ord[s];
+    PLH_WAVE_SYNC();
+    if ((c.bm[seed >> 5] >> (seed & 31)) & 1u) continue;
+    double reg_angle;
+    int cnt = lsd_region_grow(c, seed, a.prec, &reg_angle);
+    if (cnt < a.minRegSize) continue;
+    __syncthreads();   // queue stores visible to every lane
+    LsdRect rec;
+    lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
+    bool ok = true;
+    double density = rect_density(cnt, rec);
+    if (density < a.densityTh) {   // refine(): retry with a tighter angle tolerance, then shrink the radius
+      const uint32_t p0 = c.reg[0];
+      const double xc = (double)(int)(p0 % (uint32_t)c.spitch), yc = (double)(int)(p0 / (uint32_t)c.spitch);
+      const double ang_c = g_angle(c.G[p0]);
+      double sum = 0, s_sum = 0;
+      int n = 0;
+      for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        bool flag = false;
+        double ang_d = 0;
+        if (i < cnt) {
+          const uint32_t p = c.reg[i];
+          atomicAnd(&c.bm[p >> 5], ~(1u << (p & 31)));
+          const double px = (double)(int)(p % (uint32_t)c.spitch), py = (double)(int)(p / (uint32_t)c.spitch);
+          if (sqrt(dist_sq(xc, yc, px, py)) < rec.width) {
+            flag = true;
+            ang_d = angle_diff_signed(g_angle(c.G[p]), ang_c);
+          }
+        }
+        unsigned long long m = __ballot(flag);
+        while (m) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const double v = __shfl(ang_d, l);
+          sum += v;
+          s_sum += v * v;
+          ++n;
+        }
+      }
+      const double mean_angle = sum / (double)n;
+      const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+      __syncthreads();
+      cnt = lsd_region_grow(c, p0, tau, &reg_angle);
+      if (cnt < 2) {
+        ok = false;
+      } else {
+        __syncthreads();
+        lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
+        density = rect_density(cnt, rec);
+        if (density < a.densityTh) {   // reduce_region_radius()
+          const double r1 = dist_sq(xc, yc, rec.x1, rec.y1), r2 = dist_sq(xc, yc, rec.x2, rec.y2);
+          double radSq = r1 > r2 ? r1 : r2;
+          while (density < a.densityTh) {
+            radSq *= 0.75 * 0.75;
+            int n2 = cnt;
+            if (lane == 0) {   // order-dependent swap-with-last removal: kept strictly sequential
+              for (int i = 0; i < n2; ++i) {
+                const uint32_t p = c.reg[i];
+                const double px = (double)(int)(p % (uint32_t)c.spitch), py = (double)(int)(p / (uint32_t)c.spitch);
+                if (dist_sq(xc, yc, px, py) > radSq) {
+                  atomicAnd(&c.bm[p >> 5], ~(1u << (p & 31)));
+                  c.reg[i] = c.reg[n2 - 1];
+                  --n2;
+                  --i;
+                }
+              }
+            }
+            __syncthreads();
+            cnt = __shfl(n2, 0);
+            if (cnt < 2) { ok = false; break; }
+            lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
+            density = rect_density(cnt, rec);
+          }
+        }
+      }
+    }
+    if (!ok) continue;
+    rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+    rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
+    if (lane == 0 && nseg < a.segCap) {
+      segs[nseg * 4 + 0] = (float)rec.x1; segs[nseg * 4 + 1] = (float)rec.y1;
+      segs[nseg * 4 + 2] = (float)rec.x2; segs[nseg * 4 + 3] = (float)rec.y2;
+    }
+    nseg++;
+  }
+  if (lane == 0) {
+    if (nseg > a.segCap) { atomicOr(a.status, 4); nseg = a.segCap; }
+    a.nSegs[b] = nseg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KeyLine construction + LINEextractor's selection.  One block per frame.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void clamp_extremes(float e[4], int w, int h) {   // checkLineExtremes()
+  if (e[0] < 0) e[0] = 0;
+  if (e[0] >= w) e[0] = (float)w - 1.0f;
+  if (e[2] < 0) e[2] = 0;
+  if (e[2] >= w) e[2] = (float)w - 1.0f;
+  if (e[1] < 0) e[1] = 0;
+  if (e[1] >= h) e[1] = (float)h - 1.0f;
+  if (e[3] < 0) e[3] = 0;
+  if (e[3] >= h) e[3] = (float)h - 1.0f;
+}
+__device__ __forceinline__ float seg_length(const float e[4]) {
+  const double dxx = (double)(e[0] - e[2]), dyy = (double)(e[1] - e[3]);
+  return (float)sqrt(dxx * dxx + dyy * dyy);
+}
+
+__global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  unsigned long long* sel = (unsigned long long*)smem;   // [outCap]
+  __shared__ unsigned long long s_red[4];
+  __shared__ int s_valid, s_keep;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = min(a.nSegs[b], a.segCap);
+  const float* segs = a.segs + (long long)b * a.segCap * 4;
+  unsigned long long* keys = (unsigned long long*)(a.reg + (long long)b * a.scaledStride);   // scratch (free after k_lsd_grow)
+  if (tid == 0) s_valid = 0;
+  __syncthreads();
+  int myValid = 0;
+  for (int i = tid; i < n; i += 256) {
+    float e[4] = {segs[i * 4], segs[i * 4 + 1], segs[i * 4 + 2], segs[i * 4 + 3]};
+    clamp_extremes(e, a.w, a.h);
+    bool valid = true;
+    if (a.mask) {   // drop only if BOTH endpoints lie on mask == 0
+      if (a.mask[(long long)(int)e[1] * a.w + (int)e[0]] == 0 && a.mask[(long long)(int)e[3] * a.w + (int)e[2]] == 0) valid = false;
+    }
+    const float response = seg_length(e) / (float)max(a.w, a.h);
+    keys[i] = valid ? (((unsigned long long)__float_as_uint(response) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i)) : 0ull;
+    myValid += valid;
+  }
+  if (myValid) atomicAdd(&s_valid, myValid);
+  __syncthreads();
+  // top-(outCap) by (response desc, detection index asc): repeated arg-max below the previous pick
+  unsigned long long prev = ~0ull;
+  int K = 0;
+  for (int k = 0; k < a.outCap; k++) {
+    unsigned long long best = 0;
+    for (int i = tid; i < n; i += 256) {
+      const unsigned long long v = keys[i];
+      if (v < prev && v > best) best = v;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+      const unsigned long long o = __shfl_xor(best, m);
+      best = o > best ? o : best;
+    }
+    __syncthreads();
+    if (lane == 0) s_red[wv] = best;
+    __syncthreads();
+    best = s_red[0];
+    for (int w = 1; w < 4; w++) best = s_red[w] > best ? s_red[w] : best;
+    if (best == 0) break;
+    if (tid == 0) sel[k] = best;
+    prev = best;
+    K++;
+  }
+  __syncthreads();
+  if (tid == 0) {   // LineExtractor.cpp:44-64
+    const int nv = s_valid;
+    int total, index;
+    if (nv > a.nFeature) { total = a.nFeature; index = a.nFeature; }
+    else { total = nv; index = nv; }
+    auto lenOf = [&](int k) -> float {
+      const int i = (int)(0xffffffffu - (unsigned)(sel[k] & 0xffffffffull));
+      float e[4] = {segs[i * 4], segs[i * 4 + 1], segs[i * 4 + 2], segs[i * 4 + 3]};
+      clamp_extremes(e, a.w, a.h);
+      return seg_length(e);
+    };
+    if (total >= 1 && (double)lenOf(total - 1) < a.minLineLength) {
+      for (int i = 0; i < total - 1; i++) {
+        if ((double)lenOf(i) >= a.minLineLength && (double)lenOf(i + 1) < a.minLineLength) { index = i; break; }
+      }
+    }
+    int keep = min(index + 1, nv);
+    keep = min(keep, K);
+    s_keep = keep;
+    nOut[b] = keep;
+  }
+  __syncthreads();
+  const int keep = s_keep;
+  for (int k = tid; k < keep; k += 256) {
+    const int i = (int)(0xffffffffu - (unsigned)(sel[k] & 0xffffffffull));
+    float e[4] = {segs[i * 4], segs[i * 4 + 1], segs[i * 4 + 2], segs[i * 4 + 3]};
+    clamp_extremes(e, a.w, a.h);
+    plh_keyline kl;
+    kl.startPointX = e[0]; kl.startPointY = e[1]; kl.endPointX = e[2]; kl.endPointY = e[3];
+    kl.sPointInOctaveX = e[0]; kl.sPointInOctaveY = e[1]; kl.ePointInOctaveX = e[2]; kl.ePointInOctaveY = e[3];
+    kl.lineLength = seg_length(e);
+    const int x1 = cv_round(e[0]), y1 = cv_round(e[1]), x2 = cv_round(e[2]), y2 = cv_round(e[3]);
+    kl.numOfPixels = max(abs(x2 - x1), abs(y2 - y1)) + 1;
+    kl.angle = (float)atan2((double)(kl.endPointY - kl.startPointY), (double)(kl.endPointX - kl.startPointX));
+    kl.class_id = k;
+    kl.octave = 0;
+    kl.size = (kl.endPointX - kl.startPointX) * (kl.endPointY - kl.startPointY);
+    kl.response = kl.lineLength / (float)max(a.w, a.h);
+    kl.pt_x = (kl.endPointX + kl.startPointX) / 2;
+    kl.pt_y = (kl.endPointY + kl.startPointY) / 2;
+    outKl[(long long)b * a.outCap + k] = kl;
+    const double sx = kl.startPointX, sy = kl.startPointY, ex = kl.endPointX, ey = kl.endPointY;
+    const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;
+    const double nrm = sqrt(l0 * l0 + l1 * l1);
+    double* fn = outFn + ((long long)b * a.outCap + k) * 3;
+    fn[0] = l0 / nrm; fn[1] = l1 / nrm; fn[2] = l2 / nrm;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sobel 3x3 (dx, dy) of the 5x5-blurred frame, packed int16 x 2, REFLECT_101.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sobel_pack(LineDeviceArgs a) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= a.w) return;
+  const uint8_t* S = a.tmpA + (long long)b * a.fullStride;
+  const int xm = refl101(x - 1, a.w), xp = refl101(x + 1, a.w), ym = refl101(y - 1, a.h), yp = refl101(y + 1, a.h);
+  const uint8_t *r0 = S + (long long)ym * a.w, *r1 = S + (long long)y * a.w, *r2 = S + (long long)yp * a.w;
+  const int gx = (r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]);
+  const int gy = (r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]);
+  a.dxdy[(long long)b * a.fullStride + (long long)y * a.w + x] = pack_g(gx, gy);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LBD.  One wavefront per line: lane = row of the 63-row line support region, walking the line's
+// numOfPixels columns with the reference's sequential float accumulation; bands are then accumulated
+// in row order by 9 band lanes, and the 72-float vector is normalised / binarised.
+// coef = { gaussCoefL_[21], gaussCoefG_[63] } as float (host: exp() in double, cast at use).
+// ---------------------------------------------------------------------------------------------
+__device__ const unsigned char c_lbd_comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 1, 2, 1, 3, 1, 4, 1, 5, 1, 6, 2, 3,
+                                                 2, 4, 2, 5, 2, 6, 2, 7, 2, 8, 3, 4, 3, 5, 3, 6, 3, 7, 3, 8, 4, 5, 4, 6,
+                                                 4, 7, 4, 8, 5, 6, 5, 7, 5, 8, 6, 7, 6, 8, 7, 8};
+
+__global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline* kls, const int* nOut, const float* coef,
+                                            uint8_t* desc) {
+  __shared__ float des[LBD_NUM_BANDS * 8];
+  const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  if (li >= nOut[b]) return;
+  const plh_keyline L = kls[(long long)b * a.outCap + li];
+  const uint32_t* D = a.dxdy + (long long)b * a.fullStride;
+  const short lengthOfLSP = (short)L.numOfPixels;
+  const short halfWidth = (lengthOfLSP - 1) / 2;
+  const short halfHeight = (LBD_ROWS - 1) / 2;
+  const int imageWidth = a.w - 1, imageHeight = a.h - 1;
+  const float midX = (float)(0.5 * (L.sPointInOctaveX + L.ePointInOctaveX));
+  const float midY = (float)(0.5 * (L.sPointInOctaveY + L.ePointInOctaveY));
+  const float dL0 = (float)cos((double)L.angle), dL1 = (float)sin((double)L.angle);
+  const float dO0 = -dL1, dO1 = dL0;
+  float pL = 0, nL = 0, pO = 0, nO = 0;
+  if (lane < LBD_ROWS) {
+    float sCorX0 = -dL0 * halfWidth + dL1 * halfHeight + midX;
+    float sCorY0 = -dL1 * halfWidth - dL0 * halfHeight + midY;
+    for (int r = 0; r < lane; r++) { sCorX0 -= dL1; sCorY0 += dL0; }
+    float sCorX = sCorX0, sCorY = sCorY0;
+    for (short wID = 0; wID < lengthOfLSP; wID++) {
+      int tc = (int)(short)roundf(sCorX);
+      const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
+      tc = (int)(short)roundf(sCorY);
+      const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+      const uint32_t g = D[(long long)yCor * a.w + xCor];
+      const short dx = (short)g_x(g), dy = (short)g_y(g);
+      const float gDL = dx * dL0 + dy * dL1;
+      const float gDO = dx * dO0 + dy * dO1;
+      if (gDL > 0) pL += gDL; else nL -= gDL;
+      if (gDO > 0) pO += gDO; else nO -= gDO;
+      sCorX += dL0;
+      sCorY += dL1;
+    }
+    const float cg = coef[21 + lane];
+    pL = cg * pL; nL = cg * nL; pO = cg * pO; nO = cg * nO;
+  }
+  // band accumulation in row order: band lane bb takes rows 7(bb-1) .. 7(bb+2)-1
+  const int bb = lane;
+  float spL = 0, snL = 0, spL2 = 0, snL2 = 0, spO = 0, snO = 0, spO2 = 0, snO2 = 0;
+  for (int r = 0; r < 3 * LBD_BAND_WIDTH; r++) {
+    const int hID = LBD_BAND_WIDTH * (bb - 1) + r;
+    const bool valid = bb < LBD_NUM_BANDS && hID >= 0 && hID < LBD_ROWS;
+    const int src = valid ? hID : 0;
+    const float rpL = __shfl(pL, src), rnL = __shfl(nL, src), rpO = __shfl(pO, src), rnO = __shfl(nO, src);
+    if (valid) {
+      // r in [0,7): row of the band above -> "band below the current band" coefficient gaussCoefL_[hID % 7]
+      // r in [7,14): own band -> [hID % 7 + 7];  r in [14,21): row of the band below -> [hID % 7 + 14]
+      const float cL = coef[(hID % LBD_BAND_WIDTH) + LBD_BAND_WIDTH * (r / LBD_BAND_WIDTH)];
+      spL += cL * rpL;
+      snL += cL * rnL;
+      spL2 += cL * cL * (rpL * rpL);
+      snL2 += cL * cL * (rnL * rnL);
+      spO += cL * rpO;
+      snO += cL * rnO;
+      spO2 += cL * cL * (rpO * rpO);
+      snO2 += cL * cL * (rnO * rnO);
+    }
+  }
+  if (bb < LBD_NUM_BANDS) {
+    const float invN2 = (float)(1.0 / (LBD_BAND_WIDTH * 2.0)), invN3 = (float)(1.0 / (LBD_BAND_WIDTH * 3.0));
+    const float invN = (bb == 0 || bb == LBD_NUM_BANDS - 1) ? invN2 : invN3;
+    float* d = &des[bb * 8];
+    float temp = spL * invN;
+    d[0] = temp; d[4] = sqrtf(spL2 * invN - temp * temp);
+    temp = snL * invN;
+    d[1] = temp; d[5] = sqrtf(snL2 * invN - temp * temp);
+    temp = spO * invN;
+    d[2] = temp; d[6] = sqrtf(spO2 * invN - temp * temp);
+    temp = snO * invN;
+    d[3] = temp; d[7] = sqrtf(snO2 * invN - temp * temp);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float tempM = 0, tempS = 0;
+    for (int q = 0; q < LBD_NUM_BANDS; q++) {
+      const float* d = &des[q * 8];
+      tempM += d[0] * d[0]; tempM += d[1] * d[1]; tempM += d[2] * d[2]; tempM += d[3] * d[3];
+      tempS += d[4] * d[4]; tempS += d[5] * d[5]; tempS += d[6] * d[6]; tempS += d[7] * d[7];
+    }
+    tempM = 1 / sqrtf(tempM);
+    tempS = 1 / sqrtf(tempS);
+    for (int q = 0; q < LBD_NUM_BANDS; q++) {
+      float* d = &des[q * 8];
+      for (int k = 0; k < 4; k++) d[k] = d[k] * tempM;
+      for (int k = 4; k < 8; k++) d[k] = d[k] * tempS;
+    }
+    for (int i = 0; i < LBD_NUM_BANDS * 8; i++)
+      if ((double)des[i] > 0.4) des[i] = (float)0.4;
+    float temp = 0;
+    for (int i = 0; i < LBD_NUM_BANDS * 8; i++) temp += des[i] * des[i];
+    temp = 1 / sqrtf(temp);
+    for (int i = 0; i < LBD_NUM_BANDS * 8; i++) des[i] = des[i] * temp;
+  }
+  __syncthreads();
+  if (lane < 32) {
+    const float* f1 = &des[8 * c_lbd_comb[lane * 2]];
+    const float* f2 = &des[8 * c_lbd_comb[lane * 2 + 1]];
+    int result = 0;
+    for (int i = 0; i < 8; i++)
+      if (f1[i] > f2[i]) result += 1 << i;
+    desc[((long long)b * a.outCap + li) * 32 + lane] = (uint8_t)result;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)((a.spitch * a.sh + 31) / 32 + LSD_RING) * 4 + 64;
+  hipLaunchKernelGGL(k_lsd_grow, dim3(a.batch), dim3(64), lds, s, a);
+}
+void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s) {
+  hipLaunchKernelGGL(k_keylines, dim3(a.batch), dim3(256), (size_t)a.outCap * 8 + 64, s, a, kl, fn, n);
+}
+void launch_sobel(const LineDeviceArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_sobel_pack, dim3((a.w + 255) / 256, a.h, a.batch), dim3(256), 0, s, a);
+}
+void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, const float* coef, uint8_t* desc, hipStream_t s) {
+  hipLaunchKernelGGL(k_lbd, dim3(a.outCap, a.batch), dim3(64), 0, s, a, kl, n, coef, desc);
+}
+size_t lsd_grow_lds_bytes(int spitch, int sh) { return (size_t)((spitch * sh + 31) / 32 + LSD_RING) * 4 + 64; }
+
+}  // namespace plh

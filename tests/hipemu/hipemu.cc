@@ -21,6 +21,8 @@ Fiber fibers[kMaxThreads];
 char* stacks = nullptr;
 int cur = 0, nthreads = 0, alive = 0;
 unsigned long events = 0;
+unsigned long launches = 0;
+int wait_kind[kMaxThreads];
 void (*g_tramp)(void*) = nullptr;
 void* g_args = nullptr;
 
@@ -66,7 +68,9 @@ int wave_rendezvous(int w) {  // returns the generation that was completed
     release_wave(w);
     return gen;
   }
+  wait_kind[cur] = 2;
   while (wave_gen[w] == gen) yield();
+  wait_kind[cur] = 0;
   return gen;
 }
 }  // namespace
@@ -80,7 +84,9 @@ void block_barrier() {
     release_block();
     return;
   }
+  wait_kind[cur] = 1;
   while (blk_gen == gen) yield();
+  wait_kind[cur] = 0;
 }
 void wave_barrier() { wave_rendezvous(cur / 64); }
 unsigned long long wave_ballot(int pred) {
@@ -110,6 +116,7 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* a
   std::vector<unsigned char> smem(shmem + 64);
   dyn_smem = (unsigned char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
   g_tramp = tramp;
+  launches++;
   g_args = args;
   blockDim_ = block;
   gridDim_ = grid;
@@ -142,6 +149,9 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* a
             swapcontext(&sched_ctx, &fibers[t].ctx);
           }
           if (alive > 0 && events == before) {
+            fprintf(stderr, "hipemu: launch #%lu block dim %u grid %u,%u\n", launches, blockDim_.x, gridDim_.x, gridDim_.y);
+            for (int t = 0; t < n && t < 64; t++) fprintf(stderr, "%d", fibers[t].done ? 9 : wait_kind[t]);
+            fprintf(stderr, "\n");
             fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): %d threads alive, barrier arrivals %d\n", bx, by, bz, alive, blk_arrived);
             abort();
           }
