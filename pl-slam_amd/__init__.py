@@ -85,6 +85,11 @@ def load(path=None):
     path = os.path.abspath(path or os.environ.get("PLSLAM_HIP_LIB", DEFAULT_LIB))
     if path in _libs:
         return _libs[path]
+    if "hipemu" not in path:
+        try:   # share PyTorch's HIP runtime instance when it is present (it provides device memory / streams)
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(path):
         raise PlhError("HIP library not found: %s -- run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
     lib = C.CDLL(path)

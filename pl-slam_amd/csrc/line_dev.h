@@ -25,9 +25,31 @@ __device__ __forceinline__ int refl101(int p, int n) {
   return p;
 }
 
-// LSD level-line field.  gx = DA+BC, gy = DA-BC are stored packed (int16 x 2); the angle
-// fastAtan2(gx,-gy)*DEG_TO_RADS and the gradient norm sqrt((gx^2+gy^2)/4.0) are recomputed from the pair
-// wherever needed -- exactly the doubles cv::LineSegmentDetector keeps in its angles/modgrad Mats.
+// LSD level-line field, one 16-byte record per pixel of the 0.8x image (a single dwordx4 load in the
+// region-growing loop):
+//   angf : fastAtan2(gx, -gy) in degrees (float); the reference's double angle is angf * DEG_TO_RADS
+//   cs,sn: (float)cos / sin of float(angle) -- the increments region_grow() adds to sumdx / sumdy
+//   q    : gx^2 + gy^2; modgrad = sqrt(q / 4.0) (double) is recomputed where needed; q <= qThresh <=> NOTDEF
+// All four are exactly the values cv::LineSegmentDetector would compute on the fly.
+struct LsdPix {
+  float angf, cs, sn;
+  unsigned q;
+};
+__device__ __forceinline__ double pix_angle(const LsdPix& p) { return (double)p.angf * kDegToRads; }
+__device__ __forceinline__ double q_modgrad(unsigned q) { return sqrt((double)(int)q / 4.0); }
+
+// uniform-lane broadcast of a double: v_readlane (SGPR) on hardware, a shuffle under emulation
+#if defined(HIPEMU)
+__device__ __forceinline__ double bcast_f64(double v, int l) { return __shfl(v, l); }
+#else
+__device__ __forceinline__ double bcast_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+#endif
+
+// packed int16 pair (used for the Sobel dx,dy image of LBD)
 __device__ __forceinline__ uint32_t pack_g(int gx, int gy) { return ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16); }
 __device__ __forceinline__ int g_x(uint32_t g) { return (int)(short)(g & 0xffffu); }
 __device__ __forceinline__ int g_y(uint32_t g) { return (int)(short)(g >> 16); }

@@ -31,7 +31,8 @@ struct plh_line {
   int taps075[7], taps1[7];
   // device buffers
   uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dUsed = nullptr, *dMask = nullptr;
-  uint32_t *dGxgy = nullptr, *dOrdered = nullptr, *dReg = nullptr, *dDxdy = nullptr;
+  uint8_t* dPix = nullptr;
+  uint32_t *dOrdered = nullptr, *dReg = nullptr, *dDxdy = nullptr;
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
   float *dSegs = nullptr, *dMap = nullptr, *dCoef = nullptr;
@@ -101,7 +102,7 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dUsed, h->dMask, h->dGxgy, h->dOrdered, h->dReg, h->dDxdy, h->dQmax,
+  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dUsed, h->dMask, h->dPix, h->dOrdered, h->dReg, h->dDxdy, h->dQmax,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dSegs, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -177,7 +178,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
 #define TRYHIP(x) do { if ((x) != hipSuccess) { set_error("plh_line_create: %s failed (batch %d)", #x, max_batch); plh_line_destroy(h); return PLH_ERR_ALLOC; } } while (0)
   TRYHIP(hipMalloc((void**)&h->dTmpA, B * a.fullStride));
   TRYHIP(hipMalloc((void**)&h->dScaled, B * a.scaledStride));
-  TRYHIP(hipMalloc((void**)&h->dGxgy, B * a.scaledStride * 4));
+  TRYHIP(hipMalloc((void**)&h->dPix, B * a.scaledStride * 16));
   TRYHIP(hipMalloc((void**)&h->dOrdered, B * a.scaledStride * 4));
   TRYHIP(hipMalloc((void**)&h->dReg, B * a.scaledStride * 4));
   TRYHIP(hipMalloc((void**)&h->dDxdy, B * a.fullStride * 4));
@@ -195,7 +196,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   TRYHIP(hipMemcpy(h->dCoef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 #undef TRYHIP
-  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.gxgy = h->dGxgy; a.used = nullptr; a.ordered = h->dOrdered; a.reg = h->dReg;
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.used = nullptr; a.ordered = h->dOrdered; a.reg = h->dReg;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = h->dSegs; a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
   *out = h;
@@ -240,6 +241,7 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
     set_error("plh_line_extract_batch_dev: invalid argument (batch %d, plan max %d)", batch, h ? h->maxBatch : 0);
     return PLH_ERR_INVALID;
   }
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   hipStream_t s = (hipStream_t)stream;
   LineDeviceArgs a = h->a;
   a.batch = batch;

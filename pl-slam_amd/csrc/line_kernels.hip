@@ -109,16 +109,23 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   __syncthreads();
   if (x < a.spitch) {
     const uint8_t* I = a.scaled + (long long)b * a.scaledStride;
-    uint32_t g = 0;
+    LsdPix px;
+    px.angf = -1024.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
     if (x < a.sw - 1 && y < a.sh - 1) {
       const int p00 = I[(long long)y * a.spitch + x], p01 = I[(long long)y * a.spitch + x + 1];
       const int p10 = I[(long long)(y + 1) * a.spitch + x], p11 = I[(long long)(y + 1) * a.spitch + x + 1];
       const int DA = p11 - p00, BC = p01 - p10;
-      g = pack_g(DA + BC, DA - BC);
-      const unsigned q = g_q(g);
-      if (q > a.qThresh) atomicMax(&s_max, q);
+      const int gx = DA + BC, gy = DA - BC;
+      px.q = (unsigned)(gx * gx + gy * gy);
+      if (px.q > a.qThresh) {
+        px.angf = fast_atan2_deg((float)gx, (float)(-gy));
+        const float af = (float)((double)px.angf * kDegToRads);
+        px.cs = (float)cos((double)af);
+        px.sn = (float)sin((double)af);
+        atomicMax(&s_max, px.q);
+      }
     }
-    a.gxgy[(long long)b * a.scaledStride + (long long)y * a.spitch + x] = g;
+    reinterpret_cast<LsdPix*>(a.pix)[(long long)b * a.scaledStride + (long long)y * a.spitch + x] = px;
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);
@@ -131,7 +138,7 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   int* hist = (int*)smem;                 // [16][1024] counts, then running offsets
   int* scan = hist + 16 * LSD_NBINS;      // [1024]
   const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const uint32_t* G = a.gxgy + (long long)b * a.scaledStride;
+  const LsdPix* G = reinterpret_cast<const LsdPix*>(a.pix) + (long long)b * a.scaledStride;
   uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
   const unsigned qmax = a.qmax[b];
   const double bin_coef = qmax > 0 ? (double)(LSD_NBINS - 1) / sqrt((double)(int)qmax / 4.0) : 0.0;
@@ -143,8 +150,8 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   for (int base = c0; base < c1; base += 64) {
     const int i = base + lane;
     if (i < c1) {
-      const uint32_t g = G[i];
-      if (g_q(g) > a.qThresh) atomicAdd(&hist[wv * LSD_NBINS + (int)(g_modgrad(g) * bin_coef)], 1);
+      const unsigned q = G[i].q;
+      if (q > a.qThresh) atomicAdd(&hist[wv * LSD_NBINS + (int)(q_modgrad(q) * bin_coef)], 1);
     }
   }
   __syncthreads();
@@ -174,8 +181,8 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
     bool active = false;
     int bin = 0;
     if (i < c1) {
-      const uint32_t g = G[i];
-      if (g_q(g) > a.qThresh) { active = true; bin = (int)(g_modgrad(g) * bin_coef); }
+      const unsigned q = G[i].q;
+      if (q > a.qThresh) { active = true; bin = (int)(q_modgrad(q) * bin_coef); }
     }
     for (;;) {
       const unsigned long long m = __ballot(active);

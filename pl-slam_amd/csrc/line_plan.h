@@ -28,7 +28,7 @@ struct LineDeviceArgs {
   uint8_t* undist;          // remapped frames (== img when no undistortion), pitch w
   uint8_t* tmpA;            // full-res scratch plane (blur output), pitch w
   uint8_t* scaled;          // 0.8x image, pitch spitch
-  uint32_t* gxgy;           // packed (gx:int16 | gy:int16 << 16) per scaled pixel, pitch spitch
+  void* pix;                // LsdPix[16 B] level-line record per scaled pixel, pitch spitch (line_dev.h)
   uint8_t* used;            // region-growing marks, pitch spitch
   uint32_t* ordered;        // seed list (pixel index y*spitch+x), bins descending / raster inside a bin
   uint32_t* reg;            // region point queue

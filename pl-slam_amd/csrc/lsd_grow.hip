@@ -9,25 +9,40 @@ struct LsdRect {
 };
 
 struct GrowCtx {
-  const uint32_t* G;   // packed gx,gy of the scaled image
+  const LsdPix* G;     // level-line records of the scaled image
   uint32_t* reg;       // region queue (global memory)
   uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
   uint32_t* bm;        // LDS `used` bitmap
   int spitch, sw, sh, lane;
   unsigned qThresh;
 };
-constexpr int LSD_RING = 2048;
+constexpr int LSD_RING = 1024;
+constexpr int LSD_GROUPS = 7;   // queue points examined per step (7 x 9 neighbour lanes = 63 lanes)
 
 __device__ __forceinline__ uint32_t reg_get(const GrowCtx& c, int i, int cnt) {
   return (cnt - i <= LSD_RING) ? c.ring[i & (LSD_RING - 1)] : c.reg[i];
 }
 
-// region_grow(): BFS over reg[] used as a queue; lanes 0..8 fetch the 3x3 neighbourhood (yy outer, xx inner),
-// acceptance is resolved in that order because every accepted pixel moves the running region angle.
+#if defined(HIPEMU)
+__device__ __forceinline__ float bcast_f32(float v, int l) { return __shfl(v, l); }
+__device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return __shfl(v, l); }
+#else
+__device__ __forceinline__ float bcast_f32(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+#endif
+
+// region_grow(): BFS over reg[] used as a queue.  Each step examines up to 7 queued points at once: lane
+// 9g+n fetches neighbour n (yy outer, xx inner) of point i+g with ONE 16-byte load, so the memory latency
+// is paid once per 7 points.  Acceptance is then resolved strictly in (point, neighbour) order -- every
+// accepted pixel moves the running region angle -- and a pixel accepted for an earlier point cancels its
+// later duplicates, which is exactly what the sequential `used` map does.  Points appended during a step
+// are examined in later steps, so the queue order is the reference's.
 // Returns the region size; *regAngleOut = final reg_angle.  All lanes hold identical (uniform) state.
 __device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, double* regAngleOut) {
   const int lane = c.lane;
-  double reg_angle = g_angle(c.G[seed]);
+  double reg_angle = pix_angle(c.G[seed]);
   float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
   PLH_WAVE_SYNC();   // every lane has finished reading the seed's `used` bit before it is set
   if (lane == 0) {
@@ -36,24 +51,24 @@ __device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, dou
     atomicOr(&c.bm[seed >> 5], 1u << (seed & 31));
   }
   int cnt = 1;
-  const int dy = lane / 3 - 1, dx = lane - (lane / 3) * 3 - 1;
-  for (int i = 0; i < cnt; i++) {
+  const int grp = lane / 9, nb = lane - grp * 9;
+  const int dy = nb / 3 - 1, dx = nb - (nb / 3) * 3 - 1;
+  int i = 0;
+  while (i < cnt) {
     PLH_WAVE_SYNC();
-    const uint32_t p = reg_get(c, i, cnt);
-    const int px = (int)(p % (uint32_t)c.spitch), py = (int)(p / (uint32_t)c.spitch);
+    const int m = min(LSD_GROUPS, cnt - i);
     bool cand = false;
     uint32_t nidx = 0;
-    double ang = 0;
-    if (lane < 9) {
-      const int xx = px + dx, yy = py + dy;
+    LsdPix px;
+    px.angf = 0.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
+    if (grp < m) {
+      const uint32_t p = reg_get(c, i + grp, cnt);
+      const int xx = (int)(p % (uint32_t)c.spitch) + dx, yy = (int)(p / (uint32_t)c.spitch) + dy;
       if (xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
         nidx = (uint32_t)(yy * c.spitch + xx);
         if (!((c.bm[nidx >> 5] >> (nidx & 31)) & 1u)) {
-          const uint32_t g = c.G[nidx];
-          if (g_q(g) > c.qThresh) {   // angle != NOTDEF
-            cand = true;
-            ang = g_angle(g);
-          }
+          px = c.G[nidx];
+          cand = px.q > c.qThresh;   // angle != NOTDEF
         }
       }
     }
@@ -61,7 +76,7 @@ __device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, dou
     while (cm) {
       const int k = __ffsll((long long)cm) - 1;
       cm &= cm - 1;
-      const double a = __shfl(ang, k);
+      const double a = (double)bcast_f32(px.angf, k) * kDegToRads;
       double n_theta = reg_angle - a;   // isAligned()
       if (n_theta < 0) n_theta = -n_theta;
       if (n_theta > k3_2PI) {
@@ -69,18 +84,20 @@ __device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, dou
         if (n_theta < 0) n_theta = -n_theta;
       }
       if (n_theta <= prec) {
+        const uint32_t nk = bcast_u32(nidx, k);
         if (lane == k) {
           atomicOr(&c.bm[nidx >> 5], 1u << (nidx & 31));
           c.reg[cnt] = nidx;
           c.ring[cnt & (LSD_RING - 1)] = nidx;
         }
-        const float af = (float)a;
-        sumdx += (float)cos((double)af);
-        sumdy += (float)sin((double)af);
+        sumdx += bcast_f32(px.cs, k);
+        sumdy += bcast_f32(px.sn, k);
         reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * kDegToRads;
         cnt++;
+        cm &= ~__ballot(cand && nidx == nk);   // the same pixel seen from a later point is now `used`
       }
     }
+    i += m;
   }
   *regAngleOut = reg_angle;
   return cnt;
@@ -103,15 +120,15 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     double w = 0, wx = 0, wy = 0;
     if (i < cnt) {
       const uint32_t p = c.reg[i];
-      w = g_modgrad(c.G[p]);
+      w = q_modgrad(c.G[p].q);
       wx = (double)(int)(p % (uint32_t)c.spitch) * w;
       wy = (double)(int)(p / (uint32_t)c.spitch) * w;
     }
     const int n = min(64, cnt - base);
     for (int l = 0; l < n; l++) {
-      x += __shfl(wx, l);
-      y += __shfl(wy, l);
-      sum += __shfl(w, l);
+      x += bcast_f64(wx, l);
+      y += bcast_f64(wy, l);
+      sum += bcast_f64(w, l);
     }
   }
   x /= sum;
@@ -122,7 +139,7 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     double a = 0, b = 0, cc = 0;
     if (i < cnt) {
       const uint32_t p = c.reg[i];
-      const double w = g_modgrad(c.G[p]);
+      const double w = q_modgrad(c.G[p].q);
       const double ddx = (double)(int)(p % (uint32_t)c.spitch) - x, ddy = (double)(int)(p / (uint32_t)c.spitch) - y;
       a = ddy * ddy * w;
       b = ddx * ddx * w;
@@ -130,9 +147,9 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     }
     const int n = min(64, cnt - base);
     for (int l = 0; l < n; l++) {
-      Ixx += __shfl(a, l);
-      Iyy += __shfl(b, l);
-      Ixy -= __shfl(cc, l);
+      Ixx += bcast_f64(a, l);
+      Iyy += bcast_f64(b, l);
+      Ixy -= bcast_f64(cc, l);
     }
   }
   const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
@@ -175,7 +192,7 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   GrowCtx c;
   c.bm = (uint32_t*)smem;
   c.ring = c.bm + nWords;
-  c.G = a.gxgy + (long long)b * a.scaledStride;
+  c.G = reinterpret_cast<const LsdPix*>(a.pix) + (long long)b * a.scaledStride;
   c.reg = a.reg + (long long)b * a.scaledStride;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   const uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
@@ -184,8 +201,16 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   __syncthreads();
   const int nOrd = a.nOrdered[b];
   int nseg = 0;
-  for (int s = 0; s < nOrd; s++) {
-    const uint32_t seed = ord[s];
+  for (int sbase = 0; sbase < nOrd; sbase += 64) {
+   // 64 seeds per scan: one coalesced load + one parallel `used` test; survivors are re-tested in order
+   const int si = sbase + lane;
+   const uint32_t seedL = si < nOrd ? ord[si] : 0u;
+   PLH_WAVE_SYNC();
+   unsigned long long fm = __ballot(si < nOrd && !((c.bm[seedL >> 5] >> (seedL & 31)) & 1u));
+   while (fm) {
+    const int sk = __ffsll((long long)fm) - 1;
+    fm &= fm - 1;
+    const uint32_t seed = bcast_u32(seedL, sk);
     PLH_WAVE_SYNC();
     if ((c.bm[seed >> 5] >> (seed & 31)) & 1u) continue;
     double reg_angle;
@@ -199,7 +224,7 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
     if (density < a.densityTh) {   // refine(): retry with a tighter angle tolerance, then shrink the radius
       const uint32_t p0 = c.reg[0];
       const double xc = (double)(int)(p0 % (uint32_t)c.spitch), yc = (double)(int)(p0 / (uint32_t)c.spitch);
-      const double ang_c = g_angle(c.G[p0]);
+      const double ang_c = pix_angle(c.G[p0]);
       double sum = 0, s_sum = 0;
       int n = 0;
       for (int base = 0; base < cnt; base += 64) {
@@ -212,14 +237,14 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
           const double px = (double)(int)(p % (uint32_t)c.spitch), py = (double)(int)(p / (uint32_t)c.spitch);
           if (sqrt(dist_sq(xc, yc, px, py)) < rec.width) {
             flag = true;
-            ang_d = angle_diff_signed(g_angle(c.G[p]), ang_c);
+            ang_d = angle_diff_signed(pix_angle(c.G[p]), ang_c);
           }
         }
         unsigned long long m = __ballot(flag);
         while (m) {
           const int l = __ffsll((long long)m) - 1;
           m &= m - 1;
-          const double v = __shfl(ang_d, l);
+          const double v = bcast_f64(ang_d, l);
           sum += v;
           s_sum += v * v;
           ++n;
@@ -270,6 +295,7 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
       segs[nseg * 4 + 2] = (float)rec.x2; segs[nseg * 4 + 3] = (float)rec.y2;
     }
     nseg++;
+   }
   }
   if (lane == 0) {
     if (nseg > a.segCap) { atomicOr(a.status, 4); nseg = a.segCap; }

@@ -302,6 +302,7 @@ int plh_descriptor_distance(const uint8_t* a, const uint8_t* b) {
 plh_status plh_hamming_knn2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, int q_cap, const uint8_t* d_t,
                                       const int32_t* d_nt, int t_cap, int pairs, int32_t* d_idx, int32_t* d_dist,
                                       void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   if (!d_q || !d_t || !d_idx || !d_dist || !d_nq || !d_nt || q_cap <= 0 || t_cap <= 0 || pairs <= 0) {
     set_error("plh_hamming_knn2_batch_dev: invalid argument");
     return PLH_ERR_INVALID;
@@ -315,6 +316,7 @@ plh_status plh_hamming_knn2_batch_dev(const uint8_t* d_q, const int32_t* d_nq, i
 
 plh_status plh_hamming_knn2_dev(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, int32_t* d_dist,
                                 void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   if (nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist)) || (nt > 0 && !d_t)) {
     set_error("plh_hamming_knn2_dev: invalid argument");
     return PLH_ERR_INVALID;
@@ -351,6 +353,7 @@ plh_status plh_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, 
 
 plh_status plh_line_bfmatch_batch_dev(const int32_t* d_idx, const int32_t* d_dist, const int32_t* d_nq, const int32_t* d_nt,
                                       int q_cap, int pairs, float th, float nnratio, int32_t* d_matches, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   if (!d_idx || !d_dist || !d_nq || !d_nt || !d_matches || q_cap <= 0 || pairs <= 0) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_line_bfmatch, dim3(pairs), dim3(256), 0, (hipStream_t)stream, d_idx, d_dist, (const int*)d_nq,
                      (const int*)d_nt, q_cap, th, nnratio, d_matches);
@@ -367,6 +370,7 @@ plh_status plh_line_search_double_batch_dev(const uint8_t* d_desc1, const int32_
                                             const int32_t* d_n2, int cap, int pairs, float th, float nnratio,
                                             int32_t* d_matches12, int32_t* d_nmatches, void* d_workspace,
                                             size_t workspace_bytes, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   if (!d_desc1 || !d_desc2 || !d_n1 || !d_n2 || !d_matches12 || !d_nmatches || !d_workspace || cap <= 0 || pairs <= 0 ||
       workspace_bytes < plh_line_search_double_workspace(cap, pairs)) {
     set_error("plh_line_search_double_batch_dev: invalid argument / workspace too small");
@@ -395,6 +399,7 @@ plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const float* 
                                            const float* d_angle2, const int32_t* d_node2, const int32_t* d_n2, int cap,
                                            int pairs, int th_low, float nnratio, int check_ori, int32_t* d_matches21,
                                            int32_t* d_nmatches, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   if (!d_desc1 || !d_angle1 || !d_node1 || !d_valid1 || !d_n1 || !d_desc2 || !d_angle2 || !d_node2 || !d_n2 ||
       !d_matches21 || !d_nmatches || cap <= 0 || cap > 6000 || pairs <= 0) {
     set_error("plh_orb_search_by_bow_batch_dev: invalid argument (cap must be in 1..6000)");

@@ -26,6 +26,16 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+plh_status ensure_runtime() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device visible (the product path has no CPU fallback)");
+    return PLH_ERR_NO_DEVICE;
+  }
+  (void)hipGetLastError();
+  return PLH_OK;
+}
+
 static inline int cv_round_host(float v) { return (int)lrintf(v); }
 static inline int cv_floor_host(float v) { int i = (int)v; return i - (i > v); }
 
@@ -338,6 +348,7 @@ plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batc
     set_error("plh_orb_extract_batch_dev: invalid argument (batch %d, plan max %d)", batch, h ? h->maxBatch : 0);
     return PLH_ERR_INVALID;
   }
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   hipStream_t s = (hipStream_t)stream;
   OrbDeviceArgs a;
   fill_args(h, d_imgs, (long long)frame_stride, batch, &a);

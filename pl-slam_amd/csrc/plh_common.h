@@ -15,6 +15,10 @@ namespace plh {
 
 char* tls_error();
 void set_error(const char* fmt, ...);
+// First thing every C-ABI entry point does: make sure the HIP runtime is initialised in this process
+// (the library may have been dlopen'ed before the caller's own HIP user, e.g. PyTorch) and drop any stale
+// sticky error so that the launch checks below report only our own failures.
+plh_status ensure_runtime();
 
 #define PLH_HIP(call)                                                                         \
   do {                                                                                        \
