@@ -4,17 +4,19 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-A "step" is one pass of the hot path over one batch of synthetic frames that is already resident in HBM.
-Workload (BASELINE.json configs[1]/[2]): 640x480 mono frames, 8-level pyramid, 1000 ORB features
-(TUM1.yaml parameters), batch of `--batch` frames per GPU (weak scaling: every rank processes its own batch;
-frames are independent), followed -- for N > 1 -- by one RCCL all_gather of the fixed-stride
-keypoint/descriptor records, as the north star asks.
+A "step" is one pass of the whole front end over one batch of synthetic frames already resident in HBM
+(pl-slam_amd/pipeline.py): ORB extract + LSD/LBD line extract (with the Frame.cc undistortion remap) + BoW feature
+vectors + ORBmatcher::SearchByBoW and LSDmatcher::SearchDouble between consecutive frames.
+Workload = BASELINE.json configs[2] ("640x480 ORB+LSD+LBD full extract, TUM-style intrinsics, 1000 ORB / 200 lines")
+plus the frame-to-frame match of configs[3]; `--batch` frames per GPU (weak scaling: frames are independent,
+SURVEY.md 8e), and for N > 1 one RCCL all_gather of the fixed-stride keypoint / descriptor / keyline records.
 
-One JSON line on stdout (rank 0): metric/value/unit ... plus
-  "roofline":     dominant kernel, algorithmic bytes per launch / its mean duration measured live with HIP
-                  events on the launch stream, against the 8 TB/s HBM peak
-  "cpu_baseline": the CPU oracle (a from-scratch restatement, kind "port") timed on this box's host cores on a
-                  bounded sample of the same frames.
+One JSON line on stdout (rank 0) with, besides the contract fields,
+  "roofline":     the dominant kernel: algorithmic bytes per launch / its mean duration measured live with HIP events
+                  on the launch stream, against the 8 TB/s HBM peak; "roofline_fast" repeats it for the FAST kernel
+                  the north star sets its 60 % goal on;
+  "cpu_baseline": the CPU oracle (from-scratch restatement, kind "port") timed on this box's host cores on a
+                  bounded sample of the same frames (same stages, all cores, one frame per task).
 """
 import argparse
 import json
@@ -29,10 +31,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _util  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+TUM1_K = [517.306408, 516.469215, 318.643040, 255.313989]        # Examples/Monocular/TUM1.yaml:8-11
+TUM1_D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]    # TUM1.yaml:13-17
 
 
-def level_sizes(P, rows, cols, nlevels):
-    ex_isf = [np.float32(1.0)]
+def level_sizes(rows, cols, nlevels):
     sf = np.float32(1.0)
     out = []
     for l in range(nlevels):
@@ -43,23 +46,53 @@ def level_sizes(P, rows, cols, nlevels):
     return out
 
 
-def cpu_baseline(O, frames, nfeatures, nlevels, budget_s=15.0):
-    """Oracle (port) on all host cores, one frame per task (ctypes releases the GIL)."""
+def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, budget_s=20.0):
+    """The oracle on all host cores: per frame ORB + (remap) + lines + BoW transform + both matchers against the
+    previous frame of the same worker (ctypes releases the GIL, so threads run in parallel)."""
+    import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
     cores = os.cpu_count() or 1
-    handles = [O.OrbOracle(nfeatures, 1.2, nlevels, 20, 7) for _ in range(cores)]
+    L = O.lib()
+    L.plo_bow_transform.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.plo_bow_transform.restype = None
+    rows, cols = frames[0].shape
+    mx = np.zeros((rows, cols), np.float32)
+    my = np.zeros((rows, cols), np.float32)
+    Kf, Df = np.asarray(K, np.float32), np.asarray(D, np.float32)
+    L.plo_undistort_maps(O._p(Kf), O._p(Df), cols, rows, O._p(mx), O._p(my))
 
-    # calibrate on one frame, then size the sample (frames are cycled) to the time budget
+    def one_frame(orb, img, prev):
+        kps, desc = orb.extract(img)
+        und = np.zeros_like(img)
+        L.plo_remap_linear_u8(O._p(img), cols, rows, cols, O._p(mx), O._p(my), O._p(und), cols)
+        kl, ldesc, fn = O.line_extract(und, nlines, 0.0)
+        n = len(desc)
+        nid = np.zeros(max(n, 1), np.int32)
+        word = np.zeros(max(n, 1), np.int32)
+        L.plo_bow_transform(O._p(desc), n, O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id),
+                            O._p(voc.weight), voc.L, 4, O._p(nid), O._p(word))
+        cur = (desc, np.ascontiguousarray(kps["angle"]), nid, ldesc)
+        if prev is not None:
+            pd, pa, pn, pl = prev
+            valid = np.ones(len(pd), np.uint8)
+            m = np.zeros(max(n, 1), np.int32)
+            L.plo_orb_search_by_bow(O._p(pd), O._p(pa), O._p(pn), O._p(valid), len(pd), O._p(desc), O._p(cur[1]), O._p(nid), n,
+                                    50, 0.7, 1, O._p(m))
+            ml = np.zeros(max(len(pl), 1), np.int32)
+            L.plo_line_search_double(O._p(pl), len(pl), O._p(ldesc), len(ldesc), 50.0, 0.7, O._p(ml))
+        return cur
+
+    orbs = [O.OrbOracle(nfeatures, 1.2, nlevels, 20, 7) for _ in range(cores)]
     t0 = time.perf_counter()
-    handles[0].extract(frames[0])
-    per = time.perf_counter() - t0
-    per_thread = int(max(2, min(64, budget_s / max(per, 1e-4))))
-    total = per_thread * cores
+    one_frame(orbs[0], frames[0], one_frame(orbs[0], frames[1 % len(frames)], None))
+    per = (time.perf_counter() - t0) / 2
+    per_thread = int(max(2, min(48, budget_s / max(per, 1e-4))))
     nf = len(frames)
 
     def work(t):
+        prev = None
         for k in range(per_thread):
-            handles[t].extract(frames[(t * per_thread + k) % nf])
+            prev = one_frame(orbs[t], frames[(t * per_thread + k) % nf], prev)
         return per_thread
 
     t0 = time.perf_counter()
@@ -67,20 +100,22 @@ def cpu_baseline(O, frames, nfeatures, nlevels, budget_s=15.0):
         done = sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": round(done / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic 640x480 frame extractions (ORB, oracle/ restatement, g++ -O2 -ffp-contract=off), %d host threads x %d frames" % (done, cores, per_thread)}
+            "sample": "%d synthetic %dx%d frames (ORB + remap + LSD/LBD + BoW + SearchByBoW + SearchDouble), oracle/ restatement "
+                      "(g++ -O2 -ffp-contract=off, no OpenCV SIMD), %d host threads x %d frames" % (done, cols, rows, cores, per_thread)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--nlevels", type=int, default=8)
-    ap.add_argument("--unique", type=int, default=32, help="distinct rasterised frames (rest are cheap variants)")
+    ap.add_argument("--nlines", type=int, default=200)
+    ap.add_argument("--unique", type=int, default=32, help="distinct rasterised frames (the rest are cheap variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,31 +136,31 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     P, S = _util.plslam(), _util.synth()
+    V = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
+    PL = _util._load("plslam_amd_pipeline", os.path.join(ROOT, "pl-slam_amd", "pipeline.py"))
     B, rows, cols = args.batch, args.rows, args.cols
+    tum = (rows, cols) == (480, 640)
+    K, D = (TUM1_K, TUM1_D) if tum else (None, None)     # KITTI: zero distortion -> no remap (Frame.cc:917-921)
     frames = S.make_frames(2 + 100000 * rank, B, rows, cols, unique=args.unique)
     d_imgs = torch.from_numpy(frames).to(dev)
-    ex = P.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7, rows=rows, cols=cols, max_batch=B, device=local_rank)
-    cap = ex.capacity
-    d_kps = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)     # 28-byte records
-    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=S)
+    fe = PL.FrontEndBatch(P, voc, B, rows, cols, args.nfeatures, args.nlevels, args.nlines, 0.0, K, D, device=local_rank)
     if world > 1:
-        g_kps = torch.empty((world * B, cap, 7), dtype=torch.float32, device=dev)
-        g_desc = torch.empty((world * B, cap, 32), dtype=torch.uint8, device=dev)
-        g_n = torch.empty((world * B,), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev)
+        gather = [(t[:B], torch.empty((world * B,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev))
+                  for t in (fe.n, fe.kps, fe.desc, fe.nl, fe.kl, fe.ldesc)]
 
     def step():
-        ex.extract_batch_dev(d_imgs, B, rows * cols, d_kps, d_desc, d_n, stream.cuda_stream)
+        fe.step(d_imgs)
         if world > 1:   # RCCL gather of the fixed-stride records over xGMI
-            dist.all_gather_into_tensor(g_n, d_n)
-            dist.all_gather_into_tensor(g_kps, d_kps)
-            dist.all_gather_into_tensor(g_desc, d_desc)
+            for src, dst in gather:
+                dist.all_gather_into_tensor(dst, src.contiguous())
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    ex.set_profiling(True)
+    fe.orb.set_profiling(True)
+    fe.line.lib.plh_line_set_profiling.argtypes = [C_VOID, C_INT]
+    fe.line.lib.plh_line_set_profiling(fe.line.h, 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -143,58 +178,82 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        names = ["k_pyr_down (7 levels)", "k_fast_cells", "k_octree", "k_orient_brief"]
-        kms = [ex.kernel_ms(k) for k in range(4)]
-        sizes = level_sizes(P, rows, cols, args.nlevels)
+        import ctypes as C
+        names = ["k_pyr_down x7", "k_fast_cells", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
+                 "k_lsd_grow", "k_keylines", "LBD (blur+sobel+k_lbd)"]
+        per_ms = []
+        for k in range(4):
+            ms, n = fe.orb.kernel_ms(k)
+            per_ms.append(ms / max(n, 1))
+        lib = fe.line.lib
+        lib.plh_line_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        for k in range(4):
+            ms, n = C.c_double(0), C.c_int(0)
+            lib.plh_line_kernel_ms(fe.line.h, k, C.byref(ms), C.byref(n))
+            per_ms.append(ms.value / max(n.value, 1))
+        sizes = level_sizes(rows, cols, args.nlevels)
         Ppx = sum(w * h for w, h in sizes)
         WH = rows * cols
-        nkp = float(d_n.float().mean().item())
-        # algorithmic bytes per frame of each kernel group (DESIGN.md "kernels")
-        alg = [(Ppx - sizes[-1][0] * sizes[-1][1]) + (Ppx - WH),       # pyramid: read levels 0..L-2, write levels 1..L-1
-               Ppx,                                                    # FAST: every level read once
-               0,                                                      # quad-tree: latency-bound list work
-               nkp * (43 * 43 + 32 + 28)]                              # orientation + rBRIEF patch gathers
-        per_launch_ms = [ms / max(n, 1) for ms, n in kms]
-        dom = int(np.argmax(per_launch_ms))
-        if alg[dom] == 0:   # report the dominant *streaming* kernel against HBM; the list kernel has no byte roofline
-            dom_stream = int(np.argmax([per_launch_ms[k] if alg[k] > 0 else -1 for k in range(4)]))
-        else:
-            dom_stream = dom
-        ach = alg[dom_stream] * B / (per_launch_ms[dom_stream] * 1e-3) / 1e9 if per_launch_ms[dom_stream] > 0 else 0.0
-        traffic = None
+        res = fe.results()
+        nkp, nln = float(res["n"].mean()), float(res["nl"].mean())
+        sWH = int(np.rint(cols * 0.8)) * int(np.rint(rows * 0.8))
+        # algorithmic bytes per frame of each kernel group (DESIGN.md "kernels and rooflines")
+        alg = [(Ppx - sizes[-1][0] * sizes[-1][1]) + (Ppx - WH),         # pyramid: read levels 0..L-2, write 1..L-1
+               Ppx,                                                      # FAST: every level read once
+               0,                                                        # quad-tree: latency-bound list work
+               nkp * (43 * 43 + 32 + 28),                                # orientation + rBRIEF patch gathers
+               (2 * WH if tum else 0) + 2 * WH + WH + sWH + sWH * (1 + 16) + sWH * (16 + 4),   # remap, blur, resize, records, order
+               3 * sWH * 9,                                              # region growing: ~3 passes over the 0.64WH field
+               0,
+               2 * WH + WH + 4 * WH + nln * 63 * 80 * 4]                 # LBD: blur, Sobel read/write, band gathers
+        dom = int(np.argmax(per_ms))
+
+        def roof(k):
+            ach = alg[k] * B / (per_ms[k] * 1e-3) / 1e9 if per_ms[k] > 0 else 0.0
+            return {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(alg[k] * B),
+                    "ms_per_launch": round(per_ms[k], 4)}
+
+        r_dom = roof(dom)
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("kernel_group") == dom_stream:
-                    traffic = tj["bytes_per_frame"] * B
+                if tj.get("kernel") == names[dom]:
+                    r_dom["traffic"] = int(tj["bytes_per_frame"] * B)
             except Exception:
-                traffic = None
+                pass
         out = {
-            "metric": "frames/s ORB extract (pyramid+FAST+quad-tree+IC-angle+rBRIEF), 640x480 mono",
+            "metric": "frames/s ORB+LSD extract+match, %dx%d mono" % (cols, rows),
             "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%dx%d mono, %d-level pyramid, %d ORB (TUM1.yaml), batch %d frames/GPU resident in HBM"
-                                   % (cols, rows, args.nlevels, args.nfeatures, B),
-                       "stages": "ORB extract", "mean_keypoints_per_frame": round(nkp, 1),
+            "config": {"workload": "%dx%d mono, %d-level pyramid, %d ORB / %d lines (%s parameters), batch %d frames/GPU resident in HBM; "
+                                   "extract + BoW + SearchByBoW + line SearchDouble per consecutive frame pair"
+                                   % (cols, rows, args.nlevels, args.nfeatures, args.nlines, "TUM1.yaml" if tum else "KITTI00-02.yaml", B),
+                       "mean_keypoints_per_frame": round(nkp, 1), "mean_keylines_per_frame": round(nln, 1),
+                       "mean_orb_matches_per_pair": round(float(res["nm_orb"].mean()), 1),
+                       "mean_line_matches_per_pair": round(float(res["nm_line"].mean()), 1),
+                       "vocabulary": "synthetic k=10 L=6 (ORBvoc.bin is not in the mount)",
                        "parallelism": "frames sharded 1 batch/GPU" + (", RCCL all_gather of records" if world > 1 else "")},
-            "kernel_ms_per_launch": {names[k]: round(per_launch_ms[k], 4) for k in range(4)},
-            "roofline": {"bound": "hbm", "kernel": names[dom_stream], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(alg[dom_stream] * B),
-                         "dominant_by_time": names[dom]},
+            "kernel_ms_per_launch": {names[k]: round(per_ms[k], 4) for k in range(8)},
+            "roofline": r_dom, "roofline_fast": roof(1),
         }
         if not args.no_cpu_baseline:
             O = _util.oracle()
             O.build()
-            out["cpu_baseline"] = cpu_baseline(O, frames[:min(B, 256)], args.nfeatures, args.nlevels)
+            out["cpu_baseline"] = cpu_baseline(O, V, frames[:min(B, 64)], voc, args.nfeatures, args.nlevels, args.nlines,
+                                               TUM1_K if tum else [718.856, 718.856, 607.1928, 185.2157],
+                                               TUM1_D if tum else [0, 0, 0, 0, 0])
         print(json.dumps(out), flush=True)
-    ex.close()
+    fe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
+
+import ctypes as _C  # noqa: E402
+C_VOID, C_INT = _C.c_void_p, _C.c_int
 
 if __name__ == "__main__":
     main()

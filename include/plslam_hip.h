@@ -177,6 +177,25 @@ PLH_API plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const
                                                    int check_ori, int32_t* d_matches21, int32_t* d_nmatches,
                                                    void* stream);
 
+/* Same search, angles taken from plh_keypoint records (kp.angle of mvKeysUn / mvKeys, ORBmatcher.cc:268-276). */
+PLH_API plh_status plh_orb_search_by_bow_kp_batch_dev(const uint8_t* d_desc1, const plh_keypoint* d_kps1,
+                                                      const int32_t* d_node1, const uint8_t* d_valid1, const int32_t* d_n1,
+                                                      const uint8_t* d_desc2, const plh_keypoint* d_kps2,
+                                                      const int32_t* d_node2, const int32_t* d_n2, int cap, int pairs,
+                                                      int th_low, float nnratio, int check_ori, int32_t* d_matches21,
+                                                      int32_t* d_nmatches, void* stream);
+
+/* DBoW2 TemplatedVocabulary::transform(feature, word, weight, &nid, levelsup) for every descriptor of a batch
+ * (Frame::ComputeBoW, Frame.cc:906-913 -> Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1255).
+ * The tree is given as flat arrays over node ids (root = 0): 32-byte node descriptors, contiguous children
+ * [child_start, child_start + child_count), word id and weight of the leaves.  L = tree depth, levelsup as in
+ * ComputeBoW (4).  Outputs per descriptor: FeatureVector node id (or -1 for a stopped word / unused row) and word id. */
+PLH_API plh_status plh_bow_transform_batch_dev(const uint8_t* d_desc, const int32_t* d_n, int cap, int batch,
+                                               const uint8_t* d_node_desc, const int32_t* d_child_start,
+                                               const int32_t* d_child_count, const int32_t* d_word_id,
+                                               const float* d_weight, int L, int levelsup, int32_t* d_nid,
+                                               int32_t* d_word, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Line extractor  (replaces ORB_SLAM2::LINEextractor, include/LineExtractor.h:20-62)
  * ------------------------------------------------------------------------------------------- */
@@ -206,6 +225,10 @@ PLH_API plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, i
 PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride,
                                               const uint8_t* d_mask, plh_keyline* d_keylines, uint8_t* d_desc,
                                               double* d_linefn, int32_t* d_n, void* stream);
+/* Per-stage device time (HIP events on the caller's stream): 0 = image prep + level-line field + seed order,
+ * 1 = LSD region growing (k_lsd_grow), 2 = KeyLine selection, 3 = LBD (blur + Sobel + descriptor). */
+PLH_API plh_status plh_line_set_profiling(plh_line* h, int on);
+PLH_API plh_status plh_line_kernel_ms(plh_line* h, int stage, double* total_ms, int* intervals);
 /* parity taps */
 PLH_API plh_status plh_line_read_segments(plh_line* h, int b, float* out_xyxy, int cap, int* n_out);
 

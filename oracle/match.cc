@@ -189,4 +189,33 @@ int plo_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int32
   return nmatches;
 }
 
+// DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup), reference
+// Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1255, over a flat tree (children contiguous).
+// nid = -1 / word = -1 when the word's weight is not > 0 (transform(features,...) skips those, :1158-1163).
+void plo_bow_transform(const uint8_t* desc, int n, const uint8_t* node_desc, const int32_t* child_start,
+                       const int32_t* child_count, const int32_t* word_id, const float* weight, int L, int levelsup,
+                       int32_t* nid_out, int32_t* word_out) {
+  const int nid_level = L - levelsup;
+  for (int i = 0; i < n; i++) {
+    const uint8_t* f = desc + (size_t)i * 32;
+    int nid = nid_level <= 0 ? 0 : -1;
+    int final_id = 0, current_level = 0;
+    do {
+      ++current_level;
+      const int cs = child_start[final_id], cc = child_count[final_id];
+      final_id = cs;
+      double best_d = plo_descriptor_distance(f, node_desc + (size_t)final_id * 32);
+      for (int k = 1; k < cc; k++) {
+        const int id = cs + k;
+        double d = plo_descriptor_distance(f, node_desc + (size_t)id * 32);
+        if (d < best_d) { best_d = d; final_id = id; }
+      }
+      if (current_level == nid_level) nid = final_id;
+    } while (child_count[final_id] > 0);
+    const bool keep = weight[final_id] > 0;
+    nid_out[i] = keep ? nid : -1;
+    word_out[i] = keep ? word_id[final_id] : -1;
+  }
+}
+
 }  // extern "C"

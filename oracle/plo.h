@@ -85,6 +85,10 @@ int  plo_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int3
                            const uint8_t* desc2, const float* angle2, const int32_t* node2, int n2,
                            int th_low, float nnratio, int check_ori, int32_t* matches21);
 
+void plo_bow_transform(const uint8_t* desc, int n, const uint8_t* node_desc, const int32_t* child_start,
+                       const int32_t* child_count, const int32_t* word_id, const float* weight, int L, int levelsup,
+                       int32_t* nid_out, int32_t* word_out);   /* DBoW2 TemplatedVocabulary::transform */
+
 /* ---- Line extractor (reference src/LineExtractor.cpp + contrib LSDDetector / BinaryDescriptor) ---- */
 int  plo_lsd_detect(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap);  /* cv::LineSegmentDetector (STD) */
 int  plo_lsd_stage_taps(const uint8_t* img, int w, int h, size_t step, uint8_t* scaled, double* angles, double* modgrad,

@@ -416,6 +416,24 @@ class ORBmatcher:
         return int(c[0]), m[0, :len(frame["desc"])].copy()
 
 
+def bow_transform(descs, vocab, levelsup=4, device=0, lib=None):
+    """Frame::ComputeBoW's per-feature part: DBoW2 transform of every descriptor set in `descs`
+    (list of [n,32] u8).  Returns (nid[P,cap], word[P,cap]) with -1 for unused rows / stopped words."""
+    L = load(lib)
+    L.plh_bow_transform_batch_dev.argtypes = [_V, _V, _I, _I, _V, _V, _V, _V, _V, _I, _I, _V, _V, _V]
+    L.plh_bow_transform_batch_dev.restype = _I
+    D = _Dev(L, device)
+    P = len(descs)
+    cap = max(1, max(len(d) for d in descs))
+    a, n = _pad_sets(descs, cap, 32, np.uint8)
+    da, dn = D.put(a), D.put(n)
+    nd, cs, cc, wi, wt = vocab.device_arrays(D)
+    dnid, dword = D.empty((P, cap), np.int32), D.empty((P, cap), np.int32)
+    _check(L, L.plh_bow_transform_batch_dev(_p(da), _p(dn), cap, P, _p(nd), _p(cs), _p(cc), _p(wi), _p(wt), vocab.L, levelsup,
+                                            _p(dnid), _p(dword), C.c_void_p(D.stream())), "plh_bow_transform_batch_dev")
+    return D.get(dnid), D.get(dword)
+
+
 class LINEextractor:
     """ORB_SLAM2::LINEextractor(numOctaves, scale, nLSDFeature, min_line_length) on the GPU
     (reference include/LineExtractor.h:20-62).  `__call__(image, mask)` is operator()

@@ -44,7 +44,26 @@ struct plh_line {
   int* dN = nullptr;
   hipStream_t stream = nullptr;
   bool hasUndistort = false;
+  // optional per-stage timing with HIP events on the caller's stream (bench.py roofline leg)
+  bool profiling = false;
+  std::vector<hipEvent_t> evPool;
+  std::vector<int> evKind;
+  size_t evUsed = 0;
+  double kernelMs[4] = {0, 0, 0, 0};
+  int kernelLaunches[4] = {0, 0, 0, 0};
 };
+
+static void line_prof_mark(plh_line* h, int kind, hipStream_t s) {
+  if (!h->profiling) return;
+  if (h->evUsed == h->evPool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    h->evPool.push_back(e);
+    h->evKind.push_back(kind);
+  }
+  h->evKind[h->evUsed] = kind;
+  (void)hipEventRecord(h->evPool[h->evUsed++], s);
+}
 
 namespace {
 
@@ -108,6 +127,7 @@ plh_status plh_line_destroy(plh_line* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
   delete h;
   return PLH_OK;
 }
@@ -256,6 +276,7 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
     src = h->dUndist; srcStride = a.fullStride;
   }
   // LSD: 7x7 sigma 0.75 blur -> 0.8x resize -> level-line field -> seed order -> region growing
+  line_prof_mark(h, 0, s);
   launch_blur7(src, srcStride, a.w, h->dTmpA, a.fullStride, a.w, a.w, a.h, batch, h->taps075, s);
   PLH_LAUNCH_CHECK();
   launch_resize(h->dTmpA, a.fullStride, a.w, a.h, h->dScaled, a.scaledStride, a.spitch, a.sw, a.sh, batch, h->dXtab, h->dYtab, s);
@@ -265,10 +286,16 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   PLH_LAUNCH_CHECK();
   launch_lsd_order(a, s);
   PLH_LAUNCH_CHECK();
+  line_prof_mark(h, 0, s);
+  line_prof_mark(h, 1, s);
   launch_lsd_grow(a, s);
   PLH_LAUNCH_CHECK();
+  line_prof_mark(h, 1, s);
+  line_prof_mark(h, 2, s);
   launch_keylines(a, d_keylines, d_linefn, d_n, s);
   PLH_LAUNCH_CHECK();
+  line_prof_mark(h, 2, s);
+  line_prof_mark(h, 3, s);
   // LBD: 5x5 sigma 1 blur -> Sobel -> band descriptor
   launch_blur7(src, srcStride, a.w, h->dTmpA, a.fullStride, a.w, a.w, a.h, batch, h->taps1, s);
   PLH_LAUNCH_CHECK();
@@ -276,6 +303,7 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   PLH_LAUNCH_CHECK();
   launch_lbd(a, d_keylines, d_n, h->dCoef, d_desc, s);
   PLH_LAUNCH_CHECK();
+  line_prof_mark(h, 3, s);
   return PLH_OK;
 }
 
@@ -326,6 +354,29 @@ plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, int cols,
     set_error("line kernels reported a capacity overflow (flags 0x%x)", stf);
     return PLH_ERR_CAPACITY;
   }
+  return PLH_OK;
+}
+
+plh_status plh_line_set_profiling(plh_line* h, int on) {
+  if (!h) return PLH_ERR_INVALID;
+  h->profiling = on != 0;
+  h->evUsed = 0;
+  for (int k = 0; k < 4; k++) { h->kernelMs[k] = 0; h->kernelLaunches[k] = 0; }
+  return PLH_OK;
+}
+
+plh_status plh_line_kernel_ms(plh_line* h, int stage, double* total_ms, int* intervals) {
+  if (!h || stage < 0 || stage > 3 || !total_ms || !intervals) return PLH_ERR_INVALID;
+  for (size_t i = 0; i + 1 < h->evUsed; i += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->evPool[i], h->evPool[i + 1]) == hipSuccess) {
+      h->kernelMs[h->evKind[i]] += ms;
+      h->kernelLaunches[h->evKind[i]]++;
+    }
+  }
+  h->evUsed = 0;
+  *total_ms = h->kernelMs[stage];
+  *intervals = h->kernelLaunches[stage];
   return PLH_OK;
 }
 

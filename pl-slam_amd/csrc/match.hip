@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) k_line_mutual(const int32_t* m1, const in
 __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1,
                                                        const uint8_t* valid1, const int* n1Arr, const uint8_t* desc2,
                                                        const float* angle2, const int32_t* node2, const int* n2Arr, int cap,
-                                                       int thLow, float nnratio, int checkOri, int32_t* matches21,
+                                                       int angStride, int thLow, float nnratio, int checkOri, int32_t* matches21,
                                                        int32_t* nmatchesOut) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   int* nd1 = (int*)smem;                 // node id per feature
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
       const int bestF = ord2[bestPos];
       int bin = 255;
       if (checkOri) {
-        float rot = angle1[o + i] - angle2[o + bestF];
+        float rot = angle1[(o + i) * angStride] - angle2[(o + bestF) * angStride];
         if (rot < 0.0f) rot += 360.0f;
         bin = (int)roundf(rot * factor);
         if (bin == 30) bin = 0;
@@ -406,8 +406,29 @@ plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const float* 
     return PLH_ERR_INVALID;
   }
   hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1, d_angle1,
-                     d_node1, d_valid1, (const int*)d_n1, d_desc2, d_angle2, d_node2, (const int*)d_n2, cap, th_low, nnratio,
+                     d_node1, d_valid1, (const int*)d_n1, d_desc2, d_angle2, d_node2, (const int*)d_n2, cap, 1, th_low, nnratio,
                      check_ori, d_matches21, d_nmatches);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+// Same search with the angles read from plh_keypoint records (kp.angle, as the reference does from mvKeysUn / mvKeys).
+plh_status plh_orb_search_by_bow_kp_batch_dev(const uint8_t* d_desc1, const plh_keypoint* d_kps1, const int32_t* d_node1,
+                                              const uint8_t* d_valid1, const int32_t* d_n1, const uint8_t* d_desc2,
+                                              const plh_keypoint* d_kps2, const int32_t* d_node2, const int32_t* d_n2, int cap,
+                                              int pairs, int th_low, float nnratio, int check_ori, int32_t* d_matches21,
+                                              int32_t* d_nmatches, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_desc1 || !d_kps1 || !d_node1 || !d_valid1 || !d_n1 || !d_desc2 || !d_kps2 || !d_node2 || !d_n2 || !d_matches21 ||
+      !d_nmatches || cap <= 0 || cap > 6000 || pairs <= 0) {
+    set_error("plh_orb_search_by_bow_kp_batch_dev: invalid argument (cap must be in 1..6000)");
+    return PLH_ERR_INVALID;
+  }
+  static_assert(sizeof(plh_keypoint) == 28, "plh_keypoint layout");
+  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
+                     reinterpret_cast<const float*>(d_kps1) + 3, d_node1, d_valid1, (const int*)d_n1, d_desc2,
+                     reinterpret_cast<const float*>(d_kps2) + 3, d_node2, (const int*)d_n2, cap, 7, th_low, nnratio, check_ori,
+                     d_matches21, d_nmatches);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
 }

@@ -1,0 +1,95 @@
+"""Batch front end on one GPU: ORB extract + line extract + frame-to-frame matching, all on device buffers.
+
+This is the hot path bench.py times and the end-to-end GPU test checks.  One `step()` processes a batch of B
+independent frames that are already resident in HBM:
+
+    ORBextractor::operator()            per frame                      (plh_orb_extract_batch_dev)
+    LINEextractor::operator()           per frame, optional undistort  (plh_line_extract_batch_dev)
+    Frame::ComputeBoW (feature vector)  per frame                      (plh_bow_transform_batch_dev)
+    ORBmatcher(0.7).SearchByBoW         frame b (as KeyFrame) -> frame b+1   (plh_orb_search_by_bow_kp_batch_dev)
+    LSDmatcher(0.7).SearchDouble        frame b -> frame b+1                 (plh_line_search_double_batch_dev)
+
+Frame B's successor is frame 0 (its records are copied into slot B), so every frame is matched once.
+PyTorch only provides device memory and the stream; every computation is a kernel of libplslam_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+class FrontEndBatch:
+    def __init__(self, P, vocab, batch, rows=480, cols=640, nfeatures=1000, nlevels=8, n_lines=200, min_line_length=0.0,
+                 K=None, D=None, device=0):
+        import torch
+        self.torch, self.P = torch, P
+        self.B, self.rows, self.cols = batch, rows, cols
+        self.dev = torch.device("cuda", device)
+        self.lib = P.load()
+        self.orb = P.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, rows=rows, cols=cols, max_batch=batch, device=device)
+        self.line = P.LINEextractor(1, 1.2, n_lines, min_line_length, rows=rows, cols=cols, max_batch=batch, device=device, K=K, D=D)
+        self.vocab = vocab
+        B1 = batch + 1
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)
+        self.ocap, self.lcap = self.orb.capacity, self.line.capacity
+        self.kps = z((B1, self.ocap, 7), torch.float32)
+        self.desc = z((B1, self.ocap, 32), torch.uint8)
+        self.n = z((B1,), torch.int32)
+        self.nid = z((B1, self.ocap), torch.int32)
+        self.word = z((B1, self.ocap), torch.int32)
+        self.valid = torch.ones((batch, self.ocap), dtype=torch.uint8, device=self.dev)
+        self.m_orb = z((batch, self.ocap), torch.int32)
+        self.nm_orb = z((batch,), torch.int32)
+        self.kl = z((B1, self.lcap, 17), torch.float32)
+        self.ldesc = z((B1, self.lcap, 32), torch.uint8)
+        self.lfn = z((B1, self.lcap, 3), torch.float64)
+        self.nl = z((B1,), torch.int32)
+        self.m_line = z((batch, self.lcap), torch.int32)
+        self.nm_line = z((batch,), torch.int32)
+        self.ws_bytes = self.lib.plh_line_search_double_workspace(self.lcap, batch)
+        self.ws = z((self.ws_bytes,), torch.uint8)
+        helper = P._Dev(self.lib, device)
+        self.voc_dev = vocab.device_arrays(helper)
+        L = self.lib
+        V, I, F, Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        L.plh_bow_transform_batch_dev.argtypes = [V, V, I, I, V, V, V, V, V, I, I, V, V, V]
+        L.plh_bow_transform_batch_dev.restype = I
+        L.plh_orb_search_by_bow_kp_batch_dev.argtypes = [V] * 9 + [I, I, I, F, I, V, V, V]
+        L.plh_orb_search_by_bow_kp_batch_dev.restype = I
+
+    def close(self):
+        self.orb.close()
+        self.line.close()
+
+    def step(self, d_imgs, stream=None):
+        """Enqueue one pass over the resident batch `d_imgs` (uint8 [B, rows, cols]) on the current stream."""
+        P, L, B, t = self.P, self.lib, self.B, self.torch
+        s = t.cuda.current_stream(self.dev).cuda_stream if stream is None else stream
+        sp = C.c_void_p(s)
+        p = P._p
+        self.orb.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kps, self.desc, self.n, s)
+        self.line.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kl, self.ldesc, self.lfn, self.nl, s)
+        # slot B := frame 0 (so that frame B-1 has a successor)
+        for buf in (self.kps, self.desc, self.n, self.kl, self.ldesc, self.nl):
+            buf[B].copy_(buf[0], non_blocking=True)
+        nd, cs, cc, wi, wt = self.voc_dev
+        P._check(L, L.plh_bow_transform_batch_dev(p(self.desc), p(self.n), self.ocap, B + 1, p(nd), p(cs), p(cc), p(wi), p(wt),
+                                                  self.vocab.L, 4, p(self.nid), p(self.word), sp), "plh_bow_transform_batch_dev")
+        P._check(L, L.plh_orb_search_by_bow_kp_batch_dev(p(self.desc), p(self.kps), p(self.nid), p(self.valid), p(self.n),
+                                                         p(self.desc[1:]), p(self.kps[1:]), p(self.nid[1:]), p(self.n[1:]),
+                                                         self.ocap, B, 50, 0.7, 1, p(self.m_orb), p(self.nm_orb), sp),
+                 "plh_orb_search_by_bow_kp_batch_dev")
+        P._check(L, L.plh_line_search_double_batch_dev(p(self.ldesc), p(self.nl), p(self.ldesc[1:]), p(self.nl[1:]), self.lcap, B,
+                                                       50.0, 0.7, p(self.m_line), p(self.nm_line), p(self.ws), self.ws_bytes, sp),
+                 "plh_line_search_double_batch_dev")
+
+    def results(self):
+        """Host copies of everything one step produced (synchronises)."""
+        t, P = self.torch, self.P
+        t.cuda.synchronize(self.dev)
+        B = self.B
+        kps = self.kps[:B].cpu().numpy().view(np.uint8).reshape(B, self.ocap, 28).copy().view(P.KP_DTYPE).reshape(B, self.ocap)
+        kl = self.kl[:B].cpu().numpy().view(np.uint8).reshape(B, self.lcap, 68).copy().view(P.KL_DTYPE).reshape(B, self.lcap)
+        return dict(n=self.n[:B].cpu().numpy(), kps=kps, desc=self.desc[:B].cpu().numpy(), nid=self.nid[:B].cpu().numpy(),
+                    nl=self.nl[:B].cpu().numpy(), kl=kl, ldesc=self.ldesc[:B].cpu().numpy(), lfn=self.lfn[:B].cpu().numpy(),
+                    m_orb=self.m_orb.cpu().numpy(), nm_orb=self.nm_orb.cpu().numpy(), m_line=self.m_line.cpu().numpy(),
+                    nm_line=self.nm_line.cpu().numpy())

@@ -1,0 +1,61 @@
+"""GPU end-to-end: the batch front end bench.py times (pl-slam_amd/pipeline.py) vs the oracle, stage by stage."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import _util
+from test_line import TUM1_D, TUM1_K, _close, _exact, _oracle_line
+
+pytestmark = pytest.mark.gpu
+
+
+def test_front_end_batch_vs_oracle(plslam, oracle, synth):
+    import torch
+    V = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    PL = _util._load("plslam_amd_pipeline", os.path.join(_util.ROOT, "pl-slam_amd", "pipeline.py"))
+    B = 6
+    frames = synth.make_frames(500, B, 480, 640)
+    voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=synth)
+    fe = PL.FrontEndBatch(plslam, voc, B, 480, 640, 1000, 8, 200, 0.0, TUM1_K, TUM1_D)
+    d = torch.from_numpy(frames).cuda()
+    fe.step(d)
+    fe.step(d)          # second pass over the same buffers: results must not depend on stale state
+    r = fe.results()
+    fe.close()
+    O = oracle
+    L = O.lib()
+    L.plo_bow_transform.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.plo_bow_transform.restype = None
+    orb = O.OrbOracle(1000, 1.2, 8, 20, 7)
+    ref = []
+    for b in range(B):
+        rk, rd = orb.extract(frames[b])
+        n = r["n"][b]
+        assert n == len(rk)
+        for f in rk.dtype.names:
+            assert (r["kps"][b, :n][f] == rk[f]).all(), (b, f)
+        assert (r["desc"][b, :n] == rd).all()
+        nid = np.zeros(n, np.int32)
+        word = np.zeros(n, np.int32)
+        L.plo_bow_transform(O._p(rd), n, O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id),
+                            O._p(voc.weight), voc.L, 4, O._p(nid), O._p(word))
+        assert (r["nid"][b, :n] == nid).all()
+        lk, ld, lf, _ = _oracle_line(O, frames[b], 200, 0.0, TUM1_K, TUM1_D)
+        nl = r["nl"][b]
+        if not _exact(r["kl"][b, :nl], r["ldesc"][b, :nl], r["lfn"][b, :nl], lk, ld, lf):
+            _close(r["kl"][b, :nl], r["ldesc"][b, :nl], r["lfn"][b, :nl], lk, ld, lf, "frame %d" % b)
+        ref.append((rk, rd, nid, ld))
+    for b in range(B):       # frame b (KeyFrame) -> frame (b+1) % B
+        k1, d1, n1, l1 = ref[b]
+        k2, d2, n2, l2 = ref[(b + 1) % B]
+        m = np.zeros(len(d2), np.int32)
+        valid = np.ones(len(d1), np.uint8)
+        a1, a2 = np.ascontiguousarray(k1["angle"]), np.ascontiguousarray(k2["angle"])
+        c = L.plo_orb_search_by_bow(O._p(d1), O._p(a1), O._p(n1), O._p(valid), len(d1), O._p(d2), O._p(a2), O._p(n2), len(d2),
+                                    50, 0.7, 1, O._p(m))
+        assert r["nm_orb"][b] == c and (r["m_orb"][b, :len(d2)] == m).all(), b
+        ml = np.zeros(len(l1), np.int32)
+        cl = L.plo_line_search_double(O._p(l1), len(l1), O._p(l2), len(l2), 50.0, 0.7, O._p(ml))
+        assert r["nm_line"][b] == cl and (r["m_line"][b, :len(l1)] == ml).all(), b
