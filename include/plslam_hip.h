@@ -177,6 +177,18 @@ PLH_API plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const
                                                    int check_ori, int32_t* d_matches21, int32_t* d_nmatches,
                                                    void* stream);
 
+/* Host-buffer forms of the two matchers (one call = one reference call; they stage over PCIe and block):
+ *   plh_line_search_double : LSDmatcher::SearchDouble(Frame&, Frame&, vector<int>&) on two mLdesc matrices
+ *                            (LSDmatcher.cpp:427-460); matches12[n1] = row of ldesc2 or -1; th = TH_LOW (50).
+ *   plh_orb_search_by_bow  : ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:187-327) on flat arrays;
+ *                            matches21[n2] = KeyFrame feature whose MapPoint goes to Frame feature j, or -1. */
+PLH_API plh_status plh_line_search_double(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, float th,
+                                          float nnratio, int32_t* matches12, int* nmatches, int device);
+PLH_API plh_status plh_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1,
+                                         const uint8_t* valid1, int n1, const uint8_t* desc2, const float* angle2,
+                                         const int32_t* node2, int n2, int th_low, float nnratio, int check_ori,
+                                         int32_t* matches21, int* nmatches, int device);
+
 /* Same search, angles taken from plh_keypoint records (kp.angle of mvKeysUn / mvKeys, ORBmatcher.cc:268-276). */
 PLH_API plh_status plh_orb_search_by_bow_kp_batch_dev(const uint8_t* d_desc1, const plh_keypoint* d_kps1,
                                                       const int32_t* d_node1, const uint8_t* d_valid1, const int32_t* d_n1,

@@ -433,4 +433,78 @@ plh_status plh_orb_search_by_bow_kp_batch_dev(const uint8_t* d_desc1, const plh_
   return PLH_OK;
 }
 
+// ---- host-buffer conveniences (one call = one reference call; stage over PCIe, block until done) ----
+extern "C++" {
+namespace {
+struct DevBuf {   // RAII device allocation
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+  template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+}  // namespace
+}  // extern "C++"
+
+// LSDmatcher::SearchDouble(Frame&, Frame&, vector<int>&) on two mLdesc matrices (LSDmatcher.cpp:427-460).
+plh_status plh_line_search_double(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, float th, float nnratio,
+                                  int32_t* matches12, int* nmatches, int device) {
+  if (n1 < 0 || n2 < 0 || !nmatches || (n1 > 0 && (!ldesc1 || !matches12)) || (n2 > 0 && !ldesc2)) return PLH_ERR_INVALID;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  *nmatches = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;   // reference: `if(ldesc1.rows == 0 || ldesc2.rows == 0) return 0;`
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  const int cap = std::max(n1, n2);
+  DevBuf d1, d2, dn, dm, dc, ws;
+  const size_t wsb = plh_line_search_double_workspace(cap, 1);
+  PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(dn.alloc(8));
+  PLH_HIP(dm.alloc((size_t)cap * 4)); PLH_HIP(dc.alloc(4)); PLH_HIP(ws.alloc(wsb));
+  const int32_t ns[2] = {n1, n2};
+  PLH_HIP(hipMemcpy(d1.p, ldesc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(d2.p, ldesc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
+  plh_status st = plh_line_search_double_batch_dev(d1.as<uint8_t>(), dn.as<int32_t>(), d2.as<uint8_t>(), dn.as<int32_t>() + 1, cap, 1,
+                                                   th, nnratio, dm.as<int32_t>(), dc.as<int32_t>(), ws.p, wsb, nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(matches12, dm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nmatches, dc.p, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) on flat host arrays (see plh_orb_search_by_bow_batch_dev).
+plh_status plh_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
+                                 const uint8_t* desc2, const float* angle2, const int32_t* node2, int n2, int th_low,
+                                 float nnratio, int check_ori, int32_t* matches21, int* nmatches, int device) {
+  if (n1 < 0 || n2 < 0 || !nmatches || (n2 > 0 && !matches21)) return PLH_ERR_INVALID;
+  for (int j = 0; j < n2; j++) matches21[j] = -1;
+  *nmatches = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (!desc1 || !angle1 || !node1 || !valid1 || !desc2 || !angle2 || !node2) return PLH_ERR_INVALID;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  const int cap = std::max(n1, n2);
+  DevBuf d1, a1, k1, v1, d2, a2, k2, dn, dm, dc;
+  PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(a1.alloc((size_t)cap * 4)); PLH_HIP(k1.alloc((size_t)cap * 4)); PLH_HIP(v1.alloc(cap));
+  PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(a2.alloc((size_t)cap * 4)); PLH_HIP(k2.alloc((size_t)cap * 4));
+  PLH_HIP(dn.alloc(8)); PLH_HIP(dm.alloc((size_t)cap * 4)); PLH_HIP(dc.alloc(4));
+  const int32_t ns[2] = {n1, n2};
+  PLH_HIP(hipMemcpy(d1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(a1.p, angle1, (size_t)n1 * 4, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(k1.p, node1, (size_t)n1 * 4, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(v1.p, valid1, (size_t)n1, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(d2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(a2.p, angle2, (size_t)n2 * 4, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(k2.p, node2, (size_t)n2 * 4, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
+  plh_status st = plh_orb_search_by_bow_batch_dev(d1.as<uint8_t>(), a1.as<float>(), k1.as<int32_t>(), v1.as<uint8_t>(), dn.as<int32_t>(),
+                                                  d2.as<uint8_t>(), a2.as<float>(), k2.as<int32_t>(), dn.as<int32_t>() + 1, cap, 1, th_low,
+                                                  nnratio, check_ori, dm.as<int32_t>(), dc.as<int32_t>(), nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(matches21, dm.p, (size_t)n2 * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nmatches, dc.p, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
 }  // extern "C"

@@ -84,10 +84,13 @@ def make_frames(seed0, count, rows=480, cols=640, unique=None):
     distinct variants (cyclic shift of rows + small brightness offset) so no two frames are equal."""
     unique = count if unique is None else max(1, min(unique, count))
     base = [make_frame(seed0 + i, rows, cols) for i in range(unique)]
+    reps = -(-count // unique)
     out = np.empty((count, rows, cols), dtype=np.uint8)
     for i in range(count):
-        b = base[i % unique]
-        k = i // unique
+        # consecutive indices are consecutive "camera poses" of the same scene (3-row shift + exposure change),
+        # so frame-to-frame matching has real correspondences
+        b = base[i // reps]
+        k = i % reps
         if k == 0:
             out[i] = b
         else:
