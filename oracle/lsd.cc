@@ -48,6 +48,9 @@ inline double angle_diff_signed(double a, double b) {
 }
 inline double angle_diff(double a, double b) { return std::fabs(angle_diff_signed(a, b)); }
 
+// counters for tools/ (how much sequential work a frame carries); not part of any result
+static thread_local long g_stats[8];
+
 struct Lsd {
   int w = 0, h = 0;
   std::vector<uint8_t> img;
@@ -112,6 +115,7 @@ struct Lsd {
 
   void region_grow(int sx, int sy, std::vector<RegionPoint>& reg, double& reg_angle, double prec) {
     reg.clear();
+    g_stats[0]++;
     RegionPoint seed;
     seed.x = sx; seed.y = sy;
     reg_angle = angles[(size_t)sy * w + sx];
@@ -142,6 +146,7 @@ struct Lsd {
           }
         }
     }
+    g_stats[1] += (long)reg.size();
   }
 
   double get_theta(const std::vector<RegionPoint>& reg, double x, double y, double reg_angle, double prec) const {
@@ -162,6 +167,7 @@ struct Lsd {
   }
 
   void region2rect(const std::vector<RegionPoint>& reg, double reg_angle, double prec, double p, Rect& rec) const {
+    g_stats[2]++; g_stats[3] += (long)reg.size();
     double x = 0, y = 0, sum = 0;
     for (size_t i = 0; i < reg.size(); ++i) {
       const double weight = reg[i].modgrad;
@@ -194,6 +200,7 @@ struct Lsd {
     double radSq1 = distSq(xc, yc, rec.x1, rec.y1), radSq2 = distSq(xc, yc, rec.x2, rec.y2);
     double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
     while (density < density_th) {
+      g_stats[5]++; g_stats[6] += (long)reg.size();
       radSq *= 0.75 * 0.75;
       for (size_t i = 0; i < reg.size(); ++i) {
         if (distSq(xc, yc, double(reg[i].x), double(reg[i].y)) > radSq) {
@@ -213,6 +220,7 @@ struct Lsd {
   bool refine(std::vector<RegionPoint>& reg, double reg_angle, double prec, double p, Rect& rec, double density_th) {
     double density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     if (density >= density_th) return true;
+    g_stats[4]++;
     double xc = double(reg[0].x), yc = double(reg[0].y);
     const double ang_c = reg[0].angle;
     double sum = 0, s_sum = 0;
@@ -283,6 +291,10 @@ struct Lsd {
 }  // namespace
 
 extern "C" {
+
+void plo_lsd_stats(long* out8, int reset) {
+  for (int i = 0; i < 8; i++) { out8[i] = g_stats[i]; if (reset) g_stats[i] = 0; }
+}
 
 int plo_lsd_detect(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap) {
   if (w < 8 || h < 8) return 0;

@@ -32,7 +32,8 @@ struct plh_line {
   // device buffers
   uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dUsed = nullptr, *dMask = nullptr;
   uint8_t* dPix = nullptr;
-  uint32_t *dOrdered = nullptr, *dReg = nullptr, *dDxdy = nullptr;
+  uint32_t *dOrdered = nullptr, *dReg = nullptr, *dScr = nullptr, *dDxdy = nullptr;
+  float* dSeedCs = nullptr;
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
   float *dSegs = nullptr, *dMap = nullptr, *dCoef = nullptr;
@@ -121,7 +122,7 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dUsed, h->dMask, h->dPix, h->dOrdered, h->dReg, h->dDxdy, h->dQmax,
+  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dUsed, h->dMask, h->dPix, h->dOrdered, h->dReg, h->dScr, h->dSeedCs, h->dDxdy, h->dQmax,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dSegs, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -201,6 +202,8 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   TRYHIP(hipMalloc((void**)&h->dPix, B * a.scaledStride * 16));
   TRYHIP(hipMalloc((void**)&h->dOrdered, B * a.scaledStride * 4));
   TRYHIP(hipMalloc((void**)&h->dReg, B * a.scaledStride * 4));
+  TRYHIP(hipMalloc((void**)&h->dScr, B * a.scaledStride * 4));
+  TRYHIP(hipMalloc((void**)&h->dSeedCs, B * a.scaledStride * 8));
   TRYHIP(hipMalloc((void**)&h->dDxdy, B * a.fullStride * 4));
   TRYHIP(hipMalloc((void**)&h->dSegs, B * a.segCap * 16));
   TRYHIP(hipMalloc((void**)&h->dQmax, B * 4));
@@ -216,7 +219,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   TRYHIP(hipMemcpy(h->dCoef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 #undef TRYHIP
-  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.used = nullptr; a.ordered = h->dOrdered; a.reg = h->dReg;
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.used = nullptr; a.ordered = h->dOrdered; a.reg = h->dReg; a.scr = h->dScr; a.seedcs = h->dSeedCs;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = h->dSegs; a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
   *out = h;

@@ -111,6 +111,8 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
     const uint8_t* I = a.scaled + (long long)b * a.scaledStride;
     LsdPix px;
     px.angf = -1024.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
+    float2 seed;
+    seed.x = 0.f; seed.y = 0.f;
     if (x < a.sw - 1 && y < a.sh - 1) {
       const int p00 = I[(long long)y * a.spitch + x], p01 = I[(long long)y * a.spitch + x + 1];
       const int p10 = I[(long long)(y + 1) * a.spitch + x], p11 = I[(long long)(y + 1) * a.spitch + x + 1];
@@ -122,10 +124,14 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
         const float af = (float)((double)px.angf * kDegToRads);
         px.cs = (float)cos((double)af);
         px.sn = (float)sin((double)af);
+        const double ad = (double)px.angf * kDegToRads;   // seed terms: float(cos(reg_angle)), float(sin(reg_angle))
+        seed.x = (float)cos(ad);
+        seed.y = (float)sin(ad);
         atomicMax(&s_max, px.q);
       }
     }
     reinterpret_cast<LsdPix*>(a.pix)[(long long)b * a.scaledStride + (long long)y * a.spitch + x] = px;
+    reinterpret_cast<float2*>(a.seedcs)[(long long)b * a.scaledStride + (long long)y * a.spitch + x] = seed;
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);

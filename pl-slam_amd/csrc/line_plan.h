@@ -32,6 +32,8 @@ struct LineDeviceArgs {
   uint8_t* used;            // region-growing marks, pitch spitch
   uint32_t* ordered;        // seed list (pixel index y*spitch+x), bins descending / raster inside a bin
   uint32_t* reg;            // region point queue
+  uint32_t* scr;            // scratch of the same size
+  void* seedcs;             // float2 per scaled pixel: (float)cos, (float)sin of the pixel's double angle
   unsigned int* qmax;       // per frame max(gx^2+gy^2) over defined pixels
   int* nOrdered;            // per frame
   float* segs;              // [frame][segCap][4]

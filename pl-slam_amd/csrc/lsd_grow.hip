@@ -10,7 +10,9 @@ struct LsdRect {
 
 struct GrowCtx {
   const LsdPix* G;     // level-line records of the scaled image
-  uint32_t* reg;       // region queue (global memory)
+  const float2* S;     // per pixel (float)cos / (float)sin of the double angle: region_grow()'s seed terms
+  uint32_t* reg;       // region queue (global memory); entries are packed coordinates x | y << 16
+  uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
   uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
   uint32_t* bm;        // LDS `used` bitmap
   int spitch, sw, sh, lane;
@@ -18,6 +20,10 @@ struct GrowCtx {
 };
 constexpr int LSD_RING = 1024;
 constexpr int LSD_GROUPS = 7;   // queue points examined per step (7 x 9 neighbour lanes = 63 lanes)
+
+__device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xffffu); }
+__device__ __forceinline__ int pk_y(uint32_t p) { return (int)(p >> 16); }
+__device__ __forceinline__ uint32_t pk_lin(const GrowCtx& c, uint32_t p) { return (uint32_t)(pk_y(p) * c.spitch + pk_x(p)); }
 
 __device__ __forceinline__ uint32_t reg_get(const GrowCtx& c, int i, int cnt) {
   return (cnt - i <= LSD_RING) ? c.ring[i & (LSD_RING - 1)] : c.reg[i];
@@ -43,11 +49,13 @@ __device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return (unsig
 __device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, double* regAngleOut) {
   const int lane = c.lane;
   double reg_angle = pix_angle(c.G[seed]);
-  float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+  const float2 sc = c.S[seed];
+  float sumdx = sc.x, sumdy = sc.y;   // float(cos(reg_angle)), float(sin(reg_angle)), precomputed by k_lsd_grad
+  const uint32_t seedPk = (uint32_t)(seed % (uint32_t)c.spitch) | ((uint32_t)(seed / (uint32_t)c.spitch) << 16);
   PLH_WAVE_SYNC();   // every lane has finished reading the seed's `used` bit before it is set
   if (lane == 0) {
-    c.reg[0] = seed;
-    c.ring[0] = seed;
+    c.reg[0] = seedPk;
+    c.ring[0] = seedPk;
     atomicOr(&c.bm[seed >> 5], 1u << (seed & 31));
   }
   int cnt = 1;
@@ -58,18 +66,18 @@ __device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, dou
     PLH_WAVE_SYNC();
     const int m = min(LSD_GROUPS, cnt - i);
     bool cand = false;
-    uint32_t nidx = 0;
+    uint32_t nidx = 0, npk = 0;
     LsdPix px;
     px.angf = 0.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
     if (grp < m) {
       const uint32_t p = reg_get(c, i + grp, cnt);
-      const int xx = (int)(p % (uint32_t)c.spitch) + dx, yy = (int)(p / (uint32_t)c.spitch) + dy;
+      const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
       if (xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
         nidx = (uint32_t)(yy * c.spitch + xx);
-        if (!((c.bm[nidx >> 5] >> (nidx & 31)) & 1u)) {
-          px = c.G[nidx];
-          cand = px.q > c.qThresh;   // angle != NOTDEF
-        }
+        npk = (uint32_t)xx | ((uint32_t)yy << 16);
+        px = c.G[nidx];                                                  // issued together with the LDS bitmap read
+        const bool isUsed = (c.bm[nidx >> 5] >> (nidx & 31)) & 1u;
+        cand = !isUsed && px.q > c.qThresh;                              // angle != NOTDEF
       }
     }
     unsigned long long cm = __ballot(cand);
@@ -87,8 +95,8 @@ __device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, dou
         const uint32_t nk = bcast_u32(nidx, k);
         if (lane == k) {
           atomicOr(&c.bm[nidx >> 5], 1u << (nidx & 31));
-          c.reg[cnt] = nidx;
-          c.ring[cnt & (LSD_RING - 1)] = nidx;
+          c.reg[cnt] = npk;
+          c.ring[cnt & (LSD_RING - 1)] = npk;
         }
         sumdx += bcast_f32(px.cs, k);
         sumdy += bcast_f32(px.sn, k);
@@ -120,9 +128,9 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     double w = 0, wx = 0, wy = 0;
     if (i < cnt) {
       const uint32_t p = c.reg[i];
-      w = q_modgrad(c.G[p].q);
-      wx = (double)(int)(p % (uint32_t)c.spitch) * w;
-      wy = (double)(int)(p / (uint32_t)c.spitch) * w;
+      w = q_modgrad(c.G[pk_lin(c, p)].q);
+      wx = (double)pk_x(p) * w;
+      wy = (double)pk_y(p) * w;
     }
     const int n = min(64, cnt - base);
     for (int l = 0; l < n; l++) {
@@ -139,8 +147,8 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     double a = 0, b = 0, cc = 0;
     if (i < cnt) {
       const uint32_t p = c.reg[i];
-      const double w = q_modgrad(c.G[p].q);
-      const double ddx = (double)(int)(p % (uint32_t)c.spitch) - x, ddy = (double)(int)(p / (uint32_t)c.spitch) - y;
+      const double w = q_modgrad(c.G[pk_lin(c, p)].q);
+      const double ddx = (double)pk_x(p) - x, ddy = (double)pk_y(p) - y;
       a = ddy * ddy * w;
       b = ddx * ddx * w;
       cc = ddx * ddy * w;
@@ -161,7 +169,7 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
   double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
   for (int i = lane; i < cnt; i += 64) {
     const uint32_t p = c.reg[i];
-    const double rdx = (double)(int)(p % (uint32_t)c.spitch) - x, rdy = (double)(int)(p / (uint32_t)c.spitch) - y;
+    const double rdx = (double)pk_x(p) - x, rdy = (double)pk_y(p) - y;
     const double l = rdx * dx + rdy * dy;
     const double w = -rdx * dy + rdy * dx;
     l_max = fmax(l_max, l); l_min = fmin(l_min, l);
@@ -184,6 +192,57 @@ __device__ __forceinline__ double rect_density(int cnt, const LsdRect& r) {
   return (double)cnt / (sqrt(dist_sq(r.x1, r.y1, r.x2, r.y2)) * r.width);
 }
 
+// One iteration of reduce_region_radius(): drop every point farther than sqrt(radSq) from reg[0].
+// The reference removes with "swap with the last element, pop, re-check": near points of the final prefix
+// [0, K) stay in place and the holes (far points with index < K, ascending) are filled with the near points
+// of the tail [K, cnt) in DESCENDING index order.  That permutation is reproduced here with parallel passes.
+__device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, double yc, double radSq) {
+  const int lane = c.lane;
+  int K = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    bool near = false;
+    if (i < cnt) {
+      const uint32_t p = c.reg[i];
+      near = !(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p)) > radSq);
+      if (!near) {
+        const uint32_t li = pk_lin(c, p);
+        atomicAnd(&c.bm[li >> 5], ~(1u << (li & 31)));
+      }
+    }
+    K += __popcll(__ballot(near));
+  }
+  int H = 0;
+  for (int base = 0; base < K; base += 64) {
+    const int i = base + lane;
+    bool hole = false;
+    if (i < K) {
+      const uint32_t p = c.reg[i];
+      hole = dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p)) > radSq;
+    }
+    const unsigned long long m = __ballot(hole);
+    if (hole) c.scr[H + __popcll(m & lanemask_lt())] = (uint32_t)i;
+    H += __popcll(m);
+  }
+  int F = 0;
+  for (int top = cnt; top > K; top -= 64) {
+    const int i = top - 1 - lane;
+    bool fil = false;
+    uint32_t p = 0;
+    if (i >= K) {
+      p = c.reg[i];
+      fil = !(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p)) > radSq);
+    }
+    const unsigned long long m = __ballot(fil);
+    if (fil) c.scr[H + F + __popcll(m & lanemask_lt())] = p;
+    F += __popcll(m);
+  }
+  __syncthreads();
+  for (int j = lane; j < H; j += 64) c.reg[c.scr[j]] = c.scr[H + j];
+  __syncthreads();
+  return K;
+}
+
 // flsd(): one wavefront per frame, seeds in pseudo-order, sequential semantics.
 __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
@@ -193,7 +252,9 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   c.bm = (uint32_t*)smem;
   c.ring = c.bm + nWords;
   c.G = reinterpret_cast<const LsdPix*>(a.pix) + (long long)b * a.scaledStride;
+  c.S = reinterpret_cast<const float2*>(a.seedcs) + (long long)b * a.scaledStride;
   c.reg = a.reg + (long long)b * a.scaledStride;
+  c.scr = a.scr + (long long)b * a.scaledStride;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   const uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
   float* segs = a.segs + (long long)b * a.segCap * 4;
@@ -223,8 +284,9 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
     double density = rect_density(cnt, rec);
     if (density < a.densityTh) {   // refine(): retry with a tighter angle tolerance, then shrink the radius
       const uint32_t p0 = c.reg[0];
-      const double xc = (double)(int)(p0 % (uint32_t)c.spitch), yc = (double)(int)(p0 / (uint32_t)c.spitch);
-      const double ang_c = pix_angle(c.G[p0]);
+      const uint32_t seed0 = pk_lin(c, p0);
+      const double xc = (double)pk_x(p0), yc = (double)pk_y(p0);
+      const double ang_c = pix_angle(c.G[seed0]);
       double sum = 0, s_sum = 0;
       int n = 0;
       for (int base = 0; base < cnt; base += 64) {
@@ -233,11 +295,11 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
         double ang_d = 0;
         if (i < cnt) {
           const uint32_t p = c.reg[i];
-          atomicAnd(&c.bm[p >> 5], ~(1u << (p & 31)));
-          const double px = (double)(int)(p % (uint32_t)c.spitch), py = (double)(int)(p / (uint32_t)c.spitch);
-          if (sqrt(dist_sq(xc, yc, px, py)) < rec.width) {
+          const uint32_t li = pk_lin(c, p);
+          atomicAnd(&c.bm[li >> 5], ~(1u << (li & 31)));
+          if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < rec.width) {
             flag = true;
-            ang_d = angle_diff_signed(pix_angle(c.G[p]), ang_c);
+            ang_d = angle_diff_signed(pix_angle(c.G[li]), ang_c);
           }
         }
         unsigned long long m = __ballot(flag);
@@ -253,7 +315,7 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
       const double mean_angle = sum / (double)n;
       const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
       __syncthreads();
-      cnt = lsd_region_grow(c, p0, tau, &reg_angle);
+      cnt = lsd_region_grow(c, seed0, tau, &reg_angle);
       if (cnt < 2) {
         ok = false;
       } else {
@@ -265,21 +327,7 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
           double radSq = r1 > r2 ? r1 : r2;
           while (density < a.densityTh) {
             radSq *= 0.75 * 0.75;
-            int n2 = cnt;
-            if (lane == 0) {   // order-dependent swap-with-last removal: kept strictly sequential
-              for (int i = 0; i < n2; ++i) {
-                const uint32_t p = c.reg[i];
-                const double px = (double)(int)(p % (uint32_t)c.spitch), py = (double)(int)(p / (uint32_t)c.spitch);
-                if (dist_sq(xc, yc, px, py) > radSq) {
-                  atomicAnd(&c.bm[p >> 5], ~(1u << (p & 31)));
-                  c.reg[i] = c.reg[n2 - 1];
-                  --n2;
-                  --i;
-                }
-              }
-            }
-            __syncthreads();
-            cnt = __shfl(n2, 0);
+            cnt = lsd_reduce_radius_step(c, cnt, xc, yc, radSq);
             if (cnt < 2) { ok = false; break; }
             lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
             density = rect_density(cnt, rec);

@@ -35,6 +35,7 @@ struct dim3 {
 struct uint3e { unsigned x, y, z; };
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
+struct float2 { float x, y; };
 
 typedef int hipError_t;
 typedef void* hipStream_t;
