@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
       basep = __shfl(basep, leader);
       if (lane == leader) hist[wv * LSD_NBINS + lb] = basep + __popcll(same);
       if (active && bin == lb) {
-        ord[basep + __popcll(same & lanemask_lt())] = (uint32_t)i;
+        ord[basep + __popcll(same & lanemask_lt())] = (uint32_t)(i % a.spitch) | ((uint32_t)(i / a.spitch) << 16);
         active = false;
       }
     }

@@ -30,7 +30,7 @@ struct LineDeviceArgs {
   uint8_t* scaled;          // 0.8x image, pitch spitch
   void* pix;                // LsdPix[16 B] level-line record per scaled pixel, pitch spitch (line_dev.h)
   uint8_t* used;            // region-growing marks, pitch spitch
-  uint32_t* ordered;        // seed list (pixel index y*spitch+x), bins descending / raster inside a bin
+  uint32_t* ordered;        // seed list (packed coordinates x | y << 16), bins descending / raster inside a bin
   uint32_t* reg;            // region point queue
   uint32_t* scr;            // scratch of the same size
   void* seedcs;             // float2 per scaled pixel: (float)cos, (float)sin of the pixel's double angle

@@ -8,6 +8,10 @@ struct LsdRect {
   double x1, y1, x2, y2, width;
 };
 
+struct alignas(16) D2 {
+  double x, y;
+};
+
 struct GrowCtx {
   const LsdPix* G;     // level-line records of the scaled image
   const float2* S;     // per pixel (float)cos / (float)sin of the double angle: region_grow()'s seed terms
@@ -15,11 +19,23 @@ struct GrowCtx {
   uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
   uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
   uint32_t* bm;        // LDS `used` bitmap
+  double* T;           // LDS [3][64] doubles: lane -> chain transposition buffer of the sequential double sums
   int spitch, sw, sh, lane;
   unsigned qThresh;
+#if defined(PLH_GROW_PROF)
+  unsigned long long* pf;   // per-wave phase counters (debug build only, tools/grow_prof.py)
+#endif
 };
+#if defined(PLH_GROW_PROF)
+__device__ unsigned long long g_grow_prof[16];
+#define PF_NOW() __builtin_amdgcn_s_memtime()
+#define PF_ADD(c, k, v) ((c).pf[k] += (unsigned long long)(v))
+#else
+#define PF_NOW() 0ull
+#define PF_ADD(c, k, v) ((void)sizeof(v))
+#endif
 constexpr int LSD_RING = 1024;
-constexpr int LSD_GROUPS = 7;   // queue points examined per step (7 x 9 neighbour lanes = 63 lanes)
+constexpr int LSD_PTS = 8;      // queue points examined per step (8 points x 8 neighbours = 64 lanes)
 
 __device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xffffu); }
 __device__ __forceinline__ int pk_y(uint32_t p) { return (int)(p >> 16); }
@@ -39,75 +55,181 @@ __device__ __forceinline__ float bcast_f32(float v, int l) {
 __device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 #endif
 
-// region_grow(): BFS over reg[] used as a queue.  Each step examines up to 7 queued points at once: lane
-// 9g+n fetches neighbour n (yy outer, xx inner) of point i+g with ONE 16-byte load, so the memory latency
-// is paid once per 7 points.  Acceptance is then resolved strictly in (point, neighbour) order -- every
-// accepted pixel moves the running region angle -- and a pixel accepted for an earlier point cancels its
-// later duplicates, which is exactly what the sequential `used` map does.  Points appended during a step
-// are examined in later steps, so the queue order is the reference's.
-// Returns the region size; *regAngleOut = final reg_angle.  All lanes hold identical (uniform) state.
-__device__ int lsd_region_grow(const GrowCtx& c, uint32_t seed, double prec, double* regAngleOut) {
+// isAligned() of cv::LineSegmentDetector for a defined pixel: |theta - a| folded at 3pi/2, compared with prec.
+__device__ __forceinline__ bool lsd_aligned(double theta, double a, double prec) {
+  double n_theta = theta - a;
+  if (n_theta < 0) n_theta = -n_theta;
+  if (n_theta > k3_2PI) {
+    n_theta -= k2PI;
+    if (n_theta < 0) n_theta = -n_theta;
+  }
+  return n_theta <= prec;
+}
+
+// One step's candidates: lane order == the reference's examination order (queue point, then yy, then xx).
+struct LsdCand {
+  LsdPix px;
+  uint32_t nidx, npk;
+  bool inb;
+};
+
+// Resolve the candidates of one step with the sequential semantics of region_grow(): every accepted pixel
+// moves the running region angle, a pixel accepted for an earlier point cancels its later duplicates.
+//
+// The sequential chain is cut down to one packed float add per accepted pixel.  Each pass
+//   1. predicts every remaining candidate against the current (exact) region angle,
+//   2. walks the predicted-accepted lanes in order, adding their (cos, sin) to the running sums of all LATER
+//      lanes -- so lane j holds exactly the sums the reference has when it examines candidate j, built by the
+//      same sequence of float additions,
+//   3. lets every lane evaluate fastAtan2 of its own post-state and test its alignment against the angle of
+//      the state in front of it -- in parallel,
+//   4. commits everything up to the first lane whose real decision differs from the prediction (decisions in
+//      front of it were taken on exact states, so they are the reference's), and repeats from there.
+// Mispredictions only happen for pixels within the step's angle drift of the tolerance boundary.
+__device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const LsdCand& cd, bool mayDup, double prec,
+                                            float& sumdx, float& sumdy, float& regAngF, int& cnt) {
   const int lane = c.lane;
-  double reg_angle = pix_angle(c.G[seed]);
-  const float2 sc = c.S[seed];
-  float sumdx = sc.x, sumdy = sc.y;   // float(cos(reg_angle)), float(sin(reg_angle)), precomputed by k_lsd_grad
-  const uint32_t seedPk = (uint32_t)(seed % (uint32_t)c.spitch) | ((uint32_t)(seed / (uint32_t)c.spitch) << 16);
+  unsigned long long rem = __ballot(cand);
+  PF_ADD(c, 10, __popcll(rem));
+  if (!rem) return;
+  const double a = (double)cd.px.angf * kDegToRads;
+  const unsigned long long ltMask = lanemask_lt();
+  while (rem) {
+    const bool inRem = (rem >> lane) & 1ull;
+    const bool pred = inRem && lsd_aligned((double)regAngF * kDegToRads, a, prec);
+    const unsigned long long P = __ballot(pred);
+    if (!P) break;   // the state cannot change any more: every remaining candidate is rejected on the exact angle
+    PF_ADD(c, 12, 1);
+    float preX = sumdx, preY = sumdy;
+    unsigned long long m = P, acc = 0, canc = 0;
+    while (m) {
+      const int k = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      acc |= 1ull << k;
+      if (mayDup) {
+        const uint32_t nk = bcast_u32(cd.nidx, k);
+        const unsigned long long dup = __ballot(inRem && cd.nidx == nk) & ~((2ull << k) - 1ull);
+        m &= ~dup;
+        canc |= dup;
+      }
+      const float ck = bcast_f32(cd.px.cs, k), sk = bcast_f32(cd.px.sn, k);
+      if (lane > k) { preX += ck; preY += sk; }
+    }
+    const float postX = preX + cd.px.cs, postY = preY + cd.px.sn;
+    const float angPost = fast_atan2_deg(postY, postX);
+    const unsigned long long below = acc & ltMask;
+    const int prev = below ? 63 - __clzll((long long)below) : 0;
+    float angPrev = __shfl(angPost, prev);
+    if (!below) angPrev = regAngF;
+    const bool d = lsd_aligned((double)angPrev * kDegToRads, a, prec);
+    const bool e = (acc >> lane) & 1ull;
+    const bool live = inRem && !((canc >> lane) & 1ull);
+    const unsigned long long mism = __ballot(live && d != e);
+    unsigned long long A = acc;
+    int f = 64;
+    if (mism) {
+      f = __ffsll((long long)mism) - 1;
+      A &= (1ull << f) - 1ull;
+      if (!((acc >> f) & 1ull)) A |= 1ull << f;   // predicted rejected, really accepted
+    }
+    if (A) {
+      if ((A >> lane) & 1ull) {
+        const int slot = cnt + __popcll(A & ltMask);
+        c.reg[slot] = cd.npk;
+        c.ring[slot & (LSD_RING - 1)] = cd.npk;
+        atomicOr(&c.bm[cd.nidx >> 5], 1u << (cd.nidx & 31));
+      }
+      const int last = 63 - __clzll((long long)A);
+      sumdx = bcast_f32(postX, last);
+      sumdy = bcast_f32(postY, last);
+      regAngF = bcast_f32(angPost, last);
+      cnt += __popcll(A);
+    }
+    if (f >= 64) break;
+    PF_ADD(c, 13, 1);
+    rem &= ~((2ull << f) - 1ull);
+    if (mayDup && rem) {   // drop the duplicates of what has just been committed
+      PLH_WAVE_SYNC();
+      const bool nowUsed = ((rem >> lane) & 1ull) && ((c.bm[cd.nidx >> 5] >> (cd.nidx & 31)) & 1u);
+      rem &= ~__ballot(nowUsed);
+    }
+  }
+}
+
+// Issue the level-line loads of queue points [base, base + 8) whose index q satisfies lo <= q < hi:
+// lane 8g+n fetches neighbour n (yy outer, xx inner, centre skipped) of point base+g with one 16-byte load.
+__device__ __forceinline__ void lsd_fetch(const GrowCtx& c, LsdCand& d, int base, int lo, int hi, int cnt) {
+  const int g = c.lane >> 3, n = c.lane & 7;
+  const int q = base + g;
+  if (q >= lo && q < hi) {
+    const int nb = n < 4 ? n : n + 1;
+    const int dy = nb / 3 - 1, dx = nb - (nb / 3) * 3 - 1;
+    const uint32_t p = reg_get(c, q, cnt);
+    const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
+    d.inb = xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh;
+    d.nidx = d.inb ? (uint32_t)(yy * c.spitch + xx) : 0u;
+    d.npk = (uint32_t)xx | ((uint32_t)yy << 16);
+    if (d.inb) d.px = c.G[d.nidx];
+  }
+}
+
+// region_grow(): BFS over reg[] used as a queue, 8 queued points (64 neighbour lanes) per step.  The records of
+// the next step's points that are already queued are requested before the current step is resolved, so their
+// latency hides behind it.  `first` holds the seed's 8 neighbours prefetched in lane group `firstGrp` (firstGrp < 0: not prefetched).
+// Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
+// reference's float fastAtan2 result).  All lanes hold identical (uniform) state.
+__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk, float seedAngF, float seedCos, float seedSin,
+                                               double prec, const LsdCand& first, int firstGrp, float* regAngOut) {
+  const int lane = c.lane;
+  float regAngF = seedAngF, sumdx = seedCos, sumdy = seedSin;
+  const uint32_t seed = pk_lin(c, seedPk);
   PLH_WAVE_SYNC();   // every lane has finished reading the seed's `used` bit before it is set
   if (lane == 0) {
     c.reg[0] = seedPk;
     c.ring[0] = seedPk;
     atomicOr(&c.bm[seed >> 5], 1u << (seed & 31));
   }
-  int cnt = 1;
-  const int grp = lane / 9, nb = lane - grp * 9;
-  const int dy = nb / 3 - 1, dx = nb - (nb / 3) * 3 - 1;
-  int i = 0;
-  while (i < cnt) {
-    PLH_WAVE_SYNC();
-    const int m = min(LSD_GROUPS, cnt - i);
-    bool cand = false;
-    uint32_t nidx = 0, npk = 0;
-    LsdPix px;
-    px.angf = 0.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
-    if (grp < m) {
-      const uint32_t p = reg_get(c, i + grp, cnt);
-      const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
-      if (xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
-        nidx = (uint32_t)(yy * c.spitch + xx);
-        npk = (uint32_t)xx | ((uint32_t)yy << 16);
-        px = c.G[nidx];                                                  // issued together with the LDS bitmap read
-        const bool isUsed = (c.bm[nidx >> 5] >> (nidx & 31)) & 1u;
-        cand = !isUsed && px.q > c.qThresh;                              // angle != NOTDEF
-      }
-    }
-    unsigned long long cm = __ballot(cand);
-    while (cm) {
-      const int k = __ffsll((long long)cm) - 1;
-      cm &= cm - 1;
-      const double a = (double)bcast_f32(px.angf, k) * kDegToRads;
-      double n_theta = reg_angle - a;   // isAligned()
-      if (n_theta < 0) n_theta = -n_theta;
-      if (n_theta > k3_2PI) {
-        n_theta -= k2PI;
-        if (n_theta < 0) n_theta = -n_theta;
-      }
-      if (n_theta <= prec) {
-        const uint32_t nk = bcast_u32(nidx, k);
-        if (lane == k) {
-          atomicOr(&c.bm[nidx >> 5], 1u << (nidx & 31));
-          c.reg[cnt] = npk;
-          c.ring[cnt & (LSD_RING - 1)] = npk;
-        }
-        sumdx += bcast_f32(px.cs, k);
-        sumdy += bcast_f32(px.sn, k);
-        reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * kDegToRads;
-        cnt++;
-        cm &= ~__ballot(cand && nidx == nk);   // the same pixel seen from a later point is now `used`
-      }
-    }
-    i += m;
+  PF_ADD(c, 11, 1);
+  int cnt = 1, i = 0;
+  PLH_WAVE_SYNC();
+  if (firstGrp >= 0) {
+    const unsigned long long pt1 = PF_NOW();
+    const bool cand = (lane >> 3) == firstGrp && first.inb && first.px.q > c.qThresh &&
+                      !((c.bm[first.nidx >> 5] >> (first.nidx & 31)) & 1u);
+    lsd_resolve(c, cand, first, false, prec, sumdx, sumdy, regAngF, cnt);
+    PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
+    i = 1;
   }
-  *regAngleOut = reg_angle;
+  LsdCand cur;
+  cur.inb = false; cur.nidx = 0; cur.npk = 0;
+  cur.px.angf = 0.f; cur.px.cs = 0.f; cur.px.sn = 0.f; cur.px.q = 0;
+  if (i < cnt) {
+    PLH_WAVE_SYNC();
+    lsd_fetch(c, cur, i, i, cnt, cnt);
+  }
+  while (i < cnt) {
+    const unsigned long long pt0 = PF_NOW();
+    const int m = min(LSD_PTS, cnt - i), cnt0 = cnt;
+    LsdCand nxt = cur;
+    nxt.inb = false;
+    if (cnt > i + LSD_PTS) lsd_fetch(c, nxt, i + LSD_PTS, i + LSD_PTS, cnt, cnt);   // prefetch
+    PLH_WAVE_SYNC();
+    const bool cand = (lane >> 3) < m && cur.inb && cur.px.q > c.qThresh &&
+                      !((c.bm[cur.nidx >> 5] >> (cur.nidx & 31)) & 1u);
+    const unsigned long long any = __ballot(cand);   // (forces the wait for this step's records)
+    const unsigned long long pt1 = PF_NOW();
+    PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
+    if (any) lsd_resolve(c, cand, cur, true, prec, sumdx, sumdy, regAngF, cnt);
+    PF_ADD(c, 4, PF_NOW() - pt1);
+    i += m;
+    if (i < cnt && cnt > cnt0) {   // points queued during this step: fetch them now
+      PLH_WAVE_SYNC();
+      lsd_fetch(c, nxt, i, max(i, cnt0), cnt, cnt);
+    }
+    cur = nxt;
+  }
+  PF_ADD(c, 9, cnt);
+  *regAngOut = regAngF;
   return cnt;
 }
 
@@ -118,11 +240,27 @@ __device__ __forceinline__ double angle_diff_signed(double a, double b) {
   return diff;
 }
 
-// region2rect() + get_theta().  The weighted sums are accumulated in region order (sequentially, via lane
-// broadcasts) so the doubles are bit-identical to the sequential reference; the extents are min/max (exact).
+// Sequential double sums of up to three series at once.  Every lane has stored its three terms for element
+// base+lane into c.T ([3][64], zero beyond the end); lane ch < 3 then adds series ch in element order from LDS,
+// so the three dependent v_add_f64 chains of the reference run side by side in three lanes, one add per element
+// (adding the +0.0 padding is exact: the accumulators are never -0.0).
+__device__ __forceinline__ double lsd_chain_add(const GrowCtx& c, double acc, int n) {
+  const int ch = min(c.lane, 2);
+  const D2* row = reinterpret_cast<const D2*>(c.T + ch * 64);
+  const int n2 = ((n + 7) >> 3) << 2;
+  for (int l = 0; l < n2; l += 4) {
+    const D2 v0 = row[l], v1 = row[l + 1], v2 = row[l + 2], v3 = row[l + 3];
+    acc += v0.x; acc += v0.y; acc += v1.x; acc += v1.y;
+    acc += v2.x; acc += v2.y; acc += v3.x; acc += v3.y;
+  }
+  return acc;
+}
+
+// region2rect() + get_theta().  The weighted sums are accumulated in region order (lsd_chain_add) so the doubles
+// are bit-identical to the sequential reference; the extents are min/max (exact).
 __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, double prec, LsdRect* rec) {
   const int lane = c.lane;
-  double x = 0, y = 0, sum = 0;
+  double acc = 0;
   for (int base = 0; base < cnt; base += 64) {
     const int i = base + lane;
     double w = 0, wx = 0, wy = 0;
@@ -132,16 +270,16 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
       wx = (double)pk_x(p) * w;
       wy = (double)pk_y(p) * w;
     }
-    const int n = min(64, cnt - base);
-    for (int l = 0; l < n; l++) {
-      x += bcast_f64(wx, l);
-      y += bcast_f64(wy, l);
-      sum += bcast_f64(w, l);
-    }
+    PLH_WAVE_SYNC();
+    c.T[lane] = wx; c.T[64 + lane] = wy; c.T[128 + lane] = w;
+    PLH_WAVE_SYNC();
+    acc = lsd_chain_add(c, acc, min(64, cnt - base));
   }
+  double x = bcast_f64(acc, 0), y = bcast_f64(acc, 1);
+  const double sum = bcast_f64(acc, 2);
   x /= sum;
   y /= sum;
-  double Ixx = 0, Iyy = 0, Ixy = 0;
+  acc = 0;
   for (int base = 0; base < cnt; base += 64) {
     const int i = base + lane;
     double a = 0, b = 0, cc = 0;
@@ -151,15 +289,14 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
       const double ddx = (double)pk_x(p) - x, ddy = (double)pk_y(p) - y;
       a = ddy * ddy * w;
       b = ddx * ddx * w;
-      cc = ddx * ddy * w;
+      cc = -(ddx * ddy * w);   // Ixy -= v  ==  Ixy += -v
     }
-    const int n = min(64, cnt - base);
-    for (int l = 0; l < n; l++) {
-      Ixx += bcast_f64(a, l);
-      Iyy += bcast_f64(b, l);
-      Ixy -= bcast_f64(cc, l);
-    }
+    PLH_WAVE_SYNC();
+    c.T[lane] = a; c.T[64 + lane] = b; c.T[128 + lane] = cc;
+    PLH_WAVE_SYNC();
+    acc = lsd_chain_add(c, acc, min(64, cnt - base));
   }
+  const double Ixx = bcast_f64(acc, 0), Iyy = bcast_f64(acc, 1), Ixy = bcast_f64(acc, 2);
   const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
   double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
                                          : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
@@ -249,106 +386,164 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int nWords = (a.spitch * a.sh + 31) / 32;
   GrowCtx c;
-  c.bm = (uint32_t*)smem;
+  c.T = (double*)smem;
+  c.bm = (uint32_t*)(smem + 3 * 64 * 8);
   c.ring = c.bm + nWords;
   c.G = reinterpret_cast<const LsdPix*>(a.pix) + (long long)b * a.scaledStride;
   c.S = reinterpret_cast<const float2*>(a.seedcs) + (long long)b * a.scaledStride;
   c.reg = a.reg + (long long)b * a.scaledStride;
   c.scr = a.scr + (long long)b * a.scaledStride;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
-  const uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
+  const uint32_t* ord = a.ordered + (long long)b * a.scaledStride;   // packed coordinates x | y << 16
   float* segs = a.segs + (long long)b * a.segCap * 4;
+#if defined(PLH_GROW_PROF)
+  unsigned long long pfv[16];
+  for (int i = 0; i < 16; i++) pfv[i] = 0;
+  c.pf = pfv;
+  const unsigned long long pfStart = PF_NOW();
+#endif
   for (int i = lane; i < nWords; i += 64) c.bm[i] = 0;
   __syncthreads();
   const int nOrd = a.nOrdered[b];
+  const int grp = lane >> 3, nbr = lane & 7;
+  const int nbq = nbr < 4 ? nbr : nbr + 1;
+  const int ndy = nbq / 3 - 1, ndx = nbq - (nbq / 3) * 3 - 1;
   int nseg = 0;
   for (int sbase = 0; sbase < nOrd; sbase += 64) {
-   // 64 seeds per scan: one coalesced load + one parallel `used` test; survivors are re-tested in order
-   const int si = sbase + lane;
-   const uint32_t seedL = si < nOrd ? ord[si] : 0u;
-   PLH_WAVE_SYNC();
-   unsigned long long fm = __ballot(si < nOrd && !((c.bm[seedL >> 5] >> (seedL & 31)) & 1u));
-   while (fm) {
-    const int sk = __ffsll((long long)fm) - 1;
-    fm &= fm - 1;
-    const uint32_t seed = bcast_u32(seedL, sk);
+    // 64 seeds per scan: one coalesced load + one parallel `used` test; the survivors' own records (angle, seed
+    // cos/sin) are fetched by their scan lanes, all at once
+    const int si = sbase + lane;
+    const uint32_t seedP = si < nOrd ? ord[si] : 0u;
+    const uint32_t seedL = pk_lin(c, seedP);
     PLH_WAVE_SYNC();
-    if ((c.bm[seed >> 5] >> (seed & 31)) & 1u) continue;
-    double reg_angle;
-    int cnt = lsd_region_grow(c, seed, a.prec, &reg_angle);
-    if (cnt < a.minRegSize) continue;
-    __syncthreads();   // queue stores visible to every lane
-    LsdRect rec;
-    lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
-    bool ok = true;
-    double density = rect_density(cnt, rec);
-    if (density < a.densityTh) {   // refine(): retry with a tighter angle tolerance, then shrink the radius
-      const uint32_t p0 = c.reg[0];
-      const uint32_t seed0 = pk_lin(c, p0);
-      const double xc = (double)pk_x(p0), yc = (double)pk_y(p0);
-      const double ang_c = pix_angle(c.G[seed0]);
-      double sum = 0, s_sum = 0;
-      int n = 0;
-      for (int base = 0; base < cnt; base += 64) {
-        const int i = base + lane;
-        bool flag = false;
-        double ang_d = 0;
-        if (i < cnt) {
-          const uint32_t p = c.reg[i];
-          const uint32_t li = pk_lin(c, p);
-          atomicAnd(&c.bm[li >> 5], ~(1u << (li & 31)));
-          if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < rec.width) {
-            flag = true;
-            ang_d = angle_diff_signed(pix_angle(c.G[li]), ang_c);
-          }
-        }
-        unsigned long long m = __ballot(flag);
-        while (m) {
-          const int l = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          const double v = bcast_f64(ang_d, l);
-          sum += v;
-          s_sum += v * v;
-          ++n;
+    const bool alive = si < nOrd && !((c.bm[seedL >> 5] >> (seedL & 31)) & 1u);
+    unsigned long long fm = __ballot(alive);
+    float sAng = 0.f;
+    float2 sCS;
+    sCS.x = 0.f; sCS.y = 0.f;
+    if (alive) {
+      sAng = c.G[seedL].angf;
+      sCS = c.S[seedL];
+    }
+    while (fm) {
+      // up to 8 surviving seeds at a time: lane group t prefetches the 8 neighbours of the t-th of them
+      int skv = 0, mySk = 0, nb = 0;
+      for (; nb < 8 && fm; nb++) {
+        const int k = __ffsll((long long)fm) - 1;
+        fm &= fm - 1;
+        if (grp == nb) mySk = k;
+        if (lane == nb) skv = k;
+      }
+      LsdCand fst;
+      fst.inb = false; fst.nidx = 0; fst.npk = 0;
+      fst.px.angf = 0.f; fst.px.cs = 0.f; fst.px.sn = 0.f; fst.px.q = 0;
+      {
+        const uint32_t sp = __shfl(seedP, mySk);
+        const int xx = pk_x(sp) + ndx, yy = pk_y(sp) + ndy;
+        if (grp < nb && xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
+          fst.inb = true;
+          fst.nidx = (uint32_t)(yy * c.spitch + xx);
+          fst.npk = (uint32_t)xx | ((uint32_t)yy << 16);
+          fst.px = c.G[fst.nidx];
         }
       }
-      const double mean_angle = sum / (double)n;
-      const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-      __syncthreads();
-      cnt = lsd_region_grow(c, seed0, tau, &reg_angle);
-      if (cnt < 2) {
-        ok = false;
-      } else {
-        __syncthreads();
-        lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
-        density = rect_density(cnt, rec);
-        if (density < a.densityTh) {   // reduce_region_radius()
+      for (int t = 0; t < nb; t++) {
+        const int sk = (int)bcast_u32((unsigned)skv, t);
+        uint32_t seedPk = bcast_u32(seedP, sk);
+        uint32_t seed = bcast_u32(seedL, sk);
+        PLH_WAVE_SYNC();
+        if ((c.bm[seed >> 5] >> (seed & 31)) & 1u) continue;   // swallowed by a region grown since the scan
+        // region_grow -> region2rect -> [refine: tighter tolerance, re-grow -> region2rect -> reduce_region_radius]
+        float gAng = bcast_f32(sAng, sk), gCos = bcast_f32(sCS.x, sk), gSin = bcast_f32(sCS.y, sk);
+        double gPrec = a.prec, xc = 0, yc = 0;
+        int phase = 0, firstGrp = t;
+        bool emit = false;
+        LsdRect rec;
+        for (;;) {
+          float regAngF;
+          const unsigned long long pg0 = PF_NOW();
+          int cnt = lsd_region_grow(c, seedPk, gAng, gCos, gSin, gPrec, fst, firstGrp, &regAngF);
+          const unsigned long long pg1 = PF_NOW();
+          PF_ADD(c, 2, pg1 - pg0);
+          if (cnt < (phase == 0 ? a.minRegSize : 2)) break;
+          const double reg_angle = (double)regAngF * kDegToRads;
+          __syncthreads();   // queue stores visible to every lane
+          lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
+          const unsigned long long pg2 = PF_NOW();
+          PF_ADD(c, 5, pg2 - pg1);
+          double density = rect_density(cnt, rec);
+          if (!(density < a.densityTh)) { emit = true; break; }
+          if (phase == 0) {   // refine(): tolerance from the angle spread near the seed, everything un-marked
+            seedPk = c.reg[0];
+            seed = pk_lin(c, seedPk);
+            xc = (double)pk_x(seedPk); yc = (double)pk_y(seedPk);
+            const LsdPix g0 = c.G[seed];
+            const float2 s0 = c.S[seed];
+            const double ang_c = pix_angle(g0);
+            double acc = 0;
+            int n = 0;
+            for (int base = 0; base < cnt; base += 64) {
+              const int i = base + lane;
+              bool flag = false;
+              double ang_d = 0;
+              if (i < cnt) {
+                const uint32_t p = c.reg[i];
+                const uint32_t li = pk_lin(c, p);
+                atomicAnd(&c.bm[li >> 5], ~(1u << (li & 31)));
+                if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < rec.width) {
+                  flag = true;
+                  ang_d = angle_diff_signed(pix_angle(c.G[li]), ang_c);
+                }
+              }
+              n += __popcll(__ballot(flag));
+              PLH_WAVE_SYNC();
+              c.T[lane] = ang_d; c.T[64 + lane] = ang_d * ang_d; c.T[128 + lane] = 0.0;
+              PLH_WAVE_SYNC();
+              acc = lsd_chain_add(c, acc, min(64, cnt - base));
+            }
+            const double sum = bcast_f64(acc, 0), s_sum = bcast_f64(acc, 1);
+            const double mean_angle = sum / (double)n;
+            gPrec = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+            gAng = g0.angf; gCos = s0.x; gSin = s0.y;
+            phase = 1; firstGrp = -1;
+            __syncthreads();
+            PF_ADD(c, 6, PF_NOW() - pg2);
+            continue;
+          }
+          // reduce_region_radius()
           const double r1 = dist_sq(xc, yc, rec.x1, rec.y1), r2 = dist_sq(xc, yc, rec.x2, rec.y2);
           double radSq = r1 > r2 ? r1 : r2;
+          emit = true;
           while (density < a.densityTh) {
             radSq *= 0.75 * 0.75;
             cnt = lsd_reduce_radius_step(c, cnt, xc, yc, radSq);
-            if (cnt < 2) { ok = false; break; }
+            if (cnt < 2) { emit = false; break; }
             lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
             density = rect_density(cnt, rec);
           }
+          PF_ADD(c, 6, PF_NOW() - pg2);
+          break;
         }
+        if (!emit) continue;
+        rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+        rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
+        if (lane == 0 && nseg < a.segCap) {
+          segs[nseg * 4 + 0] = (float)rec.x1; segs[nseg * 4 + 1] = (float)rec.y1;
+          segs[nseg * 4 + 2] = (float)rec.x2; segs[nseg * 4 + 3] = (float)rec.y2;
+        }
+        nseg++;
       }
     }
-    if (!ok) continue;
-    rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
-    rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
-    if (lane == 0 && nseg < a.segCap) {
-      segs[nseg * 4 + 0] = (float)rec.x1; segs[nseg * 4 + 1] = (float)rec.y1;
-      segs[nseg * 4 + 2] = (float)rec.x2; segs[nseg * 4 + 3] = (float)rec.y2;
-    }
-    nseg++;
-   }
   }
   if (lane == 0) {
     if (nseg > a.segCap) { atomicOr(a.status, 4); nseg = a.segCap; }
     a.nSegs[b] = nseg;
   }
+#if defined(PLH_GROW_PROF)
+  pfv[0] = PF_NOW() - pfStart;
+  if (lane == 0)
+    for (int i = 0; i < 16; i++) atomicAdd(&g_grow_prof[i], pfv[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -598,8 +793,9 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
 }
 
 // ---------------------------------------------------------------------------------------------
+size_t lsd_grow_lds_bytes(int spitch, int sh);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)((a.spitch * a.sh + 31) / 32 + LSD_RING) * 4 + 64;
+  const size_t lds = lsd_grow_lds_bytes(a.spitch, a.sh);
   hipLaunchKernelGGL(k_lsd_grow, dim3(a.batch), dim3(64), lds, s, a);
 }
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s) {
@@ -611,6 +807,16 @@ void launch_sobel(const LineDeviceArgs& a, hipStream_t s) {
 void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, const float* coef, uint8_t* desc, hipStream_t s) {
   hipLaunchKernelGGL(k_lbd, dim3(a.outCap, a.batch), dim3(64), 0, s, a, kl, n, coef, desc);
 }
-size_t lsd_grow_lds_bytes(int spitch, int sh) { return (size_t)((spitch * sh + 31) / 32 + LSD_RING) * 4 + 64; }
+#if defined(PLH_GROW_PROF)
+extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_grow_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_grow_prof), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+size_t lsd_grow_lds_bytes(int spitch, int sh) { return (size_t)((spitch * sh + 31) / 32 + LSD_RING) * 4 + 3 * 64 * 8 + 64; }
 
 }  // namespace plh

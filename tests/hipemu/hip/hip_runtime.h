@@ -108,6 +108,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 inline unsigned __float_as_uint(float v) { unsigned u; memcpy(&u, &v, 4); return u; }
 inline float __uint_as_float(unsigned u) { float v; memcpy(&v, &u, 4); return v; }
 template <typename T> inline T atomicAnd(T* p, T v) { T o = *p; *p = (T)(o & v); return o; }
