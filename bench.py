@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=1536, help="frames per GPU per step (6 resident LSD frames per CU x 256 CUs)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--nfeatures", type=int, default=1000)

@@ -34,7 +34,7 @@ __device__ unsigned long long g_grow_prof[16];
 #define PF_NOW() 0ull
 #define PF_ADD(c, k, v) ((void)sizeof(v))
 #endif
-constexpr int LSD_RING = 1024;
+constexpr int LSD_RING = 512;    // 2 KiB; the chain buffer T (1.5 KiB) aliases it (never live at the same time)
 constexpr int LSD_PTS = 8;      // queue points examined per step (8 points x 8 neighbours = 64 lanes)
 
 __device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xffffu); }
@@ -48,7 +48,10 @@ __device__ __forceinline__ uint32_t reg_get(const GrowCtx& c, int i, int cnt) {
 #if defined(HIPEMU)
 __device__ __forceinline__ float bcast_f32(float v, int l) { return __shfl(v, l); }
 __device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return __shfl(v, l); }
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __ballot(p); }
 #else
+// the compare mask itself (HIP's __ballot materialises the predicate as an int first)
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ float bcast_f32(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -89,7 +92,7 @@ struct LsdCand {
 __device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const LsdCand& cd, bool mayDup, double prec,
                                             float& sumdx, float& sumdy, float& regAngF, int& cnt) {
   const int lane = c.lane;
-  unsigned long long rem = __ballot(cand);
+  unsigned long long rem = wballot(cand);
   PF_ADD(c, 10, __popcll(rem));
   if (!rem) return;
   const double a = (double)cd.px.angf * kDegToRads;
@@ -97,7 +100,7 @@ __device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const L
   while (rem) {
     const bool inRem = (rem >> lane) & 1ull;
     const bool pred = inRem && lsd_aligned((double)regAngF * kDegToRads, a, prec);
-    const unsigned long long P = __ballot(pred);
+    const unsigned long long P = wballot(pred);
     if (!P) break;   // the state cannot change any more: every remaining candidate is rejected on the exact angle
     PF_ADD(c, 12, 1);
     float preX = sumdx, preY = sumdy;
@@ -108,7 +111,7 @@ __device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const L
       acc |= 1ull << k;
       if (mayDup) {
         const uint32_t nk = bcast_u32(cd.nidx, k);
-        const unsigned long long dup = __ballot(inRem && cd.nidx == nk) & ~((2ull << k) - 1ull);
+        const unsigned long long dup = wballot(inRem && cd.nidx == nk) & ~((2ull << k) - 1ull);
         m &= ~dup;
         canc |= dup;
       }
@@ -124,7 +127,7 @@ __device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const L
     const bool d = lsd_aligned((double)angPrev * kDegToRads, a, prec);
     const bool e = (acc >> lane) & 1ull;
     const bool live = inRem && !((canc >> lane) & 1ull);
-    const unsigned long long mism = __ballot(live && d != e);
+    const unsigned long long mism = wballot(live && d != e);
     unsigned long long A = acc;
     int f = 64;
     if (mism) {
@@ -151,36 +154,40 @@ __device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const L
     if (mayDup && rem) {   // drop the duplicates of what has just been committed
       PLH_WAVE_SYNC();
       const bool nowUsed = ((rem >> lane) & 1ull) && ((c.bm[cd.nidx >> 5] >> (cd.nidx & 31)) & 1u);
-      rem &= ~__ballot(nowUsed);
+      rem &= ~wballot(nowUsed);
     }
   }
 }
 
-// Issue the level-line loads of queue points [base, base + 8) whose index q satisfies lo <= q < hi:
-// lane 8g+n fetches neighbour n (yy outer, xx inner, centre skipped) of point base+g with one 16-byte load.
-__device__ __forceinline__ void lsd_fetch(const GrowCtx& c, LsdCand& d, int base, int lo, int hi, int cnt) {
-  const int g = c.lane >> 3, n = c.lane & 7;
-  const int q = base + g;
-  if (q >= lo && q < hi) {
-    const int nb = n < 4 ? n : n + 1;
-    const int dy = nb / 3 - 1, dx = nb - (nb / 3) * 3 - 1;
-    const uint32_t p = reg_get(c, q, cnt);
-    const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
-    d.inb = xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh;
-    d.nidx = d.inb ? (uint32_t)(yy * c.spitch + xx) : 0u;
-    d.npk = (uint32_t)xx | ((uint32_t)yy << 16);
-    if (d.inb) d.px = c.G[d.nidx];
+// Addressing of one neighbour lane: lane 8g+n looks at neighbour n (yy outer, xx inner, centre skipped) of queue
+// point q = base+g.  Returns whether the lane has an in-bounds pixel to examine.
+__device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int q, int cnt, bool valid, uint32_t& nidx, uint32_t& npk) {
+  const int n = c.lane & 7;
+  const int nb = n < 4 ? n : n + 1;
+  const int dy = nb / 3 - 1, dx = nb - (nb / 3) * 3 - 1;
+  uint32_t p = c.ring[q & (LSD_RING - 1)];
+  if (wballot(valid && cnt - q > LSD_RING)) {   // the queue ran ahead of the LDS mirror (rare; kept a real branch)
+    if (valid && cnt - q > LSD_RING) p = *(volatile const uint32_t*)&c.reg[q];
   }
+  const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
+  const bool inb = valid && xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh;
+  nidx = inb ? (uint32_t)(yy * c.spitch + xx) : 0u;
+  npk = (uint32_t)xx | ((uint32_t)yy << 16);
+  return inb;
 }
 
-// region_grow(): BFS over reg[] used as a queue, 8 queued points (64 neighbour lanes) per step.  The records of
-// the next step's points that are already queued are requested before the current step is resolved, so their
-// latency hides behind it.  `first` holds the seed's 8 neighbours prefetched in lane group `firstGrp` (firstGrp < 0: not prefetched).
+// region_grow(): BFS over reg[] used as a queue, 8 queued points (64 neighbour lanes) per step; each lane fetches
+// its neighbour's 16-byte level-line record with one load.  The loads are software-pipelined: the records of the
+// next step's points that are already queued are requested (set A) BEFORE the current step is resolved, the
+// points queued by the current step are requested right after it (set B); every lane loads unconditionally
+// (record 0 when it has nothing to examine) so that no register of a set is touched before the next step
+// selects between the two.  `first` holds the seed's 8 neighbours prefetched in lane group `firstGrp`
+// (firstGrp < 0: not prefetched).
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
 // reference's float fastAtan2 result).  All lanes hold identical (uniform) state.
 __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk, float seedAngF, float seedCos, float seedSin,
                                                double prec, const LsdCand& first, int firstGrp, float* regAngOut) {
-  const int lane = c.lane;
+  const int lane = c.lane, g = lane >> 3;
   float regAngF = seedAngF, sumdx = seedCos, sumdy = seedSin;
   const uint32_t seed = pk_lin(c, seedPk);
   PLH_WAVE_SYNC();   // every lane has finished reading the seed's `used` bit before it is set
@@ -194,39 +201,46 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
   PLH_WAVE_SYNC();
   if (firstGrp >= 0) {
     const unsigned long long pt1 = PF_NOW();
-    const bool cand = (lane >> 3) == firstGrp && first.inb && first.px.q > c.qThresh &&
+    const bool cand = g == firstGrp && first.inb && first.px.q > c.qThresh &&
                       !((c.bm[first.nidx >> 5] >> (first.nidx & 31)) & 1u);
     lsd_resolve(c, cand, first, false, prec, sumdx, sumdy, regAngF, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
     i = 1;
   }
-  LsdCand cur;
-  cur.inb = false; cur.nidx = 0; cur.npk = 0;
-  cur.px.angf = 0.f; cur.px.cs = 0.f; cur.px.sn = 0.f; cur.px.q = 0;
-  if (i < cnt) {
-    PLH_WAVE_SYNC();
-    lsd_fetch(c, cur, i, i, cnt, cnt);
+  if (i >= cnt) {
+    PF_ADD(c, 9, cnt);
+    *regAngOut = regAngF;
+    return cnt;
   }
+  PLH_WAVE_SYNC();
+  uint32_t nidxA, npkA, nidxB = 0, npkB = 0;
+  bool inbA = lsd_addr(c, i + g, cnt, i + g < cnt, nidxA, npkA), inbB = false;
+  LsdPix pxA = c.G[nidxA], pxB = pxA;
   while (i < cnt) {
     const unsigned long long pt0 = PF_NOW();
     const int m = min(LSD_PTS, cnt - i), cnt0 = cnt;
-    LsdCand nxt = cur;
-    nxt.inb = false;
-    if (cnt > i + LSD_PTS) lsd_fetch(c, nxt, i + LSD_PTS, i + LSD_PTS, cnt, cnt);   // prefetch
+    LsdCand cur;
+    cur.inb = inbA || inbB;
+    cur.nidx = inbB ? nidxB : nidxA;
+    cur.npk = inbB ? npkB : npkA;
+    cur.px.angf = inbB ? pxB.angf : pxA.angf;
+    cur.px.cs = inbB ? pxB.cs : pxA.cs;
+    cur.px.sn = inbB ? pxB.sn : pxA.sn;
+    cur.px.q = inbB ? pxB.q : pxA.q;
+    // set A of the next step: its points that are already queued (unconditional: see above)
+    inbA = lsd_addr(c, i + LSD_PTS + g, cnt, i + LSD_PTS + g < cnt, nidxA, npkA);
+    pxA = c.G[nidxA];
     PLH_WAVE_SYNC();
-    const bool cand = (lane >> 3) < m && cur.inb && cur.px.q > c.qThresh &&
-                      !((c.bm[cur.nidx >> 5] >> (cur.nidx & 31)) & 1u);
-    const unsigned long long any = __ballot(cand);   // (forces the wait for this step's records)
+    const bool cand = cur.inb && cur.px.q > c.qThresh && !((c.bm[cur.nidx >> 5] >> (cur.nidx & 31)) & 1u);
     const unsigned long long pt1 = PF_NOW();
     PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
-    if (any) lsd_resolve(c, cand, cur, true, prec, sumdx, sumdy, regAngF, cnt);
+    lsd_resolve(c, cand, cur, true, prec, sumdx, sumdy, regAngF, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1);
     i += m;
-    if (i < cnt && cnt > cnt0) {   // points queued during this step: fetch them now
-      PLH_WAVE_SYNC();
-      lsd_fetch(c, nxt, i, max(i, cnt0), cnt, cnt);
-    }
-    cur = nxt;
+    // set B: the points queued by this step
+    PLH_WAVE_SYNC();
+    inbB = lsd_addr(c, i + g, cnt, i + g >= cnt0 && i + g < cnt, nidxB, npkB);
+    pxB = c.G[nidxB];
   }
   PF_ADD(c, 9, cnt);
   *regAngOut = regAngF;
@@ -386,9 +400,12 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int nWords = (a.spitch * a.sh + 31) / 32;
   GrowCtx c;
+  // LDS: ring | bitmap.  T aliases the ring: the ring is only live inside lsd_region_grow (which restarts it),
+  // T only inside region2rect / refine, which read the queue from global memory.  24 KiB bitmap + 2 KiB keeps a
+  // 512x384 frame at 26 KiB, i.e. 6 resident frames per CU (27 KiB already drops to 5, measured).
+  c.ring = (uint32_t*)smem;
   c.T = (double*)smem;
-  c.bm = (uint32_t*)(smem + 3 * 64 * 8);
-  c.ring = c.bm + nWords;
+  c.bm = c.ring + LSD_RING;
   c.G = reinterpret_cast<const LsdPix*>(a.pix) + (long long)b * a.scaledStride;
   c.S = reinterpret_cast<const float2*>(a.seedcs) + (long long)b * a.scaledStride;
   c.reg = a.reg + (long long)b * a.scaledStride;
@@ -817,6 +834,6 @@ extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsign
   return 0;
 }
 #endif
-size_t lsd_grow_lds_bytes(int spitch, int sh) { return (size_t)((spitch * sh + 31) / 32 + LSD_RING) * 4 + 3 * 64 * 8 + 64; }
+size_t lsd_grow_lds_bytes(int spitch, int sh) { return (size_t)((spitch * sh + 31) / 32 + LSD_RING) * 4; }
 
 }  // namespace plh

@@ -10,7 +10,12 @@ independent frames that are already resident in HBM:
     LSDmatcher(0.7).SearchDouble        frame b -> frame b+1                 (plh_line_search_double_batch_dev)
 
 Frame B's successor is frame 0 (its records are copied into slot B), so every frame is matched once.
-PyTorch only provides device memory and the stream; every computation is a kernel of libplslam_hip.so.
+PyTorch only provides device memory and the streams; every computation is a kernel of libplslam_hip.so.
+
+The ORB half (+ BoW + SearchByBoW) and the line half (+ SearchDouble) are independent until the results are
+consumed, exactly as the reference runs ExtractORB and ExtractLSD on two threads (Frame.cc:224-227): they are
+enqueued on two HIP streams.  LSD region growing is one latency-bound wavefront per frame (<= 6 per CU), so the
+ORB kernels run in the SIMD slots it leaves idle.
 """
 import ctypes as C
 
@@ -47,6 +52,13 @@ class FrontEndBatch:
         self.nm_line = z((batch,), torch.int32)
         self.ws_bytes = self.lib.plh_line_search_double_workspace(self.lcap, batch)
         self.ws = z((self.ws_bytes,), torch.uint8)
+        # the line chain is the critical path (image prep -> region growing -> LBD): high priority, so that its
+        # streaming kernels are dispatched first and the ORB kernels fill in underneath the region growing
+        self.line_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+        self.orb_stream = torch.cuda.Stream(device=self.dev, priority=0)
+        self.ev_start = torch.cuda.Event()
+        self.ev_orb = torch.cuda.Event()
+        self.ev_line = torch.cuda.Event()
         helper = P._Dev(self.lib, device)
         self.voc_dev = vocab.device_arrays(helper)
         L = self.lib
@@ -63,24 +75,40 @@ class FrontEndBatch:
     def step(self, d_imgs, stream=None):
         """Enqueue one pass over the resident batch `d_imgs` (uint8 [B, rows, cols]) on the current stream."""
         P, L, B, t = self.P, self.lib, self.B, self.torch
-        s = t.cuda.current_stream(self.dev).cuda_stream if stream is None else stream
-        sp = C.c_void_p(s)
+        main = t.cuda.current_stream(self.dev) if stream is None else t.cuda.ExternalStream(stream, device=self.dev)
         p = P._p
-        self.orb.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kps, self.desc, self.n, s)
-        self.line.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kl, self.ldesc, self.lfn, self.nl, s)
-        # slot B := frame 0 (so that frame B-1 has a successor)
-        for buf in (self.kps, self.desc, self.n, self.kl, self.ldesc, self.nl):
-            buf[B].copy_(buf[0], non_blocking=True)
         nd, cs, cc, wi, wt = self.voc_dev
+        self.ev_start.record(main)
+        # ---- line half on the high-priority stream
+        sl = self.line_stream
+        sl.wait_event(self.ev_start)
+        sm = sl.cuda_stream
+        self.line.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kl, self.ldesc, self.lfn, self.nl, sm)
+        with t.cuda.stream(sl):
+            for buf in (self.kl, self.ldesc, self.nl):
+                buf[B].copy_(buf[0], non_blocking=True)
+        P._check(L, L.plh_line_search_double_batch_dev(p(self.ldesc), p(self.nl), p(self.ldesc[1:]), p(self.nl[1:]), self.lcap, B,
+                                                       50.0, 0.7, p(self.m_line), p(self.nm_line), p(self.ws), self.ws_bytes,
+                                                       C.c_void_p(sm)),
+                 "plh_line_search_double_batch_dev")
+        # ---- ORB half on its own stream
+        so = self.orb_stream
+        so.wait_event(self.ev_start)
+        sp = C.c_void_p(so.cuda_stream)
+        self.orb.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kps, self.desc, self.n, so.cuda_stream)
+        with t.cuda.stream(so):   # slot B := frame 0 (so that frame B-1 has a successor)
+            for buf in (self.kps, self.desc, self.n):
+                buf[B].copy_(buf[0], non_blocking=True)
         P._check(L, L.plh_bow_transform_batch_dev(p(self.desc), p(self.n), self.ocap, B + 1, p(nd), p(cs), p(cc), p(wi), p(wt),
                                                   self.vocab.L, 4, p(self.nid), p(self.word), sp), "plh_bow_transform_batch_dev")
         P._check(L, L.plh_orb_search_by_bow_kp_batch_dev(p(self.desc), p(self.kps), p(self.nid), p(self.valid), p(self.n),
                                                          p(self.desc[1:]), p(self.kps[1:]), p(self.nid[1:]), p(self.n[1:]),
                                                          self.ocap, B, 50, 0.7, 1, p(self.m_orb), p(self.nm_orb), sp),
                  "plh_orb_search_by_bow_kp_batch_dev")
-        P._check(L, L.plh_line_search_double_batch_dev(p(self.ldesc), p(self.nl), p(self.ldesc[1:]), p(self.nl[1:]), self.lcap, B,
-                                                       50.0, 0.7, p(self.m_line), p(self.nm_line), p(self.ws), self.ws_bytes, sp),
-                 "plh_line_search_double_batch_dev")
+        self.ev_orb.record(so)
+        self.ev_line.record(sl)
+        main.wait_event(self.ev_orb)   # the step is complete on the caller's stream
+        main.wait_event(self.ev_line)
 
     def results(self):
         """Host copies of everything one step produced (synchronises)."""

@@ -29,8 +29,7 @@ def main():
     import torch
     P, S = _util.plslam(), _util.synth()
     lib = P.load()
-    if not hasattr(lib, "plh_debug_grow_prof"):
-        raise SystemExit("not a PLH_GROW_PROF build (set PLSLAM_HIP_LIB)")
+    prof = hasattr(lib, "plh_debug_grow_prof")   # only in a PLH_GROW_PROF build (set PLSLAM_HIP_LIB); else timing only
     B = a.batch
     frames = S.make_frames(2, B, 480, 640, unique=32)
     d = torch.from_numpy(frames).cuda()
@@ -46,16 +45,19 @@ def main():
     out = (C.c_ulonglong * 16)()
     le.extract_batch_dev(d, B, 480 * 640, kl, ld, fn, nl, s)
     torch.cuda.synchronize()
-    lib.plh_debug_grow_prof(out, 1)
+    if prof:
+        lib.plh_debug_grow_prof(out, 1)
     t0 = time.perf_counter()
     for _ in range(a.reps):
         le.extract_batch_dev(d, B, 480 * 640, kl, ld, fn, nl, s)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
+    print("line extract %.2f ms / batch of %d = %.0f frames/s" % (dt * 1e3, B, B / dt))
+    if not prof:
+        return
     lib.plh_debug_grow_prof(out, 0)
     n = B * a.reps
     res = {NAMES[i] if NAMES[i] != "-" else "c%d" % i: out[i] / n for i in range(16)}
-    print("line extract %.2f ms / batch of %d" % (dt * 1e3, B))
     for k, v in res.items():
         print("  %-16s %14.1f per frame" % (k, v))
     print(json.dumps(res))
