@@ -1,0 +1,432 @@
+// ORACLE (test infrastructure) -- CPU restatement of the windowed (grid) searches of the tracking front end:
+//   Frame::PosInGrid / AssignFeaturesToGrid            reference src/Frame.cc:278-293, 893-905
+//   Frame::AssignFeaturesToGridForLine + LineIterator   reference src/Frame.cc:295-320, src/lineIterator.cpp:34-77
+//   Frame::GetFeaturesInArea                            reference src/Frame.cc:713-766
+//   Frame::GetFeaturesInAreaForLine                     reference src/Frame.cc:768-842
+//   ORBmatcher::SearchForInitialization                 reference src/ORBmatcher.cc:455-572
+//   ORBmatcher::SearchByProjection(F, MapPoints, th)    reference src/ORBmatcher.cc:56-144
+//   ORBmatcher::SearchByProjection(Cur, Last, th, mono) reference src/ORBmatcher.cc:1441-1585
+//   LSDmatcher::SearchByProjection(Cur, Last, th)       reference src/LSDmatcher.cpp:72-176
+//   LSDmatcher::SearchByProjection(F, MapLines, th)     reference src/LSDmatcher.cpp:221-338
+// Frame / MapPoint / MapLine objects are replaced by flat arrays.  The boundary sits after the projection: a
+// query carries what the reference reads from the map element (mTrackProjX/Y, mnTrackScaleLevel, mTrackViewCos,
+// descriptor, "Observations() > 0") or what it computes from the pose (u, v); pose algebra on cv::Mat stays
+// with the caller.  The grid is CSR: cell (ix, iy) -> index ix*48 + iy, items in insertion order.
+// PARITY UNPINNED, see oracle/plo.h.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "plo.h"
+
+namespace {
+const int GRID_COLS = 64, GRID_ROWS = 48;   // Frame.h:44-45
+const int HISTO_LENGTH = 30;
+const int ORB_TH_HIGH = 100, ORB_TH_LOW = 50, LSD_TH_HIGH = 80;
+
+struct GridP { float min_x, min_y, max_x, max_y, inv_w, inv_h; };
+
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {   // ORBmatcher.cc:1718-1759
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// Frame::GetFeaturesInArea, Frame.cc:713-766
+void features_in_area(const plo_keypoint* kps, const GridP& g, const int32_t* cs, const int32_t* ci, float x, float y, float r,
+                      int minLevel, int maxLevel, std::vector<int>& out) {
+  out.clear();
+  const int nMinCellX = std::max(0, (int)floorf((x - g.min_x - r) * g.inv_w));
+  if (nMinCellX >= GRID_COLS) return;
+  const int nMaxCellX = std::min(GRID_COLS - 1, (int)ceilf((x - g.min_x + r) * g.inv_w));
+  if (nMaxCellX < 0) return;
+  const int nMinCellY = std::max(0, (int)floorf((y - g.min_y - r) * g.inv_h));
+  if (nMinCellY >= GRID_ROWS) return;
+  const int nMaxCellY = std::min(GRID_ROWS - 1, (int)ceilf((y - g.min_y + r) * g.inv_h));
+  if (nMaxCellY < 0) return;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      const int c = ix * GRID_ROWS + iy;
+      for (int j = cs[c]; j < cs[c + 1]; j++) {
+        const plo_keypoint& kp = kps[ci[j]];
+        if (bCheckLevels) {
+          if (kp.octave < minLevel) continue;
+          if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+        }
+        const float distx = kp.x - x, disty = kp.y - y;
+        if (fabsf(distx) < r && fabsf(disty) < r) out.push_back(ci[j]);
+      }
+    }
+}
+
+// Frame::GetFeaturesInAreaForLine, Frame.cc:768-842 (minLevel / maxLevel are ignored there).
+// `abs(float)` resolves to std::abs(float) (libstdc++ exports the overloads globally); sqrt on float operands.
+void features_in_area_for_line(const plo_keyline* kl, const double* fn, const GridP& g, const int32_t* cs, const int32_t* ci,
+                               float x1, float y1, float x2, float y2, float r, float TH, std::vector<int>& out,
+                               std::vector<uint8_t>& seen) {
+  out.clear();
+  const float x[3] = {x1, (float)((x1 + x2) / 2.0), x2};
+  const float y[3] = {y1, (float)((y1 + y2) / 2.0), y2};
+  float delta1x = x1 - x2, delta1y = y1 - y2;
+  const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
+  delta1x /= norm_delta1;
+  delta1y /= norm_delta1;
+  for (int i = 0; i < 3; i++) {
+    const int nMinCellX = std::max(0, (int)floorf((x[i] - g.min_x - r) * g.inv_w));
+    if (nMinCellX >= GRID_COLS) continue;
+    const int nMaxCellX = std::min(GRID_COLS - 1, (int)ceilf((x[i] - g.min_x + r) * g.inv_w));
+    if (nMaxCellX < 0) continue;
+    const int nMinCellY = std::max(0, (int)floorf((y[i] - g.min_y - r) * g.inv_h));
+    if (nMinCellY >= GRID_ROWS) continue;
+    const int nMaxCellY = std::min(GRID_ROWS - 1, (int)ceilf((y[i] - g.min_y + r) * g.inv_h));
+    if (nMaxCellY < 0) continue;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+        const int c = ix * GRID_ROWS + iy;
+        for (int j = cs[c]; j < cs[c + 1]; j++) {
+          const int id = ci[j];
+          if (seen[id]) continue;
+          const plo_keyline& k = kl[id];
+          float delta2x = k.startPointX - k.endPointX, delta2y = k.startPointY - k.endPointY;
+          const float norm_delta2 = sqrtf(delta2x * delta2x + delta2y * delta2y);
+          delta2x /= norm_delta2;
+          delta2y /= norm_delta2;
+          const float CosSita = fabsf(delta1x * delta2x + delta1y * delta2y);
+          if (CosSita < TH) continue;
+          const float dist = (float)(fn[id * 3 + 0] * x[i] + fn[id * 3 + 1] * y[i] + fn[id * 3 + 2]);
+          if (fabsf(dist) < r) {
+            out.push_back(id);
+            seen[id] = 1;
+          }
+        }
+      }
+  }
+  for (int id : out) seen[id] = 0;
+}
+}  // namespace
+
+extern "C" {
+
+// Frame::AssignFeaturesToGrid.  cell_start[64*48+1], cell_items[n].  Returns the number of keypoints placed.
+int plo_frame_assign_grid(const plo_keypoint* kps_un, int n, const float gp[6], int32_t* cell_start, int32_t* cell_items) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  std::vector<std::vector<int>> cells(GRID_COLS * GRID_ROWS);
+  for (int i = 0; i < n; i++) {
+    const int posX = (int)roundf((kps_un[i].x - g.min_x) * g.inv_w);   // PosInGrid: round(), not floor()
+    const int posY = (int)roundf((kps_un[i].y - g.min_y) * g.inv_h);
+    if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+    cells[posX * GRID_ROWS + posY].push_back(i);
+  }
+  int k = 0;
+  for (int c = 0; c < GRID_COLS * GRID_ROWS; c++) {
+    cell_start[c] = k;
+    for (int id : cells[c]) cell_items[k++] = id;
+  }
+  cell_start[GRID_COLS * GRID_ROWS] = k;
+  return k;
+}
+
+// Frame::AssignFeaturesToGridForLine with the custom Bresenham LineIterator.  Returns the number of items (a
+// line occupies every cell it crosses); items beyond `cap` are dropped (the return value still counts them).
+int plo_frame_assign_grid_lines(const plo_keyline* kl, int nl, const float gp[6], int32_t* cell_start, int32_t* cell_items,
+                                int cap) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  std::vector<std::vector<int>> cells(GRID_COLS * GRID_ROWS);
+  for (int i = 0; i < nl; i++) {
+    double x1 = kl[i].startPointX * g.inv_w, y1 = kl[i].startPointY * g.inv_h;   // float products, widened
+    double x2 = kl[i].endPointX * g.inv_w, y2 = kl[i].endPointY * g.inv_h;
+    const bool steep = std::abs(y2 - y1) > std::abs(x2 - x1);
+    if (steep) { std::swap(x1, y1); std::swap(x2, y2); }
+    if (x1 > x2) { std::swap(x1, x2); std::swap(y1, y2); }
+    const double dx = x2 - x1, dy = std::abs(y2 - y1);
+    double error = dx / 2.0;
+    const int ystep = (y1 < y2) ? 1 : -1;
+    int x = static_cast<int>(x1), y = static_cast<int>(y1);
+    const int maxX = static_cast<int>(x2);
+    while (x <= maxX) {
+      const int px = steep ? y : x, py = steep ? x : y;
+      error -= dy;
+      if (error < 0) { y += ystep; error += dx; }
+      x++;
+      if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) cells[px * GRID_ROWS + py].push_back(i);
+    }
+  }
+  int k = 0;
+  for (int c = 0; c < GRID_COLS * GRID_ROWS; c++) {
+    cell_start[c] = std::min(k, cap);
+    for (int id : cells[c]) {
+      if (k < cap) cell_items[k] = id;
+      k++;
+    }
+  }
+  cell_start[GRID_COLS * GRID_ROWS] = std::min(k, cap);
+  return k;
+}
+
+int plo_features_in_area(const plo_keypoint* kps_un, const float gp[6], const int32_t* cs, const int32_t* ci, float x, float y,
+                         float r, int min_level, int max_level, int32_t* out, int cap) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  std::vector<int> v;
+  features_in_area(kps_un, g, cs, ci, x, y, r, min_level, max_level, v);
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+  return (int)v.size();
+}
+
+int plo_features_in_area_for_line(const plo_keyline* kl, const double* fn, int nl, const float gp[6], const int32_t* cs,
+                                  const int32_t* ci, float x1, float y1, float x2, float y2, float r, float TH, int32_t* out,
+                                  int cap) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  std::vector<int> v;
+  std::vector<uint8_t> seen(std::max(nl, 1), 0);
+  features_in_area_for_line(kl, fn, g, cs, ci, x1, y1, x2, y2, r, TH, v, seen);
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+  return (int)v.size();
+}
+
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize).
+// kps1 = F1.mvKeysUn, kps2 = F2.mvKeysUn (+ F2's grid); prev_matched[n1][2] is updated in place.
+int plo_orb_search_for_initialization(const plo_keypoint* kps1, const uint8_t* desc1, int n1, const plo_keypoint* kps2,
+                                      const uint8_t* desc2, int n2, const float gp2[6], const int32_t* cs2, const int32_t* ci2,
+                                      float* prev_matched, int window_size, float nnratio, int check_ori, int32_t* matches12) {
+  GridP g;
+  memcpy(&g, gp2, sizeof(g));
+  int nmatches = 0;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<int> vMatchedDistance(std::max(n2, 1), INT_MAX), vnMatches21(std::max(n2, 1), -1), vIndices2;
+  for (int i1 = 0; i1 < n1; i1++) {
+    const int level1 = kps1[i1].octave;
+    if (level1 > 0) continue;
+    features_in_area(kps2, g, cs2, ci2, prev_matched[i1 * 2], prev_matched[i1 * 2 + 1], (float)window_size, level1, level1,
+                     vIndices2);
+    if (vIndices2.empty()) continue;
+    const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      const int dist = plo_descriptor_distance(d1, desc2 + (size_t)i2 * 32);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= ORB_TH_LOW) {
+      if (bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        matches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_ori) {
+          float rot = kps1[i1].angle - kps2[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)roundf(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(i1);
+        }
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i])
+        if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)
+    if (matches12[i1] >= 0) {
+      prev_matched[i1 * 2] = kps2[matches12[i1]].x;
+      prev_matched[i1 * 2 + 1] = kps2[matches12[i1]].y;
+    }
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th), monocular (mvuRight < 0).
+// Query iMP: q_valid = mbTrackInView && !isBad(); q_xy = (mTrackProjX, mTrackProjY); q_level = mnTrackScaleLevel;
+// q_viewcos = mTrackViewCos; q_hasobs = Observations() > 0.  occupied[idx] = F.mvpMapPoints[idx] &&
+// Observations() > 0 (updated as matches are assigned); assigned[idx] = query whose MapPoint now sits at idx.
+int plo_orb_search_by_projection_mp(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6], const int32_t* cs,
+                                    const int32_t* ci, const float* scale_factors, uint8_t* occupied, int nq,
+                                    const uint8_t* q_valid, const float* q_xy, const int32_t* q_level, const float* q_viewcos,
+                                    const uint8_t* q_desc, const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  int nmatches = 0;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
+  const bool bFactor = th != 1.0;
+  std::vector<int> vIndices;
+  for (int iMP = 0; iMP < nq; iMP++) {
+    if (!q_valid[iMP]) continue;
+    const int nPredictedLevel = q_level[iMP];
+    float r = q_viewcos[iMP] > 0.998 ? 2.5 : 4.0;   // RadiusByViewingCos, ORBmatcher.cc:146-152
+    if (bFactor) r *= th;
+    features_in_area(kps_un, g, cs, ci, q_xy[iMP * 2], q_xy[iMP * 2 + 1], r * scale_factors[nPredictedLevel], nPredictedLevel - 1,
+                     nPredictedLevel, vIndices);
+    if (vIndices.empty()) continue;
+    const uint8_t* MPdescriptor = q_desc + (size_t)iMP * 32;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (occupied[idx]) continue;
+      const int dist = plo_descriptor_distance(MPdescriptor, desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kps_un[idx].octave; bestIdx = idx; }
+      else if (dist < bestDist2) { bestLevel2 = kps_un[idx].octave; bestDist2 = dist; }
+    }
+    if (bestDist <= ORB_TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      assigned[bestIdx] = iMP;
+      occupied[bestIdx] = q_hasobs[iMP];
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono).
+// Query i = LastFrame feature i: q_valid = MapPoint present && !mvbOutlier[i] && invzc >= 0; q_uv = projection
+// (u, v) into the current frame; q_octave = LastFrame.mvKeys[i].octave; q_angle = LastFrame.mvKeysUn[i].angle;
+// q_desc = pMP->GetDescriptor(); mode 0 = monocular / lateral (octave-1 .. octave+1), 1 = forward
+// (>= octave), 2 = backward (0 .. octave).
+int plo_orb_search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                                       const int32_t* cs, const int32_t* ci, const float* scale_factors, uint8_t* occupied,
+                                       int nq, const uint8_t* q_valid, const float* q_uv, const int32_t* q_octave,
+                                       const float* q_angle, const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int mode,
+                                       int check_ori, int32_t* assigned) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  int nmatches = 0;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<int> vIndices2;
+  for (int i = 0; i < nq; i++) {
+    if (!q_valid[i]) continue;
+    const float u = q_uv[i * 2], v = q_uv[i * 2 + 1];
+    if (u < g.min_x || u > g.max_x) continue;
+    if (v < g.min_y || v > g.max_y) continue;
+    const int nLastOctave = q_octave[i];
+    const float radius = th * scale_factors[nLastOctave];
+    if (mode == 1) features_in_area(kps_un, g, cs, ci, u, v, radius, nLastOctave, -1, vIndices2);
+    else if (mode == 2) features_in_area(kps_un, g, cs, ci, u, v, radius, 0, nLastOctave, vIndices2);
+    else features_in_area(kps_un, g, cs, ci, u, v, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = q_desc + (size_t)i * 32;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (occupied[i2]) continue;
+      const int dist = plo_descriptor_distance(dMP, desc + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= ORB_TH_HIGH) {
+      assigned[bestIdx2] = i;
+      occupied[bestIdx2] = q_hasobs[i];
+      nmatches++;
+      if (check_ori) {
+        float rot = q_angle[i] - kps_un[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) { assigned[idx] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
+// LSDmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th).
+// Query i = LastFrame line i: q_valid = MapLine present && !mvbLineOutlier[i] && CurrentFrame.isInFrustum(pML, 0.5);
+// q_seg = (mTrackProjX1, Y1, X2, Y2); q_length = LastFrame.mvKeylinesUn[i].lineLength.
+int plo_line_search_by_projection_frame(const plo_keyline* kl, const uint8_t* ldesc, const double* fn, int nl, const float gp[6],
+                                        const int32_t* cs, const int32_t* ci, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                        const float* q_seg, const float* q_length, const uint8_t* q_desc,
+                                        const uint8_t* q_hasobs, float th, int32_t* assigned) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  int nmatches = 0;
+  for (int i = 0; i < nl; i++) assigned[i] = -1;
+  std::vector<int> vIndices2;
+  std::vector<uint8_t> seen(std::max(nl, 1), 0);
+  for (int i = 0; i < nq; i++) {
+    if (!q_valid[i]) continue;
+    const float radius = th;
+    features_in_area_for_line(kl, fn, g, cs, ci, q_seg[i * 4], q_seg[i * 4 + 1], q_seg[i * 4 + 2], q_seg[i * 4 + 3], radius, 0.96f,
+                              vIndices2, seen);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dML = q_desc + (size_t)i * 32;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (occupied[i2]) continue;
+      const int dist = plo_descriptor_distance(dML, ldesc + (size_t)i2 * 32);
+      const float max_ = std::max(q_length[i], kl[i2].lineLength), min_ = std::min(q_length[i], kl[i2].lineLength);
+      if (min_ / max_ < 0.75) continue;
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= LSD_TH_HIGH) {
+      assigned[bestIdx2] = i;
+      occupied[bestIdx2] = q_hasobs[i];
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+// LSDmatcher::SearchByProjection(Frame& F, const vector<MapLine*>&, th).
+int plo_line_search_by_projection_ml(const plo_keyline* kl, const uint8_t* ldesc, const double* fn, int nl, const float gp[6],
+                                     const int32_t* cs, const int32_t* ci, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                     const float* q_seg, const float* q_viewcos, const uint8_t* q_desc, const uint8_t* q_hasobs,
+                                     float th, float nnratio, int32_t* assigned) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  int nmatches = 0;
+  for (int i = 0; i < nl; i++) assigned[i] = -1;
+  const bool bFactor = th != 1.0;
+  std::vector<int> vIndices;
+  std::vector<uint8_t> seen(std::max(nl, 1), 0);
+  for (int iML = 0; iML < nq; iML++) {
+    if (!q_valid[iML]) continue;
+    float r = q_viewcos[iML] > 0.998 ? 5.0 : 8.0;   // LSDmatcher::RadiusByViewingCos, LSDmatcher.cpp:1004-1010
+    if (bFactor) r *= th;
+    features_in_area_for_line(kl, fn, g, cs, ci, q_seg[iML * 4], q_seg[iML * 4 + 1], q_seg[iML * 4 + 2], q_seg[iML * 4 + 3], r,
+                              0.998f, vIndices, seen);
+    if (vIndices.empty()) continue;
+    const uint8_t* MLdescriptor = q_desc + (size_t)iML * 32;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (occupied[idx]) continue;
+      const int dist = plo_descriptor_distance(MLdescriptor, ldesc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kl[idx].octave; bestIdx = idx; }
+      else if (dist < bestDist2) { bestLevel2 = kl[idx].octave; bestDist2 = dist; }
+    }
+    if (bestDist <= LSD_TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      assigned[bestIdx] = iML;
+      occupied[bestIdx] = q_hasobs[iML];
+      nmatches++;
+    }
+  }
+  (void)ORB_TH_LOW;
+  return nmatches;
+}
+
+}  // extern "C"

@@ -101,6 +101,38 @@ int  plo_line_extract(const uint8_t* img, int rows, int cols, size_t step, const
                       unsigned n_lsd_feature, double min_line_length,
                       plo_keyline* keylines, uint8_t* desc, double* linefn, int cap);           /* LINEextractor::operator() */
 
+/* ---- Windowed (grid) searches of the tracking front end (reference src/Frame.cc, ORBmatcher.cc, LSDmatcher.cpp;
+ *      oracle/frame_search.cc).  gp = {mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv};
+ *      grid = CSR over 64 x 48 cells, cell (ix, iy) -> ix*48 + iy. ---- */
+int  plo_frame_assign_grid(const plo_keypoint* kps_un, int n, const float gp[6], int32_t* cell_start, int32_t* cell_items);
+int  plo_frame_assign_grid_lines(const plo_keyline* kl, int nl, const float gp[6], int32_t* cell_start, int32_t* cell_items,
+                                 int cap);
+int  plo_features_in_area(const plo_keypoint* kps_un, const float gp[6], const int32_t* cs, const int32_t* ci, float x, float y,
+                          float r, int min_level, int max_level, int32_t* out, int cap);
+int  plo_features_in_area_for_line(const plo_keyline* kl, const double* fn, int nl, const float gp[6], const int32_t* cs,
+                                   const int32_t* ci, float x1, float y1, float x2, float y2, float r, float TH, int32_t* out,
+                                   int cap);
+int  plo_orb_search_for_initialization(const plo_keypoint* kps1, const uint8_t* desc1, int n1, const plo_keypoint* kps2,
+                                       const uint8_t* desc2, int n2, const float gp2[6], const int32_t* cs2, const int32_t* ci2,
+                                       float* prev_matched, int window_size, float nnratio, int check_ori, int32_t* matches12);
+int  plo_orb_search_by_projection_mp(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6], const int32_t* cs,
+                                     const int32_t* ci, const float* scale_factors, uint8_t* occupied, int nq,
+                                     const uint8_t* q_valid, const float* q_xy, const int32_t* q_level, const float* q_viewcos,
+                                     const uint8_t* q_desc, const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned);
+int  plo_orb_search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                                        const int32_t* cs, const int32_t* ci, const float* scale_factors, uint8_t* occupied,
+                                        int nq, const uint8_t* q_valid, const float* q_uv, const int32_t* q_octave,
+                                        const float* q_angle, const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int mode,
+                                        int check_ori, int32_t* assigned);
+int  plo_line_search_by_projection_frame(const plo_keyline* kl, const uint8_t* ldesc, const double* fn, int nl, const float gp[6],
+                                         const int32_t* cs, const int32_t* ci, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                         const float* q_seg, const float* q_length, const uint8_t* q_desc,
+                                         const uint8_t* q_hasobs, float th, int32_t* assigned);
+int  plo_line_search_by_projection_ml(const plo_keyline* kl, const uint8_t* ldesc, const double* fn, int nl, const float gp[6],
+                                      const int32_t* cs, const int32_t* ci, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                      const float* q_seg, const float* q_viewcos, const uint8_t* q_desc, const uint8_t* q_hasobs,
+                                      float th, float nnratio, int32_t* assigned);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,17 @@ _SIGS = {
     "plh_line_extract": ([_V, _V, _I, _I, _Z, _V, _V, _V, _V, _I, _V], _I),
     "plh_line_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
+    "plh_frame_assign_grid_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
+    "plh_frame_assign_grid_lines_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _I, _V], _I),
+    "plh_orb_search_for_initialization_batch_dev": ([_V] * 6 + [_I, _I, _V, _V, _V, _V, _I, _F, _I, _V, _V, _V], _I),
+    "plh_orb_search_by_projection_mp_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 6 +
+                                                  [_F, _F, _V, _V, _V], _I),
+    "plh_orb_search_by_projection_frame_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 6 +
+                                                     [_F, _I, _I, _V, _V, _V], _I),
+    "plh_line_search_by_projection_frame_batch_dev": ([_V, _V, _V, _V, _I, _I, _V, _V, _V, _I, _V, _V, _I] + [_V] * 5 +
+                                                      [_F, _V, _V, _V], _I),
+    "plh_line_search_by_projection_ml_batch_dev": ([_V, _V, _V, _V, _I, _I, _V, _V, _V, _I, _V, _V, _I] + [_V] * 5 +
+                                                   [_F, _F, _V, _V, _V], _I),
 }
 
 _libs = {}
@@ -309,6 +320,170 @@ def _pad_sets(sets, cap, width, dtype):
         if len(s):
             out[i, :len(s)] = s
     return out, n
+
+
+
+GRID_COLS, GRID_ROWS = 64, 48          # FRAME_GRID_COLS / FRAME_GRID_ROWS, include/Frame.h:44-45
+GRID_CELLS = GRID_COLS * GRID_ROWS
+
+
+class GridParams(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("inv_w", C.c_float), ("inv_h", C.c_float)]
+
+
+def grid_params(cols, rows, min_x=0.0, min_y=0.0, max_x=None, max_y=None):
+    """Frame::ComputeImageBounds + the static grid members (Frame.cc:113-117): bounds of the undistorted image and
+    mfGridElementWidthInv / HeightInv = 64 / (maxX - minX), 48 / (maxY - minY), all in float32."""
+    max_x = np.float32(cols if max_x is None else max_x)
+    max_y = np.float32(rows if max_y is None else max_y)
+    min_x, min_y = np.float32(min_x), np.float32(min_y)
+    return GridParams(min_x, min_y, max_x, max_y, np.float32(GRID_COLS) / (max_x - min_x), np.float32(GRID_ROWS) / (max_y - min_y))
+
+
+def _gp_array(gp):
+    return np.array([gp.min_x, gp.min_y, gp.max_x, gp.max_y, gp.inv_w, gp.inv_h], np.float32)
+
+
+def _pad_records(sets, cap, dtype):
+    """list of structured arrays -> (P, cap) array + counts."""
+    out = np.zeros((len(sets), cap), dtype)
+    n = np.zeros(len(sets), np.int32)
+    for i, s in enumerate(sets):
+        out[i, :len(s)] = s
+        n[i] = len(s)
+    return out, n
+
+
+class FrameSearch:
+    """The grid ("windowed") searches of the tracking thread on flat arrays, batched over independent frames.
+    One instance holds the device copies of a batch of frames (the `Frame` side of every call):
+      points: kps_un [KP_DTYPE], desc [n,32]         -> Frame::AssignFeaturesToGrid        (Frame.cc:278-293)
+      lines : keylines [KL_DTYPE], ldesc, linefn     -> Frame::AssignFeaturesToGridForLine (Frame.cc:295-320)
+    and exposes ORBmatcher::SearchForInitialization / SearchByProjection and LSDmatcher::SearchByProjection."""
+
+    def __init__(self, gp, scale_factors, frames, device=0, lib=None):
+        self.lib = load(lib)
+        self.D = _Dev(self.lib, device)
+        self.gp = gp
+        self.sf = np.ascontiguousarray(scale_factors, np.float32)
+        D, L = self.D, self.lib
+        self.P = len(frames)
+        s = C.c_void_p(D.stream())
+        self.cap = max(1, max(len(f.get("kps", ())) for f in frames))
+        kps, self.n = _pad_records([f.get("kps", np.zeros(0, KP_DTYPE)) for f in frames], self.cap, KP_DTYPE)
+        desc, _ = _pad_sets([f.get("desc", np.zeros((0, 32), np.uint8)) for f in frames], self.cap, 32, np.uint8)
+        self.d_kps, self.d_desc, self.d_n = D.put(kps), D.put(desc), D.put(self.n)
+        self.d_cs = D.empty((self.P, GRID_CELLS + 1), np.int32)
+        self.d_ci = D.empty((self.P, self.cap), np.int32)
+        _check(L, L.plh_frame_assign_grid_batch_dev(_p(self.d_kps), _p(self.d_n), self.cap, self.P, C.byref(gp), _p(self.d_cs),
+                                                    _p(self.d_ci), s), "plh_frame_assign_grid_batch_dev")
+        self.lcap = max(1, max(len(f.get("keylines", ())) for f in frames))
+        self.item_cap = self.lcap * GRID_COLS
+        kl, self.nl = _pad_records([f.get("keylines", np.zeros(0, KL_DTYPE)) for f in frames], self.lcap, KL_DTYPE)
+        ld, _ = _pad_sets([f.get("ldesc", np.zeros((0, 32), np.uint8)) for f in frames], self.lcap, 32, np.uint8)
+        fn, _ = _pad_sets([f.get("linefn", np.zeros((0, 3), np.float64)) for f in frames], self.lcap, 3, np.float64)
+        self.d_kl, self.d_ld, self.d_fn, self.d_nl = D.put(kl), D.put(ld), D.put(fn), D.put(self.nl)
+        self.d_lcs = D.empty((self.P, GRID_CELLS + 1), np.int32)
+        self.d_lci = D.empty((self.P, self.item_cap), np.int32)
+        _check(L, L.plh_frame_assign_grid_lines_batch_dev(_p(self.d_kl), _p(self.d_nl), self.lcap, self.P, C.byref(gp),
+                                                          _p(self.d_lcs), _p(self.d_lci), self.item_cap, s),
+               "plh_frame_assign_grid_lines_batch_dev")
+
+    def grids(self):
+        """(cell_start[P, 3073], cell_items[P, cap]) of the point grid and of the line grid."""
+        D = self.D
+        return (D.get(self.d_cs), D.get(self.d_ci)), (D.get(self.d_lcs), D.get(self.d_lci))
+
+    def _queries(self, qs, fields):
+        qcap = max(1, max(len(q["valid"]) for q in qs))
+        out = []
+        for name, width, dt in fields:
+            a, nq = _pad_sets([q[name] for q in qs], qcap, width, dt)
+            out.append(self.D.put(a))
+        return qcap, self.D.put(nq), out
+
+    def SearchForInitialization(self, f1s, prev_matched, windowSize=100, nnratio=0.9, checkOri=True):
+        """ORBmatcher(nnratio, checkOri).SearchForInitialization(F1, F2 = this frame, vbPrevMatched, vnMatches12,
+        windowSize).  f1s: list of dict(kps, desc); prev_matched: list of [n1, 2] float32 (returned updated).
+        Returns (matches12[P, cap], nmatches[P], prev_matched[P, cap, 2])."""
+        D, L = self.D, self.lib
+        cap = max(self.cap, max(len(f["kps"]) for f in f1s))
+        assert cap == self.cap, "F1 may not have more keypoints than the planned capacity"
+        k1, n1 = _pad_records([f["kps"] for f in f1s], cap, KP_DTYPE)
+        d1, _ = _pad_sets([f["desc"] for f in f1s], cap, 32, np.uint8)
+        pm, _ = _pad_sets(prev_matched, cap, 2, np.float32)
+        dk1, dd1, dn1, dpm = D.put(k1), D.put(d1), D.put(n1), D.put(pm)
+        dm, dc = D.empty((self.P, cap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_orb_search_for_initialization_batch_dev(
+            _p(dk1), _p(dd1), _p(dn1), _p(self.d_kps), _p(self.d_desc), _p(self.d_n), cap, self.P, C.byref(self.gp),
+            _p(self.d_cs), _p(self.d_ci), _p(dpm), int(windowSize), float(nnratio), int(checkOri), _p(dm), _p(dc),
+            C.c_void_p(D.stream())), "plh_orb_search_for_initialization_batch_dev")
+        return D.get(dm), D.get(dc), D.get(dpm)
+
+    def SearchByProjectionMapPoints(self, qs, occupied, th=1.0, nnratio=0.8):
+        """ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th).  qs: per frame dict(valid, xy, level, viewcos,
+        desc, hasobs); occupied: per frame u8[n].  Returns (assigned[P, cap], nmatches[P], occupied[P, cap])."""
+        D, L = self.D, self.lib
+        qcap, dnq, (qv, qxy, ql, qc, qd, qh) = self._queries(qs, [("valid", 0, np.uint8), ("xy", 2, np.float32),
+                                                                   ("level", 0, np.int32), ("viewcos", 0, np.float32),
+                                                                   ("desc", 32, np.uint8), ("hasobs", 0, np.uint8)])
+        occ, _ = _pad_sets(occupied, self.cap, 0, np.uint8)
+        docc = D.put(occ)
+        da, dc = D.empty((self.P, self.cap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_orb_search_by_projection_mp_batch_dev(
+            _p(self.d_kps), _p(self.d_desc), _p(self.d_n), self.cap, self.P, C.byref(self.gp), _p(self.d_cs), _p(self.d_ci),
+            _p(self.sf), len(self.sf), _p(docc), _p(dnq), qcap, _p(qv), _p(qxy), _p(ql), _p(qc), _p(qd), _p(qh), float(th),
+            float(nnratio), _p(da), _p(dc), C.c_void_p(D.stream())), "plh_orb_search_by_projection_mp_batch_dev")
+        return D.get(da), D.get(dc), D.get(docc)
+
+    def SearchByProjectionLastFrame(self, qs, occupied, th=15.0, mode=0, checkOri=True):
+        """ORBmatcher(0.9, checkOri).SearchByProjection(CurrentFrame = this frame, LastFrame, th, bMono).
+        qs: per frame dict(valid, uv, octave, angle, desc, hasobs)."""
+        D, L = self.D, self.lib
+        qcap, dnq, (qv, quv, qo, qa, qd, qh) = self._queries(qs, [("valid", 0, np.uint8), ("uv", 2, np.float32),
+                                                                   ("octave", 0, np.int32), ("angle", 0, np.float32),
+                                                                   ("desc", 32, np.uint8), ("hasobs", 0, np.uint8)])
+        occ, _ = _pad_sets(occupied, self.cap, 0, np.uint8)
+        docc = D.put(occ)
+        da, dc = D.empty((self.P, self.cap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_orb_search_by_projection_frame_batch_dev(
+            _p(self.d_kps), _p(self.d_desc), _p(self.d_n), self.cap, self.P, C.byref(self.gp), _p(self.d_cs), _p(self.d_ci),
+            _p(self.sf), len(self.sf), _p(docc), _p(dnq), qcap, _p(qv), _p(quv), _p(qo), _p(qa), _p(qd), _p(qh), float(th),
+            int(mode), int(checkOri), _p(da), _p(dc), C.c_void_p(D.stream())), "plh_orb_search_by_projection_frame_batch_dev")
+        return D.get(da), D.get(dc), D.get(docc)
+
+    def LineSearchByProjectionLastFrame(self, qs, occupied, th=8.0):
+        """LSDmatcher.SearchByProjection(CurrentFrame = this frame, LastFrame, th).
+        qs: per frame dict(valid, seg[nq,4], length, desc, hasobs)."""
+        D, L = self.D, self.lib
+        qcap, dnq, (qv, qs_, ql, qd, qh) = self._queries(qs, [("valid", 0, np.uint8), ("seg", 4, np.float32),
+                                                              ("length", 0, np.float32), ("desc", 32, np.uint8),
+                                                              ("hasobs", 0, np.uint8)])
+        occ, _ = _pad_sets(occupied, self.lcap, 0, np.uint8)
+        docc = D.put(occ)
+        da, dc = D.empty((self.P, self.lcap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_line_search_by_projection_frame_batch_dev(
+            _p(self.d_kl), _p(self.d_ld), _p(self.d_fn), _p(self.d_nl), self.lcap, self.P, C.byref(self.gp), _p(self.d_lcs),
+            _p(self.d_lci), self.item_cap, _p(docc), _p(dnq), qcap, _p(qv), _p(qs_), _p(ql), _p(qd), _p(qh), float(th),
+            _p(da), _p(dc), C.c_void_p(D.stream())), "plh_line_search_by_projection_frame_batch_dev")
+        return D.get(da), D.get(dc), D.get(docc)
+
+    def LineSearchByProjectionMapLines(self, qs, occupied, th=1.0, nnratio=0.7):
+        """LSDmatcher(nnratio).SearchByProjection(F = this frame, vpMapLines, th).
+        qs: per frame dict(valid, seg[nq,4], viewcos, desc, hasobs)."""
+        D, L = self.D, self.lib
+        qcap, dnq, (qv, qs_, qc, qd, qh) = self._queries(qs, [("valid", 0, np.uint8), ("seg", 4, np.float32),
+                                                              ("viewcos", 0, np.float32), ("desc", 32, np.uint8),
+                                                              ("hasobs", 0, np.uint8)])
+        occ, _ = _pad_sets(occupied, self.lcap, 0, np.uint8)
+        docc = D.put(occ)
+        da, dc = D.empty((self.P, self.lcap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_line_search_by_projection_ml_batch_dev(
+            _p(self.d_kl), _p(self.d_ld), _p(self.d_fn), _p(self.d_nl), self.lcap, self.P, C.byref(self.gp), _p(self.d_lcs),
+            _p(self.d_lci), self.item_cap, _p(docc), _p(dnq), qcap, _p(qv), _p(qs_), _p(qc), _p(qd), _p(qh), float(th),
+            float(nnratio), _p(da), _p(dc), C.c_void_p(D.stream())), "plh_line_search_by_projection_ml_batch_dev")
+        return D.get(da), D.get(dc), D.get(docc)
 
 
 class LSDmatcher:

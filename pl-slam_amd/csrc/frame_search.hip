@@ -1,0 +1,704 @@
+// Windowed (grid) searches of the tracking front end, batch-first (gfx950 / CDNA4, wave64).
+//
+//   k_grid_points / k_grid_lines   Frame::AssignFeaturesToGrid / AssignFeaturesToGridForLine (+ LineIterator)
+//                                  reference src/Frame.cc:278-320, 893-905; src/lineIterator.cpp:34-77
+//   k_search_init                  ORBmatcher::SearchForInitialization            src/ORBmatcher.cc:455-572
+//   k_search_proj_points           ORBmatcher::SearchByProjection(F, MapPoints)    src/ORBmatcher.cc:56-144
+//                                  ORBmatcher::SearchByProjection(Cur, Last)       src/ORBmatcher.cc:1441-1585
+//   k_search_proj_lines            LSDmatcher::SearchByProjection(Cur, Last)       src/LSDmatcher.cpp:72-176
+//                                  LSDmatcher::SearchByProjection(F, MapLines)     src/LSDmatcher.cpp:221-338
+//   (candidate generation = Frame::GetFeaturesInArea / GetFeaturesInAreaForLine, src/Frame.cc:713-842)
+//
+// Every search is greedy and order dependent (a keypoint taken by an earlier query is skipped by later ones), so
+// one wavefront walks the queries of a frame pair in the reference's order; inside a query the 64 lanes gather
+// the candidates of the grid window (one grid column = one contiguous CSR range), compute the 256-bit Hamming
+// distances in parallel, and the best / second-best replay runs over the candidate list in the reference's
+// enumeration order.  Per-frame match state lives in LDS.  Throughput comes from the batch (one wave per pair).
+#include "plh_common.h"
+
+namespace plh {
+
+#if defined(HIPEMU)
+#define FS_WAVE_SYNC() hipemu::wave_barrier()
+#else
+#define FS_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+constexpr int GCOLS = PLH_GRID_COLS, GROWS = PLH_GRID_ROWS, GCELLS = PLH_GRID_CELLS;
+
+struct ScaleTab {
+  float v[16];
+};
+
+__device__ __forceinline__ int hamming_rows(const uint8_t* a, const uint8_t* b) {
+  const unsigned long long* x = reinterpret_cast<const unsigned long long*>(a);
+  const unsigned long long* y = reinterpret_cast<const unsigned long long*>(b);
+  return __popcll(x[0] ^ y[0]) + __popcll(x[1] ^ y[1]) + __popcll(x[2] ^ y[2]) + __popcll(x[3] ^ y[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Grid construction: count -> exclusive scan -> scatter (atomics) -> per-cell ascending sort (= insertion order,
+// because the reference appends feature indices in increasing order).  One 256-thread block per frame.
+// ------------------------------------------------------------------------------------------------------------
+__device__ void grid_scan_and_publish(int* cnt, int* part, int32_t* cellStart) {
+  const int tid = threadIdx.x;
+  constexpr int PER = GCELLS / 256;   // 12
+  int s = 0;
+  for (int k = 0; k < PER; k++) s += cnt[tid * PER + k];
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  for (int k = 0; k < PER; k++) {
+    const int c = cnt[tid * PER + k];
+    cellStart[tid * PER + k] = run;
+    cnt[tid * PER + k] = run;   // becomes the scatter cursor
+    run += c;
+  }
+  if (tid == 255) cellStart[GCELLS] = run;
+  __syncthreads();
+}
+
+__device__ void grid_sort_cells(const int32_t* cellStart, int32_t* items) {
+  for (int c = threadIdx.x; c < GCELLS; c += 256) {
+    const int s = cellStart[c], e = cellStart[c + 1];
+    for (int i = s + 1; i < e; i++) {
+      const int v = items[i];
+      int j = i - 1;
+      while (j >= s && items[j] > v) { items[j + 1] = items[j]; j--; }
+      items[j + 1] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_grid_points(const plh_keypoint* kps, const int* nArr, int cap, plh_grid_params g,
+                                                     int32_t* cellStartAll, int32_t* itemsAll) {
+  __shared__ int cnt[GCELLS];
+  __shared__ int part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = min(nArr[b], cap);
+  const plh_keypoint* K = kps + (long long)b * cap;
+  int32_t* cellStart = cellStartAll + (long long)b * (GCELLS + 1);
+  int32_t* items = itemsAll + (long long)b * cap;
+  for (int i = tid; i < GCELLS; i += 256) cnt[i] = 0;
+  __syncthreads();
+  auto cellOf = [&](int i) -> int {   // Frame::PosInGrid: round(), not floor()
+    const int posX = (int)roundf((K[i].x - g.min_x) * g.inv_w);
+    const int posY = (int)roundf((K[i].y - g.min_y) * g.inv_h);
+    if (posX < 0 || posX >= GCOLS || posY < 0 || posY >= GROWS) return -1;
+    return posX * GROWS + posY;
+  };
+  for (int i = tid; i < n; i += 256) {
+    const int c = cellOf(i);
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+  }
+  __syncthreads();
+  grid_scan_and_publish(cnt, part, cellStart);
+  for (int i = tid; i < n; i += 256) {
+    const int c = cellOf(i);
+    if (c >= 0) items[atomicAdd(&cnt[c], 1)] = i;
+  }
+  __syncthreads();
+  __threadfence_block();
+  grid_sort_cells(cellStart, items);
+}
+
+// The reference's Bresenham-style LineIterator over grid coordinates; calls f(cell) for every in-range cell.
+template <typename F>
+__device__ __forceinline__ void line_cells(const plh_keyline& kl, const plh_grid_params& g, F f) {
+  double x1 = (double)(kl.startPointX * g.inv_w), y1 = (double)(kl.startPointY * g.inv_h);
+  double x2 = (double)(kl.endPointX * g.inv_w), y2 = (double)(kl.endPointY * g.inv_h);
+  const bool steep = fabs(y2 - y1) > fabs(x2 - x1);
+  if (steep) { double t = x1; x1 = y1; y1 = t; t = x2; x2 = y2; y2 = t; }
+  if (x1 > x2) { double t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+  const double dx = x2 - x1, dy = fabs(y2 - y1);
+  double error = dx / 2.0;
+  const int ystep = (y1 < y2) ? 1 : -1;
+  int x = (int)x1, y = (int)y1;
+  const int maxX = (int)x2;
+  while (x <= maxX) {
+    const int px = steep ? y : x, py = steep ? x : y;
+    error -= dy;
+    if (error < 0) { y += ystep; error += dx; }
+    x++;
+    if (px >= 0 && px < GCOLS && py >= 0 && py < GROWS) f(px * GROWS + py);
+    if (x > 4096) break;   // NaN / absurd coordinates: bounded walk
+  }
+}
+
+__global__ void __launch_bounds__(256) k_grid_lines(const plh_keyline* kls, const int* nArr, int cap, plh_grid_params g,
+                                                    int32_t* cellStartAll, int32_t* itemsAll, int itemCap) {
+  __shared__ int cnt[GCELLS];
+  __shared__ int part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = min(nArr[b], cap);
+  const plh_keyline* K = kls + (long long)b * cap;
+  int32_t* cellStart = cellStartAll + (long long)b * (GCELLS + 1);
+  int32_t* items = itemsAll + (long long)b * itemCap;
+  for (int i = tid; i < GCELLS; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) line_cells(K[i], g, [&](int c) { atomicAdd(&cnt[c], 1); });
+  __syncthreads();
+  grid_scan_and_publish(cnt, part, cellStart);
+  for (int i = tid; i < n; i += 256)
+    line_cells(K[i], g, [&](int c) {
+      const int pos = atomicAdd(&cnt[c], 1);
+      if (pos < itemCap) items[pos] = i;
+    });
+  __syncthreads();
+  __threadfence_block();
+  grid_sort_cells(cellStart, items);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Candidate generation
+// ------------------------------------------------------------------------------------------------------------
+struct CellWin {
+  int x0, x1, y0, y1;
+  bool ok;
+};
+__device__ __forceinline__ CellWin cell_window(const plh_grid_params& g, float x, float y, float r) {
+  CellWin w;
+  w.ok = false;
+  w.x0 = max(0, (int)floorf((x - g.min_x - r) * g.inv_w));
+  if (w.x0 >= GCOLS) return w;
+  w.x1 = min(GCOLS - 1, (int)ceilf((x - g.min_x + r) * g.inv_w));
+  if (w.x1 < 0) return w;
+  w.y0 = max(0, (int)floorf((y - g.min_y - r) * g.inv_h));
+  if (w.y0 >= GROWS) return w;
+  w.y1 = min(GROWS - 1, (int)ceilf((y - g.min_y + r) * g.inv_h));
+  if (w.y1 < 0) return w;
+  w.ok = true;
+  return w;
+}
+
+// Frame::GetFeaturesInArea: candidate indices in the reference's order (ix, then iy, then insertion order) into
+// list[]; returns their number (uniform).
+__device__ int collect_points(const plh_keypoint* K, const plh_grid_params& g, const int32_t* cs, const int32_t* ci, float x,
+                              float y, float r, int minLevel, int maxLevel, int* list, int lane) {
+  const CellWin w = cell_window(g, x, y, r);
+  if (!w.ok) return 0;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  int cnt = 0;
+  for (int ix = w.x0; ix <= w.x1; ix++) {
+    const int s = cs[ix * GROWS + w.y0], e = cs[ix * GROWS + w.y1 + 1];
+    for (int base = s; base < e; base += 64) {
+      const int j = base + lane;
+      bool ok = false;
+      int id = 0;
+      if (j < e) {
+        id = ci[j];
+        const plh_keypoint kp = K[id];
+        ok = true;
+        if (bCheckLevels) {
+          if (kp.octave < minLevel) ok = false;
+          if (maxLevel >= 0 && kp.octave > maxLevel) ok = false;
+        }
+        const float distx = kp.x - x, disty = kp.y - y;
+        if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
+      }
+      const unsigned long long m = __ballot(ok);
+      if (ok) list[cnt + __popcll(m & lanemask_lt())] = id;
+      cnt += __popcll(m);
+    }
+  }
+  return cnt;
+}
+
+// Frame::GetFeaturesInAreaForLine (minLevel / maxLevel are ignored by the reference).  seen[] must be all zero on
+// entry and is restored to zero on exit.
+__device__ int collect_lines(const plh_keyline* K, const double* fn, const plh_grid_params& g, const int32_t* cs,
+                             const int32_t* ci, float x1, float y1, float x2, float y2, float r, float TH, int* list,
+                             unsigned char* seen, int lane) {
+  const float xs[3] = {x1, (float)((x1 + x2) / 2.0), x2};
+  const float ys[3] = {y1, (float)((y1 + y2) / 2.0), y2};
+  float delta1x = x1 - x2, delta1y = y1 - y2;
+  const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
+  delta1x /= norm_delta1;
+  delta1y /= norm_delta1;
+  int cnt = 0;
+  for (int i = 0; i < 3; i++) {
+    const CellWin w = cell_window(g, xs[i], ys[i], r);
+    if (!w.ok) continue;
+    for (int ix = w.x0; ix <= w.x1; ix++) {
+      const int s = cs[ix * GROWS + w.y0], e = cs[ix * GROWS + w.y1 + 1];
+      for (int base = s; base < e; base += 64) {
+        const int j = base + lane;
+        bool ok = false;
+        int id = 0;
+        FS_WAVE_SYNC();
+        if (j < e) {
+          id = ci[j];
+          if (!seen[id]) {
+            const plh_keyline k = K[id];
+            float delta2x = k.startPointX - k.endPointX, delta2y = k.startPointY - k.endPointY;
+            const float norm_delta2 = sqrtf(delta2x * delta2x + delta2y * delta2y);
+            delta2x /= norm_delta2;
+            delta2y /= norm_delta2;
+            const float CosSita = fabsf(delta1x * delta2x + delta1y * delta2y);
+            if (!(CosSita < TH)) {
+              const float dist = (float)(fn[id * 3 + 0] * (double)xs[i] + fn[id * 3 + 1] * (double)ys[i] + fn[id * 3 + 2]);
+              ok = fabsf(dist) < r;
+            }
+          }
+        }
+        // the same line sits in several cells of the window: only its first occurrence is appended
+        unsigned long long m = __ballot(ok);
+        while (m) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const int idl = __shfl(id, l);
+          FS_WAVE_SYNC();
+          if (!seen[idl]) {
+            FS_WAVE_SYNC();
+            if (lane == 0) { list[cnt] = idl; seen[idl] = 1; }
+            cnt++;
+          }
+        }
+      }
+    }
+  }
+  FS_WAVE_SYNC();
+  for (int t = lane; t < cnt; t += 64) seen[list[t]] = 0;
+  FS_WAVE_SYNC();
+  return cnt;
+}
+
+__device__ __forceinline__ void three_maxima_lanes(int myHist, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  ind1 = -1; ind2 = -1; ind3 = -1;
+  for (int b = 0; b < 30; b++) {
+    const int s = __shfl(myHist, b);
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+    else if (s > max3) { max3 = s; ind3 = b; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+__device__ __forceinline__ int rot_bin(float a1, float a2) {
+  const float factor = 1.0f / 30;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == 30) bin = 0;
+  return bin;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForInitialization.  LDS: list[cap] dist[cap] m12[cap] m21[cap] mdist[cap] (int) + bin1[cap] (u8)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_search_init(const plh_keypoint* kps1, const uint8_t* desc1, const int* n1Arr,
+                                                    const plh_keypoint* kps2, const uint8_t* desc2, const int* n2Arr, int cap,
+                                                    plh_grid_params g, const int32_t* csAll, const int32_t* ciAll,
+                                                    float* prevMatched, int windowSize, float nnratio, int checkOri,
+                                                    int32_t* matches12, int32_t* nmatchesOut) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  int* list = (int*)smem;
+  int* dist = list + cap;
+  int* m12 = dist + cap;
+  int* m21 = m12 + cap;
+  int* mdist = m21 + cap;
+  unsigned char* bin1 = (unsigned char*)(mdist + cap);
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  const long long o = (long long)pair * cap;
+  const plh_keypoint *K1 = kps1 + o, *K2 = kps2 + o;
+  const uint8_t *D1 = desc1 + o * 32, *D2 = desc2 + o * 32;
+  const int32_t* cs = csAll + (long long)pair * (GCELLS + 1);
+  const int32_t* ci = ciAll + o;
+  float* PM = prevMatched + o * 2;
+  const int n1 = min(n1Arr[pair], cap), n2 = min(n2Arr[pair], cap);
+  for (int i = lane; i < cap; i += 64) { m12[i] = -1; m21[i] = -1; mdist[i] = 0x7fffffff; bin1[i] = 255; }
+  FS_WAVE_SYNC();
+  int nmatches = 0, myHist = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    const int level1 = K1[i1].octave;
+    if (level1 > 0) continue;
+    FS_WAVE_SYNC();
+    const int K = collect_points(K2, g, cs, ci, PM[i1 * 2], PM[i1 * 2 + 1], (float)windowSize, level1, level1, list, lane);
+    if (K == 0) continue;
+    FS_WAVE_SYNC();
+    for (int t = lane; t < K; t += 64) dist[t] = hamming_rows(D1 + (long long)i1 * 32, D2 + (long long)list[t] * 32);
+    FS_WAVE_SYNC();
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+    for (int t = 0; t < K; t++) {
+      const int i2 = list[t], d = dist[t];
+      if (mdist[i2] <= d) continue;
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
+      else if (d < bestDist2) { bestDist2 = d; }
+    }
+    if (bestDist <= 50) {
+      if ((float)bestDist < (float)bestDist2 * nnratio) {
+        FS_WAVE_SYNC();
+        const int prev = m21[bestIdx2];
+        FS_WAVE_SYNC();
+        if (prev >= 0) { m12[prev] = -1; nmatches--; }
+        m12[i1] = bestIdx2;
+        m21[bestIdx2] = i1;
+        mdist[bestIdx2] = bestDist;
+        nmatches++;
+        if (checkOri) {
+          const int bin = rot_bin(K1[i1].angle, K2[bestIdx2].angle);
+          bin1[i1] = (unsigned char)bin;
+          if (lane == bin) myHist++;
+        }
+      }
+    }
+  }
+  FS_WAVE_SYNC();
+  if (checkOri) {
+    int ind1, ind2, ind3;
+    three_maxima_lanes(myHist, ind1, ind2, ind3);
+    int removed = 0;
+    for (int i = lane; i < n1; i += 64) {
+      const int b = bin1[i];
+      if (b != 255 && b != ind1 && b != ind2 && b != ind3 && m12[i] >= 0) { m12[i] = -1; removed++; }
+    }
+    nmatches -= wave_sum(removed);
+  }
+  FS_WAVE_SYNC();
+  for (int i = lane; i < cap; i += 64) {
+    const int m = i < n1 ? m12[i] : -1;
+    matches12[o + i] = m;
+    if (m >= 0) { PM[i * 2] = K2[m].x; PM[i * 2 + 1] = K2[m].y; }
+  }
+  if (lane == 0) nmatchesOut[pair] = nmatches;
+  (void)n2;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection, both forms.  variant 0: (F, MapPoints, th) -- radius from the viewing cosine,
+// levels (l-1, l), best + second with the same-level ratio test; variant 1: (Cur, Last, th, mono) -- image-bounds
+// test, radius th*scale[octave], level band by `mode`, best only, rotation histogram.
+// LDS: list[cap] dist[cap] asg[cap] (int) + occ[cap] (u8) ; per query (variant 1): pushBin[qcap] (u8), pushIdx[qcap] (int)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_search_proj_points(int variant, const plh_keypoint* kps, const uint8_t* desc,
+                                                           const int* nArr, int cap, plh_grid_params g, const int32_t* csAll,
+                                                           const int32_t* ciAll, ScaleTab sf, uint8_t* occupiedAll,
+                                                           const int* nqArr, int qcap, const uint8_t* qValid, const float* qXY,
+                                                           const int32_t* qLevel, const float* qAux, const uint8_t* qDesc,
+                                                           const uint8_t* qHasObs, float th, float nnratio, int mode,
+                                                           int checkOri, int32_t* assignedAll, int32_t* nmatchesOut) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  int* list = (int*)smem;
+  int* dist = list + cap;
+  int* asg = dist + cap;
+  int* pushIdx = asg + cap;
+  unsigned char* occ = (unsigned char*)(pushIdx + qcap);
+  unsigned char* pushBin = occ + cap;
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
+  const plh_keypoint* K = kps + o;
+  const uint8_t* D = desc + o * 32;
+  const int32_t* cs = csAll + (long long)pair * (GCELLS + 1);
+  const int32_t* ci = ciAll + o;
+  const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
+  for (int i = lane; i < cap; i += 64) { asg[i] = -1; occ[i] = i < n ? occupiedAll[o + i] : 1; }
+  for (int i = lane; i < qcap; i += 64) pushBin[i] = 255;
+  FS_WAVE_SYNC();
+  int nmatches = 0, myHist = 0;
+  const bool bFactor = th != 1.0;
+  for (int q = 0; q < nq; q++) {
+    if (!qValid[qo + q]) continue;
+    const float x = qXY[(qo + q) * 2], y = qXY[(qo + q) * 2 + 1];
+    const int lvl = qLevel[qo + q];
+    float radius;
+    int minL, maxL;
+    if (variant == 0) {
+      float r = qAux[qo + q] > 0.998 ? 2.5 : 4.0;   // RadiusByViewingCos
+      if (bFactor) r *= th;
+      radius = r * sf.v[lvl];
+      minL = lvl - 1; maxL = lvl;
+    } else {
+      if (x < g.min_x || x > g.max_x) continue;
+      if (y < g.min_y || y > g.max_y) continue;
+      radius = th * sf.v[lvl];
+      if (mode == 1) { minL = lvl; maxL = -1; }
+      else if (mode == 2) { minL = 0; maxL = lvl; }
+      else { minL = lvl - 1; maxL = lvl + 1; }
+    }
+    FS_WAVE_SYNC();
+    const int Kc = collect_points(K, g, cs, ci, x, y, radius, minL, maxL, list, lane);
+    if (Kc == 0) continue;
+    FS_WAVE_SYNC();
+    for (int t = lane; t < Kc; t += 64) dist[t] = hamming_rows(qDesc + (qo + q) * 32, D + (long long)list[t] * 32);
+    FS_WAVE_SYNC();
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int t = 0; t < Kc; t++) {
+      const int idx = list[t];
+      if (occ[idx]) continue;
+      const int d = dist[t];
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = K[idx].octave; bestIdx = idx; }
+      else if (variant == 0 && d < bestDist2) { bestLevel2 = K[idx].octave; bestDist2 = d; }
+    }
+    if (bestDist <= 100) {
+      if (variant == 0 && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      FS_WAVE_SYNC();
+      asg[bestIdx] = q;
+      occ[bestIdx] = qHasObs[qo + q];
+      nmatches++;
+      if (variant == 1 && checkOri) {
+        const int bin = rot_bin(qAux[qo + q], K[bestIdx].angle);
+        pushBin[q] = (unsigned char)bin;
+        pushIdx[q] = bestIdx;
+        if (lane == bin) myHist++;
+      }
+    }
+  }
+  FS_WAVE_SYNC();
+  if (variant == 1 && checkOri) {
+    int ind1, ind2, ind3;
+    three_maxima_lanes(myHist, ind1, ind2, ind3);
+    int removed = 0;
+    for (int q = lane; q < nq; q += 64) {
+      const int b = pushBin[q];
+      if (b != 255 && b != ind1 && b != ind2 && b != ind3) { asg[pushIdx[q]] = -1; removed++; }
+    }
+    nmatches -= wave_sum(removed);
+  }
+  FS_WAVE_SYNC();
+  for (int i = lane; i < cap; i += 64) {
+    assignedAll[o + i] = i < n ? asg[i] : -1;
+    if (i < n) occupiedAll[o + i] = occ[i];
+  }
+  if (lane == 0) nmatchesOut[pair] = nmatches;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LSDmatcher::SearchByProjection, both forms.  variant 0: (F, MapLines, th); variant 1: (Cur, Last, th).
+// LDS: list[cap] dist[cap] asg[cap] (int) + occ[cap] seen[cap] (u8)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_search_proj_lines(int variant, const plh_keyline* kls, const uint8_t* ldesc,
+                                                          const double* fnAll, const int* nArr, int cap, plh_grid_params g,
+                                                          const int32_t* csAll, const int32_t* ciAll, int itemCap,
+                                                          uint8_t* occupiedAll, const int* nqArr, int qcap,
+                                                          const uint8_t* qValid, const float* qSeg, const float* qAux,
+                                                          const uint8_t* qDesc, const uint8_t* qHasObs, float th, float nnratio,
+                                                          int32_t* assignedAll, int32_t* nmatchesOut) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  int* list = (int*)smem;
+  int* dist = list + cap;
+  int* asg = dist + cap;
+  unsigned char* occ = (unsigned char*)(asg + cap);
+  unsigned char* seen = occ + cap;
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
+  const plh_keyline* K = kls + o;
+  const uint8_t* D = ldesc + o * 32;
+  const double* fn = fnAll + o * 3;
+  const int32_t* cs = csAll + (long long)pair * (GCELLS + 1);
+  const int32_t* ci = ciAll + (long long)pair * itemCap;
+  const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
+  for (int i = lane; i < cap; i += 64) { asg[i] = -1; seen[i] = 0; occ[i] = i < n ? occupiedAll[o + i] : 1; }
+  FS_WAVE_SYNC();
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int q = 0; q < nq; q++) {
+    if (!qValid[qo + q]) continue;
+    const float* sg = qSeg + (qo + q) * 4;
+    float r, TH;
+    if (variant == 0) {
+      r = qAux[qo + q] > 0.998 ? 5.0 : 8.0;   // LSDmatcher::RadiusByViewingCos
+      if (bFactor) r *= th;
+      TH = 0.998f;
+    } else {
+      r = th;
+      TH = 0.96f;
+    }
+    FS_WAVE_SYNC();
+    const int Kc = collect_lines(K, fn, g, cs, ci, sg[0], sg[1], sg[2], sg[3], r, TH, list, seen, lane);
+    if (Kc == 0) continue;
+    for (int t = lane; t < Kc; t += 64) dist[t] = hamming_rows(qDesc + (qo + q) * 32, D + (long long)list[t] * 32);
+    FS_WAVE_SYNC();
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int t = 0; t < Kc; t++) {
+      const int idx = list[t];
+      if (occ[idx]) continue;
+      const int d = dist[t];
+      if (variant == 1) {
+        const float la = qAux[qo + q], lb = K[idx].lineLength;
+        const float max_ = fmaxf(la, lb), min_ = fminf(la, lb);
+        if (min_ / max_ < 0.75) continue;
+        if (d < bestDist) { bestDist = d; bestIdx = idx; }
+      } else {
+        if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = K[idx].octave; bestIdx = idx; }
+        else if (d < bestDist2) { bestLevel2 = K[idx].octave; bestDist2 = d; }
+      }
+    }
+    if (bestDist <= 80) {
+      if (variant == 0 && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      FS_WAVE_SYNC();
+      asg[bestIdx] = q;
+      occ[bestIdx] = qHasObs[qo + q];
+      nmatches++;
+    }
+  }
+  FS_WAVE_SYNC();
+  for (int i = lane; i < cap; i += 64) {
+    assignedAll[o + i] = i < n ? asg[i] : -1;
+    if (i < n) occupiedAll[o + i] = occ[i];
+  }
+  if (lane == 0) nmatchesOut[pair] = nmatches;
+}
+
+}  // namespace plh
+
+using namespace plh;
+
+namespace {
+bool scale_tab(const float* sf, int nlevels, ScaleTab* t) {
+  if (!sf || nlevels <= 0 || nlevels > 16) return false;
+  for (int i = 0; i < 16; i++) t->v[i] = i < nlevels ? sf[i] : 0.f;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+plh_status plh_frame_assign_grid_batch_dev(const plh_keypoint* d_kps_un, const int32_t* d_n, int cap, int batch,
+                                           const plh_grid_params* gp, int32_t* d_cell_start, int32_t* d_cell_items,
+                                           void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_kps_un || !d_n || !gp || !d_cell_start || !d_cell_items || cap <= 0 || batch <= 0) {
+    set_error("plh_frame_assign_grid_batch_dev: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(k_grid_points, dim3(batch), dim3(256), 0, (hipStream_t)stream, d_kps_un, (const int*)d_n, cap, *gp,
+                     d_cell_start, d_cell_items);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_frame_assign_grid_lines_batch_dev(const plh_keyline* d_kl, const int32_t* d_nl, int cap, int batch,
+                                                 const plh_grid_params* gp, int32_t* d_cell_start, int32_t* d_cell_items,
+                                                 int item_cap, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_kl || !d_nl || !gp || !d_cell_start || !d_cell_items || cap <= 0 || batch <= 0 || item_cap < cap * PLH_GRID_COLS) {
+    set_error("plh_frame_assign_grid_lines_batch_dev: invalid argument (item_cap must be >= cap * 64)");
+    return PLH_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(k_grid_lines, dim3(batch), dim3(256), 0, (hipStream_t)stream, d_kl, (const int*)d_nl, cap, *gp,
+                     d_cell_start, d_cell_items, item_cap);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_orb_search_for_initialization_batch_dev(const plh_keypoint* d_kps1, const uint8_t* d_desc1, const int32_t* d_n1,
+                                                       const plh_keypoint* d_kps2, const uint8_t* d_desc2, const int32_t* d_n2,
+                                                       int cap, int pairs, const plh_grid_params* gp2,
+                                                       const int32_t* d_cell_start2, const int32_t* d_cell_items2,
+                                                       float* d_prev_matched, int window_size, float nnratio, int check_ori,
+                                                       int32_t* d_matches12, int32_t* d_nmatches, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_kps1 || !d_desc1 || !d_n1 || !d_kps2 || !d_desc2 || !d_n2 || !gp2 || !d_cell_start2 || !d_cell_items2 ||
+      !d_prev_matched || !d_matches12 || !d_nmatches || cap <= 0 || cap > 6000 || pairs <= 0) {
+    set_error("plh_orb_search_for_initialization_batch_dev: invalid argument (cap must be in 1..6000)");
+    return PLH_ERR_INVALID;
+  }
+  const size_t lds = (size_t)cap * (5 * 4 + 1) + 64;
+  hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), lds, (hipStream_t)stream, d_kps1, d_desc1, (const int*)d_n1, d_kps2,
+                     d_desc2, (const int*)d_n2, cap, *gp2, d_cell_start2, d_cell_items2, d_prev_matched, window_size, nnratio,
+                     check_ori, d_matches12, d_nmatches);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n, int cap,
+                                     int pairs, const plh_grid_params* gp, const int32_t* d_cs, const int32_t* d_ci,
+                                     const float* scale_factors, int nlevels, uint8_t* d_occupied, const int32_t* d_nq, int qcap,
+                                     const uint8_t* d_q_valid, const float* d_q_xy, const int32_t* d_q_level, const float* d_q_aux,
+                                     const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, float nnratio, int mode,
+                                     int check_ori, int32_t* d_assigned, int32_t* d_nmatches, void* stream, const char* who) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  ScaleTab sf;
+  if (!d_kps_un || !d_desc || !d_n || !gp || !d_cs || !d_ci || !scale_tab(scale_factors, nlevels, &sf) || !d_occupied || !d_nq ||
+      !d_q_valid || !d_q_xy || !d_q_level || !d_q_aux || !d_q_desc || !d_q_hasobs || !d_assigned || !d_nmatches || cap <= 0 ||
+      cap > 6000 || qcap <= 0 || qcap > 6000 || pairs <= 0 || mode < 0 || mode > 2) {
+    set_error("%s: invalid argument (cap, qcap in 1..6000; 1..16 levels)", who);
+    return PLH_ERR_INVALID;
+  }
+  const size_t lds = (size_t)cap * (3 * 4 + 1) + (size_t)qcap * (4 + 1) + 64;
+  hipLaunchKernelGGL(k_search_proj_points, dim3(pairs), dim3(64), lds, (hipStream_t)stream, variant, d_kps_un, d_desc,
+                     (const int*)d_n, cap, *gp, d_cs, d_ci, sf, d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy, d_q_level,
+                     d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, mode, check_ori, d_assigned, d_nmatches);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_orb_search_by_projection_mp_batch_dev(const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n,
+                                                     int cap, int pairs, const plh_grid_params* gp, const int32_t* d_cell_start,
+                                                     const int32_t* d_cell_items, const float* scale_factors, int nlevels,
+                                                     uint8_t* d_occupied, const int32_t* d_nq, int qcap, const uint8_t* d_q_valid,
+                                                     const float* d_q_xy, const int32_t* d_q_level, const float* d_q_viewcos,
+                                                     const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, float nnratio,
+                                                     int32_t* d_assigned, int32_t* d_nmatches, void* stream) {
+  return launch_proj_points(0, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
+                            d_occupied, d_nq, qcap, d_q_valid, d_q_xy, d_q_level, d_q_viewcos, d_q_desc, d_q_hasobs, th, nnratio, 0,
+                            0, d_assigned, d_nmatches, stream, "plh_orb_search_by_projection_mp_batch_dev");
+}
+
+plh_status plh_orb_search_by_projection_frame_batch_dev(const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n,
+                                                        int cap, int pairs, const plh_grid_params* gp,
+                                                        const int32_t* d_cell_start, const int32_t* d_cell_items,
+                                                        const float* scale_factors, int nlevels, uint8_t* d_occupied,
+                                                        const int32_t* d_nq, int qcap, const uint8_t* d_q_valid,
+                                                        const float* d_q_uv, const int32_t* d_q_octave, const float* d_q_angle,
+                                                        const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int mode,
+                                                        int check_ori, int32_t* d_assigned, int32_t* d_nmatches, void* stream) {
+  return launch_proj_points(1, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
+                            d_occupied, d_nq, qcap, d_q_valid, d_q_uv, d_q_octave, d_q_angle, d_q_desc, d_q_hasobs, th, 0.f, mode,
+                            check_ori, d_assigned, d_nmatches, stream, "plh_orb_search_by_projection_frame_batch_dev");
+}
+
+static plh_status launch_proj_lines(int variant, const plh_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn,
+                                    const int32_t* d_nl, int cap, int pairs, const plh_grid_params* gp, const int32_t* d_cs,
+                                    const int32_t* d_ci, int item_cap, uint8_t* d_occupied, const int32_t* d_nq, int qcap,
+                                    const uint8_t* d_q_valid, const float* d_q_seg, const float* d_q_aux, const uint8_t* d_q_desc,
+                                    const uint8_t* d_q_hasobs, float th, float nnratio, int32_t* d_assigned, int32_t* d_nmatches,
+                                    void* stream, const char* who) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_kl || !d_ldesc || !d_linefn || !d_nl || !gp || !d_cs || !d_ci || !d_occupied || !d_nq || !d_q_valid || !d_q_seg ||
+      !d_q_aux || !d_q_desc || !d_q_hasobs || !d_assigned || !d_nmatches || cap <= 0 || cap > 8000 || qcap <= 0 || pairs <= 0 ||
+      item_cap < cap) {
+    set_error("%s: invalid argument (cap in 1..8000)", who);
+    return PLH_ERR_INVALID;
+  }
+  const size_t lds = (size_t)cap * (3 * 4 + 2) + 64;
+  hipLaunchKernelGGL(k_search_proj_lines, dim3(pairs), dim3(64), lds, (hipStream_t)stream, variant, d_kl, d_ldesc, d_linefn,
+                     (const int*)d_nl, cap, *gp, d_cs, d_ci, item_cap, d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_seg,
+                     d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, d_assigned, d_nmatches);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_line_search_by_projection_frame_batch_dev(const plh_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn,
+                                                         const int32_t* d_nl, int cap, int pairs, const plh_grid_params* gp,
+                                                         const int32_t* d_cell_start, const int32_t* d_cell_items, int item_cap,
+                                                         uint8_t* d_occupied, const int32_t* d_nq, int qcap,
+                                                         const uint8_t* d_q_valid, const float* d_q_seg, const float* d_q_length,
+                                                         const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th,
+                                                         int32_t* d_assigned, int32_t* d_nmatches, void* stream) {
+  return launch_proj_lines(1, d_kl, d_ldesc, d_linefn, d_nl, cap, pairs, gp, d_cell_start, d_cell_items, item_cap, d_occupied, d_nq,
+                           qcap, d_q_valid, d_q_seg, d_q_length, d_q_desc, d_q_hasobs, th, 0.f, d_assigned, d_nmatches, stream,
+                           "plh_line_search_by_projection_frame_batch_dev");
+}
+
+plh_status plh_line_search_by_projection_ml_batch_dev(const plh_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn,
+                                                      const int32_t* d_nl, int cap, int pairs, const plh_grid_params* gp,
+                                                      const int32_t* d_cell_start, const int32_t* d_cell_items, int item_cap,
+                                                      uint8_t* d_occupied, const int32_t* d_nq, int qcap, const uint8_t* d_q_valid,
+                                                      const float* d_q_seg, const float* d_q_viewcos, const uint8_t* d_q_desc,
+                                                      const uint8_t* d_q_hasobs, float th, float nnratio, int32_t* d_assigned,
+                                                      int32_t* d_nmatches, void* stream) {
+  return launch_proj_lines(0, d_kl, d_ldesc, d_linefn, d_nl, cap, pairs, gp, d_cell_start, d_cell_items, item_cap, d_occupied, d_nq,
+                           qcap, d_q_valid, d_q_seg, d_q_viewcos, d_q_desc, d_q_hasobs, th, nnratio, d_assigned, d_nmatches, stream,
+                           "plh_line_search_by_projection_ml_batch_dev");
+}
+
+}  // extern "C"

@@ -1,0 +1,288 @@
+"""Grid ("windowed") searches of the tracking front end: Frame::AssignFeaturesToGrid*, GetFeaturesInArea*,
+ORBmatcher::SearchForInitialization / SearchByProjection, LSDmatcher::SearchByProjection.
+Oracle known answers (CPU), the kernel sources under hipemu (CPU), GPU parity.  Everything is integer / index work:
+the bar is exact equality with the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _util
+
+V, I, F = C.c_void_p, C.c_int, C.c_float
+
+
+def _olib(O):
+    L = O.lib()
+    if getattr(L, "_fs_ready", False):
+        return L
+    L.plo_frame_assign_grid.argtypes = [V, I, V, V, V]
+    L.plo_frame_assign_grid_lines.argtypes = [V, I, V, V, V, I]
+    L.plo_features_in_area.argtypes = [V, V, V, V, F, F, F, I, I, V, I]
+    L.plo_features_in_area_for_line.argtypes = [V, V, I, V, V, V, F, F, F, F, F, F, V, I]
+    L.plo_orb_search_for_initialization.argtypes = [V, V, I, V, V, I, V, V, V, V, I, F, I, V]
+    L.plo_orb_search_by_projection_mp.argtypes = [V, V, I, V, V, V, V, V, I, V, V, V, V, V, V, F, F, V]
+    L.plo_orb_search_by_projection_frame.argtypes = [V, V, I, V, V, V, V, V, I, V, V, V, V, V, V, F, I, I, V]
+    L.plo_line_search_by_projection_frame.argtypes = [V, V, V, I, V, V, V, V, I, V, V, V, V, V, F, V]
+    L.plo_line_search_by_projection_ml.argtypes = [V, V, V, I, V, V, V, V, I, V, V, V, V, V, F, F, V]
+    for f in ("plo_frame_assign_grid", "plo_frame_assign_grid_lines", "plo_features_in_area", "plo_features_in_area_for_line",
+              "plo_orb_search_for_initialization", "plo_orb_search_by_projection_mp", "plo_orb_search_by_projection_frame",
+              "plo_line_search_by_projection_frame", "plo_line_search_by_projection_ml"):
+        getattr(L, f).restype = I
+    L._fs_ready = True
+    return L
+
+
+SCALE = np.cumprod(np.r_[np.float32(1.0), np.full(7, np.float32(1.2))]).astype(np.float32)
+
+
+def _gp(P, cols=640, rows=480, distorted=False):
+    if distorted:   # undistorted image bounds stick out of the sensor (Frame::ComputeImageBounds)
+        return P.grid_params(cols, rows, -18.5, -11.25, cols + 21.75, rows + 14.5)
+    return P.grid_params(cols, rows)
+
+
+def _gpa(P, gp):
+    return P._gp_array(gp)
+
+
+def make_frame_pair(P, S, seed, n, cols=640, rows=480, move=6.0, nl=60):
+    """Two synthetic frames with known correspondences: keypoints of frame 2 = permuted, displaced, noisy copies."""
+    rng = S.SplitMix64(seed)
+    d1, d2, perm = S.make_descriptor_sets(seed + 1, max(n, 1), 0.07)
+    d1, d2 = d1[:n], d2[:n]
+    k1 = np.zeros(n, P.KP_DTYPE)
+    k1["x"] = rng.uniform(n, 2, cols - 2).astype(np.float32)
+    k1["y"] = rng.uniform(n, 2, rows - 2).astype(np.float32)
+    k1["octave"] = np.minimum(7, (rng.uniform(n) ** 2 * 8).astype(np.int32))   # mostly fine levels
+    k1["angle"] = rng.uniform(n, 0, 360).astype(np.float32)
+    k1["size"] = 31.0 * SCALE[k1["octave"]]
+    k1["response"] = rng.randint(n, 20, 200).astype(np.float32)
+    k1["class_id"] = -1
+    k2 = k1.copy()
+    if n:
+        k2 = np.zeros(n, P.KP_DTYPE)
+        src = perm                      # b = a[perm] (see synth.make_descriptor_sets): row j of set 2 comes from perm[j]
+        k2[:] = k1[src]
+        k2["x"] = (k2["x"] + rng.uniform(n, -move, move)).astype(np.float32)
+        k2["y"] = (k2["y"] + rng.uniform(n, -move, move)).astype(np.float32)
+        k2["angle"] = ((k2["angle"] + 10.0 + rng.uniform(n, -4, 4)) % 360).astype(np.float32)
+        wrong = rng.uniform(n) < 0.1
+        k2["angle"][wrong] = rng.uniform(int(wrong.sum()), 0, 360).astype(np.float32)
+        k2["octave"] = np.clip(k2["octave"] + (rng.uniform(n) < 0.2) * rng.randint(n, -1, 2), 0, 7).astype(np.int32)
+    # lines
+    kl1 = np.zeros(nl, P.KL_DTYPE)
+    sx, sy = rng.uniform(nl, 5, cols - 5), rng.uniform(nl, 5, rows - 5)
+    ang, ln = rng.uniform(nl, 0, np.pi), rng.uniform(nl, 15, 220)
+    ex, ey = np.clip(sx + ln * np.cos(ang), 0, cols - 1), np.clip(sy + ln * np.sin(ang), 0, rows - 1)
+
+    def fill(kl, sx, sy, ex, ey):
+        kl["startPointX"], kl["startPointY"], kl["endPointX"], kl["endPointY"] = sx, sy, ex, ey
+        kl["sPointInOctaveX"], kl["sPointInOctaveY"], kl["ePointInOctaveX"], kl["ePointInOctaveY"] = sx, sy, ex, ey
+        kl["lineLength"] = np.hypot(ex - sx, ey - sy).astype(np.float32)
+        kl["class_id"] = np.arange(len(kl))
+        fn = np.zeros((len(kl), 3))
+        s = np.stack([kl["startPointX"], kl["startPointY"], np.ones(len(kl))], 1).astype(np.float64)
+        e = np.stack([kl["endPointX"], kl["endPointY"], np.ones(len(kl))], 1).astype(np.float64)
+        fn = np.cross(s, e)
+        nrm = np.hypot(fn[:, 0], fn[:, 1])
+        nrm[nrm == 0] = 1
+        return fn / nrm[:, None]
+    fn1 = fill(kl1, sx, sy, ex, ey)
+    ld1, ld2, lperm = S.make_descriptor_sets(seed + 2, max(nl, 1), 0.06)
+    ld1, ld2 = ld1[:nl], ld2[:nl]
+    kl2 = kl1[lperm].copy() if nl else kl1.copy()
+    if nl:
+        j = rng.uniform(nl, -3, 3)
+        shrink = rng.uniform(nl, 0.7, 1.0)
+        mx, my = (kl2["startPointX"] + kl2["endPointX"]) / 2, (kl2["startPointY"] + kl2["endPointY"]) / 2
+        hx, hy = (kl2["endPointX"] - kl2["startPointX"]) / 2 * shrink, (kl2["endPointY"] - kl2["startPointY"]) / 2 * shrink
+        fn2 = fill(kl2, np.clip(mx - hx + j, 0, cols - 1), np.clip(my - hy + j, 0, rows - 1), np.clip(mx + hx + j, 0, cols - 1),
+                   np.clip(my + hy + j, 0, rows - 1))
+    else:
+        fn2 = fn1
+    f1 = dict(kps=k1, desc=d1, keylines=kl1, ldesc=ld1, linefn=fn1)
+    f2 = dict(kps=k2, desc=d2, keylines=kl2, ldesc=ld2, linefn=np.ascontiguousarray(fn2))
+    return f1, f2, perm, (lperm if nl else None)
+
+
+def _oracle_grids(O, P, f, gp):
+    L, g = _olib(O), _gpa(P, gp)
+    cs, ci = np.zeros(64 * 48 + 1, np.int32), np.zeros(max(len(f["kps"]), 1), np.int32)
+    L.plo_frame_assign_grid(O._p(f["kps"]), len(f["kps"]), O._p(g), O._p(cs), O._p(ci))
+    nl = len(f["keylines"])
+    lcs, lci = np.zeros(64 * 48 + 1, np.int32), np.zeros(max(nl, 1) * 64, np.int32)
+    L.plo_frame_assign_grid_lines(O._p(f["keylines"]), nl, O._p(g), O._p(lcs), O._p(lci), len(lci))
+    return (cs, ci), (lcs, lci)
+
+
+def _queries_points(P, S, seed, f_last, f_cur, variant):
+    """Queries as Tracking builds them: projections of the last frame's map points near their true new position."""
+    rng = S.SplitMix64(seed)
+    n = len(f_last["kps"])
+    k = f_last["kps"]
+    q = dict(valid=(rng.uniform(n) < 0.85).astype(np.uint8), desc=f_last["desc"].copy(), hasobs=(rng.uniform(n) < 0.9).astype(np.uint8))
+    xy = np.stack([k["x"] + rng.uniform(n, -4, 4), k["y"] + rng.uniform(n, -4, 4)], 1).astype(np.float32)
+    far = rng.uniform(n) < 0.05          # some projections fall outside the image
+    xy[far] += 900
+    if variant == "mp":
+        q.update(xy=xy, level=k["octave"].astype(np.int32), viewcos=rng.uniform(n, 0.99, 1.0).astype(np.float32))
+    else:
+        q.update(uv=xy, octave=k["octave"].astype(np.int32), angle=k["angle"].astype(np.float32))
+    return q
+
+
+def _queries_lines(P, S, seed, f_last, variant):
+    rng = S.SplitMix64(seed)
+    kl = f_last["keylines"]
+    nl = len(kl)
+    seg = np.stack([kl["startPointX"], kl["startPointY"], kl["endPointX"], kl["endPointY"]], 1).astype(np.float32)
+    seg += rng.uniform(nl * 4, -2.5, 2.5).reshape(nl, 4).astype(np.float32)
+    q = dict(valid=(rng.uniform(nl) < 0.9).astype(np.uint8), seg=seg, desc=f_last["ldesc"].copy(),
+             hasobs=(rng.uniform(nl) < 0.9).astype(np.uint8))
+    if variant == "ml":
+        q["viewcos"] = rng.uniform(nl, 0.99, 1.0).astype(np.float32)
+    else:
+        q["length"] = kl["lineLength"].astype(np.float32)
+    return q
+
+
+def _run_all(P, O, S, lib, seeds, n, nl, distorted=False):
+    """Every search on a batch of frame pairs through the C ABI vs the oracle; returns the number of matches found."""
+    L = _olib(O)
+    gp = _gp(P, distorted=distorted)
+    g = _gpa(P, gp)
+    pairs = [make_frame_pair(P, S, s, n if i % 3 else max(0, n - 37 * i), nl=nl if i % 2 == 0 else max(0, nl - 11)) for i, s in enumerate(seeds)]
+    lasts, curs = [p[0] for p in pairs], [p[1] for p in pairs]
+    fs = P.FrameSearch(gp, SCALE, curs, lib=lib)
+    (cs, ci), (lcs, lci) = fs.grids()
+    total = 0
+    for b, (f1, f2) in enumerate(zip(lasts, curs)):
+        (rcs, rci), (rlcs, rlci) = _oracle_grids(O, P, f2, gp)
+        assert (cs[b] == rcs).all() and (ci[b, :rcs[-1]] == rci[:rcs[-1]]).all(), "point grid %d" % b
+        assert (lcs[b] == rlcs).all() and (lci[b, :rlcs[-1]] == rlci[:rlcs[-1]]).all(), "line grid %d" % b
+    # ---- SearchForInitialization
+    prev = [np.stack([f["kps"]["x"], f["kps"]["y"]], 1).astype(np.float32) for f in lasts]
+    m12, cnt, pm = fs.SearchForInitialization(lasts, prev, 100, 0.9, True)
+    for b, (f1, f2) in enumerate(zip(lasts, curs)):
+        (rcs, rci), _ = _oracle_grids(O, P, f2, gp)
+        n1 = len(f1["kps"])
+        rp = prev[b].copy()
+        ref = np.zeros(max(n1, 1), np.int32)
+        rc = L.plo_orb_search_for_initialization(O._p(f1["kps"]), O._p(f1["desc"]), n1, O._p(f2["kps"]), O._p(f2["desc"]), len(f2["kps"]),
+                                                 O._p(g), O._p(rcs), O._p(rci), O._p(rp), 100, 0.9, 1, O._p(ref))
+        assert cnt[b] == rc and (m12[b, :n1] == ref[:n1]).all() and (pm[b, :n1] == rp).all(), "SearchForInitialization %d" % b
+        total += rc
+    # ---- ORB SearchByProjection, both forms
+    for variant in ("mp", "frame"):
+        qs = [_queries_points(P, S, 900 + b, f1, f2, variant) for b, (f1, f2) in enumerate(zip(lasts, curs))]
+        occ0 = [(S.SplitMix64(77 + b).uniform(len(f2["kps"])) < 0.1).astype(np.uint8) for b, f2 in enumerate(curs)]
+        if variant == "mp":
+            asg, cnt, occ = fs.SearchByProjectionMapPoints(qs, occ0, th=3.0, nnratio=0.8)
+        else:
+            asg, cnt, occ = fs.SearchByProjectionLastFrame(qs, occ0, th=15.0, mode=0, checkOri=True)
+        for b, (f1, f2) in enumerate(zip(lasts, curs)):
+            (rcs, rci), _ = _oracle_grids(O, P, f2, gp)
+            n2, q = len(f2["kps"]), qs[b]
+            ro, ra = occ0[b].copy(), np.zeros(max(n2, 1), np.int32)
+            if variant == "mp":
+                rc = L.plo_orb_search_by_projection_mp(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(rcs), O._p(rci), O._p(SCALE),
+                                                       O._p(ro), len(q["valid"]), O._p(q["valid"]), O._p(q["xy"]), O._p(q["level"]),
+                                                       O._p(q["viewcos"]), O._p(q["desc"]), O._p(q["hasobs"]), 3.0, 0.8, O._p(ra))
+            else:
+                rc = L.plo_orb_search_by_projection_frame(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(rcs), O._p(rci),
+                                                          O._p(SCALE), O._p(ro), len(q["valid"]), O._p(q["valid"]), O._p(q["uv"]),
+                                                          O._p(q["octave"]), O._p(q["angle"]), O._p(q["desc"]), O._p(q["hasobs"]),
+                                                          15.0, 0, 1, O._p(ra))
+            assert cnt[b] == rc and (asg[b, :n2] == ra[:n2]).all() and (occ[b, :n2] == ro[:n2]).all(), "%s %d" % (variant, b)
+            total += rc
+    # ---- LSD SearchByProjection, both forms
+    for variant in ("ml", "frame"):
+        qs = [_queries_lines(P, S, 950 + b, f1, variant) for b, f1 in enumerate(lasts)]
+        occ0 = [(S.SplitMix64(88 + b).uniform(len(f2["keylines"])) < 0.1).astype(np.uint8) for b, f2 in enumerate(curs)]
+        if variant == "ml":
+            asg, cnt, occ = fs.LineSearchByProjectionMapLines(qs, occ0, th=3.0, nnratio=0.9)
+        else:
+            asg, cnt, occ = fs.LineSearchByProjectionLastFrame(qs, occ0, th=12.0)
+        for b, (f1, f2) in enumerate(zip(lasts, curs)):
+            _, (rlcs, rlci) = _oracle_grids(O, P, f2, gp)
+            n2, q = len(f2["keylines"]), qs[b]
+            ro, ra = occ0[b].copy(), np.zeros(max(n2, 1), np.int32)
+            if variant == "ml":
+                rc = L.plo_line_search_by_projection_ml(O._p(f2["keylines"]), O._p(f2["ldesc"]), O._p(f2["linefn"]), n2, O._p(g),
+                                                        O._p(rlcs), O._p(rlci), O._p(ro), len(q["valid"]), O._p(q["valid"]),
+                                                        O._p(q["seg"]), O._p(q["viewcos"]), O._p(q["desc"]), O._p(q["hasobs"]), 3.0,
+                                                        0.9, O._p(ra))
+            else:
+                rc = L.plo_line_search_by_projection_frame(O._p(f2["keylines"]), O._p(f2["ldesc"]), O._p(f2["linefn"]), n2, O._p(g),
+                                                           O._p(rlcs), O._p(rlci), O._p(ro), len(q["valid"]), O._p(q["valid"]),
+                                                           O._p(q["seg"]), O._p(q["length"]), O._p(q["desc"]), O._p(q["hasobs"]), 12.0,
+                                                           O._p(ra))
+            assert cnt[b] == rc and (asg[b, :n2] == ra[:n2]).all() and (occ[b, :n2] == ro[:n2]).all(), "line %s %d" % (variant, b)
+            total += rc
+    return total
+
+
+# ------------------------------------------------------------------ oracle known answers (CPU)
+def test_oracle_grid_known_answers(oracle, plslam):
+    P, O, L = plslam, oracle, _olib(oracle)
+    gp = P.grid_params(640, 480)
+    g = P._gp_array(gp)
+    assert abs(gp.inv_w - 0.1) < 1e-7 and abs(gp.inv_h - 0.1) < 1e-7
+    k = np.zeros(5, P.KP_DTYPE)
+    k["x"] = [0.0, 4.9, 5.1, 639.0, 320.0]      # PosInGrid rounds: 4.9 -> cell 0, 5.1 -> cell 1, 639 -> 64 = out of range
+    k["y"] = [0.0, 0.0, 0.0, 100.0, 474.9]      # 474.9 * 0.1 = 47.49 -> 47 (last row)
+    cs, ci = np.zeros(3073, np.int32), np.zeros(5, np.int32)
+    assert L.plo_frame_assign_grid(O._p(k), 5, O._p(g), O._p(cs), O._p(ci)) == 4
+    cells = {c: ci[cs[c]:cs[c + 1]].tolist() for c in range(3072) if cs[c + 1] > cs[c]}
+    assert cells == {0: [0, 1], 48: [2], 32 * 48 + 47: [4]}
+    out = np.zeros(8, np.int32)
+    # window |dx| < r, |dy| < r strictly; level band (min, max)
+    assert L.plo_features_in_area(O._p(k), O._p(g), O._p(cs), O._p(ci), 2.0, 0.0, 3.0, -1, -1, O._p(out), 8) == 2
+    assert out[:2].tolist() == [0, 1]
+    assert L.plo_features_in_area(O._p(k), O._p(g), O._p(cs), O._p(ci), 2.0, 0.0, 2.0, -1, -1, O._p(out), 8) == 0   # |0-2| < 2 fails
+    k["octave"] = [0, 3, 0, 0, 0]
+    assert L.plo_features_in_area(O._p(k), O._p(g), O._p(cs), O._p(ci), 2.0, 0.0, 3.5, 0, 0, O._p(out), 8) == 2   # octave-3 keypoint 1 is out
+    assert out[:2].tolist() == [0, 2]
+    # a horizontal line crosses every cell of its row once (LineIterator), a point-like line occupies one cell
+    kl = np.zeros(2, P.KL_DTYPE)
+    kl["startPointX"], kl["startPointY"], kl["endPointX"], kl["endPointY"] = [5.0, 300.0], [105.0, 200.0], [205.0, 300.5], [105.0, 200.2]
+    lcs, lci = np.zeros(3073, np.int32), np.zeros(128, np.int32)
+    assert L.plo_frame_assign_grid_lines(O._p(kl), 2, O._p(g), O._p(lcs), O._p(lci), 128) == 21 + 1
+    occ = [c for c in range(3072) if lcs[c + 1] > lcs[c]]
+    assert occ == [ix * 48 + 10 for ix in range(0, 21)] + [30 * 48 + 20]
+
+
+def test_oracle_search_recovers_correspondences(oracle, plslam, synth):
+    P, O, S, L = plslam, oracle, synth, _olib(oracle)
+    f1, f2, perm, _ = make_frame_pair(P, S, 5, 400, nl=0)
+    gp = _gp(P)
+    g = P._gp_array(gp)
+    (cs, ci), _ = _oracle_grids(O, P, f2, gp)
+    prev = np.stack([f1["kps"]["x"], f1["kps"]["y"]], 1).astype(np.float32)
+    m = np.zeros(400, np.int32)
+    c = L.plo_orb_search_for_initialization(O._p(f1["kps"]), O._p(f1["desc"]), 400, O._p(f2["kps"]), O._p(f2["desc"]), 400, O._p(g),
+                                            O._p(cs), O._p(ci), O._p(prev), 100, 0.9, 1, O._p(m))
+    inv = np.empty(400, np.int64)
+    inv[perm] = np.arange(400)             # feature i of frame 1 sits at row inv[i] of frame 2
+    ok = m >= 0
+    assert c == ok.sum() and c > 60        # only level-0 keypoints take part
+    assert (f1["kps"]["octave"][ok] == 0).all() and (m[ok] == inv[ok]).mean() > 0.95
+    assert (prev[ok] == np.stack([f2["kps"]["x"][m[ok]], f2["kps"]["y"][m[ok]]], 1)).all()
+
+
+# ------------------------------------------------------------------ HIP sources under hipemu (CPU)
+def test_emu_frame_search(plslam, oracle, synth, emu_lib):
+    assert _run_all(plslam, oracle, synth, emu_lib, [11, 12, 13], 260, 40) > 100
+    assert _run_all(plslam, oracle, synth, emu_lib, [14, 15], 90, 25, distorted=True) > 20
+
+
+def test_emu_frame_search_empty(plslam, oracle, synth, emu_lib):
+    _run_all(plslam, oracle, synth, emu_lib, [21], 0, 0)
+
+
+# ------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+def test_gpu_frame_search_2000(plslam, oracle, synth):
+    assert _run_all(plslam, oracle, synth, None, [31, 32, 33, 34, 35, 36], 2000, 201) > 3000
+    assert _run_all(plslam, oracle, synth, None, [41, 42], 1000, 201, distorted=True) > 500
