@@ -285,6 +285,34 @@ PLH_API plh_status plh_line_search_by_projection_ml_batch_dev(
     const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, float nnratio, int32_t* d_assigned, int32_t* d_nmatches,
     void* stream);
 
+/* Host-buffer forms: one call = one reference call on one frame (they stage over PCIe, rebuild the frame's grid on the
+ * device and block).  Arrays as in the *_batch_dev forms, without padding. */
+PLH_API plh_status plh_orb_search_for_initialization(const plh_keypoint* kps1, const uint8_t* desc1, int n1,
+                                                     const plh_keypoint* kps2, const uint8_t* desc2, int n2,
+                                                     const plh_grid_params* gp2, float* prev_matched, int window_size,
+                                                     float nnratio, int check_ori, int32_t* matches12, int* nmatches, int device);
+PLH_API plh_status plh_orb_search_by_projection_mp(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                                   const float* scale_factors, int nlevels, uint8_t* occupied, int nq,
+                                                   const uint8_t* q_valid, const float* q_xy, const int32_t* q_level,
+                                                   const float* q_viewcos, const uint8_t* q_desc, const uint8_t* q_hasobs, float th,
+                                                   float nnratio, int32_t* assigned, int* nmatches, int device);
+PLH_API plh_status plh_orb_search_by_projection_frame(const plh_keypoint* kps_un, const uint8_t* desc, int n,
+                                                      const plh_grid_params* gp, const float* scale_factors, int nlevels,
+                                                      uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_uv,
+                                                      const int32_t* q_octave, const float* q_angle, const uint8_t* q_desc,
+                                                      const uint8_t* q_hasobs, float th, int mode, int check_ori,
+                                                      int32_t* assigned, int* nmatches, int device);
+PLH_API plh_status plh_line_search_by_projection_frame(const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
+                                                       const plh_grid_params* gp, uint8_t* occupied, int nq,
+                                                       const uint8_t* q_valid, const float* q_seg, const float* q_length,
+                                                       const uint8_t* q_desc, const uint8_t* q_hasobs, float th,
+                                                       int32_t* assigned, int* nmatches, int device);
+PLH_API plh_status plh_line_search_by_projection_ml(const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
+                                                    const plh_grid_params* gp, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                                    const float* q_seg, const float* q_viewcos, const uint8_t* q_desc,
+                                                    const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned,
+                                                    int* nmatches, int device);
+
 /* ---------------------------------------------------------------------------------------------
  * Line extractor  (replaces ORB_SLAM2::LINEextractor, include/LineExtractor.h:20-62)
  * ------------------------------------------------------------------------------------------- */

@@ -6,12 +6,17 @@
 //     ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)     src/ORBmatcher.cc:187-327
 //     LSDmatcher::SearchDouble(Frame&, Frame&, vector<int>&)             src/LSDmatcher.cpp:427-460
 //     LSDmatcher::SearchDouble(KeyFrame*, Frame&)                        src/LSDmatcher.cpp:375-425
+//     ORBmatcher::SearchForInitialization(F1, F2, prev, matches, win)     src/ORBmatcher.cc:455-572
+//     ORBmatcher::SearchByProjection(F, MapPoints, th) / (Cur, Last, th)  src/ORBmatcher.cc:56-144, 1441-1585
+//     LSDmatcher::SearchByProjection(Cur, Last, th) / (F, MapLines, th)   src/LSDmatcher.cpp:72-176, 221-338
 // become a few lines of glue (shown in INTEGRATION.md) and keep their signatures.
 #ifndef PLSLAM_HIP_ADAPTOR_MATCHERS_H
 #define PLSLAM_HIP_ADAPTOR_MATCHERS_H
 
 #include <opencv2/core/core.hpp>
 #include <opencv2/features2d/features2d.hpp>
+#include <opencv2/line_descriptor/descriptor.hpp>
+#include <Eigen/Core>
 
 #include <map>
 #include <stdexcept>
@@ -84,6 +89,98 @@ inline void knnMatch2(const cv::Mat& q, const cv::Mat& t, std::vector<std::vecto
   for (int i = 0; i < q.rows; i++)
     for (int k = 0; k < 2; k++)
       if (idx[i * 2 + k] >= 0) matches[i].push_back(cv::DMatch(i, idx[i * 2 + k], (float)dist[i * 2 + k]));
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grid ("windowed") searches.  cv::KeyPoint and KeyLine are layout-identical to plh_keypoint / plh_keyline.
+// ---------------------------------------------------------------------------------------------------------------
+static_assert(sizeof(cv::KeyPoint) == sizeof(plh_keypoint), "cv::KeyPoint layout");
+static_assert(sizeof(cv::line_descriptor::KeyLine) == sizeof(plh_keyline), "KeyLine layout");
+static_assert(sizeof(cv::Point2f) == 2 * sizeof(float), "cv::Point2f layout");
+
+// Frame::mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv (static members, Frame.cc:113-117)
+inline plh_grid_params GridParams(float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, float widthInv, float heightInv) {
+  plh_grid_params g = {mnMinX, mnMinY, mnMaxX, mnMaxY, widthInv, heightInv};
+  return g;
+}
+
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): pass F1.mvKeysUn / mDescriptors,
+// F2.mvKeysUn / mDescriptors.  vbPrevMatched is updated in place exactly as the reference does (:567-569).
+inline int SearchForInitialization(const std::vector<cv::KeyPoint>& keysUn1, const cv::Mat& desc1,
+                                   const std::vector<cv::KeyPoint>& keysUn2, const cv::Mat& desc2, const plh_grid_params& gp2,
+                                   std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize,
+                                   float nnratio, bool checkOri, int device = 0) {
+  vnMatches12.assign(keysUn1.size(), -1);
+  cv::Mat d1 = desc1.isContinuous() ? desc1 : desc1.clone(), d2 = desc2.isContinuous() ? desc2 : desc2.clone();
+  int nmatches = 0;
+  check(plh_orb_search_for_initialization(reinterpret_cast<const plh_keypoint*>(keysUn1.data()), d1.ptr<uchar>(), (int)keysUn1.size(),
+                                          reinterpret_cast<const plh_keypoint*>(keysUn2.data()), d2.ptr<uchar>(), (int)keysUn2.size(),
+                                          &gp2, reinterpret_cast<float*>(vbPrevMatched.data()), windowSize, nnratio, checkOri ? 1 : 0,
+                                          vnMatches12.data(), &nmatches, device));
+  return nmatches;
+}
+
+// What the projection searches read from the map elements, one row per query (MapPoint / MapLine / last-frame feature).
+struct ProjQueries {
+  std::vector<uchar> valid;      // MapPoints: mbTrackInView && !isBad();  last frame: pMP && !mvbOutlier[i] && invzc >= 0
+  std::vector<uchar> hasObs;     // Observations() > 0
+  std::vector<float> pos;        // points: (x, y) per query; lines: (x1, y1, x2, y2) per query
+  std::vector<int32_t> level;    // mnTrackScaleLevel / LastFrame.mvKeys[i].octave (points only)
+  std::vector<float> aux;        // mTrackViewCos (map elements) | mvKeysUn[i].angle (last-frame points) | lineLength (last-frame lines)
+  cv::Mat desc;                  // n x 32 CV_8U: GetDescriptor() of every query
+};
+
+// ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th).  occupied[idx] = F.mvpMapPoints[idx] != NULL &&
+// Observations() > 0 (in/out).  assigned[idx] = query whose MapPoint the reference stores in F.mvpMapPoints[idx], or -1.
+inline int SearchByProjection(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& desc, const plh_grid_params& gp,
+                              const std::vector<float>& scaleFactors, std::vector<uchar>& occupied, const ProjQueries& q, float th,
+                              float nnratio, std::vector<int>& assigned, int device = 0) {
+  assigned.assign(keysUn.size(), -1);
+  cv::Mat d = desc.isContinuous() ? desc : desc.clone(), qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nmatches = 0;
+  check(plh_orb_search_by_projection_mp(reinterpret_cast<const plh_keypoint*>(keysUn.data()), d.ptr<uchar>(), (int)keysUn.size(), &gp,
+                                        scaleFactors.data(), (int)scaleFactors.size(), occupied.data(), (int)q.valid.size(),
+                                        q.valid.data(), q.pos.data(), q.level.data(), q.aux.data(), qd.ptr<uchar>(), q.hasObs.data(),
+                                        th, nnratio, assigned.data(), &nmatches, device));
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono); mode 0 mono, 1 forward, 2 backward.
+inline int SearchByProjectionLastFrame(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& desc, const plh_grid_params& gp,
+                                       const std::vector<float>& scaleFactors, std::vector<uchar>& occupied, const ProjQueries& q,
+                                       float th, int mode, bool checkOri, std::vector<int>& assigned, int device = 0) {
+  assigned.assign(keysUn.size(), -1);
+  cv::Mat d = desc.isContinuous() ? desc : desc.clone(), qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nmatches = 0;
+  check(plh_orb_search_by_projection_frame(reinterpret_cast<const plh_keypoint*>(keysUn.data()), d.ptr<uchar>(), (int)keysUn.size(),
+                                           &gp, scaleFactors.data(), (int)scaleFactors.size(), occupied.data(), (int)q.valid.size(),
+                                           q.valid.data(), q.pos.data(), q.level.data(), q.aux.data(), qd.ptr<uchar>(),
+                                           q.hasObs.data(), th, mode, checkOri ? 1 : 0, assigned.data(), &nmatches, device));
+  return nmatches;
+}
+
+// LSDmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th)   (lastFrame = true,  aux = lineLength)
+// LSDmatcher::SearchByProjection(Frame& F, const vector<MapLine*>&, th)             (lastFrame = false, aux = mTrackViewCos)
+inline int LineSearchByProjection(const std::vector<cv::line_descriptor::KeyLine>& keylinesUn, const cv::Mat& ldesc,
+                                  const std::vector<Eigen::Vector3d>& lineFunctions, const plh_grid_params& gp,
+                                  std::vector<uchar>& occupied, const ProjQueries& q, float th, float nnratio, bool lastFrame,
+                                  std::vector<int>& assigned, int device = 0) {
+  assigned.assign(keylinesUn.size(), -1);
+  cv::Mat d = ldesc.isContinuous() ? ldesc : ldesc.clone(), qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double), "Eigen::Vector3d layout");
+  const double* fn = reinterpret_cast<const double*>(lineFunctions.data());
+  const plh_keyline* kl = reinterpret_cast<const plh_keyline*>(keylinesUn.data());
+  int nmatches = 0;
+  if (lastFrame)
+    check(plh_line_search_by_projection_frame(kl, d.ptr<uchar>(), fn, (int)keylinesUn.size(), &gp, occupied.data(), (int)q.valid.size(),
+                                              q.valid.data(), q.pos.data(), q.aux.data(), qd.ptr<uchar>(), q.hasObs.data(), th,
+                                              assigned.data(), &nmatches, device));
+  else
+    check(plh_line_search_by_projection_ml(kl, d.ptr<uchar>(), fn, (int)keylinesUn.size(), &gp, occupied.data(), (int)q.valid.size(),
+                                           q.valid.data(), q.pos.data(), q.aux.data(), qd.ptr<uchar>(), q.hasObs.data(), th, nnratio,
+                                           assigned.data(), &nmatches, device));
+  return nmatches;
 }
 
 }  // namespace hip

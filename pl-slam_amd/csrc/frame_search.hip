@@ -14,6 +14,9 @@
 // the candidates of the grid window (one grid column = one contiguous CSR range), compute the 256-bit Hamming
 // distances in parallel, and the best / second-best replay runs over the candidate list in the reference's
 // enumeration order.  Per-frame match state lives in LDS.  Throughput comes from the batch (one wave per pair).
+#include <algorithm>
+#include <vector>
+
 #include "plh_common.h"
 
 namespace plh {
@@ -699,6 +702,176 @@ plh_status plh_line_search_by_projection_ml_batch_dev(const plh_keyline* d_kl, c
   return launch_proj_lines(0, d_kl, d_ldesc, d_linefn, d_nl, cap, pairs, gp, d_cell_start, d_cell_items, item_cap, d_occupied, d_nq,
                            qcap, d_q_valid, d_q_seg, d_q_viewcos, d_q_desc, d_q_hasobs, th, nnratio, d_assigned, d_nmatches, stream,
                            "plh_line_search_by_projection_ml_batch_dev");
+}
+
+// ---- host-buffer conveniences: one call = one reference call on ONE frame (stage over PCIe, block until done).
+// The frame's grid is rebuilt on the device inside the call (two tiny kernels); the reference builds it once in the
+// Frame constructor, a caller that keeps frames resident uses the *_batch_dev entry points instead.
+extern "C++" {
+namespace {
+struct Stage {   // RAII device staging of host arrays
+  std::vector<void*> ptrs;
+  hipError_t err = hipSuccess;
+  ~Stage() { for (void* p : ptrs) (void)hipFree(p); }
+  template <typename T> T* up(const T* host, size_t count, size_t alloc_count = 0) {
+    void* d = nullptr;
+    const size_t bytes = std::max(std::max(count, alloc_count), (size_t)1) * sizeof(T);
+    if (err == hipSuccess) err = hipMalloc(&d, bytes);
+    if (err != hipSuccess) return nullptr;
+    ptrs.push_back(d);
+    if (count && host) err = hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice);
+    else if (err == hipSuccess) err = hipMemset(d, 0, bytes);
+    return reinterpret_cast<T*>(d);
+  }
+  template <typename T> T* alloc(size_t count) { return up<T>(nullptr, 0, count); }
+};
+#define STAGE_OK(st)                                                                     \
+  do {                                                                                   \
+    if ((st).err != hipSuccess) {                                                        \
+      plh::set_error("%s:%d staging -> %s", __FILE__, __LINE__, hipGetErrorString((st).err)); \
+      return PLH_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+}  // namespace
+}  // extern "C++"
+
+plh_status plh_orb_search_for_initialization(const plh_keypoint* kps1, const uint8_t* desc1, int n1, const plh_keypoint* kps2,
+                                             const uint8_t* desc2, int n2, const plh_grid_params* gp2, float* prev_matched,
+                                             int window_size, float nnratio, int check_ori, int32_t* matches12, int* nmatches,
+                                             int device) {
+  if (n1 < 0 || n2 < 0 || !nmatches || !gp2 || (n1 > 0 && (!kps1 || !desc1 || !prev_matched || !matches12)) ||
+      (n2 > 0 && (!kps2 || !desc2)))
+    return PLH_ERR_INVALID;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  *nmatches = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  const int cap = std::max(n1, n2);
+  Stage s;
+  plh_keypoint* dk1 = s.up(kps1, n1, cap); uint8_t* dd1 = s.up(desc1, (size_t)n1 * 32, (size_t)cap * 32);
+  plh_keypoint* dk2 = s.up(kps2, n2, cap); uint8_t* dd2 = s.up(desc2, (size_t)n2 * 32, (size_t)cap * 32);
+  const int32_t ns[2] = {n1, n2};
+  int32_t* dn = s.up(ns, 2);
+  float* dpm = s.up(prev_matched, (size_t)n1 * 2, (size_t)cap * 2);
+  int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(cap);
+  int32_t* dm = s.alloc<int32_t>(cap); int32_t* dc = s.alloc<int32_t>(1);
+  STAGE_OK(s);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk2, dn + 1, cap, 1, gp2, dcs, dci, nullptr);
+  if (st == PLH_OK)
+    st = plh_orb_search_for_initialization_batch_dev(dk1, dd1, dn, dk2, dd2, dn + 1, cap, 1, gp2, dcs, dci, dpm, window_size, nnratio,
+                                                     check_ori, dm, dc, nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(matches12, dm, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(prev_matched, dpm, (size_t)n1 * 8, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
+static plh_status host_proj_points(int variant, const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                   const float* scale_factors, int nlevels, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                   const float* q_xy, const int32_t* q_level, const float* q_aux, const uint8_t* q_desc,
+                                   const uint8_t* q_hasobs, float th, float nnratio, int mode, int check_ori, int32_t* assigned,
+                                   int* nmatches, int device) {
+  if (n < 0 || nq < 0 || !nmatches || !gp || !scale_factors || (n > 0 && (!kps_un || !desc || !occupied || !assigned)) ||
+      (nq > 0 && (!q_valid || !q_xy || !q_level || !q_aux || !q_desc || !q_hasobs)))
+    return PLH_ERR_INVALID;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
+  *nmatches = 0;
+  if (n == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  Stage s;
+  plh_keypoint* dk = s.up(kps_un, n); uint8_t* dd = s.up(desc, (size_t)n * 32); uint8_t* docc = s.up(occupied, n);
+  const int32_t ns[2] = {n, nq};
+  int32_t* dn = s.up(ns, 2);
+  uint8_t* qv = s.up(q_valid, nq); float* qx = s.up(q_xy, (size_t)nq * 2); int32_t* ql = s.up(q_level, nq);
+  float* qa = s.up(q_aux, nq); uint8_t* qd = s.up(q_desc, (size_t)nq * 32); uint8_t* qh = s.up(q_hasobs, nq);
+  int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(n);
+  int32_t* da = s.alloc<int32_t>(n); int32_t* dc = s.alloc<int32_t>(1);
+  STAGE_OK(s);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, nullptr);
+  if (st == PLH_OK)
+    st = launch_proj_points(variant, dk, dd, dn, n, 1, gp, dcs, dci, scale_factors, nlevels, docc, dn + 1, nq, qv, qx, ql, qa, qd, qh,
+                            th, nnratio, mode, check_ori, da, dc, nullptr, "plh_orb_search_by_projection");
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(assigned, da, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(occupied, docc, (size_t)n, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
+plh_status plh_orb_search_by_projection_mp(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                           const float* scale_factors, int nlevels, uint8_t* occupied, int nq,
+                                           const uint8_t* q_valid, const float* q_xy, const int32_t* q_level,
+                                           const float* q_viewcos, const uint8_t* q_desc, const uint8_t* q_hasobs, float th,
+                                           float nnratio, int32_t* assigned, int* nmatches, int device) {
+  return host_proj_points(0, kps_un, desc, n, gp, scale_factors, nlevels, occupied, nq, q_valid, q_xy, q_level, q_viewcos, q_desc,
+                          q_hasobs, th, nnratio, 0, 0, assigned, nmatches, device);
+}
+
+plh_status plh_orb_search_by_projection_frame(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                              const float* scale_factors, int nlevels, uint8_t* occupied, int nq,
+                                              const uint8_t* q_valid, const float* q_uv, const int32_t* q_octave,
+                                              const float* q_angle, const uint8_t* q_desc, const uint8_t* q_hasobs, float th,
+                                              int mode, int check_ori, int32_t* assigned, int* nmatches, int device) {
+  if (mode < 0 || mode > 2) return PLH_ERR_INVALID;
+  return host_proj_points(1, kps_un, desc, n, gp, scale_factors, nlevels, occupied, nq, q_valid, q_uv, q_octave, q_angle, q_desc,
+                          q_hasobs, th, 0.f, mode, check_ori, assigned, nmatches, device);
+}
+
+static plh_status host_proj_lines(int variant, const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
+                                  const plh_grid_params* gp, uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_seg,
+                                  const float* q_aux, const uint8_t* q_desc, const uint8_t* q_hasobs, float th, float nnratio,
+                                  int32_t* assigned, int* nmatches, int device) {
+  if (nl < 0 || nq < 0 || !nmatches || !gp || (nl > 0 && (!kl || !ldesc || !linefn || !occupied || !assigned)) ||
+      (nq > 0 && (!q_valid || !q_seg || !q_aux || !q_desc || !q_hasobs)))
+    return PLH_ERR_INVALID;
+  for (int i = 0; i < nl; i++) assigned[i] = -1;
+  *nmatches = 0;
+  if (nl == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  Stage s;
+  const int itemCap = nl * PLH_GRID_COLS;
+  plh_keyline* dk = s.up(kl, nl); uint8_t* dd = s.up(ldesc, (size_t)nl * 32); double* dfn = s.up(linefn, (size_t)nl * 3);
+  uint8_t* docc = s.up(occupied, nl);
+  const int32_t ns[2] = {nl, nq};
+  int32_t* dn = s.up(ns, 2);
+  uint8_t* qv = s.up(q_valid, nq); float* qs = s.up(q_seg, (size_t)nq * 4); float* qa = s.up(q_aux, nq);
+  uint8_t* qd = s.up(q_desc, (size_t)nq * 32); uint8_t* qh = s.up(q_hasobs, nq);
+  int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(itemCap);
+  int32_t* da = s.alloc<int32_t>(nl); int32_t* dc = s.alloc<int32_t>(1);
+  STAGE_OK(s);
+  plh_status st = plh_frame_assign_grid_lines_batch_dev(dk, dn, nl, 1, gp, dcs, dci, itemCap, nullptr);
+  if (st == PLH_OK)
+    st = launch_proj_lines(variant, dk, dd, dfn, dn, nl, 1, gp, dcs, dci, itemCap, docc, dn + 1, nq, qv, qs, qa, qd, qh, th, nnratio, da,
+                           dc, nullptr, "plh_line_search_by_projection");
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(assigned, da, (size_t)nl * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(occupied, docc, (size_t)nl, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
+plh_status plh_line_search_by_projection_frame(const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
+                                               const plh_grid_params* gp, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                               const float* q_seg, const float* q_length, const uint8_t* q_desc,
+                                               const uint8_t* q_hasobs, float th, int32_t* assigned, int* nmatches, int device) {
+  return host_proj_lines(1, kl, ldesc, linefn, nl, gp, occupied, nq, q_valid, q_seg, q_length, q_desc, q_hasobs, th, 0.f, assigned,
+                         nmatches, device);
+}
+
+plh_status plh_line_search_by_projection_ml(const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
+                                            const plh_grid_params* gp, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                            const float* q_seg, const float* q_viewcos, const uint8_t* q_desc,
+                                            const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned, int* nmatches,
+                                            int device) {
+  return host_proj_lines(0, kl, ldesc, linefn, nl, gp, occupied, nq, q_valid, q_seg, q_viewcos, q_desc, q_hasobs, th, nnratio,
+                         assigned, nmatches, device);
 }
 
 }  // extern "C"

@@ -32,7 +32,18 @@ def test_adaptor_header_typechecks(hdr, tmp_path):
                        '}\n')
     else:
         src.write_text('#include "HipMatchers.h"\n'
-                       'int f(cv::Mat& a, cv::Mat& b, std::vector<int>& m) { return ORB_SLAM2::hip::SearchDouble(a, b, m, 0.7f); }\n')
+                       'int f(cv::Mat& a, cv::Mat& b, std::vector<int>& m) { return ORB_SLAM2::hip::SearchDouble(a, b, m, 0.7f); }\n'
+                       'int g(std::vector<cv::KeyPoint>& k1, std::vector<cv::KeyPoint>& k2, cv::Mat& a, cv::Mat& b,\n'
+                       '      std::vector<cv::Point2f>& prev, std::vector<int>& m) {\n'
+                       '  plh_grid_params gp = ORB_SLAM2::hip::GridParams(0, 0, 640, 480, 0.1f, 0.1f);\n'
+                       '  return ORB_SLAM2::hip::SearchForInitialization(k1, a, k2, b, gp, prev, m, 100, 0.9f, true); }\n'
+                       'int h(std::vector<cv::KeyPoint>& k, cv::Mat& d, std::vector<float>& sf, std::vector<uchar>& occ,\n'
+                       '      ORB_SLAM2::hip::ProjQueries& q, std::vector<int>& asg, std::vector<cv::line_descriptor::KeyLine>& kl,\n'
+                       '      std::vector<Eigen::Vector3d>& fn) {\n'
+                       '  plh_grid_params gp = ORB_SLAM2::hip::GridParams(0, 0, 640, 480, 0.1f, 0.1f);\n'
+                       '  return ORB_SLAM2::hip::SearchByProjection(k, d, gp, sf, occ, q, 1.f, 0.8f, asg) +\n'
+                       '         ORB_SLAM2::hip::SearchByProjectionLastFrame(k, d, gp, sf, occ, q, 15.f, 0, true, asg) +\n'
+                       '         ORB_SLAM2::hip::LineSearchByProjection(kl, d, fn, gp, occ, q, 8.f, 0.7f, true, asg); }\n')
     inc = [os.path.join(_util.ROOT, "pl-slam_amd", "adaptor"), os.path.join(_util.ROOT, "include"),
            os.path.join(_util.ROOT, "tests", "cv_stub")]
     cmd = ["g++", "-std=c++11", "-fsyntax-only", "-Wall"] + ["-I" + i for i in inc] + [str(src)]

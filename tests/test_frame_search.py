@@ -286,3 +286,52 @@ def test_emu_frame_search_empty(plslam, oracle, synth, emu_lib):
 def test_gpu_frame_search_2000(plslam, oracle, synth):
     assert _run_all(plslam, oracle, synth, None, [31, 32, 33, 34, 35, 36], 2000, 201) > 3000
     assert _run_all(plslam, oracle, synth, None, [41, 42], 1000, 201, distorted=True) > 500
+
+
+@pytest.mark.gpu
+def test_gpu_host_buffer_forms(plslam, oracle, synth):
+    """The one-call-per-reference-call entry points (host buffers, grid rebuilt inside) agree with the oracle."""
+    P, O, S, L = plslam, oracle, synth, _olib(oracle)
+    H = P.load()
+    gp = _gp(P)
+    g = _gpa(P, gp)
+    f1, f2, _, _ = make_frame_pair(P, S, 51, 1500, nl=180)
+    (cs, ci), (lcs, lci) = _oracle_grids(O, P, f2, gp)
+    n1, n2, nl = len(f1["kps"]), len(f2["kps"]), len(f2["keylines"])
+    p = P._p
+    # SearchForInitialization
+    prev = np.stack([f1["kps"]["x"], f1["kps"]["y"]], 1).astype(np.float32)
+    rp, ref = prev.copy(), np.zeros(n1, np.int32)
+    rc = L.plo_orb_search_for_initialization(O._p(f1["kps"]), O._p(f1["desc"]), n1, O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g),
+                                             O._p(cs), O._p(ci), O._p(rp), 100, 0.9, 1, O._p(ref))
+    H.plh_orb_search_for_initialization.argtypes = [V, V, I, V, V, I, V, V, I, F, I, V, V, I]
+    got, cnt = np.zeros(n1, np.int32), C.c_int(0)
+    P._check(H, H.plh_orb_search_for_initialization(p(f1["kps"]), p(f1["desc"]), n1, p(f2["kps"]), p(f2["desc"]), n2, C.byref(gp),
+                                                    p(prev), 100, 0.9, 1, p(got), C.byref(cnt), 0), "init")
+    assert cnt.value == rc and (got == ref).all() and (prev == rp).all() and rc > 100
+    # ORB SearchByProjection(Cur, Last)
+    q = _queries_points(P, S, 901, f1, f2, "frame")
+    occ = np.zeros(n2, np.uint8)
+    ro, ra = occ.copy(), np.zeros(n2, np.int32)
+    rc = L.plo_orb_search_by_projection_frame(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(cs), O._p(ci), O._p(SCALE), O._p(ro),
+                                              n1, O._p(q["valid"]), O._p(q["uv"]), O._p(q["octave"]), O._p(q["angle"]), O._p(q["desc"]),
+                                              O._p(q["hasobs"]), 15.0, 0, 1, O._p(ra))
+    H.plh_orb_search_by_projection_frame.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, F, I, I, V, V, I]
+    got = np.zeros(n2, np.int32)
+    P._check(H, H.plh_orb_search_by_projection_frame(p(f2["kps"]), p(f2["desc"]), n2, C.byref(gp), p(SCALE), len(SCALE), p(occ), n1,
+                                                     p(q["valid"]), p(q["uv"]), p(q["octave"]), p(q["angle"]), p(q["desc"]),
+                                                     p(q["hasobs"]), 15.0, 0, 1, p(got), C.byref(cnt), 0), "proj frame")
+    assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > 300
+    # LSD SearchByProjection(F, MapLines)
+    q = _queries_lines(P, S, 951, f1, "ml")
+    occ = np.zeros(nl, np.uint8)
+    ro, ra = occ.copy(), np.zeros(nl, np.int32)
+    rc = L.plo_line_search_by_projection_ml(O._p(f2["keylines"]), O._p(f2["ldesc"]), O._p(f2["linefn"]), nl, O._p(g), O._p(lcs), O._p(lci),
+                                            O._p(ro), len(q["valid"]), O._p(q["valid"]), O._p(q["seg"]), O._p(q["viewcos"]),
+                                            O._p(q["desc"]), O._p(q["hasobs"]), 3.0, 0.9, O._p(ra))
+    H.plh_line_search_by_projection_ml.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, F, F, V, V, I]
+    got = np.zeros(nl, np.int32)
+    P._check(H, H.plh_line_search_by_projection_ml(p(f2["keylines"]), p(f2["ldesc"]), p(f2["linefn"]), nl, C.byref(gp), p(occ),
+                                                   len(q["valid"]), p(q["valid"]), p(q["seg"]), p(q["viewcos"]), p(q["desc"]),
+                                                   p(q["hasobs"]), 3.0, 0.9, p(got), C.byref(cnt), 0), "line ml")
+    assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > 30
