@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--nlines", type=int, default=200)
     ap.add_argument("--unique", type=int, default=32, help="distinct rasterised frames (the rest are cheap variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="ORB and line halves on one stream (no overlap); used for PMC runs")
     args = ap.parse_args()
 
     import torch
@@ -145,6 +146,7 @@ def main():
     d_imgs = torch.from_numpy(frames).to(dev)
     voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=S)
     fe = PL.FrontEndBatch(P, voc, B, rows, cols, args.nfeatures, args.nlevels, args.nlines, 0.0, K, D, device=local_rank)
+    fe.overlap = not args.serial
     if world > 1:
         gather = [(t[:B], torch.empty((world * B,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev))
                   for t in (fe.n, fe.kps, fe.desc, fe.nl, fe.kl, fe.ldesc)]
@@ -177,20 +179,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    if rank == 0:
+    def read_kernel_totals():
+        """Cumulative (ms, intervals) of the 8 kernel groups since profiling was switched on."""
         import ctypes as C
-        names = ["k_pyr_down x7", "k_fast_cells", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
-                 "k_lsd_grow", "k_keylines", "LBD (blur+sobel+k_lbd)"]
-        per_ms = []
+        tot = []
         for k in range(4):
-            ms, n = fe.orb.kernel_ms(k)
-            per_ms.append(ms / max(n, 1))
+            tot.append(fe.orb.kernel_ms(k))
         lib = fe.line.lib
         lib.plh_line_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         for k in range(4):
             ms, n = C.c_double(0), C.c_int(0)
             lib.plh_line_kernel_ms(fe.line.h, k, C.byref(ms), C.byref(n))
-            per_ms.append(ms.value / max(n.value, 1))
+            tot.append((ms.value, n.value))
+        return tot
+
+    if rank == 0:
+        names = ["k_pyr_down x7", "k_fast_cells", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
+                 "k_lsd_grow", "k_keylines", "LBD (blur+sobel+k_lbd)"]
+        t1 = read_kernel_totals()
+        per_ms_timed = [ms / max(n, 1) for ms, n in t1]   # HIP events on the launch streams, over the timed region
+        # one more pass with both halves on one stream: per-kernel durations without interference between the halves
+        fe.overlap = False
+        for _ in range(2):
+            fe.step(d_imgs)
+        torch.cuda.synchronize(dev)
+        t2 = read_kernel_totals()
+        per_ms = [(b[0] - a[0]) / max(b[1] - a[1], 1) for a, b in zip(t1, t2)]
+        fe.overlap = not args.serial
         sizes = level_sizes(rows, cols, args.nlevels)
         Ppx = sum(w * h for w, h in sizes)
         WH = rows * cols
@@ -207,22 +222,25 @@ def main():
                0,
                2 * WH + WH + 4 * WH + nln * 63 * 80 * 4]                 # LBD: blur, Sobel read/write, band gathers
         dom = int(np.argmax(per_ms))
-
-        def roof(k):
-            ach = alg[k] * B / (per_ms[k] * 1e-3) / 1e9 if per_ms[k] > 0 else 0.0
-            return {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(alg[k] * B),
-                    "ms_per_launch": round(per_ms[k], 4)}
-
-        r_dom = roof(dom)
+        # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                if tj.get("kernel") == names[dom]:
-                    r_dom["traffic"] = int(tj["bytes_per_frame"] * B)
+                traffic = json.load(open(tpath)).get("kernels", {})
             except Exception:
-                pass
+                traffic = {}
+        pmc_names = {1: ["k_fast_cells"], 5: ["k_lsd_grow"], 0: ["k_pyr_down"], 2: ["k_octree"], 3: ["k_orient_brief"]}
+
+        def roof(k, ms, where):
+            ach = alg[k] * B / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            t = [traffic[n]["total"] * traffic[n].get("launches_per_step", 1) for n in pmc_names.get(k, []) if n in traffic]
+            return {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": int(sum(t) * B) if t else None,
+                    "algorithmic_bytes_per_launch": int(alg[k] * B), "ms_per_launch": round(ms, 4), "measured": where}
+
+        r_dom = roof(dom, per_ms_timed[dom], "HIP events on the launch stream over the timed region")
+        r_dom["ms_per_launch_alone"] = round(per_ms[dom], 4)
         out = {
             "metric": "frames/s ORB+LSD extract+match, %dx%d mono" % (cols, rows),
             "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
@@ -235,9 +253,12 @@ def main():
                        "mean_orb_matches_per_pair": round(float(res["nm_orb"].mean()), 1),
                        "mean_line_matches_per_pair": round(float(res["nm_line"].mean()), 1),
                        "vocabulary": "synthetic k=10 L=6 (ORBvoc.bin is not in the mount)",
+                       "streams": "line chain on a high-priority stream, ORB + BoW + SearchByBoW on a second stream" if not args.serial else "one stream",
                        "parallelism": "frames sharded 1 batch/GPU" + (", RCCL all_gather of records" if world > 1 else "")},
             "kernel_ms_per_launch": {names[k]: round(per_ms[k], 4) for k in range(8)},
-            "roofline": r_dom, "roofline_fast": roof(1),
+            "kernel_ms_per_launch_timed_region": {names[k]: round(per_ms_timed[k], 4) for k in range(8)},
+            "roofline": r_dom,
+            "roofline_fast": roof(1, per_ms[1], "HIP events, extra pass after the timed region with both halves on one stream"),
         }
         if not args.no_cpu_baseline:
             O = _util.oracle()

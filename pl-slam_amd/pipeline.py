@@ -59,6 +59,7 @@ class FrontEndBatch:
         self.ev_start = torch.cuda.Event()
         self.ev_orb = torch.cuda.Event()
         self.ev_line = torch.cuda.Event()
+        self.overlap = True    # False: both halves on the caller's stream (per-kernel timing without interference)
         helper = P._Dev(self.lib, device)
         self.voc_dev = vocab.device_arrays(helper)
         L = self.lib
@@ -80,8 +81,9 @@ class FrontEndBatch:
         nd, cs, cc, wi, wt = self.voc_dev
         self.ev_start.record(main)
         # ---- line half on the high-priority stream
-        sl = self.line_stream
-        sl.wait_event(self.ev_start)
+        sl = self.line_stream if self.overlap else main
+        if self.overlap:
+            sl.wait_event(self.ev_start)
         sm = sl.cuda_stream
         self.line.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kl, self.ldesc, self.lfn, self.nl, sm)
         with t.cuda.stream(sl):
@@ -92,8 +94,9 @@ class FrontEndBatch:
                                                        C.c_void_p(sm)),
                  "plh_line_search_double_batch_dev")
         # ---- ORB half on its own stream
-        so = self.orb_stream
-        so.wait_event(self.ev_start)
+        so = self.orb_stream if self.overlap else main
+        if self.overlap:
+            so.wait_event(self.ev_start)
         sp = C.c_void_p(so.cuda_stream)
         self.orb.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kps, self.desc, self.n, so.cuda_stream)
         with t.cuda.stream(so):   # slot B := frame 0 (so that frame B-1 has a successor)
@@ -105,10 +108,11 @@ class FrontEndBatch:
                                                          p(self.desc[1:]), p(self.kps[1:]), p(self.nid[1:]), p(self.n[1:]),
                                                          self.ocap, B, 50, 0.7, 1, p(self.m_orb), p(self.nm_orb), sp),
                  "plh_orb_search_by_bow_kp_batch_dev")
-        self.ev_orb.record(so)
-        self.ev_line.record(sl)
-        main.wait_event(self.ev_orb)   # the step is complete on the caller's stream
-        main.wait_event(self.ev_line)
+        if self.overlap:
+            self.ev_orb.record(so)
+            self.ev_line.record(sl)
+            main.wait_event(self.ev_orb)   # the step is complete on the caller's stream
+            main.wait_event(self.ev_line)
 
     def results(self):
         """Host copies of everything one step produced (synchronises)."""
