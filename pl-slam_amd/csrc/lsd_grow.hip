@@ -13,12 +13,11 @@ struct alignas(16) D2 {
 };
 
 struct GrowCtx {
-  const LsdPix* G;     // level-line records of the scaled image
+  LsdPix* G;           // level-line records of the scaled image; bit 31 of .q is the region-growing `used` mark
   const float2* S;     // per pixel (float)cos / (float)sin of the double angle: region_grow()'s seed terms
   uint32_t* reg;       // region queue (global memory); entries are packed coordinates x | y << 16
   uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
   uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
-  uint32_t* bm;        // LDS `used` bitmap
   double* T;           // LDS [3][64] doubles: lane -> chain transposition buffer of the sequential double sums
   int spitch, sw, sh, lane;
   unsigned qThresh;
@@ -36,6 +35,7 @@ __device__ unsigned long long g_grow_prof[16];
 #endif
 constexpr int LSD_RING = 512;    // 2 KiB; the chain buffer T (1.5 KiB) aliases it (never live at the same time)
 constexpr int LSD_PTS = 8;      // queue points examined per step (8 points x 8 neighbours = 64 lanes)
+constexpr unsigned LSD_USED = 0x80000000u;   // `used` mark, kept in bit 31 of LsdPix::q (q = gx^2+gy^2 < 2^20)
 
 __device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xffffu); }
 __device__ __forceinline__ int pk_y(uint32_t p) { return (int)(p >> 16); }
@@ -89,12 +89,14 @@ struct LsdCand {
 //   4. commits everything up to the first lane whose real decision differs from the prediction (decisions in
 //      front of it were taken on exact states, so they are the reference's), and repeats from there.
 // Mispredictions only happen for pixels within the step's angle drift of the tolerance boundary.
-__device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const LsdCand& cd, bool mayDup, double prec,
-                                            float& sumdx, float& sumdy, float& regAngF, int& cnt) {
+// Returns the mask of the lanes whose pixel was accepted.
+__device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, bool cand, const LsdCand& cd, bool mayDup,
+                                                          double prec, float& sumdx, float& sumdy, float& regAngF, int& cnt) {
   const int lane = c.lane;
+  unsigned long long accAll = 0;
   unsigned long long rem = wballot(cand);
   PF_ADD(c, 10, __popcll(rem));
-  if (!rem) return;
+  if (!rem) return 0;
   const double a = (double)cd.px.angf * kDegToRads;
   const unsigned long long ltMask = lanemask_lt();
   while (rem) {
@@ -140,8 +142,9 @@ __device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const L
         const int slot = cnt + __popcll(A & ltMask);
         c.reg[slot] = cd.npk;
         c.ring[slot & (LSD_RING - 1)] = cd.npk;
-        atomicOr(&c.bm[cd.nidx >> 5], 1u << (cd.nidx & 31));
+        c.G[cd.nidx].q = cd.px.q | LSD_USED;
       }
+      accAll |= A;
       const int last = 63 - __clzll((long long)A);
       sumdx = bcast_f32(postX, last);
       sumdy = bcast_f32(postY, last);
@@ -152,11 +155,15 @@ __device__ __forceinline__ void lsd_resolve(const GrowCtx& c, bool cand, const L
     PF_ADD(c, 13, 1);
     rem &= ~((2ull << f) - 1ull);
     if (mayDup && rem) {   // drop the duplicates of what has just been committed
-      PLH_WAVE_SYNC();
-      const bool nowUsed = ((rem >> lane) & 1ull) && ((c.bm[cd.nidx >> 5] >> (cd.nidx & 31)) & 1u);
-      rem &= ~wballot(nowUsed);
+      unsigned long long am = A;
+      while (am) {
+        const int k = __ffsll((long long)am) - 1;
+        am &= am - 1;
+        rem &= ~wballot(cd.nidx == bcast_u32(cd.nidx, k));
+      }
     }
   }
+  return accAll;
 }
 
 // Addressing of one neighbour lane: lane 8g+n looks at neighbour n (yy outer, xx inner, centre skipped) of queue
@@ -185,24 +192,26 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int q, int cnt, bool 
 // (firstGrp < 0: not prefetched).
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
 // reference's float fastAtan2 result).  All lanes hold identical (uniform) state.
-__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk, float seedAngF, float seedCos, float seedSin,
-                                               double prec, const LsdCand& first, int firstGrp, float* regAngOut) {
+__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk, unsigned seedQ, float seedAngF, float seedCos,
+                                               float seedSin, double prec, const LsdCand& first, int firstGrp,
+                                               float* regAngOut) {
   const int lane = c.lane, g = lane >> 3;
   float regAngF = seedAngF, sumdx = seedCos, sumdy = seedSin;
   const uint32_t seed = pk_lin(c, seedPk);
-  PLH_WAVE_SYNC();   // every lane has finished reading the seed's `used` bit before it is set
+  PLH_WAVE_SYNC();
   if (lane == 0) {
     c.reg[0] = seedPk;
     c.ring[0] = seedPk;
-    atomicOr(&c.bm[seed >> 5], 1u << (seed & 31));
+    c.G[seed].q = seedQ | LSD_USED;
   }
   PF_ADD(c, 11, 1);
   int cnt = 1, i = 0;
   PLH_WAVE_SYNC();
   if (firstGrp >= 0) {
     const unsigned long long pt1 = PF_NOW();
-    const bool cand = g == firstGrp && first.inb && first.px.q > c.qThresh &&
-                      !((c.bm[first.nidx >> 5] >> (first.nidx & 31)) & 1u);
+    // first.px.q was re-read after the previous region finished: > qThresh also rejects marked pixels? no -- the mark
+    // is bit 31, so test it explicitly
+    const bool cand = g == firstGrp && first.inb && !(first.px.q & LSD_USED) && first.px.q > c.qThresh;
     lsd_resolve(c, cand, first, false, prec, sumdx, sumdy, regAngF, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
     i = 1;
@@ -216,6 +225,8 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
   uint32_t nidxA, npkA, nidxB = 0, npkB = 0;
   bool inbA = lsd_addr(c, i + g, cnt, i + g < cnt, nidxA, npkA), inbB = false;
   LsdPix pxA = c.G[nidxA], pxB = pxA;
+  unsigned long long accPrev = 0;   // lanes accepted by the previous step (their marks may postdate set A's loads)
+  uint32_t nidxPrev = 0;
   while (i < cnt) {
     const unsigned long long pt0 = PF_NOW();
     const int m = min(LSD_PTS, cnt - i), cnt0 = cnt;
@@ -231,10 +242,18 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
     inbA = lsd_addr(c, i + LSD_PTS + g, cnt, i + LSD_PTS + g < cnt, nidxA, npkA);
     pxA = c.G[nidxA];
     PLH_WAVE_SYNC();
-    const bool cand = cur.inb && cur.px.q > c.qThresh && !((c.bm[cur.nidx >> 5] >> (cur.nidx & 31)) & 1u);
+    // set A of this step was requested before the previous step marked its pixels: cancel those by comparison
+    unsigned long long stale = 0;
+    while (accPrev) {
+      const int k = __ffsll((long long)accPrev) - 1;
+      accPrev &= accPrev - 1;
+      stale |= wballot(cur.nidx == bcast_u32(nidxPrev, k));
+    }
+    const bool cand = cur.inb && !(cur.px.q & LSD_USED) && cur.px.q > c.qThresh && !((stale >> lane) & 1ull);
     const unsigned long long pt1 = PF_NOW();
     PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
-    lsd_resolve(c, cand, cur, true, prec, sumdx, sumdy, regAngF, cnt);
+    accPrev = lsd_resolve(c, cand, cur, true, prec, sumdx, sumdy, regAngF, cnt);
+    nidxPrev = cur.nidx;
     PF_ADD(c, 4, PF_NOW() - pt1);
     i += m;
     // set B: the points queued by this step
@@ -280,7 +299,7 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     double w = 0, wx = 0, wy = 0;
     if (i < cnt) {
       const uint32_t p = c.reg[i];
-      w = q_modgrad(c.G[pk_lin(c, p)].q);
+      w = q_modgrad(c.G[pk_lin(c, p)].q & ~LSD_USED);
       wx = (double)pk_x(p) * w;
       wy = (double)pk_y(p) * w;
     }
@@ -299,7 +318,7 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     double a = 0, b = 0, cc = 0;
     if (i < cnt) {
       const uint32_t p = c.reg[i];
-      const double w = q_modgrad(c.G[pk_lin(c, p)].q);
+      const double w = q_modgrad(c.G[pk_lin(c, p)].q & ~LSD_USED);
       const double ddx = (double)pk_x(p) - x, ddy = (double)pk_y(p) - y;
       a = ddy * ddy * w;
       b = ddx * ddx * w;
@@ -358,7 +377,7 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
       near = !(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p)) > radSq);
       if (!near) {
         const uint32_t li = pk_lin(c, p);
-        atomicAnd(&c.bm[li >> 5], ~(1u << (li & 31)));
+        c.G[li].q &= ~LSD_USED;
       }
     }
     K += __popcll(__ballot(near));
@@ -398,15 +417,15 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
 __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int nWords = (a.spitch * a.sh + 31) / 32;
   GrowCtx c;
-  // LDS: ring | bitmap.  T aliases the ring: the ring is only live inside lsd_region_grow (which restarts it),
-  // T only inside region2rect / refine, which read the queue from global memory.  24 KiB bitmap + 2 KiB keeps a
-  // 512x384 frame at 26 KiB, i.e. 6 resident frames per CU (27 KiB already drops to 5, measured).
+  // LDS: the 2 KiB ring only.  T aliases it: the ring is only live inside lsd_region_grow (which restarts it), T only
+  // inside region2rect / refine, which read the queue from global memory.  The `used` map of the reference lives in
+  // bit 31 of the level-line records themselves (k_lsd_grad rewrites them every frame): the test comes for free with
+  // the record load, and with no per-frame bitmap in LDS the number of resident frames per CU is bounded by registers
+  // only.  Marks are plain stores: a frame is owned by one wavefront, whose later loads observe its earlier stores.
   c.ring = (uint32_t*)smem;
   c.T = (double*)smem;
-  c.bm = c.ring + LSD_RING;
-  c.G = reinterpret_cast<const LsdPix*>(a.pix) + (long long)b * a.scaledStride;
+  c.G = reinterpret_cast<LsdPix*>(a.pix) + (long long)b * a.scaledStride;
   c.S = reinterpret_cast<const float2*>(a.seedcs) + (long long)b * a.scaledStride;
   c.reg = a.reg + (long long)b * a.scaledStride;
   c.scr = a.scr + (long long)b * a.scaledStride;
@@ -419,8 +438,6 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   c.pf = pfv;
   const unsigned long long pfStart = PF_NOW();
 #endif
-  for (int i = lane; i < nWords; i += 64) c.bm[i] = 0;
-  __syncthreads();
   const int nOrd = a.nOrdered[b];
   const int grp = lane >> 3, nbr = lane & 7;
   const int nbq = nbr < 4 ? nbr : nbr + 1;
@@ -433,15 +450,18 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
     const uint32_t seedP = si < nOrd ? ord[si] : 0u;
     const uint32_t seedL = pk_lin(c, seedP);
     PLH_WAVE_SYNC();
-    const bool alive = si < nOrd && !((c.bm[seedL >> 5] >> (seedL & 31)) & 1u);
-    unsigned long long fm = __ballot(alive);
-    float sAng = 0.f;
+    LsdPix sPx;
+    sPx.angf = 0.f; sPx.cs = 0.f; sPx.sn = 0.f; sPx.q = LSD_USED;
     float2 sCS;
     sCS.x = 0.f; sCS.y = 0.f;
-    if (alive) {
-      sAng = c.G[seedL].angf;
+    if (si < nOrd) {
+      sPx = c.G[seedL];
       sCS = c.S[seedL];
     }
+    const bool alive = !(sPx.q & LSD_USED);
+    unsigned long long fm = __ballot(alive);
+    const float sAng = sPx.angf;
+    bool dirtySeed = false, dirtyFst = false;   // a region has been grown since this scan / since fst was fetched
     while (fm) {
       // up to 8 surviving seeds at a time: lane group t prefetches the 8 neighbours of the t-th of them
       int skv = 0, mySk = 0, nb = 0;
@@ -464,12 +484,18 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
           fst.px = c.G[fst.nidx];
         }
       }
+      dirtyFst = false;
       for (int t = 0; t < nb; t++) {
         const int sk = (int)bcast_u32((unsigned)skv, t);
         uint32_t seedPk = bcast_u32(seedP, sk);
         uint32_t seed = bcast_u32(seedL, sk);
+        unsigned seedQ = bcast_u32(sPx.q, sk);
         PLH_WAVE_SYNC();
-        if ((c.bm[seed >> 5] >> (seed & 31)) & 1u) continue;   // swallowed by a region grown since the scan
+        // marks may have changed since the scan / the neighbourhood prefetch: re-read them (one round trip)
+        if (dirtySeed) seedQ = c.G[seed].q;
+        if (dirtyFst && grp == t && fst.inb) fst.px.q = c.G[fst.nidx].q;
+        if (seedQ & LSD_USED) continue;   // swallowed by a region grown since the scan
+        dirtySeed = true; dirtyFst = true;
         // region_grow -> region2rect -> [refine: tighter tolerance, re-grow -> region2rect -> reduce_region_radius]
         float gAng = bcast_f32(sAng, sk), gCos = bcast_f32(sCS.x, sk), gSin = bcast_f32(sCS.y, sk);
         double gPrec = a.prec, xc = 0, yc = 0;
@@ -479,7 +505,7 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
         for (;;) {
           float regAngF;
           const unsigned long long pg0 = PF_NOW();
-          int cnt = lsd_region_grow(c, seedPk, gAng, gCos, gSin, gPrec, fst, firstGrp, &regAngF);
+          int cnt = lsd_region_grow(c, seedPk, seedQ, gAng, gCos, gSin, gPrec, fst, firstGrp, &regAngF);
           const unsigned long long pg1 = PF_NOW();
           PF_ADD(c, 2, pg1 - pg0);
           if (cnt < (phase == 0 ? a.minRegSize : 2)) break;
@@ -496,6 +522,7 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
             xc = (double)pk_x(seedPk); yc = (double)pk_y(seedPk);
             const LsdPix g0 = c.G[seed];
             const float2 s0 = c.S[seed];
+            seedQ = g0.q & ~LSD_USED;
             const double ang_c = pix_angle(g0);
             double acc = 0;
             int n = 0;
@@ -506,10 +533,11 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
               if (i < cnt) {
                 const uint32_t p = c.reg[i];
                 const uint32_t li = pk_lin(c, p);
-                atomicAnd(&c.bm[li >> 5], ~(1u << (li & 31)));
+                LsdPix gp = c.G[li];
+                c.G[li].q = gp.q & ~LSD_USED;
                 if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < rec.width) {
                   flag = true;
-                  ang_d = angle_diff_signed(pix_angle(c.G[li]), ang_c);
+                  ang_d = angle_diff_signed(pix_angle(gp), ang_c);
                 }
               }
               n += __popcll(__ballot(flag));
@@ -834,6 +862,6 @@ extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsign
   return 0;
 }
 #endif
-size_t lsd_grow_lds_bytes(int spitch, int sh) { return (size_t)((spitch * sh + 31) / 32 + LSD_RING) * 4; }
+size_t lsd_grow_lds_bytes(int spitch, int sh) { (void)spitch; (void)sh; return (size_t)LSD_RING * 4; }
 
 }  // namespace plh
