@@ -12,7 +12,8 @@ namespace plh {
 
 // launchers implemented in orb_kernels.hip
 void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, hipStream_t s);
-void launch_fast_cells(const OrbDeviceArgs& a, hipStream_t s);
+void launch_fast_strips(const OrbDeviceArgs& a, size_t lds, hipStream_t s);
+size_t fast_strip_lds_bytes(int width, int ch);
 size_t octree_lds_bytes(int nodeCap);
 void launch_octree(const OrbDeviceArgs& a, int nodeCapMax, hipStream_t s);
 void launch_orient_brief(const OrbDeviceArgs& a, plh_keypoint* kps, uint8_t* desc, int* nOut, int cap, hipStream_t s);
@@ -52,12 +53,15 @@ struct plh_orb {
   std::vector<int> perLevel;
   std::vector<OrbLevel> levels;
   std::vector<OrbCell> cells;
+  std::vector<OrbStrip> strips;
+  size_t fastLds = 0;
   std::vector<ResizeTap> xtab, ytab;
   int nodeCapMax = 0, selPerFrame = 0;
   long long pyrFrameBytes = 0, slotsPerFrame = 0;
   // device
   OrbLevel* dLevels = nullptr;
   OrbCell* dCells = nullptr;
+  OrbStrip* dStrips = nullptr;
   ResizeTap *dXtab = nullptr, *dYtab = nullptr;
   uint8_t* dPyr = nullptr;
   uint32_t *dSlots = nullptr, *dCellCount = nullptr, *dKeys = nullptr, *dSel = nullptr;
@@ -196,6 +200,20 @@ plh_status build_plan(plh_orb* h) {
     }
     L.nCells = (int)h->cells.size() - L.cellBase;
     L.slotCap = slotOff - L.slotOff;
+    // strips: consecutive cells of one cell row (same y0) -> one k_fast_strips block
+    for (int ci = L.cellBase; ci < (int)h->cells.size();) {
+      int cj = ci;
+      while (cj < (int)h->cells.size() && h->cells[cj].y0 == h->cells[ci].y0) cj++;
+      OrbStrip st;
+      st.level = (short)l; st.nCells = (short)(cj - ci); st.cellFirst = ci;
+      st.x0 = h->cells[ci].x0; st.y0 = h->cells[ci].y0;
+      st.xEnd = (short)(h->cells[cj - 1].x0 + h->cells[cj - 1].cw); st.ch = h->cells[ci].ch;
+      st.wCell = (short)(cj - ci > 1 ? h->cells[ci + 1].x0 - h->cells[ci].x0 : std::max<int>(h->cells[ci].cw - 6, 1));
+      st.pad = 0;
+      h->strips.push_back(st);
+      h->fastLds = std::max(h->fastLds, fast_strip_lds_bytes(st.xEnd - st.x0, st.ch));
+      ci = cj;
+    }
     // DistributeOctTree, ORBextractor.cc:543-545
     L.nFeat = h->perLevel[l];
     L.nIni = (int)std::round(static_cast<float>(L.maxBX - L.minBX) / (L.maxBY - L.minBY));
@@ -212,6 +230,10 @@ plh_status build_plan(plh_orb* h) {
   h->pyrFrameBytes = align_up<long long>(off, 256);
   h->slotsPerFrame = align_up<long long>(slotOff, 64);
   h->selPerFrame = selOff;
+  if (h->fastLds > 150 * 1024) {
+    set_error("image too wide for the FAST strip tile (%zu bytes of LDS)", h->fastLds);
+    return PLH_ERR_INVALID;
+  }
   if (h->nodeCapMax > 8000 || octree_lds_bytes(h->nodeCapMax) > 150 * 1024) {
     set_error("nfeatures too large for the quad-tree LDS plan (node cap %d)", h->nodeCapMax);
     return PLH_ERR_INVALID;
@@ -222,7 +244,7 @@ plh_status build_plan(plh_orb* h) {
 void fill_args(const plh_orb* h, const uint8_t* dImgs, long long stride, int batch, OrbDeviceArgs* a) {
   a->img0 = dImgs; a->stride0 = stride;
   a->pyr = h->dPyr; a->pyrFrameBytes = h->pyrFrameBytes;
-  a->levels = h->dLevels; a->cells = h->dCells; a->xtab = h->dXtab; a->ytab = h->dYtab;
+  a->levels = h->dLevels; a->cells = h->dCells; a->strips = h->dStrips; a->nStrips = (int)h->strips.size(); a->xtab = h->dXtab; a->ytab = h->dYtab;
   a->slots = h->dSlots; a->slotsPerFrame = h->slotsPerFrame; a->cellCount = h->dCellCount;
   a->keys = h->dKeys; a->sel = h->dSel; a->selCount = h->dSelCount; a->selPerFrame = h->selPerFrame;
   a->nlevels = h->nlevels; a->nCellsTotal = (int)h->cells.size(); a->batch = batch;
@@ -295,6 +317,7 @@ plh_status plh_orb_create(const plh_orb_params* p, int device, int rows, int col
 #define TRYHIP(x) do { if ((x) != hipSuccess) { set_error("plh_orb_create: %s failed (batch %d)", #x, max_batch); plh_orb_destroy(h); return PLH_ERR_ALLOC; } } while (0)
   TRY(upload(h->levels, &h->dLevels));
   TRY(upload(h->cells, &h->dCells));
+  TRY(upload(h->strips, &h->dStrips));
   TRY(upload(h->xtab, &h->dXtab));
   TRY(upload(h->ytab, &h->dYtab));
   TRYHIP(hipMalloc((void**)&h->dPyr, std::max<size_t>(B * h->pyrFrameBytes, 256)));
@@ -315,7 +338,7 @@ plh_status plh_orb_create(const plh_orb_params* p, int device, int rows, int col
 plh_status plh_orb_destroy(plh_orb* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dLevels, h->dCells, h->dXtab, h->dYtab, h->dPyr, h->dSlots, h->dCellCount, h->dKeys,
+  void* ptrs[] = {h->dLevels, h->dCells, h->dStrips, h->dXtab, h->dYtab, h->dPyr, h->dSlots, h->dCellCount, h->dKeys,
                   h->dSel, h->dSelCount, h->dStatus, h->dImgs, h->dKps, h->dDesc, h->dN};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -359,7 +382,7 @@ plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batc
   }
   prof_mark(h, 0, s);
   prof_mark(h, 1, s);
-  launch_fast_cells(a, s);
+  launch_fast_strips(a, h->fastLds, s);
   PLH_LAUNCH_CHECK();
   prof_mark(h, 1, s);
   prof_mark(h, 2, s);

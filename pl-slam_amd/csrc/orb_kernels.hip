@@ -3,7 +3,7 @@
 // never fill 256 CUs by itself (DESIGN.md "batch-first").
 //
 //   k_pyr_down      cv::resize(INTER_LINEAR) level l-1 -> l      ORBextractor::ComputePyramid   (ORBextractor.cc:1107-1132)
-//   k_fast_cells    per-cell cv::FAST 9/16 + 3x3 NMS + fallback   ComputeKeyPointsOctTree        (ORBextractor.cc:789-829)
+//   k_fast_strips   per-cell cv::FAST 9/16 + 3x3 NMS + fallback   ComputeKeyPointsOctTree        (ORBextractor.cc:789-829)
 //   k_octree        quad-tree keypoint distribution               DistributeOctTree / DivideNode (ORBextractor.cc:481-763)
 //   k_orient_brief  IC_Angle + 7x7 blur + steered rBRIEF          IC_Angle / GaussianBlur / computeOrbDescriptor
 //                                                                 (ORBextractor.cc:77-147, 1085-1101)
@@ -107,112 +107,216 @@ __device__ __forceinline__ int fast_arc_measure(int v, const int p[16]) {
   return max(dark, -bright);
 }
 
-// One block per (cell, frame).  The cell sub-image (<= 66x66) is staged in LDS; scores for the
-// evaluated window go to an LDS score tile; NMS treats everything outside the cell's window as
-// score 0 exactly like a per-cell cv::FAST call; wave 0 then emits survivors in raster order.
-// If no survivor reaches iniThFAST the cell falls back to minThFAST (ORBextractor.cc:808-816).
-__global__ void __launch_bounds__(256) k_fast_cells(OrbDeviceArgs a) {
-  __shared__ uint8_t tile[ORB_CELL_MAX * (ORB_CELL_MAX + 2)];
-  __shared__ uint8_t sc[60 * 60];
-  __shared__ uint8_t fl[60 * 60];
-  __shared__ int s_hi;
-  constexpr int TP = ORB_CELL_MAX + 2;
+// One block per (row of FAST cells, frame).  The rows of the level that the cell row covers are staged in LDS with
+// aligned dword copies; every lane then works on groups of 4 horizontally adjacent pixels held in one dword:
+//   1. compass quick test (every 9-arc contains one pixel of each antipodal pair) on the packed bytes; pixels that
+//      pass are queued per wave and the full 16-ring arc measure runs on dense batches of 64 queued pixels, so the
+//      expensive part never executes with mostly idle lanes,
+//   2. 3x3 NMS on the score tile, where everything outside the pixel's own cell window counts as score 0 exactly
+//      like a per-cell cv::FAST call,
+//   3. one wavefront per cell emits the survivors in raster order; a cell without a survivor at iniThFAST falls
+//      back to minThFAST (ORBextractor.cc:808-816).
+// Tile column c holds level column xa + c with xa = (x0 & ~3) - 4, so pixel groups are dword aligned in the tile,
+// the score tile and the flag tile (which reuses the image tile's memory).
+constexpr int FAST_QCAP = 128;   // per-wave queue of pixels that passed the quick test
+#if defined(HIPEMU)
+#define ORB_WAVE_SYNC() hipemu::wave_barrier()
+#else
+#define ORB_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 
-  // XCD-aware decode: block L runs on XCD (L % 8); keep all cells of a frame on one XCD so the
-  // overlapping cell halos and the level rows are served from that XCD's L2.
+__device__ __forceinline__ unsigned ld_u32(const uint8_t* p) { return *reinterpret_cast<const unsigned*>(p); }
+__device__ __forceinline__ unsigned align_bytes(unsigned hi, unsigned lo, int sh) {   // bytes sh..sh+3 of {hi:lo}
+  return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * sh));
+}
+
+__device__ __forceinline__ void fast_score_pixel(const uint8_t* tile, int TP, uint8_t* sc, int r, int cx, int tlo) {
+  const uint8_t* t = tile + r * TP + cx;
+  const int v = t[0];
+  int p[16];
+  p[0] = t[3 * TP];       p[1] = t[3 * TP + 1];   p[2] = t[2 * TP + 2];   p[3] = t[TP + 3];
+  p[4] = t[3];            p[5] = t[-TP + 3];      p[6] = t[-2 * TP + 2];  p[7] = t[-3 * TP + 1];
+  p[8] = t[-3 * TP];      p[9] = t[-3 * TP - 1];  p[10] = t[-2 * TP - 2]; p[11] = t[-TP - 3];
+  p[12] = t[-3];          p[13] = t[TP - 3];      p[14] = t[2 * TP - 2];  p[15] = t[3 * TP - 1];
+  const int M = fast_arc_measure(v, p);
+  if (M > tlo) sc[(r - 2) * TP + cx] = (uint8_t)(M - 1);   // score row rr = r - 3 is stored at sc row rr + 1
+}
+
+__global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  __shared__ unsigned s_queue[4][FAST_QCAP];
+  __shared__ int s_hi[64];
+
+  // XCD-aware decode: block L runs on XCD (L % 8); keep all strips of a frame on one XCD so the overlapping halos
+  // and the level rows are served from that XCD's L2.
   const int L = blockIdx.x;
   const int xcd = L & 7, q = L >> 3;
-  const int cell = q % a.nCellsTotal;
-  const int b = (q / a.nCellsTotal) * 8 + xcd;
+  const int strip = q % a.nStrips;
+  const int b = (q / a.nStrips) * 8 + xcd;
   if (b >= a.batch) return;
 
-  const OrbCell c = a.cells[cell];
-  const OrbLevel lv = a.levels[c.level];
-  const uint8_t* src = level_ptr(a, lv, c.level, b);
-  const int tid = threadIdx.x;
-  const int cw = c.cw, ch = c.ch;
-
-  for (int i = tid; i < cw * ch; i += 256) {
-    const int r = i / cw, col = i - r * cw;
-    tile[r * TP + col] = src[(long long)(c.y0 + r) * lv.pitch + c.x0 + col];
-  }
-  if (tid == 0) s_hi = 0;
-  __syncthreads();
-
-  const int ew = cw - 6, eh = ch - 6;
-  const int npx = (ew > 0 && eh > 0) ? ew * eh : 0;
+  const OrbStrip st = a.strips[strip];
+  const OrbLevel lv = a.levels[st.level];
+  const uint8_t* src = level_ptr(a, lv, st.level, b);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int xa = (st.x0 & ~3) - 4;                       // level column of tile column 0
+  const int TP = ((st.xEnd + 4 - xa + 3) & ~3) + 4;      // tile pitch (bytes), multiple of 4
+  const int ch = st.ch, eh = ch - 6;
+  const int ex0 = st.x0 + 3, ex1 = st.xEnd - 3;          // evaluated columns [ex0, ex1), level coordinates
+  uint8_t* tile = smem;                                  // [ch][TP]
+  uint8_t* sc = smem + ((ch * TP + 15) & ~15);           // [eh + 2][TP], rows 0 and eh + 1 stay zero
+  uint8_t* fl = tile;                                    // [eh][TP], reuses the image tile after the scores are done
   const int tlo = min(a.iniTh, a.minTh);
 
-  for (int i = tid; i < npx; i += 256) {
-    const int ey = i / ew, ex = i - ey * ew;
-    const uint8_t* t = &tile[(ey + 3) * TP + ex + 3];
-    const int v = t[0];
-    int S = 0;
-    // antipodal quick reject: every 9-arc contains one pixel of each antipodal pair
-    const int p0 = t[3 * TP], p8 = t[-3 * TP], p4 = t[3], p12 = t[-3];
-    const bool q0 = (abs(v - p0) > tlo) || (abs(v - p8) > tlo);
-    const bool q4 = (abs(v - p4) > tlo) || (abs(v - p12) > tlo);
-    if (q0 && q4) {
-      int p[16];
-      p[0] = p0;              p[1] = t[3 * TP + 1];   p[2] = t[2 * TP + 2];   p[3] = t[TP + 3];
-      p[4] = p4;              p[5] = t[-TP + 3];      p[6] = t[-2 * TP + 2];  p[7] = t[-3 * TP + 1];
-      p[8] = p8;              p[9] = t[-3 * TP - 1];  p[10] = t[-2 * TP - 2]; p[11] = t[-TP - 3];
-      p[12] = p12;            p[13] = t[TP - 3];      p[14] = t[2 * TP - 2];  p[15] = t[3 * TP - 1];
-      const int M = fast_arc_measure(v, p);
-      if (M > tlo) S = M - 1;
+  // ---- stage the rows (dword copies when the source rows are dword aligned), clear the score tile
+  {
+    const int nd = TP >> 2;
+    const int xmaxd = (lv.pitch - xa) >> 2;              // dwords that stay inside the source row
+    if (((lv.pitch | (int)(size_t)src) & 3) == 0) {
+      for (int i = tid; i < ch * nd; i += 256) {
+        const int r = i / nd, d = i - r * nd;
+        unsigned v = 0;
+        if (d < xmaxd) v = ld_u32(src + (long long)(st.y0 + r) * lv.pitch + xa + 4 * d);
+        reinterpret_cast<unsigned*>(tile)[r * nd + d] = v;
+      }
+    } else {
+      for (int i = tid; i < ch * TP; i += 256) {
+        const int r = i / TP, c = i - r * TP;
+        tile[i] = (xa + c < lv.w) ? src[(long long)(st.y0 + r) * lv.pitch + xa + c] : (uint8_t)0;
+      }
     }
-    sc[i] = (uint8_t)S;
+    const int ns = ((eh + 2) * TP) >> 2;
+    for (int i = tid; i < ns; i += 256) reinterpret_cast<unsigned*>(sc)[i] = 0u;
+    if (tid < 64) s_hi[tid] = 0;
   }
   __syncthreads();
 
-  int myhi = 0;
-  for (int i = tid; i < npx; i += 256) {
-    const int ey = i / ew, ex = i - ey * ew;
-    const int s = sc[i];
-    int f = 0;
-    if (s > 0 && s >= tlo) {
-      int m = 0;
-      const bool l = ex > 0, r = ex < ew - 1, u = ey > 0, d = ey < eh - 1;
-      if (l) m = max(m, (int)sc[i - 1]);
-      if (r) m = max(m, (int)sc[i + 1]);
-      if (u) {
-        m = max(m, (int)sc[i - ew]);
-        if (l) m = max(m, (int)sc[i - ew - 1]);
-        if (r) m = max(m, (int)sc[i - ew + 1]);
+  // ---- scores
+  const int gx0 = (ex0 - xa) >> 2, gx1 = (ex1 - 1 - xa) >> 2;   // dword columns that contain evaluated pixels
+  const int ngx = gx1 - gx0 + 1;
+  const int ngroups = eh > 0 && ex1 > ex0 ? ngx * eh : 0;
+  unsigned* myq = s_queue[wv];
+  int qn = 0;
+  for (int base = wv * 64; base < ngroups; base += 256) {
+    const int g = base + lane;
+    unsigned pass = 0;
+    int r = 0, cx = 0;
+    if (g < ngroups) {
+      const int rr = g / ngx;
+      r = rr + 3;
+      cx = (gx0 + (g - rr * ngx)) << 2;
+      const uint8_t* t = tile + r * TP + cx;
+      const unsigned C = ld_u32(t), Lw = ld_u32(t - 4), R = ld_u32(t + 4), U = ld_u32(t - 3 * TP), D = ld_u32(t + 3 * TP);
+      const unsigned P12 = align_bytes(C, Lw, 1), P4 = align_bytes(R, C, 3);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int x = xa + cx + k;
+        const int v = (C >> (8 * k)) & 255;
+        const int d0 = v - (int)((D >> (8 * k)) & 255), d8 = v - (int)((U >> (8 * k)) & 255);
+        const int d4 = v - (int)((P4 >> (8 * k)) & 255), d12 = v - (int)((P12 >> (8 * k)) & 255);
+        const bool q0 = (abs(d0) > tlo) || (abs(d8) > tlo);
+        const bool q4 = (abs(d4) > tlo) || (abs(d12) > tlo);
+        if (q0 && q4 && x >= ex0 && x < ex1) pass |= 1u << k;
       }
-      if (d) {
-        m = max(m, (int)sc[i + ew]);
-        if (l) m = max(m, (int)sc[i + ew - 1]);
-        if (r) m = max(m, (int)sc[i + ew + 1]);
-      }
-      if (s > m) f = (s >= a.iniTh) ? 2 : (s >= a.minTh ? 1 : 0);
     }
-    fl[i] = (uint8_t)f;
-    myhi += (f == 2);
+    // queue the passing pixels of this wave (row : 8 | column : 16), drain dense batches of 64
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool pk = (pass >> k) & 1u;
+      const unsigned long long m = __ballot(pk);
+      if (pk) myq[qn + __popcll(m & lanemask_lt())] = ((unsigned)r << 16) | (unsigned)(cx + k);
+      qn += __popcll(m);
+      if (qn >= 64) {
+        ORB_WAVE_SYNC();
+        const unsigned e = myq[qn - 64 + lane];
+        ORB_WAVE_SYNC();
+        fast_score_pixel(tile, TP, sc, (int)(e >> 16), (int)(e & 0xffffu), tlo);
+        qn -= 64;
+      }
+    }
   }
-  if (myhi) atomicAdd(&s_hi, myhi);
+  ORB_WAVE_SYNC();
+  if (lane < qn) {
+    const unsigned e = myq[lane];
+    fast_score_pixel(tile, TP, sc, (int)(e >> 16), (int)(e & 0xffffu), tlo);
+  }
   __syncthreads();
 
-  if (tid < 64) {
-    const int need = s_hi > 0 ? 2 : 1;
+  // ---- 3x3 NMS inside each cell window + threshold class (2: >= iniThFAST, 1: >= minThFAST)
+  {
+    const int nf = (eh * TP) >> 2;
+    for (int i = tid; i < nf; i += 256) reinterpret_cast<unsigned*>(fl)[i] = 0u;
+  }
+  __syncthreads();
+  const int lastCell = st.nCells - 1;
+  for (int g = tid; g < ngroups; g += 256) {
+    const int rr = g / ngx;
+    const int cx = (gx0 + (g - rr * ngx)) << 2;
+    const uint8_t* s1 = sc + (rr + 1) * TP + cx;
+    const unsigned S = ld_u32(s1);
+    if (S == 0u) continue;
+    const unsigned Sl = ld_u32(s1 - 4), Sr = ld_u32(s1 + 4);
+    const unsigned Tc = ld_u32(s1 - TP), Tl = ld_u32(s1 - TP - 4), Tr = ld_u32(s1 - TP + 4);
+    const unsigned Bc = ld_u32(s1 + TP), Bl = ld_u32(s1 + TP - 4), Br = ld_u32(s1 + TP + 4);
+    unsigned F = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int s = (S >> (8 * k)) & 255;
+      if (s == 0 || s < tlo) continue;
+      const int x = xa + cx + k;
+      const int ex = x - ex0;                             // column inside the strip's evaluated window
+      const int cj = min(ex / st.wCell, lastCell);
+      const int cxs = ex - cj * st.wCell;                 // column inside the cell's evaluated window
+      const int cew = (cj == lastCell ? (ex1 - ex0) - cj * st.wCell : (int)st.wCell);
+      const bool lft = cxs > 0, rgt = cxs < cew - 1;
+      // neighbours at x-1 / x+1 : bytes 3..6 and 5..8 of the 12-byte window {left, centre, right}
+      const unsigned sL = k > 0 ? (S >> (8 * (k - 1))) & 255 : (Sl >> 24);
+      const unsigned sR = k < 3 ? (S >> (8 * (k + 1))) & 255 : (Sr & 255);
+      const unsigned tL = k > 0 ? (Tc >> (8 * (k - 1))) & 255 : (Tl >> 24);
+      const unsigned tR = k < 3 ? (Tc >> (8 * (k + 1))) & 255 : (Tr & 255);
+      const unsigned bL = k > 0 ? (Bc >> (8 * (k - 1))) & 255 : (Bl >> 24);
+      const unsigned bR = k < 3 ? (Bc >> (8 * (k + 1))) & 255 : (Br & 255);
+      int m = max((int)((Tc >> (8 * k)) & 255), (int)((Bc >> (8 * k)) & 255));   // rows outside the strip are zero
+      if (lft) m = max(m, (int)max(sL, max(tL, bL)));
+      if (rgt) m = max(m, (int)max(sR, max(tR, bR)));
+      if (s > m) {
+        const int f = (s >= a.iniTh) ? 2 : (s >= a.minTh ? 1 : 0);
+        F |= (unsigned)f << (8 * k);
+        if (f == 2) s_hi[cj] = 1;
+      }
+    }
+    if (F) *reinterpret_cast<unsigned*>(fl + rr * TP + cx) = F;
+  }
+  __syncthreads();
+
+  // ---- emission: one wavefront per cell, raster order
+  for (int cj = wv; cj < st.nCells; cj += 4) {
+    const OrbCell c = a.cells[st.cellFirst + cj];
+    const int ew = c.cw - 6;
+    const int npx = (ew > 0 && eh > 0) ? ew * eh : 0;
+    const int need = s_hi[cj] ? 2 : 1;
+    const int colBase = c.x0 + 3 - xa;
     uint32_t* out = a.slots + (long long)b * a.slotsPerFrame + c.slotOff;
     int cnt = 0;
     for (int base = 0; base < npx; base += 64) {
-      const int i = base + tid;
-      const int f = i < npx ? fl[i] : 0;
-      const bool keep = f >= need;
+      const int i = base + lane;
+      int ey = 0, ex = 0;
+      bool keep = false;
+      if (i < npx) {
+        ey = i / ew; ex = i - ey * ew;
+        keep = fl[ey * TP + colBase + ex] >= need;
+      }
       const unsigned long long mask = __ballot(keep);
       if (keep) {
         const int pos = cnt + __popcll(mask & lanemask_lt());
-        const int ey = i / ew, ex = i - ey * ew;
         if (pos < c.slotCap)
-          out[pos] = ((uint32_t)(c.x0 + 3 + ex) << 20) | ((uint32_t)(c.y0 + 3 + ey) << 8) | sc[i];
+          out[pos] = ((uint32_t)(c.x0 + 3 + ex) << 20) | ((uint32_t)(c.y0 + 3 + ey) << 8) | sc[(ey + 1) * TP + colBase + ex];
       }
       cnt += __popcll(mask);
     }
-    if (tid == 0) {
+    if (lane == 0) {
       if (cnt > c.slotCap) { atomicOr(a.status, 1); cnt = c.slotCap; }
-      a.cellCount[(long long)b * a.nCellsTotal + cell] = (uint32_t)cnt;
+      a.cellCount[(long long)b * a.nCellsTotal + st.cellFirst + cj] = (uint32_t)cnt;
     }
   }
 }
@@ -682,10 +786,14 @@ void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, hipStream_
   dim3 grid((pitch / 4 + 63) / 64, (h + 3) / 4, a.batch), block(64, 4);
   hipLaunchKernelGGL(k_pyr_down, grid, block, 0, s, a, l);
 }
-void launch_fast_cells(const OrbDeviceArgs& a, hipStream_t s) {
+size_t fast_strip_lds_bytes(int width, int ch) {   // image tile + score tile of k_fast_strips (width = xEnd - x0)
+  const size_t TP = (size_t)((width + 8 + 3 + 3) & ~3) + 4;
+  return (((size_t)ch * TP + 15) & ~(size_t)15) + (size_t)(ch - 6 + 2 > 2 ? ch - 4 : 2) * TP + 64;
+}
+void launch_fast_strips(const OrbDeviceArgs& a, size_t lds, hipStream_t s) {
   const int groups = (a.batch + 7) / 8;
-  dim3 grid((unsigned)((long long)a.nCellsTotal * groups * 8)), block(256);
-  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, a);
+  dim3 grid((unsigned)((long long)a.nStrips * groups * 8)), block(256);
+  hipLaunchKernelGGL(k_fast_strips, grid, block, lds, s, a);
 }
 size_t octree_lds_bytes(int nodeCap) { return (size_t)nodeCap * (4 * 7 + 2 * 10 + 1) + 64 + 64; }
 void launch_octree(const OrbDeviceArgs& a, int nodeCapMax, hipStream_t s) {

@@ -39,6 +39,15 @@ struct OrbCell {               // one FAST cell = one cv::FAST call on a sub-ima
   int slotCap;                 // ceil(ew/2)*ceil(eh/2): hard upper bound of 3x3-NMS survivors
 };
 
+struct OrbStrip {              // one row of FAST cells of a level = the work of one k_fast_strips block
+  short level;
+  short nCells;                // cells in the row (consecutive entries of the cell table)
+  int cellFirst;               // index of the row's first cell
+  short x0, y0;                // origin of the row's sub-images (level-image coordinates): x0 = first cell's x0
+  short xEnd, ch;              // last cell's x0 + cw ; sub-image height (evaluated rows are [y0+3, y0+ch-3))
+  short wCell, pad;            // nominal cell width: cell j's evaluated window starts at x0 + 3 + j*wCell
+};
+
 struct ResizeTap {             // one entry of the cv::resize coefficient tables
   short ofs, a0, a1, pad;
 };
@@ -50,6 +59,8 @@ struct OrbDeviceArgs {         // kernel argument block (passed by value)
   long long pyrFrameBytes;
   const OrbLevel* levels;
   const OrbCell* cells;
+  const OrbStrip* strips;
+  int nStrips;
   const ResizeTap* xtab;
   const ResizeTap* ytab;
   uint32_t* slots;             // candidate slots [frame][slot]
