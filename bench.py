@@ -109,7 +109,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1536, help="frames per GPU per step (6 resident LSD frames per CU x 256 CUs)")
+    ap.add_argument("--batch", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--nsplit", type=int, default=4, help="sub-batches pipelined against each other (pl-slam_amd/pipeline.py)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -145,14 +146,18 @@ def main():
     frames = S.make_frames(2 + 100000 * rank, B, rows, cols, unique=args.unique)
     d_imgs = torch.from_numpy(frames).to(dev)
     voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=S)
-    fe = PL.FrontEndBatch(P, voc, B, rows, cols, args.nfeatures, args.nlevels, args.nlines, 0.0, K, D, device=local_rank)
+    fe = PL.FrontEndPipelined(P, voc, B, rows, cols, args.nfeatures, args.nlevels, args.nlines, 0.0, K, D, device=local_rank,
+                              nsplit=args.nsplit)
     fe.overlap = not args.serial
+    Bp = fe.Bp
     if world > 1:
-        gather = [(t[:B], torch.empty((world * B,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev))
-                  for t in (fe.n, fe.kps, fe.desc, fe.nl, fe.kl, fe.ldesc)]
+        gather = [(t[:Bp], torch.empty((world * Bp,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev))
+                  for part in fe.parts for t in (part.n, part.kps, part.desc, part.nl, part.kl, part.ldesc)]
 
     def step():
-        fe.step(d_imgs)
+        # N = 1: consecutive steps are independent batches and may overlap (sub-batch pipelining); N > 1: the records
+        # are consumed on this stream by the RCCL gather, so every step completes before the collective
+        fe.step(d_imgs, join=(world > 1))
         if world > 1:   # RCCL gather of the fixed-stride records over xGMI
             for src, dst in gather:
                 dist.all_gather_into_tensor(dst, src.contiguous())
@@ -160,9 +165,10 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    fe.orb.set_profiling(True)
-    fe.line.lib.plh_line_set_profiling.argtypes = [C_VOID, C_INT]
-    fe.line.lib.plh_line_set_profiling(fe.line.h, 1)
+    for part in fe.parts:
+        part.orb.set_profiling(True)
+        part.line.lib.plh_line_set_profiling.argtypes = [C_VOID, C_INT]
+        part.line.lib.plh_line_set_profiling(part.line.h, 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -182,16 +188,20 @@ def main():
     def read_kernel_totals():
         """Cumulative (ms, intervals) of the 8 kernel groups since profiling was switched on."""
         import ctypes as C
-        tot = []
-        for k in range(4):
-            tot.append(fe.orb.kernel_ms(k))
-        lib = fe.line.lib
-        lib.plh_line_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        for k in range(4):
-            ms, n = C.c_double(0), C.c_int(0)
-            lib.plh_line_kernel_ms(fe.line.h, k, C.byref(ms), C.byref(n))
-            tot.append((ms.value, n.value))
-        return tot
+        tot = [[0.0, 0] for _ in range(8)]
+        for part in fe.parts:
+            for k in range(4):
+                ms, n = part.orb.kernel_ms(k)
+                tot[k][0] += ms
+                tot[k][1] += n
+            lib = part.line.lib
+            lib.plh_line_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+            for k in range(4):
+                ms, n = C.c_double(0), C.c_int(0)
+                lib.plh_line_kernel_ms(part.line.h, k, C.byref(ms), C.byref(n))
+                tot[4 + k][0] += ms.value
+                tot[4 + k][1] += n.value
+        return [tuple(x) for x in tot]
 
     if rank == 0:
         names = ["k_pyr_down x7", "k_fast_cells", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
@@ -201,7 +211,7 @@ def main():
         # one more pass with both halves on one stream: per-kernel durations without interference between the halves
         fe.overlap = False
         for _ in range(2):
-            fe.step(d_imgs)
+            fe.step(d_imgs, join=True)
         torch.cuda.synchronize(dev)
         t2 = read_kernel_totals()
         per_ms = [(b[0] - a[0]) / max(b[1] - a[1], 1) for a, b in zip(t1, t2)]
@@ -233,11 +243,12 @@ def main():
         pmc_names = {1: ["k_fast_cells"], 5: ["k_lsd_grow"], 0: ["k_pyr_down"], 2: ["k_octree"], 3: ["k_orient_brief"]}
 
         def roof(k, ms, where):
-            ach = alg[k] * B / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            ach = alg[k] * Bp / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             t = [traffic[n]["total"] * traffic[n].get("launches_per_step", 1) for n in pmc_names.get(k, []) if n in traffic]
             return {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": int(sum(t) * B) if t else None,
-                    "algorithmic_bytes_per_launch": int(alg[k] * B), "ms_per_launch": round(ms, 4), "measured": where}
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": int(sum(t) * Bp) if t else None,
+                    "algorithmic_bytes_per_launch": int(alg[k] * Bp), "frames_per_launch": Bp, "ms_per_launch": round(ms, 4),
+                    "measured": where}
 
         r_dom = roof(dom, per_ms_timed[dom], "HIP events on the launch stream over the timed region")
         r_dom["ms_per_launch_alone"] = round(per_ms[dom], 4)
@@ -246,9 +257,10 @@ def main():
             "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%dx%d mono, %d-level pyramid, %d ORB / %d lines (%s parameters), batch %d frames/GPU resident in HBM; "
-                                   "extract + BoW + SearchByBoW + line SearchDouble per consecutive frame pair"
-                                   % (cols, rows, args.nlevels, args.nfeatures, args.nlines, "TUM1.yaml" if tum else "KITTI00-02.yaml", B),
+            "config": {"workload": "%dx%d mono, %d-level pyramid, %d ORB / %d lines (%s parameters), batch %d frames/GPU resident in HBM "
+                                   "(%d sub-batches of %d pipelined); extract + BoW + SearchByBoW + line SearchDouble per consecutive "
+                                   "frame pair" % (cols, rows, args.nlevels, args.nfeatures, args.nlines,
+                                                   "TUM1.yaml" if tum else "KITTI00-02.yaml", B, args.nsplit, Bp),
                        "mean_keypoints_per_frame": round(nkp, 1), "mean_keylines_per_frame": round(nln, 1),
                        "mean_orb_matches_per_pair": round(float(res["nm_orb"].mean()), 1),
                        "mean_line_matches_per_pair": round(float(res["nm_line"].mean()), 1),

@@ -14,8 +14,8 @@ PyTorch only provides device memory and the streams; every computation is a kern
 
 The ORB half (+ BoW + SearchByBoW) and the line half (+ SearchDouble) are independent until the results are
 consumed, exactly as the reference runs ExtractORB and ExtractLSD on two threads (Frame.cc:224-227): they are
-enqueued on two HIP streams.  LSD region growing is one latency-bound wavefront per frame (<= 6 per CU), so the
-ORB kernels run in the SIMD slots it leaves idle.
+enqueued on two HIP streams.  LSD region growing is one latency-bound wavefront per frame, so the ORB kernels run in
+the SIMD slots it leaves idle.  FrontEndPipelined (below) additionally staggers sub-batches.
 """
 import ctypes as C
 
@@ -73,33 +73,36 @@ class FrontEndBatch:
         self.orb.close()
         self.line.close()
 
-    def step(self, d_imgs, stream=None):
-        """Enqueue one pass over the resident batch `d_imgs` (uint8 [B, rows, cols]) on the current stream."""
+    def enqueue_line(self, d_imgs, main, ev_start):
+        """Line half: LINEextractor batch + SearchDouble against the next frame, on the high-priority stream."""
         P, L, B, t = self.P, self.lib, self.B, self.torch
-        main = t.cuda.current_stream(self.dev) if stream is None else t.cuda.ExternalStream(stream, device=self.dev)
         p = P._p
-        nd, cs, cc, wi, wt = self.voc_dev
-        self.ev_start.record(main)
-        # ---- line half on the high-priority stream
         sl = self.line_stream if self.overlap else main
         if self.overlap:
-            sl.wait_event(self.ev_start)
+            sl.wait_event(ev_start)
         sm = sl.cuda_stream
         self.line.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kl, self.ldesc, self.lfn, self.nl, sm)
-        with t.cuda.stream(sl):
+        with t.cuda.stream(sl):   # slot B := frame 0 (so that frame B-1 has a successor)
             for buf in (self.kl, self.ldesc, self.nl):
                 buf[B].copy_(buf[0], non_blocking=True)
         P._check(L, L.plh_line_search_double_batch_dev(p(self.ldesc), p(self.nl), p(self.ldesc[1:]), p(self.nl[1:]), self.lcap, B,
                                                        50.0, 0.7, p(self.m_line), p(self.nm_line), p(self.ws), self.ws_bytes,
                                                        C.c_void_p(sm)),
                  "plh_line_search_double_batch_dev")
-        # ---- ORB half on its own stream
+        if self.overlap:
+            self.ev_line.record(sl)
+
+    def enqueue_orb(self, d_imgs, main, ev_start):
+        """ORB half: ORBextractor batch + BoW feature vectors + SearchByBoW against the next frame, on its own stream."""
+        P, L, B, t = self.P, self.lib, self.B, self.torch
+        p = P._p
+        nd, cs, cc, wi, wt = self.voc_dev
         so = self.orb_stream if self.overlap else main
         if self.overlap:
-            so.wait_event(self.ev_start)
+            so.wait_event(ev_start)
         sp = C.c_void_p(so.cuda_stream)
         self.orb.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kps, self.desc, self.n, so.cuda_stream)
-        with t.cuda.stream(so):   # slot B := frame 0 (so that frame B-1 has a successor)
+        with t.cuda.stream(so):
             for buf in (self.kps, self.desc, self.n):
                 buf[B].copy_(buf[0], non_blocking=True)
         P._check(L, L.plh_bow_transform_batch_dev(p(self.desc), p(self.n), self.ocap, B + 1, p(nd), p(cs), p(cc), p(wi), p(wt),
@@ -110,9 +113,21 @@ class FrontEndBatch:
                  "plh_orb_search_by_bow_kp_batch_dev")
         if self.overlap:
             self.ev_orb.record(so)
-            self.ev_line.record(sl)
-            main.wait_event(self.ev_orb)   # the step is complete on the caller's stream
+
+    def join(self, main):
+        """Make the caller's stream wait for everything this part has enqueued."""
+        if self.overlap:
+            main.wait_event(self.ev_orb)
             main.wait_event(self.ev_line)
+
+    def step(self, d_imgs, stream=None):
+        """Enqueue one pass over the resident batch `d_imgs` (uint8 [B, rows, cols]); complete on the caller's stream."""
+        t = self.torch
+        main = t.cuda.current_stream(self.dev) if stream is None else t.cuda.ExternalStream(stream, device=self.dev)
+        self.ev_start.record(main)
+        self.enqueue_line(d_imgs, main, self.ev_start)
+        self.enqueue_orb(d_imgs, main, self.ev_start)
+        self.join(main)
 
     def results(self):
         """Host copies of everything one step produced (synchronises)."""
@@ -125,3 +140,55 @@ class FrontEndBatch:
                     nl=self.nl[:B].cpu().numpy(), kl=kl, ldesc=self.ldesc[:B].cpu().numpy(), lfn=self.lfn[:B].cpu().numpy(),
                     m_orb=self.m_orb.cpu().numpy(), nm_orb=self.nm_orb.cpu().numpy(), m_line=self.m_line.cpu().numpy(),
                     nm_line=self.nm_line.cpu().numpy())
+
+
+class FrontEndPipelined:
+    """The same front end over `nsplit` sub-batches, each with its own extractor handles and stream pair.
+    LSD region growing is latency-bound (one wavefront per frame) while every other kernel is a dense streaming
+    kernel: with the sub-batches staggered, the dense kernels of one run underneath the region growing of another,
+    and -- because a sub-batch only depends on its own previous step -- consecutive steps overlap as well (the
+    batches of a video stream are independent).  `step(..., join=True)` restores strict step-by-step completion on
+    the caller's stream (needed when the results are consumed there, e.g. by an RCCL gather)."""
+
+    def __init__(self, P, vocab, batch, rows=480, cols=640, nfeatures=1000, nlevels=8, n_lines=200, min_line_length=0.0,
+                 K=None, D=None, device=0, nsplit=2):
+        import torch
+        assert batch % nsplit == 0
+        self.torch, self.B, self.nsplit, self.Bp = torch, batch, nsplit, batch // nsplit
+        self.dev = torch.device("cuda", device)
+        self.parts = [FrontEndBatch(P, vocab, self.Bp, rows, cols, nfeatures, nlevels, n_lines, min_line_length, K, D, device)
+                      for _ in range(nsplit)]
+        self.ev_start = torch.cuda.Event()
+
+    @property
+    def overlap(self):
+        return self.parts[0].overlap
+
+    @overlap.setter
+    def overlap(self, v):
+        for p in self.parts:
+            p.overlap = v
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+
+    def step(self, d_imgs, join=True):
+        main = self.torch.cuda.current_stream(self.dev)
+        self.ev_start.record(main)
+        Bp = self.Bp
+        for k, p in enumerate(self.parts):      # critical-path (line) chains first, then the ORB chains
+            p.enqueue_line(d_imgs[k * Bp:(k + 1) * Bp], main, self.ev_start)
+        for k, p in enumerate(self.parts):
+            p.enqueue_orb(d_imgs[k * Bp:(k + 1) * Bp], main, self.ev_start)
+        if join:
+            self.join()
+
+    def join(self):
+        main = self.torch.cuda.current_stream(self.dev)
+        for p in self.parts:
+            p.join(main)
+
+    def results(self):
+        rs = [p.results() for p in self.parts]
+        return {k: np.concatenate([r[k] for r in rs], axis=0) for k in rs[0]}

@@ -59,3 +59,39 @@ def test_front_end_batch_vs_oracle(plslam, oracle, synth):
         ml = np.zeros(len(l1), np.int32)
         cl = L.plo_line_search_double(O._p(l1), len(l1), O._p(l2), len(l2), 50.0, 0.7, O._p(ml))
         assert r["nm_line"][b] == cl and (r["m_line"][b, :len(l1)] == ml).all(), b
+
+
+def test_pipelined_sub_batches_match_plain_batches(plslam, synth):
+    """FrontEndPipelined (staggered sub-batches, steps not joined) produces exactly what FrontEndBatch produces on each
+    sub-batch (which the test above checks against the oracle)."""
+    import torch
+    V = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    PL = _util._load("plslam_amd_pipeline", os.path.join(_util.ROOT, "pl-slam_amd", "pipeline.py"))
+    B, ns = 8, 2
+    frames = synth.make_frames(510, B, 480, 640)
+    voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=synth)
+    d = torch.from_numpy(frames).cuda()
+    fp = PL.FrontEndPipelined(plslam, voc, B, 480, 640, 1000, 8, 200, 0.0, TUM1_K, TUM1_D, nsplit=ns)
+    for _ in range(3):
+        fp.step(d, join=False)
+    rp = fp.results()
+    fp.close()
+    fe = PL.FrontEndBatch(plslam, voc, B // ns, 480, 640, 1000, 8, 200, 0.0, TUM1_K, TUM1_D)
+    for k in range(ns):
+        fe.step(d[k * (B // ns):(k + 1) * (B // ns)])
+        r = fe.results()
+        sl = slice(k * (B // ns), (k + 1) * (B // ns))
+        Bp = B // ns
+        assert (rp["n"][sl] == r["n"]).all() and (rp["nl"][sl] == r["nl"]).all()
+        for key in r:       # rows beyond the per-frame counts are unspecified: compare the live ones
+            for i in range(Bp):
+                cnt = {"kps": r["n"][i], "desc": r["n"][i], "nid": r["n"][i], "kl": r["nl"][i], "ldesc": r["nl"][i],
+                       "lfn": r["nl"][i], "m_orb": r["n"][(i + 1) % Bp], "m_line": r["nl"][i]}.get(key)
+                a, b = rp[key][sl][i], r[key][i]
+                if cnt is not None:
+                    a, b = a[:cnt], b[:cnt]
+                if a.dtype.names:
+                    assert all((a[f] == b[f]).all() for f in a.dtype.names), (k, key, i)
+                else:
+                    assert np.array_equal(a, b, equal_nan=True), (k, key, i)
+    fe.close()
