@@ -204,7 +204,7 @@ def main():
         return [tuple(x) for x in tot]
 
     if rank == 0:
-        names = ["k_pyr_down x7", "k_fast_cells", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
+        names = ["k_pyr_down x7", "k_fast_strips", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
                  "k_lsd_grow", "k_keylines", "LBD (blur+sobel+k_lbd)"]
         t1 = read_kernel_totals()
         per_ms_timed = [ms / max(n, 1) for ms, n in t1]   # HIP events on the launch streams, over the timed region
@@ -240,7 +240,7 @@ def main():
                 traffic = json.load(open(tpath)).get("kernels", {})
             except Exception:
                 traffic = {}
-        pmc_names = {1: ["k_fast_cells"], 5: ["k_lsd_grow"], 0: ["k_pyr_down"], 2: ["k_octree"], 3: ["k_orient_brief"]}
+        pmc_names = {1: ["k_fast_strips"], 5: ["k_lsd_grow"], 0: ["k_pyr_down"], 2: ["k_octree"], 3: ["k_orient_brief"]}
 
         def roof(k, ms, where):
             ach = alg[k] * Bp / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
