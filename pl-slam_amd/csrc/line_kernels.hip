@@ -121,30 +121,41 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
       px.q = (unsigned)(gx * gx + gy * gy);
       if (px.q > a.qThresh) {
         px.angf = fast_atan2_deg((float)gx, (float)(-gy));
-        const float af = (float)((double)px.angf * kDegToRads);
-        px.cs = (float)cos((double)af);
-        px.sn = (float)sin((double)af);
-        const double ad = (double)px.angf * kDegToRads;   // seed terms: float(cos(reg_angle)), float(sin(reg_angle))
-        seed.x = (float)cos(ad);
-        seed.y = (float)sin(ad);
+        // seed terms: float(cos(ad)), float(sin(ad)) of the double angle ad; region increments: float(cos(af)),
+        // float(sin(af)) of af = float(ad).  One double sincos serves both: af = ad - d with |d| <= 2^-22, and
+        // cos(ad - d) = c (1 - d^2/2) + s d, sin(ad - d) = s (1 - d^2/2) - c d hold to O(d^3) < 1e-19, far below the
+        // double ulp the direct evaluation carries itself.
+        const double ad = (double)px.angf * kDegToRads;
+        double sd, cd;
+        sincos(ad, &sd, &cd);
+        seed.x = (float)cd;
+        seed.y = (float)sd;
+        const float af = (float)ad;
+        const double d = ad - (double)af, h = 1.0 - 0.5 * d * d;
+        px.cs = (float)(cd * h + sd * d);
+        px.sn = (float)(sd * h - cd * d);
         atomicMax(&s_max, px.q);
       }
     }
-    reinterpret_cast<LsdPix*>(a.pix)[(long long)b * a.scaledStride + (long long)y * a.spitch + x] = px;
-    reinterpret_cast<float2*>(a.seedcs)[(long long)b * a.scaledStride + (long long)y * a.spitch + x] = seed;
+    const long long o = (long long)b * a.scaledStride + (long long)y * a.spitch + x;
+    reinterpret_cast<LsdPix*>(a.pix)[o] = px;
+    reinterpret_cast<float2*>(a.seedcs)[o] = seed;
+    a.scr[o] = px.q;   // compact copy of q for the seed ordering (scr is free until region growing)
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);
 }
 
 // One 1024-thread block per frame: stable counting sort of the DEFINED pixels by bin (descending), raster
-// order inside a bin.  16 waves own contiguous raster chunks; per-(wave,bin) counters live in LDS.
+// order inside a bin.  16 waves own contiguous raster chunks; per-(wave,bin) counters live in LDS.  Inside a
+// 64-pixel group the rank of a lane among the lanes of the same bin comes from ten ballots (one per bin bit).
 __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   int* hist = (int*)smem;                 // [16][1024] counts, then running offsets
   int* scan = hist + 16 * LSD_NBINS;      // [1024]
   const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const LsdPix* G = reinterpret_cast<const LsdPix*>(a.pix) + (long long)b * a.scaledStride;
+  const uint32_t* Q = a.scr + (long long)b * a.scaledStride;      // q per pixel (k_lsd_grad)
+  uint32_t* BIN = a.reg + (long long)b * a.scaledStride;          // bin + 1 per pixel, 0 = NOTDEF (scratch)
   uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
   const unsigned qmax = a.qmax[b];
   const double bin_coef = qmax > 0 ? (double)(LSD_NBINS - 1) / sqrt((double)(int)qmax / 4.0) : 0.0;
@@ -156,8 +167,14 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   for (int base = c0; base < c1; base += 64) {
     const int i = base + lane;
     if (i < c1) {
-      const unsigned q = G[i].q;
-      if (q > a.qThresh) atomicAdd(&hist[wv * LSD_NBINS + (int)(q_modgrad(q) * bin_coef)], 1);
+      const unsigned q = Q[i];
+      unsigned bp1 = 0;
+      if (q > a.qThresh) {
+        const int bin = (int)(q_modgrad(q) * bin_coef);
+        atomicAdd(&hist[wv * LSD_NBINS + bin], 1);
+        bp1 = (unsigned)bin + 1u;
+      }
+      BIN[i] = bp1;
     }
   }
   __syncthreads();
@@ -182,28 +199,28 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
     if (tid == 1023) a.nOrdered[b] = scan[1023];
   }
   __syncthreads();
+  const unsigned long long lt = lanemask_lt();
   for (int base = c0; base < c1; base += 64) {
     const int i = base + lane;
-    bool active = false;
-    int bin = 0;
-    if (i < c1) {
-      const unsigned q = G[i].q;
-      if (q > a.qThresh) { active = true; bin = (int)(q_modgrad(q) * bin_coef); }
+    const unsigned bp1 = i < c1 ? BIN[i] : 0u;
+    const bool active = bp1 != 0u;
+    const unsigned bin = bp1 - 1u;
+    unsigned long long same = __ballot(active);
+    if (!same) continue;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      const bool bit = (bin >> k) & 1u;
+      const unsigned long long m = __ballot(active && bit);
+      same &= bit ? m : ~m;
     }
-    for (;;) {
-      const unsigned long long m = __ballot(active);
-      if (!m) break;
-      const int leader = __ffsll((long long)m) - 1;
-      const int lb = __shfl(bin, leader);
-      const unsigned long long same = __ballot(active && bin == lb);
-      int basep = 0;
-      if (lane == leader) basep = hist[wv * LSD_NBINS + lb];
-      basep = __shfl(basep, leader);
-      if (lane == leader) hist[wv * LSD_NBINS + lb] = basep + __popcll(same);
-      if (active && bin == lb) {
-        ord[basep + __popcll(same & lanemask_lt())] = (uint32_t)(i % a.spitch) | ((uint32_t)(i / a.spitch) << 16);
-        active = false;
-      }
+    PLH_WAVE_SYNC();
+    int basep = 0;
+    if (active) basep = hist[wv * LSD_NBINS + bin];
+    PLH_WAVE_SYNC();
+    if (active) {
+      const int rank = __popcll(same & lt);
+      if (rank == 0) hist[wv * LSD_NBINS + bin] = basep + __popcll(same);
+      ord[basep + rank] = (uint32_t)(i % a.spitch) | ((uint32_t)(i / a.spitch) << 16);
     }
   }
 }

@@ -77,32 +77,22 @@ __global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
 //   M = max( max_i min(d[i..i+8]),  max_i min(-d[i..i+8]) )
 // pixel is a corner at threshold t  <=>  M > t ; cornerScore<16>() = M - 1 for any corner
 // (the `threshold` floor inside cornerScore only matters for non-corners).  The sliding 9-window
-// min/max over the circular 16-ring is built by doubling (2,4,8,+1).
+// min/max over the circular 16-ring is built from windows of 3 (3-input min/max instructions).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int fast_arc_measure(int v, const int p[16]) {
-  int d[16], lo2[16], lo4[16], lo8[16], hi2[16], hi4[16], hi8[16];
+  int d[16], lo3[16], hi3[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) d[i] = v - p[i];
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo2[i] = min(d[i], d[(i + 1) & 15]);
-    hi2[i] = max(d[i], d[(i + 1) & 15]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo4[i] = min(lo2[i], lo2[(i + 2) & 15]);
-    hi4[i] = max(hi2[i], hi2[(i + 2) & 15]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo8[i] = min(lo4[i], lo4[(i + 4) & 15]);
-    hi8[i] = max(hi4[i], hi4[(i + 4) & 15]);
+  for (int i = 0; i < 16; i++) {   // windows of 3, then 3 windows of 3 = the 9-arc starting at i (v_min3 / v_max3)
+    lo3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+    hi3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
   }
   int dark = -512, bright = 512;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    dark = max(dark, min(lo8[i], d[(i + 8) & 15]));
-    bright = min(bright, max(hi8[i], d[(i + 8) & 15]));
+    dark = max(dark, min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]));
+    bright = min(bright, max(max(hi3[i], hi3[(i + 3) & 15]), hi3[(i + 6) & 15]));
   }
   return max(dark, -bright);
 }
@@ -171,19 +161,18 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
   // ---- stage the rows (dword copies when the source rows are dword aligned), clear the score tile
   {
     const int nd = TP >> 2;
-    const int xmaxd = (lv.pitch - xa) >> 2;              // dwords that stay inside the source row
-    if (((lv.pitch | (int)(size_t)src) & 3) == 0) {
-      for (int i = tid; i < ch * nd; i += 256) {
-        const int r = i / nd, d = i - r * nd;
-        unsigned v = 0;
-        if (d < xmaxd) v = ld_u32(src + (long long)(st.y0 + r) * lv.pitch + xa + 4 * d);
-        reinterpret_cast<unsigned*>(tile)[r * nd + d] = v;
+    const int xmaxd = (lv.pitch - xa - 4) >> 2;          // dwords whose aligned pair stays inside the source row
+    for (int r = wv; r < ch; r += 4)                     // aligned dword loads + byte funnel for odd row addresses
+     for (int d = lane; d < nd; d += 64) {
+      unsigned v = 0;
+      if (d < xmaxd) {
+        const uint8_t* rowp = src + (long long)(st.y0 + r) * lv.pitch + xa + 4 * d;
+        const int m = (int)((size_t)rowp & 3);
+        const unsigned* ap = reinterpret_cast<const unsigned*>(rowp - m);
+        const unsigned lo = ap[0];
+        v = m ? align_bytes(ap[1], lo, m) : lo;
       }
-    } else {
-      for (int i = tid; i < ch * TP; i += 256) {
-        const int r = i / TP, c = i - r * TP;
-        tile[i] = (xa + c < lv.w) ? src[(long long)(st.y0 + r) * lv.pitch + xa + c] : (uint8_t)0;
-      }
+      reinterpret_cast<unsigned*>(tile)[r * nd + d] = v;
     }
     const int ns = ((eh + 2) * TP) >> 2;
     for (int i = tid; i < ns; i += 256) reinterpret_cast<unsigned*>(sc)[i] = 0u;
@@ -193,18 +182,15 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
 
   // ---- scores
   const int gx0 = (ex0 - xa) >> 2, gx1 = (ex1 - 1 - xa) >> 2;   // dword columns that contain evaluated pixels
-  const int ngx = gx1 - gx0 + 1;
-  const int ngroups = eh > 0 && ex1 > ex0 ? ngx * eh : 0;
+  const int ngx = (eh > 0 && ex1 > ex0) ? gx1 - gx0 + 1 : 0;
   unsigned* myq = s_queue[wv];
   int qn = 0;
-  for (int base = wv * 64; base < ngroups; base += 256) {
-    const int g = base + lane;
+  for (int rr = wv; rr < eh; rr += 4)
+   for (int gb = 0; gb < ngx; gb += 64) {
+    const int gxi = gb + lane;
     unsigned pass = 0;
-    int r = 0, cx = 0;
-    if (g < ngroups) {
-      const int rr = g / ngx;
-      r = rr + 3;
-      cx = (gx0 + (g - rr * ngx)) << 2;
+    const int r = rr + 3, cx = (gx0 + gxi) << 2;
+    if (gxi < ngx) {
       const uint8_t* t = tile + r * TP + cx;
       const unsigned C = ld_u32(t), Lw = ld_u32(t - 4), R = ld_u32(t + 4), U = ld_u32(t - 3 * TP), D = ld_u32(t + 3 * TP);
       const unsigned P12 = align_bytes(C, Lw, 1), P4 = align_bytes(R, C, 3);
@@ -243,18 +229,13 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
   __syncthreads();
 
   // ---- 3x3 NMS inside each cell window + threshold class (2: >= iniThFAST, 1: >= minThFAST)
-  {
-    const int nf = (eh * TP) >> 2;
-    for (int i = tid; i < nf; i += 256) reinterpret_cast<unsigned*>(fl)[i] = 0u;
-  }
-  __syncthreads();
   const int lastCell = st.nCells - 1;
-  for (int g = tid; g < ngroups; g += 256) {
-    const int rr = g / ngx;
-    const int cx = (gx0 + (g - rr * ngx)) << 2;
+  for (int rr = wv; rr < eh; rr += 4)
+   for (int gxi = lane; gxi < ngx; gxi += 64) {
+    const int cx = (gx0 + gxi) << 2;
     const uint8_t* s1 = sc + (rr + 1) * TP + cx;
     const unsigned S = ld_u32(s1);
-    if (S == 0u) continue;
+    if (S == 0u) { *reinterpret_cast<unsigned*>(fl + rr * TP + cx) = 0u; continue; }
     const unsigned Sl = ld_u32(s1 - 4), Sr = ld_u32(s1 + 4);
     const unsigned Tc = ld_u32(s1 - TP), Tl = ld_u32(s1 - TP - 4), Tr = ld_u32(s1 - TP + 4);
     const unsigned Bc = ld_u32(s1 + TP), Bl = ld_u32(s1 + TP - 4), Br = ld_u32(s1 + TP + 4);
@@ -285,7 +266,7 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
         if (f == 2) s_hi[cj] = 1;
       }
     }
-    if (F) *reinterpret_cast<unsigned*>(fl + rr * TP + cx) = F;
+    *reinterpret_cast<unsigned*>(fl + rr * TP + cx) = F;
   }
   __syncthreads();
 
@@ -298,14 +279,12 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
     const int colBase = c.x0 + 3 - xa;
     uint32_t* out = a.slots + (long long)b * a.slotsPerFrame + c.slotOff;
     int cnt = 0;
-    for (int base = 0; base < npx; base += 64) {
-      const int i = base + lane;
-      int ey = 0, ex = 0;
+    // lanes cover whole rows of the cell window: rpi rows of pw (power of two >= ew) columns per iteration
+    const int pw = ew > 32 ? 64 : (ew > 16 ? 32 : 16), sh = ew > 32 ? 6 : (ew > 16 ? 5 : 4), rpi = 64 >> sh;
+    for (int row0 = 0; row0 < (npx ? eh : 0); row0 += rpi) {
+      const int ey = row0 + (lane >> sh), ex = lane & (pw - 1);
       bool keep = false;
-      if (i < npx) {
-        ey = i / ew; ex = i - ey * ew;
-        keep = fl[ey * TP + colBase + ex] >= need;
-      }
+      if (ey < eh && ex < ew) keep = fl[ey * TP + colBase + ex] >= need;
       const unsigned long long mask = __ballot(keep);
       if (keep) {
         const int pos = cnt + __popcll(mask & lanemask_lt());

@@ -58,3 +58,9 @@ def test_emu_plan_errors(plslam, emu_lib):
     with pytest.raises(plslam.PlhError):
         ex(np.zeros((90, 120), np.uint8))        # size does not match the plan
     ex.close()
+
+
+def test_emu_wide_odd_pitch_frame(plslam, oracle, synth, emu_lib):
+    # width 403: level-0 rows are not dword aligned (funnel-shifted staging) and a cell row is split into two FAST strips
+    img = synth.make_frame(12, 110, 403, n_rect=60, n_line=30)
+    assert _cmp(plslam, oracle, img, 300, 2, emu_lib) > 150
