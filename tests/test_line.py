@@ -162,3 +162,20 @@ def test_gpu_line_batch_and_mask(plslam, oracle, synth):
     if not _exact(k1, d1, f1, rk, rd, rf):
         _close(k1, d1, f1, rk, rd, rf, "mask")
     ex.close()
+
+
+@pytest.mark.gpu
+def test_gpu_line_golden(plslam, synth):
+    """GPU vs the committed golden vectors (tests/golden/line_*.npz, tools/gen_golden.py)."""
+    import glob
+    import os
+    for path in sorted(glob.glob(os.path.join(_util.ROOT, "tests", "golden", "line_*.npz"))):
+        g = np.load(path)
+        rows, cols = int(g["rows"]), int(g["cols"])
+        img = synth.make_frame(int(g["seed"]), rows, cols, n_rect=int(g["n_rect"]), n_line=int(g["n_line"]))
+        ex = plslam.LINEextractor(1, 1.2, int(g["nfeature"]), float(g["minlen"]), rows=rows, cols=cols, max_batch=1)
+        kl, desc, fn = ex(img)
+        gs = ex.read_segments(0)
+        ex.close()
+        if not (_exact(kl, desc, fn, g["keylines"], g["desc"], g["linefn"]) and gs.shape == g["segs"].shape and (gs == g["segs"]).all()):
+            _close(kl, desc, fn, g["keylines"], g["desc"], g["linefn"], os.path.basename(path))

@@ -158,3 +158,22 @@ def test_gpu_search_by_bow_2000(plslam, oracle, synth):
         rc, ref = _oracle_bow(oracle, kf, fr, 50, 0.7, True)
         assert cnt[p] == rc and (got[p, :len(fr["desc"])] == ref).all(), p
     assert cnt[0] > 500
+
+
+@pytest.mark.gpu
+def test_gpu_match_golden(plslam, synth):
+    """GPU vs the committed golden vectors (tests/golden/match_*.npz, tools/gen_golden.py)."""
+    import glob
+    import os
+    for path in sorted(glob.glob(os.path.join(_util.ROOT, "tests", "golden", "match_*.npz"))):
+        g = np.load(path)
+        n = int(g["n"])
+        a, b, perm = synth.make_descriptor_sets(int(g["seed"]), n, 0.08)
+        idx, dist = plslam.hamming_knn2(a, b)
+        assert (idx == g["knn_idx"]).all() and (dist == g["knn_dist"]).all()
+        c, m = plslam.LSDmatcher(0.7, True).SearchDouble(a, b)
+        assert c == int(g["double_n"]) and (m == g["double_m"]).all()
+        kf = dict(desc=a, angle=g["ang_a"], node=g["node_a"], valid=np.ones(n, np.uint8))
+        fr = dict(desc=b, angle=g["ang_b"], node=g["node_b"])
+        cb, mb = plslam.ORBmatcher(0.7, True).SearchByBoW(kf, fr)
+        assert cb == int(g["bow_n"]) and (mb == g["bow_m"]).all()

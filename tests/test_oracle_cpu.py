@@ -124,3 +124,35 @@ def test_orb_output_invariants(oracle, synth):
     sf = o.scale_table(0)
     lx = kps["x"] / sf[kps["octave"]]
     assert (lx >= 19 - 1e-3).all()
+
+
+# ------------------------------------------------------------------ golden vectors: lines and matchers
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(_util.ROOT, "tests", "golden", "line_*.npz"))))
+def test_oracle_matches_golden_lines(oracle, synth, path):
+    g = np.load(path)
+    img = synth.make_frame(int(g["seed"]), int(g["rows"]), int(g["cols"]), n_rect=int(g["n_rect"]), n_line=int(g["n_line"]))
+    assert int(img.astype(np.int64).sum()) == int(g["img_sum"])          # the generator itself is pinned
+    segs = oracle.lsd_detect(img)
+    kl, desc, fn = oracle.line_extract(img, int(g["nfeature"]), float(g["minlen"]))
+    assert segs.shape == g["segs"].shape and (segs == g["segs"]).all()
+    assert len(kl) == len(g["keylines"]) and all((kl[f] == g["keylines"][f]).all() for f in kl.dtype.names)
+    assert (desc == g["desc"]).all() and (fn == g["linefn"]).all()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(_util.ROOT, "tests", "golden", "match_*.npz"))))
+def test_oracle_matches_golden_matchers(oracle, synth, path):
+    import ctypes as C
+    g = np.load(path)
+    n = int(g["n"])
+    a, b, perm = synth.make_descriptor_sets(int(g["seed"]), n, 0.08)
+    idx, dist = oracle.knn2(a, b)
+    assert (idx == g["knn_idx"]).all() and (dist == g["knn_dist"]).all()
+    m = np.zeros(n, np.int32)
+    L = oracle.lib()
+    c = L.plo_line_search_double(oracle._p(a), n, oracle._p(b), n, C.c_float(50.0), C.c_float(0.7), oracle._p(m))
+    assert c == int(g["double_n"]) and (m == g["double_m"]).all()
+    mb = np.zeros(n, np.int32)
+    valid = np.ones(n, np.uint8)
+    cb = L.plo_orb_search_by_bow(oracle._p(a), oracle._p(g["ang_a"]), oracle._p(g["node_a"]), oracle._p(valid), n, oracle._p(b),
+                                 oracle._p(g["ang_b"]), oracle._p(g["node_b"]), n, 50, C.c_float(0.7), 1, oracle._p(mb))
+    assert cb == int(g["bow_n"]) and (mb == g["bow_m"]).all()

@@ -37,3 +37,44 @@ def orb_case(name, seed, rows, cols, nf, nl=8, ini=20, mn=7, **kw):
 orb_case("orb_s1_640x480", 1, 480, 640, 1000)
 orb_case("orb_kitti_1241x376", 1000, 376, 1241, 2000)
 orb_case("orb_small_160x120", 7, 120, 160, 200, nl=3, n_rect=40, n_line=20)
+
+
+# ---- line extractor (LSD + KeyLine selection + LBD): segments, keylines, descriptors, line equations
+def line_case(name, seed, rows, cols, nf, minlen=0.0, **kw):
+    img = S.make_frame(seed, rows, cols, **kw)
+    segs = O.lsd_detect(img)
+    kl, desc, fn = O.line_extract(img, nf, minlen)
+    np.savez_compressed(os.path.join(G, name + ".npz"), seed=seed, rows=rows, cols=cols, nfeature=nf, minlen=minlen,
+                        n_rect=kw.get("n_rect", 400), n_line=kw.get("n_line", 200), img_sum=int(img.astype(np.int64).sum()),
+                        segs=segs, keylines=kl, desc=desc, linefn=fn)
+    print(name, len(segs), len(kl))
+
+
+line_case("line_s1_640x480", 1, 480, 640, 200)
+line_case("line_small_160x120", 7, 120, 160, 50, n_rect=40, n_line=20)
+
+
+# ---- Hamming matchers on the S3 descriptor sets: knn2 table checksum, SearchDouble, SearchByBoW
+def match_case(name, seed, n):
+    import ctypes as C
+    a, b, perm = S.make_descriptor_sets(seed, n, 0.08)
+    idx, dist = O.knn2(a, b)
+    m = np.zeros(n, np.int32)
+    L = O.lib()
+    c = L.plo_line_search_double(O._p(a), n, O._p(b), n, C.c_float(50.0), C.c_float(0.7), O._p(m))
+    rng = S.SplitMix64(seed + 7)
+    node_a = rng.randint(n, 0, 100).astype(np.int32)
+    node_b = node_a[perm].copy()
+    ang_a = rng.uniform(n, 0, 360).astype(np.float32)
+    ang_b = ((ang_a[perm] + 12.0) % 360).astype(np.float32)
+    valid = np.ones(n, np.uint8)
+    mb = np.zeros(n, np.int32)
+    cb = L.plo_orb_search_by_bow(O._p(a), O._p(ang_a), O._p(node_a), O._p(valid), n, O._p(b), O._p(ang_b), O._p(node_b), n, 50,
+                                 C.c_float(0.7), 1, O._p(mb))
+    np.savez_compressed(os.path.join(G, name + ".npz"), seed=seed, n=n, knn_idx=idx, knn_dist=dist, double_n=c, double_m=m,
+                        bow_n=cb, bow_m=mb, node_a=node_a, node_b=node_b, ang_a=ang_a, ang_b=ang_b)
+    print(name, c, cb)
+
+
+match_case("match_s3_2000", 100, 2000)
+match_case("match_s3_200", 103, 200)
