@@ -314,6 +314,20 @@ PLH_API plh_status plh_line_search_by_projection_ml(const plh_keyline* kl, const
                                                     int* nmatches, int device);
 
 /* ---------------------------------------------------------------------------------------------
+ * Frame / map post-processing either side of the matching path
+ * ------------------------------------------------------------------------------------------- */
+/* Frame::UndistortKeyPoints (Frame.cc:915-945): cv::undistortPoints(pts, pts, K, D, noArray(), K) on every keypoint,
+ * all other KeyPoint fields copied; D[0] == 0 -> plain copy.  K = fx,fy,cx,cy ; D = k1,k2,p1,p2,k3 (host arrays).
+ * d_kps / d_kps_un: batch x cap records (may alias). */
+PLH_API plh_status plh_undistort_keypoints_batch_dev(const plh_keypoint* d_kps, const int32_t* d_n, int cap, int batch,
+                                                     const float K[4], const float D[5], plh_keypoint* d_kps_un, void* stream);
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:249-314) / MapLine twin (MapLine.cpp:256-330) for many map
+ * elements at once: set s owns the descriptor rows [d_offsets[s], d_offsets[s+1]) of d_desc (32 bytes each, <= 1024 rows);
+ * d_best[s] = row (relative to the set) with the least median Hamming distance to the others, -1 for an empty set. */
+PLH_API plh_status plh_distinctive_descriptor_batch_dev(const uint8_t* d_desc, const int32_t* d_offsets, int nsets,
+                                                        int32_t* d_best, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Line extractor  (replaces ORB_SLAM2::LINEextractor, include/LineExtractor.h:20-62)
  * ------------------------------------------------------------------------------------------- */
 typedef struct plh_line plh_line;

@@ -430,3 +430,47 @@ int plo_line_search_by_projection_ml(const plo_keyline* kl, const uint8_t* ldesc
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Frame::UndistortKeyPoints (reference src/Frame.cc:915-945): cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK)
+// on the keypoint coordinates, everything else of the KeyPoint copied; zero k1 -> plain copy (:917-921).
+// cv::undistortPoints is OpenCV (not in tree): restated from the 3.2 cvUndistortPoints algorithm -- normalise with the
+// reciprocal focal lengths, 5 fixed-point iterations of the inverse Brown model in double, re-project with P = K.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" void plo_undistort_keypoints(const plo_keypoint* kps, int n, const float K[4], const float D[5], plo_keypoint* out) {
+  for (int i = 0; i < n; i++) out[i] = kps[i];
+  if (D[0] == 0.0) return;
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], ifx = 1. / fx, ify = 1. / fy;
+  const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+  for (int i = 0; i < n; i++) {
+    double x = kps[i].x, y = kps[i].y;
+    const double x0 = x = (x - cx) * ifx, y0 = y = (y - cy) * ify;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+    out[i].x = (float)(xx * ww);
+    out[i].y = (float)(yy * ww);
+  }
+}
+
+// MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:249-314) / MapLine twin (src/MapLine.cpp:256-330):
+// of N observed descriptors pick the one with the least median Hamming distance to the others
+// (median = sorted row[(size_t)(0.5*(N-1))], first minimum wins).  Returns the index, -1 for N == 0.
+extern "C" int plo_distinctive_descriptor(const uint8_t* desc, int n) {
+  if (n <= 0) return -1;
+  int BestMedian = INT_MAX, BestIdx = 0;
+  std::vector<int> vDists(n);
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) vDists[j] = i == j ? 0 : plo_descriptor_distance(desc + (size_t)i * 32, desc + (size_t)j * 32);
+    std::sort(vDists.begin(), vDists.end());
+    const int median = vDists[(size_t)(0.5 * (n - 1))];
+    if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+  }
+  return BestIdx;
+}

@@ -133,6 +133,11 @@ int  plo_line_search_by_projection_ml(const plo_keyline* kl, const uint8_t* ldes
                                       const float* q_seg, const float* q_viewcos, const uint8_t* q_desc, const uint8_t* q_hasobs,
                                       float th, float nnratio, int32_t* assigned);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:915-945) and MapPoint / MapLine::ComputeDistinctiveDescriptors
+ * (src/MapPoint.cc:249-314, src/MapLine.cpp:256-330) */
+void plo_undistort_keypoints(const plo_keypoint* kps, int n, const float K[4], const float D[5], plo_keypoint* out);
+int  plo_distinctive_descriptor(const uint8_t* desc, int n);
+
 #ifdef __cplusplus
 }
 #endif

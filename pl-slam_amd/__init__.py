@@ -75,6 +75,8 @@ _SIGS = {
     "plh_line_extract": ([_V, _V, _I, _I, _Z, _V, _V, _V, _V, _I, _V], _I),
     "plh_line_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
+    "plh_undistort_keypoints_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
+    "plh_distinctive_descriptor_batch_dev": ([_V, _V, _I, _V, _V], _I),
     "plh_frame_assign_grid_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
     "plh_frame_assign_grid_lines_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _I, _V], _I),
     "plh_orb_search_for_initialization_batch_dev": ([_V] * 6 + [_I, _I, _V, _V, _V, _V, _I, _F, _I, _V, _V, _V], _I),
@@ -484,6 +486,35 @@ class FrameSearch:
             _p(self.d_lci), self.item_cap, _p(docc), _p(dnq), qcap, _p(qv), _p(qs_), _p(qc), _p(qd), _p(qh), float(th),
             float(nnratio), _p(da), _p(dc), C.c_void_p(D.stream())), "plh_line_search_by_projection_ml_batch_dev")
         return D.get(da), D.get(dc), D.get(docc)
+
+
+def undistort_keypoints(kps_list, K, D, device=0, lib=None):
+    """Frame::UndistortKeyPoints for a batch of frames: list of KP_DTYPE arrays -> list of undistorted copies."""
+    L = load(lib)
+    Dv = _Dev(L, device)
+    cap = max(1, max(len(k) for k in kps_list))
+    a, n = _pad_records(kps_list, cap, KP_DTYPE)
+    da, dn = Dv.put(a), Dv.put(n)
+    Kf = np.ascontiguousarray(K, np.float32)
+    Df = np.ascontiguousarray(D if D is not None else np.zeros(5), np.float32)
+    _check(L, L.plh_undistort_keypoints_batch_dev(_p(da), _p(dn), cap, len(kps_list), _p(Kf), _p(Df), _p(da),
+                                                  C.c_void_p(Dv.stream())), "plh_undistort_keypoints_batch_dev")
+    out = np.ascontiguousarray(Dv.get(da)).view(np.uint8).reshape(len(kps_list), cap, 28).copy().view(KP_DTYPE).reshape(len(kps_list), cap)
+    return [out[i, :len(k)].copy() for i, k in enumerate(kps_list)]
+
+
+def distinctive_descriptors(sets, device=0, lib=None):
+    """MapPoint / MapLine::ComputeDistinctiveDescriptors for many map elements: list of [n_s, 32] u8 -> best row per set."""
+    L = load(lib)
+    Dv = _Dev(L, device)
+    off = np.zeros(len(sets) + 1, np.int32)
+    off[1:] = np.cumsum([len(s) for s in sets])
+    allrows = np.concatenate([np.asarray(s, np.uint8).reshape(-1, 32) for s in sets] + [np.zeros((1, 32), np.uint8)])
+    dd, do = Dv.put(allrows), Dv.put(off)
+    db = Dv.empty((len(sets),), np.int32)
+    _check(L, L.plh_distinctive_descriptor_batch_dev(_p(dd), _p(do), len(sets), _p(db), C.c_void_p(Dv.stream())),
+           "plh_distinctive_descriptor_batch_dev")
+    return Dv.get(db)
 
 
 class LSDmatcher:

@@ -335,3 +335,44 @@ def test_gpu_host_buffer_forms(plslam, oracle, synth):
                                                    len(q["valid"]), p(q["valid"]), p(q["seg"]), p(q["viewcos"]), p(q["desc"]),
                                                    p(q["hasobs"]), 3.0, 0.9, p(got), C.byref(cnt), 0), "line ml")
     assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > 30
+
+
+# ------------------------------------------------------------------ UndistortKeyPoints / ComputeDistinctiveDescriptors
+TUM1_K = [517.306408, 516.469215, 318.643040, 255.313989]
+TUM1_D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+
+
+def _check_post(P, O, S, lib, nk, sizes):
+    L = O.lib()
+    L.plo_undistort_keypoints.argtypes = [V, I, V, V, V]
+    L.plo_distinctive_descriptor.argtypes = [V, I]
+    L.plo_distinctive_descriptor.restype = I
+    Kf, Df = np.asarray(TUM1_K, np.float32), np.asarray(TUM1_D, np.float32)
+    frames = [make_frame_pair(P, S, 60 + i, n, nl=0)[0]["kps"] for i, n in enumerate(nk)]
+    for D in (Df, np.zeros(5, np.float32)):
+        got = P.undistort_keypoints(frames, Kf, D, lib=lib)
+        for k, g in zip(frames, got):
+            ref = np.zeros(len(k), P.KP_DTYPE)
+            L.plo_undistort_keypoints(O._p(k), len(k), O._p(Kf), O._p(D), O._p(ref))
+            assert all((g[f] == ref[f]).all() for f in ref.dtype.names)
+            if D[0] != 0 and len(k) > 50:
+                assert np.abs(g["x"] - k["x"]).max() > 0.5      # the distortion really moves border points
+    rng = S.SplitMix64(5)
+    sets = []
+    for n in sizes:
+        base = S.make_descriptor_sets(200 + n, 1, 0.0)[0][0]
+        flips = (rng.uniform(n * 256) < 0.1).reshape(n, 256)
+        sets.append(base[None, :] ^ np.packbits(flips, axis=1, bitorder="little") if n else np.zeros((0, 32), np.uint8))
+    got = P.distinctive_descriptors(sets, lib=lib)
+    for s, g in zip(sets, got):
+        s = np.ascontiguousarray(s)
+        assert g == L.plo_distinctive_descriptor(O._p(s), len(s))
+
+
+def test_emu_undistort_and_distinctive(plslam, oracle, synth, emu_lib):
+    _check_post(plslam, oracle, synth, emu_lib, [150, 0, 37], [1, 2, 3, 8, 0, 33, 70])
+
+
+@pytest.mark.gpu
+def test_gpu_undistort_and_distinctive(plslam, oracle, synth):
+    _check_post(plslam, oracle, synth, None, [2000, 1000, 0, 1], [1, 2, 3, 5, 8, 0, 33, 64, 65, 200, 700])
