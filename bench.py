@@ -272,7 +272,7 @@ def main():
             "roofline": r_dom,
             "roofline_fast": roof(1, per_ms[1], "HIP events, extra pass after the timed region with both halves on one stream"),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0)
             O = _util.oracle()
             O.build()
             out["cpu_baseline"] = cpu_baseline(O, V, frames[:min(B, 64)], voc, args.nfeatures, args.nlevels, args.nlines,

@@ -251,7 +251,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
     }
     const bool cand = cur.inb && !(cur.px.q & LSD_USED) && cur.px.q > c.qThresh && !((stale >> lane) & 1ull);
     const unsigned long long pt1 = PF_NOW();
-    PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
+    PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1); PF_ADD(c, 14, m == LSD_PTS ? 1 : 0); PF_ADD(c, 15, (cnt - i) >= 2 * LSD_PTS ? 1 : 0); PF_ADD(c, 1, m == 1 ? 1 : 0);
     accPrev = lsd_resolve(c, cand, cur, true, prec, sumdx, sumdy, regAngF, cnt);
     nidxPrev = cur.nidx;
     PF_ADD(c, 4, PF_NOW() - pt1);
