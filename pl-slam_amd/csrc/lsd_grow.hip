@@ -69,6 +69,31 @@ __device__ __forceinline__ bool lsd_aligned(double theta, double a, double prec)
   return n_theta <= prec;
 }
 
+// The same test decided in float degrees whenever the angles are clearly inside / outside the tolerance; only the
+// pixels within 2e-3 degrees of a decision boundary (tolerance or the 270-degree fold) take the exact double path.
+// (theta = thF * DEG_TO_RADS and a = aF * DEG_TO_RADS carry ~1e-15 rad of rounding, the float difference ~3e-5 degrees.)
+struct LsdTol {
+  double prec;
+  float lo, hi;
+};
+__device__ __forceinline__ LsdTol lsd_tol(double prec) {
+  LsdTol t;
+  t.prec = prec;
+  const float pd = (float)(prec * (180.0 / kPI));
+  const float m = 2e-3f + pd * 1e-6f;
+  t.lo = pd - m;
+  t.hi = pd + m;
+  return t;
+}
+__device__ __forceinline__ bool lsd_aligned_f(float thF, float aF, const LsdTol& t) {
+  float d = fabsf(thF - aF);
+  const bool nearFold = fabsf(d - 270.f) < 1e-2f;
+  if (d > 270.f) d = fabsf(d - 360.f);
+  bool r = d < t.lo;
+  if (nearFold || (d >= t.lo && d <= t.hi)) r = lsd_aligned((double)thF * kDegToRads, (double)aF * kDegToRads, t.prec);
+  return r;
+}
+
 // One step's candidates: lane order == the reference's examination order (queue point, then yy, then xx).
 struct LsdCand {
   LsdPix px;
@@ -91,17 +116,17 @@ struct LsdCand {
 // Mispredictions only happen for pixels within the step's angle drift of the tolerance boundary.
 // Returns the mask of the lanes whose pixel was accepted.
 __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, bool cand, const LsdCand& cd, bool mayDup,
-                                                          double prec, float& sumdx, float& sumdy, float& regAngF, int& cnt) {
+                                                          const LsdTol& tol, float& sumdx, float& sumdy, float& regAngF,
+                                                          int& cnt) {
   const int lane = c.lane;
   unsigned long long accAll = 0;
   unsigned long long rem = wballot(cand);
   PF_ADD(c, 10, __popcll(rem));
   if (!rem) return 0;
-  const double a = (double)cd.px.angf * kDegToRads;
   const unsigned long long ltMask = lanemask_lt();
   while (rem) {
     const bool inRem = (rem >> lane) & 1ull;
-    const bool pred = inRem && lsd_aligned((double)regAngF * kDegToRads, a, prec);
+    const bool pred = inRem && lsd_aligned_f(regAngF, cd.px.angf, tol);
     const unsigned long long P = wballot(pred);
     if (!P) break;   // the state cannot change any more: every remaining candidate is rejected on the exact angle
     PF_ADD(c, 12, 1);
@@ -126,7 +151,7 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, bool
     const int prev = below ? 63 - __clzll((long long)below) : 0;
     float angPrev = __shfl(angPost, prev);
     if (!below) angPrev = regAngF;
-    const bool d = lsd_aligned((double)angPrev * kDegToRads, a, prec);
+    const bool d = lsd_aligned_f(angPrev, cd.px.angf, tol);
     const bool e = (acc >> lane) & 1ull;
     const bool live = inRem && !((canc >> lane) & 1ull);
     const unsigned long long mism = wballot(live && d != e);
@@ -196,6 +221,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
                                                float seedSin, double prec, const LsdCand& first, int firstGrp,
                                                float* regAngOut) {
   const int lane = c.lane, g = lane >> 3;
+  const LsdTol tol = lsd_tol(prec);
   float regAngF = seedAngF, sumdx = seedCos, sumdy = seedSin;
   const uint32_t seed = pk_lin(c, seedPk);
   PLH_WAVE_SYNC();
@@ -212,7 +238,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
     // first.px.q was re-read after the previous region finished: > qThresh also rejects marked pixels? no -- the mark
     // is bit 31, so test it explicitly
     const bool cand = g == firstGrp && first.inb && !(first.px.q & LSD_USED) && first.px.q > c.qThresh;
-    lsd_resolve(c, cand, first, false, prec, sumdx, sumdy, regAngF, cnt);
+    lsd_resolve(c, cand, first, false, tol, sumdx, sumdy, regAngF, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
     i = 1;
   }
@@ -252,7 +278,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
     const bool cand = cur.inb && !(cur.px.q & LSD_USED) && cur.px.q > c.qThresh && !((stale >> lane) & 1ull);
     const unsigned long long pt1 = PF_NOW();
     PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1); PF_ADD(c, 14, m == LSD_PTS ? 1 : 0); PF_ADD(c, 15, (cnt - i) >= 2 * LSD_PTS ? 1 : 0); PF_ADD(c, 1, m == 1 ? 1 : 0);
-    accPrev = lsd_resolve(c, cand, cur, true, prec, sumdx, sumdy, regAngF, cnt);
+    accPrev = lsd_resolve(c, cand, cur, true, tol, sumdx, sumdy, regAngF, cnt);
     nidxPrev = cur.nidx;
     PF_ADD(c, 4, PF_NOW() - pt1);
     i += m;
