@@ -150,17 +150,16 @@ def main():
                               nsplit=args.nsplit)
     fe.overlap = not args.serial
     Bp = fe.Bp
-    if world > 1:
-        gather = [(t[:Bp], torch.empty((world * Bp,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev))
-                  for part in fe.parts for t in (part.n, part.kps, part.desc, part.nl, part.kl, part.ldesc)]
+    DI = _util._load("plslam_amd_dist", os.path.join(ROOT, "pl-slam_amd", "dist.py"))
 
     def step():
         # N = 1: consecutive steps are independent batches and may overlap (sub-batch pipelining); N > 1: the records
         # are consumed on this stream by the RCCL gather, so every step completes before the collective
         fe.step(d_imgs, join=(world > 1))
-        if world > 1:   # RCCL gather of the fixed-stride records over xGMI
-            for src, dst in gather:
-                dist.all_gather_into_tensor(dst, src.contiguous())
+        if world > 1:   # RCCL gather of the fixed-stride records over xGMI (pl-slam_amd/dist.py; gloo-tested on CPU)
+            for part in fe.parts:
+                DI.all_gather_records({"n": part.n[:Bp], "kps": part.kps[:Bp], "desc": part.desc[:Bp], "nl": part.nl[:Bp],
+                                       "kl": part.kl[:Bp], "ldesc": part.ldesc[:Bp]}, world, dist)
 
     for _ in range(args.warmup):
         step()

@@ -30,7 +30,7 @@ struct plh_line {
   LineDeviceArgs a;   // template (pointers filled at create)
   int taps075[7], taps1[7];
   // device buffers
-  uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dUsed = nullptr, *dMask = nullptr;
+  uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dMask = nullptr;
   uint8_t* dPix = nullptr;
   uint32_t *dOrdered = nullptr, *dReg = nullptr, *dScr = nullptr, *dDxdy = nullptr;
   float* dSeedCs = nullptr;
@@ -122,7 +122,7 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dUsed, h->dMask, h->dPix, h->dOrdered, h->dReg, h->dScr, h->dSeedCs, h->dDxdy, h->dQmax,
+  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dPix, h->dOrdered, h->dReg, h->dScr, h->dSeedCs, h->dDxdy, h->dQmax,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dSegs, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -175,8 +175,8 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   a.outCap = a.nFeature + 1;
   gaussian_q8_7(7, 0.6 / 0.8, h->taps075);
   gaussian_q8_7(5, 1.0, h->taps1);
-  if (lsd_grow_lds_bytes(a.spitch, a.sh) > 150 * 1024) {
-    set_error("plh_line_create: image too large for the LDS `used` bitmap (%d x %d scaled)", a.sw, a.sh);
+  if (a.sw >= 65536 || a.sh >= 32768) {   // packed queue coordinates x:16 | y:16, mark in bit 31 of q
+    set_error("plh_line_create: image too large (%d x %d scaled)", a.sw, a.sh);
     delete h;
     return PLH_ERR_INVALID;
   }
@@ -219,7 +219,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   TRYHIP(hipMemcpy(h->dCoef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 #undef TRYHIP
-  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.used = nullptr; a.ordered = h->dOrdered; a.reg = h->dReg; a.scr = h->dScr; a.seedcs = h->dSeedCs;
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.ordered = h->dOrdered; a.reg = h->dReg; a.scr = h->dScr; a.seedcs = h->dSeedCs;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = h->dSegs; a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
   *out = h;

@@ -12,8 +12,9 @@
 //   k_lbd           BinaryDescriptor::computeLBD + binaryConversion             binary_descriptor_custom.cpp:1026-1372, 401-412
 //
 // LSD's region growing is inherently sequential per frame (global `used` map, seed order, running mean
-// angle): it runs as ONE WAVEFRONT PER FRAME with the sequential semantics kept, the 3x3 neighbourhood
-// fetched by 9 lanes, the `used` map as a bitmap in LDS and the region queue mirrored in an LDS ring.
+// angle): it runs as ONE WAVEFRONT PER FRAME with the sequential semantics kept (lsd_grow.hip): 8 queue points x
+// 8 neighbours per step, speculative in-order resolution, the `used` map in bit 31 of the level-line records and
+// the region queue mirrored in an LDS ring.
 // Throughput comes from the batch (thousands of frames = thousands of independent wavefronts).
 // Float32 / float64 arithmetic follows the oracle's operation order exactly (-ffp-contract=off).
 #include "line_dev.h"

@@ -28,8 +28,7 @@ struct LineDeviceArgs {
   uint8_t* undist;          // remapped frames (== img when no undistortion), pitch w
   uint8_t* tmpA;            // full-res scratch plane (blur output), pitch w
   uint8_t* scaled;          // 0.8x image, pitch spitch
-  void* pix;                // LsdPix[16 B] level-line record per scaled pixel, pitch spitch (line_dev.h)
-  uint8_t* used;            // region-growing marks, pitch spitch
+  void* pix;                // LsdPix[16 B] level-line record per scaled pixel, pitch spitch (line_dev.h); q bit 31 = `used`
   uint32_t* ordered;        // seed list (packed coordinates x | y << 16), bins descending / raster inside a bin
   uint32_t* reg;            // region point queue
   uint32_t* scr;            // scratch of the same size
