@@ -648,9 +648,9 @@ __device__ __forceinline__ int reflect101(int p, int nn) {
 
 __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoint* kps, uint8_t* desc, int* nOut,
                                                      int cap) {
-  constexpr int PR = 21, PW = 43, PP = 44;   // patch radius / width / pitch
+  constexpr int PR = 21, PW = 43, PP = 48;   // patch radius / width / pitch (pitch 48 = 12 dwords)
   constexpr int BR = 18, BW = 37, BP = 40;   // blurred radius / width / pitch
-  __shared__ uint8_t patch[PW * PP];
+  __shared__ uint8_t patchBuf[PW * PP + 16];
   __shared__ unsigned short hbuf[PW * BP];
   __shared__ uint8_t blur[BW * BP];
 
@@ -685,51 +685,93 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
   const int kx = key_x(key), ky = key_y(key);
   const uint8_t* img = level_ptr(a, lv, level, b);
 
-  for (int i = lane; i < PW * PW; i += 64) {
-    const int r = i / PW, c = i - r * PW;
-    const int yy = reflect101(ky - PR + r, lv.h), xx = reflect101(kx - PR + c, lv.w);
-    patch[r * PP + c] = img[(long long)yy * lv.pitch + xx];
+  // ---- stage the 43x43 patch.  Interior keypoints with dword-aligned rows: 12 aligned dwords per row, the patch then
+  // starts `sh` bytes into the buffer; otherwise (reflection needed / odd pitch) byte by byte.
+  const int xl = kx - PR;
+  const int x0a = xl & ~3;
+  const bool fastPath = xl >= 0 && kx + PR < lv.w && ky - PR >= 0 && ky + PR < lv.h && x0a + PP <= lv.pitch &&
+                        (((size_t)img | (size_t)lv.pitch) & 3) == 0;
+  const int sh = fastPath ? xl - x0a : 0;
+  uint8_t* patch = patchBuf + sh;   // patch[r * PP + c] = level pixel (kx - 21 + c, ky - 21 + r)
+  if (fastPath) {
+    for (int i = lane; i < PW * 12; i += 64) {
+      const int r = i / 12, d = i - r * 12;
+      reinterpret_cast<unsigned*>(patchBuf)[r * 12 + d] =
+          *reinterpret_cast<const unsigned*>(img + (long long)(ky - PR + r) * lv.pitch + x0a + 4 * d);
+    }
+  } else {
+    for (int i = lane; i < PW * PW; i += 64) {
+      const int r = i / PW, c = i - r * PW;
+      const int yy = reflect101(ky - PR + r, lv.h), xx = reflect101(kx - PR + c, lv.w);
+      patch[r * PP + c] = img[(long long)yy * lv.pitch + xx];
+    }
   }
   __syncthreads();
 
-  // IC_Angle: integer moments over the circular patch
+  // IC_Angle: integer moments over the circular patch, two rows of 31 per iteration
   int m10 = 0, m01 = 0;
-  for (int i = lane; i < 31 * 31; i += 64) {
-    const int r = i / 31, c = i - r * 31;
-    const int v = r - 15, u = c - 15;
-    const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-    if (au <= c_umax[av]) {
-      const int val = patch[(PR + v) * PP + PR + u];
-      m10 += u * val;
-      m01 += v * val;
+  {
+    const int u = (lane & 31) - 15;
+    const int au = u < 0 ? -u : u;
+    for (int v0 = -15; v0 <= 15; v0 += 2) {
+      const int v = v0 + (lane >> 5);
+      const int av = v < 0 ? -v : v;
+      if (v <= 15 && au <= 15 && au <= c_umax[av]) {
+        const int val = patch[(PR + v) * PP + PR + u];
+        m10 += u * val;
+        m01 += v * val;
+      }
     }
   }
   m10 = wave_sum(m10);
   m01 = wave_sum(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-  // horizontal pass: rows 0..42, output columns 3..39 (37 wide)
-  for (int i = lane; i < PW * BW; i += 64) {
-    const int r = i / BW, c = i - r * BW;
-    const uint8_t* p = &patch[r * PP + c];
-    const int s = c_gauss7[0] * (p[0] + p[6]) + c_gauss7[1] * (p[1] + p[5]) + c_gauss7[2] * (p[2] + p[4]) + c_gauss7[3] * p[3];
-    hbuf[r * BP + c] = (unsigned short)s;
+  // horizontal pass: rows 0..42, output columns 0..36 (patch columns c..c+6), four outputs per lane
+  for (int i = lane; i < PW * 10; i += 64) {
+    const int r = i / 10, c0 = (i - r * 10) * 4;
+    const uint8_t* p = &patch[r * PP + c0];
+    int q[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) q[k] = p[k];   // columns >= 43 of the last group only feed outputs >= 37 (discarded)
+    unsigned hs[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      hs[k] = (unsigned)(c_gauss7[0] * (q[k] + q[k + 6]) + c_gauss7[1] * (q[k + 1] + q[k + 5]) +
+                         c_gauss7[2] * (q[k + 2] + q[k + 4]) + c_gauss7[3] * q[k + 3]);   // <= 257 * 255 < 2^16
+    uint2 hw;
+    hw.x = hs[0] | (hs[1] << 16);
+    hw.y = hs[2] | (hs[3] << 16);
+    *reinterpret_cast<uint2*>(&hbuf[r * BP + c0]) = hw;
   }
   __syncthreads();
-  for (int i = lane; i < BW * BW; i += 64) {
-    const int r = i / BW, c = i - r * BW;
-    const unsigned short* p = &hbuf[r * BP + c];
-    const int s = c_gauss7[0] * (p[0] + p[6 * BP]) + c_gauss7[1] * (p[BP] + p[5 * BP]) + c_gauss7[2] * (p[2 * BP] + p[4 * BP]) +
-                  c_gauss7[3] * p[3 * BP];
-    int v = (s + (1 << 15)) >> 16;
-    blur[r * BP + c] = (uint8_t)(v > 255 ? 255 : v);
+  // vertical pass: four outputs per lane, 8-byte reads of the 16-bit row sums
+  for (int i = lane; i < BW * 10; i += 64) {
+    const int r = i / 10, c0 = (i - r * 10) * 4;
+    uint2 w[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++) w[t] = *reinterpret_cast<const uint2*>(&hbuf[(r + t) * BP + c0]);
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      auto f = [&](int t) -> int {
+        const unsigned d = k < 2 ? w[t].x : w[t].y;
+        return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
+      };
+      const int sacc = c_gauss7[0] * (f(0) + f(6)) + c_gauss7[1] * (f(1) + f(5)) + c_gauss7[2] * (f(2) + f(4)) + c_gauss7[3] * f(3);
+      const int v = (sacc + (1 << 15)) >> 16;
+      out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
+    }
+    *reinterpret_cast<unsigned*>(&blur[r * BP + c0]) = out;
   }
   __syncthreads();
 
   // steered rBRIEF: lane -> 4 pairs (one nibble)
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float ang = angle * factorPI;
-  const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
+  double sd, cd;
+  sincos((double)ang, &sd, &cd);   // correctly rounded cosf / sinf of the pinned definition: double evaluation, one rounding
+  const float ca = (float)cd, sa = (float)sd;
   const signed char* pat = c_orb_pattern + lane * 16;
   int nib = 0;
 #pragma unroll
