@@ -38,36 +38,78 @@ __global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
   a.undist[(long long)b * a.fullStride + (long long)y * a.w + x] = (uint8_t)(v > 255 ? 255 : v);
 }
 
-// Separable 7-tap Q8 blur; 64x16 output tile per block, input tile (+3 halo, REFLECT_101) staged in LDS.
+// Separable 7-tap Q8 blur; 64x16 output tile per block, input tile (+3 halo, REFLECT_101) staged in LDS with aligned
+// dword loads (byte funnel for odd row addresses; byte-wise with reflection only in the image's edge columns).
+// Every thread produces 4 adjacent outputs per pass: 3 dword LDS reads -> 4 x 7 MACs -> one 8-byte row-sum store,
+// then 7 x 8-byte reads -> 4 x 7 MACs -> one dword of pixels.  Tile column j holds image column x0 - 4 + j.
 __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst,
                                                   long long dStride, int dPitch, int w, int h, Taps7 t) {
-  constexpr int TW = 64, TH = 16, IW = TW + 6, IH = TH + 6, IP = IW + 2;
-  __shared__ uint8_t tin[IH * IP];
-  __shared__ unsigned short hb[IH * TW];
+  constexpr int TW = 64, TH = 16, IH = TH + 6, IP = TW + 8;   // 72-byte tile rows = 18 dwords
+  __shared__ unsigned tin[IH * IP / 4];
+  __shared__ uint2 hb[IH * TW / 4];
   const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
   const uint8_t* S = src + (long long)b * sStride;
-  for (int i = tid; i < IH * IW; i += 256) {
-    const int r = i / IW, c = i - r * IW;
-    tin[r * IP + c] = S[(long long)refl101(y0 - 3 + r, h) * sPitch + refl101(x0 - 3 + c, w)];
+  const bool interior = x0 >= 4 && x0 + TW + 8 <= w;   // the aligned dword pairs stay inside the row
+  for (int i = tid; i < IH * (IP / 4); i += 256) {
+    const int r = i / (IP / 4), d = i - r * (IP / 4);
+    const uint8_t* row = S + (long long)refl101(y0 - 3 + r, h) * sPitch;
+    unsigned v;
+    if (interior) {
+      const uint8_t* p = row + x0 - 4 + 4 * d;
+      const int m = (int)((size_t)p & 3);
+      const unsigned* ap = reinterpret_cast<const unsigned*>(p - m);
+      const unsigned lo = ap[0];
+      v = m ? (unsigned)(((((unsigned long long)ap[1]) << 32) | lo) >> (8 * m)) : lo;
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) v |= (unsigned)row[refl101(x0 - 4 + 4 * d + k, w)] << (8 * k);
+    }
+    tin[i] = v;
   }
   __syncthreads();
-  for (int i = tid; i < IH * TW; i += 256) {
-    const int r = i / TW, c = i - r * TW;
-    const uint8_t* p = &tin[r * IP + c];
-    hb[i] = (unsigned short)(t.k[0] * p[0] + t.k[1] * p[1] + t.k[2] * p[2] + t.k[3] * p[3] + t.k[4] * p[4] + t.k[5] * p[5] +
-                             t.k[6] * p[6]);
+  for (int i = tid; i < IH * (TW / 4); i += 256) {
+    const int r = i / (TW / 4), g = i - r * (TW / 4);
+    const unsigned A = tin[r * (IP / 4) + g], B = tin[r * (IP / 4) + g + 1], Cc = tin[r * (IP / 4) + g + 2];
+    int q[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { q[k] = (A >> (8 * k)) & 255; q[4 + k] = (B >> (8 * k)) & 255; q[8 + k] = (Cc >> (8 * k)) & 255; }
+    unsigned hs[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)   // output column 4g+k reads tile columns 4g+k+1 .. 4g+k+7
+      hs[k] = (unsigned)(t.k[0] * q[k + 1] + t.k[1] * q[k + 2] + t.k[2] * q[k + 3] + t.k[3] * q[k + 4] + t.k[4] * q[k + 5] +
+                         t.k[5] * q[k + 6] + t.k[6] * q[k + 7]);
+    uint2 hw;
+    hw.x = hs[0] | (hs[1] << 16);
+    hw.y = hs[2] | (hs[3] << 16);
+    hb[i] = hw;
   }
   __syncthreads();
   uint8_t* D = dst + (long long)b * dStride;
-  for (int i = tid; i < TH * TW; i += 256) {
-    const int r = i / TW, c = i - r * TW;
-    const int x = x0 + c, y = y0 + r;
+  {
+    const int r = tid / (TW / 4), g = tid - r * (TW / 4);   // 16 rows x 16 groups = 256 threads
+    const int x = x0 + 4 * g, y = y0 + r;
     if (x < w && y < h) {
-      const unsigned short* p = &hb[r * TW + c];
-      const int s = t.k[0] * p[0] + t.k[1] * p[TW] + t.k[2] * p[2 * TW] + t.k[3] * p[3 * TW] + t.k[4] * p[4 * TW] +
-                    t.k[5] * p[5 * TW] + t.k[6] * p[6 * TW];
-      const int v = (s + (1 << 15)) >> 16;
-      D[(long long)y * dPitch + x] = (uint8_t)(v > 255 ? 255 : v);
+      uint2 wv[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) wv[k] = hb[(r + k) * (TW / 4) + g];
+      unsigned out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        auto f = [&](int tt) -> int {
+          const unsigned d = k < 2 ? wv[tt].x : wv[tt].y;
+          return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
+        };
+        const int s = t.k[0] * f(0) + t.k[1] * f(1) + t.k[2] * f(2) + t.k[3] * f(3) + t.k[4] * f(4) + t.k[5] * f(5) + t.k[6] * f(6);
+        const int v = (s + (1 << 15)) >> 16;
+        out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
+      }
+      uint8_t* o = D + (long long)y * dPitch + x;
+      if (x + 4 <= w && (((size_t)o) & 3) == 0) {
+        *reinterpret_cast<unsigned*>(o) = out;
+      } else {
+        for (int k = 0; k < 4 && x + k < w; k++) o[k] = (uint8_t)(out >> (8 * k));
+      }
     }
   }
 }

@@ -84,7 +84,7 @@ def test_oracle_lbd_determinism_and_norm(oracle, synth):
 
 # ------------------------------------------------------------------ HIP sources under hipemu (CPU)
 @pytest.mark.parametrize("seed,rows,cols,nf,minlen,undist", [(7, 120, 160, 50, 0.0, False), (8, 120, 160, 20, 15.0, False),
-                                                            (10, 120, 160, 50, 0.0, True)])
+                                                            (10, 120, 160, 50, 0.0, True), (11, 118, 203, 40, 0.0, False)])
 def test_emu_line_extract(plslam, oracle, synth, emu_lib, seed, rows, cols, nf, minlen, undist):
     img = synth.make_frame(seed, rows, cols, n_rect=40, n_line=20)
     K, D = ([150.0, 150.0, 80.0, 60.0], TUM1_D) if undist else (None, None)
