@@ -736,15 +736,50 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
 // ---------------------------------------------------------------------------------------------
 // Sobel 3x3 (dx, dy) of the 5x5-blurred frame, packed int16 x 2, REFLECT_101.
 // ---------------------------------------------------------------------------------------------
+// 4 bytes at p (any alignment) from aligned dword loads
+__device__ __forceinline__ unsigned ld4_any(const uint8_t* p) {
+  const int m = (int)((size_t)p & 3);
+  const unsigned* ap = reinterpret_cast<const unsigned*>(p - m);
+  const unsigned lo = ap[0];
+  return m ? (unsigned)(((((unsigned long long)ap[1]) << 32) | lo) >> (8 * m)) : lo;
+}
+
+// One thread per 4 adjacent pixels: three rows x {left, centre, right} dwords -> 4 packed (dx, dy) -> one 16-byte store.
 __global__ void __launch_bounds__(256) k_sobel_pack(LineDeviceArgs a) {
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
   if (x >= a.w) return;
   const uint8_t* S = a.tmpA + (long long)b * a.fullStride;
-  const int xm = refl101(x - 1, a.w), xp = refl101(x + 1, a.w), ym = refl101(y - 1, a.h), yp = refl101(y + 1, a.h);
+  const int ym = refl101(y - 1, a.h), yp = refl101(y + 1, a.h);
   const uint8_t *r0 = S + (long long)ym * a.w, *r1 = S + (long long)y * a.w, *r2 = S + (long long)yp * a.w;
-  const int gx = (r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]);
-  const int gy = (r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]);
-  a.dxdy[(long long)b * a.fullStride + (long long)y * a.w + x] = pack_g(gx, gy);
+  int p0[6], p1[6], p2[6];   // columns x-1 .. x+4 of the three rows
+  if (x >= 4 && x + 8 <= a.w) {
+    const unsigned l0 = ld4_any(r0 + x - 4), c0 = ld4_any(r0 + x), h0 = ld4_any(r0 + x + 4);
+    const unsigned l1 = ld4_any(r1 + x - 4), c1 = ld4_any(r1 + x), h1 = ld4_any(r1 + x + 4);
+    const unsigned l2 = ld4_any(r2 + x - 4), c2 = ld4_any(r2 + x), h2 = ld4_any(r2 + x + 4);
+    p0[0] = l0 >> 24; p1[0] = l1 >> 24; p2[0] = l2 >> 24;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { p0[1 + k] = (c0 >> (8 * k)) & 255; p1[1 + k] = (c1 >> (8 * k)) & 255; p2[1 + k] = (c2 >> (8 * k)) & 255; }
+    p0[5] = h0 & 255; p1[5] = h1 & 255; p2[5] = h2 & 255;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int xx = refl101(min(x - 1 + k, a.w), a.w);   // columns beyond the row only feed discarded outputs
+      p0[k] = r0[xx]; p1[k] = r1[xx]; p2[k] = r2[xx];
+    }
+  }
+  uint32_t out[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int gx = (p0[k + 2] - p0[k]) + 2 * (p1[k + 2] - p1[k]) + (p2[k + 2] - p2[k]);
+    const int gy = (p2[k] - p0[k]) + 2 * (p2[k + 1] - p0[k + 1]) + (p2[k + 2] - p0[k + 2]);
+    out[k] = pack_g(gx, gy);
+  }
+  uint32_t* o = a.dxdy + (long long)b * a.fullStride + (long long)y * a.w + x;
+  if (x + 4 <= a.w && (((size_t)o) & 15) == 0) {
+    *reinterpret_cast<uint4*>(o) = uint4{out[0], out[1], out[2], out[3]};
+  } else {
+    for (int k = 0; k < 4 && x + k < a.w; k++) o[k] = out[k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -873,7 +908,7 @@ void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* 
   hipLaunchKernelGGL(k_keylines, dim3(a.batch), dim3(256), (size_t)a.outCap * 8 + 64, s, a, kl, fn, n);
 }
 void launch_sobel(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_sobel_pack, dim3((a.w + 255) / 256, a.h, a.batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_sobel_pack, dim3((a.w + 1023) / 1024, a.h, a.batch), dim3(256), 0, s, a);
 }
 void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, const float* coef, uint8_t* desc, hipStream_t s) {
   hipLaunchKernelGGL(k_lbd, dim3(a.outCap, a.batch), dim3(64), 0, s, a, kl, n, coef, desc);
