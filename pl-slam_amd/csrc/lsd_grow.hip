@@ -209,12 +209,10 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int q, int cnt, bool 
 }
 
 // region_grow(): BFS over reg[] used as a queue, 8 queued points (64 neighbour lanes) per step; each lane fetches
-// its neighbour's 16-byte level-line record with one load.  The loads are software-pipelined: the records of the
-// next step's points that are already queued are requested (set A) BEFORE the current step is resolved, the
-// points queued by the current step are requested right after it (set B); every lane loads unconditionally
-// (record 0 when it has nothing to examine) so that no register of a set is touched before the next step
-// selects between the two.  `first` holds the seed's 8 neighbours prefetched in lane group `firstGrp`
-// (firstGrp < 0: not prefetched).
+// its neighbour's 16-byte level-line record (angle, cos, sin, q | used mark) with one load, issued right after the
+// previous step's marks.  (A frontier wider than 8 points is rare -- 7 % of the steps -- so prefetching across steps
+// costs more instructions than it hides; latency is hidden by the other resident frames.)  `first` holds the seed's
+// 8 neighbours prefetched in lane group `firstGrp` (firstGrp < 0: not prefetched).
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
 // reference's float fastAtan2 result).  All lanes hold identical (uniform) state.
 __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk, unsigned seedQ, float seedAngF, float seedCos,
@@ -248,44 +246,23 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
     return cnt;
   }
   PLH_WAVE_SYNC();
-  uint32_t nidxA, npkA, nidxB = 0, npkB = 0;
-  bool inbA = lsd_addr(c, i + g, cnt, i + g < cnt, nidxA, npkA), inbB = false;
-  LsdPix pxA = c.G[nidxA], pxB = pxA;
-  unsigned long long accPrev = 0;   // lanes accepted by the previous step (their marks may postdate set A's loads)
-  uint32_t nidxPrev = 0;
+  LsdCand cur;
+  cur.inb = lsd_addr(c, i + g, cnt, i + g < cnt, cur.nidx, cur.npk);
+  cur.px = c.G[cur.nidx];
   while (i < cnt) {
     const unsigned long long pt0 = PF_NOW();
-    const int m = min(LSD_PTS, cnt - i), cnt0 = cnt;
-    LsdCand cur;
-    cur.inb = inbA || inbB;
-    cur.nidx = inbB ? nidxB : nidxA;
-    cur.npk = inbB ? npkB : npkA;
-    cur.px.angf = inbB ? pxB.angf : pxA.angf;
-    cur.px.cs = inbB ? pxB.cs : pxA.cs;
-    cur.px.sn = inbB ? pxB.sn : pxA.sn;
-    cur.px.q = inbB ? pxB.q : pxA.q;
-    // set A of the next step: its points that are already queued (unconditional: see above)
-    inbA = lsd_addr(c, i + LSD_PTS + g, cnt, i + LSD_PTS + g < cnt, nidxA, npkA);
-    pxA = c.G[nidxA];
-    PLH_WAVE_SYNC();
-    // set A of this step was requested before the previous step marked its pixels: cancel those by comparison
-    unsigned long long stale = 0;
-    while (accPrev) {
-      const int k = __ffsll((long long)accPrev) - 1;
-      accPrev &= accPrev - 1;
-      stale |= wballot(cur.nidx == bcast_u32(nidxPrev, k));
-    }
-    const bool cand = cur.inb && !(cur.px.q & LSD_USED) && cur.px.q > c.qThresh && !((stale >> lane) & 1ull);
+    const int m = min(LSD_PTS, cnt - i);
+    const bool cand = cur.inb && !(cur.px.q & LSD_USED) && cur.px.q > c.qThresh;
     const unsigned long long pt1 = PF_NOW();
-    PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1); PF_ADD(c, 14, m == LSD_PTS ? 1 : 0); PF_ADD(c, 15, (cnt - i) >= 2 * LSD_PTS ? 1 : 0); PF_ADD(c, 1, m == 1 ? 1 : 0);
-    accPrev = lsd_resolve(c, cand, cur, true, tol, sumdx, sumdy, regAngF, cnt);
-    nidxPrev = cur.nidx;
+    PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
+    lsd_resolve(c, cand, cur, true, tol, sumdx, sumdy, regAngF, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1);
     i += m;
-    // set B: the points queued by this step
+    // the next step's records, requested after this step's marks were stored (a wavefront observes its own stores);
+    // every lane loads (record 0 when it has nothing to examine) so the carried registers are simply overwritten
     PLH_WAVE_SYNC();
-    inbB = lsd_addr(c, i + g, cnt, i + g >= cnt0 && i + g < cnt, nidxB, npkB);
-    pxB = c.G[nidxB];
+    cur.inb = lsd_addr(c, i + g, cnt, i + g < cnt, cur.nidx, cur.npk);
+    cur.px = c.G[cur.nidx];
   }
   PF_ADD(c, 9, cnt);
   *regAngOut = regAngF;

@@ -64,17 +64,14 @@ __host__ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
   const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
   const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
-  float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
-  if (ax >= ay) {
-    c = ay / (ax + 2.2204460492503131e-16f);
-    c2 = c * c;
-    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  } else {
-    c = ax / (ay + 2.2204460492503131e-16f);
-    c2 = c * c;
-    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  }
+  // both branches of the reference (ax >= ay ? ay / (ax + eps) : ax / (ay + eps)) are min / (max + eps): one division and
+  // one polynomial for every lane, bit-identical to the branched form
+  const float ax = fabsf(x), ay = fabsf(y);
+  const bool swap = !(ax >= ay);
+  const float c = (swap ? ax : ay) / ((swap ? ay : ax) + 2.2204460492503131e-16f);
+  const float c2 = c * c;
+  float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  if (swap) a = 90.f - a;
   if (x < 0) a = 180.f - a;
   if (y < 0) a = 360.f - a;
   return a;
