@@ -338,7 +338,8 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
                                          : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
   theta *= kDegToRads;
   if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += kPI;
-  const double dx = cos(theta), dy = sin(theta);
+  double dx, dy;
+  sincos(theta, &dy, &dx);
   double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
   for (int i = lane; i < cnt; i += 64) {
     const uint32_t p = c.reg[i];

@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _util  # noqa: E402
 
-NAMES = ["total", "#steps m=1", "region_grow", "grow:load wait", "grow:resolve", "region2rect", "refine", "-",
-         "#steps", "#accepted", "#cands", "#grow calls", "#passes", "#mispredicts", "#steps m=8", "#steps pending>=16"]
+NAMES = ["total", "-", "region_grow", "grow:load wait", "grow:resolve", "region2rect", "refine", "-",
+         "#steps", "#accepted", "#cands", "#grow calls", "#passes", "#mispredicts", "-", "-"]
 
 
 def main():
