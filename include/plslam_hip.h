@@ -197,6 +197,16 @@ PLH_API plh_status plh_orb_search_by_bow_kp_batch_dev(const uint8_t* d_desc1, co
                                                       int th_low, float nnratio, int check_ori, int32_t* d_matches21,
                                                       int32_t* d_nmatches, void* stream);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (ORBmatcher.cc:574-709; SURVEY 8f
+ * row 2).  valid1 / valid2: the feature carries a non-bad MapPoint.  d_matches12[pairs][cap]: for feature idx1 of the first
+ * KeyFrame the matched feature of the second one (the reference stores vpMapPoints2[idx2]) or -1. */
+PLH_API plh_status plh_orb_search_by_bow_kfkf_batch_dev(const uint8_t* d_desc1, const plh_keypoint* d_kps1,
+                                                        const int32_t* d_node1, const uint8_t* d_valid1, const int32_t* d_n1,
+                                                        const uint8_t* d_desc2, const plh_keypoint* d_kps2,
+                                                        const int32_t* d_node2, const uint8_t* d_valid2, const int32_t* d_n2,
+                                                        int cap, int pairs, int th_low, float nnratio, int check_ori,
+                                                        int32_t* d_matches12, int32_t* d_nmatches, void* stream);
+
 /* DBoW2 TemplatedVocabulary::transform(feature, word, weight, &nid, levelsup) for every descriptor of a batch
  * (Frame::ComputeBoW, Frame.cc:906-913 -> Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1255).
  * The tree is given as flat arrays over node ids (root = 0): 32-byte node descriptors, contiguous children
@@ -266,6 +276,17 @@ PLH_API plh_status plh_orb_search_by_projection_frame_batch_dev(
     const int32_t* d_cell_start, const int32_t* d_cell_items, const float* scale_factors, int nlevels, uint8_t* d_occupied,
     const int32_t* d_nq, int qcap, const uint8_t* d_q_valid, const float* d_q_uv, const int32_t* d_q_octave,
     const float* d_q_angle, const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int mode, int check_ori,
+    int32_t* d_assigned, int32_t* d_nmatches, void* stream);
+
+/* ORBmatcher::SearchByProjection(Frame& Cur, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * (ORBmatcher.cc:1587-1716, relocalisation): the last-frame form with the caller's distance threshold.
+ * Query i = KeyFrame map point i: valid = pMP && !isBad() && !sAlreadyFound.count(pMP) && depth inside the scale pyramid;
+ * level = pMP->PredictScale(dist3D, &Cur); angle = pKF->mvKeysUn[i].angle; occupied = Cur.mvpMapPoints[i2] != NULL; hasobs = 1. */
+PLH_API plh_status plh_orb_search_by_projection_kf_batch_dev(
+    const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n, int cap, int pairs, const plh_grid_params* gp,
+    const int32_t* d_cell_start, const int32_t* d_cell_items, const float* scale_factors, int nlevels, uint8_t* d_occupied,
+    const int32_t* d_nq, int qcap, const uint8_t* d_q_valid, const float* d_q_uv, const int32_t* d_q_level,
+    const float* d_q_angle, const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int orb_dist, int check_ori,
     int32_t* d_assigned, int32_t* d_nmatches, void* stream);
 
 /* LSDmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th) (LSDmatcher.cpp:72-176).

@@ -301,11 +301,11 @@ int plo_orb_search_by_projection_mp(const plo_keypoint* kps_un, const uint8_t* d
 // (u, v) into the current frame; q_octave = LastFrame.mvKeys[i].octave; q_angle = LastFrame.mvKeysUn[i].angle;
 // q_desc = pMP->GetDescriptor(); mode 0 = monocular / lateral (octave-1 .. octave+1), 1 = forward
 // (>= octave), 2 = backward (0 .. octave).
-int plo_orb_search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
-                                       const int32_t* cs, const int32_t* ci, const float* scale_factors, uint8_t* occupied,
-                                       int nq, const uint8_t* q_valid, const float* q_uv, const int32_t* q_octave,
-                                       const float* q_angle, const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int mode,
-                                       int check_ori, int32_t* assigned) {
+static int search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                                      const int32_t* cs, const int32_t* ci, const float* scale_factors, uint8_t* occupied,
+                                      int nq, const uint8_t* q_valid, const float* q_uv, const int32_t* q_octave,
+                                      const float* q_angle, const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int mode,
+                                      int check_ori, int dist_th, int32_t* assigned) {
   GridP g;
   memcpy(&g, gp, sizeof(g));
   int nmatches = 0;
@@ -331,7 +331,7 @@ int plo_orb_search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t
       const int dist = plo_descriptor_distance(dMP, desc + (size_t)i2 * 32);
       if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
     }
-    if (bestDist <= ORB_TH_HIGH) {
+    if (bestDist <= dist_th) {
       assigned[bestIdx2] = i;
       occupied[bestIdx2] = q_hasobs[i];
       nmatches++;
@@ -352,6 +352,27 @@ int plo_orb_search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t
         for (int idx : rotHist[i]) { assigned[idx] = -1; nmatches--; }
   }
   return nmatches;
+}
+
+int plo_orb_search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                                       const int32_t* cs, const int32_t* ci, const float* scale_factors, uint8_t* occupied,
+                                       int nq, const uint8_t* q_valid, const float* q_uv, const int32_t* q_octave,
+                                       const float* q_angle, const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int mode,
+                                       int check_ori, int32_t* assigned) {
+  return search_by_projection_frame(kps_un, desc, n, gp, cs, ci, scale_factors, occupied, nq, q_valid, q_uv, q_octave, q_angle,
+                                    q_desc, q_hasobs, th, mode, check_ori, ORB_TH_HIGH, assigned);
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist),
+// reference src/ORBmatcher.cc:1587-1716 (relocalisation): same scan with the caller's distance threshold; q_level =
+// pMP->PredictScale(...), band level-1..level+1; `occupied` = CurrentFrame.mvpMapPoints[i2] != NULL (q_hasobs all 1).
+int plo_orb_search_by_projection_kf(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6], const int32_t* cs,
+                                    const int32_t* ci, const float* scale_factors, uint8_t* occupied, int nq,
+                                    const uint8_t* q_valid, const float* q_uv, const int32_t* q_level, const float* q_angle,
+                                    const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int orb_dist, int check_ori,
+                                    int32_t* assigned) {
+  return search_by_projection_frame(kps_un, desc, n, gp, cs, ci, scale_factors, occupied, nq, q_valid, q_uv, q_level, q_angle,
+                                    q_desc, q_hasobs, th, 0, check_ori, orb_dist, assigned);
 }
 
 // LSDmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th).

@@ -219,3 +219,67 @@ void plo_bow_transform(const uint8_t* desc, int n, const uint8_t* node_desc, con
 }
 
 }  // extern "C"
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), reference
+// src/ORBmatcher.cc:574-709.  valid1 / valid2 = feature carries a non-bad MapPoint; matches12[idx1] = feature of the second
+// KeyFrame whose MapPoint the reference stores, or -1.  Note the strict `bestDist1 < TH_LOW` (:646) of this overload.
+extern "C" int plo_orb_search_by_bow_kfkf(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1,
+                                          int n1, const uint8_t* desc2, const float* angle2, const int32_t* node2,
+                                          const uint8_t* valid2, int n2, int th_low, float nnratio, int check_ori,
+                                          int32_t* matches12) {
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::map<int, std::vector<unsigned>> fv1, fv2;
+  for (int i = 0; i < n1; i++) if (node1[i] >= 0) fv1[node1[i]].push_back((unsigned)i);
+  for (int j = 0; j < n2; j++) if (node2[j] >= 0) fv2[node2[j]].push_back((unsigned)j);
+  std::vector<bool> vbMatched2(std::max(n2, 1), false);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  auto f1it = fv1.begin(), f1end = fv1.end();
+  auto f2it = fv2.begin(), f2end = fv2.end();
+  while (f1it != f1end && f2it != f2end) {
+    if (f1it->first == f2it->first) {
+      for (size_t i1 = 0; i1 < f1it->second.size(); i1++) {
+        const size_t idx1 = f1it->second[i1];
+        if (!valid1[idx1]) continue;
+        const uint8_t* d1 = desc1 + idx1 * 32;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (size_t i2 = 0; i2 < f2it->second.size(); i2++) {
+          const size_t idx2 = f2it->second[i2];
+          if (vbMatched2[idx2] || !valid2[idx2]) continue;
+          const int dist = plo_descriptor_distance(d1, desc2 + idx2 * 32);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+          else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist1 < th_low) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches12[idx1] = bestIdx2;
+            vbMatched2[bestIdx2] = true;
+            if (check_ori) {
+              float rot = angle1[idx1] - angle2[bestIdx2];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)roundf(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin].push_back((int)idx1);
+            }
+            nmatches++;
+          }
+        }
+      }
+      ++f1it; ++f2it;
+    } else if (f1it->first < f2it->first) {
+      f1it = fv1.lower_bound(f2it->first);
+    } else {
+      f2it = fv2.lower_bound(f1it->first);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}

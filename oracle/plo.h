@@ -137,6 +137,16 @@ int  plo_line_search_by_projection_ml(const plo_keyline* kl, const uint8_t* ldes
  * (src/MapPoint.cc:249-314, src/MapLine.cpp:256-330) */
 void plo_undistort_keypoints(const plo_keypoint* kps, int n, const float K[4], const float D[5], plo_keypoint* out);
 int  plo_distinctive_descriptor(const uint8_t* desc, int n);
+/* ORBmatcher::SearchByBoW(KF, KF) (src/ORBmatcher.cc:574-709) and the relocalisation
+ * SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1587-1716) */
+int  plo_orb_search_by_bow_kfkf(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
+                                const uint8_t* desc2, const float* angle2, const int32_t* node2, const uint8_t* valid2, int n2,
+                                int th_low, float nnratio, int check_ori, int32_t* matches12);
+int  plo_orb_search_by_projection_kf(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6], const int32_t* cs,
+                                     const int32_t* ci, const float* scale_factors, uint8_t* occupied, int nq,
+                                     const uint8_t* q_valid, const float* q_uv, const int32_t* q_level, const float* q_angle,
+                                     const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int orb_dist, int check_ori,
+                                     int32_t* assigned);
 
 #ifdef __cplusplus
 }

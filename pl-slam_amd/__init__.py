@@ -75,6 +75,9 @@ _SIGS = {
     "plh_line_extract": ([_V, _V, _I, _I, _Z, _V, _V, _V, _V, _I, _V], _I),
     "plh_line_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
+    "plh_orb_search_by_bow_kfkf_batch_dev": ([_V] * 10 + [_I, _I, _I, _F, _I, _V, _V, _V], _I),
+    "plh_orb_search_by_projection_kf_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 6 +
+                                                  [_F, _I, _I, _V, _V, _V], _I),
     "plh_undistort_keypoints_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
     "plh_distinctive_descriptor_batch_dev": ([_V, _V, _I, _V, _V], _I),
     "plh_frame_assign_grid_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
@@ -455,6 +458,22 @@ class FrameSearch:
             int(mode), int(checkOri), _p(da), _p(dc), C.c_void_p(D.stream())), "plh_orb_search_by_projection_frame_batch_dev")
         return D.get(da), D.get(dc), D.get(docc)
 
+    def SearchByProjectionKeyFrame(self, qs, occupied, th=10.0, ORBdist=100, checkOri=True):
+        """ORBmatcher(0.9, checkOri).SearchByProjection(CurrentFrame = this frame, pKF, sAlreadyFound, th, ORBdist)
+        (relocalisation).  qs: per frame dict(valid, uv, level, angle, desc, hasobs)."""
+        D, L = self.D, self.lib
+        qcap, dnq, (qv, quv, ql, qa, qd, qh) = self._queries(qs, [("valid", 0, np.uint8), ("uv", 2, np.float32),
+                                                                   ("level", 0, np.int32), ("angle", 0, np.float32),
+                                                                   ("desc", 32, np.uint8), ("hasobs", 0, np.uint8)])
+        occ, _ = _pad_sets(occupied, self.cap, 0, np.uint8)
+        docc = D.put(occ)
+        da, dc = D.empty((self.P, self.cap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_orb_search_by_projection_kf_batch_dev(
+            _p(self.d_kps), _p(self.d_desc), _p(self.d_n), self.cap, self.P, C.byref(self.gp), _p(self.d_cs), _p(self.d_ci),
+            _p(self.sf), len(self.sf), _p(docc), _p(dnq), qcap, _p(qv), _p(quv), _p(ql), _p(qa), _p(qd), _p(qh), float(th),
+            int(ORBdist), int(checkOri), _p(da), _p(dc), C.c_void_p(D.stream())), "plh_orb_search_by_projection_kf_batch_dev")
+        return D.get(da), D.get(dc), D.get(docc)
+
     def LineSearchByProjectionLastFrame(self, qs, occupied, th=8.0):
         """LSDmatcher.SearchByProjection(CurrentFrame = this frame, LastFrame, th).
         qs: per frame dict(valid, seg[nq,4], length, desc, hasobs)."""
@@ -613,6 +632,25 @@ class ORBmatcher:
         _check(L, L.plh_orb_search_by_bow_batch_dev(*[_p(x) for x in bufs], cap, P, self.TH_LOW, self.mfNNratio,
                                                     int(self.mbCheckOrientation), _p(dm), _p(dc), C.c_void_p(D.stream())),
                "plh_orb_search_by_bow_batch_dev")
+        return D.get(dm), D.get(dc)
+
+    def SearchByBoWKeyFramesBatch(self, kf1_sets, kf2_sets):
+        """SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (ORBmatcher.cc:574-709) for P pairs.  Each set =
+        dict(desc, kps[KP_DTYPE], node, valid).  Returns (matches12[P, cap], nmatches[P])."""
+        P = len(kf1_sets)
+        cap = max(1, max(len(s["desc"]) for s in list(kf1_sets) + list(kf2_sets)))
+        D, L = self.D, self.lib
+        bufs = []
+        for sets in (kf1_sets, kf2_sets):
+            d, n = _pad_sets([s["desc"] for s in sets], cap, 32, np.uint8)
+            k, _ = _pad_records([s["kps"] for s in sets], cap, KP_DTYPE)
+            nd, _ = _pad_sets([s["node"] for s in sets], cap, 0, np.int32)
+            v, _ = _pad_sets([s["valid"] for s in sets], cap, 0, np.uint8)
+            bufs += [D.put(d), D.put(k), D.put(nd), D.put(v), D.put(n)]
+        dm, dc = D.empty((P, cap), np.int32), D.empty((P,), np.int32)
+        _check(L, L.plh_orb_search_by_bow_kfkf_batch_dev(*[_p(x) for x in bufs], cap, P, self.TH_LOW, self.mfNNratio,
+                                                         int(self.mbCheckOrientation), _p(dm), _p(dc), C.c_void_p(D.stream())),
+               "plh_orb_search_by_bow_kfkf_batch_dev")
         return D.get(dm), D.get(dc)
 
     def SearchByBoW(self, kf, frame):

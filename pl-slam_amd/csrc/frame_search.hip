@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
                                                            const int* nqArr, int qcap, const uint8_t* qValid, const float* qXY,
                                                            const int32_t* qLevel, const float* qAux, const uint8_t* qDesc,
                                                            const uint8_t* qHasObs, float th, float nnratio, int mode,
-                                                           int checkOri, int32_t* assignedAll, int32_t* nmatchesOut) {
+                                                           int checkOri, int distTh, int32_t* assignedAll, int32_t* nmatchesOut) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   int* list = (int*)smem;
   int* dist = list + cap;
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
       if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = K[idx].octave; bestIdx = idx; }
       else if (variant == 0 && d < bestDist2) { bestLevel2 = K[idx].octave; bestDist2 = d; }
     }
-    if (bestDist <= 100) {
+    if (bestDist <= distTh) {
       if (variant == 0 && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
       FS_WAVE_SYNC();
       asg[bestIdx] = q;
@@ -617,7 +617,8 @@ static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, 
                                      const float* scale_factors, int nlevels, uint8_t* d_occupied, const int32_t* d_nq, int qcap,
                                      const uint8_t* d_q_valid, const float* d_q_xy, const int32_t* d_q_level, const float* d_q_aux,
                                      const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, float nnratio, int mode,
-                                     int check_ori, int32_t* d_assigned, int32_t* d_nmatches, void* stream, const char* who) {
+                                     int check_ori, int32_t* d_assigned, int32_t* d_nmatches, void* stream, const char* who,
+                                     int dist_th = 100 /* ORBmatcher::TH_HIGH */) {
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   ScaleTab sf;
   if (!d_kps_un || !d_desc || !d_n || !gp || !d_cs || !d_ci || !scale_tab(scale_factors, nlevels, &sf) || !d_occupied || !d_nq ||
@@ -629,7 +630,7 @@ static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, 
   const size_t lds = (size_t)cap * (3 * 4 + 1) + (size_t)qcap * (4 + 1) + 64;
   hipLaunchKernelGGL(k_search_proj_points, dim3(pairs), dim3(64), lds, (hipStream_t)stream, variant, d_kps_un, d_desc,
                      (const int*)d_n, cap, *gp, d_cs, d_ci, sf, d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy, d_q_level,
-                     d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, mode, check_ori, d_assigned, d_nmatches);
+                     d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, mode, check_ori, dist_th, d_assigned, d_nmatches);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
 }
@@ -657,6 +658,22 @@ plh_status plh_orb_search_by_projection_frame_batch_dev(const plh_keypoint* d_kp
   return launch_proj_points(1, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
                             d_occupied, d_nq, qcap, d_q_valid, d_q_uv, d_q_octave, d_q_angle, d_q_desc, d_q_hasobs, th, 0.f, mode,
                             check_ori, d_assigned, d_nmatches, stream, "plh_orb_search_by_projection_frame_batch_dev");
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+// (ORBmatcher.cc:1587-1716, relocalisation): the last-frame form with the caller's distance threshold; queries are the
+// KeyFrame's map points (valid = pMP && !isBad() && !sAlreadyFound.count(pMP) && depth inside the scale pyramid,
+// level = PredictScale, angle = pKF->mvKeysUn[i].angle), occupied = CurrentFrame.mvpMapPoints[i2] != NULL, hasobs = 1.
+plh_status plh_orb_search_by_projection_kf_batch_dev(const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n,
+                                                     int cap, int pairs, const plh_grid_params* gp, const int32_t* d_cell_start,
+                                                     const int32_t* d_cell_items, const float* scale_factors, int nlevels,
+                                                     uint8_t* d_occupied, const int32_t* d_nq, int qcap, const uint8_t* d_q_valid,
+                                                     const float* d_q_uv, const int32_t* d_q_level, const float* d_q_angle,
+                                                     const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int orb_dist,
+                                                     int check_ori, int32_t* d_assigned, int32_t* d_nmatches, void* stream) {
+  return launch_proj_points(1, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
+                            d_occupied, d_nq, qcap, d_q_valid, d_q_uv, d_q_level, d_q_angle, d_q_desc, d_q_hasobs, th, 0.f, 0,
+                            check_ori, d_assigned, d_nmatches, stream, "plh_orb_search_by_projection_kf_batch_dev", orb_dist);
 }
 
 static plh_status launch_proj_lines(int variant, const plh_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn,

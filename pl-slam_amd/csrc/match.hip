@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
                                                        const uint8_t* valid1, const int* n1Arr, const uint8_t* desc2,
                                                        const float* angle2, const int32_t* node2, const int* n2Arr, int cap,
                                                        int angStride, int thLow, float nnratio, int checkOri, int32_t* matches21,
-                                                       int32_t* nmatchesOut) {
+                                                       int32_t* nmatchesOut, const uint8_t* valid2, int kfkf) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   int* nd1 = (int*)smem;                 // node id per feature
   int* nd2 = nd1 + cap;
@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     for (int c = lo + lane; c < hi2; c += 64) {
       const int f = ord2[c];
       if (m2[f] >= 0) continue;
+      if (valid2 && !valid2[o + f]) continue;   // KeyFrame-KeyFrame form: pMP2 missing or bad (ORBmatcher.cc:628-632)
       const Desc256 df = load_desc(D2 + (long long)f * 32);
       const int d = hamming256(dk.w, df.w);
       if (d < b1) { b2 = b1; b1 = d; p1 = c; }
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     for (int s = 32; s >= 1; s >>= 1) second = min(second, __shfl_xor(second, s));
     if (kmin == 0x7fffffff) continue;
     const int bestDist1 = kmin >> 20, bestPos = (kmin & 0xfffff) + lo, bestDist2 = second;
-    if (bestDist1 <= thLow && (float)bestDist1 < nnratio * (float)bestDist2) {
+    if ((kfkf ? bestDist1 < thLow : bestDist1 <= thLow) && (float)bestDist1 < nnratio * (float)bestDist2) {
       const int bestF = ord2[bestPos];
       int bin = 255;
       if (checkOri) {
@@ -276,7 +277,14 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     removed = wave_sum(removed);
     nmatches -= removed;
   }
-  for (int f = lane; f < cap; f += 64) matches21[o + f] = f < n2 ? m2[f] : -1;
+  if (!kfkf) {
+    for (int f = lane; f < cap; f += 64) matches21[o + f] = f < n2 ? m2[f] : -1;
+  } else {   // vpMatches12: indexed by the first KeyFrame's features (the match relation is a partial bijection)
+    for (int f = lane; f < cap; f += 64) matches21[o + f] = -1;
+    PLH_WAVE_SYNC();
+    for (int f = lane; f < n2; f += 64)
+      if (m2[f] >= 0) matches21[o + m2[f]] = f;
+  }
   if (lane == 0) nmatchesOut[pair] = nmatches;
 }
 
@@ -407,7 +415,7 @@ plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const float* 
   }
   hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1, d_angle1,
                      d_node1, d_valid1, (const int*)d_n1, d_desc2, d_angle2, d_node2, (const int*)d_n2, cap, 1, th_low, nnratio,
-                     check_ori, d_matches21, d_nmatches);
+                     check_ori, d_matches21, d_nmatches, (const uint8_t*)nullptr, 0);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
 }
@@ -428,7 +436,27 @@ plh_status plh_orb_search_by_bow_kp_batch_dev(const uint8_t* d_desc1, const plh_
   hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
                      reinterpret_cast<const float*>(d_kps1) + 3, d_node1, d_valid1, (const int*)d_n1, d_desc2,
                      reinterpret_cast<const float*>(d_kps2) + 3, d_node2, (const int*)d_n2, cap, 7, th_low, nnratio, check_ori,
-                     d_matches21, d_nmatches);
+                     d_matches21, d_nmatches, (const uint8_t*)nullptr, 0);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (ORBmatcher.cc:574-709).
+plh_status plh_orb_search_by_bow_kfkf_batch_dev(const uint8_t* d_desc1, const plh_keypoint* d_kps1, const int32_t* d_node1,
+                                                const uint8_t* d_valid1, const int32_t* d_n1, const uint8_t* d_desc2,
+                                                const plh_keypoint* d_kps2, const int32_t* d_node2, const uint8_t* d_valid2,
+                                                const int32_t* d_n2, int cap, int pairs, int th_low, float nnratio, int check_ori,
+                                                int32_t* d_matches12, int32_t* d_nmatches, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_desc1 || !d_kps1 || !d_node1 || !d_valid1 || !d_n1 || !d_desc2 || !d_kps2 || !d_node2 || !d_valid2 || !d_n2 ||
+      !d_matches12 || !d_nmatches || cap <= 0 || cap > 6000 || pairs <= 0) {
+    set_error("plh_orb_search_by_bow_kfkf_batch_dev: invalid argument (cap must be in 1..6000)");
+    return PLH_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
+                     reinterpret_cast<const float*>(d_kps1) + 3, d_node1, d_valid1, (const int*)d_n1, d_desc2,
+                     reinterpret_cast<const float*>(d_kps2) + 3, d_node2, (const int*)d_n2, cap, 7, th_low, nnratio, check_ori,
+                     d_matches12, d_nmatches, d_valid2, 1);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
 }

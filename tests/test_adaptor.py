@@ -66,3 +66,13 @@ def test_library_exports_every_declared_symbol(plslam):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     assert b"gfx950" in ctypes.cast(ctypes.CDLL(lib_path).plh_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
+
+
+def test_every_c_entry_point_is_declared(plslam, emu_lib):
+    """Every extern "C" plh_* function of the sources (the emulation build exports them all) is declared in
+    include/plslam_hip.h -- an undeclared one would be hidden (-fvisibility=hidden) in the product library."""
+    out = subprocess.run(["nm", "-D", "--defined-only", emu_lib], capture_output=True, text=True, check=True).stdout
+    defined = {l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("plh_") and " T " in l}
+    declared = set(plslam.exported_symbols())
+    internal = {"plh_debug_grow_prof"}
+    assert not (defined - declared - internal), sorted(defined - declared - internal)

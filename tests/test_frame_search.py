@@ -196,6 +196,26 @@ def _run_all(P, O, S, lib, seeds, n, nl, distorted=False):
                                                           15.0, 0, 1, O._p(ra))
             assert cnt[b] == rc and (asg[b, :n2] == ra[:n2]).all() and (occ[b, :n2] == ro[:n2]).all(), "%s %d" % (variant, b)
             total += rc
+    # ---- relocalisation form: caller's distance threshold, every assignment occupies its keypoint
+    L.plo_orb_search_by_projection_kf.argtypes = [V, V, I, V, V, V, V, V, I, V, V, V, V, V, V, F, I, I, V]
+    L.plo_orb_search_by_projection_kf.restype = I
+    for orb_dist in (64, 100):
+        qs = []
+        for b, (f1, f2) in enumerate(zip(lasts, curs)):
+            q = _queries_points(P, S, 930 + b, f1, f2, "frame")
+            qs.append(dict(valid=q["valid"], uv=q["uv"], level=q["octave"], angle=q["angle"], desc=q["desc"],
+                           hasobs=np.ones(len(q["valid"]), np.uint8)))
+        occ0 = [(S.SplitMix64(99 + b).uniform(len(f2["kps"])) < 0.05).astype(np.uint8) for b, f2 in enumerate(curs)]
+        asg, cnt, occ = fs.SearchByProjectionKeyFrame(qs, occ0, th=10.0, ORBdist=orb_dist, checkOri=True)
+        for b, (f1, f2) in enumerate(zip(lasts, curs)):
+            (rcs, rci), _ = _oracle_grids(O, P, f2, gp)
+            n2, q = len(f2["kps"]), qs[b]
+            ro, ra = occ0[b].copy(), np.zeros(max(n2, 1), np.int32)
+            rc = L.plo_orb_search_by_projection_kf(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(rcs), O._p(rci), O._p(SCALE),
+                                                   O._p(ro), len(q["valid"]), O._p(q["valid"]), O._p(q["uv"]), O._p(q["level"]),
+                                                   O._p(q["angle"]), O._p(q["desc"]), O._p(q["hasobs"]), 10.0, orb_dist, 1, O._p(ra))
+            assert cnt[b] == rc and (asg[b, :n2] == ra[:n2]).all() and (occ[b, :n2] == ro[:n2]).all(), "reloc %d %d" % (orb_dist, b)
+            total += rc
     # ---- LSD SearchByProjection, both forms
     for variant in ("ml", "frame"):
         qs = [_queries_lines(P, S, 950 + b, f1, variant) for b, f1 in enumerate(lasts)]

@@ -177,3 +177,44 @@ def test_gpu_match_golden(plslam, synth):
         fr = dict(desc=b, angle=g["ang_b"], node=g["node_b"])
         cb, mb = plslam.ORBmatcher(0.7, True).SearchByBoW(kf, fr)
         assert cb == int(g["bow_n"]) and (mb == g["bow_m"]).all()
+
+
+# ------------------------------------------------------------------ SearchByBoW(KeyFrame, KeyFrame)
+def _kfkf_case(plslam, synth, seed, n, nodes):
+    kf, fr = _bow_sets(synth, seed, n, nodes, valid_p=0.85)
+    rng = synth.SplitMix64(seed + 31)
+    k1 = np.zeros(n, plslam.KP_DTYPE); k1["angle"] = kf["angle"]
+    k2 = np.zeros(n, plslam.KP_DTYPE); k2["angle"] = fr["angle"]
+    a = dict(desc=kf["desc"], kps=k1, node=kf["node"], valid=kf["valid"], angle=kf["angle"])
+    b = dict(desc=fr["desc"], kps=k2, node=fr["node"], valid=(rng.uniform(n) < 0.85).astype(np.uint8), angle=fr["angle"])
+    return a, b
+
+
+def _check_kfkf(plslam, oracle, synth, lib, cases):
+    import ctypes as C
+    L = oracle.lib()
+    L.plo_orb_search_by_bow_kfkf.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int,
+                                                                                                C.c_void_p]
+    L.plo_orb_search_by_bow_kfkf.restype = C.c_int
+    om = plslam.ORBmatcher(0.8, True, lib=lib)
+    sets = [_kfkf_case(plslam, synth, *c) for c in cases]
+    got, cnt = om.SearchByBoWKeyFramesBatch([s[0] for s in sets], [s[1] for s in sets])
+    tot = 0
+    for p, (a, b) in enumerate(sets):
+        n1, n2 = len(a["desc"]), len(b["desc"])
+        ref = np.zeros(max(n1, 1), np.int32)
+        p_ = oracle._p
+        rc = L.plo_orb_search_by_bow_kfkf(p_(a["desc"]), p_(a["angle"]), p_(a["node"]), p_(a["valid"]), n1, p_(b["desc"]),
+                                          p_(b["angle"]), p_(b["node"]), p_(b["valid"]), n2, 50, 0.8, 1, p_(ref))
+        assert cnt[p] == rc and (got[p, :n1] == ref[:n1]).all(), p
+        tot += rc
+    return tot
+
+
+def test_emu_search_by_bow_keyframes(plslam, oracle, synth, emu_lib):
+    assert _check_kfkf(plslam, oracle, synth, emu_lib, [(400, 300, 20), (401, 120, 5), (402, 64, 64)]) > 100
+
+
+@pytest.mark.gpu
+def test_gpu_search_by_bow_keyframes(plslam, oracle, synth):
+    assert _check_kfkf(plslam, oracle, synth, None, [(410, 2000, 100), (411, 2000, 1000), (412, 1500, 10), (413, 1, 1)]) > 1000
