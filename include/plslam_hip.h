@@ -207,6 +207,17 @@ PLH_API plh_status plh_orb_search_by_bow_kfkf_batch_dev(const uint8_t* d_desc1, 
                                                         int cap, int pairs, int th_low, float nnratio, int check_ori,
                                                         int32_t* d_matches12, int32_t* d_nmatches, void* stream);
 
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo = false) (ORBmatcher.cc:720-912 +
+ * CheckDistEpipolarLine :154-173), monocular.  has_mp1 / has_mp2: the feature already carries a MapPoint
+ * (skipped).  F12: row-major 3x3 float (HOST); (ex, ey): epipole of KF1's centre in KF2 (:731-735, from the caller's poses);
+ * scale_factors2 / level_sigma2_2: HOST arrays pKF2->mvScaleFactors / mvLevelSigma2.  d_matches12[pairs][cap] = feature of
+ * KF2 paired with feature idx1 of KF1, or -1 (vMatchedPairs = the (i, matches12[i]) pairs in index order). */
+PLH_API plh_status plh_orb_search_for_triangulation_batch_dev(
+    const plh_keypoint* d_kps1, const uint8_t* d_desc1, const int32_t* d_node1, const uint8_t* d_has_mp1, const int32_t* d_n1,
+    const plh_keypoint* d_kps2, const uint8_t* d_desc2, const int32_t* d_node2, const uint8_t* d_has_mp2, const int32_t* d_n2,
+    int cap, int pairs, const float F12[9], float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+    int nlevels, int th_low, int check_ori, int32_t* d_matches12, int32_t* d_nmatches, void* stream);
+
 /* DBoW2 TemplatedVocabulary::transform(feature, word, weight, &nid, levelsup) for every descriptor of a batch
  * (Frame::ComputeBoW, Frame.cc:906-913 -> Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1255).
  * The tree is given as flat arrays over node ids (root = 0): 32-byte node descriptors, contiguous children

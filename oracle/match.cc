@@ -283,3 +283,82 @@ extern "C" int plo_orb_search_by_bow_kfkf(const uint8_t* desc1, const float* ang
   }
   return nmatches;
 }
+
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo = false), monocular, reference
+// src/ORBmatcher.cc:720-912 (+ CheckDistEpipolarLine :154-173).  has_mp1 / has_mp2 = the feature already carries a MapPoint
+// (those are skipped); F12 row-major 3x3 float; (ex, ey) = epipole of KF1's centre in KF2 (:731-735, computed by the caller
+// from the poses); scale_factors2 / level_sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2.  Note that this fork never sets
+// vbMatched2 (the upstream `vbMatched2[bestIdx2]=true` is missing at :856-859), so a feature of KF2 can be paired with
+// several features of KF1 -- kept.  matches12[idx1] = idx2 or -1 (vMatchedPairs is its list of (i, matches12[i]) pairs).
+extern "C" int plo_orb_search_for_triangulation(const plo_keypoint* kps1, const uint8_t* desc1, const int32_t* node1,
+                                                const uint8_t* has_mp1, int n1, const plo_keypoint* kps2, const uint8_t* desc2,
+                                                const int32_t* node2, const uint8_t* has_mp2, int n2, const float F12[9], float ex,
+                                                float ey, const float* scale_factors2, const float* level_sigma2_2, int th_low,
+                                                int check_ori, int32_t* matches12) {
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::map<int, std::vector<unsigned>> fv1, fv2;
+  for (int i = 0; i < n1; i++) if (node1[i] >= 0) fv1[node1[i]].push_back((unsigned)i);
+  for (int j = 0; j < n2; j++) if (node2[j] >= 0) fv2[node2[j]].push_back((unsigned)j);
+  int nmatches = 0;
+  std::vector<bool> vbMatched2(std::max(n2, 1), false);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  auto f1it = fv1.begin(), f1end = fv1.end();
+  auto f2it = fv2.begin(), f2end = fv2.end();
+  while (f1it != f1end && f2it != f2end) {
+    if (f1it->first == f2it->first) {
+      for (size_t i1 = 0; i1 < f1it->second.size(); i1++) {
+        const size_t idx1 = f1it->second[i1];
+        if (has_mp1[idx1]) continue;
+        const plo_keypoint& kp1 = kps1[idx1];
+        const uint8_t* d1 = desc1 + idx1 * 32;
+        int bestDist = th_low, bestIdx2 = -1;
+        for (size_t i2 = 0; i2 < f2it->second.size(); i2++) {
+          const size_t idx2 = f2it->second[i2];
+          if (vbMatched2[idx2] || has_mp2[idx2]) continue;
+          const int dist = plo_descriptor_distance(d1, desc2 + idx2 * 32);
+          if (dist > th_low || dist > bestDist) continue;
+          const plo_keypoint& kp2 = kps2[idx2];
+          {   // !bStereo1 && !bStereo2
+            const float distex = ex - kp2.x, distey = ey - kp2.y;
+            if (distex * distex + distey * distey < 100 * scale_factors2[kp2.octave]) continue;
+          }
+          // CheckDistEpipolarLine(kp1, kp2, F12, pKF2)
+          const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+          const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+          const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+          const float num = a * kp2.x + b * kp2.y + c;
+          const float den = a * a + b * b;
+          if (den == 0) continue;
+          const float dsqr = num * num / den;
+          if (dsqr < 3.84 * level_sigma2_2[kp2.octave]) { bestIdx2 = (int)idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+          matches12[idx1] = bestIdx2;
+          nmatches++;
+          if (check_ori) {
+            float rot = kp1.angle - kps2[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back((int)idx1);
+          }
+        }
+      }
+      ++f1it; ++f2it;
+    } else if (f1it->first < f2it->first) {
+      f1it = fv1.lower_bound(f2it->first);
+    } else {
+      f2it = fv2.lower_bound(f1it->first);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}

@@ -142,6 +142,11 @@ int  plo_distinctive_descriptor(const uint8_t* desc, int n);
 int  plo_orb_search_by_bow_kfkf(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
                                 const uint8_t* desc2, const float* angle2, const int32_t* node2, const uint8_t* valid2, int n2,
                                 int th_low, float nnratio, int check_ori, int32_t* matches12);
+int  plo_orb_search_for_triangulation(const plo_keypoint* kps1, const uint8_t* desc1, const int32_t* node1,
+                                      const uint8_t* has_mp1, int n1, const plo_keypoint* kps2, const uint8_t* desc2,
+                                      const int32_t* node2, const uint8_t* has_mp2, int n2, const float F12[9], float ex,
+                                      float ey, const float* scale_factors2, const float* level_sigma2_2, int th_low,
+                                      int check_ori, int32_t* matches12);   /* src/ORBmatcher.cc:720-912, monocular */
 int  plo_orb_search_by_projection_kf(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6], const int32_t* cs,
                                      const int32_t* ci, const float* scale_factors, uint8_t* occupied, int nq,
                                      const uint8_t* q_valid, const float* q_uv, const int32_t* q_level, const float* q_angle,

@@ -75,6 +75,7 @@ _SIGS = {
     "plh_line_extract": ([_V, _V, _I, _I, _Z, _V, _V, _V, _V, _I, _V], _I),
     "plh_line_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
+    "plh_orb_search_for_triangulation_batch_dev": ([_V] * 10 + [_I, _I, _V, _F, _F, _V, _V, _I, _I, _I, _V, _V, _V], _I),
     "plh_orb_search_by_bow_kfkf_batch_dev": ([_V] * 10 + [_I, _I, _I, _F, _I, _V, _V, _V], _I),
     "plh_orb_search_by_projection_kf_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 6 +
                                                   [_F, _I, _I, _V, _V, _V], _I),
@@ -651,6 +652,30 @@ class ORBmatcher:
         _check(L, L.plh_orb_search_by_bow_kfkf_batch_dev(*[_p(x) for x in bufs], cap, P, self.TH_LOW, self.mfNNratio,
                                                          int(self.mbCheckOrientation), _p(dm), _p(dc), C.c_void_p(D.stream())),
                "plh_orb_search_by_bow_kfkf_batch_dev")
+        return D.get(dm), D.get(dc)
+
+    def SearchForTriangulationBatch(self, kf1_sets, kf2_sets, F12, epipole, scale_factors2, level_sigma2_2):
+        """SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) (ORBmatcher.cc:720-912) for P pairs sharing one
+        geometry.  Each set = dict(desc, kps[KP_DTYPE], node, has_mp).  Returns (matches12[P, cap], nmatches[P])."""
+        P = len(kf1_sets)
+        cap = max(1, max(len(s["desc"]) for s in list(kf1_sets) + list(kf2_sets)))
+        D, L = self.D, self.lib
+        bufs = []
+        for sets in (kf1_sets, kf2_sets):
+            d, n = _pad_sets([s["desc"] for s in sets], cap, 32, np.uint8)
+            k, _ = _pad_records([s["kps"] for s in sets], cap, KP_DTYPE)
+            nd, _ = _pad_sets([s["node"] for s in sets], cap, 0, np.int32)
+            v, _ = _pad_sets([s["has_mp"] for s in sets], cap, 0, np.uint8)
+            bufs += [D.put(k), D.put(d), D.put(nd), D.put(v), D.put(n)]
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf = np.ascontiguousarray(scale_factors2, np.float32)
+        s2 = np.ascontiguousarray(level_sigma2_2, np.float32)
+        dm, dc = D.empty((P, cap), np.int32), D.empty((P,), np.int32)
+        _check(L, L.plh_orb_search_for_triangulation_batch_dev(*[_p(x) for x in bufs], cap, P, _p(F), float(epipole[0]),
+                                                               float(epipole[1]), _p(sf), _p(s2), len(sf), self.TH_LOW,
+                                                               int(self.mbCheckOrientation), _p(dm), _p(dc),
+                                                               C.c_void_p(D.stream())),
+               "plh_orb_search_for_triangulation_batch_dev")
         return D.get(dm), D.get(dc)
 
     def SearchByBoW(self, kf, frame):

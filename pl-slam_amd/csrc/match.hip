@@ -288,6 +288,144 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
   if (lane == 0) nmatchesOut[pair] = nmatches;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation (monocular), reference src/ORBmatcher.cc:720-912 + CheckDistEpipolarLine :154-173.
+// Phase A as in k_search_by_bow.  Phase B: this fork never marks KF2 features as matched, so the KF1 features are
+// independent: the four waves take them round-robin, lanes scan the node's candidates; the reference's scan
+// ("dist <= bestDist" before the geometric tests) ends on the eligible candidate of least distance, LAST one among ties.
+// ---------------------------------------------------------------------------------------------
+struct TriGeom {
+  float F[9];
+  float ex, ey;
+  float sf[16], sig2[16];
+};
+
+__global__ void __launch_bounds__(256) k_search_triangulation(const plh_keypoint* kps1, const uint8_t* desc1, const int32_t* node1,
+                                                              const uint8_t* hasMp1, const int* n1Arr, const plh_keypoint* kps2,
+                                                              const uint8_t* desc2, const int32_t* node2, const uint8_t* hasMp2,
+                                                              const int* n2Arr, int cap, TriGeom g, int thLow, int checkOri,
+                                                              int32_t* matches12, int32_t* nmatchesOut) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  int* nd1 = (int*)smem;
+  int* nd2 = nd1 + cap;
+  int* snode2 = nd2 + cap;
+  int* m12 = snode2 + cap;
+  unsigned short* ord1 = (unsigned short*)(m12 + cap);
+  unsigned short* ord2 = ord1 + cap;
+  unsigned char* bin1 = (unsigned char*)(ord2 + cap);
+  __shared__ int s_hist[32];
+  __shared__ int s_cnt;
+
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n1 = min(n1Arr[pair], cap), n2 = min(n2Arr[pair], cap);
+  const long long o = (long long)pair * cap;
+  for (int i = tid; i < cap; i += 256) {
+    nd1[i] = i < n1 ? node1[o + i] : -1;
+    nd2[i] = i < n2 ? node2[o + i] : -1;
+    m12[i] = -1;
+    bin1[i] = 255;
+  }
+  if (tid < 32) s_hist[tid] = 0;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int i = tid; i < n1; i += 256) {
+    const int k = nd1[i] < 0 ? INT_MAX : nd1[i];
+    int r = 0;
+    for (int j = 0; j < n1; j++) {
+      const int kj = nd1[j] < 0 ? INT_MAX : nd1[j];
+      r += (kj < k) || (kj == k && j < i);
+    }
+    ord1[r] = (unsigned short)i;
+  }
+  for (int i = tid; i < n2; i += 256) {
+    const int k = nd2[i] < 0 ? INT_MAX : nd2[i];
+    int r = 0;
+    for (int j = 0; j < n2; j++) {
+      const int kj = nd2[j] < 0 ? INT_MAX : nd2[j];
+      r += (kj < k) || (kj == k && j < i);
+    }
+    ord2[r] = (unsigned short)i;
+    snode2[r] = k;
+  }
+  __syncthreads();
+
+  const plh_keypoint *K1 = kps1 + o, *K2 = kps2 + o;
+  const uint8_t *D1 = desc1 + o * 32, *D2 = desc2 + o * 32;
+  int myMatches = 0;
+  for (int r1 = wv; r1 < n1; r1 += 4) {
+    const int i = ord1[r1];
+    const int nd = nd1[i];
+    if (nd < 0) break;
+    if (hasMp1[o + i]) continue;
+    int lo = 0, hi = n2;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (snode2[mid] < nd) lo = mid + 1; else hi = mid; }
+    int hi2 = lo, top = n2;
+    while (hi2 < top) { const int mid = (hi2 + top) >> 1; if (snode2[mid] <= nd) hi2 = mid + 1; else top = mid; }
+    if (lo >= hi2) continue;
+    const plh_keypoint kp1 = K1[i];
+    const Desc256 dk = load_desc(D1 + (long long)i * 32);
+    const float a = kp1.x * g.F[0] + kp1.y * g.F[3] + g.F[6];
+    const float b = kp1.x * g.F[1] + kp1.y * g.F[4] + g.F[7];
+    const float c = kp1.x * g.F[2] + kp1.y * g.F[5] + g.F[8];
+    const float den = a * a + b * b;
+    int key = 0x7fffffff;
+    for (int p = lo + lane; p < hi2; p += 64) {
+      const int f = ord2[p];
+      if (hasMp2[o + f]) continue;
+      const Desc256 df = load_desc(D2 + (long long)f * 32);
+      const int d = hamming256(dk.w, df.w);
+      if (d > thLow) continue;
+      const plh_keypoint kp2 = K2[f];
+      const float distex = g.ex - kp2.x, distey = g.ey - kp2.y;
+      if (distex * distex + distey * distey < 100 * g.sf[kp2.octave & 15]) continue;
+      const float num = a * kp2.x + b * kp2.y + c;
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (!((double)dsqr < 3.84 * (double)g.sig2[kp2.octave & 15])) continue;
+      key = min(key, (d << 16) | (0xffff - (p - lo)));
+    }
+    for (int s = 32; s >= 1; s >>= 1) key = min(key, __shfl_xor(key, s));
+    if (key == 0x7fffffff) continue;
+    const int bestIdx2 = ord2[lo + (0xffff - (key & 0xffff))];
+    if (lane == 0) {
+      m12[i] = bestIdx2;
+      myMatches++;
+      if (checkOri) {
+        float rot = kp1.angle - K2[bestIdx2].angle;
+        if (rot < 0.0f) rot += 360.0f;
+        int bin = (int)roundf(rot * (1.0f / 30));
+        if (bin == 30) bin = 0;
+        bin1[i] = (unsigned char)bin;
+        atomicAdd(&s_hist[bin], 1);
+      }
+    }
+  }
+  if (lane == 0 && myMatches) atomicAdd(&s_cnt, myMatches);
+  __syncthreads();
+  if (checkOri) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int b = 0; b < 30; b++) {
+      const int sz = s_hist[b];
+      if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = b; }
+      else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = b; }
+      else if (sz > max3) { max3 = sz; ind3 = b; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    int removed = 0;
+    for (int i = tid; i < n1; i += 256) {
+      const int b = bin1[i];
+      if (b != 255 && b != ind1 && b != ind2 && b != ind3) { m12[i] = -1; removed++; }
+    }
+    if (removed) atomicAdd(&s_cnt, -removed);
+  }
+  __syncthreads();
+  for (int i = tid; i < cap; i += 256) matches12[o + i] = i < n1 ? m12[i] : -1;
+  if (tid == 0) nmatchesOut[pair] = s_cnt;
+}
+
+static size_t tri_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
+
 static size_t bow_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
 
 }  // namespace plh
@@ -457,6 +595,32 @@ plh_status plh_orb_search_by_bow_kfkf_batch_dev(const uint8_t* d_desc1, const pl
                      reinterpret_cast<const float*>(d_kps1) + 3, d_node1, d_valid1, (const int*)d_n1, d_desc2,
                      reinterpret_cast<const float*>(d_kps2) + 3, d_node2, (const int*)d_n2, cap, 7, th_low, nnratio, check_ori,
                      d_matches12, d_nmatches, d_valid2, 1);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) (ORBmatcher.cc:720-912), monocular.
+plh_status plh_orb_search_for_triangulation_batch_dev(const plh_keypoint* d_kps1, const uint8_t* d_desc1, const int32_t* d_node1,
+                                                      const uint8_t* d_has_mp1, const int32_t* d_n1, const plh_keypoint* d_kps2,
+                                                      const uint8_t* d_desc2, const int32_t* d_node2, const uint8_t* d_has_mp2,
+                                                      const int32_t* d_n2, int cap, int pairs, const float F12[9], float ex, float ey,
+                                                      const float* scale_factors2, const float* level_sigma2_2, int nlevels,
+                                                      int th_low, int check_ori, int32_t* d_matches12, int32_t* d_nmatches,
+                                                      void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_kps1 || !d_desc1 || !d_node1 || !d_has_mp1 || !d_n1 || !d_kps2 || !d_desc2 || !d_node2 || !d_has_mp2 || !d_n2 || !F12 ||
+      !scale_factors2 || !level_sigma2_2 || nlevels <= 0 || nlevels > 16 || !d_matches12 || !d_nmatches || cap <= 0 || cap > 6000 ||
+      pairs <= 0) {
+    set_error("plh_orb_search_for_triangulation_batch_dev: invalid argument (cap in 1..6000, 1..16 levels)");
+    return PLH_ERR_INVALID;
+  }
+  TriGeom g;
+  for (int i = 0; i < 9; i++) g.F[i] = F12[i];
+  g.ex = ex; g.ey = ey;
+  for (int i = 0; i < 16; i++) { g.sf[i] = i < nlevels ? scale_factors2[i] : 0.f; g.sig2[i] = i < nlevels ? level_sigma2_2[i] : 0.f; }
+  hipLaunchKernelGGL(k_search_triangulation, dim3(pairs), dim3(256), tri_lds_bytes(cap), (hipStream_t)stream, d_kps1, d_desc1, d_node1,
+                     d_has_mp1, (const int*)d_n1, d_kps2, d_desc2, d_node2, d_has_mp2, (const int*)d_n2, cap, g, th_low, check_ori,
+                     d_matches12, d_nmatches);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
 }

@@ -218,3 +218,57 @@ def test_emu_search_by_bow_keyframes(plslam, oracle, synth, emu_lib):
 @pytest.mark.gpu
 def test_gpu_search_by_bow_keyframes(plslam, oracle, synth):
     assert _check_kfkf(plslam, oracle, synth, None, [(410, 2000, 100), (411, 2000, 1000), (412, 1500, 10), (413, 1, 1)]) > 1000
+
+
+# ------------------------------------------------------------------ SearchForTriangulation
+def _tri_case(plslam, synth, seed, n, nodes):
+    """Two keyframes of a pure x-translation stereo pair: F12 = [t]_x up to scale, epipolar lines are horizontal."""
+    kf, fr = _bow_sets(synth, seed, n, nodes)
+    rng = synth.SplitMix64(seed + 17)
+    perm = synth.make_descriptor_sets(seed, n, 0.06)[2]
+    k1 = np.zeros(n, plslam.KP_DTYPE)
+    k1["x"], k1["y"] = rng.uniform(n, 20, 620).astype(np.float32), rng.uniform(n, 20, 460).astype(np.float32)
+    k1["octave"] = rng.randint(n, 0, 8).astype(np.int32)
+    k1["angle"] = kf["angle"]
+    k2 = k1[perm].copy()
+    k2["x"] = (k2["x"] - rng.uniform(n, 2, 40)).astype(np.float32)          # disparity along the epipolar line
+    k2["y"] = (k2["y"] + rng.uniform(n, -3.0, 3.0)).astype(np.float32)       # some violate the 3.84 sigma^2 gate
+    k2["angle"] = fr["angle"]
+    a = dict(desc=kf["desc"], kps=k1, node=kf["node"], has_mp=(rng.uniform(n) < 0.3).astype(np.uint8))
+    b = dict(desc=fr["desc"], kps=k2, node=fr["node"], has_mp=(rng.uniform(n) < 0.3).astype(np.uint8))
+    return a, b
+
+
+def _check_tri(plslam, oracle, synth, lib, cases):
+    import ctypes as C
+    L = oracle.lib()
+    V, I, F = C.c_void_p, C.c_int, C.c_float
+    L.plo_orb_search_for_triangulation.argtypes = [V, V, V, V, I, V, V, V, V, I, V, F, F, V, V, I, I, V]
+    L.plo_orb_search_for_triangulation.restype = I
+    F12 = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)     # l = (0, -1, y1): distance^2 = (y2 - y1)^2
+    epi = (-5000.0, 240.0)
+    sf = np.cumprod(np.r_[np.float32(1.0), np.full(7, np.float32(1.2))]).astype(np.float32)
+    sig2 = (sf * sf).astype(np.float32)
+    om = plslam.ORBmatcher(0.6, True, lib=lib)
+    sets = [_tri_case(plslam, synth, *c) for c in cases]
+    got, cnt = om.SearchForTriangulationBatch([s[0] for s in sets], [s[1] for s in sets], F12, epi, sf, sig2)
+    tot = 0
+    p_ = oracle._p
+    for p, (a, b) in enumerate(sets):
+        n1, n2 = len(a["desc"]), len(b["desc"])
+        ref = np.zeros(max(n1, 1), np.int32)
+        rc = L.plo_orb_search_for_triangulation(p_(a["kps"]), p_(a["desc"]), p_(a["node"]), p_(a["has_mp"]), n1, p_(b["kps"]),
+                                                p_(b["desc"]), p_(b["node"]), p_(b["has_mp"]), n2, p_(F12), epi[0], epi[1], p_(sf),
+                                                p_(sig2), 50, 1, p_(ref))
+        assert cnt[p] == rc and (got[p, :n1] == ref[:n1]).all(), p
+        tot += rc
+    return tot
+
+
+def test_emu_search_for_triangulation(plslam, oracle, synth, emu_lib):
+    assert _check_tri(plslam, oracle, synth, emu_lib, [(500, 300, 20), (501, 120, 5), (502, 64, 64)]) > 50
+
+
+@pytest.mark.gpu
+def test_gpu_search_for_triangulation(plslam, oracle, synth):
+    assert _check_tri(plslam, oracle, synth, None, [(510, 2000, 100), (511, 2000, 1000), (512, 1500, 10), (513, 1, 1)]) > 500
