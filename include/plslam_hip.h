@@ -300,6 +300,27 @@ PLH_API plh_status plh_orb_search_by_projection_kf_batch_dev(
     const float* d_q_angle, const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int orb_dist, int check_ori,
     int32_t* d_assigned, int32_t* d_nmatches, void* stream);
 
+/* The search inside ORBmatcher::Fuse(pKF, vpMapPoints, th) / Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:914-1061,
+ * 1063-1197): per query (valid = every pre-check of the loop passed; uv = projection; level = PredictScale)
+ * the best keypoint of level l-1..l in the window th*scale[l] whose reprojection error passes e2*invLevelSigma2 <= 5.99 and
+ * whose Hamming distance is <= th_low (TH_LOW).  d_best_idx[pairs][qcap] = keypoint index or -1.  The replace / add logic on
+ * the map stays with the caller.  scale_factors / inv_level_sigma2: HOST arrays of the KeyFrame. */
+PLH_API plh_status plh_orb_fuse_search_batch_dev(const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n, int cap,
+                                                 int pairs, const plh_grid_params* gp, const int32_t* d_cell_start,
+                                                 const int32_t* d_cell_items, const float* scale_factors,
+                                                 const float* inv_level_sigma2, int nlevels, const int32_t* d_nq, int qcap,
+                                                 const uint8_t* d_q_valid, const float* d_q_uv, const int32_t* d_q_level,
+                                                 const uint8_t* d_q_desc, float th, int th_low, int32_t* d_best_idx,
+                                                 int32_t* d_nfound, void* stream);
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:329-453, loop closing).
+ * occupied = vpMatched[idx] != NULL (in/out); d_assigned[pairs][cap] = query whose MapPoint goes to vpMatched[idx], or -1. */
+PLH_API plh_status plh_orb_search_by_projection_sim3_batch_dev(
+    const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n, int cap, int pairs, const plh_grid_params* gp,
+    const int32_t* d_cell_start, const int32_t* d_cell_items, const float* scale_factors, int nlevels, uint8_t* d_occupied,
+    const int32_t* d_nq, int qcap, const uint8_t* d_q_valid, const float* d_q_uv, const int32_t* d_q_level,
+    const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int th_low, int32_t* d_assigned, int32_t* d_nmatches,
+    void* stream);
+
 /* LSDmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th) (LSDmatcher.cpp:72-176).
  * Query i = Last line i: valid = MapLine && !mvbLineOutlier[i] && Cur.isInFrustum(pML, 0.5);
  * seg = (mTrackProjX1, Y1, X2, Y2); length = Last.mvKeylinesUn[i].lineLength.  d_linefn = mvKeyLineFunctions. */

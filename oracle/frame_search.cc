@@ -495,3 +495,73 @@ extern "C" int plo_distinctive_descriptor(const uint8_t* desc, int n) {
   }
   return BestIdx;
 }
+
+// The search inside ORBmatcher::Fuse (reference src/ORBmatcher.cc:914-1061; the Sim3 overload :1063-1197 has the same
+// core): KeyFrame::GetFeaturesInArea(u, v, th*scale[l]) (src/KeyFrame.cc:606-645: no level filter), then kpLevel in
+// [l-1, l], the monocular chi-square gate e2 * mvInvLevelSigma2[kpLevel] > 5.99, best Hamming <= TH_LOW.
+// best_idx[q] = keypoint or -1; returns the number of queries with a result.
+extern "C" int plo_orb_fuse_search(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6], const int32_t* cs,
+                                   const int32_t* ci, const float* scale_factors, const float* inv_level_sigma2, int nq,
+                                   const uint8_t* q_valid, const float* q_uv, const int32_t* q_level, const uint8_t* q_desc, float th,
+                                   int th_low, int32_t* best_idx) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  int nfound = 0;
+  std::vector<int> vIndices;
+  (void)n;
+  for (int i = 0; i < nq; i++) {
+    best_idx[i] = -1;
+    if (!q_valid[i]) continue;
+    const float u = q_uv[i * 2], v = q_uv[i * 2 + 1];
+    const int nPredictedLevel = q_level[i];
+    const float radius = th * scale_factors[nPredictedLevel];
+    features_in_area(kps_un, g, cs, ci, u, v, radius, -1, -1, vIndices);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = q_desc + (size_t)i * 32;
+    int bestDist = 256, bestIdx = -1;
+    for (int idx : vIndices) {
+      const plo_keypoint& kp = kps_un[idx];
+      const int kpLevel = kp.octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const float ex = u - kp.x, ey = v - kp.y;
+      const float e2 = ex * ex + ey * ey;
+      if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+      const int dist = plo_descriptor_distance(dMP, desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= th_low) { best_idx[i] = bestIdx; nfound++; }
+  }
+  return nfound;
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th), reference src/ORBmatcher.cc:329-453
+// (loop closing).  occupied[idx] = vpMatched[idx] != NULL (in/out); assigned[idx] = query stored there, or -1.
+extern "C" int plo_orb_search_by_projection_sim3(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                                                 const int32_t* cs, const int32_t* ci, const float* scale_factors,
+                                                 uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_uv,
+                                                 const int32_t* q_level, const uint8_t* q_desc, float th, int th_low,
+                                                 int32_t* assigned) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  int nmatches = 0;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
+  std::vector<int> vIndices;
+  for (int iMP = 0; iMP < nq; iMP++) {
+    if (!q_valid[iMP]) continue;
+    const int nPredictedLevel = q_level[iMP];
+    const float radius = th * scale_factors[nPredictedLevel];
+    features_in_area(kps_un, g, cs, ci, q_uv[iMP * 2], q_uv[iMP * 2 + 1], radius, -1, -1, vIndices);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = q_desc + (size_t)iMP * 32;
+    int bestDist = 256, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (occupied[idx]) continue;
+      const int kpLevel = kps_un[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int dist = plo_descriptor_distance(dMP, desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= th_low) { assigned[bestIdx] = iMP; occupied[bestIdx] = 1; nmatches++; }
+  }
+  return nmatches;
+}

@@ -79,6 +79,9 @@ _SIGS = {
     "plh_orb_search_by_bow_kfkf_batch_dev": ([_V] * 10 + [_I, _I, _I, _F, _I, _V, _V, _V], _I),
     "plh_orb_search_by_projection_kf_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 6 +
                                                   [_F, _I, _I, _V, _V, _V], _I),
+    "plh_orb_fuse_search_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _V, _I, _V, _I, _V, _V, _V, _V, _F, _I, _V, _V, _V], _I),
+    "plh_orb_search_by_projection_sim3_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 5 +
+                                                    [_F, _I, _V, _V, _V], _I),
     "plh_undistort_keypoints_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
     "plh_distinctive_descriptor_batch_dev": ([_V, _V, _I, _V, _V], _I),
     "plh_frame_assign_grid_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
@@ -473,6 +476,35 @@ class FrameSearch:
             _p(self.d_kps), _p(self.d_desc), _p(self.d_n), self.cap, self.P, C.byref(self.gp), _p(self.d_cs), _p(self.d_ci),
             _p(self.sf), len(self.sf), _p(docc), _p(dnq), qcap, _p(qv), _p(quv), _p(ql), _p(qa), _p(qd), _p(qh), float(th),
             int(ORBdist), int(checkOri), _p(da), _p(dc), C.c_void_p(D.stream())), "plh_orb_search_by_projection_kf_batch_dev")
+        return D.get(da), D.get(dc), D.get(docc)
+
+    def FuseSearch(self, qs, inv_level_sigma2, th=3.0, TH_LOW=50):
+        """The search inside ORBmatcher::Fuse(pKF = this frame, vpMapPoints, th).  qs: per frame dict(valid, uv, level, desc).
+        Returns (best_idx[P, qcap], nfound[P])."""
+        D, L = self.D, self.lib
+        qcap, dnq, (qv, quv, ql, qd) = self._queries(qs, [("valid", 0, np.uint8), ("uv", 2, np.float32), ("level", 0, np.int32),
+                                                         ("desc", 32, np.uint8)])
+        is2 = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        db, dc = D.empty((self.P, qcap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_orb_fuse_search_batch_dev(
+            _p(self.d_kps), _p(self.d_desc), _p(self.d_n), self.cap, self.P, C.byref(self.gp), _p(self.d_cs), _p(self.d_ci),
+            _p(self.sf), _p(is2), len(self.sf), _p(dnq), qcap, _p(qv), _p(quv), _p(ql), _p(qd), float(th), int(TH_LOW), _p(db),
+            _p(dc), C.c_void_p(D.stream())), "plh_orb_fuse_search_batch_dev")
+        return D.get(db), D.get(dc)
+
+    def SearchByProjectionSim3(self, qs, occupied, th=10, TH_LOW=50):
+        """ORBmatcher.SearchByProjection(pKF = this frame, Scw, vpPoints, vpMatched, th) (loop closing).
+        qs: per frame dict(valid, uv, level, desc, hasobs)."""
+        D, L = self.D, self.lib
+        qcap, dnq, (qv, quv, ql, qd, qh) = self._queries(qs, [("valid", 0, np.uint8), ("uv", 2, np.float32), ("level", 0, np.int32),
+                                                             ("desc", 32, np.uint8), ("hasobs", 0, np.uint8)])
+        occ, _ = _pad_sets(occupied, self.cap, 0, np.uint8)
+        docc = D.put(occ)
+        da, dc = D.empty((self.P, self.cap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_orb_search_by_projection_sim3_batch_dev(
+            _p(self.d_kps), _p(self.d_desc), _p(self.d_n), self.cap, self.P, C.byref(self.gp), _p(self.d_cs), _p(self.d_ci),
+            _p(self.sf), len(self.sf), _p(docc), _p(dnq), qcap, _p(qv), _p(quv), _p(ql), _p(qd), _p(qh), float(th), int(TH_LOW),
+            _p(da), _p(dc), C.c_void_p(D.stream())), "plh_orb_search_by_projection_sim3_batch_dev")
         return D.get(da), D.get(dc), D.get(docc)
 
     def LineSearchByProjectionLastFrame(self, qs, occupied, th=8.0):

@@ -378,12 +378,15 @@ __global__ void __launch_bounds__(64) k_search_init(const plh_keypoint* kps1, co
 // ------------------------------------------------------------------------------------------------------------
 // ORBmatcher::SearchByProjection, both forms.  variant 0: (F, MapPoints, th) -- radius from the viewing cosine,
 // levels (l-1, l), best + second with the same-level ratio test; variant 1: (Cur, Last, th, mono) -- image-bounds
-// test, radius th*scale[octave], level band by `mode`, best only, rotation histogram.
+// test, radius th*scale[octave], level band by `mode`, best only, rotation histogram;
+// variant 2: the search inside ORBmatcher::Fuse (ORBmatcher.cc:914-1061, 1063-1197) -- no occupancy, levels (l-1, l), the
+// monocular chi-square gate e2 * invLevelSigma2 > 5.99, result per QUERY (assigned[q] = best keypoint or -1);
+// variant 3: loop-closing SearchByProjection(KF, Scw, points, vpMatched, th) (:329-453) -- occupancy, levels (l-1, l), best.
 // LDS: list[cap] dist[cap] asg[cap] (int) + occ[cap] (u8) ; per query (variant 1): pushBin[qcap] (u8), pushIdx[qcap] (int)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const plh_keypoint* kps, const uint8_t* desc,
                                                            const int* nArr, int cap, plh_grid_params g, const int32_t* csAll,
-                                                           const int32_t* ciAll, ScaleTab sf, uint8_t* occupiedAll,
+                                                           const int32_t* ciAll, ScaleTab sf, ScaleTab invSig2, uint8_t* occupiedAll,
                                                            const int* nqArr, int qcap, const uint8_t* qValid, const float* qXY,
                                                            const int32_t* qLevel, const float* qAux, const uint8_t* qDesc,
                                                            const uint8_t* qHasObs, float th, float nnratio, int mode,
@@ -402,8 +405,10 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
   const int32_t* cs = csAll + (long long)pair * (GCELLS + 1);
   const int32_t* ci = ciAll + o;
   const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
-  for (int i = lane; i < cap; i += 64) { asg[i] = -1; occ[i] = i < n ? occupiedAll[o + i] : 1; }
+  for (int i = lane; i < cap; i += 64) { asg[i] = -1; occ[i] = (i < n && variant != 2) ? occupiedAll[o + i] : (variant == 2 ? 0 : 1); }
   for (int i = lane; i < qcap; i += 64) pushBin[i] = 255;
+  if (variant == 2)
+    for (int i = lane; i < qcap; i += 64) assignedAll[qo + i] = -1;
   FS_WAVE_SYNC();
   int nmatches = 0, myHist = 0;
   const bool bFactor = th != 1.0;
@@ -418,13 +423,16 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
       if (bFactor) r *= th;
       radius = r * sf.v[lvl];
       minL = lvl - 1; maxL = lvl;
-    } else {
+    } else if (variant == 1) {
       if (x < g.min_x || x > g.max_x) continue;
       if (y < g.min_y || y > g.max_y) continue;
       radius = th * sf.v[lvl];
       if (mode == 1) { minL = lvl; maxL = -1; }
       else if (mode == 2) { minL = 0; maxL = lvl; }
       else { minL = lvl - 1; maxL = lvl + 1; }
+    } else {   // Fuse / loop closing: KeyFrame::GetFeaturesInArea(u, v, radius), then kpLevel in [l-1, l]
+      radius = th * sf.v[lvl];
+      minL = lvl - 1; maxL = lvl;
     }
     FS_WAVE_SYNC();
     const int Kc = collect_points(K, g, cs, ci, x, y, radius, minL, maxL, list, lane);
@@ -436,12 +444,22 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
     for (int t = 0; t < Kc; t++) {
       const int idx = list[t];
       if (occ[idx]) continue;
+      if (variant == 2) {   // reprojection error gate (monocular): e2 * mvInvLevelSigma2[kpLevel] > 5.99
+        const float ex = x - K[idx].x, ey = y - K[idx].y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * invSig2.v[K[idx].octave & 15] > 5.99) continue;
+      }
       const int d = dist[t];
       if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = K[idx].octave; bestIdx = idx; }
       else if (variant == 0 && d < bestDist2) { bestLevel2 = K[idx].octave; bestDist2 = d; }
     }
     if (bestDist <= distTh) {
       if (variant == 0 && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      if (variant == 2) {
+        if (lane == 0) assignedAll[qo + q] = bestIdx;
+        nmatches++;
+        continue;
+      }
       FS_WAVE_SYNC();
       asg[bestIdx] = q;
       occ[bestIdx] = qHasObs[qo + q];
@@ -466,10 +484,11 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
     nmatches -= wave_sum(removed);
   }
   FS_WAVE_SYNC();
-  for (int i = lane; i < cap; i += 64) {
-    assignedAll[o + i] = i < n ? asg[i] : -1;
-    if (i < n) occupiedAll[o + i] = occ[i];
-  }
+  if (variant != 2)
+    for (int i = lane; i < cap; i += 64) {
+      assignedAll[o + i] = i < n ? asg[i] : -1;
+      if (i < n) occupiedAll[o + i] = occ[i];
+    }
   if (lane == 0) nmatchesOut[pair] = nmatches;
 }
 
@@ -618,9 +637,10 @@ static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, 
                                      const uint8_t* d_q_valid, const float* d_q_xy, const int32_t* d_q_level, const float* d_q_aux,
                                      const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, float nnratio, int mode,
                                      int check_ori, int32_t* d_assigned, int32_t* d_nmatches, void* stream, const char* who,
-                                     int dist_th = 100 /* ORBmatcher::TH_HIGH */) {
+                                     int dist_th = 100 /* ORBmatcher::TH_HIGH */, const float* inv_level_sigma2 = nullptr) {
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  ScaleTab sf;
+  ScaleTab sf, is2;
+  for (int i = 0; i < 16; i++) is2.v[i] = (inv_level_sigma2 && i < nlevels) ? inv_level_sigma2[i] : 0.f;
   if (!d_kps_un || !d_desc || !d_n || !gp || !d_cs || !d_ci || !scale_tab(scale_factors, nlevels, &sf) || !d_occupied || !d_nq ||
       !d_q_valid || !d_q_xy || !d_q_level || !d_q_aux || !d_q_desc || !d_q_hasobs || !d_assigned || !d_nmatches || cap <= 0 ||
       cap > 6000 || qcap <= 0 || qcap > 6000 || pairs <= 0 || mode < 0 || mode > 2) {
@@ -629,7 +649,7 @@ static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, 
   }
   const size_t lds = (size_t)cap * (3 * 4 + 1) + (size_t)qcap * (4 + 1) + 64;
   hipLaunchKernelGGL(k_search_proj_points, dim3(pairs), dim3(64), lds, (hipStream_t)stream, variant, d_kps_un, d_desc,
-                     (const int*)d_n, cap, *gp, d_cs, d_ci, sf, d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy, d_q_level,
+                     (const int*)d_n, cap, *gp, d_cs, d_ci, sf, is2, d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy, d_q_level,
                      d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, mode, check_ori, dist_th, d_assigned, d_nmatches);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
@@ -674,6 +694,38 @@ plh_status plh_orb_search_by_projection_kf_batch_dev(const plh_keypoint* d_kps_u
   return launch_proj_points(1, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
                             d_occupied, d_nq, qcap, d_q_valid, d_q_uv, d_q_level, d_q_angle, d_q_desc, d_q_hasobs, th, 0.f, 0,
                             check_ori, d_assigned, d_nmatches, stream, "plh_orb_search_by_projection_kf_batch_dev", orb_dist);
+}
+
+// The search inside ORBmatcher::Fuse(pKF, vpMapPoints, th) and Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
+// (ORBmatcher.cc:914-1061, 1063-1197): per query the best keypoint of the KeyFrame (Hamming <= TH_LOW) among those of
+// level l-1..l inside the window whose reprojection error passes the chi-square gate.  The MapPoint replace / add logic
+// that follows mutates the map and stays with the caller.
+plh_status plh_orb_fuse_search_batch_dev(const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n, int cap, int pairs,
+                                         const plh_grid_params* gp, const int32_t* d_cell_start, const int32_t* d_cell_items,
+                                         const float* scale_factors, const float* inv_level_sigma2, int nlevels,
+                                         const int32_t* d_nq, int qcap, const uint8_t* d_q_valid, const float* d_q_uv,
+                                         const int32_t* d_q_level, const uint8_t* d_q_desc, float th, int th_low,
+                                         int32_t* d_best_idx, int32_t* d_nfound, void* stream) {
+  if (!inv_level_sigma2) return PLH_ERR_INVALID;
+  // occupancy / hasobs / aux are unused by this variant: any valid device pointers do
+  return launch_proj_points(2, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
+                            const_cast<uint8_t*>(d_q_valid), d_nq, qcap, d_q_valid, d_q_uv, d_q_level, d_q_uv, d_q_desc, d_q_valid, th,
+                            0.f, 0, 0, d_best_idx, d_nfound, stream, "plh_orb_fuse_search_batch_dev", th_low, inv_level_sigma2);
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:329-453, loop closing).
+// Query iMP: valid = !isBad() && !spAlreadyFound.count(pMP) && depth > 0 && IsInImage && distance range && viewing angle;
+// occupied = vpMatched[idx] != NULL (in/out), hasobs all 1.
+plh_status plh_orb_search_by_projection_sim3_batch_dev(const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n,
+                                                       int cap, int pairs, const plh_grid_params* gp, const int32_t* d_cell_start,
+                                                       const int32_t* d_cell_items, const float* scale_factors, int nlevels,
+                                                       uint8_t* d_occupied, const int32_t* d_nq, int qcap,
+                                                       const uint8_t* d_q_valid, const float* d_q_uv, const int32_t* d_q_level,
+                                                       const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int th_low,
+                                                       int32_t* d_assigned, int32_t* d_nmatches, void* stream) {
+  return launch_proj_points(3, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
+                            d_occupied, d_nq, qcap, d_q_valid, d_q_uv, d_q_level, d_q_uv, d_q_desc, d_q_hasobs, th, 0.f, 0, 0,
+                            d_assigned, d_nmatches, stream, "plh_orb_search_by_projection_sim3_batch_dev", th_low);
 }
 
 static plh_status launch_proj_lines(int variant, const plh_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn,

@@ -216,6 +216,34 @@ def _run_all(P, O, S, lib, seeds, n, nl, distorted=False):
                                                    O._p(q["angle"]), O._p(q["desc"]), O._p(q["hasobs"]), 10.0, orb_dist, 1, O._p(ra))
             assert cnt[b] == rc and (asg[b, :n2] == ra[:n2]).all() and (occ[b, :n2] == ro[:n2]).all(), "reloc %d %d" % (orb_dist, b)
             total += rc
+    # ---- the search inside Fuse and the loop-closing projection search
+    L.plo_orb_fuse_search.argtypes = [V, V, I, V, V, V, V, V, I, V, V, V, V, F, I, V]
+    L.plo_orb_fuse_search.restype = I
+    L.plo_orb_search_by_projection_sim3.argtypes = [V, V, I, V, V, V, V, V, I, V, V, V, V, F, I, V]
+    L.plo_orb_search_by_projection_sim3.restype = I
+    INVSIG2 = (np.float32(1.0) / (SCALE * SCALE)).astype(np.float32)
+    qs = []
+    for b, (f1, f2) in enumerate(zip(lasts, curs)):
+        q = _queries_points(P, S, 960 + b, f1, f2, "frame")
+        qs.append(dict(valid=q["valid"], uv=q["uv"], level=q["octave"], desc=q["desc"], hasobs=np.ones(len(q["valid"]), np.uint8)))
+    best, nf = fs.FuseSearch(qs, INVSIG2, th=3.0)
+    occ0 = [(S.SplitMix64(111 + b).uniform(len(f2["kps"])) < 0.05).astype(np.uint8) for b, f2 in enumerate(curs)]
+    asg, cnt, occ = fs.SearchByProjectionSim3(qs, occ0, th=10)
+    for b, (f1, f2) in enumerate(zip(lasts, curs)):
+        (rcs, rci), _ = _oracle_grids(O, P, f2, gp)
+        n2, q = len(f2["kps"]), qs[b]
+        nq = len(q["valid"])
+        rb = np.zeros(max(nq, 1), np.int32)
+        rc = L.plo_orb_fuse_search(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(rcs), O._p(rci), O._p(SCALE), O._p(INVSIG2), nq,
+                                   O._p(q["valid"]), O._p(q["uv"]), O._p(q["level"]), O._p(q["desc"]), 3.0, 50, O._p(rb))
+        assert nf[b] == rc and (best[b, :nq] == rb[:nq]).all(), "fuse %d" % b
+        total += rc
+        ro, ra = occ0[b].copy(), np.zeros(max(n2, 1), np.int32)
+        rc = L.plo_orb_search_by_projection_sim3(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(rcs), O._p(rci), O._p(SCALE),
+                                                 O._p(ro), nq, O._p(q["valid"]), O._p(q["uv"]), O._p(q["level"]), O._p(q["desc"]),
+                                                 10.0, 50, O._p(ra))
+        assert cnt[b] == rc and (asg[b, :n2] == ra[:n2]).all() and (occ[b, :n2] == ro[:n2]).all(), "sim3 %d" % b
+        total += rc
     # ---- LSD SearchByProjection, both forms
     for variant in ("ml", "frame"):
         qs = [_queries_lines(P, S, 950 + b, f1, variant) for b, f1 in enumerate(lasts)]
