@@ -330,6 +330,16 @@ PLH_API plh_status plh_line_search_by_projection_frame_batch_dev(
     const int32_t* d_nq, int qcap, const uint8_t* d_q_valid, const float* d_q_seg, const float* d_q_length,
     const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int32_t* d_assigned, int32_t* d_nmatches, void* stream);
 
+/* The search inside LSDmatcher::Fuse(pKF, vpMapLines, th) (LSDmatcher.cpp:860-1002) with
+ * KeyFrame::GetLinesInArea (KeyFrame.cc:647-683, cos_th = 0.998): per query the best line of level l-1..l near the projected
+ * segment, Hamming <= th_low.  d_cand_desc is the matrix the reference reads the candidates from (it reads pKF->mDescriptors
+ * with the line index, :963 -- pass mLineDescriptors for the intended behaviour).  d_best_idx[pairs][qcap] = line or -1. */
+PLH_API plh_status plh_line_fuse_search_batch_dev(const plh_keyline* d_kl, const uint8_t* d_cand_desc, const int32_t* d_nl, int cap,
+                                                  int pairs, const float* scale_factors_line, int nlevels, const int32_t* d_nq,
+                                                  int qcap, const uint8_t* d_q_valid, const float* d_q_seg,
+                                                  const int32_t* d_q_level, const uint8_t* d_q_desc, float th, float cos_th,
+                                                  int th_low, int32_t* d_best_idx, int32_t* d_nfound, void* stream);
+
 /* LSDmatcher::SearchByProjection(Frame& F, const vector<MapLine*>&, th) (LSDmatcher.cpp:221-338). */
 PLH_API plh_status plh_line_search_by_projection_ml_batch_dev(
     const plh_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn, const int32_t* d_nl, int cap, int pairs,

@@ -142,6 +142,9 @@ int  plo_distinctive_descriptor(const uint8_t* desc, int n);
 int  plo_orb_search_by_bow_kfkf(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
                                 const uint8_t* desc2, const float* angle2, const int32_t* node2, const uint8_t* valid2, int n2,
                                 int th_low, float nnratio, int check_ori, int32_t* matches12);
+int  plo_line_fuse_search(const plo_keyline* kl, const uint8_t* cand_desc, int nl, const float* scale_factors_line, int nq,
+                          const uint8_t* q_valid, const float* q_seg, const int32_t* q_level, const uint8_t* q_desc, float th,
+                          float TH, int th_low, int32_t* best_idx);           /* search inside LSDmatcher::Fuse, :860-1002 */
 int  plo_orb_fuse_search(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6], const int32_t* cs,
                          const int32_t* ci, const float* scale_factors, const float* inv_level_sigma2, int nq,
                          const uint8_t* q_valid, const float* q_uv, const int32_t* q_level, const uint8_t* q_desc, float th,

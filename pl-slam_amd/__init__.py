@@ -79,6 +79,7 @@ _SIGS = {
     "plh_orb_search_by_bow_kfkf_batch_dev": ([_V] * 10 + [_I, _I, _I, _F, _I, _V, _V, _V], _I),
     "plh_orb_search_by_projection_kf_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 6 +
                                                   [_F, _I, _I, _V, _V, _V], _I),
+    "plh_line_fuse_search_batch_dev": ([_V, _V, _V, _I, _I, _V, _I, _V, _I, _V, _V, _V, _V, _F, _F, _I, _V, _V, _V], _I),
     "plh_orb_fuse_search_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _V, _I, _V, _I, _V, _V, _V, _V, _F, _I, _V, _V, _V], _I),
     "plh_orb_search_by_projection_sim3_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 5 +
                                                     [_F, _I, _V, _V, _V], _I),
@@ -506,6 +507,23 @@ class FrameSearch:
             _p(self.sf), len(self.sf), _p(docc), _p(dnq), qcap, _p(qv), _p(quv), _p(ql), _p(qd), _p(qh), float(th), int(TH_LOW),
             _p(da), _p(dc), C.c_void_p(D.stream())), "plh_orb_search_by_projection_sim3_batch_dev")
         return D.get(da), D.get(dc), D.get(docc)
+
+    def LineFuseSearch(self, qs, scale_factors_line, cand_descs=None, th=3.0, cos_th=0.998, TH_LOW=50):
+        """The search inside LSDmatcher::Fuse(pKF = this frame, vpMapLines, th).  qs: per frame dict(valid, seg, level, desc);
+        cand_descs: per frame the rows compared against (default: the frame's LBD descriptors)."""
+        D, L = self.D, self.lib
+        qcap, dnq, (qv, qs_, ql, qd) = self._queries(qs, [("valid", 0, np.uint8), ("seg", 4, np.float32), ("level", 0, np.int32),
+                                                         ("desc", 32, np.uint8)])
+        dcand = self.d_ld
+        if cand_descs is not None:
+            cd, _ = _pad_sets(cand_descs, self.lcap, 32, np.uint8)
+            dcand = D.put(cd)
+        sfl = np.ascontiguousarray(scale_factors_line, np.float32)
+        db, dc = D.empty((self.P, qcap), np.int32), D.empty((self.P,), np.int32)
+        _check(L, L.plh_line_fuse_search_batch_dev(_p(self.d_kl), _p(dcand), _p(self.d_nl), self.lcap, self.P, _p(sfl), len(sfl), _p(dnq),
+                                                   qcap, _p(qv), _p(qs_), _p(ql), _p(qd), float(th), float(cos_th), int(TH_LOW),
+                                                   _p(db), _p(dc), C.c_void_p(D.stream())), "plh_line_fuse_search_batch_dev")
+        return D.get(db), D.get(dc)
 
     def LineSearchByProjectionLastFrame(self, qs, occupied, th=8.0):
         """LSDmatcher.SearchByProjection(CurrentFrame = this frame, LastFrame, th).

@@ -569,6 +569,57 @@ __global__ void __launch_bounds__(64) k_search_proj_lines(int variant, const plh
   if (lane == 0) nmatchesOut[pair] = nmatches;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The search inside LSDmatcher::Fuse (reference src/LSDmatcher.cpp:860-1002) with KeyFrame::GetLinesInArea
+// (src/KeyFrame.cc:647-683): brute force over the KeyFrame's lines -- lanes take the lines, the minimum of
+// (distance, line index) over the wave is the reference's first best.  One wave per frame walks the queries.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_line_fuse_search(const plh_keyline* kls, const uint8_t* candDesc, const int* nArr, int cap,
+                                                         ScaleTab sfl, const int* nqArr, int qcap, const uint8_t* qValid,
+                                                         const float* qSeg, const int32_t* qLevel, const uint8_t* qDesc, float th,
+                                                         float TH, int thLow, int32_t* bestAll, int32_t* nfoundOut) {
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
+  const plh_keyline* K = kls + o;
+  const uint8_t* D = candDesc + o * 32;
+  const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
+  int nfound = 0;
+  for (int q = 0; q < qcap; q++) {
+    int best = -1;
+    if (q < nq && qValid[qo + q]) {
+      const float* sg = qSeg + (qo + q) * 4;
+      const float x1 = sg[0], y1 = sg[1], x2 = sg[2], y2 = sg[3];
+      const int lvl = qLevel[qo + q];
+      const float r = th * sfl.v[lvl & 15];
+      float delta1x = x1 - x2, delta1y = y1 - y2;
+      const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
+      delta1x /= norm_delta1;
+      delta1y /= norm_delta1;
+      int key = 0x7fffffff;
+      for (int j = lane; j < n; j += 64) {
+        const plh_keyline k = K[j];
+        const float distance = (float)((0.5 * (x1 + x2) - k.pt_x) * (0.5 * (x1 + x2) - k.pt_x) +
+                                       (0.5 * (y1 + y2) - k.pt_y) * (0.5 * (y1 + y2) - k.pt_y));
+        if (distance > r * r) continue;
+        float delta2x = k.startPointX - k.endPointX, delta2y = k.startPointY - k.endPointY;
+        const float norm_delta2 = sqrtf(delta2x * delta2x + delta2y * delta2y);
+        delta2x /= norm_delta2;
+        delta2y /= norm_delta2;
+        const float CosSita = fabsf(delta1x * delta2x + delta1y * delta2y);
+        if (CosSita < TH) continue;
+        if (k.octave < lvl - 1 || k.octave > lvl) continue;
+        const int d = hamming_rows(qDesc + (qo + q) * 32, D + (long long)j * 32);
+        key = min(key, (d << 16) | j);
+      }
+      for (int s = 32; s >= 1; s >>= 1) key = min(key, __shfl_xor(key, s));
+      if (key != 0x7fffffff && (key >> 16) <= thLow) { best = key & 0xffff; nfound++; }
+    }
+    if (lane == 0) bestAll[qo + q] = best;
+  }
+  if (lane == 0) nfoundOut[pair] = nfound;
+}
+
 }  // namespace plh
 
 using namespace plh;
@@ -726,6 +777,24 @@ plh_status plh_orb_search_by_projection_sim3_batch_dev(const plh_keypoint* d_kps
   return launch_proj_points(3, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
                             d_occupied, d_nq, qcap, d_q_valid, d_q_uv, d_q_level, d_q_uv, d_q_desc, d_q_hasobs, th, 0.f, 0, 0,
                             d_assigned, d_nmatches, stream, "plh_orb_search_by_projection_sim3_batch_dev", th_low);
+}
+
+plh_status plh_line_fuse_search_batch_dev(const plh_keyline* d_kl, const uint8_t* d_cand_desc, const int32_t* d_nl, int cap, int pairs,
+                                          const float* scale_factors_line, int nlevels, const int32_t* d_nq, int qcap,
+                                          const uint8_t* d_q_valid, const float* d_q_seg, const int32_t* d_q_level,
+                                          const uint8_t* d_q_desc, float th, float cos_th, int th_low, int32_t* d_best_idx,
+                                          int32_t* d_nfound, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  ScaleTab sfl;
+  if (!d_kl || !d_cand_desc || !d_nl || !scale_tab(scale_factors_line, nlevels, &sfl) || !d_nq || !d_q_valid || !d_q_seg ||
+      !d_q_level || !d_q_desc || !d_best_idx || !d_nfound || cap <= 0 || cap > 65535 || qcap <= 0 || pairs <= 0) {
+    set_error("plh_line_fuse_search_batch_dev: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(k_line_fuse_search, dim3(pairs), dim3(64), 0, (hipStream_t)stream, d_kl, d_cand_desc, (const int*)d_nl, cap, sfl,
+                     (const int*)d_nq, qcap, d_q_valid, d_q_seg, d_q_level, d_q_desc, th, cos_th, th_low, d_best_idx, d_nfound);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
 }
 
 static plh_status launch_proj_lines(int variant, const plh_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn,

@@ -80,6 +80,8 @@ def make_frame_pair(P, S, seed, n, cols=640, rows=480, move=6.0, nl=60):
         kl["startPointX"], kl["startPointY"], kl["endPointX"], kl["endPointY"] = sx, sy, ex, ey
         kl["sPointInOctaveX"], kl["sPointInOctaveY"], kl["ePointInOctaveX"], kl["ePointInOctaveY"] = sx, sy, ex, ey
         kl["lineLength"] = np.hypot(ex - sx, ey - sy).astype(np.float32)
+        kl["pt_x"], kl["pt_y"] = ((kl["startPointX"] + kl["endPointX"]) / 2).astype(np.float32), \
+            ((kl["startPointY"] + kl["endPointY"]) / 2).astype(np.float32)
         kl["class_id"] = np.arange(len(kl))
         fn = np.zeros((len(kl), 3))
         s = np.stack([kl["startPointX"], kl["startPointY"], np.ones(len(kl))], 1).astype(np.float64)
@@ -268,6 +270,24 @@ def _run_all(P, O, S, lib, seeds, n, nl, distorted=False):
                                                            O._p(ra))
             assert cnt[b] == rc and (asg[b, :n2] == ra[:n2]).all() and (occ[b, :n2] == ro[:n2]).all(), "line %s %d" % (variant, b)
             total += rc
+    # ---- the search inside LSDmatcher::Fuse
+    L.plo_line_fuse_search.argtypes = [V, V, I, V, I, V, V, V, V, F, F, I, V]
+    L.plo_line_fuse_search.restype = I
+    SFL = np.ones(4, np.float32)
+    qs = []
+    for b, f1 in enumerate(lasts):
+        q = _queries_lines(P, S, 970 + b, f1, "ml")
+        qs.append(dict(valid=q["valid"], seg=q["seg"], level=np.zeros(len(q["valid"]), np.int32), desc=q["desc"]))
+    best, nf = fs.LineFuseSearch(qs, SFL, th=6.0, cos_th=0.998)
+    for b, f2 in enumerate(curs):
+        nl2, q = len(f2["keylines"]), qs[b]
+        nq = len(q["valid"])
+        rb = np.zeros(max(nq, 1), np.int32)
+        rc = L.plo_line_fuse_search(O._p(f2["keylines"]), O._p(f2["ldesc"]), nl2, O._p(SFL), nq, O._p(q["valid"]), O._p(q["seg"]),
+                                    O._p(q["level"]), O._p(q["desc"]), 6.0, 0.998, 50, O._p(rb))
+        assert nf[b] == rc and (best[b, :nq] == rb[:nq]).all(), "line fuse %d" % b
+        assert rc > 0 or nl2 < 5, "line fuse finds nothing"
+        total += rc
     return total
 
 
