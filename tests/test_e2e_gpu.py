@@ -95,3 +95,47 @@ def test_pipelined_sub_batches_match_plain_batches(plslam, synth):
                 else:
                     assert np.array_equal(a, b, equal_nan=True), (k, key, i)
     fe.close()
+
+
+def test_partial_batches_and_blank_frames(plslam, oracle, synth):
+    """A handle planned for 8 frames is driven with 3 (ragged use), and a batch that contains feature-less frames (flat /
+    nearly flat images: zero keypoints, zero lines) goes through every stage without touching its neighbours."""
+    import torch
+    B = 8
+    frames = synth.make_frames(520, B, 480, 640)
+    frames[1] = 77                                        # flat: no keypoints, no lines
+    frames[4] = (np.arange(640, dtype=np.uint8) // 64 * 2 + 100)[None, :]   # faint ramp: below every threshold
+    d = torch.from_numpy(frames).cuda()
+    orb = plslam.ORBextractor(1000, 1.2, 8, 20, 7, rows=480, cols=640, max_batch=B)
+    le = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=480, cols=640, max_batch=B)
+    ocap, lcap = orb.capacity, le.capacity
+    s = torch.cuda.current_stream().cuda_stream
+    ref = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    for nb in (3, B):
+        kps = torch.zeros((B, ocap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((B, ocap, 32), dtype=torch.uint8, device="cuda")
+        n = torch.full((B,), -5, dtype=torch.int32, device="cuda")
+        kl = torch.zeros((B, lcap, 17), dtype=torch.float32, device="cuda")
+        ld = torch.zeros((B, lcap, 32), dtype=torch.uint8, device="cuda")
+        fn = torch.zeros((B, lcap, 3), dtype=torch.float64, device="cuda")
+        nl = torch.full((B,), -5, dtype=torch.int32, device="cuda")
+        orb.extract_batch_dev(d, nb, 480 * 640, kps, desc, n, s)
+        le.extract_batch_dev(d, nb, 480 * 640, kl, ld, fn, nl, s)
+        torch.cuda.synchronize()
+        n_h, nl_h = n.cpu().numpy(), nl.cpu().numpy()
+        assert (n_h[nb:] == -5).all() and (nl_h[nb:] == -5).all()          # frames beyond the call's batch are untouched
+        k_h = kps.cpu().numpy().view(np.uint8).reshape(B, ocap, 28).copy().view(plslam.KP_DTYPE).reshape(B, ocap)
+        d_h = desc.cpu().numpy()
+        kl_h = kl.cpu().numpy().view(np.uint8).reshape(B, lcap, 68).copy().view(plslam.KL_DTYPE).reshape(B, lcap)
+        ld_h, fn_h = ld.cpu().numpy(), fn.cpu().numpy()
+        for b in range(nb):
+            rk, rd = ref.extract(frames[b])
+            assert n_h[b] == len(rk) and (d_h[b, :n_h[b]] == rd).all()
+            assert all((k_h[b, :n_h[b]][f] == rk[f]).all() for f in rk.dtype.names)
+            lk, ldr, lfr = oracle.line_extract(frames[b], 200, 0.0)
+            assert nl_h[b] == len(lk)
+            if not _exact(kl_h[b, :nl_h[b]], ld_h[b, :nl_h[b]], fn_h[b, :nl_h[b]], lk, ldr, lfr):
+                _close(kl_h[b, :nl_h[b]], ld_h[b, :nl_h[b]], fn_h[b, :nl_h[b]], lk, ldr, lfr, "frame %d" % b)
+        assert n_h[1] == 0 and nl_h[1] == 0 and (nb <= 4 or (n_h[4] == 0 and nl_h[4] == 0))
+    orb.close()
+    le.close()
