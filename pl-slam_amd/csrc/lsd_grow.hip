@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(256) k_sobel_pack(LineDeviceArgs a) {
   const int ym = refl101(y - 1, a.h), yp = refl101(y + 1, a.h);
   const uint8_t *r0 = S + (long long)ym * a.w, *r1 = S + (long long)y * a.w, *r2 = S + (long long)yp * a.w;
   int p0[6], p1[6], p2[6];   // columns x-1 .. x+4 of the three rows
-  if (x >= 4 && x + 8 <= a.w) {
+  if (x >= 4 && x + 12 <= a.w) {   // the aligned dword pairs of ld4_any stay inside the row
     const unsigned l0 = ld4_any(r0 + x - 4), c0 = ld4_any(r0 + x), h0 = ld4_any(r0 + x + 4);
     const unsigned l1 = ld4_any(r1 + x - 4), c1 = ld4_any(r1 + x), h1 = ld4_any(r1 + x + 4);
     const unsigned l2 = ld4_any(r2 + x - 4), c2 = ld4_any(r2 + x), h2 = ld4_any(r2 + x + 4);
