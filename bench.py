@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--nlines", type=int, default=200)
     ap.add_argument("--unique", type=int, default=32, help="distinct rasterised frames (the rest are cheap variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fake-gather", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # 1-rank RCCL group: rehearses the N > 1 path
     ap.add_argument("--serial", action="store_true", help="ORB and line halves on one stream (no overlap); used for PMC runs")
     args = ap.parse_args()
 
@@ -133,8 +135,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # keep stdout to the one JSON line: RCCL's NCCL_DEBUG=VERSION banner (set in this image) goes to a file
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/plslam_bench_rccl_%h_%p.log")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     P, S = _util.plslam(), _util.synth()
@@ -152,14 +157,23 @@ def main():
     Bp = fe.Bp
     DI = _util._load("plslam_amd_dist", os.path.join(ROOT, "pl-slam_amd", "dist.py"))
 
+    gathering = world > 1 or args.fake_gather or args.force_dist
+    comm = torch.cuda.Stream(device=dev) if gathering else None
+    gdist = dist
+    if args.fake_gather and world == 1:   # single-GPU rehearsal of the N > 1 choreography (a copy stands in for RCCL)
+        class _Loop:
+            @staticmethod
+            def all_gather_into_tensor(dst, src):
+                dst.copy_(src)
+        gdist = _Loop
+
     def step():
-        # N = 1: consecutive steps are independent batches and may overlap (sub-batch pipelining); N > 1: the records
-        # are consumed on this stream by the RCCL gather, so every step completes before the collective
-        fe.step(d_imgs, join=(world > 1))
-        if world > 1:   # RCCL gather of the fixed-stride records over xGMI (pl-slam_amd/dist.py; gloo-tested on CPU)
-            for part in fe.parts:
-                DI.all_gather_records({"n": part.n[:Bp], "kps": part.kps[:Bp], "desc": part.desc[:Bp], "nl": part.nl[:Bp],
-                                       "kl": part.kl[:Bp], "ldesc": part.ldesc[:Bp]}, world, dist)
+        # consecutive steps are independent batches and overlap (sub-batch pipelining).  N > 1: the fixed-stride records of
+        # every sub-batch are all_gather'ed over RCCL / xGMI on a communication stream as soon as that sub-batch is done
+        # (pl-slam_amd/dist.py, gloo-tested on CPU); only the sub-batch's own next step waits for its gather
+        fe.step(d_imgs, join=False)
+        if gathering:
+            fe.gather(comm, world, gdist, DI.all_gather_records)
 
     for _ in range(args.warmup):
         step()
@@ -265,7 +279,8 @@ def main():
                        "mean_line_matches_per_pair": round(float(res["nm_line"].mean()), 1),
                        "vocabulary": "synthetic k=10 L=6 (ORBvoc.bin is not in the mount)",
                        "streams": "line chain on a high-priority stream, ORB + BoW + SearchByBoW on a second stream" if not args.serial else "one stream",
-                       "parallelism": "frames sharded 1 batch/GPU" + (", RCCL all_gather of records" if world > 1 else "")},
+                       "parallelism": "frames sharded 1 batch/GPU" + (", RCCL all_gather of the records per sub-batch on a "
+                                                                       "communication stream" if world > 1 else "")},
             "kernel_ms_per_launch": {names[k]: round(per_ms[k], 4) for k in range(8)},
             "kernel_ms_per_launch_timed_region": {names[k]: round(per_ms_timed[k], 4) for k in range(8)},
             "roofline": r_dom,
@@ -277,9 +292,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(O, V, frames[:min(B, 64)], voc, args.nfeatures, args.nlevels, args.nlines,
                                                TUM1_K if tum else [718.856, 718.856, 607.1928, 185.2157],
                                                TUM1_D if tum else [0, 0, 0, 0, 0])
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
     fe.close()
-    if world > 1:
+    try:   # flush what native libraries (the RCCL version banner) buffered on C stdio, on every rank, BEFORE the result line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if world > 1 or args.force_dist:
+        dist.barrier()
+    if rank == 0:
+        print(result_line, flush=True)   # the one JSON line, last on stdout
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -60,6 +60,7 @@ class FrontEndBatch:
         self.ev_orb = torch.cuda.Event()
         self.ev_line = torch.cuda.Event()
         self.overlap = True    # False: both halves on the caller's stream (per-kernel timing without interference)
+        self.ev_free = None    # optional event a consumer records when it has read this part's records (see gather())
         helper = P._Dev(self.lib, device)
         self.voc_dev = vocab.device_arrays(helper)
         L = self.lib
@@ -80,6 +81,8 @@ class FrontEndBatch:
         sl = self.line_stream if self.overlap else main
         if self.overlap:
             sl.wait_event(ev_start)
+        if self.ev_free is not None:
+            sl.wait_event(self.ev_free)       # the previous step's records have been consumed
         sm = sl.cuda_stream
         self.line.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kl, self.ldesc, self.lfn, self.nl, sm)
         with t.cuda.stream(sl):   # slot B := frame 0 (so that frame B-1 has a successor)
@@ -100,6 +103,8 @@ class FrontEndBatch:
         so = self.orb_stream if self.overlap else main
         if self.overlap:
             so.wait_event(ev_start)
+        if self.ev_free is not None:
+            so.wait_event(self.ev_free)
         sp = C.c_void_p(so.cuda_stream)
         self.orb.extract_batch_dev(d_imgs, B, self.rows * self.cols, self.kps, self.desc, self.n, so.cuda_stream)
         with t.cuda.stream(so):
@@ -188,6 +193,27 @@ class FrontEndPipelined:
         main = self.torch.cuda.current_stream(self.dev)
         for p in self.parts:
             p.join(main)
+
+    def gather(self, comm_stream, world, dist, gather_fn):
+        """N > 1: all_gather the fixed-stride records of every sub-batch on `comm_stream` as soon as that sub-batch is done,
+        without joining the step: a sub-batch's next step waits only for its own gather (which reads its buffers), so the
+        RCCL traffic over xGMI overlaps with the compute of the other sub-batches.  Returns the gathered dicts."""
+        t = self.torch
+        out = []
+        for p in self.parts:
+            if p.overlap:
+                comm_stream.wait_event(p.ev_line)
+                comm_stream.wait_event(p.ev_orb)
+            else:
+                comm_stream.wait_stream(t.cuda.current_stream(self.dev))
+            with t.cuda.stream(comm_stream):
+                B = p.B
+                out.append(gather_fn({"n": p.n[:B], "kps": p.kps[:B], "desc": p.desc[:B], "nl": p.nl[:B], "kl": p.kl[:B],
+                                      "ldesc": p.ldesc[:B]}, world, dist))
+            if p.ev_free is None:
+                p.ev_free = t.cuda.Event()
+            p.ev_free.record(comm_stream)
+        return out
 
     def results(self):
         rs = [p.results() for p in self.parts]
