@@ -321,6 +321,22 @@ PLH_API plh_status plh_orb_search_by_projection_sim3_batch_dev(
     const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, int th_low, int32_t* d_assigned, int32_t* d_nmatches,
     void* stream);
 
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1199-1439, loop closing).
+ * Both KeyFrames share `cap`, the grid geometry and the scale table; query i of a direction belongs to keypoint slot i.
+ * q12_* = KeyFrame 1's map points transformed into KeyFrame 2 (valid = pMP && !vbAlreadyMatched1[i] && !isBad() && depth >= 0 &&
+ * IsInImage && distance inside the invariance region; uv; level = PredictScale; desc = pMP->GetDescriptor()), q21_* the reverse.
+ * Per direction the best keypoint of level l-1..l in the window th*scale[l] with Hamming <= th_high (TH_HIGH); outputs
+ * d_match1 / d_match2 [pairs][cap] = vnMatch1 / vnMatch2, d_match12[pairs][cap] = agreed index in KeyFrame 2 or -1
+ * (vpMatches12[i1] = vpMapPoints2[that index]), d_nfound[pairs] = nFound. */
+PLH_API plh_status plh_orb_search_by_sim3_batch_dev(
+    const plh_keypoint* d_kps1_un, const uint8_t* d_desc1, const int32_t* d_n1, const int32_t* d_cell_start1,
+    const int32_t* d_cell_items1, const plh_keypoint* d_kps2_un, const uint8_t* d_desc2, const int32_t* d_n2,
+    const int32_t* d_cell_start2, const int32_t* d_cell_items2, int cap, int pairs, const plh_grid_params* gp,
+    const float* scale_factors, int nlevels, const uint8_t* d_q12_valid, const float* d_q12_uv, const int32_t* d_q12_level,
+    const uint8_t* d_q12_desc, const uint8_t* d_q21_valid, const float* d_q21_uv, const int32_t* d_q21_level,
+    const uint8_t* d_q21_desc, float th, int th_high, int32_t* d_match1, int32_t* d_match2, int32_t* d_match12,
+    int32_t* d_nfound, void* stream);
+
 /* LSDmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th) (LSDmatcher.cpp:72-176).
  * Query i = Last line i: valid = MapLine && !mvbLineOutlier[i] && Cur.isInFrustum(pML, 0.5);
  * seg = (mTrackProjX1, Y1, X2, Y2); length = Last.mvKeylinesUn[i].lineLength.  d_linefn = mvKeyLineFunctions. */

@@ -566,6 +566,58 @@ extern "C" int plo_orb_search_by_projection_sim3(const plo_keypoint* kps_un, con
   return nmatches;
 }
 
+// ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), reference src/ORBmatcher.cc:1199-1439 (loop closing,
+// LoopClosing.cc:330).  The caller hands over the projections: q12_* = KeyFrame 1's map points transformed into KeyFrame 2
+// (valid = pMP && !vbAlreadyMatched1 && !isBad() && depth >= 0 && IsInImage && distance inside the invariance region;
+// uv, level = PredictScale, desc = pMP->GetDescriptor()), q21_* the other way round; query i belongs to keypoint slot i.
+// Each direction: KeyFrame::GetFeaturesInArea(u, v, th*scale[l]), octave in [l-1, l], best Hamming (first minimum),
+// accepted when <= TH_HIGH (:1283-1313, :1363-1393); then the agreement check (:1396-1412).
+// match1[n1] / match2[n2] = vnMatch1 / vnMatch2; match12[i1] = agreed index in KeyFrame 2 or -1; returns nFound.
+static void sim3_one_way(const plo_keypoint* kps, const uint8_t* desc, const GridP& g, const int32_t* cs, const int32_t* ci,
+                         const float* scale_factors, int nq, const uint8_t* q_valid, const float* q_uv, const int32_t* q_level,
+                         const uint8_t* q_desc, float th, int th_high, int32_t* vnMatch) {
+  std::vector<int> vIndices;
+  for (int i = 0; i < nq; i++) {
+    vnMatch[i] = -1;
+    if (!q_valid[i]) continue;
+    const int nPredictedLevel = q_level[i];
+    const float radius = th * scale_factors[nPredictedLevel];
+    features_in_area(kps, g, cs, ci, q_uv[i * 2], q_uv[i * 2 + 1], radius, -1, -1, vIndices);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = q_desc + (size_t)i * 32;
+    int bestDist = INT_MAX, bestIdx = -1;
+    for (int idx : vIndices) {
+      const plo_keypoint& kp = kps[idx];
+      if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
+      const int dist = plo_descriptor_distance(dMP, desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= th_high) vnMatch[i] = bestIdx;
+  }
+}
+
+extern "C" int plo_orb_search_by_sim3(const plo_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* cs1, const int32_t* ci1,
+                                      const plo_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* cs2, const int32_t* ci2,
+                                      const float gp[6], const float* scale_factors, const uint8_t* q12_valid, const float* q12_uv,
+                                      const int32_t* q12_level, const uint8_t* q12_desc, const uint8_t* q21_valid,
+                                      const float* q21_uv, const int32_t* q21_level, const uint8_t* q21_desc, float th, int th_high,
+                                      int32_t* match1, int32_t* match2, int32_t* match12) {
+  GridP g;
+  memcpy(&g, gp, sizeof(g));
+  sim3_one_way(kps2, desc2, g, cs2, ci2, scale_factors, n1, q12_valid, q12_uv, q12_level, q12_desc, th, th_high, match1);
+  sim3_one_way(kps1, desc1, g, cs1, ci1, scale_factors, n2, q21_valid, q21_uv, q21_level, q21_desc, th, th_high, match2);
+  int nFound = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    match12[i1] = -1;
+    const int idx2 = match1[i1];
+    if (idx2 >= 0) {
+      const int idx1 = match2[idx2];
+      if (idx1 == i1) { match12[i1] = idx2; nFound++; }
+    }
+  }
+  return nFound;
+}
+
 // The search inside LSDmatcher::Fuse(pKF, vpMapLines, th) (reference src/LSDmatcher.cpp:860-1002) with
 // KeyFrame::GetLinesInArea (src/KeyFrame.cc:647-683: brute force over the KeyFrame's lines, midpoint distance <= r^2 and
 // |cos| of the direction angle >= TH = 0.998).  Reference quirk kept: the candidate rows are read from

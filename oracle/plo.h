@@ -153,6 +153,12 @@ int  plo_orb_search_by_projection_sim3(const plo_keypoint* kps_un, const uint8_t
                                        const int32_t* cs, const int32_t* ci, const float* scale_factors, uint8_t* occupied,
                                        int nq, const uint8_t* q_valid, const float* q_uv, const int32_t* q_level,
                                        const uint8_t* q_desc, float th, int th_low, int32_t* assigned);   /* :329-453 */
+int  plo_orb_search_by_sim3(const plo_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* cs1, const int32_t* ci1,
+                            const plo_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* cs2, const int32_t* ci2,
+                            const float gp[6], const float* scale_factors, const uint8_t* q12_valid, const float* q12_uv,
+                            const int32_t* q12_level, const uint8_t* q12_desc, const uint8_t* q21_valid, const float* q21_uv,
+                            const int32_t* q21_level, const uint8_t* q21_desc, float th, int th_high, int32_t* match1,
+                            int32_t* match2, int32_t* match12);            /* src/ORBmatcher.cc:1199-1439 */
 int  plo_orb_search_for_triangulation(const plo_keypoint* kps1, const uint8_t* desc1, const int32_t* node1,
                                       const uint8_t* has_mp1, int n1, const plo_keypoint* kps2, const uint8_t* desc2,
                                       const int32_t* node2, const uint8_t* has_mp2, int n2, const float F12[9], float ex,

@@ -83,6 +83,7 @@ _SIGS = {
     "plh_orb_fuse_search_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _V, _I, _V, _I, _V, _V, _V, _V, _F, _I, _V, _V, _V], _I),
     "plh_orb_search_by_projection_sim3_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 5 +
                                                     [_F, _I, _V, _V, _V], _I),
+    "plh_orb_search_by_sim3_batch_dev": ([_V] * 10 + [_I, _I, _V, _V, _I] + [_V] * 8 + [_F, _I, _V, _V, _V, _V, _V], _I),
     "plh_undistort_keypoints_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
     "plh_distinctive_descriptor_batch_dev": ([_V, _V, _I, _V, _V], _I),
     "plh_frame_assign_grid_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
@@ -372,7 +373,7 @@ class FrameSearch:
       lines : keylines [KL_DTYPE], ldesc, linefn     -> Frame::AssignFeaturesToGridForLine (Frame.cc:295-320)
     and exposes ORBmatcher::SearchForInitialization / SearchByProjection and LSDmatcher::SearchByProjection."""
 
-    def __init__(self, gp, scale_factors, frames, device=0, lib=None):
+    def __init__(self, gp, scale_factors, frames, device=0, lib=None, cap=None):
         self.lib = load(lib)
         self.D = _Dev(self.lib, device)
         self.gp = gp
@@ -380,7 +381,7 @@ class FrameSearch:
         D, L = self.D, self.lib
         self.P = len(frames)
         s = C.c_void_p(D.stream())
-        self.cap = max(1, max(len(f.get("kps", ())) for f in frames))
+        self.cap = max(1, max(len(f.get("kps", ())) for f in frames), cap or 0)   # cap: a common capacity for SearchBySim3
         kps, self.n = _pad_records([f.get("kps", np.zeros(0, KP_DTYPE)) for f in frames], self.cap, KP_DTYPE)
         desc, _ = _pad_sets([f.get("desc", np.zeros((0, 32), np.uint8)) for f in frames], self.cap, 32, np.uint8)
         self.d_kps, self.d_desc, self.d_n = D.put(kps), D.put(desc), D.put(self.n)
@@ -507,6 +508,28 @@ class FrameSearch:
             _p(self.sf), len(self.sf), _p(docc), _p(dnq), qcap, _p(qv), _p(quv), _p(ql), _p(qd), _p(qh), float(th), int(TH_LOW),
             _p(da), _p(dc), C.c_void_p(D.stream())), "plh_orb_search_by_projection_sim3_batch_dev")
         return D.get(da), D.get(dc), D.get(docc)
+
+    def SearchBySim3(self, other, q12, q21, th=7.5, TH_HIGH=100):
+        """ORBmatcher.SearchBySim3(pKF1 = this batch, pKF2 = `other`, vpMatches12, s12, R12, t12, th) (loop closing).
+        q12: per pair dict(valid, uv, level, desc), one query per keypoint slot of KeyFrame 1 (its map point transformed into
+        KeyFrame 2); q21 the reverse.  Returns (match12[P, cap], nfound[P], vnMatch1[P, cap], vnMatch2[P, cap])."""
+        D, L = self.D, self.lib
+        assert other.cap == self.cap and other.P == self.P, "both KeyFrame batches need the same capacity (FrameSearch(cap=...))"
+        fields = [("valid", 0, np.uint8), ("uv", 2, np.float32), ("level", 0, np.int32), ("desc", 32, np.uint8)]
+        dq = []
+        for qs, fs in ((q12, self), (q21, other)):
+            for b, q in enumerate(qs):
+                assert len(q["valid"]) == fs.n[b], "one query per keypoint slot"
+            dq.append([D.put(_pad_sets([q[name] for q in qs], self.cap, width, dt)[0]) for name, width, dt in fields])
+        dm1, dm2, dm12 = (D.empty((self.P, self.cap), np.int32) for _ in range(3))
+        dc = D.empty((self.P,), np.int32)
+        _check(L, L.plh_orb_search_by_sim3_batch_dev(
+            _p(self.d_kps), _p(self.d_desc), _p(self.d_n), _p(self.d_cs), _p(self.d_ci), _p(other.d_kps), _p(other.d_desc),
+            _p(other.d_n), _p(other.d_cs), _p(other.d_ci), self.cap, self.P, C.byref(self.gp), _p(self.sf), len(self.sf),
+            _p(dq[0][0]), _p(dq[0][1]), _p(dq[0][2]), _p(dq[0][3]), _p(dq[1][0]), _p(dq[1][1]), _p(dq[1][2]), _p(dq[1][3]),
+            float(th), int(TH_HIGH), _p(dm1), _p(dm2), _p(dm12), _p(dc), C.c_void_p(D.stream())),
+            "plh_orb_search_by_sim3_batch_dev")
+        return D.get(dm12), D.get(dc), D.get(dm1), D.get(dm2)
 
     def LineFuseSearch(self, qs, scale_factors_line, cand_descs=None, th=3.0, cos_th=0.998, TH_LOW=50):
         """The search inside LSDmatcher::Fuse(pKF = this frame, vpMapLines, th).  qs: per frame dict(valid, seg, level, desc);

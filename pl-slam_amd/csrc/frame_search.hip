@@ -624,6 +624,26 @@ __global__ void __launch_bounds__(64) k_line_fuse_search(const plh_keyline* kls,
 
 using namespace plh;
 
+// ORBmatcher::SearchBySim3, agreement check (ORBmatcher.cc:1396-1412): match12[i1] = vnMatch1[i1] when
+// vnMatch2[vnMatch1[i1]] == i1.
+__global__ void __launch_bounds__(64) k_sim3_agree(const int* n1Arr, const int* n2Arr, int cap, const int32_t* match1,
+                                                   const int32_t* match2, int32_t* match12, int32_t* nfoundOut) {
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  const long long o = (long long)pair * cap;
+  const int n1 = min(n1Arr[pair], cap), n2 = min(n2Arr[pair], cap);
+  int found = 0;
+  for (int i1 = lane; i1 < cap; i1 += 64) {
+    int r = -1;
+    if (i1 < n1) {
+      const int idx2 = match1[o + i1];
+      if (idx2 >= 0 && idx2 < n2 && match2[o + idx2] == i1) { r = idx2; found++; }
+    }
+    match12[o + i1] = r;
+  }
+  found = wave_sum(found);
+  if (lane == 0) nfoundOut[pair] = found;
+}
+
 namespace {
 bool scale_tab(const float* sf, int nlevels, ScaleTab* t) {
   if (!sf || nlevels <= 0 || nlevels > 16) return false;
@@ -777,6 +797,39 @@ plh_status plh_orb_search_by_projection_sim3_batch_dev(const plh_keypoint* d_kps
   return launch_proj_points(3, d_kps_un, d_desc, d_n, cap, pairs, gp, d_cell_start, d_cell_items, scale_factors, nlevels,
                             d_occupied, d_nq, qcap, d_q_valid, d_q_uv, d_q_level, d_q_uv, d_q_desc, d_q_hasobs, th, 0.f, 0, 0,
                             d_assigned, d_nmatches, stream, "plh_orb_search_by_projection_sim3_batch_dev", th_low);
+}
+
+// ORBmatcher::SearchBySim3 (ORBmatcher.cc:1199-1439): the two one-way searches are the per-query best-candidate search
+// (variant 2 with the chi-square gate open and TH_HIGH), the agreement check (:1396-1412) is k_sim3_agree.
+plh_status plh_orb_search_by_sim3_batch_dev(const plh_keypoint* d_kps1_un, const uint8_t* d_desc1, const int32_t* d_n1,
+                                            const int32_t* d_cell_start1, const int32_t* d_cell_items1,
+                                            const plh_keypoint* d_kps2_un, const uint8_t* d_desc2, const int32_t* d_n2,
+                                            const int32_t* d_cell_start2, const int32_t* d_cell_items2, int cap, int pairs,
+                                            const plh_grid_params* gp, const float* scale_factors, int nlevels,
+                                            const uint8_t* d_q12_valid, const float* d_q12_uv, const int32_t* d_q12_level,
+                                            const uint8_t* d_q12_desc, const uint8_t* d_q21_valid, const float* d_q21_uv,
+                                            const int32_t* d_q21_level, const uint8_t* d_q21_desc, float th, int th_high,
+                                            int32_t* d_match1, int32_t* d_match2, int32_t* d_match12, int32_t* d_nfound,
+                                            void* stream) {
+  static const char* who = "plh_orb_search_by_sim3_batch_dev";
+  if (!d_match1 || !d_match2 || !d_match12 || !d_nfound || !d_q12_valid || !d_q21_valid || !d_n1 || !d_n2) {
+    set_error("%s: invalid argument", who);
+    return PLH_ERR_INVALID;
+  }
+  // KeyFrame 1's map points searched in KeyFrame 2 (one query per keypoint slot of KeyFrame 1), then the reverse;
+  // d_nfound doubles as the per-direction counter until the agreement kernel overwrites it
+  plh_status st = launch_proj_points(2, d_kps2_un, d_desc2, d_n2, cap, pairs, gp, d_cell_start2, d_cell_items2, scale_factors, nlevels,
+                                     const_cast<uint8_t*>(d_q12_valid), d_n1, cap, d_q12_valid, d_q12_uv, d_q12_level, d_q12_uv,
+                                     d_q12_desc, d_q12_valid, th, 0.f, 0, 0, d_match1, d_nfound, stream, who, th_high, nullptr);
+  if (st != PLH_OK) return st;
+  st = launch_proj_points(2, d_kps1_un, d_desc1, d_n1, cap, pairs, gp, d_cell_start1, d_cell_items1, scale_factors, nlevels,
+                          const_cast<uint8_t*>(d_q21_valid), d_n2, cap, d_q21_valid, d_q21_uv, d_q21_level, d_q21_uv, d_q21_desc,
+                          d_q21_valid, th, 0.f, 0, 0, d_match2, d_nfound, stream, who, th_high, nullptr);
+  if (st != PLH_OK) return st;
+  hipLaunchKernelGGL(k_sim3_agree, dim3(pairs), dim3(64), 0, (hipStream_t)stream, (const int*)d_n1, (const int*)d_n2, cap,
+                     (const int32_t*)d_match1, (const int32_t*)d_match2, d_match12, d_nfound);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
 }
 
 plh_status plh_line_fuse_search_batch_dev(const plh_keyline* d_kl, const uint8_t* d_cand_desc, const int32_t* d_nl, int cap, int pairs,

@@ -246,6 +246,31 @@ def _run_all(P, O, S, lib, seeds, n, nl, distorted=False):
                                                  10.0, 50, O._p(ra))
         assert cnt[b] == rc and (asg[b, :n2] == ra[:n2]).all() and (occ[b, :n2] == ro[:n2]).all(), "sim3 %d" % b
         total += rc
+    # ---- SearchBySim3: both one-way searches and the agreement check
+    L.plo_orb_search_by_sim3.argtypes = [V, V, I, V, V, V, V, I, V, V, V, V, V, V, V, V, V, V, V, V, F, I, V, V, V]
+    L.plo_orb_search_by_sim3.restype = I
+    fs1 = P.FrameSearch(gp, SCALE, lasts, lib=lib, cap=fs.cap)
+    fs2 = fs if fs.cap == fs1.cap else P.FrameSearch(gp, SCALE, curs, lib=lib, cap=fs1.cap)
+    q12, q21 = [], []
+    for b, (f1, f2) in enumerate(zip(lasts, curs)):
+        a, c = _queries_points(P, S, 970 + b, f1, f2, "frame"), _queries_points(P, S, 980 + b, f2, f1, "frame")
+        q12.append(dict(valid=a["valid"], uv=a["uv"], level=a["octave"], desc=a["desc"]))
+        q21.append(dict(valid=c["valid"], uv=c["uv"], level=c["octave"], desc=c["desc"]))
+    m12, nf, m1, m2 = fs1.SearchBySim3(fs2, q12, q21, th=7.5)
+    for b, (f1, f2) in enumerate(zip(lasts, curs)):
+        (cs1, ci1), _ = _oracle_grids(O, P, f1, gp)
+        (cs2, ci2), _ = _oracle_grids(O, P, f2, gp)
+        n1, n2, a, c = len(f1["kps"]), len(f2["kps"]), q12[b], q21[b]
+        r1, r2, r12 = np.zeros(max(n1, 1), np.int32), np.zeros(max(n2, 1), np.int32), np.zeros(max(n1, 1), np.int32)
+        rc = L.plo_orb_search_by_sim3(O._p(f1["kps"]), O._p(f1["desc"]), n1, O._p(cs1), O._p(ci1), O._p(f2["kps"]), O._p(f2["desc"]), n2,
+                                      O._p(cs2), O._p(ci2), O._p(g), O._p(SCALE), O._p(a["valid"]), O._p(a["uv"]), O._p(a["level"]),
+                                      O._p(a["desc"]), O._p(c["valid"]), O._p(c["uv"]), O._p(c["level"]), O._p(c["desc"]), 7.5, 100,
+                                      O._p(r1), O._p(r2), O._p(r12))
+        assert nf[b] == rc and (m12[b, :n1] == r12[:n1]).all() and (m1[b, :n1] == r1[:n1]).all() and \
+            (m2[b, :n2] == r2[:n2]).all(), "SearchBySim3 %d" % b
+        assert (m12[b, n1:] == -1).all()
+        assert rc > min(n1, n2) // 8 or min(n1, n2) < 50, "SearchBySim3 agrees on too few (%d of %d)" % (rc, n1)
+        total += rc
     # ---- LSD SearchByProjection, both forms
     for variant in ("ml", "frame"):
         qs = [_queries_lines(P, S, 950 + b, f1, variant) for b, f1 in enumerate(lasts)]
