@@ -248,7 +248,7 @@ def main():
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and tum and args.nfeatures == 1000:   # the counters were collected on this workload only
             try:
                 traffic = json.load(open(tpath)).get("kernels", {})
             except Exception:

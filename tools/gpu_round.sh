@@ -12,6 +12,8 @@ echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 echo "== bench"
 timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 2 ${BENCH_ARGS:-} 2>&1 | tail -3 | tee gpurun_out/bench.log
+echo "== bench KITTI 1241x376 / 2000 features (BASELINE.json configs[4] shape, one GPU's share)"
+timeout 600 python bench.py --steps ${KITTI_STEPS:-3} --warmup 1 --rows 376 --cols 1241 --nfeatures 2000 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_kitti.log
 echo "== rocprof"
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o orb -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/rocprof.log" 2>&1
 cd "$OLDPWD"
