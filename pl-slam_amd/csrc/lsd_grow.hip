@@ -294,6 +294,14 @@ __device__ __forceinline__ double lsd_chain_add(const GrowCtx& c, double acc, in
 
 // region2rect() + get_theta().  The weighted sums are accumulated in region order (lsd_chain_add) so the doubles
 // are bit-identical to the sequential reference; the extents are min/max (exact).
+// double sincos out of line: the library routine's argument reduction is register hungry, and k_lsd_grow's occupancy
+// is bounded by its VGPR count
+__device__ __attribute__((noinline)) D2 lsd_sincos(double t) {
+  D2 r;
+  sincos(t, &r.y, &r.x);   // x = cos, y = sin
+  return r;
+}
+
 __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, double prec, LsdRect* rec) {
   const int lane = c.lane;
   double acc = 0;
@@ -338,8 +346,8 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
                                          : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
   theta *= kDegToRads;
   if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += kPI;
-  double dx, dy;
-  sincos(theta, &dy, &dx);
+  const D2 cs = lsd_sincos(theta);
+  const double dx = cs.x, dy = cs.y;
   double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
   for (int i = lane; i < cnt; i += 64) {
     const uint32_t p = c.reg[i];
@@ -418,7 +426,12 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
 }
 
 // flsd(): one wavefront per frame, seeds in pseudo-order, sequential semantics.
-__global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
+#if defined(PLH_GROW_WAVES)   // experiment switch: cap the VGPR budget for PLH_GROW_WAVES wavefronts per SIMD
+#define PLH_GROW_ATTR __attribute__((amdgpu_waves_per_eu(PLH_GROW_WAVES)))
+#else
+#define PLH_GROW_ATTR
+#endif
+__global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   const int b = blockIdx.x, lane = threadIdx.x;
   GrowCtx c;
@@ -447,61 +460,83 @@ __global__ void __launch_bounds__(64) k_lsd_grow(LineDeviceArgs a) {
   const int nbq = nbr < 4 ? nbr : nbr + 1;
   const int ndy = nbq / 3 - 1, ndx = nbq - (nbq / 3) * 3 - 1;
   int nseg = 0;
+  // LDS tables that keep the seed scan and the prefetched neighbourhoods out of the registers (the wavefront's VGPR
+  // count decides how many frames are resident): the 64 seeds of a scan, and per lane the first-step record
+  uint32_t* tabP = (uint32_t*)(smem + LSD_RING * 4);   // packed coordinates
+  uint32_t* tabQ = tabP + 64;
+  float* tabA = (float*)(tabQ + 64);                   // angle, seed cos / sin
+  float* tabC = tabA + 64;
+  float* tabS = tabC + 64;
+  LsdPix* fstPx = (LsdPix*)(tabS + 64);                // [64] neighbour records of the batch's seeds (lane group t = seed t)
+  uint32_t* fstIdx = (uint32_t*)(fstPx + 64);          // [64] linear index, 0xffffffff = out of bounds / no seed
+  uint32_t* fstPk = fstIdx + 64;
+  int* batchSk = (int*)(fstPk + 64);                   // [8] scan lane of the batch's t-th seed
   for (int sbase = 0; sbase < nOrd; sbase += 64) {
     // 64 seeds per scan: one coalesced load + one parallel `used` test; the survivors' own records (angle, seed
     // cos/sin) are fetched by their scan lanes, all at once
-    const int si = sbase + lane;
-    const uint32_t seedP = si < nOrd ? ord[si] : 0u;
-    const uint32_t seedL = pk_lin(c, seedP);
-    PLH_WAVE_SYNC();
-    LsdPix sPx;
-    sPx.angf = 0.f; sPx.cs = 0.f; sPx.sn = 0.f; sPx.q = LSD_USED;
-    float2 sCS;
-    sCS.x = 0.f; sCS.y = 0.f;
-    if (si < nOrd) {
-      sPx = c.G[seedL];
-      sCS = c.S[seedL];
+    unsigned long long fm;
+    {
+      const int si = sbase + lane;
+      const uint32_t seedP = si < nOrd ? ord[si] : 0u;
+      const uint32_t seedL = pk_lin(c, seedP);
+      LsdPix sPx;
+      sPx.angf = 0.f; sPx.cs = 0.f; sPx.sn = 0.f; sPx.q = LSD_USED;
+      float2 sCS;
+      sCS.x = 0.f; sCS.y = 0.f;
+      if (si < nOrd) {
+        sPx = c.G[seedL];
+        sCS = c.S[seedL];
+      }
+      fm = __ballot(!(sPx.q & LSD_USED));
+      PLH_WAVE_SYNC();
+      tabP[lane] = seedP; tabQ[lane] = sPx.q; tabA[lane] = sPx.angf; tabC[lane] = sCS.x; tabS[lane] = sCS.y;
+      PLH_WAVE_SYNC();
     }
-    const bool alive = !(sPx.q & LSD_USED);
-    unsigned long long fm = __ballot(alive);
-    const float sAng = sPx.angf;
     bool dirtySeed = false, dirtyFst = false;   // a region has been grown since this scan / since fst was fetched
     while (fm) {
       // up to 8 surviving seeds at a time: lane group t prefetches the 8 neighbours of the t-th of them
-      int skv = 0, mySk = 0, nb = 0;
-      for (; nb < 8 && fm; nb++) {
-        const int k = __ffsll((long long)fm) - 1;
-        fm &= fm - 1;
-        if (grp == nb) mySk = k;
-        if (lane == nb) skv = k;
-      }
-      LsdCand fst;
-      fst.inb = false; fst.nidx = 0; fst.npk = 0;
-      fst.px.angf = 0.f; fst.px.cs = 0.f; fst.px.sn = 0.f; fst.px.q = 0;
+      int nb = 0;
       {
-        const uint32_t sp = __shfl(seedP, mySk);
-        const int xx = pk_x(sp) + ndx, yy = pk_y(sp) + ndy;
-        if (grp < nb && xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
-          fst.inb = true;
-          fst.nidx = (uint32_t)(yy * c.spitch + xx);
-          fst.npk = (uint32_t)xx | ((uint32_t)yy << 16);
-          fst.px = c.G[fst.nidx];
+        int mySk = 0;
+        for (; nb < 8 && fm; nb++) {
+          const int k = __ffsll((long long)fm) - 1;
+          fm &= fm - 1;
+          if (grp == nb) mySk = k;
         }
+        PLH_WAVE_SYNC();
+        if (nbr == 0) batchSk[grp] = mySk;
+        const uint32_t sp = tabP[mySk];
+        const int xx = pk_x(sp) + ndx, yy = pk_y(sp) + ndy;
+        LsdPix px;
+        px.angf = 0.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
+        uint32_t nidx = 0xffffffffu;
+        if (grp < nb && xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
+          nidx = (uint32_t)(yy * c.spitch + xx);
+          px = c.G[nidx];
+        }
+        fstPx[lane] = px; fstIdx[lane] = nidx; fstPk[lane] = (uint32_t)xx | ((uint32_t)yy << 16);
+        PLH_WAVE_SYNC();
       }
       dirtyFst = false;
       for (int t = 0; t < nb; t++) {
-        const int sk = (int)bcast_u32((unsigned)skv, t);
-        uint32_t seedPk = bcast_u32(seedP, sk);
-        uint32_t seed = bcast_u32(seedL, sk);
-        unsigned seedQ = bcast_u32(sPx.q, sk);
+        const int sk = (int)bcast_u32((unsigned)batchSk[t], 0);
+        uint32_t seedPk = bcast_u32(tabP[sk], 0);
+        uint32_t seed = pk_lin(c, seedPk);
+        unsigned seedQ = bcast_u32(tabQ[sk], 0);
         PLH_WAVE_SYNC();
         // marks may have changed since the scan / the neighbourhood prefetch: re-read them (one round trip)
         if (dirtySeed) seedQ = c.G[seed].q;
-        if (dirtyFst && grp == t && fst.inb) fst.px.q = c.G[fst.nidx].q;
         if (seedQ & LSD_USED) continue;   // swallowed by a region grown since the scan
+        LsdCand fst;
+        fst.nidx = fstIdx[lane];
+        fst.inb = grp == t && fst.nidx != 0xffffffffu;
+        if (!fst.inb) fst.nidx = 0;
+        fst.npk = fstPk[lane];
+        fst.px = fstPx[lane];
+        if (dirtyFst && fst.inb) fst.px.q = c.G[fst.nidx].q;
         dirtySeed = true; dirtyFst = true;
         // region_grow -> region2rect -> [refine: tighter tolerance, re-grow -> region2rect -> reduce_region_radius]
-        float gAng = bcast_f32(sAng, sk), gCos = bcast_f32(sCS.x, sk), gSin = bcast_f32(sCS.y, sk);
+        float gAng = bcast_f32(tabA[sk], 0), gCos = bcast_f32(tabC[sk], 0), gSin = bcast_f32(tabS[sk], 0);
         double gPrec = a.prec, xc = 0, yc = 0;
         int phase = 0, firstGrp = t;
         bool emit = false;
@@ -901,6 +936,9 @@ extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsign
   return 0;
 }
 #endif
-size_t lsd_grow_lds_bytes(int spitch, int sh) { (void)spitch; (void)sh; return (size_t)LSD_RING * 4; }
+size_t lsd_grow_lds_bytes(int spitch, int sh) {   // ring + scan table + first-step records + batch index
+  (void)spitch; (void)sh;
+  return (size_t)LSD_RING * 4 + 5 * 64 * 4 + 64 * (16 + 4 + 4) + 8 * 4;
+}
 
 }  // namespace plh
