@@ -58,6 +58,16 @@ __device__ __forceinline__ float bcast_f32(float v, int l) {
 __device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 #endif
 
+// Per-wavefront state that lives in LDS rather than in registers (uniform values the compiler would keep in VGPRs):
+// the parameters of the current region_grow() call, the fitted rectangle, and the first-step prefetch tables.
+struct GrowState {
+  double* d;          // [0] prec of the call, [1..5] rectangle x1 y1 x2 y2 width
+  uint32_t* u;        // [0] seed (packed), [1] seed q, [2..4] bits of seed angle (degrees), cos, sin
+  const LsdPix* fstPx;      // [64] neighbour records of the batch's seeds (lane group t = seed t)
+  const uint32_t* fstIdx;   // [64] linear index, 0xffffffff = out of bounds / no seed
+  const uint32_t* fstPk;    // [64] packed coordinates
+};
+
 // isAligned() of cv::LineSegmentDetector for a defined pixel: |theta - a| folded at 3pi/2, compared with prec.
 __device__ __forceinline__ bool lsd_aligned(double theta, double a, double prec) {
   double n_theta = theta - a;
@@ -215,12 +225,15 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int q, int cnt, bool 
 // 8 neighbours prefetched in lane group `firstGrp` (firstGrp < 0: not prefetched).
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
 // reference's float fastAtan2 result).  All lanes hold identical (uniform) state.
-__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk, unsigned seedQ, float seedAngF, float seedCos,
-                                               float seedSin, double prec, const LsdCand& first, int firstGrp,
+__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, int firstGrp, bool dirtyFst,
                                                float* regAngOut) {
   const int lane = c.lane, g = lane >> 3;
-  const LsdTol tol = lsd_tol(prec);
-  float regAngF = seedAngF, sumdx = seedCos, sumdy = seedSin;
+  // the call's parameters come from LDS (uniform): nothing of the caller's state has to stay in registers across the loop
+  const uint32_t seedPk = bcast_u32(gs.u[0], 0);
+  const unsigned seedQ = bcast_u32(gs.u[1], 0);
+  const LsdTol tol = lsd_tol(bcast_f64(gs.d[0], 0));
+  float regAngF = bcast_f32(__uint_as_float(gs.u[2]), 0), sumdx = bcast_f32(__uint_as_float(gs.u[3]), 0),
+        sumdy = bcast_f32(__uint_as_float(gs.u[4]), 0);
   const uint32_t seed = pk_lin(c, seedPk);
   PLH_WAVE_SYNC();
   if (lane == 0) {
@@ -233,9 +246,15 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, uint32_t seedPk
   PLH_WAVE_SYNC();
   if (firstGrp >= 0) {
     const unsigned long long pt1 = PF_NOW();
-    // first.px.q was re-read after the previous region finished: > qThresh also rejects marked pixels? no -- the mark
-    // is bit 31, so test it explicitly
-    const bool cand = g == firstGrp && first.inb && !(first.px.q & LSD_USED) && first.px.q > c.qThresh;
+    // the seed's 8 neighbours were prefetched into LDS by lane group firstGrp; their marks may have changed since
+    LsdCand first;
+    first.nidx = gs.fstIdx[lane];
+    first.inb = g == firstGrp && first.nidx != 0xffffffffu;
+    if (!first.inb) first.nidx = 0;
+    first.npk = gs.fstPk[lane];
+    first.px = gs.fstPx[lane];
+    if (dirtyFst && first.inb) first.px.q = c.G[first.nidx].q;
+    const bool cand = first.inb && !(first.px.q & LSD_USED) && first.px.q > c.qThresh;
     lsd_resolve(c, cand, first, false, tol, sumdx, sumdy, regAngF, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
     i = 1;
@@ -302,7 +321,7 @@ __device__ __attribute__((noinline)) D2 lsd_sincos(double t) {
   return r;
 }
 
-__device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, double prec, LsdRect* rec) {
+__device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, double prec, double* rec) {
   const int lane = c.lane;
   double acc = 0;
   for (int base = 0; base < cnt; base += 64) {
@@ -361,17 +380,21 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     l_max = fmax(l_max, __shfl_xor(l_max, m)); l_min = fmin(l_min, __shfl_xor(l_min, m));
     w_max = fmax(w_max, __shfl_xor(w_max, m)); w_min = fmin(w_min, __shfl_xor(w_min, m));
   }
-  rec->x1 = x + l_min * dx; rec->y1 = y + l_min * dy;
-  rec->x2 = x + l_max * dx; rec->y2 = y + l_max * dy;
-  rec->width = w_max - w_min;
-  if (rec->width < 1.0) rec->width = 1.0;
+  PLH_WAVE_SYNC();
+  if (lane == 0) {   // rec[] is in LDS: x1 y1 x2 y2 width
+    rec[0] = x + l_min * dx; rec[1] = y + l_min * dy;
+    rec[2] = x + l_max * dx; rec[3] = y + l_max * dy;
+    const double width = w_max - w_min;
+    rec[4] = width < 1.0 ? 1.0 : width;
+  }
+  PLH_WAVE_SYNC();
 }
 
 __device__ __forceinline__ double dist_sq(double x1, double y1, double x2, double y2) {
   return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
 }
-__device__ __forceinline__ double rect_density(int cnt, const LsdRect& r) {
-  return (double)cnt / (sqrt(dist_sq(r.x1, r.y1, r.x2, r.y2)) * r.width);
+__device__ __forceinline__ double rect_density(int cnt, const double* r) {
+  return (double)cnt / (sqrt(dist_sq(r[0], r[1], r[2], r[3])) * r[4]);
 }
 
 // One iteration of reduce_region_radius(): drop every point farther than sqrt(radSq) from reg[0].
@@ -471,6 +494,11 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
   uint32_t* fstIdx = (uint32_t*)(fstPx + 64);          // [64] linear index, 0xffffffff = out of bounds / no seed
   uint32_t* fstPk = fstIdx + 64;
   int* batchSk = (int*)(fstPk + 64);                   // [8] scan lane of the batch's t-th seed
+  GrowState gs;
+  gs.d = (double*)(batchSk + 8);
+  gs.u = (uint32_t*)(gs.d + 6);
+  gs.fstPx = fstPx; gs.fstIdx = fstIdx; gs.fstPk = fstPk;
+  double* rec = gs.d + 1;
   for (int sbase = 0; sbase < nOrd; sbase += 64) {
     // 64 seeds per scan: one coalesced load + one parallel `used` test; the survivors' own records (angle, seed
     // cos/sin) are fetched by their scan lanes, all at once
@@ -527,42 +555,38 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
         // marks may have changed since the scan / the neighbourhood prefetch: re-read them (one round trip)
         if (dirtySeed) seedQ = c.G[seed].q;
         if (seedQ & LSD_USED) continue;   // swallowed by a region grown since the scan
-        LsdCand fst;
-        fst.nidx = fstIdx[lane];
-        fst.inb = grp == t && fst.nidx != 0xffffffffu;
-        if (!fst.inb) fst.nidx = 0;
-        fst.npk = fstPk[lane];
-        fst.px = fstPx[lane];
-        if (dirtyFst && fst.inb) fst.px.q = c.G[fst.nidx].q;
-        dirtySeed = true; dirtyFst = true;
         // region_grow -> region2rect -> [refine: tighter tolerance, re-grow -> region2rect -> reduce_region_radius]
-        float gAng = bcast_f32(tabA[sk], 0), gCos = bcast_f32(tabC[sk], 0), gSin = bcast_f32(tabS[sk], 0);
-        double gPrec = a.prec, xc = 0, yc = 0;
-        int phase = 0, firstGrp = t;
+        PLH_WAVE_SYNC();
+        if (lane == 0) {
+          gs.d[0] = a.prec;
+          gs.u[0] = seedPk; gs.u[1] = seedQ;
+          gs.u[2] = __float_as_uint(tabA[sk]); gs.u[3] = __float_as_uint(tabC[sk]); gs.u[4] = __float_as_uint(tabS[sk]);
+        }
+        PLH_WAVE_SYNC();
+        int phase = 0;
         bool emit = false;
-        LsdRect rec;
         for (;;) {
           float regAngF;
           const unsigned long long pg0 = PF_NOW();
-          int cnt = lsd_region_grow(c, seedPk, seedQ, gAng, gCos, gSin, gPrec, fst, firstGrp, &regAngF);
+          int cnt = lsd_region_grow(c, gs, phase == 0 ? t : -1, dirtyFst, &regAngF);
+          dirtySeed = true; dirtyFst = true;
           const unsigned long long pg1 = PF_NOW();
           PF_ADD(c, 2, pg1 - pg0);
           if (cnt < (phase == 0 ? a.minRegSize : 2)) break;
           const double reg_angle = (double)regAngF * kDegToRads;
           __syncthreads();   // queue stores visible to every lane
-          lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
+          lsd_region2rect(c, cnt, reg_angle, a.prec, rec);
           const unsigned long long pg2 = PF_NOW();
           PF_ADD(c, 5, pg2 - pg1);
           double density = rect_density(cnt, rec);
           if (!(density < a.densityTh)) { emit = true; break; }
+          const uint32_t cPk = c.reg[0];   // refine() and reduce_region_radius() work around reg[0]
+          const double xc = (double)pk_x(cPk), yc = (double)pk_y(cPk);
           if (phase == 0) {   // refine(): tolerance from the angle spread near the seed, everything un-marked
-            seedPk = c.reg[0];
-            seed = pk_lin(c, seedPk);
-            xc = (double)pk_x(seedPk); yc = (double)pk_y(seedPk);
-            const LsdPix g0 = c.G[seed];
-            const float2 s0 = c.S[seed];
-            seedQ = g0.q & ~LSD_USED;
-            const double ang_c = pix_angle(g0);
+            const uint32_t cLin = pk_lin(c, cPk);
+            const LsdPix g0 = c.G[cLin];
+            const float2 s0 = c.S[cLin];
+            const double ang_c = pix_angle(g0), width = rec[4];
             double acc = 0;
             int n = 0;
             for (int base = 0; base < cnt; base += 64) {
@@ -574,7 +598,7 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
                 const uint32_t li = pk_lin(c, p);
                 LsdPix gp = c.G[li];
                 c.G[li].q = gp.q & ~LSD_USED;
-                if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < rec.width) {
+                if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < width) {
                   flag = true;
                   ang_d = angle_diff_signed(pix_angle(gp), ang_c);
                 }
@@ -587,33 +611,35 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
             }
             const double sum = bcast_f64(acc, 0), s_sum = bcast_f64(acc, 1);
             const double mean_angle = sum / (double)n;
-            gPrec = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-            gAng = g0.angf; gCos = s0.x; gSin = s0.y;
-            phase = 1; firstGrp = -1;
+            PLH_WAVE_SYNC();
+            if (lane == 0) {   // parameters of the second region_grow()
+              gs.d[0] = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+              gs.u[0] = cPk; gs.u[1] = g0.q & ~LSD_USED;
+              gs.u[2] = __float_as_uint(g0.angf); gs.u[3] = __float_as_uint(s0.x); gs.u[4] = __float_as_uint(s0.y);
+            }
+            phase = 1;
             __syncthreads();
             PF_ADD(c, 6, PF_NOW() - pg2);
             continue;
           }
           // reduce_region_radius()
-          const double r1 = dist_sq(xc, yc, rec.x1, rec.y1), r2 = dist_sq(xc, yc, rec.x2, rec.y2);
+          const double r1 = dist_sq(xc, yc, rec[0], rec[1]), r2 = dist_sq(xc, yc, rec[2], rec[3]);
           double radSq = r1 > r2 ? r1 : r2;
           emit = true;
           while (density < a.densityTh) {
             radSq *= 0.75 * 0.75;
             cnt = lsd_reduce_radius_step(c, cnt, xc, yc, radSq);
             if (cnt < 2) { emit = false; break; }
-            lsd_region2rect(c, cnt, reg_angle, a.prec, &rec);
+            lsd_region2rect(c, cnt, reg_angle, a.prec, rec);
             density = rect_density(cnt, rec);
           }
           PF_ADD(c, 6, PF_NOW() - pg2);
           break;
         }
         if (!emit) continue;
-        rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
-        rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
         if (lane == 0 && nseg < a.segCap) {
-          segs[nseg * 4 + 0] = (float)rec.x1; segs[nseg * 4 + 1] = (float)rec.y1;
-          segs[nseg * 4 + 2] = (float)rec.x2; segs[nseg * 4 + 3] = (float)rec.y2;
+          segs[nseg * 4 + 0] = (float)((rec[0] + 0.5) / 0.8); segs[nseg * 4 + 1] = (float)((rec[1] + 0.5) / 0.8);
+          segs[nseg * 4 + 2] = (float)((rec[2] + 0.5) / 0.8); segs[nseg * 4 + 3] = (float)((rec[3] + 0.5) / 0.8);
         }
         nseg++;
       }
@@ -938,7 +964,7 @@ extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsign
 #endif
 size_t lsd_grow_lds_bytes(int spitch, int sh) {   // ring + scan table + first-step records + batch index
   (void)spitch; (void)sh;
-  return (size_t)LSD_RING * 4 + 5 * 64 * 4 + 64 * (16 + 4 + 4) + 8 * 4;
+  return (size_t)LSD_RING * 4 + 5 * 64 * 4 + 64 * (16 + 4 + 4) + 8 * 4 + 6 * 8 + 8 * 4;
 }
 
 }  // namespace plh
