@@ -622,16 +622,24 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
             PF_ADD(c, 6, PF_NOW() - pg2);
             continue;
           }
-          // reduce_region_radius()
-          const double r1 = dist_sq(xc, yc, rec[0], rec[1]), r2 = dist_sq(xc, yc, rec[2], rec[3]);
-          double radSq = r1 > r2 ? r1 : r2;
+          // reduce_region_radius(); the squared radius is carried in LDS (gs.d[0] is free now), the centre and the region
+          // angle are recomputed, so that only the point count stays in registers across region2rect
+          {
+            const double r1 = dist_sq(xc, yc, rec[0], rec[1]), r2 = dist_sq(xc, yc, rec[2], rec[3]);
+            PLH_WAVE_SYNC();
+            if (lane == 0) gs.d[0] = r1 > r2 ? r1 : r2;
+            PLH_WAVE_SYNC();
+          }
           emit = true;
-          while (density < a.densityTh) {
-            radSq *= 0.75 * 0.75;
-            cnt = lsd_reduce_radius_step(c, cnt, xc, yc, radSq);
+          const float regAngS = bcast_f32(regAngF, 0);
+          while (rect_density(cnt, rec) < a.densityTh) {
+            const uint32_t oPk = c.reg[0];
+            const double radSq = gs.d[0] * (0.75 * 0.75);
+            PLH_WAVE_SYNC();
+            if (lane == 0) gs.d[0] = radSq;
+            cnt = lsd_reduce_radius_step(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
             if (cnt < 2) { emit = false; break; }
-            lsd_region2rect(c, cnt, reg_angle, a.prec, rec);
-            density = rect_density(cnt, rec);
+            lsd_region2rect(c, cnt, (double)regAngS * kDegToRads, a.prec, rec);
           }
           PF_ADD(c, 6, PF_NOW() - pg2);
           break;
