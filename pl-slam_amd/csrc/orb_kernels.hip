@@ -35,41 +35,57 @@ __device__ __forceinline__ const uint8_t* level_ptr(const OrbDeviceArgs& a, cons
 
 // ---------------------------------------------------------------------------------------------
 // Pyramid: one level-to-level bilinear downscale, OpenCV fixed-point semantics.
-// grid (ceil(pitch/256), ceil(h/4), batch), block (64,4); each thread produces 4 pixels = one
-// aligned 32-bit store.  Coefficient tables are built on the host in float exactly as cv::resize
-// does, so the device does integer work only.
+// grid (ceil(pitch/256), ceil(h/(4*PYR_ROWS)), batch), block (64,4); each thread produces 4 pixels (one aligned 32-bit
+// store) of PYR_ROWS consecutive rows: the column taps are fetched once, and the byte gathers of all the rows are in
+// flight together -- the kernel is bound by memory latency, so fewer and fatter wavefronts give the wave slots back to
+// the kernels it runs next to.  Coefficient tables are built on the host in float exactly as cv::resize does, so the
+// device does integer work only.
 // ---------------------------------------------------------------------------------------------
+constexpr int PYR_ROWS = 4;
 __global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
   const OrbLevel S = a.levels[l - 1];
   const OrbLevel D = a.levels[l];
   const int b = blockIdx.z;
   const int x4 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
-  const int y = (int)blockIdx.y * 4 + (int)threadIdx.y;
-  if (y >= D.h || x4 >= D.pitch) return;
+  const int y0 = ((int)blockIdx.y * 4 + (int)threadIdx.y) * PYR_ROWS;
+  if (y0 >= D.h || x4 >= D.pitch) return;
   const uint8_t* src = level_ptr(a, S, l - 1, b);
   uint8_t* dst = a.pyr + (long long)b * a.pyrFrameBytes + D.off;
-  const ResizeTap ty = a.ytab[D.ytabOff + y];
-  const int sy0 = min(max((int)ty.ofs, 0), S.h - 1);
-  const int sy1 = min(max((int)ty.ofs + 1, 0), S.h - 1);
-  const uint8_t* r0 = src + (long long)sy0 * S.pitch;
-  const uint8_t* r1 = src + (long long)sy1 * S.pitch;
-  const int b0 = ty.a0, b1 = ty.a1;
-  uint32_t out = 0;
+  ResizeTap tx[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int x = x4 + k;
-    if (x < D.w) {
-      const ResizeTap tx = a.xtab[D.xtabOff + x];
-      int s0 = r0[tx.ofs] * tx.a0, s1 = r1[tx.ofs] * tx.a0;
-      if (tx.a1) {
-        s0 += r0[tx.ofs + 1] * tx.a1;
-        s1 += r1[tx.ofs + 1] * tx.a1;
-      }
-      const int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
-      out |= (uint32_t)(v & 255) << (8 * k);
-    }
+    tx[k].ofs = 0; tx[k].a0 = 0; tx[k].a1 = 0;
+    if (x4 + k < D.w) tx[k] = a.xtab[D.xtabOff + x4 + k];
   }
-  *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + x4) = out;
+  ResizeTap ty[PYR_ROWS];
+#pragma unroll
+  for (int r = 0; r < PYR_ROWS; r++) ty[r] = a.ytab[D.ytabOff + min(y0 + r, D.h - 1)];
+  uint32_t out[PYR_ROWS];
+#pragma unroll
+  for (int r = 0; r < PYR_ROWS; r++) {
+    const int sy0 = min(max((int)ty[r].ofs, 0), S.h - 1);
+    const int sy1 = min(max((int)ty[r].ofs + 1, 0), S.h - 1);
+    const uint8_t* r0 = src + (long long)sy0 * S.pitch;
+    const uint8_t* r1 = src + (long long)sy1 * S.pitch;
+    const int b0 = ty[r].a0, b1 = ty[r].a1;
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (x4 + k < D.w) {
+        int s0 = r0[tx[k].ofs] * tx[k].a0, s1 = r1[tx[k].ofs] * tx[k].a0;
+        if (tx[k].a1) {
+          s0 += r0[tx[k].ofs + 1] * tx[k].a1;
+          s1 += r1[tx[k].ofs + 1] * tx[k].a1;
+        }
+        const int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+        o |= (uint32_t)(v & 255) << (8 * k);
+      }
+    }
+    out[r] = o;
+  }
+#pragma unroll
+  for (int r = 0; r < PYR_ROWS; r++)
+    if (y0 + r < D.h) *reinterpret_cast<uint32_t*>(dst + (long long)(y0 + r) * D.pitch + x4) = out[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -804,7 +820,7 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
 // host-callable launchers (kept in this translation unit so the kernels stay file-local)
 // ---------------------------------------------------------------------------------------------
 void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, hipStream_t s) {
-  dim3 grid((pitch / 4 + 63) / 64, (h + 3) / 4, a.batch), block(64, 4);
+  dim3 grid((pitch / 4 + 63) / 64, (h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), a.batch), block(64, 4);
   hipLaunchKernelGGL(k_pyr_down, grid, block, 0, s, a, l);
 }
 size_t fast_strip_lds_bytes(int width, int ch) {   // image tile + score tile of k_fast_strips (width = xEnd - x0)
