@@ -115,78 +115,112 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
 }
 
 // cv::resize INTER_LINEAR (fixed point), one thread per 4 output pixels.  dPitch must be a multiple of 4.
+constexpr int RESIZE_ROWS = 4;   // rows per thread: the column taps are fetched once and 4x the gathers are in flight
 __global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst,
                                                    long long dStride, int dPitch, int dw, int dh, const ResizeTap* xtab,
                                                    const ResizeTap* ytab) {
   const int b = blockIdx.z;
   const int x4 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
-  const int y = (int)blockIdx.y * 4 + (int)threadIdx.y;
-  if (y >= dh || x4 >= dPitch) return;
+  const int y0 = ((int)blockIdx.y * 4 + (int)threadIdx.y) * RESIZE_ROWS;
+  if (y0 >= dh || x4 >= dPitch) return;
   const uint8_t* S = src + (long long)b * sStride;
-  const ResizeTap ty = ytab[y];
-  const int sy0 = min(max((int)ty.ofs, 0), sh - 1), sy1 = min(max((int)ty.ofs + 1, 0), sh - 1);
-  const uint8_t* r0 = S + (long long)sy0 * sPitch;
-  const uint8_t* r1 = S + (long long)sy1 * sPitch;
-  uint32_t out = 0;
+  ResizeTap tx[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int x = x4 + k;
-    if (x < dw) {
-      const ResizeTap tx = xtab[x];
-      int s0 = r0[tx.ofs] * tx.a0, s1 = r1[tx.ofs] * tx.a0;
-      if (tx.a1) { s0 += r0[tx.ofs + 1] * tx.a1; s1 += r1[tx.ofs + 1] * tx.a1; }
-      const int v = ((((int)ty.a0 * (s0 >> 4)) >> 16) + (((int)ty.a1 * (s1 >> 4)) >> 16) + 2) >> 2;
-      out |= (uint32_t)(v & 255) << (8 * k);
-    }
+    tx[k].ofs = 0; tx[k].a0 = 0; tx[k].a1 = 0;
+    if (x4 + k < dw) tx[k] = xtab[x4 + k];
   }
-  *reinterpret_cast<uint32_t*>(dst + (long long)b * dStride + (long long)y * dPitch + x4) = out;
+  ResizeTap ty[RESIZE_ROWS];
+#pragma unroll
+  for (int r = 0; r < RESIZE_ROWS; r++) ty[r] = ytab[min(y0 + r, dh - 1)];
+  uint32_t out[RESIZE_ROWS];
+#pragma unroll
+  for (int r = 0; r < RESIZE_ROWS; r++) {
+    const int sy0 = min(max((int)ty[r].ofs, 0), sh - 1), sy1 = min(max((int)ty[r].ofs + 1, 0), sh - 1);
+    const uint8_t* r0 = S + (long long)sy0 * sPitch;
+    const uint8_t* r1 = S + (long long)sy1 * sPitch;
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (x4 + k < dw) {
+        int s0 = r0[tx[k].ofs] * tx[k].a0, s1 = r1[tx[k].ofs] * tx[k].a0;
+        if (tx[k].a1) { s0 += r0[tx[k].ofs + 1] * tx[k].a1; s1 += r1[tx[k].ofs + 1] * tx[k].a1; }
+        const int v = ((((int)ty[r].a0 * (s0 >> 4)) >> 16) + (((int)ty[r].a1 * (s1 >> 4)) >> 16) + 2) >> 2;
+        o |= (uint32_t)(v & 255) << (8 * k);
+      }
+    }
+    out[r] = o;
+  }
+#pragma unroll
+  for (int r = 0; r < RESIZE_ROWS; r++)
+    if (y0 + r < dh) *reinterpret_cast<uint32_t*>(dst + (long long)b * dStride + (long long)(y0 + r) * dPitch + x4) = out[r];
 }
 
 // ---------------------------------------------------------------------------------------------
 // ll_angle(): level-line field (packed gx,gy, see line_dev.h), padding columns cleared, per-frame max gradient.
 // ---------------------------------------------------------------------------------------------
+// Block (64,4): 4 rows x 256 columns, 4 horizontally adjacent pixels per thread (two aligned dword loads per row).
 __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   __shared__ unsigned s_max;
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-  if (threadIdx.x == 0) s_max = 0;
+  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+  if (threadIdx.x == 0 && threadIdx.y == 0) s_max = 0;
   __syncthreads();
-  if (x < a.spitch) {
+  if (x4 < a.spitch && y < a.sh) {
     const uint8_t* I = a.scaled + (long long)b * a.scaledStride;
-    LsdPix px;
-    px.angf = -1024.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
-    float2 seed;
-    seed.x = 0.f; seed.y = 0.f;
-    if (x < a.sw - 1 && y < a.sh - 1) {
-      const int p00 = I[(long long)y * a.spitch + x], p01 = I[(long long)y * a.spitch + x + 1];
-      const int p10 = I[(long long)(y + 1) * a.spitch + x], p11 = I[(long long)(y + 1) * a.spitch + x + 1];
-      const int DA = p11 - p00, BC = p01 - p10;
-      const int gx = DA + BC, gy = DA - BC;
-      px.q = (unsigned)(gx * gx + gy * gy);
-      if (px.q > a.qThresh) {
-        px.angf = fast_atan2_deg((float)gx, (float)(-gy));
-        // seed terms: float(cos(ad)), float(sin(ad)) of the double angle ad; region increments: float(cos(af)),
-        // float(sin(af)) of af = float(ad).  One double sincos serves both: af = ad - d with |d| <= 2^-22, and
-        // cos(ad - d) = c (1 - d^2/2) + s d, sin(ad - d) = s (1 - d^2/2) - c d hold to O(d^3) < 1e-19, far below the
-        // double ulp the direct evaluation carries itself.
-        const double ad = (double)px.angf * kDegToRads;
-        double sd, cd;
-        sincos(ad, &sd, &cd);
-        seed.x = (float)cd;
-        seed.y = (float)sd;
-        const float af = (float)ad;
-        const double d = ad - (double)af, h = 1.0 - 0.5 * d * d;
-        px.cs = (float)(cd * h + sd * d);
-        px.sn = (float)(sd * h - cd * d);
-        atomicMax(&s_max, px.q);
+    // pixels x4 .. x4+4 of rows y and y+1 (the row below the last one and the dword beyond the pitch are never used)
+    unsigned long long r0 = 0, r1 = 0;
+    {
+      const unsigned* p0 = reinterpret_cast<const unsigned*>(I + (long long)y * a.spitch + x4);
+      const bool more = x4 + 4 < a.spitch;
+      r0 = p0[0] | ((unsigned long long)(more ? p0[1] : 0u) << 32);
+      if (y < a.sh - 1) {
+        const unsigned* p1 = reinterpret_cast<const unsigned*>(I + (long long)(y + 1) * a.spitch + x4);
+        r1 = p1[0] | ((unsigned long long)(more ? p1[1] : 0u) << 32);
       }
     }
-    const long long o = (long long)b * a.scaledStride + (long long)y * a.spitch + x;
-    reinterpret_cast<LsdPix*>(a.pix)[o] = px;
-    reinterpret_cast<float2*>(a.seedcs)[o] = seed;
-    a.scr[o] = px.q;   // compact copy of q for the seed ordering (scr is free until region growing)
+    unsigned qmax = 0;
+    const long long o = (long long)b * a.scaledStride + (long long)y * a.spitch + x4;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+      const int x = x4 + k;
+      LsdPix px;
+      px.angf = -1024.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
+      float2 seed;
+      seed.x = 0.f; seed.y = 0.f;
+      if (x < a.sw - 1 && y < a.sh - 1) {
+        const int p00 = (int)((r0 >> (8 * k)) & 255), p01 = (int)((r0 >> (8 * k + 8)) & 255);
+        const int p10 = (int)((r1 >> (8 * k)) & 255), p11 = (int)((r1 >> (8 * k + 8)) & 255);
+        const int DA = p11 - p00, BC = p01 - p10;
+        const int gx = DA + BC, gy = DA - BC;
+        px.q = (unsigned)(gx * gx + gy * gy);
+        if (px.q > a.qThresh) {
+          px.angf = fast_atan2_deg((float)gx, (float)(-gy));
+          // seed terms: float(cos(ad)), float(sin(ad)) of the double angle ad; region increments: float(cos(af)),
+          // float(sin(af)) of af = float(ad).  One double sincos serves both: af = ad - d with |d| <= 2^-22, and
+          // cos(ad - d) = c (1 - d^2/2) + s d, sin(ad - d) = s (1 - d^2/2) - c d hold to O(d^3) < 1e-19, far below the
+          // double ulp the direct evaluation carries itself.
+          const double ad = (double)px.angf * kDegToRads;
+          double sd, cd;
+          sincos(ad, &sd, &cd);
+          seed.x = (float)cd;
+          seed.y = (float)sd;
+          const float af = (float)ad;
+          const double d = ad - (double)af, h = 1.0 - 0.5 * d * d;
+          px.cs = (float)(cd * h + sd * d);
+          px.sn = (float)(sd * h - cd * d);
+          qmax = max(qmax, px.q);
+        }
+      }
+      if (x < a.spitch) {
+        reinterpret_cast<LsdPix*>(a.pix)[o + k] = px;
+        reinterpret_cast<float2*>(a.seedcs)[o + k] = seed;
+        a.scr[o + k] = px.q;   // compact copy of q for the seed ordering (scr is free until region growing)
+      }
+    }
+    if (qmax) atomicMax(&s_max, qmax);
   }
   __syncthreads();
-  if (threadIdx.x == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);
+  if (threadIdx.x == 0 && threadIdx.y == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);
 }
 
 // One 1024-thread block per frame: stable counting sort of the DEFINED pixels by bin (descending), raster
@@ -283,11 +317,11 @@ void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* ds
 }
 void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst, long long dStride, int dPitch, int dw,
                    int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, hipStream_t s) {
-  hipLaunchKernelGGL(k_resize_u8, dim3((dPitch / 4 + 63) / 64, (dh + 3) / 4, batch), dim3(64, 4), 0, s, src, sStride, sPitch, sh,
+  hipLaunchKernelGGL(k_resize_u8, dim3((dPitch / 4 + 63) / 64, (dh + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), batch), dim3(64, 4), 0, s, src, sStride, sPitch, sh,
                      dst, dStride, dPitch, dw, dh, xtab, ytab);
 }
 void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_lsd_grad, dim3((a.spitch + 255) / 256, a.sh, a.batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_lsd_grad, dim3((a.spitch + 255) / 256, (a.sh + 3) / 4, a.batch), dim3(64, 4), 0, s, a);
 }
 void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lsd_order, dim3(a.batch), dim3(1024), (size_t)(16 * LSD_NBINS + 1024) * 4, s, a);
