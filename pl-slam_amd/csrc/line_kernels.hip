@@ -22,20 +22,39 @@
 namespace plh {
 
 // ---------------------------------------------------------------------------------------------
+// Block (64,4): 4 rows x 256 columns, 4 adjacent pixels per thread: the 8 map floats are one 32-byte run, the 16 byte
+// gathers are in flight together and the result leaves as one dword when the address allows.
 __global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-  if (x >= a.w) return;
+  const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+  if (x4 >= a.w || y >= a.h) return;
   const uint8_t* src = a.img + (long long)b * a.imgStride;
-  const float mx = a.mapxy[((long long)y * a.w + x) * 2], my = a.mapxy[((long long)y * a.w + x) * 2 + 1];
-  const int sx = cv_round(mx * 32.f), sy = cv_round(my * 32.f);
-  const int ix = sx >> 5, iy = sy >> 5, ax = sx & 31, ay = sy & 31;
-  auto P = [&](int yy, int xx) -> int {
-    return (xx >= 0 && xx < a.w && yy >= 0 && yy < a.h) ? (int)src[(long long)yy * a.w + xx] : 0;
-  };
-  const int s = (32 - ax) * (32 - ay) * 32 * P(iy, ix) + ax * (32 - ay) * 32 * P(iy, ix + 1) +
-                (32 - ax) * ay * 32 * P(iy + 1, ix) + ax * ay * 32 * P(iy + 1, ix + 1);
-  int v = (s + (1 << 14)) >> 15;
-  a.undist[(long long)b * a.fullStride + (long long)y * a.w + x] = (uint8_t)(v > 255 ? 255 : v);
+  const float* mp = a.mapxy + ((long long)y * a.w + x4) * 2;
+  const int nk = min(4, a.w - x4);
+  float m[8];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    m[2 * k] = 0.f; m[2 * k + 1] = 0.f;
+    if (k < nk) { m[2 * k] = mp[2 * k]; m[2 * k + 1] = mp[2 * k + 1]; }
+  }
+  unsigned out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int sx = cv_round(m[2 * k] * 32.f), sy = cv_round(m[2 * k + 1] * 32.f);
+    const int ix = sx >> 5, iy = sy >> 5, ax = sx & 31, ay = sy & 31;
+    auto P = [&](int yy, int xx) -> int {
+      return (xx >= 0 && xx < a.w && yy >= 0 && yy < a.h) ? (int)src[(long long)yy * a.w + xx] : 0;
+    };
+    const int s = (32 - ax) * (32 - ay) * 32 * P(iy, ix) + ax * (32 - ay) * 32 * P(iy, ix + 1) +
+                  (32 - ax) * ay * 32 * P(iy + 1, ix) + ax * ay * 32 * P(iy + 1, ix + 1);
+    const int v = (s + (1 << 14)) >> 15;
+    out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
+  }
+  uint8_t* o = a.undist + (long long)b * a.fullStride + (long long)y * a.w + x4;
+  if (nk == 4 && (((size_t)o) & 3) == 0) {
+    *reinterpret_cast<unsigned*>(o) = out;
+  } else {
+    for (int k = 0; k < nk; k++) o[k] = (uint8_t)(out >> (8 * k));
+  }
 }
 
 // Separable 7-tap Q8 blur; 64x16 output tile per block, input tile (+3 halo, REFLECT_101) staged in LDS with aligned
@@ -241,17 +260,26 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
   for (int i = tid; i < 16 * LSD_NBINS; i += 1024) hist[i] = 0;
   __syncthreads();
-  for (int base = c0; base < c1; base += 64) {
-    const int i = base + lane;
+  // pass 1: histogram; order is irrelevant here, so every lane takes 4 consecutive pixels (16-byte loads / stores;
+  // chunk bounds are multiples of 64)
+  for (int base = c0; base < c1; base += 256) {
+    const int i = base + lane * 4;
     if (i < c1) {
-      const unsigned q = Q[i];
-      unsigned bp1 = 0;
-      if (q > a.qThresh) {
-        const int bin = (int)(q_modgrad(q) * bin_coef);
-        atomicAdd(&hist[wv * LSD_NBINS + bin], 1);
-        bp1 = (unsigned)bin + 1u;
+      const uint4 q4 = *reinterpret_cast<const uint4*>(Q + i);
+      const unsigned qq[4] = {q4.x, q4.y, q4.z, q4.w};
+      unsigned bb[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        bb[k] = 0;
+        if (qq[k] > a.qThresh) {
+          const int bin = (int)(q_modgrad(qq[k]) * bin_coef);
+          atomicAdd(&hist[wv * LSD_NBINS + bin], 1);
+          bb[k] = (unsigned)bin + 1u;
+        }
       }
-      BIN[i] = bp1;
+      uint4 o4;
+      o4.x = bb[0]; o4.y = bb[1]; o4.z = bb[2]; o4.w = bb[3];
+      *reinterpret_cast<uint4*>(BIN + i) = o4;
     }
   }
   __syncthreads();
@@ -277,9 +305,13 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   }
   __syncthreads();
   const unsigned long long lt = lanemask_lt();
+  // pass 2: lane order = raster order inside a 64-pixel group; the next group's bins are requested before this one
+  // is ranked
+  unsigned nextBp1 = c0 + lane < c1 ? BIN[c0 + lane] : 0u;
   for (int base = c0; base < c1; base += 64) {
     const int i = base + lane;
-    const unsigned bp1 = i < c1 ? BIN[i] : 0u;
+    const unsigned bp1 = nextBp1;
+    nextBp1 = i + 64 < c1 ? BIN[i + 64] : 0u;
     const bool active = bp1 != 0u;
     const unsigned bin = bp1 - 1u;
     unsigned long long same = __ballot(active);
@@ -306,7 +338,7 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
 // host-callable launchers (stage 1: image preparation + level-line field + seed ordering)
 // ---------------------------------------------------------------------------------------------
 void launch_remap(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_remap_u8, dim3((a.w + 255) / 256, a.h, a.batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_remap_u8, dim3((a.w + 255) / 256, (a.h + 3) / 4, a.batch), dim3(64, 4), 0, s, a);
 }
 void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst, long long dStride, int dPitch, int w, int h,
                   int batch, const int taps[7], hipStream_t s) {
