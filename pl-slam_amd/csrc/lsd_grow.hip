@@ -860,19 +860,33 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
     float sCorY0 = -dL1 * halfWidth - dL0 * halfHeight + midY;
     for (int r = 0; r < lane; r++) { sCorX0 -= dL1; sCorY0 += dL0; }
     float sCorX = sCorX0, sCorY = sCorY0;
-    for (short wID = 0; wID < lengthOfLSP; wID++) {
-      int tc = (int)(short)roundf(sCorX);
-      const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
-      tc = (int)(short)roundf(sCorY);
-      const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
-      const uint32_t g = D[(long long)yCor * a.w + xCor];
-      const short dx = (short)g_x(g), dy = (short)g_y(g);
-      const float gDL = dx * dL0 + dy * dL1;
-      const float gDO = dx * dO0 + dy * dO1;
-      if (gDL > 0) pL += gDL; else nL -= gDL;
-      if (gDO > 0) pO += gDO; else nO -= gDO;
-      sCorX += dL0;
-      sCorY += dL1;
+    // the walk's addresses do not depend on the data: 8 gathers are issued together, then accumulated in walk order
+    // (coordinates and sums advance by the same float additions, in the same order, as the one-pixel-at-a-time loop)
+    for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
+      uint32_t g[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        g[k] = 0;
+        if (w0 + k < lengthOfLSP) {
+          int tc = (int)(short)roundf(sCorX);
+          const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
+          tc = (int)(short)roundf(sCorY);
+          const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+          g[k] = D[(long long)yCor * a.w + xCor];
+          sCorX += dL0;
+          sCorY += dL1;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (w0 + k < lengthOfLSP) {
+          const short dx = (short)g_x(g[k]), dy = (short)g_y(g[k]);
+          const float gDL = dx * dL0 + dy * dL1;
+          const float gDO = dx * dO0 + dy * dO1;
+          if (gDL > 0) pL += gDL; else nL -= gDL;
+          if (gDO > 0) pO += gDO; else nO -= gDO;
+        }
+      }
     }
     const float cg = coef[21 + lane];
     pL = cg * pL; nL = cg * nL; pO = cg * pO; nO = cg * nO;
