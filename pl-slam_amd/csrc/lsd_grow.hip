@@ -104,6 +104,31 @@ __device__ __forceinline__ bool lsd_aligned_f(float thF, float aF, const LsdTol&
   return r;
 }
 
+// A wave mask used as a per-lane predicate: the SGPR pair feeds v_cndmask / exec directly (no v_cmp), the emulator
+// tests the lane's bit.
+#if defined(HIPEMU)
+#define LSD_INV_BALLOT(c, m) ((((m) >> (c).lane) & 1ull) != 0)
+#else
+#define LSD_INV_BALLOT(c, m) __builtin_amdgcn_inverse_ballot_w64(m)
+#endif
+
+// lsd_aligned_f for a whole step, as wave masks: every compare result is used as the 64-bit mask it already is and the
+// set logic runs on the scalar unit.  `act` = lanes whose answer matters; only they can trigger the exact double path.
+__device__ __forceinline__ unsigned long long lsd_aligned_mask(const GrowCtx& c, float thF, float aF, const LsdTol& t,
+                                                              unsigned long long act) {
+  float d = fabsf(thF - aF);
+  const unsigned long long nearFold = wballot(fabsf(d - 270.f) < 1e-2f);
+  if (d > 270.f) d = fabsf(d - 360.f);
+  unsigned long long r = wballot(d < t.lo);
+  const unsigned long long ex = ((~r & wballot(d <= t.hi)) | nearFold) & act;   // d >= lo  <=>  !(d < lo): angles are finite
+  if (ex) {
+    bool e = false;
+    if (LSD_INV_BALLOT(c, ex)) e = lsd_aligned((double)thF * kDegToRads, (double)aF * kDegToRads, t.prec);
+    r = (r & ~ex) | (wballot(e) & ex);
+  }
+  return r & act;
+}
+
 // One step's candidates: lane order == the reference's examination order (queue point, then yy, then xx).
 struct LsdCand {
   LsdPix px;
@@ -125,19 +150,16 @@ struct LsdCand {
 //      front of it were taken on exact states, so they are the reference's), and repeats from there.
 // Mispredictions only happen for pixels within the step's angle drift of the tolerance boundary.
 // Returns the mask of the lanes whose pixel was accepted.
-__device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, bool cand, const LsdCand& cd, bool mayDup,
-                                                          const LsdTol& tol, float& sumdx, float& sumdy, float& regAngF,
-                                                          int& cnt) {
-  const int lane = c.lane;
+__device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsigned long long rem, const LsdCand& cd,
+                                                          bool mayDup, const LsdTol& tol, float& sumdx, float& sumdy,
+                                                          float& regAngF, int& cnt) {
+  // rem = mask of the candidate lanes; all bookkeeping below is on 64-bit masks (scalar unit)
   unsigned long long accAll = 0;
-  unsigned long long rem = wballot(cand);
   PF_ADD(c, 10, __popcll(rem));
   if (!rem) return 0;
   const unsigned long long ltMask = lanemask_lt();
   while (rem) {
-    const bool inRem = (rem >> lane) & 1ull;
-    const bool pred = inRem && lsd_aligned_f(regAngF, cd.px.angf, tol);
-    const unsigned long long P = wballot(pred);
+    const unsigned long long P = lsd_aligned_mask(c, regAngF, cd.px.angf, tol, rem);
     if (!P) break;   // the state cannot change any more: every remaining candidate is rejected on the exact angle
     PF_ADD(c, 12, 1);
     float preX = sumdx, preY = sumdy;
@@ -146,14 +168,14 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, bool
       const int k = __ffsll((long long)m) - 1;
       m &= m - 1;
       acc |= 1ull << k;
+      const unsigned long long above = ~((2ull << k) - 1ull);   // lanes behind lane k
       if (mayDup) {
-        const uint32_t nk = bcast_u32(cd.nidx, k);
-        const unsigned long long dup = wballot(inRem && cd.nidx == nk) & ~((2ull << k) - 1ull);
+        const unsigned long long dup = wballot(cd.nidx == bcast_u32(cd.nidx, k)) & rem & above;
         m &= ~dup;
         canc |= dup;
       }
       const float ck = bcast_f32(cd.px.cs, k), sk = bcast_f32(cd.px.sn, k);
-      if (lane > k) { preX += ck; preY += sk; }
+      if (LSD_INV_BALLOT(c, above)) { preX += ck; preY += sk; }
     }
     const float postX = preX + cd.px.cs, postY = preY + cd.px.sn;
     const float angPost = fast_atan2_deg(postY, postX);
@@ -161,10 +183,9 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, bool
     const int prev = below ? 63 - __clzll((long long)below) : 0;
     float angPrev = __shfl(angPost, prev);
     if (!below) angPrev = regAngF;
-    const bool d = lsd_aligned_f(angPrev, cd.px.angf, tol);
-    const bool e = (acc >> lane) & 1ull;
-    const bool live = inRem && !((canc >> lane) & 1ull);
-    const unsigned long long mism = wballot(live && d != e);
+    const unsigned long long live = rem & ~canc;
+    const unsigned long long D = lsd_aligned_mask(c, angPrev, cd.px.angf, tol, live);
+    const unsigned long long mism = (D ^ acc) & live;
     unsigned long long A = acc;
     int f = 64;
     if (mism) {
@@ -173,7 +194,7 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, bool
       if (!((acc >> f) & 1ull)) A |= 1ull << f;   // predicted rejected, really accepted
     }
     if (A) {
-      if ((A >> lane) & 1ull) {
+      if (LSD_INV_BALLOT(c, A)) {
         const int slot = cnt + __popcll(A & ltMask);
         c.reg[slot] = cd.npk;
         c.ring[slot & (LSD_RING - 1)] = cd.npk;
@@ -213,7 +234,7 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int q, int cnt, bool 
   }
   const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
   const bool inb = valid && xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh;
-  nidx = inb ? (uint32_t)(yy * c.spitch + xx) : 0u;
+  nidx = inb ? (uint32_t)(yy * c.spitch + xx) : (uint32_t)(c.sw - 1);   // (sw-1, 0): never defined (k_lsd_grad), never marked
   npk = (uint32_t)xx | ((uint32_t)yy << 16);
   return inb;
 }
@@ -254,8 +275,9 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     first.npk = gs.fstPk[lane];
     first.px = gs.fstPx[lane];
     if (dirtyFst && first.inb) first.px.q = c.G[first.nidx].q;
-    const bool cand = first.inb && !(first.px.q & LSD_USED) && first.px.q > c.qThresh;
-    lsd_resolve(c, cand, first, false, tol, sumdx, sumdy, regAngF, cnt);
+    // `used` is bit 31: one signed compare covers "not marked and above the gradient threshold"
+    const unsigned long long candM = wballot(first.inb) & wballot((int)first.px.q > (int)c.qThresh);
+    lsd_resolve(c, candM, first, false, tol, sumdx, sumdy, regAngF, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
     i = 1;
   }
@@ -271,10 +293,11 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   while (i < cnt) {
     const unsigned long long pt0 = PF_NOW();
     const int m = min(LSD_PTS, cnt - i);
-    const bool cand = cur.inb && !(cur.px.q & LSD_USED) && cur.px.q > c.qThresh;
+    // lanes with nothing to examine loaded the NOTDEF pixel (sw-1, 0), and `used` is bit 31: one signed compare decides
+    const unsigned long long candM = wballot((int)cur.px.q > (int)c.qThresh);
     const unsigned long long pt1 = PF_NOW();
     PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
-    lsd_resolve(c, cand, cur, true, tol, sumdx, sumdy, regAngF, cnt);
+    lsd_resolve(c, candM, cur, true, tol, sumdx, sumdy, regAngF, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1);
     i += m;
     // the next step's records, requested after this step's marks were stored (a wavefront observes its own stores);
