@@ -224,17 +224,19 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
 
 // Addressing of one neighbour lane: lane 8g+n looks at neighbour n (yy outer, xx inner, centre skipped) of queue
 // point q = base+g.  Returns whether the lane has an in-bounds pixel to examine.
-__device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int q, int cnt, bool valid, uint32_t& nidx, uint32_t& npk) {
-  const int n = c.lane & 7;
+__device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint32_t& nidx, uint32_t& npk) {
+  const int n = c.lane & 7, q = i + (c.lane >> 3);
   const int nb = n < 4 ? n : n + 1;
   const int dy = nb / 3 - 1, dx = nb - (nb / 3) * 3 - 1;
   uint32_t p = c.ring[q & (LSD_RING - 1)];
-  if (wballot(valid && cnt - q > LSD_RING)) {   // the queue ran ahead of the LDS mirror (rare; kept a real branch)
-    if (valid && cnt - q > LSD_RING) p = *(volatile const uint32_t*)&c.reg[q];
+  if (cnt - i > LSD_RING) {   // the queue ran ahead of the LDS mirror (rare; uniform test, kept a real branch)
+    if (q < cnt && cnt - q > LSD_RING) p = *(volatile const uint32_t*)&c.reg[q];
   }
+  // Queue points are defined pixels, and k_lsd_grad never defines the last column / row: x + dx <= sw - 1 and
+  // y + dy <= sh - 1 always hold, only the -1 side can leave the image.
   const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
-  const bool inb = valid && xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh;
-  nidx = inb ? (uint32_t)(yy * c.spitch + xx) : (uint32_t)(c.sw - 1);   // (sw-1, 0): never defined (k_lsd_grad), never marked
+  const bool inb = q < cnt && (xx | yy) >= 0;
+  nidx = inb ? (uint32_t)(yy * c.spitch + xx) : (uint32_t)(c.sw - 1);   // (sw-1, 0): never defined, never marked
   npk = (uint32_t)xx | ((uint32_t)yy << 16);
   return inb;
 }
@@ -288,7 +290,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   }
   PLH_WAVE_SYNC();
   LsdCand cur;
-  cur.inb = lsd_addr(c, i + g, cnt, i + g < cnt, cur.nidx, cur.npk);
+  cur.inb = lsd_addr(c, i, cnt, cur.nidx, cur.npk);
   cur.px = c.G[cur.nidx];
   while (i < cnt) {
     const unsigned long long pt0 = PF_NOW();
@@ -303,7 +305,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     // the next step's records, requested after this step's marks were stored (a wavefront observes its own stores);
     // every lane loads (record 0 when it has nothing to examine) so the carried registers are simply overwritten
     PLH_WAVE_SYNC();
-    cur.inb = lsd_addr(c, i + g, cnt, i + g < cnt, cur.nidx, cur.npk);
+    cur.inb = lsd_addr(c, i, cnt, cur.nidx, cur.npk);
     cur.px = c.G[cur.nidx];
   }
   PF_ADD(c, 9, cnt);
