@@ -308,20 +308,31 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   // pass 2: lane order = raster order inside a 64-pixel group; the next group's bins are requested before this one
   // is ranked
   unsigned nextBp1 = c0 + lane < c1 ? BIN[c0 + lane] : 0u;
+  // a 64-pixel group never straddles a row (pitch and chunk bounds are multiples of 64): its row and first column are
+  // uniform and advance without divisions
+  int gy = c0 / a.spitch, gx = c0 - gy * a.spitch;
   for (int base = c0; base < c1; base += 64) {
     const int i = base + lane;
     const unsigned bp1 = nextBp1;
     nextBp1 = i + 64 < c1 ? BIN[i + 64] : 0u;
-    const bool active = bp1 != 0u;
+    const uint32_t coord = (uint32_t)(gx + lane) | ((uint32_t)gy << 16);
+    gx += 64;
+    if (gx >= a.spitch) { gx = 0; gy++; }
     const unsigned bin = bp1 - 1u;
-    unsigned long long same = __ballot(active);
-    if (!same) continue;
+    const unsigned long long act = wballot(bp1 != 0u);
+    if (!act) continue;
+    // lanes that differ from this lane in some bin bit: (ballot of bit k) xor (own bit k, spread over the word), or-ed
+    // over the ten bits -- compare results are used as the masks they are, the rest is 32-bit logic
+    unsigned dlo = 0, dhi = 0;
 #pragma unroll
     for (int k = 0; k < 10; k++) {
-      const bool bit = (bin >> k) & 1u;
-      const unsigned long long m = __ballot(active && bit);
-      same &= bit ? m : ~m;
+      const unsigned long long m = wballot((bin & (1u << k)) != 0u);
+      const unsigned mine = (unsigned)((int)(bin << (31 - k)) >> 31);
+      dlo |= (unsigned)m ^ mine;
+      dhi |= (unsigned)(m >> 32) ^ mine;
     }
+    const unsigned long long same = ~(((unsigned long long)dhi << 32) | dlo) & act;
+    const bool active = bp1 != 0u;
     PLH_WAVE_SYNC();
     int basep = 0;
     if (active) basep = hist[wv * LSD_NBINS + bin];
@@ -329,7 +340,7 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
     if (active) {
       const int rank = __popcll(same & lt);
       if (rank == 0) hist[wv * LSD_NBINS + bin] = basep + __popcll(same);
-      ord[basep + rank] = (uint32_t)(i % a.spitch) | ((uint32_t)(i / a.spitch) << 16);
+      ord[basep + rank] = coord;
     }
   }
 }

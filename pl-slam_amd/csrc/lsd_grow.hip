@@ -48,10 +48,7 @@ __device__ __forceinline__ uint32_t reg_get(const GrowCtx& c, int i, int cnt) {
 #if defined(HIPEMU)
 __device__ __forceinline__ float bcast_f32(float v, int l) { return __shfl(v, l); }
 __device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return __shfl(v, l); }
-__device__ __forceinline__ unsigned long long wballot(bool p) { return __ballot(p); }
 #else
-// the compare mask itself (HIP's __ballot materialises the predicate as an int first)
-__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ float bcast_f32(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }

@@ -47,6 +47,15 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 // cvRound: round-half-to-even (v_cvt_i32_f32 with the default RNE mode / v_rndne)
 __device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
 
+// Wave vote that returns the compare mask itself (HIP's __ballot materialises the predicate as an int first:
+// v_cndmask + v_cmp, 8 issue cycles per vote on gfx950).  Feed it direct comparisons and combine the masks with
+// scalar logic.
+#if defined(HIPEMU)
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __ballot(p); }
+#else
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#endif
+
 __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }
