@@ -307,20 +307,16 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   const unsigned long long lt = lanemask_lt();
   // pass 2: lane order = raster order inside a 64-pixel group; the next group's bins are requested before this one
   // is ranked
-  unsigned nextBp1 = c0 + lane < c1 ? BIN[c0 + lane] : 0u;
   // a 64-pixel group never straddles a row (pitch and chunk bounds are multiples of 64): its row and first column are
   // uniform and advance without divisions
   int gy = c0 / a.spitch, gx = c0 - gy * a.spitch;
-  for (int base = c0; base < c1; base += 64) {
-    const int i = base + lane;
-    const unsigned bp1 = nextBp1;
-    nextBp1 = i + 64 < c1 ? BIN[i + 64] : 0u;
+  auto rank_group = [&](unsigned bp1) {
     const uint32_t coord = (uint32_t)(gx + lane) | ((uint32_t)gy << 16);
     gx += 64;
     if (gx >= a.spitch) { gx = 0; gy++; }
     const unsigned bin = bp1 - 1u;
     const unsigned long long act = wballot(bp1 != 0u);
-    if (!act) continue;
+    if (!act) return;
     // lanes that differ from this lane in some bin bit: (ballot of bit k) xor (own bit k, spread over the word), or-ed
     // over the ten bits -- compare results are used as the masks they are, the rest is 32-bit logic
     unsigned dlo = 0, dhi = 0;
@@ -342,6 +338,24 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
       if (rank == 0) hist[wv * LSD_NBINS + bin] = basep + __popcll(same);
       ord[basep + rank] = coord;
     }
+  };
+  // Bins are fetched two groups ahead into three named registers that take turns (no copies): memory operations
+  // retire in order, so a load can only be waited for without also waiting for the scattered stores of the groups in
+  // between if younger operations have been issued behind it.  Loads are unconditional (index clamped, value masked
+  // afterwards) so that they sit in straight-line code.
+  const int last = npix - 1;
+  auto fetch = [&](int g0) { return BIN[min(g0 + lane, last)]; };
+  auto mask = [&](unsigned v, int g0) { return g0 + lane < c1 ? v : 0u; };
+  unsigned b0 = fetch(c0), b1 = fetch(c0 + 64), b2;
+  for (int base = c0; base < c1; base += 192) {
+    b2 = fetch(base + 128);
+    rank_group(mask(b0, base));
+    if (base + 64 >= c1) break;
+    b0 = fetch(base + 192);
+    rank_group(mask(b1, base + 64));
+    if (base + 128 >= c1) break;
+    b1 = fetch(base + 256);
+    rank_group(mask(b2, base + 128));
   }
 }
 
