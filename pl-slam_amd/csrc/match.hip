@@ -158,6 +158,23 @@ __global__ void __launch_bounds__(256) k_line_mutual(const int32_t* m1, const in
 // Phase B (wave 0): KeyFrame features in that order, strictly sequential because of the greedy
 // "already matched" skip (ORBmatcher.cc:240); the 64 lanes scan the Frame candidates of the node.
 // ---------------------------------------------------------------------------------------------
+// min over the wavefront, result uniform.  Hardware: row_shr 1/2/4/8 + row_bcast 15/31 DPP steps (register-to-register,
+// no LDS crossbar round trips) and one v_readlane; the emulator uses the butterfly.
+__device__ __forceinline__ int wave_min_i32(int v) {
+#if defined(HIPEMU)
+  for (int s = 32; s >= 1; s >>= 1) v = min(v, __shfl_xor(v, s));
+  return v;
+#else
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x118, 0xf, 0xf, false));   // row_shr:8: lane 15 of a row = row min
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
+
 __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1,
                                                        const uint8_t* valid1, const int* n1Arr, const uint8_t* desc2,
                                                        const float* angle2, const int32_t* node2, const int* n2Arr, int cap,
@@ -168,9 +185,12 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
   int* nd2 = nd1 + cap;
   int* snode2 = nd2 + cap;               // node id by sorted position (set 2)
   int* m2 = snode2 + cap;                // Frame feature -> KeyFrame feature
-  unsigned short* ord1 = (unsigned short*)(m2 + cap);
+  float* ang2 = (float*)(m2 + cap);      // angle of the Frame's keypoints (read at every accepted match)
+  unsigned short* ord1 = (unsigned short*)(ang2 + cap);
   unsigned short* ord2 = ord1 + cap;
-  unsigned char* bin2 = (unsigned char*)(ord2 + cap);
+  unsigned short* rlo = ord2 + cap;      // per sorted position of set 1: [rlo, rhi) = sorted positions of set 2 with
+  unsigned short* rhi = rlo + cap;       // the same node (empty for invalid / unusable features)
+  unsigned char* bin2 = (unsigned char*)(rhi + cap);
 
   const int pair = blockIdx.x, tid = threadIdx.x;
   const int n1 = n1Arr[pair], n2 = n2Arr[pair];
@@ -180,6 +200,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     nd2[i] = i < n2 ? node2[o + i] : -1;
     m2[i] = -1;
     bin2[i] = 255;
+    ang2[i] = (checkOri && i < n2) ? angle2[(o + i) * angStride] : 0.f;
   }
   __syncthreads();
   // invalid nodes (< 0) sort to the end: key = node<0 ? INT_MAX : node
@@ -203,6 +224,22 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     snode2[r] = k;
   }
   __syncthreads();
+  // candidate ranges of every KeyFrame feature, in parallel: the sequential walk below then only reads them
+  for (int r1 = tid; r1 < n1; r1 += 256) {
+    const int i = ord1[r1];
+    const int nd = nd1[i];
+    int lo = 0, hi2 = 0;
+    if (nd >= 0 && valid1[o + i]) {
+      int hi = n2;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (snode2[mid] < nd) lo = mid + 1; else hi = mid; }
+      int top = n2;
+      hi2 = lo;
+      while (hi2 < top) { const int mid = (hi2 + top) >> 1; if (snode2[mid] <= nd) hi2 = mid + 1; else top = mid; }
+    }
+    rlo[r1] = (unsigned short)lo;
+    rhi[r1] = (unsigned short)hi2;
+  }
+  __syncthreads();
   if (tid >= 64) return;
 
   const int lane = tid;
@@ -211,51 +248,78 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
   int nmatches = 0;
   const uint8_t* D1 = desc1 + o * 32;
   const uint8_t* D2 = desc2 + o * 32;
-  for (int r1 = 0; r1 < n1; r1++) {
-    const int i = ord1[r1];
-    const int nd = nd1[i];
-    if (nd < 0) break;                       // sorted: only invalid nodes follow
-    if (!valid1[o + i]) continue;
-    // [lo, hi) = sorted positions of set 2 with node == nd
-    int lo = 0, hi = n2;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (snode2[mid] < nd) lo = mid + 1; else hi = mid; }
-    int hi2 = lo, top = n2;
-    while (hi2 < top) { const int mid = (hi2 + top) >> 1; if (snode2[mid] <= nd) hi2 = mid + 1; else top = mid; }
-    if (lo >= hi2) continue;
-    const Desc256 dk = load_desc(D1 + (long long)i * 32);
+  // The walk is sequential (a match removes its Frame feature from every later search), but what a step READS from
+  // global memory does not depend on the matching state: the KeyFrame descriptor, its angle and the first 64 candidate
+  // descriptors of the NEXT feature are requested before the current one is decided.  Two named register sets take
+  // turns (no copies), all loads are unconditional (indices clamped).
+  struct Pre {
+    int i, lo, hi, f;
+    float a1;
+    Desc256 dk, df;
+  };
+  auto fetch = [&](int r1, Pre& p) {
+    const int rr = min(r1, max(n1 - 1, 0));
+    p.i = ord1[rr];
+    p.lo = rlo[rr];
+    p.hi = r1 < n1 ? (int)rhi[rr] : 0;
+    if (r1 >= n1) p.lo = 0;
+    p.f = ord2[min(p.lo + lane, max(n2 - 1, 0))];
+    p.dk = load_desc(D1 + (long long)p.i * 32);
+    p.df = load_desc(D2 + (long long)p.f * 32);
+    p.a1 = angle1[(o + p.i) * angStride];
+  };
+  auto step = [&](const Pre& p) {
+    const int lo = p.lo, hi2 = p.hi;
+    if (lo >= hi2) return;
     int b1 = 256, b2 = 256, p1 = 0x7fffffff;
-    for (int c = lo + lane; c < hi2; c += 64) {
+    {
+      const int c = lo + lane;
+      bool ok = c < hi2 && m2[p.f] < 0;
+      if (ok && valid2) ok = valid2[o + p.f] != 0;   // KeyFrame-KeyFrame form: pMP2 missing or bad (ORBmatcher.cc:628-632)
+      if (ok) { b1 = hamming256(p.dk.w, p.df.w); p1 = c; }
+    }
+    for (int c = lo + 64 + lane; c < hi2; c += 64) {   // more than 64 features under one node (rare)
       const int f = ord2[c];
       if (m2[f] >= 0) continue;
-      if (valid2 && !valid2[o + f]) continue;   // KeyFrame-KeyFrame form: pMP2 missing or bad (ORBmatcher.cc:628-632)
+      if (valid2 && !valid2[o + f]) continue;
       const Desc256 df = load_desc(D2 + (long long)f * 32);
-      const int d = hamming256(dk.w, df.w);
+      const int d = hamming256(p.dk.w, df.w);
       if (d < b1) { b2 = b1; b1 = d; p1 = c; }
       else if (d < b2) { b2 = d; }
     }
     // wave reduction: best = min (dist, position); second = min over everything except the winning element
-    int key = b1 < 256 ? ((b1 << 20) | (p1 - lo)) : 0x7fffffff;
-    int kmin = key;
-    for (int s = 32; s >= 1; s >>= 1) kmin = min(kmin, __shfl_xor(kmin, s));
+    const int key = b1 < 256 ? ((b1 << 20) | (p1 - lo)) : 0x7fffffff;
+    const int kmin = wave_min_i32(key);
+    if (kmin == 0x7fffffff) return;
     const bool winner = (key == kmin) && b1 < 256;
-    int second = winner ? b2 : b1;
-    for (int s = 32; s >= 1; s >>= 1) second = min(second, __shfl_xor(second, s));
-    if (kmin == 0x7fffffff) continue;
-    const int bestDist1 = kmin >> 20, bestPos = (kmin & 0xfffff) + lo, bestDist2 = second;
+    const int bestDist2 = wave_min_i32(winner ? b2 : b1);
+    const int bestDist1 = kmin >> 20, bestPos = (kmin & 0xfffff) + lo;
     if ((kfkf ? bestDist1 < thLow : bestDist1 <= thLow) && (float)bestDist1 < nnratio * (float)bestDist2) {
       const int bestF = ord2[bestPos];
       int bin = 255;
       if (checkOri) {
-        float rot = angle1[(o + i) * angStride] - angle2[(o + bestF) * angStride];
+        float rot = p.a1 - ang2[bestF];
         if (rot < 0.0f) rot += 360.0f;
         bin = (int)roundf(rot * factor);
         if (bin == 30) bin = 0;
         if (lane == bin) myHist++;
       }
       // every lane performs the same store (uniform values): later reads by any lane see it
-      m2[bestF] = i;
+      PLH_WAVE_SYNC();
+      m2[bestF] = p.i;
       bin2[bestF] = (unsigned char)bin;
+      PLH_WAVE_SYNC();
       nmatches++;
+    }
+  };
+  if (n1 > 0 && n2 > 0) {
+    Pre A, B;
+    fetch(0, A);
+    for (int r1 = 0; r1 < n1; r1 += 2) {
+      fetch(r1 + 1, B);
+      step(A);
+      fetch(r1 + 2, A);
+      step(B);
     }
   }
   PLH_WAVE_SYNC();
@@ -426,7 +490,7 @@ __global__ void __launch_bounds__(256) k_search_triangulation(const plh_keypoint
 
 static size_t tri_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
 
-static size_t bow_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
+static size_t bow_lds_bytes(int cap) { return (size_t)cap * (5 * 4 + 4 * 2 + 1) + 64; }
 
 }  // namespace plh
 
