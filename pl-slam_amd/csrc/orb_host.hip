@@ -11,7 +11,7 @@
 namespace plh {
 
 // launchers implemented in orb_kernels.hip
-void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, hipStream_t s);
+void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds, hipStream_t s);
 void launch_fast_strips(const OrbDeviceArgs& a, size_t lds, hipStream_t s);
 size_t fast_strip_lds_bytes(int width, int ch);
 constexpr int FAST_STRIP_MAX_W = 330;
@@ -161,6 +161,21 @@ plh_status build_plan(plh_orb* h) {
       resize_axis(h->levels[l - 1].w, L.w, true, h->xtab, &L.xmax);
       L.ytabOff = (int)h->ytab.size();
       resize_axis(h->levels[l - 1].h, L.h, false, h->ytab, nullptr);
+      // exact extent of the source tile behind any 256 x 16 output block (k_pyr_down stages it in LDS)
+      const int sw = h->levels[l - 1].w, sh = h->levels[l - 1].h;
+      int maxW = 0, maxH = 0;
+      for (int x0 = 0; x0 < L.w; x0 += 256) {
+        const int lo = h->xtab[L.xtabOff + x0].ofs & ~3;
+        const int hi = std::min((int)h->xtab[L.xtabOff + std::min(x0 + 255, L.w - 1)].ofs + 1, sw - 1);
+        maxW = std::max(maxW, hi - lo + 1);
+      }
+      for (int y0 = 0; y0 < L.h; y0 += 16) {
+        const int lo = std::min(std::max((int)h->ytab[L.ytabOff + y0].ofs, 0), sh - 1);
+        const int hi = std::min(std::max((int)h->ytab[L.ytabOff + std::min(y0 + 15, L.h - 1)].ofs + 1, 0), sh - 1);
+        maxH = std::max(maxH, hi - lo + 1);
+      }
+      L.pyrTP = align_up(maxW, 4);
+      L.pyrTR = maxH;
     }
     // ComputeKeyPointsOctTree, ORBextractor.cc:771-787
     L.minBX = ORB_EDGE_THRESHOLD - 3; L.minBY = L.minBX;
@@ -379,7 +394,7 @@ plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batc
   fill_args(h, d_imgs, (long long)frame_stride, batch, &a);
   prof_mark(h, 0, s);
   for (int l = 1; l < h->nlevels; l++) {
-    launch_pyr_down(a, l, h->levels[l].pitch, h->levels[l].h, s);
+    launch_pyr_down(a, l, h->levels[l].pitch, h->levels[l].h, (size_t)h->levels[l].pyrTP * h->levels[l].pyrTR, s);
     PLH_LAUNCH_CHECK();
   }
   prof_mark(h, 0, s);

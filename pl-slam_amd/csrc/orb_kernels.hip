@@ -35,39 +35,67 @@ __device__ __forceinline__ const uint8_t* level_ptr(const OrbDeviceArgs& a, cons
 
 // ---------------------------------------------------------------------------------------------
 // Pyramid: one level-to-level bilinear downscale, OpenCV fixed-point semantics.
-// grid (ceil(pitch/256), ceil(h/(4*PYR_ROWS)), batch), block (64,4); each thread produces 4 pixels (one aligned 32-bit
-// store) of PYR_ROWS consecutive rows: the column taps are fetched once, and the byte gathers of all the rows are in
-// flight together -- the kernel is bound by memory latency, so fewer and fatter wavefronts give the wave slots back to
-// the kernels it runs next to.  Coefficient tables are built on the host in float exactly as cv::resize does, so the
-// device does integer work only.
+// grid (ceil(pitch/256), ceil(h/16), batch), block (64,4) = a 256 x 16 output tile.  The source pixels behind the tile
+// (exact extent precomputed on the host: pyrTP x pyrTR, 7 KiB at scale 1.2) are staged in LDS with aligned dword loads;
+// every thread then produces 4 pixels (one aligned 32-bit store) of 4 consecutive rows, reading its taps from LDS.
+// (Gathering the taps straight from memory -- 4 byte loads per pixel -- ran at 350 Gpixel/s whatever the number of
+// loads in flight: bound by the vector-memory address path.)  Coefficient tables are built on the host in float
+// exactly as cv::resize does, so the device does integer work only.
 // ---------------------------------------------------------------------------------------------
 constexpr int PYR_ROWS = 4;
 __global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
   const OrbLevel S = a.levels[l - 1];
   const OrbLevel D = a.levels[l];
-  const int b = blockIdx.z;
-  const int x4 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
-  const int y0 = ((int)blockIdx.y * 4 + (int)threadIdx.y) * PYR_ROWS;
-  if (y0 >= D.h || x4 >= D.pitch) return;
+  const int b = blockIdx.z, tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+  const int xb = (int)blockIdx.x * 256, yb = (int)blockIdx.y * 16;
   const uint8_t* src = level_ptr(a, S, l - 1, b);
   uint8_t* dst = a.pyr + (long long)b * a.pyrFrameBytes + D.off;
+  const ResizeTap* xt = a.xtab + D.xtabOff;
+  const ResizeTap* yt = a.ytab + D.ytabOff;
+  const int TP = D.pyrTP;
+  // source extent of this tile (uniform)
+  const int xBase = xb < D.w ? (xt[xb].ofs & ~3) : 0;
+  const int xHi = xb < D.w ? min((int)xt[min(xb + 255, D.w - 1)].ofs + 1, S.w - 1) : -1;
+  const int syBase = min(max((int)yt[min(yb, D.h - 1)].ofs, 0), S.h - 1);
+  const int syHi = min(max((int)yt[min(yb + 15, D.h - 1)].ofs + 1, 0), S.h - 1);
+  const int nd = (xHi - xBase + 4) >> 2, nrows = syHi - syBase + 1;   // dwords per tile row (0 for an all-padding block)
+  for (int i = tid; i < nrows * nd; i += 256) {
+    const int r = i / nd, d = i - r * nd;
+    const int xs = xBase + 4 * d;
+    const uint8_t* rowp = src + (long long)(syBase + r) * S.pitch + xs;
+    const int m = (int)((size_t)rowp & 3);
+    unsigned v;
+    if (xs + 4 + (m ? 4 : 0) <= S.pitch) {   // the aligned dword (pair) stays inside the source row
+      const unsigned* ap = reinterpret_cast<const unsigned*>(rowp - m);
+      const unsigned lo = ap[0];
+      v = m ? (unsigned)(((((unsigned long long)ap[1]) << 32) | lo) >> (8 * m)) : lo;
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) v |= (unsigned)rowp[min(k, S.w - 1 - xs)] << (8 * k);
+    }
+    reinterpret_cast<unsigned*>(smem)[r * (TP >> 2) + d] = v;
+  }
+  __syncthreads();
+  const int x4 = xb + (int)threadIdx.x * 4;
+  const int y0 = yb + (int)threadIdx.y * PYR_ROWS;
+  if (y0 >= D.h || x4 >= D.pitch) return;
   ResizeTap tx[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    tx[k].ofs = 0; tx[k].a0 = 0; tx[k].a1 = 0;
-    if (x4 + k < D.w) tx[k] = a.xtab[D.xtabOff + x4 + k];
+    tx[k].ofs = (short)xBase; tx[k].a0 = 0; tx[k].a1 = 0;
+    if (x4 + k < D.w) tx[k] = xt[x4 + k];
   }
-  ResizeTap ty[PYR_ROWS];
-#pragma unroll
-  for (int r = 0; r < PYR_ROWS; r++) ty[r] = a.ytab[D.ytabOff + min(y0 + r, D.h - 1)];
-  uint32_t out[PYR_ROWS];
 #pragma unroll
   for (int r = 0; r < PYR_ROWS; r++) {
-    const int sy0 = min(max((int)ty[r].ofs, 0), S.h - 1);
-    const int sy1 = min(max((int)ty[r].ofs + 1, 0), S.h - 1);
-    const uint8_t* r0 = src + (long long)sy0 * S.pitch;
-    const uint8_t* r1 = src + (long long)sy1 * S.pitch;
-    const int b0 = ty[r].a0, b1 = ty[r].a1;
+    if (y0 + r >= D.h) break;
+    const ResizeTap ty = yt[y0 + r];
+    const int sy0 = min(max((int)ty.ofs, 0), S.h - 1);
+    const int sy1 = min(max((int)ty.ofs + 1, 0), S.h - 1);
+    const uint8_t* r0 = smem + (sy0 - syBase) * TP - xBase;
+    const uint8_t* r1 = smem + (sy1 - syBase) * TP - xBase;
+    const int b0 = ty.a0, b1 = ty.a1;
     uint32_t o = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -81,11 +109,8 @@ __global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
         o |= (uint32_t)(v & 255) << (8 * k);
       }
     }
-    out[r] = o;
+    *reinterpret_cast<uint32_t*>(dst + (long long)(y0 + r) * D.pitch + x4) = o;
   }
-#pragma unroll
-  for (int r = 0; r < PYR_ROWS; r++)
-    if (y0 + r < D.h) *reinterpret_cast<uint32_t*>(dst + (long long)(y0 + r) * D.pitch + x4) = out[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -819,9 +844,9 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (kept in this translation unit so the kernels stay file-local)
 // ---------------------------------------------------------------------------------------------
-void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, hipStream_t s) {
+void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds, hipStream_t s) {
   dim3 grid((pitch / 4 + 63) / 64, (h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), a.batch), block(64, 4);
-  hipLaunchKernelGGL(k_pyr_down, grid, block, 0, s, a, l);
+  hipLaunchKernelGGL(k_pyr_down, grid, block, lds, s, a, l);
 }
 size_t fast_strip_lds_bytes(int width, int ch) {   // image tile + score tile of k_fast_strips (width = xEnd - x0)
   const size_t TP = (size_t)((width + 8 + 3 + 3) & ~3) + 4;

@@ -26,6 +26,7 @@ struct OrbLevel {
   int nodeCap;                 // quad-tree node slots
   int xtabOff, ytabOff;        // resize tables (levels >= 1)
   int xmax;                    // first dx using the single-tap path (cv::resize)
+  int pyrTP, pyrTR;            // k_pyr_down source tile of a 256 x 16 output block: pitch (bytes, multiple of 4) and rows
   float scale;                 // mvScaleFactor[l]
   float kpSize;                // (int)(31 * mvScaleFactor[l])
 };
