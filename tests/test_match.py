@@ -107,7 +107,7 @@ def test_emu_line_search_double(plslam, oracle, synth, emu_lib):
 
 def test_emu_search_by_bow(plslam, oracle, synth, emu_lib):
     om = plslam.ORBmatcher(0.7, True, lib=emu_lib)
-    for seed, n, nodes in [(200, 300, 20), (201, 150, 5), (202, 64, 64)]:
+    for seed, n, nodes in [(200, 300, 20), (201, 150, 5), (202, 64, 64), (203, 200, 2)]:   # last: > 64 candidates per node
         kf, fr = _bow_sets(synth, seed, n, nodes)
         c, got = om.SearchByBoW(kf, fr)
         rc, ref = _oracle_bow(oracle, kf, fr, 50, 0.7, True)
