@@ -57,13 +57,16 @@ __global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
   }
 }
 
-// Separable 7-tap Q8 blur; 64x16 output tile per block, input tile (+3 halo, REFLECT_101) staged in LDS with aligned
-// dword loads (byte funnel for odd row addresses; byte-wise with reflection only in the image's edge columns).
-// Every thread produces 4 adjacent outputs per pass: 3 dword LDS reads -> 4 x 7 MACs -> one 8-byte row-sum store,
-// then 7 x 8-byte reads -> 4 x 7 MACs -> one dword of pixels.  Tile column j holds image column x0 - 4 + j.
+// Separable Q8 blur with 2R+1 taps (R = 3: general 7 taps; R = 2 when the outer taps are zero, which is the case for
+// both users: LSD's sigma 0.75 and LBD's 5x5); 64x16 output tile per block, input tile (+R halo rows, REFLECT_101)
+// staged in LDS with aligned dword loads (byte funnel for odd row addresses; byte-wise with reflection only in the
+// image's edge columns).  Every thread produces 4 adjacent outputs per pass: 3 dword LDS reads -> 4 x (2R+1) MACs -> one
+// 8-byte row-sum store, then (2R+1) x 8-byte reads -> 4 x (2R+1) MACs -> one dword of pixels.  Tile column j holds image
+// column x0 - 4 + j.
+template <int R>
 __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst,
                                                   long long dStride, int dPitch, int w, int h, Taps7 t) {
-  constexpr int TW = 64, TH = 16, IH = TH + 6, IP = TW + 8;   // 72-byte tile rows = 18 dwords
+  constexpr int TW = 64, TH = 16, IH = TH + 2 * R, IP = TW + 8;   // 72-byte tile rows = 18 dwords
   __shared__ unsigned tin[IH * IP / 4];
   __shared__ uint2 hb[IH * TW / 4];
   const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
   const bool interior = x0 >= 4 && x0 + TW + 8 <= w;   // the aligned dword pairs stay inside the row
   for (int i = tid; i < IH * (IP / 4); i += 256) {
     const int r = i / (IP / 4), d = i - r * (IP / 4);
-    const uint8_t* row = S + (long long)refl101(y0 - 3 + r, h) * sPitch;
+    const uint8_t* row = S + (long long)refl101(y0 - R + r, h) * sPitch;
     unsigned v;
     if (interior) {
       const uint8_t* p = row + x0 - 4 + 4 * d;
@@ -95,9 +98,12 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
     for (int k = 0; k < 4; k++) { q[k] = (A >> (8 * k)) & 255; q[4 + k] = (B >> (8 * k)) & 255; q[8 + k] = (Cc >> (8 * k)) & 255; }
     unsigned hs[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++)   // output column 4g+k reads tile columns 4g+k+1 .. 4g+k+7
-      hs[k] = (unsigned)(t.k[0] * q[k + 1] + t.k[1] * q[k + 2] + t.k[2] * q[k + 3] + t.k[3] * q[k + 4] + t.k[4] * q[k + 5] +
-                         t.k[5] * q[k + 6] + t.k[6] * q[k + 7]);
+    for (int k = 0; k < 4; k++) {   // output column 4g+k is tile column 4g+k+4: taps at tile columns 4g+k+4-R .. 4g+k+4+R
+      int acc = 0;
+#pragma unroll
+      for (int j = -R; j <= R; j++) acc += t.k[3 + j] * q[k + 4 + j];
+      hs[k] = (unsigned)acc;
+    }
     uint2 hw;
     hw.x = hs[0] | (hs[1] << 16);
     hw.y = hs[2] | (hs[3] << 16);
@@ -109,17 +115,18 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
     const int r = tid / (TW / 4), g = tid - r * (TW / 4);   // 16 rows x 16 groups = 256 threads
     const int x = x0 + 4 * g, y = y0 + r;
     if (x < w && y < h) {
-      uint2 wv[7];
+      uint2 wv[2 * R + 1];
 #pragma unroll
-      for (int k = 0; k < 7; k++) wv[k] = hb[(r + k) * (TW / 4) + g];
+      for (int k = 0; k < 2 * R + 1; k++) wv[k] = hb[(r + k) * (TW / 4) + g];
       unsigned out = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        auto f = [&](int tt) -> int {
+        int s = 0;
+#pragma unroll
+        for (int tt = 0; tt < 2 * R + 1; tt++) {
           const unsigned d = k < 2 ? wv[tt].x : wv[tt].y;
-          return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
-        };
-        const int s = t.k[0] * f(0) + t.k[1] * f(1) + t.k[2] * f(2) + t.k[3] * f(3) + t.k[4] * f(4) + t.k[5] * f(5) + t.k[6] * f(6);
+          s += t.k[3 - R + tt] * (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
+        }
         const int v = (s + (1 << 15)) >> 16;
         out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
       }
@@ -133,7 +140,6 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
   }
 }
 
-// cv::resize INTER_LINEAR (fixed point), one thread per 4 output pixels.  dPitch must be a multiple of 4.
 constexpr int RESIZE_ROWS = 4;   // rows per thread: the column taps are fetched once and 4x the gathers are in flight
 __global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst,
                                                    long long dStride, int dPitch, int dw, int dh, const ResizeTap* xtab,
@@ -369,8 +375,11 @@ void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* ds
                   int batch, const int taps[7], hipStream_t s) {
   Taps7 t;
   for (int i = 0; i < 7; i++) t.k[i] = taps[i];
-  hipLaunchKernelGGL(k_blur7_u8, dim3((w + 63) / 64, (h + 15) / 16, batch), dim3(256), 0, s, src, sStride, sPitch, dst, dStride,
-                     dPitch, w, h, t);
+  const dim3 grid((w + 63) / 64, (h + 15) / 16, batch);
+  if (taps[0] == 0 && taps[6] == 0)   // integer sums: dropping zero taps changes nothing
+    hipLaunchKernelGGL(k_blur7_u8<2>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, t);
+  else
+    hipLaunchKernelGGL(k_blur7_u8<3>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, t);
 }
 void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst, long long dStride, int dPitch, int dw,
                    int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, hipStream_t s) {
