@@ -11,8 +11,8 @@ namespace plh {
 void launch_remap(const LineDeviceArgs& a, hipStream_t s);
 void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst, long long dStride, int dPitch, int w, int h,
                   int batch, const int taps[7], hipStream_t s);
-void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst, long long dStride, int dPitch, int dw,
-                   int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, hipStream_t s);
+void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sw, int sh, uint8_t* dst, long long dStride, int dPitch, int dw,
+                   int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, int tileTP, int tileTR, hipStream_t s);
 void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s);
 void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s);
@@ -29,6 +29,7 @@ struct plh_line {
   int device, rows, cols, maxBatch;
   LineDeviceArgs a;   // template (pointers filled at create)
   int taps075[7], taps1[7];
+  int rszTP = 0, rszTR = 0;   // k_resize_u8 source tile of a 256 x 16 output block (pitch in bytes, rows)
   // device buffers
   uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dMask = nullptr;
   uint8_t* dPix = nullptr;
@@ -183,6 +184,20 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   std::vector<ResizeTap> xt, yt;
   resize_axis_scale(cols, a.sw, 0.8, true, xt);
   resize_axis_scale(rows, a.sh, 0.8, false, yt);
+  {   // exact extent of the source tile behind any 256 x 16 output block (k_resize_u8 stages it in LDS)
+    int maxW = 0, maxH = 0;
+    for (int x0 = 0; x0 < a.sw; x0 += 256) {
+      const int lo = xt[x0].ofs & ~3, hi = std::min((int)xt[std::min(x0 + 255, a.sw - 1)].ofs + 1, cols - 1);
+      maxW = std::max(maxW, hi - lo + 1);
+    }
+    for (int y0 = 0; y0 < a.sh; y0 += 16) {
+      const int lo = std::min(std::max((int)yt[y0].ofs, 0), rows - 1);
+      const int hi = std::min(std::max((int)yt[std::min(y0 + 15, a.sh - 1)].ofs + 1, 0), rows - 1);
+      maxH = std::max(maxH, hi - lo + 1);
+    }
+    h->rszTP = (maxW + 3) & ~3;
+    h->rszTR = maxH;
+  }
   // LBD weights: BinaryDescriptor ctor, binary_descriptor_custom.cpp:217-259 (integer divisions as written there)
   std::vector<float> coef(21 + 63);
   {
@@ -282,7 +297,8 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   line_prof_mark(h, 0, s);
   launch_blur7(src, srcStride, a.w, h->dTmpA, a.fullStride, a.w, a.w, a.h, batch, h->taps075, s);
   PLH_LAUNCH_CHECK();
-  launch_resize(h->dTmpA, a.fullStride, a.w, a.h, h->dScaled, a.scaledStride, a.spitch, a.sw, a.sh, batch, h->dXtab, h->dYtab, s);
+  launch_resize(h->dTmpA, a.fullStride, a.w, a.w, a.h, h->dScaled, a.scaledStride, a.spitch, a.sw, a.sh, batch, h->dXtab, h->dYtab,
+                h->rszTP, h->rszTR, s);
   PLH_LAUNCH_CHECK();
   PLH_HIP(hipMemsetAsync(h->dQmax, 0, (size_t)batch * 4, s));
   launch_lsd_grad(a, s);

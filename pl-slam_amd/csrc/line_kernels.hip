@@ -140,45 +140,68 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
   }
 }
 
-constexpr int RESIZE_ROWS = 4;   // rows per thread: the column taps are fetched once and 4x the gathers are in flight
-__global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst,
+// cv::resize(INTER_LINEAR) fixed point, same scheme as k_pyr_down: block (64,4) = a 256 x 16 output tile whose source
+// pixels (exact extent from the host tables: TP x TR) are staged in LDS with aligned dword loads (byte funnel for odd
+// row addresses); every thread produces 4 pixels of 4 consecutive rows from LDS taps.
+constexpr int RESIZE_ROWS = 4;
+__global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long sStride, int sPitch, int sw, int sh, uint8_t* dst,
                                                    long long dStride, int dPitch, int dw, int dh, const ResizeTap* xtab,
-                                                   const ResizeTap* ytab) {
-  const int b = blockIdx.z;
-  const int x4 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
-  const int y0 = ((int)blockIdx.y * 4 + (int)threadIdx.y) * RESIZE_ROWS;
-  if (y0 >= dh || x4 >= dPitch) return;
+                                                   const ResizeTap* ytab, int TP) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  const int b = blockIdx.z, tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+  const int xb = (int)blockIdx.x * 256, yb = (int)blockIdx.y * 16;
   const uint8_t* S = src + (long long)b * sStride;
+  const int xBase = xb < dw ? (xtab[xb].ofs & ~3) : 0;
+  const int xHi = xb < dw ? min((int)xtab[min(xb + 255, dw - 1)].ofs + 1, sw - 1) : -1;
+  const int syBase = min(max((int)ytab[min(yb, dh - 1)].ofs, 0), sh - 1);
+  const int syHi = min(max((int)ytab[min(yb + 15, dh - 1)].ofs + 1, 0), sh - 1);
+  const int nd = (xHi - xBase + 4) >> 2, nrows = syHi - syBase + 1;
+  for (int i = tid; i < nrows * nd; i += 256) {
+    const int r = i / nd, d = i - r * nd;
+    const int xs = xBase + 4 * d;
+    const uint8_t* rowp = S + (long long)(syBase + r) * sPitch + xs;
+    const int m = (int)((size_t)rowp & 3);
+    unsigned v;
+    if (xs + 4 + (m ? 4 : 0) <= sPitch) {   // the aligned dword (pair) stays inside the source row
+      const unsigned* ap = reinterpret_cast<const unsigned*>(rowp - m);
+      const unsigned lo = ap[0];
+      v = m ? (unsigned)(((((unsigned long long)ap[1]) << 32) | lo) >> (8 * m)) : lo;
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) v |= (unsigned)rowp[min(k, sw - 1 - xs)] << (8 * k);
+    }
+    reinterpret_cast<unsigned*>(smem)[r * (TP >> 2) + d] = v;
+  }
+  __syncthreads();
+  const int x4 = xb + (int)threadIdx.x * 4;
+  const int y0 = yb + (int)threadIdx.y * RESIZE_ROWS;
+  if (y0 >= dh || x4 >= dPitch) return;
   ResizeTap tx[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    tx[k].ofs = 0; tx[k].a0 = 0; tx[k].a1 = 0;
+    tx[k].ofs = (short)xBase; tx[k].a0 = 0; tx[k].a1 = 0;
     if (x4 + k < dw) tx[k] = xtab[x4 + k];
   }
-  ResizeTap ty[RESIZE_ROWS];
-#pragma unroll
-  for (int r = 0; r < RESIZE_ROWS; r++) ty[r] = ytab[min(y0 + r, dh - 1)];
-  uint32_t out[RESIZE_ROWS];
 #pragma unroll
   for (int r = 0; r < RESIZE_ROWS; r++) {
-    const int sy0 = min(max((int)ty[r].ofs, 0), sh - 1), sy1 = min(max((int)ty[r].ofs + 1, 0), sh - 1);
-    const uint8_t* r0 = S + (long long)sy0 * sPitch;
-    const uint8_t* r1 = S + (long long)sy1 * sPitch;
+    if (y0 + r >= dh) break;
+    const ResizeTap ty = ytab[y0 + r];
+    const int sy0 = min(max((int)ty.ofs, 0), sh - 1), sy1 = min(max((int)ty.ofs + 1, 0), sh - 1);
+    const uint8_t* r0 = smem + (sy0 - syBase) * TP - xBase;
+    const uint8_t* r1 = smem + (sy1 - syBase) * TP - xBase;
     uint32_t o = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (x4 + k < dw) {
         int s0 = r0[tx[k].ofs] * tx[k].a0, s1 = r1[tx[k].ofs] * tx[k].a0;
         if (tx[k].a1) { s0 += r0[tx[k].ofs + 1] * tx[k].a1; s1 += r1[tx[k].ofs + 1] * tx[k].a1; }
-        const int v = ((((int)ty[r].a0 * (s0 >> 4)) >> 16) + (((int)ty[r].a1 * (s1 >> 4)) >> 16) + 2) >> 2;
+        const int v = ((((int)ty.a0 * (s0 >> 4)) >> 16) + (((int)ty.a1 * (s1 >> 4)) >> 16) + 2) >> 2;
         o |= (uint32_t)(v & 255) << (8 * k);
       }
     }
-    out[r] = o;
+    *reinterpret_cast<uint32_t*>(dst + (long long)b * dStride + (long long)(y0 + r) * dPitch + x4) = o;
   }
-#pragma unroll
-  for (int r = 0; r < RESIZE_ROWS; r++)
-    if (y0 + r < dh) *reinterpret_cast<uint32_t*>(dst + (long long)b * dStride + (long long)(y0 + r) * dPitch + x4) = out[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -381,10 +404,10 @@ void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* ds
   else
     hipLaunchKernelGGL(k_blur7_u8<3>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, t);
 }
-void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sh, uint8_t* dst, long long dStride, int dPitch, int dw,
-                   int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, hipStream_t s) {
-  hipLaunchKernelGGL(k_resize_u8, dim3((dPitch / 4 + 63) / 64, (dh + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), batch), dim3(64, 4), 0, s, src, sStride, sPitch, sh,
-                     dst, dStride, dPitch, dw, dh, xtab, ytab);
+void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sw, int sh, uint8_t* dst, long long dStride, int dPitch,
+                   int dw, int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, int tileTP, int tileTR, hipStream_t s) {
+  hipLaunchKernelGGL(k_resize_u8, dim3((dPitch / 4 + 63) / 64, (dh + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), batch), dim3(64, 4),
+                     (size_t)tileTP * tileTR, s, src, sStride, sPitch, sw, sh, dst, dStride, dPitch, dw, dh, xtab, ytab, tileTP);
 }
 void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lsd_grad, dim3((a.spitch + 255) / 256, (a.sh + 3) / 4, a.batch), dim3(64, 4), 0, s, a);
