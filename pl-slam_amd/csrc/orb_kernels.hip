@@ -603,6 +603,24 @@ __global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) 
       const uint32_t* src = kbuf[sb] + st;
       uint32_t* dst = kbuf[sb ^ 1] + st;
       int tot[4] = {0, 0, 0, 0};
+      if (cnt <= 64) {   // most splits: one load serves the count and the scatter
+        int cls = -1;
+        uint32_t key = 0;
+        if (lane < cnt) {
+          key = src[lane];
+          const int xw = key_x(key) - lv.minBX, yw = key_y(key) - lv.minBY;
+          cls = (xw < bx) ? (yw < by ? 0 : 2) : (yw < by ? 1 : 3);
+        }
+        unsigned long long m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { m[k] = wballot(cls == k); tot[k] = __popcll(m[k]); }
+        const int r1 = tot[0], r2 = r1 + tot[1], r3 = r2 + tot[2];
+        if (cls >= 0) {
+          const unsigned long long mm = cls == 0 ? m[0] : (cls == 1 ? m[1] : (cls == 2 ? m[2] : m[3]));
+          const int rb = cls == 0 ? 0 : (cls == 1 ? r1 : (cls == 2 ? r2 : r3));
+          dst[rb + __popcll(mm & lanemask_lt())] = key;
+        }
+      } else {
       for (int base = 0; base < cnt; base += 64) {
         const int i = base + lane;
         int cls = -1;
@@ -631,6 +649,7 @@ __global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) 
           if (cls == k) dst[run[k] + __popcll(m & lanemask_lt())] = key;
           run[k] += __popcll(m);
         }
+      }
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) c4[k] = tot[k];
