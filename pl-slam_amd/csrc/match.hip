@@ -491,6 +491,21 @@ __global__ void __launch_bounds__(256) k_search_triangulation(const plh_keypoint
 static size_t tri_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
 
 static size_t bow_lds_bytes(int cap) { return (size_t)cap * (5 * 4 + 4 * 2 + 1) + 64; }
+// Dynamic LDS above 64 KiB has to be requested per kernel; gfx950 has 160 KiB per workgroup.
+template <typename K>
+static plh_status lds_request(K kernel, size_t bytes, const char* who) {
+  if (bytes > 160u * 1024u) {
+    set_error("%s: %zu bytes of LDS needed (capacity too large for one workgroup)", who, bytes);
+    return PLH_ERR_INVALID;
+  }
+  if (bytes > 64u * 1024u &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: cannot reserve %zu bytes of LDS", who, bytes);
+    return PLH_ERR_INVALID;
+  }
+  return PLH_OK;
+}
 
 }  // namespace plh
 
@@ -615,6 +630,7 @@ plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const float* 
     set_error("plh_orb_search_by_bow_batch_dev: invalid argument (cap must be in 1..6000)");
     return PLH_ERR_INVALID;
   }
+  if (lds_request(k_search_by_bow, bow_lds_bytes(cap), "SearchByBoW") != PLH_OK) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1, d_angle1,
                      d_node1, d_valid1, (const int*)d_n1, d_desc2, d_angle2, d_node2, (const int*)d_n2, cap, 1, th_low, nnratio,
                      check_ori, d_matches21, d_nmatches, (const uint8_t*)nullptr, 0);
@@ -635,6 +651,7 @@ plh_status plh_orb_search_by_bow_kp_batch_dev(const uint8_t* d_desc1, const plh_
     return PLH_ERR_INVALID;
   }
   static_assert(sizeof(plh_keypoint) == 28, "plh_keypoint layout");
+  if (lds_request(k_search_by_bow, bow_lds_bytes(cap), "SearchByBoW") != PLH_OK) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
                      reinterpret_cast<const float*>(d_kps1) + 3, d_node1, d_valid1, (const int*)d_n1, d_desc2,
                      reinterpret_cast<const float*>(d_kps2) + 3, d_node2, (const int*)d_n2, cap, 7, th_low, nnratio, check_ori,
@@ -655,6 +672,7 @@ plh_status plh_orb_search_by_bow_kfkf_batch_dev(const uint8_t* d_desc1, const pl
     set_error("plh_orb_search_by_bow_kfkf_batch_dev: invalid argument (cap must be in 1..6000)");
     return PLH_ERR_INVALID;
   }
+  if (lds_request(k_search_by_bow, bow_lds_bytes(cap), "SearchByBoW") != PLH_OK) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
                      reinterpret_cast<const float*>(d_kps1) + 3, d_node1, d_valid1, (const int*)d_n1, d_desc2,
                      reinterpret_cast<const float*>(d_kps2) + 3, d_node2, (const int*)d_n2, cap, 7, th_low, nnratio, check_ori,

@@ -161,6 +161,16 @@ def test_gpu_search_by_bow_2000(plslam, oracle, synth):
 
 
 @pytest.mark.gpu
+def test_gpu_search_by_bow_large_capacity(plslam, oracle, synth):
+    """3000 features per set: the kernel's LDS request (87 KiB) goes beyond the 64 KiB default."""
+    om = plslam.ORBmatcher(0.7, True)
+    kf, fr = _bow_sets(synth, 305, 3000, 150)
+    got, cnt = om.SearchByBoWBatch([kf], [fr])
+    rc, ref = _oracle_bow(oracle, kf, fr, 50, 0.7, True)
+    assert cnt[0] == rc and (got[0, :3000] == ref).all() and rc > 800
+
+
+@pytest.mark.gpu
 def test_gpu_match_golden(plslam, synth):
     """GPU vs the committed golden vectors (tests/golden/match_*.npz, tools/gen_golden.py)."""
     import glob
