@@ -695,6 +695,7 @@ plh_status plh_orb_search_for_initialization_batch_dev(const plh_keypoint* d_kps
     return PLH_ERR_INVALID;
   }
   const size_t lds = (size_t)cap * (5 * 4 + 1) + 64;
+  if (lds_request(k_search_init, lds, "plh_orb_search_for_initialization_batch_dev") != PLH_OK) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_search_init, dim3(pairs), dim3(64), lds, (hipStream_t)stream, d_kps1, d_desc1, (const int*)d_n1, d_kps2,
                      d_desc2, (const int*)d_n2, cap, *gp2, d_cell_start2, d_cell_items2, d_prev_matched, window_size, nnratio,
                      check_ori, d_matches12, d_nmatches);
@@ -719,6 +720,7 @@ static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, 
     return PLH_ERR_INVALID;
   }
   const size_t lds = (size_t)cap * (3 * 4 + 1) + (size_t)qcap * (4 + 1) + 64;
+  if (lds_request(k_search_proj_points, lds, who) != PLH_OK) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_search_proj_points, dim3(pairs), dim3(64), lds, (hipStream_t)stream, variant, d_kps_un, d_desc,
                      (const int*)d_n, cap, *gp, d_cs, d_ci, sf, is2, d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy, d_q_level,
                      d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, mode, check_ori, dist_th, d_assigned, d_nmatches);
@@ -864,6 +866,7 @@ static plh_status launch_proj_lines(int variant, const plh_keyline* d_kl, const 
     return PLH_ERR_INVALID;
   }
   const size_t lds = (size_t)cap * (3 * 4 + 2) + 64;
+  if (lds_request(k_search_proj_lines, lds, who) != PLH_OK) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_search_proj_lines, dim3(pairs), dim3(64), lds, (hipStream_t)stream, variant, d_kl, d_ldesc, d_linefn,
                      (const int*)d_nl, cap, *gp, d_cs, d_ci, item_cap, d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_seg,
                      d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, d_assigned, d_nmatches);

@@ -491,21 +491,7 @@ __global__ void __launch_bounds__(256) k_search_triangulation(const plh_keypoint
 static size_t tri_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
 
 static size_t bow_lds_bytes(int cap) { return (size_t)cap * (5 * 4 + 4 * 2 + 1) + 64; }
-// Dynamic LDS above 64 KiB has to be requested per kernel; gfx950 has 160 KiB per workgroup.
-template <typename K>
-static plh_status lds_request(K kernel, size_t bytes, const char* who) {
-  if (bytes > 160u * 1024u) {
-    set_error("%s: %zu bytes of LDS needed (capacity too large for one workgroup)", who, bytes);
-    return PLH_ERR_INVALID;
-  }
-  if (bytes > 64u * 1024u &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    set_error("%s: cannot reserve %zu bytes of LDS", who, bytes);
-    return PLH_ERR_INVALID;
-  }
-  return PLH_OK;
-}
+
 
 }  // namespace plh
 
@@ -700,6 +686,7 @@ plh_status plh_orb_search_for_triangulation_batch_dev(const plh_keypoint* d_kps1
   for (int i = 0; i < 9; i++) g.F[i] = F12[i];
   g.ex = ex; g.ey = ey;
   for (int i = 0; i < 16; i++) { g.sf[i] = i < nlevels ? scale_factors2[i] : 0.f; g.sig2[i] = i < nlevels ? level_sigma2_2[i] : 0.f; }
+  if (lds_request(k_search_triangulation, tri_lds_bytes(cap), "SearchForTriangulation") != PLH_OK) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_search_triangulation, dim3(pairs), dim3(256), tri_lds_bytes(cap), (hipStream_t)stream, d_kps1, d_desc1, d_node1,
                      d_has_mp1, (const int*)d_n1, d_kps2, d_desc2, d_node2, d_has_mp2, (const int*)d_n2, cap, g, th_low, check_ori,
                      d_matches12, d_nmatches);

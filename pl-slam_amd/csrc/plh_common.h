@@ -20,6 +20,23 @@ void set_error(const char* fmt, ...);
 // sticky error so that the launch checks below report only our own failures.
 plh_status ensure_runtime();
 
+// Dynamic LDS above 64 KiB has to be requested per kernel; gfx950 has 160 KiB per workgroup.  Called by the launchers
+// whose LDS footprint scales with a caller-supplied capacity.
+template <typename K>
+inline plh_status lds_request(K kernel, size_t bytes, const char* who) {
+  if (bytes > 160u * 1024u) {
+    set_error("%s: %zu bytes of LDS needed (capacity too large for one workgroup)", who, bytes);
+    return PLH_ERR_INVALID;
+  }
+  if (bytes > 64u * 1024u &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: cannot reserve %zu bytes of LDS", who, bytes);
+    return PLH_ERR_INVALID;
+  }
+  return PLH_OK;
+}
+
 #define PLH_HIP(call)                                                                         \
   do {                                                                                        \
     hipError_t e__ = (call);                                                                  \
