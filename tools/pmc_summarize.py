@@ -18,7 +18,7 @@ def fold(dirname, counter):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0].replace("plh::", "")
+            k = r["Kernel_Name"].split("(")[0].replace("plh::", "").replace("void ", "").split("<")[0]
             tot[k] += float(r["Counter_Value"])
             calls[k] += 1
     return tot, calls
