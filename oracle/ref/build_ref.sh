@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build oracle/_ref/libdbow2_ref.so from the REFERENCE's own DBoW2 sources, where they lie (nothing is copied into the
+# repo): Thirdparty/DBoW2/{DBoW2/*.cpp, DUtils/Random.cpp, DUtils/Timestamp.cpp} + the C wrapper oracle/ref/ref_dbow2.cc,
+# compiled against oracle/ref/stub (a minimal cv::Mat; OpenCV is not in the image).  Output: oracle/_ref/.  The rest of the reference's path needs real OpenCV
+# (imgproc, features2d, line_descriptor) and Eigen and stays unbuildable.  Test infrastructure only.
+set -e
+REF=${1:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+D=$REF/Thirdparty/DBoW2
+[ -f "$D/DBoW2/TemplatedVocabulary.h" ] || { echo "no reference at $REF: skipping oracle/_ref"; exit 0; }
+OUT="$HERE/../_ref"
+mkdir -p "$OUT"
+g++ -O2 -std=c++14 -fPIC -shared -w -I "$HERE/stub" -I "$D" -o "$OUT/libdbow2_ref.so" \
+  "$HERE/ref_dbow2.cc" "$D/DBoW2/FORB.cpp" "$D/DBoW2/BowVector.cpp" "$D/DBoW2/FeatureVector.cpp" "$D/DBoW2/ScoringObject.cpp" \
+  "$D/DUtils/Random.cpp" "$D/DUtils/Timestamp.cpp"
+echo "built $OUT/libdbow2_ref.so"

@@ -49,6 +49,54 @@ class Vocabulary:
             weight[stopped & (idx >= first_leaf)] = 0.0
         return Vocabulary(desc, child_start, child_count, word_id, weight, k, L)
 
+    # ---- DBoW2 text format (the reference's TemplatedVocabulary::loadFromTextFile / saveToTextFile,
+    #      Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1350-1462; ORBvoc.txt of ORB-SLAM2 is such a file):
+    #      line 1 "k L scoring weighting", then one line per non-root node in id order:
+    #      "parent isLeaf d0 .. d31 weight".  Node ids are line numbers, a node's children are the lines naming it as
+    #      parent in file order, word ids count the leaves in file order.
+    def save_text(self, path, scoring=0, weighting=0):
+        """Write the tree so that the reference's loader rebuilds it with identical node and word ids.  Requires the
+        flat layout to be in id order already (children contiguous and ascending -- true for `synthetic`)."""
+        n = self.n_nodes
+        parent = np.zeros(n, np.int64)
+        for p in range(n):
+            c0, cc = int(self.child_start[p]), int(self.child_count[p])
+            parent[c0:c0 + cc] = p
+        lines = ["%d %d %d %d" % (self.k, self.L, scoring, weighting)]
+        for i in range(1, n):
+            lines.append("%d %d %s %r" % (parent[i], 1 if self.child_count[i] == 0 else 0,
+                                          " ".join(str(int(b)) for b in self.node_desc[i]), float(self.weight[i])))
+        with open(path, "w") as f:
+            f.write("\n".join(lines))   # no trailing newline: the reference's eof loop would read one node too many
+
+    @staticmethod
+    def load_text(path):
+        """Read a DBoW2 text vocabulary (e.g. ORBvoc.txt) into the flat form, ids as the reference assigns them."""
+        with open(path) as f:
+            k, L, _scoring, _weighting = (int(v) for v in f.readline().split()[:4])
+            rows = [ln.split() for ln in f if ln.strip()]
+        n = len(rows) + 1
+        parent = np.zeros(n, np.int64)
+        leaf = np.zeros(n, bool)
+        desc = np.zeros((n, 32), np.uint8)
+        weight = np.zeros(n, np.float32)
+        for i, r in enumerate(rows, start=1):
+            parent[i], leaf[i] = int(r[0]), int(r[1]) > 0
+            desc[i] = [int(v) for v in r[2:34]]
+            weight[i] = float(r[34])
+        # children of a node in file order; the flat form wants them contiguous: renumber breadth first when they are not
+        kids = [[] for _ in range(n)]
+        for i in range(1, n):
+            kids[parent[i]].append(i)
+        contiguous = all(len(c) == 0 or c == list(range(c[0], c[0] + len(c))) for c in kids)
+        if not contiguous:
+            raise ValueError("vocabulary file whose children are not contiguous in id order is not supported yet")
+        child_start = np.array([c[0] if c else 0 for c in kids], np.int32)
+        child_count = np.array([len(c) for c in kids], np.int32)
+        word_id = np.full(n, -1, np.int32)
+        word_id[leaf] = np.arange(int(leaf.sum()), dtype=np.int32)
+        return Vocabulary(desc, child_start, child_count, word_id, weight, k, L)
+
     def device_arrays(self, dev):
         """Upload once per device helper (`plslam_amd._Dev`)."""
         if self._dev is None:

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Golden vectors produced by the REFERENCE's own code (oracle/_ref/libdbow2_ref.so = Thirdparty/DBoW2 compiled from
+/root/reference by oracle/ref/build_ref.sh): DBoW2::FORB::distance and TemplatedVocabulary::transform on synthetic
+vocabularies written in the reference's text format.  Run in the build container (the reference is not on the GPU box):
+
+    bash oracle/ref/build_ref.sh && python tools/gen_golden_ref.py
+
+Writes tests/golden/ref_dbow2_*.npz; tests/test_ref_dbow2.py checks the oracle and the GPU against them."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _util  # noqa: E402
+
+
+def ref_lib():
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdbow2_ref.so"))
+    V, I = C.c_void_p, C.c_int
+    L.ref_forb_distance.argtypes = [V, V]
+    L.ref_voc_load_text.argtypes = [C.c_char_p]
+    L.ref_voc_load_text.restype = V
+    L.ref_voc_free.argtypes = [V]
+    L.ref_voc_size.argtypes = [V]
+    L.ref_voc_transform_each.argtypes = [V, V, I, I, V, V, V]
+    L.ref_voc_transform.argtypes = [V, V, I, I, V, V, I, V]
+    return L
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def reference_transform(L, voc, desc, levelsup):
+    """(word[n], weight[n], node[n], feat_node[n], bow_word[m], bow_value[m]) from the reference."""
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "voc.txt")
+        voc.save_text(path)
+        h = L.ref_voc_load_text(path.encode())
+        assert h, "reference loader rejected the file"
+        try:
+            assert L.ref_voc_size(h) == int((voc.word_id >= 0).sum())
+            n = len(desc)
+            word, node, fnode = (np.zeros(n, np.int32) for _ in range(3))
+            weight = np.zeros(n, np.float64)
+            L.ref_voc_transform_each(h, p(desc), n, levelsup, p(word), p(weight), p(node))
+            bw, bv = np.zeros(n, np.int32), np.zeros(n, np.float64)
+            m = L.ref_voc_transform(h, p(desc), n, levelsup, p(bw), p(bv), n, p(fnode))
+        finally:
+            L.ref_voc_free(h)
+    return word, weight, node, fnode, bw[:m], bv[:m]
+
+
+CASES = [   # name, vocabulary seed, k, L, stop fraction, descriptor seed, n, levelsup
+    ("k10L4", 102, 10, 4, 0.02, 7, 1500, 2),
+    ("k8L3", 5, 8, 3, 0.0, 9, 600, 1),
+    ("k10L5_up4", 11, 10, 5, 0.01, 13, 1000, 4),
+]
+
+
+def make_case(S, VM, vseed, k, Lv, stop, dseed, n):
+    voc = VM.Vocabulary.synthetic(vseed, k=k, L=Lv, synth=S, stop_fraction=stop)
+    a, b, _ = S.make_descriptor_sets(dseed, n)
+    # half random descriptors, half noisy copies of leaf descriptors (realistic descents, few ties)
+    first_leaf = (k ** Lv - 1) // (k - 1)
+    rng = S.SplitMix64(dseed + 1)
+    pick = rng.randint(n // 2, first_leaf, voc.n_nodes)
+    noisy = voc.node_desc[pick] ^ np.packbits((rng.uniform(n // 2 * 256) < 0.04).reshape(-1, 256), axis=1, bitorder="little")
+    desc = np.ascontiguousarray(np.concatenate([a[: n - n // 2], noisy]), np.uint8)
+    return voc, desc
+
+
+def main():
+    S = _util.synth()
+    VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
+    L = ref_lib()
+    out = os.path.join(ROOT, "tests", "golden")
+    for name, vseed, k, Lv, stop, dseed, n, up in CASES:
+        voc, desc = make_case(S, VM, vseed, k, Lv, stop, dseed, n)
+        word, weight, node, fnode, bw, bv = reference_transform(L, voc, desc, up)
+        # Hamming distances of the reference on a sample of pairs
+        ia, ib = np.arange(0, n - 1, 7), np.arange(1, n, 7)[: len(np.arange(0, n - 1, 7))]
+        dist = np.array([L.ref_forb_distance(p(desc[i]), p(desc[j])) for i, j in zip(ia, ib)], np.int32)
+        np.savez_compressed(os.path.join(out, "ref_dbow2_%s.npz" % name), vseed=vseed, k=k, L=Lv, stop=stop, dseed=dseed, n=n,
+                            levelsup=up, word=word, weight=weight, node=node, feat_node=fnode, bow_word=bw, bow_value=bv,
+                            pair_a=ia.astype(np.int32), pair_b=ib.astype(np.int32), pair_dist=dist)
+        print(name, "words", len(bw), "stopped", int((fnode < 0).sum()), "nodes", len(np.unique(node)))
+
+
+if __name__ == "__main__":
+    main()
