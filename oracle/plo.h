@@ -5,12 +5,19 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the CHECKER.  Nothing in the
  * product path (pl-slam_amd/) may include, link or call this.
  *
- * PARITY UNPINNED: the reference (HarborC/PL-SLAM) ships no tests, golden vectors or fixtures
- * for this path, and its sources cannot be built here: every file on the
- * path needs OpenCV 3.x (+ opencv_contrib line_descriptor) and Eigen3, none of which exist in
- * this image.  OpenCV version is un-pinned upstream (CMakeLists.txt:29-35).  The arithmetic of
- * the OpenCV primitives below is restated from the published OpenCV 3.2-3.4.0 algorithms and is
- * THE definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions").
+ * PARITY, what is pinned and what is not.  The reference (HarborC/PL-SLAM) ships no tests, golden vectors or fixtures for
+ * this path and its build needs OpenCV 3.x (+ opencv_contrib line_descriptor) and Eigen3, none of which
+ * exist in this image.  Two pieces of the reference DO compile from the sources where they lie once a stand-in for the
+ * OpenCV *types* is supplied (oracle/ref/, output oracle/_ref/):
+ *   - src/ORBextractor.cc (all of it) on top of this oracle's restated cv::resize / GaussianBlur / FAST / fastAtan2:
+ *     the ORB restatement here (orb.cc) is bit-identical to it on every image and parameter set tried
+ *     (tests/test_ref_orb.py, goldens tests/golden/ref_orb_*.npz);
+ *   - Thirdparty/DBoW2 (FORB::distance, TemplatedVocabulary loader + transform): match.cc's BoW transform and
+ *     descriptor distance reproduce it (tests/test_ref_dbow2.py, goldens ref_dbow2_*.npz).
+ * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
+ * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE
+ * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); the line path (LSD / LBD wrappers,
+ * LSDmatcher) and the ORBmatcher searches are restatements of the in-tree sources with no executable reference behind them.
  *
  * Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off: no FMA contraction, IEEE float32).
  */

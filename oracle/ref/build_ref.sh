@@ -14,3 +14,9 @@ g++ -O2 -std=c++14 -fPIC -shared -w -I "$HERE/stub" -I "$D" -o "$OUT/libdbow2_re
   "$HERE/ref_dbow2.cc" "$D/DBoW2/FORB.cpp" "$D/DBoW2/BowVector.cpp" "$D/DBoW2/FeatureVector.cpp" "$D/DBoW2/ScoringObject.cpp" \
   "$D/DUtils/Random.cpp" "$D/DUtils/Timestamp.cpp"
 echo "built $OUT/libdbow2_ref.so"
+# The reference's ORB extractor on top of the oracle's restated OpenCV primitives (oracle/img_ops.cc); same float rules as
+# the oracle build (no FMA contraction).
+g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wl,-Bsymbolic -I "$HERE/stub" -I "$REF/include" \
+  -o "$OUT/liborb_ref.so" \
+  "$HERE/ref_orb.cc" "$REF/src/ORBextractor.cc" "$HERE/../img_ops.cc"
+echo "built $OUT/liborb_ref.so"

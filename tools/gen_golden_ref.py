@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Golden vectors produced by the REFERENCE's own code (oracle/_ref/libdbow2_ref.so = Thirdparty/DBoW2 compiled from
+"""Golden vectors produced by the REFERENCE's own code (oracle/_ref/libdbow2_ref.so = Thirdparty/DBoW2, liborb_ref.so =
+src/ORBextractor.cc on the oracle's OpenCV primitives; compiled from
 /root/reference by oracle/ref/build_ref.sh): DBoW2::FORB::distance and TemplatedVocabulary::transform on synthetic
 vocabularies written in the reference's text format.  Run in the build container (the reference is not on the GPU box):
 
     bash oracle/ref/build_ref.sh && python tools/gen_golden_ref.py
 
-Writes tests/golden/ref_dbow2_*.npz; tests/test_ref_dbow2.py checks the oracle and the GPU against them."""
+Writes tests/golden/ref_dbow2_*.npz and ref_orb_*.npz; tests/test_ref_dbow2.py / test_ref_orb.py check the oracle and the
+GPU against them."""
 import ctypes as C
 import os
 import sys
@@ -74,6 +76,53 @@ def make_case(S, VM, vseed, k, Lv, stop, dseed, n):
     return voc, desc
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's ORB extractor (src/ORBextractor.cc compiled into oracle/_ref/liborb_ref.so on top of the oracle's
+# restated OpenCV primitives, list nodes from a monotonic arena so that its address-ordered tie-break is reproducible)
+# ---------------------------------------------------------------------------------------------------------------
+ORB_CASES = [   # name, frame seed, rows, cols, nfeatures, scale, nlevels, iniTh, minTh
+    ("s1_640x480", 1, 480, 640, 1000, 1.2, 8, 20, 7),
+    ("s3_320x240", 3, 240, 320, 500, 1.2, 6, 20, 7),
+    ("s7_200x160_sparse", 7, 160, 200, 300, 1.5, 4, 40, 12),   # every level >= 38 px (the GPU plan refuses smaller ones)
+]
+
+
+def ref_orb_lib():
+    R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "liborb_ref.so"))
+    R.ref_orb_create.restype = C.c_void_p
+    R.ref_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    R.ref_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    R.ref_orb_destroy.argtypes = [C.c_void_p]
+    R.ref_orb_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return R
+
+
+def reference_orb(R, P, img, nf, scale, nl, ini, mn):
+    h = R.ref_orb_create(nf, scale, nl, ini, mn)
+    try:
+        cap = nf * 2 + 64
+        kps, desc = np.zeros(cap, P.KP_DTYPE), np.zeros((cap, 32), np.uint8)
+        img = np.ascontiguousarray(img)
+        n = R.ref_orb_extract(h, p(img), img.shape[0], img.shape[1], img.shape[1], p(kps), p(desc), cap)
+        assert n >= 0
+        sf, sg = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        nlv = C.c_int(0)
+        R.ref_orb_tables(h, p(sf), p(sg), C.byref(nlv))
+    finally:
+        R.ref_orb_destroy(h)
+    return kps[:n].copy(), desc[:n].copy(), sf[:nlv.value].copy(), sg[:nlv.value].copy()
+
+
+def gen_orb(S, out):
+    R, P = ref_orb_lib(), _util.plslam()
+    for name, seed, rows, cols, nf, scale, nl, ini, mn in ORB_CASES:
+        img = S.make_frame(seed, rows, cols)
+        kps, desc, sf, sg = reference_orb(R, P, img, nf, scale, nl, ini, mn)
+        np.savez_compressed(os.path.join(out, "ref_orb_%s.npz" % name), seed=seed, rows=rows, cols=cols, nfeatures=nf,
+                            scale=scale, nlevels=nl, ini=ini, mn=mn, kps=kps, desc=desc, scale_factors=sf, sigma2=sg)
+        print("orb", name, "keypoints", len(kps))
+
+
 def main():
     S = _util.synth()
     VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
@@ -89,6 +138,7 @@ def main():
                             levelsup=up, word=word, weight=weight, node=node, feat_node=fnode, bow_word=bw, bow_value=bv,
                             pair_a=ia.astype(np.int32), pair_b=ib.astype(np.int32), pair_dist=dist)
         print(name, "words", len(bw), "stopped", int((fnode < 0).sum()), "nodes", len(np.unique(node)))
+    gen_orb(S, out)
 
 
 if __name__ == "__main__":
