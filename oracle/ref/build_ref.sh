@@ -20,3 +20,5 @@ g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -fvisibilit
   -o "$OUT/liborb_ref.so" \
   "$HERE/ref_orb.cc" "$REF/src/ORBextractor.cc" "$HERE/../img_ops.cc"
 echo "built $OUT/liborb_ref.so"
+g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -I "$REF/include" -o "$OUT/libmisc_ref.so" "$HERE/ref_misc.cc" "$REF/src/lineIterator.cpp"
+echo "built $OUT/libmisc_ref.so"

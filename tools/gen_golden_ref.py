@@ -123,6 +123,63 @@ def gen_orb(S, out):
         print("orb", name, "keypoints", len(kps))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Frame::AssignFeaturesToGridForLine (src/Frame.cc:295-320) re-enacted around the reference's real LineIterator
+# (src/lineIterator.cpp in oracle/_ref/libmisc_ref.so): cell -> line indices in insertion order.
+# ---------------------------------------------------------------------------------------------------------------
+def reference_line_grid(M, kl, gp_array):
+    inv_w, inv_h = np.float32(gp_array[4]), np.float32(gp_array[5])
+    cells = [[] for _ in range(64 * 48)]
+    buf = np.zeros(2 * 4096, np.int32)
+    for i in range(len(kl)):
+        x1, y1 = np.float32(kl["startPointX"][i]) * inv_w, np.float32(kl["startPointY"][i]) * inv_h   # float products
+        x2, y2 = np.float32(kl["endPointX"][i]) * inv_w, np.float32(kl["endPointY"][i]) * inv_h
+        n = M.ref_line_iterator(float(x1), float(y1), float(x2), float(y2), p(buf), 4096)
+        assert n <= 4096
+        for j in range(n):
+            cx, cy = int(buf[2 * j]), int(buf[2 * j + 1])
+            if 0 <= cx < 64 and 0 <= cy < 48:
+                cells[cx * 48 + cy].append(i)
+    start = np.zeros(64 * 48 + 1, np.int32)
+    items = []
+    for c in range(64 * 48):
+        start[c] = len(items)
+        items += cells[c]
+    start[64 * 48] = len(items)
+    return start, np.asarray(items, np.int32)
+
+
+def ref_misc_lib():
+    M = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libmisc_ref.so"))
+    M.ref_line_iterator.argtypes = [C.c_double] * 4 + [C.c_void_p, C.c_int]
+    return M
+
+
+def random_keylines(S, P, seed, n, cols=640, rows=480):
+    rng = S.SplitMix64(seed)
+    kl = np.zeros(n, P.KL_DTYPE)
+    sx, sy = rng.uniform(n, -20, cols + 20), rng.uniform(n, -20, rows + 20)     # a few leave the image on purpose
+    ang, ln = rng.uniform(n, 0, 2 * np.pi), rng.uniform(n, 0.5, 300)
+    kl["startPointX"], kl["startPointY"] = sx.astype(np.float32), sy.astype(np.float32)
+    kl["endPointX"], kl["endPointY"] = (sx + ln * np.cos(ang)).astype(np.float32), (sy + ln * np.sin(ang)).astype(np.float32)
+    # exact verticals / horizontals / points / grid-aligned ends
+    kl["endPointX"][:10] = kl["startPointX"][:10]
+    kl["endPointY"][10:20] = kl["startPointY"][10:20]
+    kl["endPointX"][20:25], kl["endPointY"][20:25] = kl["startPointX"][20:25], kl["startPointY"][20:25]
+    kl["startPointX"][25:35] = np.round(kl["startPointX"][25:35] / 10) * 10
+    return kl
+
+
+def gen_line_grid(S, out):
+    M, P = ref_misc_lib(), _util.plslam()
+    for name, seed, n, gp in (("plain", 41, 260, P.grid_params(640, 480)),
+                              ("bounds", 42, 200, P.grid_params(640, 480, -18.5, -11.25, 661.75, 494.5))):
+        kl = random_keylines(S, P, seed, n)
+        start, items = reference_line_grid(M, kl, P._gp_array(gp))
+        np.savez_compressed(os.path.join(out, "ref_linegrid_%s.npz" % name), seed=seed, n=n, gp=P._gp_array(gp), start=start, items=items)
+        print("line grid", name, "items", len(items))
+
+
 def main():
     S = _util.synth()
     VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
@@ -139,6 +196,7 @@ def main():
                             pair_a=ia.astype(np.int32), pair_b=ib.astype(np.int32), pair_dist=dist)
         print(name, "words", len(bw), "stopped", int((fnode < 0).sum()), "nodes", len(np.unique(node)))
     gen_orb(S, out)
+    gen_line_grid(S, out)
 
 
 if __name__ == "__main__":
