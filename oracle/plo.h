@@ -13,11 +13,16 @@
  *     the ORB restatement here (orb.cc) is bit-identical to it on every image and parameter set tried
  *     (tests/test_ref_orb.py, goldens tests/golden/ref_orb_*.npz);
  *   - Thirdparty/DBoW2 (FORB::distance, TemplatedVocabulary loader + transform): match.cc's BoW transform and
- *     descriptor distance reproduce it (tests/test_ref_dbow2.py, goldens ref_dbow2_*.npz).
+ *     descriptor distance reproduce it (tests/test_ref_dbow2.py, goldens ref_dbow2_*.npz);
+ *   - src/LineExtractor.cpp + the vendored twin of opencv_contrib's line_descriptor (LSDDetector_custom.cpp,
+ *     binary_descriptor_custom.cpp) on top of this oracle's LSD / GaussianBlur / Sobel: line.cc's KeyLines, LBD bytes and
+ *     line equations are bit-identical to it (KeyLine.angle within one float ulp: an atan2 overload that depends on the
+ *     toolchain, see tests/test_ref_line.py; goldens ref_line_*.npz);
+ *   - src/lineIterator.cpp: the line grid of frame_search.cc (tests/test_ref_linegrid.py).
  * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
  * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE
- * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); the line path (LSD / LBD wrappers,
- * LSDmatcher) and the ORBmatcher searches are restatements of the in-tree sources with no executable reference behind them.
+ * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); the ORBmatcher / LSDmatcher searches
+ * are restatements of the in-tree sources with no executable reference behind them.
  *
  * Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off: no FMA contraction, IEEE float32).
  */

@@ -22,3 +22,10 @@ g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -fvisibilit
 echo "built $OUT/liborb_ref.so"
 g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -I "$REF/include" -o "$OUT/libmisc_ref.so" "$HERE/ref_misc.cc" "$REF/src/lineIterator.cpp"
 echo "built $OUT/libmisc_ref.so"
+# The reference's line path (LINEextractor + the vendored twin of opencv_contrib's line_descriptor) on top of the oracle's
+# restated LSD / GaussianBlur / Sobel; same float rules as the oracle build.
+LD=$REF/Thirdparty/line_descriptor
+g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -I "$HERE/stub" -I "$REF/include" -I "$LD/include" \
+  -o "$OUT/libline_ref.so" "$HERE/ref_line.cc" "$REF/src/LineExtractor.cpp" "$LD/src/LSDDetector_custom.cpp" \
+  "$LD/src/binary_descriptor_custom.cpp" "$HERE/../img_ops.cc" "$HERE/../lsd.cc"
+echo "built $OUT/libline_ref.so"

@@ -15,6 +15,10 @@
 // (the real headers pull these in transitively; the reference sources rely on it)
 #include <algorithm>
 #include <cassert>
+#include <cfloat>
+#include <climits>
+#include <map>
+#include <stdexcept>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -34,8 +38,31 @@ typedef unsigned char uchar;
 #define CV_32F 5
 #define CV_Assert(x) assert(x)
 #define CV_PI 3.1415926535897932384626433832795
+#define CV_8S 1
+#define CV_8SC1 1
+#define CV_16S 3
+#define CV_32S 4
+#define CV_32SC1 4
+#define CV_16SC1 3
+#define CV_32FC1 5
+#define CV_64F 6
+#define CV_64FC1 6
+#define CV_8UC3 16
+#define CV_EXPORTS
+#define CV_EXPORTS_W
+#define CV_EXPORTS_W_SIMPLE
+#define CV_WRAP
+#define CV_OUT
+#define CV_IN_OUT
+#define CV_PROP_RW
+#define CV_PROP
+#define CV_Error(code, msg) do { std::cerr << "CV_Error: " << (msg) << std::endl; std::abort(); } while (0)
+#define CV_DbgAssert(x) assert(x)
 
 namespace cv {
+
+// cvstd.hpp does this inside namespace cv: unqualified calls in the reference resolve to the std overloads
+using std::min; using std::max; using std::abs; using std::swap; using std::sqrt; using std::exp; using std::pow; using std::log;
 
 inline int cvRound(double v) { return (int)lrint(v); }
 inline int cvRound(float v) { return (int)lrintf(v); }
@@ -53,11 +80,59 @@ template <typename T> struct Point_ {
 typedef Point_<int> Point2i;
 typedef Point2i Point;
 typedef Point_<float> Point2f;
+typedef Point_<double> Point2d;
+inline Point2i to_point(const Point2f& p) { return Point2i((int)lrintf(p.x), (int)lrintf(p.y)); }   // saturate_cast<int>(float)
 struct Size {
   int width, height;
   Size() : width(0), height(0) {}
   Size(int w, int h) : width(w), height(h) {}
+  bool operator==(const Size& o) const { return width == o.width && height == o.height; }
+  bool operator!=(const Size& o) const { return !(*this == o); }
 };
+template <typename T, int N> struct Vec {
+  T val[N];
+  Vec() { for (int i = 0; i < N; i++) val[i] = T(); }
+  Vec(T a, T b, T c, T d) { static_assert(N == 4, "4 values"); val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+  T& operator[](int i) { return val[i]; }
+  const T& operator[](int i) const { return val[i]; }
+};
+typedef Vec<float, 4> Vec4f;
+typedef Vec<int, 4> Vec4i;
+typedef Vec<unsigned char, 3> Vec3b;
+struct Scalar {
+  double val[4];
+  Scalar(double a = 0, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+  static Scalar all(double v) { return Scalar(v, v, v, v); }
+};
+typedef std::string String;
+template <typename T> class Ptr : public std::shared_ptr<T> {
+ public:
+  Ptr() {}
+  Ptr(T* p) : std::shared_ptr<T>(p) {}
+  template <typename U> Ptr(const Ptr<U>& o) : std::shared_ptr<T>(o) {}
+  Ptr(const std::shared_ptr<T>& o) : std::shared_ptr<T>(o) {}
+  bool empty() const { return !this->get(); }
+  operator T*() const { return this->get(); }
+};
+template <typename T, typename... A> Ptr<T> makePtr(A&&... a) { return Ptr<T>(new T(std::forward<A>(a)...)); }
+class FileNode;
+class FileStorage;
+class Algorithm {
+ public:
+  virtual ~Algorithm() {}
+  virtual void read(const FileNode&) {}
+  virtual void write(FileStorage&) const {}
+};
+struct DMatch {
+  int queryIdx, trainIdx, imgIdx;
+  float distance;
+  DMatch() : queryIdx(-1), trainIdx(-1), imgIdx(-1), distance(0) {}
+  DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
+  DMatch(int q, int t, int i, float d) : queryIdx(q), trainIdx(t), imgIdx(i), distance(d) {}
+  bool operator<(const DMatch& m) const { return distance < m.distance; }
+};
+namespace Error { enum { StsBadArg = -5, BadDataPtr = -12, StsBadSize = -201 }; }
+enum { NORM_HAMMING = 6, NORM_L2 = 4, COLOR_BGR2GRAY = 6, COLOR_GRAY2BGR = 8, THRESH_BINARY = 0, DECOMP_LU = 0 };
 struct Rect {
   int x, y, width, height;
   Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
@@ -116,6 +191,25 @@ class Mat {
   bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
   int type() const { return type_; }
   Size size() const { return Size(cols, rows); }
+  int channels() const { return type_ == CV_8UC3 ? 3 : 1; }
+  int depth() const { return type_ == CV_8UC3 ? CV_8U : type_; }
+  bool isContinuous() const { return step.p == (size_t)cols * elem(); }
+  size_t total() const { return (size_t)rows * cols; }
+  void copyTo(Mat& m) const { m = clone(); }
+  void copyTo(const class _OutputArray& o) const;
+  Mat& setTo(const Scalar& v) {
+    for (int r = 0; r < rows; r++)
+      for (int c = 0; c < cols; c++) {
+        if (type_ == CV_8U) at<unsigned char>(r, c) = (unsigned char)v.val[0];
+        else if (type_ == CV_16S) at<short>(r, c) = (short)v.val[0];
+        else if (type_ == CV_32F) at<float>(r, c) = (float)v.val[0];
+        else if (type_ == CV_64F) at<double>(r, c) = v.val[0];
+      }
+    return *this;
+  }
+  Mat t() const;                     // compile-only users (EDLine's least squares): see below
+  Mat row(int r) const { return rowRange(r, r + 1); }
+  Mat col(int c) const { return colRange(c, c + 1); }
   Mat rowRange(int a, int b) const { Mat m(*this); m.data = data + (size_t)a * step.p; m.rows = b - a; return m; }
   Mat colRange(int a, int b) const { Mat m(*this); m.data = data + (size_t)a * elem(); m.cols = b - a; return m; }
   Mat operator()(const Rect& r) const { return rowRange(r.y, r.y + r.height).colRange(r.x, r.x + r.width); }
@@ -126,12 +220,52 @@ class Mat {
   template <typename T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data + (size_t)r * step.p); }
   template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
   template <typename T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
+  template <typename T> T& at(int i) { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i)[0]; }
+  template <typename T> const T& at(int i) const { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i)[0]; }
 
  private:
-  size_t elem() const { return type_ == CV_32F ? 4 : 1; }
+  size_t elem() const { return (type_ == CV_32F || type_ == CV_32S) ? 4 : type_ == CV_16S ? 2 : type_ == CV_64F ? 8 : type_ == CV_8UC3 ? 3 : 1; }
   int type_ = CV_8U;
   std::shared_ptr<std::vector<unsigned char> > buf_;
 };
+
+template <typename T> struct MatType;
+template <> struct MatType<unsigned char> { enum { value = CV_8U }; };
+template <> struct MatType<short> { enum { value = CV_16S }; };
+template <> struct MatType<int> { enum { value = CV_32S }; };
+template <> struct MatType<float> { enum { value = CV_32F }; };
+template <> struct MatType<double> { enum { value = CV_64F }; };
+template <typename T> class Mat_ : public Mat {
+ public:
+  Mat_() {}
+  Mat_(int r, int c) : Mat(r, c, MatType<T>::value) {}
+  Mat_(const Mat& m) : Mat(m) {}
+  template <typename U> Mat_& operator=(const Mat_<U>& o) {   // converting assignment (Mat_<float> = Mat_<int>(r, c))
+    create(o.rows, o.cols, MatType<T>::value);
+    for (int r = 0; r < rows; r++)
+      for (int c = 0; c < cols; c++) (*this)[r][c] = (T)o[r][c];
+    return *this;
+  }
+  Mat_& operator=(const Mat& m) { Mat::operator=(m); return *this; }
+  T* operator[](int r) { return ptr<T>(r); }
+  const T* operator[](int r) const { return ptr<T>(r); }
+  T& operator()(int r, int c) { return ptr<T>(r)[c]; }
+  Mat_ t() const { stub_unreachable_("Mat_::t"); return Mat_(); }
+ private:
+  static void stub_unreachable_(const char* w) { std::cerr << "oracle/ref stub: " << w << " is compile-only" << std::endl; std::abort(); }
+};
+template <typename T> struct MatCommaInitializer_ {
+  Mat_<T> m; int k;
+  template <typename U> MatCommaInitializer_& operator,(U x) { m.template ptr<T>(k / m.cols)[k % m.cols] = (T)x; k++; return *this; }
+  operator Mat() const { return m; }
+  operator Mat_<T>() const { return m; }
+};
+template <typename T, typename U> inline MatCommaInitializer_<T> operator<<(const Mat_<T>& m, U x) {
+  MatCommaInitializer_<T> c{m, 0};
+  c, x;
+  return c;
+}
+inline Mat operator+(const Mat&, const Mat&) { std::cerr << "oracle/ref stub: Mat + Mat is compile-only" << std::endl; std::abort(); }
 
 // InputArray / OutputArray: thin handles on a Mat
 class _InputArray {
@@ -147,12 +281,26 @@ class _OutputArray : public _InputArray {
   _OutputArray(Mat& m) : _InputArray(m) {}
   void create(int r, int c, int type) const { m_->create(r, c, type); }
   void release() const { m_->release(); }
+  void assign(const Mat& m) const { *m_ = m; }
 };
 typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
+inline void Mat::copyTo(const _OutputArray& o) const { Mat c = clone(); o.assign(c); }
+[[noreturn]] inline void stub_unreachable(const char* what) { std::cerr << "oracle/ref stub: " << what << " is compile-only" << std::endl; std::abort(); }
+inline Mat Mat::t() const { stub_unreachable("Mat::t"); }
+inline Mat operator*(const Mat&, const Mat&) { stub_unreachable("Mat * Mat"); }
+inline bool solve(const Mat&, const Mat&, Mat&, int = 0) { stub_unreachable("cv::solve"); }
+inline void cvtColor(const Mat&, Mat&, int) { stub_unreachable("cv::cvtColor"); }
+inline void pyrDown(const Mat&, Mat&, Size = Size()) { stub_unreachable("cv::pyrDown (numOctaves is 1 on this path)"); }
+inline double threshold(const Mat&, Mat&, double, double, int) { stub_unreachable("cv::threshold"); }
+inline Mat abs(const Mat&) { stub_unreachable("cv::abs(Mat)"); }
+inline void add(const Mat&, const Mat&, Mat&) { stub_unreachable("cv::add"); }
+inline void compare(const Mat&, const Mat&, Mat&, int) { stub_unreachable("cv::compare"); }
+inline Mat operator/(const Mat&, double) { stub_unreachable("Mat / scalar"); }
+enum { THRESH_TOZERO = 3, CMP_LT = 3, CMP_GT = 1 };
 
 // ---- image-processing primitives: forwarded to the oracle's restatements ----
-inline void resize(const Mat& src, Mat& dst, Size sz, double, double, int) {
+inline void resize(const Mat& src, Mat& dst, Size sz, double = 0, double = 0, int = INTER_LINEAR) {
   dst.create(sz.height, sz.width, src.type());   // no-op for the pre-sized pyramid views
   plo_resize_linear_u8(src.data, src.cols, src.rows, src.step, dst.data, dst.cols, dst.rows, dst.step);
 }
@@ -178,7 +326,7 @@ inline void copyMakeBorder(const Mat& src, Mat& dst, int top, int bottom, int le
     std::memcpy(dst.data + (size_t)(top + src.rows + y) * dst.step,
                 dst.data + (size_t)(top + reflect101(src.rows + y, src.rows)) * dst.step, dst.cols);
 }
-inline void GaussianBlur(const Mat& src, Mat& dst, Size k, double sx, double, int) {
+inline void GaussianBlur(const Mat& src, Mat& dst, Size k, double sx, double = 0, int = BORDER_REFLECT_101) {
   assert(k.width == k.height);
   Mat tmp(src.rows, src.cols, src.type());
   plo_gaussian_blur_u8(src.data, src.cols, src.rows, src.step, tmp.data, tmp.step, k.width, sx);
@@ -191,6 +339,39 @@ inline void FAST(const Mat& img, std::vector<KeyPoint>& kps, int threshold, bool
   kps.clear();
   for (int i = 0; i < n; i++) kps.push_back(KeyPoint(out[i].x, out[i].y, out[i].size, out[i].angle, out[i].response, out[i].octave, out[i].class_id));
 }
+// cv::Sobel(src8u, dst, CV_16S, dx, dy, 3): the oracle computes both derivatives at once
+inline void Sobel(const Mat& src, Mat& dst, int ddepth, int dx, int dy, int ksize) {
+  assert(ddepth == CV_16S && ksize == 3 && src.type() == CV_8U && dx + dy == 1);
+  std::vector<int16_t> gx((size_t)src.rows * src.cols), gy((size_t)src.rows * src.cols);
+  plo_sobel3_s16(src.data, src.cols, src.rows, src.step, gx.data(), gy.data());
+  dst.create(src.rows, src.cols, CV_16S);
+  const std::vector<int16_t>& g = dx ? gx : gy;
+  for (int r = 0; r < src.rows; r++) std::memcpy(dst.data + (size_t)r * dst.step, &g[(size_t)r * src.cols], (size_t)src.cols * 2);
+}
+// cv::LineSegmentDetector (imgproc lsd.cpp) = the oracle's restatement
+class LineSegmentDetector {
+ public:
+  void detect(const Mat& img, std::vector<Vec4f>& lines) {
+    const int cap = img.rows * img.cols / 4 + 64;
+    std::vector<float> seg((size_t)cap * 4);
+    const int n = plo_lsd_detect(img.data, img.cols, img.rows, img.step, seg.data(), cap);
+    lines.clear();
+    for (int i = 0; i < n && i < cap; i++) lines.push_back(Vec4f(seg[4 * i], seg[4 * i + 1], seg[4 * i + 2], seg[4 * i + 3]));
+  }
+};
+inline Ptr<LineSegmentDetector> createLineSegmentDetector(int = 0, double = 0.8, double = 0.6, double = 2.0, double = 22.5,
+                                                          double = 0, double = 0.7, int = 1024) {
+  return Ptr<LineSegmentDetector>(new LineSegmentDetector());
+}
+// cv::LineIterator: only .count is used, for end points inside the image (8-connected: max(|dx|, |dy|) + 1)
+class LineIterator {
+ public:
+  int count;
+  LineIterator(const Mat&, Point2f a, Point2f b, int = 8, bool = false) {
+    const Point2i p = to_point(a), q = to_point(b);
+    count = std::max(std::abs(q.x - p.x), std::abs(q.y - p.y)) + 1;
+  }
+};
 struct KeyPointsFilter {   // only ComputeKeyPointsOld (dead code in the reference) uses it
   static void retainBest(std::vector<KeyPoint>& k, int n) {
     if (n >= 0 && (int)k.size() > n) {
