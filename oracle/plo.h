@@ -18,6 +18,8 @@
  *     binary_descriptor_custom.cpp) on top of this oracle's LSD / GaussianBlur / Sobel: line.cc's KeyLines, LBD bytes and
  *     line equations are bit-identical to it (KeyLine.angle within one float ulp: an atan2 overload that depends on the
  *     toolchain, see tests/test_ref_line.py; goldens ref_line_*.npz);
+ *   - src/ORBmatcher.cc (against stand-ins for Frame / KeyFrame / MapPoint): SearchByBoW (both), SearchForInitialization
+ *     and SearchByProjection(F, MapPoints) of match.cc / frame_search.cc return the same matches (tests/test_ref_orbmatcher.py);
  *   - src/lineIterator.cpp: the line grid of frame_search.cc (tests/test_ref_linegrid.py).
  * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
  * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE

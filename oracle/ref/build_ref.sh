@@ -29,3 +29,9 @@ g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -I "$HERE/s
   -o "$OUT/libline_ref.so" "$HERE/ref_line.cc" "$REF/src/LineExtractor.cpp" "$LD/src/LSDDetector_custom.cpp" \
   "$LD/src/binary_descriptor_custom.cpp" "$HERE/../img_ops.cc" "$HERE/../lsd.cc"
 echo "built $OUT/libline_ref.so"
+# The reference's ORBmatcher.cc against stand-ins for Frame / KeyFrame / MapPoint (slam_stub.h replaces the three headers,
+# whose include guards are pre-defined); grid lookups and descriptor helpers from the oracle.
+g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -DMAPPOINT_H -DKEYFRAME_H -DFRAME_H -I "$HERE/stub" -I "$REF/include" \
+  -I "$REF" -include "$HERE/slam_stub.h" -o "$OUT/libmatcher_ref.so" "$HERE/ref_matcher.cc" "$REF/src/ORBmatcher.cc" \
+  "$D/DBoW2/FeatureVector.cpp" "$D/DBoW2/BowVector.cpp" "$HERE/../frame_search.cc" "$HERE/../match.cc" "$HERE/../img_ops.cc"
+echo "built $OUT/libmatcher_ref.so"

@@ -1,0 +1,179 @@
+// oracle/_ref: the reference's own ORBmatcher (src/ORBmatcher.cc, every function, compiled from the source where it lies
+// by oracle/ref/build_ref.sh) driven from flat arrays.  Frame / KeyFrame / MapPoint are the stand-ins of slam_stub.h
+// (the real classes pull in the whole SLAM system); the grid lookup behind Frame::GetFeaturesInArea is the oracle's.
+// Entry points exist for the searches that involve no pose algebra:
+//   SearchByBoW(KeyFrame*, Frame&)            src/ORBmatcher.cc:187-327   (+ ComputeThreeMaxima :1718-1759, DescriptorDistance)
+//   SearchByBoW(KeyFrame*, KeyFrame*)         :574-709
+//   SearchForInitialization                   :455-572
+//   SearchByProjection(Frame&, MapPoints, th) :56-144
+// TEST INFRASTRUCTURE ONLY.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "ORBmatcher.h"
+
+namespace ORB_SLAM2 {
+float Frame::mnMinX = 0, Frame::mnMaxX = 0, Frame::mnMinY = 0, Frame::mnMaxY = 0;
+
+void GridLookup::build() {
+  cellStart.assign(64 * 48 + 1, 0);
+  cellItems.assign(kps.size() + 1, 0);
+  plo_frame_assign_grid(kps.data(), (int)kps.size(), gp, cellStart.data(), cellItems.data());
+}
+std::vector<size_t> GridLookup::query(float x, float y, float r, int minLevel, int maxLevel) const {
+  std::vector<int32_t> out(kps.size() + 1);
+  const int n = plo_features_in_area(kps.data(), gp, cellStart.data(), cellItems.data(), x, y, r, minLevel, maxLevel, out.data(),
+                                     (int)out.size());
+  return std::vector<size_t>(out.begin(), out.begin() + n);
+}
+}  // namespace ORB_SLAM2
+
+using namespace ORB_SLAM2;
+
+namespace {
+cv::Mat desc_mat(const uint8_t* d, int n) {
+  cv::Mat m(n > 0 ? n : 1, 32, CV_8U);
+  if (n > 0) std::memcpy(m.data, d, (size_t)n * 32);
+  if (n == 0) m = m.rowRange(0, 0);
+  return m;
+}
+std::vector<cv::KeyPoint> keypoints(const plo_keypoint* k, int n) {
+  std::vector<cv::KeyPoint> v(n);
+  for (int i = 0; i < n; i++) v[i] = cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id);
+  return v;
+}
+void feat_vec(DBoW2::FeatureVector& fv, const int32_t* node, int n) {   // Frame::ComputeBoW order: ascending feature index
+  for (int i = 0; i < n; i++)
+    if (node[i] >= 0) fv.addFeature((DBoW2::NodeId)node[i], (unsigned)i);
+}
+struct Points {   // owns the MapPoints of one harness call
+  std::vector<std::unique_ptr<MapPoint> > all;
+  MapPoint* make(long id) {
+    all.emplace_back(new MapPoint());
+    all.back()->mnId = (unsigned long)id;
+    return all.back().get();
+  }
+};
+}  // namespace
+
+extern "C" {
+
+// valid1[i] = KeyFrame feature i has a MapPoint that is not bad.  matches21[f] = KeyFrame feature whose MapPoint went to
+// Frame feature f, or -1.  Returns nmatches.
+int ref_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
+                          const uint8_t* desc2, const float* angle2, const int32_t* node2, int n2, float nnratio, int check_ori,
+                          int32_t* matches21) {
+  Points pts;
+  KeyFrame kf;
+  Frame f;
+  kf.N = n1; f.N = n2;
+  kf.mvKeysUn.resize(n1); kf.mvpMapPoints.assign(n1, nullptr);
+  for (int i = 0; i < n1; i++) {
+    kf.mvKeysUn[i].angle = angle1[i];
+    if (valid1[i]) kf.mvpMapPoints[i] = pts.make(i);
+  }
+  kf.mvKeys = kf.mvKeysUn;
+  f.mvKeys.resize(n2);
+  for (int i = 0; i < n2; i++) f.mvKeys[i].angle = angle2[i];
+  f.mvKeysUn = f.mvKeys;
+  f.mvpMapPoints.assign(n2, nullptr);
+  kf.mDescriptors = desc_mat(desc1, n1);
+  f.mDescriptors = desc_mat(desc2, n2);
+  feat_vec(kf.mFeatVec, node1, n1);
+  feat_vec(f.mFeatVec, node2, n2);
+  ORBmatcher m(nnratio, check_ori != 0);
+  std::vector<MapPoint*> out;
+  const int n = m.SearchByBoW(&kf, f, out);
+  for (int i = 0; i < n2; i++) matches21[i] = out[i] ? (int32_t)out[i]->mnId : -1;
+  return n;
+}
+
+// matches12[i1] = KeyFrame-2 feature whose MapPoint was matched to KeyFrame-1 feature i1, or -1
+int ref_orb_search_by_bow_kfkf(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
+                               const uint8_t* desc2, const float* angle2, const int32_t* node2, const uint8_t* valid2, int n2,
+                               float nnratio, int check_ori, int32_t* matches12) {
+  Points pts;
+  KeyFrame k1, k2;
+  k1.N = n1; k2.N = n2;
+  k1.mvKeysUn.resize(n1); k1.mvpMapPoints.assign(n1, nullptr);
+  k2.mvKeysUn.resize(n2); k2.mvpMapPoints.assign(n2, nullptr);
+  for (int i = 0; i < n1; i++) { k1.mvKeysUn[i].angle = angle1[i]; if (valid1[i]) k1.mvpMapPoints[i] = pts.make(i); }
+  for (int i = 0; i < n2; i++) { k2.mvKeysUn[i].angle = angle2[i]; if (valid2[i]) k2.mvpMapPoints[i] = pts.make(i); }
+  k1.mvKeys = k1.mvKeysUn; k2.mvKeys = k2.mvKeysUn;
+  k1.mDescriptors = desc_mat(desc1, n1);
+  k2.mDescriptors = desc_mat(desc2, n2);
+  feat_vec(k1.mFeatVec, node1, n1);
+  feat_vec(k2.mFeatVec, node2, n2);
+  ORBmatcher m(nnratio, check_ori != 0);
+  std::vector<MapPoint*> out;
+  const int n = m.SearchByBoW(&k1, &k2, out);
+  for (int i = 0; i < n1; i++) matches12[i] = out[i] ? (int32_t)out[i]->mnId : -1;
+  return n;
+}
+
+// prev_matched [n1][2] in/out, matches12 [n1] out
+int ref_orb_search_for_initialization(const plo_keypoint* kps1, const uint8_t* desc1, int n1, const plo_keypoint* kps2,
+                                      const uint8_t* desc2, int n2, const float gp[6], float* prev_matched, int window_size,
+                                      float nnratio, int check_ori, int32_t* matches12) {
+  Frame f1, f2;
+  f1.N = n1; f2.N = n2;
+  f1.mvKeysUn = keypoints(kps1, n1); f1.mvKeys = f1.mvKeysUn;
+  f2.mvKeysUn = keypoints(kps2, n2); f2.mvKeys = f2.mvKeysUn;
+  f1.mDescriptors = desc_mat(desc1, n1);
+  f2.mDescriptors = desc_mat(desc2, n2);
+  f2.grid.kps.assign(kps2, kps2 + n2);
+  std::memcpy(f2.grid.gp, gp, sizeof(f2.grid.gp));
+  f2.grid.build();
+  std::vector<cv::Point2f> prev(n1);
+  for (int i = 0; i < n1; i++) prev[i] = cv::Point2f(prev_matched[2 * i], prev_matched[2 * i + 1]);
+  std::vector<int> m12;
+  ORBmatcher m(nnratio, check_ori != 0);
+  const int n = m.SearchForInitialization(f1, f2, prev, m12, window_size);
+  for (int i = 0; i < n1; i++) { matches12[i] = m12[i]; prev_matched[2 * i] = prev[i].x; prev_matched[2 * i + 1] = prev[i].y; }
+  return n;
+}
+
+// SearchByProjection(F, vpMapPoints, th).  Query q: valid = mbTrackInView && !isBad(); xy = mTrackProjX / Y; level =
+// mnTrackScaleLevel; viewcos; desc; hasobs = Observations() > 0.  occupied[idx] (in/out) = F.mvpMapPoints[idx] is set and
+// has observations.  assigned[idx] = query stored into F.mvpMapPoints[idx] by this call, or -1.  Monocular (mvuRight = -1).
+int ref_orb_search_by_projection_mp(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                                    const float* scale_factors, int nlevels, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                    const float* q_xy, const int32_t* q_level, const float* q_viewcos, const uint8_t* q_desc,
+                                    const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned) {
+  Points pts;
+  Frame f;
+  f.N = n;
+  f.mvKeysUn = keypoints(kps_un, n); f.mvKeys = f.mvKeysUn;
+  f.mDescriptors = desc_mat(desc, n);
+  f.mvuRight.assign(n, -1.f);
+  f.mvScaleFactors.assign(scale_factors, scale_factors + nlevels);
+  f.mvpMapPoints.assign(n, nullptr);
+  for (int i = 0; i < n; i++)
+    if (occupied[i]) { f.mvpMapPoints[i] = pts.make(-1); f.mvpMapPoints[i]->nobs = 1; }
+  f.grid.kps.assign(kps_un, kps_un + n);
+  std::memcpy(f.grid.gp, gp, sizeof(f.grid.gp));
+  f.grid.build();
+  std::vector<MapPoint*> q(nq);
+  for (int i = 0; i < nq; i++) {
+    MapPoint* p = pts.make(i);
+    p->mbTrackInView = q_valid[i] != 0;
+    p->mTrackProjX = q_xy[2 * i]; p->mTrackProjY = q_xy[2 * i + 1];
+    p->mnTrackScaleLevel = q_level[i];
+    p->mTrackViewCos = q_viewcos[i];
+    p->desc = desc_mat(q_desc + (size_t)i * 32, 1);
+    p->nobs = q_hasobs[i] ? 1 : 0;
+    q[i] = p;
+  }
+  ORBmatcher m(nnratio, true);
+  const int nm = m.SearchByProjection(f, q, th);
+  for (int i = 0; i < n; i++) {
+    MapPoint* p = f.mvpMapPoints[i];
+    assigned[i] = (p && (long)p->mnId >= 0) ? (int32_t)p->mnId : -1;
+    occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
+  }
+  return nm;
+}
+
+}  // extern "C"

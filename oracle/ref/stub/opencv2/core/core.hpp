@@ -207,7 +207,13 @@ class Mat {
       }
     return *this;
   }
-  Mat t() const;                     // compile-only users (EDLine's least squares): see below
+  Mat t() const;
+  double dot(const Mat& o) const {
+    double s = 0;
+    for (int i = 0; i < rows; i++)
+      for (int j = 0; j < cols; j++) s += (double)at<float>(i, j) * o.at<float>(i, j);
+    return s;
+  }
   Mat row(int r) const { return rowRange(r, r + 1); }
   Mat col(int c) const { return colRange(c, c + 1); }
   Mat rowRange(int a, int b) const { Mat m(*this); m.data = data + (size_t)a * step.p; m.rows = b - a; return m; }
@@ -265,7 +271,6 @@ template <typename T, typename U> inline MatCommaInitializer_<T> operator<<(cons
   c, x;
   return c;
 }
-inline Mat operator+(const Mat&, const Mat&) { std::cerr << "oracle/ref stub: Mat + Mat is compile-only" << std::endl; std::abort(); }
 
 // InputArray / OutputArray: thin handles on a Mat
 class _InputArray {
@@ -287,8 +292,52 @@ typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
 inline void Mat::copyTo(const _OutputArray& o) const { Mat c = clone(); o.assign(c); }
 [[noreturn]] inline void stub_unreachable(const char* what) { std::cerr << "oracle/ref stub: " << what << " is compile-only" << std::endl; std::abort(); }
-inline Mat Mat::t() const { stub_unreachable("Mat::t"); }
-inline Mat operator*(const Mat&, const Mat&) { stub_unreachable("Mat * Mat"); }
+// Small dense float algebra (the pose arithmetic of ORBmatcher.cc).  Plain float accumulation in index order; OpenCV's
+// gemm may round differently, so nothing computed through these is claimed to be pinned.
+inline Mat Mat::t() const {
+  assert(type() == CV_32F);
+  Mat r(cols, rows, CV_32F);
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) r.at<float>(j, i) = at<float>(i, j);
+  return r;
+}
+inline Mat operator*(const Mat& a, const Mat& b) {
+  assert(a.type() == CV_32F && b.type() == CV_32F && a.cols == b.rows);
+  Mat r(a.rows, b.cols, CV_32F);
+  for (int i = 0; i < a.rows; i++)
+    for (int j = 0; j < b.cols; j++) {
+      float acc = 0;
+      for (int k = 0; k < a.cols; k++) acc += a.at<float>(i, k) * b.at<float>(k, j);
+      r.at<float>(i, j) = acc;
+    }
+  return r;
+}
+inline Mat mat_scale(const Mat& a, double s) {
+  assert(a.type() == CV_32F);
+  Mat r(a.rows, a.cols, CV_32F);
+  for (int i = 0; i < a.rows; i++)
+    for (int j = 0; j < a.cols; j++) r.at<float>(i, j) = (float)(a.at<float>(i, j) * s);
+  return r;
+}
+inline Mat operator*(double s, const Mat& a) { return mat_scale(a, s); }
+inline Mat operator*(const Mat& a, double s) { return mat_scale(a, s); }
+inline Mat operator-(const Mat& a) { return mat_scale(a, -1.0); }
+inline Mat mat_addsub(const Mat& a, const Mat& b, float sgn) {
+  assert(a.type() == CV_32F && b.type() == CV_32F && a.rows == b.rows && a.cols == b.cols);
+  Mat r(a.rows, a.cols, CV_32F);
+  for (int i = 0; i < a.rows; i++)
+    for (int j = 0; j < a.cols; j++) r.at<float>(i, j) = a.at<float>(i, j) + sgn * b.at<float>(i, j);
+  return r;
+}
+inline Mat operator-(const Mat& a, const Mat& b) { return mat_addsub(a, b, -1.f); }
+inline Mat operator+(const Mat& a, const Mat& b) { return mat_addsub(a, b, 1.f); }
+inline double norm(const Mat& a) {
+  assert(a.type() == CV_32F);
+  double s = 0;
+  for (int i = 0; i < a.rows; i++)
+    for (int j = 0; j < a.cols; j++) s += (double)a.at<float>(i, j) * a.at<float>(i, j);
+  return std::sqrt(s);
+}
 inline bool solve(const Mat&, const Mat&, Mat&, int = 0) { stub_unreachable("cv::solve"); }
 inline void cvtColor(const Mat&, Mat&, int) { stub_unreachable("cv::cvtColor"); }
 inline void pyrDown(const Mat&, Mat&, Size = Size()) { stub_unreachable("cv::pyrDown (numOctaves is 1 on this path)"); }

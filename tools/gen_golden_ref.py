@@ -236,6 +236,109 @@ def gen_lines(S, out):
         print("lines", name, "keylines", len(kl))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's ORBmatcher (src/ORBmatcher.cc compiled into oracle/_ref/libmatcher_ref.so against stand-ins for
+# Frame / KeyFrame / MapPoint): the searches without pose algebra.  Inputs come from the test-suite generators.
+# ---------------------------------------------------------------------------------------------------------------
+def _test_module(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tests", name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def ref_matcher_lib():
+    R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libmatcher_ref.so"))
+    V, I, F = C.c_void_p, C.c_int, C.c_float
+    R.ref_orb_search_by_bow.argtypes = [V, V, V, V, I, V, V, V, I, F, I, V]
+    R.ref_orb_search_by_bow_kfkf.argtypes = [V, V, V, V, I, V, V, V, V, I, F, I, V]
+    R.ref_orb_search_for_initialization.argtypes = [V, V, I, V, V, I, V, V, I, F, I, V]
+    R.ref_orb_search_by_projection_mp.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, F, F, V]
+    return R
+
+
+BOW_CASES = [(300, 2000, 100, 0.7, 1), (302, 1500, 10, 0.9, 0), (305, 777, 40, 0.7, 1)]     # seed, n, nodes, nnratio, checkOri
+KFKF_CASES = [(400, 1500, 80), (401, 300, 5)]                                              # seed, n, nodes (nnratio 0.8)
+FRAME_CASES = [(31, 2000, False), (32, 700, True)]                                         # seed, n, distorted bounds
+
+
+def bow_inputs(S, TM, seed, n, nodes):
+    return TM._bow_sets(S, seed, n, nodes)
+
+
+def kfkf_inputs(S, TM, seed, n, nodes):
+    kf, fr = TM._bow_sets(S, seed, n, nodes, valid_p=0.85)
+    v2 = (S.SplitMix64(seed + 5).uniform(n) < 0.85).astype(np.uint8)
+    return kf, fr, v2
+
+
+def frame_inputs(S, P, TF, seed, n, distorted):
+    f1, f2, _, _ = TF.make_frame_pair(P, S, seed, n, nl=0)
+    gp = TF._gp(P, distorted=distorted)
+    q = TF._queries_points(P, S, 900 + seed, f1, f2, "mp")
+    occ0 = (S.SplitMix64(77 + seed).uniform(n) < 0.1).astype(np.uint8)
+    return f1, f2, gp, q, occ0
+
+
+def reference_bow(R, kf, fr, nnratio, check):
+    n1, n2 = len(kf["desc"]), len(fr["desc"])
+    out = np.zeros(max(n2, 1), np.int32)
+    c = R.ref_orb_search_by_bow(p(kf["desc"]), p(kf["angle"]), p(kf["node"]), p(kf["valid"]), n1, p(fr["desc"]), p(fr["angle"]),
+                                p(fr["node"]), n2, nnratio, check, p(out))
+    return c, out[:n2]
+
+
+def reference_kfkf(R, kf, fr, v2):
+    n = len(kf["desc"])
+    out = np.zeros(max(n, 1), np.int32)
+    c = R.ref_orb_search_by_bow_kfkf(p(kf["desc"]), p(kf["angle"]), p(kf["node"]), p(kf["valid"]), n, p(fr["desc"]), p(fr["angle"]),
+                                     p(fr["node"]), p(v2), n, 0.8, 1, p(out))
+    return c, out[:n]
+
+
+def reference_init(R, P, f1, f2, gp):
+    n1, n2 = len(f1["kps"]), len(f2["kps"])
+    prev = np.stack([f1["kps"]["x"], f1["kps"]["y"]], 1).astype(np.float32)
+    out = np.zeros(max(n1, 1), np.int32)
+    g = P._gp_array(gp)
+    c = R.ref_orb_search_for_initialization(p(f1["kps"]), p(f1["desc"]), n1, p(f2["kps"]), p(f2["desc"]), n2, p(g), p(prev), 100, 0.9, 1,
+                                            p(out))
+    return c, out[:n1], prev
+
+
+def reference_proj_mp(R, P, f2, gp, q, occ0, scale):
+    n = len(f2["kps"])
+    occ, asg = occ0.copy(), np.zeros(max(n, 1), np.int32)
+    g = P._gp_array(gp)
+    c = R.ref_orb_search_by_projection_mp(p(f2["kps"]), p(f2["desc"]), n, p(g), p(scale), len(scale), p(occ), len(q["valid"]),
+                                          p(q["valid"]), p(q["xy"]), p(q["level"]), p(q["viewcos"]), p(q["desc"]), p(q["hasobs"]),
+                                          3.0, 0.8, p(asg))
+    return c, asg[:n], occ
+
+
+def gen_matchers(S, out):
+    R, P = ref_matcher_lib(), _util.plslam()
+    TM, TF = _test_module("test_match"), _test_module("test_frame_search")
+    g = {}
+    for seed, n, nodes, nn, chk in BOW_CASES:
+        kf, fr = bow_inputs(S, TM, seed, n, nodes)
+        c, m = reference_bow(R, kf, fr, nn, chk)
+        g["bow_%d_n" % seed], g["bow_%d_m" % seed] = c, m
+    for seed, n, nodes in KFKF_CASES:
+        kf, fr, v2 = kfkf_inputs(S, TM, seed, n, nodes)
+        c, m = reference_kfkf(R, kf, fr, v2)
+        g["kfkf_%d_n" % seed], g["kfkf_%d_m" % seed] = c, m
+    for seed, n, dist in FRAME_CASES:
+        f1, f2, gp, q, occ0 = frame_inputs(S, P, TF, seed, n, dist)
+        c, m, prev = reference_init(R, P, f1, f2, gp)
+        g["init_%d_n" % seed], g["init_%d_m" % seed], g["init_%d_prev" % seed] = c, m, prev
+        c, a, o = reference_proj_mp(R, P, f2, gp, q, occ0, TF.SCALE)
+        g["proj_%d_n" % seed], g["proj_%d_asg" % seed], g["proj_%d_occ" % seed] = c, a, o
+    np.savez_compressed(os.path.join(out, "ref_orbmatcher.npz"), **g)
+    print("matchers:", {k: int(v) for k, v in g.items() if k.endswith("_n")})
+
+
 def main():
     S = _util.synth()
     VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
@@ -254,6 +357,7 @@ def main():
     gen_orb(S, out)
     gen_line_grid(S, out)
     gen_lines(S, out)
+    gen_matchers(S, out)
 
 
 if __name__ == "__main__":
