@@ -29,9 +29,19 @@ g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -I "$HERE/s
   -o "$OUT/libline_ref.so" "$HERE/ref_line.cc" "$REF/src/LineExtractor.cpp" "$LD/src/LSDDetector_custom.cpp" \
   "$LD/src/binary_descriptor_custom.cpp" "$HERE/../img_ops.cc" "$HERE/../lsd.cc"
 echo "built $OUT/libline_ref.so"
+# The oracle's grid / descriptor helpers the matcher harnesses lean on, compiled apart (slam_stub.h is force-included
+# into the reference's translation units only).
+for f in frame_search match img_ops; do
+  g++ -O2 -std=c++14 -fPIC -c -w -ffp-contract=off -fno-fast-math -o "$OUT/plo_$f.o" "$HERE/../$f.cc"
+done
+PLO_OBJS="$OUT/plo_frame_search.o $OUT/plo_match.o $OUT/plo_img_ops.o"
+MFLAGS="-O2 -std=c++14 -fPIC -shared -w -pthread -ffp-contract=off -fno-fast-math -DMAPPOINT_H -DKEYFRAME_H -DFRAME_H"
+MINC="-I $HERE/stub -I $LD/include -I $REF/include -I $REF -include $HERE/slam_stub.h"
 # The reference's ORBmatcher.cc against stand-ins for Frame / KeyFrame / MapPoint (slam_stub.h replaces the three headers,
 # whose include guards are pre-defined); grid lookups and descriptor helpers from the oracle.
-g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -DMAPPOINT_H -DKEYFRAME_H -DFRAME_H -I "$HERE/stub" -I "$REF/include" \
-  -I "$REF" -include "$HERE/slam_stub.h" -o "$OUT/libmatcher_ref.so" "$HERE/ref_matcher.cc" "$REF/src/ORBmatcher.cc" \
-  "$D/DBoW2/FeatureVector.cpp" "$D/DBoW2/BowVector.cpp" "$HERE/../frame_search.cc" "$HERE/../match.cc" "$HERE/../img_ops.cc"
+g++ $MFLAGS $MINC -o "$OUT/libmatcher_ref.so" "$HERE/ref_matcher.cc" "$REF/src/ORBmatcher.cc" \
+  "$D/DBoW2/FeatureVector.cpp" "$D/DBoW2/BowVector.cpp" $PLO_OBJS
 echo "built $OUT/libmatcher_ref.so"
+# The reference's LSDmatcher.cpp against the same stand-ins (+ MapLine); cv::BFMatcher::knnMatch = the oracle's knn2.
+g++ $MFLAGS $MINC -o "$OUT/liblsdmatcher_ref.so" "$HERE/ref_lsdmatcher.cc" "$REF/src/LSDmatcher.cpp" "$D/DBoW2/FeatureVector.cpp" "$D/DBoW2/BowVector.cpp" $PLO_OBJS
+echo "built $OUT/liblsdmatcher_ref.so"

@@ -1,0 +1,163 @@
+// oracle/_ref: the reference's own LSDmatcher (src/LSDmatcher.cpp, every function, compiled from the source where it
+// lies by oracle/ref/build_ref.sh) driven from flat arrays.  Frame / KeyFrame / MapLine are the stand-ins of slam_stub.h;
+// cv::BFMatcher::knnMatch and the grid lookup behind Frame::GetFeaturesInAreaForLine are the oracle's restatements; the
+// matcher's debugging pictures (cv::line / cv::imwrite) are no-ops.  Entry points:
+//   FrameBFMatch + lineDescriptorMAD                 src/LSDmatcher.cpp:462-486, 627-652
+//   SearchDouble(Frame&, Frame&, LineMatches)        :427-460
+//   SearchByProjection(Cur, Last, th)                :72-176
+//   SearchByProjection(F, vpMapLines, th)            :221-338
+// TEST INFRASTRUCTURE ONLY.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "LSDmatcher.h"
+
+namespace ORB_SLAM2 {
+void LineGridLookup::build() {
+  cellStart.assign(64 * 48 + 1, 0);
+  cellItems.assign(kl.size() * 64 + 64, 0);
+  plo_frame_assign_grid_lines(kl.data(), (int)kl.size(), gp, cellStart.data(), cellItems.data(), (int)cellItems.size());
+}
+std::vector<size_t> LineGridLookup::query(float x1, float y1, float x2, float y2, float r, float TH) const {
+  std::vector<int32_t> out(kl.size() + 1);
+  const int n = plo_features_in_area_for_line(kl.data(), fn.data(), (int)kl.size(), gp, cellStart.data(), cellItems.data(), x1, y1, x2,
+                                              y2, r, TH, out.data(), (int)out.size());
+  return std::vector<size_t>(out.begin(), out.begin() + n);
+}
+}  // namespace ORB_SLAM2
+
+using namespace ORB_SLAM2;
+
+namespace {
+struct Matcher : LSDmatcher {   // FrameBFMatch / lineDescriptorMAD are protected members
+  Matcher(float r) : LSDmatcher(r, true) {}
+  using LSDmatcher::FrameBFMatch;
+  using LSDmatcher::lineDescriptorMAD;
+};
+cv::Mat desc_mat(const uint8_t* d, int n) {
+  cv::Mat m(n > 0 ? n : 1, 32, CV_8U);
+  if (n > 0) std::memcpy(m.data, d, (size_t)n * 32);
+  if (n == 0) m = m.rowRange(0, 0);
+  return m;
+}
+cv::Mat identity4() {
+  cv::Mat m = cv::Mat::zeros(4, 4, CV_32F);
+  for (int i = 0; i < 4; i++) m.at<float>(i, i) = 1.f;
+  return m;
+}
+struct Lines {
+  std::vector<std::unique_ptr<MapLine> > all;
+  MapLine* make(long id) {
+    all.emplace_back(new MapLine());
+    all.back()->mnId = (unsigned long)id;
+    return all.back().get();
+  }
+};
+void fill_frame(Frame& f, const plo_keyline* kl, const uint8_t* ldesc, const double* fn, int nl, const float gp[6]) {
+  f.NL = nl;
+  f.mvKeylinesUn.resize(nl);
+  f.mvKeyLineFunctions.resize(nl);
+  for (int i = 0; i < nl; i++) {
+    std::memcpy(&f.mvKeylinesUn[i], &kl[i], sizeof(plo_keyline));
+    f.mvKeyLineFunctions[i](0) = fn[3 * i]; f.mvKeyLineFunctions[i](1) = fn[3 * i + 1]; f.mvKeyLineFunctions[i](2) = fn[3 * i + 2];
+  }
+  f.mLdesc = desc_mat(ldesc, nl);
+  f.mvpMapLines.assign(nl, nullptr);
+  f.mvbLineOutlier.assign(nl, false);
+  f.mTcw = identity4();
+  f.lineGrid.kl.assign(kl, kl + nl);
+  f.lineGrid.fn.assign(fn, fn + (size_t)nl * 3);
+  std::memcpy(f.lineGrid.gp, gp, sizeof(f.lineGrid.gp));
+  f.lineGrid.build();
+}
+}  // namespace
+
+extern "C" {
+
+void ref_line_bfmatch(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float th, float nnratio, int32_t* matches) {
+  Matcher m(nnratio);
+  std::vector<int> out;
+  m.FrameBFMatch(desc_mat(d1, n1), desc_mat(d2, n2), out, th);
+  for (int i = 0; i < n1; i++) matches[i] = out[i];
+}
+
+int ref_line_search_double(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnratio, int32_t* matches12) {
+  Frame a, b;
+  a.NL = n1; b.NL = n2;
+  a.mLdesc = desc_mat(d1, n1);
+  b.mLdesc = desc_mat(d2, n2);
+  LSDmatcher m(nnratio, true);
+  std::vector<int> out;
+  const int n = m.SearchDouble(a, b, out);
+  for (int i = 0; i < n1; i++) matches12[i] = i < (int)out.size() ? out[i] : -1;
+  return n;
+}
+
+// SearchByProjection(Cur, Last, th).  Query i = Last line i: valid = MapLine && !outlier && isInFrustum; seg = mTrackProj*;
+// length = Last.mvKeylinesUn[i].lineLength; desc; hasobs.  occupied (in/out), assigned[i2] = query or -1.
+int ref_line_search_by_projection_frame(const plo_keyline* kl, const uint8_t* ldesc, const double* fn, int nl, const float gp[6],
+                                        uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_seg, const float* q_length,
+                                        const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int32_t* assigned) {
+  Lines ls;
+  Frame cur, last;
+  fill_frame(cur, kl, ldesc, fn, nl, gp);
+  for (int i = 0; i < nl; i++)
+    if (occupied[i]) { cur.mvpMapLines[i] = ls.make(-1); cur.mvpMapLines[i]->nobs = 1; }
+  last.NL = nq;
+  last.mvKeylinesUn.resize(nq);
+  last.mvpMapLines.assign(nq, nullptr);
+  last.mvbLineOutlier.assign(nq, false);
+  last.mTcw = identity4();
+  for (int i = 0; i < nq; i++) {
+    std::memset(&last.mvKeylinesUn[i], 0, sizeof(plo_keyline));
+    last.mvKeylinesUn[i].lineLength = q_length[i];
+    if (!q_valid[i]) continue;
+    MapLine* p = ls.make(i);
+    p->mbTrackInView = true;
+    p->mTrackProjX1 = q_seg[4 * i]; p->mTrackProjY1 = q_seg[4 * i + 1]; p->mTrackProjX2 = q_seg[4 * i + 2]; p->mTrackProjY2 = q_seg[4 * i + 3];
+    p->mLDescriptor = desc_mat(q_desc + (size_t)i * 32, 1);
+    p->nobs = q_hasobs[i] ? 1 : 0;
+    last.mvpMapLines[i] = p;
+  }
+  LSDmatcher m(0.9f, true);
+  const int n = m.SearchByProjection(cur, last, th);
+  for (int i = 0; i < nl; i++) {
+    MapLine* p = cur.mvpMapLines[i];
+    assigned[i] = (p && (long)p->mnId >= 0) ? (int32_t)p->mnId : -1;
+    occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
+  }
+  return n;
+}
+
+// SearchByProjection(F, vpMapLines, th).  Query: valid = mbTrackInView && !isBad(); seg; viewcos; desc; hasobs.
+int ref_line_search_by_projection_ml(const plo_keyline* kl, const uint8_t* ldesc, const double* fn, int nl, const float gp[6],
+                                     uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_seg, const float* q_viewcos,
+                                     const uint8_t* q_desc, const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned) {
+  Lines ls;
+  Frame f;
+  fill_frame(f, kl, ldesc, fn, nl, gp);
+  for (int i = 0; i < nl; i++)
+    if (occupied[i]) { f.mvpMapLines[i] = ls.make(-1); f.mvpMapLines[i]->nobs = 1; }
+  std::vector<MapLine*> q(nq);
+  for (int i = 0; i < nq; i++) {
+    MapLine* p = ls.make(i);
+    p->mbTrackInView = q_valid[i] != 0;
+    p->mTrackProjX1 = q_seg[4 * i]; p->mTrackProjY1 = q_seg[4 * i + 1]; p->mTrackProjX2 = q_seg[4 * i + 2]; p->mTrackProjY2 = q_seg[4 * i + 3];
+    p->mTrackViewCos = q_viewcos[i];
+    p->mLDescriptor = desc_mat(q_desc + (size_t)i * 32, 1);
+    p->nobs = q_hasobs[i] ? 1 : 0;
+    q[i] = p;
+  }
+  LSDmatcher m(nnratio, true);
+  const int n = m.SearchByProjection(f, q, th);
+  for (int i = 0; i < nl; i++) {
+    MapLine* p = f.mvpMapLines[i];
+    assigned[i] = (p && (long)p->mnId >= 0) ? (int32_t)p->mnId : -1;
+    occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
+  }
+  return n;
+}
+
+}  // extern "C"

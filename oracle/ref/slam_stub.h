@@ -13,11 +13,18 @@
 #include <vector>
 
 #include <opencv2/core/core.hpp>
+#include <opencv2/line_descriptor/descriptor.hpp>
+#include <eigen3/Eigen/Core>
 
 #include "Thirdparty/DBoW2/DBoW2/BowVector.h"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 
 using namespace std;   // the reference's own headers do this, and ORBmatcher.h relies on it (unqualified vector / pair)
+using namespace cv;
+using namespace cv::line_descriptor;
+using namespace Eigen;
+#define ORB_SLAM2_MAPLINE_H
+#include "auxiliar.h"   // the reference's own header: sort functors, SkewSymmetricMatrix, Vector6d
 
 namespace ORB_SLAM2 {
 
@@ -55,6 +62,45 @@ class MapPoint {
   void Replace(MapPoint* p) { replaced = p; }
 };
 
+class MapLine {   // include/MapLine.h, the members src/LSDmatcher.cpp touches
+ public:
+  float mTrackProjX1 = 0, mTrackProjY1 = 0, mTrackProjX2 = 0, mTrackProjY2 = 0;
+  bool mbTrackInView = false;
+  int mnTrackScaleLevel = 0;
+  float mTrackViewCos = 1;
+  long unsigned int mnLastFrameSeen = 0, mnFuseCandidateForKF = 0, mnId = 0;
+  cv::Mat mLDescriptor;
+  bool bad = false;
+  Vector6d pos;
+  Eigen::Vector3d normal;
+  float minDist = 0, maxDist = 1e30f;
+  int nobs = 1, predicted = 0;
+  std::map<KeyFrame*, size_t> obs;
+  MapLine* replaced = nullptr;
+  bool isBad() const { return bad; }
+  cv::Mat GetDescriptor() const { return mLDescriptor.clone(); }
+  Vector6d GetWorldPos() const { return pos; }
+  Eigen::Vector3d GetNormal() const { return normal; }
+  float GetMinDistanceInvariance() const { return minDist; }
+  float GetMaxDistanceInvariance() const { return maxDist; }
+  int PredictScale(const float&, const float&) const { return predicted; }
+  int PredictScale(const float&, KeyFrame*) const { return predicted; }
+  int Observations() const { return nobs; }
+  void AddObservation(KeyFrame* k, size_t i) { obs[k] = i; }
+  bool IsInKeyFrame(KeyFrame* k) const { return obs.count(k) != 0; }
+  int GetIndexInKeyFrame(KeyFrame* k) const { auto it = obs.find(k); return it == obs.end() ? -1 : (int)it->second; }
+  void Replace(MapLine* p) { replaced = p; }
+};
+
+struct LineGridLookup {   // the oracle's Frame::GetFeaturesInAreaForLine on a CSR grid (oracle/frame_search.cc)
+  std::vector<plo_keyline> kl;
+  std::vector<double> fn;
+  std::vector<int32_t> cellStart, cellItems;
+  float gp[6] = {0, 0, 0, 0, 0, 0};
+  void build();
+  std::vector<size_t> query(float x1, float y1, float x2, float y2, float r, float TH) const;
+};
+
 struct GridLookup {   // the oracle's Frame::GetFeaturesInArea on a CSR grid (oracle/frame_search.cc)
   std::vector<plo_keypoint> kps;
   std::vector<int32_t> cellStart, cellItems;
@@ -80,6 +126,28 @@ class Frame {
                                         const int maxLevel = -1) const {
     return grid.query(x, y, r, minLevel, maxLevel);
   }
+  // lines
+  int NL = 0;
+  std::vector<KeyLine> mvKeylinesUn;
+  std::vector<Eigen::Vector3d> mvKeyLineFunctions;
+  std::vector<MapLine*> mvpMapLines;
+  std::vector<bool> mvbLineOutlier;
+  std::vector<float> mvScaleFactorsLine;
+  cv::Mat mLdesc, ImageGray, mK;
+  LineGridLookup lineGrid;
+  std::vector<size_t> GetFeaturesInAreaForLine(const float& x1, const float& y1, const float& x2, const float& y2, const float& r,
+                                               const int minLevel = -1, const int maxLevel = -1, const float TH = 0.998) const {
+    return lineGrid.query(x1, y1, x2, y2, r, TH);
+  }
+  std::vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r,
+                                     const int minLevel = -1, const int maxLevel = -1, const float TH = 0.998) const {
+    return lineGrid.query(x1, y1, x2, y2, r, TH);
+  }
+  bool isInFrustum(MapLine* p, float) const { return p->mbTrackInView; }   // the harness stores the verdict in the MapLine
+  void lineDescriptorMAD(std::vector<std::vector<cv::DMatch> >, double&, double&) const {
+    std::cerr << "oracle/ref stub: Frame::lineDescriptorMAD is compile-only" << std::endl;
+    std::abort();
+  }
 };
 
 class KeyFrame {
@@ -95,6 +163,19 @@ class KeyFrame {
   long unsigned int mnId = 0;
   int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
   GridLookup grid;
+  // lines
+  int NL = 0;
+  std::vector<KeyLine> mvKeyLines, mvKeylinesUn;
+  std::vector<Eigen::Vector3d> mvKeyLineFunctions;
+  std::vector<MapLine*> mvpMapLines;
+  std::vector<float> mvScaleFactorsLine;
+  float mfLogScaleFactorLine = 0;
+  cv::Mat mLineDescriptors, ImageGray, mK;
+  MapLine* GetMapLine(const size_t& i) const { return mvpMapLines[i]; }
+  std::vector<MapLine*> GetMapLineMatches() const { return mvpMapLines; }
+  void AddMapLine(MapLine* p, const size_t& i) { mvpMapLines[i] = p; }
+  std::vector<size_t> GetLinesInArea(const float&, const float&, const float&, const float&, const float&, const int = -1,
+                                     const int = -1, const float = 0.998) const { return std::vector<size_t>(); }
   std::vector<MapPoint*> GetMapPointMatches() const { return mvpMapPoints; }
   std::set<MapPoint*> GetMapPoints() const {
     std::set<MapPoint*> s;

@@ -208,6 +208,18 @@ class Mat {
     return *this;
   }
   Mat t() const;
+  Mat inv(int = 0) const { std::cerr << "oracle/ref stub: Mat::inv is compile-only" << std::endl; std::abort(); }
+  Mat cross(const Mat& o) const {
+    Mat r(rows, cols, CV_32F);
+    const float a0 = at<float>(0), a1 = at<float>(1), a2 = at<float>(2), b0 = o.at<float>(0), b1 = o.at<float>(1), b2 = o.at<float>(2);
+    r.at<float>(0) = a1 * b2 - a2 * b1; r.at<float>(1) = a2 * b0 - a0 * b2; r.at<float>(2) = a0 * b1 - a1 * b0;
+    return r;
+  }
+  Mat& operator/=(double s) {
+    for (int i = 0; i < rows; i++)
+      for (int j = 0; j < cols; j++) at<float>(i, j) = (float)(at<float>(i, j) / s);
+    return *this;
+  }
   double dot(const Mat& o) const {
     double s = 0;
     for (int i = 0; i < rows; i++)
@@ -421,6 +433,23 @@ class LineIterator {
     count = std::max(std::abs(q.x - p.x), std::abs(q.y - p.y)) + 1;
   }
 };
+// cv::BFMatcher(NORM_HAMMING, false)::knnMatch(q, t, matches, 2) = the oracle's restatement (plo_knn2)
+class BFMatcher {
+ public:
+  BFMatcher(int = NORM_HAMMING, bool = false) {}
+  void knnMatch(const Mat& q, const Mat& t, std::vector<std::vector<DMatch> >& matches, int k) const {
+    assert(k == 2 && q.cols == 32 && t.cols == 32 && q.isContinuous() && t.isContinuous());
+    std::vector<int32_t> idx((size_t)q.rows * 2 + 2), dist((size_t)q.rows * 2 + 2);
+    plo_knn2(q.data, q.rows, t.data, t.rows, idx.data(), dist.data());
+    matches.assign(q.rows, std::vector<DMatch>());
+    for (int i = 0; i < q.rows; i++)
+      for (int j = 0; j < 2 && j < t.rows; j++) matches[i].push_back(DMatch(i, idx[2 * i + j], (float)dist[2 * i + j]));
+  }
+};
+// debugging output of the matchers: no-ops
+enum { CV_AA = 16, LINE_AA = 16 };
+inline void line(Mat&, Point, Point, const Scalar&, int = 1, int = 8, int = 0) {}
+inline bool imwrite(const std::string&, const Mat&) { return true; }
 struct KeyPointsFilter {   // only ComputeKeyPointsOld (dead code in the reference) uses it
   static void retainBest(std::vector<KeyPoint>& k, int n) {
     if (n >= 0 && (int)k.size() > n) {
