@@ -349,7 +349,7 @@ static int search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t*
     three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
     for (int i = 0; i < HISTO_LENGTH; i++)
       if (i != ind1 && i != ind2 && i != ind3)
-        for (int idx : rotHist[i]) { assigned[idx] = -1; nmatches--; }
+        for (int idx : rotHist[i]) { assigned[idx] = -1; occupied[idx] = 0; nmatches--; }   // mvpMapPoints[idx] = NULL
   }
   return nmatches;
 }

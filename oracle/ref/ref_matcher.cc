@@ -1,11 +1,13 @@
 // oracle/_ref: the reference's own ORBmatcher (src/ORBmatcher.cc, every function, compiled from the source where it lies
 // by oracle/ref/build_ref.sh) driven from flat arrays.  Frame / KeyFrame / MapPoint are the stand-ins of slam_stub.h
 // (the real classes pull in the whole SLAM system); the grid lookup behind Frame::GetFeaturesInArea is the oracle's.
-// Entry points exist for the searches that involve no pose algebra:
+// Entry points:
 //   SearchByBoW(KeyFrame*, Frame&)            src/ORBmatcher.cc:187-327   (+ ComputeThreeMaxima :1718-1759, DescriptorDistance)
 //   SearchByBoW(KeyFrame*, KeyFrame*)         :574-709
 //   SearchForInitialization                   :455-572
 //   SearchByProjection(Frame&, MapPoints, th) :56-144
+//   SearchByProjection(Cur, Last, th, bMono)  :1441-1585   } driven with the current pose = identity; the projection the
+//   SearchByProjection(Cur, pKF, found, th, ORBdist) :1587-1716 } reference computes inline is handed back to the caller
 // TEST INFRASTRUCTURE ONLY.
 #include <cstdint>
 #include <cstring>
@@ -172,6 +174,124 @@ int ref_orb_search_by_projection_mp(const plo_keypoint* kps_un, const uint8_t* d
     MapPoint* p = f.mvpMapPoints[i];
     assigned[i] = (p && (long)p->mnId >= 0) ? (int32_t)p->mnId : -1;
     occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
+  }
+  return nm;
+}
+
+}  // extern "C"
+
+// Shared by the two pose-driven searches below: the current frame with pose = identity (so that the reference's
+// Rcw*x3Dw+tcw returns x3Dw exactly and nothing depends on how the stub's float algebra rounds).
+static void fill_current(Frame& f, Points& pts, const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                         const float* scale_factors, int nlevels, const uint8_t* occupied, const float K[4]) {
+  f.N = n;
+  f.mvKeysUn = keypoints(kps_un, n); f.mvKeys = f.mvKeysUn;
+  f.mDescriptors = desc_mat(desc, n);
+  f.mvuRight.assign(n, -1.f);
+  f.mvScaleFactors.assign(scale_factors, scale_factors + nlevels);
+  f.mvpMapPoints.assign(n, nullptr);
+  for (int i = 0; i < n; i++)
+    if (occupied[i]) { f.mvpMapPoints[i] = pts.make(-1); f.mvpMapPoints[i]->nobs = 1; }
+  f.grid.kps.assign(kps_un, kps_un + n);
+  std::memcpy(f.grid.gp, gp, sizeof(f.grid.gp));
+  f.grid.build();
+  f.fx = K[0]; f.fy = K[1]; f.cx = K[2]; f.cy = K[3];
+  Frame::mnMinX = gp[0]; Frame::mnMinY = gp[1]; Frame::mnMaxX = gp[2]; Frame::mnMaxY = gp[3];
+  f.mTcw = cv::Mat::zeros(4, 4, CV_32F);
+  for (int i = 0; i < 4; i++) f.mTcw.at<float>(i, i) = 1.f;
+}
+static cv::Mat point3(const float* x) {
+  cv::Mat m(3, 1, CV_32F);
+  for (int i = 0; i < 3; i++) m.at<float>(i) = x[i];
+  return m;
+}
+// The projection exactly as ORBmatcher.cc:1476-1484 / :1617-1622 writes it (same compiler, same flags): what the caller of the
+// flat-array searches hands over as q_uv.
+static void project(const float* x, const float K[4], float* uv, uint8_t* front) {
+  const float xc = x[0], yc = x[1];
+  const float invzc = 1.0 / x[2];
+  uv[0] = K[0] * xc * invzc + K[2];
+  uv[1] = K[1] * yc * invzc + K[3];
+  if (front) *front = invzc < 0 ? 0 : 1;
+}
+
+extern "C" {
+
+// SearchByProjection(CurrentFrame, LastFrame, th, bMono), src/ORBmatcher.cc:1441-1585.  Query i = LastFrame feature i with
+// MapPoint (q_mp) at world position q_xyz; mode 0 = bMono, 1 = forward (LastFrame ahead along z by more than mb), 2 = backward.
+// Writes the projections (uv_out) and invzc >= 0 (front_out) the flat-array searches take as inputs.
+int ref_orb_search_by_projection_frame(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                                       const float* scale_factors, int nlevels, uint8_t* occupied, int nq, const uint8_t* q_mp,
+                                       const uint8_t* q_outlier, const float* q_xyz, const int32_t* q_octave, const float* q_angle,
+                                       const uint8_t* q_desc, const uint8_t* q_hasobs, const float K[4], float th, int mode,
+                                       int check_ori, float* uv_out, uint8_t* front_out, int32_t* assigned) {
+  Points pts;
+  Frame cur, last;
+  fill_current(cur, pts, kps_un, desc, n, gp, scale_factors, nlevels, occupied, K);
+  cur.mb = 0.1f;
+  last.N = nq;
+  last.mvKeys.resize(nq); last.mvKeysUn.resize(nq);
+  last.mvpMapPoints.assign(nq, nullptr);
+  last.mvbOutlier.assign(nq, false);
+  last.mTcw = cur.mTcw.clone();
+  last.mTcw.at<float>(2, 3) = mode == 1 ? 1.f : mode == 2 ? -1.f : 0.f;
+  for (int i = 0; i < nq; i++) {
+    last.mvKeys[i].octave = q_octave[i]; last.mvKeysUn[i].octave = q_octave[i];
+    last.mvKeys[i].angle = q_angle[i]; last.mvKeysUn[i].angle = q_angle[i];
+    last.mvbOutlier[i] = q_outlier[i] != 0;
+    project(q_xyz + 3 * i, K, uv_out + 2 * i, front_out + i);
+    if (!q_mp[i]) continue;
+    MapPoint* p = pts.make(i);
+    p->pos = point3(q_xyz + 3 * i);
+    p->desc = desc_mat(q_desc + (size_t)i * 32, 1);
+    p->nobs = q_hasobs[i] ? 1 : 0;
+    last.mvpMapPoints[i] = p;
+  }
+  ORBmatcher m(0.9f, check_ori != 0);
+  const int nm = m.SearchByProjection(cur, last, th, mode == 0);
+  for (int i = 0; i < n; i++) {
+    MapPoint* p = cur.mvpMapPoints[i];
+    assigned[i] = (p && (long)p->mnId >= 0) ? (int32_t)p->mnId : -1;
+    occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
+  }
+  return nm;
+}
+
+// SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1587-1716 (relocalisation).
+// Query i = pKF feature i: q_mp, q_bad, q_found (in sAlreadyFound), q_inrange (0 = the point's distance-invariance interval
+// excludes it), q_level = PredictScale.  occupied = CurrentFrame.mvpMapPoints[i2] != NULL.
+int ref_orb_search_by_projection_kf(const plo_keypoint* kps_un, const uint8_t* desc, int n, const float gp[6],
+                                    const float* scale_factors, int nlevels, uint8_t* occupied, int nq, const uint8_t* q_mp,
+                                    const uint8_t* q_bad, const uint8_t* q_found, const uint8_t* q_inrange, const float* q_xyz,
+                                    const int32_t* q_level, const float* q_angle, const uint8_t* q_desc, const float K[4], float th,
+                                    int orb_dist, int check_ori, float* uv_out, int32_t* assigned) {
+  Points pts;
+  Frame cur;
+  fill_current(cur, pts, kps_un, desc, n, gp, scale_factors, nlevels, occupied, K);
+  KeyFrame kf;
+  kf.N = nq;
+  kf.mvKeysUn.resize(nq);
+  kf.mvpMapPoints.assign(nq, nullptr);
+  std::set<MapPoint*> found;
+  for (int i = 0; i < nq; i++) {
+    kf.mvKeysUn[i].angle = q_angle[i];
+    project(q_xyz + 3 * i, K, uv_out + 2 * i, nullptr);
+    if (!q_mp[i]) continue;
+    MapPoint* p = pts.make(i);
+    p->pos = point3(q_xyz + 3 * i);
+    p->desc = desc_mat(q_desc + (size_t)i * 32, 1);
+    p->bad = q_bad[i] != 0;
+    p->predicted = q_level[i];
+    if (!q_inrange[i]) { p->minDist = 1e29f; }
+    if (q_found[i]) found.insert(p);
+    kf.mvpMapPoints[i] = p;
+  }
+  ORBmatcher m(0.9f, check_ori != 0);
+  const int nm = m.SearchByProjection(cur, &kf, found, th, orb_dist);
+  for (int i = 0; i < n; i++) {
+    MapPoint* p = cur.mvpMapPoints[i];
+    assigned[i] = (p && (long)p->mnId >= 0) ? (int32_t)p->mnId : -1;
+    occupied[i] = p ? 1 : 0;
   }
   return nm;
 }

@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
     int removed = 0;
     for (int q = lane; q < nq; q += 64) {
       const int b = pushBin[q];
-      if (b != 255 && b != ind1 && b != ind2 && b != ind3) { asg[pushIdx[q]] = -1; removed++; }
+      if (b != 255 && b != ind1 && b != ind2 && b != ind3) { asg[pushIdx[q]] = -1; occ[pushIdx[q]] = 0; removed++; }   // mvpMapPoints[..] = NULL
     }
     nmatches -= wave_sum(removed);
   }

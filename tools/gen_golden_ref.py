@@ -255,12 +255,62 @@ def ref_matcher_lib():
     R.ref_orb_search_by_bow_kfkf.argtypes = [V, V, V, V, I, V, V, V, V, I, F, I, V]
     R.ref_orb_search_for_initialization.argtypes = [V, V, I, V, V, I, V, V, I, F, I, V]
     R.ref_orb_search_by_projection_mp.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, F, F, V]
+    R.ref_orb_search_by_projection_frame.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, V, V, F, I, I, V, V, V]
+    R.ref_orb_search_by_projection_kf.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, V, V, V, F, I, I, V, V]
     return R
 
 
 BOW_CASES = [(300, 2000, 100, 0.7, 1), (302, 1500, 10, 0.9, 0), (305, 777, 40, 0.7, 1)]     # seed, n, nodes, nnratio, checkOri
 KFKF_CASES = [(400, 1500, 80), (401, 300, 5)]                                              # seed, n, nodes (nnratio 0.8)
 FRAME_CASES = [(31, 2000, False), (32, 700, True)]                                         # seed, n, distorted bounds
+
+
+POSE_CASES = [(51, 2000, False), (52, 600, True), (53, 40, False)]                         # seed, n, distorted bounds
+POSE_FRAME_VARIANTS = [(0, 15.0, 1), (0, 7.0, 0), (1, 15.0, 1), (2, 15.0, 1), (2, 7.0, 0)]     # mode, th, checkOri
+POSE_KF_VARIANTS = [(64, 1), (100, 1), (100, 0)]                                             # ORBdist, checkOri (th = 10)
+POSE_K = np.array([517.3, 516.5, 318.6, 255.3], np.float32)                                # fx fy cx cy
+
+
+def pose_inputs(S, P, TF, seed, n, distorted):
+    """Last-frame / keyframe map points at world positions in front of (a few behind) a current camera with pose = identity."""
+    f1, f2, _, _ = TF.make_frame_pair(P, S, seed, n, nl=0)
+    gp = TF._gp(P, distorted=distorted)
+    q = TF._queries_points(P, S, 900 + seed, f1, f2, "frame")
+    rng = S.SplitMix64(seed + 7)
+    z = rng.uniform(n, 0.8, 6.0).astype(np.float32)
+    behind = rng.uniform(n) < 0.04
+    z[behind] = -z[behind]
+    K = POSE_K
+    xyz = np.ascontiguousarray(np.stack([(q["uv"][:, 0] - K[2]) / K[0] * z, (q["uv"][:, 1] - K[3]) / K[1] * z, z], 1).astype(np.float32))
+    flags = {k: (rng.uniform(n) < pr).astype(np.uint8) for k, pr in (("mp", 0.9), ("outlier", 0.07), ("bad", 0.05), ("found", 0.1),
+                                                                     ("inrange", 0.95))}
+    occ_f = (S.SplitMix64(77 + seed).uniform(n) < 0.1).astype(np.uint8)
+    occ_k = (S.SplitMix64(99 + seed).uniform(n) < 0.05).astype(np.uint8)
+    return f2, gp, q, xyz, flags, occ_f, occ_k
+
+
+def reference_pose_frame(R, P, TF, f2, gp, q, xyz, fl, occ0, mode, th, chk):
+    n = len(f2["kps"])
+    g = P._gp_array(gp)
+    uv, front = np.zeros((max(n, 1), 2), np.float32), np.zeros(max(n, 1), np.uint8)
+    occ, asg = occ0.copy(), np.zeros(max(n, 1), np.int32)
+    c = R.ref_orb_search_by_projection_frame(p(f2["kps"]), p(f2["desc"]), n, p(g), p(TF.SCALE), len(TF.SCALE), p(occ), n, p(fl["mp"]),
+                                             p(fl["outlier"]), p(xyz), p(q["octave"]), p(q["angle"]), p(q["desc"]), p(q["hasobs"]),
+                                             p(POSE_K), th, mode, chk, p(uv), p(front), p(asg))
+    valid = (fl["mp"] & (1 - fl["outlier"]) & front[:n]).astype(np.uint8)
+    return c, asg[:n], occ, uv[:n].copy(), valid
+
+
+def reference_pose_kf(R, P, TF, f2, gp, q, xyz, fl, occ0, orb_dist, chk):
+    n = len(f2["kps"])
+    g = P._gp_array(gp)
+    uv = np.zeros((max(n, 1), 2), np.float32)
+    occ, asg = occ0.copy(), np.zeros(max(n, 1), np.int32)
+    c = R.ref_orb_search_by_projection_kf(p(f2["kps"]), p(f2["desc"]), n, p(g), p(TF.SCALE), len(TF.SCALE), p(occ), n, p(fl["mp"]),
+                                          p(fl["bad"]), p(fl["found"]), p(fl["inrange"]), p(xyz), p(q["octave"]), p(q["angle"]),
+                                          p(q["desc"]), p(POSE_K), 10.0, orb_dist, chk, p(uv), p(asg))
+    valid = (fl["mp"] & (1 - fl["bad"]) & (1 - fl["found"]) & fl["inrange"]).astype(np.uint8)
+    return c, asg[:n], occ, uv[:n].copy(), valid
 
 
 def bow_inputs(S, TM, seed, n, nodes):
@@ -335,6 +385,19 @@ def gen_matchers(S, out):
         g["init_%d_n" % seed], g["init_%d_m" % seed], g["init_%d_prev" % seed] = c, m, prev
         c, a, o = reference_proj_mp(R, P, f2, gp, q, occ0, TF.SCALE)
         g["proj_%d_n" % seed], g["proj_%d_asg" % seed], g["proj_%d_occ" % seed] = c, a, o
+    for seed, n, dist in POSE_CASES:
+        f2, gp, q, xyz, fl, occ_f, occ_k = pose_inputs(S, P, TF, seed, n, dist)
+        for k, (mode, th, chk) in enumerate(POSE_FRAME_VARIANTS):
+            c, a, o, uv, valid = reference_pose_frame(R, P, TF, f2, gp, q, xyz, fl, occ_f, mode, th, chk)
+            key = "pf_%d_%d" % (seed, k)
+            g[key + "_n"], g[key + "_asg"], g[key + "_occ"] = c, a, o
+            g["pose_%d_uv" % seed], g["pf_%d_valid" % seed] = uv, valid
+        for k, (orb_dist, chk) in enumerate(POSE_KF_VARIANTS):
+            c, a, o, uv, valid = reference_pose_kf(R, P, TF, f2, gp, q, xyz, fl, occ_k, orb_dist, chk)
+            key = "pk_%d_%d" % (seed, k)
+            g[key + "_n"], g[key + "_asg"], g[key + "_occ"] = c, a, o
+            assert (uv == g["pose_%d_uv" % seed]).all()
+            g["pk_%d_valid" % seed] = valid
     np.savez_compressed(os.path.join(out, "ref_orbmatcher.npz"), **g)
     print("matchers:", {k: int(v) for k, v in g.items() if k.endswith("_n")})
 
