@@ -304,7 +304,8 @@ PLH_API plh_status plh_orb_search_by_projection_kf_batch_dev(
  * 1063-1197): per query (valid = every pre-check of the loop passed; uv = projection; level = PredictScale)
  * the best keypoint of level l-1..l in the window th*scale[l] whose reprojection error passes e2*invLevelSigma2 <= 5.99 and
  * whose Hamming distance is <= th_low (TH_LOW).  d_best_idx[pairs][qcap] = keypoint index or -1.  The replace / add logic on
- * the map stays with the caller.  scale_factors / inv_level_sigma2: HOST arrays of the KeyFrame. */
+ * the map stays with the caller.  scale_factors / inv_level_sigma2: HOST arrays of the KeyFrame.  The Sim3 overload (:1063-1197)
+ * has no reprojection-error gate: pass inv_level_sigma2 = 0 for it. */
 PLH_API plh_status plh_orb_fuse_search_batch_dev(const plh_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_n, int cap,
                                                  int pairs, const plh_grid_params* gp, const int32_t* d_cell_start,
                                                  const int32_t* d_cell_items, const float* scale_factors,
@@ -349,7 +350,9 @@ PLH_API plh_status plh_line_search_by_projection_frame_batch_dev(
 /* The search inside LSDmatcher::Fuse(pKF, vpMapLines, th) (LSDmatcher.cpp:860-1002) with
  * KeyFrame::GetLinesInArea (KeyFrame.cc:647-683, cos_th = 0.998): per query the best line of level l-1..l near the projected
  * segment, Hamming <= th_low.  d_cand_desc is the matrix the reference reads the candidates from (it reads pKF->mDescriptors
- * with the line index, :963 -- pass mLineDescriptors for the intended behaviour).  d_best_idx[pairs][qcap] = line or -1. */
+ * with the line index, :963 -- pass mLineDescriptors for the intended behaviour).  d_best_idx[pairs][qcap] = line or -1.
+ * Reference quirk for the caller: a line with an endpoint behind the camera makes Fuse `return false` (:893-894), i.e. no
+ * later query is searched -- set valid = 0 from that query on to reproduce it. */
 PLH_API plh_status plh_line_fuse_search_batch_dev(const plh_keyline* d_kl, const uint8_t* d_cand_desc, const int32_t* d_nl, int cap,
                                                   int pairs, const float* scale_factors_line, int nlevels, const int32_t* d_nq,
                                                   int qcap, const uint8_t* d_q_valid, const float* d_q_seg,

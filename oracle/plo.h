@@ -19,18 +19,18 @@
  *     line equations are bit-identical to it (KeyLine.angle within one float ulp: an atan2 overload that depends on the
  *     toolchain, see tests/test_ref_line.py; goldens ref_line_*.npz);
  *   - src/ORBmatcher.cc (against stand-ins for Frame / KeyFrame / MapPoint): SearchByBoW (both), SearchForInitialization
- *     SearchByProjection(F, MapPoints), SearchByProjection(Cur, Last, th, bMono) and the relocalisation
- *     SearchByProjection(Cur, pKF, found, th, ORBdist) of match.cc / frame_search.cc return the same matches
- *     (tests/test_ref_orbmatcher.py);
+ *     SearchByProjection(F, MapPoints), SearchByProjection(Cur, Last, th, bMono), the relocalisation
+ *     SearchByProjection(Cur, pKF, found, th, ORBdist), both Fuse overloads, the loop-closing SearchByProjection(pKF, Scw),
+ *     SearchBySim3 and SearchForTriangulation of match.cc / frame_search.cc return the same matches
+ *     (tests/test_ref_orbmatcher.py, tests/test_ref_orbmatcher_kf.py);
  *   - src/LSDmatcher.cpp (same stand-ins + MapLine; knnMatch = this oracle's knn2): FrameBFMatch / lineDescriptorMAD,
- *     SearchDouble and both SearchByProjection forms of match.cc / frame_search.cc return the same matches
+ *     SearchDouble, both SearchByProjection forms and the search inside Fuse of match.cc / frame_search.cc return the same matches
  *     (tests/test_ref_lsdmatcher.py);
  *   - src/lineIterator.cpp: the line grid of frame_search.cc (tests/test_ref_linegrid.py).
  * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
  * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE
- * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); the ORBmatcher searches over Sim3 poses,
- * Fuse and triangulation and the search inside LSDmatcher::Fuse are restatements of the
- * in-tree sources that are not driven against the compiled reference.
+ * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); KeyFrame::GetLinesInArea, Frame::UndistortKeyPoints
+ * and the ComputeDistinctiveDescriptors medians are restatements of in-tree sources that do not compile on their own.
  *
  * Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off: no FMA contraction, IEEE float32).
  */

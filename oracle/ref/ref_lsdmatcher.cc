@@ -26,6 +26,28 @@ std::vector<size_t> LineGridLookup::query(float x1, float y1, float x2, float y2
                                               y2, r, TH, out.data(), (int)out.size());
   return std::vector<size_t>(out.begin(), out.begin() + n);
 }
+// KeyFrame::GetLinesInArea restated from src/KeyFrame.cc:647-683 (brute force over the KeyFrame's lines).
+std::vector<size_t> KeyFrame::GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r,
+                                             const float TH) const {
+  std::vector<size_t> vIndices;
+  float delta1x = x1 - x2, delta1y = y1 - y2;
+  const float norm_delta1 = std::sqrt(delta1x * delta1x + delta1y * delta1y);
+  delta1x /= norm_delta1;
+  delta1y /= norm_delta1;
+  for (size_t i = 0; i < mvKeyLines.size(); i++) {
+    const KeyLine& k = mvKeyLines[i];
+    const float distance = (0.5 * (x1 + x2) - k.pt.x) * (0.5 * (x1 + x2) - k.pt.x) + (0.5 * (y1 + y2) - k.pt.y) * (0.5 * (y1 + y2) - k.pt.y);
+    if (distance > r * r) continue;
+    float delta2x = k.startPointX - k.endPointX, delta2y = k.startPointY - k.endPointY;
+    const float norm_delta2 = std::sqrt(delta2x * delta2x + delta2y * delta2y);
+    delta2x /= norm_delta2;
+    delta2y /= norm_delta2;
+    const float CosSita = std::abs(delta1x * delta2x + delta1y * delta2y);
+    if (CosSita < TH) continue;
+    vIndices.push_back(i);
+  }
+  return vIndices;
+}
 }  // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;
@@ -158,6 +180,68 @@ int ref_line_search_by_projection_ml(const plo_keyline* kl, const uint8_t* ldesc
     occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
   }
   return n;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// LSDmatcher::Fuse(pKF, vpMapLines, th), src/LSDmatcher.cpp:860-1002, KeyFrame pose = identity.  kf_ml[idx]: 0 empty, 1 a
+// MapLine with more observations than the queries, 2 a bad one.  cand_desc = pKF->mDescriptors (the matrix :963 reads the
+// candidate rows from, with the LINE index).  q_pos = the six world coordinates (start, end).  Outputs: seg_out = (u1, v1, u2,
+// v2) as :898-906 computes them, front_out = both endpoints have z >= 0 (otherwise the reference leaves the whole function
+// with `return false`, :893-894), inimg_out = both inside the image; best_idx[q] from the GetMapLine(bestIdx) call of query q.
+int ref_line_fuse(const plo_keyline* kl, const uint8_t* cand_desc, int nl, const float* scale_factors_line, int nlevels,
+                  const uint8_t* kf_ml, const float gp[6], int nq, const uint8_t* q_ml, const uint8_t* q_bad, const uint8_t* q_inkf,
+                  const uint8_t* q_inrange, const uint8_t* q_viewok, const float* q_pos, const int32_t* q_level, const uint8_t* q_desc,
+                  const float K[4], float th, float* seg_out, uint8_t* front_out, uint8_t* inimg_out, int32_t* best_idx) {
+  Lines ls;
+  KeyFrame kf;
+  kf.NL = nl;
+  kf.mvKeyLines.resize(nl);
+  for (int i = 0; i < nl; i++) std::memcpy(&kf.mvKeyLines[i], &kl[i], sizeof(plo_keyline));
+  kf.mvKeylinesUn = kf.mvKeyLines;
+  kf.mDescriptors = desc_mat(cand_desc, nl);
+  kf.mLineDescriptors = kf.mDescriptors;
+  kf.mvScaleFactorsLine.assign(scale_factors_line, scale_factors_line + nlevels);
+  kf.mvpMapLines.assign(nl, nullptr);
+  for (int i = 0; i < nl; i++)
+    if (kf_ml[i]) { MapLine* p = ls.make(-1); p->nobs = 2; p->bad = kf_ml[i] == 2; kf.mvpMapLines[i] = p; }
+  kf.fx = K[0]; kf.fy = K[1]; kf.cx = K[2]; kf.cy = K[3];
+  kf.mnMinX = gp[0]; kf.mnMinY = gp[1]; kf.mnMaxX = gp[2]; kf.mnMaxY = gp[3];
+  kf.Rcw = cv::Mat::zeros(3, 3, CV_32F);
+  for (int i = 0; i < 3; i++) kf.Rcw.at<float>(i, i) = 1.f;
+  kf.tcw = cv::Mat::zeros(3, 1, CV_32F);
+  kf.Ow = cv::Mat::zeros(3, 1, CV_32F);
+  std::vector<MapLine*> q(nq, nullptr);
+  for (int i = 0; i < nq; i++) {
+    const float* X = q_pos + 6 * i;
+    const float invz1 = 1.0f / X[2];
+    seg_out[4 * i] = K[0] * X[0] * invz1 + K[2];
+    seg_out[4 * i + 1] = K[1] * X[1] * invz1 + K[3];
+    const float invz2 = 1.0f / X[5];
+    seg_out[4 * i + 2] = K[0] * X[3] * invz2 + K[2];
+    seg_out[4 * i + 3] = K[1] * X[4] * invz2 + K[3];
+    front_out[i] = (X[2] < 0.0f || X[5] < 0.0f) ? 0 : 1;
+    inimg_out[i] = (kf.IsInImage(seg_out[4 * i], seg_out[4 * i + 1]) && kf.IsInImage(seg_out[4 * i + 2], seg_out[4 * i + 3])) ? 1 : 0;
+    best_idx[i] = -1;
+    if (!q_ml[i]) continue;
+    MapLine* p = ls.make(i);
+    for (int k = 0; k < 6; k++) p->pos(k) = X[k];
+    p->normal(0) = 0; p->normal(1) = 0; p->normal(2) = q_viewok[i] ? 1.0 : -1.0;
+    p->mLDescriptor = desc_mat(q_desc + (size_t)i * 32, 1);
+    p->bad = q_bad[i] != 0;
+    p->predicted = q_level[i];
+    if (!q_inrange[i]) p->minDist = 1e29f;
+    p->nobs = 1;
+    if (q_inkf[i]) p->obs[&kf] = 0;
+    q[i] = p;
+  }
+  LSDmatcher m(0.6f, true);
+  const int nf = m.Fuse(&kf, q, th);
+  for (const auto& e : kf.lineLog)
+    if (e.first && (long)e.first->mnId >= 0) best_idx[e.first->mnId] = e.second;
+  return nf;
 }
 
 }  // extern "C"

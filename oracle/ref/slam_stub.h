@@ -48,7 +48,9 @@ class MapPoint {
   MapPoint* replaced = nullptr;
 
   bool isBad() const { return bad; }
-  cv::Mat GetDescriptor() const { return desc.clone(); }
+  // harness hook: the map point whose descriptor was fetched last = the query a Fuse loop is working on
+  static const MapPoint*& lastQuery() { static thread_local const MapPoint* p = nullptr; return p; }
+  cv::Mat GetDescriptor() const { lastQuery() = this; return desc.clone(); }
   cv::Mat GetWorldPos() const { return pos.clone(); }
   cv::Mat GetNormal() const { return normal.clone(); }
   float GetMinDistanceInvariance() const { return minDist; }
@@ -87,7 +89,8 @@ class MapLine {   // include/MapLine.h, the members src/LSDmatcher.cpp touches
   int PredictScale(const float&, KeyFrame*) const { return predicted; }
   int Observations() const { return nobs; }
   void AddObservation(KeyFrame* k, size_t i) { obs[k] = i; }
-  bool IsInKeyFrame(KeyFrame* k) const { return obs.count(k) != 0; }
+  static const MapLine*& lastQuery() { static thread_local const MapLine* p = nullptr; return p; }   // harness hook
+  bool IsInKeyFrame(KeyFrame* k) const { lastQuery() = this; return obs.count(k) != 0; }
   int GetIndexInKeyFrame(KeyFrame* k) const { auto it = obs.find(k); return it == obs.end() ? -1 : (int)it->second; }
   void Replace(MapLine* p) { replaced = p; }
 };
@@ -171,18 +174,22 @@ class KeyFrame {
   std::vector<float> mvScaleFactorsLine;
   float mfLogScaleFactorLine = 0;
   cv::Mat mLineDescriptors, ImageGray, mK;
-  MapLine* GetMapLine(const size_t& i) const { return mvpMapLines[i]; }
+  mutable std::vector<std::pair<const MapLine*, int> > lineLog;   // harness hook: (query, line) of every GetMapLine call
+  MapLine* GetMapLine(const size_t& i) const { lineLog.emplace_back(MapLine::lastQuery(), (int)i); return mvpMapLines[i]; }
   std::vector<MapLine*> GetMapLineMatches() const { return mvpMapLines; }
   void AddMapLine(MapLine* p, const size_t& i) { mvpMapLines[i] = p; }
-  std::vector<size_t> GetLinesInArea(const float&, const float&, const float&, const float&, const float&, const int = -1,
-                                     const int = -1, const float = 0.998) const { return std::vector<size_t>(); }
+  // include/KeyFrame.h:108; src/KeyFrame.cc:647-683 cannot be compiled on its own, so the body (ref_lsdmatcher.cc) is a
+  // restatement and what the Fuse harness pins is the loop around it
+  std::vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r,
+                                     const float TH = 0.998) const;
   std::vector<MapPoint*> GetMapPointMatches() const { return mvpMapPoints; }
   std::set<MapPoint*> GetMapPoints() const {
     std::set<MapPoint*> s;
     for (MapPoint* p : mvpMapPoints) if (p && !p->isBad()) s.insert(p);
     return s;
   }
-  MapPoint* GetMapPoint(const size_t& i) const { return mvpMapPoints[i]; }
+  mutable std::vector<std::pair<const MapPoint*, int> > getLog;   // harness hook: (query, keypoint) of every GetMapPoint call
+  MapPoint* GetMapPoint(const size_t& i) const { getLog.emplace_back(MapPoint::lastQuery(), (int)i); return mvpMapPoints[i]; }
   void AddMapPoint(MapPoint* p, const size_t& i) { mvpMapPoints[i] = p; }
   cv::Mat GetRotation() const { return Rcw.clone(); }
   cv::Mat GetTranslation() const { return tcw.clone(); }

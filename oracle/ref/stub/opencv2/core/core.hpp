@@ -357,7 +357,7 @@ inline double threshold(const Mat&, Mat&, double, double, int) { stub_unreachabl
 inline Mat abs(const Mat&) { stub_unreachable("cv::abs(Mat)"); }
 inline void add(const Mat&, const Mat&, Mat&) { stub_unreachable("cv::add"); }
 inline void compare(const Mat&, const Mat&, Mat&, int) { stub_unreachable("cv::compare"); }
-inline Mat operator/(const Mat&, double) { stub_unreachable("Mat / scalar"); }
+inline Mat operator/(const Mat& a, double s) { return mat_scale(a, 1.0 / s); }   // MatExpr: scale by alpha = 1/s
 enum { THRESH_TOZERO = 3, CMP_LT = 3, CMP_GT = 1 };
 
 // ---- image-processing primitives: forwarded to the oracle's restatements ----

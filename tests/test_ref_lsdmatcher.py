@@ -6,6 +6,11 @@ not in the tree); the grid lookup behind Frame::GetFeaturesInAreaForLine is the 
 
     FrameBFMatch (+ lineDescriptorMAD)     SearchDouble(Frame&, Frame&, LineMatches)
     SearchByProjection(Cur, Last, th)      SearchByProjection(F, vpMapLines, th)
+    Fuse(pKF, vpMapLines, th)  -- keyframe pose = identity; the projected segments come back from the harness' copy of
+                                  the reference's expressions; KeyFrame::GetLinesInArea underneath is restated (KeyFrame.cc
+                                  cannot be compiled alone), so what is pinned is the loop: level band, the candidate rows
+                                  read from pKF->mDescriptors, best / TH_LOW, and the `return false` that leaves the whole
+                                  function at the first line with an endpoint behind the camera (LSDmatcher.cpp:893-894)
 
 What this pins: the MAD thresholds (median selection, the 1.4826 factor), the ratio / TH / nn12 acceptance tests, the
 mutual-consistency pass, and the greedy projection searches (candidate order, best / second best, occupancy rules,
@@ -50,6 +55,20 @@ def _oracle_proj(O, L, P, TF, f2, gp, q, occ0, variant, th, nn):
     return rc, ra[:n2], ro
 
 
+def _oracle_lfuse(O, L, f2, q, seg, valid, level, th):
+    nl, n2 = len(level), len(f2["keylines"])
+    L.plo_line_fuse_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p]
+    L.plo_line_fuse_search.restype = C.c_int
+    rb = np.zeros(max(nl, 1), np.int32)
+    rc = L.plo_line_fuse_search(O._p(f2["keylines"]), O._p(f2["ldesc"]), n2, O._p(_SFL), nl, O._p(valid), O._p(seg), O._p(level),
+                                O._p(q["desc"]), th, 0.998, 50, O._p(rb))
+    return rc, rb[:nl]
+
+
+_SFL = np.array([1.0, 1.4142135, 2.0, 2.828427], np.float32)
+
+
 def _oracle_bf(O, a, b, th, ratio):
     m = np.zeros(max(len(a), 1), np.int32)
     O.lib().plo_line_bfmatch(O._p(a), len(a), O._p(b), len(b), C.c_float(th), C.c_float(ratio), O._p(m))
@@ -77,6 +96,13 @@ def test_oracle_reproduces_reference_lsdmatcher(oracle, plslam, synth):
             rc, ra, ro = _oracle_proj(oracle, L, plslam, TF, f2, gp, q, occ0, variant, th, nn)
             key = "proj_%d_%d" % (seed, k)
             assert rc == int(g[key + "_n"]) and (ra == g[key + "_asg"]).all() and (ro == g[key + "_occ"]).all(), key
+    for seed, nl, dist, nb in G.LFUSE_CASES:
+        f2, gp, q, pos, fl, kfml, level = G.lfuse_inputs(synth, plslam, TF, seed, nl, dist, nb)
+        for k, th in enumerate(G.LFUSE_TH):
+            rc, rb = _oracle_lfuse(oracle, L, f2, q, np.ascontiguousarray(g["lfuse_%d_seg" % seed]),
+                                   np.ascontiguousarray(g["lfuse_%d_valid" % seed]), level, th)
+            assert (rb == g["lfuse_%d_%d_best" % (seed, k)]).all(), "Fuse %d %g" % (seed, th)
+            assert int(g["lfuse_%d_%d_n" % (seed, k)]) == (0 if int(g["lfuse_%d_stopped" % seed]) else rc)
 
 
 @pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (no /root/reference on this machine)")
@@ -98,6 +124,11 @@ def test_reference_lsdmatcher_live(oracle, plslam, synth):
             c, a, o = G.reference_lproj(R, plslam, f2, gp, q, occ0, variant, th, nn)
             rc, ra, ro = _oracle_proj(oracle, L, plslam, TF, f2, gp, q, occ0, variant, th, nn)
             assert c == rc and (a == ra).all() and (o == ro).all(), "live SearchByProjection %s %d" % (variant, seed)
+    for seed, nl, dist, nb in [(91, 250, True, 0), (92, 90, False, 1)]:
+        f2, gp, q, pos, fl, kfml, level = G.lfuse_inputs(synth, plslam, TF, seed, nl, dist, nb)
+        c, best, seg, valid, stopped = G.reference_lfuse(R, plslam, f2, gp, q, pos, fl, kfml, level, 5.0)
+        rc, rb = _oracle_lfuse(oracle, L, f2, q, seg, valid, level, 5.0)
+        assert (best == rb).all() and c == (0 if stopped else rc), "live Fuse %d" % seed
 
 
 def _check_device(P, synth, lib):
@@ -122,6 +153,15 @@ def _check_device(P, synth, lib):
             n2_ = len(f2["keylines"])
             key = "proj_%d_%d" % (seed, k)
             assert cnt[0] == int(g[key + "_n"]) and (asg[0, :n2_] == g[key + "_asg"]).all() and (occ[0, :n2_] == g[key + "_occ"]).all(), key
+    for seed, nl, dist, nb in G.LFUSE_CASES:
+        f2, gp, q, pos, fl, kfml, level = G.lfuse_inputs(synth, P, TF, seed, nl, dist, nb)
+        fs = P.FrameSearch(gp, TF.SCALE, [f2], lib=lib)
+        qd = dict(valid=np.ascontiguousarray(g["lfuse_%d_valid" % seed]), seg=np.ascontiguousarray(g["lfuse_%d_seg" % seed]), level=level,
+                  desc=q["desc"])
+        for k, th in enumerate(G.LFUSE_TH):
+            best, nf = fs.LineFuseSearch([qd], _SFL, th=th, cos_th=0.998)
+            assert (best[0, :nl] == g["lfuse_%d_%d_best" % (seed, k)]).all(), "Fuse %d %g" % (seed, th)
+            assert int(g["lfuse_%d_%d_n" % (seed, k)]) == (0 if int(g["lfuse_%d_stopped" % seed]) else nf[0])
 
 
 def test_emu_reproduces_reference_lsdmatcher(plslam, synth, emu_lib):

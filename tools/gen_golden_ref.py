@@ -257,6 +257,11 @@ def ref_matcher_lib():
     R.ref_orb_search_by_projection_mp.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, F, F, V]
     R.ref_orb_search_by_projection_frame.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, V, V, F, I, I, V, V, V]
     R.ref_orb_search_by_projection_kf.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, V, V, V, F, I, I, V, V]
+    R.ref_orb_fuse.argtypes = [V, V, I, V, V, V, I, V, I, V, V, V, V, V, V, V, V, V, F, V, V, V, V]
+    R.ref_orb_fuse_sim3.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, V, V, F, V, V, V, V]
+    R.ref_orb_search_by_projection_sim3.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, V, V, I, V, V, V, V]
+    R.ref_orb_search_by_sim3.argtypes = [V, V, I, V, V, V, V, V, V, V, V, I, V, V, V, V, V, V, V, V, I, V, V, F] + [V] * 7
+    R.ref_orb_search_for_triangulation.argtypes = [V, V, V, V, I, V, V, V, V, I, V, V, V, V, V, I, I, V, V]
     return R
 
 
@@ -413,6 +418,7 @@ def ref_lsdmatcher_lib():
     R.ref_line_bfmatch.argtypes = [V, I, V, I, F, F, V]
     R.ref_line_search_by_projection_frame.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, F, V]
     R.ref_line_search_by_projection_ml.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, F, F, V]
+    R.ref_line_fuse.argtypes = [V, V, I, V, I, V, V, I, V, V, V, V, V, V, V, V, V, F, V, V, V, V]
     return R
 
 
@@ -475,10 +481,200 @@ def gen_lsdmatcher(S, out):
             f2, gp, q, occ0 = lproj_inputs(S, P, TF, seed, nl, dist, variant)
             c, a, o = reference_lproj(R, P, f2, gp, q, occ0, variant, th, nn)
             g["proj_%d_%d_n" % (seed, k)], g["proj_%d_%d_asg" % (seed, k)], g["proj_%d_%d_occ" % (seed, k)] = c, a, o
+    for seed, nl, dist, nb in LFUSE_CASES:
+        f2, gp, q, pos, fl, kfml, level = lfuse_inputs(S, P, TF, seed, nl, dist, nb)
+        for k, th in enumerate(LFUSE_TH):
+            c, best, seg, valid, stopped = reference_lfuse(R, P, f2, gp, q, pos, fl, kfml, level, th)
+            g["lfuse_%d_%d_n" % (seed, k)], g["lfuse_%d_%d_best" % (seed, k)] = c, best
+            g["lfuse_%d_seg" % seed], g["lfuse_%d_valid" % seed], g["lfuse_%d_stopped" % seed] = seg, valid, int(stopped)
     np.savez_compressed(os.path.join(out, "ref_lsdmatcher.npz"), **g)
     print("lsdmatcher:", {k: int(v) for k, v in g.items() if k.endswith("_n")},
           {k: int((v >= 0).sum()) for k, v in g.items() if k.startswith("bf_")})
 
+
+# ---- KeyFrame-side searches: Fuse (both overloads), loop-closing SearchByProjection, SearchBySim3, SearchForTriangulation
+KF_TH = {"fuse": (3.0, 6.0), "fuse3": (3.0, 6.0), "s3p": (10, 4), "sim3": (7.5, 3.0)}
+TRI_CASES = [(510, 2000, 100), (512, 1500, 10), (514, 300, 20), (513, 1, 1)]                # seed, n, nodes
+TRI_VARIANTS = [(np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32), np.array([-10.0, 0.03, 1.0], np.float32), 1),
+                (np.array([1e-6, 2e-5, -0.004, -2e-5, 1e-6, -1.0, 0.005, 1.0, 0.3], np.float32), np.array([0.1, 0.05, 1.0], np.float32), 0)]
+TRI_SF = np.cumprod(np.r_[np.float32(1.0), np.full(7, np.float32(1.2))]).astype(np.float32)
+
+
+def kf_inputs(S, P, TF, seed, n, distorted):
+    f2, gp, q, xyz, fl, occ_f, occ_k = pose_inputs(S, P, TF, seed, n, distorted)
+    rng = S.SplitMix64(seed + 13)
+    kfmp = np.where(rng.uniform(n) < 0.3, 1, 0).astype(np.uint8)
+    kfmp[rng.uniform(n) < 0.03] = 2
+    fl = dict(fl, inkf=(rng.uniform(n) < 0.08).astype(np.uint8), viewok=(rng.uniform(n) < 0.93).astype(np.uint8))
+    slot = np.full(max(n, 1), -1, np.int32)
+    if n:
+        pick = np.where(rng.uniform(n) < 0.08)[0]
+        tgt = rng.randint(len(pick), 0, n) if len(pick) else []
+        used = set()
+        for a, b in zip(pick, tgt):
+            if int(b) not in used:
+                slot[a] = b
+                used.add(int(b))
+    return f2, gp, q, xyz, fl, occ_k, kfmp, slot
+
+
+def _bufs(n):
+    return np.zeros((max(n, 1), 2), np.float32), np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+
+
+def reference_fuse(R, P, TF, f2, gp, q, xyz, fl, kfmp, th):
+    n, g = len(f2["kps"]), P._gp_array(gp)
+    inv = (np.float32(1.0) / (TF.SCALE * TF.SCALE)).astype(np.float32)
+    (uv, fr, im), best = _bufs(n), np.zeros(max(n, 1), np.int32)
+    c = R.ref_orb_fuse(p(f2["kps"]), p(f2["desc"]), n, p(g), p(TF.SCALE), p(inv), len(TF.SCALE), p(kfmp), n, p(fl["mp"]), p(fl["bad"]),
+                       p(fl["inkf"]), p(fl["inrange"]), p(fl["viewok"]), p(xyz), p(q["octave"]), p(q["desc"]), p(POSE_K), th, p(uv), p(fr),
+                       p(im), p(best))
+    valid = (fl["mp"] & (1 - fl["bad"]) & (1 - fl["inkf"]) & fr[:n] & im[:n] & fl["inrange"] & fl["viewok"]).astype(np.uint8)
+    return c, best[:n], uv[:n].copy(), valid
+
+
+def reference_fuse3(R, P, TF, f2, gp, q, xyz, fl, kfmp, slot, th):
+    n, g = len(f2["kps"]), P._gp_array(gp)
+    (uv, fr, im), best = _bufs(n), np.zeros(max(n, 1), np.int32)
+    c = R.ref_orb_fuse_sim3(p(f2["kps"]), p(f2["desc"]), n, p(g), p(TF.SCALE), len(TF.SCALE), p(kfmp), n, p(fl["bad"]), p(slot),
+                            p(fl["inrange"]), p(fl["viewok"]), p(xyz), p(q["octave"]), p(q["desc"]), p(POSE_K), th, p(uv), p(fr), p(im),
+                            p(best))
+    valid = ((1 - fl["bad"]) & (slot[:n] < 0) & fr[:n] & im[:n] & fl["inrange"] & fl["viewok"]).astype(np.uint8)
+    return c, best[:n], uv[:n].copy(), valid
+
+
+def reference_s3p(R, P, TF, f2, gp, q, xyz, fl, occ0, slot, th):
+    n, g = len(f2["kps"]), P._gp_array(gp)
+    (uv, fr, im), asg, occ = _bufs(n), np.zeros(max(n, 1), np.int32), occ0.copy()
+    c = R.ref_orb_search_by_projection_sim3(p(f2["kps"]), p(f2["desc"]), n, p(g), p(TF.SCALE), len(TF.SCALE), p(occ), n, p(fl["bad"]),
+                                            p(slot), p(fl["inrange"]), p(fl["viewok"]), p(xyz), p(q["octave"]), p(q["desc"]), p(POSE_K),
+                                            int(th), p(uv), p(fr), p(im), p(asg))
+    valid = ((1 - fl["bad"]) & (slot[:n] < 0) & fr[:n] & im[:n] & fl["inrange"] & fl["viewok"]).astype(np.uint8)
+    occ_in = occ0.copy()
+    occ_in[slot[:n][slot[:n] >= 0]] = 1          # vpMatched slots holding a query are occupied too
+    return c, asg[:n], occ, uv[:n].copy(), valid, occ_in
+
+
+def sim3_inputs(S, P, TF, seed, n, distorted):
+    f1, f2, _, _ = TF.make_frame_pair(P, S, seed, n, nl=0)
+    gp = TF._gp(P, distorted=distorted)
+    a, c = TF._queries_points(P, S, 970 + seed, f1, f2, "frame"), TF._queries_points(P, S, 980 + seed, f2, f1, "frame")
+    rng = S.SplitMix64(seed + 21)
+    K, sides = POSE_K, []
+    for q in (a, c):
+        z = rng.uniform(n, 0.8, 6.0).astype(np.float32)
+        behind = rng.uniform(n) < 0.04
+        z[behind] = -z[behind]
+        xyz = np.ascontiguousarray(np.stack([(q["uv"][:, 0] - K[2]) / K[0] * z, (q["uv"][:, 1] - K[3]) / K[1] * z, z], 1).astype(np.float32))
+        sides.append(dict(xyz=xyz, mp=(rng.uniform(n) < 0.9).astype(np.uint8), bad=(rng.uniform(n) < 0.05).astype(np.uint8),
+                          inr=(rng.uniform(n) < 0.95).astype(np.uint8), level=q["octave"], desc=q["desc"]))
+    already = np.full(max(n, 1), -1, np.int32)
+    if n:
+        pick = rng.uniform(n) < 0.1
+        already[:n][pick] = rng.randint(int(pick.sum()), 0, n + n // 4 + 1)
+    return f1, f2, gp, sides, already
+
+
+def reference_sim3(R, P, TF, f1, f2, gp, sides, already, th):
+    n, g = len(f1["kps"]), P._gp_array(gp)
+    s1, s2 = sides
+    (uv12, fr12, im12), (uv21, fr21, im21), m12 = _bufs(n), _bufs(n), np.zeros(max(n, 1), np.int32)
+    c = R.ref_orb_search_by_sim3(p(f1["kps"]), p(f1["desc"]), n, p(s1["mp"]), p(s1["bad"]), p(s1["xyz"]), p(s1["level"]), p(s1["inr"]),
+                                 p(s1["desc"]), p(f2["kps"]), p(f2["desc"]), n, p(s2["mp"]), p(s2["bad"]), p(s2["xyz"]), p(s2["level"]),
+                                 p(s2["inr"]), p(s2["desc"]), p(g), p(TF.SCALE), len(TF.SCALE), p(already), p(POSE_K), th, p(uv12), p(fr12),
+                                 p(im12), p(uv21), p(fr21), p(im21), p(m12))
+    am1 = already[:n] >= 0
+    am2 = np.zeros(n, bool)
+    idx = already[:n][am1]
+    am2[idx[idx < n]] = True
+    v12 = (s1["mp"] & (1 - s1["bad"]) & ~am1 & fr12[:n] & im12[:n] & s1["inr"]).astype(np.uint8)
+    v21 = (s2["mp"] & (1 - s2["bad"]) & ~am2 & fr21[:n] & im21[:n] & s2["inr"]).astype(np.uint8)
+    return c, m12[:n], uv12[:n].copy(), v12, uv21[:n].copy(), v21
+
+
+def reference_tri(R, a, b, F12, cw, chk):
+    n = len(a["desc"])
+    epi, m = np.zeros(2, np.float32), np.zeros(max(n, 1), np.int32)
+    sig2 = (TRI_SF * TRI_SF).astype(np.float32)
+    c = R.ref_orb_search_for_triangulation(p(a["kps"]), p(a["desc"]), p(a["node"]), p(a["has_mp"]), n, p(b["kps"]), p(b["desc"]), p(b["node"]),
+                                           p(b["has_mp"]), n, p(F12), p(cw), p(POSE_K), p(TRI_SF), p(sig2), 8, chk, p(epi), p(m))
+    return c, m[:n], epi
+
+
+def gen_keyframe_searches(S, out):
+    R, P = ref_matcher_lib(), _util.plslam()
+    TM, TF = _test_module("test_match"), _test_module("test_frame_search")
+    g = {}
+    for seed, n, dist in POSE_CASES:
+        f2, gp, q, xyz, fl, occ_k, kfmp, slot = kf_inputs(S, P, TF, seed, n, dist)
+        for k, th in enumerate(KF_TH["fuse"]):
+            c, best, uv, valid = reference_fuse(R, P, TF, f2, gp, q, xyz, fl, kfmp, th)
+            g["fuse_%d_%d_n" % (seed, k)], g["fuse_%d_%d_best" % (seed, k)] = c, best
+            g["fuse_%d_uv" % seed], g["fuse_%d_valid" % seed] = uv, valid
+        for k, th in enumerate(KF_TH["fuse3"]):
+            c, best, uv, valid = reference_fuse3(R, P, TF, f2, gp, q, xyz, fl, kfmp, slot, th)
+            g["fuse3_%d_%d_n" % (seed, k)], g["fuse3_%d_%d_best" % (seed, k)] = c, best
+            g["fuse3_%d_uv" % seed], g["fuse3_%d_valid" % seed] = uv, valid
+        for k, th in enumerate(KF_TH["s3p"]):
+            c, asg, occ, uv, valid, occ_in = reference_s3p(R, P, TF, f2, gp, q, xyz, fl, occ_k, slot, th)
+            key = "s3p_%d_%d" % (seed, k)
+            g[key + "_n"], g[key + "_asg"], g[key + "_occ"] = c, asg, occ
+            g["s3p_%d_uv" % seed], g["s3p_%d_valid" % seed], g["s3p_%d_occin" % seed] = uv, valid, occ_in
+        f1, f2, gp, sides, already = sim3_inputs(S, P, TF, seed, n, dist)
+        for k, th in enumerate(KF_TH["sim3"]):
+            c, m12, uv12, v12, uv21, v21 = reference_sim3(R, P, TF, f1, f2, gp, sides, already, th)
+            g["sim3_%d_%d_n" % (seed, k)], g["sim3_%d_%d_m12" % (seed, k)] = c, m12
+            g["sim3_%d_uv12" % seed], g["sim3_%d_v12" % seed], g["sim3_%d_uv21" % seed], g["sim3_%d_v21" % seed] = uv12, v12, uv21, v21
+    for seed, n, nodes in TRI_CASES:
+        a, b = TM._tri_case(P, S, seed, n, nodes)
+        for k, (F12, cw, chk) in enumerate(TRI_VARIANTS):
+            c, m, epi = reference_tri(R, a, b, F12, cw, chk)
+            g["tri_%d_%d_n" % (seed, k)], g["tri_%d_%d_m" % (seed, k)], g["tri_%d_epi" % k] = c, m, epi
+    np.savez_compressed(os.path.join(out, "ref_orbmatcher_kf.npz"), **g)
+    print("keyframe searches:", {k: int(v) for k, v in g.items() if k.endswith("_n")})
+
+
+# ---- the search inside LSDmatcher::Fuse
+LFUSE_CASES = [(21, 60, False, 0), (22, 300, True, 0), (24, 700, False, 1), (26, 201, False, 0)]   # seed, lines, distorted, one line behind
+LFUSE_TH = (6.0, 3.0)
+LFUSE_SFL = np.array([1.0, 1.4142135, 2.0, 2.828427], np.float32)
+
+
+def lfuse_inputs(S, P, TF, seed, nl, distorted, nbehind):
+    gp = TF._gp(P, distorted=distorted)
+    f1, f2, _, _ = TF.make_frame_pair(P, S, seed, 50, nl=nl)
+    q = TF._queries_lines(P, S, 970 + seed, f1, "ml")
+    rng = S.SplitMix64(seed + 31)
+    K = POSE_K
+    z1 = rng.uniform(nl, 0.8, 6.0).astype(np.float32)
+    z2 = (z1 + rng.uniform(nl, -0.3, 0.3)).astype(np.float32)
+    if nbehind and nl:
+        z2[int(nl * 0.8)] = -1.0
+    seg = q["seg"]
+    pos = np.ascontiguousarray(np.stack([(seg[:, 0] - K[2]) / K[0] * z1, (seg[:, 1] - K[3]) / K[1] * z1, z1, (seg[:, 2] - K[2]) / K[0] * z2,
+                                         (seg[:, 3] - K[3]) / K[1] * z2, z2], 1).astype(np.float32))
+    fl = {k: (rng.uniform(nl) < pr).astype(np.uint8) for k, pr in (("ml", 0.92), ("bad", 0.05), ("inkf", 0.08), ("inrange", 0.95),
+                                                                    ("viewok", 0.93))}
+    kfml = np.where(rng.uniform(nl) < 0.3, 1, 0).astype(np.uint8)
+    kfml[rng.uniform(nl) < 0.03] = 2
+    level = rng.randint(nl, 0, 2).astype(np.int32)
+    f2["keylines"]["octave"] = rng.randint(len(f2["keylines"]), 0, 2)
+    return f2, gp, q, pos, fl, kfml, level
+
+
+def reference_lfuse(R, P, f2, gp, q, pos, fl, kfml, level, th):
+    nl, n2, g = len(level), len(f2["keylines"]), P._gp_array(gp)
+    sg, fr, im = np.zeros((max(nl, 1), 4), np.float32), np.zeros(max(nl, 1), np.uint8), np.zeros(max(nl, 1), np.uint8)
+    best = np.zeros(max(nl, 1), np.int32)
+    c = R.ref_line_fuse(p(f2["keylines"]), p(f2["ldesc"]), n2, p(LFUSE_SFL), 4, p(kfml), p(g), nl, p(fl["ml"]), p(fl["bad"]), p(fl["inkf"]),
+                        p(fl["inrange"]), p(fl["viewok"]), p(pos), p(level), p(q["desc"]), p(POSE_K), th, p(sg), p(fr), p(im), p(best))
+    pre = (fl["ml"] & (1 - fl["bad"]) & (1 - fl["inkf"])).astype(bool)
+    stop = np.where(pre & (fr[:nl] == 0))[0]       # LSDmatcher.cpp:893-894: `return false` leaves the whole function
+    alive = np.ones(nl, bool)
+    if len(stop):
+        alive[stop[0]:] = False
+    valid = (pre & alive & im[:nl].astype(bool) & fl["inrange"].astype(bool) & fl["viewok"].astype(bool)).astype(np.uint8)
+    return c, best[:nl], sg[:nl].copy(), valid, len(stop) > 0
 
 def main():
     S = _util.synth()
@@ -499,6 +695,7 @@ def main():
     gen_line_grid(S, out)
     gen_lines(S, out)
     gen_matchers(S, out)
+    gen_keyframe_searches(S, out)
     gen_lsdmatcher(S, out)
 
 
