@@ -26,11 +26,13 @@
  *   - src/LSDmatcher.cpp (same stand-ins + MapLine; knnMatch = this oracle's knn2): FrameBFMatch / lineDescriptorMAD,
  *     SearchDouble, both SearchByProjection forms and the search inside Fuse of match.cc / frame_search.cc return the same matches
  *     (tests/test_ref_lsdmatcher.py);
+ *   - src/MapPoint.cc, src/MapLine.cpp with their own headers: ComputeDistinctiveDescriptors picks the same observation
+ *     as plo_distinctive_descriptor (tests/test_ref_mapobj.py);
  *   - src/lineIterator.cpp: the line grid of frame_search.cc (tests/test_ref_linegrid.py).
  * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
  * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE
- * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); KeyFrame::GetLinesInArea, Frame::UndistortKeyPoints
- * and the ComputeDistinctiveDescriptors medians are restatements of in-tree sources that do not compile on their own.
+ * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); KeyFrame::GetLinesInArea and
+ * Frame::UndistortKeyPoints (cv::undistortPoints underneath) are restatements that nothing executable stands behind.
  *
  * Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off: no FMA contraction, IEEE float32).
  */

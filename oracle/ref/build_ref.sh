@@ -45,3 +45,9 @@ echo "built $OUT/libmatcher_ref.so"
 # The reference's LSDmatcher.cpp against the same stand-ins (+ MapLine); cv::BFMatcher::knnMatch = the oracle's knn2.
 g++ $MFLAGS $MINC -o "$OUT/liblsdmatcher_ref.so" "$HERE/ref_lsdmatcher.cc" "$REF/src/LSDmatcher.cpp" "$D/DBoW2/FeatureVector.cpp" "$D/DBoW2/BowVector.cpp" $PLO_OBJS
 echo "built $OUT/liblsdmatcher_ref.so"
+# The reference's MapPoint.cc / MapLine.cpp (ComputeDistinctiveDescriptors) with their own headers, against stand-ins for
+# KeyFrame / Frame / Map only (mapobj_stub.h).
+g++ -O2 -std=c++14 -fPIC -shared -w -pthread -ffp-contract=off -fno-fast-math -DKEYFRAME_H -DFRAME_H -DMAP_H -I "$HERE/stub" \
+  -I "$LD/include" -I "$REF/include" -I "$REF" -include "$HERE/mapobj_stub.h" -o "$OUT/libmapobj_ref.so" "$HERE/ref_mapobj.cc" \
+  "$REF/src/MapPoint.cc" "$REF/src/MapLine.cpp" "$OUT/plo_match.o"
+echo "built $OUT/libmapobj_ref.so"

@@ -350,6 +350,12 @@ inline double norm(const Mat& a) {
     for (int j = 0; j < a.cols; j++) s += (double)a.at<float>(i, j) * a.at<float>(i, j);
   return std::sqrt(s);
 }
+inline double norm(const Mat& a, const Mat& b, int type) {   // NORM_HAMMING over two byte rows (MapLine.cpp:297)
+  assert(type == NORM_HAMMING && a.type() == CV_8U && b.type() == CV_8U && a.rows == 1 && b.rows == 1 && a.cols == b.cols);
+  int d = 0;
+  for (int i = 0; i < a.cols; i++) d += __builtin_popcount((unsigned)(a.ptr<uchar>(0)[i] ^ b.ptr<uchar>(0)[i]));
+  return d;
+}
 inline bool solve(const Mat&, const Mat&, Mat&, int = 0) { stub_unreachable("cv::solve"); }
 inline void cvtColor(const Mat&, Mat&, int) { stub_unreachable("cv::cvtColor"); }
 inline void pyrDown(const Mat&, Mat&, Size = Size()) { stub_unreachable("cv::pyrDown (numOctaves is 1 on this path)"); }
