@@ -28,6 +28,8 @@
  *     (tests/test_ref_lsdmatcher.py);
  *   - src/MapPoint.cc, src/MapLine.cpp with their own headers: ComputeDistinctiveDescriptors picks the same observation
  *     as plo_distinctive_descriptor (tests/test_ref_mapobj.py);
+ *   - src/Frame.cc with its own header: AssignFeaturesToGrid[ForLine], GetFeaturesInArea, GetFeaturesInAreaForLine return
+ *     the same cells and the same candidates in the same order as frame_search.cc (tests/test_ref_frame.py);
  *   - src/lineIterator.cpp: the line grid of frame_search.cc (tests/test_ref_linegrid.py).
  * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
  * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE

@@ -32,6 +32,9 @@ class Map {
   void EraseMapLine(MapLine*) {}
 };
 
+#ifdef PLO_REAL_FRAME   // the Frame.cc build uses the reference's own include/Frame.h
+class Frame;
+#else
 class Frame {
  public:
   long unsigned int mnId = 0;
@@ -43,6 +46,7 @@ class Frame {
   cv::Mat mDescriptors, mLdesc, mOw;
   cv::Mat GetCameraCenter() const { return mOw.clone(); }
 };
+#endif
 
 class KeyFrame {
  public:

@@ -1,0 +1,78 @@
+// oracle/_ref: the reference's own include/Frame.h + src/Frame.cc, compiled as they are (oracle/ref/build_ref.sh) with the
+// real MapPoint / MapLine / ORBextractor / LINEextractor / DBoW2 / lineIterator sources around them and stand-ins for
+// KeyFrame / Map / Converter only.  The harness fills a default-constructed Frame from flat arrays and calls the spatial
+// index the windowed searches stand on:
+//   Frame::AssignFeaturesToGrid (+ PosInGrid)        src/Frame.cc:278-293, 893-904
+//   Frame::AssignFeaturesToGridForLine               :296-320  (with the real src/lineIterator.cpp)
+//   Frame::GetFeaturesInArea                         :713-766
+//   Frame::GetFeaturesInAreaForLine                  :768-842
+// Not reachable without OpenCV proper: the constructors (remap, extractor threads), UndistortKeyPoints (cv::undistortPoints),
+// the stereo code.  TEST INFRASTRUCTURE ONLY.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#define private public   // AssignFeaturesToGrid / AssignFeaturesToGridForLine are private members
+#include "Frame.h"
+#undef private
+#include "ORBmatcher.h"
+
+namespace ORB_SLAM2 {
+// src/ORBmatcher.cc:37-39 (the stereo code of Frame.cc refers to them; src/ORBmatcher.cc itself needs the full KeyFrame)
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return plo_descriptor_distance(a.ptr<uchar>(0), b.ptr<uchar>(0)); }
+}  // namespace ORB_SLAM2
+
+using namespace ORB_SLAM2;
+
+extern "C" {
+
+void* ref_frame_create(const plo_keypoint* kps, int n, const plo_keyline* kl, const double* fn, int nl, const float gp[6]) {
+  Frame* f = new Frame();
+  Frame::mnMinX = gp[0]; Frame::mnMinY = gp[1]; Frame::mnMaxX = gp[2]; Frame::mnMaxY = gp[3];
+  Frame::mfGridElementWidthInv = gp[4]; Frame::mfGridElementHeightInv = gp[5];
+  f->N = n;
+  f->mvKeysUn.resize(n);
+  for (int i = 0; i < n; i++)
+    f->mvKeysUn[i] = cv::KeyPoint(kps[i].x, kps[i].y, kps[i].size, kps[i].angle, kps[i].response, kps[i].octave, kps[i].class_id);
+  f->mvKeys = f->mvKeysUn;
+  f->NL = nl;
+  f->mvKeylinesUn.resize(nl);
+  f->mvKeyLineFunctions.resize(nl);
+  for (int i = 0; i < nl; i++) {
+    std::memcpy(&f->mvKeylinesUn[i], &kl[i], sizeof(plo_keyline));
+    f->mvKeyLineFunctions[i] << fn[3 * i], fn[3 * i + 1], fn[3 * i + 2];
+  }
+  f->AssignFeaturesToGrid();
+  f->AssignFeaturesToGridForLine();
+  return f;
+}
+void ref_frame_destroy(void* h) { delete (Frame*)h; }
+
+static int csr(const std::vector<std::size_t> (*grid)[FRAME_GRID_ROWS], int32_t* cell_start, int32_t* cell_items, int cap) {
+  int k = 0;
+  for (int x = 0; x < FRAME_GRID_COLS; x++)
+    for (int y = 0; y < FRAME_GRID_ROWS; y++) {
+      cell_start[x * FRAME_GRID_ROWS + y] = k;
+      for (std::size_t id : grid[x][y]) { if (k < cap) cell_items[k] = (int32_t)id; k++; }
+    }
+  cell_start[FRAME_GRID_COLS * FRAME_GRID_ROWS] = k;
+  return k;
+}
+int ref_frame_grid_points(void* h, int32_t* cell_start, int32_t* cell_items, int cap) { return csr(((Frame*)h)->mGrid, cell_start, cell_items, cap); }
+int ref_frame_grid_lines(void* h, int32_t* cell_start, int32_t* cell_items, int cap) { return csr(((Frame*)h)->mGridForLine, cell_start, cell_items, cap); }
+
+int ref_frame_features_in_area(void* h, float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap) {
+  const std::vector<size_t> v = ((Frame*)h)->GetFeaturesInArea(x, y, r, minLevel, maxLevel);
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
+  return (int)v.size();
+}
+int ref_frame_features_in_area_for_line(void* h, float x1, float y1, float x2, float y2, float r, float TH, int32_t* out, int cap) {
+  const std::vector<size_t> v = ((Frame*)h)->GetFeaturesInAreaForLine(x1, y1, x2, y2, r, -1, -1, TH);
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
+  return (int)v.size();
+}
+
+}  // extern "C"

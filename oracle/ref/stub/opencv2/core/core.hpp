@@ -132,7 +132,7 @@ struct DMatch {
   bool operator<(const DMatch& m) const { return distance < m.distance; }
 };
 namespace Error { enum { StsBadArg = -5, BadDataPtr = -12, StsBadSize = -201 }; }
-enum { NORM_HAMMING = 6, NORM_L2 = 4, COLOR_BGR2GRAY = 6, COLOR_GRAY2BGR = 8, THRESH_BINARY = 0, DECOMP_LU = 0 };
+enum { NORM_HAMMING = 6, NORM_L2 = 4, NORM_L1 = 2, COLOR_BGR2GRAY = 6, COLOR_GRAY2BGR = 8, THRESH_BINARY = 0, DECOMP_LU = 0 };
 struct Rect {
   int x, y, width, height;
   Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
@@ -208,6 +208,10 @@ class Mat {
     return *this;
   }
   Mat t() const;
+  // compile-only members (stereo / triangulation code of Frame.cc that the harnesses never reach)
+  Mat reshape(int, int = 0) const { std::cerr << "oracle/ref stub: Mat::reshape is compile-only" << std::endl; std::abort(); }
+  void convertTo(Mat&, int) const { std::cerr << "oracle/ref stub: Mat::convertTo is compile-only" << std::endl; std::abort(); }
+  static Mat ones(int, int, int) { std::cerr << "oracle/ref stub: Mat::ones is compile-only" << std::endl; std::abort(); }
   Mat inv(int = 0) const { std::cerr << "oracle/ref stub: Mat::inv is compile-only" << std::endl; std::abort(); }
   Mat cross(const Mat& o) const {
     Mat r(rows, cols, CV_32F);
@@ -269,6 +273,7 @@ template <typename T> class Mat_ : public Mat {
   const T* operator[](int r) const { return ptr<T>(r); }
   T& operator()(int r, int c) { return ptr<T>(r)[c]; }
   Mat_ t() const { stub_unreachable_("Mat_::t"); return Mat_(); }
+  static Mat_ eye(int, int) { stub_unreachable_("Mat_::eye"); return Mat_(); }
  private:
   static void stub_unreachable_(const char* w) { std::cerr << "oracle/ref stub: " << w << " is compile-only" << std::endl; std::abort(); }
 };
@@ -296,6 +301,7 @@ class _InputArray {
 class _OutputArray : public _InputArray {
  public:
   _OutputArray(Mat& m) : _InputArray(m) {}
+  _OutputArray(const Mat& m) : _InputArray(m) {}   // temporaries (views) as destinations, as OpenCV allows
   void create(int r, int c, int type) const { m_->create(r, c, type); }
   void release() const { m_->release(); }
   void assign(const Mat& m) const { *m_ = m; }
@@ -356,6 +362,13 @@ inline double norm(const Mat& a, const Mat& b, int type) {   // NORM_HAMMING ove
   for (int i = 0; i < a.cols; i++) d += __builtin_popcount((unsigned)(a.ptr<uchar>(0)[i] ^ b.ptr<uchar>(0)[i]));
   return d;
 }
+struct SVD {
+  enum { MODIFY_A = 1, NO_UV = 2, FULL_UV = 4 };
+  static void compute(const Mat&, Mat&, Mat&, Mat&, int = 0) { stub_unreachable("cv::SVD::compute"); }
+};
+inline void initUndistortRectifyMap(const Mat&, const Mat&, const Mat&, const Mat&, Size, int, Mat&, Mat&) { stub_unreachable("cv::initUndistortRectifyMap"); }
+inline void remap(const Mat&, Mat&, const Mat&, const Mat&, int) { stub_unreachable("cv::remap"); }
+inline void undistortPoints(const Mat&, Mat&, const Mat&, const Mat&, const Mat& = Mat(), const Mat& = Mat()) { stub_unreachable("cv::undistortPoints"); }
 inline bool solve(const Mat&, const Mat&, Mat&, int = 0) { stub_unreachable("cv::solve"); }
 inline void cvtColor(const Mat&, Mat&, int) { stub_unreachable("cv::cvtColor"); }
 inline void pyrDown(const Mat&, Mat&, Size = Size()) { stub_unreachable("cv::pyrDown (numOctaves is 1 on this path)"); }
