@@ -208,43 +208,6 @@ __global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long
 // ll_angle(): level-line field (packed gx,gy, see line_dev.h), padding columns cleared, per-frame max gradient.
 // ---------------------------------------------------------------------------------------------
 // Block (64,4): 4 rows x 256 columns, 4 horizontally adjacent pixels per thread (two aligned dword loads per row).
-// sin / cos of a double in [0, 2 pi] for results that are going to be rounded to float.  Three-part pi/2 reduction (the
-// first two products are exact, Cody-Waite) and the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]: the
-// values carry a relative error below 2^-48, the library's below 2^-52.  `float_round_is_safe` says whether a double is
-// further than 2^-40 (relative) from the nearest float rounding boundary, in which case both round to the same float;
-// the caller falls back to the library sincos for the one pixel in ~10^4 where that is not so, which keeps the stored
-// floats bit-identical to a plain (float)sincos(ad).
-__device__ __forceinline__ void sincos_0_2pi(double ad, double& s, double& c) {
-  const double kd = (double)(int)(ad * 0.63661977236758138 + 0.5);
-  const int k = (int)kd;
-  double x = __builtin_fma(-kd, 1.57079632673412561417e+00, ad);   // 33-bit head of pi/2: exact
-  x = __builtin_fma(-kd, 6.07710050630396597660e-11, x);           // next 33 bits
-  x = __builtin_fma(-kd, 2.02226624879595063154e-21, x);           // tail
-  const double z = x * x;
-  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-  ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
-  const double sp = __builtin_fma(x * z, ps, x);
-  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
-  const double cp = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-  const bool swap = (k & 1) != 0;
-  const double s0 = swap ? cp : sp, c0 = swap ? sp : cp;
-  s = (k & 2) ? -s0 : s0;
-  c = ((k + 1) & 2) ? -c0 : c0;
-}
-__device__ __forceinline__ bool float_round_is_safe(double v) {
-  unsigned long long u;
-  __builtin_memcpy(&u, &v, 8);
-  const unsigned t = (unsigned)u & 0x1fffffffu;            // the 29 mantissa bits a float drops; the boundary is 2^28
-  return (unsigned)(t - (0x10000000u - 4096u)) >= 8192u;
-}
-
 __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   __shared__ unsigned s_max;
   const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;

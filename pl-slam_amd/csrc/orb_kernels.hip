@@ -829,8 +829,11 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
   // steered rBRIEF: lane -> 4 pairs (one nibble)
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
   const float ang = angle * factorPI;
+  // correctly rounded cosf / sinf of the pinned definition: double evaluation, one rounding (the short evaluation unless
+  // a result sits next to a float rounding boundary, see plh_common.h)
   double sd, cd;
-  sincos((double)ang, &sd, &cd);   // correctly rounded cosf / sinf of the pinned definition: double evaluation, one rounding
+  sincos_0_2pi((double)ang, sd, cd);
+  if (!(float_round_is_safe(cd) && float_round_is_safe(sd))) sincos((double)ang, &sd, &cd);
   const float ca = (float)cd, sa = (float)sd;
   const signed char* pat = c_orb_pattern + lane * 16;
   int nib = 0;
