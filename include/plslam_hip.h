@@ -403,6 +403,33 @@ PLH_API plh_status plh_line_search_by_projection_ml(const plh_keyline* kl, const
  * d_kps / d_kps_un: batch x cap records (may alias). */
 PLH_API plh_status plh_undistort_keypoints_batch_dev(const plh_keypoint* d_kps, const int32_t* d_n, int cap, int batch,
                                                      const float K[4], const float D[5], plh_keypoint* d_kps_un, void* stream);
+/* Frame::isInFrustum(MapPoint*, viewingCosLimit) / (MapLine*, viewingCosLimit) (Frame.cc:560-623, 625-711) with
+ * MapPoint::PredictScale(dist, Frame*) (MapPoint.cc:413-428) / MapLine::PredictScale (MapLine.cpp:395-404): the per-element
+ * visibility test Tracking::SearchLocalPoints / SearchLocalLines run in front of SearchByProjection(F, MapPoints / MapLines);
+ * its outputs are that search's query arrays.  One plh_frame_view per frame (device array), d_nq[frames] elements per frame
+ * at stride qcap.  Points: d_pos[..][3] = GetWorldPos, d_normal[..][3] = GetNormal, d_min_dist / d_max_dist = mfMinDistance /
+ * mfMaxDistance (the 0.8 / 1.2 invariance factors are applied inside); outputs valid = mbTrackInView, uv = (mTrackProjX,
+ * mTrackProjY), level = mnTrackScaleLevel (clamped to the frame's levels), viewcos = mTrackViewCos.  Lines: d_pos6[..][6] =
+ * (float) of the six world coordinates, d_normal = (float) GetNormal; outputs seg = (mTrackProjX1, Y1, X2, Y2), level
+ * unclamped as the reference leaves it (it passes the ORB log scale factor, Frame.cc:701).  cv::Mat arithmetic: `mRcw*P+mtcw`
+ * as one gemm with double accumulation, cv::norm / Mat::dot in double (the definition pinned in oracle/plo.h). */
+typedef struct plh_frame_view {
+  float Rcw[9];            /* mRcw, row-major */
+  float tcw[3];            /* mtcw */
+  float Ow[3];             /* mOw */
+  float fx, fy, cx, cy;
+  float min_x, min_y, max_x, max_y;   /* mnMinX .. mnMaxY */
+  float log_scale_factor;  /* mfLogScaleFactor */
+  int32_t n_scale_levels;  /* mnScaleLevels */
+} plh_frame_view;
+PLH_API plh_status plh_frame_is_in_frustum_points_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap,
+                                                            const float* d_pos, const float* d_normal, const float* d_min_dist,
+                                                            const float* d_max_dist, float viewing_cos_limit, uint8_t* d_valid,
+                                                            float* d_uv, int32_t* d_level, float* d_viewcos, void* stream);
+PLH_API plh_status plh_frame_is_in_frustum_lines_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap,
+                                                           const float* d_pos6, const float* d_normal, const float* d_min_dist,
+                                                           const float* d_max_dist, float viewing_cos_limit, uint8_t* d_valid,
+                                                           float* d_seg, int32_t* d_level, float* d_viewcos, void* stream);
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:249-314) / MapLine twin (MapLine.cpp:256-330) for many map
  * elements at once: set s owns the descriptor rows [d_offsets[s], d_offsets[s+1]) of d_desc (32 bytes each, <= 1024 rows);
  * d_best[s] = row (relative to the set) with the least median Hamming distance to the others, -1 for an empty set. */

@@ -657,3 +657,96 @@ extern "C" int plo_line_fuse_search(const plo_keyline* kl, const uint8_t* cand_d
   }
   return nfound;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Frame::isInFrustum for map points and map lines (reference src/Frame.cc:560-623, 625-711) + PredictScale.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct View { float R[9], t[3], Ow[3], fx, fy, cx, cy, minX, minY, maxX, maxY, logScale; };
+// `mRcw*P + mtcw`: cv::gemm(A, B, 1, C, 1) on CV_32F accumulates in double and rounds once (pinned definition)
+inline void to_camera(const View& v, const float* P, float* Pc) {
+  for (int i = 0; i < 3; i++) {
+    double s = (double)v.R[i * 3] * (double)P[0];
+    s += (double)v.R[i * 3 + 1] * (double)P[1];
+    s += (double)v.R[i * 3 + 2] * (double)P[2];
+    Pc[i] = (float)(s + (double)v.t[i]);
+  }
+}
+inline float norm3(const float* a) {   // cv::norm(NORM_L2) of a CV_32F vector: double accumulation
+  double s = (double)a[0] * (double)a[0];
+  s += (double)a[1] * (double)a[1];
+  s += (double)a[2] * (double)a[2];
+  return (float)std::sqrt(s);
+}
+inline double dot3(const float* a, const float* b) {   // Mat::dot: double accumulation, returns double
+  double s = (double)a[0] * (double)b[0];
+  s += (double)a[1] * (double)b[1];
+  s += (double)a[2] * (double)b[2];
+  return s;
+}
+}  // namespace
+
+extern "C" void plo_frame_is_in_frustum_points(const float view[24], int nlevels, int n, const float* pos, const float* normal,
+                                               const float* min_dist, const float* max_dist, float viewing_cos_limit,
+                                               uint8_t* valid, float* uv, int32_t* level, float* viewcos) {
+  View v;
+  memcpy(&v, view, sizeof(v));
+  for (int i = 0; i < n; i++) {
+    valid[i] = 0; uv[2 * i] = uv[2 * i + 1] = 0.f; level[i] = 0; viewcos[i] = 0.f;
+    const float* P = pos + 3 * i;
+    float Pc[3];
+    to_camera(v, P, Pc);
+    if (Pc[2] < 0.0f) continue;
+    const float invz = 1.0f / Pc[2];
+    const float u = v.fx * Pc[0] * invz + v.cx;
+    const float w = v.fy * Pc[1] * invz + v.cy;
+    if (u < v.minX || u > v.maxX) continue;
+    if (w < v.minY || w > v.maxY) continue;
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];   // Get{Max,Min}DistanceInvariance
+    const float PO[3] = {P[0] - v.Ow[0], P[1] - v.Ow[1], P[2] - v.Ow[2]};
+    const float dist = norm3(PO);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const float viewCos = (float)(dot3(PO, normal + 3 * i) / dist);
+    if (viewCos < viewing_cos_limit) continue;
+    const float ratio = max_dist[i] / dist;   // MapPoint::PredictScale(dist, Frame*)
+    int nScale = (int)ceilf(logf(ratio) / v.logScale);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nlevels) nScale = nlevels - 1;
+    valid[i] = 1; uv[2 * i] = u; uv[2 * i + 1] = w; level[i] = nScale; viewcos[i] = viewCos;
+  }
+}
+
+extern "C" void plo_frame_is_in_frustum_lines(const float view[24], int n, const float* pos6, const float* normal,
+                                              const float* min_dist, const float* max_dist, float viewing_cos_limit,
+                                              uint8_t* valid, float* seg, int32_t* level, float* viewcos) {
+  View v;
+  memcpy(&v, view, sizeof(v));
+  for (int i = 0; i < n; i++) {
+    valid[i] = 0; seg[4 * i] = seg[4 * i + 1] = seg[4 * i + 2] = seg[4 * i + 3] = 0.f; level[i] = 0; viewcos[i] = 0.f;
+    const float *SP = pos6 + 6 * i, *EP = SP + 3;
+    float SPc[3], EPc[3];
+    to_camera(v, SP, SPc);
+    to_camera(v, EP, EPc);
+    if (SPc[2] < 0.0f || EPc[2] < 0.0f) continue;
+    const float invz1 = 1.0f / SPc[2];
+    const float u1 = v.fx * SPc[0] * invz1 + v.cx;
+    const float v1 = v.fy * SPc[1] * invz1 + v.cy;
+    if (u1 < v.minX || u1 > v.maxX) continue;
+    if (v1 < v.minY || v1 > v.maxY) continue;
+    const float invz2 = 1.0f / EPc[2];
+    const float u2 = v.fx * EPc[0] * invz2 + v.cx;
+    const float v2 = v.fy * EPc[1] * invz2 + v.cy;
+    if (u2 < v.minX || u2 > v.maxX) continue;
+    if (v2 < v.minY || v2 > v.maxY) continue;
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    float OM[3];
+    for (int k = 0; k < 3; k++) OM[k] = 0.5f * (SP[k] + EP[k]) - v.Ow[k];   // 0.5*(SP+EP) - mOw
+    const float dist = norm3(OM);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const float viewCos = (float)(dot3(OM, normal + 3 * i) / dist);
+    if (viewCos < viewing_cos_limit) continue;
+    const float ratio = max_dist[i] / dist;   // MapLine::PredictScale(dist, mfLogScaleFactor): no clamping
+    const int nScale = (int)ceilf(logf(ratio) / v.logScale);
+    valid[i] = 1; seg[4 * i] = u1; seg[4 * i + 1] = v1; seg[4 * i + 2] = u2; seg[4 * i + 3] = v2; level[i] = nScale; viewcos[i] = viewCos;
+  }
+}

@@ -30,6 +30,8 @@
  *     as plo_distinctive_descriptor (tests/test_ref_mapobj.py);
  *   - src/Frame.cc with its own header: AssignFeaturesToGrid[ForLine], GetFeaturesInArea, GetFeaturesInAreaForLine return
  *     the same cells and the same candidates in the same order as frame_search.cc (tests/test_ref_frame.py);
+ *     Frame::isInFrustum (points and lines, with the real MapPoint / MapLine::PredictScale) for poses without rotation
+ *     (tests/test_frustum.py); with a rotation the gemm rounding is this oracle's definition (unpinned);
  *   - src/lineIterator.cpp: the line grid of frame_search.cc (tests/test_ref_linegrid.py).
  * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
  * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE
@@ -193,6 +195,21 @@ int  plo_orb_search_by_projection_kf(const plo_keypoint* kps_un, const uint8_t* 
                                      const uint8_t* q_valid, const float* q_uv, const int32_t* q_level, const float* q_angle,
                                      const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int orb_dist, int check_ori,
                                      int32_t* assigned);
+
+
+/* Frame::isInFrustum(MapPoint*, viewingCosLimit) / (MapLine*, ...) (src/Frame.cc:560-623, 625-711) with
+ * MapPoint::PredictScale (src/MapPoint.cc:413-428) / MapLine::PredictScale (src/MapLine.cpp:395-404): what Tracking runs on
+ * every local map element to produce the queries of SearchByProjection(F, MapPoints / MapLines).  view[24] = Rcw[9] row-major,
+ * tcw[3], Ow[3], fx, fy, cx, cy, mnMinX, mnMinY, mnMaxX, mnMaxY, mfLogScaleFactor; nlevels = mnScaleLevels.
+ * Pinned definition of the cv::Mat arithmetic inside (OpenCV is not in the tree): `mRcw*P+mtcw` is ONE gemm call with double
+ * accumulation and a single rounding to float; cv::norm and Mat::dot accumulate in double; everything else is the float
+ * expression as written.  log() of a float resolves to the float overload (as with g++ / libstdc++ here). */
+void plo_frame_is_in_frustum_points(const float view[24], int nlevels, int n, const float* pos, const float* normal,
+                                    const float* min_dist, const float* max_dist, float viewing_cos_limit, uint8_t* valid,
+                                    float* uv, int32_t* level, float* viewcos);
+void plo_frame_is_in_frustum_lines(const float view[24], int n, const float* pos6, const float* normal, const float* min_dist,
+                                   const float* max_dist, float viewing_cos_limit, uint8_t* valid, float* seg, int32_t* level,
+                                   float* viewcos);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,9 @@
 //   Frame::AssignFeaturesToGridForLine               :296-320  (with the real src/lineIterator.cpp)
 //   Frame::GetFeaturesInArea                         :713-766
 //   Frame::GetFeaturesInAreaForLine                  :768-842
+//   Frame::isInFrustum(MapPoint*, cos) / (MapLine*, cos)   :560-623, 625-711  (+ the real MapPoint / MapLine::PredictScale),
+//     driven with poses that have no rotation (mRcw = I, any translation), for which the stand-in's float algebra and
+//     OpenCV's gemm give the same floats
 // Not reachable without OpenCV proper: the constructors (remap, extractor threads), UndistortKeyPoints (cv::undistortPoints),
 // the stereo code.  TEST INFRASTRUCTURE ONLY.
 #include <cstdint>
@@ -13,8 +16,10 @@
 #include <vector>
 
 #define private public   // AssignFeaturesToGrid / AssignFeaturesToGridForLine are private members
+#define protected public   // MapPoint / MapLine: mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance
 #include "Frame.h"
 #undef private
+#undef protected
 #include "ORBmatcher.h"
 
 namespace ORB_SLAM2 {
@@ -73,6 +78,74 @@ int ref_frame_features_in_area_for_line(void* h, float x1, float y1, float x2, f
   const std::vector<size_t> v = ((Frame*)h)->GetFeaturesInAreaForLine(x1, y1, x2, y2, r, -1, -1, TH);
   for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
   return (int)v.size();
+}
+
+
+// view[24] as in oracle/plo.h (Rcw must be the identity).  Points: real MapPoint objects, Frame::isInFrustum(MapPoint*, cos).
+void ref_frame_is_in_frustum_points(const float view[24], int nlevels, int n, const float* pos, const float* normal,
+                                    const float* min_dist, const float* max_dist, float cos_limit, uint8_t* valid, float* uv,
+                                    int32_t* level, float* viewcos) {
+  Frame f;
+  Map map;
+  KeyFrame kf;
+  cv::Mat T = cv::Mat::zeros(4, 4, CV_32F);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T.at<float>(i, j) = view[i * 3 + j];
+    T.at<float>(i, 3) = view[9 + i];
+  }
+  T.at<float>(3, 3) = 1.f;
+  f.SetPose(T);
+  Frame::fx = view[15]; Frame::fy = view[16]; Frame::cx = view[17]; Frame::cy = view[18];
+  Frame::mnMinX = view[19]; Frame::mnMinY = view[20]; Frame::mnMaxX = view[21]; Frame::mnMaxY = view[22];
+  f.mfLogScaleFactor = view[23];
+  f.mnScaleLevels = nlevels;
+  f.mbf = 0.f;
+  for (int i = 0; i < n; i++) {
+    cv::Mat P(3, 1, CV_32F);
+    for (int k = 0; k < 3; k++) P.at<float>(k) = pos[3 * i + k];
+    MapPoint mp(P, &kf, &map);
+    mp.mNormalVector = cv::Mat(3, 1, CV_32F);
+    for (int k = 0; k < 3; k++) mp.mNormalVector.at<float>(k) = normal[3 * i + k];
+    mp.mfMinDistance = min_dist[i];
+    mp.mfMaxDistance = max_dist[i];
+    const bool ok = f.isInFrustum(&mp, cos_limit);
+    valid[i] = (ok && mp.mbTrackInView) ? 1 : 0;
+    uv[2 * i] = ok ? mp.mTrackProjX : 0.f; uv[2 * i + 1] = ok ? mp.mTrackProjY : 0.f;
+    level[i] = ok ? mp.mnTrackScaleLevel : 0;
+    viewcos[i] = ok ? mp.mTrackViewCos : 0.f;
+  }
+}
+
+void ref_frame_is_in_frustum_lines(const float view[24], int n, const float* pos6, const float* normal, const float* min_dist,
+                                   const float* max_dist, float cos_limit, uint8_t* valid, float* seg, int32_t* level,
+                                   float* viewcos) {
+  Frame f;
+  Map map;
+  KeyFrame kf;
+  cv::Mat T = cv::Mat::zeros(4, 4, CV_32F);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T.at<float>(i, j) = view[i * 3 + j];
+    T.at<float>(i, 3) = view[9 + i];
+  }
+  T.at<float>(3, 3) = 1.f;
+  f.SetPose(T);
+  Frame::fx = view[15]; Frame::fy = view[16]; Frame::cx = view[17]; Frame::cy = view[18];
+  Frame::mnMinX = view[19]; Frame::mnMinY = view[20]; Frame::mnMaxX = view[21]; Frame::mnMaxY = view[22];
+  f.mfLogScaleFactor = view[23];
+  for (int i = 0; i < n; i++) {
+    Vector6d P;
+    for (int k = 0; k < 6; k++) P(k) = pos6[6 * i + k];
+    MapLine ml(P, &kf, &map);
+    for (int k = 0; k < 3; k++) ml.mNormalVector(k) = normal[3 * i + k];
+    ml.mfMinDistance = min_dist[i];
+    ml.mfMaxDistance = max_dist[i];
+    const bool ok = f.isInFrustum(&ml, cos_limit);
+    valid[i] = (ok && ml.mbTrackInView) ? 1 : 0;
+    seg[4 * i] = ok ? ml.mTrackProjX1 : 0.f; seg[4 * i + 1] = ok ? ml.mTrackProjY1 : 0.f;
+    seg[4 * i + 2] = ok ? ml.mTrackProjX2 : 0.f; seg[4 * i + 3] = ok ? ml.mTrackProjY2 : 0.f;
+    level[i] = ok ? ml.mnTrackScaleLevel : 0;
+    viewcos[i] = ok ? ml.mTrackViewCos : 0.f;
+  }
 }
 
 }  // extern "C"

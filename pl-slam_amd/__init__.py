@@ -86,6 +86,8 @@ _SIGS = {
     "plh_orb_search_by_sim3_batch_dev": ([_V] * 10 + [_I, _I, _V, _V, _I] + [_V] * 8 + [_F, _I, _V, _V, _V, _V, _V], _I),
     "plh_undistort_keypoints_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
     "plh_distinctive_descriptor_batch_dev": ([_V, _V, _I, _V, _V], _I),
+    "plh_frame_is_in_frustum_points_batch_dev": ([_V, _I, _V, _I, _V, _V, _V, _V, C.c_float, _V, _V, _V, _V, _V], _I),
+    "plh_frame_is_in_frustum_lines_batch_dev": ([_V, _I, _V, _I, _V, _V, _V, _V, C.c_float, _V, _V, _V, _V, _V], _I),
     "plh_frame_assign_grid_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
     "plh_frame_assign_grid_lines_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _I, _V], _I),
     "plh_orb_search_for_initialization_batch_dev": ([_V] * 6 + [_I, _I, _V, _V, _V, _V, _I, _F, _I, _V, _V, _V], _I),
@@ -594,6 +596,41 @@ def undistort_keypoints(kps_list, K, D, device=0, lib=None):
                                                   C.c_void_p(Dv.stream())), "plh_undistort_keypoints_batch_dev")
     out = np.ascontiguousarray(Dv.get(da)).view(np.uint8).reshape(len(kps_list), cap, 28).copy().view(KP_DTYPE).reshape(len(kps_list), cap)
     return [out[i, :len(k)].copy() for i, k in enumerate(kps_list)]
+
+
+VIEW_DTYPE = np.dtype([("Rcw", np.float32, 9), ("tcw", np.float32, 3), ("Ow", np.float32, 3), ("fx", np.float32), ("fy", np.float32),
+                       ("cx", np.float32), ("cy", np.float32), ("min_x", np.float32), ("min_y", np.float32), ("max_x", np.float32),
+                       ("max_y", np.float32), ("log_scale_factor", np.float32), ("n_scale_levels", np.int32)])   # == plh_frame_view
+
+
+def is_in_frustum(views, elems, viewing_cos_limit, lines=False, device=0, lib=None):
+    """Frame::isInFrustum for the local map of a batch of frames.  views: VIEW_DTYPE[P]; elems: per frame
+    dict(pos [n,3] (points) or [n,6] (lines), normal [n,3], min_dist [n], max_dist [n]).  Returns per frame
+    dict(valid, uv | seg, level, viewcos) -- the query arrays of SearchByProjection(F, MapPoints / MapLines)."""
+    L = load(lib)
+    Dv = _Dev(L, device)
+    P = len(elems)
+    w = 6 if lines else 3
+    qcap = max(1, max(len(e["min_dist"]) for e in elems))
+    pos, nq = _pad_sets([np.asarray(e["pos"], np.float32).reshape(-1, w) for e in elems], qcap, w, np.float32)
+    nrm, _ = _pad_sets([np.asarray(e["normal"], np.float32).reshape(-1, 3) for e in elems], qcap, 3, np.float32)
+    mind, _ = _pad_sets([e["min_dist"] for e in elems], qcap, 0, np.float32)
+    maxd, _ = _pad_sets([e["max_dist"] for e in elems], qcap, 0, np.float32)
+    dv = Dv.put(np.ascontiguousarray(views, VIEW_DTYPE).view(np.uint8).reshape(P, VIEW_DTYPE.itemsize))
+    dp, dn, dmi, dma, dnq = Dv.put(pos), Dv.put(nrm), Dv.put(mind), Dv.put(maxd), Dv.put(nq)
+    pw = 4 if lines else 2
+    ov, op, ol, oc = Dv.empty((P, qcap), np.uint8), Dv.empty((P, qcap, pw), np.float32), Dv.empty((P, qcap), np.int32), \
+        Dv.empty((P, qcap), np.float32)
+    fn = L.plh_frame_is_in_frustum_lines_batch_dev if lines else L.plh_frame_is_in_frustum_points_batch_dev
+    _check(L, fn(_p(dv), P, _p(dnq), qcap, _p(dp), _p(dn), _p(dmi), _p(dma), float(viewing_cos_limit), _p(ov), _p(op), _p(ol), _p(oc),
+                 C.c_void_p(Dv.stream())), "plh_frame_is_in_frustum_%s_batch_dev" % ("lines" if lines else "points"))
+    v, pr, lv, vc = Dv.get(ov), Dv.get(op), Dv.get(ol), Dv.get(oc)
+    out = []
+    for b, e in enumerate(elems):
+        n = len(e["min_dist"])
+        out.append({"valid": v[b, :n].copy(), ("seg" if lines else "uv"): pr[b, :n].copy(), "level": lv[b, :n].copy(),
+                    "viewcos": vc[b, :n].copy()})
+    return out
 
 
 def distinctive_descriptors(sets, device=0, lib=None):

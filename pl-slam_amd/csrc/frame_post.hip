@@ -76,6 +76,123 @@ __global__ void __launch_bounds__(64) k_distinctive(const uint8_t* desc, const i
   if (lane == 0) best[s] = bestIdx;
 }
 
+// Frame::isInFrustum for map points / map lines (reference src/Frame.cc:560-623, 625-711) with PredictScale
+// (src/MapPoint.cc:413-428, src/MapLine.cpp:395-404).  One thread per map element, one pose per frame.  The cv::Mat
+// arithmetic follows the pinned definition of oracle/plo.h: `mRcw*P+mtcw` = one gemm with double accumulation and a single
+// rounding, cv::norm / Mat::dot accumulate in double, the rest is the float expression as written (no FMA contraction).
+__device__ __forceinline__ void to_camera(const plh_frame_view& v, const float* P, float* Pc) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double s = (double)v.Rcw[i * 3] * (double)P[0];
+    s += (double)v.Rcw[i * 3 + 1] * (double)P[1];
+    s += (double)v.Rcw[i * 3 + 2] * (double)P[2];
+    Pc[i] = (float)(s + (double)v.tcw[i]);
+  }
+}
+__device__ __forceinline__ float norm3(const float* a) {
+  double s = (double)a[0] * (double)a[0];
+  s += (double)a[1] * (double)a[1];
+  s += (double)a[2] * (double)a[2];
+  return (float)sqrt(s);
+}
+__device__ __forceinline__ double dot3(const float* a, const float* b) {
+  double s = (double)a[0] * (double)b[0];
+  s += (double)a[1] * (double)b[1];
+  s += (double)a[2] * (double)b[2];
+  return s;
+}
+// ceil(log(ratio) / logScaleFactor) with log = the float overload; the double logarithm rounded to float is logf
+// wherever logf is correctly rounded
+__device__ __forceinline__ int predict_scale(float maxDist, float dist, float logScale) {
+  const float ratio = maxDist / dist;
+  return (int)ceilf((float)log((double)ratio) / logScale);
+}
+
+__global__ void __launch_bounds__(256) k_frustum_points(const plh_frame_view* views, const int* nArr, int qcap, const float* pos,
+                                                        const float* normal, const float* minDist, const float* maxDist,
+                                                        float cosLimit, uint8_t* valid, float* uv, int* level, float* viewcos) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= qcap) return;
+  const long long o = (long long)b * qcap + i;
+  uint8_t ok = 0;
+  float u = 0.f, w = 0.f, vc = 0.f;
+  int lvl = 0;
+  if (i < nArr[b]) {
+    const plh_frame_view v = views[b];
+    const float P[3] = {pos[o * 3], pos[o * 3 + 1], pos[o * 3 + 2]};
+    float Pc[3];
+    to_camera(v, P, Pc);
+    if (!(Pc[2] < 0.0f)) {
+      const float invz = 1.0f / Pc[2];
+      const float uu = v.fx * Pc[0] * invz + v.cx;
+      const float ww = v.fy * Pc[1] * invz + v.cy;
+      if (!(uu < v.min_x || uu > v.max_x) && !(ww < v.min_y || ww > v.max_y)) {
+        const float maxD = 1.2f * maxDist[o], minD = 0.8f * minDist[o];
+        const float PO[3] = {P[0] - v.Ow[0], P[1] - v.Ow[1], P[2] - v.Ow[2]};
+        const float dist = norm3(PO);
+        if (!(dist < minD || dist > maxD)) {
+          const float N[3] = {normal[o * 3], normal[o * 3 + 1], normal[o * 3 + 2]};
+          const float c = (float)(dot3(PO, N) / dist);
+          if (!(c < cosLimit)) {
+            int nScale = predict_scale(maxDist[o], dist, v.log_scale_factor);
+            if (nScale < 0) nScale = 0;
+            else if (nScale >= v.n_scale_levels) nScale = v.n_scale_levels - 1;
+            ok = 1; u = uu; w = ww; vc = c; lvl = nScale;
+          }
+        }
+      }
+    }
+  }
+  valid[o] = ok; uv[o * 2] = u; uv[o * 2 + 1] = w; level[o] = lvl; viewcos[o] = vc;
+}
+
+__global__ void __launch_bounds__(256) k_frustum_lines(const plh_frame_view* views, const int* nArr, int qcap, const float* pos6,
+                                                       const float* normal, const float* minDist, const float* maxDist,
+                                                       float cosLimit, uint8_t* valid, float* seg, int* level, float* viewcos) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= qcap) return;
+  const long long o = (long long)b * qcap + i;
+  uint8_t ok = 0;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, vc = 0.f;
+  int lvl = 0;
+  if (i < nArr[b]) {
+    const plh_frame_view v = views[b];
+    float SP[3], EP[3], SPc[3], EPc[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { SP[k] = pos6[o * 6 + k]; EP[k] = pos6[o * 6 + 3 + k]; }
+    to_camera(v, SP, SPc);
+    to_camera(v, EP, EPc);
+    if (!(SPc[2] < 0.0f || EPc[2] < 0.0f)) {
+      const float invz1 = 1.0f / SPc[2];
+      const float u1 = v.fx * SPc[0] * invz1 + v.cx;
+      const float v1 = v.fy * SPc[1] * invz1 + v.cy;
+      const float invz2 = 1.0f / EPc[2];
+      const float u2 = v.fx * EPc[0] * invz2 + v.cx;
+      const float v2 = v.fy * EPc[1] * invz2 + v.cy;
+      const bool in1 = !(u1 < v.min_x || u1 > v.max_x) && !(v1 < v.min_y || v1 > v.max_y);
+      const bool in2 = !(u2 < v.min_x || u2 > v.max_x) && !(v2 < v.min_y || v2 > v.max_y);
+      if (in1 && in2) {
+        const float maxD = 1.2f * maxDist[o], minD = 0.8f * minDist[o];
+        float OM[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) OM[k] = 0.5f * (SP[k] + EP[k]) - v.Ow[k];
+        const float dist = norm3(OM);
+        if (!(dist < minD || dist > maxD)) {
+          const float N[3] = {normal[o * 3], normal[o * 3 + 1], normal[o * 3 + 2]};
+          const float c = (float)(dot3(OM, N) / dist);
+          if (!(c < cosLimit)) {
+            ok = 1; s4[0] = u1; s4[1] = v1; s4[2] = u2; s4[3] = v2; vc = c;
+            lvl = predict_scale(maxDist[o], dist, v.log_scale_factor);   // MapLine::PredictScale does not clamp
+          }
+        }
+      }
+    }
+  }
+  valid[o] = ok; level[o] = lvl; viewcos[o] = vc;
+#pragma unroll
+  for (int k = 0; k < 4; k++) seg[o * 4 + k] = s4[k];
+}
+
 }  // namespace plh
 
 using namespace plh;
@@ -109,6 +226,43 @@ plh_status plh_distinctive_descriptor_batch_dev(const uint8_t* d_desc, const int
   hipLaunchKernelGGL(k_distinctive, dim3(nsets), dim3(64), 0, (hipStream_t)stream, d_desc, (const int*)d_offsets, nsets, d_best);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
+}
+
+
+static plh_status launch_frustum(int lines, const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap, const float* d_pos,
+                                 const float* d_normal, const float* d_min_dist, const float* d_max_dist, float cos_limit,
+                                 uint8_t* d_valid, float* d_proj, int32_t* d_level, float* d_viewcos, void* stream, const char* who) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_views || !d_nq || !d_pos || !d_normal || !d_min_dist || !d_max_dist || !d_valid || !d_proj || !d_level || !d_viewcos ||
+      frames <= 0 || qcap <= 0) {
+    set_error("%s: invalid argument", who);
+    return PLH_ERR_INVALID;
+  }
+  const dim3 grid((qcap + 255) / 256, frames);
+  if (lines)
+    hipLaunchKernelGGL(k_frustum_lines, grid, dim3(256), 0, (hipStream_t)stream, d_views, (const int*)d_nq, qcap, d_pos, d_normal,
+                       d_min_dist, d_max_dist, cos_limit, d_valid, d_proj, (int*)d_level, d_viewcos);
+  else
+    hipLaunchKernelGGL(k_frustum_points, grid, dim3(256), 0, (hipStream_t)stream, d_views, (const int*)d_nq, qcap, d_pos, d_normal,
+                       d_min_dist, d_max_dist, cos_limit, d_valid, d_proj, (int*)d_level, d_viewcos);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_frame_is_in_frustum_points_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap,
+                                                    const float* d_pos, const float* d_normal, const float* d_min_dist,
+                                                    const float* d_max_dist, float viewing_cos_limit, uint8_t* d_valid, float* d_uv,
+                                                    int32_t* d_level, float* d_viewcos, void* stream) {
+  return launch_frustum(0, d_views, frames, d_nq, qcap, d_pos, d_normal, d_min_dist, d_max_dist, viewing_cos_limit, d_valid, d_uv, d_level,
+                        d_viewcos, stream, "plh_frame_is_in_frustum_points_batch_dev");
+}
+
+plh_status plh_frame_is_in_frustum_lines_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap,
+                                                   const float* d_pos6, const float* d_normal, const float* d_min_dist,
+                                                   const float* d_max_dist, float viewing_cos_limit, uint8_t* d_valid, float* d_seg,
+                                                   int32_t* d_level, float* d_viewcos, void* stream) {
+  return launch_frustum(1, d_views, frames, d_nq, qcap, d_pos6, d_normal, d_min_dist, d_max_dist, viewing_cos_limit, d_valid, d_seg,
+                        d_level, d_viewcos, stream, "plh_frame_is_in_frustum_lines_batch_dev");
 }
 
 }  // extern "C"

@@ -1,0 +1,141 @@
+"""Frame::isInFrustum for map points and map lines (+ MapPoint / MapLine::PredictScale) -- the visibility test in front of
+SearchByProjection(F, MapPoints / MapLines) (reference src/Frame.cc:560-623, 625-711; src/MapPoint.cc:413-428;
+src/MapLine.cpp:395-404).  C ABI: plh_frame_is_in_frustum_{points,lines}_batch_dev.
+
+* the oracle against hand-derived known answers;
+* the oracle against the REFERENCE's own Frame.cc / MapPoint.cc / MapLine.cpp (oracle/_ref/libframe_ref.so, real Frame,
+  MapPoint and MapLine objects) for poses without rotation -- the case in which the stand-in cv::Mat algebra and OpenCV's
+  gemm provably give the same floats; committed as tests/golden/ref_frustum.npz.  With a rotation the result depends on
+  how cv::gemm rounds `mRcw*P+mtcw` (one double-accumulated product, the definition pinned in oracle/plo.h): PARITY
+  UNPINNED there, the GPU is held to the oracle;
+* the HIP kernels (host emulator, and `-m gpu` on the GPU) against the oracle for rotated poses and against the goldens."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import _util
+
+GOLDEN = os.path.join(_util.ROOT, "tests", "golden", "ref_frustum.npz")
+REF_SO = os.path.join(_util.ROOT, "oracle", "_ref", "libframe_ref.so")
+V, I, F = C.c_void_p, C.c_int, C.c_float
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_golden_ref", os.path.join(_util.ROOT, "tools", "gen_golden_ref.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _oracle(O, view, nlv, e, lines, cos):
+    L = O.lib()
+    L.plo_frame_is_in_frustum_points.argtypes = [V, I, I, V, V, V, V, F, V, V, V, V]
+    L.plo_frame_is_in_frustum_lines.argtypes = [V, I, V, V, V, V, F, V, V, V, V]
+    n = len(e["min_dist"])
+    valid, proj = np.zeros(max(n, 1), np.uint8), np.zeros((max(n, 1), 4 if lines else 2), np.float32)
+    level, vc = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32)
+    p = O._p
+    if lines:
+        L.plo_frame_is_in_frustum_lines(p(view), n, p(e["pos"]), p(e["normal"]), p(e["min_dist"]), p(e["max_dist"]), cos, p(valid), p(proj),
+                                        p(level), p(vc))
+    else:
+        L.plo_frame_is_in_frustum_points(p(view), nlv, n, p(e["pos"]), p(e["normal"]), p(e["min_dist"]), p(e["max_dist"]), cos, p(valid),
+                                         p(proj), p(level), p(vc))
+    return valid[:n], proj[:n], level[:n], vc[:n]
+
+
+def _view_record(P, view, nlv):
+    r = np.zeros(1, P.VIEW_DTYPE)
+    r["Rcw"], r["tcw"], r["Ow"] = view[:9], view[9:12], view[12:15]
+    for k, name in enumerate(("fx", "fy", "cx", "cy", "min_x", "min_y", "max_x", "max_y", "log_scale_factor")):
+        r[name] = view[15 + k]
+    r["n_scale_levels"] = nlv
+    return r[0]
+
+
+def _same(a, b):
+    return all((x == y).all() for x, y in zip(a, b))
+
+
+def test_oracle_known_answers(oracle):
+    # camera at the origin looking down +z, fx = fy = 500, principal point (320, 240), image 640 x 480, 8 levels of 1.2
+    view = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 500, 500, 320, 240, 0, 0, 640, 480, np.log(np.float32(1.2))], np.float32)
+    e = dict(pos=np.array([[0, 0, 2], [0.2, -0.1, 2], [0, 0, -2], [2, 0, 2], [0, 0, 2], [0, 0, 2], [0, 0, 2]], np.float32),
+             normal=np.array([[0, 0, 1]] * 5 + [[1, 0, 0], [0, 0, 1]], np.float32),
+             min_dist=np.array([0.5] * 6 + [0.5], np.float32), max_dist=np.array([4.0, 4.0, 4.0, 4.0, 1.0, 4.0, 2.0], np.float32))
+    valid, uv, level, vc = _oracle(oracle, view, 8, e, 0, 0.5)
+    assert list(valid) == [1, 1, 0, 0, 0, 0, 1]            # behind / outside the image / beyond 1.2 max / seen at 90 degrees
+    assert (uv[0] == [320, 240]).all() and (uv[1] == [370, 215]).all() and vc[0] == 1.0
+    assert level[0] == 4 and level[6] == 0                 # ceil(log(4/2) / log 1.2) = ceil(3.80) = 4 ; ratio 1 -> 0
+    le = dict(pos=np.array([[-0.2, 0, 2, 0.2, 0, 2], [-0.2, 0, 2, 0.2, 0, -1]], np.float32), normal=np.array([[0, 0, 1]] * 2, np.float32),
+              min_dist=np.array([0.5, 0.5], np.float32), max_dist=np.array([64.0, 4.0], np.float32))
+    valid, seg, level, vc = _oracle(oracle, view, 8, le, 1, 0.5)
+    assert list(valid) == [1, 0] and (seg[0] == [270, 240, 370, 240]).all()
+    assert level[0] == 20                                   # MapLine::PredictScale does not clamp: ceil(log 32 / log 1.2) = 20
+
+
+def test_golden_file_present():
+    assert os.path.exists(GOLDEN)
+
+
+def test_oracle_reproduces_reference_frustum(oracle, plslam, synth):
+    G = _gen()
+    TF = G._test_module("test_frame_search")
+    g = np.load(GOLDEN)
+    for seed, n, dist in G.FRUSTUM_CASES:
+        view, nlv = G.frustum_view(synth, plslam, TF, seed, dist, rotate=False)
+        for lines in (0, 1):
+            e = G.frustum_elems(synth, seed, n, view, lines)
+            key = "%s_%d" % ("l" if lines else "p", seed)
+            assert _same(_oracle(oracle, view, nlv, e, lines, G.FRUSTUM_COS), [g[key + s] for s in ("_valid", "_proj", "_level", "_vc")]), key
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (no /root/reference on this machine)")
+def test_reference_frustum_live(oracle, plslam, synth):
+    G = _gen()
+    TF = G._test_module("test_frame_search")
+    R = G.ref_frame_lib()
+    for seed, n, dist in [(11, 2000, True), (12, 77, False)]:
+        view, nlv = G.frustum_view(synth, plslam, TF, seed, dist, rotate=False)
+        for lines in (0, 1):
+            e = G.frustum_elems(synth, seed, n, view, lines)
+            ref = G.reference_frustum(R, view, nlv, e, lines)
+            assert ref[0].sum() > n // 5 and _same(_oracle(oracle, view, nlv, e, lines, G.FRUSTUM_COS), ref), (seed, lines)
+
+
+def _device(P, O, synth, lib, sizes):
+    G = _gen()
+    TF = G._test_module("test_frame_search")
+    g = np.load(GOLDEN)
+    for lines in (0, 1):
+        # rotated poses, several frames per launch, ragged element counts: against the oracle
+        views, elems, refs = [], [], []
+        for b, n in enumerate(sizes):
+            view, nlv = G.frustum_view(synth, P, TF, 40 + b, b % 2 == 1, rotate=True)
+            e = G.frustum_elems(synth, 40 + b, n, view, lines)
+            views.append(_view_record(P, view, nlv)); elems.append(e)
+            refs.append(_oracle(O, view, nlv, e, lines, 0.5))
+        got = P.is_in_frustum(np.array(views, P.VIEW_DTYPE), elems, 0.5, lines=bool(lines), lib=lib)
+        for b, (r, q) in enumerate(zip(refs, got)):
+            assert _same(r, (q["valid"], q["seg" if lines else "uv"], q["level"], q["viewcos"])), "frame %d %s" % (b, "lines" if lines else "points")
+            assert r[0].sum() > len(r[0]) // 6 or len(r[0]) < 10
+        # the committed reference outputs
+        for seed, n, dist in G.FRUSTUM_CASES:
+            view, nlv = G.frustum_view(synth, P, TF, seed, dist, rotate=False)
+            e = G.frustum_elems(synth, seed, n, view, lines)
+            q = P.is_in_frustum(np.array([_view_record(P, view, nlv)], P.VIEW_DTYPE), [e], G.FRUSTUM_COS, lines=bool(lines), lib=lib)[0]
+            key = "%s_%d" % ("l" if lines else "p", seed)
+            assert _same((q["valid"], q["seg" if lines else "uv"], q["level"], q["viewcos"]),
+                         [g[key + s] for s in ("_valid", "_proj", "_level", "_vc")]), key
+
+
+def test_emu_frustum(plslam, oracle, synth, emu_lib):
+    _device(plslam, oracle, synth, emu_lib, [400, 0, 37, 1])
+
+
+@pytest.mark.gpu
+def test_gpu_frustum(plslam, oracle, synth):
+    _device(plslam, oracle, synth, None, [5000, 0, 37, 1, 2048, 999])

@@ -733,6 +733,8 @@ def ref_frame_lib():
     R.ref_frame_grid_lines.argtypes = [V, V, V, I]
     R.ref_frame_features_in_area.argtypes = [V, F, F, F, I, I, V, I]
     R.ref_frame_features_in_area_for_line.argtypes = [V, F, F, F, F, F, F, V, I]
+    R.ref_frame_is_in_frustum_points.argtypes = [V, I, I, V, V, V, V, F, V, V, V, V]
+    R.ref_frame_is_in_frustum_lines.argtypes = [V, I, V, V, V, V, F, V, V, V, V]
     return R
 
 
@@ -789,6 +791,87 @@ def gen_framegrid(S, out):
         print("frame grid", seed, "points placed", int(cs[-1]), "line items", int(lcs[-1]), "point hits", len(pa), "line hits", len(la))
     np.savez_compressed(os.path.join(out, "ref_framegrid.npz"), **g)
 
+# ---- Frame::isInFrustum (points and lines) through the reference's Frame.cc / MapPoint.cc / MapLine.cpp (libframe_ref.so)
+FRUSTUM_CASES = [(1, 3000, False), (2, 500, True), (3, 1, False)]       # seed, map elements, distorted image bounds
+FRUSTUM_COS = 0.5
+
+
+def frustum_view(S, P, TF, seed, distorted, rotate):
+    """plh_frame_view fields as the flat float[24] the oracle takes (+ nlevels).  rotate=False: Rcw = I (what the reference
+    harness can be driven with), any translation."""
+    rng = S.SplitMix64(seed + 500)
+    R = np.eye(3)
+    if rotate:
+        ax, ay, az = rng.uniform(3, -0.4, 0.4)
+        cx_, sx_, cy_, sy_, cz_, sz_ = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+        R = (np.array([[cz_, -sz_, 0], [sz_, cz_, 0], [0, 0, 1]]) @ np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]]) @
+             np.array([[1, 0, 0], [0, cx_, -sx_], [0, sx_, cx_]]))
+    R = R.astype(np.float32)
+    t = rng.uniform(3, -0.5, 0.5).astype(np.float32)
+    Ow = (-(R.T.astype(np.float64) @ t.astype(np.float64))).astype(np.float32) if rotate else (-t).astype(np.float32)
+    gp = P._gp_array(TF._gp(P, distorted=distorted))
+    view = np.concatenate([R.reshape(9), t, Ow, POSE_K, gp[:4], [np.float32(np.log(np.float32(1.2)))]]).astype(np.float32)
+    return view, 8
+
+
+def frustum_elems(S, seed, n, view, lines):
+    """World positions scattered around the viewing cone: most in front, some behind / outside / too far / seen edge-on."""
+    rng = S.SplitMix64(seed + (900 if lines else 700))
+    K = POSE_K
+    R, t = view[:9].reshape(3, 3).astype(np.float64), view[9:12].astype(np.float64)
+
+    def world(u, v, z):
+        pc = np.stack([(u - K[2]) / K[0] * z, (v - K[3]) / K[1] * z, z], 1)
+        return ((pc - t) @ R).astype(np.float32)          # R^T (pc - t)
+    u, v = rng.uniform(n, -80, 720), rng.uniform(n, -60, 540)
+    z = rng.uniform(n, 0.5, 8.0)
+    z[rng.uniform(n) < 0.05] *= -1
+    pos = world(u, v, z)
+    if lines:
+        u2, v2 = u + rng.uniform(n, -90, 90), v + rng.uniform(n, -90, 90)
+        z2 = z + rng.uniform(n, -0.4, 0.4)
+        pos = np.ascontiguousarray(np.concatenate([pos, world(u2, v2, z2)], 1))
+        mid = 0.5 * (pos[:, :3] + pos[:, 3:])
+    else:
+        mid = pos
+    Ow = view[12:15]
+    d = np.linalg.norm(mid - Ow, axis=1)
+    nrm = (mid - Ow) / np.maximum(d, 1e-6)[:, None]
+    nrm = nrm + rng.uniform(n * 3, -0.9, 0.9).reshape(n, 3)            # tilt the mean viewing direction, some beyond 60 deg
+    nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1), 1e-6)[:, None]).astype(np.float32)
+    lvl = rng.randint(n, 0, 8)
+    maxd = (d * (1.2 ** lvl) * rng.uniform(n, 0.7, 1.5)).astype(np.float32)       # mfMaxDistance = dist * scale[level] at creation
+    mind = (maxd / np.float32(1.2 ** 7)).astype(np.float32)
+    return dict(pos=np.ascontiguousarray(pos), normal=np.ascontiguousarray(nrm), min_dist=mind, max_dist=maxd)
+
+
+def reference_frustum(R, view, nlevels, e, lines):
+    n = len(e["min_dist"])
+    valid, proj = np.zeros(max(n, 1), np.uint8), np.zeros((max(n, 1), 4 if lines else 2), np.float32)
+    level, vc = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32)
+    if lines:
+        R.ref_frame_is_in_frustum_lines(p(view), n, p(e["pos"]), p(e["normal"]), p(e["min_dist"]), p(e["max_dist"]), FRUSTUM_COS, p(valid),
+                                        p(proj), p(level), p(vc))
+    else:
+        R.ref_frame_is_in_frustum_points(p(view), nlevels, n, p(e["pos"]), p(e["normal"]), p(e["min_dist"]), p(e["max_dist"]), FRUSTUM_COS,
+                                         p(valid), p(proj), p(level), p(vc))
+    return valid[:n], proj[:n], level[:n], vc[:n]
+
+
+def gen_frustum(S, out):
+    R, P = ref_frame_lib(), _util.plslam()
+    TF = _test_module("test_frame_search")
+    g = {}
+    for seed, n, dist in FRUSTUM_CASES:
+        view, nlv = frustum_view(S, P, TF, seed, dist, rotate=False)
+        for lines in (0, 1):
+            e = frustum_elems(S, seed, n, view, lines)
+            valid, proj, level, vc = reference_frustum(R, view, nlv, e, lines)
+            key = "%s_%d" % ("l" if lines else "p", seed)
+            g[key + "_valid"], g[key + "_proj"], g[key + "_level"], g[key + "_vc"] = valid, proj, level, vc
+            print("frustum", key, "in view", int(valid.sum()), "of", n)
+    np.savez_compressed(os.path.join(out, "ref_frustum.npz"), **g)
+
 def main():
     S = _util.synth()
     VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
@@ -812,6 +895,7 @@ def main():
     gen_lsdmatcher(S, out)
     gen_distinctive(S, out)
     gen_framegrid(S, out)
+    gen_frustum(S, out)
 
 
 if __name__ == "__main__":
