@@ -623,32 +623,52 @@ extern "C" int plo_orb_search_by_sim3(const plo_keypoint* kps1, const uint8_t* d
 // |cos| of the direction angle >= TH = 0.998).  Reference quirk kept: the candidate rows are read from
 // pKF->mDescriptors (the ORB matrix, :963) with the LINE index -- `cand_desc` is whatever matrix the caller passes there.
 // best_idx[q] = line index or -1; returns the number of queries with a result.
+// KeyFrame::GetLinesInArea (reference src/KeyFrame.cc:647-683): brute force over the KeyFrame's lines -- squared distance
+// between the query's midpoint and the line's midpoint (kl.pt) <= r^2, |cos| of the angle between the directions >= TH.
+static void keyframe_lines_in_area(const plo_keyline* kl, int nl, float x1, float y1, float x2, float y2, float r, float TH,
+                                   std::vector<int>& out) {
+  out.clear();
+  float delta1x = x1 - x2, delta1y = y1 - y2;
+  const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
+  delta1x /= norm_delta1;
+  delta1y /= norm_delta1;
+  for (int j = 0; j < nl; j++) {
+    const plo_keyline& k = kl[j];
+    const float distance = (float)((0.5 * (x1 + x2) - k.pt_x) * (0.5 * (x1 + x2) - k.pt_x) +
+                                   (0.5 * (y1 + y2) - k.pt_y) * (0.5 * (y1 + y2) - k.pt_y));
+    if (distance > r * r) continue;
+    float delta2x = k.startPointX - k.endPointX, delta2y = k.startPointY - k.endPointY;
+    const float norm_delta2 = sqrtf(delta2x * delta2x + delta2y * delta2y);
+    delta2x /= norm_delta2;
+    delta2y /= norm_delta2;
+    const float CosSita = fabsf(delta1x * delta2x + delta1y * delta2y);
+    if (CosSita < TH) continue;
+    out.push_back(j);
+  }
+}
+extern "C" int plo_keyframe_lines_in_area(const plo_keyline* kl, int nl, float x1, float y1, float x2, float y2, float r, float TH,
+                                          int32_t* out, int cap) {
+  std::vector<int> v;
+  keyframe_lines_in_area(kl, nl, x1, y1, x2, y2, r, TH, v);
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+  return (int)v.size();
+}
+
 extern "C" int plo_line_fuse_search(const plo_keyline* kl, const uint8_t* cand_desc, int nl, const float* scale_factors_line, int nq,
                                     const uint8_t* q_valid, const float* q_seg, const int32_t* q_level, const uint8_t* q_desc,
                                     float th, float TH, int th_low, int32_t* best_idx) {
   int nfound = 0;
+  std::vector<int> vIndices;
   for (int i = 0; i < nq; i++) {
     best_idx[i] = -1;
     if (!q_valid[i]) continue;
     const float x1 = q_seg[i * 4], y1 = q_seg[i * 4 + 1], x2 = q_seg[i * 4 + 2], y2 = q_seg[i * 4 + 3];
     const int nPredictedLevel = q_level[i];
     const float r = th * scale_factors_line[nPredictedLevel];
-    float delta1x = x1 - x2, delta1y = y1 - y2;
-    const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
-    delta1x /= norm_delta1;
-    delta1y /= norm_delta1;
+    keyframe_lines_in_area(kl, nl, x1, y1, x2, y2, r, TH, vIndices);
     int bestDist = 256, bestIdx = -1;
-    for (int j = 0; j < nl; j++) {
+    for (int j : vIndices) {
       const plo_keyline& k = kl[j];
-      const float distance = (float)((0.5 * (x1 + x2) - k.pt_x) * (0.5 * (x1 + x2) - k.pt_x) +
-                                     (0.5 * (y1 + y2) - k.pt_y) * (0.5 * (y1 + y2) - k.pt_y));
-      if (distance > r * r) continue;
-      float delta2x = k.startPointX - k.endPointX, delta2y = k.startPointY - k.endPointY;
-      const float norm_delta2 = sqrtf(delta2x * delta2x + delta2y * delta2y);
-      delta2x /= norm_delta2;
-      delta2y /= norm_delta2;
-      const float CosSita = fabsf(delta1x * delta2x + delta1y * delta2y);
-      if (CosSita < TH) continue;
       if (k.octave < nPredictedLevel - 1 || k.octave > nPredictedLevel) continue;
       const int dist = plo_descriptor_distance(q_desc + (size_t)i * 32, cand_desc + (size_t)j * 32);
       if (dist < bestDist) { bestDist = dist; bestIdx = j; }

@@ -29,14 +29,15 @@
  *   - src/MapPoint.cc, src/MapLine.cpp with their own headers: ComputeDistinctiveDescriptors picks the same observation
  *     as plo_distinctive_descriptor (tests/test_ref_mapobj.py);
  *   - src/Frame.cc with its own header: AssignFeaturesToGrid[ForLine], GetFeaturesInArea, GetFeaturesInAreaForLine return
- *     the same cells and the same candidates in the same order as frame_search.cc (tests/test_ref_frame.py);
+ *     the same cells and the same candidates in the same order as frame_search.cc; so do KeyFrame::GetFeaturesInArea /
+ *     GetLinesInArea of a real KeyFrame (src/KeyFrame.cc) built from that Frame (tests/test_ref_frame.py);
  *     Frame::isInFrustum (points and lines, with the real MapPoint / MapLine::PredictScale) for poses without rotation
  *     (tests/test_frustum.py); with a rotation the gemm rounding is this oracle's definition (unpinned);
  *   - src/lineIterator.cpp: the line grid of frame_search.cc (tests/test_ref_linegrid.py).
  * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
  * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE
- * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); KeyFrame::GetLinesInArea and
- * Frame::UndistortKeyPoints (cv::undistortPoints underneath) are restatements that nothing executable stands behind.
+ * definition wherever the reference is ambiguous (SURVEY.md 8c "pinned definitions"); Frame::UndistortKeyPoints
+ * (cv::undistortPoints underneath) is a restatement that nothing executable stands behind.
  *
  * Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off: no FMA contraction, IEEE float32).
  */
@@ -168,6 +169,8 @@ int  plo_distinctive_descriptor(const uint8_t* desc, int n);
 int  plo_orb_search_by_bow_kfkf(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
                                 const uint8_t* desc2, const float* angle2, const int32_t* node2, const uint8_t* valid2, int n2,
                                 int th_low, float nnratio, int check_ori, int32_t* matches12);
+int  plo_keyframe_lines_in_area(const plo_keyline* kl, int nl, float x1, float y1, float x2, float y2, float r, float TH,
+                                int32_t* out, int cap);                  /* KeyFrame::GetLinesInArea, src/KeyFrame.cc:647-683 */
 int  plo_line_fuse_search(const plo_keyline* kl, const uint8_t* cand_desc, int nl, const float* scale_factors_line, int nq,
                           const uint8_t* q_valid, const float* q_seg, const int32_t* q_level, const uint8_t* q_desc, float th,
                           float TH, int th_low, int32_t* best_idx);           /* search inside LSDmatcher::Fuse, :860-1002 */

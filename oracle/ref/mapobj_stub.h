@@ -30,6 +30,7 @@ class Map {
   std::mutex mMutexPointCreation, mMutexLineCreation;
   void EraseMapPoint(MapPoint*) {}
   void EraseMapLine(MapLine*) {}
+  void EraseKeyFrame(class KeyFrame*) {}
 };
 
 #ifdef PLO_REAL_FRAME   // the Frame.cc build uses the reference's own include/Frame.h
@@ -48,6 +49,13 @@ class Frame {
 };
 #endif
 
+#ifdef PLO_REAL_KEYFRAME   // the KeyFrame.cc build uses the reference's own include/KeyFrame.h
+class KeyFrame;
+class KeyFrameDatabase {   // include/KeyFrameDatabase.h (skipped through its include guard)
+ public:
+  void erase(KeyFrame*) {}
+};
+#else
 class KeyFrame {
  public:
   long unsigned int mnId = 0, mnFrameId = 0;
@@ -67,6 +75,7 @@ class KeyFrame {
   void EraseMapLineMatch(MapLine*) {}
   void ReplaceMapLineMatch(const size_t&, MapLine*) {}
 };
+#endif
 
 }  // namespace ORB_SLAM2
 #endif

@@ -1,6 +1,6 @@
 // oracle/_ref: the reference's own include/Frame.h + src/Frame.cc, compiled as they are (oracle/ref/build_ref.sh) with the
-// real MapPoint / MapLine / ORBextractor / LINEextractor / DBoW2 / lineIterator sources around them and stand-ins for
-// KeyFrame / Map / Converter only.  The harness fills a default-constructed Frame from flat arrays and calls the spatial
+// real KeyFrame (include/KeyFrame.h + src/KeyFrame.cc) / MapPoint / MapLine / ORBextractor / LINEextractor / DBoW2 /
+// lineIterator sources around them and stand-ins for Map / KeyFrameDatabase / Converter only.  The harness fills a default-constructed Frame from flat arrays and calls the spatial
 // index the windowed searches stand on:
 //   Frame::AssignFeaturesToGrid (+ PosInGrid)        src/Frame.cc:278-293, 893-904
 //   Frame::AssignFeaturesToGridForLine               :296-320  (with the real src/lineIterator.cpp)
@@ -9,6 +9,7 @@
 //   Frame::isInFrustum(MapPoint*, cos) / (MapLine*, cos)   :560-623, 625-711  (+ the real MapPoint / MapLine::PredictScale),
 //     driven with poses that have no rotation (mRcw = I, any translation), for which the stand-in's float algebra and
 //     OpenCV's gemm give the same floats
+//   KeyFrame::GetFeaturesInArea / GetLinesInArea      src/KeyFrame.cc:606-645, 647-683 (a real KeyFrame built from the Frame)
 // Not reachable without OpenCV proper: the constructors (remap, extractor threads), UndistortKeyPoints (cv::undistortPoints),
 // the stereo code.  TEST INFRASTRUCTURE ONLY.
 #include <cstdint>
@@ -31,6 +32,19 @@ int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return 
 }  // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;
+
+namespace {
+// A real KeyFrame needs a Frame to be built from (its constructor copies the grids and ends with SetPose(F.mTcw)).
+KeyFrame* make_keyframe(Frame& f, Map& map, KeyFrameDatabase& db) {
+  if (f.mTcw.empty()) f.mTcw = cv::Mat::eye(4, 4, CV_32F);
+  return new KeyFrame(f, &map, &db);
+}
+struct RefKF {   // owner of the keyframe handed to MapPoint / MapLine constructors
+  Frame f; Map map; KeyFrameDatabase db; KeyFrame* kf;
+  RefKF() : kf(make_keyframe(f, map, db)) {}
+  ~RefKF() { delete kf; }
+};
+}  // namespace
 
 extern "C" {
 
@@ -86,8 +100,9 @@ void ref_frame_is_in_frustum_points(const float view[24], int nlevels, int n, co
                                     const float* min_dist, const float* max_dist, float cos_limit, uint8_t* valid, float* uv,
                                     int32_t* level, float* viewcos) {
   Frame f;
-  Map map;
-  KeyFrame kf;
+  RefKF owner;
+  Map& map = owner.map;
+  KeyFrame& kf = *owner.kf;
   cv::Mat T = cv::Mat::zeros(4, 4, CV_32F);
   for (int i = 0; i < 3; i++) {
     for (int j = 0; j < 3; j++) T.at<float>(i, j) = view[i * 3 + j];
@@ -120,8 +135,9 @@ void ref_frame_is_in_frustum_lines(const float view[24], int n, const float* pos
                                    const float* max_dist, float cos_limit, uint8_t* valid, float* seg, int32_t* level,
                                    float* viewcos) {
   Frame f;
-  Map map;
-  KeyFrame kf;
+  RefKF owner;
+  Map& map = owner.map;
+  KeyFrame& kf = *owner.kf;
   cv::Mat T = cv::Mat::zeros(4, 4, CV_32F);
   for (int i = 0; i < 3; i++) {
     for (int j = 0; j < 3; j++) T.at<float>(i, j) = view[i * 3 + j];
@@ -146,6 +162,26 @@ void ref_frame_is_in_frustum_lines(const float view[24], int n, const float* pos
     level[i] = ok ? ml.mnTrackScaleLevel : 0;
     viewcos[i] = ok ? ml.mTrackViewCos : 0.f;
   }
+}
+
+
+// KeyFrame::GetFeaturesInArea / GetLinesInArea on a real KeyFrame constructed from the Frame behind the handle (the
+// constructor copies F's grids and converts the float image bounds to its `const int` members).
+int ref_keyframe_features_in_area(void* h, float x, float y, float r, int32_t* out, int cap) {
+  Map map; KeyFrameDatabase db;
+  KeyFrame* kf = make_keyframe(*(Frame*)h, map, db);
+  const std::vector<size_t> v = kf->GetFeaturesInArea(x, y, r);
+  delete kf;
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
+  return (int)v.size();
+}
+int ref_keyframe_lines_in_area(void* h, float x1, float y1, float x2, float y2, float r, float TH, int32_t* out, int cap) {
+  Map map; KeyFrameDatabase db;
+  KeyFrame* kf = make_keyframe(*(Frame*)h, map, db);
+  const std::vector<size_t> v = kf->GetLinesInArea(x1, y1, x2, y2, r, TH);
+  delete kf;
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
+  return (int)v.size();
 }
 
 }  // extern "C"

@@ -211,6 +211,12 @@ class Mat {
   // compile-only members (stereo / triangulation code of Frame.cc that the harnesses never reach)
   Mat reshape(int, int = 0) const { std::cerr << "oracle/ref stub: Mat::reshape is compile-only" << std::endl; std::abort(); }
   void convertTo(Mat&, int) const { std::cerr << "oracle/ref stub: Mat::convertTo is compile-only" << std::endl; std::abort(); }
+  static Mat eye(int r, int c, int type) {
+    Mat m = Mat::zeros(r, c, type);
+    assert(type == CV_32F);
+    for (int i = 0; i < (r < c ? r : c); i++) m.at<float>(i, i) = 1.f;
+    return m;
+  }
   static Mat ones(int, int, int) { std::cerr << "oracle/ref stub: Mat::ones is compile-only" << std::endl; std::abort(); }
   Mat inv(int = 0) const { std::cerr << "oracle/ref stub: Mat::inv is compile-only" << std::endl; std::abort(); }
   Mat cross(const Mat& o) const {
@@ -305,10 +311,22 @@ class _OutputArray : public _InputArray {
   void create(int r, int c, int type) const { m_->create(r, c, type); }
   void release() const { m_->release(); }
   void assign(const Mat& m) const { *m_ = m; }
+  // OpenCV's copyTo: create() is a no-op for a destination of the right size and type, so the data lands in the existing
+  // storage (this is what makes `a.copyTo(b.rowRange(..))` fill a block of b)
+  void copy_from(const Mat& src) const;
 };
 typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
-inline void Mat::copyTo(const _OutputArray& o) const { Mat c = clone(); o.assign(c); }
+inline void _OutputArray::copy_from(const Mat& src) const {
+  Mat& d = *m_;
+  if (d.data && src.data && d.data != src.data && d.rows == src.rows && d.cols == src.cols && d.type() == src.type()) {
+    const size_t row_bytes = (size_t)src.cols * (src.type() == CV_8U || src.type() == CV_8S ? 1 : src.type() == CV_16S ? 2 : src.type() == CV_64F ? 8 : src.type() == CV_8UC3 ? 3 : 4);
+    for (int r = 0; r < src.rows; r++) std::memcpy(d.data + (size_t)r * d.step.p, src.data + (size_t)r * src.step.p, row_bytes);
+  } else if (d.data != src.data || !d.data) {
+    d = src.clone();
+  }
+}
+inline void Mat::copyTo(const _OutputArray& o) const { o.copy_from(*this); }
 [[noreturn]] inline void stub_unreachable(const char* what) { std::cerr << "oracle/ref stub: " << what << " is compile-only" << std::endl; std::abort(); }
 // Small dense float algebra (the pose arithmetic of ORBmatcher.cc).  Plain float accumulation in index order; OpenCV's
 // gemm may round differently, so nothing computed through these is claimed to be pinned.

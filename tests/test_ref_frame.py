@@ -5,6 +5,10 @@ Converter only.  The harness (oracle/ref/ref_frame.cc) fills a default-construct
 
     Frame::AssignFeaturesToGrid (+ PosInGrid)     Frame::AssignFeaturesToGridForLine (with the real LineIterator)
     Frame::GetFeaturesInArea                      Frame::GetFeaturesInAreaForLine
+    KeyFrame::GetFeaturesInArea                   KeyFrame::GetLinesInArea      (src/KeyFrame.cc, a real KeyFrame built from
+                                                  the Frame: its image bounds are `const int`, i.e. truncated -- the
+                                                  lookup still returns what the Frame-style lookup without level filter
+                                                  returns, which is how the Fuse / Sim3 kernels generate candidates)
 
 Pinned: which cell a keypoint lands in (round, not floor), every cell a line crosses, the cell ranges a window covers, the
 level filter, the order in which candidates come back (cell-major, insertion order inside a cell; the line lookup's
@@ -41,6 +45,8 @@ def _oracle_all(O, P, TF, f2, gp, pq, lv, seg, lr, lth):
     L.plo_features_in_area.restype = I
     L.plo_features_in_area_for_line.argtypes = [V, V, I, V, V, V, F, F, F, F, F, F, V, I]
     L.plo_features_in_area_for_line.restype = I
+    L.plo_keyframe_lines_in_area.argtypes = [V, I, F, F, F, F, F, F, V, I]
+    L.plo_keyframe_lines_in_area.restype = I
     g = TF._gpa(P, gp)
     (cs, ci), (lcs, lci) = TF._oracle_grids(O, P, f2, gp)
     n, nl = len(f2["kps"]), len(f2["keylines"])
@@ -54,7 +60,15 @@ def _oracle_all(O, P, TF, f2, gp, pq, lv, seg, lr, lth):
                                             float(seg[q, 1]), float(seg[q, 2]), float(seg[q, 3]), float(lr[q]), float(lth[q]), O._p(buf),
                                             len(buf))
         la.append(buf[:k].copy())
-    return cs, ci, lcs, lci, pa, la
+    ka, kla = [], []   # KeyFrame::GetFeaturesInArea = the Frame lookup without level filter; KeyFrame::GetLinesInArea = brute force
+    for q in range(len(pq)):
+        k = L.plo_features_in_area(O._p(f2["kps"]), O._p(g), O._p(cs), O._p(ci), float(pq[q, 0]), float(pq[q, 1]), float(pq[q, 2]), -1, -1,
+                                   O._p(buf), len(buf))
+        ka.append(buf[:k].copy())
+        k = L.plo_keyframe_lines_in_area(O._p(f2["keylines"]), nl, float(seg[q, 0]), float(seg[q, 1]), float(seg[q, 2]), float(seg[q, 3]),
+                                         float(lr[q]) * 4, float(lth[q]), O._p(buf), len(buf))
+        kla.append(buf[:k].copy())
+    return cs, ci, lcs, lci, pa, la, ka, kla
 
 
 def _same_lists(got, flat, offs):
@@ -72,7 +86,9 @@ def test_oracle_reproduces_reference_frame_index(oracle, plslam, synth):
     g = np.load(GOLDEN)
     for seed, n, nl, dist in G.FRAMEGRID_CASES:
         f2, gp, pq, lv, seg, lr, lth = G.framegrid_inputs(synth, plslam, TF, seed, n, nl, dist)
-        cs, ci, lcs, lci, pa, la = _oracle_all(oracle, plslam, TF, f2, gp, pq, lv, seg, lr, lth)
+        cs, ci, lcs, lci, pa, la, ka, kla = _oracle_all(oracle, plslam, TF, f2, gp, pq, lv, seg, lr, lth)
+        assert _same_lists(ka, g["ka_%d" % seed], g["ko_%d" % seed]), "KeyFrame::GetFeaturesInArea %d" % seed
+        assert _same_lists(kla, g["kla_%d" % seed], g["klo_%d" % seed]), "KeyFrame::GetLinesInArea %d" % seed
         assert (cs == g["cs_%d" % seed]).all() and (ci[:cs[-1]] == g["ci_%d" % seed][:cs[-1]]).all(), "AssignFeaturesToGrid %d" % seed
         assert (lcs == g["lcs_%d" % seed]).all() and (lci[:lcs[-1]] == g["lci_%d" % seed]).all(), "AssignFeaturesToGridForLine %d" % seed
         assert _same_lists(pa, g["pa_%d" % seed], g["po_%d" % seed]), "GetFeaturesInArea %d" % seed
@@ -107,7 +123,8 @@ def test_reference_frame_index_live(oracle, plslam, synth):
     R = G.ref_frame_lib()
     for seed, n, nl, dist in [(11, 1500, 150, True), (12, 64, 9, False), (13, 0, 0, False)]:
         f2, gp, pq, lv, seg, lr, lth = G.framegrid_inputs(synth, plslam, TF, seed, n, nl, dist)
-        rcs, rci, rlcs, rlci, (rpa, rpo), (rla, rlo) = G.reference_framegrid(R, plslam, f2, gp, pq, lv, seg, lr, lth)
-        cs, ci, lcs, lci, pa, la = _oracle_all(oracle, plslam, TF, f2, gp, pq, lv, seg, lr, lth)
+        rcs, rci, rlcs, rlci, (rpa, rpo), (rla, rlo), (rka, rko), (rkla, rklo) = G.reference_framegrid(R, plslam, f2, gp, pq, lv, seg, lr, lth)
+        cs, ci, lcs, lci, pa, la, ka, kla = _oracle_all(oracle, plslam, TF, f2, gp, pq, lv, seg, lr, lth)
+        assert _same_lists(ka, rka, rko) and _same_lists(kla, rkla, rklo), "live keyframe lookups %d" % seed
         assert (cs == rcs).all() and (ci[:cs[-1]] == rci[:cs[-1]]).all() and (lcs == rlcs).all() and (lci[:lcs[-1]] == rlci[:lcs[-1]]).all()
         assert _same_lists(pa, rpa, rpo) and _same_lists(la, rla, rlo), "live lookups %d" % seed

@@ -733,6 +733,8 @@ def ref_frame_lib():
     R.ref_frame_grid_lines.argtypes = [V, V, V, I]
     R.ref_frame_features_in_area.argtypes = [V, F, F, F, I, I, V, I]
     R.ref_frame_features_in_area_for_line.argtypes = [V, F, F, F, F, F, F, V, I]
+    R.ref_keyframe_features_in_area.argtypes = [V, F, F, F, V, I]
+    R.ref_keyframe_lines_in_area.argtypes = [V, F, F, F, F, F, F, V, I]
     R.ref_frame_is_in_frustum_points.argtypes = [V, I, I, V, V, V, V, F, V, V, V, V]
     R.ref_frame_is_in_frustum_lines.argtypes = [V, I, V, V, V, V, F, V, V, V, V]
     return R
@@ -773,10 +775,17 @@ def reference_framegrid(R, P, f2, gp, pq, lv, seg, lr, lth):
         k = R.ref_frame_features_in_area_for_line(h, float(seg[q, 0]), float(seg[q, 1]), float(seg[q, 2]), float(seg[q, 3]), float(lr[q]),
                                                   float(lth[q]), p(buf), len(buf))
         la.append(buf[:k].copy())
+    ka, kla = [], []          # the same windows through a real KeyFrame built from this Frame (no level filter; brute-force lines)
+    for q in range(len(pq)):
+        k = R.ref_keyframe_features_in_area(h, float(pq[q, 0]), float(pq[q, 1]), float(pq[q, 2]), p(buf), len(buf))
+        ka.append(buf[:k].copy())
+        k = R.ref_keyframe_lines_in_area(h, float(seg[q, 0]), float(seg[q, 1]), float(seg[q, 2]), float(seg[q, 3]), float(lr[q]) * 4,
+                                         float(lth[q]), p(buf), len(buf))
+        kla.append(buf[:k].copy())
     R.ref_frame_destroy(h)
     flat = lambda v: (np.concatenate(v).astype(np.int32) if sum(len(a) for a in v) else np.zeros(0, np.int32),
                       np.cumsum([0] + [len(a) for a in v]).astype(np.int32))
-    return cs, ci, lcs, lci, flat(pa), flat(la)
+    return cs, ci, lcs, lci, flat(pa), flat(la), flat(ka), flat(kla)
 
 
 def gen_framegrid(S, out):
@@ -785,10 +794,11 @@ def gen_framegrid(S, out):
     g = {}
     for seed, n, nl, dist in FRAMEGRID_CASES:
         f2, gp, pq, lv, seg, lr, lth = framegrid_inputs(S, P, TF, seed, n, nl, dist)
-        cs, ci, lcs, lci, (pa, po), (la, lo) = reference_framegrid(R, P, f2, gp, pq, lv, seg, lr, lth)
-        for k, v in (("cs", cs), ("ci", ci), ("lcs", lcs), ("lci", lci[:lcs[-1]]), ("pa", pa), ("po", po), ("la", la), ("lo", lo)):
+        cs, ci, lcs, lci, (pa, po), (la, lo), (ka, ko), (kla, klo) = reference_framegrid(R, P, f2, gp, pq, lv, seg, lr, lth)
+        for k, v in (("cs", cs), ("ci", ci), ("lcs", lcs), ("lci", lci[:lcs[-1]]), ("pa", pa), ("po", po), ("la", la), ("lo", lo),
+                     ("ka", ka), ("ko", ko), ("kla", kla), ("klo", klo)):
             g["%s_%d" % (k, seed)] = v
-        print("frame grid", seed, "points placed", int(cs[-1]), "line items", int(lcs[-1]), "point hits", len(pa), "line hits", len(la))
+        print("frame grid", seed, "points placed", int(cs[-1]), "line items", int(lcs[-1]), "point hits", len(pa), "line hits", len(la), "keyframe point / line hits", len(ka), len(kla))
     np.savez_compressed(os.path.join(out, "ref_framegrid.npz"), **g)
 
 # ---- Frame::isInFrustum (points and lines) through the reference's Frame.cc / MapPoint.cc / MapLine.cpp (libframe_ref.so)
