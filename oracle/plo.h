@@ -33,6 +33,8 @@
  *     GetLinesInArea of a real KeyFrame (src/KeyFrame.cc) built from that Frame (tests/test_ref_frame.py);
  *     Frame::isInFrustum (points and lines, with the real MapPoint / MapLine::PredictScale) for poses without rotation
  *     (tests/test_frustum.py); with a rotation the gemm rounding is this oracle's definition (unpinned);
+ *     and Tracking's local-map search on real Frame / MapPoint / MapLine objects (isInFrustum -> SearchByProjection) assigns
+ *     the same map elements as the chain of this oracle's functions (tests/test_ref_track.py);
  *   - src/lineIterator.cpp: the line grid of frame_search.cc (tests/test_ref_linegrid.py).
  * PARITY UNPINNED for the rest: the OpenCV primitives themselves (resize, GaussianBlur, FAST, fastAtan2, Sobel, remap,
  * LineSegmentDetector, LineIterator, BFMatcher) are restated from the published OpenCV 3.2-3.4.0 algorithms and are THE

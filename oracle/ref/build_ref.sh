@@ -56,7 +56,8 @@ echo "built $OUT/libmapobj_ref.so"
 for f in lsd; do g++ -O2 -std=c++14 -fPIC -c -w -ffp-contract=off -fno-fast-math -o "$OUT/plo_$f.o" "$HERE/../$f.cc"; done
 g++ -O2 -std=c++14 -fPIC -shared -w -pthread -ffp-contract=off -fno-fast-math -DPLO_REAL_FRAME -DPLO_REAL_KEYFRAME -DMAP_H -DCONVERTER_H \
   -DLOCALMAPPING_H -DKEYFRAMEDATABASE_H -I "$HERE/stub" -I "$HERE/stub/eigen3" -I "$LD/include" -I "$REF/include" -I "$REF" -include "$HERE/frame_stub.h" \
-  -o "$OUT/libframe_ref.so" "$HERE/ref_frame.cc" "$REF/src/Frame.cc" "$REF/src/KeyFrame.cc" "$REF/src/MapPoint.cc" "$REF/src/MapLine.cpp" \
+  -o "$OUT/libframe_ref.so" "$HERE/ref_frame.cc" "$REF/src/Frame.cc" "$REF/src/KeyFrame.cc" "$REF/src/ORBmatcher.cc" \
+  "$REF/src/LSDmatcher.cpp" "$REF/src/MapPoint.cc" "$REF/src/MapLine.cpp" \
   "$REF/src/lineIterator.cpp" "$REF/src/ORBextractor.cc" "$REF/src/LineExtractor.cpp" "$LD/src/LSDDetector_custom.cpp" \
   "$LD/src/binary_descriptor_custom.cpp" "$D/DBoW2/FORB.cpp" "$D/DBoW2/BowVector.cpp" "$D/DBoW2/FeatureVector.cpp" \
   "$D/DBoW2/ScoringObject.cpp" "$D/DUtils/Random.cpp" "$D/DUtils/Timestamp.cpp" $PLO_OBJS "$OUT/plo_lsd.o"

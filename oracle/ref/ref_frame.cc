@@ -10,10 +10,14 @@
 //     driven with poses that have no rotation (mRcw = I, any translation), for which the stand-in's float algebra and
 //     OpenCV's gemm give the same floats
 //   KeyFrame::GetFeaturesInArea / GetLinesInArea      src/KeyFrame.cc:606-645, 647-683 (a real KeyFrame built from the Frame)
+//   Tracking::SearchLocalPoints / SearchLocalLines' core (src/Tracking.cc:1772-1800, 1825-1849): isInFrustum over a local map
+//     of real MapPoint / MapLine objects, then the real ORBmatcher / LSDmatcher::SearchByProjection(F, map elements, th) --
+//     src/ORBmatcher.cc and src/LSDmatcher.cpp compiled against the REAL Frame / KeyFrame / MapPoint / MapLine here
 // Not reachable without OpenCV proper: the constructors (remap, extractor threads), UndistortKeyPoints (cv::undistortPoints),
 // the stereo code.  TEST INFRASTRUCTURE ONLY.
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #define private public   // AssignFeaturesToGrid / AssignFeaturesToGridForLine are private members
@@ -22,14 +26,8 @@
 #undef private
 #undef protected
 #include "ORBmatcher.h"
+#include "LSDmatcher.h"
 
-namespace ORB_SLAM2 {
-// src/ORBmatcher.cc:37-39 (the stereo code of Frame.cc refers to them; src/ORBmatcher.cc itself needs the full KeyFrame)
-const int ORBmatcher::TH_HIGH = 100;
-const int ORBmatcher::TH_LOW = 50;
-const int ORBmatcher::HISTO_LENGTH = 30;
-int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return plo_descriptor_distance(a.ptr<uchar>(0), b.ptr<uchar>(0)); }
-}  // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;
 
@@ -182,6 +180,129 @@ int ref_keyframe_lines_in_area(void* h, float x1, float y1, float x2, float y2, 
   delete kf;
   for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
   return (int)v.size();
+}
+
+
+// ---- the local-map search of Tracking on real objects.  view[24] as in oracle/plo.h (no rotation).
+static void set_view(Frame& f, const float view[24], int nlevels, const float* scale_factors) {
+  cv::Mat T = cv::Mat::zeros(4, 4, CV_32F);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T.at<float>(i, j) = view[i * 3 + j];
+    T.at<float>(i, 3) = view[9 + i];
+  }
+  T.at<float>(3, 3) = 1.f;
+  f.SetPose(T);
+  Frame::fx = view[15]; Frame::fy = view[16]; Frame::cx = view[17]; Frame::cy = view[18];
+  f.mfLogScaleFactor = view[23];
+  f.mnScaleLevels = nlevels;
+  f.mbf = 0.f;
+  f.mvScaleFactors.assign(scale_factors, scale_factors + nlevels);
+}
+
+// Frame behind `h` = current frame (keypoints, grid); desc[n][32] its descriptors; occupied[idx] (in/out) = the frame already
+// holds a MapPoint with observations there.  Local map: npts real MapPoints (pos, normal, mfMin/MaxDistance, descriptor,
+// has observations).  Runs `if (isInFrustum(pMP, 0.5)) ...` over the map and ORBmatcher(0.8).SearchByProjection(F, map, th).
+// assigned[idx] = map point now stored at keypoint idx, or -1.  Returns nmatches.
+int ref_track_local_points(void* h, const uint8_t* desc, const float view[24], int nlevels, const float* scale_factors,
+                           uint8_t* occupied, int npts, const float* pos, const float* normal, const float* min_dist,
+                           const float* max_dist, const uint8_t* mp_desc, const uint8_t* hasobs, float th, int32_t* assigned) {
+  Frame& f = *(Frame*)h;
+  RefKF owner;
+  set_view(f, view, nlevels, scale_factors);
+  const int n = f.N;
+  f.mDescriptors = cv::Mat(n > 0 ? n : 1, 32, CV_8U);
+  if (n > 0) std::memcpy(f.mDescriptors.data, desc, (size_t)n * 32);
+  f.mvuRight.assign(n, -1.f);
+  std::vector<std::unique_ptr<MapPoint> > pts;
+  auto make = [&](const float* x) {
+    cv::Mat P(3, 1, CV_32F);
+    for (int k = 0; k < 3; k++) P.at<float>(k) = x[k];
+    pts.emplace_back(new MapPoint(P, owner.kf, &owner.map));
+    return pts.back().get();
+  };
+  const float zero[3] = {0, 0, 0};
+  f.mvpMapPoints.assign(n, nullptr);
+  for (int i = 0; i < n; i++)
+    if (occupied[i]) { MapPoint* p = make(zero); p->nObs = 1; f.mvpMapPoints[i] = p; }
+  std::vector<MapPoint*> before = f.mvpMapPoints, local(npts);
+  for (int i = 0; i < npts; i++) {
+    MapPoint* p = make(pos + 3 * i);
+    p->mNormalVector = cv::Mat(3, 1, CV_32F);
+    for (int k = 0; k < 3; k++) p->mNormalVector.at<float>(k) = normal[3 * i + k];
+    p->mfMinDistance = min_dist[i];
+    p->mfMaxDistance = max_dist[i];
+    p->mDescriptor = cv::Mat(1, 32, CV_8U);
+    std::memcpy(p->mDescriptor.data, mp_desc + (size_t)i * 32, 32);
+    p->nObs = hasobs[i] ? 1 : 0;
+    p->mnId = (unsigned long)i;
+    local[i] = p;
+  }
+  int nToMatch = 0;
+  for (MapPoint* p : local)
+    if (f.isInFrustum(p, 0.5)) { p->IncreaseVisible(); nToMatch++; }
+  int nm = 0;
+  if (nToMatch > 0) {
+    ORBmatcher matcher(0.8);
+    nm = matcher.SearchByProjection(f, local, th);
+  }
+  for (int i = 0; i < n; i++) {
+    MapPoint* p = f.mvpMapPoints[i];
+    assigned[i] = (p && p != before[i]) ? (int32_t)p->mnId : -1;
+    occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
+  }
+  f.mvpMapPoints.clear();
+  return nm;
+}
+
+// The line twin: LSDmatcher().SearchByProjection(F, local map lines, th) after isInFrustum(pML, 0.5).  ldesc[nl][32].
+int ref_track_local_lines(void* h, const uint8_t* ldesc, const float view[24], const float* scale_factors, int nlevels,
+                          uint8_t* occupied, int nml, const float* pos6, const float* normal, const float* min_dist,
+                          const float* max_dist, const uint8_t* ml_desc, const uint8_t* hasobs, float th, int32_t* assigned) {
+  Frame& f = *(Frame*)h;
+  RefKF owner;
+  set_view(f, view, nlevels, scale_factors);
+  const int nl = f.NL;
+  f.mLdesc = cv::Mat(nl > 0 ? nl : 1, 32, CV_8U);
+  if (nl > 0) std::memcpy(f.mLdesc.data, ldesc, (size_t)nl * 32);
+  std::vector<std::unique_ptr<MapLine> > mls;
+  auto make = [&](const float* x) {
+    Vector6d P;
+    for (int k = 0; k < 6; k++) P(k) = x[k];
+    mls.emplace_back(new MapLine(P, owner.kf, &owner.map));
+    return mls.back().get();
+  };
+  const float unit[6] = {0, 0, 1, 1, 0, 1};
+  f.mvpMapLines.assign(nl, nullptr);
+  f.mvbLineOutlier.assign(nl, false);
+  for (int i = 0; i < nl; i++)
+    if (occupied[i]) { MapLine* p = make(unit); p->nObs = 1; f.mvpMapLines[i] = p; }
+  std::vector<MapLine*> before = f.mvpMapLines, local(nml);
+  for (int i = 0; i < nml; i++) {
+    MapLine* p = make(pos6 + 6 * i);
+    for (int k = 0; k < 3; k++) p->mNormalVector(k) = normal[3 * i + k];
+    p->mfMinDistance = min_dist[i];
+    p->mfMaxDistance = max_dist[i];
+    p->mLDescriptor = cv::Mat(1, 32, CV_8U);
+    std::memcpy(p->mLDescriptor.data, ml_desc + (size_t)i * 32, 32);
+    p->nObs = hasobs[i] ? 1 : 0;
+    p->mnId = (unsigned long)i;
+    local[i] = p;
+  }
+  int nToMatch = 0;
+  for (MapLine* p : local)
+    if (f.isInFrustum(p, 0.5)) { p->IncreaseVisible(); nToMatch++; }
+  int nm = 0;
+  if (nToMatch > 0) {
+    LSDmatcher matcher;
+    nm = matcher.SearchByProjection(f, local, th);
+  }
+  for (int i = 0; i < nl; i++) {
+    MapLine* p = f.mvpMapLines[i];
+    assigned[i] = (p && p != before[i]) ? (int32_t)p->mnId : -1;
+    occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
+  }
+  f.mvpMapLines.clear();
+  return nm;
 }
 
 }  // extern "C"

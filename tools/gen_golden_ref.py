@@ -735,6 +735,8 @@ def ref_frame_lib():
     R.ref_frame_features_in_area_for_line.argtypes = [V, F, F, F, F, F, F, V, I]
     R.ref_keyframe_features_in_area.argtypes = [V, F, F, F, V, I]
     R.ref_keyframe_lines_in_area.argtypes = [V, F, F, F, F, F, F, V, I]
+    R.ref_track_local_points.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, V, F, V]
+    R.ref_track_local_lines.argtypes = [V, V, V, V, I, V, I, V, V, V, V, V, V, F, V]
     R.ref_frame_is_in_frustum_points.argtypes = [V, I, I, V, V, V, V, F, V, V, V, V]
     R.ref_frame_is_in_frustum_lines.argtypes = [V, I, V, V, V, V, F, V, V, V, V]
     return R
@@ -882,6 +884,75 @@ def gen_frustum(S, out):
             print("frustum", key, "in view", int(valid.sum()), "of", n)
     np.savez_compressed(os.path.join(out, "ref_frustum.npz"), **g)
 
+# ---- Tracking::SearchLocalPoints / SearchLocalLines on real objects: isInFrustum over a local map, then SearchByProjection
+TRACK_CASES = [(1, 2000, 201, False, 1.0), (2, 800, 120, True, 5.0), (3, 30, 4, False, 3.0)]   # seed, keypoints, lines, distorted, th
+
+
+def track_inputs(S, P, TF, seed, n, nl, distorted):
+    """Current frame = frame 2 of a synthetic pair; local map = frame 1's features lifted to world points / lines that
+    project near their counterparts (camera without rotation, translated), with descriptors, distance ranges that predict
+    the counterpart's octave, a few behind the camera / edge-on / out of range."""
+    f1, f2, _, _ = TF.make_frame_pair(P, S, seed, n, nl=nl)
+    view, nlv = frustum_view(S, P, TF, seed, distorted, rotate=False)
+    K, t, Ow = POSE_K, view[9:12].astype(np.float64), view[12:15]
+    rng = S.SplitMix64(seed + 1300)
+
+    def lift(u, v, z):
+        return (np.stack([(u - K[2]) / K[0] * z, (v - K[3]) / K[1] * z, z], 1) - t).astype(np.float32)
+
+    def ranges(mid, octave, m):
+        d = np.linalg.norm(mid - Ow, axis=1)
+        nrm = (mid - Ow) / np.maximum(d, 1e-6)[:, None] + rng.uniform(m * 3, -0.5, 0.5).reshape(m, 3)
+        nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1), 1e-6)[:, None]).astype(np.float32)
+        maxd = (d * np.float32(1.2) ** octave * 0.98).astype(np.float32)
+        maxd[rng.uniform(m) < 0.04] *= 0.3                      # out of the distance-invariance range
+        return np.ascontiguousarray(nrm), (maxd / np.float32(1.2 ** 7)).astype(np.float32), maxd
+    k = f1["kps"]
+    z = rng.uniform(n, 0.8, 6.0)
+    z[rng.uniform(n) < 0.04] *= -1
+    pos = lift(k["x"] + rng.uniform(n, -3, 3), k["y"] + rng.uniform(n, -3, 3), z)
+    nrm, mind, maxd = ranges(pos, k["octave"], n)
+    pts = dict(pos=np.ascontiguousarray(pos), normal=nrm, min_dist=mind, max_dist=maxd, desc=f1["desc"].copy(),
+               hasobs=(rng.uniform(n) < 0.9).astype(np.uint8))
+    kl = f1["keylines"]
+    z1 = rng.uniform(nl, 0.8, 6.0)
+    z1[rng.uniform(nl) < 0.04] *= -1
+    z2 = z1 + rng.uniform(nl, -0.2, 0.2)
+    j = rng.uniform(nl * 4, -2, 2).reshape(nl, 4)
+    lp = np.ascontiguousarray(np.concatenate([lift(kl["startPointX"] + j[:, 0], kl["startPointY"] + j[:, 1], z1),
+                                              lift(kl["endPointX"] + j[:, 2], kl["endPointY"] + j[:, 3], z2)], 1))
+    lnrm, lmind, lmaxd = ranges(0.5 * (lp[:, :3] + lp[:, 3:]), np.zeros(nl), nl)
+    lns = dict(pos=lp, normal=lnrm, min_dist=lmind, max_dist=lmaxd, desc=f1["ldesc"].copy(), hasobs=(rng.uniform(nl) < 0.9).astype(np.uint8))
+    occ_p = (S.SplitMix64(77 + seed).uniform(n) < 0.1).astype(np.uint8)
+    occ_l = (S.SplitMix64(88 + seed).uniform(len(f2["keylines"])) < 0.1).astype(np.uint8)
+    return f2, TF._gp(P, distorted=distorted), view, nlv, pts, lns, occ_p, occ_l
+
+
+def reference_track(R, P, TF, f2, gp, view, nlv, pts, lns, occ_p, occ_l, th):
+    n, nl, g = len(f2["kps"]), len(f2["keylines"]), P._gp_array(gp)
+    h = R.ref_frame_create(p(f2["kps"]), n, p(f2["keylines"]), p(f2["linefn"]), nl, p(g))
+    op, ap = occ_p.copy(), np.zeros(max(n, 1), np.int32)
+    cp = R.ref_track_local_points(h, p(f2["desc"]), p(view), nlv, p(TF.SCALE), p(op), len(pts["min_dist"]), p(pts["pos"]), p(pts["normal"]),
+                                  p(pts["min_dist"]), p(pts["max_dist"]), p(pts["desc"]), p(pts["hasobs"]), th, p(ap))
+    ol, al = occ_l.copy(), np.zeros(max(nl, 1), np.int32)
+    cl = R.ref_track_local_lines(h, p(f2["ldesc"]), p(view), p(TF.SCALE), nlv, p(ol), len(lns["min_dist"]), p(lns["pos"]), p(lns["normal"]),
+                                 p(lns["min_dist"]), p(lns["max_dist"]), p(lns["desc"]), p(lns["hasobs"]), th, p(al))
+    R.ref_frame_destroy(h)
+    return (cp, ap[:n], op), (cl, al[:nl], ol)
+
+
+def gen_track(S, out):
+    R, P = ref_frame_lib(), _util.plslam()
+    TF = _test_module("test_frame_search")
+    g = {}
+    for seed, n, nl, dist, th in TRACK_CASES:
+        f2, gp, view, nlv, pts, lns, occ_p, occ_l = track_inputs(S, P, TF, seed, n, nl, dist)
+        (cp, ap, op), (cl, al, ol) = reference_track(R, P, TF, f2, gp, view, nlv, pts, lns, occ_p, occ_l, th)
+        g["p_%d_n" % seed], g["p_%d_asg" % seed], g["p_%d_occ" % seed] = cp, ap, op
+        g["l_%d_n" % seed], g["l_%d_asg" % seed], g["l_%d_occ" % seed] = cl, al, ol
+        print("local map search", seed, "points matched", cp, "of", n, "lines matched", cl, "of", nl)
+    np.savez_compressed(os.path.join(out, "ref_track.npz"), **g)
+
 def main():
     S = _util.synth()
     VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
@@ -906,6 +977,7 @@ def main():
     gen_distinctive(S, out)
     gen_framegrid(S, out)
     gen_frustum(S, out)
+    gen_track(S, out)
 
 
 if __name__ == "__main__":
