@@ -422,6 +422,16 @@ typedef struct plh_frame_view {
   float log_scale_factor;  /* mfLogScaleFactor */
   int32_t n_scale_levels;  /* mnScaleLevels */
 } plh_frame_view;
+/* The projection the pose-driven searches compute inline before the window lookup, for the caller that keeps its map on the
+ * device: camera coordinates by `R*P + t` (one double-accumulated gemm, as above), then
+ *   form 0  ORBmatcher::SearchByProjection(Cur, Last, th, mono) :1474-1484 and (Cur, pKF, found, th, ORBdist) :1614-1622:
+ *           invz = (float)(1.0 / z); u = fx*xc*invz + cx; front = !(invz < 0)
+ *   form 1  Fuse(pKF, vpMapPoints, th) :945-957, SearchByProjection(pKF, Scw, ..) :362-375: front = !(z < 0); invz = 1 / z in
+ *           float; x = X*invz; u = fx*x + cx
+ *   form 2  Fuse(pKF, Scw, ..) :1096-1108, SearchBySim3 :1253-1267: as form 1 with invz = (float)(1.0 / z).
+ * d_front / d_uv are what goes into q_valid (together with the caller's map-side flags) and q_uv of the searches. */
+PLH_API plh_status plh_frame_project_points_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap,
+                                                      const float* d_pos, int form, uint8_t* d_front, float* d_uv, void* stream);
 PLH_API plh_status plh_frame_is_in_frustum_points_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap,
                                                             const float* d_pos, const float* d_normal, const float* d_min_dist,
                                                             const float* d_max_dist, float viewing_cos_limit, uint8_t* d_valid,

@@ -770,3 +770,26 @@ extern "C" void plo_frame_is_in_frustum_lines(const float view[24], int n, const
     valid[i] = 1; seg[4 * i] = u1; seg[4 * i + 1] = v1; seg[4 * i + 2] = u2; seg[4 * i + 3] = v2; level[i] = nScale; viewcos[i] = viewCos;
   }
 }
+
+extern "C" void plo_frame_project_points(const float view[24], int form, int n, const float* pos, uint8_t* front, float* uv) {
+  View v;
+  memcpy(&v, view, sizeof(v));
+  for (int i = 0; i < n; i++) {
+    float Pc[3];
+    to_camera(v, pos + 3 * i, Pc);
+    if (form == 0) {
+      const float xc = Pc[0], yc = Pc[1];
+      const float invzc = 1.0 / Pc[2];
+      front[i] = invzc < 0 ? 0 : 1;
+      uv[2 * i] = v.fx * xc * invzc + v.cx;
+      uv[2 * i + 1] = v.fy * yc * invzc + v.cy;
+    } else {
+      front[i] = Pc[2] < 0.0f ? 0 : 1;
+      const float invz = form == 2 ? (float)(1.0 / Pc[2]) : 1 / Pc[2];
+      const float x = Pc[0] * invz;
+      const float y = Pc[1] * invz;
+      uv[2 * i] = v.fx * x + v.cx;
+      uv[2 * i + 1] = v.fy * y + v.cy;
+    }
+  }
+}

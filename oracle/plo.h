@@ -209,6 +209,12 @@ int  plo_orb_search_by_projection_kf(const plo_keypoint* kps_un, const uint8_t* 
  * Pinned definition of the cv::Mat arithmetic inside (OpenCV is not in the tree): `mRcw*P+mtcw` is ONE gemm call with double
  * accumulation and a single rounding to float; cv::norm and Mat::dot accumulate in double; everything else is the float
  * expression as written.  log() of a float resolves to the float overload (as with g++ / libstdc++ here). */
+/* The projection the pose-driven searches compute inline before they look anything up.  form 0: ORBmatcher::SearchByProjection
+ * (Cur, Last, th, mono) :1474-1484 and the relocalisation form :1614-1622 -- invz = (float)(1.0 / z), u = fx*xc*invz + cx,
+ * front = !(invz < 0); form 1: Fuse :945-957 and the loop-closing SearchByProjection :362-375 -- front = !(z < 0),
+ * invz = 1 / z in float, x = X*invz, u = fx*x + cx; form 2: Fuse(Scw) :1096-1108, SearchBySim3 :1253-1267 -- as form 1 with
+ * invz = (float)(1.0 / z).  Camera coordinates = `R*P + t` as one double-accumulated gemm (see plo_frame_is_in_frustum_*). */
+void plo_frame_project_points(const float view[24], int form, int n, const float* pos, uint8_t* front, float* uv);
 void plo_frame_is_in_frustum_points(const float view[24], int nlevels, int n, const float* pos, const float* normal,
                                     const float* min_dist, const float* max_dist, float viewing_cos_limit, uint8_t* valid,
                                     float* uv, int32_t* level, float* viewcos);

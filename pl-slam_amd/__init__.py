@@ -86,6 +86,7 @@ _SIGS = {
     "plh_orb_search_by_sim3_batch_dev": ([_V] * 10 + [_I, _I, _V, _V, _I] + [_V] * 8 + [_F, _I, _V, _V, _V, _V, _V], _I),
     "plh_undistort_keypoints_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
     "plh_distinctive_descriptor_batch_dev": ([_V, _V, _I, _V, _V], _I),
+    "plh_frame_project_points_batch_dev": ([_V, _I, _V, _I, _V, _I, _V, _V, _V], _I),
     "plh_frame_is_in_frustum_points_batch_dev": ([_V, _I, _V, _I, _V, _V, _V, _V, C.c_float, _V, _V, _V, _V, _V], _I),
     "plh_frame_is_in_frustum_lines_batch_dev": ([_V, _I, _V, _I, _V, _V, _V, _V, C.c_float, _V, _V, _V, _V, _V], _I),
     "plh_frame_assign_grid_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V], _I),
@@ -601,6 +602,23 @@ def undistort_keypoints(kps_list, K, D, device=0, lib=None):
 VIEW_DTYPE = np.dtype([("Rcw", np.float32, 9), ("tcw", np.float32, 3), ("Ow", np.float32, 3), ("fx", np.float32), ("fy", np.float32),
                        ("cx", np.float32), ("cy", np.float32), ("min_x", np.float32), ("min_y", np.float32), ("max_x", np.float32),
                        ("max_y", np.float32), ("log_scale_factor", np.float32), ("n_scale_levels", np.int32)])   # == plh_frame_view
+
+
+def project_points(views, positions, form, device=0, lib=None):
+    """The inline projection of the pose-driven searches (form 0 / 1 / 2, see include/plslam_hip.h) for a batch of frames:
+    positions = list of [n, 3] float32 world points.  Returns per frame (front[n] u8, uv[n, 2] float32)."""
+    L = load(lib)
+    Dv = _Dev(L, device)
+    P = len(positions)
+    qcap = max(1, max(len(x) for x in positions))
+    pos, nq = _pad_sets([np.asarray(x, np.float32).reshape(-1, 3) for x in positions], qcap, 3, np.float32)
+    dv = Dv.put(np.ascontiguousarray(views, VIEW_DTYPE).view(np.uint8).reshape(P, VIEW_DTYPE.itemsize))
+    dp, dnq = Dv.put(pos), Dv.put(nq)
+    of, ou = Dv.empty((P, qcap), np.uint8), Dv.empty((P, qcap, 2), np.float32)
+    _check(L, L.plh_frame_project_points_batch_dev(_p(dv), P, _p(dnq), qcap, _p(dp), int(form), _p(of), _p(ou), C.c_void_p(Dv.stream())),
+           "plh_frame_project_points_batch_dev")
+    f, u = Dv.get(of), Dv.get(ou)
+    return [(f[b, :len(x)].copy(), u[b, :len(x)].copy()) for b, x in enumerate(positions)]
 
 
 def is_in_frustum(views, elems, viewing_cos_limit, lines=False, device=0, lib=None):

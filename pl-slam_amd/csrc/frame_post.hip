@@ -108,6 +108,36 @@ __device__ __forceinline__ int predict_scale(float maxDist, float dist, float lo
   return (int)ceilf((float)log((double)ratio) / logScale);
 }
 
+// The projection in front of the pose-driven searches, three spellings (see plh_frame_project_points_batch_dev).
+__global__ void __launch_bounds__(256) k_project_points(const plh_frame_view* views, const int* nArr, int qcap, const float* pos, int form,
+                                                        uint8_t* front, float* uv) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= qcap) return;
+  const long long o = (long long)b * qcap + i;
+  uint8_t fr = 0;
+  float u = 0.f, w = 0.f;
+  if (i < nArr[b]) {
+    const plh_frame_view v = views[b];
+    const float P[3] = {pos[o * 3], pos[o * 3 + 1], pos[o * 3 + 2]};
+    float Pc[3];
+    to_camera(v, P, Pc);
+    if (form == 0) {
+      const float invzc = (float)(1.0 / (double)Pc[2]);
+      fr = invzc < 0 ? 0 : 1;
+      u = v.fx * Pc[0] * invzc + v.cx;
+      w = v.fy * Pc[1] * invzc + v.cy;
+    } else {
+      fr = Pc[2] < 0.0f ? 0 : 1;
+      const float invz = form == 2 ? (float)(1.0 / (double)Pc[2]) : 1.0f / Pc[2];
+      const float x = Pc[0] * invz;
+      const float y = Pc[1] * invz;
+      u = v.fx * x + v.cx;
+      w = v.fy * y + v.cy;
+    }
+  }
+  front[o] = fr; uv[o * 2] = u; uv[o * 2 + 1] = w;
+}
+
 __global__ void __launch_bounds__(256) k_frustum_points(const plh_frame_view* views, const int* nArr, int qcap, const float* pos,
                                                         const float* normal, const float* minDist, const float* maxDist,
                                                         float cosLimit, uint8_t* valid, float* uv, int* level, float* viewcos) {
@@ -263,6 +293,20 @@ plh_status plh_frame_is_in_frustum_lines_batch_dev(const plh_frame_view* d_views
                                                    int32_t* d_level, float* d_viewcos, void* stream) {
   return launch_frustum(1, d_views, frames, d_nq, qcap, d_pos6, d_normal, d_min_dist, d_max_dist, viewing_cos_limit, d_valid, d_seg,
                         d_level, d_viewcos, stream, "plh_frame_is_in_frustum_lines_batch_dev");
+}
+
+
+plh_status plh_frame_project_points_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap, const float* d_pos,
+                                              int form, uint8_t* d_front, float* d_uv, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!d_views || !d_nq || !d_pos || !d_front || !d_uv || frames <= 0 || qcap <= 0 || form < 0 || form > 2) {
+    set_error("plh_frame_project_points_batch_dev: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(k_project_points, dim3((qcap + 255) / 256, frames), dim3(256), 0, (hipStream_t)stream, d_views, (const int*)d_nq, qcap,
+                     d_pos, form, d_front, d_uv);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
 }
 
 }  // extern "C"

@@ -139,3 +139,73 @@ def test_emu_frustum(plslam, oracle, synth, emu_lib):
 @pytest.mark.gpu
 def test_gpu_frustum(plslam, oracle, synth):
     _device(plslam, oracle, synth, None, [5000, 0, 37, 1, 2048, 999])
+
+
+# ---- the inline projection of the pose-driven searches (plh_frame_project_points_batch_dev)
+def _oracle_project(O, view, form, pos):
+    L = O.lib()
+    L.plo_frame_project_points.argtypes = [V, I, I, V, V, V]
+    n = len(pos)
+    front, uv = np.zeros(max(n, 1), np.uint8), np.zeros((max(n, 1), 2), np.float32)
+    L.plo_frame_project_points(O._p(view), form, n, O._p(pos), O._p(front), O._p(uv))
+    return front[:n], uv[:n]
+
+
+def _identity_view(G):
+    return np.concatenate([np.eye(3).reshape(9), np.zeros(6), G.POSE_K, [0, 0, 640, 480], [np.log(np.float32(1.2))]]).astype(np.float32)
+
+
+def _project_goldens(G, P, S):
+    """(form, world points, golden uv, golden front or None) from the matcher pins: the uv there were produced by the harness'
+    copy of each reference expression, compiled next to the reference code that consumed them."""
+    TF = G._test_module("test_frame_search")
+    go = np.load(os.path.join(_util.ROOT, "tests", "golden", "ref_orbmatcher.npz"))
+    gk = np.load(os.path.join(_util.ROOT, "tests", "golden", "ref_orbmatcher_kf.npz"))
+    out = []
+    for seed, n, dist in G.POSE_CASES:
+        f2, gp, q, xyz, fl, occ_f, occ_k = G.pose_inputs(S, P, TF, seed, n, dist)
+        out.append((0, xyz, go["pose_%d_uv" % seed], None, (go["pf_%d_valid" % seed], fl["mp"] & (1 - fl["outlier"]))))
+        out.append((1, xyz, gk["fuse_%d_uv" % seed], None, None))
+        out.append((1, xyz, gk["s3p_%d_uv" % seed], None, None))
+        out.append((2, xyz, gk["fuse3_%d_uv" % seed], None, None))
+        f1, f2, gp, sides, already = G.sim3_inputs(S, P, TF, seed, n, dist)
+        out.append((2, sides[0]["xyz"], gk["sim3_%d_uv12" % seed], None, None))
+        out.append((2, sides[1]["xyz"], gk["sim3_%d_uv21" % seed], None, None))
+    return out
+
+
+def test_oracle_projection_reproduces_matcher_goldens(oracle, plslam, synth):
+    G = _gen()
+    view = _identity_view(G)
+    for form, xyz, uv, _, vf in _project_goldens(G, plslam, synth):
+        front, got = _oracle_project(oracle, view, form, xyz)
+        assert (got == uv).all(), "form %d" % form
+        if vf is not None:
+            assert (vf[0] == (vf[1] & front)).all()
+
+
+def _device_project(P, O, synth, lib):
+    G = _gen()
+    TF = G._test_module("test_frame_search")
+    ident = _view_record(P, _identity_view(G), 8)
+    for form in (0, 1, 2):
+        views, poss, refs = [], [], []
+        for b, n in enumerate([700, 0, 33, 1]):
+            view, nlv = G.frustum_view(synth, P, TF, 60 + b, False, rotate=True)
+            pos = G.frustum_elems(synth, 60 + b, n, view, 0)["pos"]
+            views.append(_view_record(P, view, nlv)); poss.append(pos); refs.append(_oracle_project(O, view, form, pos))
+        got = P.project_points(np.array(views, P.VIEW_DTYPE), poss, form, lib=lib)
+        for (rf, ru), (gf, gu) in zip(refs, got):
+            assert (rf == gf).all() and (ru == gu).all(), "form %d" % form
+    for form, xyz, uv, _, _ in _project_goldens(G, P, synth):
+        gf, gu = P.project_points(np.array([ident], P.VIEW_DTYPE), [xyz], form, lib=lib)[0]
+        assert (gu == uv).all(), "golden form %d" % form
+
+
+def test_emu_projection(plslam, oracle, synth, emu_lib):
+    _device_project(plslam, oracle, synth, emu_lib)
+
+
+@pytest.mark.gpu
+def test_gpu_projection(plslam, oracle, synth):
+    _device_project(plslam, oracle, synth, None)
