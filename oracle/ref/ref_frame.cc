@@ -13,6 +13,7 @@
 //   Tracking::SearchLocalPoints / SearchLocalLines' core (src/Tracking.cc:1772-1800, 1825-1849): isInFrustum over a local map
 //     of real MapPoint / MapLine objects, then the real ORBmatcher / LSDmatcher::SearchByProjection(F, map elements, th) --
 //     src/ORBmatcher.cc and src/LSDmatcher.cpp compiled against the REAL Frame / KeyFrame / MapPoint / MapLine here
+//   TrackWithMotionModel's search: the real ORBmatcher::SearchByProjection(Cur, Last, th, mono) on two real Frames
 // Not reachable without OpenCV proper: the constructors (remap, extractor threads), UndistortKeyPoints (cv::undistortPoints),
 // the stereo code.  TEST INFRASTRUCTURE ONLY.
 #include <cstdint>
@@ -302,6 +303,63 @@ int ref_track_local_lines(void* h, const uint8_t* ldesc, const float view[24], c
     occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
   }
   f.mvpMapLines.clear();
+  return nm;
+}
+
+
+// Tracking::TrackWithMotionModel's search on real objects: ORBmatcher(0.9, true).SearchByProjection(Cur, Last, th, mono = true),
+// src/ORBmatcher.cc:1441-1585, with Cur = the Frame behind `h` (pose from view, no rotation) and a real LastFrame whose
+// keypoints carry real MapPoints at world positions q_xyz.
+int ref_track_last_frame(void* h, const uint8_t* desc, const float view[24], int nlevels, const float* scale_factors,
+                         uint8_t* occupied, int nq, const uint8_t* q_mp, const uint8_t* q_outlier, const float* q_xyz,
+                         const int32_t* q_octave, const float* q_angle, const uint8_t* q_desc, const uint8_t* q_hasobs, float th,
+                         int32_t* assigned) {
+  Frame& cur = *(Frame*)h;
+  RefKF owner;
+  set_view(cur, view, nlevels, scale_factors);
+  const int n = cur.N;
+  cur.mDescriptors = cv::Mat(n > 0 ? n : 1, 32, CV_8U);
+  if (n > 0) std::memcpy(cur.mDescriptors.data, desc, (size_t)n * 32);
+  cur.mvuRight.assign(n, -1.f);
+  cur.mb = 0.f;
+  std::vector<std::unique_ptr<MapPoint> > pts;
+  auto make = [&](const float* x) {
+    cv::Mat P(3, 1, CV_32F);
+    for (int k = 0; k < 3; k++) P.at<float>(k) = x[k];
+    pts.emplace_back(new MapPoint(P, owner.kf, &owner.map));
+    return pts.back().get();
+  };
+  const float zero[3] = {0, 0, 0};
+  cur.mvpMapPoints.assign(n, nullptr);
+  for (int i = 0; i < n; i++)
+    if (occupied[i]) { MapPoint* p = make(zero); p->nObs = 1; cur.mvpMapPoints[i] = p; }
+  std::vector<MapPoint*> before = cur.mvpMapPoints;
+  Frame last;
+  last.N = nq;
+  last.mvKeys.resize(nq); last.mvKeysUn.resize(nq);
+  last.mvpMapPoints.assign(nq, nullptr);
+  last.mvbOutlier.assign(nq, false);
+  last.mTcw = cv::Mat::eye(4, 4, CV_32F);
+  for (int i = 0; i < nq; i++) {
+    last.mvKeys[i].octave = q_octave[i]; last.mvKeysUn[i].octave = q_octave[i];
+    last.mvKeys[i].angle = q_angle[i]; last.mvKeysUn[i].angle = q_angle[i];
+    last.mvbOutlier[i] = q_outlier[i] != 0;
+    if (!q_mp[i]) continue;
+    MapPoint* p = make(q_xyz + 3 * i);
+    p->mDescriptor = cv::Mat(1, 32, CV_8U);
+    std::memcpy(p->mDescriptor.data, q_desc + (size_t)i * 32, 32);
+    p->nObs = q_hasobs[i] ? 1 : 0;
+    p->mnId = (unsigned long)i;
+    last.mvpMapPoints[i] = p;
+  }
+  ORBmatcher matcher(0.9, true);
+  const int nm = matcher.SearchByProjection(cur, last, th, true);
+  for (int i = 0; i < n; i++) {
+    MapPoint* p = cur.mvpMapPoints[i];
+    assigned[i] = (p && p != before[i]) ? (int32_t)p->mnId : -1;
+    occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
+  }
+  cur.mvpMapPoints.clear();
   return nm;
 }
 

@@ -10,7 +10,9 @@ local map of real MapPoint / MapLine objects, and runs the core of Tracking::Sea
 
 i.e. real isInFrustum + PredictScale -> mTrackProj* / mnTrackScaleLevel / mTrackViewCos -> real GetFeaturesInArea[ForLine]
 -> the real matching loops writing mvpMapPoints / mvpMapLines.  The product does the same with two calls per feature
-type: plh_frame_is_in_frustum_* -> plh_*_search_by_projection_{mp,ml}.  Committed reference outputs:
+type: plh_frame_is_in_frustum_* -> plh_*_search_by_projection_{mp,ml}.  The same library runs TrackWithMotionModel's
+search -- the real ORBmatcher(0.9, true).SearchByProjection(Cur, Last, th, mono) on two real Frames (src/ORBmatcher.cc:
+1441-1585) -- against plh_frame_project_points (form 0) -> plh_orb_search_by_projection_frame.  Committed reference outputs:
 tests/golden/ref_track.npz (camera without rotation, see tests/test_frustum.py); the oracle chain, the HIP sources on the
 host emulator and the GPU (`-m gpu`) must reproduce which map element ends up on which keypoint / line."""
 import ctypes as C
@@ -65,6 +67,59 @@ def _device_chain(P, TF, G, lib, f2, gp, view, nlv, pts, lns, occ_p, occ_l, th):
     q = dict(valid=q["valid"], seg=q["seg"], viewcos=q["viewcos"], desc=lns["desc"], hasobs=lns["hasobs"])
     al, cl, ol = fs.LineSearchByProjectionMapLines([q], [occ_l], th=th, nnratio=0.7)
     return (cp[0], ap[0, :n], op[0, :max(n, 1)][:len(occ_p)]), (cl[0], al[0, :nl], ol[0, :max(nl, 1)][:len(occ_l)])
+
+
+def _motion_oracle(O, P, TF, G, f2, gp, view, nlv, pts, flags, q, occ, th):
+    FR = G._test_module("test_frustum")
+    L = TF._olib(O)
+    g = TF._gpa(P, gp)
+    (cs, ci), _ = TF._oracle_grids(O, P, f2, gp)
+    n, p = len(f2["kps"]), O._p
+    front, uv = FR._oracle_project(O, view, 0, pts["pos"])
+    valid = np.ascontiguousarray(flags["mp"] & (1 - flags["outlier"]) & front)
+    uv = np.ascontiguousarray(uv)
+    o, a = occ.copy(), np.zeros(max(n, 1), np.int32)
+    c = L.plo_orb_search_by_projection_frame(p(f2["kps"]), p(f2["desc"]), n, p(g), p(cs), p(ci), p(TF.SCALE), p(o), len(valid), p(valid), p(uv),
+                                             p(q["octave"]), p(q["angle"]), p(pts["desc"]), p(pts["hasobs"]), th, 0, 1, p(a))
+    return c, a[:n], o
+
+
+def _motion_device(P, TF, G, lib, f2, gp, view, nlv, pts, flags, q, occ, th):
+    FR = G._test_module("test_frustum")
+    n = len(f2["kps"])
+    rec = np.array([FR._view_record(P, view, nlv)], P.VIEW_DTYPE)
+    front, uv = P.project_points(rec, [pts["pos"]], 0, lib=lib)[0]
+    qd = dict(valid=(flags["mp"] & (1 - flags["outlier"]) & front).astype(np.uint8), uv=uv, octave=q["octave"], angle=q["angle"],
+              desc=pts["desc"], hasobs=pts["hasobs"])
+    a, c, o = P.FrameSearch(gp, TF.SCALE, [f2], lib=lib).SearchByProjectionLastFrame([qd], [occ], th=th, mode=0, checkOri=True)
+    return c[0], a[0, :n], o[0, :max(n, 1)][:len(occ)]
+
+
+def _check_motion(run, G, P, S):
+    TF = G._test_module("test_frame_search")
+    g = np.load(GOLDEN)
+    for seed, n, nl, dist, _ in G.TRACK_CASES:
+        f2, gp, view, nlv, pts, lns, occ_p, occ_l = G.track_inputs(S, P, TF, seed, n, nl, dist)
+        flags, q = G.track_last_inputs(S, P, TF, seed, n, nl, dist)
+        c, a, o = run(TF, f2, gp, view, nlv, pts, flags, q, occ_p, 15.0 if seed != 2 else 7.0)
+        assert c == int(g["m_%d_n" % seed]) and (a == g["m_%d_asg" % seed]).all() and (o == g["m_%d_occ" % seed]).all(), "motion model %d" % seed
+        assert c > n // 3
+
+
+def test_oracle_chain_reproduces_reference_motion_model_search(oracle, plslam, synth):
+    G = _gen()
+    _check_motion(lambda TF, *a: _motion_oracle(oracle, plslam, TF, G, *a), G, plslam, synth)
+
+
+def test_emu_chain_reproduces_reference_motion_model_search(plslam, synth, emu_lib):
+    G = _gen()
+    _check_motion(lambda TF, *a: _motion_device(plslam, TF, G, emu_lib, *a), G, plslam, synth)
+
+
+@pytest.mark.gpu
+def test_gpu_chain_reproduces_reference_motion_model_search(plslam, synth):
+    G = _gen()
+    _check_motion(lambda TF, *a: _motion_device(plslam, TF, G, None, *a), G, plslam, synth)
 
 
 def _check(run, G, P, S):

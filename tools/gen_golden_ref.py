@@ -735,6 +735,7 @@ def ref_frame_lib():
     R.ref_frame_features_in_area_for_line.argtypes = [V, F, F, F, F, F, F, V, I]
     R.ref_keyframe_features_in_area.argtypes = [V, F, F, F, V, I]
     R.ref_keyframe_lines_in_area.argtypes = [V, F, F, F, F, F, F, V, I]
+    R.ref_track_last_frame.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, V, V, F, V]
     R.ref_track_local_points.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, V, F, V]
     R.ref_track_local_lines.argtypes = [V, V, V, V, I, V, I, V, V, V, V, V, V, F, V]
     R.ref_frame_is_in_frustum_points.argtypes = [V, I, I, V, V, V, V, F, V, V, V, V]
@@ -941,6 +942,25 @@ def reference_track(R, P, TF, f2, gp, view, nlv, pts, lns, occ_p, occ_l, th):
     return (cp, ap[:n], op), (cl, al[:nl], ol)
 
 
+def reference_track_last(R, P, TF, f2, gp, view, nlv, pts, flags, q, occ, th):
+    n, g = len(f2["kps"]), P._gp_array(gp)
+    h = R.ref_frame_create(p(f2["kps"]), n, p(f2["keylines"]), p(f2["linefn"]), len(f2["keylines"]), p(g))
+    o, a = occ.copy(), np.zeros(max(n, 1), np.int32)
+    c = R.ref_track_last_frame(h, p(f2["desc"]), p(view), nlv, p(TF.SCALE), p(o), len(pts["min_dist"]), p(flags["mp"]), p(flags["outlier"]),
+                               p(pts["pos"]), p(q["octave"]), p(q["angle"]), p(pts["desc"]), p(pts["hasobs"]), th, p(a))
+    R.ref_frame_destroy(h)
+    return c, a[:n], o
+
+
+def track_last_inputs(S, P, TF, seed, n, nl, distorted):
+    """TrackWithMotionModel: the last frame's map points (the local map of track_inputs) with its keypoints' octave / angle."""
+    f1, _, _, _ = TF.make_frame_pair(P, S, seed, n, nl=nl)
+    rng = S.SplitMix64(seed + 1700)
+    flags = dict(mp=(rng.uniform(n) < 0.9).astype(np.uint8), outlier=(rng.uniform(n) < 0.07).astype(np.uint8))
+    q = dict(octave=f1["kps"]["octave"].astype(np.int32), angle=f1["kps"]["angle"].astype(np.float32))
+    return flags, q
+
+
 def gen_track(S, out):
     R, P = ref_frame_lib(), _util.plslam()
     TF = _test_module("test_frame_search")
@@ -950,6 +970,10 @@ def gen_track(S, out):
         (cp, ap, op), (cl, al, ol) = reference_track(R, P, TF, f2, gp, view, nlv, pts, lns, occ_p, occ_l, th)
         g["p_%d_n" % seed], g["p_%d_asg" % seed], g["p_%d_occ" % seed] = cp, ap, op
         g["l_%d_n" % seed], g["l_%d_asg" % seed], g["l_%d_occ" % seed] = cl, al, ol
+        flags, q = track_last_inputs(S, P, TF, seed, n, nl, dist)
+        c, a, o = reference_track_last(R, P, TF, f2, gp, view, nlv, pts, flags, q, occ_p, 15.0 if seed != 2 else 7.0)
+        g["m_%d_n" % seed], g["m_%d_asg" % seed], g["m_%d_occ" % seed] = c, a, o
+        print("   motion-model search matched", c)
         print("local map search", seed, "points matched", cp, "of", n, "lines matched", cl, "of", nl)
     np.savez_compressed(os.path.join(out, "ref_track.npz"), **g)
 
