@@ -14,6 +14,7 @@
 //     of real MapPoint / MapLine objects, then the real ORBmatcher / LSDmatcher::SearchByProjection(F, map elements, th) --
 //     src/ORBmatcher.cc and src/LSDmatcher.cpp compiled against the REAL Frame / KeyFrame / MapPoint / MapLine here
 //   TrackWithMotionModel's search: the real ORBmatcher::SearchByProjection(Cur, Last, th, mono) on two real Frames
+//   TrackReferenceKeyFrame's search: Frame / KeyFrame::ComputeBoW with a real ORBVocabulary, then the real SearchByBoW(pKF, F)
 // Not reachable without OpenCV proper: the constructors (remap, extractor threads), UndistortKeyPoints (cv::undistortPoints),
 // the stereo code.  TEST INFRASTRUCTURE ONLY.
 #include <cstdint>
@@ -360,6 +361,52 @@ int ref_track_last_frame(void* h, const uint8_t* desc, const float view[24], int
     occupied[i] = (p && p->Observations() > 0) ? 1 : 0;
   }
   cur.mvpMapPoints.clear();
+  return nm;
+}
+
+
+// Tracking::TrackReferenceKeyFrame's search on real objects (src/Tracking.cc:1144-1153): Frame::ComputeBoW on the current
+// frame, a real KeyFrame (built from a Frame, KeyFrame::ComputeBoW) holding real MapPoints where kf_valid is set, a real
+// ORBVocabulary loaded from `voc_path` (DBoW2 text format), then ORBmatcher(nnratio, check_ori).SearchByBoW(pKF, F, matches).
+// matches21[j] = keyframe feature whose MapPoint was assigned to frame feature j, or -1.  Returns nmatches.
+int ref_track_reference_keyframe(const char* voc_path, const plo_keypoint* kps1, const uint8_t* desc1, const uint8_t* kf_valid, int n1,
+                                 const plo_keypoint* kps2, const uint8_t* desc2, int n2, float nnratio, int check_ori,
+                                 int32_t* matches21) {
+  ORBVocabulary voc;
+  if (!voc.loadFromTextFile(voc_path)) return -1;
+  auto fill = [&](Frame& f, const plo_keypoint* kps, const uint8_t* desc, int n) {
+    f.N = n;
+    f.mvKeysUn.resize(n);
+    for (int i = 0; i < n; i++)
+      f.mvKeysUn[i] = cv::KeyPoint(kps[i].x, kps[i].y, kps[i].size, kps[i].angle, kps[i].response, kps[i].octave, kps[i].class_id);
+    f.mvKeys = f.mvKeysUn;
+    f.mDescriptors = cv::Mat(n > 0 ? n : 1, 32, CV_8U);
+    if (n > 0) std::memcpy(f.mDescriptors.data, desc, (size_t)n * 32);
+    if (n == 0) f.mDescriptors = f.mDescriptors.rowRange(0, 0);
+    f.mpORBvocabulary = &voc;
+    f.mvpMapPoints.assign(n, nullptr);
+    f.mvbOutlier.assign(n, false);
+    f.mTcw = cv::Mat::eye(4, 4, CV_32F);
+  };
+  Frame fk, fc;
+  fill(fk, kps1, desc1, n1);
+  fill(fc, kps2, desc2, n2);
+  fc.ComputeBoW();
+  Map map; KeyFrameDatabase db;
+  KeyFrame kf(fk, &map, &db);
+  kf.ComputeBoW();
+  std::vector<std::unique_ptr<MapPoint> > pts;
+  for (int i = 0; i < n1; i++) {
+    if (!kf_valid[i]) continue;
+    cv::Mat P = cv::Mat::zeros(3, 1, CV_32F);
+    pts.emplace_back(new MapPoint(P, &kf, &map));
+    pts.back()->mnId = (unsigned long)i;
+    kf.AddMapPoint(pts.back().get(), i);
+  }
+  ORBmatcher matcher(nnratio, check_ori != 0);
+  std::vector<MapPoint*> m;
+  const int nm = matcher.SearchByBoW(&kf, fc, m);
+  for (int j = 0; j < n2; j++) matches21[j] = (j < (int)m.size() && m[j]) ? (int32_t)m[j]->mnId : -1;
   return nm;
 }
 

@@ -735,6 +735,7 @@ def ref_frame_lib():
     R.ref_frame_features_in_area_for_line.argtypes = [V, F, F, F, F, F, F, V, I]
     R.ref_keyframe_features_in_area.argtypes = [V, F, F, F, V, I]
     R.ref_keyframe_lines_in_area.argtypes = [V, F, F, F, F, F, F, V, I]
+    R.ref_track_reference_keyframe.argtypes = [C.c_char_p, V, V, V, I, V, V, I, F, I, V]
     R.ref_track_last_frame.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, V, V, F, V]
     R.ref_track_local_points.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, V, F, V]
     R.ref_track_local_lines.argtypes = [V, V, V, V, I, V, I, V, V, V, V, V, V, F, V]
@@ -961,6 +962,40 @@ def track_last_inputs(S, P, TF, seed, n, nl, distorted):
     return flags, q
 
 
+BOWTRACK_CASES = [(601, 10, 4, 1500, 0.7, 1), (602, 8, 3, 400, 0.9, 0), (603, 10, 6, 2000, 0.7, 1)]   # seed, k, L, n, nnratio, checkOri
+
+
+def bowtrack_inputs(S, P, VM, seed, k, Lv, n):
+    """A synthetic vocabulary, a keyframe's descriptors (half of them near vocabulary leaves) and a frame observing the same
+    features: permuted, noisy copies with slightly turned orientations."""
+    voc, d1 = make_case(S, VM, seed, k, Lv, 0.0, seed + 1, n)
+    rng = S.SplitMix64(seed + 3)
+    perm = np.argsort(rng.uniform(n))
+    d2 = np.ascontiguousarray(d1[perm] ^ np.packbits((rng.uniform(n * 256) < 0.05).reshape(n, 256), axis=1, bitorder="little"))
+    k1 = np.zeros(n, P.KP_DTYPE)
+    k1["x"], k1["y"] = rng.uniform(n, 20, 620).astype(np.float32), rng.uniform(n, 20, 460).astype(np.float32)
+    k1["angle"] = rng.uniform(n, 0, 360).astype(np.float32)
+    k1["octave"] = rng.randint(n, 0, 8)
+    k1["size"], k1["class_id"] = 31, -1
+    k2 = k1[perm].copy()
+    k2["angle"] = ((k2["angle"] + 12.0 + rng.uniform(n, -4, 4)) % 360).astype(np.float32)
+    wrong = rng.uniform(n) < 0.1
+    k2["angle"][wrong] = rng.uniform(int(wrong.sum()), 0, 360).astype(np.float32)
+    valid = (rng.uniform(n) < 0.8).astype(np.uint8)
+    return voc, dict(kps=k1, desc=d1, valid=valid), dict(kps=k2, desc=d2)
+
+
+def reference_bowtrack(R, voc, kf, fr, nnratio, chk, tmpdir):
+    path = os.path.join(tmpdir, "voc_%d.txt" % len(voc.node_desc))
+    voc.save_text(path)
+    n1, n2 = len(kf["desc"]), len(fr["desc"])
+    m = np.zeros(max(n2, 1), np.int32)
+    c = R.ref_track_reference_keyframe(path.encode(), p(kf["kps"]), p(kf["desc"]), p(kf["valid"]), n1, p(fr["kps"]), p(fr["desc"]), n2,
+                                       nnratio, chk, p(m))
+    os.remove(path)
+    return c, m[:n2]
+
+
 def gen_track(S, out):
     R, P = ref_frame_lib(), _util.plslam()
     TF = _test_module("test_frame_search")
@@ -975,6 +1010,13 @@ def gen_track(S, out):
         g["m_%d_n" % seed], g["m_%d_asg" % seed], g["m_%d_occ" % seed] = c, a, o
         print("   motion-model search matched", c)
         print("local map search", seed, "points matched", cp, "of", n, "lines matched", cl, "of", nl)
+    import tempfile
+    VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
+    for seed, k, Lv, n, nn, chk in BOWTRACK_CASES:
+        voc, kf, fr = bowtrack_inputs(S, P, VM, seed, k, Lv, n)
+        c, m = reference_bowtrack(R, voc, kf, fr, nn, chk, tempfile.gettempdir())
+        g["b_%d_n" % seed], g["b_%d_m" % seed] = c, m
+        print("reference-keyframe search", seed, "matched", c, "of", n)
     np.savez_compressed(os.path.join(out, "ref_track.npz"), **g)
 
 def main():
