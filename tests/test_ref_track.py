@@ -143,6 +143,20 @@ def _check_bow(run, G, P, S, cases=None):
         assert c > n // 3
 
 
+def _bow_oracle(O, G, voc, kf, fr, nn, chk):
+    TB, TM = G._test_module("test_bow"), G._test_module("test_match")
+    a = dict(desc=kf["desc"], angle=kf["kps"]["angle"].astype(np.float32), node=np.ascontiguousarray(TB._oracle_transform(O, kf["desc"], voc, 4)[0]),
+             valid=kf["valid"])
+    b = dict(desc=fr["desc"], angle=fr["kps"]["angle"].astype(np.float32), node=np.ascontiguousarray(TB._oracle_transform(O, fr["desc"], voc, 4)[0]))
+    c, m = TM._oracle_bow(O, a, b, 50, nn, bool(chk))
+    return c, m[:len(fr["desc"])]
+
+
+def test_oracle_chain_reproduces_reference_keyframe_search(oracle, plslam, synth):
+    G = _gen()
+    _check_bow(lambda VM, *a: _bow_oracle(oracle, G, *a), G, plslam, synth, G.BOWTRACK_CASES[:2])   # the 10^6-node one: GPU only
+
+
 def test_emu_chain_reproduces_reference_keyframe_search(plslam, synth, emu_lib):
     G = _gen()
     _check_bow(lambda VM, *a: _bow_device(plslam, VM, emu_lib, *a), G, plslam, synth, G.BOWTRACK_CASES[:2])   # the 10^6-node one: GPU only
