@@ -111,6 +111,13 @@ PLH_API plh_status plh_orb_extract_batch(plh_orb* h, const uint8_t* imgs, int ba
 PLH_API plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batch, size_t frame_stride,
                                              plh_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, void* stream);
 
+/* Capacity flags of the most recent extract call on this handle (any entry point; the call clears them in stream order
+ * before its kernels run, so they never leak from one call into the next).  Waits for that call's stream, then reads the
+ * device word.  bit 0: a FAST cell produced more candidates than its slot array; bit 1: a level's quad tree selected more
+ * keypoints than the record capacity.  Both are impossible by construction of the plan; a non-zero value
+ * means truncated lists.  The host-buffer entry points check it themselves and return PLH_ERR_CAPACITY. */
+PLH_API plh_status plh_orb_status(plh_orb* h, int* flags);
+
 /* Per-kernel device time, measured with HIP events recorded on the caller's stream around each launch
  * group.  kernel: 0 = pyramid (all levels), 1 = FAST cells, 2 = quad-tree, 3 = orientation+rBRIEF.
  * Call plh_orb_kernel_ms only after synchronising the stream; it folds and clears the pending events. */
@@ -237,6 +244,10 @@ PLH_API plh_status plh_bow_transform_batch_dev(const uint8_t* d_desc, const int3
  * (mTrackProjX/Y, mnTrackScaleLevel, mTrackViewCos, descriptor, "Observations() > 0") or computes from the pose
  * (u, v); the cv::Mat pose algebra stays with the caller (pl-slam_amd/adaptor/HipMatchers.h).
  * Batched over `pairs` independent frames at fixed strides: `cap` rows per frame, `qcap` queries per frame.
+ * Limits: cap <= 6000 (per-frame state lives in LDS); qcap is unlimited -- queries are streamed -- except for the two
+ * forms with a rotation histogram (`check_ori` != 0 in *_projection_frame / *_projection_kf: qcap <= 12000).
+ * A query whose predicted level lies outside [0, nlevels) is skipped (the reference would index mvScaleFactors out of
+ * bounds there; MapPoint::PredictScale clamps, MapLine::PredictScale does not).
  * ------------------------------------------------------------------------------------------- */
 #define PLH_GRID_COLS 64   /* FRAME_GRID_COLS, include/Frame.h:45 */
 #define PLH_GRID_ROWS 48   /* FRAME_GRID_ROWS, include/Frame.h:44 */
@@ -475,6 +486,9 @@ PLH_API plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, i
 PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride,
                                               const uint8_t* d_mask, plh_keyline* d_keylines, uint8_t* d_desc,
                                               double* d_linefn, int32_t* d_n, void* stream);
+/* Capacity flags of the most recent extract call (see plh_orb_status).  bit 2: LSD produced more segments than the
+ * segment list holds (|scaled pixels| / min_reg_size + 16 -- a hard bound, so never expected). */
+PLH_API plh_status plh_line_status(plh_line* h, int* flags);
 /* Per-stage device time (HIP events on the caller's stream): 0 = image prep + level-line field + seed order,
  * 1 = LSD region growing (k_lsd_grow), 2 = KeyLine selection, 3 = LBD (blur + Sobel + descriptor). */
 PLH_API plh_status plh_line_set_profiling(plh_line* h, int on);

@@ -55,6 +55,8 @@ _SIGS = {
     "plh_orb_extract": ([_V, _V, _I, _I, _Z, _V, _V, _I, _V], _I),
     "plh_orb_extract_batch": ([_V, _V, _I, _Z, _V, _V, _V], _I),
     "plh_orb_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V], _I),
+    "plh_orb_status": ([_V, _V], _I),
+    "plh_line_status": ([_V, _V], _I),
     "plh_orb_set_profiling": ([_V, _I], _I),
     "plh_orb_kernel_ms": ([_V, _I, _V, _V], _I),
     "plh_orb_pyramid_dev": ([_V, _I, _I, _V, _V, _V, _V], _I),
@@ -237,6 +239,12 @@ class ORBextractor:
         """Device pointers (ints or torch tensors); asynchronous on `stream` (hipStream_t as int)."""
         _check(self.lib, self.lib.plh_orb_extract_batch_dev(self.h, _p(d_imgs), batch, frame_stride, _p(d_kps), _p(d_desc),
                                                             _p(d_n), C.c_void_p(stream)), "plh_orb_extract_batch_dev")
+
+    def status(self):
+        """Capacity flags of the most recent extract call (0 = nothing was truncated); waits for that call."""
+        f = C.c_int(0)
+        _check(self.lib, self.lib.plh_orb_status(self.h, C.byref(f)), "plh_orb_status")
+        return f.value
 
     def set_profiling(self, on=True):
         _check(self.lib, self.lib.plh_orb_set_profiling(self.h, int(on)), "plh_orb_set_profiling")
@@ -913,6 +921,12 @@ class LINEextractor:
         _check(self.lib, self.lib.plh_line_extract_batch_dev(self.h, _p(d_imgs), batch, frame_stride, _p(d_mask), _p(d_keylines),
                                                              _p(d_desc), _p(d_linefn), _p(d_n), C.c_void_p(stream)),
                "plh_line_extract_batch_dev")
+
+    def status(self):
+        """Capacity flags of the most recent extract call (0 = nothing was truncated); waits for that call."""
+        f = C.c_int(0)
+        _check(self.lib, self.lib.plh_line_status(self.h, C.byref(f)), "plh_line_status")
+        return f.value
 
     def read_segments(self, b=0, cap=20000):
         out = np.zeros((cap, 4), np.float32)

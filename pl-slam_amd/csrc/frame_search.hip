@@ -390,13 +390,17 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
                                                            const int* nqArr, int qcap, const uint8_t* qValid, const float* qXY,
                                                            const int32_t* qLevel, const float* qAux, const uint8_t* qDesc,
                                                            const uint8_t* qHasObs, float th, float nnratio, int mode,
-                                                           int checkOri, int distTh, int32_t* assignedAll, int32_t* nmatchesOut) {
+                                                           int checkOri, int distTh, int nlevels, int qLds, int32_t* assignedAll,
+                                                           int32_t* nmatchesOut) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
+  // qLds = qcap when the rotation histogram needs its per-query records (variant 1 with checkOri), else 0: the queries
+  // themselves are streamed from global memory, so the other variants take any number of them (a local map of
+  // Tracking::SearchLocalPoints routinely holds more than 6000 points).
   int* list = (int*)smem;
   int* dist = list + cap;
   int* asg = dist + cap;
   int* pushIdx = asg + cap;
-  unsigned char* occ = (unsigned char*)(pushIdx + qcap);
+  unsigned char* occ = (unsigned char*)(pushIdx + qLds);
   unsigned char* pushBin = occ + cap;
   const int pair = blockIdx.x, lane = threadIdx.x;
   const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
@@ -406,7 +410,7 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
   const int32_t* ci = ciAll + o;
   const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
   for (int i = lane; i < cap; i += 64) { asg[i] = -1; occ[i] = (i < n && variant != 2) ? occupiedAll[o + i] : (variant == 2 ? 0 : 1); }
-  for (int i = lane; i < qcap; i += 64) pushBin[i] = 255;
+  for (int i = lane; i < qLds; i += 64) pushBin[i] = 255;
   if (variant == 2)
     for (int i = lane; i < qcap; i += 64) assignedAll[qo + i] = -1;
   FS_WAVE_SYNC();
@@ -416,6 +420,7 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
     if (!qValid[qo + q]) continue;
     const float x = qXY[(qo + q) * 2], y = qXY[(qo + q) * 2 + 1];
     const int lvl = qLevel[qo + q];
+    if (lvl < 0 || lvl >= nlevels) continue;   // outside mvScaleFactors: the reference would read past the vector; skipped
     float radius;
     int minL, maxL;
     if (variant == 0) {
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
       asg[bestIdx] = q;
       occ[bestIdx] = qHasObs[qo + q];
       nmatches++;
-      if (variant == 1 && checkOri) {
+      if (variant == 1 && checkOri && qLds) {
         const int bin = rot_bin(qAux[qo + q], K[bestIdx].angle);
         pushBin[q] = (unsigned char)bin;
         pushIdx[q] = bestIdx;
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(64) k_search_proj_points(int variant, const pl
     }
   }
   FS_WAVE_SYNC();
-  if (variant == 1 && checkOri) {
+  if (variant == 1 && checkOri && qLds) {
     int ind1, ind2, ind3;
     three_maxima_lanes(myHist, ind1, ind2, ind3);
     int removed = 0;
@@ -576,7 +581,7 @@ __global__ void __launch_bounds__(64) k_search_proj_lines(int variant, const plh
 // (distance, line index) over the wave is the reference's first best.  One wave per frame walks the queries.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_line_fuse_search(const plh_keyline* kls, const uint8_t* candDesc, const int* nArr, int cap,
-                                                         ScaleTab sfl, const int* nqArr, int qcap, const uint8_t* qValid,
+                                                         ScaleTab sfl, int nlevels, const int* nqArr, int qcap, const uint8_t* qValid,
                                                          const float* qSeg, const int32_t* qLevel, const uint8_t* qDesc, float th,
                                                          float TH, int thLow, int32_t* bestAll, int32_t* nfoundOut) {
   const int pair = blockIdx.x, lane = threadIdx.x;
@@ -587,11 +592,13 @@ __global__ void __launch_bounds__(64) k_line_fuse_search(const plh_keyline* kls,
   int nfound = 0;
   for (int q = 0; q < qcap; q++) {
     int best = -1;
-    if (q < nq && qValid[qo + q]) {
+    // a predicted level outside the KeyFrame's scale table (MapLine::PredictScale does not clamp) is skipped: the reference
+    // would index mvScaleFactorsLine out of bounds there
+    if (q < nq && qValid[qo + q] && qLevel[qo + q] >= 0 && qLevel[qo + q] < nlevels) {
       const float* sg = qSeg + (qo + q) * 4;
       const float x1 = sg[0], y1 = sg[1], x2 = sg[2], y2 = sg[3];
       const int lvl = qLevel[qo + q];
-      const float r = th * sfl.v[lvl & 15];
+      const float r = th * sfl.v[lvl];
       float delta1x = x1 - x2, delta1y = y1 - y2;
       const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
       delta1x /= norm_delta1;
@@ -715,15 +722,21 @@ static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, 
   for (int i = 0; i < 16; i++) is2.v[i] = (inv_level_sigma2 && i < nlevels) ? inv_level_sigma2[i] : 0.f;
   if (!d_kps_un || !d_desc || !d_n || !gp || !d_cs || !d_ci || !scale_tab(scale_factors, nlevels, &sf) || !d_occupied || !d_nq ||
       !d_q_valid || !d_q_xy || !d_q_level || !d_q_aux || !d_q_desc || !d_q_hasobs || !d_assigned || !d_nmatches || cap <= 0 ||
-      cap > 6000 || qcap <= 0 || qcap > 6000 || pairs <= 0 || mode < 0 || mode > 2) {
-    set_error("%s: invalid argument (cap, qcap in 1..6000; 1..16 levels)", who);
+      cap > 6000 || qcap <= 0 || pairs <= 0 || mode < 0 || mode > 2) {
+    set_error("%s: invalid argument (cap in 1..6000; 1..16 levels)", who);
     return PLH_ERR_INVALID;
   }
-  const size_t lds = (size_t)cap * (3 * 4 + 1) + (size_t)qcap * (4 + 1) + 64;
+  // per-query LDS records exist only for the rotation histogram of the (Cur, Last) / (Cur, KeyFrame) forms
+  const int q_lds = (variant == 1 && check_ori) ? qcap : 0;
+  if (q_lds > 12000) {
+    set_error("%s: invalid argument (qcap <= 12000 with check_ori)", who);
+    return PLH_ERR_INVALID;
+  }
+  const size_t lds = (size_t)cap * (3 * 4 + 1) + (size_t)q_lds * (4 + 1) + 64;
   if (lds_request(k_search_proj_points, lds, who) != PLH_OK) return PLH_ERR_INVALID;
   hipLaunchKernelGGL(k_search_proj_points, dim3(pairs), dim3(64), lds, (hipStream_t)stream, variant, d_kps_un, d_desc,
                      (const int*)d_n, cap, *gp, d_cs, d_ci, sf, is2, d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy, d_q_level,
-                     d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, mode, check_ori, dist_th, d_assigned, d_nmatches);
+                     d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, mode, check_ori, dist_th, nlevels, q_lds, d_assigned, d_nmatches);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
 }
@@ -847,7 +860,7 @@ plh_status plh_line_fuse_search_batch_dev(const plh_keyline* d_kl, const uint8_t
     return PLH_ERR_INVALID;
   }
   hipLaunchKernelGGL(k_line_fuse_search, dim3(pairs), dim3(64), 0, (hipStream_t)stream, d_kl, d_cand_desc, (const int*)d_nl, cap, sfl,
-                     (const int*)d_nq, qcap, d_q_valid, d_q_seg, d_q_level, d_q_desc, th, cos_th, th_low, d_best_idx, d_nfound);
+                     nlevels, (const int*)d_nq, qcap, d_q_valid, d_q_seg, d_q_level, d_q_desc, th, cos_th, th_low, d_best_idx, d_nfound);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
 }

@@ -37,6 +37,7 @@ struct plh_line {
   float* dSeedCs = nullptr;
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
+  hipStream_t lastStream = nullptr;   // stream of the most recent extract call (plh_line_status waits on it)
   float *dSegs = nullptr, *dMap = nullptr, *dCoef = nullptr;
   ResizeTap *dXtab = nullptr, *dYtab = nullptr;
   // staging (host-buffer entry points)
@@ -287,6 +288,8 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   a.mask = d_mask;
   const uint8_t* src = d_imgs;
   long long srcStride = (long long)frame_stride;
+  PLH_HIP(hipMemsetAsync(h->dStatus, 0, 4, s));   // capacity flags of this call only (plh_line_status)
+  h->lastStream = s;
   if (h->hasUndistort) {
     a.mapxy = h->dMap; a.undist = h->dUndist;
     launch_remap(a, s);
@@ -369,10 +372,17 @@ plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, int cols,
   int stf = 0;
   PLH_HIP(hipMemcpy(&stf, h->dStatus, 4, hipMemcpyDeviceToHost));
   if (stf) {
-    (void)hipMemset(h->dStatus, 0, 4);
     set_error("line kernels reported a capacity overflow (flags 0x%x)", stf);
     return PLH_ERR_CAPACITY;
   }
+  return PLH_OK;
+}
+
+plh_status plh_line_status(plh_line* h, int* flags) {
+  if (!h || !flags) return PLH_ERR_INVALID;
+  PLH_HIP(hipSetDevice(h->device));
+  PLH_HIP(hipStreamSynchronize(h->lastStream));
+  PLH_HIP(hipMemcpy(flags, h->dStatus, 4, hipMemcpyDeviceToHost));
   return PLH_OK;
 }
 

@@ -43,8 +43,9 @@ __global__ void __launch_bounds__(256) k_knn2(const uint8_t* q, const int* nqArr
                                               const int* ntArr, int ntConst, int tCap, int32_t* idx, int32_t* dist) {
   __shared__ unsigned long long tile[256 * 4];
   const int pair = blockIdx.y;
-  const int nq = nqArr ? nqArr[pair] : nqConst;
-  const int nt = ntArr ? ntArr[pair] : ntConst;
+  // counts are clamped to the row capacities like everywhere else (a count from another handle must not overrun the sets)
+  const int nq = max(0, min(nqArr ? nqArr[pair] : nqConst, qCap));
+  const int nt = max(0, min(ntArr ? ntArr[pair] : ntConst, tCap));
   const int tid = threadIdx.x;
   const int i = blockIdx.x * 256 + tid;
   if (blockIdx.x * 256 >= max(nq, 1) && blockIdx.x > 0) return;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) k_line_bfmatch(const int32_t* idx, const 
   __shared__ int s_med;
   __shared__ double s_th;
   const int pair = blockIdx.x, tid = threadIdx.x;
-  const int nq = nqArr[pair], nt = ntArr[pair];
+  const int nq = max(0, min(nqArr[pair], qCap)), nt = max(0, ntArr[pair]);
   const int32_t* D = dist + (long long)pair * qCap * 2;
   const int32_t* I = idx + (long long)pair * qCap * 2;
   int32_t* M = matches + (long long)pair * qCap;
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(256) k_line_mutual(const int32_t* m1, const in
                                                      int cap, int32_t* out, int32_t* nmatches) {
   __shared__ int s_cnt;
   const int pair = blockIdx.x, tid = threadIdx.x;
-  const int n1 = n1Arr[pair], n2 = n2Arr[pair];
+  const int n1 = max(0, min(n1Arr[pair], cap)), n2 = max(0, min(n2Arr[pair], cap));
   if (tid == 0) s_cnt = 0;
   __syncthreads();
   int c = 0;
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
   unsigned char* bin2 = (unsigned char*)(rhi + cap);
 
   const int pair = blockIdx.x, tid = threadIdx.x;
-  const int n1 = n1Arr[pair], n2 = n2Arr[pair];
+  const int n1 = max(0, min(n1Arr[pair], cap)), n2 = max(0, min(n2Arr[pair], cap));
   const long long o = (long long)pair * cap;
   for (int i = tid; i < cap; i += 256) {
     nd1[i] = i < n1 ? node1[o + i] : -1;

@@ -67,6 +67,7 @@ struct plh_orb {
   uint8_t* dPyr = nullptr;
   uint32_t *dSlots = nullptr, *dCellCount = nullptr, *dKeys = nullptr, *dSel = nullptr;
   int *dSelCount = nullptr, *dStatus = nullptr;
+  hipStream_t lastStream = nullptr;   // stream of the most recent extract call (plh_orb_status waits on it)
   // staging for the host-buffer entry points
   uint8_t* dImgs = nullptr;
   plh_keypoint* dKps = nullptr;
@@ -296,11 +297,16 @@ plh_status upload(const std::vector<T>& v, T** d) {
 extern "C" {
 
 const char* plh_last_error(void) { return plh::tls_error(); }
+// PLH_BUILD_ID: hash of the sources this library was compiled from (set by __graft_entry__.build_hip); the GPU tests compare
+// it with the hash of the sources next to them, so a stale shipped binary cannot pass for the current code.
+#ifndef PLH_BUILD_ID
+#define PLH_BUILD_ID "unknown"
+#endif
 const char* plh_version(void) {
 #if defined(HIPEMU)
-  return "plslam_hip 0.1 (hipemu CPU emulation -- test infrastructure, not the product)";
+  return "plslam_hip 0.2 (hipemu CPU emulation -- test infrastructure, not the product) build " PLH_BUILD_ID;
 #else
-  return "plslam_hip 0.1 (gfx950)";
+  return "plslam_hip 0.2 (gfx950) build " PLH_BUILD_ID;
 #endif
 }
 int plh_device_count(void) {
@@ -392,6 +398,9 @@ plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batc
   hipStream_t s = (hipStream_t)stream;
   OrbDeviceArgs a;
   fill_args(h, d_imgs, (long long)frame_stride, batch, &a);
+  // the capacity flags describe THIS call only (plh_orb_status): cleared in stream order in front of the kernels
+  PLH_HIP(hipMemsetAsync(h->dStatus, 0, sizeof(int), s));
+  h->lastStream = s;
   prof_mark(h, 0, s);
   for (int l = 1; l < h->nlevels; l++) {
     launch_pyr_down(a, l, h->levels[l].pitch, h->levels[l].h, (size_t)h->levels[l].pyrTP * h->levels[l].pyrTR, s);
@@ -428,10 +437,17 @@ static plh_status check_status(plh_orb* h) {
   int st = 0;
   PLH_HIP(hipMemcpy(&st, h->dStatus, sizeof(int), hipMemcpyDeviceToHost));
   if (st != 0) {
-    (void)hipMemset(h->dStatus, 0, sizeof(int));
     set_error("ORB kernels reported a capacity overflow (flags 0x%x)", st);
     return PLH_ERR_CAPACITY;
   }
+  return PLH_OK;
+}
+
+plh_status plh_orb_status(plh_orb* h, int* flags) {
+  if (!h || !flags) return PLH_ERR_INVALID;
+  PLH_HIP(hipSetDevice(h->device));
+  PLH_HIP(hipStreamSynchronize(h->lastStream));
+  PLH_HIP(hipMemcpy(flags, h->dStatus, sizeof(int), hipMemcpyDeviceToHost));
   return PLH_OK;
 }
 

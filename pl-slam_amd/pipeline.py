@@ -138,6 +138,9 @@ class FrontEndBatch:
         """Host copies of everything one step produced (synchronises)."""
         t, P = self.torch, self.P
         t.cuda.synchronize(self.dev)
+        flags = self.orb.status() | self.line.status()   # the _dev path reports truncation here, never silently
+        if flags:
+            raise P.PlhError("front end: a fixed-capacity buffer overflowed (flags 0x%x)" % flags)
         B = self.B
         kps = self.kps[:B].cpu().numpy().view(np.uint8).reshape(B, self.ocap, 28).copy().view(P.KP_DTYPE).reshape(B, self.ocap)
         kl = self.kl[:B].cpu().numpy().view(np.uint8).reshape(B, self.lcap, 68).copy().view(P.KL_DTYPE).reshape(B, self.lcap)

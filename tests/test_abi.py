@@ -1,0 +1,101 @@
+"""C-ABI housekeeping: the build id the library carries, the capacity-flag query of the throughput path and the host
+helper plh_descriptor_distance (ORBmatcher::DescriptorDistance, reference src/ORBmatcher.cc:1764-1780;
+LSDmatcher::DescriptorDistance, src/LSDmatcher.cpp:654-670)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import _util
+
+LIB = os.path.join(_util.ROOT, "pl-slam_amd", "libplslam_hip.so")
+
+
+def _graft():
+    sys.path.insert(0, _util.ROOT)
+    import __graft_entry__ as g
+    return g
+
+
+def _version(path):
+    lib = C.CDLL(path)
+    lib.plh_version.restype = C.c_char_p
+    return lib.plh_version().decode()
+
+
+def test_library_is_built_from_these_sources():
+    """The shipped libplslam_hip.so carries the hash of the sources next to it (a stale binary cannot pass)."""
+    g = _graft()
+    if not os.path.exists(LIB):
+        g.build_hip()
+    assert ("build " + g.source_id()) in _version(LIB), "libplslam_hip.so was not built from the current sources"
+
+
+@pytest.mark.gpu
+def test_gpu_library_is_built_from_these_sources(plslam):
+    g = _graft()
+    v = plslam.load().plh_version().decode()
+    assert "gfx950" in v and ("build " + g.source_id()) in v, v
+
+
+def _bitcount_ref(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def _distance_cases(S):
+    rng = S.SplitMix64(2024)
+    rows = rng.randint(64 * 32, 0, 256).astype(np.uint8).reshape(64, 32)
+    cases = [(np.zeros(32, np.uint8), np.zeros(32, np.uint8), 0), (np.zeros(32, np.uint8), np.full(32, 255, np.uint8), 256)]
+    one = np.zeros(32, np.uint8)
+    one[31] = 0x80
+    cases.append((np.zeros(32, np.uint8), one, 1))
+    for i in range(0, 64, 2):
+        cases.append((rows[i], rows[i + 1], _bitcount_ref(rows[i], rows[i + 1])))
+    return cases
+
+
+def test_descriptor_distance_product_host_helper(plslam, oracle, synth):
+    """plh_descriptor_distance of the product library (a host popcount, no GPU involved) against a bit count and the
+    oracle's restatement of the reference's SWAR loop."""
+    if not os.path.exists(LIB):
+        _graft().build_hip()
+    L = plslam.load(LIB)
+    O = oracle.lib()
+    has_oracle = hasattr(O, "plo_descriptor_distance")
+    if has_oracle:
+        O.plo_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        O.plo_descriptor_distance.restype = C.c_int
+    for a, b, want in _distance_cases(synth):
+        assert plslam.descriptor_distance(a, b, LIB) == want
+        assert plslam.descriptor_distance(b, a, LIB) == want
+        if has_oracle:
+            assert O.plo_descriptor_distance(oracle._p(np.ascontiguousarray(a)), oracle._p(np.ascontiguousarray(b))) == want
+    # unaligned rows (a cv::Mat row pointer has no 8-byte guarantee)
+    buf = np.zeros(80, np.uint8)
+    buf[1:33] = 0xF0
+    assert L.plh_descriptor_distance(C.c_void_p(buf.ctypes.data + 1), C.c_void_p(buf.ctypes.data + 40)) == 128
+
+
+def _status_case(P, S, lib):
+    img = S.make_frame(3, 120, 160, n_rect=40, n_line=20)
+    ex = P.ORBextractor(200, 1.2, 3, 20, 7, rows=120, cols=160, max_batch=1, lib=lib)
+    ln = P.LINEextractor(1, 1.2, 50, 0.0, rows=120, cols=160, max_batch=1, lib=lib)
+    try:
+        k, d = ex(img)
+        kl, ld, fn = ln(img)
+        assert len(k) > 50 and len(kl) > 5
+        assert ex.status() == 0 and ln.status() == 0
+    finally:
+        ex.close()
+        ln.close()
+
+
+def test_emu_status_query(plslam, synth, emu_lib):
+    _status_case(plslam, synth, emu_lib)
+
+
+@pytest.mark.gpu
+def test_gpu_status_query(plslam, synth):
+    _status_case(plslam, synth, None)

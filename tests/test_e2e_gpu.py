@@ -6,19 +6,28 @@ import numpy as np
 import pytest
 
 import _util
-from test_line import TUM1_D, TUM1_K, _close, _exact, _oracle_line
+from test_line import TUM1_D, TUM1_K, _match, _oracle_line
 
 pytestmark = pytest.mark.gpu
 
 
-def test_front_end_batch_vs_oracle(plslam, oracle, synth):
+KITTI_K = [718.856, 718.856, 607.1928, 185.2157]      # Examples/Monocular/KITTI00-02.yaml:8-11
+KITTI_D = [0.0, 0.0, 0.0, 0.0, 0.0]                   # :13-16 (rectified sequence: no remap in front of LSD)
+
+
+@pytest.mark.parametrize("rows,cols,nfeat,K,D,seed", [(480, 640, 1000, TUM1_K, TUM1_D, 500), (376, 1241, 2000, KITTI_K, KITTI_D, 1500)],
+                         ids=["tum1_640x480_1000", "kitti_1241x376_2000"])
+def test_front_end_batch_vs_oracle(plslam, oracle, synth, rows, cols, nfeat, K, D, seed):
+    """The whole batch front end against the oracle, stage by stage, on both frame shapes the north star names:
+    TUM1 (Examples/Monocular/TUM1.yaml: 640x480, 1000 features, distorted) and KITTI 00-02
+    (Examples/Monocular/KITTI00-02.yaml:8-51: 1241x376, 2000 features, 4 quad-tree roots, no distortion)."""
     import torch
     V = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
     PL = _util._load("plslam_amd_pipeline", os.path.join(_util.ROOT, "pl-slam_amd", "pipeline.py"))
     B = 6
-    frames = synth.make_frames(500, B, 480, 640)
+    frames = synth.make_frames(seed, B, rows, cols)
     voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=synth)
-    fe = PL.FrontEndBatch(plslam, voc, B, 480, 640, 1000, 8, 200, 0.0, TUM1_K, TUM1_D)
+    fe = PL.FrontEndBatch(plslam, voc, B, rows, cols, nfeat, 8, 200, 0.0, K, D)
     d = torch.from_numpy(frames).cuda()
     fe.step(d)
     fe.step(d)          # second pass over the same buffers: results must not depend on stale state
@@ -28,12 +37,12 @@ def test_front_end_batch_vs_oracle(plslam, oracle, synth):
     L = O.lib()
     L.plo_bow_transform.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.plo_bow_transform.restype = None
-    orb = O.OrbOracle(1000, 1.2, 8, 20, 7)
+    orb = O.OrbOracle(nfeat, 1.2, 8, 20, 7)
     ref = []
     for b in range(B):
         rk, rd = orb.extract(frames[b])
         n = r["n"][b]
-        assert n == len(rk)
+        assert n == len(rk) and n >= nfeat
         for f in rk.dtype.names:
             assert (r["kps"][b, :n][f] == rk[f]).all(), (b, f)
         assert (r["desc"][b, :n] == rd).all()
@@ -42,10 +51,9 @@ def test_front_end_batch_vs_oracle(plslam, oracle, synth):
         L.plo_bow_transform(O._p(rd), n, O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id),
                             O._p(voc.weight), voc.L, 4, O._p(nid), O._p(word))
         assert (r["nid"][b, :n] == nid).all()
-        lk, ld, lf, _ = _oracle_line(O, frames[b], 200, 0.0, TUM1_K, TUM1_D)
+        lk, ld, lf, _ = _oracle_line(O, frames[b], 200, 0.0, *((K, D) if any(D) else (None, None)))
         nl = r["nl"][b]
-        if not _exact(r["kl"][b, :nl], r["ldesc"][b, :nl], r["lfn"][b, :nl], lk, ld, lf):
-            _close(r["kl"][b, :nl], r["ldesc"][b, :nl], r["lfn"][b, :nl], lk, ld, lf, "frame %d" % b)
+        _match(r["kl"][b, :nl], r["ldesc"][b, :nl], r["lfn"][b, :nl], lk, ld, lf, "frame %d" % b)
         ref.append((rk, rd, nid, ld))
     for b in range(B):       # frame b (KeyFrame) -> frame (b+1) % B
         k1, d1, n1, l1 = ref[b]
@@ -134,8 +142,7 @@ def test_partial_batches_and_blank_frames(plslam, oracle, synth):
             assert all((k_h[b, :n_h[b]][f] == rk[f]).all() for f in rk.dtype.names)
             lk, ldr, lfr = oracle.line_extract(frames[b], 200, 0.0)
             assert nl_h[b] == len(lk)
-            if not _exact(kl_h[b, :nl_h[b]], ld_h[b, :nl_h[b]], fn_h[b, :nl_h[b]], lk, ldr, lfr):
-                _close(kl_h[b, :nl_h[b]], ld_h[b, :nl_h[b]], fn_h[b, :nl_h[b]], lk, ldr, lfr, "frame %d" % b)
+            _match(kl_h[b, :nl_h[b]], ld_h[b, :nl_h[b]], fn_h[b, :nl_h[b]], lk, ldr, lfr, "frame %d" % b)
         assert n_h[1] == 0 and nl_h[1] == 0 and (nb <= 4 or (n_h[4] == 0 and nl_h[4] == 0))
     orb.close()
     le.close()

@@ -381,6 +381,56 @@ def test_gpu_frame_search_2000(plslam, oracle, synth):
     assert _run_all(plslam, oracle, synth, None, [41, 42], 1000, 201, distorted=True) > 500
 
 
+def _large_local_map(P, O, S, lib, nq_total=9000, n=700):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) with a local map larger than a frame: Tracking::SearchLocalPoints
+    hands over mvpLocalMapPoints, which routinely holds more than 6000 points (the per-query LDS records exist only for the
+    rotation-histogram forms).  Queries outside [0, nlevels) are skipped."""
+    L = _olib(O)
+    gp = _gp(P)
+    g = _gpa(P, gp)
+    f1, f2, _, _ = make_frame_pair(P, S, 4242, n, nl=0)
+    fs = P.FrameSearch(gp, SCALE, [f2], lib=lib)
+    rng = S.SplitMix64(99)
+    src = (rng.uniform(nq_total) * n).astype(np.int64) % n          # map points re-observing the frame's features
+    k = f1["kps"][src]
+    pv = np.where(np.arange(nq_total) < 6100, 0.03, 0.6)              # most of the early queries are not in view
+    q = dict(valid=(rng.uniform(nq_total) < pv).astype(np.uint8), desc=f1["desc"][src].copy(),
+             hasobs=(rng.uniform(nq_total) < 0.9).astype(np.uint8),
+             xy=np.stack([k["x"] + rng.uniform(nq_total, -4, 4), k["y"] + rng.uniform(nq_total, -4, 4)], 1).astype(np.float32),
+             level=k["octave"].astype(np.int32), viewcos=rng.uniform(nq_total, 0.99, 1.0).astype(np.float32))
+    flip = rng.uniform(nq_total) < 0.3                                # noisy descriptors so that not everything matches
+    q["desc"][flip] ^= rng.randint(int(flip.sum()) * 32, 0, 256).astype(np.uint8).reshape(-1, 32) & 0x11
+    occ0 = (S.SplitMix64(5).uniform(n) < 0.1).astype(np.uint8)
+    asg, cnt, occ = fs.SearchByProjectionMapPoints([q], [occ0], th=3.0, nnratio=0.8)
+    (rcs, rci), _ = _oracle_grids(O, P, f2, gp)
+    ro, ra = occ0.copy(), np.zeros(n, np.int32)
+    rc = L.plo_orb_search_by_projection_mp(O._p(f2["kps"]), O._p(f2["desc"]), n, O._p(g), O._p(rcs), O._p(rci), O._p(SCALE), O._p(ro),
+                                           nq_total, O._p(q["valid"]), O._p(q["xy"]), O._p(q["level"]), O._p(q["viewcos"]),
+                                           O._p(q["desc"]), O._p(q["hasobs"]), 3.0, 0.8, O._p(ra))
+    assert cnt[0] == rc and (asg[0, :n] == ra).all() and (occ[0, :n] == ro).all()
+    assert rc > 100 and ra.max() >= 6000, "the late queries must take part (max assigned query %d)" % ra.max()
+    # out-of-range predicted levels are skipped, exactly as if the caller had cleared their valid flag
+    q2 = dict(q)
+    q2["level"] = q["level"].copy()
+    bad = rng.uniform(nq_total) < 0.2
+    q2["level"][bad] = np.where(rng.uniform(int(bad.sum())) < 0.5, -1, len(SCALE)).astype(np.int32)
+    q3 = dict(q2)
+    q3["valid"] = (q["valid"] * ~bad).astype(np.uint8)
+    q3["level"] = np.where(bad, 0, q["level"]).astype(np.int32)
+    a2, c2, o2 = fs.SearchByProjectionMapPoints([q2], [occ0], th=3.0, nnratio=0.8)
+    a3, c3, o3 = fs.SearchByProjectionMapPoints([q3], [occ0], th=3.0, nnratio=0.8)
+    assert c2[0] == c3[0] and (a2 == a3).all() and (o2 == o3).all()
+
+
+def test_emu_large_local_map(plslam, oracle, synth, emu_lib):
+    _large_local_map(plslam, oracle, synth, emu_lib, nq_total=7000, n=300)
+
+
+@pytest.mark.gpu
+def test_gpu_large_local_map(plslam, oracle, synth):
+    _large_local_map(plslam, oracle, synth, None, nq_total=20000, n=2000)
+
+
 @pytest.mark.gpu
 def test_gpu_host_buffer_forms(plslam, oracle, synth):
     """The one-call-per-reference-call entry points (host buffers, grid rebuilt inside) agree with the oracle."""

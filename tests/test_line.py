@@ -1,8 +1,11 @@
 """Line half of the front end (LSD + KeyLine selection + LBD): oracle sanity (CPU), HIP sources under hipemu (CPU),
-GPU parity.  Tolerance (north star: "LSD endpoints/LBD within a stated float tolerance"):
-  * LSD works in float64 with libm cos/sin; device libm may differ from glibc in the last ulp, so the GPU test
-    accepts |endpoint difference| <= 1e-3 px on >= 99% of the segments (observed: bit-identical);
-  * LBD given the same keylines: <= 2 differing bits per 256-bit descriptor on >= 99% of lines (observed: 0)."""
+GPU parity.  The bar is BIT-EXACT: segments, KeyLines (every field), LBD bytes and line equations equal the oracle's.
+The north star would allow a float tolerance for this half ("LSD endpoints/LBD within a stated float tolerance"); it is
+only available behind an explicit escape, PLSLAM_LINE_TOLERANCE=1, which downgrades a mismatch to
+  * |endpoint difference| <= 1e-3 px on >= 99% of the lines, <= 2 differing LBD bits on >= 99% of those, equal
+    numOfPixels, line equations within 1e-3
+and says so on stdout.  Without the flag any difference fails the test."""
+import os
 import numpy as np
 import pytest
 
@@ -29,6 +32,20 @@ def _oracle_line(O, img, nf, minlen, K=None, D=None, mask=None):
 def _exact(kl, desc, fn, rk, rd, rf):
     return (len(kl) == len(rk) and all((kl[f] == rk[f]).all() for f in rk.dtype.names) and (desc == rd).all()
             and (fn == rf).all())
+
+
+def _match(kl, desc, fn, rk, rd, rf, what=""):
+    """Exactness is the assertion; the tolerance is an explicit, reported escape."""
+    if _exact(kl, desc, fn, rk, rd, rf):
+        return True
+    if os.environ.get("PLSLAM_LINE_TOLERANCE") == "1":
+        print("PLSLAM_LINE_TOLERANCE=1: %s is NOT bit-exact, checking the float tolerance instead" % what)
+        _close(kl, desc, fn, rk, rd, rf, what)
+        return False
+    assert len(kl) == len(rk), "%s: %d vs %d keylines" % (what, len(kl), len(rk))
+    bad = [f for f in rk.dtype.names if not (kl[f] == rk[f]).all()]
+    raise AssertionError("%s: not bit-exact (keyline fields %s, %d descriptor bytes, %d line-equation terms differ)" %
+                         (what, bad, int((desc != rd).sum()), int((fn != rf).sum())))
 
 
 def _close(kl, desc, fn, rk, rd, rf, what=""):
@@ -122,11 +139,11 @@ def test_gpu_line_extract(plslam, oracle, synth, seed, rows, cols, nf, minlen, u
     kl, desc, fn = ex(img)
     gs = ex.read_segments(0)
     ex.close()
-    exact = _exact(kl, desc, fn, rk, rd, rf) and len(gs) == len(rs) and (gs == rs).all()
-    print("line parity seed %d: %s (%d segments, %d lines)" % (seed, "BIT-EXACT" if exact else "within tolerance", len(rs), len(rk)))
-    if not exact:
+    if os.environ.get("PLSLAM_LINE_TOLERANCE") == "1":
         assert abs(len(gs) - len(rs)) <= max(2, len(rs) // 100)
-        _close(kl, desc, fn, rk, rd, rf, "seed %d" % seed)
+    else:
+        assert len(gs) == len(rs) and (gs == rs).all(), "seed %d: LSD segments differ from the oracle" % seed
+    _match(kl, desc, fn, rk, rd, rf, "seed %d" % seed)
 
 
 @pytest.mark.gpu
@@ -150,17 +167,13 @@ def test_gpu_line_batch_and_mask(plslam, oracle, synth):
     nexact = 0
     for b in range(B):
         rk, rd, rf = oracle.line_extract(frames[b], 200, 0.0)
-        if _exact(kl[b, :n[b]], desc[b, :n[b]], fn[b, :n[b]], rk, rd, rf):
-            nexact += 1
-        else:
-            _close(kl[b, :n[b]], desc[b, :n[b]], fn[b, :n[b]], rk, rd, rf, "frame %d" % b)
+        nexact += _match(kl[b, :n[b]], desc[b, :n[b]], fn[b, :n[b]], rk, rd, rf, "frame %d" % b)
     print("batch: %d/%d frames bit-exact" % (nexact, B))
     mask = np.zeros((480, 640), np.uint8)                  # mask through the single-frame entry point
     mask[:, :320] = 255
     k1, d1, f1 = ex(frames[0], mask)
     rk, rd, rf = oracle.line_extract(frames[0], 200, 0.0, mask)
-    if not _exact(k1, d1, f1, rk, rd, rf):
-        _close(k1, d1, f1, rk, rd, rf, "mask")
+    _match(k1, d1, f1, rk, rd, rf, "mask")
     ex.close()
 
 
@@ -168,7 +181,6 @@ def test_gpu_line_batch_and_mask(plslam, oracle, synth):
 def test_gpu_line_golden(plslam, synth):
     """GPU vs the committed golden vectors (tests/golden/line_*.npz, tools/gen_golden.py)."""
     import glob
-    import os
     for path in sorted(glob.glob(os.path.join(_util.ROOT, "tests", "golden", "line_*.npz"))):
         g = np.load(path)
         rows, cols = int(g["rows"]), int(g["cols"])
@@ -177,5 +189,5 @@ def test_gpu_line_golden(plslam, synth):
         kl, desc, fn = ex(img)
         gs = ex.read_segments(0)
         ex.close()
-        if not (_exact(kl, desc, fn, g["keylines"], g["desc"], g["linefn"]) and gs.shape == g["segs"].shape and (gs == g["segs"]).all()):
-            _close(kl, desc, fn, g["keylines"], g["desc"], g["linefn"], os.path.basename(path))
+        assert gs.shape == g["segs"].shape and (gs == g["segs"]).all(), os.path.basename(path)
+        _match(kl, desc, fn, g["keylines"], g["desc"], g["linefn"], os.path.basename(path))

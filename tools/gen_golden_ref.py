@@ -84,6 +84,7 @@ ORB_CASES = [   # name, frame seed, rows, cols, nfeatures, scale, nlevels, iniTh
     ("s1_640x480", 1, 480, 640, 1000, 1.2, 8, 20, 7),
     ("s3_320x240", 3, 240, 320, 500, 1.2, 6, 20, 7),
     ("s7_200x160_sparse", 7, 160, 200, 300, 1.5, 4, 40, 12),   # every level >= 38 px (the GPU plan refuses smaller ones)
+    ("kitti_1241x376", 1000, 376, 1241, 2000, 1.2, 8, 20, 7),  # Examples/Monocular/KITTI00-02.yaml:32-51 (4 root nodes)
 ]
 
 
@@ -188,6 +189,7 @@ LINE_CASES = [   # name, frame seed, rows, cols, nLSDFeature, min_line_length, m
     ("s1_640x480", 1, 480, 640, 200, 0.0, False),
     ("s3_320x240_minlen", 3, 240, 320, 300, 25.0, False),
     ("s4_403x200_mask", 4, 200, 403, 120, 0.0, True),
+    ("kitti_1241x376", 1000, 376, 1241, 200, 0.0, False),     # BASELINE configs[4]'s frame shape
 ]
 
 
