@@ -236,6 +236,54 @@ PLH_API plh_status plh_bow_transform_batch_dev(const uint8_t* d_desc, const int3
                                                const float* d_weight, int L, int levelsup, int32_t* d_nid,
                                                int32_t* d_word, void* stream);
 
+/* The BowVector half of TemplatedVocabulary::transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1139-1205) on the
+ * word ids plh_bow_transform_batch_dev produced: per frame the distinct words of the live features in ascending order
+ * (std::map order) with their weights accumulated and normalised exactly as BowVector::addWeight / addIfNotExist /
+ * normalize do (BowVector.cpp:34-84; WordValue = double, sums in map order -> bit-identical values).
+ * d_word_weight[word id] = weight of the word's node (double); weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring:
+ * 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT (BowVector.h:36-53; ORBvoc is TF_IDF / L1_NORM).
+ * Outputs: d_bow_word / d_bow_value [batch][cap] (the first d_bow_n[b] entries of frame b), cap <= 8192. */
+PLH_API plh_status plh_bow_vector_batch_dev(const int32_t* d_word, const int32_t* d_n, int cap, int batch,
+                                            const double* d_word_weight, int weighting, int scoring, int32_t* d_bow_word,
+                                            double* d_bow_value, int32_t* d_bow_n, void* stream);
+
+/* DBoW2 vocabulary handle (ORBVocabulary = TemplatedVocabulary<FORB::TDescriptor, FORB>, include/ORBVocabulary.h:30-31), so that
+ * a C++ host gets ORBvoc.txt / ORBvoc.bin onto the device without any Python (System.cc:66-84 loads one of the two by suffix).
+ *   plh_vocab_load_text    TemplatedVocabulary::loadFromTextFile   (TemplatedVocabulary.h:1350-1438)
+ *   plh_vocab_load_binary  TemplatedVocabulary::loadFromBinaryFile (:1465-1506; file layout of saveToBinaryFile :1511-1536)
+ *   plh_vocab_save_binary  TemplatedVocabulary::saveToBinaryFile
+ *   plh_vocab_create       from arrays in the reference's node numbering: node 0 = root, arrays indexed by node id (entry 0
+ *                          ignored), parent[i] < i, weight in double.
+ * Node and word ids are the reference's (word ids count the leaves in node order). */
+typedef struct plh_vocab plh_vocab;
+typedef struct plh_vocab_info {
+  int32_t k, L, scoring, weighting;   /* m_k, m_L, m_scoring, m_weighting */
+  int32_t n_nodes, n_words;           /* m_nodes.size(), m_words.size() */
+  int32_t identity_ids;               /* 1: flat index == NodeId (children were contiguous in the file); 0: renumbered */
+} plh_vocab_info;
+PLH_API plh_status plh_vocab_load_text(const char* path, int device, plh_vocab** out);
+PLH_API plh_status plh_vocab_load_binary(const char* path, int device, plh_vocab** out);
+PLH_API plh_status plh_vocab_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                                    const uint8_t* is_leaf, const uint8_t* node_desc, const double* weight, int device,
+                                    plh_vocab** out);
+PLH_API plh_status plh_vocab_save_binary(const plh_vocab* v, const char* path);
+PLH_API plh_status plh_vocab_destroy(plh_vocab* v);
+PLH_API plh_status plh_vocab_get_info(const plh_vocab* v, plh_vocab_info* info);
+/* The handle's device arrays in the form plh_bow_transform_batch_dev takes (any pointer may be NULL); *d_node_id is NULL when
+ * the flat index is the NodeId, else the map flat index -> NodeId. */
+PLH_API plh_status plh_vocab_device_arrays(const plh_vocab* v, const uint8_t** d_node_desc, const int32_t** d_child_start,
+                                           const int32_t** d_child_count, const int32_t** d_word_id, const float** d_weight,
+                                           const int32_t** d_node_id);
+/* Host copies of the flat tree, n_nodes entries each (any pointer may be NULL). */
+PLH_API plh_status plh_vocab_read(const plh_vocab* v, uint8_t* node_desc, int32_t* child_start, int32_t* child_count,
+                                  int32_t* word_id, double* weight, int32_t* node_id);
+/* Frame::ComputeBoW for a batch (Frame.cc:906-913: transform(vCurrentDesc, mBowVec, mFeatVec, 4)): d_nid / d_word per
+ * descriptor as plh_bow_transform_batch_dev (FeatureVector = rows grouped by d_nid), BowVector as plh_bow_vector_batch_dev
+ * (pass NULL for the three bow outputs to skip it). */
+PLH_API plh_status plh_vocab_transform_batch_dev(const plh_vocab* v, const uint8_t* d_desc, const int32_t* d_n, int cap, int batch,
+                                                 int levelsup, int32_t* d_nid, int32_t* d_word, int32_t* d_bow_word,
+                                                 double* d_bow_value, int32_t* d_bow_n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Windowed (grid) searches  (Frame::AssignFeaturesToGrid*, GetFeaturesInArea*, ORBmatcher::SearchForInitialization /
  * SearchByProjection, LSDmatcher::SearchByProjection)

@@ -117,6 +117,14 @@ int  plo_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int3
 void plo_bow_transform(const uint8_t* desc, int n, const uint8_t* node_desc, const int32_t* child_start,
                        const int32_t* child_count, const int32_t* word_id, const float* weight, int L, int levelsup,
                        int32_t* nid_out, int32_t* word_out);   /* DBoW2 TemplatedVocabulary::transform */
+/* BowVector of TemplatedVocabulary::transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1139-1205) and the two
+ * vocabulary file formats (loadFromTextFile :1350-1438, loadFromBinaryFile :1465-1506) -- oracle/bow.cc */
+int  plo_bow_vector(const int32_t* word, int n, const double* word_weight, int weighting, int scoring, int32_t* out_word,
+                    double* out_value, int cap);
+int  plo_vocab_parse_text(const char* path, int32_t header[4], int32_t* parent, uint8_t* is_leaf, uint8_t* desc, double* weight,
+                          int cap);
+int  plo_vocab_parse_bin(const char* path, int32_t header[4], int32_t* parent, uint8_t* is_leaf, uint8_t* desc, double* weight,
+                         int cap);
 
 /* ---- Line extractor (reference src/LineExtractor.cpp + contrib LSDDetector / BinaryDescriptor) ---- */
 int  plo_lsd_detect(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap);  /* cv::LineSegmentDetector (STD) */

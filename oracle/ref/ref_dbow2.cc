@@ -32,6 +32,15 @@ void* ref_voc_load_text(const char* path) {
   if (!v->loadFromTextFile(path)) { delete v; return nullptr; }
   return v;
 }
+// TemplatedVocabulary::loadFromBinaryFile / saveToBinaryFile / saveToTextFile (TemplatedVocabulary.h:1465-1536, 1442-1462):
+// the file formats plh_vocab_load_binary / plh_vocab_load_text read.
+void* ref_voc_load_binary(const char* path) {
+  ORBVocabulary* v = new ORBVocabulary();
+  if (!v->loadFromBinaryFile(path)) { delete v; return nullptr; }
+  return v;
+}
+void ref_voc_save_binary(void* v, const char* path) { static_cast<ORBVocabulary*>(v)->saveToBinaryFile(path); }
+void ref_voc_save_text(void* v, const char* path) { static_cast<ORBVocabulary*>(v)->saveToTextFile(path); }
 void ref_voc_free(void* v) { delete static_cast<ORBVocabulary*>(v); }
 int ref_voc_size(void* v) { return (int)static_cast<ORBVocabulary*>(v)->size(); }
 

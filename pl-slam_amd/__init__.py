@@ -70,6 +70,17 @@ _SIGS = {
     "plh_line_search_double_batch_dev": ([_V, _V, _V, _V, _I, _I, _F, _F, _V, _V, _V, _Z, _V], _I),
     "plh_line_search_double_workspace": ([_I, _I], _Z),
     "plh_orb_search_by_bow_batch_dev": ([_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _F, _I, _V, _V, _V], _I),
+    "plh_bow_transform_batch_dev": ([_V, _V, _I, _I, _V, _V, _V, _V, _V, _I, _I, _V, _V, _V], _I),
+    "plh_bow_vector_batch_dev": ([_V, _V, _I, _I, _V, _I, _I, _V, _V, _V, _V], _I),
+    "plh_vocab_load_text": ([C.c_char_p, _I, _V], _I),
+    "plh_vocab_load_binary": ([C.c_char_p, _I, _V], _I),
+    "plh_vocab_create": ([_I, _I, _I, _I, _I, _V, _V, _V, _V, _I, _V], _I),
+    "plh_vocab_save_binary": ([_V, C.c_char_p], _I),
+    "plh_vocab_destroy": ([_V], _I),
+    "plh_vocab_get_info": ([_V, _V], _I),
+    "plh_vocab_device_arrays": ([_V, _V, _V, _V, _V, _V, _V], _I),
+    "plh_vocab_read": ([_V, _V, _V, _V, _V, _V, _V], _I),
+    "plh_vocab_transform_batch_dev": ([_V, _V, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_create": ([_V, _I, _I, _I, _I, _V], _I),
     "plh_line_destroy": ([_V], _I),
     "plh_line_capacity": ([_V], _I),
@@ -825,8 +836,6 @@ def bow_transform(descs, vocab, levelsup=4, device=0, lib=None):
     """Frame::ComputeBoW's per-feature part: DBoW2 transform of every descriptor set in `descs`
     (list of [n,32] u8).  Returns (nid[P,cap], word[P,cap]) with -1 for unused rows / stopped words."""
     L = load(lib)
-    L.plh_bow_transform_batch_dev.argtypes = [_V, _V, _I, _I, _V, _V, _V, _V, _V, _I, _I, _V, _V, _V]
-    L.plh_bow_transform_batch_dev.restype = _I
     D = _Dev(L, device)
     P = len(descs)
     cap = max(1, max(len(d) for d in descs))
@@ -837,6 +846,90 @@ def bow_transform(descs, vocab, levelsup=4, device=0, lib=None):
     _check(L, L.plh_bow_transform_batch_dev(_p(da), _p(dn), cap, P, _p(nd), _p(cs), _p(cc), _p(wi), _p(wt), vocab.L, levelsup,
                                             _p(dnid), _p(dword), C.c_void_p(D.stream())), "plh_bow_transform_batch_dev")
     return D.get(dnid), D.get(dword)
+
+
+class VocabInfo(C.Structure):
+    _fields_ = [("k", C.c_int32), ("L", C.c_int32), ("scoring", C.c_int32), ("weighting", C.c_int32), ("n_nodes", C.c_int32),
+                ("n_words", C.c_int32), ("identity_ids", C.c_int32)]
+
+
+class ORBVocabulary:
+    """ORB_SLAM2::ORBVocabulary (DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>, include/ORBVocabulary.h:30-31) held by the
+    C library: loadFromTextFile / loadFromBinaryFile / saveToBinaryFile are the reference's file formats
+    (TemplatedVocabulary.h:1350-1536), `transform` is Frame::ComputeBoW's call (Frame.cc:906-913) on a batch of
+    descriptor sets and returns both the FeatureVector node per feature and the BowVector."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = load(lib)
+        self.device = device
+        self.h = None
+
+    def _set(self, h):
+        self.close()
+        self.h = h
+        self.info = VocabInfo()
+        _check(self.lib, self.lib.plh_vocab_get_info(self.h, C.byref(self.info)), "plh_vocab_get_info")
+        return True
+
+    def loadFromTextFile(self, path):
+        h = C.c_void_p()
+        _check(self.lib, self.lib.plh_vocab_load_text(os.fsencode(path), self.device, C.byref(h)), "plh_vocab_load_text")
+        return self._set(h)
+
+    def loadFromBinaryFile(self, path):
+        h = C.c_void_p()
+        _check(self.lib, self.lib.plh_vocab_load_binary(os.fsencode(path), self.device, C.byref(h)), "plh_vocab_load_binary")
+        return self._set(h)
+
+    def create(self, k, L, parent, is_leaf, node_desc, weight, scoring=0, weighting=0):
+        parent = np.ascontiguousarray(parent, np.int32)
+        is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        node_desc = np.ascontiguousarray(node_desc, np.uint8)
+        weight = np.ascontiguousarray(weight, np.float64)
+        h = C.c_void_p()
+        _check(self.lib, self.lib.plh_vocab_create(k, L, scoring, weighting, len(parent), _p(parent), _p(is_leaf), _p(node_desc),
+                                                   _p(weight), self.device, C.byref(h)), "plh_vocab_create")
+        return self._set(h)
+
+    def saveToBinaryFile(self, path):
+        _check(self.lib, self.lib.plh_vocab_save_binary(self.h, os.fsencode(path)), "plh_vocab_save_binary")
+
+    def size(self):
+        return int(self.info.n_words)
+
+    def arrays(self):
+        """Host copies of the flat tree: dict(node_desc, child_start, child_count, word_id, weight (f64), node_id)."""
+        n = int(self.info.n_nodes)
+        a = dict(node_desc=np.zeros((n, 32), np.uint8), child_start=np.zeros(n, np.int32), child_count=np.zeros(n, np.int32),
+                 word_id=np.zeros(n, np.int32), weight=np.zeros(n, np.float64), node_id=np.zeros(n, np.int32))
+        _check(self.lib, self.lib.plh_vocab_read(self.h, _p(a["node_desc"]), _p(a["child_start"]), _p(a["child_count"]),
+                                                 _p(a["word_id"]), _p(a["weight"]), _p(a["node_id"])), "plh_vocab_read")
+        return a
+
+    def transform(self, descs, levelsup=4):
+        """descs: list of [n,32] u8.  Returns (nid[P,cap], word[P,cap], bow): bow[p] = (word ids, values f64) in map order."""
+        L, D = self.lib, _Dev(self.lib, self.device)
+        P = len(descs)
+        cap = max(1, max(len(d) for d in descs))
+        a, n = _pad_sets(descs, cap, 32, np.uint8)
+        da, dn = D.put(a), D.put(n)
+        dnid, dword, dbw = D.empty((P, cap), np.int32), D.empty((P, cap), np.int32), D.empty((P, cap), np.int32)
+        dbv, dbn = D.empty((P, cap), np.float64), D.empty((P,), np.int32)
+        _check(L, L.plh_vocab_transform_batch_dev(self.h, _p(da), _p(dn), cap, P, levelsup, _p(dnid), _p(dword), _p(dbw), _p(dbv),
+                                                  _p(dbn), C.c_void_p(D.stream())), "plh_vocab_transform_batch_dev")
+        bw, bv, bn = D.get(dbw), D.get(dbv), D.get(dbn)
+        return D.get(dnid), D.get(dword), [(bw[i, :bn[i]].copy(), bv[i, :bn[i]].copy()) for i in range(P)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.plh_vocab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LINEextractor:

@@ -5,7 +5,7 @@ independent frames that are already resident in HBM:
 
     ORBextractor::operator()            per frame                      (plh_orb_extract_batch_dev)
     LINEextractor::operator()           per frame, optional undistort  (plh_line_extract_batch_dev)
-    Frame::ComputeBoW (feature vector)  per frame                      (plh_bow_transform_batch_dev)
+    Frame::ComputeBoW (mFeatVec + mBowVec) per frame                   (plh_vocab_transform_batch_dev)
     ORBmatcher(0.7).SearchByBoW         frame b (as KeyFrame) -> frame b+1   (plh_orb_search_by_bow_kp_batch_dev)
     LSDmatcher(0.7).SearchDouble        frame b -> frame b+1                 (plh_line_search_double_batch_dev)
 
@@ -41,6 +41,9 @@ class FrontEndBatch:
         self.n = z((B1,), torch.int32)
         self.nid = z((B1, self.ocap), torch.int32)
         self.word = z((B1, self.ocap), torch.int32)
+        self.bow_word = z((B1, self.ocap), torch.int32)      # mBowVec: word ids in map order ...
+        self.bow_value = z((B1, self.ocap), torch.float64)   # ... and their L1-normalised tf-idf weights (WordValue = double)
+        self.bow_n = z((B1,), torch.int32)
         self.valid = torch.ones((batch, self.ocap), dtype=torch.uint8, device=self.dev)
         self.m_orb = z((batch, self.ocap), torch.int32)
         self.nm_orb = z((batch,), torch.int32)
@@ -61,12 +64,15 @@ class FrontEndBatch:
         self.ev_line = torch.cuda.Event()
         self.overlap = True    # False: both halves on the caller's stream (per-kernel timing without interference)
         self.ev_free = None    # optional event a consumer records when it has read this part's records (see gather())
-        helper = P._Dev(self.lib, device)
-        self.voc_dev = vocab.device_arrays(helper)
+        # the vocabulary lives in the C library (plh_vocab): one handle per vocabulary object and device
+        if getattr(vocab, "_plh_handle", None) is None or vocab._plh_handle.device != device:
+            hv = P.ORBVocabulary(device=device)
+            parent, leaf = vocab.tree_arrays()
+            hv.create(vocab.k, vocab.L, parent, leaf, vocab.node_desc, vocab.weight64)
+            vocab._plh_handle = hv
+        self.hvoc = vocab._plh_handle
         L = self.lib
         V, I, F, Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
-        L.plh_bow_transform_batch_dev.argtypes = [V, V, I, I, V, V, V, V, V, I, I, V, V, V]
-        L.plh_bow_transform_batch_dev.restype = I
         L.plh_orb_search_by_bow_kp_batch_dev.argtypes = [V] * 9 + [I, I, I, F, I, V, V, V]
         L.plh_orb_search_by_bow_kp_batch_dev.restype = I
 
@@ -99,7 +105,6 @@ class FrontEndBatch:
         """ORB half: ORBextractor batch + BoW feature vectors + SearchByBoW against the next frame, on its own stream."""
         P, L, B, t = self.P, self.lib, self.B, self.torch
         p = P._p
-        nd, cs, cc, wi, wt = self.voc_dev
         so = self.orb_stream if self.overlap else main
         if self.overlap:
             so.wait_event(ev_start)
@@ -110,8 +115,9 @@ class FrontEndBatch:
         with t.cuda.stream(so):
             for buf in (self.kps, self.desc, self.n):
                 buf[B].copy_(buf[0], non_blocking=True)
-        P._check(L, L.plh_bow_transform_batch_dev(p(self.desc), p(self.n), self.ocap, B + 1, p(nd), p(cs), p(cc), p(wi), p(wt),
-                                                  self.vocab.L, 4, p(self.nid), p(self.word), sp), "plh_bow_transform_batch_dev")
+        P._check(L, L.plh_vocab_transform_batch_dev(self.hvoc.h, p(self.desc), p(self.n), self.ocap, B + 1, 4, p(self.nid),
+                                                    p(self.word), p(self.bow_word), p(self.bow_value), p(self.bow_n), sp),
+                 "plh_vocab_transform_batch_dev")
         P._check(L, L.plh_orb_search_by_bow_kp_batch_dev(p(self.desc), p(self.kps), p(self.nid), p(self.valid), p(self.n),
                                                          p(self.desc[1:]), p(self.kps[1:]), p(self.nid[1:]), p(self.n[1:]),
                                                          self.ocap, B, 50, 0.7, 1, p(self.m_orb), p(self.nm_orb), sp),
@@ -145,6 +151,8 @@ class FrontEndBatch:
         kps = self.kps[:B].cpu().numpy().view(np.uint8).reshape(B, self.ocap, 28).copy().view(P.KP_DTYPE).reshape(B, self.ocap)
         kl = self.kl[:B].cpu().numpy().view(np.uint8).reshape(B, self.lcap, 68).copy().view(P.KL_DTYPE).reshape(B, self.lcap)
         return dict(n=self.n[:B].cpu().numpy(), kps=kps, desc=self.desc[:B].cpu().numpy(), nid=self.nid[:B].cpu().numpy(),
+                    word=self.word[:B].cpu().numpy(), bow_word=self.bow_word[:B].cpu().numpy(),
+                    bow_value=self.bow_value[:B].cpu().numpy(), bow_n=self.bow_n[:B].cpu().numpy(),
                     nl=self.nl[:B].cpu().numpy(), kl=kl, ldesc=self.ldesc[:B].cpu().numpy(), lfn=self.lfn[:B].cpu().numpy(),
                     m_orb=self.m_orb.cpu().numpy(), nm_orb=self.nm_orb.cpu().numpy(), m_line=self.m_line.cpu().numpy(),
                     nm_line=self.nm_line.cpu().numpy())

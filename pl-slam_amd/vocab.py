@@ -14,7 +14,9 @@ class Vocabulary:
         self.child_start = np.ascontiguousarray(child_start, np.int32)
         self.child_count = np.ascontiguousarray(child_count, np.int32)
         self.word_id = np.ascontiguousarray(word_id, np.int32)
-        self.weight = np.ascontiguousarray(weight, np.float32)
+        self.weight64 = np.ascontiguousarray(weight, np.float64)        # WordValue is double in DBoW2
+        self.weight = self.weight64.astype(np.float32)                  # the descent only tests `w > 0`
+        self.weight[(self.weight64 > 0) & ~(self.weight > 0)] = np.finfo(np.float32).tiny
         self.k, self.L = k, L
         self._dev = None
 
@@ -23,8 +25,9 @@ class Vocabulary:
         return len(self.child_start)
 
     @staticmethod
-    def synthetic(seed=102, k=10, L=6, synth=None, stop_fraction=0.0):
-        """Complete k-ary tree of depth L in BFS numbering (children of node n: k*n+1 .. k*n+k)."""
+    def synthetic(seed=102, k=10, L=6, synth=None, stop_fraction=0.0, idf=False):
+        """Complete k-ary tree of depth L in BFS numbering (children of node n: k*n+1 .. k*n+k).  idf=True gives the words
+        idf-like weights with full double mantissas (ORBvoc's are log(N / n_i)) instead of 1.0."""
         if synth is None:
             raise ValueError("pass the synth module (SplitMix64 generator)")
         rng = synth.SplitMix64(seed)
@@ -43,7 +46,9 @@ class Vocabulary:
         child_start = np.where(idx < first_leaf, k * idx + 1, 0).astype(np.int32)
         child_count = np.where(idx < first_leaf, k, 0).astype(np.int32)
         word_id = np.where(idx >= first_leaf, idx - first_leaf, -1).astype(np.int32)
-        weight = np.ones(n_nodes, np.float32)
+        weight = np.ones(n_nodes, np.float64)
+        if idf:
+            weight = np.log(1.0 + 1.0 / (1e-3 + rng.uniform(n_nodes))) * 3.0
         if stop_fraction > 0:
             stopped = rng.uniform(n_nodes) < stop_fraction
             weight[stopped & (idx >= first_leaf)] = 0.0
@@ -65,7 +70,7 @@ class Vocabulary:
         lines = ["%d %d %d %d" % (self.k, self.L, scoring, weighting)]
         for i in range(1, n):
             lines.append("%d %d %s %r" % (parent[i], 1 if self.child_count[i] == 0 else 0,
-                                          " ".join(str(int(b)) for b in self.node_desc[i]), float(self.weight[i])))
+                                          " ".join(str(int(b)) for b in self.node_desc[i]), float(self.weight64[i])))
         with open(path, "w") as f:
             f.write("\n".join(lines))   # no trailing newline: the reference's eof loop would read one node too many
 
@@ -79,7 +84,7 @@ class Vocabulary:
         parent = np.zeros(n, np.int64)
         leaf = np.zeros(n, bool)
         desc = np.zeros((n, 32), np.uint8)
-        weight = np.zeros(n, np.float32)
+        weight = np.zeros(n, np.float64)
         for i, r in enumerate(rows, start=1):
             parent[i], leaf[i] = int(r[0]), int(r[1]) > 0
             desc[i] = [int(v) for v in r[2:34]]
@@ -96,6 +101,22 @@ class Vocabulary:
         word_id = np.full(n, -1, np.int32)
         word_id[leaf] = np.arange(int(leaf.sum()), dtype=np.int32)
         return Vocabulary(desc, child_start, child_count, word_id, weight, k, L)
+
+    def tree_arrays(self):
+        """(parent, is_leaf) in node order, as plh_vocab_create takes them."""
+        n = self.n_nodes
+        parent = np.zeros(n, np.int32)
+        for p in range(n):
+            c0, cc = int(self.child_start[p]), int(self.child_count[p])
+            parent[c0:c0 + cc] = p
+        parent[0] = -1
+        return parent, (self.child_count == 0).astype(np.uint8)
+
+    def word_weight(self):
+        """weight (f64) by word id."""
+        ww = np.zeros(max(1, int((self.word_id >= 0).sum())), np.float64)
+        ww[self.word_id[self.word_id >= 0]] = self.weight64[self.word_id >= 0]
+        return ww
 
     def device_arrays(self, dev):
         """Upload once per device helper (`plslam_amd._Dev`)."""

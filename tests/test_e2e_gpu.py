@@ -26,7 +26,7 @@ def test_front_end_batch_vs_oracle(plslam, oracle, synth, rows, cols, nfeat, K, 
     PL = _util._load("plslam_amd_pipeline", os.path.join(_util.ROOT, "pl-slam_amd", "pipeline.py"))
     B = 6
     frames = synth.make_frames(seed, B, rows, cols)
-    voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=synth)
+    voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=synth, idf=True)
     fe = PL.FrontEndBatch(plslam, voc, B, rows, cols, nfeat, 8, 200, 0.0, K, D)
     d = torch.from_numpy(frames).cuda()
     fe.step(d)
@@ -37,6 +37,8 @@ def test_front_end_batch_vs_oracle(plslam, oracle, synth, rows, cols, nfeat, K, 
     L = O.lib()
     L.plo_bow_transform.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.plo_bow_transform.restype = None
+    L.plo_bow_vector.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.plo_bow_vector.restype = C.c_int
     orb = O.OrbOracle(nfeat, 1.2, 8, 20, 7)
     ref = []
     for b in range(B):
@@ -50,7 +52,10 @@ def test_front_end_batch_vs_oracle(plslam, oracle, synth, rows, cols, nfeat, K, 
         word = np.zeros(n, np.int32)
         L.plo_bow_transform(O._p(rd), n, O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id),
                             O._p(voc.weight), voc.L, 4, O._p(nid), O._p(word))
-        assert (r["nid"][b, :n] == nid).all()
+        assert (r["nid"][b, :n] == nid).all() and (r["word"][b, :n] == word).all()
+        bw, bv = np.zeros(n, np.int32), np.zeros(n, np.float64)      # mBowVec (TF_IDF / L1_NORM like ORBvoc)
+        m = L.plo_bow_vector(O._p(word), n, O._p(voc.word_weight()), 0, 0, O._p(bw), O._p(bv), n)
+        assert r["bow_n"][b] == m and (r["bow_word"][b, :m] == bw[:m]).all() and (r["bow_value"][b, :m] == bv[:m]).all()
         lk, ld, lf, _ = _oracle_line(O, frames[b], 200, 0.0, *((K, D) if any(D) else (None, None)))
         nl = r["nl"][b]
         _match(r["kl"][b, :nl], r["ldesc"][b, :nl], r["lfn"][b, :nl], lk, ld, lf, "frame %d" % b)
@@ -93,7 +98,8 @@ def test_pipelined_sub_batches_match_plain_batches(plslam, synth):
         assert (rp["n"][sl] == r["n"]).all() and (rp["nl"][sl] == r["nl"]).all()
         for key in r:       # rows beyond the per-frame counts are unspecified: compare the live ones
             for i in range(Bp):
-                cnt = {"kps": r["n"][i], "desc": r["n"][i], "nid": r["n"][i], "kl": r["nl"][i], "ldesc": r["nl"][i],
+                cnt = {"kps": r["n"][i], "desc": r["n"][i], "nid": r["n"][i], "word": r["n"][i], "bow_word": r["bow_n"][i],
+                       "bow_value": r["bow_n"][i], "kl": r["nl"][i], "ldesc": r["nl"][i],
                        "lfn": r["nl"][i], "m_orb": r["n"][(i + 1) % Bp], "m_line": r["nl"][i]}.get(key)
                 a, b = rp[key][sl][i], r[key][i]
                 if cnt is not None:

@@ -30,6 +30,10 @@ def ref_lib():
     L.ref_voc_size.argtypes = [V]
     L.ref_voc_transform_each.argtypes = [V, V, I, I, V, V, V]
     L.ref_voc_transform.argtypes = [V, V, I, I, V, V, I, V]
+    L.ref_voc_load_binary.argtypes = [C.c_char_p]
+    L.ref_voc_load_binary.restype = V
+    L.ref_voc_save_binary.argtypes = [V, C.c_char_p]
+    L.ref_voc_save_text.argtypes = [V, C.c_char_p]
     return L
 
 
@@ -55,6 +59,95 @@ def reference_transform(L, voc, desc, levelsup):
         finally:
             L.ref_voc_free(h)
     return word, weight, node, fnode, bw[:m], bv[:m]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Vocabulary FILES written by the reference (saveToTextFile / saveToBinaryFile) and what its transform makes of them.
+#   A  ref_voc_<name>_src.txt   the synthetic tree written by pl-slam_amd/vocab.py (weights with all 17 digits)
+#   B  ref_voc_<name>_ref.txt   A loaded by the reference and written back by ITS saveToTextFile (6-digit weights)
+#   C  ref_voc_<name>_ref.bin   ... by ITS saveToBinaryFile (float weights)
+# and the per-feature word / node plus the BowVector (std::map order, doubles) the reference computes after loading each.
+# "dfs": the same kind of tree with its nodes numbered depth first, i.e. children NOT contiguous in the file.
+# ---------------------------------------------------------------------------------------------------------------
+VOC_CASES = [   # name, seed, k, L, stop fraction, dfs order, descriptor seed, n, levelsup, scoring, weighting
+    ("k5L3", 31, 5, 3, 0.05, False, 41, 400, 1, 0, 0),       # L1_NORM / TF_IDF like ORBvoc
+    ("dfs_k4L3", 32, 4, 3, 0.0, True, 42, 300, 2, 0, 0),
+    ("k6L2_l2_tf", 33, 6, 2, 0.1, False, 43, 250, 1, 1, 1),  # L2_NORM / TF
+    ("k3L4_dot_bin", 34, 3, 4, 0.0, False, 44, 200, 2, 5, 3),  # DOT_PRODUCT (no normalisation) / BINARY
+]
+
+
+def write_text_dfs(voc, path, scoring, weighting):
+    """The tree of `voc` with depth-first node numbering (a legal DBoW2 text file whose children are not contiguous)."""
+    lines = ["%d %d %d %d" % (voc.k, voc.L, scoring, weighting)]
+    new_id = {0: 0}
+
+    def visit(node):
+        for c in range(int(voc.child_start[node]), int(voc.child_start[node]) + int(voc.child_count[node])):
+            new_id[c] = len(new_id)
+            lines.append("%d %d %s %r" % (new_id[node], 1 if voc.child_count[c] == 0 else 0,
+                                          " ".join(str(int(b)) for b in voc.node_desc[c]), float(voc.weight64[c])))
+            visit(c)
+    visit(0)
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+
+
+def voc_case_inputs(S, VM, seed, k, Lv, stop, dseed, n):
+    voc = VM.Vocabulary.synthetic(seed, k=k, L=Lv, synth=S, stop_fraction=stop, idf=True)
+    a, _, _ = S.make_descriptor_sets(dseed, n)
+    first_leaf = (k ** Lv - 1) // (k - 1)
+    rng = S.SplitMix64(dseed + 1)
+    pick = rng.randint(n - n // 3, first_leaf, voc.n_nodes)      # two thirds near leaves (several features per word)
+    noisy = voc.node_desc[pick] ^ np.packbits((rng.uniform(len(pick) * 256) < 0.02).reshape(-1, 256), axis=1, bitorder="little")
+    return voc, np.ascontiguousarray(np.concatenate([a[: n // 3], noisy]), np.uint8)
+
+
+def reference_voc_outputs(L, h, desc, levelsup):
+    n = len(desc)
+    word, node, fnode = (np.zeros(n, np.int32) for _ in range(3))
+    weight = np.zeros(n, np.float64)
+    L.ref_voc_transform_each(h, p(desc), n, levelsup, p(word), p(weight), p(node))
+    bw, bv = np.zeros(n, np.int32), np.zeros(n, np.float64)
+    m = L.ref_voc_transform(h, p(desc), n, levelsup, p(bw), p(bv), n, p(fnode))
+    return dict(word=word, weight=weight, node=node, feat_node=fnode, bow_word=bw[:m].copy(), bow_value=bv[:m].copy())
+
+
+def gen_vocab_files(S, VM, L, out):
+    g = {}
+    for name, seed, k, Lv, stop, dfs, dseed, n, up, scoring, weighting in VOC_CASES:
+        voc, desc = voc_case_inputs(S, VM, seed, k, Lv, stop, dseed, n)
+        a = os.path.join(out, "ref_voc_%s_src.txt" % name)
+        b = os.path.join(out, "ref_voc_%s_ref.txt" % name)
+        c = os.path.join(out, "ref_voc_%s_ref.bin" % name)
+        if dfs:
+            write_text_dfs(voc, a, scoring, weighting)
+        else:
+            voc.save_text(a, scoring, weighting)
+        h = L.ref_voc_load_text(a.encode())
+        assert h
+        for key, v in reference_voc_outputs(L, h, desc, up).items():
+            g["%s_A_%s" % (name, key)] = v
+        L.ref_voc_save_text(h, b.encode())
+        L.ref_voc_save_binary(h, c.encode())
+        L.ref_voc_free(h)
+        # the reference's text writer ends every line with a newline, which its own reader turns into a stray node with an
+        # uninitialised parent (undefined behaviour): strip the final newline before handing the file back to it
+        txt = open(b).read().rstrip("\n")
+        stripped = b + ".tmp"
+        open(stripped, "w").write(txt)
+        h = L.ref_voc_load_text(stripped.encode())
+        os.remove(stripped)
+        for key, v in reference_voc_outputs(L, h, desc, up).items():
+            g["%s_B_%s" % (name, key)] = v
+        L.ref_voc_free(h)
+        h = L.ref_voc_load_binary(c.encode())
+        for key, v in reference_voc_outputs(L, h, desc, up).items():
+            g["%s_C_%s" % (name, key)] = v
+        g["%s_C_size" % name] = np.int32(L.ref_voc_size(h))
+        L.ref_voc_free(h)
+        print("vocabulary files", name, "bow entries", len(g["%s_A_bow_word" % name]), len(g["%s_C_bow_word" % name]))
+    np.savez_compressed(os.path.join(out, "ref_voc.npz"), **g)
 
 
 CASES = [   # name, vocabulary seed, k, L, stop fraction, descriptor seed, n, levelsup
@@ -1036,6 +1129,7 @@ def main():
                             levelsup=up, word=word, weight=weight, node=node, feat_node=fnode, bow_word=bw, bow_value=bv,
                             pair_a=ia.astype(np.int32), pair_b=ib.astype(np.int32), pair_dist=dist)
         print(name, "words", len(bw), "stopped", int((fnode < 0).sum()), "nodes", len(np.unique(node)))
+    gen_vocab_files(S, VM, L, out)
     gen_orb(S, out)
     gen_line_grid(S, out)
     gen_lines(S, out)
