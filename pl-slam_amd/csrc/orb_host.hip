@@ -14,7 +14,7 @@ namespace plh {
 void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds, hipStream_t s);
 void launch_fast_strips(const OrbDeviceArgs& a, size_t lds, hipStream_t s);
 size_t fast_strip_lds_bytes(int width, int ch);
-constexpr int FAST_STRIP_MAX_W = 330;
+constexpr int FAST_STRIP_MAX_W = 200;   // measured on MI355X (1024 frames): 100 -> 3.13 ms, 140 -> 2.82, 200 -> 2.64, 270 -> 3.15, 330 -> 3.24, 660 -> 3.44
 size_t octree_lds_bytes(int nodeCap);
 void launch_octree(const OrbDeviceArgs& a, int nodeCapMax, hipStream_t s);
 void launch_orient_brief(const OrbDeviceArgs& a, plh_keypoint* kps, uint8_t* desc, int* nOut, int cap, hipStream_t s);
@@ -220,8 +220,13 @@ plh_status build_plan(plh_orb* h) {
     // strips: consecutive cells of one cell row (same y0) -> one k_fast_strips block
     for (int ci = L.cellBase; ci < (int)h->cells.size();) {
       int cj = ci;   // at most ~FAST_STRIP_MAX_W columns per strip: small LDS tiles keep >= 5 blocks per CU resident
+      static const int stripW = [] {   // tuning knob for experiments (plan time only)
+        const char* e = getenv("PLH_FAST_STRIP_W");
+        const int v = e ? atoi(e) : 0;
+        return v >= 64 && v <= 1000 ? v : FAST_STRIP_MAX_W;
+      }();
       while (cj < (int)h->cells.size() && h->cells[cj].y0 == h->cells[ci].y0 &&
-             (cj == ci || h->cells[cj].x0 + h->cells[cj].cw - h->cells[ci].x0 <= FAST_STRIP_MAX_W)) cj++;
+             (cj == ci || h->cells[cj].x0 + h->cells[cj].cw - h->cells[ci].x0 <= stripW)) cj++;
       OrbStrip st;
       st.level = (short)l; st.nCells = (short)(cj - ci); st.cellFirst = ci;
       st.x0 = h->cells[ci].x0; st.y0 = h->cells[ci].y0;

@@ -114,42 +114,42 @@ __global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// FAST-9/16 corner measure.  For ring differences d[i] = v - p[i]:
-//   M = max( max_i min(d[i..i+8]),  max_i min(-d[i..i+8]) )
-// pixel is a corner at threshold t  <=>  M > t ; cornerScore<16>() = M - 1 for any corner
-// (the `threshold` floor inside cornerScore only matters for non-corners).  The sliding 9-window
-// min/max over the circular 16-ring is built from windows of 3 (3-input min/max instructions).
+// FAST-9/16.  For ring differences d[i] = v - p[i]:
+//   dark = max_i min(d[i..i+8]),  bright = max_i min(-d[i..i+8]),  M = max(dark, bright)
+// pixel is a corner at threshold t  <=>  M > t ; cornerScore<16>() = M - 1 for any corner (the `threshold` floor inside
+// cornerScore only matters for non-corners).  A pixel cannot be a dark and a bright corner at once (9 + 9 > 16), so only
+// the side a pixel can be a corner on is ever measured: fast_arc_side(sv, ns, p) = max_i min_j (sv + ns * p[i+j]) with
+// (sv, ns) = (v, -1) for the dark side and (-v, +1) for the bright side.  The sliding 9-window minimum over the circular
+// 16-ring is built from windows of 3 (v_min3), the maximum over the 16 arcs is a v_max3 tree: 16 + 16 + 16 + 8 instructions.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_arc_measure(int v, const int p[16]) {
-  int d[16], lo3[16], hi3[16];
+__device__ __forceinline__ int fast_arc_side(int sv, int ns, const int p[16]) {
+  int x[16], lo3[16], lo9[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) d[i] = v - p[i];
+  for (int i = 0; i < 16; i++) x[i] = __mul24(ns, p[i]) + sv;      // v_mad_i32_i24
 #pragma unroll
-  for (int i = 0; i < 16; i++) {   // windows of 3, then 3 windows of 3 = the 9-arc starting at i (v_min3 / v_max3)
-    lo3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
-    hi3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
-  }
-  int dark = -512, bright = 512;
+  for (int i = 0; i < 16; i++) lo3[i] = min(min(x[i], x[(i + 1) & 15]), x[(i + 2) & 15]);
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    dark = max(dark, min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]));
-    bright = min(bright, max(max(hi3[i], hi3[(i + 3) & 15]), hi3[(i + 6) & 15]));
-  }
-  return max(dark, -bright);
+  for (int i = 0; i < 16; i++) lo9[i] = min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]);
+  int a[6];
+#pragma unroll
+  for (int i = 0; i < 5; i++) a[i] = max(max(lo9[3 * i], lo9[3 * i + 1]), lo9[3 * i + 2]);
+  a[5] = lo9[15];
+  return max(max(max(a[0], a[1]), a[2]), max(max(a[3], a[4]), a[5]));
 }
 
 // One block per (row of FAST cells, frame).  The rows of the level that the cell row covers are staged in LDS with
-// aligned dword copies; every lane then works on groups of 4 horizontally adjacent pixels held in one dword:
-//   1. compass quick test (every 9-arc contains one pixel of each antipodal pair) on the packed bytes; pixels that
-//      pass are queued per wave and the full 16-ring arc measure runs on dense batches of 64 queued pixels, so the
-//      expensive part never executes with mostly idle lanes,
-//   2. 3x3 NMS on the score tile, where everything outside the pixel's own cell window counts as score 0 exactly
-//      like a per-cell cv::FAST call,
-//   3. one wavefront per cell emits the survivors in raster order; a cell without a survivor at iniThFAST falls
-//      back to minThFAST (ORBextractor.cc:808-816).
-// Tile column c holds level column xa + c with xa = (x0 & ~3) - 4, so pixel groups are dword aligned in the tile,
-// the score tile and the flag tile (which reuses the image tile's memory).
-constexpr int FAST_QCAP = 128;   // per-wave queue of pixels that passed the quick test
+// aligned dword copies; then
+//   1. compass quick test per pixel, class consistent (a dark corner needs a darker pixel in each of the antipodal pairs
+//      (0, 8) and (4, 12), a bright corner a brighter one): byte compares straight out of the packed dwords (SDWA) whose
+//      results are wave masks, combined on the scalar unit.  Passing (pixel, side) pairs are queued per wave and the arc
+//      measure of that side runs on dense batches of 64; a corner stores its score byte and sets its bit in a corner bitmap;
+//   2. the corner bitmap is compacted into a list (in the dead image tile) and the 3x3 NMS runs on dense batches of corners,
+//      everything outside the pixel's own cell window counting as score 0 exactly like a per-cell cv::FAST call; survivors
+//      set a bit in the "any" (>= minThFAST) / "hi" (>= iniThFAST) bitmaps;
+//   3. one wavefront per cell, one lane per row of the cell window, emits the survivors in raster order from the bitmap
+//      the cell uses: "hi" if the cell has a survivor at iniThFAST, else the minThFAST fallback (ORBextractor.cc:808-816).
+// Tile column c holds level column xa + c with xa = (x0 & ~3) - 4, so pixel groups are dword aligned in the tile.
+constexpr int FAST_QCAP = 320;   // per-wave queue of (pixel, side) pairs that passed the quick test (63 + 2 * 128 + slack)
 #if defined(HIPEMU)
 #define ORB_WAVE_SYNC() hipemu::wave_barrier()
 #else
@@ -161,7 +161,11 @@ __device__ __forceinline__ unsigned align_bytes(unsigned hi, unsigned lo, int sh
   return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * sh));
 }
 
-__device__ __forceinline__ void fast_score_pixel(const uint8_t* tile, int TP, uint8_t* sc, int r, int cx, int tlo) {
+// queue entry: row (tile) : 8 | bright side : 1 | tile column : 16
+__device__ __forceinline__ void fast_score_entry(const uint8_t* tile, int TP, uint8_t* sc, unsigned* cmask, int W32, unsigned e,
+                                                 int tlo) {
+  const int r = (int)(e >> 24), cx = (int)(e & 0xffffu);
+  const bool bright = (e >> 16) & 1u;
   const uint8_t* t = tile + r * TP + cx;
   const int v = t[0];
   int p[16];
@@ -169,14 +173,18 @@ __device__ __forceinline__ void fast_score_pixel(const uint8_t* tile, int TP, ui
   p[4] = t[3];            p[5] = t[-TP + 3];      p[6] = t[-2 * TP + 2];  p[7] = t[-3 * TP + 1];
   p[8] = t[-3 * TP];      p[9] = t[-3 * TP - 1];  p[10] = t[-2 * TP - 2]; p[11] = t[-TP - 3];
   p[12] = t[-3];          p[13] = t[TP - 3];      p[14] = t[2 * TP - 2];  p[15] = t[3 * TP - 1];
-  const int M = fast_arc_measure(v, p);
-  if (M > tlo) sc[(r - 2) * TP + cx] = (uint8_t)(M - 1);   // score row rr = r - 3 is stored at sc row rr + 1
+  const int M = fast_arc_side(bright ? -v : v, bright ? 1 : -1, p);
+  if (M > tlo) {
+    sc[(r - 2) * TP + cx] = (uint8_t)(M - 1);   // score row rr = r - 3 is stored at sc row rr + 1
+    atomicOr(&cmask[(r - 3) * W32 + (cx >> 5)], 1u << (cx & 31));
+  }
 }
 
 __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   __shared__ unsigned s_queue[4][FAST_QCAP];
   __shared__ int s_hi[64];
+  __shared__ int s_total, s_listN;
 
   // XCD-aware decode: block L runs on XCD (L % 8); keep all strips of a frame on one XCD so the overlapping halos
   // and the level rows are served from that XCD's L2.
@@ -192,14 +200,16 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int xa = (st.x0 & ~3) - 4;                       // level column of tile column 0
   const int TP = ((st.xEnd + 4 - xa + 3) & ~3) + 4;      // tile pitch (bytes), multiple of 4
+  const int W32 = (TP + 31) >> 5;                        // bitmap words per row
   const int ch = st.ch, eh = ch - 6;
   const int ex0 = st.x0 + 3, ex1 = st.xEnd - 3;          // evaluated columns [ex0, ex1), level coordinates
+  const int tileBytes = (ch * TP + 15) & ~15;
   uint8_t* tile = smem;                                  // [ch][TP]
-  uint8_t* sc = smem + ((ch * TP + 15) & ~15);           // [eh + 2][TP], rows 0 and eh + 1 stay zero
-  uint8_t* fl = tile;                                    // [eh][TP], reuses the image tile after the scores are done
+  uint8_t* sc = smem + tileBytes;                        // [eh + 2][TP], rows 0 and eh + 1 stay zero
+  unsigned* cmask = reinterpret_cast<unsigned*>(sc + (((max(eh, 0) + 2) * TP + 15) & ~15));   // [eh][W32] corner bitmap
   const int tlo = min(a.iniTh, a.minTh);
 
-  // ---- stage the rows (dword copies when the source rows are dword aligned), clear the score tile
+  // ---- stage the rows (dword copies when the source rows are dword aligned), clear the score tile and the bitmap
   {
     const int nd = TP >> 2;
     const int xmaxd = (lv.pitch - xa - 4) >> 2;          // dwords whose aligned pair stays inside the source row
@@ -215,128 +225,169 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
       }
       reinterpret_cast<unsigned*>(tile)[r * nd + d] = v;
     }
-    const int ns = ((eh + 2) * TP) >> 2;
-    for (int i = tid; i < ns; i += 256) reinterpret_cast<unsigned*>(sc)[i] = 0u;
+    const int ns = (((max(eh, 0) + 2) * TP + 15) & ~15) >> 2;
+    for (int i = tid; i < ns + max(eh, 0) * W32; i += 256) reinterpret_cast<unsigned*>(sc)[i] = 0u;   // sc and cmask are adjacent
     if (tid < 64) s_hi[tid] = 0;
+    if (tid == 0) { s_total = 0; s_listN = 0; }
   }
   __syncthreads();
 
-  // ---- scores
+  // ---- scores.  A wave owns rows wv, wv + 4, ..; its (row, pixel group) items are laid out densely over the lanes, so a
+  // strip whose width is not a multiple of 256 pixels still fills the wavefront.
   const int gx0 = (ex0 - xa) >> 2, gx1 = (ex1 - 1 - xa) >> 2;   // dword columns that contain evaluated pixels
   const int ngx = (eh > 0 && ex1 > ex0) ? gx1 - gx0 + 1 : 0;
+  const int nrw = eh > wv ? (eh - wv + 3) >> 2 : 0;             // rows of this wave
+  const int nitems = nrw * ngx;
+  const unsigned rowMul = 65536u / (unsigned)max(ngx, 1) + 1u;  // it / ngx == (it * rowMul) >> 16 for it < 16384
   unsigned* myq = s_queue[wv];
   int qn = 0;
-  for (int rr = wv; rr < eh; rr += 4)
-   for (int gb = 0; gb < ngx; gb += 64) {
-    const int gxi = gb + lane;
-    unsigned pass = 0;
-    const int r = rr + 3, cx = (gx0 + gxi) << 2;
-    if (gxi < ngx) {
-      const uint8_t* t = tile + r * TP + cx;
-      const unsigned C = ld_u32(t), Lw = ld_u32(t - 4), R = ld_u32(t + 4), U = ld_u32(t - 3 * TP), D = ld_u32(t + 3 * TP);
-      const unsigned P12 = align_bytes(C, Lw, 1), P4 = align_bytes(R, C, 3);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int x = xa + cx + k;
-        const int v = (C >> (8 * k)) & 255;
-        const int d0 = v - (int)((D >> (8 * k)) & 255), d8 = v - (int)((U >> (8 * k)) & 255);
-        const int d4 = v - (int)((P4 >> (8 * k)) & 255), d12 = v - (int)((P12 >> (8 * k)) & 255);
-        const bool q0 = (abs(d0) > tlo) || (abs(d8) > tlo);
-        const bool q4 = (abs(d4) > tlo) || (abs(d12) > tlo);
-        if (q0 && q4 && x >= ex0 && x < ex1) pass |= 1u << k;
-      }
-    }
-    // queue the passing pixels of this wave (row : 8 | column : 16), drain dense batches of 64
+  for (int ib = 0; ib < nitems; ib += 64) {
+    const int it = ib + lane;
+    const int j = (int)(((unsigned)it * rowMul) >> 16);
+    const int g = it - j * ngx;
+    const bool live = it < nitems;
+    const int r = live ? wv + 4 * j + 3 : 3;
+    const int cx = live ? (gx0 + g) << 2 : gx0 << 2;
+    const int lo = live ? ex0 - (xa + cx) : 4, hi = ex1 - (xa + cx);   // evaluated pixels of the group: lo <= k < hi
+    const uint8_t* t = tile + r * TP + cx;
+    const unsigned C = ld_u32(t), Lw = ld_u32(t - 4), R = ld_u32(t + 4), U = ld_u32(t - 3 * TP), D = ld_u32(t + 3 * TP);
+    const unsigned P12 = align_bytes(C, Lw, 1), P4 = align_bytes(R, C, 3);
+    const unsigned ebase = ((unsigned)r << 24) | (unsigned)cx;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const bool pk = (pass >> k) & 1u;
-      const unsigned long long m = __ballot(pk);
-      if (pk) myq[qn + __popcll(m & lanemask_lt())] = ((unsigned)r << 16) | (unsigned)(cx + k);
+      const int v = (int)((C >> (8 * k)) & 255);
+      const int vlo = v - tlo, vhi = v + tlo;
+      const int n0 = (int)((D >> (8 * k)) & 255), n8 = (int)((U >> (8 * k)) & 255);
+      const int n4 = (int)((P4 >> (8 * k)) & 255), n12 = (int)((P12 >> (8 * k)) & 255);
+      // every 9-arc holds one pixel of each antipodal pair: the compares are wave masks, the logic is scalar
+      const unsigned long long in = wballot(k >= lo) & wballot(k < hi);
+      const unsigned long long mD = (wballot(n0 < vlo) | wballot(n8 < vlo)) & (wballot(n4 < vlo) | wballot(n12 < vlo)) & in;
+      const unsigned long long mB = (wballot(n0 > vhi) | wballot(n8 > vhi)) & (wballot(n4 > vhi) | wballot(n12 > vhi)) & in;
+      const unsigned long long m = mD | mB;
+      if (PLH_INV_BALLOT(m)) myq[qn + mbcnt64(m)] = (ebase + (unsigned)k) | (PLH_INV_BALLOT(mD) ? 0u : 0x10000u);
       qn += __popcll(m);
-      if (qn >= 64) {
-        ORB_WAVE_SYNC();
-        const unsigned e = myq[qn - 64 + lane];
-        ORB_WAVE_SYNC();
-        fast_score_pixel(tile, TP, sc, (int)(e >> 16), (int)(e & 0xffffu), tlo);
-        qn -= 64;
+      const unsigned long long m2 = mD & mB;          // both sides possible (rare): the bright side as a second entry
+      if (m2) {
+        if (PLH_INV_BALLOT(m2)) myq[qn + mbcnt64(m2)] = (ebase + (unsigned)k) | 0x10000u;
+        qn += __popcll(m2);
+      }
+      if (k & 1) {                                    // at most 63 + 2 * 128 entries are queued at this point
+        while (qn >= 64) {
+          ORB_WAVE_SYNC();
+          const unsigned e = myq[qn - 64 + lane];
+          ORB_WAVE_SYNC();
+          fast_score_entry(tile, TP, sc, cmask, W32, e, tlo);
+          qn -= 64;
+        }
       }
     }
   }
   ORB_WAVE_SYNC();
-  if (lane < qn) {
-    const unsigned e = myq[lane];
-    fast_score_pixel(tile, TP, sc, (int)(e >> 16), (int)(e & 0xffffu), tlo);
-  }
+  if (lane < qn) fast_score_entry(tile, TP, sc, cmask, W32, myq[lane], tlo);
   __syncthreads();
 
-  // ---- 3x3 NMS inside each cell window + threshold class (2: >= iniThFAST, 1: >= minThFAST)
+  // ---- corner bitmap -> list -> 3x3 NMS inside each cell window + threshold class (hi: >= iniThFAST, any: >= minThFAST).
+  // The image tile is dead: it now holds the two survivor bitmaps and the corner list (u16: row : 6 | tile column : 10).
+  unsigned* anyMask = reinterpret_cast<unsigned*>(tile);             // [eh][W32]
+  unsigned* hiMask = anyMask + max(eh, 0) * W32;
+  unsigned short* list = reinterpret_cast<unsigned short*>(hiMask + max(eh, 0) * W32);
+  const int LCAP = (tileBytes - 8 * max(eh, 0) * W32) >> 1;          // >= one bitmap row (host-checked plan invariant)
+  const int nmw = max(eh, 0) * W32;
+  {
+    int c = 0;
+    for (int i = tid; i < nmw; i += 256) { c += __popc(cmask[i]); anyMask[i] = 0u; hiMask[i] = 0u; }
+    c = wave_sum(c);
+    if (lane == 0 && c) atomicAdd(&s_total, c);
+  }
+  __syncthreads();
+  // one chunk when every corner fits the list, else chunks of as many rows as fit in the worst case
+#if defined(HIPEMU)   // the emulator tests force the multi-chunk path, which real frames only take when > 40 % of the pixels are corners
+  const int forcedRows = getenv("PLH_EMU_FAST_ROWS") ? atoi(getenv("PLH_EMU_FAST_ROWS")) : 0;
+  const int rowsPer = forcedRows > 0 ? forcedRows : (s_total <= LCAP ? max(eh, 1) : max(LCAP / (32 * W32), 1));
+#else
+  const int rowsPer = s_total <= LCAP ? max(eh, 1) : max(LCAP / (32 * W32), 1);
+#endif
   const int lastCell = st.nCells - 1;
-  for (int rr = wv; rr < eh; rr += 4)
-   for (int gxi = lane; gxi < ngx; gxi += 64) {
-    const int cx = (gx0 + gxi) << 2;
-    const uint8_t* s1 = sc + (rr + 1) * TP + cx;
-    const unsigned S = ld_u32(s1);
-    if (S == 0u) { *reinterpret_cast<unsigned*>(fl + rr * TP + cx) = 0u; continue; }
-    const unsigned Sl = ld_u32(s1 - 4), Sr = ld_u32(s1 + 4);
-    const unsigned Tc = ld_u32(s1 - TP), Tl = ld_u32(s1 - TP - 4), Tr = ld_u32(s1 - TP + 4);
-    const unsigned Bc = ld_u32(s1 + TP), Bl = ld_u32(s1 + TP - 4), Br = ld_u32(s1 + TP + 4);
-    unsigned F = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int s = (S >> (8 * k)) & 255;
-      if (s == 0 || s < tlo) continue;
-      const int x = xa + cx + k;
-      const int ex = x - ex0;                             // column inside the strip's evaluated window
-      const int cj = min(ex / st.wCell, lastCell);
-      const int cxs = ex - cj * st.wCell;                 // column inside the cell's evaluated window
-      const int cew = (cj == lastCell ? (ex1 - ex0) - cj * st.wCell : (int)st.wCell);
-      const bool lft = cxs > 0, rgt = cxs < cew - 1;
-      // neighbours at x-1 / x+1 : bytes 3..6 and 5..8 of the 12-byte window {left, centre, right}
-      const unsigned sL = k > 0 ? (S >> (8 * (k - 1))) & 255 : (Sl >> 24);
-      const unsigned sR = k < 3 ? (S >> (8 * (k + 1))) & 255 : (Sr & 255);
-      const unsigned tL = k > 0 ? (Tc >> (8 * (k - 1))) & 255 : (Tl >> 24);
-      const unsigned tR = k < 3 ? (Tc >> (8 * (k + 1))) & 255 : (Tr & 255);
-      const unsigned bL = k > 0 ? (Bc >> (8 * (k - 1))) & 255 : (Bl >> 24);
-      const unsigned bR = k < 3 ? (Bc >> (8 * (k + 1))) & 255 : (Br & 255);
-      int m = max((int)((Tc >> (8 * k)) & 255), (int)((Bc >> (8 * k)) & 255));   // rows outside the strip are zero
-      if (lft) m = max(m, (int)max(sL, max(tL, bL)));
-      if (rgt) m = max(m, (int)max(sR, max(tR, bR)));
-      if (s > m) {
-        const int f = (s >= a.iniTh) ? 2 : (s >= a.minTh ? 1 : 0);
-        F |= (unsigned)f << (8 * k);
-        if (f == 2) s_hi[cj] = 1;
+  const int wCell = st.wCell;
+  const unsigned cellMul = 65536u / (unsigned)wCell + 1u;            // ex / wCell == (ex * cellMul) >> 16 for ex < 4096
+  for (int r0 = 0; r0 < eh; r0 += rowsPer) {
+    const int r1 = min(r0 + rowsPer, eh);
+    for (int i = r0 * W32 + tid; i < r1 * W32; i += 256) {
+      unsigned w = cmask[i];
+      if (w) {
+        const int rr = i / W32, c0 = (i - rr * W32) << 5;
+        int pos = atomicAdd(&s_listN, __popc(w));
+        while (w) {
+          const int bit = __ffs((int)w) - 1;
+          w &= w - 1;
+          list[pos++] = (unsigned short)((rr << 10) | (c0 + bit));
+        }
       }
     }
-    *reinterpret_cast<unsigned*>(fl + rr * TP + cx) = F;
+    __syncthreads();
+    const int nlist = s_listN;
+    for (int i = tid; i < nlist; i += 256) {
+      const unsigned e = list[i];
+      const int rr = (int)(e >> 10), cxk = (int)(e & 1023u);
+      const uint8_t* s1 = sc + (rr + 1) * TP + cxk;
+      const int s = s1[0];
+      const int ex = xa + cxk - ex0;                      // column inside the strip's evaluated window
+      const int cj = min((int)(((unsigned)ex * cellMul) >> 16), lastCell);
+      const int cxs = ex - cj * wCell;                    // column inside the cell's evaluated window
+      const int cew = (cj == lastCell ? (ex1 - ex0) - cj * wCell : wCell);
+      const int mL = max(max((int)s1[-1], (int)s1[-TP - 1]), (int)s1[TP - 1]);
+      const int mR = max(max((int)s1[1], (int)s1[-TP + 1]), (int)s1[TP + 1]);
+      int m = max((int)s1[-TP], (int)s1[TP]);             // rows outside the strip are zero
+      m = max(m, max(cxs > 0 ? mL : 0, cxs < cew - 1 ? mR : 0));
+      if (s > m && s >= a.minTh) {
+        const unsigned bit = 1u << (cxk & 31);
+        atomicOr(&anyMask[rr * W32 + (cxk >> 5)], bit);
+        if (s >= a.iniTh) { atomicOr(&hiMask[rr * W32 + (cxk >> 5)], bit); s_hi[cj] = 1; }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_listN = 0;
+    __syncthreads();
   }
-  __syncthreads();
 
-  // ---- emission: one wavefront per cell, raster order
+  // ---- emission: one wavefront per cell, one lane per row of the cell window, raster order
   for (int cj = wv; cj < st.nCells; cj += 4) {
     const OrbCell c = a.cells[st.cellFirst + cj];
     const int ew = c.cw - 6;
-    const int npx = (ew > 0 && eh > 0) ? ew * eh : 0;
-    const int need = s_hi[cj] ? 2 : 1;
+    const unsigned* mk = s_hi[cj] ? hiMask : anyMask;
     const int colBase = c.x0 + 3 - xa;
     uint32_t* out = a.slots + (long long)b * a.slotsPerFrame + c.slotOff;
-    int cnt = 0;
-    // lanes cover whole rows of the cell window: rpi rows of pw (power of two >= ew) columns per iteration
-    const int pw = ew > 32 ? 64 : (ew > 16 ? 32 : 16), sh = ew > 32 ? 6 : (ew > 16 ? 5 : 4), rpi = 64 >> sh;
-    for (int row0 = 0; row0 < (npx ? eh : 0); row0 += rpi) {
-      const int ey = row0 + (lane >> sh), ex = lane & (pw - 1);
-      bool keep = false;
-      if (ey < eh && ex < ew) keep = fl[ey * TP + colBase + ex] >= need;
-      const unsigned long long mask = __ballot(keep);
-      if (keep) {
-        const int pos = cnt + __popcll(mask & lanemask_lt());
-        if (pos < c.slotCap)
-          out[pos] = ((uint32_t)(c.x0 + 3 + ex) << 20) | ((uint32_t)(c.y0 + 3 + ey) << 8) | sc[(ey + 1) * TP + colBase + ex];
+    int total = 0;
+    for (int row0 = 0; row0 < ((ew > 0 && eh > 0) ? eh : 0); row0 += 64) {
+      const int ey = row0 + lane;
+      unsigned long long bits = 0;
+      if (ey < eh) {                                       // the row's window [colBase, colBase + ew), ew <= 60: three words
+        const unsigned* mr = mk + ey * W32;
+        const int w0 = colBase >> 5, sh = colBase & 31;
+        const unsigned long long lo = (unsigned long long)mr[w0] | ((unsigned long long)(w0 + 1 < W32 ? mr[w0 + 1] : 0u) << 32);
+        const unsigned long long hi = w0 + 2 < W32 ? mr[w0 + 2] : 0u;
+        bits = (lo >> sh) | (sh ? hi << (64 - sh) : 0ull);
+        bits &= (1ull << ew) - 1ull;
       }
-      cnt += __popcll(mask);
+      const int cnt = __popcll(bits);
+      int incl = cnt;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int tv = __shfl_up(incl, d);
+        if (lane >= d) incl += tv;
+      }
+      int pos = total + incl - cnt;
+      while (bits) {
+        const int exb = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        if (pos < c.slotCap)
+          out[pos] = ((uint32_t)(c.x0 + 3 + exb) << 20) | ((uint32_t)(c.y0 + 3 + ey) << 8) | sc[(ey + 1) * TP + colBase + exb];
+        pos++;
+      }
+      total += __shfl(incl, 63);
     }
     if (lane == 0) {
-      if (cnt > c.slotCap) { atomicOr(a.status, 1); cnt = c.slotCap; }
-      a.cellCount[(long long)b * a.nCellsTotal + st.cellFirst + cj] = (uint32_t)cnt;
+      if (total > c.slotCap) { atomicOr(a.status, 1); total = c.slotCap; }
+      a.cellCount[(long long)b * a.nCellsTotal + st.cellFirst + cj] = (uint32_t)total;
     }
   }
 }
@@ -870,9 +921,10 @@ void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds
   dim3 grid((pitch / 4 + 63) / 64, (h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), a.batch), block(64, 4);
   hipLaunchKernelGGL(k_pyr_down, grid, block, lds, s, a, l);
 }
-size_t fast_strip_lds_bytes(int width, int ch) {   // image tile + score tile of k_fast_strips (width = xEnd - x0)
+size_t fast_strip_lds_bytes(int width, int ch) {   // image tile + score tile + corner bitmap of k_fast_strips (width = xEnd - x0)
   const size_t TP = (size_t)((width + 8 + 3 + 3) & ~3) + 4;
-  return (((size_t)ch * TP + 15) & ~(size_t)15) + (size_t)(ch - 6 + 2 > 2 ? ch - 4 : 2) * TP + 64;
+  const size_t eh = ch > 6 ? ch - 6 : 0, W32 = (TP + 31) / 32;
+  return (((size_t)ch * TP + 15) & ~(size_t)15) + (((eh + 2) * TP + 15) & ~(size_t)15) + eh * W32 * 4 + 64;
 }
 void launch_fast_strips(const OrbDeviceArgs& a, size_t lds, hipStream_t s) {
   const int groups = (a.batch + 7) / 8;

@@ -73,6 +73,19 @@ __device__ __forceinline__ unsigned long long wballot(bool p) { return __ballot(
 __device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 #endif
 
+// A wave mask used as a per-lane predicate: the SGPR pair feeds exec / v_cndmask directly (no v_cmp); the emulator tests
+// the lane's bit.
+#if defined(HIPEMU)
+#define PLH_INV_BALLOT(m) ((((m) >> plh::lane_id()) & 1ull) != 0)
+#else
+#define PLH_INV_BALLOT(m) __builtin_amdgcn_inverse_ballot_w64(m)
+#endif
+
+// number of set bits of a wave mask below this lane (v_mbcnt_lo + v_mbcnt_hi)
+__device__ __forceinline__ int mbcnt64(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }

@@ -64,3 +64,14 @@ def test_emu_wide_odd_pitch_frame(plslam, oracle, synth, emu_lib):
     # width 403: level-0 rows are not dword aligned (funnel-shifted staging) and a cell row is split into two FAST strips
     img = synth.make_frame(12, 110, 403, n_rect=60, n_line=30)
     assert _cmp(plslam, oracle, img, 300, 2, emu_lib) > 150
+
+
+def test_emu_dense_corners_chunked_nms(plslam, oracle, synth, emu_lib, monkeypatch):
+    # white noise at low thresholds: a third of the pixels are corners, many of them possible on both sides; the corner list
+    # is processed in chunks of 5 rows (the path real frames take only above ~40 % corner density)
+    rng = synth.SplitMix64(77)
+    img = rng.randint(130 * 170, 0, 256).astype(np.uint8).reshape(130, 170)
+    monkeypatch.setenv("PLH_EMU_FAST_ROWS", "5")
+    assert _cmp(plslam, oracle, img, 400, 2, emu_lib, ini=9, mn=3) > 300
+    monkeypatch.delenv("PLH_EMU_FAST_ROWS")
+    assert _cmp(plslam, oracle, img, 400, 2, emu_lib, ini=9, mn=3) > 300
