@@ -1,0 +1,50 @@
+#!/bin/bash
+# oracle/_ref/libadaptor_hip.so and libadaptor_emu.so: the reference's own src/Frame.cc (+ KeyFrame.cc, MapPoint.cc, MapLine.cpp,
+# lineIterator.cpp, DBoW2, and ORBmatcher.cc / LSDmatcher.cpp as the CPU base classes) compiled from where they lie with the
+# product's adaptor headers AHEAD of the reference's include directory -- INTEGRATION.md section 1 -- against the stand-in OpenCV /
+# Eigen headers of oracle/ref/stub, and linked to the product library (hip: GPU box) or to the emulator build of the same kernel
+# sources (emu: CPU tests).  src/ORBextractor.cc and src/LineExtractor.cpp are not compiled: the adaptor classes replace them.
+# Harness: oracle/ref/ref_frame.cc (the tracking searches on real Frame / KeyFrame / MapPoint / MapLine objects, unchanged) +
+# oracle/ref/ref_adaptor.cc (the monocular Frame constructor and the initialisation matchers).  TEST INFRASTRUCTURE ONLY.
+set -e
+REF=${1:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+ROOT=$(cd "$HERE/../.." && pwd)
+D=$REF/Thirdparty/DBoW2
+LD=$REF/Thirdparty/line_descriptor
+[ -f "$REF/src/Frame.cc" ] || { echo "no reference at $REF: skipping the adaptor libraries"; exit 0; }
+OUT="$HERE/../_ref"
+mkdir -p "$OUT"
+[ -f "$OUT/plo_frame_search.o" ] || bash "$HERE/build_ref.sh" "$REF"
+PLO_OBJS="$OUT/plo_frame_search.o $OUT/plo_match.o $OUT/plo_img_ops.o $OUT/plo_lsd.o"
+FLAGS="-O2 -std=c++14 -fPIC -w -pthread -ffp-contract=off -fno-fast-math -DPLO_REAL_FRAME -DPLO_REAL_KEYFRAME -DMAP_H -DCONVERTER_H -DLOCALMAPPING_H -DKEYFRAMEDATABASE_H"
+INC="-I $ROOT/pl-slam_amd/adaptor -I $ROOT/include -I $HERE/stub -I $HERE/stub/eigen3 -I $LD/include -I $REF/include -I $REF -include $HERE/frame_stub.h"
+# what the maintainer adds to every translation unit of the reference
+DROPIN="-include $ROOT/pl-slam_amd/adaptor/plslam_hip_dropin.h"
+OBJ="$OUT/adaptor_obj"
+mkdir -p "$OBJ"
+rm -f "$OBJ"/*.o
+# the two harness files include the drop-in header themselves (after their `#define private public`)
+for f in "$HERE/ref_frame.cc" "$HERE/ref_adaptor.cc"; do
+  g++ $FLAGS $INC -DPLO_ADAPTOR_BUILD -c -o "$OBJ/$(basename "$f").o" "$f" &
+done
+for f in "$REF/src/Frame.cc" "$REF/src/KeyFrame.cc" "$REF/src/MapPoint.cc" "$REF/src/MapLine.cpp" \
+         "$REF/src/lineIterator.cpp" "$D/DBoW2/FORB.cpp" "$D/DBoW2/BowVector.cpp" "$D/DBoW2/FeatureVector.cpp" "$D/DBoW2/ScoringObject.cpp" \
+         "$D/DUtils/Random.cpp" "$D/DUtils/Timestamp.cpp"; do
+  g++ $FLAGS $INC $DROPIN -c -o "$OBJ/$(basename "$f").o" "$f" &
+done
+# the reference's matcher sources become the CPU base classes of the adaptor classes
+for f in "$REF/src/ORBmatcher.cc" "$REF/src/LSDmatcher.cpp"; do
+  g++ $FLAGS $INC $DROPIN -DORBmatcher=ORBmatcherCPU -DLSDmatcher=LSDmatcherCPU -c -o "$OBJ/$(basename "$f").o" "$f" &
+done
+wait
+if [ -f "$ROOT/pl-slam_amd/libplslam_hip.so" ]; then
+  g++ -shared -pthread -o "$OUT/libadaptor_hip.so" "$OBJ"/*.o $PLO_OBJS -L "$ROOT/pl-slam_amd" -lplslam_hip \
+    -Wl,-rpath,'$ORIGIN/../../pl-slam_amd' -Wl,-rpath,/opt/rocm/lib
+  echo "built $OUT/libadaptor_hip.so"
+fi
+EMU="$ROOT/tests/hipemu/_build"
+if [ -f "$EMU/libplslam_emu.so" ]; then
+  g++ -shared -pthread -o "$OUT/libadaptor_emu.so" "$OBJ"/*.o $PLO_OBJS -L "$EMU" -lplslam_emu -Wl,-rpath,'$ORIGIN/../../tests/hipemu/_build'
+  echo "built $OUT/libadaptor_emu.so"
+fi

@@ -24,6 +24,9 @@
 
 #define private public   // AssignFeaturesToGrid / AssignFeaturesToGridForLine are private members
 #define protected public   // MapPoint / MapLine: mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance
+#ifdef PLO_ADAPTOR_BUILD   // oracle/ref/build_adaptor.sh: the same harness with the product's adaptor classes behind the class names
+#include "plslam_hip_dropin.h"
+#endif
 #include "Frame.h"
 #undef private
 #undef protected

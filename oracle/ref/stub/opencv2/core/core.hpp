@@ -209,7 +209,12 @@ class Mat {
   }
   Mat t() const;
   // compile-only members (stereo / triangulation code of Frame.cc that the harnesses never reach)
-  Mat reshape(int, int = 0) const { std::cerr << "oracle/ref stub: Mat::reshape is compile-only" << std::endl; std::abort(); }
+  // The stand-in has no channels: an N x 2 CV_32F matrix stands for N two-channel points, so the reshape(2) / reshape(1) pair
+  // around cv::undistortPoints (Frame.cc:930-934, 957-959) is the identity here.  Anything else stays compile-only.
+  Mat reshape(int cn, int = 0) const {
+    if (type_ == CV_32F && cols == 2 && (cn == 1 || cn == 2)) return *this;
+    std::cerr << "oracle/ref stub: Mat::reshape is compile-only" << std::endl; std::abort();
+  }
   void convertTo(Mat&, int) const { std::cerr << "oracle/ref stub: Mat::convertTo is compile-only" << std::endl; std::abort(); }
   static Mat eye(int r, int c, int type) {
     Mat m = Mat::zeros(r, c, type);
@@ -279,7 +284,12 @@ template <typename T> class Mat_ : public Mat {
   const T* operator[](int r) const { return ptr<T>(r); }
   T& operator()(int r, int c) { return ptr<T>(r)[c]; }
   Mat_ t() const { stub_unreachable_("Mat_::t"); return Mat_(); }
-  static Mat_ eye(int, int) { stub_unreachable_("Mat_::eye"); return Mat_(); }
+  static Mat_ eye(int r, int c) {   // Mat_<double>::eye(3, 3): the rectification argument of initUndistortRectifyMap (Frame.cc:221)
+    Mat_ m(r, c);
+    for (int i = 0; i < r; i++)
+      for (int j = 0; j < c; j++) m(i, j) = (T)(i == j);
+    return m;
+  }
  private:
   static void stub_unreachable_(const char* w) { std::cerr << "oracle/ref stub: " << w << " is compile-only" << std::endl; std::abort(); }
 };
@@ -384,9 +394,39 @@ struct SVD {
   enum { MODIFY_A = 1, NO_UV = 2, FULL_UV = 4 };
   static void compute(const Mat&, Mat&, Mat&, Mat&, int = 0) { stub_unreachable("cv::SVD::compute"); }
 };
-inline void initUndistortRectifyMap(const Mat&, const Mat&, const Mat&, const Mat&, Size, int, Mat&, Mat&) { stub_unreachable("cv::initUndistortRectifyMap"); }
-inline void remap(const Mat&, Mat&, const Mat&, const Mat&, int) { stub_unreachable("cv::remap"); }
-inline void undistortPoints(const Mat&, Mat&, const Mat&, const Mat&, const Mat& = Mat(), const Mat& = Mat()) { stub_unreachable("cv::undistortPoints"); }
+// The three OpenCV calls of the monocular Frame constructor (Frame.cc:220-222, 933, 959), forwarded to the oracle's
+// restatements (oracle/img_ops.cc, oracle/frame_search.cc) so that the constructor can be EXECUTED against this stand-in:
+// K = 3x3 CV_32F, D = 4x1 or 5x1 CV_32F, R = identity, newK = P = K (the only way the reference calls them).
+inline void stub_intrinsics(const Mat& K, const Mat& D, float k[4], float d[5]) {
+  k[0] = K.at<float>(0, 0); k[1] = K.at<float>(1, 1); k[2] = K.at<float>(0, 2); k[3] = K.at<float>(1, 2);
+  for (int i = 0; i < 5; i++) d[i] = i < D.rows * D.cols ? D.at<float>(i) : 0.f;
+}
+inline void initUndistortRectifyMap(const Mat& K, const Mat& D, const Mat&, const Mat&, Size sz, int, Mat& m1, Mat& m2) {
+  float k[4], d[5];
+  stub_intrinsics(K, D, k, d);
+  m1.create(sz.height, sz.width, CV_32F);
+  m2.create(sz.height, sz.width, CV_32F);
+  plo_undistort_maps(k, d, sz.width, sz.height, m1.ptr<float>(0), m2.ptr<float>(0));
+}
+inline void remap(const Mat& src, Mat& dst, const Mat& mx, const Mat& my, int) {
+  assert(src.type() == CV_8U && mx.isContinuous() && my.isContinuous());
+  Mat out(src.rows, src.cols, CV_8U);
+  plo_remap_linear_u8(src.data, src.cols, src.rows, src.step, mx.ptr<float>(0), my.ptr<float>(0), out.data, out.step);
+  dst = out;
+}
+inline void undistortPoints(const Mat& src, Mat& dst, const Mat& K, const Mat& D, const Mat& = Mat(), const Mat& = Mat()) {
+  assert(src.type() == CV_32F && src.cols == 2);   // N points as an N x 2 float matrix (see Mat::reshape)
+  float k[4], d[5];
+  stub_intrinsics(K, D, k, d);
+  std::vector<plo_keypoint> in(src.rows), out(src.rows);
+  for (int i = 0; i < src.rows; i++) { in[i] = plo_keypoint(); in[i].x = src.at<float>(i, 0); in[i].y = src.at<float>(i, 1); }
+  // plo_undistort_keypoints copies for k1 == 0 (that shortcut is Frame::UndistortKeyPoints' own, :917-921, and the reference
+  // never reaches cv::undistortPoints then)
+  plo_undistort_keypoints(in.data(), src.rows, k, d, out.data());
+  Mat r(src.rows, 2, CV_32F);
+  for (int i = 0; i < src.rows; i++) { r.at<float>(i, 0) = out[i].x; r.at<float>(i, 1) = out[i].y; }
+  dst = r;
+}
 inline bool solve(const Mat&, const Mat&, Mat&, int = 0) { stub_unreachable("cv::solve"); }
 inline void cvtColor(const Mat&, Mat&, int) { stub_unreachable("cv::cvtColor"); }
 inline void pyrDown(const Mat&, Mat&, Size = Size()) { stub_unreachable("cv::pyrDown (numOctaves is 1 on this path)"); }

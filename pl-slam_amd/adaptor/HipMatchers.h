@@ -18,6 +18,7 @@
 #include <opencv2/line_descriptor/descriptor.hpp>
 #include <Eigen/Core>
 
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>

@@ -6,6 +6,8 @@
 // built once instead of once per frame, and Frame passes the raw grey image.
 #ifndef PLSLAM_HIP_ADAPTOR_LINEEXTRACTOR_H
 #define PLSLAM_HIP_ADAPTOR_LINEEXTRACTOR_H
+#define LINEEXTRACTOR_H   // the include guard of the reference's own header: a later `#include "LineExtractor.h"` from include/Frame.h,
+// KeyFrame.h or Tracking.h (sibling lookup, which no -I order can override) then finds nothing left to declare
 
 #include <opencv2/core/core.hpp>
 #include <opencv2/line_descriptor/descriptor.hpp>

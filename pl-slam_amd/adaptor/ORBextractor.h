@@ -6,6 +6,8 @@
 // syntax-checks this file against tests/cv_stub/).
 #ifndef PLSLAM_HIP_ADAPTOR_ORBEXTRACTOR_H
 #define PLSLAM_HIP_ADAPTOR_ORBEXTRACTOR_H
+#define ORBEXTRACTOR_H   // the include guard of the reference's own header: a later `#include "ORBextractor.h"` from include/Frame.h,
+// KeyFrame.h or Tracking.h (sibling lookup, which no -I order can override) then finds nothing left to declare
 
 #include <opencv2/core/core.hpp>
 #include <opencv2/features2d/features2d.hpp>
@@ -68,9 +70,7 @@ class ORBextractor {
     if (n == 0) {
       _descriptors.release();   // ORBextractor.cc:1064-1065
     } else {
-      _descriptors.create(n, 32, CV_8U);
-      cv::Mat out = _descriptors.getMat();
-      mDescBuf.rowRange(0, n).copyTo(out);
+      mDescBuf.rowRange(0, n).copyTo(_descriptors);   // n x 32 CV_8U (ORBextractor.cc:1068-1069)
     }
   }
 

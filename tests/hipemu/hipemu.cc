@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
+#include <mutex>
+
 namespace hipemu {
 
 uint3e threadIdx_, blockIdx_;
@@ -104,6 +106,10 @@ unsigned long long wave_exchange(unsigned long long v, int src_lane, int) {
 }
 
 void run_grid(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* args) {
+  // one launch at a time: the fiber scheduler is global state, and a host may drive two handles from two threads (the
+  // reference's Frame constructor runs ExtractORB and ExtractLSD concurrently, Frame.cc:224-227)
+  static std::mutex launch_mutex;
+  std::lock_guard<std::mutex> lock(launch_mutex);
   int n = (int)(block.x * block.y * block.z);
   if (n > kMaxThreads || n <= 0) {
     fprintf(stderr, "hipemu: bad block size %d\n", n);

@@ -1,0 +1,266 @@
+"""The C++ drop-in boundary EXECUTED: the reference's own src/Frame.cc, compiled from where it lies with the adaptor
+headers of pl-slam_amd/adaptor ahead of the reference's include directory (oracle/ref/build_adaptor.sh),
+linked to libplslam_hip.so (GPU box, `-m gpu`) or to the emulator build of the same kernel sources (CPU suite).
+
+  * test_adaptor_executes_frame_constructor: `Frame(imGray, t, ORBextractor*, LINEextractor*, voc, K, distCoef, bf, thDepth, mask)`
+    (src/Frame.cc:193-276) runs unchanged -- Frame::ExtractORB and Frame::ExtractLSD on two threads call the adaptor classes -- and
+    its members mvKeys, mDescriptors, mvKeylinesUn, mLdesc, mvKeyLineFunctions equal what the reference's own ORBextractor.cc /
+    LineExtractor.cpp produced on the same image (tests/golden/ref_orb_*.npz, ref_line_*.npz); mvKeysUn, the image bounds and both
+    grids equal the oracle's.
+  * test_adaptor_executes_tracking_searches: the real ORBmatcher / LSDmatcher call sites of Tracking (SearchLocalPoints /
+    SearchLocalLines, TrackWithMotionModel, TrackReferenceKeyFrame) on real Frame / KeyFrame / MapPoint / MapLine objects, with
+    `ORBmatcher` / `LSDmatcher` now being the adaptor classes; results equal tests/golden/ref_track.npz, which the reference's own
+    src/ORBmatcher.cc / src/LSDmatcher.cpp produced.
+  * test_adaptor_executes_initialization_matchers: SearchForInitialization and SearchDouble on two constructed Frames vs the oracle.
+The libraries are built in the build container (the reference is not on the GPU box) and travel with the snapshot."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import _util
+
+GOLD = os.path.join(_util.ROOT, "tests", "golden")
+LIB_HIP = os.path.join(_util.ROOT, "oracle", "_ref", "libadaptor_hip.so")
+LIB_EMU = os.path.join(_util.ROOT, "oracle", "_ref", "libadaptor_emu.so")
+V, I, F = C.c_void_p, C.c_int, C.c_float
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_golden_ref", os.path.join(_util.ROOT, "tools", "gen_golden_ref.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _lib(path):
+    if not os.path.exists(path):
+        pytest.skip("%s not built (oracle/ref/build_adaptor.sh needs /root/reference)" % os.path.basename(path))
+    G = _gen()
+    R = G.ref_frame_lib(path)
+    R.adx_tracker_create.restype = V
+    R.adx_tracker_create.argtypes = [I, F, I, I, I, I, C.c_double]
+    R.adx_tracker_destroy.argtypes = [V]
+    R.adx_frame_create.restype = V
+    R.adx_frame_create.argtypes = [V, V, I, I, V, V, V, C.c_char_p, I]
+    R.adx_frame_destroy.argtypes = [V]
+    R.adx_frame_counts.argtypes = [V, V, V]
+    R.adx_frame_read.argtypes = [V] * 8
+    R.adx_search_for_initialization.argtypes = [V, V, V, I, F, I, V]
+    R.adx_search_double.argtypes = [V, V, F, V]
+    R.adx_descriptor_distance.argtypes = [V, V]
+    assert R.adx_uses_adaptor_classes() == 1
+    return G, R
+
+
+class _Frame:
+    def __init__(self, R, P, tracker, img, K, D, mask=None):
+        self.R = R
+        img = np.ascontiguousarray(img)
+        err = C.create_string_buffer(512)
+        Kf, Df = np.asarray(K, np.float32), np.asarray(D, np.float32)
+        mp = mask.ctypes.data_as(V) if mask is not None else None
+        self.h = R.adx_frame_create(tracker, img.ctypes.data_as(V), img.shape[0], img.shape[1], Kf.ctypes.data_as(V), Df.ctypes.data_as(V),
+                                    mp, err, 512)
+        assert self.h, "Frame constructor threw: " + err.value.decode()
+        n, nl = C.c_int(0), C.c_int(0)
+        R.adx_frame_counts(self.h, C.byref(n), C.byref(nl))
+        self.N, self.NL = n.value, nl.value
+        self.keys, self.keys_un = np.zeros(max(self.N, 1), P.KP_DTYPE), np.zeros(max(self.N, 1), P.KP_DTYPE)
+        self.desc = np.zeros((max(self.N, 1), 32), np.uint8)
+        self.kl, self.ldesc = np.zeros(max(self.NL, 1), P.KL_DTYPE), np.zeros((max(self.NL, 1), 32), np.uint8)
+        self.fn, self.bounds = np.zeros((max(self.NL, 1), 3)), np.zeros(6, np.float32)
+        p = lambda a: a.ctypes.data_as(V)
+        R.adx_frame_read(self.h, p(self.keys), p(self.keys_un), p(self.desc), p(self.kl), p(self.ldesc), p(self.fn), p(self.bounds))
+        for a in ("keys", "keys_un", "desc"):
+            setattr(self, a, getattr(self, a)[:self.N])
+        for a in ("kl", "ldesc", "fn"):
+            setattr(self, a, getattr(self, a)[:self.NL])
+
+    def grids(self):
+        R = self.R
+        cs, ci = np.zeros(64 * 48 + 1, np.int32), np.zeros(max(self.N, 1), np.int32)
+        R.ref_frame_grid_points(self.h, cs.ctypes.data_as(V), ci.ctypes.data_as(V), len(ci))
+        lcs, lci = np.zeros(64 * 48 + 1, np.int32), np.zeros(max(self.NL, 1) * 64, np.int32)
+        R.ref_frame_grid_lines(self.h, lcs.ctypes.data_as(V), lci.ctypes.data_as(V), len(lci))
+        return (cs, ci), (lcs, lci)
+
+    def close(self):
+        if self.h:
+            self.R.adx_frame_destroy(self.h)
+            self.h = None
+
+
+def _ulps(a, b):
+    ia, ib = a.astype(np.float32).view(np.int32).astype(np.int64), b.astype(np.float32).view(np.int32).astype(np.int64)
+    ia, ib = np.where(ia < 0, -(ia & 0x7fffffff), ia), np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    return np.abs(ia - ib)
+
+
+def _check_frame_vs_reference(fr, go, gl, what):
+    """mvKeys / mDescriptors vs the reference's ORBextractor.cc, mvKeylinesUn / mLdesc / mvKeyLineFunctions vs its LineExtractor.cpp."""
+    assert fr.N == len(go["kps"]), "%s: %d keypoints, reference %d" % (what, fr.N, len(go["kps"]))
+    for f in go["kps"].dtype.names:
+        assert (fr.keys[f] == go["kps"][f]).all(), "%s: mvKeys.%s" % (what, f)
+    assert (fr.desc == go["desc"]).all(), what + ": mDescriptors"
+    assert fr.NL == len(gl["keylines"]), "%s: %d keylines, reference %d" % (what, fr.NL, len(gl["keylines"]))
+    for f in gl["keylines"].dtype.names:
+        if f == "angle":   # toolchain-dependent atan2 overload inside the reference (see tests/test_ref_line.py)
+            assert _ulps(fr.kl[f], gl["keylines"][f]).max(initial=0) <= 1
+        else:
+            assert (fr.kl[f] == gl["keylines"][f]).all(), "%s: mvKeylinesUn.%s" % (what, f)
+    assert (fr.ldesc == gl["desc"]).all(), what + ": mLdesc"
+    assert (fr.fn == gl["linefn"]).all(), what + ": mvKeyLineFunctions"
+
+
+def _frame_constructor(P, S, O, path, cases):
+    G, R = _lib(path)
+    TF = G._test_module("test_frame_search")
+    for orb_name, line_name, K in cases:
+        go, gl = np.load(os.path.join(GOLD, "ref_orb_%s.npz" % orb_name)), np.load(os.path.join(GOLD, "ref_line_%s.npz" % line_name))
+        rows, cols, seed = int(go["rows"]), int(go["cols"]), int(go["seed"])
+        assert (int(gl["rows"]), int(gl["cols"]), int(gl["seed"])) == (rows, cols, seed) and not bool(gl["masked"])
+        img = S.make_frame(seed, rows, cols)
+        trk = R.adx_tracker_create(int(go["nfeatures"]), float(go["scale"]), int(go["nlevels"]), int(go["ini"]), int(go["mn"]),
+                                   int(gl["nfeatures"]), float(gl["min_len"]))
+        try:
+            # --- no distortion (KITTI-style calibration): LSD sees the image itself, so both reference goldens apply
+            for rep in range(2):   # the extractor objects persist across frames like Tracking's
+                fr = _Frame(R, P, trk, img, K, [0, 0, 0, 0, 0])
+                _check_frame_vs_reference(fr, go, gl, "%s (frame %d)" % (orb_name, rep))
+                assert all((fr.keys_un[f] == fr.keys[f]).all() for f in fr.keys.dtype.names)      # Frame.cc:917-921
+                assert tuple(fr.bounds[:4]) == (0.0, 0.0, float(cols), float(rows))
+                gp = P.grid_params(cols, rows)
+                assert fr.bounds[4] == gp.inv_w and fr.bounds[5] == gp.inv_h
+                (cs, ci), (lcs, lci) = fr.grids()
+                (rcs, rci), (rlcs, rlci) = TF._oracle_grids(O, P, dict(kps=fr.keys_un, keylines=fr.kl), gp)
+                assert (cs == rcs).all() and (ci[:rcs[-1]] == rci[:rcs[-1]]).all(), "mGrid"
+                assert (lcs == rlcs).all() and (lci[:rlcs[-1]] == rlci[:rlcs[-1]]).all(), "mGridForLine"
+                fr.close()
+            # --- with distortion: ORB still runs on the raw image (Frame.cc:224), LSD on the remapped one (:221-225)
+            D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]       # TUM1.yaml:13-17
+            fr = _Frame(R, P, trk, img, K, D)
+            assert fr.N == len(go["kps"]) and (fr.desc == go["desc"]).all()
+            assert all((fr.keys[f] == go["kps"][f]).all() for f in go["kps"].dtype.names)
+            Kf, Df = np.asarray(K, np.float32), np.asarray(D, np.float32)
+            un = np.zeros(fr.N, P.KP_DTYPE)
+            O.lib().plo_undistort_keypoints.argtypes = [V, I, V, V, V]
+            O.lib().plo_undistort_keypoints(O._p(np.ascontiguousarray(fr.keys)), fr.N, O._p(Kf), O._p(Df), O._p(un))
+            assert all((fr.keys_un[f] == un[f]).all() for f in un.dtype.names), "mvKeysUn"
+            mx, my = np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32)
+            O.lib().plo_undistort_maps(O._p(Kf), O._p(Df), cols, rows, O._p(mx), O._p(my))
+            und = np.zeros_like(img)
+            O.lib().plo_remap_linear_u8(O._p(img), cols, rows, cols, O._p(mx), O._p(my), O._p(und), cols)
+            rk, rd, rf = O.line_extract(und, int(gl["nfeatures"]), float(gl["min_len"]))
+            assert fr.NL == len(rk) and (fr.ldesc == rd).all() and (fr.fn == rf).all()
+            assert all((fr.kl[f] == rk[f]).all() for f in rk.dtype.names), "mvKeylinesUn on the undistorted image"
+            # Frame::ComputeImageBounds (Frame.cc:947-974): the undistorted image corners
+            cn = np.zeros(4, P.KP_DTYPE)
+            cn["x"], cn["y"] = [0, cols, 0, cols], [0, 0, rows, rows]
+            cu = np.zeros(4, P.KP_DTYPE)
+            O.lib().plo_undistort_keypoints(O._p(cn), 4, O._p(Kf), O._p(Df), O._p(cu))
+            want = (min(cu["x"][0], cu["x"][2]), min(cu["y"][0], cu["y"][1]), max(cu["x"][1], cu["x"][3]), max(cu["y"][2], cu["y"][3]))
+            assert tuple(fr.bounds[:4]) == tuple(np.float32(w) for w in want) and tuple(fr.bounds[:4]) != (0.0, 0.0, float(cols), float(rows))
+            fr.close()
+        finally:
+            R.adx_tracker_destroy(trk)
+
+
+SMALL = [("s3_320x240", "s3_320x240_minlen", [258.6, 258.2, 159.3, 127.6])]
+FULL = SMALL + [("s1_640x480", "s1_640x480", [517.306408, 516.469215, 318.643040, 255.313989]),
+                ("kitti_1241x376", "kitti_1241x376", [718.856, 718.856, 607.1928, 185.2157])]
+
+
+def test_adaptor_executes_frame_constructor_emu(plslam, synth, oracle, emu_lib):
+    _frame_constructor(plslam, synth, oracle, LIB_EMU, SMALL)
+
+
+@pytest.mark.gpu
+def test_adaptor_executes_frame_constructor(plslam, synth, oracle):
+    _frame_constructor(plslam, synth, oracle, LIB_HIP, FULL)
+
+
+def _tracking_searches(P, S, path, track_cases, bow_cases):
+    G, R = _lib(path)
+    TF = G._test_module("test_frame_search")
+    VM = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    g = np.load(os.path.join(GOLD, "ref_track.npz"))
+    for seed, n, nl, dist, th in track_cases:
+        f2, gp, view, nlv, pts, lns, occ_p, occ_l = G.track_inputs(S, P, TF, seed, n, nl, dist)
+        (cp, ap, op), (cl, al, ol) = G.reference_track(R, P, TF, f2, gp, view, nlv, pts, lns, occ_p, occ_l, th)
+        assert cp == int(g["p_%d_n" % seed]) and (ap == g["p_%d_asg" % seed]).all() and (op == g["p_%d_occ" % seed]).all(), \
+            "ORBmatcher::SearchByProjection(F, MapPoints) case %d" % seed
+        assert cl == int(g["l_%d_n" % seed]) and (al == g["l_%d_asg" % seed]).all() and (ol == g["l_%d_occ" % seed]).all(), \
+            "LSDmatcher::SearchByProjection(F, MapLines) case %d" % seed
+        flags, q = G.track_last_inputs(S, P, TF, seed, n, nl, dist)
+        c, a, o = G.reference_track_last(R, P, TF, f2, gp, view, nlv, pts, flags, q, occ_p, 15.0 if seed != 2 else 7.0)
+        assert c == int(g["m_%d_n" % seed]) and (a == g["m_%d_asg" % seed]).all() and (o == g["m_%d_occ" % seed]).all(), \
+            "ORBmatcher::SearchByProjection(Cur, Last) case %d" % seed
+    import tempfile
+    for seed, k, Lv, n, nn, chk in bow_cases:
+        voc, kf, fr = G.bowtrack_inputs(S, P, VM, seed, k, Lv, n)
+        c, m = G.reference_bowtrack(R, voc, kf, fr, nn, chk, tempfile.gettempdir())
+        assert c == int(g["b_%d_n" % seed]) and (m == g["b_%d_m" % seed]).all(), "ORBmatcher::SearchByBoW(KF, F) case %d" % seed
+
+
+def test_adaptor_executes_tracking_searches_emu(plslam, synth, emu_lib):
+    G = _gen()
+    _tracking_searches(plslam, synth, LIB_EMU, [c for c in G.TRACK_CASES if c[1] <= 800], [c for c in G.BOWTRACK_CASES if c[3] <= 400])
+
+
+@pytest.mark.gpu
+def test_adaptor_executes_tracking_searches(plslam, synth):
+    G = _gen()
+    _tracking_searches(plslam, synth, LIB_HIP, G.TRACK_CASES, G.BOWTRACK_CASES)
+
+
+def _initialization_matchers(P, S, O, path, rows, cols, nfeat):
+    G, R = _lib(path)
+    TF = G._test_module("test_frame_search")
+    L = TF._olib(O)
+    K = [0.8 * cols, 0.8 * cols, cols / 2.0 - 0.7, rows / 2.0 + 0.4]
+    frames = S.make_frames(900, 2, rows, cols, unique=1)              # frame 1 = frame 0 shifted by 3 rows, other exposure
+    trk = R.adx_tracker_create(nfeat, 1.2, 4, 20, 7, 80, 0.0)
+    f1 = _Frame(R, P, trk, frames[0], K, [0, 0, 0, 0, 0])
+    f2 = _Frame(R, P, trk, frames[1], K, [0, 0, 0, 0, 0])
+    try:
+        assert f1.N > 100 and f2.N > 100 and f1.NL > 10 and f2.NL > 10
+        # ORBmatcher(0.9, true).SearchForInitialization(F1, F2, prev, matches, 100)   (Tracking.cc:706-708)
+        prev = np.ascontiguousarray(np.stack([f1.keys_un["x"], f1.keys_un["y"]], 1).astype(np.float32))
+        m12 = np.zeros(f1.N, np.int32)
+        pm = prev.copy()
+        c = R.adx_search_for_initialization(f1.h, f2.h, pm.ctypes.data_as(V), 100, 0.9, 1, m12.ctypes.data_as(V))
+        gp = P.grid_params(cols, rows)
+        g = TF._gpa(P, gp)
+        (rcs, rci), _ = TF._oracle_grids(O, P, dict(kps=f2.keys_un, keylines=f2.kl), gp)
+        rp, ref = prev.copy(), np.zeros(f1.N, np.int32)
+        k1, k2 = np.ascontiguousarray(f1.keys_un), np.ascontiguousarray(f2.keys_un)
+        d1, d2 = np.ascontiguousarray(f1.desc), np.ascontiguousarray(f2.desc)
+        rc = L.plo_orb_search_for_initialization(O._p(k1), O._p(d1), f1.N, O._p(k2), O._p(d2), f2.N, O._p(g), O._p(rcs), O._p(rci), O._p(rp),
+                                                 100, 0.9, 1, O._p(ref))
+        assert c == rc and (m12 == ref).all() and (pm == rp).all() and rc > 20, "SearchForInitialization (%d matches)" % rc
+        # LSDmatcher(0.7).SearchDouble(InitialFrame, CurrentFrame, LineMatches)      (Tracking.cc:711)
+        ml = np.full(f1.NL, -7, np.int32)
+        cl = R.adx_search_double(f1.h, f2.h, 0.7, ml.ctypes.data_as(V))
+        rl = np.zeros(f1.NL, np.int32)
+        l1, l2 = np.ascontiguousarray(f1.ldesc), np.ascontiguousarray(f2.ldesc)
+        rcl = O.lib().plo_line_search_double(O._p(l1), f1.NL, O._p(l2), f2.NL, 50.0, 0.7, O._p(rl))
+        assert cl == rcl and (ml == rl).all() and rcl > 3, "SearchDouble (%d matches)" % rcl
+        a, b = np.ascontiguousarray(d1[0]), np.ascontiguousarray(d2[0])
+        dist = int(np.unpackbits(a ^ b).sum())
+        assert R.adx_descriptor_distance(a.ctypes.data_as(V), b.ctypes.data_as(V)) == dist * 1001
+    finally:
+        f1.close()
+        f2.close()
+        R.adx_tracker_destroy(trk)
+
+
+def test_adaptor_executes_initialization_matchers_emu(plslam, synth, oracle, emu_lib):
+    _initialization_matchers(plslam, synth, oracle, LIB_EMU, 200, 280, 400)
+
+
+@pytest.mark.gpu
+def test_adaptor_executes_initialization_matchers(plslam, synth, oracle):
+    _initialization_matchers(plslam, synth, oracle, LIB_HIP, 480, 640, 1000)

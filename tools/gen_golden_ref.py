@@ -818,8 +818,10 @@ def gen_distinctive(S, out):
 FRAMEGRID_CASES = [(1, 2000, 201, False), (2, 700, 60, True), (3, 5, 1, False), (5, 1200, 300, True)]   # seed, n, lines, distorted bounds
 
 
-def ref_frame_lib():
-    R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libframe_ref.so"))
+def ref_frame_lib(path=None):
+    """libframe_ref.so (the reference's classes throughout) or, with `path`, a library with the same harness built differently
+    (oracle/_ref/libadaptor_*.so: the adaptor extractor / matcher classes in place of the reference's)."""
+    R = C.CDLL(path or os.path.join(ROOT, "oracle", "_ref", "libframe_ref.so"))
     V, I, F = C.c_void_p, C.c_int, C.c_float
     R.ref_frame_create.restype = V
     R.ref_frame_create.argtypes = [V, I, V, V, I, V]
