@@ -4,24 +4,35 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-A "step" is one pass of the whole front end over one batch of synthetic frames already resident in HBM
-(pl-slam_amd/pipeline.py): ORB extract + LSD/LBD line extract (with the Frame.cc undistortion remap) + BoW feature
-vectors + ORBmatcher::SearchByBoW and LSDmatcher::SearchDouble between consecutive frames.
+A "step" is one pass of the whole front end over one batch of synthetic frames ALREADY RESIDENT IN HBM
+(pl-slam_amd/pipeline.py): ORB extract + LSD/LBD line extract (with the Frame.cc undistortion remap) + Frame::ComputeBoW
+(FeatureVector and BowVector) + ORBmatcher::SearchByBoW and LSDmatcher::SearchDouble between consecutive frames.
 Workload = BASELINE.json configs[2] ("640x480 ORB+LSD+LBD full extract, TUM-style intrinsics, 1000 ORB / 200 lines")
 plus the frame-to-frame match of configs[3]; `--batch` frames per GPU (weak scaling: frames are independent,
-SURVEY.md 8e), and for N > 1 one RCCL all_gather of the fixed-stride keypoint / descriptor / keyline records.
+SURVEY.md 8e), and for N > 1 the RCCL gather of the fixed-stride keypoint / descriptor / keyline records through the C ABI
+(plh_gather_records, one grouped launch per sub-batch on a communication stream).
+
+`value` is the resident-batch kernel throughput: the same batch is re-processed every step, nothing crosses PCIe inside the
+timed region and consecutive steps overlap.  What a host that streams frames sees is reported next to it ("streaming":
+fresh frames uploaded and all records downloaded every step, steps joined).
 
 One JSON line on stdout (rank 0) with, besides the contract fields,
-  "roofline":     the dominant kernel: algorithmic bytes per launch / its mean duration measured live with HIP events
-                  on the launch stream, against the 8 TB/s HBM peak; "roofline_fast" repeats it for the FAST kernel
-                  the north star sets its 60 % goal on;
-  "cpu_baseline": the CPU oracle (from-scratch restatement, kind "port") timed on this box's host cores on a
-                  bounded sample of the same frames (same stages, all cores, one frame per task).
+  "roofline":      the dominant kernel: algorithmic bytes per launch / its mean duration measured live with HIP events on the
+                   launch stream over the timed region, against the 8 TB/s HBM peak;
+  "roofline_fast": the same for the FAST kernel the north star sets its 60 % goal on, plus its VALU-issue roofline (the
+                   bound it really runs against);
+  "cpu_baseline":  the CPU oracle (from-scratch restatement, kind "port") on this box's host cores, bounded sample;
+  "secondary":     (N = 1) the KITTI 1241x376 / 2000-feature workload of BASELINE configs[4]: one GPU's resident-batch rate,
+                   and the literal configs[4] share of 4096 / 8 = 512 frames per GPU;
+  "streaming":     (N = 1) the PCIe-inclusive rate described above;
+  "latency_ms_single_frame": (N = 1) one Frame() worth of extraction through the host-buffer entry points, ORB and lines on
+                   two threads as Frame.cc:224-227 runs them.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,8 +42,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _util  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_PEAK_GINST = 1024 * 2.4 / 4.2   # wave64 VALU instructions / ns: 1024 SIMDs, 2.4 GHz, 4.2 cycles per instruction of the
+                                     # front end's op mix (profiles/r01_valu_issue_rate_gfx950.txt)
 TUM1_K = [517.306408, 516.469215, 318.643040, 255.313989]        # Examples/Monocular/TUM1.yaml:8-11
 TUM1_D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]    # TUM1.yaml:13-17
+KITTI_K = [718.856, 718.856, 607.1928, 185.2157]                  # Examples/Monocular/KITTI00-02.yaml:8-11
+NAMES = ["k_pyr_down x7", "k_fast_strips", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
+         "k_lsd_grow", "k_keylines", "LBD (blur+sobel+k_lbd)"]
 
 
 def level_sizes(rows, cols, nlevels):
@@ -55,11 +71,14 @@ def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, budget_s=2
     L = O.lib()
     L.plo_bow_transform.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.plo_bow_transform.restype = None
+    L.plo_bow_vector.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.plo_bow_vector.restype = C.c_int
     rows, cols = frames[0].shape
     mx = np.zeros((rows, cols), np.float32)
     my = np.zeros((rows, cols), np.float32)
     Kf, Df = np.asarray(K, np.float32), np.asarray(D, np.float32)
     L.plo_undistort_maps(O._p(Kf), O._p(Df), cols, rows, O._p(mx), O._p(my))
+    ww = voc.word_weight()
 
     def one_frame(orb, img, prev):
         kps, desc = orb.extract(img)
@@ -71,6 +90,8 @@ def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, budget_s=2
         word = np.zeros(max(n, 1), np.int32)
         L.plo_bow_transform(O._p(desc), n, O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id),
                             O._p(voc.weight), voc.L, 4, O._p(nid), O._p(word))
+        bw, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        L.plo_bow_vector(O._p(word), n, O._p(ww), 0, 0, O._p(bw), O._p(bv), max(n, 1))
         cur = (desc, np.ascontiguousarray(kps["angle"]), nid, ldesc)
         if prev is not None:
             pd, pa, pn, pl = prev
@@ -100,8 +121,124 @@ def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, budget_s=2
         done = sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": round(done / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "single_thread_ms_per_frame": round(per * 1e3, 1),
             "sample": "%d synthetic %dx%d frames (ORB + remap + LSD/LBD + BoW + SearchByBoW + SearchDouble), oracle/ restatement "
                       "(g++ -O2 -ffp-contract=off, no OpenCV SIMD), %d host threads x %d frames" % (done, cols, rows, cores, per_thread)}
+
+
+class Workload:
+    """One resident batch + the pipelined front end over it."""
+
+    def __init__(self, P, S, V, PL, torch, dev, rank, batch, nsplit, rows, cols, nfeatures, nlevels, nlines, unique, voc, serial=False):
+        self.P, self.torch, self.dev = P, torch, dev
+        self.B, self.rows, self.cols, self.nfeatures, self.nlevels, self.nlines = batch, rows, cols, nfeatures, nlevels, nlines
+        self.tum = (rows, cols) == (480, 640)
+        K, D = (TUM1_K, TUM1_D) if self.tum else (None, None)     # KITTI: zero distortion -> no remap (Frame.cc:917-921)
+        self.frames = S.make_frames(2 + 100000 * rank, batch, rows, cols, unique=unique)
+        self.d_imgs = torch.from_numpy(self.frames).to(dev)
+        self.fe = PL.FrontEndPipelined(P, voc, batch, rows, cols, nfeatures, nlevels, nlines, 0.0, K, D, device=dev.index, nsplit=nsplit)
+        self.fe.overlap = not serial
+        self.serial = serial
+        self.nsplit, self.Bp = nsplit, self.fe.Bp
+
+    def set_profiling(self, on):
+        for part in self.fe.parts:
+            part.orb.set_profiling(on)
+            part.line.lib.plh_line_set_profiling.argtypes = [C_VOID, C_INT]
+            part.line.lib.plh_line_set_profiling(part.line.h, int(on))
+
+    def kernel_totals(self):
+        """Cumulative (ms, intervals) of the 8 kernel groups since profiling was switched on."""
+        import ctypes as C
+        tot = [[0.0, 0] for _ in range(8)]
+        for part in self.fe.parts:
+            for k in range(4):
+                ms, n = part.orb.kernel_ms(k)
+                tot[k][0] += ms
+                tot[k][1] += n
+            lib = part.line.lib
+            lib.plh_line_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+            for k in range(4):
+                ms, n = C.c_double(0), C.c_int(0)
+                lib.plh_line_kernel_ms(part.line.h, k, C.byref(ms), C.byref(n))
+                tot[4 + k][0] += ms.value
+                tot[4 + k][1] += n.value
+        return [tuple(x) for x in tot]
+
+    def run(self, steps, warmup, step_fn=None):
+        """warmup untimed steps, then `steps` timed ones between device synchronisations; returns seconds."""
+        t = self.torch
+        step_fn = step_fn or (lambda: self.fe.step(self.d_imgs, join=False))
+        for _ in range(warmup):
+            step_fn()
+        t.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        t.cuda.synchronize(self.dev)
+        return time.perf_counter() - t0
+
+    def algorithmic_bytes(self, res):
+        """per frame and kernel group (DESIGN.md "kernels and rooflines")"""
+        sizes = level_sizes(self.rows, self.cols, self.nlevels)
+        Ppx = sum(w * h for w, h in sizes)
+        WH = self.rows * self.cols
+        nkp, nln = float(res["n"].mean()), float(res["nl"].mean())
+        sWH = int(np.rint(self.cols * 0.8)) * int(np.rint(self.rows * 0.8))
+        return [(Ppx - sizes[-1][0] * sizes[-1][1]) + (Ppx - WH),         # pyramid: read levels 0..L-2, write 1..L-1
+                Ppx,                                                      # FAST: every level read once
+                0,                                                        # quad-tree: latency-bound list work
+                nkp * (43 * 43 + 32 + 28),                                # orientation + rBRIEF patch gathers
+                (2 * WH if self.tum else 0) + 2 * WH + WH + sWH + sWH * (1 + 16) + sWH * (16 + 4),   # remap, blur, resize, records, order
+                3 * sWH * 9,                                              # region growing: ~3 passes over the 0.64WH field (SURVEY 8d)
+                0,
+                2 * WH + WH + 4 * WH + nln * 63 * 80 * 4]                 # LBD: blur, Sobel read/write, band gathers
+
+    def close(self):
+        if self.fe is not None:
+            self.fe.close()
+        self.fe = None
+        self.d_imgs = None
+
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            pass
+    return {}
+
+
+def single_frame_latency(P, torch, dev, frames, nfeatures, nlevels, nlines, K, D, reps=12):
+    """One Frame() worth of extraction through the host-buffer entry points (plh_orb_extract / plh_line_extract: H2D, kernels,
+    D2H, blocking), ORB and lines on two host threads as Frame.cc:224-227 runs ExtractORB / ExtractLSD."""
+    rows, cols = frames[0].shape
+    orb = P.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, rows=rows, cols=cols, max_batch=1, device=dev.index)
+    line = P.LINEextractor(1, 1.2, nlines, 0.0, rows=rows, cols=cols, max_batch=1, device=dev.index, K=K, D=D)
+    out = {}
+
+    def timed(fn, n):
+        fn(frames[0])                        # first call: plan + staging buffers
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(frames[(i + 1) % len(frames)])
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def both(img):
+        ta = threading.Thread(target=orb, args=(img,))
+        tb = threading.Thread(target=line, args=(img,))
+        ta.start(); tb.start(); ta.join(); tb.join()
+
+    out["orb"] = round(timed(orb, reps), 3)
+    out["line"] = round(timed(line, reps), 3)
+    out["total"] = round(timed(both, reps), 3)
+    out["note"] = ("host-buffer calls on one %dx%d frame, %d ORB / %d lines, two host threads (Frame.cc:224-227); one wavefront walks the "
+                   "frame's LSD region growing, see DESIGN.md 'single-frame latency'" % (cols, rows, nfeatures, nlines))
+    orb.close()
+    line.close()
+    return out
 
 
 def main():
@@ -117,9 +254,10 @@ def main():
     ap.add_argument("--nlevels", type=int, default=8)
     ap.add_argument("--nlines", type=int, default=200)
     ap.add_argument("--unique", type=int, default=32, help="distinct rasterised frames (the rest are cheap variants)")
+    ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: records gathered to rank 0 or to every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fake-gather", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # 1-rank RCCL group: rehearses the N > 1 path
+    ap.add_argument("--no-extras", action="store_true", help="skip the N = 1 secondary / streaming / latency legs")
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # 1-rank RCCL communicator: rehearses the N > 1 path
     ap.add_argument("--serial", action="store_true", help="ORB and line halves on one stream (no overlap); used for PMC runs")
     args = ap.parse_args()
 
@@ -135,53 +273,52 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.force_dist:
+    gathering = world > 1 or args.force_dist
+    rccl_log = "/tmp/plslam_bench_rccl_%d.log" % os.getpid()
+    if gathering:
+        # keep stdout to the one JSON line: RCCL's log (topology and the transport of every channel) goes to a file,
+        # which rank 0 summarises into the JSON afterwards
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # keep stdout to the one JSON line: RCCL's NCCL_DEBUG=VERSION banner (set in this image) goes to a file
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/plslam_bench_rccl_%h_%p.log")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # barrier + max-over-ranks + id exchange
 
     P, S = _util.plslam(), _util.synth()
     V = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
     PL = _util._load("plslam_amd_pipeline", os.path.join(ROOT, "pl-slam_amd", "pipeline.py"))
-    B, rows, cols = args.batch, args.rows, args.cols
-    tum = (rows, cols) == (480, 640)
-    K, D = (TUM1_K, TUM1_D) if tum else (None, None)     # KITTI: zero distortion -> no remap (Frame.cc:917-921)
-    frames = S.make_frames(2 + 100000 * rank, B, rows, cols, unique=args.unique)
-    d_imgs = torch.from_numpy(frames).to(dev)
-    voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=S)
-    fe = PL.FrontEndPipelined(P, voc, B, rows, cols, args.nfeatures, args.nlevels, args.nlines, 0.0, K, D, device=local_rank,
-                              nsplit=args.nsplit)
-    fe.overlap = not args.serial
-    Bp = fe.Bp
-    DI = _util._load("plslam_amd_dist", os.path.join(ROOT, "pl-slam_amd", "dist.py"))
+    voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=S, idf=True)
+    W = Workload(P, S, V, PL, torch, dev, rank, args.batch, args.nsplit, args.rows, args.cols, args.nfeatures, args.nlevels, args.nlines,
+                 args.unique, voc, serial=args.serial)
+    fe, B, Bp, rows, cols = W.fe, W.B, W.Bp, W.rows, W.cols
 
-    gathering = world > 1 or args.fake_gather or args.force_dist
-    comm = torch.cuda.Stream(device=dev) if gathering else None
-    gdist = dist
-    if args.fake_gather and world == 1:   # single-GPU rehearsal of the N > 1 choreography (a copy stands in for RCCL)
-        class _Loop:
-            @staticmethod
-            def all_gather_into_tensor(dst, src):
-                dst.copy_(src)
-        gdist = _Loop
+    comm = comm_stream = None
+    recv = None
+    if gathering:
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(P.Comm.unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(uid, 0)
+        comm = P.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world, device=local_rank)
+        comm_stream = torch.cuda.Stream(device=dev)
+        root = 0 if args.gather == "root" else -1
+        recv = fe.alloc_gather_buffers(world, receives=(root < 0 or rank == root))
 
     def step():
         # consecutive steps are independent batches and overlap (sub-batch pipelining).  N > 1: the fixed-stride records of
-        # every sub-batch are all_gather'ed over RCCL / xGMI on a communication stream as soon as that sub-batch is done
-        # (pl-slam_amd/dist.py, gloo-tested on CPU); only the sub-batch's own next step waits for its gather
-        fe.step(d_imgs, join=False)
+        # every sub-batch go over RCCL / xGMI on a communication stream as soon as that sub-batch is done (plh_gather_records,
+        # one grouped launch); only the sub-batch's own next step waits for its gather
+        fe.step(W.d_imgs, join=False)
         if gathering:
-            fe.gather(comm, world, gdist, DI.all_gather_records)
+            fe.gather(comm_stream, comm, root, recv)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    for part in fe.parts:
-        part.orb.set_profiling(True)
-        part.line.lib.plh_line_set_profiling.argtypes = [C_VOID, C_INT]
-        part.line.lib.plh_line_set_profiling(part.line.h, 1)
+    W.set_profiling(True)     # HIP events around the kernel groups: the roofline is measured over the timed region itself
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -198,113 +335,200 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    def read_kernel_totals():
-        """Cumulative (ms, intervals) of the 8 kernel groups since profiling was switched on."""
-        import ctypes as C
-        tot = [[0.0, 0] for _ in range(8)]
-        for part in fe.parts:
-            for k in range(4):
-                ms, n = part.orb.kernel_ms(k)
-                tot[k][0] += ms
-                tot[k][1] += n
-            lib = part.line.lib
-            lib.plh_line_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-            for k in range(4):
-                ms, n = C.c_double(0), C.c_int(0)
-                lib.plh_line_kernel_ms(part.line.h, k, C.byref(ms), C.byref(n))
-                tot[4 + k][0] += ms.value
-                tot[4 + k][1] += n.value
-        return [tuple(x) for x in tot]
-
+    result_line = None
     if rank == 0:
-        names = ["k_pyr_down x7", "k_fast_strips", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
-                 "k_lsd_grow", "k_keylines", "LBD (blur+sobel+k_lbd)"]
-        t1 = read_kernel_totals()
+        t1 = W.kernel_totals()
         per_ms_timed = [ms / max(n, 1) for ms, n in t1]   # HIP events on the launch streams, over the timed region
         # one more pass with both halves on one stream: per-kernel durations without interference between the halves
         fe.overlap = False
         for _ in range(2):
-            fe.step(d_imgs, join=True)
+            fe.step(W.d_imgs, join=True)
         torch.cuda.synchronize(dev)
-        t2 = read_kernel_totals()
+        t2 = W.kernel_totals()
         per_ms = [(b[0] - a[0]) / max(b[1] - a[1], 1) for a, b in zip(t1, t2)]
         fe.overlap = not args.serial
-        sizes = level_sizes(rows, cols, args.nlevels)
-        Ppx = sum(w * h for w, h in sizes)
-        WH = rows * cols
         res = fe.results()
-        nkp, nln = float(res["n"].mean()), float(res["nl"].mean())
-        sWH = int(np.rint(cols * 0.8)) * int(np.rint(rows * 0.8))
-        # algorithmic bytes per frame of each kernel group (DESIGN.md "kernels and rooflines")
-        alg = [(Ppx - sizes[-1][0] * sizes[-1][1]) + (Ppx - WH),         # pyramid: read levels 0..L-2, write 1..L-1
-               Ppx,                                                      # FAST: every level read once
-               0,                                                        # quad-tree: latency-bound list work
-               nkp * (43 * 43 + 32 + 28),                                # orientation + rBRIEF patch gathers
-               (2 * WH if tum else 0) + 2 * WH + WH + sWH + sWH * (1 + 16) + sWH * (16 + 4),   # remap, blur, resize, records, order
-               3 * sWH * 9,                                              # region growing: ~3 passes over the 0.64WH field (SURVEY 8d)
-               0,
-               2 * WH + WH + 4 * WH + nln * 63 * 80 * 4]                 # LBD: blur, Sobel read/write, band gathers
+        alg = W.algorithmic_bytes(res)
         dom = int(np.argmax(per_ms))
-        # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and tum and args.nfeatures == 1000:   # the counters were collected on this workload only
-            try:
-                traffic = json.load(open(tpath)).get("kernels", {})
-            except Exception:
-                traffic = {}
+        # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame, and the
+        # SQ instruction counters (tools/pmc_insts.sh -> profiles/r02_insts.json): collected on the headline workload only
+        headline = W.tum and args.nfeatures == 1000
+        traffic = load_profile_json("hbm_traffic.json").get("kernels", {}) if headline else {}
+        insts = load_profile_json("r02_insts.json").get("kernels", {}) if headline else {}
         pmc_names = {1: ["k_fast_strips"], 5: ["k_lsd_grow"], 0: ["k_pyr_down"], 2: ["k_octree"], 3: ["k_orient_brief"]}
 
-        def roof(k, ms, where):
-            ach = alg[k] * Bp / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            t = [traffic[n]["total"] * traffic[n].get("launches_per_step", 1) for n in pmc_names.get(k, []) if n in traffic]
-            return {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": int(sum(t) * Bp) if t else None,
-                    "algorithmic_bytes_per_launch": int(alg[k] * Bp), "frames_per_launch": Bp, "ms_per_launch": round(ms, 4),
-                    "measured": where}
+        def roof(k, ms, where, frames_per_launch=Bp, algb=None):
+            algb = alg if algb is None else algb
+            ach = algb[k] * frames_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            tr = [traffic[n]["total"] * traffic[n].get("launches_per_step", 1) for n in pmc_names.get(k, []) if n in traffic]
+            return {"bound": "hbm", "kernel": NAMES[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": int(sum(tr) * frames_per_launch) if tr else None,
+                    "algorithmic_bytes_per_launch": int(algb[k] * frames_per_launch), "frames_per_launch": frames_per_launch,
+                    "ms_per_launch": round(ms, 4), "measured": where}
 
         r_dom = roof(dom, per_ms_timed[dom], "HIP events on the launch stream over the timed region")
         r_dom["ms_per_launch_alone"] = round(per_ms[dom], 4)
+        r_fast = roof(1, per_ms[1], "HIP events, extra pass after the timed region with both halves on one stream")
+        if "k_fast_strips" in insts and per_ms[1] > 0:
+            # the bound this kernel actually runs against: VALU issue: wave64 VALU instructions per second against
+            # 1024 SIMDs x 2.4 GHz / 4.2 cycles
+            gi = insts["k_fast_strips"]["valu"] * Bp / (per_ms[1] * 1e-3) / 1e9
+            r_fast["valu_issue"] = {"achieved": round(gi, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+                                    "frac": round(gi / VALU_PEAK_GINST, 4), "valu_wave_instructions_per_frame": insts["k_fast_strips"]["valu"]}
         out = {
             "metric": "frames/s ORB+LSD extract+match, %dx%d mono" % (cols, rows),
             "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%dx%d mono, %d-level pyramid, %d ORB / %d lines (%s parameters), batch %d frames/GPU resident in HBM "
-                                   "(%d sub-batches of %d pipelined); extract + BoW + SearchByBoW + line SearchDouble per consecutive "
-                                   "frame pair" % (cols, rows, args.nlevels, args.nfeatures, args.nlines,
-                                                   "TUM1.yaml" if tum else "KITTI00-02.yaml", B, args.nsplit, Bp),
-                       "mean_keypoints_per_frame": round(nkp, 1), "mean_keylines_per_frame": round(nln, 1),
+                                   "(%d sub-batches of %d pipelined, consecutive steps overlap, nothing crosses PCIe in the timed region); "
+                                   "extract + ComputeBoW + SearchByBoW + line SearchDouble per consecutive frame pair"
+                                   % (cols, rows, args.nlevels, args.nfeatures, args.nlines, "TUM1.yaml" if W.tum else "KITTI00-02.yaml",
+                                      B, args.nsplit, Bp),
+                       "mean_keypoints_per_frame": round(float(res["n"].mean()), 1), "mean_keylines_per_frame": round(float(res["nl"].mean()), 1),
                        "mean_orb_matches_per_pair": round(float(res["nm_orb"].mean()), 1),
                        "mean_line_matches_per_pair": round(float(res["nm_line"].mean()), 1),
-                       "vocabulary": "synthetic k=10 L=6 (ORBvoc.bin is not in the mount)",
+                       "mean_bow_words_per_frame": round(float(res["bow_n"].mean()), 1),
+                       "frames": "%d rasterised synthetic frames per GPU + cheap variants (row shift, exposure); busy by construction: "
+                                 "~2/3 of the 0.8x-scaled pixels end up in LSD regions, ~10%% of the pyramid pixels are FAST corners at "
+                                 "minThFAST -- a stress case, real TUM frames are sparser" % args.unique,
+                       "vocabulary": "synthetic k=10 L=6, idf-like weights (ORBvoc.bin is not in the mount)",
                        "streams": "line chain on a high-priority stream, ORB + BoW + SearchByBoW on a second stream" if not args.serial else "one stream",
-                       "parallelism": "frames sharded 1 batch/GPU" + (", RCCL all_gather of the records per sub-batch on a "
-                                                                       "communication stream" if world > 1 else "")},
-            "kernel_ms_per_launch": {names[k]: round(per_ms[k], 4) for k in range(8)},
-            "kernel_ms_per_launch_timed_region": {names[k]: round(per_ms_timed[k], 4) for k in range(8)},
+                       "parallelism": "frames sharded 1 batch/GPU" + (
+                           ", records gathered %s through plh_gather_records (RCCL, one grouped launch per sub-batch on a communication "
+                           "stream)" % ("to rank 0" if args.gather == "root" else "to every rank") if gathering else "")},
+            "kernel_ms_per_launch": {NAMES[k]: round(per_ms[k], 4) for k in range(8)},
+            "kernel_ms_per_launch_timed_region": {NAMES[k]: round(per_ms_timed[k], 4) for k in range(8)},
             "roofline": r_dom,
-            "roofline_fast": roof(1, per_ms[1], "HIP events, extra pass after the timed region with both halves on one stream"),
+            "roofline_fast": r_fast,
         }
+        if gathering:
+            tr = {}
+            try:
+                import glob
+                import re
+                for f in glob.glob(rccl_log + "*") + glob.glob("/tmp/plslam_bench_rccl_*.log*"):
+                    for ln in open(f, errors="ignore"):
+                        m = re.search(r"via (P2P/\S+|SHM\S*|NET/\S+|direct\S*)", ln)
+                        if m:
+                            tr[m.group(1)] = tr.get(m.group(1), 0) + 1
+                        if "XGMI" in ln.upper() and "xgmi_lines" not in tr:
+                            tr["xgmi_lines"] = ln.strip()[-160:]
+            except Exception:
+                pass
+            out["rccl"] = {"version": comm.rccl_version(), "gather": args.gather, "channel_transports": tr,
+                           "bytes_per_rank_per_step": int(sum(b.numel() * b.element_size() for part in recv["send"] for b in part))}
+        W.set_profiling(False)
+
+    # ---- N = 1 extras (rank 0 only, after the timed region; none of this is in `value`)
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras_t0 = time.perf_counter()
+        # streaming: fresh frames uploaded from pinned host memory and every record downloaded, each step joined
+        try:
+            host = torch.from_numpy(W.frames).pin_memory()
+            d_alt = [torch.empty_like(W.d_imgs), torch.empty_like(W.d_imgs)]
+            copy_s = torch.cuda.Stream(device=dev)
+            ev = [torch.cuda.Event(), torch.cuda.Event()]
+            keys = ("n", "kps", "desc", "nid", "bow_n", "bow_word", "bow_value", "nl", "kl", "ldesc", "lfn", "m_orb", "nm_orb", "m_line", "nm_line")
+            pinned = [{k: torch.empty_like(getattr(p, k)[:p.B], device="cpu").pin_memory() for k in keys} for p in fe.parts]
+
+            def upload(i):
+                with torch.cuda.stream(copy_s):
+                    d_alt[i & 1].copy_(host, non_blocking=True)
+                    ev[i & 1].record(copy_s)
+
+            nst = 3
+            upload(0)
+            torch.cuda.synchronize(dev)
+            ts = time.perf_counter()
+            for i in range(nst):
+                if i + 1 < nst:
+                    upload(i + 1)                       # next batch crosses PCIe underneath this step's kernels
+                torch.cuda.current_stream(dev).wait_event(ev[i & 1])
+                fe.step(d_alt[i & 1], join=True)
+                for p, dst in zip(fe.parts, pinned):    # D2H of everything one step produced
+                    for k in keys:
+                        dst[k].copy_(getattr(p, k)[:p.B], non_blocking=True)
+                torch.cuda.synchronize(dev)
+            tstream = (time.perf_counter() - ts) / nst
+            up = W.frames.nbytes
+            down = sum(v.numel() * v.element_size() for d in pinned for v in d.values())
+            out["streaming"] = {"value": round(B / tstream, 1), "unit": "frames/s", "ms_per_step": round(tstream * 1e3, 2), "steps": nst,
+                                "h2d_bytes_per_step": int(up), "d2h_bytes_per_step": int(down),
+                                "what": "per step: %d fresh frames H2D from pinned memory (overlapped with the previous step's kernels), one "
+                                        "joined pass, all records D2H; not the contract's `value`" % B}
+            del host, d_alt, pinned
+        except Exception as e:   # the extras never take the headline down
+            out["streaming"] = {"error": repr(e)[:200]}
+        lat_frames = W.frames[:8].copy()
+        W.close()
+        fe = None
+        torch.cuda.empty_cache()
+        try:
+            out["latency_ms_single_frame"] = single_frame_latency(P, torch, dev, lat_frames, args.nfeatures, args.nlevels, args.nlines,
+                                                                  TUM1_K if W.tum else None, TUM1_D if W.tum else None)
+        except Exception as e:
+            out["latency_ms_single_frame"] = {"error": repr(e)[:200]}
+        # secondary workload: KITTI 1241x376 / 2000 features (BASELINE configs[4]'s frame shape)
+        if headline:
+            try:
+                sec = {}
+                for label, b2, ns2 in (("resident_6144", 6144, 4), ("configs4_share_512", 512, 1)):
+                    W2 = Workload(P, S, V, PL, torch, dev, rank, b2, ns2, 376, 1241, 2000, 8, 200, 16, voc)
+                    dt2 = W2.run(3, 1)
+                    W2.set_profiling(True)
+                    W2.fe.overlap = False
+                    for _ in range(2):
+                        W2.fe.step(W2.d_imgs, join=True)
+                    torch.cuda.synchronize(dev)
+                    tk = W2.kernel_totals()
+                    pm2 = [ms / max(n, 1) for ms, n in tk]
+                    res2 = W2.fe.results()
+                    alg2 = W2.algorithmic_bytes(res2)
+                    d2 = int(np.argmax(pm2))
+                    sec[label] = {"value": round(b2 * 3 / dt2, 1), "ms_per_step": round(dt2 / 3 * 1e3, 3), "steps": 3, "batch": b2, "nsplit": ns2,
+                                  "mean_keypoints_per_frame": round(float(res2["n"].mean()), 1),
+                                  "roofline": roof(d2, pm2[d2], "HIP events, extra pass with both halves on one stream", W2.Bp, alg2),
+                                  "roofline_fast": roof(1, pm2[1], "HIP events, extra pass with both halves on one stream", W2.Bp, alg2)}
+                    W2.close()
+                    del W2
+                    torch.cuda.empty_cache()
+                out["secondary"] = {"workload": "1241x376 mono (KITTI00-02.yaml: 2000 ORB, 8 levels, no distortion) + 200 lines, same pipeline; "
+                                                "BASELINE configs[4] shards 4096 such frames over 8 GPUs = 512 per GPU",
+                                    "unit": "frames/s", "value": sec["resident_6144"]["value"], "ms_per_step": sec["resident_6144"]["ms_per_step"],
+                                    "roofline": sec["resident_6144"]["roofline"], "resident_6144": sec["resident_6144"],
+                                    "configs4_share_512": sec["configs4_share_512"],
+                                    "note": "at 512 resident frames k_lsd_grow (one wavefront per frame) leaves most SIMD slots empty: the "
+                                            "per-GPU rate of the literal configs[4] job is the configs4_share_512 figure, the 6144-frame one is "
+                                            "what a GPU sustains on a long sequence"}
+            except Exception as e:
+                out["secondary"] = {"error": repr(e)[:300]}
+        out["extras_seconds"] = round(time.perf_counter() - extras_t0, 1)
+    else:
+        W.close()
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0)
             O = _util.oracle()
             O.build()
-            out["cpu_baseline"] = cpu_baseline(O, V, frames[:min(B, 64)], voc, args.nfeatures, args.nlevels, args.nlines,
-                                               TUM1_K if tum else [718.856, 718.856, 607.1928, 185.2157],
-                                               TUM1_D if tum else [0, 0, 0, 0, 0])
+            fr = S.make_frames(2, 64, rows, cols, unique=min(args.unique, 64))
+            out["cpu_baseline"] = cpu_baseline(O, V, fr, voc, args.nfeatures, args.nlevels, args.nlines,
+                                               TUM1_K if (rows, cols) == (480, 640) else KITTI_K,
+                                               TUM1_D if (rows, cols) == (480, 640) else [0, 0, 0, 0, 0])
         result_line = json.dumps(out)
-    fe.close()
-    try:   # flush what native libraries (the RCCL version banner) buffered on C stdio, on every rank, BEFORE the result line
+    if comm is not None:
+        comm.close()
+    try:   # flush what native libraries buffered on C stdio, on every rank, BEFORE the result line
         import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
     sys.stdout.flush()
-    if world > 1 or args.force_dist:
+    if world > 1:
         dist.barrier()
     if rank == 0:
         print(result_line, flush=True)   # the one JSON line, last on stdout
-    if world > 1 or args.force_dist:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -506,6 +506,36 @@ PLH_API plh_status plh_distinctive_descriptor_batch_dev(const uint8_t* d_desc, c
                                                         int32_t* d_best, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: collecting the records of a frame batch that is sharded over the GPUs of a node
+ *
+ * Frames are independent, so every rank (one process per GPU) runs the front end on its own frames with no collective
+ * inside; the one exchange is the gather of the fixed-stride result records -- counts, plh_keypoint records, ORB
+ * descriptors, plh_keyline records, LBD descriptors, line equations, ... -- over RCCL (xGMI inside a node).  RCCL is bound
+ * at run time (the copy already loaded in the process, else librccl.so.1); a host that never calls these never loads it.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct plh_comm plh_comm;
+#define PLH_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
+/* ncclGetUniqueId: called by ONE rank, whose host hands the 128 bytes to the others (MPI, a socket, a file, torch.distributed). */
+PLH_API plh_status plh_comm_unique_id(uint8_t id[PLH_COMM_ID_BYTES]);
+/* ncclCommInitRank on `device`: collective over the `world` ranks that share `id`. */
+PLH_API plh_status plh_comm_create(const uint8_t id[PLH_COMM_ID_BYTES], int rank, int world, int device, plh_comm** out);
+/* Use an ncclComm_t the host already owns (not destroyed by plh_comm_destroy). */
+PLH_API plh_status plh_comm_wrap(void* nccl_comm, int rank, int world, plh_comm** out);
+PLH_API plh_status plh_comm_destroy(plh_comm* c);
+PLH_API plh_status plh_comm_info(const plh_comm* c, int* rank, int* world, int* rccl_version);
+/* One block = `bytes` bytes of records per rank (the same on every rank: fixed strides, frames per rank equal).
+ * recv holds world * bytes, rank r's records at recv + r * bytes; it may be NULL on ranks that do not receive. */
+typedef struct plh_gather_block {
+  const void* send;
+  void* recv;
+  size_t bytes;
+} plh_gather_block;
+/* All blocks of a sub-batch in ONE grouped RCCL launch, asynchronous on `stream` (device pointers).
+ * root = -1: every rank receives everything (ncclAllGather); root >= 0: only that rank does (ncclGather), which is what a
+ * tracker that consumes the records on one GPU needs and moves 1/world of the all-gather's bytes per link. */
+PLH_API plh_status plh_gather_records(plh_comm* c, const plh_gather_block* blocks, int nblocks, int root, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Line extractor  (replaces ORB_SLAM2::LINEextractor, include/LineExtractor.h:20-62)
  * ------------------------------------------------------------------------------------------- */
 typedef struct plh_line plh_line;

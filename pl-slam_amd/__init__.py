@@ -81,6 +81,12 @@ _SIGS = {
     "plh_vocab_device_arrays": ([_V, _V, _V, _V, _V, _V, _V], _I),
     "plh_vocab_read": ([_V, _V, _V, _V, _V, _V, _V], _I),
     "plh_vocab_transform_batch_dev": ([_V, _V, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V], _I),
+    "plh_comm_unique_id": ([_V], _I),
+    "plh_comm_create": ([_V, _I, _I, _I, _V], _I),
+    "plh_comm_wrap": ([_V, _I, _I, _V], _I),
+    "plh_comm_destroy": ([_V], _I),
+    "plh_comm_info": ([_V, _V, _V, _V], _I),
+    "plh_gather_records": ([_V, _V, _I, _I, _V], _I),
     "plh_line_create": ([_V, _I, _I, _I, _I, _V], _I),
     "plh_line_destroy": ([_V], _I),
     "plh_line_capacity": ([_V], _I),
@@ -846,6 +852,53 @@ def bow_transform(descs, vocab, levelsup=4, device=0, lib=None):
     _check(L, L.plh_bow_transform_batch_dev(_p(da), _p(dn), cap, P, _p(nd), _p(cs), _p(cc), _p(wi), _p(wt), vocab.L, levelsup,
                                             _p(dnid), _p(dword), C.c_void_p(D.stream())), "plh_bow_transform_batch_dev")
     return D.get(dnid), D.get(dword)
+
+
+class GatherBlock(C.Structure):
+    _fields_ = [("send", C.c_void_p), ("recv", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+class Comm:
+    """One communicator per process / GPU for collecting the records of a sharded frame batch (plh_comm_*, RCCL inside)."""
+
+    def __init__(self, unique_id, rank, world, device=0, lib=None):
+        self.lib = load(lib)
+        self.rank, self.world = rank, world
+        uid = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        h = C.c_void_p()
+        _check(self.lib, self.lib.plh_comm_create(uid, rank, world, device, C.byref(h)), "plh_comm_create")
+        self.h = h
+
+    @staticmethod
+    def unique_id(lib=None):
+        L = load(lib)
+        uid = (C.c_uint8 * 128)()
+        _check(L, L.plh_comm_unique_id(uid), "plh_comm_unique_id")
+        return bytes(uid)
+
+    def rccl_version(self):
+        v = C.c_int(0)
+        _check(self.lib, self.lib.plh_comm_info(self.h, None, None, C.byref(v)), "plh_comm_info")
+        return v.value
+
+    def gather(self, pairs, root=-1, stream=0):
+        """pairs: [(send tensor / array, recv tensor / array or None)]; one grouped launch on `stream`."""
+        blocks = (GatherBlock * len(pairs))()
+        for i, (snd, rcv) in enumerate(pairs):
+            nbytes = snd.numel() * snd.element_size() if hasattr(snd, "numel") else snd.nbytes
+            blocks[i] = GatherBlock(_p(snd), _p(rcv) if rcv is not None else None, nbytes)
+        _check(self.lib, self.lib.plh_gather_records(self.h, blocks, len(pairs), root, C.c_void_p(stream)), "plh_gather_records")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.plh_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class VocabInfo(C.Structure):

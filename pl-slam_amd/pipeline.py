@@ -188,6 +188,7 @@ class FrontEndPipelined:
     def close(self):
         for p in self.parts:
             p.close()
+        self.parts = []
 
     def step(self, d_imgs, join=True):
         main = self.torch.cuda.current_stream(self.dev)
@@ -205,26 +206,33 @@ class FrontEndPipelined:
         for p in self.parts:
             p.join(main)
 
-    def gather(self, comm_stream, world, dist, gather_fn):
-        """N > 1: all_gather the fixed-stride records of every sub-batch on `comm_stream` as soon as that sub-batch is done,
-        without joining the step: a sub-batch's next step waits only for its own gather (which reads its buffers), so the
-        RCCL traffic over xGMI overlaps with the compute of the other sub-batches.  Returns the gathered dicts."""
-        t = self.torch
-        out = []
+    GATHERED = ("n", "kps", "desc", "nl", "kl", "ldesc", "lfn")   # the records a tracker on another GPU needs
+
+    def alloc_gather_buffers(self, world, receives=True):
+        """Per sub-batch: the send views (this rank's records) and, on receiving ranks, buffers for `world` ranks' records."""
+        send, recv = [], []
         for p in self.parts:
+            sv = [getattr(p, k)[:p.B] for k in self.GATHERED]
+            send.append(sv)
+            recv.append([v.new_empty((world,) + tuple(v.shape)) for v in sv] if receives else [None] * len(sv))
+        return {"send": send, "recv": recv}
+
+    def gather(self, comm_stream, comm, root, bufs):
+        """N > 1: the fixed-stride records of every sub-batch go over RCCL on `comm_stream` as soon as that sub-batch is done
+        (plh_gather_records: one grouped launch per sub-batch; root = -1 all ranks receive, else only `root`), without joining
+        the step: a sub-batch's next step waits only for its own gather (which reads its buffers), so the xGMI traffic overlaps
+        with the compute of the other sub-batches."""
+        t = self.torch
+        for p, sv, rv in zip(self.parts, bufs["send"], bufs["recv"]):
             if p.overlap:
                 comm_stream.wait_event(p.ev_line)
                 comm_stream.wait_event(p.ev_orb)
             else:
                 comm_stream.wait_stream(t.cuda.current_stream(self.dev))
-            with t.cuda.stream(comm_stream):
-                B = p.B
-                out.append(gather_fn({"n": p.n[:B], "kps": p.kps[:B], "desc": p.desc[:B], "nl": p.nl[:B], "kl": p.kl[:B],
-                                      "ldesc": p.ldesc[:B]}, world, dist))
+            comm.gather(list(zip(sv, rv)), root=root, stream=comm_stream.cuda_stream)
             if p.ev_free is None:
                 p.ev_free = t.cuda.Event()
             p.ev_free.record(comm_stream)
-        return out
 
     def results(self):
         rs = [p.results() for p in self.parts]

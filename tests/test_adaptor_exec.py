@@ -39,6 +39,10 @@ def _lib(path):
     if not os.path.exists(path):
         pytest.skip("%s not built (oracle/ref/build_adaptor.sh needs /root/reference)" % os.path.basename(path))
     G = _gen()
+    if path == LIB_HIP:
+        # the product library first, through the mirror: it imports torch so that the process holds ONE HIP runtime
+        # (libadaptor_hip.so would otherwise pull /opt/rocm's in before PyTorch brings its own)
+        _util.plslam().load()
     R = G.ref_frame_lib(path)
     R.adx_tracker_create.restype = V
     R.adx_tracker_create.argtypes = [I, F, I, I, I, I, C.c_double]
