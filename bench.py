@@ -302,7 +302,20 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(P.Comm.unique_id()), dtype=torch.uint8))
         if world > 1:
             dist.broadcast(uid, 0)
-        comm = P.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world, device=local_rank)
+        # RCCL prints a version banner on stdout when a communicator is created (NCCL_DEBUG >= VERSION): stdout is the one
+        # JSON line's, so the descriptor points at the log file while ncclCommInitRank runs
+        sys.stdout.flush()
+        saved = os.dup(1)
+        logfd = os.open(rccl_log + ".stdout", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.dup2(logfd, 1)
+        try:
+            comm = P.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world, device=local_rank)
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+            os.close(logfd)
         comm_stream = torch.cuda.Stream(device=dev)
         root = 0 if args.gather == "root" else -1
         recv = fe.alloc_gather_buffers(world, receives=(root < 0 or rank == root))
@@ -358,9 +371,11 @@ def main():
         pmc_names = {1: ["k_fast_strips"], 5: ["k_lsd_grow"], 0: ["k_pyr_down"], 2: ["k_octree"], 3: ["k_orient_brief"]}
 
         def roof(k, ms, where, frames_per_launch=Bp, algb=None):
+            tr = []
+            if algb is None:   # PMC traffic was collected on the headline workload only
+                tr = [traffic[n]["total"] * traffic[n].get("launches_per_step", 1) for n in pmc_names.get(k, []) if n in traffic]
             algb = alg if algb is None else algb
             ach = algb[k] * frames_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            tr = [traffic[n]["total"] * traffic[n].get("launches_per_step", 1) for n in pmc_names.get(k, []) if n in traffic]
             return {"bound": "hbm", "kernel": NAMES[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": int(sum(tr) * frames_per_launch) if tr else None,
                     "algorithmic_bytes_per_launch": int(algb[k] * frames_per_launch), "frames_per_launch": frames_per_launch,

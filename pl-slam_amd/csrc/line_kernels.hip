@@ -41,8 +41,8 @@ __global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
   for (int k = 0; k < 4; k++) {
     const int sx = cv_round(m[2 * k] * 32.f), sy = cv_round(m[2 * k + 1] * 32.f);
     const int ix = sx >> 5, iy = sy >> 5, ax = sx & 31, ay = sy & 31;
-    auto P = [&](int yy, int xx) -> int {
-      return (xx >= 0 && xx < a.w && yy >= 0 && yy < a.h) ? (int)src[(long long)yy * a.w + xx] : 0;
+    auto P = [&](int yy, int xx) -> int {   // 24-bit multiply + 32-bit offset: a 64-bit v_mad per tap is a quarter-rate instruction
+      return (xx >= 0 && xx < a.w && yy >= 0 && yy < a.h) ? (int)src[__mul24(yy, a.w) + xx] : 0;
     };
     const int s = (32 - ax) * (32 - ay) * 32 * P(iy, ix) + ax * (32 - ay) * 32 * P(iy, ix + 1) +
                   (32 - ax) * ay * 32 * P(iy + 1, ix) + ax * ay * 32 * P(iy + 1, ix + 1);
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
     for (int k = 0; k < 4; k++) {   // output column 4g+k is tile column 4g+k+4: taps at tile columns 4g+k+4-R .. 4g+k+4+R
       int acc = 0;
 #pragma unroll
-      for (int j = -R; j <= R; j++) acc += t.k[3 + j] * q[k + 4 + j];
+      for (int j = -R; j <= R; j++) acc += __mul24(t.k[3 + j], q[k + 4 + j]);   // Q8 tap x byte: v_mad_i32_i24
       hs[k] = (unsigned)acc;
     }
     uint2 hw;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
 #pragma unroll
         for (int tt = 0; tt < 2 * R + 1; tt++) {
           const unsigned d = k < 2 ? wv[tt].x : wv[tt].y;
-          s += t.k[3 - R + tt] * (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
+          s += __mul24(t.k[3 - R + tt], (int)((k & 1) ? (d >> 16) : (d & 0xffffu)));   // Q8 tap x 16-bit row sum < 2^24
         }
         const int v = (s + (1 << 15)) >> 16;
         out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
@@ -194,9 +194,10 @@ __global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (x4 + k < dw) {
-        int s0 = r0[tx[k].ofs] * tx[k].a0, s1 = r1[tx[k].ofs] * tx[k].a0;
-        if (tx[k].a1) { s0 += r0[tx[k].ofs + 1] * tx[k].a1; s1 += r1[tx[k].ofs + 1] * tx[k].a1; }
-        const int v = ((((int)ty.a0 * (s0 >> 4)) >> 16) + (((int)ty.a1 * (s1 >> 4)) >> 16) + 2) >> 2;
+        // every product is (<= 12 bits) x (<= 15 bits): 24-bit multiplies, a plain 32-bit one is a quarter-rate instruction
+        int s0 = __mul24((int)r0[tx[k].ofs], (int)tx[k].a0), s1 = __mul24((int)r1[tx[k].ofs], (int)tx[k].a0);
+        if (tx[k].a1) { s0 += __mul24((int)r0[tx[k].ofs + 1], (int)tx[k].a1); s1 += __mul24((int)r1[tx[k].ofs + 1], (int)tx[k].a1); }
+        const int v = ((__mul24((int)ty.a0, s0 >> 4) >> 16) + (__mul24((int)ty.a1, s1 >> 4) >> 16) + 2) >> 2;
         o |= (uint32_t)(v & 255) << (8 * k);
       }
     }

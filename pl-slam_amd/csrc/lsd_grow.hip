@@ -501,6 +501,21 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
   const unsigned long long pfStart = PF_NOW();
 #endif
   const int nOrd = a.nOrdered[b];
+  if (a.batch <= 8) {
+    // latency mode (a handful of frames, one lone wavefront each): every step of the walk below waits for one dependent
+    // record fetch, so pull the frame's records through this XCD's L2 once, with all loads in flight, before it starts
+    const uint4* P4 = reinterpret_cast<const uint4*>(c.G);
+    const int n16 = a.spitch * a.sh;
+    unsigned acc = 0;
+    for (int i = lane; i < n16; i += 64 * 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int j = i + 64 * k;
+        if (j < n16) acc |= P4[j].w & 0x40000000u;   // bit 30 is never set (q < 2^20 | used = bit 31)
+      }
+    }
+    if (acc) atomicOr(a.status, 8);   // keeps the loads alive; never taken
+  }
   const int grp = lane >> 3, nbr = lane & 7;
   const int nbq = nbr < 4 ? nbr : nbr + 1;
   const int ndy = nbq / 3 - 1, ndx = nbq - (nbq / 3) * 3 - 1;
@@ -894,7 +909,7 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
           const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
           tc = (int)(short)roundf(sCorY);
           const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
-          g[k] = D[(long long)yCor * a.w + xCor];
+          g[k] = D[__mul24(yCor, a.w) + xCor];   // 32-bit offset: the 64-bit multiply-add of a long long index is a quarter-rate instruction
           sCorX += dL0;
           sCorY += dL1;
         }

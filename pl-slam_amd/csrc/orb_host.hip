@@ -11,7 +11,7 @@
 namespace plh {
 
 // launchers implemented in orb_kernels.hip
-void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds, hipStream_t s);
+void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds, const PyrLaunch* fast, hipStream_t s);
 void launch_fast_strips(const OrbDeviceArgs& a, size_t lds, hipStream_t s);
 size_t fast_strip_lds_bytes(int width, int ch);
 constexpr int FAST_STRIP_MAX_W = 200;   // measured on MI355X (1024 frames): 100 -> 3.13 ms, 140 -> 2.82, 200 -> 2.64, 270 -> 3.15, 330 -> 3.24, 660 -> 3.44
@@ -175,8 +175,42 @@ plh_status build_plan(plh_orb* h) {
         const int hi = std::min(std::max((int)h->ytab[L.ytabOff + std::min(y0 + 15, L.h - 1)].ofs + 1, 0), sh - 1);
         maxH = std::max(maxH, hi - lo + 1);
       }
-      L.pyrTP = align_up(maxW, 4);
+      // the fast kernel wants the 8 taps of every 4-pixel group inside one 8-byte window (true up to scale 2) and reads three
+      // aligned dwords from the window's dword on: 12 bytes of slack at the end of a tile row
+      bool fast = true;
+      for (int x4 = 0; x4 < L.w; x4 += 4)
+        if (h->xtab[L.xtabOff + std::min(x4 + 3, L.w - 1)].ofs + 1 - h->xtab[L.xtabOff + x4].ofs > 7) fast = false;
+      L.pyrFast = fast ? 1 : 0;
+      L.pyrTP = align_up(maxW, 4) + (fast ? 12 : 0);
       L.pyrTR = maxH;
+      // Both tables are padded to a multiple of 4 entries (a thread fetches the taps of its 4 columns / 4 rows with two
+      // 16-byte loads; padding taps have zero weights), followed by one entry per 256-column / 16-row output block that holds
+      // the origin and the extent of the block's source tile (ofs = first source column / row, a0 = dwords per tile row /
+      // rows): k_pyr_down then starts with ONE dependent table fetch instead of a chain of them.
+      auto pad4 = [](std::vector<ResizeTap>& t, int base) {
+        while (((int)t.size() - base) & 3) { ResizeTap z = t.back(); z.a0 = 0; z.a1 = 0; t.push_back(z); }
+      };
+      pad4(h->xtab, L.xtabOff);
+      pad4(h->ytab, L.ytabOff);
+      L.xtileOff = (int)h->xtab.size();
+      for (int x0 = 0; x0 < L.pitch; x0 += 256) {
+        ResizeTap e = {0, 0, 0, 0};
+        if (x0 < L.w) {
+          const int lo = h->xtab[L.xtabOff + x0].ofs & ~3;
+          const int hi = std::min((int)h->xtab[L.xtabOff + std::min(x0 + 255, L.w - 1)].ofs + 1, sw - 1);
+          e.ofs = (short)lo; e.a0 = (short)((hi - lo + 4) >> 2);
+        }
+        h->xtab.push_back(e);
+      }
+      pad4(h->xtab, L.xtabOff);
+      L.ytileOff = (int)h->ytab.size();
+      for (int y0 = 0; y0 < L.h; y0 += 16) {
+        const int lo = std::min(std::max((int)h->ytab[L.ytabOff + y0].ofs, 0), sh - 1);
+        const int hi = std::min(std::max((int)h->ytab[L.ytabOff + std::min(y0 + 15, L.h - 1)].ofs + 1, 0), sh - 1);
+        ResizeTap e = {(short)lo, (short)(hi - lo + 1), 0, 0};
+        h->ytab.push_back(e);
+      }
+      pad4(h->ytab, L.ytabOff);
     }
     // ComputeKeyPointsOctTree, ORBextractor.cc:771-787
     L.minBX = ORB_EDGE_THRESHOLD - 3; L.minBY = L.minBX;
@@ -408,7 +442,15 @@ plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batc
   h->lastStream = s;
   prof_mark(h, 0, s);
   for (int l = 1; l < h->nlevels; l++) {
-    launch_pyr_down(a, l, h->levels[l].pitch, h->levels[l].h, (size_t)h->levels[l].pyrTP * h->levels[l].pyrTR, s);
+    const OrbLevel &S = h->levels[l - 1], &D = h->levels[l];
+    PyrLaunch pl;
+    pl.src = l == 1 ? d_imgs : h->dPyr + S.off;
+    pl.srcStride = l == 1 ? (long long)frame_stride : h->pyrFrameBytes;
+    pl.dst = h->dPyr + D.off; pl.dstStride = h->pyrFrameBytes;
+    pl.sW = S.w; pl.sH = S.h; pl.sPitch = S.pitch; pl.dW = D.w; pl.dH = D.h; pl.dPitch = D.pitch; pl.TP = D.pyrTP;
+    pl.xt = h->dXtab + D.xtabOff; pl.yt = h->dYtab + D.ytabOff;
+    pl.xtile = D.xtileOff - D.xtabOff; pl.ytile = D.ytileOff - D.ytabOff;
+    launch_pyr_down(a, l, D.pitch, D.h, (size_t)D.pyrTP * D.pyrTR, D.pyrFast ? &pl : nullptr, s);
     PLH_LAUNCH_CHECK();
   }
   prof_mark(h, 0, s);

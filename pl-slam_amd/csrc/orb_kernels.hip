@@ -33,6 +33,14 @@ __device__ __forceinline__ const uint8_t* level_ptr(const OrbDeviceArgs& a, cons
   return level == 0 ? a.img0 + (long long)b * a.stride0 : a.pyr + (long long)b * a.pyrFrameBytes + lv.off;
 }
 
+__device__ __forceinline__ unsigned align_bytes_u(unsigned hi, unsigned lo, int sh) {   // bytes sh..sh+3 of {hi:lo}, sh in 0..3
+#if defined(HIPEMU)
+  return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * sh));
+#else
+  return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)sh);   // one v_alignbyte_b32 instead of a 64-bit shift
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pyramid: one level-to-level bilinear downscale, OpenCV fixed-point semantics.
 // grid (ceil(pitch/256), ceil(h/16), batch), block (64,4) = a 256 x 16 output tile.  The source pixels behind the tile
@@ -43,21 +51,38 @@ __device__ __forceinline__ const uint8_t* level_ptr(const OrbDeviceArgs& a, cons
 // exactly as cv::resize does, so the device does integer work only.
 // ---------------------------------------------------------------------------------------------
 constexpr int PYR_ROWS = 4;
-__global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
-  HIP_DYNAMIC_SHARED(unsigned char, smem)
-  const OrbLevel S = a.levels[l - 1];
-  const OrbLevel D = a.levels[l];
-  const int b = blockIdx.z, tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
-  const int xb = (int)blockIdx.x * 256, yb = (int)blockIdx.y * 16;
-  const uint8_t* src = level_ptr(a, S, l - 1, b);
-  uint8_t* dst = a.pyr + (long long)b * a.pyrFrameBytes + D.off;
-  const ResizeTap* xt = a.xtab + D.xtabOff;
-  const ResizeTap* yt = a.ytab + D.ytabOff;
+
+// v_perm_b32 / v_dot2_u32_u16 / v_alignbyte_b32 with plain-C++ twins for the emulator build
+#if defined(HIPEMU)
+__device__ __forceinline__ unsigned plh_perm(unsigned hi, unsigned lo, unsigned sel) {   // byte i of the result = byte sel[i] of {hi:lo}; 0x0c -> 0
+  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  unsigned r = 0;
+  for (int i = 0; i < 4; i++) {
+    const unsigned c = (sel >> (8 * i)) & 255u;
+    r |= (c <= 7u ? (unsigned)((v >> (8 * c)) & 255u) : 0u) << (8 * i);
+  }
+  return r;
+}
+__device__ __forceinline__ unsigned plh_udot2(unsigned a, unsigned b, unsigned c) { return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c; }
+#else
+__device__ __forceinline__ unsigned plh_perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ unsigned plh_udot2(unsigned a, unsigned b, unsigned c) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  return __builtin_amdgcn_udot2(x, y, c, false);
+}
+#endif
+
+// Source tile of a 256 x 16 output block -> LDS (aligned dword loads, byte funnel for odd row addresses); shared by both
+// pyramid kernels.  Returns the tile origin (xBase, syBase).
+__device__ __forceinline__ void pyr_stage_tile(const OrbLevel& S, const OrbLevel& D, const ResizeTap* xt, const ResizeTap* yt,
+                                               const uint8_t* src, unsigned char* smem, int xb, int yb, int tid, int& xBase, int& syBase) {
   const int TP = D.pyrTP;
-  // source extent of this tile (uniform)
-  const int xBase = xb < D.w ? (xt[xb].ofs & ~3) : 0;
+  xBase = xb < D.w ? (xt[xb].ofs & ~3) : 0;
   const int xHi = xb < D.w ? min((int)xt[min(xb + 255, D.w - 1)].ofs + 1, S.w - 1) : -1;
-  const int syBase = min(max((int)yt[min(yb, D.h - 1)].ofs, 0), S.h - 1);
+  syBase = min(max((int)yt[min(yb, D.h - 1)].ofs, 0), S.h - 1);
   const int syHi = min(max((int)yt[min(yb + 15, D.h - 1)].ofs + 1, 0), S.h - 1);
   const int nd = (xHi - xBase + 4) >> 2, nrows = syHi - syBase + 1;   // dwords per tile row (0 for an all-padding block)
   for (int i = tid; i < nrows * nd; i += 256) {
@@ -77,6 +102,22 @@ __global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
     }
     reinterpret_cast<unsigned*>(smem)[r * (TP >> 2) + d] = v;
   }
+}
+
+// General form: every tap is a byte read from the LDS tile (any scale factor).
+__global__ void __launch_bounds__(256) k_pyr_down_gather(OrbDeviceArgs a, int l) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  const OrbLevel S = a.levels[l - 1];
+  const OrbLevel D = a.levels[l];
+  const int b = blockIdx.z, tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+  const int xb = (int)blockIdx.x * 256, yb = (int)blockIdx.y * 16;
+  const uint8_t* src = level_ptr(a, S, l - 1, b);
+  uint8_t* dst = a.pyr + (long long)b * a.pyrFrameBytes + D.off;
+  const ResizeTap* xt = a.xtab + D.xtabOff;
+  const ResizeTap* yt = a.ytab + D.ytabOff;
+  const int TP = D.pyrTP;
+  int xBase, syBase;
+  pyr_stage_tile(S, D, xt, yt, src, smem, xb, yb, tid, xBase, syBase);
   __syncthreads();
   const int x4 = xb + (int)threadIdx.x * 4;
   const int y0 = yb + (int)threadIdx.y * PYR_ROWS;
@@ -100,16 +141,115 @@ __global__ void __launch_bounds__(256) k_pyr_down(OrbDeviceArgs a, int l) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (x4 + k < D.w) {
-        int s0 = r0[tx[k].ofs] * tx[k].a0, s1 = r1[tx[k].ofs] * tx[k].a0;
+        int s0 = __mul24((int)r0[tx[k].ofs], (int)tx[k].a0), s1 = __mul24((int)r1[tx[k].ofs], (int)tx[k].a0);
         if (tx[k].a1) {
-          s0 += r0[tx[k].ofs + 1] * tx[k].a1;
-          s1 += r1[tx[k].ofs + 1] * tx[k].a1;
+          s0 += __mul24((int)r0[tx[k].ofs + 1], (int)tx[k].a1);
+          s1 += __mul24((int)r1[tx[k].ofs + 1], (int)tx[k].a1);
         }
-        const int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+        const int v = ((__mul24(b0, s0 >> 4) >> 16) + (__mul24(b1, s1 >> 4) >> 16) + 2) >> 2;
         o |= (uint32_t)(v & 255) << (8 * k);
       }
     }
     *reinterpret_cast<uint32_t*>(dst + (long long)(y0 + r) * D.pitch + x4) = o;
+  }
+}
+
+// Fast form (every group of 4 output pixels draws its 8 taps from one 8-byte source window -- any scale factor up to 2, in
+// particular the reference's 1.2): per source row a thread reads three aligned dwords of the tile, funnels them to the
+// window (2 x v_alignbyte), and every output pixel costs one v_perm_b32 (its two taps as a u16 pair, selector precomputed
+// per column) and one v_dot2_u32_u16 against the packed (a0, a1) coefficients per source row; the vertical pass and the
+// rounding are OpenCV's fixed-point expressions unchanged.  The kernel is latency-bound (a block is a handful of dependent
+// memory round trips), so the table fetches are few and wide: the block's tile origin / extent comes precomputed from the
+// host, the taps of a thread's 4 columns and 4 rows are four 16-byte loads issued before the staging loop.
+struct alignas(16) Tap4 {
+  uint4 lo, hi;   // 4 ResizeTap entries
+};
+__device__ __forceinline__ void tap_unpack(const Tap4& t, int k, int& ofs, int& a0, int& a1) {
+  const unsigned w0 = k == 0 ? t.lo.x : k == 1 ? t.lo.z : k == 2 ? t.hi.x : t.hi.z;
+  const unsigned w1 = k == 0 ? t.lo.y : k == 1 ? t.lo.w : k == 2 ? t.hi.y : t.hi.w;
+  ofs = (int)(short)(w0 & 0xffffu); a0 = (int)(short)(w0 >> 16); a1 = (int)(short)(w1 & 0xffffu);
+}
+__global__ void __launch_bounds__(256) k_pyr_down(PyrLaunch p) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  struct { int w, h, pitch; } S = {p.sW, p.sH, p.sPitch}, D = {p.dW, p.dH, p.dPitch};
+  const int b = blockIdx.z, tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+  const int xb = (int)blockIdx.x * 256, yb = (int)blockIdx.y * 16;
+  const uint8_t* src = p.src + (long long)b * p.srcStride;
+  uint8_t* dst = p.dst + (long long)b * p.dstStride;
+  const int TP = p.TP;
+  const int x4 = xb + (int)threadIdx.x * 4;
+  const int y0 = yb + (int)threadIdx.y * PYR_ROWS;
+  // every table fetch of the block, independent of each other (the tables are padded, see the host plan)
+  const ResizeTap tileX = p.xt[p.xtile + (int)blockIdx.x], tileY = p.yt[p.ytile + (int)blockIdx.y];
+  const bool work = y0 < D.h && x4 < D.pitch;
+  Tap4 tx4, ty4;
+  tx4.lo = tx4.hi = ty4.lo = ty4.hi = uint4{0u, 0u, 0u, 0u};
+  if (work) {
+    const uint4* px = reinterpret_cast<const uint4*>(p.xt + min(x4, (D.w - 1) & ~3));
+    const uint4* py = reinterpret_cast<const uint4*>(p.yt + y0);
+    tx4.lo = px[0]; tx4.hi = px[1];
+    ty4.lo = py[0]; ty4.hi = py[1];
+  }
+  // stage the source tile
+  const int xBase = tileX.ofs, nd = tileX.a0, syBase = tileY.ofs, nrows = tileY.a0;
+  for (int i = tid; i < nrows * nd; i += 256) {
+    const int r = i / nd, d = i - r * nd;
+    const int xs = xBase + 4 * d;
+    const uint8_t* rowp = src + (__mul24(syBase + r, S.pitch) + xs);
+    const int m = (int)((size_t)rowp & 3);
+    unsigned v;
+    if (xs + 4 + (m ? 4 : 0) <= S.pitch) {   // the aligned dword (pair) stays inside the source row
+      const unsigned* ap = reinterpret_cast<const unsigned*>(rowp - m);
+      const unsigned lo = ap[0];
+      v = m ? align_bytes_u(ap[1], lo, m) : lo;
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) v |= (unsigned)rowp[min(k, S.w - 1 - xs)] << (8 * k);
+    }
+    reinterpret_cast<unsigned*>(smem)[__mul24(r, TP >> 2) + d] = v;
+  }
+  __syncthreads();
+  if (!work) return;
+  // per column constants: window origin, byte selectors and packed coefficients of the 4 pixels
+  unsigned sel[4], coef[4];
+  int wx, a0, a1;
+  tap_unpack(tx4, 0, wx, a0, a1);                           // source column of the window's first byte
+  if (x4 >= D.w) wx = xBase;                                // an all-padding group (pitch > width): reads the tile origin, writes zeros
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int ofs;
+    tap_unpack(tx4, k, ofs, a0, a1);
+    const bool live = x4 + k < D.w;
+    const unsigned o = live ? (unsigned)(ofs - wx) : 0u;    // 0 .. 6 (host-checked)
+    sel[k] = 0x0c000c00u | o | ((o + 1u) << 16);            // bytes: tap, 0, tap + 1, 0
+    coef[k] = live ? ((unsigned)(unsigned short)a0 | ((unsigned)(unsigned short)a1 << 16)) : 0u;
+  }
+  const int wofs = wx - xBase;                              // byte offset of the window in a tile row
+  const int wd = wofs >> 2, wsh = wofs & 3;
+#pragma unroll
+  for (int r = 0; r < PYR_ROWS; r++) {
+    if (y0 + r >= D.h) break;
+    int yofs, yb0, yb1;
+    tap_unpack(ty4, r, yofs, yb0, yb1);
+    const int sy0 = min(max(yofs, 0), S.h - 1);
+    const int sy1 = min(max(yofs + 1, 0), S.h - 1);
+    const unsigned* r0 = reinterpret_cast<const unsigned*>(smem + __mul24(sy0 - syBase, TP)) + wd;
+    const unsigned* r1 = reinterpret_cast<const unsigned*>(smem + __mul24(sy1 - syBase, TP)) + wd;
+    const unsigned p0 = r0[0], p1 = r0[1], p2 = r0[2], q0 = r1[0], q1 = r1[1], q2 = r1[2];
+    const unsigned A0 = align_bytes_u(p1, p0, wsh), B0 = align_bytes_u(p2, p1, wsh);   // window bytes 0..3 / 4..7, upper source row
+    const unsigned A1 = align_bytes_u(q1, q0, wsh), B1 = align_bytes_u(q2, q1, wsh);
+    const unsigned b0 = (unsigned)yb0, b1 = (unsigned)yb1;
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned s0 = plh_udot2(plh_perm(B0, A0, sel[k]), coef[k], 0u);   // S[sx] * a0 + S[sx + 1] * a1, < 2^19
+      const unsigned s1 = plh_udot2(plh_perm(B1, A1, sel[k]), coef[k], 0u);
+      // 11-bit coefficient x 15-bit sum: v_mul_u32_u24 (a plain 32-bit multiply is a quarter-rate instruction)
+      const unsigned v = ((__umul24(b0, s0 >> 4) >> 16) + (__umul24(b1, s1 >> 4) >> 16) + 2u) >> 2;
+      o |= (v & 255u) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (__mul24(y0 + r, D.pitch) + x4)) = o;
   }
 }
 
@@ -175,8 +315,8 @@ __device__ __forceinline__ void fast_score_entry(const uint8_t* tile, int TP, ui
   p[12] = t[-3];          p[13] = t[TP - 3];      p[14] = t[2 * TP - 2];  p[15] = t[3 * TP - 1];
   const int M = fast_arc_side(bright ? -v : v, bright ? 1 : -1, p);
   if (M > tlo) {
-    sc[(r - 2) * TP + cx] = (uint8_t)(M - 1);   // score row rr = r - 3 is stored at sc row rr + 1
-    atomicOr(&cmask[(r - 3) * W32 + (cx >> 5)], 1u << (cx & 31));
+    sc[__mul24(r - 2, TP) + cx] = (uint8_t)(M - 1);   // score row rr = r - 3 is stored at sc row rr + 1
+    atomicOr(&cmask[__mul24(r - 3, W32) + (cx >> 5)], 1u << (cx & 31));
   }
 }
 
@@ -243,13 +383,13 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
   int qn = 0;
   for (int ib = 0; ib < nitems; ib += 64) {
     const int it = ib + lane;
-    const int j = (int)(((unsigned)it * rowMul) >> 16);
-    const int g = it - j * ngx;
+    const int j = (int)(__umul24((unsigned)it, rowMul) >> 16);
+    const int g = it - __mul24(j, ngx);
     const bool live = it < nitems;
     const int r = live ? wv + 4 * j + 3 : 3;
     const int cx = live ? (gx0 + g) << 2 : gx0 << 2;
     const int lo = live ? ex0 - (xa + cx) : 4, hi = ex1 - (xa + cx);   // evaluated pixels of the group: lo <= k < hi
-    const uint8_t* t = tile + r * TP + cx;
+    const uint8_t* t = tile + __mul24(r, TP) + cx;
     const unsigned C = ld_u32(t), Lw = ld_u32(t - 4), R = ld_u32(t + 4), U = ld_u32(t - 3 * TP), D = ld_u32(t + 3 * TP);
     const unsigned P12 = align_bytes(C, Lw, 1), P4 = align_bytes(R, C, 3);
     const unsigned ebase = ((unsigned)r << 24) | (unsigned)cx;
@@ -329,20 +469,20 @@ __global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
     for (int i = tid; i < nlist; i += 256) {
       const unsigned e = list[i];
       const int rr = (int)(e >> 10), cxk = (int)(e & 1023u);
-      const uint8_t* s1 = sc + (rr + 1) * TP + cxk;
+      const uint8_t* s1 = sc + __mul24(rr + 1, TP) + cxk;
       const int s = s1[0];
       const int ex = xa + cxk - ex0;                      // column inside the strip's evaluated window
-      const int cj = min((int)(((unsigned)ex * cellMul) >> 16), lastCell);
-      const int cxs = ex - cj * wCell;                    // column inside the cell's evaluated window
-      const int cew = (cj == lastCell ? (ex1 - ex0) - cj * wCell : wCell);
+      const int cj = min((int)(__umul24((unsigned)ex, cellMul) >> 16), lastCell);
+      const int cxs = ex - __mul24(cj, wCell);            // column inside the cell's evaluated window
+      const int cew = (cj == lastCell ? (ex1 - ex0) - __mul24(cj, wCell) : wCell);
       const int mL = max(max((int)s1[-1], (int)s1[-TP - 1]), (int)s1[TP - 1]);
       const int mR = max(max((int)s1[1], (int)s1[-TP + 1]), (int)s1[TP + 1]);
       int m = max((int)s1[-TP], (int)s1[TP]);             // rows outside the strip are zero
       m = max(m, max(cxs > 0 ? mL : 0, cxs < cew - 1 ? mR : 0));
       if (s > m && s >= a.minTh) {
         const unsigned bit = 1u << (cxk & 31);
-        atomicOr(&anyMask[rr * W32 + (cxk >> 5)], bit);
-        if (s >= a.iniTh) { atomicOr(&hiMask[rr * W32 + (cxk >> 5)], bit); s_hi[cj] = 1; }
+        atomicOr(&anyMask[__mul24(rr, W32) + (cxk >> 5)], bit);
+        if (s >= a.iniTh) { atomicOr(&hiMask[__mul24(rr, W32) + (cxk >> 5)], bit); s_hi[cj] = 1; }
       }
     }
     __syncthreads();
@@ -761,6 +901,9 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
                                                      int cap) {
   constexpr int PR = 21, PW = 43, PP = 48;   // patch radius / width / pitch (pitch 48 = 12 dwords)
   constexpr int BR = 18, BW = 37, BP = 40;   // blurred radius / width / pitch
+  // 7x7 sigma = 2 Gaussian in Q8 as literals (= c_gauss7, which the host checks against its own float evaluation at create
+  // time): multiplications by literals are shifts and adds, a multiply by a value loaded from memory is a quarter-rate v_mul_lo_u32
+  constexpr int G0 = 18, G1 = 34, G2 = 49, G3 = 55;
   __shared__ uint8_t patchBuf[PW * PP + 16];
   __shared__ unsigned short hbuf[PW * BP];
   __shared__ uint8_t blur[BW * BP];
@@ -808,7 +951,7 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
     for (int i = lane; i < PW * 12; i += 64) {
       const int r = i / 12, d = i - r * 12;
       reinterpret_cast<unsigned*>(patchBuf)[r * 12 + d] =
-          *reinterpret_cast<const unsigned*>(img + (long long)(ky - PR + r) * lv.pitch + x0a + 4 * d);
+          *reinterpret_cast<const unsigned*>(img + (__mul24(ky - PR + r, lv.pitch) + x0a + 4 * d));   // 32-bit offset, 24-bit multiply
     }
   } else {
     for (int i = lane; i < PW * PW; i += 64) {
@@ -848,8 +991,7 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
     unsigned hs[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      hs[k] = (unsigned)(c_gauss7[0] * (q[k] + q[k + 6]) + c_gauss7[1] * (q[k + 1] + q[k + 5]) +
-                         c_gauss7[2] * (q[k + 2] + q[k + 4]) + c_gauss7[3] * q[k + 3]);   // <= 257 * 255 < 2^16
+      hs[k] = (unsigned)(G0 * (q[k] + q[k + 6]) + G1 * (q[k + 1] + q[k + 5]) + G2 * (q[k + 2] + q[k + 4]) + G3 * q[k + 3]);   // <= 257 * 255 < 2^16
     uint2 hw;
     hw.x = hs[0] | (hs[1] << 16);
     hw.y = hs[2] | (hs[3] << 16);
@@ -869,7 +1011,7 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
         const unsigned d = k < 2 ? w[t].x : w[t].y;
         return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
       };
-      const int sacc = c_gauss7[0] * (f(0) + f(6)) + c_gauss7[1] * (f(1) + f(5)) + c_gauss7[2] * (f(2) + f(4)) + c_gauss7[3] * f(3);
+      const int sacc = __mul24(G0, f(0) + f(6)) + __mul24(G1, f(1) + f(5)) + __mul24(G2, f(2) + f(4)) + __mul24(G3, f(3));
       const int v = (sacc + (1 << 15)) >> 16;
       out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
     }
@@ -917,9 +1059,10 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (kept in this translation unit so the kernels stay file-local)
 // ---------------------------------------------------------------------------------------------
-void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds, hipStream_t s) {
+void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds, const PyrLaunch* fast, hipStream_t s) {
   dim3 grid((pitch / 4 + 63) / 64, (h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), a.batch), block(64, 4);
-  hipLaunchKernelGGL(k_pyr_down, grid, block, lds, s, a, l);
+  if (fast) hipLaunchKernelGGL(k_pyr_down, grid, block, lds, s, *fast);
+  else hipLaunchKernelGGL(k_pyr_down_gather, grid, block, lds, s, a, l);
 }
 size_t fast_strip_lds_bytes(int width, int ch) {   // image tile + score tile + corner bitmap of k_fast_strips (width = xEnd - x0)
   const size_t TP = (size_t)((width + 8 + 3 + 3) & ~3) + 4;

@@ -27,6 +27,8 @@ struct OrbLevel {
   int xtabOff, ytabOff;        // resize tables (levels >= 1)
   int xmax;                    // first dx using the single-tap path (cv::resize)
   int pyrTP, pyrTR;            // k_pyr_down source tile of a 256 x 16 output block: pitch (bytes, multiple of 4) and rows
+  int xtileOff, ytileOff;      // per output block column / row: source tile origin and extent (entries of xtab / ytab)
+  int pyrFast;                 // 1: the 8 taps of every 4-pixel group lie in one 8-byte window (k_pyr_down), 0: k_pyr_down_gather
   float scale;                 // mvScaleFactor[l]
   float kpSize;                // (int)(31 * mvScaleFactor[l])
 };
@@ -51,6 +53,18 @@ struct OrbStrip {              // one row of FAST cells of a level = the work of
 
 struct ResizeTap {             // one entry of the cv::resize coefficient tables
   short ofs, a0, a1, pad;
+};
+
+struct PyrLaunch {             // everything one k_pyr_down launch needs, by value (no dependent table-of-levels fetches)
+  const uint8_t* src;          // level l-1 of frame 0
+  long long srcStride;         // bytes between frames of the source level
+  uint8_t* dst;                // level l of frame 0
+  long long dstStride;
+  int sW, sH, sPitch, dW, dH, dPitch;
+  int TP;                      // tile pitch (bytes)
+  const ResizeTap* xt;         // the level's x taps (padded), then its per-block-column tile entries at xt + xtile
+  const ResizeTap* yt;
+  int xtile, ytile;
 };
 
 struct OrbDeviceArgs {         // kernel argument block (passed by value)

@@ -106,6 +106,7 @@ template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) {
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __mul24(int a, int b) { return a * b; }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
