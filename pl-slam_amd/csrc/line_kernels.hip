@@ -156,8 +156,10 @@ __global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long
   const int syBase = min(max((int)ytab[min(yb, dh - 1)].ofs, 0), sh - 1);
   const int syHi = min(max((int)ytab[min(yb + 15, dh - 1)].ofs + 1, 0), sh - 1);
   const int nd = (xHi - xBase + 4) >> 2, nrows = syHi - syBase + 1;
+  const unsigned rowMul = (1u << 18) / (unsigned)max(nd, 1) + 1u;
+  const bool mulOk = (unsigned)(nrows * nd) * (unsigned)nd < (1u << 18);   // uniform; false only for scale factors near 2   // i / nd by multiplication, exact while i * nd < 2^18
   for (int i = tid; i < nrows * nd; i += 256) {
-    const int r = i / nd, d = i - r * nd;
+    const int r = mulOk ? (int)(__umul24((unsigned)i, rowMul) >> 18) : i / nd, d = i - __mul24(r, nd);
     const int xs = xBase + 4 * d;
     const uint8_t* rowp = S + (long long)(syBase + r) * sPitch + xs;
     const int m = (int)((size_t)rowp & 3);

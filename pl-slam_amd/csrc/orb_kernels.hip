@@ -85,8 +85,12 @@ __device__ __forceinline__ void pyr_stage_tile(const OrbLevel& S, const OrbLevel
   syBase = min(max((int)yt[min(yb, D.h - 1)].ofs, 0), S.h - 1);
   const int syHi = min(max((int)yt[min(yb + 15, D.h - 1)].ofs + 1, 0), S.h - 1);
   const int nd = (xHi - xBase + 4) >> 2, nrows = syHi - syBase + 1;   // dwords per tile row (0 for an all-padding block)
+  // i / nd by multiplication (exact while i * nd < 2^18; a division by a run-time value costs ~30 VALU instructions per
+  // element -- more than the rest of the staging loop)
+  const unsigned rowMul = (1u << 18) / (unsigned)max(nd, 1) + 1u;
+  const bool mulOk = (unsigned)(nrows * nd) * (unsigned)nd < (1u << 18);   // uniform; false only for scale factors near 2
   for (int i = tid; i < nrows * nd; i += 256) {
-    const int r = i / nd, d = i - r * nd;
+    const int r = mulOk ? (int)(__umul24((unsigned)i, rowMul) >> 18) : i / nd, d = i - __mul24(r, nd);
     const int xs = xBase + 4 * d;
     const uint8_t* rowp = src + (long long)(syBase + r) * S.pitch + xs;
     const int m = (int)((size_t)rowp & 3);
@@ -192,8 +196,12 @@ __global__ void __launch_bounds__(256) k_pyr_down(PyrLaunch p) {
   }
   // stage the source tile
   const int xBase = tileX.ofs, nd = tileX.a0, syBase = tileY.ofs, nrows = tileY.a0;
+  // i / nd by multiplication (exact while i * nd < 2^18; a division by a run-time value costs ~30 VALU instructions per
+  // element -- more than the rest of the staging loop)
+  const unsigned rowMul = (1u << 18) / (unsigned)max(nd, 1) + 1u;
+  const bool mulOk = (unsigned)(nrows * nd) * (unsigned)nd < (1u << 18);   // uniform; false only for scale factors near 2
   for (int i = tid; i < nrows * nd; i += 256) {
-    const int r = i / nd, d = i - r * nd;
+    const int r = mulOk ? (int)(__umul24((unsigned)i, rowMul) >> 18) : i / nd, d = i - __mul24(r, nd);
     const int xs = xBase + 4 * d;
     const uint8_t* rowp = src + (__mul24(syBase + r, S.pitch) + xs);
     const int m = (int)((size_t)rowp & 3);
