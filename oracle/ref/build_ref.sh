@@ -1,8 +1,19 @@
 #!/bin/bash
-# Build oracle/_ref/libdbow2_ref.so from the REFERENCE's own DBoW2 sources, where they lie (nothing is copied into the
-# repo): Thirdparty/DBoW2/{DBoW2/*.cpp, DUtils/Random.cpp, DUtils/Timestamp.cpp} + the C wrapper oracle/ref/ref_dbow2.cc,
-# compiled against oracle/ref/stub (a minimal cv::Mat; OpenCV is not in the image).  Output: oracle/_ref/.  The rest of the reference's path needs real OpenCV
-# (imgproc, features2d, line_descriptor) and Eigen and stays unbuildable.  Test infrastructure only.
+# Build oracle/_ref/*.so from the REFERENCE's own sources, where they lie under /root/reference (nothing is copied into the
+# repo), against the stand-in OpenCV / Eigen headers of oracle/ref/stub (neither library is in the image; the OpenCV
+# ALGORITHMS underneath -- resize, GaussianBlur, FAST, Sobel, LSD, remap, knnMatch -- are the oracle's restatements):
+#   libdbow2_ref.so      Thirdparty/DBoW2 (FORB, BowVector, FeatureVector, ScoringObject, vocabulary I/O, transform)
+#   liborb_ref.so        src/ORBextractor.cc
+#   libmisc_ref.so       src/lineIterator.cpp
+#   libline_ref.so       src/LineExtractor.cpp + Thirdparty/line_descriptor (LSDDetector_custom, binary_descriptor_custom)
+#   libmatcher_ref.so    src/ORBmatcher.cc   against stand-ins for Frame / KeyFrame / MapPoint (slam_stub.h)
+#   liblsdmatcher_ref.so src/LSDmatcher.cpp  against the same stand-ins + MapLine
+#   libmapobj_ref.so     src/MapPoint.cc, src/MapLine.cpp with their own headers
+#   libframe_ref.so      src/Frame.cc, KeyFrame.cc, ORBmatcher.cc, LSDmatcher.cpp, MapPoint.cc, MapLine.cpp, the extractors,
+#                        DBoW2, lineIterator -- the reference's real classes throughout (stand-ins: Map, KeyFrameDatabase, Converter)
+# (see the echo lines below for the exact list this script produced).  oracle/ref/build_adaptor.sh builds the same harness
+# once more with the PRODUCT's adaptor classes in place of the extractors and matchers (libadaptor_hip.so / libadaptor_emu.so).
+# Test infrastructure only.
 set -e
 REF=${1:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)

@@ -273,16 +273,22 @@ __device__ int collect_lines(const plh_keyline* K, const double* fn, const plh_g
 }
 
 __device__ __forceinline__ void three_maxima_lanes(int myHist, int& ind1, int& ind2, int& ind3) {
-  int max1 = 0, max2 = 0, max3 = 0;
-  ind1 = -1; ind2 = -1; ind3 = -1;
+  // ComputeThreeMaxima's insertion cascade as selects on locals (written through the reference parameters the compiler
+  // turned the three indices into a scratch array addressed by a selected pointer)
+  int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
   for (int b = 0; b < 30; b++) {
     const int s = __shfl(myHist, b);
-    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
-    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
-    else if (s > max3) { max3 = s; ind3 = b; }
+    const bool g1 = s > max1, g2 = s > max2, g3 = s > max3;
+    max3 = g2 ? max2 : (g3 ? s : max3);
+    i3 = g2 ? i2 : (g3 ? b : i3);
+    max2 = g1 ? max1 : (g2 ? s : max2);
+    i2 = g1 ? i1 : (g2 ? b : i2);
+    max1 = g1 ? s : max1;
+    i1 = g1 ? b : i1;
   }
-  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+  if (max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { i3 = -1; }
+  ind1 = i1; ind2 = i2; ind3 = i3;
 }
 
 __device__ __forceinline__ int rot_bin(float a1, float a2) {

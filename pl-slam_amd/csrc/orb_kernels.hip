@@ -557,10 +557,13 @@ struct OctLds {
   short *x0, *x1, *y0, *y1, *next, *prev, *freeStack, *order;
   int *start, *cnt, *id;
   uint8_t* buf;
-  int* evSize[2];
-  int* evId[2];
-  short* evSlot[2];
+  int *evSize0, *evId0;   // two event lists each; list k starts at + k * evStride / + k * cap (a pointer ARRAY indexed at run time
+  short* evSlot0;         // would push this whole struct into scratch memory)
+  int evStride, cap;
   int* req;   // [0] op [1] slot/prevIdx [2] n
+  __device__ __forceinline__ int* evSize(int k) const { return evSize0 + k * evStride; }
+  __device__ __forceinline__ int* evId(int k) const { return evId0 + k * evStride; }
+  __device__ __forceinline__ short* evSlot(int k) const { return evSlot0 + k * cap; }
 };
 
 __device__ __forceinline__ int key_x(uint32_t k) { return (int)(k >> 20); }
@@ -580,7 +583,8 @@ __global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) 
     n.start = (int*)p;      p += 4 * cap;
     n.cnt = (int*)p;        p += 4 * cap;
     n.id = (int*)p;         p += 4 * cap;
-    for (int k = 0; k < 2; k++) { n.evSize[k] = (int*)p; p += 4 * cap; n.evId[k] = (int*)p; p += 4 * cap; }
+    n.evSize0 = (int*)p; n.evId0 = (int*)p + cap; n.evStride = 2 * cap; n.cap = cap;   // [size 0][id 0][size 1][id 1]
+    p += 16 * cap;
     n.req = (int*)p;        p += 4 * 16;
     n.x0 = (short*)p;       p += 2 * cap;
     n.x1 = (short*)p;       p += 2 * cap;
@@ -590,7 +594,7 @@ __global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) 
     n.prev = (short*)p;     p += 2 * cap;
     n.freeStack = (short*)p; p += 2 * cap;
     n.order = (short*)p;    p += 2 * cap;
-    for (int k = 0; k < 2; k++) { n.evSlot[k] = (short*)p; p += 2 * cap; }
+    n.evSlot0 = (short*)p; p += 4 * cap;
     n.buf = (uint8_t*)p;
   }
 
@@ -728,9 +732,9 @@ __global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) 
                 if (ck > 1) {
                   if (state == S_P1_AFTER) nToExpand++;
                   const int e = evN[evCur]++;
-                  n.evSize[evCur][e] = ck;
-                  n.evId[evCur][e] = n.id[s];
-                  n.evSlot[evCur][e] = (short)s;
+                  n.evSize(evCur)[e] = ck;
+                  n.evId(evCur)[e] = n.id[s];
+                  n.evSlot(evCur)[e] = (short)s;
                 }
               }
               st += ck;
@@ -769,7 +773,7 @@ __global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) 
             if (jdx < 0) {
               state = S_P2_END;
             } else {
-              splitSlot = n.evSlot[prevIdx][n.order[jdx]];
+              splitSlot = n.evSlot(prevIdx)[n.order[jdx]];
               op = OCT_SPLIT;
               state = S_P2_AFTER;
             }
@@ -856,10 +860,10 @@ __global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) 
       // rank sort of the expand vector by (size, creation id) ascending -> order[rank] = entry
       const int pi = n.req[1], cntE = n.req[2];
       for (int e = lane; e < cntE; e += 64) {
-        const int sz = n.evSize[pi][e], id = n.evId[pi][e];
+        const int sz = n.evSize(pi)[e], id = n.evId(pi)[e];
         int rank = 0;
         for (int f = 0; f < cntE; f++) {
-          const int sf = n.evSize[pi][f], idf = n.evId[pi][f];
+          const int sf = n.evSize(pi)[f], idf = n.evId(pi)[f];
           rank += (sf < sz) || (sf == sz && idf < id);
         }
         n.order[rank] = (short)e;
