@@ -1,6 +1,7 @@
 // Host side of the line extractor: plan (LSD constants computed in double exactly as flsd() does),
 // workspace, launch sequence and the C ABI (include/plslam_hip.h, plh_line_*).
 #include <cmath>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -14,6 +15,7 @@ void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* ds
 void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sw, int sh, uint8_t* dst, long long dStride, int dPitch, int dw,
                    int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, int tileTP, int tileTR, hipStream_t s);
 void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s);
+void launch_lsd_angle_table(LsdAngleEntry* tab, hipStream_t s);
 void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s);
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s);
@@ -23,6 +25,36 @@ size_t lsd_grow_lds_bytes(int spitch, int sh);
 }  // namespace plh
 
 using namespace plh;
+
+// The ll_angle() table (line_plan.h) is a property of the device, not of a handle: one copy per device, filled by the
+// first plh_line_create on it and released with the last handle.
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_angleMu;
+LsdAngleEntry* g_angleTab[kMaxDevices] = {};
+int g_angleRefs[kMaxDevices] = {};
+const LsdAngleEntry* angle_table_acquire(int device) {   // current device == `device`
+  if (device < 0 || device >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lk(g_angleMu);
+  if (!g_angleTab[device]) {
+    LsdAngleEntry* t = nullptr;
+    if (hipMalloc((void**)&t, ((size_t)LSD_ANGLE_ROWS << LSD_ANGLE_PITCH_LOG2) * sizeof(LsdAngleEntry)) != hipSuccess) return nullptr;
+    launch_lsd_angle_table(t, nullptr);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(t); return nullptr; }
+    g_angleTab[device] = t;
+  }
+  g_angleRefs[device]++;
+  return g_angleTab[device];
+}
+void angle_table_release(int device) {
+  if (device < 0 || device >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lk(g_angleMu);
+  if (g_angleRefs[device] > 0 && --g_angleRefs[device] == 0) {
+    (void)hipFree(g_angleTab[device]);
+    g_angleTab[device] = nullptr;
+  }
+}
+}  // namespace
 
 struct plh_line {
   plh_line_params p;
@@ -131,6 +163,7 @@ plh_status plh_line_destroy(plh_line* h) {
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
+  if (h->a.angleTab) angle_table_release(h->device);
   delete h;
   return PLH_OK;
 }
@@ -235,6 +268,13 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   TRYHIP(hipMemcpy(h->dCoef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 #undef TRYHIP
+  h->a.angleTab = angle_table_acquire(device);
+  if (!h->a.angleTab) {
+    set_error("plh_line_create: the ll_angle table could not be built on device %d", device);
+    plh_line_destroy(h);
+    return PLH_ERR_ALLOC;
+  }
+  a.angleTab = h->a.angleTab;
   a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.ordered = h->dOrdered; a.reg = h->dReg; a.scr = h->dScr; a.seedcs = h->dSeedCs;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = h->dSegs; a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;

@@ -208,8 +208,40 @@ __global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long
 }
 
 // ---------------------------------------------------------------------------------------------
-// ll_angle(): level-line field (packed gx,gy, see line_dev.h), padding columns cleared, per-frame max gradient.
+// ll_angle(): level-line field (LsdPix records, see line_dev.h), padding columns cleared, per-frame max gradient.
 // ---------------------------------------------------------------------------------------------
+// What ll_angle() derives from one gradient (gx, gy); evaluated once per possible pair into the per-device table
+// (line_plan.h), never per pixel.
+__device__ __forceinline__ LsdAngleEntry lsd_angle_entry(int gx, int gy) {
+  LsdAngleEntry e;
+  e.angf = fast_atan2_deg((float)gx, (float)(-gy));
+  // seed terms: float(cos(ad)), float(sin(ad)) of the double angle ad; region increments: float(cos(af)),
+  // float(sin(af)) of af = float(ad).  One double sincos serves both: af = ad - d with |d| <= 2^-22, and
+  // cos(ad - d) = c (1 - d^2/2) + s d, sin(ad - d) = s (1 - d^2/2) - c d hold to O(d^3) < 1e-19, far below the
+  // double ulp the direct evaluation carries itself.
+  const double ad = (double)e.angf * kDegToRads;
+  const float af = (float)ad;
+  const double d = ad - (double)af, h = 1.0 - 0.5 * d * d;
+  double sd, cd;
+  sincos_0_2pi(ad, sd, cd);
+  double cf = cd * h + sd * d, sf = sd * h - cd * d;
+  if (!(float_round_is_safe(cd) && float_round_is_safe(sd) && float_round_is_safe(cf) && float_round_is_safe(sf))) {
+    sincos(ad, &sd, &cd);
+    cf = cd * h + sd * d;
+    sf = sd * h - cd * d;
+  }
+  e.seedx = (float)cd;
+  e.seedy = (float)sd;
+  e.cs = (float)cf;
+  e.sn = (float)sf;
+  e.pad[0] = e.pad[1] = e.pad[2] = 0.f;
+  return e;
+}
+__global__ void __launch_bounds__(256) k_lsd_angle_table(LsdAngleEntry* tab) {
+  const int ix = blockIdx.x * 256 + threadIdx.x, iy = blockIdx.y;
+  if (ix < LSD_ANGLE_ROWS) tab[((size_t)iy << LSD_ANGLE_PITCH_LOG2) + ix] = lsd_angle_entry(ix - LSD_GRAD_MAX, iy - LSD_GRAD_MAX);
+}
+
 // Block (64,4): 4 rows x 256 columns, 4 horizontally adjacent pixels per thread (two aligned dword loads per row).
 __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   __shared__ unsigned s_max;
@@ -221,54 +253,48 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
     // pixels x4 .. x4+4 of rows y and y+1 (the row below the last one and the dword beyond the pitch are never used)
     unsigned long long r0 = 0, r1 = 0;
     {
-      const unsigned* p0 = reinterpret_cast<const unsigned*>(I + (long long)y * a.spitch + x4);
+      const unsigned* p0 = reinterpret_cast<const unsigned*>(I + (__mul24(y, a.spitch) + x4));
       const bool more = x4 + 4 < a.spitch;
       r0 = p0[0] | ((unsigned long long)(more ? p0[1] : 0u) << 32);
       if (y < a.sh - 1) {
-        const unsigned* p1 = reinterpret_cast<const unsigned*>(I + (long long)(y + 1) * a.spitch + x4);
+        const unsigned* p1 = reinterpret_cast<const unsigned*>(I + (__mul24(y + 1, a.spitch) + x4));
         r1 = p1[0] | ((unsigned long long)(more ? p1[1] : 0u) << 32);
       }
     }
     unsigned qmax = 0;
-    const long long o = (long long)b * a.scaledStride + (long long)y * a.spitch + x4;
-#pragma unroll 1
+    const long long o = (long long)b * a.scaledStride + (__mul24(y, a.spitch) + x4);
+    // all four gathers are requested before the first record is assembled
+    unsigned q[4];
+    bool def[4];
+    uint4 e0[4];
+    float e1[4];
+#pragma unroll
     for (int k = 0; k < 4; k++) {
       const int x = x4 + k;
-      LsdPix px;
-      px.angf = -1024.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
-      float2 seed;
-      seed.x = 0.f; seed.y = 0.f;
-      if (x < a.sw - 1 && y < a.sh - 1) {
-        const int p00 = (int)((r0 >> (8 * k)) & 255), p01 = (int)((r0 >> (8 * k + 8)) & 255);
-        const int p10 = (int)((r1 >> (8 * k)) & 255), p11 = (int)((r1 >> (8 * k + 8)) & 255);
-        const int DA = p11 - p00, BC = p01 - p10;
-        const int gx = DA + BC, gy = DA - BC;
-        px.q = (unsigned)(gx * gx + gy * gy);
-        if (px.q > a.qThresh) {
-          px.angf = fast_atan2_deg((float)gx, (float)(-gy));
-          // seed terms: float(cos(ad)), float(sin(ad)) of the double angle ad; region increments: float(cos(af)),
-          // float(sin(af)) of af = float(ad).  One double sincos serves both: af = ad - d with |d| <= 2^-22, and
-          // cos(ad - d) = c (1 - d^2/2) + s d, sin(ad - d) = s (1 - d^2/2) - c d hold to O(d^3) < 1e-19, far below the
-          // double ulp the direct evaluation carries itself.
-          const double ad = (double)px.angf * kDegToRads;
-          const float af = (float)ad;
-          const double d = ad - (double)af, h = 1.0 - 0.5 * d * d;
-          double sd, cd;
-          sincos_0_2pi(ad, sd, cd);
-          double cf = cd * h + sd * d, sf = sd * h - cd * d;
-          if (!(float_round_is_safe(cd) && float_round_is_safe(sd) && float_round_is_safe(cf) && float_round_is_safe(sf))) {
-            sincos(ad, &sd, &cd);
-            cf = cd * h + sd * d;
-            sf = sd * h - cd * d;
-          }
-          seed.x = (float)cd;
-          seed.y = (float)sd;
-          px.cs = (float)cf;
-          px.sn = (float)sf;
-          qmax = max(qmax, px.q);
-        }
+      const int p00 = (int)((r0 >> (8 * k)) & 255), p01 = (int)((r0 >> (8 * k + 8)) & 255);
+      const int p10 = (int)((r1 >> (8 * k)) & 255), p11 = (int)((r1 >> (8 * k + 8)) & 255);
+      const int DA = p11 - p00, BC = p01 - p10;
+      const int gx = DA + BC, gy = DA - BC;
+      q[k] = (unsigned)(__mul24(gx, gx) + __mul24(gy, gy));
+      def[k] = x < a.sw - 1 && y < a.sh - 1 && q[k] > a.qThresh;
+      e0[k].x = __float_as_uint(-1024.f); e0[k].y = 0u; e0[k].z = 0u; e0[k].w = 0u;
+      e1[k] = 0.f;
+      if (def[k]) {
+        const LsdAngleEntry* e = a.angleTab + (((gy + LSD_GRAD_MAX) << LSD_ANGLE_PITCH_LOG2) + gx + LSD_GRAD_MAX);
+        e0[k] = *reinterpret_cast<const uint4*>(e);
+        e1[k] = e->seedy;
       }
-      if (x < a.spitch) {
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      LsdPix px;
+      px.angf = __uint_as_float(e0[k].x); px.cs = __uint_as_float(e0[k].y); px.sn = __uint_as_float(e0[k].z);
+      px.q = (x4 + k < a.sw - 1 && y < a.sh - 1) ? q[k] : 0u;
+      float2 seed;
+      seed.x = def[k] ? __uint_as_float(e0[k].w) : 0.f;
+      seed.y = e1[k];
+      if (def[k]) qmax = max(qmax, q[k]);
+      if (x4 + k < a.spitch) {
         reinterpret_cast<LsdPix*>(a.pix)[o + k] = px;
         reinterpret_cast<float2*>(a.seedcs)[o + k] = seed;
         a.scr[o + k] = px.q;   // compact copy of q for the seed ordering (scr is free until region growing)
@@ -417,6 +443,17 @@ void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sw, in
                    int dw, int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, int tileTP, int tileTR, hipStream_t s) {
   hipLaunchKernelGGL(k_resize_u8, dim3((dPitch / 4 + 63) / 64, (dh + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), batch), dim3(64, 4),
                      (size_t)tileTP * tileTR, s, src, sStride, sPitch, sw, sh, dst, dStride, dPitch, dw, dh, xtab, ytab, tileTP);
+}
+void launch_lsd_angle_table(LsdAngleEntry* tab, hipStream_t s) {
+#if defined(HIPEMU)
+  // the emulator runs a fiber per thread; the table is a plain loop over the same function there
+  for (int iy = 0; iy < LSD_ANGLE_ROWS; iy++)
+    for (int ix = 0; ix < LSD_ANGLE_ROWS; ix++)
+      tab[((size_t)iy << LSD_ANGLE_PITCH_LOG2) + ix] = lsd_angle_entry(ix - LSD_GRAD_MAX, iy - LSD_GRAD_MAX);
+  (void)s;
+#else
+  hipLaunchKernelGGL(k_lsd_angle_table, dim3((LSD_ANGLE_ROWS + 255) / 256, LSD_ANGLE_ROWS), dim3(256), 0, s, tab);
+#endif
 }
 void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lsd_grad, dim3((a.spitch + 255) / 256, (a.sh + 3) / 4, a.batch), dim3(64, 4), 0, s, a);

@@ -13,6 +13,18 @@ constexpr int LBD_BAND_WIDTH = 7;     // Params::widthOfBand_, binary_descriptor
 constexpr int LBD_ROWS = LBD_NUM_BANDS * LBD_BAND_WIDTH;   // 63 rows of the line support region
 constexpr int LSD_NBINS = 1024;
 
+// ll_angle() as a table.  The 2x2 gradient of 8-bit pixels is a pair of integers in [-510, 510], and everything
+// ll_angle() derives from it per pixel -- fastAtan2 in degrees, the float cos / sin of the double angle (seed terms) and of
+// the float angle (region increments), each a correctly rounded double sincos -- depends on that pair alone.  The table is
+// filled once per device by the same device code that used to run per pixel (180 VALU instructions, 45 of them f64), and
+// k_lsd_grad gathers one 32-byte entry per defined pixel.  Entry (gy + 510, gx + 510), row pitch 1024 entries: 33.5 MB,
+// of which natural images touch the few hundred KB around the origin (L2-resident).
+constexpr int LSD_GRAD_MAX = 510, LSD_ANGLE_ROWS = 2 * LSD_GRAD_MAX + 1, LSD_ANGLE_PITCH_LOG2 = 10;
+struct LsdAngleEntry {
+  float angf, cs, sn, seedx;   // first 16 bytes: the LsdPix fields + cos of the double angle
+  float seedy, pad[3];
+};
+
 struct LineDeviceArgs {
   // geometry
   int w, h;                 // full-resolution image
@@ -42,6 +54,7 @@ struct LineDeviceArgs {
   const ResizeTap* xtab;
   const ResizeTap* ytab;
   const uint8_t* mask;      // optional w*h mask shared by all frames, or null
+  const LsdAngleEntry* angleTab;   // per-device ll_angle() table (line_plan.h)
   // LSD constants (computed on the host in double exactly as flsd() does)
   double prec, p, densityTh;
   unsigned int qThresh;     // pixel is NOTDEF  <=>  gx^2+gy^2 <= qThresh  (<=> sqrt(q/4) <= rho)

@@ -876,9 +876,32 @@ __device__ const unsigned char c_lbd_comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0
                                                  2, 4, 2, 5, 2, 6, 2, 7, 2, 8, 3, 4, 3, 5, 3, 6, 3, 7, 3, 8, 4, 5, 4, 6,
                                                  4, 7, 4, 8, 5, 6, 5, 7, 5, 8, 6, 7, 6, 8, 7, 8};
 
+// v_fract_f32 (x - floor(x), exact for x >= 0) with a plain twin for the emulator
+__device__ __forceinline__ float plh_fract(float x) {
+#if defined(HIPEMU)
+  return x - floorf(x);
+#else
+  return __builtin_amdgcn_fractf(x);
+#endif
+}
+// clamp((int)(short)roundf(v), 0, hi) of the walk (binary_descriptor_custom.cpp:1117-1124) for |v| < 32767, where the cast
+// to short is the identity: everything below zero clamps to 0, and for c >= 0 roundf(c) = trunc(c) + (fract(c) >= 0.5).
+__device__ __forceinline__ int lbd_coord(float v, int hi) {
+  const float c = fmaxf(v, 0.f);
+  const int i = (int)c + (plh_fract(c) >= 0.5f ? 1 : 0);
+  return min(i, hi);
+}
+__device__ __forceinline__ int lbd_coord_wide(float v, int hi) {   // images from 16384 pixels a side: the literal form
+  const int tc = (int)(short)roundf(v);
+  return tc < 0 ? 0 : (tc > hi ? hi : tc);
+}
+
 __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline* kls, const int* nOut, const float* coef,
                                             uint8_t* desc) {
+  __shared__ float rows[4][64];                  // per support-region row: pL nL pO nO (after the global Gaussian)
   __shared__ float des[LBD_NUM_BANDS * 8];
+  __shared__ float sq[LBD_NUM_BANDS * 8];
+  __shared__ float scl[2];
   const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   if (li >= nOut[b]) return;
   const plh_keyline L = kls[(long long)b * a.outCap + li];
@@ -887,28 +910,32 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
   const short halfWidth = (lengthOfLSP - 1) / 2;
   const short halfHeight = (LBD_ROWS - 1) / 2;
   const int imageWidth = a.w - 1, imageHeight = a.h - 1;
+  const bool wide = a.w >= 16384 || a.h >= 16384;   // walk coordinates can leave the range of a short
   const float midX = (float)(0.5 * (L.sPointInOctaveX + L.ePointInOctaveX));
   const float midY = (float)(0.5 * (L.sPointInOctaveY + L.ePointInOctaveY));
   const float dL0 = (float)cos((double)L.angle), dL1 = (float)sin((double)L.angle);
   const float dO0 = -dL1, dO1 = dL0;
   float pL = 0, nL = 0, pO = 0, nO = 0;
-  if (lane < LBD_ROWS) {
+  {
     float sCorX0 = -dL0 * halfWidth + dL1 * halfHeight + midX;
     float sCorY0 = -dL1 * halfWidth - dL0 * halfHeight + midY;
-    for (int r = 0; r < lane; r++) { sCorX0 -= dL1; sCorY0 += dL0; }
+    // row r starts r sequential float steps from row 0: step r is taken by the lanes above r (the mask is scalar)
+#pragma unroll
+    for (int r = 0; r < LBD_ROWS - 1; r++)
+      if (PLH_INV_BALLOT(~0ull << (r + 1))) { sCorX0 -= dL1; sCorY0 += dL0; }
     float sCorX = sCorX0, sCorY = sCorY0;
     // the walk's addresses do not depend on the data: 8 gathers are issued together, then accumulated in walk order
-    // (coordinates and sums advance by the same float additions, in the same order, as the one-pixel-at-a-time loop)
+    // (coordinates and sums advance by the same float additions, in the same order, as the one-pixel-at-a-time loop).
+    // A sum only ever grows by positive terms, so "if (g > 0) p += g; else n -= g;" is p += max(g, 0); n += max(-g, 0):
+    // adding +0 changes nothing (the sums start at +0 and stay non-negative).
     for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
       uint32_t g[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         g[k] = 0;
         if (w0 + k < lengthOfLSP) {
-          int tc = (int)(short)roundf(sCorX);
-          const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
-          tc = (int)(short)roundf(sCorY);
-          const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+          const int xCor = wide ? lbd_coord_wide(sCorX, imageWidth) : lbd_coord(sCorX, imageWidth);
+          const int yCor = wide ? lbd_coord_wide(sCorY, imageHeight) : lbd_coord(sCorY, imageHeight);
           g[k] = D[__mul24(yCor, a.w) + xCor];   // 32-bit offset: the 64-bit multiply-add of a long long index is a quarter-rate instruction
           sCorX += dL0;
           sCorY += dL1;
@@ -917,40 +944,43 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         if (w0 + k < lengthOfLSP) {
-          const short dx = (short)g_x(g[k]), dy = (short)g_y(g[k]);
+          const float dx = (float)g_x(g[k]), dy = (float)g_y(g[k]);
           const float gDL = dx * dL0 + dy * dL1;
           const float gDO = dx * dO0 + dy * dO1;
-          if (gDL > 0) pL += gDL; else nL -= gDL;
-          if (gDO > 0) pO += gDO; else nO -= gDO;
+          pL += fmaxf(gDL, 0.f);
+          nL += fmaxf(-gDL, 0.f);
+          pO += fmaxf(gDO, 0.f);
+          nO += fmaxf(-gDO, 0.f);
         }
       }
     }
-    const float cg = coef[21 + lane];
-    pL = cg * pL; nL = cg * nL; pO = cg * pO; nO = cg * nO;
+    const float cg = coef[21 + min(lane, LBD_ROWS - 1)];
+    rows[0][lane] = cg * pL; rows[1][lane] = cg * nL; rows[2][lane] = cg * pO; rows[3][lane] = cg * nO;   // lane 63: an unused 64th row
   }
-  // band accumulation in row order: band lane bb takes rows 7(bb-1) .. 7(bb+2)-1
+  __syncthreads();
+  // band accumulation in row order: band lane bb takes rows 7 (bb - 1) .. 7 (bb + 2) - 1.  Row hID = 7 (bb - 1) + r sits in
+  // the band above (r < 7), the band itself or the band below; its local Gaussian weight gaussCoefL_[hID % 7 + 7 (r / 7)]
+  // is coef[r] -- the same for every band.
   const int bb = lane;
-  float spL = 0, snL = 0, spL2 = 0, snL2 = 0, spO = 0, snO = 0, spO2 = 0, snO2 = 0;
-  for (int r = 0; r < 3 * LBD_BAND_WIDTH; r++) {
-    const int hID = LBD_BAND_WIDTH * (bb - 1) + r;
-    const bool valid = bb < LBD_NUM_BANDS && hID >= 0 && hID < LBD_ROWS;
-    const int src = valid ? hID : 0;
-    const float rpL = __shfl(pL, src), rnL = __shfl(nL, src), rpO = __shfl(pO, src), rnO = __shfl(nO, src);
-    if (valid) {
-      // r in [0,7): row of the band above -> "band below the current band" coefficient gaussCoefL_[hID % 7]
-      // r in [7,14): own band -> [hID % 7 + 7];  r in [14,21): row of the band below -> [hID % 7 + 14]
-      const float cL = coef[(hID % LBD_BAND_WIDTH) + LBD_BAND_WIDTH * (r / LBD_BAND_WIDTH)];
-      spL += cL * rpL;
-      snL += cL * rnL;
-      spL2 += cL * cL * (rpL * rpL);
-      snL2 += cL * cL * (rnL * rnL);
-      spO += cL * rpO;
-      snO += cL * rnO;
-      spO2 += cL * cL * (rpO * rpO);
-      snO2 += cL * cL * (rnO * rnO);
-    }
-  }
   if (bb < LBD_NUM_BANDS) {
+    float spL = 0, snL = 0, spL2 = 0, snL2 = 0, spO = 0, snO = 0, spO2 = 0, snO2 = 0;
+    const int row0 = LBD_BAND_WIDTH * (bb - 1);
+#pragma unroll
+    for (int r = 0; r < 3 * LBD_BAND_WIDTH; r++) {
+      const bool valid = (r >= LBD_BAND_WIDTH || bb > 0) && (r < 2 * LBD_BAND_WIDTH || bb < LBD_NUM_BANDS - 1);
+      if (valid) {
+        const float rpL = rows[0][row0 + r], rnL = rows[1][row0 + r], rpO = rows[2][row0 + r], rnO = rows[3][row0 + r];
+        const float cL = coef[r];
+        spL += cL * rpL;
+        snL += cL * rnL;
+        spL2 += cL * cL * (rpL * rpL);
+        snL2 += cL * cL * (rnL * rnL);
+        spO += cL * rpO;
+        snO += cL * rnO;
+        spO2 += cL * cL * (rpO * rpO);
+        snO2 += cL * cL * (rnO * rnO);
+      }
+    }
     const float invN2 = (float)(1.0 / (LBD_BAND_WIDTH * 2.0)), invN3 = (float)(1.0 / (LBD_BAND_WIDTH * 3.0));
     const float invN = (bb == 0 || bb == LBD_NUM_BANDS - 1) ? invN2 : invN3;
     float* d = &des[bb * 8];
@@ -964,34 +994,49 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
     d[3] = temp; d[7] = sqrtf(snO2 * invN - temp * temp);
   }
   __syncthreads();
-  if (lane == 0) {
-    float tempM = 0, tempS = 0;
-    for (int q = 0; q < LBD_NUM_BANDS; q++) {
-      const float* d = &des[q * 8];
-      tempM += d[0] * d[0]; tempM += d[1] * d[1]; tempM += d[2] * d[2]; tempM += d[3] * d[3];
-      tempS += d[4] * d[4]; tempS += d[5] * d[5]; tempS += d[6] * d[6]; tempS += d[7] * d[7];
-    }
-    tempM = 1 / sqrtf(tempM);
-    tempS = 1 / sqrtf(tempS);
-    for (int q = 0; q < LBD_NUM_BANDS; q++) {
-      float* d = &des[q * 8];
-      for (int k = 0; k < 4; k++) d[k] = d[k] * tempM;
-      for (int k = 4; k < 8; k++) d[k] = d[k] * tempS;
-    }
-    for (int i = 0; i < LBD_NUM_BANDS * 8; i++)
-      if ((double)des[i] > 0.4) des[i] = (float)0.4;
-    float temp = 0;
-    for (int i = 0; i < LBD_NUM_BANDS * 8; i++) temp += des[i] * des[i];
-    temp = 1 / sqrtf(temp);
-    for (int i = 0; i < LBD_NUM_BANDS * 8; i++) des[i] = des[i] * temp;
+  // normalise means and deviations separately, clamp at 0.4, renormalise (binary_descriptor_custom.cpp:1322-1366).  The
+  // squares are taken by all lanes; the sums, whose order the float result depends on, by one lane per sum.
+  if (lane < 36) {   // chain position i = 4 q + k: des[8 q + k] (means), des[8 q + 4 + k] (deviations)
+    const int e = 8 * (lane >> 2) + (lane & 3);
+    const float m = des[e], sd = des[e + 4];
+    sq[lane] = m * m;
+    sq[36 + lane] = sd * sd;
   }
   __syncthreads();
-  if (lane < 32) {
+  if (lane < 2) {
+    const float* c = sq + 36 * lane;
+    float t = 0;
+#pragma unroll
+    for (int i = 0; i < 36; i++) t += c[i];
+    scl[lane] = 1 / sqrtf(t);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e0 = 0; e0 < LBD_NUM_BANDS * 8; e0 += 64) {
+    const int e = e0 + lane;
+    if (e < LBD_NUM_BANDS * 8) {
+      float v = des[e] * scl[(e >> 2) & 1];
+      if (v >= 0.4f) v = 0.4f;   // (double)v > 0.4  <=>  v >= 0.4f (the float next to 0.4 from above); NaN stays
+      des[e] = v;
+      sq[e] = v * v;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float t = 0;
+#pragma unroll
+    for (int i = 0; i < LBD_NUM_BANDS * 8; i++) t += sq[i];
+    scl[0] = 1 / sqrtf(t);
+  }
+  __syncthreads();
+  if (lane < 32) {   // des[i] * temp on both sides of each comparison
+    const float t = scl[0];
     const float* f1 = &des[8 * c_lbd_comb[lane * 2]];
     const float* f2 = &des[8 * c_lbd_comb[lane * 2 + 1]];
     int result = 0;
+#pragma unroll
     for (int i = 0; i < 8; i++)
-      if (f1[i] > f2[i]) result += 1 << i;
+      if (f1[i] * t > f2[i] * t) result += 1 << i;
     desc[((long long)b * a.outCap + li) * 32 + lane] = (uint8_t)result;
   }
 }

@@ -354,7 +354,36 @@ int plh_device_count(void) {
   return n;
 }
 
+// The kernels carry the patch disc and the blur taps as literals (orb_plan.h); recompute both the way the reference does --
+// the quarter circle of ORBextractor.cc:454-469 and cvRound(getGaussianKernel(7, 2) * 256) of the 8-bit GaussianBlur -- once
+// per process, so that an edit of one side cannot go unnoticed.
+static bool orb_literals_match_reference() {
+  int um[ORB_HALF_PATCH + 2] = {0};
+  const int vmax = (int)std::floor(ORB_HALF_PATCH * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(ORB_HALF_PATCH * std::sqrt(2.f) / 2);
+  const double hp2 = (double)ORB_HALF_PATCH * ORB_HALF_PATCH;
+  for (int v = 0; v <= vmax; v++) um[v] = (int)std::lrint(std::sqrt(hp2 - (double)v * v));
+  for (int v = ORB_HALF_PATCH, v0 = 0; v >= vmin; v--) {
+    while (um[v0] == um[v0 + 1]) v0++;
+    um[v] = v0++;
+  }
+  for (int v = 0; v <= ORB_HALF_PATCH; v++)
+    if (um[v] != ORB_UMAX[v]) return false;
+  float cf[7];
+  double sum = 0;
+  for (int i = 0; i < 7; i++) { cf[i] = (float)std::exp(-0.5 / 4.0 * (i - 3.0) * (i - 3.0)); sum += cf[i]; }
+  for (int i = 0; i < 7; i++) {
+    const float w = (float)(cf[i] * (1.0 / sum));
+    if ((unsigned)std::lrint(w * 256.f) != ORB_GAUSS7_Q8[i < 4 ? i : 6 - i]) return false;
+  }
+  return true;
+}
+
 plh_status plh_orb_create(const plh_orb_params* p, int device, int rows, int cols, int max_batch, plh_orb** out) {
+  static const bool literalsOk = orb_literals_match_reference();
+  if (!literalsOk) {
+    set_error("plh_orb_create: the patch disc / Gaussian literals of orb_plan.h do not match the reference's construction");
+    return PLH_ERR_INVALID;
+  }
   if (!p || !out || rows <= 0 || cols <= 0 || max_batch <= 0 || p->nlevels < 1 || p->nlevels > ORB_MAX_LEVELS ||
       p->nfeatures < 0 || !(p->scale_factor > 1.0f)) {
     set_error("plh_orb_create: invalid argument");

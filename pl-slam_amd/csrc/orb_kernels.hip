@@ -21,13 +21,34 @@ __device__ const signed char c_orb_pattern[1024] = {
 #include "../../include/plh_orb_pattern.inc"
 };
 
-// u_max of the circular 31-px patch; the host asserts this equals the reference's construction
-// (ORBextractor.cc:454-469).
-__device__ const signed char c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// rBRIEF pattern once more as floats: the steering multiplies them, a signed-byte load + sign extension + int -> float
+// conversion per coordinate is 16 x 3 VALU instructions per lane, a float load is none.
+__device__ const float c_orb_pattern_f[1024] = {
+#include "../../include/plh_orb_pattern.inc"
+};
 
-// 7x7 sigma=2 Gaussian in Q8 (cvRound(getGaussianKernel(7,2)*256)); host asserts against its own
-// float evaluation at create time.
-__device__ const int c_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
+// IC_Angle weights.  The integer moments of the circular 31-px patch (u_max from ORB_UMAX, orb_plan.h; the host checks that
+// table against the reference's construction, ORBextractor.cc:454-469, at create time) are linear in the pixels, so they
+// are taken four pixels at a time with v_dot4_u32_u8: entry (row r = v + 15, dword q) holds the byte weights (u + 15) and
+// the 0 / 1 disc mask of columns u = 4q - 15 .. 4q - 12.  m10 = sum (u + 15) I - 15 sum I, m01 = sum v (row sum).
+struct IcWeights { unsigned w[32 * 8 * 2]; };
+constexpr IcWeights make_ic_weights() {
+  IcWeights t{};
+  for (int r = 0; r < 31; r++) {
+    const int v = r - 15, av = v < 0 ? -v : v;
+    for (int q = 0; q < 8; q++) {
+      unsigned wu = 0, w1 = 0;
+      for (int k = 0; k < 4; k++) {
+        const int j = 4 * q + k, u = j - 15, au = u < 0 ? -u : u;
+        if (j < 31 && au <= ORB_UMAX[av]) { wu |= (unsigned)(u + 15) << (8 * k); w1 |= 1u << (8 * k); }
+      }
+      t.w[(r * 8 + q) * 2] = wu;
+      t.w[(r * 8 + q) * 2 + 1] = w1;
+    }
+  }
+  return t;   // row 31: zero weights (the lanes past the last row run the same code)
+}
+__device__ const IcWeights c_icw = make_ic_weights();
 
 __device__ __forceinline__ const uint8_t* level_ptr(const OrbDeviceArgs& a, const OrbLevel& lv, int level, int b) {
   return level == 0 ? a.img0 + (long long)b * a.stride0 : a.pyr + (long long)b * a.pyrFrameBytes + lv.off;
@@ -64,6 +85,13 @@ __device__ __forceinline__ unsigned plh_perm(unsigned hi, unsigned lo, unsigned 
   return r;
 }
 __device__ __forceinline__ unsigned plh_udot2(unsigned a, unsigned b, unsigned c) { return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c; }
+__device__ __forceinline__ unsigned plh_udot4(unsigned a, unsigned b, unsigned c) {
+  for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+  return c;
+}
+__device__ __forceinline__ unsigned plh_pk_min_u16(unsigned a, unsigned b) {
+  return min(a & 0xffffu, b & 0xffffu) | (min(a >> 16, b >> 16) << 16);
+}
 #else
 __device__ __forceinline__ unsigned plh_perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ unsigned plh_udot2(unsigned a, unsigned b, unsigned c) {
@@ -73,7 +101,21 @@ __device__ __forceinline__ unsigned plh_udot2(unsigned a, unsigned b, unsigned c
   __builtin_memcpy(&y, &b, 4);
   return __builtin_amdgcn_udot2(x, y, c, false);
 }
+__device__ __forceinline__ unsigned plh_udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+__device__ __forceinline__ unsigned plh_pk_min_u16(unsigned a, unsigned b) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  const u16x2 r = __builtin_elementwise_min(x, y);   // v_pk_min_u16
+  unsigned o;
+  __builtin_memcpy(&o, &r, 4);
+  return o;
+}
 #endif
+// dot4 / dot2 operands from tap weights (byte / half 0 = lowest address)
+constexpr unsigned w4(unsigned a, unsigned b, unsigned c, unsigned d) { return a | (b << 8) | (c << 16) | (d << 24); }
+constexpr unsigned w2(unsigned lo, unsigned hi) { return lo | (hi << 16); }
 
 // Source tile of a 256 x 16 output block -> LDS (aligned dword loads, byte funnel for odd row addresses); shared by both
 // pyramid kernels.  Returns the tile origin (xBase, syBase).
@@ -902,6 +944,15 @@ __global__ void __launch_bounds__(64) k_octree(OrbDeviceArgs a, int nodeCapMax) 
 // reference blurs a border-less clone) is evaluated for the central 37x37 region only, and the
 // 512 steered rBRIEF samples are gathered from that LDS tile.  No blurred pyramid is ever
 // written to HBM.
+//
+// Everything between the staging and the gather is linear integer arithmetic on bytes / 16-bit sums, so it runs on the
+// packed dot products: IC_Angle and the horizontal blur pass take four pixels per v_dot4_u32_u8 (the tap weights 18 34 49
+// 55 fit a byte), the vertical pass two 16-bit row sums per v_dot2_u32_u16.  For that the row sums are stored TRANSPOSED
+// (hT[column][row]) so that vertically adjacent sums share a dword, and the blurred tile comes out transposed as well
+// (the gather does not care).  Work items are laid out two-dimensionally over 60 of the 64 lanes (5 rows x 12 dwords,
+// 6 x 10 groups of four) so that no pass divides or multiplies for its addresses: round 2 measured 1 240 VALU
+// wave-instructions per keypoint for the scalar formulation of the same sums, of which 240 were address arithmetic of the
+// staging loop alone.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int nn) {
   if (p < 0) p = -p;
@@ -912,13 +963,15 @@ __device__ __forceinline__ int reflect101(int p, int nn) {
 __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoint* kps, uint8_t* desc, int* nOut,
                                                      int cap) {
   constexpr int PR = 21, PW = 43, PP = 48;   // patch radius / width / pitch (pitch 48 = 12 dwords)
-  constexpr int BR = 18, BW = 37, BP = 40;   // blurred radius / width / pitch
-  // 7x7 sigma = 2 Gaussian in Q8 as literals (= c_gauss7, which the host checks against its own float evaluation at create
-  // time): multiplications by literals are shifts and adds, a multiply by a value loaded from memory is a quarter-rate v_mul_lo_u32
-  constexpr int G0 = 18, G1 = 34, G2 = 49, G3 = 55;
-  __shared__ uint8_t patchBuf[PW * PP + 16];
-  __shared__ unsigned short hbuf[PW * BP];
-  __shared__ uint8_t blur[BW * BP];
+  constexpr int BR = 18, BW = 37, BP = 40;   // blurred radius / width / pitch of the transposed blurred tile
+  constexpr int HP = 48;                     // pitch (in u16) of the transposed row sums: rows 0..42 + the over-read of the last group
+  // 7x7 sigma = 2 Gaussian in Q8 (ORB_GAUSS7_Q8, which the host checks against its own float evaluation at create time)
+  constexpr unsigned G0 = ORB_GAUSS7_Q8[0], G1 = ORB_GAUSS7_Q8[1], G2 = ORB_GAUSS7_Q8[2], G3 = ORB_GAUSS7_Q8[3];
+  __shared__ unsigned patchW[(PW * PP + 16) / 4];
+  __shared__ unsigned short hT[40 * HP];
+  __shared__ unsigned blurW[BW * BP / 4];
+  uint8_t* const patchBuf = reinterpret_cast<uint8_t*>(patchW);
+  const uint8_t* const blurT = reinterpret_cast<const uint8_t*>(blurW);
 
   const int slot = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x;
@@ -952,82 +1005,109 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
   const uint8_t* img = level_ptr(a, lv, level, b);
 
   // ---- stage the 43x43 patch.  Interior keypoints with dword-aligned rows: 12 aligned dwords per row, the patch then
-  // starts `sh` bytes into the buffer; otherwise (reflection needed / odd pitch) byte by byte.
+  // starts `sh` bytes into the buffer (the passes below shift by it with v_alignbyte); otherwise (reflection needed / odd
+  // pitch) byte by byte.  Fast path: lane = 12 * (row in a group of five) + dword, so LDS dword index = lane + 60 * pass.
   const int xl = kx - PR;
   const int x0a = xl & ~3;
   const bool fastPath = xl >= 0 && kx + PR < lv.w && ky - PR >= 0 && ky + PR < lv.h && x0a + PP <= lv.pitch &&
                         (((size_t)img | (size_t)lv.pitch) & 3) == 0;
-  const int sh = fastPath ? xl - x0a : 0;
-  uint8_t* patch = patchBuf + sh;   // patch[r * PP + c] = level pixel (kx - 21 + c, ky - 21 + r)
+  const int sh = fastPath ? xl - x0a : 0;   // patch byte (r, c) = patchBuf[r * PP + sh + c] = level pixel (kx - 21 + c, ky - 21 + r)
   if (fastPath) {
-    for (int i = lane; i < PW * 12; i += 64) {
-      const int r = i / 12, d = i - r * 12;
-      reinterpret_cast<unsigned*>(patchBuf)[r * 12 + d] =
-          *reinterpret_cast<const unsigned*>(img + (__mul24(ky - PR + r, lv.pitch) + x0a + 4 * d));   // 32-bit offset, 24-bit multiply
+    if (lane < 60) {
+      const int lr = (lane * 43) >> 9, d = lane - lr * 12;   // lane / 12, lane % 12
+      int off = __mul24(ky - PR + lr, lv.pitch) + x0a + 4 * d;   // 32-bit offset, 24-bit multiply
+      const int step = 5 * lv.pitch;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        if (k < 8 || lane < 36) patchW[lane + 60 * k] = *reinterpret_cast<const unsigned*>(img + off);   // rows 40..42 in the last pass
+        off += step;
+      }
     }
   } else {
     for (int i = lane; i < PW * PW; i += 64) {
       const int r = i / PW, c = i - r * PW;
       const int yy = reflect101(ky - PR + r, lv.h), xx = reflect101(kx - PR + c, lv.w);
-      patch[r * PP + c] = img[(long long)yy * lv.pitch + xx];
+      patchBuf[r * PP + c] = img[(long long)yy * lv.pitch + xx];
     }
   }
   __syncthreads();
 
-  // IC_Angle: integer moments over the circular patch, two rows of 31 per iteration
-  int m10 = 0, m01 = 0;
-  {
-    const int u = (lane & 31) - 15;
-    const int au = u < 0 ? -u : u;
-    for (int v0 = -15; v0 <= 15; v0 += 2) {
-      const int v = v0 + (lane >> 5);
-      const int av = v < 0 ? -v : v;
-      if (v <= 15 && au <= 15 && au <= c_umax[av]) {
-        const int val = patch[(PR + v) * PP + PR + u];
-        m10 += u * val;
-        m01 += v * val;
+  // ---- horizontal pass: rows 0..42, output columns 0..39 (37 used), lane = 10 * (row in a group of six) + column group.
+  // Ten bytes q0..q9 of the row in three shifted dwords A B C; output k = sum_t G[t] q[k + t] as dot4s with the weights
+  // slid along the bytes.
+  if (lane < 60) {
+    const int lr = (lane * 26) >> 8, g = lane - lr * 10;   // lane / 10, lane % 10
+    const unsigned* pw = patchW + lr * 12 + g;
+    unsigned short* hp = hT + 4 * g * HP + lr;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k < 7 || lr == 0) {   // row lr + 6 k < 43
+        const unsigned w0 = pw[72 * k], w1 = pw[72 * k + 1], w2 = pw[72 * k + 2], w3 = pw[72 * k + 3];
+        const unsigned A = align_bytes_u(w1, w0, sh), B = align_bytes_u(w2, w1, sh), C = align_bytes_u(w3, w2, sh);
+        const unsigned h0 = plh_udot4(A, w4(G0, G1, G2, G3), plh_udot4(B, w4(G2, G1, G0, 0), 0u));   // <= 257 * 255 < 2^16
+        const unsigned h1 = plh_udot4(A, w4(0, G0, G1, G2), plh_udot4(B, w4(G3, G2, G1, G0), 0u));
+        const unsigned h2 = plh_udot4(A, w4(0, 0, G0, G1), plh_udot4(B, w4(G2, G3, G2, G1), plh_udot4(C, w4(G0, 0, 0, 0), 0u)));
+        const unsigned h3 = plh_udot4(A, w4(0, 0, 0, G0), plh_udot4(B, w4(G1, G2, G3, G2), plh_udot4(C, w4(G1, G0, 0, 0), 0u)));
+        hp[6 * k] = (unsigned short)h0;
+        hp[6 * k + HP] = (unsigned short)h1;
+        hp[6 * k + 2 * HP] = (unsigned short)h2;
+        hp[6 * k + 3 * HP] = (unsigned short)h3;
       }
     }
   }
-  m10 = wave_sum(m10);
-  m01 = wave_sum(m01);
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-  // horizontal pass: rows 0..42, output columns 0..36 (patch columns c..c+6), four outputs per lane
-  for (int i = lane; i < PW * 10; i += 64) {
-    const int r = i / 10, c0 = (i - r * 10) * 4;
-    const uint8_t* p = &patch[r * PP + c0];
-    int q[10];
+  // ---- IC_Angle (reads the patch only, so it runs before the barrier the vertical pass needs): lane = 8 * (row in a
+  // group of eight) + dword of the 31-byte row
+  int m10, m01;
+  {
+    const int o = sh + (PR - 15);   // byte offset of column u = -15 inside a patch row
+    const int d0 = o >> 2, s2 = o & 3;
+    const unsigned* pw = patchW + ((lane >> 3) + (PR - 15)) * 12 + d0 + (lane & 7);
+    const uint2* wt = reinterpret_cast<const uint2*>(c_icw.w) + lane;
+    unsigned S1 = 0;
+    int S0 = 0, Sv = 0;
+    const int v0 = (lane >> 3) - 15;
 #pragma unroll
-    for (int k = 0; k < 10; k++) q[k] = p[k];   // columns >= 43 of the last group only feed outputs >= 37 (discarded)
-    unsigned hs[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      hs[k] = (unsigned)(G0 * (q[k] + q[k + 6]) + G1 * (q[k + 1] + q[k + 5]) + G2 * (q[k + 2] + q[k + 4]) + G3 * q[k + 3]);   // <= 257 * 255 < 2^16
-    uint2 hw;
-    hw.x = hs[0] | (hs[1] << 16);
-    hw.y = hs[2] | (hs[3] << 16);
-    *reinterpret_cast<uint2*>(&hbuf[r * BP + c0]) = hw;
-  }
-  __syncthreads();
-  // vertical pass: four outputs per lane, 8-byte reads of the 16-bit row sums
-  for (int i = lane; i < BW * 10; i += 64) {
-    const int r = i / 10, c0 = (i - r * 10) * 4;
-    uint2 w[7];
-#pragma unroll
-    for (int t = 0; t < 7; t++) w[t] = *reinterpret_cast<const uint2*>(&hbuf[(r + t) * BP + c0]);
-    unsigned out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      auto f = [&](int t) -> int {
-        const unsigned d = k < 2 ? w[t].x : w[t].y;
-        return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
-      };
-      const int sacc = __mul24(G0, f(0) + f(6)) + __mul24(G1, f(1) + f(5)) + __mul24(G2, f(2) + f(4)) + __mul24(G3, f(3));
-      const int v = (sacc + (1 << 15)) >> 16;
-      out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
+    for (int k = 0; k < 4; k++) {   // rows 8 k + lane / 8; row 31 has zero weights
+      const unsigned A = align_bytes_u(pw[96 * k + 1], pw[96 * k], s2);
+      const uint2 w = wt[64 * k];
+      S1 = plh_udot4(A, w.x, S1);
+      const int rs = (int)plh_udot4(A, w.y, 0u);   // pixels of the row inside the disc, <= 4 * 255
+      S0 += rs;
+      Sv += __mul24(v0 + 8 * k, rs);
     }
-    *reinterpret_cast<unsigned*>(&blur[r * BP + c0]) = out;
+    m10 = wave_sum((int)S1 - 15 * S0);
+    m01 = wave_sum(Sv);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  __syncthreads();
+
+  // ---- vertical pass: lane = 10 * (column in a group of six) + group of four rows; five dwords = ten consecutive row sums
+  // of the column; an even output row takes its taps as (t, t+1) pairs from its own dword on, an odd one from the dword
+  // below with the weights slid by one.  Rounding constant in the accumulator, saturation on packed halves.
+  if (lane < 60) {
+    const int lc = (lane * 26) >> 8, m = lane - lc * 10;
+    const unsigned* hp = reinterpret_cast<const unsigned*>(hT + lc * HP + 4 * m);
+    unsigned* bo = blurW + lc * (BP / 4) + m;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      if (k < 6 || lc == 0) {   // column lc + 6 k < 37
+        const unsigned* p = hp + k * (6 * HP / 2);
+        const unsigned P0 = p[0], P1 = p[1], P2 = p[2], P3 = p[3], P4 = p[4];
+        unsigned a0 = plh_udot2(P0, w2(G0, G1), 1u << 15), a1 = plh_udot2(P0, w2(0, G0), 1u << 15);
+        a0 = plh_udot2(P1, w2(G2, G3), a0); a1 = plh_udot2(P1, w2(G1, G2), a1);
+        a0 = plh_udot2(P2, w2(G2, G1), a0); a1 = plh_udot2(P2, w2(G3, G2), a1);
+        a0 = plh_udot2(P3, w2(G0, 0), a0);  a1 = plh_udot2(P3, w2(G1, G0), a1);
+        unsigned a2 = plh_udot2(P1, w2(G0, G1), 1u << 15), a3 = plh_udot2(P1, w2(0, G0), 1u << 15);
+        a2 = plh_udot2(P2, w2(G2, G3), a2); a3 = plh_udot2(P2, w2(G1, G2), a3);
+        a2 = plh_udot2(P3, w2(G2, G1), a2); a3 = plh_udot2(P3, w2(G3, G2), a3);
+        a2 = plh_udot2(P4, w2(G0, 0), a2);  a3 = plh_udot2(P4, w2(G1, G0), a3);
+        // (a >> 16) of two results as a pair of halves, min(., 255) on both, then the four low bytes
+        const unsigned p01 = plh_pk_min_u16(plh_perm(a1, a0, 0x07060302u), 0x00ff00ffu);
+        const unsigned p23 = plh_pk_min_u16(plh_perm(a3, a2, 0x07060302u), 0x00ff00ffu);
+        bo[k * (6 * BP / 4)] = plh_perm(p23, p01, 0x06040200u);
+      }
+    }
   }
   __syncthreads();
 
@@ -1040,14 +1120,14 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
   sincos_0_2pi((double)ang, sd, cd);
   if (!(float_round_is_safe(cd) && float_round_is_safe(sd))) sincos((double)ang, &sd, &cd);
   const float ca = (float)cd, sa = (float)sd;
-  const signed char* pat = c_orb_pattern + lane * 16;
+  const float* pat = c_orb_pattern_f + lane * 16;
   int nib = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const float x0 = (float)pat[k * 4 + 0], y0 = (float)pat[k * 4 + 1];
-    const float x1 = (float)pat[k * 4 + 2], y1 = (float)pat[k * 4 + 3];
-    const int t0 = blur[(BR + cv_round(x0 * sa + y0 * ca)) * BP + BR + cv_round(x0 * ca - y0 * sa)];
-    const int t1 = blur[(BR + cv_round(x1 * sa + y1 * ca)) * BP + BR + cv_round(x1 * ca - y1 * sa)];
+    const float x0 = pat[k * 4 + 0], y0 = pat[k * 4 + 1];
+    const float x1 = pat[k * 4 + 2], y1 = pat[k * 4 + 3];
+    const int t0 = blurT[(BR + cv_round(x0 * ca - y0 * sa)) * BP + BR + cv_round(x0 * sa + y0 * ca)];   // blurT[column][row]
+    const int t1 = blurT[(BR + cv_round(x1 * ca - y1 * sa)) * BP + BR + cv_round(x1 * sa + y1 * ca)];
     nib |= (t0 < t1) << k;
   }
   const int hiNib = __shfl_down(nib, 1);

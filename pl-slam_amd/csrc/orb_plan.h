@@ -12,6 +12,11 @@ constexpr int ORB_HALF_PATCH = 15;        // ORBextractor.cc:73
 constexpr int ORB_EDGE_THRESHOLD = 19;    // ORBextractor.cc:74
 constexpr int ORB_CELL_MAX = 66;          // max cell sub-image side (wCell <= 60, +6)
 constexpr int ORB_KEY_XY_BITS = 12;       // packed candidate key: x:12 | y:12 | response:8
+// u_max of the circular 31-px patch (ORBextractor.cc:454-469) and the non-negative half of cvRound(getGaussianKernel(7, 2) * 256)
+// (GaussianBlur(7x7, 2, 2) on 8-bit data, ORBextractor.cc:1090): literals so that the kernels fold them into dot-product
+// operands; plh_orb_create recomputes both the reference's way and refuses to run if they differ.
+constexpr int ORB_UMAX[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+constexpr unsigned ORB_GAUSS7_Q8[4] = {18, 34, 49, 55};
 
 struct OrbLevel {
   int w, h, pitch;             // level image; pitch in bytes (level 0 uses the caller's pitch = cols)

@@ -9,7 +9,7 @@ import csv, collections
 f="$R/gpurun_out/pmcinst/o_counter_collection.csv"
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
 for r in csv.DictReader(open(f)):
-    k=r["Kernel_Name"].split("(")[0].replace("plh::","")
+    k=r["Kernel_Name"].split("(")[0].replace("void ","").replace("plh::","")   # template kernels print as "void plh::k<..>(...)"
     acc[k][r["Counter_Name"]]+=float(r["Counter_Value"])
     if r["Counter_Name"]=="SQ_WAVES": n[k]+=1
 steps=max(n.get("k_lsd_grow",1),1)
