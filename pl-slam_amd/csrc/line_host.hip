@@ -1,5 +1,6 @@
 // Host side of the line extractor: plan (LSD constants computed in double exactly as flsd() does),
 // workspace, launch sequence and the C ABI (include/plslam_hip.h, plh_line_*).
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <new>
@@ -70,7 +71,8 @@ struct plh_line {
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
   hipStream_t lastStream = nullptr;   // stream of the most recent extract call (plh_line_status waits on it)
-  float *dSegs = nullptr, *dMap = nullptr, *dCoef = nullptr;
+  float *dSegs = nullptr, *dCoef = nullptr;
+  RemapTap* dMap = nullptr;
   ResizeTap *dXtab = nullptr, *dYtab = nullptr;
   // staging (host-buffer entry points)
   uint8_t *dImgs = nullptr, *dDesc = nullptr;
@@ -210,6 +212,16 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   a.outCap = a.nFeature + 1;
   gaussian_q8_7(7, 0.6 / 0.8, h->taps075);
   gaussian_q8_7(5, 1.0, h->taps1);
+  for (const int* tp : {h->taps075, h->taps1}) {   // k_blur7_u8 multiplies bytes by taps in dot4s and keeps 16-bit row sums
+    int sum = 0;
+    bool ok = true;
+    for (int i = 0; i < 7; i++) { ok = ok && tp[i] >= 0 && tp[i] <= 255; sum += tp[i]; }
+    if (!ok || sum > 257) {
+      set_error("plh_line_create: Gaussian taps outside the range of the packed blur kernel");
+      delete h;
+      return PLH_ERR_INVALID;
+    }
+  }
   if (a.sw >= 65536 || a.sh >= 32768) {   // packed queue coordinates x:16 | y:16, mark in bit 31 of q
     set_error("plh_line_create: image too large (%d x %d scaled)", a.sw, a.sh);
     delete h;
@@ -292,10 +304,24 @@ plh_status plh_line_set_undistort(plh_line* h, const float K[4], const float D[5
     for (int i = 0; i < 5; i++) any |= D[i] != 0.f;
   if (!any) { h->hasUndistort = false; return PLH_OK; }
   const int w = h->cols, hh = h->rows;
-  std::vector<float> map((size_t)w * hh * 2);
-  // cv::initUndistortRectifyMap(K, D, I, K, size, CV_32F) (Frame.cc:221), evaluated per pixel in double (pinned)
+  if (w < 2 || hh < 2) { set_error("plh_line_set_undistort: image smaller than 2 x 2"); return PLH_ERR_INVALID; }
+  std::vector<RemapTap> map((size_t)w * hh);
+  // cv::initUndistortRectifyMap(K, D, I, K, size, CV_32F) (Frame.cc:221), evaluated per pixel in double (pinned), then
+  // cv::remap's fixed-point split of the float coordinates (1/32 pixel, cvRound) and its constant-0 border, folded into
+  // one RemapTap per pixel (line_plan.h)
   const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
   const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+  auto axis = [](float m, int n, int& i0, unsigned& w0, unsigned& w1) {
+    // the taps of this axis are at i and i + 1 with weights 32 - f and f; outside [0, n) a tap reads 0
+    // cvRound saturates: beyond the int range the taps are far outside either way; a NaN converts to 0
+    long s = std::isnan(m) ? 0L : (std::fabs(m) < 6.0e7f ? std::lrintf(m * 32.f) : (m > 0 ? (long)n * 64 : -64L));
+    const long i = s >> 5;
+    const unsigned f = (unsigned)(s & 31);
+    i0 = (int)std::min<long>(std::max<long>(i, 0), n - 2);
+    auto wt = [&](long pos) -> unsigned { return pos == i ? 32u - f : (pos == i + 1 ? f : 0u); };
+    w0 = wt(i0);
+    w1 = wt(i0 + 1);
+  };
   for (int v = 0; v < hh; v++)
     for (int u = 0; u < w; u++) {
       const double x = (u - cx) / fx, y = (v - cy) / fy;
@@ -303,12 +329,18 @@ plh_status plh_line_set_undistort(plh_line* h, const float K[4], const float D[5
       const double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
       const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
       const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
-      map[((size_t)v * w + u) * 2] = (float)(fx * xd + cx);
-      map[((size_t)v * w + u) * 2 + 1] = (float)(fy * yd + cy);
+      int x0, y0;
+      unsigned wx0, wx1, wy0, wy1;
+      axis((float)(fx * xd + cx), w, x0, wx0, wx1);
+      axis((float)(fy * yd + cy), hh, y0, wy0, wy1);
+      RemapTap t;
+      t.off = (uint32_t)y0 * (uint32_t)w + (uint32_t)x0;
+      t.wts = wx0 | (wx1 << 8) | (wy0 << 16) | (wy1 << 24);
+      map[(size_t)v * w + u] = t;
     }
-  if (!h->dMap) PLH_HIP(hipMalloc((void**)&h->dMap, map.size() * 4));
+  if (!h->dMap) PLH_HIP(hipMalloc((void**)&h->dMap, map.size() * sizeof(RemapTap)));
   if (!h->dUndist) PLH_HIP(hipMalloc((void**)&h->dUndist, (size_t)h->maxBatch * h->a.fullStride));
-  PLH_HIP(hipMemcpy(h->dMap, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(h->dMap, map.data(), map.size() * sizeof(RemapTap), hipMemcpyHostToDevice));
   h->hasUndistort = true;
   return PLH_OK;
 }
@@ -331,7 +363,7 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   PLH_HIP(hipMemsetAsync(h->dStatus, 0, 4, s));   // capacity flags of this call only (plh_line_status)
   h->lastStream = s;
   if (h->hasUndistort) {
-    a.mapxy = h->dMap; a.undist = h->dUndist;
+    a.remap = h->dMap; a.undist = h->dUndist;
     launch_remap(a, s);
     PLH_LAUNCH_CHECK();
     src = h->dUndist; srcStride = a.fullStride;

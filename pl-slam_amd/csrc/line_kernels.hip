@@ -22,34 +22,41 @@
 namespace plh {
 
 // ---------------------------------------------------------------------------------------------
-// Block (64,4): 4 rows x 256 columns, 4 adjacent pixels per thread: the 8 map floats are one 32-byte run, the 16 byte
-// gathers are in flight together and the result leaves as one dword when the address allows.
+// Block (64,4): 4 rows x 256 columns, 4 adjacent pixels per thread: the four RemapTap entries are one 32-byte run, the 16
+// byte gathers are in flight together and the result leaves as one dword when the address allows.  The map is fixed per
+// camera, so everything that depends on it alone -- the fixed-point split of the coordinates, the border tests -- was
+// done once on the host (plh_line_set_undistort).
 __global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
   const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
   if (x4 >= a.w || y >= a.h) return;
   const uint8_t* src = a.img + (long long)b * a.imgStride;
-  const float* mp = a.mapxy + ((long long)y * a.w + x4) * 2;
+  const int pix = __mul24(y, a.w) + x4;
+  const uint2* tp = reinterpret_cast<const uint2*>(a.remap) + pix;
   const int nk = min(4, a.w - x4);
-  float m[8];
+  uint2 t[4];
+  if (nk == 4 && (((size_t)tp) & 15) == 0) {
+    const uint4 lo = reinterpret_cast<const uint4*>(tp)[0], hi = reinterpret_cast<const uint4*>(tp)[1];
+    t[0].x = lo.x; t[0].y = lo.y; t[1].x = lo.z; t[1].y = lo.w;
+    t[2].x = hi.x; t[2].y = hi.y; t[3].x = hi.z; t[3].y = hi.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { t[k].x = 0; t[k].y = 0; if (k < nk) t[k] = tp[k]; }
+  }
+  int p[4][4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    m[2 * k] = 0.f; m[2 * k + 1] = 0.f;
-    if (k < nk) { m[2 * k] = mp[2 * k]; m[2 * k + 1] = mp[2 * k + 1]; }
+    const uint8_t* q = src + t[k].x;
+    p[k][0] = q[0]; p[k][1] = q[1]; p[k][2] = q[a.w]; p[k][3] = q[a.w + 1];
   }
   unsigned out = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int sx = cv_round(m[2 * k] * 32.f), sy = cv_round(m[2 * k + 1] * 32.f);
-    const int ix = sx >> 5, iy = sy >> 5, ax = sx & 31, ay = sy & 31;
-    auto P = [&](int yy, int xx) -> int {   // 24-bit multiply + 32-bit offset: a 64-bit v_mad per tap is a quarter-rate instruction
-      return (xx >= 0 && xx < a.w && yy >= 0 && yy < a.h) ? (int)src[__mul24(yy, a.w) + xx] : 0;
-    };
-    const int s = (32 - ax) * (32 - ay) * 32 * P(iy, ix) + ax * (32 - ay) * 32 * P(iy, ix + 1) +
-                  (32 - ax) * ay * 32 * P(iy + 1, ix) + ax * ay * 32 * P(iy + 1, ix + 1);
-    const int v = (s + (1 << 14)) >> 15;
+    const int wx0 = t[k].y & 255, wx1 = (t[k].y >> 8) & 255, wy0 = (t[k].y >> 16) & 255, wy1 = t[k].y >> 24;
+    const int top = __mul24(wx0, p[k][0]) + __mul24(wx1, p[k][1]), bot = __mul24(wx0, p[k][2]) + __mul24(wx1, p[k][3]);
+    const int v = (__mul24(wy0, top) + __mul24(wy1, bot) + (1 << 9)) >> 10;
     out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
   }
-  uint8_t* o = a.undist + (long long)b * a.fullStride + (long long)y * a.w + x4;
+  uint8_t* o = a.undist + (long long)b * a.fullStride + pix;
   if (nk == 4 && (((size_t)o) & 3) == 0) {
     *reinterpret_cast<unsigned*>(o) = out;
   } else {
@@ -60,82 +67,140 @@ __global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
 // Separable Q8 blur with 2R+1 taps (R = 3: general 7 taps; R = 2 when the outer taps are zero, which is the case for
 // both users: LSD's sigma 0.75 and LBD's 5x5); 64x16 output tile per block, input tile (+R halo rows, REFLECT_101)
 // staged in LDS with aligned dword loads (byte funnel for odd row addresses; byte-wise with reflection only in the
-// image's edge columns).  Every thread produces 4 adjacent outputs per pass: 3 dword LDS reads -> 4 x (2R+1) MACs -> one
-// 8-byte row-sum store, then (2R+1) x 8-byte reads -> 4 x (2R+1) MACs -> one dword of pixels.  Tile column j holds image
-// column x0 - 4 + j.
+// image's edge columns).  Tile column j holds image column x0 - 4 + j.
+//
+// Both passes are integer dot products (taps < 256, tap sum <= 257, checked at create time): the horizontal pass takes
+// four pixels per v_dot4_u32_u8 with the tap weights slid along three dwords of the row, the vertical pass two 16-bit
+// row sums per v_dot2_u32_u16.  For the latter the row sums are stored transposed (hT[column][row], pitch 13 dwords:
+// conflict-free for the 64 columns of a wavefront) so that vertically adjacent sums share a dword; a thread then owns
+// one column and four rows and writes its four pixels as bytes (64 lanes = 64 consecutive bytes of a row per store).
+__device__ __forceinline__ unsigned plh_udot4_l(unsigned a, unsigned b, unsigned c) {
+#if defined(HIPEMU)
+  for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+  return c;
+#else
+  return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+__device__ __forceinline__ unsigned plh_udot2_l(unsigned a, unsigned b, unsigned c) {
+#if defined(HIPEMU)
+  return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c;
+#else
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  return __builtin_amdgcn_udot2(x, y, c, false);
+#endif
+}
+// bytes 2,3 of lo and of hi as two halves (a >> 16 of two accumulators), and min(., 255) on both halves
+__device__ __forceinline__ unsigned hi_halves_sat255(unsigned hi, unsigned lo) {
+#if defined(HIPEMU)
+  return min(lo >> 16, 255u) | (min(hi >> 16, 255u) << 16);
+#else
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const unsigned p = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+  u16x2 x, y;
+  const unsigned cap = 0x00ff00ffu;
+  __builtin_memcpy(&x, &p, 4);
+  __builtin_memcpy(&y, &cap, 4);
+  const u16x2 r = __builtin_elementwise_min(x, y);
+  unsigned o;
+  __builtin_memcpy(&o, &r, 4);
+  return o;
+#endif
+}
+
 template <int R>
 __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst,
                                                   long long dStride, int dPitch, int w, int h, Taps7 t) {
-  constexpr int TW = 64, TH = 16, IH = TH + 2 * R, IP = TW + 8;   // 72-byte tile rows = 18 dwords
-  __shared__ unsigned tin[IH * IP / 4];
-  __shared__ uint2 hb[IH * TW / 4];
+  constexpr int TW = 64, TH = 16, IH = TH + 2 * R, IP = TW + 8, IPD = IP / 4;   // 72-byte tile rows = 18 dwords
+  constexpr int HP = 26;                                                        // u16 pitch of a transposed column of row sums (IH <= 22)
+  __shared__ unsigned tin[IH * IPD + 1];
+  __shared__ unsigned short hT[TW * HP];
   const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
   const uint8_t* S = src + (long long)b * sStride;
   const bool interior = x0 >= 4 && x0 + TW + 8 <= w;   // the aligned dword pairs stay inside the row
-  for (int i = tid; i < IH * (IP / 4); i += 256) {
-    const int r = i / (IP / 4), d = i - r * (IP / 4);
-    const uint8_t* row = S + (long long)refl101(y0 - R + r, h) * sPitch;
-    unsigned v;
-    if (interior) {
-      const uint8_t* p = row + x0 - 4 + 4 * d;
-      const int m = (int)((size_t)p & 3);
-      const unsigned* ap = reinterpret_cast<const unsigned*>(p - m);
-      const unsigned lo = ap[0];
-      v = m ? (unsigned)(((((unsigned long long)ap[1]) << 32) | lo) >> (8 * m)) : lo;
-    } else {
-      v = 0;
+  {   // thread = 18 * (row in a group of 14) + dword
+    const int lr = (tid * 57) >> 10, d = tid - lr * IPD;   // tid / 18, tid % 18 for tid < 256
 #pragma unroll
-      for (int k = 0; k < 4; k++) v |= (unsigned)row[refl101(x0 - 4 + 4 * d + k, w)] << (8 * k);
-    }
-    tin[i] = v;
-  }
-  __syncthreads();
-  for (int i = tid; i < IH * (TW / 4); i += 256) {
-    const int r = i / (TW / 4), g = i - r * (TW / 4);
-    const unsigned A = tin[r * (IP / 4) + g], B = tin[r * (IP / 4) + g + 1], Cc = tin[r * (IP / 4) + g + 2];
-    int q[12];
+    for (int k = 0; k < (IH + 13) / 14; k++) {
+      const int r = lr + 14 * k;
+      if (tid < 14 * IPD && r < IH) {
+        const uint8_t* row = S + __mul24(refl101(y0 - R + r, h), sPitch);
+        unsigned v;
+        if (interior) {
+          const uint8_t* p = row + x0 - 4 + 4 * d;
+          const int m = (int)((size_t)p & 3);
+          const unsigned* ap = reinterpret_cast<const unsigned*>(p - m);
+          const unsigned lo = ap[0];
+          v = m ? (unsigned)(((((unsigned long long)ap[1]) << 32) | lo) >> (8 * m)) : lo;
+        } else {
+          v = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { q[k] = (A >> (8 * k)) & 255; q[4 + k] = (B >> (8 * k)) & 255; q[8 + k] = (Cc >> (8 * k)) & 255; }
-    unsigned hs[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {   // output column 4g+k is tile column 4g+k+4: taps at tile columns 4g+k+4-R .. 4g+k+4+R
-      int acc = 0;
-#pragma unroll
-      for (int j = -R; j <= R; j++) acc += __mul24(t.k[3 + j], q[k + 4 + j]);   // Q8 tap x byte: v_mad_i32_i24
-      hs[k] = (unsigned)acc;
-    }
-    uint2 hw;
-    hw.x = hs[0] | (hs[1] << 16);
-    hw.y = hs[2] | (hs[3] << 16);
-    hb[i] = hw;
-  }
-  __syncthreads();
-  uint8_t* D = dst + (long long)b * dStride;
-  {
-    const int r = tid / (TW / 4), g = tid - r * (TW / 4);   // 16 rows x 16 groups = 256 threads
-    const int x = x0 + 4 * g, y = y0 + r;
-    if (x < w && y < h) {
-      uint2 wv[2 * R + 1];
-#pragma unroll
-      for (int k = 0; k < 2 * R + 1; k++) wv[k] = hb[(r + k) * (TW / 4) + g];
-      unsigned out = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int s = 0;
-#pragma unroll
-        for (int tt = 0; tt < 2 * R + 1; tt++) {
-          const unsigned d = k < 2 ? wv[tt].x : wv[tt].y;
-          s += __mul24(t.k[3 - R + tt], (int)((k & 1) ? (d >> 16) : (d & 0xffffu)));   // Q8 tap x 16-bit row sum < 2^24
+          for (int q = 0; q < 4; q++) v |= (unsigned)row[refl101(x0 - 4 + 4 * d + q, w)] << (8 * q);
         }
-        const int v = (s + (1 << 15)) >> 16;
-        out |= (unsigned)(v > 255 ? 255 : v) << (8 * k);
+        tin[r * IPD + d] = v;
       }
-      uint8_t* o = D + (long long)y * dPitch + x;
-      if (x + 4 <= w && (((size_t)o) & 3) == 0) {
-        *reinterpret_cast<unsigned*>(o) = out;
-      } else {
-        for (int k = 0; k < 4 && x + k < w; k++) o[k] = (uint8_t)(out >> (8 * k));
+    }
+  }
+  __syncthreads();
+  {   // horizontal pass: thread = 16 * (row in a group of 16) + group of four output columns.  Output column 4g + k is tile
+      // column 4g + k + 4: tap j (-R..R) multiplies byte 4 + k + j of the twelve bytes A B C
+    const int lr = tid >> 4, g = tid & 15;
+    auto wsel = [&](int k, int part) -> unsigned {   // weights of bytes 4 part .. 4 part + 3 for output k (uniform: scalar unit)
+      unsigned v = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int j = i + 4 * part - k - 4;
+        if (j >= -R && j <= R) v |= (unsigned)t.k[3 + j] << (8 * i);
       }
+      return v;
+    };
+#pragma unroll
+    for (int p = 0; p < (IH + 15) / 16; p++) {
+      const int r = lr + 16 * p;
+      if (r < IH) {
+        const unsigned A = tin[r * IPD + g], B = tin[r * IPD + g + 1], C = tin[r * IPD + g + 2];
+        unsigned short* hp = hT + 4 * g * HP + r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          unsigned acc = plh_udot4_l(B, wsel(k, 1), 0u);
+          if (4 * 0 - k - 1 >= -R) acc = plh_udot4_l(A, wsel(k, 0), acc);   // some tap of output k falls into A
+          if (4 * 2 - k - 4 <= R) acc = plh_udot4_l(C, wsel(k, 2), acc);    // ... into C
+          hp[k * HP] = (unsigned short)acc;   // <= 257 * 255
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {   // vertical pass: thread = column + 64 * (group of four rows); taps as (t, t+1) pairs from the dword of the output row
+      // (even rows) or the dword below with the weights slid by one (odd rows)
+    const int c = tid & 63, m = tid >> 6;
+    const unsigned* hp = reinterpret_cast<const unsigned*>(hT + c * HP + 4 * m);
+    auto tap = [&](int i) -> unsigned { return (i >= 0 && i <= 2 * R) ? (unsigned)t.k[3 - R + i] : 0u; };
+    unsigned P[R + 2];
+#pragma unroll
+    for (int i = 0; i < R + 2; i++) P[i] = hp[i];
+    unsigned acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {   // output row 4 m + o: first dword P[o / 2], weights shifted by o % 2
+      unsigned s = 1u << 15;
+#pragma unroll
+      for (int i = 0; i <= R; i++) {
+        const int t0 = 2 * i - (o & 1);
+        if (t0 + 1 >= 0 && t0 <= 2 * R) s = plh_udot2_l(P[(o >> 1) + i], tap(t0) | (tap(t0 + 1) << 16), s);
+      }
+      acc[o] = s;
+    }
+    const unsigned p01 = hi_halves_sat255(acc[1], acc[0]), p23 = hi_halves_sat255(acc[3], acc[2]);
+    const int x = x0 + c, y = y0 + 4 * m;
+    if (x < w) {
+      uint8_t* o = dst + (long long)b * dStride + (__mul24(y, dPitch) + x);
+      if (y < h) o[0] = (uint8_t)p01;
+      if (y + 1 < h) o[dPitch] = (uint8_t)(p01 >> 16);
+      if (y + 2 < h) o[2 * dPitch] = (uint8_t)p23;
+      if (y + 3 < h) o[3 * dPitch] = (uint8_t)(p23 >> 16);
     }
   }
 }

@@ -25,6 +25,16 @@ struct LsdAngleEntry {
   float seedy, pad[3];
 };
 
+// cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with a fixed map (Frame.cc:220-222) reduced to what depends on the map alone:
+// per output pixel the offset of the top-left byte of a 2 x 2 source block that lies inside the image, and the four axis
+// weights (0..32, one byte each: column 0, column 1, row 0, row 1) of that block.  A tap of the reference that falls
+// outside the image contributes 0, and it does so per axis, so it becomes a zero weight; the block is moved inside the
+// image where needed and the weights move with it.  pixel = (sum_rc wy[r] wx[c] P[r][c] + 512) >> 10, saturated.
+struct RemapTap {
+  uint32_t off;   // y0 * w + x0
+  uint32_t wts;   // wx0 | wx1 << 8 | wy0 << 16 | wy1 << 24
+};
+
 struct LineDeviceArgs {
   // geometry
   int w, h;                 // full-resolution image
@@ -36,7 +46,7 @@ struct LineDeviceArgs {
   // inputs / intermediates (frame-major)
   const uint8_t* img;       // caller's frames (pitch = w)
   long long imgStride;
-  const float* mapxy;       // undistortion maps (x,y interleaved) or null
+  const RemapTap* remap;    // undistortion taps per output pixel, or null
   uint8_t* undist;          // remapped frames (== img when no undistortion), pitch w
   uint8_t* tmpA;            // full-res scratch plane (blur output), pitch w
   uint8_t* scaled;          // 0.8x image, pitch spitch

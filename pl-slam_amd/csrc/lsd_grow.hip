@@ -828,37 +828,83 @@ __device__ __forceinline__ unsigned ld4_any(const uint8_t* p) {
   return m ? (unsigned)(((((unsigned long long)ap[1]) << 32) | lo) >> (8 * m)) : lo;
 }
 
-// One thread per 4 adjacent pixels: three rows x {left, centre, right} dwords -> 4 packed (dx, dy) -> one 16-byte store.
+// packed 16-bit lanes (v_pk_add_u16 / v_pk_sub_i16 / v_pk_mad_u16, v_perm_b32, v_alignbyte_b32) with plain twins for the emulator
+#if defined(HIPEMU)
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16); }
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
+__device__ __forceinline__ unsigned pk_twice_plus16(unsigned a, unsigned b) { return pk_add16(pk_add16(a, a), b); }
+__device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) {
+  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  unsigned r = 0;
+  for (int i = 0; i < 4; i++) {
+    const unsigned c = (sel >> (8 * i)) & 255u;
+    r |= (c <= 7u ? (unsigned)((v >> (8 * c)) & 255u) : 0u) << (8 * i);
+  }
+  return r;
+}
+__device__ __forceinline__ unsigned align_b32(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * sh)); }
+#else
+typedef unsigned short pk_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk_u16x2 pk_of(unsigned a) { pk_u16x2 v; __builtin_memcpy(&v, &a, 4); return v; }
+__device__ __forceinline__ unsigned pk_to(pk_u16x2 v) { unsigned a; __builtin_memcpy(&a, &v, 4); return a; }
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return pk_to(pk_of(a) + pk_of(b)); }
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return pk_to(pk_of(a) - pk_of(b)); }
+__device__ __forceinline__ unsigned pk_twice_plus16(unsigned a, unsigned b) { const pk_u16x2 two = {2, 2}; return pk_to(pk_of(a) * two + pk_of(b)); }
+__device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ unsigned align_b32(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+#endif
+
+// One thread per 4 adjacent pixels.  Columns x-1 .. x+4 of the three rows come from three aligned dwords per row and one
+// v_alignbyte pair; the sums are taken on pairs of columns in packed 16-bit lanes: the vertical smoothing r0 + 2 r1 + r2
+// and the vertical difference r2 - r0 of six columns (three pairs each), then dx = smooth[c + 2] - smooth[c] and
+// dy = diff[c] + 2 diff[c + 1] + diff[c + 2] for the four outputs (two pairs each), re-paired into (dx, dy) dwords with
+// v_perm: 36 VALU instructions instead of 18 byte extractions and 4 x 11 scalar-lane additions.
 __global__ void __launch_bounds__(256) k_sobel_pack(LineDeviceArgs a) {
   const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
   if (x >= a.w) return;
   const uint8_t* S = a.tmpA + (long long)b * a.fullStride;
   const int ym = refl101(y - 1, a.h), yp = refl101(y + 1, a.h);
-  const uint8_t *r0 = S + (long long)ym * a.w, *r1 = S + (long long)y * a.w, *r2 = S + (long long)yp * a.w;
-  int p0[6], p1[6], p2[6];   // columns x-1 .. x+4 of the three rows
-  if (x >= 4 && x + 12 <= a.w) {   // the aligned dword pairs of ld4_any stay inside the row
-    const unsigned l0 = ld4_any(r0 + x - 4), c0 = ld4_any(r0 + x), h0 = ld4_any(r0 + x + 4);
-    const unsigned l1 = ld4_any(r1 + x - 4), c1 = ld4_any(r1 + x), h1 = ld4_any(r1 + x + 4);
-    const unsigned l2 = ld4_any(r2 + x - 4), c2 = ld4_any(r2 + x), h2 = ld4_any(r2 + x + 4);
-    p0[0] = l0 >> 24; p1[0] = l1 >> 24; p2[0] = l2 >> 24;
+  const uint8_t *r0 = S + __mul24(ym, a.w), *r1 = S + __mul24(y, a.w), *r2 = S + __mul24(yp, a.w);
+  uint32_t out[4];
+  if (x >= 4 && x + 12 <= a.w) {   // the three aligned dwords around x-1 .. x+4 stay inside the row
+    unsigned A[3], B[3], C[3];     // column pairs (x-1, x), (x+1, x+2), (x+3, x+4) of the three rows as 16-bit lanes
+    const uint8_t* rows[3] = {r0, r1, r2};
 #pragma unroll
-    for (int k = 0; k < 4; k++) { p0[1 + k] = (c0 >> (8 * k)) & 255; p1[1 + k] = (c1 >> (8 * k)) & 255; p2[1 + k] = (c2 >> (8 * k)) & 255; }
-    p0[5] = h0 & 255; p1[5] = h1 & 255; p2[5] = h2 & 255;
+    for (int r = 0; r < 3; r++) {
+      const uint8_t* p = rows[r] + x - 1;
+      const unsigned sh = (unsigned)((size_t)p & 3);
+      const unsigned* q = reinterpret_cast<const unsigned*>(p - sh);
+      const unsigned q0 = q[0], q1 = q[1], q2 = q[2];
+      const unsigned w0 = align_b32(q1, q0, sh), w1 = align_b32(q2, q1, sh);   // columns x-1 .. x+2, x+3 .. x+6
+      A[r] = perm_b32(0u, w0, 0x0c010c00u);
+      B[r] = perm_b32(0u, w0, 0x0c030c02u);
+      C[r] = perm_b32(0u, w1, 0x0c010c00u);
+    }
+    const unsigned sA = pk_twice_plus16(A[1], pk_add16(A[0], A[2])), sB = pk_twice_plus16(B[1], pk_add16(B[0], B[2])),
+                   sC = pk_twice_plus16(C[1], pk_add16(C[0], C[2]));
+    const unsigned dA = pk_sub16(A[2], A[0]), dB = pk_sub16(B[2], B[0]), dC = pk_sub16(C[2], C[0]);
+    const unsigned gx01 = pk_sub16(sB, sA), gx23 = pk_sub16(sC, sB);
+    const unsigned gy01 = pk_add16(pk_twice_plus16(align_b32(dB, dA, 2u), dA), dB);
+    const unsigned gy23 = pk_add16(pk_twice_plus16(align_b32(dC, dB, 2u), dB), dC);
+    out[0] = perm_b32(gy01, gx01, 0x05040100u);
+    out[1] = perm_b32(gy01, gx01, 0x07060302u);
+    out[2] = perm_b32(gy23, gx23, 0x05040100u);
+    out[3] = perm_b32(gy23, gx23, 0x07060302u);
   } else {
+    int p0[6], p1[6], p2[6];   // columns x-1 .. x+4 of the three rows
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const int xx = refl101(min(x - 1 + k, a.w), a.w);   // columns beyond the row only feed discarded outputs
       p0[k] = r0[xx]; p1[k] = r1[xx]; p2[k] = r2[xx];
     }
-  }
-  uint32_t out[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int gx = (p0[k + 2] - p0[k]) + 2 * (p1[k + 2] - p1[k]) + (p2[k + 2] - p2[k]);
-    const int gy = (p2[k] - p0[k]) + 2 * (p2[k + 1] - p0[k + 1]) + (p2[k + 2] - p0[k + 2]);
-    out[k] = pack_g(gx, gy);
+    for (int k = 0; k < 4; k++) {
+      const int gx = (p0[k + 2] - p0[k]) + 2 * (p1[k + 2] - p1[k]) + (p2[k + 2] - p2[k]);
+      const int gy = (p2[k] - p0[k]) + 2 * (p2[k + 1] - p0[k + 1]) + (p2[k + 2] - p0[k + 2]);
+      out[k] = pack_g(gx, gy);
+    }
   }
-  uint32_t* o = a.dxdy + (long long)b * a.fullStride + (long long)y * a.w + x;
+  uint32_t* o = a.dxdy + (long long)b * a.fullStride + (__mul24(y, a.w) + x);
   if (x + 4 <= a.w && (((size_t)o) & 15) == 0) {
     *reinterpret_cast<uint4*>(o) = uint4{out[0], out[1], out[2], out[3]};
   } else {
@@ -913,16 +959,33 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
   const bool wide = a.w >= 16384 || a.h >= 16384;   // walk coordinates can leave the range of a short
   const float midX = (float)(0.5 * (L.sPointInOctaveX + L.ePointInOctaveX));
   const float midY = (float)(0.5 * (L.sPointInOctaveY + L.ePointInOctaveY));
-  const float dL0 = (float)cos((double)L.angle), dL1 = (float)sin((double)L.angle);
+  // (float)cos / (float)sin of the double angle: the short evaluation on |angle| in [0, pi] (cos is even, sin is odd, and so
+  // is rounding), the library's only when a result sits next to a float rounding boundary (plh_common.h) -- the two
+  // library calls were 600 of this kernel's VALU instructions per line
+  float dL0, dL1;
+  {
+    const double ad = fabs((double)L.angle);
+    double sd, cd;
+    sincos_0_2pi(ad, sd, cd);
+    if (!(ad <= 6.2831853071795862 && float_round_is_safe(cd) && float_round_is_safe(sd))) { cd = cos(ad); sd = sin(ad); }
+    dL0 = (float)cd;
+    dL1 = __builtin_signbit(L.angle) ? -(float)sd : (float)sd;   // sin(-0.0) = -0.0
+  }
   const float dO0 = -dL1, dO1 = dL0;
   float pL = 0, nL = 0, pO = 0, nO = 0;
   {
     float sCorX0 = -dL0 * halfWidth + dL1 * halfHeight + midX;
     float sCorY0 = -dL1 * halfWidth - dL0 * halfHeight + midY;
     // row r starts r sequential float steps from row 0: step r is taken by the lanes above r (the mask is scalar)
+    // (the mask is shifted from a run-time ballot: with compile-time masks, ROCm 7.2's lowering of inverse_ballot to
+    // "s_mov_b64 sN, <32-bit literal>" lost the upper 32 lanes of the masks 0xffffffffffffff80 .. 0xffffffff80000000 on
+    // gfx950 -- measured, rows 32..62 started 25 steps short)
+    unsigned long long stepMask = wballot(true);
 #pragma unroll
-    for (int r = 0; r < LBD_ROWS - 1; r++)
-      if (PLH_INV_BALLOT(~0ull << (r + 1))) { sCorX0 -= dL1; sCorY0 += dL0; }
+    for (int r = 0; r < LBD_ROWS - 1; r++) {
+      stepMask <<= 1;
+      if (PLH_INV_BALLOT(stepMask)) { sCorX0 -= dL1; sCorY0 += dL0; }
+    }
     float sCorX = sCorX0, sCorY = sCorY0;
     // the walk's addresses do not depend on the data: 8 gathers are issued together, then accumulated in walk order
     // (coordinates and sums advance by the same float additions, in the same order, as the one-pixel-at-a-time loop).

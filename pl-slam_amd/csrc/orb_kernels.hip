@@ -16,13 +16,8 @@
 
 namespace plh {
 
-// rBRIEF sampling pattern (data): 256 pairs, row i = descriptor byte i.
-__device__ const signed char c_orb_pattern[1024] = {
-#include "../../include/plh_orb_pattern.inc"
-};
-
-// rBRIEF pattern once more as floats: the steering multiplies them, a signed-byte load + sign extension + int -> float
-// conversion per coordinate is 16 x 3 VALU instructions per lane, a float load is none.
+// rBRIEF sampling pattern (data): 256 pairs, row i = descriptor byte i, as floats: the steering multiplies them, and a
+// signed-byte load + sign extension + int -> float conversion per coordinate would be 16 x 3 VALU instructions per lane.
 __device__ const float c_orb_pattern_f[1024] = {
 #include "../../include/plh_orb_pattern.inc"
 };
