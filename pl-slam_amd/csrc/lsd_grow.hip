@@ -39,7 +39,8 @@ constexpr unsigned LSD_USED = 0x80000000u;   // `used` mark, kept in bit 31 of L
 
 __device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xffffu); }
 __device__ __forceinline__ int pk_y(uint32_t p) { return (int)(p >> 16); }
-__device__ __forceinline__ uint32_t pk_lin(const GrowCtx& c, uint32_t p) { return (uint32_t)(pk_y(p) * c.spitch + pk_x(p)); }
+// rows and pitch are below 2^16 (plh_line_create): one v_mad_u32_u24 (a 32-bit v_mul_lo / 64-bit v_mad are quarter rate)
+__device__ __forceinline__ uint32_t pk_lin(const GrowCtx& c, uint32_t p) { return __umul24((unsigned)pk_y(p), (unsigned)c.spitch) + (unsigned)pk_x(p); }
 
 __device__ __forceinline__ uint32_t reg_get(const GrowCtx& c, int i, int cnt) {
   return (cnt - i <= LSD_RING) ? c.ring[i & (LSD_RING - 1)] : c.reg[i];
@@ -126,6 +127,61 @@ __device__ __forceinline__ unsigned long long lsd_aligned_mask(const GrowCtx& c,
   return r & act;
 }
 
+// x += cx, y += cy in the lanes of a wave mask, with the mask moved into EXEC by the scalar unit (the compiler turns the
+// two-instruction body into v_add + v_cndmask pairs: four VALU instructions where two do).
+__device__ __forceinline__ void lsd_masked_add2(const GrowCtx& c, float& x, float& y, float cx, float cy, unsigned long long m) {
+#if defined(HIPEMU)
+  if ((m >> c.lane) & 1ull) { x += cx; y += cy; }
+#else
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tv_add_f32_e32 %1, %4, %1\n\tv_add_f32_e32 %2, %5, %2\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved), "+v"(x), "+v"(y)
+               : "s"(m), "s"(cx), "s"(cy));
+#endif
+}
+// v = s in the lanes of a wave mask (same scheme)
+__device__ __forceinline__ void lsd_masked_set(const GrowCtx& c, float& v, float s, unsigned long long m) {
+#if defined(HIPEMU)
+  if ((m >> c.lane) & 1ull) v = s;
+#else
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\tv_mov_b32_e32 %1, %3\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved), "+v"(v)
+               : "s"(m), "s"(s));
+#endif
+}
+
+// fast_atan2_deg (plh_common.h) for the running sums of region_grow(), with the IEEE division written out as the
+// reciprocal / residual sequence the compiler emits between v_div_scale and v_div_fixup -- without those three.  They
+// only act on operands whose quotient or reciprocal leaves the normal range, and here it cannot: the divisor is
+// max(|x|, |y|) + 2.2e-16 with |x|, |y| <= 2^18 (a region has at most 2^18 pixels, each adds a cosine and a sine), and the
+// dividend min(|x|, |y|) is either 0 or at least 2^-48 (every term is a float of magnitude >= 4e-8 -- the cosine at the
+// float next to pi/2 -- so a sum is a multiple of 2^-48).  Same operations, same roundings, same result.
+__device__ __forceinline__ float lsd_atan2_deg(float y, float x) {
+#if defined(HIPEMU)
+  return fast_atan2_deg(y, x);
+#else
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float ax = fabsf(x), ay = fabsf(y);
+  const bool swap = !(ax >= ay);
+  const float num = swap ? ax : ay, den = (swap ? ay : ax) + 2.2204460492503131e-16f;
+  float r = __builtin_amdgcn_rcpf(den);
+  r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+  float q = num * r;
+  q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+  const float c = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+  const float c2 = c * c;
+  float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  if (swap) a = 90.f - a;
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+#endif
+}
+
 // One step's candidates: lane order == the reference's examination order (queue point, then yy, then xx).
 struct LsdCand {
   LsdPix px;
@@ -154,7 +210,6 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
   unsigned long long accAll = 0;
   PF_ADD(c, 10, __popcll(rem));
   if (!rem) return 0;
-  const unsigned long long ltMask = lanemask_lt();
   while (rem) {
     const unsigned long long P = lsd_aligned_mask(c, regAngF, cd.px.angf, tol, rem);
     if (!P) break;   // the state cannot change any more: every remaining candidate is rejected on the exact angle
@@ -172,14 +227,18 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
         canc |= dup;
       }
       const float ck = bcast_f32(cd.px.cs, k), sk = bcast_f32(cd.px.sn, k);
-      if (LSD_INV_BALLOT(c, above)) { preX += ck; preY += sk; }
+      lsd_masked_add2(c, preX, preY, ck, sk, above);
     }
     const float postX = preX + cd.px.cs, postY = preY + cd.px.sn;
-    const float angPost = fast_atan2_deg(postY, postX);
-    const unsigned long long below = acc & ltMask;
-    const int prev = below ? 63 - __clzll((long long)below) : 0;
-    float angPrev = __shfl(angPost, prev);
-    if (!below) angPrev = regAngF;
+    const float angPost = lsd_atan2_deg(postY, postX);
+    // the state in front of a lane: the post-state of the last predicted-accepted lane below it (the region angle when
+    // there is none), handed down the same way the sums were
+    float angPrev = regAngF;
+    for (unsigned long long am = acc; am;) {
+      const int k = __ffsll((long long)am) - 1;
+      am &= am - 1;
+      lsd_masked_set(c, angPrev, bcast_f32(angPost, k), ~((2ull << k) - 1ull));
+    }
     const unsigned long long live = rem & ~canc;
     const unsigned long long D = lsd_aligned_mask(c, angPrev, cd.px.angf, tol, live);
     const unsigned long long mism = (D ^ acc) & live;
@@ -192,7 +251,7 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
     }
     if (A) {
       if (LSD_INV_BALLOT(c, A)) {
-        const int slot = cnt + __popcll(A & ltMask);
+        const unsigned slot = (unsigned)cnt + (unsigned)mbcnt64(A);   // accepted lanes below this one: v_mbcnt on the scalar mask
         c.reg[slot] = cd.npk;
         c.ring[slot & (LSD_RING - 1)] = cd.npk;
         c.G[cd.nidx].q = cd.px.q | LSD_USED;
@@ -233,7 +292,7 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint3
   // y + dy <= sh - 1 always hold, only the -1 side can leave the image.
   const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
   const bool inb = q < cnt && (xx | yy) >= 0;
-  nidx = inb ? (uint32_t)(yy * c.spitch + xx) : (uint32_t)(c.sw - 1);   // (sw-1, 0): never defined, never marked
+  nidx = inb ? __umul24((unsigned)yy, (unsigned)c.spitch) + (unsigned)xx : (uint32_t)(c.sw - 1);   // (sw-1, 0): never defined, never marked
   npk = (uint32_t)xx | ((uint32_t)yy << 16);
   return inb;
 }
