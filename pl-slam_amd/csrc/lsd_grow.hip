@@ -127,27 +127,20 @@ __device__ __forceinline__ unsigned long long lsd_aligned_mask(const GrowCtx& c,
   return r & act;
 }
 
-// x += cx, y += cy in the lanes of a wave mask, with the mask moved into EXEC by the scalar unit (the compiler turns the
-// two-instruction body into v_add + v_cndmask pairs: four VALU instructions where two do).
-__device__ __forceinline__ void lsd_masked_add2(const GrowCtx& c, float& x, float& y, float cx, float cy, unsigned long long m) {
+// Single-bit updates of a wave mask: s_bitset0_b64 / s_bitset1_b64 (one scalar instruction; "m &= m - 1" and
+// "m |= 1ull << k" are three and two).  The walk loop of lsd_resolve runs once per accepted pixel, 130 k times per frame.
+__device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int k) {
 #if defined(HIPEMU)
-  if ((m >> c.lane) & 1ull) { x += cx; y += cy; }
+  m &= ~(1ull << k);
 #else
-  unsigned long long saved;
-  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tv_add_f32_e32 %1, %4, %1\n\tv_add_f32_e32 %2, %5, %2\n\ts_mov_b64 exec, %0"
-               : "=&s"(saved), "+v"(x), "+v"(y)
-               : "s"(m), "s"(cx), "s"(cy));
+  asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(k));
 #endif
 }
-// v = s in the lanes of a wave mask (same scheme)
-__device__ __forceinline__ void lsd_masked_set(const GrowCtx& c, float& v, float s, unsigned long long m) {
+__device__ __forceinline__ void mask_set_bit(unsigned long long& m, int k) {
 #if defined(HIPEMU)
-  if ((m >> c.lane) & 1ull) v = s;
+  m |= 1ull << k;
 #else
-  unsigned long long saved;
-  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\tv_mov_b32_e32 %1, %3\n\ts_mov_b64 exec, %0"
-               : "=&s"(saved), "+v"(v)
-               : "s"(m), "s"(s));
+  asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(k));
 #endif
 }
 
@@ -218,28 +211,29 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
     unsigned long long m = P, acc = 0, canc = 0;
     while (m) {
       const int k = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      acc |= 1ull << k;
-      const unsigned long long above = ~((2ull << k) - 1ull);   // lanes behind lane k
+      mask_clear_bit(m, k);
+      mask_set_bit(acc, k);
+      const unsigned long long above = ~1ull << k;   // lanes behind lane k
       if (mayDup) {
-        const unsigned long long dup = wballot(cd.nidx == bcast_u32(cd.nidx, k)) & rem & above;
+        // later lanes on the same pixel (m only holds candidate lanes, canc is only ever used masked with rem)
+        const unsigned long long dup = wballot(cd.nidx == bcast_u32(cd.nidx, k)) & above;
         m &= ~dup;
         canc |= dup;
       }
       const float ck = bcast_f32(cd.px.cs, k), sk = bcast_f32(cd.px.sn, k);
-      lsd_masked_add2(c, preX, preY, ck, sk, above);
+      // (v_add + v_cndmask per sum.  Moving the mask into EXEC instead -- s_mov exec, two v_add, s_mov exec -- was measured:
+      // 0.56 M fewer VALU but 1.5 M more SALU instructions per frame together with a scalar loop for angPrev below, and a
+      // slower kernel: a frame's wavefront is one dependent instruction stream, every instruction of either kind costs it
+      // an issue slot)
+      if (LSD_INV_BALLOT(c, above)) { preX += ck; preY += sk; }
     }
     const float postX = preX + cd.px.cs, postY = preY + cd.px.sn;
     const float angPost = lsd_atan2_deg(postY, postX);
-    // the state in front of a lane: the post-state of the last predicted-accepted lane below it (the region angle when
-    // there is none), handed down the same way the sums were
-    float angPrev = regAngF;
-    for (unsigned long long am = acc; am;) {
-      const int k = __ffsll((long long)am) - 1;
-      am &= am - 1;
-      lsd_masked_set(c, angPrev, bcast_f32(angPost, k), ~((2ull << k) - 1ull));
-    }
-    const unsigned long long live = rem & ~canc;
+    const unsigned long long below = acc & lanemask_lt();
+    const int prev = below ? 63 - __clzll((long long)below) : 0;
+    float angPrev = __shfl(angPost, prev);
+    if (!below) angPrev = regAngF;
+    const unsigned long long live = rem & ~canc;   // (canc may hold lanes outside rem: harmless here)
     const unsigned long long D = lsd_aligned_mask(c, angPrev, cd.px.angf, tol, live);
     const unsigned long long mism = (D ^ acc) & live;
     unsigned long long A = acc;
