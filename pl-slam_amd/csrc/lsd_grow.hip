@@ -127,23 +127,6 @@ __device__ __forceinline__ unsigned long long lsd_aligned_mask(const GrowCtx& c,
   return r & act;
 }
 
-// Single-bit updates of a wave mask: s_bitset0_b64 / s_bitset1_b64 (one scalar instruction; "m &= m - 1" and
-// "m |= 1ull << k" are three and two).  The walk loop of lsd_resolve runs once per accepted pixel, 130 k times per frame.
-__device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int k) {
-#if defined(HIPEMU)
-  m &= ~(1ull << k);
-#else
-  asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(k));
-#endif
-}
-__device__ __forceinline__ void mask_set_bit(unsigned long long& m, int k) {
-#if defined(HIPEMU)
-  m |= 1ull << k;
-#else
-  asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(k));
-#endif
-}
-
 // fast_atan2_deg (plh_common.h) for the running sums of region_grow(), with the IEEE division written out as the
 // reciprocal / residual sequence the compiler emits between v_div_scale and v_div_fixup -- without those three.  They
 // only act on operands whose quotient or reciprocal leaves the normal range, and here it cannot: the divisor is
@@ -173,6 +156,88 @@ __device__ __forceinline__ float lsd_atan2_deg(float y, float x) {
   if (y < 0) a = 360.f - a;
   return a;
 #endif
+}
+
+// The walk of lsd_resolve: the predicted-accepted lanes of mask P in lane order; lane k adds its (cos, sin) to the running
+// sums of every lane behind it, cancels its later duplicates (same pixel examined from another queue point) and leaves its
+// number in `prev` of the lanes behind it.  On return acc = the lanes walked, canc = the duplicates dropped (possibly with
+// lanes outside the candidate set: only ever used masked), prev = last walked lane below each lane (untouched: none).
+// Hand-scheduled because it runs once per accepted pixel (130 k times per frame) and the three per-lane updates are
+// cheapest under EXEC = "lanes behind k", which the scalar unit produces in one instruction (s_lshl_b64 exec, -2, k): the
+// compare then needs no mask and the updates no selects -- 7 VALU + 8 SALU instructions per pixel where the compiled form
+// had 8 + 8 and a 13-instruction search for `prev` after the loop.  Wait states (gfx940 family: an SGPR written by
+// v_readlane may be read by a VALU instruction no sooner than the third instruction after it) are kept by the order.
+__device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P, bool mayDup, uint32_t nidx, float cs, float sn,
+                                         float& preX, float& preY, int& prev, unsigned long long& accOut,
+                                         unsigned long long& cancOut) {
+  unsigned long long m = P, acc = 0, canc = 0;
+#if defined(HIPEMU)
+  while (m) {
+    const int k = __ffsll((long long)m) - 1;
+    m &= ~(1ull << k);
+    acc |= 1ull << k;
+    const unsigned long long above = ~1ull << k;
+    if (mayDup) {
+      const unsigned long long dup = wballot(nidx == bcast_u32(nidx, k)) & above;
+      m &= ~dup;
+      canc |= dup;
+    }
+    const float ck = bcast_f32(cs, k), sk = bcast_f32(sn, k);
+    if ((above >> c.lane) & 1ull) { preX += ck; preY += sk; prev = k; }
+  }
+#else
+  unsigned long long saved;
+  int k;
+  unsigned t0;
+  float t1, t2;
+  if (mayDup) {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "lsdwalk%=:\n\t"
+        "s_ff1_i32_b64 %[k], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[k]\n\t"
+        "s_bitset1_b64 %[acc], %[k]\n\t"
+        "v_readlane_b32 %[t0], %[nidx], %[k]\n\t"
+        "v_readlane_b32 %[t1], %[cs], %[k]\n\t"
+        "v_readlane_b32 %[t2], %[sn], %[k]\n\t"
+        "s_lshl_b64 exec, -2, %[k]\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[t0], %[nidx]\n\t"
+        "v_add_f32_e32 %[px], %[t1], %[px]\n\t"
+        "v_add_f32_e32 %[py], %[t2], %[py]\n\t"
+        "v_mov_b32_e32 %[prev], %[k]\n\t"
+        "s_andn2_b64 %[m], %[m], vcc\n\t"
+        "s_or_b64 %[canc], %[canc], vcc\n\t"
+        "s_cmp_lg_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 lsdwalk%=\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+s"(m), [acc] "+s"(acc), [canc] "+s"(canc), [px] "+v"(preX), [py] "+v"(preY), [prev] "+v"(prev), [k] "=&s"(k),
+          [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(saved)
+        : [nidx] "v"(nidx), [cs] "v"(cs), [sn] "v"(sn)
+        : "vcc", "scc");
+  } else {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "lsdwalk%=:\n\t"
+        "s_ff1_i32_b64 %[k], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[k]\n\t"
+        "s_bitset1_b64 %[acc], %[k]\n\t"
+        "v_readlane_b32 %[t1], %[cs], %[k]\n\t"
+        "v_readlane_b32 %[t2], %[sn], %[k]\n\t"
+        "s_lshl_b64 exec, -2, %[k]\n\t"
+        "s_cmp_lg_u64 %[m], 0\n\t"
+        "v_add_f32_e32 %[px], %[t1], %[px]\n\t"
+        "v_add_f32_e32 %[py], %[t2], %[py]\n\t"
+        "v_mov_b32_e32 %[prev], %[k]\n\t"
+        "s_cbranch_scc1 lsdwalk%=\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+s"(m), [acc] "+s"(acc), [px] "+v"(preX), [py] "+v"(preY), [prev] "+v"(prev), [k] "=&s"(k), [t1] "=&s"(t1),
+          [t2] "=&s"(t2), [sv] "=&s"(saved)
+        : [cs] "v"(cs), [sn] "v"(sn)
+        : "scc");
+  }
+#endif
+  accOut = acc;
+  cancOut = canc;
 }
 
 // One step's candidates: lane order == the reference's examination order (queue point, then yy, then xx).
@@ -208,31 +273,14 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
     if (!P) break;   // the state cannot change any more: every remaining candidate is rejected on the exact angle
     PF_ADD(c, 12, 1);
     float preX = sumdx, preY = sumdy;
-    unsigned long long m = P, acc = 0, canc = 0;
-    while (m) {
-      const int k = __ffsll((long long)m) - 1;
-      mask_clear_bit(m, k);
-      mask_set_bit(acc, k);
-      const unsigned long long above = ~1ull << k;   // lanes behind lane k
-      if (mayDup) {
-        // later lanes on the same pixel (m only holds candidate lanes, canc is only ever used masked with rem)
-        const unsigned long long dup = wballot(cd.nidx == bcast_u32(cd.nidx, k)) & above;
-        m &= ~dup;
-        canc |= dup;
-      }
-      const float ck = bcast_f32(cd.px.cs, k), sk = bcast_f32(cd.px.sn, k);
-      // (v_add + v_cndmask per sum.  Moving the mask into EXEC instead -- s_mov exec, two v_add, s_mov exec -- was measured:
-      // 0.56 M fewer VALU but 1.5 M more SALU instructions per frame together with a scalar loop for angPrev below, and a
-      // slower kernel: a frame's wavefront is one dependent instruction stream, every instruction of either kind costs it
-      // an issue slot)
-      if (LSD_INV_BALLOT(c, above)) { preX += ck; preY += sk; }
-    }
+    int prev = -1;
+    unsigned long long acc, canc;
+    lsd_walk(c, P, mayDup, cd.nidx, cd.px.cs, cd.px.sn, preX, preY, prev, acc, canc);
     const float postX = preX + cd.px.cs, postY = preY + cd.px.sn;
     const float angPost = lsd_atan2_deg(postY, postX);
-    const unsigned long long below = acc & lanemask_lt();
-    const int prev = below ? 63 - __clzll((long long)below) : 0;
-    float angPrev = __shfl(angPost, prev);
-    if (!below) angPrev = regAngF;
+    // the state in front of a lane: the post-state of the last walked lane below it, the region angle when there is none
+    float angPrev = __shfl(angPost, prev & 63);
+    if (prev < 0) angPrev = regAngF;
     const unsigned long long live = rem & ~canc;   // (canc may hold lanes outside rem: harmless here)
     const unsigned long long D = lsd_aligned_mask(c, angPrev, cd.px.angf, tol, live);
     const unsigned long long mism = (D ^ acc) & live;
