@@ -18,6 +18,14 @@ constexpr double k3_2PI = 3 * kPI / 2, k2PI = 2 * kPI;
 struct Taps7 {
   int k[7];
 };
+// The Q8 taps of k_blur7_u8 as the dot-product operands its two passes use, built once on the host (launch_blur7):
+// h[k][part] = byte weights of bytes 4 part .. 4 part + 3 of a 12-byte row window for output k (tap j of output k sits at
+// byte 4 + k + j); v[odd][i] = the (t, t+1) tap pair that multiplies dword i of a column of 16-bit row sums for an even /
+// odd output row (odd rows: the pairs slid by one tap).
+struct BlurWeights {
+  unsigned h[4][3];
+  unsigned v[2][4];
+};
 
 __device__ __forceinline__ int refl101(int p, int n) {
   if (p < 0) p = -p;

@@ -113,7 +113,7 @@ __device__ __forceinline__ unsigned hi_halves_sat255(unsigned hi, unsigned lo) {
 
 template <int R>
 __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst,
-                                                  long long dStride, int dPitch, int w, int h, Taps7 t) {
+                                                  long long dStride, int dPitch, int w, int h, BlurWeights bw) {
   constexpr int TW = 64, TH = 16, IH = TH + 2 * R, IP = TW + 8, IPD = IP / 4;   // 72-byte tile rows = 18 dwords
   constexpr int HP = 26;                                                        // u16 pitch of a transposed column of row sums (IH <= 22)
   __shared__ unsigned tin[IH * IPD + 1];
@@ -148,15 +148,6 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
   {   // horizontal pass: thread = 16 * (row in a group of 16) + group of four output columns.  Output column 4g + k is tile
       // column 4g + k + 4: tap j (-R..R) multiplies byte 4 + k + j of the twelve bytes A B C
     const int lr = tid >> 4, g = tid & 15;
-    auto wsel = [&](int k, int part) -> unsigned {   // weights of bytes 4 part .. 4 part + 3 for output k (uniform: scalar unit)
-      unsigned v = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int j = i + 4 * part - k - 4;
-        if (j >= -R && j <= R) v |= (unsigned)t.k[3 + j] << (8 * i);
-      }
-      return v;
-    };
 #pragma unroll
     for (int p = 0; p < (IH + 15) / 16; p++) {
       const int r = lr + 16 * p;
@@ -165,9 +156,9 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
         unsigned short* hp = hT + 4 * g * HP + r;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          unsigned acc = plh_udot4_l(B, wsel(k, 1), 0u);
-          if (4 * 0 - k - 1 >= -R) acc = plh_udot4_l(A, wsel(k, 0), acc);   // some tap of output k falls into A
-          if (4 * 2 - k - 4 <= R) acc = plh_udot4_l(C, wsel(k, 2), acc);    // ... into C
+          unsigned acc = plh_udot4_l(B, bw.h[k][1], 0u);
+          if (4 * 0 - k - 1 >= -R) acc = plh_udot4_l(A, bw.h[k][0], acc);   // some tap of output k falls into A
+          if (4 * 2 - k - 4 <= R) acc = plh_udot4_l(C, bw.h[k][2], acc);    // ... into C
           hp[k * HP] = (unsigned short)acc;   // <= 257 * 255
         }
       }
@@ -178,7 +169,6 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
       // (even rows) or the dword below with the weights slid by one (odd rows)
     const int c = tid & 63, m = tid >> 6;
     const unsigned* hp = reinterpret_cast<const unsigned*>(hT + c * HP + 4 * m);
-    auto tap = [&](int i) -> unsigned { return (i >= 0 && i <= 2 * R) ? (unsigned)t.k[3 - R + i] : 0u; };
     unsigned P[R + 2];
 #pragma unroll
     for (int i = 0; i < R + 2; i++) P[i] = hp[i];
@@ -188,8 +178,7 @@ __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long 
       unsigned s = 1u << 15;
 #pragma unroll
       for (int i = 0; i <= R; i++) {
-        const int t0 = 2 * i - (o & 1);
-        if (t0 + 1 >= 0 && t0 <= 2 * R) s = plh_udot2_l(P[(o >> 1) + i], tap(t0) | (tap(t0 + 1) << 16), s);
+        s = plh_udot2_l(P[(o >> 1) + i], bw.v[o & 1][i], s);
       }
       acc[o] = s;
     }
@@ -371,6 +360,23 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   if (threadIdx.x == 0 && threadIdx.y == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);
 }
 
+// bit k of v as 0 / -1 (v_bfe_i32 with width 1)
+__device__ __forceinline__ int plh_sbfe1(unsigned v, int k) {
+#if defined(HIPEMU)
+  return -(int)((v >> k) & 1u);
+#else
+  return __builtin_amdgcn_sbfe((int)v, (unsigned)k, 1u);
+#endif
+}
+// v_sqrt_f32 (1 ulp) where an estimate is all that is needed
+__device__ __forceinline__ float plh_sqrt_approx(float x) {
+#if defined(HIPEMU)
+  return sqrtf(x);
+#else
+  return __builtin_amdgcn_sqrtf(x);
+#endif
+}
+
 // One 1024-thread block per frame: stable counting sort of the DEFINED pixels by bin (descending), raster
 // order inside a bin.  16 waves own contiguous raster chunks; per-(wave,bin) counters live in LDS.  Inside a
 // 64-pixel group the rank of a lane among the lanes of the same bin comes from ten ballots (one per bin bit).
@@ -388,6 +394,26 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
   const int chunk = ((npix + 15) / 16 + 63) / 64 * 64;
   const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
   for (int i = tid; i < 16 * LSD_NBINS; i += 1024) hist[i] = 0;
+  // The bin of a pixel is (int)(sqrt(q / 4.0) * bin_coef) in double -- a correctly rounded f64 square root per pixel (about
+  // 20 instructions).  It is monotone in q, so it is fixed by the 1024 thresholds binLo[k] = smallest q whose bin is >= k,
+  // which thread k finds once per frame with the exact expression (analytic guess 4 (k / coef)^2, then stepped until
+  // exact).  Per pixel a float estimate (within 2e-4 of the real-valued product) names the bin up to one, and two
+  // compares against the thresholds decide it.
+  unsigned* binLo = (unsigned*)(scan + LSD_NBINS);   // [LSD_NBINS + 1]
+  {
+    auto exact_bin = [&](unsigned q) -> int { return (int)(q_modgrad(q) * bin_coef); };
+    unsigned t = tid > 0 ? 0xffffffffu : 0u;   // no defined pixel (bin_coef == 0): everything is bin 0
+    if (tid > 0 && bin_coef > 0.0) {
+      const double r = (double)tid / bin_coef;
+      const double g = 4.0 * r * r;
+      t = g < 4.0e9 ? (unsigned)g : 4000000000u;
+      while (t > 0u && exact_bin(t - 1u) >= tid) t--;
+      while (t < 4000000000u && exact_bin(t) < tid) t++;
+    }
+    binLo[tid] = t;
+    if (tid == 0) binLo[LSD_NBINS] = 0xffffffffu;
+  }
+  const float coefF = (float)(bin_coef * 0.5);   // sqrt(q / 4) = sqrt(q) / 2
   __syncthreads();
   // pass 1: histogram; order is irrelevant here, so every lane takes 4 consecutive pixels (16-byte loads / stores;
   // chunk bounds are multiples of 64)
@@ -401,7 +427,8 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
       for (int k = 0; k < 4; k++) {
         bb[k] = 0;
         if (qq[k] > a.qThresh) {
-          const int bin = (int)(q_modgrad(qq[k]) * bin_coef);
+          const int est = min((int)(plh_sqrt_approx((float)qq[k]) * coefF), LSD_NBINS - 1);
+          const int bin = est - (qq[k] < binLo[est] ? 1 : 0) + (qq[k] >= binLo[est + 1] ? 1 : 0);
           atomicAdd(&hist[wv * LSD_NBINS + bin], 1);
           bb[k] = (unsigned)bin + 1u;
         }
@@ -451,8 +478,9 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
     unsigned dlo = 0, dhi = 0;
 #pragma unroll
     for (int k = 0; k < 10; k++) {
-      const unsigned long long m = wballot((bin & (1u << k)) != 0u);
-      const unsigned mine = (unsigned)((int)(bin << (31 - k)) >> 31);
+      const int mineI = plh_sbfe1(bin, k);            // bit k spread over the word: one v_bfe_i32
+      const unsigned long long m = wballot(mineI < 0);
+      const unsigned mine = (unsigned)mineI;
       dlo |= (unsigned)m ^ mine;
       dhi |= (unsigned)(m >> 32) ^ mine;
     }
@@ -496,13 +524,25 @@ void launch_remap(const LineDeviceArgs& a, hipStream_t s) {
 }
 void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst, long long dStride, int dPitch, int w, int h,
                   int batch, const int taps[7], hipStream_t s) {
-  Taps7 t;
-  for (int i = 0; i < 7; i++) t.k[i] = taps[i];
+  const int R = (taps[0] == 0 && taps[6] == 0) ? 2 : 3;   // integer sums: dropping zero taps changes nothing
+  BlurWeights bw;
+  for (int k = 0; k < 4; k++)
+    for (int part = 0; part < 3; part++) {
+      unsigned v = 0;
+      for (int i = 0; i < 4; i++) {
+        const int j = i + 4 * part - k - 4;
+        if (j >= -3 && j <= 3) v |= (unsigned)taps[3 + j] << (8 * i);
+      }
+      bw.h[k][part] = v;
+    }
+  auto tap = [&](int i) -> unsigned { return (i >= 0 && i <= 2 * R) ? (unsigned)taps[3 - R + i] : 0u; };
+  for (int odd = 0; odd < 2; odd++)
+    for (int i = 0; i < 4; i++) bw.v[odd][i] = tap(2 * i - odd) | (tap(2 * i - odd + 1) << 16);
   const dim3 grid((w + 63) / 64, (h + 15) / 16, batch);
-  if (taps[0] == 0 && taps[6] == 0)   // integer sums: dropping zero taps changes nothing
-    hipLaunchKernelGGL(k_blur7_u8<2>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, t);
+  if (R == 2)
+    hipLaunchKernelGGL(k_blur7_u8<2>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, bw);
   else
-    hipLaunchKernelGGL(k_blur7_u8<3>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, t);
+    hipLaunchKernelGGL(k_blur7_u8<3>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, bw);
 }
 void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sw, int sh, uint8_t* dst, long long dStride, int dPitch,
                    int dw, int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, int tileTP, int tileTR, hipStream_t s) {
@@ -524,7 +564,7 @@ void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lsd_grad, dim3((a.spitch + 255) / 256, (a.sh + 3) / 4, a.batch), dim3(64, 4), 0, s, a);
 }
 void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_lsd_order, dim3(a.batch), dim3(1024), (size_t)(16 * LSD_NBINS + 1024) * 4, s, a);
+  hipLaunchKernelGGL(k_lsd_order, dim3(a.batch), dim3(1024), (size_t)(16 * LSD_NBINS + 1024 + LSD_NBINS + 1) * 4, s, a);
 }
 
 }  // namespace plh
