@@ -204,6 +204,13 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   unsigned q = 0;
   while (std::sqrt((double)(int)(q + 1) / 4.0) <= rho) q++;   // largest q with norm <= rho  (NOTDEF)
   a.qThresh = q;
+  {   // margins of k_lsd_grow's direction pre-test (LSD_ALIGN_MARGIN_DEG in lsd_grow.hip: 0.05 degrees)
+    const double m = 0.05 * 3.14159265358979323846 / 180.0;
+    a.alignFast = a.prec + m < 89.0 * 3.14159265358979323846 / 180.0 ? 1 : 0;
+    const double ci = a.prec > m ? std::cos(a.prec - m) : 2.0, co = std::cos(a.prec + m);
+    a.alignCin2 = (float)(ci * ci);
+    a.alignCout2 = (float)(co * co);
+  }
   const double LOG_NT = 5 * (std::log10(double(a.sw)) + std::log10(double(a.sh))) / 2 + std::log10(11.0);
   a.minRegSize = (int)(size_t)(-LOG_NT / std::log10(a.p));
   a.segCap = (a.sw * a.sh) / std::max(a.minRegSize, 1) + 16;

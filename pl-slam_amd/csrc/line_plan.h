@@ -68,6 +68,8 @@ struct LineDeviceArgs {
   // LSD constants (computed on the host in double exactly as flsd() does)
   double prec, p, densityTh;
   unsigned int qThresh;     // pixel is NOTDEF  <=>  gx^2+gy^2 <= qThresh  (<=> sqrt(q/4) <= rho)
+  float alignCin2, alignCout2;   // cos^2(prec -+ 0.05 degrees): the direction pre-test of region growing (lsd_grow.hip, lsd_classify)
+  int alignFast;
   int minRegSize;
   // selection
   int nFeature;             // nLSDFeature

@@ -21,6 +21,9 @@ struct GrowCtx {
   double* T;           // LDS [3][64] doubles: lane -> chain transposition buffer of the sequential double sums
   int spitch, sw, sh, lane;
   unsigned qThresh;
+  double precDef;             // the launch's tolerance and its direction-test margins (host: plh_line_create)
+  float cin2Def, cout2Def;
+  int fastDef;
 #if defined(PLH_GROW_PROF)
   unsigned long long* pf;   // per-wave phase counters (debug build only, tools/grow_prof.py)
 #endif
@@ -83,7 +86,25 @@ __device__ __forceinline__ bool lsd_aligned(double theta, double a, double prec)
 struct LsdTol {
   double prec;
   float lo, hi;
+  float cin2, cout2;   // cos^2(prec -+ LSD_ALIGN_MARGIN): the direction test of lsd_classify
+  bool fast;           // prec + margin < 89 degrees: the direction test applies
 };
+// The margin of the direction test, in degrees.  It has to cover |fastAtan2 - atan2| (0.0096 degrees for this polynomial,
+// scanned over 4 M ratios, plus the float rounding of the octant folding, < 1e-4), the direction error of the stored float
+// cos / sin of a pixel angle (< 1e-5) and the float rounding of the test itself (< 2e-4).
+constexpr double LSD_ALIGN_MARGIN_DEG = 0.05;
+// cos^2 of the tolerance -+ margin for a tolerance that is not the launch's default (refine()'s tau; rare): out of line, the
+// library cosine must not cost the hot loop registers
+struct LsdMargins { float cin2, cout2; int fast; };
+__device__ __attribute__((noinline)) LsdMargins lsd_tol_margins(double prec) {
+  const double m = LSD_ALIGN_MARGIN_DEG * kDegToRads;
+  LsdMargins r;
+  r.fast = prec + m < 89.0 * kDegToRads;
+  const double ci = prec > m ? cos(prec - m) : 2.0, co = cos(prec + m);
+  r.cin2 = (float)(ci * ci);
+  r.cout2 = (float)(co * co);
+  return r;
+}
 __device__ __forceinline__ LsdTol lsd_tol(double prec) {
   LsdTol t;
   t.prec = prec;
@@ -91,6 +112,7 @@ __device__ __forceinline__ LsdTol lsd_tol(double prec) {
   const float m = 2e-3f + pd * 1e-6f;
   t.lo = pd - m;
   t.hi = pd + m;
+  t.cin2 = 4.f; t.cout2 = 0.f; t.fast = false;
   return t;
 }
 __device__ __forceinline__ bool lsd_aligned_f(float thF, float aF, const LsdTol& t) {
@@ -159,16 +181,15 @@ __device__ __forceinline__ float lsd_atan2_deg(float y, float x) {
 }
 
 // The walk of lsd_resolve: the predicted-accepted lanes of mask P in lane order; lane k adds its (cos, sin) to the running
-// sums of every lane behind it, cancels its later duplicates (same pixel examined from another queue point) and leaves its
-// number in `prev` of the lanes behind it.  On return acc = the lanes walked, canc = the duplicates dropped (possibly with
-// lanes outside the candidate set: only ever used masked), prev = last walked lane below each lane (untouched: none).
-// Hand-scheduled because it runs once per accepted pixel (130 k times per frame) and the three per-lane updates are
+// sums of every lane behind it and cancels its later duplicates (same pixel examined from another queue point).  On return
+// acc = the lanes walked, canc = the duplicates dropped (possibly with lanes outside the candidate set: only ever used
+// masked).  Hand-scheduled because it runs once per accepted pixel (130 k times per frame) and the per-lane updates are
 // cheapest under EXEC = "lanes behind k", which the scalar unit produces in one instruction (s_lshl_b64 exec, -2, k): the
-// compare then needs no mask and the updates no selects -- 7 VALU + 8 SALU instructions per pixel where the compiled form
-// had 8 + 8 and a 13-instruction search for `prev` after the loop.  Wait states (gfx940 family: an SGPR written by
-// v_readlane may be read by a VALU instruction no sooner than the third instruction after it) are kept by the order.
+// compare then needs no mask and the adds no selects -- 6 VALU + 8 SALU instructions per pixel where the compiled form had
+// 8 + 9.  Wait states (gfx940 family: an SGPR written by v_readlane may be read by a VALU instruction no sooner than the
+// third instruction after it) are kept by the order of the instructions.
 __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P, bool mayDup, uint32_t nidx, float cs, float sn,
-                                         float& preX, float& preY, int& prev, unsigned long long& accOut,
+                                         float& preX, float& preY, unsigned long long& accOut,
                                          unsigned long long& cancOut) {
   unsigned long long m = P, acc = 0, canc = 0;
 #if defined(HIPEMU)
@@ -183,7 +204,7 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
       canc |= dup;
     }
     const float ck = bcast_f32(cs, k), sk = bcast_f32(sn, k);
-    if ((above >> c.lane) & 1ull) { preX += ck; preY += sk; prev = k; }
+    if ((above >> c.lane) & 1ull) { preX += ck; preY += sk; }
   }
 #else
   unsigned long long saved;
@@ -204,13 +225,12 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
         "v_cmp_eq_u32_e32 vcc, %[t0], %[nidx]\n\t"
         "v_add_f32_e32 %[px], %[t1], %[px]\n\t"
         "v_add_f32_e32 %[py], %[t2], %[py]\n\t"
-        "v_mov_b32_e32 %[prev], %[k]\n\t"
         "s_andn2_b64 %[m], %[m], vcc\n\t"
         "s_or_b64 %[canc], %[canc], vcc\n\t"
         "s_cmp_lg_u64 %[m], 0\n\t"
         "s_cbranch_scc1 lsdwalk%=\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [m] "+s"(m), [acc] "+s"(acc), [canc] "+s"(canc), [px] "+v"(preX), [py] "+v"(preY), [prev] "+v"(prev), [k] "=&s"(k),
+        : [m] "+s"(m), [acc] "+s"(acc), [canc] "+s"(canc), [px] "+v"(preX), [py] "+v"(preY), [k] "=&s"(k),
           [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(saved)
         : [nidx] "v"(nidx), [cs] "v"(cs), [sn] "v"(sn)
         : "vcc", "scc");
@@ -227,10 +247,9 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
         "s_cmp_lg_u64 %[m], 0\n\t"
         "v_add_f32_e32 %[px], %[t1], %[px]\n\t"
         "v_add_f32_e32 %[py], %[t2], %[py]\n\t"
-        "v_mov_b32_e32 %[prev], %[k]\n\t"
         "s_cbranch_scc1 lsdwalk%=\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [m] "+s"(m), [acc] "+s"(acc), [px] "+v"(preX), [py] "+v"(preY), [prev] "+v"(prev), [k] "=&s"(k), [t1] "=&s"(t1),
+        : [m] "+s"(m), [acc] "+s"(acc), [px] "+v"(preX), [py] "+v"(preY), [k] "=&s"(k), [t1] "=&s"(t1),
           [t2] "=&s"(t2), [sv] "=&s"(saved)
         : [cs] "v"(cs), [sn] "v"(sn)
         : "scc");
@@ -238,6 +257,23 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
 #endif
   accOut = acc;
   cancOut = canc;
+}
+
+// Which way does a candidate's decision go, judged by directions instead of fastAtan2 values?  The reference compares the
+// pixel angle a with reg_angle = fastAtan2(sumdy, sumdx) (or the seed's own angle before the first accept), folded to the
+// circular distance, against prec.  fastAtan2 is within 0.01 degrees of the true direction of (x, y) = the running sums, so
+// with D = the true angle between (x, y) and (cos a, sin a):  D <= prec - margin  =>  aligned,  D >= prec + margin  =>  not.
+// cos D = (cs x + sn y) / |(x, y)|, compared in squares (prec + margin < 90 degrees, t.fast).  Only the lanes in between
+// -- a 0.1-degree band around the tolerance -- need the reference's arithmetic.  Ten VALU instructions; the exact test costs
+// a fastAtan2 (30) per state plus the compare (9).  `in` / `unc` = certainly aligned / undecided lanes of `act`.
+__device__ __forceinline__ void lsd_classify(float x, float y, float cs, float sn, const LsdTol& t, unsigned long long act,
+                                             unsigned long long& in, unsigned long long& unc) {
+  if (!t.fast) { in = 0; unc = act; return; }
+  const float dot = __builtin_fmaf(sn, y, cs * x), n2 = __builtin_fmaf(y, y, x * x), dd = dot * dot;
+  const unsigned long long pos = wballot(dot > 0.f);
+  const unsigned long long ge = wballot(dd >= t.cin2 * n2), le = wballot(dd <= t.cout2 * n2);
+  in = pos & ge & act;
+  unc = act & ~(in | ~pos | le);
 }
 
 // One step's candidates: lane order == the reference's examination order (queue point, then yy, then xx).
@@ -251,38 +287,50 @@ struct LsdCand {
 // moves the running region angle, a pixel accepted for an earlier point cancels its later duplicates.
 //
 // The sequential chain is cut down to one packed float add per accepted pixel.  Each pass
-//   1. predicts every remaining candidate against the current (exact) region angle,
+//   1. predicts every remaining candidate against the current (exact) running sums,
 //   2. walks the predicted-accepted lanes in order, adding their (cos, sin) to the running sums of all LATER
 //      lanes -- so lane j holds exactly the sums the reference has when it examines candidate j, built by the
 //      same sequence of float additions,
-//   3. lets every lane evaluate fastAtan2 of its own post-state and test its alignment against the angle of
-//      the state in front of it -- in parallel,
+//   3. lets every lane test its alignment against the state in front of it (its own pre-sums) -- in parallel,
 //   4. commits everything up to the first lane whose real decision differs from the prediction (decisions in
 //      front of it were taken on exact states, so they are the reference's), and repeats from there.
-// Mispredictions only happen for pixels within the step's angle drift of the tolerance boundary.
-// Returns the mask of the lanes whose pixel was accepted.
+// Both tests (1, 3) are decided by lsd_classify (directions, ten instructions) for every lane that is not within 0.05 degrees of
+// the tolerance; only for those does a pass evaluate what the reference evaluates -- reg_angle = fastAtan2 of the sums in front
+// of the lane, then the folded angle difference (lsd_aligned_mask).  The region angle as a number is therefore not kept up
+// to date: `angValid` says whether regAngF still is the reference's reg_angle for (sumdx, sumdy); it is recomputed when a lane
+// needs it and once at the end of region_grow().  Mispredictions only happen for pixels within the step's angle drift of the
+// tolerance boundary.  Returns the mask of the lanes whose pixel was accepted.
 __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsigned long long rem, const LsdCand& cd,
                                                           bool mayDup, const LsdTol& tol, float& sumdx, float& sumdy,
-                                                          float& regAngF, int& cnt) {
+                                                          float& regAngF, bool& angValid, int& cnt) {
   // rem = mask of the candidate lanes; all bookkeeping below is on 64-bit masks (scalar unit)
   unsigned long long accAll = 0;
   PF_ADD(c, 10, __popcll(rem));
   if (!rem) return 0;
   while (rem) {
-    const unsigned long long P = lsd_aligned_mask(c, regAngF, cd.px.angf, tol, rem);
-    if (!P) break;   // the state cannot change any more: every remaining candidate is rejected on the exact angle
+    unsigned long long P, unc;
+    lsd_classify(sumdx, sumdy, cd.px.cs, cd.px.sn, tol, rem, P, unc);
+    if (unc) {
+      if (!angValid) { regAngF = lsd_atan2_deg(sumdy, sumdx); angValid = true; }
+      P |= lsd_aligned_mask(c, regAngF, cd.px.angf, tol, unc);
+    }
+    if (!P) break;   // the state cannot change any more: every remaining candidate is rejected on the exact state
     PF_ADD(c, 12, 1);
     float preX = sumdx, preY = sumdy;
-    int prev = -1;
     unsigned long long acc, canc;
-    lsd_walk(c, P, mayDup, cd.nidx, cd.px.cs, cd.px.sn, preX, preY, prev, acc, canc);
-    const float postX = preX + cd.px.cs, postY = preY + cd.px.sn;
-    const float angPost = lsd_atan2_deg(postY, postX);
-    // the state in front of a lane: the post-state of the last walked lane below it, the region angle when there is none
-    float angPrev = __shfl(angPost, prev & 63);
-    if (prev < 0) angPrev = regAngF;
+    lsd_walk(c, P, mayDup, cd.nidx, cd.px.cs, cd.px.sn, preX, preY, acc, canc);
     const unsigned long long live = rem & ~canc;   // (canc may hold lanes outside rem: harmless here)
-    const unsigned long long D = lsd_aligned_mask(c, angPrev, cd.px.angf, tol, live);
+    unsigned long long D;
+    lsd_classify(preX, preY, cd.px.cs, cd.px.sn, tol, live, D, unc);
+    if (unc) {
+      // the reference's reg_angle in front of a lane: fastAtan2 of its pre-sums once something was accepted below it in this
+      // pass, the region angle as it stood before
+      const unsigned long long moved = ~1ull << (__ffsll((long long)acc) - 1);   // lanes behind the first walked lane
+      if ((unc & ~moved) && !angValid) { regAngF = lsd_atan2_deg(sumdy, sumdx); angValid = true; }
+      float angPrev = lsd_atan2_deg(preY, preX);
+      if (!LSD_INV_BALLOT(c, moved)) angPrev = regAngF;
+      D |= lsd_aligned_mask(c, angPrev, cd.px.angf, tol, unc);
+    }
     const unsigned long long mism = (D ^ acc) & live;
     unsigned long long A = acc;
     int f = 64;
@@ -300,9 +348,9 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
       }
       accAll |= A;
       const int last = 63 - __clzll((long long)A);
-      sumdx = bcast_f32(postX, last);
-      sumdy = bcast_f32(postY, last);
-      regAngF = bcast_f32(angPost, last);
+      sumdx = bcast_f32(preX + cd.px.cs, last);
+      sumdy = bcast_f32(preY + cd.px.sn, last);
+      angValid = false;
       cnt += __popcll(A);
     }
     if (f >= 64) break;
@@ -347,12 +395,20 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint3
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
 // reference's float fastAtan2 result).  All lanes hold identical (uniform) state.
 __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, int firstGrp, bool dirtyFst,
-                                               float* regAngOut) {
+                                               int minCnt, float* regAngOut) {
   const int lane = c.lane, g = lane >> 3;
   // the call's parameters come from LDS (uniform): nothing of the caller's state has to stay in registers across the loop
   const uint32_t seedPk = bcast_u32(gs.u[0], 0);
   const unsigned seedQ = bcast_u32(gs.u[1], 0);
-  const LsdTol tol = lsd_tol(bcast_f64(gs.d[0], 0));
+  LsdTol tol = lsd_tol(bcast_f64(gs.d[0], 0));
+  if (tol.prec == c.precDef) {   // the launch's tolerance: margins from the host
+    tol.cin2 = c.cin2Def; tol.cout2 = c.cout2Def; tol.fast = c.fastDef != 0;
+  } else {
+    const LsdMargins mg = lsd_tol_margins(tol.prec);   // results of a call come back in vector registers: make them scalar again
+    tol.cin2 = bcast_f32(mg.cin2, 0); tol.cout2 = bcast_f32(mg.cout2, 0);
+    tol.fast = bcast_u32((unsigned)mg.fast, 0) != 0u;
+  }
+  bool angValid = true;   // before the first accept reg_angle is the seed's own angle
   float regAngF = bcast_f32(__uint_as_float(gs.u[2]), 0), sumdx = bcast_f32(__uint_as_float(gs.u[3]), 0),
         sumdy = bcast_f32(__uint_as_float(gs.u[4]), 0);
   const uint32_t seed = pk_lin(c, seedPk);
@@ -377,13 +433,13 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     if (dirtyFst && first.inb) first.px.q = c.G[first.nidx].q;
     // `used` is bit 31: one signed compare covers "not marked and above the gradient threshold"
     const unsigned long long candM = wballot(first.inb) & wballot((int)first.px.q > (int)c.qThresh);
-    lsd_resolve(c, candM, first, false, tol, sumdx, sumdy, regAngF, cnt);
+    lsd_resolve(c, candM, first, false, tol, sumdx, sumdy, regAngF, angValid, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
     i = 1;
   }
   if (i >= cnt) {
     PF_ADD(c, 9, cnt);
-    *regAngOut = regAngF;
+    *regAngOut = regAngF;   // nothing accepted: the seed's angle (and the caller drops the region anyway)
     return cnt;
   }
   PLH_WAVE_SYNC();
@@ -397,7 +453,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     const unsigned long long candM = wballot((int)cur.px.q > (int)c.qThresh);
     const unsigned long long pt1 = PF_NOW();
     PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
-    lsd_resolve(c, candM, cur, true, tol, sumdx, sumdy, regAngF, cnt);
+    lsd_resolve(c, candM, cur, true, tol, sumdx, sumdy, regAngF, angValid, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1);
     i += m;
     // the next step's records, requested after this step's marks were stored (a wavefront observes its own stores);
@@ -407,6 +463,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     cur.px = c.G[cur.nidx];
   }
   PF_ADD(c, 9, cnt);
+  if (!angValid && cnt >= minCnt) regAngF = lsd_atan2_deg(sumdy, sumdx);   // the caller only looks at regions it keeps
   *regAngOut = regAngF;
   return cnt;
 }
@@ -593,6 +650,7 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
   c.reg = a.reg + (long long)b * a.scaledStride;
   c.scr = a.scr + (long long)b * a.scaledStride;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
+  c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
   const uint32_t* ord = a.ordered + (long long)b * a.scaledStride;   // packed coordinates x | y << 16
   float* segs = a.segs + (long long)b * a.segCap * 4;
 #if defined(PLH_GROW_PROF)
@@ -706,7 +764,7 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
         for (;;) {
           float regAngF;
           const unsigned long long pg0 = PF_NOW();
-          int cnt = lsd_region_grow(c, gs, phase == 0 ? t : -1, dirtyFst, &regAngF);
+          int cnt = lsd_region_grow(c, gs, phase == 0 ? t : -1, dirtyFst, phase == 0 ? a.minRegSize : 2, &regAngF);
           dirtySeed = true; dirtyFst = true;
           const unsigned long long pg1 = PF_NOW();
           PF_ADD(c, 2, pg1 - pg0);

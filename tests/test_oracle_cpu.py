@@ -52,6 +52,21 @@ def test_fast_atan2_cardinals(oracle):
         assert abs(((a - np.degrees(np.arctan2(y, x))) + 180) % 360 - 180) < 0.3
 
 
+def test_fast_atan2_error_bound_behind_the_direction_test(oracle):
+    """k_lsd_grow decides alignments by directions when a pixel is further than LSD_ALIGN_MARGIN_DEG = 0.05 degrees from the
+    tolerance (lsd_grow.hip, lsd_classify); that is only exact if fastAtan2 stays well inside the margin of the true angle."""
+    f = oracle.lib().plo_fast_atan2
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    ang = np.concatenate([np.linspace(0, 360, 20001), rng.uniform(0, 360, 20000)])
+    for a in ang:
+        r = float(rng.uniform(0.5, 3.0e5))
+        y, x = np.float32(r * np.sin(np.radians(a))), np.float32(r * np.cos(np.radians(a)))
+        d = f(float(y), float(x)) - np.degrees(np.arctan2(float(y), float(x))) % 360.0
+        worst = max(worst, abs((d + 180.0) % 360.0 - 180.0))
+    assert worst < 0.012, worst
+
+
 def test_cv_round_half_even(oracle):
     r = oracle.lib().plo_cv_round_f
     assert [r(0.5), r(1.5), r(2.5), r(-0.5), r(-1.5), r(2.4999), r(2.5001)] == [0, 2, 2, 0, -2, 2, 3]
