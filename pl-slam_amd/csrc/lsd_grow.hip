@@ -87,7 +87,7 @@ struct LsdTol {
   double prec;
   float lo, hi;
   float cin2, cout2;   // cos^2(prec -+ LSD_ALIGN_MARGIN): the direction test of lsd_classify
-  bool fast;           // prec + margin < 89 degrees: the direction test applies
+  float posT;          // 0; -inf (with cin2 = +inf, cout2 = -1) when prec + margin >= 89 degrees and the test does not apply
 };
 // The margin of the direction test, in degrees.  It has to cover |fastAtan2 - atan2| (0.0096 degrees for this polynomial,
 // scanned over 4 M ratios, plus the float rounding of the octant folding, < 1e-4), the direction error of the stored float
@@ -112,7 +112,7 @@ __device__ __forceinline__ LsdTol lsd_tol(double prec) {
   const float m = 2e-3f + pd * 1e-6f;
   t.lo = pd - m;
   t.hi = pd + m;
-  t.cin2 = 4.f; t.cout2 = 0.f; t.fast = false;
+  t.cin2 = __builtin_inff(); t.cout2 = -1.f; t.posT = -__builtin_inff();
   return t;
 }
 __device__ __forceinline__ bool lsd_aligned_f(float thF, float aF, const LsdTol& t) {
@@ -263,14 +263,14 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
 // pixel angle a with reg_angle = fastAtan2(sumdy, sumdx) (or the seed's own angle before the first accept), folded to the
 // circular distance, against prec.  fastAtan2 is within 0.01 degrees of the true direction of (x, y) = the running sums, so
 // with D = the true angle between (x, y) and (cos a, sin a):  D <= prec - margin  =>  aligned,  D >= prec + margin  =>  not.
-// cos D = (cs x + sn y) / |(x, y)|, compared in squares (prec + margin < 90 degrees, t.fast).  Only the lanes in between
+// cos D = (cs x + sn y) / |(x, y)|, compared in squares (needs prec + margin < 90 degrees).  Only the lanes in between
 // -- a 0.1-degree band around the tolerance -- need the reference's arithmetic.  Ten VALU instructions; the exact test costs
 // a fastAtan2 (30) per state plus the compare (9).  `in` / `unc` = certainly aligned / undecided lanes of `act`.
 __device__ __forceinline__ void lsd_classify(float x, float y, float cs, float sn, const LsdTol& t, unsigned long long act,
                                              unsigned long long& in, unsigned long long& unc) {
-  if (!t.fast) { in = 0; unc = act; return; }
+  // (a tolerance the test does not apply to carries posT = -inf, cin2 = +inf, cout2 = -1: every lane comes out undecided)
   const float dot = __builtin_fmaf(sn, y, cs * x), n2 = __builtin_fmaf(y, y, x * x), dd = dot * dot;
-  const unsigned long long pos = wballot(dot > 0.f);
+  const unsigned long long pos = wballot(dot > t.posT);
   const unsigned long long ge = wballot(dd >= t.cin2 * n2), le = wballot(dd <= t.cout2 * n2);
   in = pos & ge & act;
   unc = act & ~(in | ~pos | le);
@@ -402,11 +402,10 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   const unsigned seedQ = bcast_u32(gs.u[1], 0);
   LsdTol tol = lsd_tol(bcast_f64(gs.d[0], 0));
   if (tol.prec == c.precDef) {   // the launch's tolerance: margins from the host
-    tol.cin2 = c.cin2Def; tol.cout2 = c.cout2Def; tol.fast = c.fastDef != 0;
+    if (c.fastDef) { tol.cin2 = c.cin2Def; tol.cout2 = c.cout2Def; tol.posT = 0.f; }
   } else {
     const LsdMargins mg = lsd_tol_margins(tol.prec);   // results of a call come back in vector registers: make them scalar again
-    tol.cin2 = bcast_f32(mg.cin2, 0); tol.cout2 = bcast_f32(mg.cout2, 0);
-    tol.fast = bcast_u32((unsigned)mg.fast, 0) != 0u;
+    if (bcast_u32((unsigned)mg.fast, 0) != 0u) { tol.cin2 = bcast_f32(mg.cin2, 0); tol.cout2 = bcast_f32(mg.cout2, 0); tol.posT = 0.f; }
   }
   bool angValid = true;   // before the first accept reg_angle is the seed's own angle
   float regAngF = bcast_f32(__uint_as_float(gs.u[2]), 0), sumdx = bcast_f32(__uint_as_float(gs.u[3]), 0),
@@ -771,6 +770,7 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
           if (cnt < (phase == 0 ? a.minRegSize : 2)) break;
           const double reg_angle = (double)regAngF * kDegToRads;
           __syncthreads();   // queue stores visible to every lane
+          PF_ADD(c, 14, 1); PF_ADD(c, 1, cnt);
           lsd_region2rect(c, cnt, reg_angle, a.prec, rec);
           const unsigned long long pg2 = PF_NOW();
           PF_ADD(c, 5, pg2 - pg1);
@@ -779,6 +779,7 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
           const uint32_t cPk = c.reg[0];   // refine() and reduce_region_radius() work around reg[0]
           const double xc = (double)pk_x(cPk), yc = (double)pk_y(cPk);
           if (phase == 0) {   // refine(): tolerance from the angle spread near the seed, everything un-marked
+            PF_ADD(c, 15, 1);
             const uint32_t cLin = pk_lin(c, cPk);
             const LsdPix g0 = c.G[cLin];
             const float2 s0 = c.S[cLin];
@@ -835,6 +836,7 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
             if (lane == 0) gs.d[0] = radSq;
             cnt = lsd_reduce_radius_step(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
             if (cnt < 2) { emit = false; break; }
+            PF_ADD(c, 7, 1); PF_ADD(c, 1, cnt);
             lsd_region2rect(c, cnt, (double)regAngS * kDegToRads, a.prec, rec);
           }
           PF_ADD(c, 6, PF_NOW() - pg2);

@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _util  # noqa: E402
 
-NAMES = ["total", "-", "region_grow", "grow:load wait", "grow:resolve", "region2rect", "refine", "-",
-         "#steps", "#accepted", "#cands", "#grow calls", "#passes", "#mispredicts", "-", "-"]
+NAMES = ["total", "#region2rect pixels", "region_grow", "grow:load wait", "grow:resolve", "region2rect", "refine", "#reduce_radius steps",
+         "#steps", "#accepted", "#cands", "#grow calls", "#passes", "#mispredicts", "#region2rect after grow", "#refine"]
 
 
 def main():
