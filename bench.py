@@ -244,8 +244,8 @@ def single_frame_latency(P, torch, dev, frames, nfeatures, nlevels, nlines, K, D
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=6144, help="frames per GPU per step (6 k_lsd_grow wavefronts per SIMD = 6144 resident frames)")
     ap.add_argument("--nsplit", type=int, default=4, help="sub-batches pipelined against each other (pl-slam_amd/pipeline.py)")
     ap.add_argument("--rows", type=int, default=480)
