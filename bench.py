@@ -336,8 +336,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(args.steps):
+        th = time.perf_counter()
         step()
+        host_ms.append((time.perf_counter() - th) * 1e3)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -394,6 +398,7 @@ def main():
             "metric": "frames/s ORB+LSD extract+match, %dx%d mono" % (cols, rows),
             "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": [round(v, 2) for v in host_ms],   # how far the host runs ahead of the GPU (launch queues)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%dx%d mono, %d-level pyramid, %d ORB / %d lines (%s parameters), batch %d frames/GPU resident in HBM "
                                    "(%d sub-batches of %d pipelined, consecutive steps overlap, nothing crosses PCIe in the timed region); "

@@ -33,18 +33,22 @@ __device__ __forceinline__ int refl101(int p, int n) {
   return p;
 }
 
-// LSD level-line field, one 16-byte record per pixel of the 0.8x image (a single dwordx4 load in the
-// region-growing loop):
+// What region growing keeps in registers for a candidate pixel: its table values (line_plan.h, LsdAngleEntry) and its
+// record word `q` (LSD_REC_*: table index, DEF, USED).
 //   angf : fastAtan2(gx, -gy) in degrees (float); the reference's double angle is angf * DEG_TO_RADS
 //   cs,sn: (float)cos / sin of float(angle) -- the increments region_grow() adds to sumdx / sumdy
-//   q    : gx^2 + gy^2; modgrad = sqrt(q / 4.0) (double) is recomputed where needed; q <= qThresh <=> NOTDEF
-// All four are exactly the values cv::LineSegmentDetector would compute on the fly.
+// All are exactly the values cv::LineSegmentDetector would compute on the fly.
 struct LsdPix {
   float angf, cs, sn;
   unsigned q;
 };
 __device__ __forceinline__ double pix_angle(const LsdPix& p) { return (double)p.angf * kDegToRads; }
 __device__ __forceinline__ double q_modgrad(unsigned q) { return sqrt((double)(int)q / 4.0); }
+// gx^2 + gy^2 of a record
+__device__ __forceinline__ unsigned lsd_rec_q(uint32_t rec) {
+  const int gx = (int)(rec & 1023u) - LSD_GRAD_MAX, gy = (int)((rec >> LSD_ANGLE_PITCH_LOG2) & 1023u) - LSD_GRAD_MAX;
+  return (unsigned)(__mul24(gx, gx) + __mul24(gy, gy));
+}
 
 // uniform-lane broadcast of a double: v_readlane (SGPR) on hardware, a shuffle under emulation
 #if defined(HIPEMU)

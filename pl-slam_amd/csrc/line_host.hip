@@ -18,6 +18,7 @@ void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sw, in
 void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s);
 void launch_lsd_angle_table(LsdAngleEntry* tab, hipStream_t s);
 void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s);
+size_t lsd_order_work_u32();
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s);
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s);
 void launch_sobel(const LineDeviceArgs& a, hipStream_t s);
@@ -65,9 +66,8 @@ struct plh_line {
   int rszTP = 0, rszTR = 0;   // k_resize_u8 source tile of a 256 x 16 output block (pitch in bytes, rows)
   // device buffers
   uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dMask = nullptr;
-  uint8_t* dPix = nullptr;
-  uint32_t *dOrdered = nullptr, *dReg = nullptr, *dScr = nullptr, *dDxdy = nullptr;
-  float* dSeedCs = nullptr;
+  uint32_t* dPix = nullptr;
+  uint32_t *dOrdered = nullptr, *dReg = nullptr, *dScr = nullptr, *dDxdy = nullptr, *dOrderWork = nullptr;
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
   hipStream_t lastStream = nullptr;   // stream of the most recent extract call (plh_line_status waits on it)
@@ -158,7 +158,7 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dPix, h->dOrdered, h->dReg, h->dScr, h->dSeedCs, h->dDxdy, h->dQmax,
+  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dPix, h->dOrdered, h->dReg, h->dScr, h->dDxdy, h->dOrderWork, h->dQmax,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dSegs, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -267,11 +267,11 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
 #define TRYHIP(x) do { if ((x) != hipSuccess) { set_error("plh_line_create: %s failed (batch %d)", #x, max_batch); plh_line_destroy(h); return PLH_ERR_ALLOC; } } while (0)
   TRYHIP(hipMalloc((void**)&h->dTmpA, B * a.fullStride));
   TRYHIP(hipMalloc((void**)&h->dScaled, B * a.scaledStride));
-  TRYHIP(hipMalloc((void**)&h->dPix, B * a.scaledStride * 16));
+  TRYHIP(hipMalloc((void**)&h->dPix, B * a.scaledStride * 4));
   TRYHIP(hipMalloc((void**)&h->dOrdered, B * a.scaledStride * 4));
   TRYHIP(hipMalloc((void**)&h->dReg, B * a.scaledStride * 4));
   TRYHIP(hipMalloc((void**)&h->dScr, B * a.scaledStride * 4));
-  TRYHIP(hipMalloc((void**)&h->dSeedCs, B * a.scaledStride * 8));
+  TRYHIP(hipMalloc((void**)&h->dOrderWork, B * lsd_order_work_u32() * 4));
   TRYHIP(hipMalloc((void**)&h->dDxdy, B * a.fullStride * 4));
   TRYHIP(hipMalloc((void**)&h->dSegs, B * a.segCap * 16));
   TRYHIP(hipMalloc((void**)&h->dQmax, B * 4));
@@ -294,7 +294,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
     return PLH_ERR_ALLOC;
   }
   a.angleTab = h->a.angleTab;
-  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.ordered = h->dOrdered; a.reg = h->dReg; a.scr = h->dScr; a.seedcs = h->dSeedCs;
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.ordered = h->dOrdered; a.reg = h->dReg; a.scr = h->dScr; a.orderWork = h->dOrderWork;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = h->dSegs; a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
   *out = h;

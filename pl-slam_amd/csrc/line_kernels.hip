@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) k_resize_u8(const uint8_t* src, long long
 }
 
 // ---------------------------------------------------------------------------------------------
-// ll_angle(): level-line field (LsdPix records, see line_dev.h), padding columns cleared, per-frame max gradient.
+// ll_angle(): level-line field (4-byte records, see line_plan.h), padding columns cleared, per-frame max gradient.
 // ---------------------------------------------------------------------------------------------
 // What ll_angle() derives from one gradient (gx, gy); evaluated once per possible pair into the per-device table
 // (line_plan.h), never per pixel.
@@ -288,7 +288,8 @@ __device__ __forceinline__ LsdAngleEntry lsd_angle_entry(int gx, int gy) {
   e.seedy = (float)sd;
   e.cs = (float)cf;
   e.sn = (float)sf;
-  e.pad[0] = e.pad[1] = e.pad[2] = 0.f;
+  e.pad = 0.f;
+  e.modgrad = q_modgrad((unsigned)(gx * gx + gy * gy));
   return e;
 }
 __global__ void __launch_bounds__(256) k_lsd_angle_table(LsdAngleEntry* tab) {
@@ -296,7 +297,9 @@ __global__ void __launch_bounds__(256) k_lsd_angle_table(LsdAngleEntry* tab) {
   if (ix < LSD_ANGLE_ROWS) tab[((size_t)iy << LSD_ANGLE_PITCH_LOG2) + ix] = lsd_angle_entry(ix - LSD_GRAD_MAX, iy - LSD_GRAD_MAX);
 }
 
-// Block (64,4): 4 rows x 256 columns, 4 horizontally adjacent pixels per thread (two aligned dword loads per row).
+// Block (64,4): 4 rows x 256 columns, 4 horizontally adjacent pixels per thread (two aligned dword loads per row, one
+// 16-byte store of four records).  A record is the gradient's table index and the DEF flag (line_plan.h); nothing else
+// is written per pixel.
 __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   __shared__ unsigned s_max;
   const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
@@ -316,12 +319,7 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
       }
     }
     unsigned qmax = 0;
-    const long long o = (long long)b * a.scaledStride + (__mul24(y, a.spitch) + x4);
-    // all four gathers are requested before the first record is assembled
-    unsigned q[4];
-    bool def[4];
-    uint4 e0[4];
-    float e1[4];
+    uint32_t rec[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int x = x4 + k;
@@ -329,31 +327,15 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
       const int p10 = (int)((r1 >> (8 * k)) & 255), p11 = (int)((r1 >> (8 * k + 8)) & 255);
       const int DA = p11 - p00, BC = p01 - p10;
       const int gx = DA + BC, gy = DA - BC;
-      q[k] = (unsigned)(__mul24(gx, gx) + __mul24(gy, gy));
-      def[k] = x < a.sw - 1 && y < a.sh - 1 && q[k] > a.qThresh;
-      e0[k].x = __float_as_uint(-1024.f); e0[k].y = 0u; e0[k].z = 0u; e0[k].w = 0u;
-      e1[k] = 0.f;
-      if (def[k]) {
-        const LsdAngleEntry* e = a.angleTab + (((gy + LSD_GRAD_MAX) << LSD_ANGLE_PITCH_LOG2) + gx + LSD_GRAD_MAX);
-        e0[k] = *reinterpret_cast<const uint4*>(e);
-        e1[k] = e->seedy;
-      }
+      const unsigned q = (unsigned)(__mul24(gx, gx) + __mul24(gy, gy));
+      const bool def = x < a.sw - 1 && y < a.sh - 1 && q > a.qThresh;
+      rec[k] = def ? ((uint32_t)(((gy + LSD_GRAD_MAX) << LSD_ANGLE_PITCH_LOG2) + gx + LSD_GRAD_MAX) | LSD_REC_DEF) : 0u;
+      if (def) qmax = max(qmax, q);
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      LsdPix px;
-      px.angf = __uint_as_float(e0[k].x); px.cs = __uint_as_float(e0[k].y); px.sn = __uint_as_float(e0[k].z);
-      px.q = (x4 + k < a.sw - 1 && y < a.sh - 1) ? q[k] : 0u;
-      float2 seed;
-      seed.x = def[k] ? __uint_as_float(e0[k].w) : 0.f;
-      seed.y = e1[k];
-      if (def[k]) qmax = max(qmax, q[k]);
-      if (x4 + k < a.spitch) {
-        reinterpret_cast<LsdPix*>(a.pix)[o + k] = px;
-        reinterpret_cast<float2*>(a.seedcs)[o + k] = seed;
-        a.scr[o + k] = px.q;   // compact copy of q for the seed ordering (scr is free until region growing)
-      }
-    }
+    uint32_t* o = a.pix + (long long)b * a.scaledStride + (__mul24(y, a.spitch) + x4);   // pitch is a multiple of 64: 16-byte aligned
+    uint4 o4;
+    o4.x = rec[0]; o4.y = rec[1]; o4.z = rec[2]; o4.w = rec[3];
+    *reinterpret_cast<uint4*>(o) = o4;
     if (qmax) atomicMax(&s_max, qmax);
   }
   __syncthreads();
@@ -377,46 +359,64 @@ __device__ __forceinline__ float plh_sqrt_approx(float x) {
 #endif
 }
 
-// One 1024-thread block per frame: stable counting sort of the DEFINED pixels by bin (descending), raster
-// order inside a bin.  16 waves own contiguous raster chunks; per-(wave,bin) counters live in LDS.  Inside a
-// 64-pixel group the rank of a lane among the lanes of the same bin comes from ten ballots (one per bin bit).
-__global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
-  HIP_DYNAMIC_SHARED(unsigned char, smem)
-  int* hist = (int*)smem;                 // [16][1024] counts, then running offsets
-  int* scan = hist + 16 * LSD_NBINS;      // [1024]
-  const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const uint32_t* Q = a.scr + (long long)b * a.scaledStride;      // q per pixel (k_lsd_grad)
-  uint32_t* BIN = a.reg + (long long)b * a.scaledStride;          // bin + 1 per pixel, 0 = NOTDEF (scratch)
-  uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
-  const unsigned qmax = a.qmax[b];
-  const double bin_coef = qmax > 0 ? (double)(LSD_NBINS - 1) / sqrt((double)(int)qmax / 4.0) : 0.0;
-  const int npix = a.spitch * a.sh;
-  const int chunk = ((npix + 15) / 16 + 63) / 64 * 64;
-  const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
-  for (int i = tid; i < 16 * LSD_NBINS; i += 1024) hist[i] = 0;
-  // The bin of a pixel is (int)(sqrt(q / 4.0) * bin_coef) in double -- a correctly rounded f64 square root per pixel (about
-  // 20 instructions).  It is monotone in q, so it is fixed by the 1024 thresholds binLo[k] = smallest q whose bin is >= k,
-  // which thread k finds once per frame with the exact expression (analytic guess 4 (k / coef)^2, then stepped until
-  // exact).  Per pixel a float estimate (within 2e-4 of the real-valued product) names the bin up to one, and two
-  // compares against the thresholds decide it.
-  unsigned* binLo = (unsigned*)(scan + LSD_NBINS);   // [LSD_NBINS + 1]
-  {
-    auto exact_bin = [&](unsigned q) -> int { return (int)(q_modgrad(q) * bin_coef); };
-    unsigned t = tid > 0 ? 0xffffffffu : 0u;   // no defined pixel (bin_coef == 0): everything is bin 0
-    if (tid > 0 && bin_coef > 0.0) {
-      const double r = (double)tid / bin_coef;
-      const double g = 4.0 * r * r;
-      t = g < 4.0e9 ? (unsigned)g : 4000000000u;
-      while (t > 0u && exact_bin(t - 1u) >= tid) t--;
-      while (t < 4000000000u && exact_bin(t) < tid) t++;
-    }
-    binLo[tid] = t;
-    if (tid == 0) binLo[LSD_NBINS] = 0xffffffffu;
+// Seed ordering: stable counting sort of the DEFINED pixels of a frame by bin (descending), raster order inside a bin.
+// A frame is cut into LSD_ORDER_CHUNKS contiguous raster chunks; the sort is four launches of small blocks
+//   k_lsd_bin_thresholds   256 threads: the frame's 1024 exact bin thresholds
+//   k_lsd_bin_hist         one wavefront per (chunk, frame): bins of the chunk's pixels + the chunk's histogram
+//   k_lsd_bin_scan         256 threads per frame: offsets of every (bin, chunk) in the output list
+//   k_lsd_bin_scatter      one wavefront per (chunk, frame): ranks inside the chunk, scatter
+// with the per-(frame, chunk, bin) counts handed over in global memory (64 KB per frame).  Round 2 started with ONE
+// 1024-thread block per frame holding all 16 histograms in 72 KB of LDS: 2.8 ms per 1536 frames alone, but 40 - 90 ms inside
+// the pipeline (`profiles/r02_pipeline_timeline_before_order_split.txt`) -- a block that needs four wave slots on every SIMD
+// of a CU and half its LDS at once waits for the region-growing wavefronts of the other sub-batches to drain, and the
+// kernel sits on the line chain's critical path in front of k_lsd_grow, so only two of the four sub-batches were ever
+// growing at the same time.  Single-wavefront blocks with 4 - 8 KB of LDS start wherever a wave slot frees up.
+//
+// The bin of a pixel is (int)(sqrt(q / 4.0) * bin_coef) in double -- a correctly rounded f64 square root per pixel (about
+// 20 instructions).  It is monotone in q, so it is fixed by the 1024 thresholds binLo[k] = smallest q whose bin is >= k,
+// found once per frame with the exact expression (analytic guess 4 (k / coef)^2, then stepped until exact).  Per pixel
+// a float estimate (within 2e-4 of the real-valued product) names the bin up to one, and two compares against the
+// thresholds decide it.
+constexpr int LSD_ORDER_CHUNKS = 16;
+constexpr int LSD_ORDER_WORK = LSD_ORDER_CHUNKS * LSD_NBINS + LSD_NBINS + 8;   // u32 per frame: counts / offsets, then thresholds (+ pad)
+__device__ __forceinline__ int lsd_order_chunk(int npix) { return ((npix + LSD_ORDER_CHUNKS - 1) / LSD_ORDER_CHUNKS + 63) / 64 * 64; }
+__device__ __forceinline__ double lsd_bin_coef(unsigned qmax) {
+  return qmax > 0 ? (double)(LSD_NBINS - 1) / sqrt((double)(int)qmax / 4.0) : 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_lsd_bin_thresholds(LineDeviceArgs a) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;   // bin
+  uint32_t* binLo = a.orderWork + (long long)b * LSD_ORDER_WORK + LSD_ORDER_CHUNKS * LSD_NBINS;
+  const double bin_coef = lsd_bin_coef(a.qmax[b]);
+  auto exact_bin = [&](unsigned q) -> int { return (int)(q_modgrad(q) * bin_coef); };
+  unsigned t = k > 0 ? 0xffffffffu : 0u;   // no defined pixel (bin_coef == 0): everything is bin 0
+  if (k > 0 && bin_coef > 0.0) {
+    const double r = (double)k / bin_coef;
+    const double g = 4.0 * r * r;
+    t = g < 4.0e9 ? (unsigned)g : 4000000000u;
+    while (t > 0u && exact_bin(t - 1u) >= k) t--;
+    while (t < 4000000000u && exact_bin(t) < k) t++;
   }
-  const float coefF = (float)(bin_coef * 0.5);   // sqrt(q / 4) = sqrt(q) / 2
+  binLo[k] = t;
+  if (k == 0) binLo[LSD_NBINS] = 0xffffffffu;
+}
+
+__global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
+  __shared__ unsigned binLo[LSD_NBINS + 8];
+  __shared__ int hist[LSD_NBINS];
+  const int wv = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const uint32_t* Q = a.pix + (long long)b * a.scaledStride;      // level-line records (k_lsd_grad)
+  uint32_t* BIN = a.reg + (long long)b * a.scaledStride;          // bin + 1 per pixel, 0 = NOTDEF (scratch)
+  uint32_t* work = a.orderWork + (long long)b * LSD_ORDER_WORK;
+  const int npix = a.spitch * a.sh;
+  const int chunk = lsd_order_chunk(npix);
+  const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
+  for (int i = lane; i < LSD_NBINS + 1; i += 64) binLo[i] = work[LSD_ORDER_CHUNKS * LSD_NBINS + i];
+  for (int i = lane; i < LSD_NBINS; i += 64) hist[i] = 0;
+  const float coefF = (float)(lsd_bin_coef(a.qmax[b]) * 0.5);   // sqrt(q / 4) = sqrt(q) / 2
   __syncthreads();
-  // pass 1: histogram; order is irrelevant here, so every lane takes 4 consecutive pixels (16-byte loads / stores;
-  // chunk bounds are multiples of 64)
+  // order is irrelevant here, so every lane takes 4 consecutive pixels (16-byte loads / stores; chunk bounds are
+  // multiples of 64)
   for (int base = c0; base < c1; base += 256) {
     const int i = base + lane * 4;
     if (i < c1) {
@@ -426,10 +426,11 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         bb[k] = 0;
-        if (qq[k] > a.qThresh) {
-          const int est = min((int)(plh_sqrt_approx((float)qq[k]) * coefF), LSD_NBINS - 1);
-          const int bin = est - (qq[k] < binLo[est] ? 1 : 0) + (qq[k] >= binLo[est + 1] ? 1 : 0);
-          atomicAdd(&hist[wv * LSD_NBINS + bin], 1);
+        if (qq[k] & LSD_REC_DEF) {
+          const unsigned q = lsd_rec_q(qq[k]);
+          const int est = min((int)(plh_sqrt_approx((float)q) * coefF), LSD_NBINS - 1);
+          const int bin = est - (q < binLo[est] ? 1 : 0) + (q >= binLo[est + 1] ? 1 : 0);
+          atomicAdd(&hist[bin], 1);
           bb[k] = (unsigned)bin + 1u;
         }
       }
@@ -439,31 +440,62 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
     }
   }
   __syncthreads();
-  {   // thread t owns bin 1023 - t (descending bins first)
-    const int bin = LSD_NBINS - 1 - tid;
-    int tot = 0;
-    for (int w = 0; w < 16; w++) tot += hist[w * LSD_NBINS + bin];
-    scan[tid] = tot;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const int v = tid >= d ? scan[tid - d] : 0;
-      __syncthreads();
-      scan[tid] += v;
-      __syncthreads();
-    }
-    int run = scan[tid] - tot;
-    for (int w = 0; w < 16; w++) {
-      const int c = hist[w * LSD_NBINS + bin];
-      hist[w * LSD_NBINS + bin] = run;
-      run += c;
-    }
-    if (tid == 1023) a.nOrdered[b] = scan[1023];
+  for (int i = lane; i < LSD_NBINS; i += 64) work[wv * LSD_NBINS + i] = (uint32_t)hist[i];
+}
+
+// counts[chunk][bin] -> offsets[chunk][bin] in place: bins descending, chunks ascending inside a bin.  Thread t owns the
+// list positions of bins 1023 - 4t .. 1020 - 4t.
+__global__ void __launch_bounds__(256) k_lsd_bin_scan(LineDeviceArgs a) {
+  __shared__ int part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  uint32_t* work = a.orderWork + (long long)b * LSD_ORDER_WORK;
+  const int bin0 = LSD_NBINS - 4 - 4 * tid;   // lowest of the thread's four bins
+  uint4 cnt[LSD_ORDER_CHUNKS];
+  int tot = 0;
+#pragma unroll
+  for (int w = 0; w < LSD_ORDER_CHUNKS; w++) {
+    cnt[w] = *reinterpret_cast<const uint4*>(work + w * LSD_NBINS + bin0);
+    tot += (int)(cnt[w].x + cnt[w].y + cnt[w].z + cnt[w].w);
   }
+  part[tid] = tot;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - tot;
+  uint4 off[LSD_ORDER_CHUNKS];
+  // descending bins: .w (bin0 + 3) first
+#pragma unroll
+  for (int w = 0; w < LSD_ORDER_CHUNKS; w++) { off[w].w = (unsigned)run; run += (int)cnt[w].w; }
+#pragma unroll
+  for (int w = 0; w < LSD_ORDER_CHUNKS; w++) { off[w].z = (unsigned)run; run += (int)cnt[w].z; }
+#pragma unroll
+  for (int w = 0; w < LSD_ORDER_CHUNKS; w++) { off[w].y = (unsigned)run; run += (int)cnt[w].y; }
+#pragma unroll
+  for (int w = 0; w < LSD_ORDER_CHUNKS; w++) { off[w].x = (unsigned)run; run += (int)cnt[w].x; }
+#pragma unroll
+  for (int w = 0; w < LSD_ORDER_CHUNKS; w++) *reinterpret_cast<uint4*>(work + w * LSD_NBINS + bin0) = off[w];
+  if (tid == 255) a.nOrdered[b] = part[255];
+}
+
+__global__ void __launch_bounds__(64) k_lsd_bin_scatter(LineDeviceArgs a) {
+  __shared__ int cur[LSD_NBINS];   // next list position of every bin for this chunk
+  const int wv = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const uint32_t* BIN = a.reg + (long long)b * a.scaledStride;
+  uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
+  const uint32_t* work = a.orderWork + (long long)b * LSD_ORDER_WORK;
+  const int npix = a.spitch * a.sh;
+  const int chunk = lsd_order_chunk(npix);
+  const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
+  if (c0 >= c1) return;
+  for (int i = lane; i < LSD_NBINS; i += 64) cur[i] = (int)work[wv * LSD_NBINS + i];
   __syncthreads();
   const unsigned long long lt = lanemask_lt();
-  // pass 2: lane order = raster order inside a 64-pixel group; the next group's bins are requested before this one
-  // is ranked
-  // a 64-pixel group never straddles a row (pitch and chunk bounds are multiples of 64): its row and first column are
+  // lane order = raster order inside a 64-pixel group; the next group's bins are requested before this one is ranked.
+  // A 64-pixel group never straddles a row (pitch and chunk bounds are multiples of 64): its row and first column are
   // uniform and advance without divisions
   int gy = c0 / a.spitch, gx = c0 - gy * a.spitch;
   auto rank_group = [&](unsigned bp1) {
@@ -488,11 +520,11 @@ __global__ void __launch_bounds__(1024) k_lsd_order(LineDeviceArgs a) {
     const bool active = bp1 != 0u;
     PLH_WAVE_SYNC();
     int basep = 0;
-    if (active) basep = hist[wv * LSD_NBINS + bin];
+    if (active) basep = cur[bin];
     PLH_WAVE_SYNC();
     if (active) {
       const int rank = __popcll(same & lt);
-      if (rank == 0) hist[wv * LSD_NBINS + bin] = basep + __popcll(same);
+      if (rank == 0) cur[bin] = basep + __popcll(same);
       ord[basep + rank] = coord;
     }
   };
@@ -563,8 +595,12 @@ void launch_lsd_angle_table(LsdAngleEntry* tab, hipStream_t s) {
 void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lsd_grad, dim3((a.spitch + 255) / 256, (a.sh + 3) / 4, a.batch), dim3(64, 4), 0, s, a);
 }
+size_t lsd_order_work_u32() { return (size_t)LSD_ORDER_WORK; }
 void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_lsd_order, dim3(a.batch), dim3(1024), (size_t)(16 * LSD_NBINS + 1024 + LSD_NBINS + 1) * 4, s, a);
+  hipLaunchKernelGGL(k_lsd_bin_thresholds, dim3(LSD_NBINS / 256, a.batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_lsd_bin_hist, dim3(LSD_ORDER_CHUNKS, a.batch), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_lsd_bin_scan, dim3(a.batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_lsd_bin_scatter, dim3(LSD_ORDER_CHUNKS, a.batch), dim3(64), 0, s, a);
 }
 
 }  // namespace plh

@@ -14,17 +14,21 @@ constexpr int LBD_ROWS = LBD_NUM_BANDS * LBD_BAND_WIDTH;   // 63 rows of the lin
 constexpr int LSD_NBINS = 1024;
 
 // ll_angle() as a table.  The 2x2 gradient of 8-bit pixels is a pair of integers in [-510, 510], and everything
-// ll_angle() derives from it per pixel -- fastAtan2 in degrees, the float cos / sin of the double angle (seed terms) and of
-// the float angle (region increments), each a correctly rounded double sincos -- depends on that pair alone.  The table is
-// filled once per device by the same device code that used to run per pixel (180 VALU instructions, 45 of them f64), and
-// k_lsd_grad gathers one 32-byte entry per defined pixel.  Entry (gy + 510, gx + 510), row pitch 1024 entries: 33.5 MB,
-// of which natural images touch the few hundred KB around the origin (L2-resident).
+// ll_angle() and its consumers derive from it per pixel -- fastAtan2 in degrees, the float cos / sin of the double angle (seed
+// terms) and of the float angle (region increments), each a correctly rounded double sincos, and the gradient norm
+// sqrt((gx^2 + gy^2) / 4) -- depends on that pair alone.  The table is filled once per device; a pixel of the level-line
+// field is then nothing but its 20-bit table index (gy + 510) << 10 | (gx + 510) plus two flag bits -- a 4-byte record
+// instead of 16 + 8 bytes -- and the kernels gather what they need from the table, whose hot part (a frame touches
+// ~19 k of the 1.04 M entries) lives in L2.  That cut k_lsd_grow's HBM traffic, which bounded it at full residency:
+// region growing reads records at random, and 64-byte sectors that held 4 records now hold 16.
 constexpr int LSD_GRAD_MAX = 510, LSD_ANGLE_ROWS = 2 * LSD_GRAD_MAX + 1, LSD_ANGLE_PITCH_LOG2 = 10;
 struct LsdAngleEntry {
-  float angf, cs, sn, seedx;   // first 16 bytes: the LsdPix fields + cos of the double angle
-  float seedy, pad[3];
+  float angf, cs, sn, seedx;   // first 16 bytes: what a region-growing candidate needs (+ cos of the double angle)
+  float seedy, pad;
+  double modgrad;              // sqrt((gx^2 + gy^2) / 4.0): region2rect()'s weights
 };
-
+// level-line record of a pixel of the 0.8x image (u32): table index | DEF (gradient above the threshold) | USED (region growing's mark)
+constexpr uint32_t LSD_REC_IDX = 0x000fffffu, LSD_REC_DEF = 0x40000000u, LSD_REC_USED = 0x80000000u;
 // cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with a fixed map (Frame.cc:220-222) reduced to what depends on the map alone:
 // per output pixel the offset of the top-left byte of a 2 x 2 source block that lies inside the image, and the four axis
 // weights (0..32, one byte each: column 0, column 1, row 0, row 1) of that block.  A tap of the reference that falls
@@ -50,11 +54,11 @@ struct LineDeviceArgs {
   uint8_t* undist;          // remapped frames (== img when no undistortion), pitch w
   uint8_t* tmpA;            // full-res scratch plane (blur output), pitch w
   uint8_t* scaled;          // 0.8x image, pitch spitch
-  void* pix;                // LsdPix[16 B] level-line record per scaled pixel, pitch spitch (line_dev.h); q bit 31 = `used`
+  uint32_t* pix;            // level-line record per scaled pixel (LSD_REC_*), pitch spitch
   uint32_t* ordered;        // seed list (packed coordinates x | y << 16), bins descending / raster inside a bin
   uint32_t* reg;            // region point queue
   uint32_t* scr;            // scratch of the same size
-  void* seedcs;             // float2 per scaled pixel: (float)cos, (float)sin of the pixel's double angle
+  uint32_t* orderWork;      // seed ordering: per frame counts / offsets [16 chunks][1024 bins] + the 1024 bin thresholds (line_kernels.hip)
   unsigned int* qmax;       // per frame max(gx^2+gy^2) over defined pixels
   int* nOrdered;            // per frame
   float* segs;              // [frame][segCap][4]

@@ -13,8 +13,8 @@ struct alignas(16) D2 {
 };
 
 struct GrowCtx {
-  LsdPix* G;           // level-line records of the scaled image; bit 31 of .q is the region-growing `used` mark
-  const float2* S;     // per pixel (float)cos / (float)sin of the double angle: region_grow()'s seed terms
+  uint32_t* P;                 // level-line records of the scaled image (LSD_REC_*: table index | DEF | USED = region growing's mark)
+  const LsdAngleEntry* A;      // per-device table of everything a gradient determines (line_plan.h)
   uint32_t* reg;       // region queue (global memory); entries are packed coordinates x | y << 16
   uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
   uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
@@ -38,7 +38,21 @@ __device__ unsigned long long g_grow_prof[16];
 #endif
 constexpr int LSD_RING = 512;    // 2 KiB; the chain buffer T (1.5 KiB) aliases it (never live at the same time)
 constexpr int LSD_PTS = 8;      // queue points examined per step (8 points x 8 neighbours = 64 lanes)
-constexpr unsigned LSD_USED = 0x80000000u;   // `used` mark, kept in bit 31 of LsdPix::q (q = gx^2+gy^2 < 2^20)
+constexpr unsigned LSD_USED = LSD_REC_USED;   // `used` mark: bit 31 of the record word (LsdPix::q holds the record word)
+// a pixel region growing may take: defined and not used -- one signed compare on the record word
+__device__ __forceinline__ bool rec_is_candidate(unsigned rec) { return (int)rec >= (int)LSD_REC_DEF; }
+// the table values of a record (one 16-byte gather; the hot part of the table is L2-resident)
+__device__ __forceinline__ LsdPix lsd_fetch_px(const LsdAngleEntry* T, unsigned rec) {
+  const uint4 e = *reinterpret_cast<const uint4*>(T + (rec & LSD_REC_IDX));
+  LsdPix px;
+  px.angf = __uint_as_float(e.x); px.cs = __uint_as_float(e.y); px.sn = __uint_as_float(e.z); px.q = rec;
+  return px;
+}
+__device__ __forceinline__ LsdPix lsd_null_px(unsigned rec) {
+  LsdPix px;
+  px.angf = 0.f; px.cs = 0.f; px.sn = 0.f; px.q = rec;
+  return px;
+}
 
 __device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xffffu); }
 __device__ __forceinline__ int pk_y(uint32_t p) { return (int)(p >> 16); }
@@ -344,7 +358,7 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
         const unsigned slot = (unsigned)cnt + (unsigned)mbcnt64(A);   // accepted lanes below this one: v_mbcnt on the scalar mask
         c.reg[slot] = cd.npk;
         c.ring[slot & (LSD_RING - 1)] = cd.npk;
-        c.G[cd.nidx].q = cd.px.q | LSD_USED;
+        c.P[cd.nidx] = cd.px.q | LSD_USED;
       }
       accAll |= A;
       const int last = 63 - __clzll((long long)A);
@@ -415,7 +429,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   if (lane == 0) {
     c.reg[0] = seedPk;
     c.ring[0] = seedPk;
-    c.G[seed].q = seedQ | LSD_USED;
+    c.P[seed] = seedQ | LSD_USED;
   }
   PF_ADD(c, 11, 1);
   int cnt = 1, i = 0;
@@ -429,9 +443,10 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     if (!first.inb) first.nidx = 0;
     first.npk = gs.fstPk[lane];
     first.px = gs.fstPx[lane];
-    if (dirtyFst && first.inb) first.px.q = c.G[first.nidx].q;
-    // `used` is bit 31: one signed compare covers "not marked and above the gradient threshold"
-    const unsigned long long candM = wballot(first.inb) & wballot((int)first.px.q > (int)c.qThresh);
+    if (dirtyFst && first.inb) first.px.q = c.P[first.nidx];
+    // one signed compare on the record word covers "not marked and above the gradient threshold" (the table values were
+    // fetched with the neighbourhood for every DEFINED pixel, so a pixel that refine() un-marked in between has them too)
+    const unsigned long long candM = wballot(first.inb) & wballot(rec_is_candidate(first.px.q));
     lsd_resolve(c, candM, first, false, tol, sumdx, sumdy, regAngF, angValid, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
     i = 1;
@@ -444,12 +459,15 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   PLH_WAVE_SYNC();
   LsdCand cur;
   cur.inb = lsd_addr(c, i, cnt, cur.nidx, cur.npk);
-  cur.px = c.G[cur.nidx];
+  {
+    const unsigned rec = c.P[cur.nidx];
+    cur.px = rec_is_candidate(rec) ? lsd_fetch_px(c.A, rec) : lsd_null_px(rec);
+  }
   while (i < cnt) {
     const unsigned long long pt0 = PF_NOW();
     const int m = min(LSD_PTS, cnt - i);
-    // lanes with nothing to examine loaded the NOTDEF pixel (sw-1, 0), and `used` is bit 31: one signed compare decides
-    const unsigned long long candM = wballot((int)cur.px.q > (int)c.qThresh);
+    // lanes with nothing to examine loaded the NOTDEF pixel (sw-1, 0): one signed compare on the record word decides
+    const unsigned long long candM = wballot(rec_is_candidate(cur.px.q));
     const unsigned long long pt1 = PF_NOW();
     PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
     lsd_resolve(c, candM, cur, true, tol, sumdx, sumdy, regAngF, angValid, cnt);
@@ -459,7 +477,10 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     // every lane loads (record 0 when it has nothing to examine) so the carried registers are simply overwritten
     PLH_WAVE_SYNC();
     cur.inb = lsd_addr(c, i, cnt, cur.nidx, cur.npk);
-    cur.px = c.G[cur.nidx];
+    {   // the 4-byte record, then -- for candidates only -- its table values
+      const unsigned rec = c.P[cur.nidx];
+      cur.px = rec_is_candidate(rec) ? lsd_fetch_px(c.A, rec) : lsd_null_px(rec);
+    }
   }
   PF_ADD(c, 9, cnt);
   if (!angValid && cnt >= minCnt) regAngF = lsd_atan2_deg(sumdy, sumdx);   // the caller only looks at regions it keeps
@@ -508,7 +529,7 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     double w = 0, wx = 0, wy = 0;
     if (i < cnt) {
       const uint32_t p = c.reg[i];
-      w = q_modgrad(c.G[pk_lin(c, p)].q & ~LSD_USED);
+      w = c.A[c.P[pk_lin(c, p)] & LSD_REC_IDX].modgrad;
       wx = (double)pk_x(p) * w;
       wy = (double)pk_y(p) * w;
     }
@@ -527,7 +548,7 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     double a = 0, b = 0, cc = 0;
     if (i < cnt) {
       const uint32_t p = c.reg[i];
-      const double w = q_modgrad(c.G[pk_lin(c, p)].q & ~LSD_USED);
+      const double w = c.A[c.P[pk_lin(c, p)] & LSD_REC_IDX].modgrad;
       const double ddx = (double)pk_x(p) - x, ddy = (double)pk_y(p) - y;
       a = ddy * ddy * w;
       b = ddx * ddx * w;
@@ -613,7 +634,7 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
       near = !(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p)) > radSq);
       if (!near) {
         const uint32_t li = pk_lin(c, p);
-        c.G[li].q &= ~LSD_USED;
+        c.P[li] &= ~LSD_USED;
       }
     }
     K += __popcll(__ballot(near));
@@ -666,8 +687,8 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
   // only.  Marks are plain stores: a frame is owned by one wavefront, whose later loads observe its earlier stores.
   c.ring = (uint32_t*)smem;
   c.T = (double*)smem;
-  c.G = reinterpret_cast<LsdPix*>(a.pix) + (long long)b * a.scaledStride;
-  c.S = reinterpret_cast<const float2*>(a.seedcs) + (long long)b * a.scaledStride;
+  c.P = a.pix + (long long)b * a.scaledStride;
+  c.A = a.angleTab;
   c.reg = a.reg + (long long)b * a.scaledStride;
   c.scr = a.scr + (long long)b * a.scaledStride;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
@@ -684,14 +705,14 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
   if (a.batch <= 8) {
     // latency mode (a handful of frames, one lone wavefront each): every step of the walk below waits for one dependent
     // record fetch, so pull the frame's records through this XCD's L2 once, with all loads in flight, before it starts
-    const uint4* P4 = reinterpret_cast<const uint4*>(c.G);
-    const int n16 = a.spitch * a.sh;
+    const uint4* P4 = reinterpret_cast<const uint4*>(c.P);
+    const int n16 = (a.spitch * a.sh) >> 2;   // the pitch is a multiple of 64
     unsigned acc = 0;
     for (int i = lane; i < n16; i += 64 * 8) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const int j = i + 64 * k;
-        if (j < n16) acc |= P4[j].w & 0x40000000u;   // bit 30 is never set (q < 2^20 | used = bit 31)
+        if (j < n16) acc |= P4[j].w & 0x20000000u;   // bit 29 is never set (index < 2^20, DEF = bit 30, USED = bit 31)
       }
     }
     if (acc) atomicOr(a.status, 8);   // keeps the loads alive; never taken
@@ -724,17 +745,17 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
       const int si = sbase + lane;
       const uint32_t seedP = si < nOrd ? ord[si] : 0u;
       const uint32_t seedL = pk_lin(c, seedP);
-      LsdPix sPx;
-      sPx.angf = 0.f; sPx.cs = 0.f; sPx.sn = 0.f; sPx.q = LSD_USED;
-      float2 sCS;
-      sCS.x = 0.f; sCS.y = 0.f;
-      if (si < nOrd) {
-        sPx = c.G[seedL];
-        sCS = c.S[seedL];
+      unsigned sRec = LSD_USED;
+      if (si < nOrd) sRec = c.P[seedL];
+      fm = __ballot(!(sRec & LSD_USED));
+      float sAng = 0.f, sCx = 0.f, sSy = 0.f;   // seed angle, (float)cos / (float)sin of its double angle
+      if (!(sRec & LSD_USED)) {
+        const LsdAngleEntry* e = c.A + (sRec & LSD_REC_IDX);
+        const uint4 e0 = *reinterpret_cast<const uint4*>(e);
+        sAng = __uint_as_float(e0.x); sCx = __uint_as_float(e0.w); sSy = e->seedy;
       }
-      fm = __ballot(!(sPx.q & LSD_USED));
       PLH_WAVE_SYNC();
-      tabP[lane] = seedP; tabQ[lane] = sPx.q; tabA[lane] = sPx.angf; tabC[lane] = sCS.x; tabS[lane] = sCS.y;
+      tabP[lane] = seedP; tabQ[lane] = sRec; tabA[lane] = sAng; tabC[lane] = sCx; tabS[lane] = sSy;
       PLH_WAVE_SYNC();
     }
     bool dirtySeed = false, dirtyFst = false;   // a region has been grown since this scan / since fst was fetched
@@ -752,12 +773,12 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
         if (nbr == 0) batchSk[grp] = mySk;
         const uint32_t sp = tabP[mySk];
         const int xx = pk_x(sp) + ndx, yy = pk_y(sp) + ndy;
-        LsdPix px;
-        px.angf = 0.f; px.cs = 0.f; px.sn = 0.f; px.q = 0;
+        LsdPix px = lsd_null_px(0u);
         uint32_t nidx = 0xffffffffu;
         if (grp < nb && xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
-          nidx = (uint32_t)(yy * c.spitch + xx);
-          px = c.G[nidx];
+          nidx = __umul24((unsigned)yy, (unsigned)c.spitch) + (unsigned)xx;
+          const unsigned rec = c.P[nidx];
+          px = (rec & LSD_REC_DEF) ? lsd_fetch_px(c.A, rec) : lsd_null_px(rec);   // every defined pixel: a mark may be taken back by refine()
         }
         fstPx[lane] = px; fstIdx[lane] = nidx; fstPk[lane] = (uint32_t)xx | ((uint32_t)yy << 16);
         PLH_WAVE_SYNC();
@@ -770,7 +791,7 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
         unsigned seedQ = bcast_u32(tabQ[sk], 0);
         PLH_WAVE_SYNC();
         // marks may have changed since the scan / the neighbourhood prefetch: re-read them (one round trip)
-        if (dirtySeed) seedQ = c.G[seed].q;
+        if (dirtySeed) seedQ = c.P[seed];
         if (seedQ & LSD_USED) continue;   // swallowed by a region grown since the scan
         // region_grow -> region2rect -> [refine: tighter tolerance, re-grow -> region2rect -> reduce_region_radius]
         PLH_WAVE_SYNC();
@@ -803,9 +824,10 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
           if (phase == 0) {   // refine(): tolerance from the angle spread near the seed, everything un-marked
             PF_ADD(c, 15, 1);
             const uint32_t cLin = pk_lin(c, cPk);
-            const LsdPix g0 = c.G[cLin];
-            const float2 s0 = c.S[cLin];
-            const double ang_c = pix_angle(g0), width = rec[4];
+            const unsigned rec0 = c.P[cLin];
+            const LsdAngleEntry* e0 = c.A + (rec0 & LSD_REC_IDX);
+            const float ang0 = e0->angf, sx0 = e0->seedx, sy0 = e0->seedy;
+            const double ang_c = (double)ang0 * kDegToRads, width = rec[4];
             double acc = 0;
             int n = 0;
             for (int base = 0; base < cnt; base += 64) {
@@ -815,11 +837,11 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
               if (i < cnt) {
                 const uint32_t p = c.reg[i];
                 const uint32_t li = pk_lin(c, p);
-                LsdPix gp = c.G[li];
-                c.G[li].q = gp.q & ~LSD_USED;
+                const unsigned rp = c.P[li];
+                c.P[li] = rp & ~LSD_USED;
                 if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < width) {
                   flag = true;
-                  ang_d = angle_diff_signed(pix_angle(gp), ang_c);
+                  ang_d = angle_diff_signed((double)c.A[rp & LSD_REC_IDX].angf * kDegToRads, ang_c);
                 }
               }
               n += __popcll(__ballot(flag));
@@ -833,8 +855,8 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
             PLH_WAVE_SYNC();
             if (lane == 0) {   // parameters of the second region_grow()
               gs.d[0] = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-              gs.u[0] = cPk; gs.u[1] = g0.q & ~LSD_USED;
-              gs.u[2] = __float_as_uint(g0.angf); gs.u[3] = __float_as_uint(s0.x); gs.u[4] = __float_as_uint(s0.y);
+              gs.u[0] = cPk; gs.u[1] = rec0 & ~LSD_USED;
+              gs.u[2] = __float_as_uint(ang0); gs.u[3] = __float_as_uint(sx0); gs.u[4] = __float_as_uint(sy0);
             }
             phase = 1;
             __syncthreads();
