@@ -712,7 +712,15 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const int j = i + 64 * k;
-        if (j < n16) acc |= P4[j].w & 0x20000000u;   // bit 29 is never set (index < 2^20, DEF = bit 30, USED = bit 31)
+        if (j < n16) {
+          const uint4 r4 = P4[j];
+          acc |= r4.w & 0x20000000u;   // bit 29 is never set (index < 2^20, DEF = bit 30, USED = bit 31)
+          // ... and the table entries the frame's defined pixels point to (about 19 k distinct ones)
+          const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (rr[q] & LSD_REC_DEF) acc |= __float_as_uint(c.A[rr[q] & LSD_REC_IDX].pad);   // pad is 0
+        }
       }
     }
     if (acc) atomicOr(a.status, 8);   // keeps the loads alive; never taken
