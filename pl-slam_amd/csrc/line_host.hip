@@ -66,12 +66,11 @@ struct plh_line {
   int rszTP = 0, rszTR = 0;   // k_resize_u8 source tile of a 256 x 16 output block (pitch in bytes, rows)
   // device buffers
   uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dMask = nullptr;
-  uint32_t* dPix = nullptr;
-  uint32_t *dOrdered = nullptr, *dReg = nullptr, *dScr = nullptr, *dDxdy = nullptr, *dOrderWork = nullptr;
+  uint32_t *dArena = nullptr, *dDxdy = nullptr;   // dArena: per-frame blocks (line_plan.h, arenaStride)
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
   hipStream_t lastStream = nullptr;   // stream of the most recent extract call (plh_line_status waits on it)
-  float *dSegs = nullptr, *dCoef = nullptr;
+  float* dCoef = nullptr;
   RemapTap* dMap = nullptr;
   ResizeTap *dXtab = nullptr, *dYtab = nullptr;
   // staging (host-buffer entry points)
@@ -158,8 +157,8 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dPix, h->dOrdered, h->dReg, h->dScr, h->dDxdy, h->dOrderWork, h->dQmax,
-                  h->dNOrdered, h->dNSegs, h->dStatus, h->dSegs, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
+  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax,
+                  h->dNOrdered, h->dNSegs, h->dStatus, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -267,13 +266,13 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
 #define TRYHIP(x) do { if ((x) != hipSuccess) { set_error("plh_line_create: %s failed (batch %d)", #x, max_batch); plh_line_destroy(h); return PLH_ERR_ALLOC; } } while (0)
   TRYHIP(hipMalloc((void**)&h->dTmpA, B * a.fullStride));
   TRYHIP(hipMalloc((void**)&h->dScaled, B * a.scaledStride));
-  TRYHIP(hipMalloc((void**)&h->dPix, B * a.scaledStride * 4));
-  TRYHIP(hipMalloc((void**)&h->dOrdered, B * a.scaledStride * 4));
-  TRYHIP(hipMalloc((void**)&h->dReg, B * a.scaledStride * 4));
-  TRYHIP(hipMalloc((void**)&h->dScr, B * a.scaledStride * 4));
-  TRYHIP(hipMalloc((void**)&h->dOrderWork, B * lsd_order_work_u32() * 4));
+  // per-frame block, hot parts first: segments | region queue | level-line records | seed list | scratch | ordering counters
+  const long long offSegs = 0, offReg = align_up<long long>((long long)a.segCap * 4, 64), offPix = offReg + a.scaledStride,
+                  offOrd = offPix + a.scaledStride, offScr = offOrd + a.scaledStride, offWork = offScr + a.scaledStride,
+                  blockWords = offWork + (long long)lsd_order_work_u32();
+  a.arenaStride = align_up<long long>(blockWords, blockWords >= (1 << 18) ? (1 << 19) : (1 << 14));   // 2 MiB (64 KiB for small frames)
+  TRYHIP(hipMalloc((void**)&h->dArena, B * (size_t)a.arenaStride * 4));
   TRYHIP(hipMalloc((void**)&h->dDxdy, B * a.fullStride * 4));
-  TRYHIP(hipMalloc((void**)&h->dSegs, B * a.segCap * 16));
   TRYHIP(hipMalloc((void**)&h->dQmax, B * 4));
   TRYHIP(hipMalloc((void**)&h->dNOrdered, B * 4));
   TRYHIP(hipMalloc((void**)&h->dNSegs, B * 4));
@@ -294,14 +293,15 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
     return PLH_ERR_ALLOC;
   }
   a.angleTab = h->a.angleTab;
-  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dPix; a.ordered = h->dOrdered; a.reg = h->dReg; a.scr = h->dScr; a.orderWork = h->dOrderWork;
-  a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = h->dSegs; a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dArena + offPix; a.ordered = h->dArena + offOrd; a.reg = h->dArena + offReg; a.scr = h->dArena + offScr; a.orderWork = h->dArena + offWork;
+  a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = reinterpret_cast<float*>(h->dArena + offSegs); a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
   *out = h;
   return PLH_OK;
 }
 
 int plh_line_capacity(const plh_line* h) { return h ? h->a.outCap : 0; }
+
 
 plh_status plh_line_set_undistort(plh_line* h, const float K[4], const float D[5]) {
   if (!h || !K) return PLH_ERR_INVALID;
@@ -497,7 +497,7 @@ plh_status plh_line_read_segments(plh_line* h, int b, float* out_xyxy, int cap, 
   *n_out = n;
   const int m = std::min(n, std::min(cap, h->a.segCap));
   if (out_xyxy && m > 0)
-    PLH_HIP(hipMemcpy(out_xyxy, h->dSegs + (size_t)b * h->a.segCap * 4, (size_t)m * 16, hipMemcpyDeviceToHost));
+    PLH_HIP(hipMemcpy(out_xyxy, h->a.segs + (size_t)b * h->a.arenaStride, (size_t)m * 16, hipMemcpyDeviceToHost));
   return PLH_OK;
 }
 

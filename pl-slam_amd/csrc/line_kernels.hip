@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
       rec[k] = def ? ((uint32_t)(((gy + LSD_GRAD_MAX) << LSD_ANGLE_PITCH_LOG2) + gx + LSD_GRAD_MAX) | LSD_REC_DEF) : 0u;
       if (def) qmax = max(qmax, q);
     }
-    uint32_t* o = a.pix + (long long)b * a.scaledStride + (__mul24(y, a.spitch) + x4);   // pitch is a multiple of 64: 16-byte aligned
+    uint32_t* o = a.pix + (long long)b * a.arenaStride + (__mul24(y, a.spitch) + x4);   // pitch is a multiple of 64: 16-byte aligned
     uint4 o4;
     o4.x = rec[0]; o4.y = rec[1]; o4.z = rec[2]; o4.w = rec[3];
     *reinterpret_cast<uint4*>(o) = o4;
@@ -386,7 +386,7 @@ __device__ __forceinline__ double lsd_bin_coef(unsigned qmax) {
 
 __global__ void __launch_bounds__(256) k_lsd_bin_thresholds(LineDeviceArgs a) {
   const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;   // bin
-  uint32_t* binLo = a.orderWork + (long long)b * LSD_ORDER_WORK + LSD_ORDER_CHUNKS * LSD_NBINS;
+  uint32_t* binLo = a.orderWork + (long long)b * a.arenaStride + LSD_ORDER_CHUNKS * LSD_NBINS;
   const double bin_coef = lsd_bin_coef(a.qmax[b]);
   auto exact_bin = [&](unsigned q) -> int { return (int)(q_modgrad(q) * bin_coef); };
   unsigned t = k > 0 ? 0xffffffffu : 0u;   // no defined pixel (bin_coef == 0): everything is bin 0
@@ -405,9 +405,9 @@ __global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
   __shared__ unsigned binLo[LSD_NBINS + 8];
   __shared__ int hist[LSD_NBINS];
   const int wv = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  const uint32_t* Q = a.pix + (long long)b * a.scaledStride;      // level-line records (k_lsd_grad)
-  uint32_t* BIN = a.reg + (long long)b * a.scaledStride;          // bin + 1 per pixel, 0 = NOTDEF (scratch)
-  uint32_t* work = a.orderWork + (long long)b * LSD_ORDER_WORK;
+  const uint32_t* Q = a.pix + (long long)b * a.arenaStride;      // level-line records (k_lsd_grad)
+  uint32_t* BIN = a.reg + (long long)b * a.arenaStride;          // bin + 1 per pixel, 0 = NOTDEF (scratch)
+  uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
   const int npix = a.spitch * a.sh;
   const int chunk = lsd_order_chunk(npix);
   const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
 __global__ void __launch_bounds__(256) k_lsd_bin_scan(LineDeviceArgs a) {
   __shared__ int part[256];
   const int b = blockIdx.x, tid = threadIdx.x;
-  uint32_t* work = a.orderWork + (long long)b * LSD_ORDER_WORK;
+  uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
   const int bin0 = LSD_NBINS - 4 - 4 * tid;   // lowest of the thread's four bins
   uint4 cnt[LSD_ORDER_CHUNKS];
   int tot = 0;
@@ -484,9 +484,9 @@ __global__ void __launch_bounds__(256) k_lsd_bin_scan(LineDeviceArgs a) {
 __global__ void __launch_bounds__(64) k_lsd_bin_scatter(LineDeviceArgs a) {
   __shared__ int cur[LSD_NBINS];   // next list position of every bin for this chunk
   const int wv = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  const uint32_t* BIN = a.reg + (long long)b * a.scaledStride;
-  uint32_t* ord = a.ordered + (long long)b * a.scaledStride;
-  const uint32_t* work = a.orderWork + (long long)b * LSD_ORDER_WORK;
+  const uint32_t* BIN = a.reg + (long long)b * a.arenaStride;
+  uint32_t* ord = a.ordered + (long long)b * a.arenaStride;
+  const uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
   const int npix = a.spitch * a.sh;
   const int chunk = lsd_order_chunk(npix);
   const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);

@@ -47,6 +47,12 @@ struct LineDeviceArgs {
   // per-frame strides (elements)
   long long fullStride;     // w*h rounded up (u8 planes at full resolution)
   long long scaledStride;   // spitch*sh rounded up
+  // The per-frame working set of the sequential stages (segment list, region queue, level-line records, seed list, scratch,
+  // ordering counters) is ONE contiguous block per frame, blocks `arenaStride` 4-byte words apart and 2 MiB aligned: a
+  // region-growing wavefront then touches one or two translation fragments instead of six (at full residency 4.4 % of
+  // k_lsd_grow's L1 requests missed the L1 TLB with one array per buffer).  pix / reg / ordered / scr / orderWork / segs
+  // below point at frame 0's part of the block; frame b's is + b * arenaStride words.
+  long long arenaStride;
   // inputs / intermediates (frame-major)
   const uint8_t* img;       // caller's frames (pitch = w)
   long long imgStride;

@@ -687,14 +687,14 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
   // only.  Marks are plain stores: a frame is owned by one wavefront, whose later loads observe its earlier stores.
   c.ring = (uint32_t*)smem;
   c.T = (double*)smem;
-  c.P = a.pix + (long long)b * a.scaledStride;
+  c.P = a.pix + (long long)b * a.arenaStride;
   c.A = a.angleTab;
-  c.reg = a.reg + (long long)b * a.scaledStride;
-  c.scr = a.scr + (long long)b * a.scaledStride;
+  c.reg = a.reg + (long long)b * a.arenaStride;
+  c.scr = a.scr + (long long)b * a.arenaStride;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
-  const uint32_t* ord = a.ordered + (long long)b * a.scaledStride;   // packed coordinates x | y << 16
-  float* segs = a.segs + (long long)b * a.segCap * 4;
+  const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;   // packed coordinates x | y << 16
+  float* segs = a.segs + (long long)b * a.arenaStride;
 #if defined(PLH_GROW_PROF)
   unsigned long long pfv[16];
   for (int i = 0; i < 16; i++) pfv[i] = 0;
@@ -939,8 +939,8 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
   __shared__ int s_valid, s_keep;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = min(a.nSegs[b], a.segCap);
-  const float* segs = a.segs + (long long)b * a.segCap * 4;
-  unsigned long long* keys = (unsigned long long*)(a.reg + (long long)b * a.scaledStride);   // scratch (free after k_lsd_grow)
+  const float* segs = a.segs + (long long)b * a.arenaStride;
+  unsigned long long* keys = (unsigned long long*)(a.reg + (long long)b * a.arenaStride);   // scratch (free after k_lsd_grow)
   if (tid == 0) s_valid = 0;
   __syncthreads();
   int myValid = 0;
