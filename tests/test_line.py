@@ -101,10 +101,13 @@ def test_oracle_lbd_determinism_and_norm(oracle, synth):
 
 # ------------------------------------------------------------------ HIP sources under hipemu (CPU)
 @pytest.mark.parametrize("seed,rows,cols,nf,minlen,undist", [(7, 120, 160, 50, 0.0, False), (8, 120, 160, 20, 15.0, False),
-                                                            (10, 120, 160, 50, 0.0, True), (11, 118, 203, 40, 0.0, False)])
+                                                            (10, 120, 160, 50, 0.0, True), (11, 118, 203, 40, 0.0, False),
+                                                            (12, 120, 160, 40, 0.0, "outside")])
 def test_emu_line_extract(plslam, oracle, synth, emu_lib, seed, rows, cols, nf, minlen, undist):
     img = synth.make_frame(seed, rows, cols, n_rect=40, n_line=20)
     K, D = ([150.0, 150.0, 80.0, 60.0], TUM1_D) if undist else (None, None)
+    if undist == "outside":   # principal point off the image: the map leaves the frame on two sides (taps outside read 0, per axis)
+        K, D = [150.0, 150.0, 20.0, 95.0], [0.4, -0.9, 0.01, -0.008, 1.1]
     rk, rd, rf, rs = _oracle_line(oracle, img, nf, minlen, K, D)
     ex = plslam.LINEextractor(1, 1.2, nf, minlen, rows=rows, cols=cols, max_batch=1, lib=emu_lib, K=K, D=D)
     kl, desc, fn = ex(img)
@@ -130,10 +133,13 @@ def test_emu_line_edge_cases(plslam, emu_lib):
 # ------------------------------------------------------------------ GPU parity
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,rows,cols,nf,minlen,undist", [(1, 480, 640, 200, 0.0, False), (2, 480, 640, 200, 20.0, True),
-                                                            (1000, 376, 1241, 200, 0.0, False), (5, 480, 640, 50, 0.0, False)])
+                                                            (1000, 376, 1241, 200, 0.0, False), (5, 480, 640, 50, 0.0, False),
+                                                            (6, 240, 320, 100, 0.0, "outside")])
 def test_gpu_line_extract(plslam, oracle, synth, seed, rows, cols, nf, minlen, undist):
     img = synth.make_frame(seed, rows, cols)
     K, D = (TUM1_K, TUM1_D) if undist else (None, None)
+    if undist == "outside":   # principal point off the image: a fifth of the map leaves the frame
+        K, D = [300.0, 300.0, 40.0, 190.0], [0.4, -0.9, 0.01, -0.008, 1.1]
     rk, rd, rf, rs = _oracle_line(oracle, img, nf, minlen, K, D)
     ex = plslam.LINEextractor(1, 1.2, nf, minlen, rows=rows, cols=cols, max_batch=1, K=K, D=D)
     kl, desc, fn = ex(img)
