@@ -4,7 +4,7 @@
 //   k_blur7_u8      8-bit separable Gaussian (Q8, REFLECT_101), 5 or 7 taps     LSD internal 7x7 s=0.75; LBD 5x5 s=1
 //   k_resize_u8     cv::resize(INTER_LINEAR) fixed point                        LSD internal 0.8x
 //   k_lsd_grad      ll_angle(): 2x2 gradient, NOTDEF threshold, max gradient    SURVEY.md B.7
-//   k_lsd_order     ll_angle(): 1024-bin pseudo-ordering of seeds (stable)      SURVEY.md B.7 / 8c pin (6)
+//   k_lsd_bin_*     ll_angle(): 1024-bin pseudo-ordering of seeds (stable)      SURVEY.md B.7 / 8c pin (6)
 //   k_lsd_grow      flsd(): region_grow / region2rect / refine / reduce_region_radius
 //   k_keylines      LSDDetector::detectImpl KeyLine fill + mask; LINEextractor sort/keep/class_id/line equation
 //                                                                              LSDDetector_custom.cpp:162-213, LineExtractor.cpp:43-90

@@ -402,12 +402,13 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint3
 }
 
 // region_grow(): BFS over reg[] used as a queue, 8 queued points (64 neighbour lanes) per step; each lane fetches
-// its neighbour's 16-byte level-line record (angle, cos, sin, q | used mark) with one load, issued right after the
-// previous step's marks.  (A frontier wider than 8 points is rare -- 7 % of the steps -- so prefetching across steps
+// its neighbour's 4-byte level-line record (table index | DEF | used mark), issued right after the previous step's
+// marks, and -- if the pixel is a candidate -- its (angle, cos, sin) from the gradient table.  (A frontier wider than 8 points is rare -- 7 % of the steps -- so prefetching across steps
 // costs more instructions than it hides; latency is hidden by the other resident frames.)  `first` holds the seed's
 // 8 neighbours prefetched in lane group `firstGrp` (firstGrp < 0: not prefetched).
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
-// reference's float fastAtan2 result).  All lanes hold identical (uniform) state.
+// reference's float fastAtan2 result; evaluated only if the region has at least minCnt pixels).  All lanes hold identical
+// (uniform) state.
 __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, int firstGrp, bool dirtyFst,
                                                int minCnt, float* regAngOut) {
   const int lane = c.lane, g = lane >> 3;
@@ -671,7 +672,15 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
 }
 
 // flsd(): one wavefront per frame, seeds in pseudo-order, sequential semantics.
-#if defined(PLH_GROW_WAVES)   // experiment switch: cap the VGPR budget for PLH_GROW_WAVES wavefronts per SIMD
+// VGPR budget: 64 registers = 8 wavefronts per SIMD.  The kernel needs 74 (6 per SIMD); capped at 64 the compiler spills six
+// values that live across region_grow() calls (a few scratch accesses per call, none inside the step loop), and the two extra
+// wave slots -- for more frames or for the dense kernels of the other sub-batches -- are worth 3 - 4 % on the whole front end
+// (profiles/r02_waves_per_simd.txt; at the start of round 2, with 30 % more instructions everywhere else, they were worth nothing).
+// -DPLH_GROW_WAVES=0 builds the spill-free 74-register version.
+#ifndef PLH_GROW_WAVES
+#define PLH_GROW_WAVES 8
+#endif
+#if PLH_GROW_WAVES > 0
 #define PLH_GROW_ATTR __attribute__((amdgpu_waves_per_eu(PLH_GROW_WAVES)))
 #else
 #define PLH_GROW_ATTR
