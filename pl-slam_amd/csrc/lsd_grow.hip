@@ -685,8 +685,7 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
 #else
 #define PLH_GROW_ATTR
 #endif
-__global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a) {
-  HIP_DYNAMIC_SHARED(unsigned char, smem)
+__device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned char* smem) {
   const int b = blockIdx.x, lane = threadIdx.x;
   GrowCtx c;
   // LDS: the 2 KiB ring only.  T aliases it: the ring is only live inside lsd_region_grow (which restarts it), T only
@@ -939,6 +938,18 @@ __device__ __forceinline__ void clamp_extremes(float e[4], int w, int h) {   // 
 __device__ __forceinline__ float seg_length(const float e[4]) {
   const double dxx = (double)(e[0] - e[2]), dyy = (double)(e[1] - e[3]);
   return (float)sqrt(dxx * dxx + dyy * dyy);
+}
+
+// Two builds of the same body: k_lsd_grow with the 64-register budget for batches (residency is what counts), and
+// k_lsd_grow_lone without the cap (74 registers, no spills) for a handful of frames, where a lone wavefront per frame runs at
+// the latency of its own instruction stream.
+__global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  lsd_grow_frame(a, smem);
+}
+__global__ void __launch_bounds__(64) k_lsd_grow_lone(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  lsd_grow_frame(a, smem);
 }
 
 __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
@@ -1330,7 +1341,8 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
 size_t lsd_grow_lds_bytes(int spitch, int sh);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
   const size_t lds = lsd_grow_lds_bytes(a.spitch, a.sh);
-  hipLaunchKernelGGL(k_lsd_grow, dim3(a.batch), dim3(64), lds, s, a);
+  if (a.batch <= 8) hipLaunchKernelGGL(k_lsd_grow_lone, dim3(a.batch), dim3(64), lds, s, a);
+  else hipLaunchKernelGGL(k_lsd_grow, dim3(a.batch), dim3(64), lds, s, a);
 }
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s) {
   hipLaunchKernelGGL(k_keylines, dim3(a.batch), dim3(256), (size_t)a.outCap * 8 + 64, s, a, kl, fn, n);
