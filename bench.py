@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=6144, help="frames per GPU per step (6 k_lsd_grow wavefronts per SIMD = 6144 resident frames)")
+    ap.add_argument("--batch", type=int, default=6144, help="frames per GPU per step (6144 = 6 k_lsd_grow wavefronts per SIMD; the kernel is built for up to 8)")
     ap.add_argument("--nsplit", type=int, default=4, help="sub-batches pipelined against each other (pl-slam_amd/pipeline.py)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)

@@ -21,6 +21,8 @@ s=d.get('secondary',{}); print('secondary', s.get('value'), s.get('configs4_shar
 print('cpu', d.get('cpu_baseline',{}).get('value'))
 PY
 tail -4 gpurun_out/bench_full.log | grep real
+echo "== bench --force-dist (1-rank RCCL rehearsal of the N > 1 path)"
+timeout 600 python bench.py --force-dist --no-cpu-baseline --no-extras --steps 8 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d.get('rccl'))" 2>&1 | cut -c1-300
 echo "== rocprof kernel stats of bench.py (5 steps)"
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof_final" -o full -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-extras > "$OLDPWD/gpurun_out/rocprof_final.log" 2>&1
 cd "$OLDPWD"
