@@ -199,18 +199,17 @@ __device__ __forceinline__ float lsd_atan2_deg(float y, float x) {
 // acc = the lanes walked, canc = the duplicates dropped (possibly with lanes outside the candidate set: only ever used
 // masked).  Hand-scheduled because it runs once per accepted pixel (130 k times per frame) and the per-lane updates are
 // cheapest under EXEC = "lanes behind k", which the scalar unit produces in one instruction (s_lshl_b64 exec, -2, k): the
-// compare then needs no mask and the adds no selects -- 6 VALU + 8 SALU instructions per pixel where the compiled form had
-// 8 + 9.  Wait states (gfx940 family: an SGPR written by v_readlane may be read by a VALU instruction no sooner than the
+// compare then needs no mask and the adds no selects -- 6 VALU + 6 SALU instructions per pixel where the compiled form had
+// 8 + 9 (the set of walked lanes is P & ~canc afterwards; the loop branches on the SCC of its last mask update).  Wait states (gfx940 family: an SGPR written by v_readlane may be read by a VALU instruction no sooner than the
 // third instruction after it) are kept by the order of the instructions.
 __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P, bool mayDup, uint32_t nidx, float cs, float sn,
                                          float& preX, float& preY, unsigned long long& accOut,
                                          unsigned long long& cancOut) {
-  unsigned long long m = P, acc = 0, canc = 0;
+  unsigned long long m = P, canc = 0;
 #if defined(HIPEMU)
   while (m) {
     const int k = __ffsll((long long)m) - 1;
     m &= ~(1ull << k);
-    acc |= 1ull << k;
     const unsigned long long above = ~1ull << k;
     if (mayDup) {
       const unsigned long long dup = wballot(nidx == bcast_u32(nidx, k)) & above;
@@ -231,7 +230,6 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
         "lsdwalk%=:\n\t"
         "s_ff1_i32_b64 %[k], %[m]\n\t"
         "s_bitset0_b64 %[m], %[k]\n\t"
-        "s_bitset1_b64 %[acc], %[k]\n\t"
         "v_readlane_b32 %[t0], %[nidx], %[k]\n\t"
         "v_readlane_b32 %[t1], %[cs], %[k]\n\t"
         "v_readlane_b32 %[t2], %[sn], %[k]\n\t"
@@ -239,12 +237,11 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
         "v_cmp_eq_u32_e32 vcc, %[t0], %[nidx]\n\t"
         "v_add_f32_e32 %[px], %[t1], %[px]\n\t"
         "v_add_f32_e32 %[py], %[t2], %[py]\n\t"
-        "s_andn2_b64 %[m], %[m], vcc\n\t"
         "s_or_b64 %[canc], %[canc], vcc\n\t"
-        "s_cmp_lg_u64 %[m], 0\n\t"
+        "s_andn2_b64 %[m], %[m], vcc\n\t"      // SCC = lanes left to walk
         "s_cbranch_scc1 lsdwalk%=\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [m] "+s"(m), [acc] "+s"(acc), [canc] "+s"(canc), [px] "+v"(preX), [py] "+v"(preY), [k] "=&s"(k),
+        : [m] "+s"(m), [canc] "+s"(canc), [px] "+v"(preX), [py] "+v"(preY), [k] "=&s"(k),
           [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(saved)
         : [nidx] "v"(nidx), [cs] "v"(cs), [sn] "v"(sn)
         : "vcc", "scc");
@@ -254,7 +251,6 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
         "lsdwalk%=:\n\t"
         "s_ff1_i32_b64 %[k], %[m]\n\t"
         "s_bitset0_b64 %[m], %[k]\n\t"
-        "s_bitset1_b64 %[acc], %[k]\n\t"
         "v_readlane_b32 %[t1], %[cs], %[k]\n\t"
         "v_readlane_b32 %[t2], %[sn], %[k]\n\t"
         "s_lshl_b64 exec, -2, %[k]\n\t"
@@ -263,13 +259,13 @@ __device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P,
         "v_add_f32_e32 %[py], %[t2], %[py]\n\t"
         "s_cbranch_scc1 lsdwalk%=\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [m] "+s"(m), [acc] "+s"(acc), [px] "+v"(preX), [py] "+v"(preY), [k] "=&s"(k), [t1] "=&s"(t1),
+        : [m] "+s"(m), [px] "+v"(preX), [py] "+v"(preY), [k] "=&s"(k), [t1] "=&s"(t1),
           [t2] "=&s"(t2), [sv] "=&s"(saved)
         : [cs] "v"(cs), [sn] "v"(sn)
         : "scc");
   }
 #endif
-  accOut = acc;
+  accOut = P & ~canc;   // the lanes walked: predicted, and not cancelled by an earlier walked lane
   cancOut = canc;
 }
 
