@@ -387,6 +387,14 @@ def main():
 
         r_dom = roof(dom, per_ms_timed[dom], "HIP events on the launch stream over the timed region")
         r_dom["ms_per_launch_alone"] = round(per_ms[dom], 4)
+        if per_ms[dom] > 0:
+            r_dom["frac_alone"] = round(alg[dom] * Bp / (per_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        # `frac` divides ONE launch's bytes by that launch's duration, and the launches of the sub-batches are resident together
+        # (each the slower for it): the kernel's bytes over the whole step against the step time is the rate the chip sustains
+        r_dom["all_launches_of_a_step"] = {
+            "launches": args.nsplit, "achieved": round(alg[dom] * B / (dt / args.steps) / 1e9, 1), "unit": "GB/s",
+            "frac": round(alg[dom] * B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "what": "algorithmic bytes of the dominant kernel over a whole step / ms_per_step (lower bound of its share of the step)"}
         r_fast = roof(1, per_ms[1], "HIP events, extra pass after the timed region with both halves on one stream")
         if "k_fast_strips" in insts and per_ms[1] > 0:
             # the bound this kernel actually runs against: VALU issue: wave64 VALU instructions per second against
