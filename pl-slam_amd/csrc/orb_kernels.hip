@@ -959,11 +959,12 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
                                                      int cap) {
   constexpr int PR = 21, PW = 43, PP = 48;   // patch radius / width / pitch (pitch 48 = 12 dwords)
   constexpr int BR = 18, BW = 37, BP = 40;   // blurred radius / width / pitch of the transposed blurred tile
-  constexpr int HP = 48;                     // pitch (in u16) of the transposed row sums: rows 0..42 + the over-read of the last group
+  constexpr int HP = 50;                     // pitch (in u16) of the transposed row sums: rows 0..42 + the over-read of the last group (up to row 45);
+                                             // 25 dwords: the ten column groups of a horizontal-pass store then fall into different LDS banks (24: one)
   // 7x7 sigma = 2 Gaussian in Q8 (ORB_GAUSS7_Q8, which the host checks against its own float evaluation at create time)
   constexpr unsigned G0 = ORB_GAUSS7_Q8[0], G1 = ORB_GAUSS7_Q8[1], G2 = ORB_GAUSS7_Q8[2], G3 = ORB_GAUSS7_Q8[3];
   __shared__ unsigned patchW[(PW * PP + 16) / 4];
-  __shared__ unsigned short hT[40 * HP];
+  __shared__ __attribute__((aligned(16))) unsigned short hT[40 * HP];
   __shared__ unsigned blurW[BW * BP / 4];
   uint8_t* const patchBuf = reinterpret_cast<uint8_t*>(patchW);
   const uint8_t* const blurT = reinterpret_cast<const uint8_t*>(blurW);
