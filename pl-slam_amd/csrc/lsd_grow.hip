@@ -1171,6 +1171,7 @@ __device__ __forceinline__ int lbd_coord_wide(float v, int hi) {   // images fro
   return tc < 0 ? 0 : (tc > hi ? hi : tc);
 }
 
+constexpr int LBD_TILE_PITCH = 20;   // dwords per row of the offset / value tile: 16 samples + pad (rows stay 16-byte aligned)
 __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline* kls, const int* nOut, const float* coef,
                                             uint8_t* desc) {
   __shared__ float rows[4][64];                  // per support-region row: pL nL pO nO (after the global Gaussian)
@@ -1216,34 +1217,74 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
       if (PLH_INV_BALLOT(stepMask)) { sCorX0 -= dL1; sCorY0 += dL0; }
     }
     float sCorX = sCorX0, sCorY = sCorY0;
-    // the walk's addresses do not depend on the data: 8 gathers are issued together, then accumulated in walk order
-    // (coordinates and sums advance by the same float additions, in the same order, as the one-pixel-at-a-time loop).
     // A sum only ever grows by positive terms, so "if (g > 0) p += g; else n -= g;" is p += max(g, 0); n += max(-g, 0):
     // adding +0 changes nothing (the sums start at +0 and stay non-negative).
-    for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
-      uint32_t g[8];
+    auto accumulate = [&](uint32_t gv) {
+      const float dx = (float)g_x(gv), dy = (float)g_y(gv);
+      const float gDL = dx * dL0 + dy * dL1;
+      const float gDO = dx * dO0 + dy * dO1;
+      pL += fmaxf(gDL, 0.f);
+      nL += fmaxf(-gDL, 0.f);
+      pO += fmaxf(gDO, 0.f);
+      nO += fmaxf(-gDO, 0.f);
+    };
+    auto next_offset = [&]() -> uint32_t {   // the current sample's linear offset; advances the walk by one float step
+      const int xCor = wide ? lbd_coord_wide(sCorX, imageWidth) : lbd_coord(sCorX, imageWidth);
+      const int yCor = wide ? lbd_coord_wide(sCorY, imageHeight) : lbd_coord(sCorY, imageHeight);
+      sCorX += dL0;
+      sCorY += dL1;
+      return (uint32_t)(__mul24(yCor, a.w) + xCor);   // 32-bit offset: the 64-bit multiply-add of a long long index is a quarter-rate instruction
+    };
+    if (fabsf(dL0) <= fabsf(dL1)) {
+      // Steep line: the 63 rows of one walk step are neighbours along an image row, a gather touches a few cache lines.  The
+      // walk's addresses do not depend on the data: 8 gathers are issued together, then accumulated in walk order (coordinates
+      // and sums advance by the same float additions, in the same order, as the one-pixel-at-a-time loop).
+      for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
+        uint32_t g[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        g[k] = 0;
-        if (w0 + k < lengthOfLSP) {
-          const int xCor = wide ? lbd_coord_wide(sCorX, imageWidth) : lbd_coord(sCorX, imageWidth);
-          const int yCor = wide ? lbd_coord_wide(sCorY, imageHeight) : lbd_coord(sCorY, imageHeight);
-          g[k] = D[__mul24(yCor, a.w) + xCor];   // 32-bit offset: the 64-bit multiply-add of a long long index is a quarter-rate instruction
-          sCorX += dL0;
-          sCorY += dL1;
+        for (int k = 0; k < 8; k++) {
+          g[k] = 0;
+          if (w0 + k < lengthOfLSP) g[k] = D[next_offset()];
         }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (w0 + k < lengthOfLSP) accumulate(g[k]);
       }
+    } else {
+      // Flat line: the 63 rows of one walk step lie in 63 different image rows -- 63 cache lines per gather, and the kernel ran
+      // at the rate the texture-address unit walks them (2.8 ms per 1536 frames for 0.5 M VALU instructions per frame).  So
+      // the gathers run ALONG the line instead: every row lane writes the offsets of its next 16 samples to an LDS tile, the
+      // wavefront re-reads the tile as 4 rows x 16 consecutive samples per instruction (consecutive samples of a flat line are
+      // neighbours in an image row), gathers, writes the values back in place, and every row lane then accumulates its 16
+      // values in walk order -- same coordinates, same float sums, a tenth of the cache lines per gather.
+      __shared__ __attribute__((aligned(16))) uint32_t tile[64 * LBD_TILE_PITCH];
+      const int gr = lane >> 4, gj = lane & 15;
+      for (int w0 = 0; w0 < lengthOfLSP; w0 += 16) {
+        uint32_t o[16];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        if (w0 + k < lengthOfLSP) {
-          const float dx = (float)g_x(g[k]), dy = (float)g_y(g[k]);
-          const float gDL = dx * dL0 + dy * dL1;
-          const float gDO = dx * dO0 + dy * dO1;
-          pL += fmaxf(gDL, 0.f);
-          nL += fmaxf(-gDL, 0.f);
-          pO += fmaxf(gDO, 0.f);
-          nO += fmaxf(-gDO, 0.f);
+        for (int k = 0; k < 16; k++) {
+          o[k] = 0;   // beyond the line: any valid address, the value is not accumulated
+          if (w0 + k < lengthOfLSP) o[k] = next_offset();
         }
+        uint4* trow = reinterpret_cast<uint4*>(tile + lane * LBD_TILE_PITCH);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { uint4 v; v.x = o[4 * q]; v.y = o[4 * q + 1]; v.z = o[4 * q + 2]; v.w = o[4 * q + 3]; trow[q] = v; }
+        __syncthreads();
+        uint32_t gv[16];
+#pragma unroll
+        for (int rb = 0; rb < 16; rb++) gv[rb] = D[tile[(4 * rb + gr) * LBD_TILE_PITCH + gj]];
+#pragma unroll
+        for (int rb = 0; rb < 16; rb++) tile[(4 * rb + gr) * LBD_TILE_PITCH + gj] = gv[rb];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint4 v = trow[q];
+          if (w0 + 4 * q < lengthOfLSP) accumulate(v.x);
+          if (w0 + 4 * q + 1 < lengthOfLSP) accumulate(v.y);
+          if (w0 + 4 * q + 2 < lengthOfLSP) accumulate(v.z);
+          if (w0 + 4 * q + 3 < lengthOfLSP) accumulate(v.w);
+        }
+        __syncthreads();
       }
     }
     const float cg = coef[21 + min(lane, LBD_ROWS - 1)];
