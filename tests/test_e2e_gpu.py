@@ -152,3 +152,42 @@ def test_partial_batches_and_blank_frames(plslam, oracle, synth):
         assert n_h[1] == 0 and nl_h[1] == 0 and (nb <= 4 or (n_h[4] == 0 and nl_h[4] == 0))
     orb.close()
     le.close()
+
+
+def test_full_residency_replicas_are_identical(plslam, oracle, synth):
+    """BASELINE's bench size (6144 resident frames, 4 pipelined sub-batches, consecutive steps not joined) through a
+    size-independent property: the batch is 384 copies of 16 distinct frames, so every copy must come out bit-identical to the
+    first one -- for every record the front end produces -- whatever wavefront slot, sub-batch or memory block it ran in; and the
+    first copies equal the oracle.  Exercises the batch build of k_lsd_grow (64 registers, 8 wavefronts per SIMD) at full
+    residency and the per-frame arena at its largest."""
+    import torch
+    V = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    PL = _util._load("plslam_amd_pipeline", os.path.join(_util.ROOT, "pl-slam_amd", "pipeline.py"))
+    B, ns, U = 6144, 4, 16
+    base = synth.make_frames(530, U, 480, 640)
+    d = torch.from_numpy(base).cuda().repeat(B // U, 1, 1).contiguous()
+    voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=synth)
+    fp = PL.FrontEndPipelined(plslam, voc, B, 480, 640, 1000, 8, 200, 0.0, TUM1_K, TUM1_D, nsplit=ns)
+    for _ in range(2):
+        fp.step(d, join=False)
+    r = fp.results()
+    fp.close()
+    n, nl = r["n"], r["nl"]
+    assert (n.reshape(-1, U) == n[:U]).all() and (nl.reshape(-1, U) == nl[:U]).all()
+    assert (r["nm_orb"].reshape(-1, U) == r["nm_orb"][:U]).all() and (r["nm_line"].reshape(-1, U) == r["nm_line"][:U]).all()
+    for key, cnt in (("desc", n), ("nid", n), ("word", n), ("ldesc", nl), ("lfn", nl), ("m_line", nl)):
+        a = r[key].reshape((B // U, U) + r[key].shape[1:])
+        for u in range(U):
+            assert np.array_equal(a[:, u, :cnt[u]], np.broadcast_to(a[0, u, :cnt[u]], a[:, u, :cnt[u]].shape), equal_nan=True), (key, u)
+    for key, cnt in (("kps", n), ("kl", nl)):
+        a = r[key].reshape(B // U, U, -1)
+        for u in range(U):
+            for f in a.dtype.names:
+                assert (a[:, u, :cnt[u]][f] == a[0, u, :cnt[u]][f]).all(), (key, f, u)
+    ref = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    for u in (0, 7):                                       # ... and the first copies are the oracle's
+        rk, rd = ref.extract(base[u])
+        assert n[u] == len(rk) and (r["desc"][u, :n[u]] == rd).all()
+        lk, ldr, lfr, _ = _oracle_line(oracle, base[u], 200, 0.0, TUM1_K, TUM1_D)
+        assert nl[u] == len(lk) and (r["ldesc"][u, :nl[u]] == ldr).all()
+
