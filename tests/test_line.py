@@ -117,6 +117,41 @@ def test_emu_line_extract(plslam, oracle, synth, emu_lib, seed, rows, cols, nf, 
     assert _exact(kl, desc, fn, rk, rd, rf)
 
 
+def _sawtooth(rows, cols, period=40, slope=6):
+    """Ramps of constant gradient: every tooth is ONE region of period x rows aligned pixels -- thousands of queue entries, far
+    beyond the 512-entry LDS mirror of the region queue (the k_lsd_grow paths that read the queue back from global memory),
+    with a wide rectangle behind it."""
+    x = np.arange(cols)
+    row = ((x % period) * slope + 8).astype(np.uint8)
+    img = np.repeat(row[None, :], rows, axis=0).copy()
+    img[::7, ::5] += 1                                     # a little texture so that not every pixel ties
+    return img
+
+
+def test_emu_line_large_regions(plslam, oracle, emu_lib):
+    img = _sawtooth(120, 200)
+    rk, rd, rf, rs = _oracle_line(oracle, img, 50, 0.0)
+    ex = plslam.LINEextractor(1, 1.2, 50, 0.0, rows=120, cols=200, max_batch=1, lib=emu_lib)
+    kl, desc, fn = ex(img)
+    gs = ex.read_segments(0)
+    ex.close()
+    assert len(rs) >= 3                                    # the teeth are found at all
+    assert len(gs) == len(rs) and (gs == rs).all()
+    assert _exact(kl, desc, fn, rk, rd, rf)
+
+
+@pytest.mark.gpu
+def test_gpu_line_large_regions(plslam, oracle):
+    img = _sawtooth(480, 640, period=42, slope=6)
+    rk, rd, rf, rs = _oracle_line(oracle, img, 200, 0.0)
+    ex = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=480, cols=640, max_batch=1)
+    kl, desc, fn = ex(img)
+    gs = ex.read_segments(0)
+    ex.close()
+    assert len(gs) == len(rs) and (gs == rs).all()
+    _match(kl, desc, fn, rk, rd, rf, "sawtooth")
+
+
 def test_emu_line_edge_cases(plslam, emu_lib):
     ex = plslam.LINEextractor(1, 1.2, 20, 0.0, rows=64, cols=96, max_batch=1, lib=emu_lib)
     kl, desc, fn = ex(np.full((64, 96), 99, np.uint8))     # flat image: no segments -> empty outputs
