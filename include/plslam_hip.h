@@ -564,8 +564,15 @@ PLH_API plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, i
 PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride,
                                               const uint8_t* d_mask, plh_keyline* d_keylines, uint8_t* d_desc,
                                               double* d_linefn, int32_t* d_n, void* stream);
+/* Wavefronts per frame of LSD's region growing (cv::LineSegmentDetector's region_grow / refine loop, the sequential core
+ * of LINEextractor::operator(), LineExtractor.cpp:40).  -1 (default): by batch size -- small batches (the per-frame call of
+ * Frame.cc:224-227) run several wavefronts per frame as optimistic transactions with in-order commit, large batches one
+ * wavefront per frame; 0: always one; n in 2..16: always n.  The segments are identical in every setting. */
+PLH_API plh_status plh_line_set_grow_waves(plh_line* h, int waves);
 /* Capacity flags of the most recent extract call (see plh_orb_status).  bit 2: LSD produced more segments than the
- * segment list holds (|scaled pixels| / min_reg_size + 16 -- a hard bound, so never expected). */
+ * segment list holds (|scaled pixels| / min_reg_size + 16 -- a hard bound, so never expected).  bit 4 (16): the
+ * multi-wavefront region growing gave up on a wait that lasted seconds (a lost wake-up would otherwise hang the GPU): the
+ * call's lines are void; the handle's workspace is re-initialised by this query. */
 PLH_API plh_status plh_line_status(plh_line* h, int* flags);
 /* Per-stage device time (HIP events on the caller's stream): 0 = image prep + level-line field + seed order,
  * 1 = LSD region growing (k_lsd_grow), 2 = KeyLine selection, 3 = LBD (blur + Sobel + descriptor). */

@@ -94,6 +94,7 @@ _SIGS = {
     "plh_line_extract": ([_V, _V, _I, _I, _Z, _V, _V, _V, _V, _I, _V], _I),
     "plh_line_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
+    "plh_line_set_grow_waves": ([_V, _I], _I),
     "plh_orb_search_for_triangulation_batch_dev": ([_V] * 10 + [_I, _I, _V, _F, _F, _V, _V, _I, _I, _I, _V, _V, _V], _I),
     "plh_orb_search_by_bow_kfkf_batch_dev": ([_V] * 10 + [_I, _I, _I, _F, _I, _V, _V, _V], _I),
     "plh_orb_search_by_projection_kf_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 6 +
@@ -1067,6 +1068,10 @@ class LINEextractor:
         _check(self.lib, self.lib.plh_line_extract_batch_dev(self.h, _p(d_imgs), batch, frame_stride, _p(d_mask), _p(d_keylines),
                                                              _p(d_desc), _p(d_linefn), _p(d_n), C.c_void_p(stream)),
                "plh_line_extract_batch_dev")
+
+    def set_grow_waves(self, waves):
+        """Wavefronts per frame of LSD's region growing: -1 automatic (by batch size), 0 one, 2..16 that many; same segments."""
+        _check(self.lib, self.lib.plh_line_set_grow_waves(self.h, int(waves)), "plh_line_set_grow_waves")
 
     def status(self):
         """Capacity flags of the most recent extract call (0 = nothing was truncated); waits for that call."""

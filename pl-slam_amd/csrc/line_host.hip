@@ -67,6 +67,11 @@ struct plh_line {
   // device buffers
   uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dMask = nullptr;
   uint32_t *dArena = nullptr, *dDxdy = nullptr;   // dArena: per-frame blocks (line_plan.h, arenaStride)
+  // multi-wavefront region growing (small batches): transaction logs and private mark planes, allocated on first use
+  uint32_t* dMwReg = nullptr;
+  uint8_t* dMwMark = nullptr;
+  long long mwWaveSlots = 0;   // (frame, wavefront) pairs the two buffers hold
+  int growWaves = -1;          // plh_line_set_grow_waves
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
   hipStream_t lastStream = nullptr;   // stream of the most recent extract call (plh_line_status waits on it)
@@ -157,7 +162,7 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax,
+  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -352,6 +357,45 @@ plh_status plh_line_set_undistort(plh_line* h, const float K[4], const float D[5
   return PLH_OK;
 }
 
+// Wavefronts per frame for k_lsd_grow's launch: small batches leave most of the 1024 SIMDs idle with one wavefront per
+// frame, so a frame gets several (k_lsd_grow_mw: optimistic transactions, in-order commit -- same segments); large batches
+// fill the GPU with frames and keep one wavefront each.  PLH_GROW_MW_WAVES overrides (0 = never, n = always n; tuning aid).
+static int mw_waves_for(const plh_line* h, int batch) {
+  int forced = h->growWaves;
+  if (forced < 0) {
+    const char* e = getenv("PLH_GROW_MW_WAVES");
+    if (e) forced = atoi(e);
+  }
+  if (forced >= 0) return forced == 1 ? 0 : std::min(forced, 16);
+  if (batch <= 64) return 8;
+  if (batch <= 512) return 4;
+  if (batch <= 1024) return 2;
+  return 0;
+}
+
+static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int waves) {
+  a.mwWaves = waves;
+  a.mwRegStride = 4 * a.scaledStride;   // three regions of a transaction + reduce_region_radius scratch
+  a.mwMarkStride = a.scaledStride;
+  const long long slots = (long long)batch * waves;
+  if (slots > h->mwWaveSlots) {
+    PLH_HIP(hipStreamSynchronize(h->lastStream));   // earlier launches may still use the old buffers
+    if (h->dMwReg) (void)hipFree(h->dMwReg);
+    if (h->dMwMark) (void)hipFree(h->dMwMark);
+    h->dMwReg = nullptr; h->dMwMark = nullptr; h->mwWaveSlots = 0;
+    if (hipMalloc((void**)&h->dMwReg, (size_t)slots * a.mwRegStride * 4) != hipSuccess ||
+        hipMalloc((void**)&h->dMwMark, (size_t)slots * a.mwMarkStride) != hipSuccess ||
+        hipMemset(h->dMwMark, 0, (size_t)slots * a.mwMarkStride) != hipSuccess) {   // planes are zero between transactions
+      (void)hipGetLastError();
+      set_error("plh_line_extract: cannot allocate the multi-wavefront region-growing workspace (%lld wavefront slots)", slots);
+      return PLH_ERR_ALLOC;
+    }
+    h->mwWaveSlots = slots;
+  }
+  a.mwReg = h->dMwReg; a.mwMark = h->dMwMark;
+  return PLH_OK;
+}
+
 plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride, const uint8_t* d_mask,
                                       plh_keyline* d_keylines, uint8_t* d_desc, double* d_linefn, int32_t* d_n, void* stream) {
   if (!h || !d_imgs || !d_keylines || !d_desc || !d_linefn || !d_n || batch <= 0 || batch > h->maxBatch ||
@@ -367,6 +411,13 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   a.mask = d_mask;
   const uint8_t* src = d_imgs;
   long long srcStride = (long long)frame_stride;
+  {
+    const int waves = mw_waves_for(h, batch);
+    if (waves > 0) {
+      const plh_status st = mw_reserve(h, a, batch, waves);
+      if (st != PLH_OK) return st;
+    }
+  }
   PLH_HIP(hipMemsetAsync(h->dStatus, 0, 4, s));   // capacity flags of this call only (plh_line_status)
   h->lastStream = s;
   if (h->hasUndistort) {
@@ -451,7 +502,8 @@ plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, int cols,
   int stf = 0;
   PLH_HIP(hipMemcpy(&stf, h->dStatus, 4, hipMemcpyDeviceToHost));
   if (stf) {
-    set_error("line kernels reported a capacity overflow (flags 0x%x)", stf);
+    if ((stf & 16) && h->dMwMark) (void)hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride);
+    set_error("line kernels reported a capacity overflow or an abandoned launch (flags 0x%x)", stf);
     return PLH_ERR_CAPACITY;
   }
   return PLH_OK;
@@ -462,6 +514,17 @@ plh_status plh_line_status(plh_line* h, int* flags) {
   PLH_HIP(hipSetDevice(h->device));
   PLH_HIP(hipStreamSynchronize(h->lastStream));
   PLH_HIP(hipMemcpy(flags, h->dStatus, 4, hipMemcpyDeviceToHost));
+  if ((*flags & 16) && h->dMwMark)   // an abandoned launch leaves private marks behind: the planes must be zero between transactions
+    PLH_HIP(hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride));
+  return PLH_OK;
+}
+
+plh_status plh_line_set_grow_waves(plh_line* h, int waves) {
+  if (!h || waves < -1 || waves > 16) {
+    set_error("plh_line_set_grow_waves: waves must be -1 (automatic), 0 or 1 (one wavefront per frame) or 2..16");
+    return PLH_ERR_INVALID;
+  }
+  h->growWaves = waves;
   return PLH_OK;
 }
 

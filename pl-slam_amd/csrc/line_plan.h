@@ -86,6 +86,13 @@ struct LineDeviceArgs {
   double minLineLength;
   int outCap;               // nFeature + 1
   int* status;
+  // multi-wavefront region growing (k_lsd_grow_mw, small batches): per (frame, wavefront) a transaction log / region queue of
+  // mwRegStride words (three regions + scratch, so no phase of a transaction can overflow it) and a private mark plane of
+  // mwMarkStride bytes (zero between transactions); null when the batch runs one wavefront per frame
+  uint32_t* mwReg;
+  uint8_t* mwMark;
+  long long mwRegStride, mwMarkStride;
+  int mwWaves;              // wavefronts per frame of this launch (0: k_lsd_grow / k_lsd_grow_lone)
 };
 
 }  // namespace plh

@@ -17,6 +17,7 @@ struct GrowCtx {
   const LsdAngleEntry* A;      // per-device table of everything a gradient determines (line_plan.h)
   uint32_t* reg;       // region queue (global memory); entries are packed coordinates x | y << 16
   uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
+  uint8_t* M;          // multi-wavefront build only: this wavefront's private `used` marks, one byte per pixel (k_lsd_grow_mw)
   uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
   double* T;           // LDS [3][64] doubles: lane -> chain transposition buffer of the sequential double sums
   int spitch, sw, sh, lane;
@@ -29,8 +30,12 @@ struct GrowCtx {
 #endif
 };
 #if defined(PLH_GROW_PROF)
-__device__ unsigned long long g_grow_prof[16];
+__device__ unsigned long long g_grow_prof[32];   // [16..31]: k_lsd_grow_mw (transactions, retired unused, reruns, wait / scan / run / commit cycles)
+#if defined(HIPEMU)
+#define PF_NOW() 0ull
+#else
 #define PF_NOW() __builtin_amdgcn_s_memtime()
+#endif
 #define PF_ADD(c, k, v) ((c).pf[k] += (unsigned long long)(v))
 #else
 #define PF_NOW() 0ull
@@ -41,6 +46,39 @@ constexpr int LSD_PTS = 8;      // queue points examined per step (8 points x 8 
 constexpr unsigned LSD_USED = LSD_REC_USED;   // `used` mark: bit 31 of the record word (LsdPix::q holds the record word)
 // a pixel region growing may take: defined and not used -- one signed compare on the record word
 __device__ __forceinline__ bool rec_is_candidate(unsigned rec) { return (int)rec >= (int)LSD_REC_DEF; }
+// Where region growing's marks live.  One wavefront per frame (MW = false): bit 31 of the record itself.  Several
+// wavefronts per frame (MW = true, k_lsd_grow_mw): a region in flight is a transaction whose marks must stay invisible to
+// the other wavefronts until it commits, so they go to a byte plane private to the wavefront; the record's bit holds the
+// committed marks only.  The record word as region growing sees it is the record with the private mark folded into bit 31.
+template <bool MW>
+__device__ __forceinline__ unsigned grow_load_rec(const GrowCtx& c, uint32_t idx) {
+  if constexpr (MW) return c.P[idx] | ((unsigned)c.M[idx] << 31);
+  else return c.P[idx];
+}
+template <bool MW>
+__device__ __forceinline__ void grow_mark(const GrowCtx& c, uint32_t idx, unsigned rec) {
+  if constexpr (MW) c.M[idx] = 1;
+  else c.P[idx] = rec | LSD_USED;
+}
+template <bool MW>
+__device__ __forceinline__ void grow_unmark(const GrowCtx& c, uint32_t idx, unsigned rec) {
+  if constexpr (MW) c.M[idx] = 0;
+  else c.P[idx] = rec & ~LSD_USED;
+}
+// store -> load order between the lanes of one wavefront (queue and mark stores read back by other lanes).  A block of the
+// one-wavefront kernels is one wavefront, where __syncthreads() is that; the multi-wavefront kernel must not meet a block
+// barrier inside a transaction.
+template <bool MW>
+__device__ __forceinline__ void grow_lane_fence() {
+  if constexpr (MW) {
+#if !defined(HIPEMU)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#endif
+    PLH_WAVE_SYNC();
+  } else {
+    __syncthreads();
+  }
+}
 // the table values of a record (one 16-byte gather; the hot part of the table is L2-resident)
 __device__ __forceinline__ LsdPix lsd_fetch_px(const LsdAngleEntry* T, unsigned rec) {
   const uint4 e = *reinterpret_cast<const uint4*>(T + (rec & LSD_REC_IDX));
@@ -310,6 +348,7 @@ struct LsdCand {
 // to date: `angValid` says whether regAngF still is the reference's reg_angle for (sumdx, sumdy); it is recomputed when a lane
 // needs it and once at the end of region_grow().  Mispredictions only happen for pixels within the step's angle drift of the
 // tolerance boundary.  Returns the mask of the lanes whose pixel was accepted.
+template <bool MW>
 __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsigned long long rem, const LsdCand& cd,
                                                           bool mayDup, const LsdTol& tol, float& sumdx, float& sumdy,
                                                           float& regAngF, bool& angValid, int& cnt) {
@@ -354,7 +393,7 @@ __device__ __forceinline__ unsigned long long lsd_resolve(const GrowCtx& c, unsi
         const unsigned slot = (unsigned)cnt + (unsigned)mbcnt64(A);   // accepted lanes below this one: v_mbcnt on the scalar mask
         c.reg[slot] = cd.npk;
         c.ring[slot & (LSD_RING - 1)] = cd.npk;
-        c.P[cd.nidx] = cd.px.q | LSD_USED;
+        grow_mark<MW>(c, cd.nidx, cd.px.q);
       }
       accAll |= A;
       const int last = 63 - __clzll((long long)A);
@@ -405,6 +444,7 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint3
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
 // reference's float fastAtan2 result; evaluated only if the region has at least minCnt pixels).  All lanes hold identical
 // (uniform) state.
+template <bool MW>
 __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, int firstGrp, bool dirtyFst,
                                                int minCnt, float* regAngOut) {
   const int lane = c.lane, g = lane >> 3;
@@ -426,7 +466,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   if (lane == 0) {
     c.reg[0] = seedPk;
     c.ring[0] = seedPk;
-    c.P[seed] = seedQ | LSD_USED;
+    grow_mark<MW>(c, seed, seedQ);
   }
   PF_ADD(c, 11, 1);
   int cnt = 1, i = 0;
@@ -444,7 +484,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     // one signed compare on the record word covers "not marked and above the gradient threshold" (the table values were
     // fetched with the neighbourhood for every DEFINED pixel, so a pixel that refine() un-marked in between has them too)
     const unsigned long long candM = wballot(first.inb) & wballot(rec_is_candidate(first.px.q));
-    lsd_resolve(c, candM, first, false, tol, sumdx, sumdy, regAngF, angValid, cnt);
+    lsd_resolve<MW>(c, candM, first, false, tol, sumdx, sumdy, regAngF, angValid, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
     i = 1;
   }
@@ -457,7 +497,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   LsdCand cur;
   cur.inb = lsd_addr(c, i, cnt, cur.nidx, cur.npk);
   {
-    const unsigned rec = c.P[cur.nidx];
+    const unsigned rec = grow_load_rec<MW>(c, cur.nidx);
     cur.px = rec_is_candidate(rec) ? lsd_fetch_px(c.A, rec) : lsd_null_px(rec);
   }
   while (i < cnt) {
@@ -467,7 +507,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     const unsigned long long candM = wballot(rec_is_candidate(cur.px.q));
     const unsigned long long pt1 = PF_NOW();
     PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
-    lsd_resolve(c, candM, cur, true, tol, sumdx, sumdy, regAngF, angValid, cnt);
+    lsd_resolve<MW>(c, candM, cur, true, tol, sumdx, sumdy, regAngF, angValid, cnt);
     PF_ADD(c, 4, PF_NOW() - pt1);
     i += m;
     // the next step's records, requested after this step's marks were stored (a wavefront observes its own stores);
@@ -475,7 +515,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     PLH_WAVE_SYNC();
     cur.inb = lsd_addr(c, i, cnt, cur.nidx, cur.npk);
     {   // the 4-byte record, then -- for candidates only -- its table values
-      const unsigned rec = c.P[cur.nidx];
+      const unsigned rec = grow_load_rec<MW>(c, cur.nidx);
       cur.px = rec_is_candidate(rec) ? lsd_fetch_px(c.A, rec) : lsd_null_px(rec);
     }
   }
@@ -620,6 +660,7 @@ __device__ __forceinline__ double rect_density(int cnt, const double* r) {
 // The reference removes with "swap with the last element, pop, re-check": near points of the final prefix
 // [0, K) stay in place and the holes (far points with index < K, ascending) are filled with the near points
 // of the tail [K, cnt) in DESCENDING index order.  That permutation is reproduced here with parallel passes.
+template <bool MW>
 __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, double yc, double radSq) {
   const int lane = c.lane;
   int K = 0;
@@ -631,7 +672,8 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
       near = !(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p)) > radSq);
       if (!near) {
         const uint32_t li = pk_lin(c, p);
-        c.P[li] &= ~LSD_USED;
+        if constexpr (MW) c.M[li] = 0;
+        else c.P[li] &= ~LSD_USED;
       }
     }
     K += __popcll(__ballot(near));
@@ -661,9 +703,9 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
     if (fil) c.scr[H + F + __popcll(m & lanemask_lt())] = p;
     F += __popcll(m);
   }
-  __syncthreads();
+  grow_lane_fence<MW>();
   for (int j = lane; j < H; j += 64) c.reg[c.scr[j]] = c.scr[H + j];
-  __syncthreads();
+  grow_lane_fence<MW>();
   return K;
 }
 
@@ -818,7 +860,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
         for (;;) {
           float regAngF;
           const unsigned long long pg0 = PF_NOW();
-          int cnt = lsd_region_grow(c, gs, phase == 0 ? t : -1, dirtyFst, phase == 0 ? a.minRegSize : 2, &regAngF);
+          int cnt = lsd_region_grow<false>(c, gs, phase == 0 ? t : -1, dirtyFst, phase == 0 ? a.minRegSize : 2, &regAngF);
           dirtySeed = true; dirtyFst = true;
           const unsigned long long pg1 = PF_NOW();
           PF_ADD(c, 2, pg1 - pg0);
@@ -890,7 +932,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
             const double radSq = gs.d[0] * (0.75 * 0.75);
             PLH_WAVE_SYNC();
             if (lane == 0) gs.d[0] = radSq;
-            cnt = lsd_reduce_radius_step(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
+            cnt = lsd_reduce_radius_step<false>(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
             if (cnt < 2) { emit = false; break; }
             PF_ADD(c, 7, 1); PF_ADD(c, 1, cnt);
             lsd_region2rect(c, cnt, (double)regAngS * kDegToRads, a.prec, rec);
@@ -915,6 +957,403 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   pfv[0] = PF_NOW() - pfStart;
   if (lane == 0)
     for (int i = 0; i < 16; i++) atomicAdd(&g_grow_prof[i], pfv[i]);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-wavefront region growing (k_lsd_grow_mw): W wavefronts of ONE workgroup share a frame.
+//
+// flsd() is a sequence of transactions, one per seed that is still free at its turn: region_grow -> region2rect ->
+// [refine -> region_grow -> region2rect -> reduce_region_radius].  A transaction reads the `used` map and marks pixels in
+// it; nothing else couples two of them.  Across transactions the map only ever changes from free to used (refine() and
+// reduce_region_radius() take back marks of their OWN region only), so a transaction that ran against a stale map -- one
+// that lacks the marks of earlier transactions still in flight -- took exactly the reference's course unless a pixel it
+// ACCEPTED at any point is used in the true map: a pixel it rejected for its angle is rejected either way, a pixel it saw
+// used is used.  Hence optimistic execution with in-order commit:
+//   * seeds are handed out in the reference's order (a FIFO in LDS, refilled 64 seeds at a time by whichever wavefront
+//     finds it low); the FIFO index is the transaction's sequence number;
+//   * a wavefront runs its transaction with its marks in a private byte plane (grow_mark<true>), reading the committed
+//     marks from the records, and keeps a log of every pixel it ever accepted (the region queues of its phases, laid
+//     end to end);
+//   * transactions commit strictly in sequence order (`head` in LDS): the wavefront whose turn it is re-reads the records
+//     of its log; if none is used it sets their USED bits for the pixels still marked (the final region), clears its
+//     plane, appends its segment and retires; otherwise it clears its marks and runs the transaction again -- it is the
+//     oldest one now, so this run is the reference's.  A seed that is already used when it is handed out retires at once.
+// The result is the one-wavefront kernel's, segment for segment; only the schedule differs.  All wavefronts of a frame sit
+// on one CU: they share its L1 (coherent for their own stores, workgroup scope) and talk through LDS.
+// Used for small batches, where one wavefront per frame leaves the GPU empty and a frame takes 47 ms (Frame.cc:224-227
+// calls the extractor once per frame).
+// ---------------------------------------------------------------------------------------------
+constexpr int MW_N = 128;    // entries of the seed FIFO and of the retire ring (power of two, > 64 + wavefronts)
+constexpr int MW_LOW = 24;   // a wavefront that finds fewer seeds queued refills the FIFO
+enum { MWC_CURSOR = 0, MWC_LOCK, MWC_PUSH, MWC_POP, MWC_HEAD, MWC_DONE, MWC_NSEG, MWC_ABORT, MWC_WORDS = 16 };
+// A wait that lasts this many polls (some seconds) cannot be a wait for work: the kernel gives up instead of hanging the GPU
+// -- every wavefront leaves at its next wait, status bit 4 (16) reports it and the frame's segments are void.
+constexpr unsigned MW_SPIN_LIMIT = 1u << 26;
+constexpr int MW_WAVE_LDS = LSD_RING * 4 + 6 * 8 + 8 * 4;   // per wavefront: ring (aliased by T) + GrowState
+
+#if defined(HIPEMU)
+__device__ __forceinline__ int mw_ld(const int* p) { return *(volatile const int*)p; }
+__device__ __forceinline__ void mw_st(int* p, int v) { *(volatile int*)p = v; }
+__device__ __forceinline__ int mw_cas(int* p, int cmp, int v) { const int o = *p; if (o == cmp) *p = v; return o; }
+__device__ __forceinline__ void mw_pause() { hipemu::spin_yield(); }
+__device__ __forceinline__ void mw_release() {}
+__device__ __forceinline__ void mw_acquire() {}
+#else
+__device__ __forceinline__ int mw_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void mw_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int mw_cas(int* p, int cmp, int v) {
+  __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return cmp;
+}
+__device__ __forceinline__ void mw_pause() { __builtin_amdgcn_s_sleep(1); }
+// publish: this wavefront's global stores are complete (L1 / L2 of its CU) before the LDS word that hands over the turn
+__device__ __forceinline__ void mw_release() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void mw_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#endif
+
+__device__ __forceinline__ bool mw_give_up(int* ctl, unsigned& polls, int* status) {
+  if (++polls > MW_SPIN_LIMIT) {
+    mw_st(&ctl[MWC_ABORT], 1);
+    atomicOr(status, 16);
+    return true;
+  }
+  return mw_ld(&ctl[MWC_ABORT]) != 0;
+}
+
+// a control word as ONE value for the whole wavefront (lane 0's read): the words change under the reader's feet, and every
+// decision taken on them has to be the same in all lanes
+__device__ __forceinline__ int mw_ld_u(const int* p) { return (int)bcast_u32((unsigned)mw_ld(p), 0); }
+
+// a transaction's turn is over: tag its ring slot, then move `head` past every retired sequence number (any wavefront may)
+__device__ __forceinline__ void mw_retire(int* ctl, int* state, int s, int lane) {
+  PLH_WAVE_SYNC();
+  if (lane == 0) {
+    mw_st(&state[s & (MW_N - 1)], s + 1);
+    for (;;) {
+      const int h = mw_ld(&ctl[MWC_HEAD]);
+      if (mw_ld(&state[h & (MW_N - 1)]) != h + 1) break;
+      mw_cas(&ctl[MWC_HEAD], h, h + 1);
+    }
+  }
+  PLH_WAVE_SYNC();
+}
+
+// Refill the seed FIFO (caller holds MWC_LOCK): 64 seeds per pass -- one coalesced load of their coordinates, their records,
+// and for those not used yet the seed terms from the gradient table -- pushed in order.  A seed that is used by the time it
+// is popped costs its wavefront one record load.
+__device__ void mw_scan(const GrowCtx& c, int* ctl, uint4* fifo, const uint32_t* ord, int nOrd) {
+  const int lane = c.lane;
+  int cursor = mw_ld_u(&ctl[MWC_CURSOR]), push = mw_ld_u(&ctl[MWC_PUSH]);   // only the lock holder moves these
+  for (;;) {
+    if (cursor >= nOrd) {
+      if (lane == 0) mw_st(&ctl[MWC_DONE], 1);
+      break;
+    }
+    const int pop = mw_ld_u(&ctl[MWC_POP]);
+    if (push - pop >= MW_LOW || push + 64 - pop > MW_N) break;
+    const int si = cursor + lane;
+    bool fr = false;
+    uint32_t seedP = 0;
+    uint4 ent = uint4{0u, 0u, 0u, 0u};
+    if (si < nOrd) {
+      seedP = ord[si];
+      const unsigned sRec = c.P[pk_lin(c, seedP)];
+      fr = !(sRec & LSD_USED);
+      if (fr) {
+        const LsdAngleEntry* e = c.A + (sRec & LSD_REC_IDX);
+        const uint4 e0 = *reinterpret_cast<const uint4*>(e);
+        ent.x = seedP; ent.y = e0.x; ent.z = e0.w; ent.w = __float_as_uint(e->seedy);   // angle (degrees), seed cos, seed sin
+      }
+    }
+    const unsigned long long m = __ballot(fr);
+    if (fr) fifo[(push + __popcll(m & lanemask_lt())) & (MW_N - 1)] = ent;
+    push += __popcll(m);
+    cursor += 64;
+    PLH_WAVE_SYNC();
+    if (lane == 0) mw_st(&ctl[MWC_PUSH], push);   // after the entries (LDS operations of a wavefront execute in order)
+  }
+  PLH_WAVE_SYNC();
+  if (lane == 0) mw_st(&ctl[MWC_CURSOR], cursor);
+}
+
+struct MwTxn {
+  int logLen;            // pixels ever accepted: regBase[0 .. logLen)
+  int finBase, finCnt;   // the pixels still marked at the end (the final region): regBase[finBase .. finBase + finCnt)
+  bool emit;             // a segment came out (its rectangle is in gs.d[1 .. 5])
+};
+
+// One transaction: the body of flsd()'s loop for one seed (oracle/lsd.cc:269-285; lsd_grow_frame's phase loop), with the
+// region queues of its phases laid end to end so that the log keeps every pixel it ever accepted.
+__device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, uint32_t* regBase, uint32_t seedPk,
+                            unsigned seedRec, unsigned sAngBits, unsigned sCxBits, unsigned sSyBits) {
+  const int lane = c.lane;
+  double* rec = gs.d + 1;
+  MwTxn t;
+  t.emit = false;
+  c.reg = regBase;
+  PLH_WAVE_SYNC();
+  if (lane == 0) {
+    gs.d[0] = a.prec;
+    gs.u[0] = seedPk; gs.u[1] = seedRec; gs.u[2] = sAngBits; gs.u[3] = sCxBits; gs.u[4] = sSyBits;
+  }
+  PLH_WAVE_SYNC();
+  float regAngF;
+  int cnt = lsd_region_grow<true>(c, gs, -1, false, a.minRegSize, &regAngF);
+  t.logLen = cnt; t.finBase = 0; t.finCnt = cnt;
+  if (cnt < a.minRegSize) return t;   // the region is dropped, its pixels stay used
+  grow_lane_fence<true>();
+  lsd_region2rect(c, cnt, (double)regAngF * kDegToRads, a.prec, rec);
+  if (!(rect_density(cnt, rec) < a.densityTh)) { t.emit = true; return t; }
+  // refine(): tolerance from the angle spread near the seed, everything un-marked, grown again
+  const int cnt1 = cnt;
+  const uint32_t cPk = c.reg[0];
+  const double xc = (double)pk_x(cPk), yc = (double)pk_y(cPk);
+  {
+    const uint32_t cLin = pk_lin(c, cPk);
+    const unsigned rec0 = c.P[cLin];
+    const LsdAngleEntry* e0 = c.A + (rec0 & LSD_REC_IDX);
+    const float ang0 = e0->angf, sx0 = e0->seedx, sy0 = e0->seedy;
+    const double ang_c = (double)ang0 * kDegToRads, width = rec[4];
+    double acc = 0;
+    int n = 0;
+    for (int base = 0; base < cnt; base += 64) {
+      const int i = base + lane;
+      bool flag = false;
+      double ang_d = 0;
+      if (i < cnt) {
+        const uint32_t p = c.reg[i];
+        const uint32_t li = pk_lin(c, p);
+        const unsigned rp = c.P[li];
+        c.M[li] = 0;
+        if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < width) {
+          flag = true;
+          ang_d = angle_diff_signed((double)c.A[rp & LSD_REC_IDX].angf * kDegToRads, ang_c);
+        }
+      }
+      n += __popcll(__ballot(flag));
+      PLH_WAVE_SYNC();
+      c.T[lane] = ang_d; c.T[64 + lane] = ang_d * ang_d; c.T[128 + lane] = 0.0;
+      PLH_WAVE_SYNC();
+      acc = lsd_chain_add(c, acc, min(64, cnt - base));
+    }
+    const double sum = bcast_f64(acc, 0), s_sum = bcast_f64(acc, 1);
+    const double mean_angle = sum / (double)n;
+    PLH_WAVE_SYNC();
+    if (lane == 0) {
+      gs.d[0] = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+      gs.u[0] = cPk; gs.u[1] = rec0 & ~LSD_USED;
+      gs.u[2] = __float_as_uint(ang0); gs.u[3] = __float_as_uint(sx0); gs.u[4] = __float_as_uint(sy0);
+    }
+  }
+  grow_lane_fence<true>();
+  c.reg = regBase + cnt1;   // the first region stays in the log
+  cnt = lsd_region_grow<true>(c, gs, -1, false, 2, &regAngF);
+  t.logLen = cnt1 + cnt; t.finBase = cnt1; t.finCnt = cnt;
+  if (cnt < 2) return t;
+  grow_lane_fence<true>();
+  lsd_region2rect(c, cnt, (double)regAngF * kDegToRads, a.prec, rec);
+  if (!(rect_density(cnt, rec) < a.densityTh)) { t.emit = true; return t; }
+  // reduce_region_radius() permutes and drops queue entries: it works on a copy, the log keeps the grown region
+  {
+    uint32_t* cp = c.reg + cnt;
+    for (int i = lane; i < cnt; i += 64) cp[i] = c.reg[i];
+    grow_lane_fence<true>();
+    c.reg = cp;
+    t.finBase = cnt1 + cnt;
+    const double r1 = dist_sq(xc, yc, rec[0], rec[1]), r2 = dist_sq(xc, yc, rec[2], rec[3]);
+    PLH_WAVE_SYNC();
+    if (lane == 0) gs.d[0] = r1 > r2 ? r1 : r2;
+    PLH_WAVE_SYNC();
+  }
+  t.emit = true;
+  const float regAngS = bcast_f32(regAngF, 0);
+  while (rect_density(cnt, rec) < a.densityTh) {
+    const uint32_t oPk = c.reg[0];
+    const double radSq = gs.d[0] * (0.75 * 0.75);
+    PLH_WAVE_SYNC();
+    if (lane == 0) gs.d[0] = radSq;
+    cnt = lsd_reduce_radius_step<true>(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
+    if (cnt < 2) { t.emit = false; break; }
+    lsd_region2rect(c, cnt, (double)regAngS * kDegToRads, a.prec, rec);
+  }
+  t.finCnt = cnt;
+  return t;
+}
+
+__device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsigned char* smem) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, W = (int)(blockDim.x >> 6);
+  int* ctl = (int*)smem;
+  int* state = ctl + MWC_WORDS;
+  uint4* fifo = (uint4*)(state + MW_N);
+  unsigned char* wsm = (unsigned char*)(fifo + MW_N) + wv * MW_WAVE_LDS;
+  GrowCtx c;
+  c.ring = (uint32_t*)wsm;
+  c.T = (double*)wsm;
+  c.P = a.pix + (long long)b * a.arenaStride;
+  c.A = a.angleTab;
+  uint32_t* const regBase = a.mwReg + ((long long)b * W + wv) * a.mwRegStride;
+  c.reg = regBase;
+  c.scr = regBase + 3 * (a.mwRegStride >> 2);
+  c.M = a.mwMark + ((long long)b * W + wv) * a.mwMarkStride;
+  c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
+  c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
+  GrowState gs;
+  gs.d = (double*)(wsm + LSD_RING * 4);
+  gs.u = (uint32_t*)(gs.d + 6);
+  gs.fstPx = nullptr; gs.fstIdx = nullptr; gs.fstPk = nullptr;
+  const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;
+  float* segs = a.segs + (long long)b * a.arenaStride;
+  const int nOrd = a.nOrdered[b];
+#if defined(PLH_GROW_PROF)
+  unsigned long long pfv[32];
+  for (int i = 0; i < 32; i++) pfv[i] = 0;
+  c.pf = pfv;
+  const unsigned long long pfStart = PF_NOW();
+#endif
+  for (int i = tid; i < MWC_WORDS + MW_N; i += (int)blockDim.x) ctl[i] = 0;   // control words and retire ring
+  if (a.batch <= 8) {
+    // a handful of frames: pull the frame's records and the table entries they point to through this XCD's L2, all loads
+    // in flight, before the dependent fetches of region growing start (as k_lsd_grow_lone does)
+    const uint4* P4 = reinterpret_cast<const uint4*>(c.P);
+    const int n16 = (a.spitch * a.sh) >> 2;
+    unsigned acc = 0;
+    for (int i = tid; i < n16; i += (int)blockDim.x * 4) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int j = i + (int)blockDim.x * k;
+        if (j < n16) {
+          const uint4 r4 = P4[j];
+          acc |= r4.w & 0x20000000u;
+          const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (rr[q] & LSD_REC_DEF) acc |= __float_as_uint(c.A[rr[q] & LSD_REC_IDX].pad);
+        }
+      }
+    }
+    if (acc) atomicOr(a.status, 8);   // keeps the loads alive; never taken
+  }
+  __syncthreads();
+  for (;;) {
+    // ---- the next seed: pop the FIFO; refill it when it runs low (one wavefront at a time)
+    int s = -1;
+    uint4 ent = uint4{0u, 0u, 0u, 0u};
+    const unsigned long long pw0 = PF_NOW();
+    for (;;) {
+      const int done = mw_ld_u(&ctl[MWC_DONE]), pop = mw_ld_u(&ctl[MWC_POP]), push = mw_ld_u(&ctl[MWC_PUSH]);
+      if (!done && push - pop < MW_LOW) {
+        int got = 0;
+        if (lane == 0) got = mw_cas(&ctl[MWC_LOCK], 0, 1) == 0;
+        got = (int)bcast_u32((unsigned)got, 0);
+        if (got) {
+          const unsigned long long ps0 = PF_NOW();
+          mw_scan(c, ctl, fifo, ord, nOrd);
+          PLH_WAVE_SYNC();
+          if (lane == 0) mw_st(&ctl[MWC_LOCK], 0);
+          PF_ADD(c, 20, PF_NOW() - ps0);
+          continue;
+        }
+      }
+      if (pop < push) {
+        ent = fifo[pop & (MW_N - 1)];   // read before the pop: the slot may be refilled right after it
+        ent.x = bcast_u32(ent.x, 0); ent.y = bcast_u32(ent.y, 0); ent.z = bcast_u32(ent.z, 0); ent.w = bcast_u32(ent.w, 0);
+        int ok = 0;
+        if (lane == 0) ok = mw_cas(&ctl[MWC_POP], pop, pop + 1) == pop;
+        ok = (int)bcast_u32((unsigned)ok, 0);
+        if (ok) { s = pop; break; }
+        continue;
+      }
+      if (done) break;
+      // nothing queued and another wavefront is refilling: lane 0 waits for its entries (or for the lock to come free)
+      if (lane == 0) {
+        unsigned polls = 0;
+        while (mw_ld(&ctl[MWC_PUSH]) == push && !mw_ld(&ctl[MWC_DONE]) && mw_ld(&ctl[MWC_LOCK]) != 0 &&
+               !mw_give_up(ctl, polls, a.status))
+          mw_pause();
+      }
+      PLH_WAVE_SYNC();
+      if (mw_ld_u(&ctl[MWC_ABORT])) break;
+    }
+    PF_ADD(c, 21, PF_NOW() - pw0);
+    if (s < 0) break;
+    const uint32_t seedPk = ent.x;
+    const uint32_t seedLin = pk_lin(c, seedPk);
+    bool spec = mw_ld_u(&ctl[MWC_HEAD]) != s, aborted = false;   // older transactions are still in flight: what this one reads may be stale
+    PF_ADD(c, 16, 1);
+    for (;;) {
+      mw_acquire();
+      const unsigned seedRec = bcast_u32(c.P[seedLin], 0);
+      if (seedRec & LSD_USED) {   // swallowed by a committed region: certain, marks are never taken back once committed
+        PF_ADD(c, 17, 1);
+        break;
+      }
+      const unsigned long long pt0 = PF_NOW();
+      const MwTxn t = lsd_txn_mw(c, gs, a, regBase, seedPk, seedRec, ent.y, ent.z, ent.w);
+      const unsigned long long pt1 = PF_NOW();
+      PF_ADD(c, 22, pt1 - pt0);
+      // ---- commit, in sequence order
+      if (lane == 0) {
+        unsigned polls = 0;
+        while (mw_ld(&ctl[MWC_HEAD]) != s && !mw_give_up(ctl, polls, a.status)) mw_pause();
+      }
+      PLH_WAVE_SYNC();
+      if (mw_ld_u(&ctl[MWC_ABORT])) { aborted = true; break; }
+      mw_acquire();
+      const unsigned long long pt2 = PF_NOW();
+      PF_ADD(c, 19, pt2 - pt1);
+      if (spec) {
+        bool bad = false;
+        for (int base = 0; base < t.logLen; base += 64) {
+          const int i = base + lane;
+          if (i < t.logLen) bad = bad || (c.P[pk_lin(c, regBase[i])] & LSD_USED) != 0u;
+        }
+        if (__ballot(bad) != 0ull) {
+          // an older transaction took a pixel this one accepted: take the marks back and run again, now as the oldest
+          for (int i = lane; i < t.logLen; i += 64) c.M[pk_lin(c, regBase[i])] = 0;
+          grow_lane_fence<true>();
+          spec = false;
+          PF_ADD(c, 18, 1);
+          continue;
+        }
+      }
+      {
+        const uint32_t* fin = regBase + t.finBase;
+        for (int i = lane; i < t.finCnt; i += 64) {
+          const uint32_t li = pk_lin(c, fin[i]);
+          c.P[li] |= LSD_USED;
+          c.M[li] = 0;
+        }
+      }
+      if (t.emit && lane == 0) {
+        const double* rec = gs.d + 1;
+        const int ns = ctl[MWC_NSEG];   // only the committing wavefront touches it
+        if (ns < a.segCap) {
+          segs[ns * 4 + 0] = (float)((rec[0] + 0.5) / 0.8); segs[ns * 4 + 1] = (float)((rec[1] + 0.5) / 0.8);
+          segs[ns * 4 + 2] = (float)((rec[2] + 0.5) / 0.8); segs[ns * 4 + 3] = (float)((rec[3] + 0.5) / 0.8);
+        }
+        ctl[MWC_NSEG] = ns + 1;
+      }
+      mw_release();
+      PF_ADD(c, 23, PF_NOW() - pt2);
+      break;
+    }
+    if (aborted) break;
+    mw_retire(ctl, state, s, lane);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int nseg = ctl[MWC_NSEG];
+    if (nseg > a.segCap) { atomicOr(a.status, 4); nseg = a.segCap; }
+    a.nSegs[b] = nseg;
+  }
+#if defined(PLH_GROW_PROF)
+  pfv[0] = PF_NOW() - pfStart;
+  if (lane == 0)
+    for (int i = 0; i < 32; i++) atomicAdd(&g_grow_prof[i], pfv[i]);
 #endif
 }
 
@@ -946,6 +1385,11 @@ __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a)
 __global__ void __launch_bounds__(64) k_lsd_grow_lone(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   lsd_grow_frame(a, smem);
+}
+
+__global__ void __launch_bounds__(1024) k_lsd_grow_mw(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  lsd_grow_frame_mw(a, smem);
 }
 
 __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
@@ -1377,6 +1821,11 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
 // ---------------------------------------------------------------------------------------------
 size_t lsd_grow_lds_bytes(int spitch, int sh);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
+  if (a.mwWaves > 0) {
+    const size_t ldsMw = (size_t)MWC_WORDS * 4 + (size_t)MW_N * 4 + (size_t)MW_N * 16 + (size_t)a.mwWaves * MW_WAVE_LDS;
+    hipLaunchKernelGGL(k_lsd_grow_mw, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
+    return;
+  }
   const size_t lds = lsd_grow_lds_bytes(a.spitch, a.sh);
   if (a.batch <= 8) hipLaunchKernelGGL(k_lsd_grow_lone, dim3(a.batch), dim3(64), lds, s, a);
   else hipLaunchKernelGGL(k_lsd_grow, dim3(a.batch), dim3(64), lds, s, a);
@@ -1391,12 +1840,17 @@ void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, co
   hipLaunchKernelGGL(k_lbd, dim3(a.outCap, a.batch), dim3(64), 0, s, a, kl, n, coef, desc);
 }
 #if defined(PLH_GROW_PROF)
-extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_grow_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsigned long long* out32, int reset) {
+#if defined(HIPEMU)
+  memcpy(out32, g_grow_prof, sizeof(g_grow_prof));
+  if (reset) memset(g_grow_prof, 0, sizeof(g_grow_prof));
+#else
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_grow_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_grow_prof), z, sizeof(z)) != hipSuccess) return 1;
   }
+#endif
   return 0;
 }
 #endif

@@ -49,6 +49,7 @@ extern dim3 blockDim_, gridDim_;
 extern unsigned char* dyn_smem;
 void block_barrier();
 void wave_barrier();
+void spin_yield();
 unsigned long long wave_ballot(int pred);
 unsigned long long wave_exchange(unsigned long long v, int src_lane, int width);  // value of lane src
 void run_grid(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* args);

@@ -91,6 +91,13 @@ void block_barrier() {
   wait_kind[cur] = 0;
 }
 void wave_barrier() { wave_rendezvous(cur / 64); }
+// a fiber that polls memory another wavefront of its block writes (multi-wavefront k_lsd_grow_mw): give the others a turn.
+// Not an event: a block whose fibers all poll is a deadlock and is reported as one.
+void spin_yield() {
+  wait_kind[cur] = 3;
+  yield();
+  wait_kind[cur] = 0;
+}
 unsigned long long wave_ballot(int pred) {
   int w = cur / 64;
   if (pred) ballot_acc[w] |= 1ull << (cur & 63);

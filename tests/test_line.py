@@ -152,6 +152,30 @@ def test_gpu_line_large_regions(plslam, oracle):
     _match(kl, desc, fn, rk, rd, rf, "sawtooth")
 
 
+@pytest.mark.parametrize("waves", [4, 8])
+def test_emu_line_multi_wavefront_growing(plslam, oracle, synth, emu_lib, waves):
+    """k_lsd_grow_mw: several wavefronts grow regions of one frame as optimistic transactions with in-order commit; the
+    segments are the one-wavefront kernel's (and the oracle's), whatever the schedule."""
+    img = synth.make_frame(7, 120, 160, n_rect=40, n_line=20)
+    rk, rd, rf, rs = _oracle_line(oracle, img, 50, 0.0)
+    ex = plslam.LINEextractor(1, 1.2, 50, 0.0, rows=120, cols=160, max_batch=1, lib=emu_lib)
+    ex.set_grow_waves(waves)
+    kl, desc, fn = ex(img)
+    gs = ex.read_segments(0)
+    assert ex.status() == 0
+    assert len(gs) == len(rs) and (gs == rs).all()
+    assert _exact(kl, desc, fn, rk, rd, rf)
+    saw = _sawtooth(120, 200)                              # regions of thousands of pixels: logs far beyond the LDS ring
+    rk, rd, rf, rs = _oracle_line(oracle, saw, 50, 0.0)
+    ex2 = plslam.LINEextractor(1, 1.2, 50, 0.0, rows=120, cols=200, max_batch=1, lib=emu_lib)
+    ex2.set_grow_waves(waves)
+    kl, desc, fn = ex2(saw)
+    assert (ex2.read_segments(0) == rs).all() and _exact(kl, desc, fn, rk, rd, rf)
+    with pytest.raises(plslam.PlhError):
+        ex.set_grow_waves(17)
+    ex.close(); ex2.close()
+
+
 def test_emu_line_edge_cases(plslam, emu_lib):
     ex = plslam.LINEextractor(1, 1.2, 20, 0.0, rows=64, cols=96, max_batch=1, lib=emu_lib)
     kl, desc, fn = ex(np.full((64, 96), 99, np.uint8))     # flat image: no segments -> empty outputs
@@ -185,6 +209,58 @@ def test_gpu_line_extract(plslam, oracle, synth, seed, rows, cols, nf, minlen, u
     else:
         assert len(gs) == len(rs) and (gs == rs).all(), "seed %d: LSD segments differ from the oracle" % seed
     _match(kl, desc, fn, rk, rd, rf, "seed %d" % seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", [0, 2, 3, 4, 8, 16])
+def test_gpu_line_grow_waves(plslam, oracle, synth, waves):
+    """Region growing with `waves` wavefronts per frame (k_lsd_grow_mw; 0 = k_lsd_grow_lone): segments, KeyLines and LBD bytes
+    equal the oracle's on textured, sparse, sawtooth (huge regions) and white-noise frames, repeatedly (the schedule of the
+    transactions differs from run to run, the result must not)."""
+    rng = np.random.RandomState(5)
+    imgs = [synth.make_frame(31, 480, 640), synth.make_frame(32, 480, 640, n_rect=20, n_line=10),
+            _sawtooth(480, 640, period=42, slope=6), rng.randint(0, 256, (480, 640)).astype(np.uint8),
+            synth.make_frame(33, 480, 640)]
+    ex = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=480, cols=640, max_batch=1)
+    ex.set_grow_waves(waves)
+    for k, img in enumerate(imgs):
+        rk, rd, rf, rs = _oracle_line(oracle, img, 200, 0.0)
+        for rep in range(3):
+            kl, desc, fn = ex(img)
+            gs = ex.read_segments(0)
+            assert ex.status() == 0
+            assert len(gs) == len(rs) and (gs == rs).all(), "image %d, run %d: LSD segments differ from the oracle" % (k, rep)
+            _match(kl, desc, fn, rk, rd, rf, "image %d, run %d" % (k, rep))
+    ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves,B", [(4, 24), (2, 48), (8, 5)])
+def test_gpu_line_grow_waves_batch(plslam, oracle, synth, waves, B):
+    """A batch of frames, several wavefronts per frame: every frame equals the oracle; the mark planes are clean afterwards
+    (a second pass over different frames in the same workspace is exact too)."""
+    import torch
+    ex = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=240, cols=320, max_batch=B)
+    ex.set_grow_waves(waves)
+    cap = ex.capacity
+    dev = torch.device("cuda", 0)
+    for seed in (50, 90):
+        frames = synth.make_frames(seed, B, 240, 320)
+        d_img = torch.from_numpy(frames).to(dev)
+        d_kl = torch.zeros((B, cap, 17), dtype=torch.float32, device=dev)
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        d_fn = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev)
+        d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+        ex.extract_batch_dev(d_img, B, 240 * 320, d_kl, d_desc, d_fn, d_n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ex.status() == 0
+        n = d_n.cpu().numpy()
+        kl = d_kl.cpu().numpy().view(np.uint8).reshape(B, cap, 68).copy().view(plslam.KL_DTYPE).reshape(B, cap)
+        desc, fn = d_desc.cpu().numpy(), d_fn.cpu().numpy()
+        for b in range(B):
+            rk, rd, rf = oracle.line_extract(frames[b], 200, 0.0)
+            _match(kl[b, :n[b]], desc[b, :n[b]], fn[b, :n[b]], rk, rd, rf, "seed %d frame %d" % (seed, b))
+    ex.close()
 
 
 @pytest.mark.gpu
