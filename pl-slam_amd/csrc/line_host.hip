@@ -70,6 +70,8 @@ struct plh_line {
   // multi-wavefront region growing (small batches): transaction logs and private mark planes, allocated on first use
   uint32_t* dMwReg = nullptr;
   uint8_t* dMwMark = nullptr;
+  uint8_t* dMwHint = nullptr;
+  long long mwHintFrames = 0;
   long long mwWaveSlots = 0;   // (frame, wavefront) pairs the two buffers hold
   int growWaves = -1;          // plh_line_set_grow_waves
   unsigned int* dQmax = nullptr;
@@ -162,7 +164,7 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark,
+  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark, h->dMwHint,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -375,9 +377,13 @@ static int mw_waves_for(const plh_line* h, int batch) {
 
 static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int waves) {
   a.mwWaves = waves;
-  a.mwRegStride = 4 * a.scaledStride;   // three regions of a transaction + reduce_region_radius scratch
+  a.mwRegStride = 5 * a.scaledStride;   // posted logs | three regions of a running transaction | reduce_region_radius scratch
   a.mwMarkStride = a.scaledStride;
-  const long long slots = (long long)batch * waves;
+  {
+    const char* e = getenv("PLH_GROW_MW_LAG");   // tuning aid
+    a.mwLag = std::min(std::max(e ? atoi(e) : 56, 1), 60);   // claim tags are sequence numbers mod 128: twice the lag stays below that
+  }
+  const long long slots = (long long)batch * (waves + 1);
   if (slots > h->mwWaveSlots) {
     PLH_HIP(hipStreamSynchronize(h->lastStream));   // earlier launches may still use the old buffers
     if (h->dMwReg) (void)hipFree(h->dMwReg);
@@ -392,7 +398,18 @@ static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int wave
     }
     h->mwWaveSlots = slots;
   }
-  a.mwReg = h->dMwReg; a.mwMark = h->dMwMark;
+  if (batch > h->mwHintFrames) {
+    PLH_HIP(hipStreamSynchronize(h->lastStream));
+    if (h->dMwHint) (void)hipFree(h->dMwHint);
+    h->dMwHint = nullptr; h->mwHintFrames = 0;
+    if (hipMalloc((void**)&h->dMwHint, (size_t)batch * a.mwMarkStride) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("plh_line_extract: cannot allocate the claim-hint planes (%d frames)", batch);
+      return PLH_ERR_ALLOC;
+    }
+    h->mwHintFrames = batch;
+  }
+  a.mwReg = h->dMwReg; a.mwMark = h->dMwMark; a.mwHint = h->dMwHint;
   return PLH_OK;
 }
 

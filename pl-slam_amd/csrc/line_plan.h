@@ -86,13 +86,16 @@ struct LineDeviceArgs {
   double minLineLength;
   int outCap;               // nFeature + 1
   int* status;
-  // multi-wavefront region growing (k_lsd_grow_mw, small batches): per (frame, wavefront) a transaction log / region queue of
-  // mwRegStride words (three regions + scratch, so no phase of a transaction can overflow it) and a private mark plane of
-  // mwMarkStride bytes (zero between transactions); null when the batch runs one wavefront per frame
+  // multi-wavefront region growing (k_lsd_grow_mw, small batches): per frame mwWaves + 1 slots (one per wavefront, one for
+  // the committing wavefront's re-runs), each a log arena of mwRegStride = 5 x scaledStride words (posted logs below 1 x, a
+  // running transaction's three region queues, reduce_region_radius scratch: no phase can overflow it) and a private mark
+  // plane of mwMarkStride bytes (zero between transactions); null when the batch runs one wavefront per frame
   uint32_t* mwReg;
   uint8_t* mwMark;
+  uint8_t* mwHint;          // per frame: claim hints shared by its wavefronts (mwMarkStride bytes, cleared by the kernel)
   long long mwRegStride, mwMarkStride;
   int mwWaves;              // wavefronts per frame of this launch (0: k_lsd_grow / k_lsd_grow_lone)
+  int mwLag;                // a wavefront starts no transaction further than this ahead of the commits
 };
 
 }  // namespace plh

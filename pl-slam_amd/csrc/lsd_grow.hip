@@ -18,6 +18,11 @@ struct GrowCtx {
   uint32_t* reg;       // region queue (global memory); entries are packed coordinates x | y << 16
   uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
   uint8_t* M;          // multi-wavefront build only: this wavefront's private `used` marks, one byte per pixel (k_lsd_grow_mw)
+  uint8_t* H;          // ... and the frame's claim hints, shared by its wavefronts: tag of the transaction that last marked the pixel
+  unsigned hTag;       // this transaction's tag, (sequence number & 127) + 1
+  unsigned hWin;       // how many sequence numbers below this one may still be uncommitted (0: none -- hints are ignored)
+  uint32_t* asmList;   // LDS: pixels this run took for used on the strength of an older transaction's claim (packed coordinates)
+  uint32_t* asmCnt;    // LDS word: their count (MW_ASM_CAP = full: no further assumptions)
   uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
   double* T;           // LDS [3][64] doubles: lane -> chain transposition buffer of the sequential double sums
   int spitch, sw, sh, lane;
@@ -50,19 +55,37 @@ __device__ __forceinline__ bool rec_is_candidate(unsigned rec) { return (int)rec
 // wavefronts per frame (MW = true, k_lsd_grow_mw): a region in flight is a transaction whose marks must stay invisible to
 // the other wavefronts until it commits, so they go to a byte plane private to the wavefront; the record's bit holds the
 // committed marks only.  The record word as region growing sees it is the record with the private mark folded into bit 31.
+// MW only.  Besides the private marks the wavefronts of a frame share a plane of CLAIM HINTS: whoever marks a pixel also
+// writes its transaction's tag there (plain byte stores, last writer wins -- a hint, never a fact).  A claim by an OLDER
+// transaction that is still uncommitted predicts that the pixel will be used by the time this one commits, so this run
+// takes it for used (and remembers that it did: the commit checks the prediction), instead of growing into a region that
+// is being grown elsewhere and finding out at its commit.  `conf` collects "this run is already lost": a pixel this
+// wavefront holds a private mark on has a committed mark, or an older transaction's claim, by now.
+constexpr int MW_ASM_CAP = 64;
+__device__ __forceinline__ bool grow_older_claim(const GrowCtx& c, unsigned h) {
+  const unsigned d = (c.hTag - h) & 127u;   // how many sequence numbers below this transaction the claimant is (mod 128)
+  return h != 0u && d != 0u && d <= c.hWin;
+}
 template <bool MW>
-__device__ __forceinline__ unsigned grow_load_rec(const GrowCtx& c, uint32_t idx) {
-  if constexpr (MW) return c.P[idx] | ((unsigned)c.M[idx] << 31);
-  else return c.P[idx];
+__device__ __forceinline__ unsigned grow_load_rec(const GrowCtx& c, uint32_t idx, unsigned& conf, bool& assumed) {
+  if constexpr (MW) {
+    const unsigned p = c.P[idx], m = (unsigned)c.M[idx], h = (unsigned)c.H[idx];
+    const bool older = grow_older_claim(c, h);
+    conf |= ((p >> 31) | (older ? 1u : 0u)) & m;
+    assumed = older && m == 0u && rec_is_candidate(p);
+    return p | (m << 31) | (assumed ? LSD_USED : 0u);
+  } else {
+    return c.P[idx];
+  }
 }
 template <bool MW>
 __device__ __forceinline__ void grow_mark(const GrowCtx& c, uint32_t idx, unsigned rec) {
-  if constexpr (MW) c.M[idx] = 1;
+  if constexpr (MW) { c.M[idx] = 1; c.H[idx] = (uint8_t)c.hTag; }
   else c.P[idx] = rec | LSD_USED;
 }
 template <bool MW>
 __device__ __forceinline__ void grow_unmark(const GrowCtx& c, uint32_t idx, unsigned rec) {
-  if constexpr (MW) c.M[idx] = 0;
+  if constexpr (MW) { c.M[idx] = 0; c.H[idx] = 0; }
   else c.P[idx] = rec & ~LSD_USED;
 }
 // store -> load order between the lanes of one wavefront (queue and mark stores read back by other lanes).  A block of the
@@ -324,6 +347,24 @@ __device__ __forceinline__ void lsd_classify(float x, float y, float cs, float s
   unc = act & ~(in | ~pos | le);
 }
 
+// remember the pixels taken for used (rare: a region growing next to an older one in flight); when the list is full the
+// run stops assuming (hWin = 0 would need a non-const context: the caller sees the count and gives the run up)
+template <bool MW>
+__device__ __forceinline__ void grow_note_assumed(const GrowCtx& c, bool assumed, uint32_t npk) {
+  if constexpr (MW) {
+    const unsigned long long am = wballot(assumed);
+    if (am) {
+      const unsigned n0 = bcast_u32(*c.asmCnt, 0);
+      if (LSD_INV_BALLOT(c, am)) {
+        const unsigned k = n0 + (unsigned)mbcnt64(am);
+        if (k < (unsigned)MW_ASM_CAP) c.asmList[k] = npk;
+      }
+      PLH_WAVE_SYNC();
+      if (c.lane == 0) *c.asmCnt = n0 + (unsigned)__popcll(am);   // may exceed the capacity: the caller checks
+      PLH_WAVE_SYNC();
+    }
+  }
+}
 // One step's candidates: lane order == the reference's examination order (queue point, then yy, then xx).
 struct LsdCand {
   LsdPix px;
@@ -446,7 +487,7 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint3
 // (uniform) state.
 template <bool MW>
 __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, int firstGrp, bool dirtyFst,
-                                               int minCnt, float* regAngOut) {
+                                               int minCnt, float* regAngOut, bool* conflictOut = nullptr) {
   const int lane = c.lane, g = lane >> 3;
   // the call's parameters come from LDS (uniform): nothing of the caller's state has to stay in registers across the loop
   const uint32_t seedPk = bcast_u32(gs.u[0], 0);
@@ -495,10 +536,13 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   }
   PLH_WAVE_SYNC();
   LsdCand cur;
+  unsigned conf = 0;
+  bool assumed = false;
   cur.inb = lsd_addr(c, i, cnt, cur.nidx, cur.npk);
   {
-    const unsigned rec = grow_load_rec<MW>(c, cur.nidx);
+    const unsigned rec = grow_load_rec<MW>(c, cur.nidx, conf, assumed);
     cur.px = rec_is_candidate(rec) ? lsd_fetch_px(c.A, rec) : lsd_null_px(rec);
+    grow_note_assumed<MW>(c, assumed, cur.npk);
   }
   while (i < cnt) {
     const unsigned long long pt0 = PF_NOW();
@@ -515,8 +559,16 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     PLH_WAVE_SYNC();
     cur.inb = lsd_addr(c, i, cnt, cur.nidx, cur.npk);
     {   // the 4-byte record, then -- for candidates only -- its table values
-      const unsigned rec = grow_load_rec<MW>(c, cur.nidx);
+      const unsigned rec = grow_load_rec<MW>(c, cur.nidx, conf, assumed);
       cur.px = rec_is_candidate(rec) ? lsd_fetch_px(c.A, rec) : lsd_null_px(rec);
+      grow_note_assumed<MW>(c, assumed, cur.npk);
+    }
+    if constexpr (MW) {
+      if (wballot(conf != 0u)) {   // overtaken by an older transaction's commit: the caller takes the marks back and starts over
+        *conflictOut = true;
+        *regAngOut = regAngF;
+        return cnt;
+      }
     }
   }
   PF_ADD(c, 9, cnt);
@@ -672,7 +724,7 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
       near = !(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p)) > radSq);
       if (!near) {
         const uint32_t li = pk_lin(c, p);
-        if constexpr (MW) c.M[li] = 0;
+        if constexpr (MW) { c.M[li] = 0; c.H[li] = 0; }
         else c.P[li] &= ~LSD_USED;
       }
     }
@@ -967,30 +1019,35 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
 // [refine -> region_grow -> region2rect -> reduce_region_radius].  A transaction reads the `used` map and marks pixels in
 // it; nothing else couples two of them.  Across transactions the map only ever changes from free to used (refine() and
 // reduce_region_radius() take back marks of their OWN region only), so a transaction that ran against a stale map -- one
-// that lacks the marks of earlier transactions still in flight -- took exactly the reference's course unless a pixel it
+// that lacks the marks of older transactions still in flight -- took exactly the reference's course unless a pixel it
 // ACCEPTED at any point is used in the true map: a pixel it rejected for its angle is rejected either way, a pixel it saw
 // used is used.  Hence optimistic execution with in-order commit:
 //   * seeds are handed out in the reference's order (a FIFO in LDS, refilled 64 seeds at a time by whichever wavefront
 //     finds it low); the FIFO index is the transaction's sequence number;
 //   * a wavefront runs its transaction with its marks in a private byte plane (grow_mark<true>), reading the committed
 //     marks from the records, and keeps a log of every pixel it ever accepted (the region queues of its phases, laid
-//     end to end);
-//   * transactions commit strictly in sequence order (`head` in LDS): the wavefront whose turn it is re-reads the records
-//     of its log; if none is used it sets their USED bits for the pixels still marked (the final region), clears its
-//     plane, appends its segment and retires; otherwise it clears its marks and runs the transaction again -- it is the
-//     oldest one now, so this run is the reference's.  A seed that is already used when it is handed out retires at once.
+//     end to end).  When the transaction is through it takes its private marks back, POSTS the result (log position, final
+//     region, segment) in a ring in LDS and goes on to the next seed -- it does not wait for its turn;
+//   * posted transactions are COMMITTED strictly in sequence order by whichever wavefront holds the drain lock: it re-reads
+//     the records of the log; if none is used it sets the USED bits of the final region and appends the segment; otherwise
+//     it runs the transaction again itself -- it is the oldest one now, so this run is the reference's -- and commits that.
+//     A transaction that notices a committed mark on a pixel it holds (while growing, or when it is through) starts over
+//     at once.  A seed that is already used when it is handed out retires without effect.
 // The result is the one-wavefront kernel's, segment for segment; only the schedule differs.  All wavefronts of a frame sit
 // on one CU: they share its L1 (coherent for their own stores, workgroup scope) and talk through LDS.
 // Used for small batches, where one wavefront per frame leaves the GPU empty and a frame takes 47 ms (Frame.cc:224-227
 // calls the extractor once per frame).
 // ---------------------------------------------------------------------------------------------
-constexpr int MW_N = 128;    // entries of the seed FIFO and of the retire ring (power of two, > 64 + wavefronts)
+constexpr int MW_N = 128;    // entries of the seed FIFO and of the ring of posted transactions (power of two)
 constexpr int MW_LOW = 24;   // a wavefront that finds fewer seeds queued refills the FIFO
-enum { MWC_CURSOR = 0, MWC_LOCK, MWC_PUSH, MWC_POP, MWC_HEAD, MWC_DONE, MWC_NSEG, MWC_ABORT, MWC_WORDS = 16 };
+constexpr int MW_MAX_WAVES = 16;
+enum { MWC_CURSOR = 0, MWC_LOCK, MWC_PUSH, MWC_POP, MWC_HEAD, MWC_DONE, MWC_NSEG, MWC_ABORT, MWC_DLOCK, MWC_RET = 16,
+       MWC_WORDS = MWC_RET + MW_MAX_WAVES };
+constexpr int MW_PEND_WORDS = 16;   // a posted transaction (MwPost)
 // A wait that lasts this many polls (some seconds) cannot be a wait for work: the kernel gives up instead of hanging the GPU
 // -- every wavefront leaves at its next wait, status bit 4 (16) reports it and the frame's segments are void.
 constexpr unsigned MW_SPIN_LIMIT = 1u << 26;
-constexpr int MW_WAVE_LDS = LSD_RING * 4 + 6 * 8 + 8 * 4;   // per wavefront: ring (aliased by T) + GrowState
+constexpr int MW_WAVE_LDS = LSD_RING * 4 + 6 * 8 + 8 * 4 + MW_ASM_CAP * 4 + 16;   // per wavefront: ring (aliased by T) + GrowState + assumed-used list + its count
 
 #if defined(HIPEMU)
 __device__ __forceinline__ int mw_ld(const int* p) { return *(volatile const int*)p; }
@@ -1007,7 +1064,7 @@ __device__ __forceinline__ int mw_cas(int* p, int cmp, int v) {
   return cmp;
 }
 __device__ __forceinline__ void mw_pause() { __builtin_amdgcn_s_sleep(1); }
-// publish: this wavefront's global stores are complete (L1 / L2 of its CU) before the LDS word that hands over the turn
+// publish: this wavefront's global stores are complete (L1 / L2 of its CU) before the LDS word that hands them over
 __device__ __forceinline__ void mw_release() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1027,19 +1084,10 @@ __device__ __forceinline__ bool mw_give_up(int* ctl, unsigned& polls, int* statu
 // a control word as ONE value for the whole wavefront (lane 0's read): the words change under the reader's feet, and every
 // decision taken on them has to be the same in all lanes
 __device__ __forceinline__ int mw_ld_u(const int* p) { return (int)bcast_u32((unsigned)mw_ld(p), 0); }
-
-// a transaction's turn is over: tag its ring slot, then move `head` past every retired sequence number (any wavefront may)
-__device__ __forceinline__ void mw_retire(int* ctl, int* state, int s, int lane) {
-  PLH_WAVE_SYNC();
-  if (lane == 0) {
-    mw_st(&state[s & (MW_N - 1)], s + 1);
-    for (;;) {
-      const int h = mw_ld(&ctl[MWC_HEAD]);
-      if (mw_ld(&state[h & (MW_N - 1)]) != h + 1) break;
-      mw_cas(&ctl[MWC_HEAD], h, h + 1);
-    }
-  }
-  PLH_WAVE_SYNC();
+__device__ __forceinline__ int mw_try_lock(int* lock, int lane) {
+  int got = 0;
+  if (lane == 0) got = mw_cas(lock, 0, 1) == 0;
+  return (int)bcast_u32((unsigned)got, 0);
 }
 
 // Refill the seed FIFO (caller holds MWC_LOCK): 64 seeds per pass -- one coalesced load of their coordinates, their records,
@@ -1084,6 +1132,7 @@ struct MwTxn {
   int logLen;            // pixels ever accepted: regBase[0 .. logLen)
   int finBase, finCnt;   // the pixels still marked at the end (the final region): regBase[finBase .. finBase + finCnt)
   bool emit;             // a segment came out (its rectangle is in gs.d[1 .. 5])
+  bool conflict;         // the run met a committed mark on a pixel it holds: not the reference's course, to be run again
 };
 
 // One transaction: the body of flsd()'s loop for one seed (oracle/lsd.cc:269-285; lsd_grow_frame's phase loop), with the
@@ -1093,21 +1142,29 @@ __device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArg
   const int lane = c.lane;
   double* rec = gs.d + 1;
   MwTxn t;
-  t.emit = false;
+  t.emit = false; t.conflict = false;
   c.reg = regBase;
   PLH_WAVE_SYNC();
   if (lane == 0) {
     gs.d[0] = a.prec;
     gs.u[0] = seedPk; gs.u[1] = seedRec; gs.u[2] = sAngBits; gs.u[3] = sCxBits; gs.u[4] = sSyBits;
+    *c.asmCnt = 0;
   }
   PLH_WAVE_SYNC();
   float regAngF;
-  int cnt = lsd_region_grow<true>(c, gs, -1, false, a.minRegSize, &regAngF);
+  const unsigned long long pg0 = PF_NOW();
+  int cnt = lsd_region_grow<true>(c, gs, -1, false, a.minRegSize, &regAngF, &t.conflict);
+  const unsigned long long pg1 = PF_NOW();
+  PF_ADD(c, 2, pg1 - pg0);
   t.logLen = cnt; t.finBase = 0; t.finCnt = cnt;
-  if (cnt < a.minRegSize) return t;   // the region is dropped, its pixels stay used
+  if (bcast_u32(*c.asmCnt, 0) > (unsigned)MW_ASM_CAP) t.conflict = true;   // more predictions than the list holds: not this time
+  if (t.conflict || cnt < a.minRegSize) return t;   // (a region below the minimum is dropped, its pixels stay used)
   grow_lane_fence<true>();
   lsd_region2rect(c, cnt, (double)regAngF * kDegToRads, a.prec, rec);
+  PF_ADD(c, 5, PF_NOW() - pg1); PF_ADD(c, 14, 1);
   if (!(rect_density(cnt, rec) < a.densityTh)) { t.emit = true; return t; }
+  const unsigned long long pg2 = PF_NOW();
+  PF_ADD(c, 15, 1);
   // refine(): tolerance from the angle spread near the seed, everything un-marked, grown again
   const int cnt1 = cnt;
   const uint32_t cPk = c.reg[0];
@@ -1120,6 +1177,7 @@ __device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArg
     const double ang_c = (double)ang0 * kDegToRads, width = rec[4];
     double acc = 0;
     int n = 0;
+    bool overtaken = false;
     for (int base = 0; base < cnt; base += 64) {
       const int i = base + lane;
       bool flag = false;
@@ -1128,7 +1186,8 @@ __device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArg
         const uint32_t p = c.reg[i];
         const uint32_t li = pk_lin(c, p);
         const unsigned rp = c.P[li];
-        c.M[li] = 0;
+        overtaken = overtaken || (rp & LSD_USED) != 0u;
+        c.M[li] = 0; c.H[li] = 0;
         if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < width) {
           flag = true;
           ang_d = angle_diff_signed((double)c.A[rp & LSD_REC_IDX].angf * kDegToRads, ang_c);
@@ -1140,6 +1199,7 @@ __device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArg
       PLH_WAVE_SYNC();
       acc = lsd_chain_add(c, acc, min(64, cnt - base));
     }
+    if (__ballot(overtaken) != 0ull) { t.conflict = true; PF_ADD(c, 6, PF_NOW() - pg2); return t; }
     const double sum = bcast_f64(acc, 0), s_sum = bcast_f64(acc, 1);
     const double mean_angle = sum / (double)n;
     PLH_WAVE_SYNC();
@@ -1151,12 +1211,13 @@ __device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArg
   }
   grow_lane_fence<true>();
   c.reg = regBase + cnt1;   // the first region stays in the log
-  cnt = lsd_region_grow<true>(c, gs, -1, false, 2, &regAngF);
+  cnt = lsd_region_grow<true>(c, gs, -1, false, 2, &regAngF, &t.conflict);
   t.logLen = cnt1 + cnt; t.finBase = cnt1; t.finCnt = cnt;
-  if (cnt < 2) return t;
+  if (bcast_u32(*c.asmCnt, 0) > (unsigned)MW_ASM_CAP) t.conflict = true;
+  if (t.conflict || cnt < 2) { PF_ADD(c, 6, PF_NOW() - pg2); return t; }
   grow_lane_fence<true>();
   lsd_region2rect(c, cnt, (double)regAngF * kDegToRads, a.prec, rec);
-  if (!(rect_density(cnt, rec) < a.densityTh)) { t.emit = true; return t; }
+  if (!(rect_density(cnt, rec) < a.densityTh)) { t.emit = true; PF_ADD(c, 6, PF_NOW() - pg2); return t; }
   // reduce_region_radius() permutes and drops queue entries: it works on a copy, the log keeps the grown region
   {
     uint32_t* cp = c.reg + cnt;
@@ -1181,24 +1242,215 @@ __device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArg
     lsd_region2rect(c, cnt, (double)regAngS * kDegToRads, a.prec, rec);
   }
   t.finCnt = cnt;
+  PF_ADD(c, 6, PF_NOW() - pg2);
   return t;
+}
+
+// A posted transaction: 16 words in LDS, ring slot = sequence number mod MW_N.
+//   w[0]  flags: bit 0 has a log (0: the seed was used already, or is predicted to be), bit 1 ran against a possibly stale map,
+//         bit 2 segment, bit 3 INLINE; bits 8-15 wavefront; bits 16-23 pixels taken for used on an older claim;
+//         bits 24-31 (inline form) pixels accepted
+//   w[1..4]  seed (packed coordinates, angle, seed cos / sin bits): to run it again
+//   inline form (a region that was dropped for its size, never refined -- four transactions in five): w[5..12] = the accepted
+//         pixels, then the assumed ones (packed coordinates; at most 8 together): nothing of it lies in global memory
+//   general form: w[5] log offset in the wavefront's arena, w[6] log length, w[7] / w[8] first / count of the final region,
+//         w[9..12] segment, w[13..15] up to 3 assumed pixels (more: in the arena behind the log)
+struct MwPost {
+  unsigned w[MW_PEND_WORDS];
+};
+enum { MWP_FLAGS = 0, MWP_SEED = 1, MWP_PIX = 5, MWP_OFF = 5, MWP_LOGLEN = 6, MWP_FINBASE = 7, MWP_FINCNT = 8, MWP_SEG = 9, MWP_ASM = 13 };
+constexpr int MW_INLINE_MAX = 8;
+
+struct MwShared {
+  int* ctl;        // MWC_*
+  int* state;      // [MW_N] sequence tag of the posted transaction in the slot
+  uint4* fifo;     // [MW_N] seeds
+  MwPost* pend;    // [MW_N]
+};
+
+__device__ __forceinline__ void mw_segment(const double* rec, float seg[4]) {   // flsd(): + 0.5, / SCALE
+  seg[0] = (float)((rec[0] + 0.5) / 0.8); seg[1] = (float)((rec[1] + 0.5) / 0.8);
+  seg[2] = (float)((rec[2] + 0.5) / 0.8); seg[3] = (float)((rec[3] + 0.5) / 0.8);
+}
+
+// Commit the posted transactions at the head of the sequence, in order, for as long as there are any (caller holds
+// MWC_DLOCK).  `ch` is the drain context: a log arena and a mark plane of its own (slot W of the frame) for the transactions
+// that have to be run again.
+// The commits are one dependency chain per frame (every one reads the marks the previous one set), so the chain is made
+// short: up to eight consecutive INLINE posts are taken together, lane group g = post h + g, lane j of it = its pixel j:
+// one LDS round trip for the posts, one load of all their records; a pixel an older post of the batch publishes counts as
+// used for the younger ones (compared lane against lane); everything in front of the first post that fails is committed
+// with one store per pixel.
+__device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
+                         uint32_t* drainReg, float* segs) {
+  const int lane = ch.lane, g = lane >> 3, j = lane & 7;
+  int h = mw_ld_u(&sh.ctl[MWC_HEAD]);
+  int nseg = mw_ld_u(&sh.ctl[MWC_NSEG]);
+  const int h0 = h;
+  for (;;) {
+    // ---- the inline posts among the next eight sequence numbers
+    const int slot = (h + g) & (MW_N - 1);
+    const bool ready = mw_ld(&sh.state[slot]) == h + g + 1;
+    const unsigned long long readyM = wballot(ready && j == 0);   // (one lane per group decides: the words change while they are read)
+    if (!(readyM & 1ull)) break;   // the head is not posted yet
+    const bool rdy = ((readyM >> (8 * g)) & 1ull) != 0ull;
+    const unsigned flags = rdy ? sh.pend[slot].w[MWP_FLAGS] : 0u;
+    const unsigned long long inlM = wballot(rdy && (flags & 8u) != 0u && j == 0);
+    const unsigned long long gap = ~inlM & 0x0101010101010101ull;
+    const int nb = gap ? (__ffsll((long long)gap) - 1) >> 3 : 8;   // leading inline posts
+    if (nb > 0) {
+      const int nAcc = (int)(flags >> 24), nAsm = (int)((flags >> 16) & 255u);
+      const bool has = g < nb && j < nAcc + nAsm, isAcc = j < nAcc, spec = (flags & 2u) != 0u;
+      const uint32_t pk = has ? sh.pend[slot].w[MWP_PIX + j] : 0u;
+      const uint32_t idx = has ? pk_lin(ch, pk) : (uint32_t)(ch.sw - 1);   // (sw - 1, 0): never defined, never marked
+      const unsigned p = ch.P[idx];
+      const bool usedNow = (p & LSD_USED) != 0u;
+      // pixels published by an older post of the batch
+      bool earlier = false;
+      unsigned long long pm = wballot(has && isAcc);
+      while (pm) {
+        const int k = __ffsll((long long)pm) - 1;
+        pm &= pm - 1;
+        const uint32_t ik = bcast_u32(idx, k);
+        earlier = earlier || (idx == ik && g > (k >> 3));
+      }
+      const bool bad = has && spec && (isAcc ? (usedNow || earlier) : !(usedNow || earlier));
+      const unsigned long long badM = wballot(bad);
+      const int gb = badM ? min((__ffsll((long long)badM) - 1) >> 3, nb) : nb;   // posts in front of the first failure
+      if (has && isAcc && g < gb) ch.P[idx] = p | LSD_USED;
+      h += gb;
+      if (gb == nb) continue;
+      // post h failed: run it again below (general path handles both forms)
+    }
+    // ---- one post, general path
+    const MwPost* e = &sh.pend[h & (MW_N - 1)];
+    const uint4* e4 = reinterpret_cast<const uint4*>(e);
+    const uint4 q0 = e4[0], q1 = e4[1], q2 = e4[2], q3 = e4[3];
+    const unsigned fl = bcast_u32(q0.x, 0);
+    const int asmLen = (int)((fl >> 16) & 255u);
+    const bool inl = (fl & 8u) != 0u;
+    const int wv = (int)((fl >> 8) & 255u);
+    bool bad = inl;   // an inline post gets here only when the batch found it invalid
+    if (!inl && ((fl & 1u) || asmLen)) {
+      const uint32_t* log = frameReg + (long long)wv * a.mwRegStride + bcast_u32(q1.y, 0);
+      const int logLen = (int)bcast_u32(q1.z, 0), finBase = (int)bcast_u32(q1.w, 0), finCnt = (int)bcast_u32(q2.x, 0);
+      if (fl & 2u) {
+        for (int base = 0; base < logLen; base += 64) {
+          const int i = base + lane;
+          if (i < logLen) bad = bad || (ch.P[pk_lin(ch, log[i])] & LSD_USED) != 0u;
+        }
+#if defined(PLH_GROW_PROF)
+        if (__ballot(bad) != 0ull) PF_ADD(ch, 29, 1);
+#endif
+        // the predictions: every pixel taken for used on an older transaction's claim is used now
+        bool badA = false;
+        if (asmLen <= 3) {
+          const unsigned ap = lane == 0 ? q3.y : (lane == 1 ? q3.z : q3.w);
+          if (lane < asmLen) badA = !(ch.P[pk_lin(ch, ap)] & LSD_USED);
+        } else {
+          const uint32_t* al = log + max(logLen, finBase + finCnt);
+          if (lane < asmLen) badA = !(ch.P[pk_lin(ch, al[lane])] & LSD_USED);
+        }
+#if defined(PLH_GROW_PROF)
+        if (__ballot(badA) != 0ull) PF_ADD(ch, 30, 1);
+#endif
+        bad = __ballot(bad || badA) != 0ull;
+      }
+      if (!bad) {
+        if (fl & 1u)
+          for (int i = lane; i < finCnt; i += 64) ch.P[pk_lin(ch, log[finBase + i])] |= LSD_USED;
+        if ((fl & 4u) && lane == 0 && nseg < a.segCap) {
+          segs[nseg * 4 + 0] = __uint_as_float(q2.y); segs[nseg * 4 + 1] = __uint_as_float(q2.z);
+          segs[nseg * 4 + 2] = __uint_as_float(q2.w); segs[nseg * 4 + 3] = __uint_as_float(q3.x);
+        }
+        nseg += (fl >> 2) & 1u;
+      }
+    }
+    if (bad) {
+      // an older transaction took a pixel this one accepted (or left one this one counted on): run it again here --
+      // everything older is committed, so this is the reference's run
+      PF_ADD(ch, 24, 1);
+      const uint32_t seedPk = bcast_u32(q0.y, 0);
+      const unsigned seedRec = bcast_u32(ch.P[pk_lin(ch, seedPk)], 0);
+      ch.hTag = ((unsigned)h & 127u) + 1u;
+      ch.hWin = 0;   // nothing older is in flight: no claim is believed
+      if (!(seedRec & LSD_USED)) {
+        const MwTxn t = lsd_txn_mw(ch, gs, a, drainReg, seedPk, seedRec, bcast_u32(q0.z, 0), bcast_u32(q0.w, 0), bcast_u32(q1.x, 0));
+        grow_lane_fence<true>();
+        for (int i = lane; i < t.finCnt; i += 64) {
+          const uint32_t li = pk_lin(ch, drainReg[t.finBase + i]);
+          ch.P[li] |= LSD_USED;
+          ch.M[li] = 0;
+        }
+        if (t.emit) {
+          if (lane == 0 && nseg < a.segCap) {
+            float sg[4];
+            mw_segment(gs.d + 1, sg);
+            segs[nseg * 4 + 0] = sg[0]; segs[nseg * 4 + 1] = sg[1]; segs[nseg * 4 + 2] = sg[2]; segs[nseg * 4 + 3] = sg[3];
+          }
+          nseg++;
+        }
+      }
+    }
+    PLH_WAVE_SYNC();
+    if (!inl && ((fl & 1u) || asmLen > 3))
+      if (lane == 0) sh.ctl[MWC_RET + wv] += 1;   // the owner may reuse the log's space (only the lock holder writes these)
+    h++;
+  }
+  if (h != h0) {
+    mw_release();   // the USED bits are in place before `head` says so: a transaction that starts as the oldest trusts them
+    if (lane == 0) {
+      mw_st(&sh.ctl[MWC_NSEG], nseg);
+      mw_st(&sh.ctl[MWC_HEAD], h);
+    }
+  }
+  PLH_WAVE_SYNC();
+}
+
+// take the drain lock if there is something to commit and nobody is at it; returns whether anything was done
+__device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
+                             uint32_t* drainReg, float* segs) {
+  bool did = false;
+  for (;;) {
+    const int h = mw_ld_u(&sh.ctl[MWC_HEAD]);
+    if (mw_ld_u(&sh.state[h & (MW_N - 1)]) != h + 1) break;
+    if (!mw_try_lock(&sh.ctl[MWC_DLOCK], ch.lane)) break;
+    mw_acquire();
+    const unsigned long long pd0 = PF_NOW();
+    mw_drain(ch, gs, a, sh, frameReg, drainReg, segs);
+    PF_ADD(ch, 23, PF_NOW() - pd0); PF_ADD(ch, 25, 1);
+    if (ch.lane == 0) mw_st(&sh.ctl[MWC_DLOCK], 0);
+    PLH_WAVE_SYNC();
+    did = true;   // and look again: a transaction posted while the lock was held found it taken
+  }
+  return did;
 }
 
 __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsigned char* smem) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, W = (int)(blockDim.x >> 6);
-  int* ctl = (int*)smem;
-  int* state = ctl + MWC_WORDS;
-  uint4* fifo = (uint4*)(state + MW_N);
-  unsigned char* wsm = (unsigned char*)(fifo + MW_N) + wv * MW_WAVE_LDS;
+  MwShared sh;
+  sh.ctl = (int*)smem;
+  sh.state = sh.ctl + MWC_WORDS;
+  sh.fifo = (uint4*)(sh.state + MW_N);
+  sh.pend = (MwPost*)(sh.fifo + MW_N);
+  int* const ctl = sh.ctl;
+  unsigned char* wsm = (unsigned char*)(sh.pend + MW_N) + wv * MW_WAVE_LDS;
+  const long long S = a.mwRegStride / 5;   // words: an arena holds posted logs below S, a running transaction (3 S) and scratch (S)
+  uint32_t* const frameReg = a.mwReg + (long long)b * (W + 1) * a.mwRegStride;
+  uint8_t* const frameMark = a.mwMark + (long long)b * (W + 1) * a.mwMarkStride;
   GrowCtx c;
   c.ring = (uint32_t*)wsm;
   c.T = (double*)wsm;
   c.P = a.pix + (long long)b * a.arenaStride;
   c.A = a.angleTab;
-  uint32_t* const regBase = a.mwReg + ((long long)b * W + wv) * a.mwRegStride;
+  uint32_t* const regBase = frameReg + (long long)wv * a.mwRegStride;
   c.reg = regBase;
-  c.scr = regBase + 3 * (a.mwRegStride >> 2);
-  c.M = a.mwMark + ((long long)b * W + wv) * a.mwMarkStride;
+  c.scr = regBase + 4 * S;
+  c.M = frameMark + (long long)wv * a.mwMarkStride;
+  c.H = a.mwHint + (long long)b * a.mwMarkStride;
+  c.hTag = 1; c.hWin = 0;
+  c.asmList = (uint32_t*)(wsm + LSD_RING * 4 + 6 * 8 + 8 * 4);
+  c.asmCnt = c.asmList + MW_ASM_CAP;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
   GrowState gs;
@@ -1214,7 +1466,18 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   c.pf = pfv;
   const unsigned long long pfStart = PF_NOW();
 #endif
-  for (int i = tid; i < MWC_WORDS + MW_N; i += (int)blockDim.x) ctl[i] = 0;   // control words and retire ring
+  GrowCtx ch = c;   // the drain context: slot W of the frame
+  uint32_t* const drainReg = frameReg + (long long)W * a.mwRegStride;
+  ch.reg = drainReg;
+  ch.scr = drainReg + 4 * S;
+  ch.M = frameMark + (long long)W * a.mwMarkStride;
+  for (int i = tid; i < MWC_WORDS + MW_N; i += (int)blockDim.x) ctl[i] = 0;   // control words and sequence tags
+  {   // no claims yet (the plane holds the previous launch's)
+    uint4* H4 = reinterpret_cast<uint4*>(c.H);
+    const int n16 = (a.spitch * a.sh) >> 4;   // the pitch is a multiple of 64
+    for (int i = tid; i < n16; i += (int)blockDim.x) H4[i] = uint4{0u, 0u, 0u, 0u};
+    mw_release();
+  }
   if (a.batch <= 8) {
     // a handful of frames: pull the frame's records and the table entries they point to through this XCD's L2, all loads
     // in flight, before the dependent fetches of region growing start (as k_lsd_grow_lone does)
@@ -1238,52 +1501,52 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     if (acc) atomicOr(a.status, 8);   // keeps the loads alive; never taken
   }
   __syncthreads();
+  int off = 0, posted = 0;   // this wavefront's arena: posted logs lie in [0, off); `posted` of them so far
+  unsigned polls = 0;        // consecutive fruitless waits (watchdog)
   for (;;) {
-    // ---- the next seed: pop the FIFO; refill it when it runs low (one wavefront at a time)
+    // ---- may this wavefront start another transaction?  Not with its arena full of posted logs, and not further than
+    // mwLag sequence numbers ahead of the commits (a stale map makes wasted runs).  While it cannot, it helps committing.
+    if (off > 0 && mw_ld_u(&ctl[MWC_RET + wv]) == posted) off = 0;
+    const int done = mw_ld_u(&ctl[MWC_DONE]), pop = mw_ld_u(&ctl[MWC_POP]), push = mw_ld_u(&ctl[MWC_PUSH]);
+    const int head = mw_ld_u(&ctl[MWC_HEAD]);
     int s = -1;
     uint4 ent = uint4{0u, 0u, 0u, 0u};
-    const unsigned long long pw0 = PF_NOW();
-    for (;;) {
-      const int done = mw_ld_u(&ctl[MWC_DONE]), pop = mw_ld_u(&ctl[MWC_POP]), push = mw_ld_u(&ctl[MWC_PUSH]);
-      if (!done && push - pop < MW_LOW) {
-        int got = 0;
-        if (lane == 0) got = mw_cas(&ctl[MWC_LOCK], 0, 1) == 0;
-        got = (int)bcast_u32((unsigned)got, 0);
-        if (got) {
-          const unsigned long long ps0 = PF_NOW();
-          mw_scan(c, ctl, fifo, ord, nOrd);
-          PLH_WAVE_SYNC();
-          if (lane == 0) mw_st(&ctl[MWC_LOCK], 0);
-          PF_ADD(c, 20, PF_NOW() - ps0);
-          continue;
-        }
-      }
-      if (pop < push) {
-        ent = fifo[pop & (MW_N - 1)];   // read before the pop: the slot may be refilled right after it
-        ent.x = bcast_u32(ent.x, 0); ent.y = bcast_u32(ent.y, 0); ent.z = bcast_u32(ent.z, 0); ent.w = bcast_u32(ent.w, 0);
-        int ok = 0;
-        if (lane == 0) ok = mw_cas(&ctl[MWC_POP], pop, pop + 1) == pop;
-        ok = (int)bcast_u32((unsigned)ok, 0);
-        if (ok) { s = pop; break; }
-        continue;
-      }
-      if (done) break;
-      // nothing queued and another wavefront is refilling: lane 0 waits for its entries (or for the lock to come free)
-      if (lane == 0) {
-        unsigned polls = 0;
-        while (mw_ld(&ctl[MWC_PUSH]) == push && !mw_ld(&ctl[MWC_DONE]) && mw_ld(&ctl[MWC_LOCK]) != 0 &&
-               !mw_give_up(ctl, polls, a.status))
-          mw_pause();
-      }
+    if (!done && push - pop < MW_LOW && mw_try_lock(&ctl[MWC_LOCK], lane)) {
+      const unsigned long long ps0 = PF_NOW();
+      mw_scan(c, ctl, sh.fifo, ord, nOrd);
       PLH_WAVE_SYNC();
-      if (mw_ld_u(&ctl[MWC_ABORT])) break;
+      if (lane == 0) mw_st(&ctl[MWC_LOCK], 0);
+      PF_ADD(c, 20, PF_NOW() - ps0);
+      polls = 0;
+      continue;
     }
-    PF_ADD(c, 21, PF_NOW() - pw0);
-    if (s < 0) break;
+    if (pop < push && off <= S && pop - head < a.mwLag) {
+      ent = sh.fifo[pop & (MW_N - 1)];   // read before the pop: the slot may be refilled right after it
+      ent.x = bcast_u32(ent.x, 0); ent.y = bcast_u32(ent.y, 0); ent.z = bcast_u32(ent.z, 0); ent.w = bcast_u32(ent.w, 0);
+      int ok = 0;
+      if (lane == 0) ok = mw_cas(&ctl[MWC_POP], pop, pop + 1) == pop;
+      ok = (int)bcast_u32((unsigned)ok, 0);
+      if (!ok) continue;
+      s = pop;
+    }
+    if (s < 0) {
+      if (done && pop >= push && head >= push) break;   // every seed handed out and committed
+      const unsigned long long pw0 = PF_NOW();
+      if (mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs)) { polls = 0; continue; }
+      int stop = 0;
+      if (lane == 0) { stop = mw_give_up(ctl, polls, a.status); mw_pause(); }
+      if (bcast_u32((unsigned)stop, 0)) break;
+      PF_ADD(c, 19, PF_NOW() - pw0);
+      continue;
+    }
+    polls = 0;
+    // ---- the transaction
     const uint32_t seedPk = ent.x;
     const uint32_t seedLin = pk_lin(c, seedPk);
-    bool spec = mw_ld_u(&ctl[MWC_HEAD]) != s, aborted = false;   // older transactions are still in flight: what this one reads may be stale
+    const bool spec = head != s;   // older transactions are still in flight: what this one reads may be stale
     PF_ADD(c, 16, 1);
+    MwPost post = {};
+    c.hTag = ((unsigned)s & 127u) + 1u;
     for (;;) {
       mw_acquire();
       const unsigned seedRec = bcast_u32(c.P[seedLin], 0);
@@ -1291,58 +1554,80 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
         PF_ADD(c, 17, 1);
         break;
       }
-      const unsigned long long pt0 = PF_NOW();
-      const MwTxn t = lsd_txn_mw(c, gs, a, regBase, seedPk, seedRec, ent.y, ent.z, ent.w);
-      const unsigned long long pt1 = PF_NOW();
-      PF_ADD(c, 22, pt1 - pt0);
-      // ---- commit, in sequence order
-      if (lane == 0) {
-        unsigned polls = 0;
-        while (mw_ld(&ctl[MWC_HEAD]) != s && !mw_give_up(ctl, polls, a.status)) mw_pause();
+      c.hWin = (unsigned)max(s - mw_ld_u(&ctl[MWC_HEAD]), 0);
+      if (grow_older_claim(c, bcast_u32((unsigned)c.H[seedLin], 0))) {
+        // an older transaction in flight holds the seed: predicted to be swallowed -- nothing to run, the commit checks
+        PF_ADD(c, 28, 1);
+        post.w[MWP_FLAGS] = 2u | 8u | ((unsigned)wv << 8) | (1u << 16);
+        post.w[MWP_PIX] = seedPk;
+        break;
       }
-      PLH_WAVE_SYNC();
-      if (mw_ld_u(&ctl[MWC_ABORT])) { aborted = true; break; }
-      mw_acquire();
-      const unsigned long long pt2 = PF_NOW();
-      PF_ADD(c, 19, pt2 - pt1);
-      if (spec) {
-        bool bad = false;
+      const unsigned long long pt0 = PF_NOW();
+      const MwTxn t = lsd_txn_mw(c, gs, a, regBase + off, seedPk, seedRec, ent.y, ent.z, ent.w);
+      grow_lane_fence<true>();
+      // through: take the private marks back (the plane is clean for the next transaction) and look once more whether an
+      // older transaction has committed a pixel of the log meanwhile
+      const uint32_t* log = regBase + off;
+      const unsigned long long pv0 = PF_NOW();
+      const int asmLen = (int)bcast_u32(*c.asmCnt, 0);
+      // a region that was dropped for its size without a refine() is all in the LDS mirror of its queue: its post goes inline
+      const bool inl = !t.emit && t.finBase == 0 && t.finCnt == t.logLen && t.logLen + asmLen <= MW_INLINE_MAX;
+      bool bad = t.conflict;
+      if (!bad) {
         for (int base = 0; base < t.logLen; base += 64) {
           const int i = base + lane;
-          if (i < t.logLen) bad = bad || (c.P[pk_lin(c, regBase[i])] & LSD_USED) != 0u;
+          if (i < t.logLen) bad = bad || (c.P[pk_lin(c, inl ? c.ring[i] : log[i])] & LSD_USED) != 0u;
         }
-        if (__ballot(bad) != 0ull) {
-          // an older transaction took a pixel this one accepted: take the marks back and run again, now as the oldest
-          for (int i = lane; i < t.logLen; i += 64) c.M[pk_lin(c, regBase[i])] = 0;
-          grow_lane_fence<true>();
-          spec = false;
-          PF_ADD(c, 18, 1);
-          continue;
-        }
+        bad = spec && __ballot(bad) != 0ull;
       }
-      {
-        const uint32_t* fin = regBase + t.finBase;
-        for (int i = lane; i < t.finCnt; i += 64) {
-          const uint32_t li = pk_lin(c, fin[i]);
-          c.P[li] |= LSD_USED;
-          c.M[li] = 0;
+      if (bad) {
+        for (int i = lane; i < t.logLen; i += 64) {
+          const uint32_t li = pk_lin(c, log[i]);
+          c.M[li] = 0; c.H[li] = 0;
         }
+        grow_lane_fence<true>();
+        PF_ADD(c, 18, 1); PF_ADD(c, 22, PF_NOW() - pt0);
+        continue;   // again, against a fresher map
       }
-      if (t.emit && lane == 0) {
-        const double* rec = gs.d + 1;
-        const int ns = ctl[MWC_NSEG];   // only the committing wavefront touches it
-        if (ns < a.segCap) {
-          segs[ns * 4 + 0] = (float)((rec[0] + 0.5) / 0.8); segs[ns * 4 + 1] = (float)((rec[1] + 0.5) / 0.8);
-          segs[ns * 4 + 2] = (float)((rec[2] + 0.5) / 0.8); segs[ns * 4 + 3] = (float)((rec[3] + 0.5) / 0.8);
+      if (inl) {
+        if (lane < t.logLen) c.M[pk_lin(c, c.ring[lane])] = 0;
+        post.w[MWP_FLAGS] = 1u | (spec ? 2u : 0u) | 8u | ((unsigned)wv << 8) | ((unsigned)asmLen << 16) | ((unsigned)t.logLen << 24);
+        for (int k = 0; k < t.logLen; k++) post.w[MWP_PIX + k] = bcast_u32(c.ring[k], 0);
+        for (int k = 0; k < asmLen; k++) post.w[MWP_PIX + t.logLen + k] = bcast_u32(c.asmList[k], 0);
+      } else {
+        for (int i = lane; i < t.finCnt; i += 64) c.M[pk_lin(c, log[t.finBase + i])] = 0;
+        const int used = max(t.logLen, t.finBase + t.finCnt);
+        post.w[MWP_FLAGS] = 1u | (spec ? 2u : 0u) | (t.emit ? 4u : 0u) | ((unsigned)wv << 8) | ((unsigned)asmLen << 16);
+        post.w[MWP_OFF] = (unsigned)off; post.w[MWP_LOGLEN] = (unsigned)t.logLen;
+        post.w[MWP_FINBASE] = (unsigned)t.finBase; post.w[MWP_FINCNT] = (unsigned)t.finCnt;
+        if (t.emit) {
+          float sg[4];
+          mw_segment(gs.d + 1, sg);
+          for (int k = 0; k < 4; k++) post.w[MWP_SEG + k] = __float_as_uint(sg[k]);
         }
-        ctl[MWC_NSEG] = ns + 1;
+        if (asmLen <= 3) {
+          for (int k = 0; k < asmLen; k++) post.w[MWP_ASM + k] = bcast_u32(c.asmList[k], 0);
+          off += used;
+        } else {
+          if (lane < asmLen) regBase[off + used + lane] = c.asmList[lane];
+          off += used + asmLen;
+        }
+        posted++;
       }
-      mw_release();
-      PF_ADD(c, 23, PF_NOW() - pt2);
+      PF_ADD(c, 22, PF_NOW() - pt0); PF_ADD(c, 26, PF_NOW() - pv0);
       break;
     }
-    if (aborted) break;
-    mw_retire(ctl, state, s, lane);
+    if (post.w[MWP_FLAGS] == 0u) post.w[MWP_FLAGS] = 8u;   // the seed was used already: nothing to check, nothing to do
+    post.w[MWP_SEED] = seedPk; post.w[MWP_SEED + 1] = ent.y; post.w[MWP_SEED + 2] = ent.z; post.w[MWP_SEED + 3] = ent.w;
+    const unsigned long long pp0 = PF_NOW();
+    if (!(post.w[MWP_FLAGS] & 8u)) mw_release();   // a log in global memory is complete before its post is visible
+    if (lane == 0) {
+      sh.pend[s & (MW_N - 1)] = post;
+      mw_st(&sh.state[s & (MW_N - 1)], s + 1);
+    }
+    PLH_WAVE_SYNC();
+    PF_ADD(c, 27, PF_NOW() - pp0);
+    mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs);
   }
   __syncthreads();
   if (tid == 0) {
@@ -1822,7 +2107,7 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
 size_t lsd_grow_lds_bytes(int spitch, int sh);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
   if (a.mwWaves > 0) {
-    const size_t ldsMw = (size_t)MWC_WORDS * 4 + (size_t)MW_N * 4 + (size_t)MW_N * 16 + (size_t)a.mwWaves * MW_WAVE_LDS;
+    const size_t ldsMw = (size_t)MWC_WORDS * 4 + (size_t)MW_N * (4 + 16 + MW_PEND_WORDS * 4) + (size_t)a.mwWaves * MW_WAVE_LDS;
     hipLaunchKernelGGL(k_lsd_grow_mw, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
     return;
   }
