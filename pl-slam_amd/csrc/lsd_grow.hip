@@ -41,9 +41,17 @@ __device__ unsigned long long g_grow_prof[32];   // [16..31]: k_lsd_grow_mw (tra
 #else
 #define PF_NOW() __builtin_amdgcn_s_memtime()
 #endif
+// the per-step clocks of region_grow() (s_memtime is a scalar memory read: it costs a wavefront hundreds of cycles) only with
+// -DPLH_GROW_PROF=2; the transaction-level ones of k_lsd_grow_mw with any PLH_GROW_PROF
+#if PLH_GROW_PROF + 0 >= 2
+#define PF_NOW_FINE() PF_NOW()
+#else
+#define PF_NOW_FINE() 0ull
+#endif
 #define PF_ADD(c, k, v) ((c).pf[k] += (unsigned long long)(v))
 #else
 #define PF_NOW() 0ull
+#define PF_NOW_FINE() 0ull
 #define PF_ADD(c, k, v) ((void)sizeof(v))
 #endif
 constexpr int LSD_RING = 512;    // 2 KiB; the chain buffer T (1.5 KiB) aliases it (never live at the same time)
@@ -513,7 +521,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   int cnt = 1, i = 0;
   PLH_WAVE_SYNC();
   if (firstGrp >= 0) {
-    const unsigned long long pt1 = PF_NOW();
+    const unsigned long long pt1 = PF_NOW_FINE();
     // the seed's 8 neighbours were prefetched into LDS by lane group firstGrp; their marks may have changed since
     LsdCand first;
     first.nidx = gs.fstIdx[lane];
@@ -526,7 +534,7 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     // fetched with the neighbourhood for every DEFINED pixel, so a pixel that refine() un-marked in between has them too)
     const unsigned long long candM = wballot(first.inb) & wballot(rec_is_candidate(first.px.q));
     lsd_resolve<MW>(c, candM, first, false, tol, sumdx, sumdy, regAngF, angValid, cnt);
-    PF_ADD(c, 4, PF_NOW() - pt1); PF_ADD(c, 8, 1);
+    PF_ADD(c, 4, PF_NOW_FINE() - pt1); PF_ADD(c, 8, 1);
     i = 1;
   }
   if (i >= cnt) {
@@ -545,14 +553,14 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     grow_note_assumed<MW>(c, assumed, cur.npk);
   }
   while (i < cnt) {
-    const unsigned long long pt0 = PF_NOW();
+    const unsigned long long pt0 = PF_NOW_FINE();
     const int m = min(LSD_PTS, cnt - i);
     // lanes with nothing to examine loaded the NOTDEF pixel (sw-1, 0): one signed compare on the record word decides
     const unsigned long long candM = wballot(rec_is_candidate(cur.px.q));
-    const unsigned long long pt1 = PF_NOW();
+    const unsigned long long pt1 = PF_NOW_FINE();
     PF_ADD(c, 3, pt1 - pt0); PF_ADD(c, 8, 1);
     lsd_resolve<MW>(c, candM, cur, true, tol, sumdx, sumdy, regAngF, angValid, cnt);
-    PF_ADD(c, 4, PF_NOW() - pt1);
+    PF_ADD(c, 4, PF_NOW_FINE() - pt1);
     i += m;
     // the next step's records, requested after this step's marks were stored (a wavefront observes its own stores);
     // every lane loads (record 0 when it has nothing to examine) so the carried registers are simply overwritten
@@ -1063,7 +1071,7 @@ __device__ __forceinline__ int mw_cas(int* p, int cmp, int v) {
   __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return cmp;
 }
-__device__ __forceinline__ void mw_pause() { __builtin_amdgcn_s_sleep(1); }
+__device__ __forceinline__ void mw_pause() { __builtin_amdgcn_s_sleep(4); }
 // publish: this wavefront's global stores are complete (L1 / L2 of its CU) before the LDS word that hands them over
 __device__ __forceinline__ void mw_release() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1319,6 +1327,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       const int gb = badM ? min((__ffsll((long long)badM) - 1) >> 3, nb) : nb;   // posts in front of the first failure
       if (has && isAcc && g < gb) ch.P[idx] = p | LSD_USED;
       h += gb;
+      PF_ADD(ch, 12, gb);
       if (gb == nb) continue;
       // post h failed: run it again below (general path handles both forms)
     }
@@ -1370,6 +1379,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       // an older transaction took a pixel this one accepted (or left one this one counted on): run it again here --
       // everything older is committed, so this is the reference's run
       PF_ADD(ch, 24, 1);
+      const unsigned long long pr0 = PF_NOW();
       const uint32_t seedPk = bcast_u32(q0.y, 0);
       const unsigned seedRec = bcast_u32(ch.P[pk_lin(ch, seedPk)], 0);
       ch.hTag = ((unsigned)h & 127u) + 1u;
@@ -1391,7 +1401,9 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
           nseg++;
         }
       }
+      PF_ADD(ch, 10, PF_NOW() - pr0);
     }
+    PF_ADD(ch, 13, 1);
     PLH_WAVE_SYNC();
     if (!inl && ((fl & 1u) || asmLen > 3))
       if (lane == 0) sh.ctl[MWC_RET + wv] += 1;   // the owner may reuse the log's space (only the lock holder writes these)
@@ -1545,7 +1557,12 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     const uint32_t seedLin = pk_lin(c, seedPk);
     const bool spec = head != s;   // older transactions are still in flight: what this one reads may be stale
     PF_ADD(c, 16, 1);
-    MwPost post = {};
+    // the post, one word per lane (MwPost): what the transaction leaves behind for its commit
+    unsigned pFlags = 8u;   // the seed was used already: nothing to check, nothing to do
+    int pMode = 0;          // 1: predicted unused, 2: inline, 3: general
+    unsigned pGen[4] = {0u, 0u, 0u, 0u};   // general form: off, logLen, finBase, finCnt
+    float pSeg[4] = {0.f, 0.f, 0.f, 0.f};
+    int pAcc = 0, pAsm = 0;
     c.hTag = ((unsigned)s & 127u) + 1u;
     for (;;) {
       mw_acquire();
@@ -1558,8 +1575,8 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       if (grow_older_claim(c, bcast_u32((unsigned)c.H[seedLin], 0))) {
         // an older transaction in flight holds the seed: predicted to be swallowed -- nothing to run, the commit checks
         PF_ADD(c, 28, 1);
-        post.w[MWP_FLAGS] = 2u | 8u | ((unsigned)wv << 8) | (1u << 16);
-        post.w[MWP_PIX] = seedPk;
+        pFlags = 2u | 8u | ((unsigned)wv << 8) | (1u << 16);
+        pMode = 1;
         break;
       }
       const unsigned long long pt0 = PF_NOW();
@@ -1589,24 +1606,19 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
         PF_ADD(c, 18, 1); PF_ADD(c, 22, PF_NOW() - pt0);
         continue;   // again, against a fresher map
       }
+      pAcc = t.logLen; pAsm = asmLen;
       if (inl) {
         if (lane < t.logLen) c.M[pk_lin(c, c.ring[lane])] = 0;
-        post.w[MWP_FLAGS] = 1u | (spec ? 2u : 0u) | 8u | ((unsigned)wv << 8) | ((unsigned)asmLen << 16) | ((unsigned)t.logLen << 24);
-        for (int k = 0; k < t.logLen; k++) post.w[MWP_PIX + k] = bcast_u32(c.ring[k], 0);
-        for (int k = 0; k < asmLen; k++) post.w[MWP_PIX + t.logLen + k] = bcast_u32(c.asmList[k], 0);
+        pFlags = 1u | (spec ? 2u : 0u) | 8u | ((unsigned)wv << 8) | ((unsigned)asmLen << 16) | ((unsigned)t.logLen << 24);
+        pMode = 2;
       } else {
         for (int i = lane; i < t.finCnt; i += 64) c.M[pk_lin(c, log[t.finBase + i])] = 0;
         const int used = max(t.logLen, t.finBase + t.finCnt);
-        post.w[MWP_FLAGS] = 1u | (spec ? 2u : 0u) | (t.emit ? 4u : 0u) | ((unsigned)wv << 8) | ((unsigned)asmLen << 16);
-        post.w[MWP_OFF] = (unsigned)off; post.w[MWP_LOGLEN] = (unsigned)t.logLen;
-        post.w[MWP_FINBASE] = (unsigned)t.finBase; post.w[MWP_FINCNT] = (unsigned)t.finCnt;
-        if (t.emit) {
-          float sg[4];
-          mw_segment(gs.d + 1, sg);
-          for (int k = 0; k < 4; k++) post.w[MWP_SEG + k] = __float_as_uint(sg[k]);
-        }
+        pFlags = 1u | (spec ? 2u : 0u) | (t.emit ? 4u : 0u) | ((unsigned)wv << 8) | ((unsigned)asmLen << 16);
+        pMode = 3;
+        pGen[0] = (unsigned)off; pGen[1] = (unsigned)t.logLen; pGen[2] = (unsigned)t.finBase; pGen[3] = (unsigned)t.finCnt;
+        if (t.emit) mw_segment(gs.d + 1, pSeg);
         if (asmLen <= 3) {
-          for (int k = 0; k < asmLen; k++) post.w[MWP_ASM + k] = bcast_u32(c.asmList[k], 0);
           off += used;
         } else {
           if (lane < asmLen) regBase[off + used + lane] = c.asmList[lane];
@@ -1617,13 +1629,25 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       PF_ADD(c, 22, PF_NOW() - pt0); PF_ADD(c, 26, PF_NOW() - pv0);
       break;
     }
-    if (post.w[MWP_FLAGS] == 0u) post.w[MWP_FLAGS] = 8u;   // the seed was used already: nothing to check, nothing to do
-    post.w[MWP_SEED] = seedPk; post.w[MWP_SEED + 1] = ent.y; post.w[MWP_SEED + 2] = ent.z; post.w[MWP_SEED + 3] = ent.w;
     const unsigned long long pp0 = PF_NOW();
-    if (!(post.w[MWP_FLAGS] & 8u)) mw_release();   // a log in global memory is complete before its post is visible
-    if (lane == 0) {
-      sh.pend[s & (MW_N - 1)] = post;
-      mw_st(&sh.state[s & (MW_N - 1)], s + 1);
+    {
+      unsigned pw = 0u;   // word `lane` of the post
+      if (lane == MWP_FLAGS) pw = pFlags;
+      else if (lane < MWP_PIX) pw = lane == 1 ? seedPk : (lane == 2 ? ent.y : (lane == 3 ? ent.z : ent.w));
+      else if (pMode == 1) pw = seedPk;   // (only word MWP_PIX is read)
+      else if (pMode == 2) {
+        const int k = lane - MWP_PIX;
+        if (k < pAcc) pw = c.ring[k];
+        else if (k < pAcc + pAsm) pw = c.asmList[k - pAcc];
+      } else if (pMode == 3) {
+        if (lane < MWP_SEG) pw = lane == MWP_OFF ? pGen[0] : (lane == MWP_LOGLEN ? pGen[1] : (lane == MWP_FINBASE ? pGen[2] : pGen[3]));
+        else if (lane < MWP_ASM) pw = __float_as_uint(lane == MWP_SEG ? pSeg[0] : (lane == MWP_SEG + 1 ? pSeg[1] : (lane == MWP_SEG + 2 ? pSeg[2] : pSeg[3])));
+        else if (lane - MWP_ASM < min(pAsm, 3)) pw = c.asmList[lane - MWP_ASM];
+      }
+      if (!(pFlags & 8u)) mw_release();   // a log in global memory is complete before its post is visible
+      if (lane < MW_PEND_WORDS) sh.pend[s & (MW_N - 1)].w[lane] = pw;
+      PLH_WAVE_SYNC();
+      if (lane == 0) mw_st(&sh.state[s & (MW_N - 1)], s + 1);   // after the words (LDS operations of a wavefront execute in order)
     }
     PLH_WAVE_SYNC();
     PF_ADD(c, 27, PF_NOW() - pp0);
@@ -1672,7 +1696,12 @@ __global__ void __launch_bounds__(64) k_lsd_grow_lone(LineDeviceArgs a) {
   lsd_grow_frame(a, smem);
 }
 
-__global__ void __launch_bounds__(1024) k_lsd_grow_mw(LineDeviceArgs a) {
+// up to 8 wavefronts per frame: 256 registers to spare; 9 .. 16: half of that (the workgroup is 1024 threads)
+__global__ void __launch_bounds__(512) k_lsd_grow_mw(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  lsd_grow_frame_mw(a, smem);
+}
+__global__ void __launch_bounds__(1024) k_lsd_grow_mw16(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   lsd_grow_frame_mw(a, smem);
 }
@@ -2108,7 +2137,9 @@ size_t lsd_grow_lds_bytes(int spitch, int sh);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
   if (a.mwWaves > 0) {
     const size_t ldsMw = (size_t)MWC_WORDS * 4 + (size_t)MW_N * (4 + 16 + MW_PEND_WORDS * 4) + (size_t)a.mwWaves * MW_WAVE_LDS;
-    hipLaunchKernelGGL(k_lsd_grow_mw, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
+    // (the roomy build holds three wavefronts per SIMD: beyond two per SIMD over the whole GPU take the 128-register one)
+    if (a.mwWaves <= 8 && (long long)a.batch * a.mwWaves <= 2048) hipLaunchKernelGGL(k_lsd_grow_mw, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
+    else hipLaunchKernelGGL(k_lsd_grow_mw16, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
     return;
   }
   const size_t lds = lsd_grow_lds_bytes(a.spitch, a.sh);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase breakdown of k_lsd_grow (debug build with -DPLH_GROW_PROF, see lsd_grow.hip).
 
-    hipcc ... -DPLH_GROW_PROF -o pl-slam_amd/libplslam_hip_prof.so pl-slam_amd/csrc/*.hip
+    hipcc ... -DPLH_GROW_PROF=2 -o pl-slam_amd/libplslam_hip_prof.so pl-slam_amd/csrc/*.hip
     PLSLAM_HIP_LIB=pl-slam_amd/libplslam_hip_prof.so python tools/grow_prof.py [--batch 1024]
 
 Prints the s_memtime cycle totals of every phase summed over all waves (one wave per frame), per frame.
