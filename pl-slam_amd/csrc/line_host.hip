@@ -70,7 +70,7 @@ struct plh_line {
   // multi-wavefront region growing (small batches): transaction logs and private mark planes, allocated on first use
   uint32_t* dMwReg = nullptr;
   uint8_t* dMwMark = nullptr;
-  uint8_t* dMwHint = nullptr;
+  uint16_t* dMwHint = nullptr;
   long long mwHintFrames = 0;
   long long mwWaveSlots = 0;   // (frame, wavefront) pairs the two buffers hold
   int growWaves = -1;          // plh_line_set_grow_waves
@@ -369,9 +369,10 @@ static int mw_waves_for(const plh_line* h, int batch) {
     if (e) forced = atoi(e);
   }
   if (forced >= 0) return forced == 1 ? 0 : std::min(forced, 16);
-  if (batch <= 64) return 8;
-  if (batch <= 512) return 4;
-  if (batch <= 1024) return 2;
+  // measured on MI355X, 640 x 480 (tools/mw_sweep.py, profiles/r03_mw_sweep.txt): 1 frame 45 -> 16 ms with 8 wavefronts (16: the
+  // same), 512 frames 58 -> 28 ms with 8, 1024 frames 64 -> 41 ms with 4; from 2048 frames on one wavefront per frame is as fast
+  if (batch <= 512) return 8;
+  if (batch <= 1024) return 4;
   return 0;
 }
 
@@ -381,7 +382,9 @@ static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int wave
   a.mwMarkStride = a.scaledStride;
   {
     const char* e = getenv("PLH_GROW_MW_LAG");   // tuning aid
-    a.mwLag = std::min(std::max(e ? atoi(e) : 56, 1), 60);   // claim tags are sequence numbers mod 128: twice the lag stays below that
+    a.mwLag = std::min(std::max(e ? atoi(e) : 448, 1), 448);   // below the ring of posted transactions (512) by more than the wavefronts' own
+    const char* g = getenv("PLH_GROW_MW_GAP");
+    a.mwDrainGap = std::max(g ? atoi(g) : 8, 1);
   }
   const long long slots = (long long)batch * (waves + 1);
   if (slots > h->mwWaveSlots) {
@@ -402,7 +405,7 @@ static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int wave
     PLH_HIP(hipStreamSynchronize(h->lastStream));
     if (h->dMwHint) (void)hipFree(h->dMwHint);
     h->dMwHint = nullptr; h->mwHintFrames = 0;
-    if (hipMalloc((void**)&h->dMwHint, (size_t)batch * a.mwMarkStride) != hipSuccess) {
+    if (hipMalloc((void**)&h->dMwHint, (size_t)batch * a.mwMarkStride * 2) != hipSuccess) {
       (void)hipGetLastError();
       set_error("plh_line_extract: cannot allocate the claim-hint planes (%d frames)", batch);
       return PLH_ERR_ALLOC;

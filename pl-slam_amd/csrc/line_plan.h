@@ -92,10 +92,11 @@ struct LineDeviceArgs {
   // plane of mwMarkStride bytes (zero between transactions); null when the batch runs one wavefront per frame
   uint32_t* mwReg;
   uint8_t* mwMark;
-  uint8_t* mwHint;          // per frame: claim hints shared by its wavefronts (mwMarkStride bytes, cleared by the kernel)
+  uint16_t* mwHint;         // per frame: claim hints shared by its wavefronts (mwMarkStride 16-bit tags, cleared by the kernel)
   long long mwRegStride, mwMarkStride;
   int mwWaves;              // wavefronts per frame of this launch (0: k_lsd_grow / k_lsd_grow_lone)
   int mwLag;                // a wavefront starts no transaction further than this ahead of the commits
+  int mwDrainGap;           // a wavefront that posted tries to commit when the commits are this far behind it (or it is the oldest)
 };
 
 }  // namespace plh

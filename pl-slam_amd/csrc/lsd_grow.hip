@@ -18,8 +18,8 @@ struct GrowCtx {
   uint32_t* reg;       // region queue (global memory); entries are packed coordinates x | y << 16
   uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
   uint8_t* M;          // multi-wavefront build only: this wavefront's private `used` marks, one byte per pixel (k_lsd_grow_mw)
-  uint8_t* H;          // ... and the frame's claim hints, shared by its wavefronts: tag of the transaction that last marked the pixel
-  unsigned hTag;       // this transaction's tag, (sequence number & 127) + 1
+  uint16_t* H;         // ... and the frame's claim hints, shared by its wavefronts: tag of the transaction that last marked the pixel
+  unsigned hTag;       // this transaction's tag, (sequence number mod 65535) + 1
   unsigned hWin;       // how many sequence numbers below this one may still be uncommitted (0: none -- hints are ignored)
   uint32_t* asmList;   // LDS: pixels this run took for used on the strength of an older transaction's claim (packed coordinates)
   uint32_t* asmCnt;    // LDS word: their count (MW_ASM_CAP = full: no further assumptions)
@@ -36,7 +36,7 @@ struct GrowCtx {
 };
 #if defined(PLH_GROW_PROF)
 __device__ unsigned long long g_grow_prof[32];   // [16..31]: k_lsd_grow_mw (transactions, retired unused, reruns, wait / scan / run / commit cycles)
-#if defined(HIPEMU)
+#if defined(HIPEMU) || PLH_GROW_PROF + 0 >= 3
 #define PF_NOW() 0ull
 #else
 #define PF_NOW() __builtin_amdgcn_s_memtime()
@@ -49,10 +49,28 @@ __device__ unsigned long long g_grow_prof[32];   // [16..31]: k_lsd_grow_mw (tra
 #define PF_NOW_FINE() 0ull
 #endif
 #define PF_ADD(c, k, v) ((c).pf[k] += (unsigned long long)(v))
+// -DPLH_GROW_PROF=3: an event trace of k_lsd_grow_mw instead (tools/mw_trace.py): {kind | wavefront << 8 | argument << 16, clock}
+#if PLH_GROW_PROF + 0 >= 3 && !defined(HIPEMU)
+__device__ unsigned long long g_mw_trace[2 * (1 << 20)];
+__device__ unsigned g_mw_trace_n;
+#define MW_TRACE(wv, lane, kind, arg)                                                                     \
+  do {                                                                                                    \
+    if ((lane) == 0) {                                                                                    \
+      const unsigned k__ = atomicAdd(&g_mw_trace_n, 1u);                                                  \
+      if (k__ < (1u << 20)) {                                                                             \
+        g_mw_trace[2 * k__] = (unsigned long long)(kind) | ((unsigned long long)(wv) << 8) | ((unsigned long long)(unsigned)(arg) << 16); \
+        g_mw_trace[2 * k__ + 1] = __builtin_amdgcn_s_memtime();                                           \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
+#else
+#define MW_TRACE(wv, lane, kind, arg) ((void)0)
+#endif
 #else
 #define PF_NOW() 0ull
 #define PF_NOW_FINE() 0ull
 #define PF_ADD(c, k, v) ((void)sizeof(v))
+#define MW_TRACE(wv, lane, kind, arg) ((void)0)
 #endif
 constexpr int LSD_RING = 512;    // 2 KiB; the chain buffer T (1.5 KiB) aliases it (never live at the same time)
 constexpr int LSD_PTS = 8;      // queue points examined per step (8 points x 8 neighbours = 64 lanes)
@@ -71,7 +89,8 @@ __device__ __forceinline__ bool rec_is_candidate(unsigned rec) { return (int)rec
 // wavefront holds a private mark on has a committed mark, or an older transaction's claim, by now.
 constexpr int MW_ASM_CAP = 64;
 __device__ __forceinline__ bool grow_older_claim(const GrowCtx& c, unsigned h) {
-  const unsigned d = (c.hTag - h) & 127u;   // how many sequence numbers below this transaction the claimant is (mod 128)
+  // how many sequence numbers below this transaction the claimant is (tags are 1 .. 65535, sequence numbers mod 65535)
+  const unsigned d = c.hTag >= h ? c.hTag - h : c.hTag + 65535u - h;
   return h != 0u && d != 0u && d <= c.hWin;
 }
 template <bool MW>
@@ -88,7 +107,7 @@ __device__ __forceinline__ unsigned grow_load_rec(const GrowCtx& c, uint32_t idx
 }
 template <bool MW>
 __device__ __forceinline__ void grow_mark(const GrowCtx& c, uint32_t idx, unsigned rec) {
-  if constexpr (MW) { c.M[idx] = 1; c.H[idx] = (uint8_t)c.hTag; }
+  if constexpr (MW) { c.M[idx] = 1; c.H[idx] = (uint16_t)c.hTag; }
   else c.P[idx] = rec | LSD_USED;
 }
 template <bool MW>
@@ -1046,7 +1065,8 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
 // Used for small batches, where one wavefront per frame leaves the GPU empty and a frame takes 47 ms (Frame.cc:224-227
 // calls the extractor once per frame).
 // ---------------------------------------------------------------------------------------------
-constexpr int MW_N = 128;    // entries of the seed FIFO and of the ring of posted transactions (power of two)
+constexpr int MW_N = 512;    // ring of posted transactions (power of two): bounds how far the transactions may run ahead of the commits
+constexpr int MW_F = 128;    // seed FIFO (power of two)
 constexpr int MW_LOW = 24;   // a wavefront that finds fewer seeds queued refills the FIFO
 constexpr int MW_MAX_WAVES = 16;
 enum { MWC_CURSOR = 0, MWC_LOCK, MWC_PUSH, MWC_POP, MWC_HEAD, MWC_DONE, MWC_NSEG, MWC_ABORT, MWC_DLOCK, MWC_RET = 16,
@@ -1071,7 +1091,7 @@ __device__ __forceinline__ int mw_cas(int* p, int cmp, int v) {
   __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return cmp;
 }
-__device__ __forceinline__ void mw_pause() { __builtin_amdgcn_s_sleep(4); }
+__device__ __forceinline__ void mw_pause() { __builtin_amdgcn_s_sleep(8); }
 // publish: this wavefront's global stores are complete (L1 / L2 of its CU) before the LDS word that hands them over
 __device__ __forceinline__ void mw_release() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1110,7 +1130,7 @@ __device__ void mw_scan(const GrowCtx& c, int* ctl, uint4* fifo, const uint32_t*
       break;
     }
     const int pop = mw_ld_u(&ctl[MWC_POP]);
-    if (push - pop >= MW_LOW || push + 64 - pop > MW_N) break;
+    if (push - pop >= MW_LOW || push + 64 - pop > MW_F) break;
     const int si = cursor + lane;
     bool fr = false;
     uint32_t seedP = 0;
@@ -1126,7 +1146,7 @@ __device__ void mw_scan(const GrowCtx& c, int* ctl, uint4* fifo, const uint32_t*
       }
     }
     const unsigned long long m = __ballot(fr);
-    if (fr) fifo[(push + __popcll(m & lanemask_lt())) & (MW_N - 1)] = ent;
+    if (fr) fifo[(push + __popcll(m & lanemask_lt())) & (MW_F - 1)] = ent;
     push += __popcll(m);
     cursor += 64;
     PLH_WAVE_SYNC();
@@ -1272,7 +1292,7 @@ constexpr int MW_INLINE_MAX = 8;
 struct MwShared {
   int* ctl;        // MWC_*
   int* state;      // [MW_N] sequence tag of the posted transaction in the slot
-  uint4* fifo;     // [MW_N] seeds
+  uint4* fifo;     // [MW_F] seeds
   MwPost* pend;    // [MW_N]
 };
 
@@ -1379,10 +1399,11 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       // an older transaction took a pixel this one accepted (or left one this one counted on): run it again here --
       // everything older is committed, so this is the reference's run
       PF_ADD(ch, 24, 1);
+      MW_TRACE(threadIdx.x >> 6, lane, 8, h);   // re-run of post h begins
       const unsigned long long pr0 = PF_NOW();
       const uint32_t seedPk = bcast_u32(q0.y, 0);
       const unsigned seedRec = bcast_u32(ch.P[pk_lin(ch, seedPk)], 0);
-      ch.hTag = ((unsigned)h & 127u) + 1u;
+      ch.hTag = (unsigned)h % 65535u + 1u;
       ch.hWin = 0;   // nothing older is in flight: no claim is believed
       if (!(seedRec & LSD_USED)) {
         const MwTxn t = lsd_txn_mw(ch, gs, a, drainReg, seedPk, seedRec, bcast_u32(q0.z, 0), bcast_u32(q0.w, 0), bcast_u32(q1.x, 0));
@@ -1402,6 +1423,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
         }
       }
       PF_ADD(ch, 10, PF_NOW() - pr0);
+      MW_TRACE(threadIdx.x >> 6, lane, 9, h);   // ... ends
     }
     PF_ADD(ch, 13, 1);
     PLH_WAVE_SYNC();
@@ -1423,13 +1445,17 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
 __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
                              uint32_t* drainReg, float* segs) {
   bool did = false;
+  const int wvTrace = (int)(threadIdx.x >> 6);
+  (void)wvTrace;
   for (;;) {
     const int h = mw_ld_u(&sh.ctl[MWC_HEAD]);
     if (mw_ld_u(&sh.state[h & (MW_N - 1)]) != h + 1) break;
     if (!mw_try_lock(&sh.ctl[MWC_DLOCK], ch.lane)) break;
     mw_acquire();
     const unsigned long long pd0 = PF_NOW();
+    MW_TRACE(wvTrace, ch.lane, 5, h);   // drain session begins at head h
     mw_drain(ch, gs, a, sh, frameReg, drainReg, segs);
+    MW_TRACE(wvTrace, ch.lane, 6, mw_ld(&sh.ctl[MWC_HEAD]));   // ... ends
     PF_ADD(ch, 23, PF_NOW() - pd0); PF_ADD(ch, 25, 1);
     if (ch.lane == 0) mw_st(&sh.ctl[MWC_DLOCK], 0);
     PLH_WAVE_SYNC();
@@ -1444,7 +1470,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   sh.ctl = (int*)smem;
   sh.state = sh.ctl + MWC_WORDS;
   sh.fifo = (uint4*)(sh.state + MW_N);
-  sh.pend = (MwPost*)(sh.fifo + MW_N);
+  sh.pend = (MwPost*)(sh.fifo + MW_F);
   int* const ctl = sh.ctl;
   unsigned char* wsm = (unsigned char*)(sh.pend + MW_N) + wv * MW_WAVE_LDS;
   const long long S = a.mwRegStride / 5;   // words: an arena holds posted logs below S, a running transaction (3 S) and scratch (S)
@@ -1459,7 +1485,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   c.reg = regBase;
   c.scr = regBase + 4 * S;
   c.M = frameMark + (long long)wv * a.mwMarkStride;
-  c.H = a.mwHint + (long long)b * a.mwMarkStride;
+  c.H = a.mwHint + (long long)b * a.mwMarkStride;   // (mwMarkStride 16-bit tags)
   c.hTag = 1; c.hWin = 0;
   c.asmList = (uint32_t*)(wsm + LSD_RING * 4 + 6 * 8 + 8 * 4);
   c.asmCnt = c.asmList + MW_ASM_CAP;
@@ -1486,7 +1512,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   for (int i = tid; i < MWC_WORDS + MW_N; i += (int)blockDim.x) ctl[i] = 0;   // control words and sequence tags
   {   // no claims yet (the plane holds the previous launch's)
     uint4* H4 = reinterpret_cast<uint4*>(c.H);
-    const int n16 = (a.spitch * a.sh) >> 4;   // the pitch is a multiple of 64
+    const int n16 = (a.spitch * a.sh) >> 3;   // 16-byte stores of eight tags; the pitch is a multiple of 64
     for (int i = tid; i < n16; i += (int)blockDim.x) H4[i] = uint4{0u, 0u, 0u, 0u};
     mw_release();
   }
@@ -1533,7 +1559,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       continue;
     }
     if (pop < push && off <= S && pop - head < a.mwLag) {
-      ent = sh.fifo[pop & (MW_N - 1)];   // read before the pop: the slot may be refilled right after it
+      ent = sh.fifo[pop & (MW_F - 1)];   // read before the pop: the slot may be refilled right after it
       ent.x = bcast_u32(ent.x, 0); ent.y = bcast_u32(ent.y, 0); ent.z = bcast_u32(ent.z, 0); ent.w = bcast_u32(ent.w, 0);
       int ok = 0;
       if (lane == 0) ok = mw_cas(&ctl[MWC_POP], pop, pop + 1) == pop;
@@ -1546,12 +1572,14 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       const unsigned long long pw0 = PF_NOW();
       if (mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs)) { polls = 0; continue; }
       int stop = 0;
+      MW_TRACE(wv, lane, 7, (pop < push ? 1 : 0) | (off > S ? 2 : 0) | (pop - head >= a.mwLag ? 4 : 0) | (done ? 8 : 0));   // nothing to do: why
       if (lane == 0) { stop = mw_give_up(ctl, polls, a.status); mw_pause(); }
       if (bcast_u32((unsigned)stop, 0)) break;
       PF_ADD(c, 19, PF_NOW() - pw0);
       continue;
     }
     polls = 0;
+    MW_TRACE(wv, lane, 1, s);   // popped
     // ---- the transaction
     const uint32_t seedPk = ent.x;
     const uint32_t seedLin = pk_lin(c, seedPk);
@@ -1563,7 +1591,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     unsigned pGen[4] = {0u, 0u, 0u, 0u};   // general form: off, logLen, finBase, finCnt
     float pSeg[4] = {0.f, 0.f, 0.f, 0.f};
     int pAcc = 0, pAsm = 0;
-    c.hTag = ((unsigned)s & 127u) + 1u;
+    c.hTag = (unsigned)s % 65535u + 1u;
     for (;;) {
       mw_acquire();
       const unsigned seedRec = bcast_u32(c.P[seedLin], 0);
@@ -1580,8 +1608,10 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
         break;
       }
       const unsigned long long pt0 = PF_NOW();
+      MW_TRACE(wv, lane, 2, s);   // run begins
       const MwTxn t = lsd_txn_mw(c, gs, a, regBase + off, seedPk, seedRec, ent.y, ent.z, ent.w);
       grow_lane_fence<true>();
+      MW_TRACE(wv, lane, 3, t.logLen);   // run ends
       // through: take the private marks back (the plane is clean for the next transaction) and look once more whether an
       // older transaction has committed a pixel of the log meanwhile
       const uint32_t* log = regBase + off;
@@ -1644,6 +1674,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
         else if (lane < MWP_ASM) pw = __float_as_uint(lane == MWP_SEG ? pSeg[0] : (lane == MWP_SEG + 1 ? pSeg[1] : (lane == MWP_SEG + 2 ? pSeg[2] : pSeg[3])));
         else if (lane - MWP_ASM < min(pAsm, 3)) pw = c.asmList[lane - MWP_ASM];
       }
+      MW_TRACE(wv, lane, 4, pMode);   // posting
       if (!(pFlags & 8u)) mw_release();   // a log in global memory is complete before its post is visible
       if (lane < MW_PEND_WORDS) sh.pend[s & (MW_N - 1)].w[lane] = pw;
       PLH_WAVE_SYNC();
@@ -1651,7 +1682,13 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     }
     PLH_WAVE_SYNC();
     PF_ADD(c, 27, PF_NOW() - pp0);
-    mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs);
+    // Commit now?  A drain session costs its set-up however few posts it finds: worth it when this was the oldest transaction
+    // (nobody else can move the head past it) or a batch's worth has piled up; otherwise the next one to come by does it
+    // (and a wavefront with nothing else to do always does).
+    {
+      const int hd = mw_ld_u(&ctl[MWC_HEAD]);
+      if (s == hd || s - hd >= a.mwDrainGap) mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs);
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -2136,7 +2173,15 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
 size_t lsd_grow_lds_bytes(int spitch, int sh);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
   if (a.mwWaves > 0) {
-    const size_t ldsMw = (size_t)MWC_WORDS * 4 + (size_t)MW_N * (4 + 16 + MW_PEND_WORDS * 4) + (size_t)a.mwWaves * MW_WAVE_LDS;
+    const size_t ldsMw = (size_t)MWC_WORDS * 4 + (size_t)MW_N * (4 + MW_PEND_WORDS * 4) + (size_t)MW_F * 16 + (size_t)a.mwWaves * MW_WAVE_LDS;
+    if (ldsMw > 64u * 1024u) {   // beyond 64 KiB the dynamic LDS has to be requested per kernel (once)
+      static bool asked = false;
+      if (!asked) {
+        (void)lds_request(k_lsd_grow_mw, 160u * 1024u, "k_lsd_grow_mw");
+        (void)lds_request(k_lsd_grow_mw16, 160u * 1024u, "k_lsd_grow_mw16");
+        asked = true;
+      }
+    }
     // (the roomy build holds three wavefronts per SIMD: beyond two per SIMD over the whole GPU take the 128-register one)
     if (a.mwWaves <= 8 && (long long)a.batch * a.mwWaves <= 2048) hipLaunchKernelGGL(k_lsd_grow_mw, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
     else hipLaunchKernelGGL(k_lsd_grow_mw16, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
@@ -2156,6 +2201,20 @@ void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, co
   hipLaunchKernelGGL(k_lbd, dim3(a.outCap, a.batch), dim3(64), 0, s, a, kl, n, coef, desc);
 }
 #if defined(PLH_GROW_PROF)
+#if PLH_GROW_PROF + 0 >= 3 && !defined(HIPEMU)
+extern "C" __attribute__((visibility("default"))) int plh_debug_mw_trace(unsigned long long* out, unsigned cap, int reset) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_mw_trace_n), 4) != hipSuccess) return -1;
+  n = n < cap ? n : cap;
+  if (n > (1u << 20)) n = 1u << 20;
+  if (out && n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mw_trace), (size_t)n * 16) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mw_trace_n), &z, 4) != hipSuccess) return -1;
+  }
+  return (int)n;
+}
+#endif
 extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsigned long long* out32, int reset) {
 #if defined(HIPEMU)
   memcpy(out32, g_grow_prof, sizeof(g_grow_prof));
