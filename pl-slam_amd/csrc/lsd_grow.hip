@@ -1623,7 +1623,12 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       if (!bad) {
         for (int base = 0; base < t.logLen; base += 64) {
           const int i = base + lane;
-          if (i < t.logLen) bad = bad || (c.P[pk_lin(c, inl ? c.ring[i] : log[i])] & LSD_USED) != 0u;
+          if (i < t.logLen) {
+            const uint32_t li = pk_lin(c, inl ? c.ring[i] : log[i]);
+            bad = bad || (c.P[li] & LSD_USED) != 0u;
+            // ... or an older transaction still in flight has claimed a pixel of the final region since: it will commit first
+            if (i >= t.finBase) bad = bad || grow_older_claim(c, (unsigned)c.H[li]);
+          }
         }
         bad = spec && __ballot(bad) != 0ull;
       }
