@@ -370,8 +370,13 @@ def main():
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame, and the
         # SQ instruction counters (tools/pmc_insts.sh -> profiles/r02_insts.json): collected on the headline workload only
         headline = W.tum and args.nfeatures == 1000
-        traffic = load_profile_json("hbm_traffic.json").get("kernels", {}) if headline else {}
-        insts = load_profile_json("r02_insts.json").get("kernels", {}) if headline else {}
+        # PMC figures are a property of a build: they are reported only when the file carries this library's build id
+        build = P.load().plh_version().decode().split("build ")[-1].strip()
+        tj, ij = load_profile_json("hbm_traffic.json"), load_profile_json("r03_insts.json")
+        traffic = tj.get("kernels", {}) if headline and tj.get("build") == build else {}
+        insts = ij.get("kernels", {}) if headline and ij.get("build") == build else {}
+        pmc_note = {"library_build": build, "hbm_traffic.json": tj.get("build"), "r03_insts.json": ij.get("build"),
+                    "note": "PMC-derived fields (roofline.traffic, valu_issue) are null unless the profile was collected on this build"}
         pmc_names = {1: ["k_fast_strips"], 5: ["k_lsd_grow"], 0: ["k_pyr_down"], 2: ["k_octree"], 3: ["k_orient_brief"]}
 
         def roof(k, ms, where, frames_per_launch=Bp, algb=None):
@@ -429,6 +434,7 @@ def main():
             "kernel_ms_per_launch_timed_region": {NAMES[k]: round(per_ms_timed[k], 4) for k in range(8)},
             "roofline": r_dom,
             "roofline_fast": r_fast,
+            "pmc_provenance": pmc_note,
         }
         if gathering:
             tr = {}

@@ -21,8 +21,10 @@ for k in acc:
 rows.sort(reverse=True)
 print("%-18s %12s %12s %10s %10s %14s %14s   (wave-instructions per frame)"%("kernel","VALU","SALU","LDS","VMEM","wave_cycles","wait_any"))
 for t,k,v,s,l,m,wc,wa in rows: print("%-18s %12.0f %12.0f %10.0f %10.0f %14.0f %14.0f"%(k,v,s,l,m,wc,wa))
-import json, subprocess
-out={"what":"SQ counters per kernel, wave-instructions per frame (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY, tools/pmc_insts.sh $B: bench.py --batch $B --nsplit 1 --serial, 640x480 / 1000 ORB / 200 lines)",
+import json, subprocess, sys
+sys.path.insert(0, "$R")
+import __graft_entry__ as g
+out={"build": g._lib_id(g.LIB), "what":"SQ counters per kernel, wave-instructions per frame (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY, tools/pmc_insts.sh $B: bench.py --batch $B --nsplit 1 --serial, 640x480 / 1000 ORB / 200 lines)",
      "kernels":{k:{"valu":round(v),"salu":round(s),"lds":round(l),"vmem":round(m),"wave_cycles":round(wc),"wait_any":round(wa)} for t,k,v,s,l,m,wc,wa in rows},
      "total_valu":round(sum(r[2] for r in rows)), "total_salu":round(sum(r[3] for r in rows))}
 json.dump(out, open("$R/gpurun_out/pmcinst/insts.json","w"), indent=1)

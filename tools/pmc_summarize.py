@@ -28,7 +28,10 @@ def main():
     root, batch = sys.argv[1], int(sys.argv[2])
     fetch, fc = fold(os.path.join(root, "fetch"), "FETCH_SIZE")
     write, wc = fold(os.path.join(root, "write"), "WRITE_SIZE")
-    out = {"batch": batch, "unit": "bytes per frame per launch", "fetch_correction": 2.0, "kernels": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as g
+    # the library build the counters were collected on: bench.py reports them only for the same build
+    out = {"batch": batch, "unit": "bytes per frame per launch", "fetch_correction": 2.0, "build": g._lib_id(g.LIB), "kernels": {}}
     steps = max(fc.get("k_lsd_grow", 0), wc.get("k_lsd_grow", 0), 1)   # one launch per front-end step
     for k in sorted(set(fetch) | set(write)):
         n = max(fc.get(k, 0), wc.get(k, 0), 1)
