@@ -112,8 +112,10 @@ PLH_API plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, 
                                              plh_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, void* stream);
 
 /* Capacity flags of the most recent extract call on this handle (any entry point; the call clears them in stream order
- * before its kernels run, so they never leak from one call into the next).  Waits for that call's stream, then reads the
- * device word.  bit 0: a FAST cell produced more candidates than its slot array; bit 1: a level's quad tree selected more
+ * before its kernels run, so they never leak from one call into the next -- hence ONE call in flight per handle: a second
+ * call enqueued on another stream before the first has run would clear or overwrite the first one's flags).  Waits for an
+ * event the handle recorded behind that call's last kernel (the caller's stream may have been destroyed since), then reads
+ * the device word.  bit 0: a FAST cell produced more candidates than its slot array; bit 1: a level's quad tree selected more
  * keypoints than the record capacity.  Both are impossible by construction of the plan; a non-zero value
  * means truncated lists.  The host-buffer entry points check it themselves and return PLH_ERR_CAPACITY. */
 PLH_API plh_status plh_orb_status(plh_orb* h, int* flags);
@@ -569,7 +571,8 @@ PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs
  * Frame.cc:224-227) run several wavefronts per frame as optimistic transactions with in-order commit, large batches one
  * wavefront per frame; 0: always one; n in 2..16: always n.  The segments are identical in every setting. */
 PLH_API plh_status plh_line_set_grow_waves(plh_line* h, int waves);
-/* Capacity flags of the most recent extract call (see plh_orb_status).  bit 2: LSD produced more segments than the
+/* Capacity flags of the most recent extract call (see plh_orb_status; a handle carries ONE call in flight: the flags are
+ * cleared in stream order by the next call on it).  bit 2: LSD produced more segments than the
  * segment list holds (|scaled pixels| / min_reg_size + 16 -- a hard bound, so never expected).  bit 4 (16): the
  * multi-wavefront region growing gave up on a wait that lasted seconds (a lost wake-up would otherwise hang the GPU): the
  * call's lines are void; the handle's workspace is re-initialised by this query. */

@@ -25,6 +25,8 @@
 #include <ORBmatcher.h>   // the reference's include/ORBmatcher.h, found on the include path
 #undef ORBmatcher
 
+#include <stdexcept>
+
 #include "HipMatchers.h"
 
 namespace ORB_SLAM2 {
@@ -41,13 +43,15 @@ class ORBmatcher : public ORBmatcherCPU {
 
   // Tracking::SearchLocalPoints: exactly the members the reference loop reads (ORBmatcher.cc:64-88), one call, write back (:137-138)
   int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3) {
+    RequireMonocular(F);
     const size_t n = vpMapPoints.size();
     hip::ProjQueries q;
     q.valid.resize(n); q.hasObs.resize(n); q.pos.resize(2 * n); q.level.resize(n); q.aux.resize(n);
-    q.desc.create((int)(n ? n : 1), 32, CV_8U);
+    q.desc = cv::Mat::zeros((int)(n ? n : 1), 32, CV_8U);
     for (size_t i = 0; i < n; i++) {
       MapPoint* p = vpMapPoints[i];
-      q.valid[i] = p->mbTrackInView && !p->isBad();
+      // (a point without a descriptor never matches in the reference: every candidate is skipped, ORBmatcher.cc:113-114)
+      q.valid[i] = p->mbTrackInView && !p->isBad() && !p->GetDescriptor().empty();
       q.hasObs[i] = p->Observations() > 0;
       q.pos[2 * i] = p->mTrackProjX; q.pos[2 * i + 1] = p->mTrackProjY;
       q.level[i] = p->mnTrackScaleLevel;
@@ -69,6 +73,8 @@ class ORBmatcher : public ORBmatcherCPU {
   // TrackWithMotionModel: the pose algebra of :1452-1484 stays here in the reference's own expressions; the window search,
   // the level band, the best-distance scan and the rotation histogram run on the GPU
   int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+    if (!bMono) ThrowStereo();
+    RequireMonocular(CurrentFrame);
     const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
     const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
     const cv::Mat twc = -Rcw.t() * tcw;
@@ -90,7 +96,7 @@ class ORBmatcher : public ORBmatcherCPU {
       const float yc = x3Dc.at<float>(1);
       const float invzc = 1.0 / x3Dc.at<float>(2);
       if (invzc < 0) continue;
-      q.valid[i] = 1;
+      q.valid[i] = !pMP->GetDescriptor().empty();   // (no descriptor: never matches, ORBmatcher.cc:1530-1531)
       q.pos[2 * i] = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
       q.pos[2 * i + 1] = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
       q.level[i] = LastFrame.mvKeys[i].octave;
@@ -136,6 +142,17 @@ class ORBmatcher : public ORBmatcherCPU {
   }
 
  protected:
+  // The GPU searches implement the monocular form (the project is monocular only, README.md:4): the right-image gates of the
+  // stereo / RGB-D form (`er = |mTrackProjXR - mvuRight|`, ORBmatcher.cc:104-109; `ur = u - mbf * invzc`, :1520-1526) are not
+  // evaluated.  A frame that carries right coordinates is refused loudly rather than matched without them.
+  static void ThrowStereo() {
+    throw std::runtime_error("plslam_hip drop-in: ORBmatcher::SearchByProjection supports monocular frames only "
+                             "(stereo / RGB-D right-coordinate gates are not implemented on the GPU path)");
+  }
+  static void RequireMonocular(const Frame& F) {
+    for (size_t i = 0; i < F.mvuRight.size(); i++)
+      if (F.mvuRight[i] > 0) ThrowStereo();
+  }
   static plh_grid_params FrameGrid() {
     return hip::GridParams(Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, Frame::mfGridElementWidthInv,
                            Frame::mfGridElementHeightInv);

@@ -12,6 +12,8 @@
 #if !defined(HIPEMU)
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+
+#include <mutex>
 #endif
 
 struct plh_comm {
@@ -42,11 +44,7 @@ struct Rccl {
   ncclResult_t (*GetVersion)(int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.lib ? &r : nullptr;
-  tried = true;
+Rccl* rccl_bind(Rccl& r) {
   // RTLD_NOLOAD first: reuse the RCCL the process already holds (two copies would each own their own communicators)
   const char* names[] = {"librccl.so.1", "librccl.so"};
   for (int pass = 0; pass < 2 && !r.lib; pass++)
@@ -66,6 +64,14 @@ Rccl* rccl() {
     return nullptr;
   }
   return &r;
+}
+// bound once, by whichever thread comes first; the others wait for the finished table (never a half-bound one)
+Rccl* rccl() {
+  static Rccl r;
+  static Rccl* bound = nullptr;
+  static std::once_flag once;
+  std::call_once(once, []() { bound = rccl_bind(r); });
+  return bound;
 }
 #define PLH_NCCL(R, call)                                                                                   \
   do {                                                                                                      \
@@ -170,21 +176,32 @@ plh_status plh_gather_records(plh_comm* c, const plh_gather_block* blocks, int n
 #else
   Rccl* R = rccl();
   if (!R) { set_error("plh_gather_records: RCCL (librccl.so.1) cannot be loaded"); return PLH_ERR_NO_DEVICE; }
-  // one grouped launch for all blocks of the sub-batch (counts, keypoints, descriptors, keylines, LBD, ...)
+  // one grouped launch for all blocks of the sub-batch (counts, keypoints, descriptors, keylines, LBD, ...).  A failure
+  // inside the group must not leave it open (every later RCCL call of this thread, PyTorch's included, would queue behind it
+  // and never launch): the first error is remembered, the group is closed, then it is reported.
   PLH_NCCL(R, R->GroupStart());
-  for (int i = 0; i < nblocks; i++) {
+  ncclResult_t first = ncclSuccess;
+  const char* what = "";
+  auto note = [&](ncclResult_t e, const char* w) { if (e != ncclSuccess && first == ncclSuccess) { first = e; what = w; } };
+  for (int i = 0; i < nblocks && first == ncclSuccess; i++) {
     const plh_gather_block& b = blocks[i];
     if (root < 0) {
-      PLH_NCCL(R, R->AllGather(b.send, b.recv, b.bytes, ncclUint8, c->comm, s));
+      note(R->AllGather(b.send, b.recv, b.bytes, ncclUint8, c->comm, s), "ncclAllGather");
     } else if (R->Gather) {
-      PLH_NCCL(R, R->Gather(b.send, b.recv, b.bytes, ncclUint8, root, c->comm, s));
+      note(R->Gather(b.send, b.recv, b.bytes, ncclUint8, root, c->comm, s), "ncclGather");
     } else {   // plain NCCL API: the root posts one receive per rank, everybody sends
       if (c->rank == root)
-        for (int r = 0; r < c->world; r++) PLH_NCCL(R, R->Recv((char*)b.recv + (size_t)r * b.bytes, b.bytes, ncclUint8, r, c->comm, s));
-      PLH_NCCL(R, R->Send(b.send, b.bytes, ncclUint8, root, c->comm, s));
+        for (int r = 0; r < c->world && first == ncclSuccess; r++)
+          note(R->Recv((char*)b.recv + (size_t)r * b.bytes, b.bytes, ncclUint8, r, c->comm, s), "ncclRecv");
+      if (first == ncclSuccess) note(R->Send(b.send, b.bytes, ncclUint8, root, c->comm, s), "ncclSend");
     }
   }
-  PLH_NCCL(R, R->GroupEnd());
+  const ncclResult_t eEnd = R->GroupEnd();
+  if (first == ncclSuccess) note(eEnd, "ncclGroupEnd");
+  if (first != ncclSuccess) {
+    set_error("plh_gather_records: %s -> %s", what, R->GetErrorString ? R->GetErrorString(first) : "RCCL error");
+    return PLH_ERR_HIP;
+  }
   return PLH_OK;
 #endif
 }

@@ -76,7 +76,9 @@ struct plh_line {
   int growWaves = -1;          // plh_line_set_grow_waves
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
-  hipStream_t lastStream = nullptr;   // stream of the most recent extract call (plh_line_status waits on it)
+  hipEvent_t doneEv = nullptr;   // recorded behind the last kernel of every extract call: plh_line_status (and a workspace
+                                 // re-allocation) waits on it -- the caller's stream may be gone by then
+  bool doneValid = false;
   float* dCoef = nullptr;
   RemapTap* dMap = nullptr;
   ResizeTap *dXtab = nullptr, *dYtab = nullptr;
@@ -171,6 +173,7 @@ plh_status plh_line_destroy(plh_line* h) {
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
+  if (h->doneEv) (void)hipEventDestroy(h->doneEv);
   if (h->a.angleTab) angle_table_release(h->device);
   delete h;
   return PLH_OK;
@@ -388,7 +391,7 @@ static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int wave
   }
   const long long slots = (long long)batch * (waves + 1);
   if (slots > h->mwWaveSlots) {
-    PLH_HIP(hipStreamSynchronize(h->lastStream));   // earlier launches may still use the old buffers
+    if (h->doneValid) PLH_HIP(hipEventSynchronize(h->doneEv));   // earlier launches may still use the old buffers
     if (h->dMwReg) (void)hipFree(h->dMwReg);
     if (h->dMwMark) (void)hipFree(h->dMwMark);
     h->dMwReg = nullptr; h->dMwMark = nullptr; h->mwWaveSlots = 0;
@@ -402,7 +405,7 @@ static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int wave
     h->mwWaveSlots = slots;
   }
   if (batch > h->mwHintFrames) {
-    PLH_HIP(hipStreamSynchronize(h->lastStream));
+    if (h->doneValid) PLH_HIP(hipEventSynchronize(h->doneEv));
     if (h->dMwHint) (void)hipFree(h->dMwHint);
     h->dMwHint = nullptr; h->mwHintFrames = 0;
     if (hipMalloc((void**)&h->dMwHint, (size_t)batch * a.mwMarkStride * 2) != hipSuccess) {
@@ -439,7 +442,6 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
     }
   }
   PLH_HIP(hipMemsetAsync(h->dStatus, 0, 4, s));   // capacity flags of this call only (plh_line_status)
-  h->lastStream = s;
   if (h->hasUndistort) {
     a.remap = h->dMap; a.undist = h->dUndist;
     launch_remap(a, s);
@@ -476,6 +478,9 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   launch_lbd(a, d_keylines, d_n, h->dCoef, d_desc, s);
   PLH_LAUNCH_CHECK();
   line_prof_mark(h, 3, s);
+  if (!h->doneEv) PLH_HIP(hipEventCreateWithFlags(&h->doneEv, hipEventDisableTiming));
+  PLH_HIP(hipEventRecord(h->doneEv, s));
+  h->doneValid = true;
   return PLH_OK;
 }
 
@@ -532,7 +537,7 @@ plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, int cols,
 plh_status plh_line_status(plh_line* h, int* flags) {
   if (!h || !flags) return PLH_ERR_INVALID;
   PLH_HIP(hipSetDevice(h->device));
-  PLH_HIP(hipStreamSynchronize(h->lastStream));
+  if (h->doneValid) PLH_HIP(hipEventSynchronize(h->doneEv));
   PLH_HIP(hipMemcpy(flags, h->dStatus, 4, hipMemcpyDeviceToHost));
   if ((*flags & 16) && h->dMwMark)   // an abandoned launch leaves private marks behind: the planes must be zero between transactions
     PLH_HIP(hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride));

@@ -67,7 +67,9 @@ struct plh_orb {
   uint8_t* dPyr = nullptr;
   uint32_t *dSlots = nullptr, *dCellCount = nullptr, *dKeys = nullptr, *dSel = nullptr;
   int *dSelCount = nullptr, *dStatus = nullptr;
-  hipStream_t lastStream = nullptr;   // stream of the most recent extract call (plh_orb_status waits on it)
+  hipEvent_t doneEv = nullptr;   // recorded behind the last kernel of every extract call: plh_orb_status waits on it (the
+                                 // caller's stream may be gone by then; the event is the handle's own)
+  bool doneValid = false;
   // staging for the host-buffer entry points
   uint8_t* dImgs = nullptr;
   plh_keypoint* dKps = nullptr;
@@ -435,6 +437,7 @@ plh_status plh_orb_destroy(plh_orb* h) {
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
+  if (h->doneEv) (void)hipEventDestroy(h->doneEv);
   delete h;
   return PLH_OK;
 }
@@ -468,7 +471,6 @@ plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batc
   fill_args(h, d_imgs, (long long)frame_stride, batch, &a);
   // the capacity flags describe THIS call only (plh_orb_status): cleared in stream order in front of the kernels
   PLH_HIP(hipMemsetAsync(h->dStatus, 0, sizeof(int), s));
-  h->lastStream = s;
   prof_mark(h, 0, s);
   for (int l = 1; l < h->nlevels; l++) {
     const OrbLevel &S = h->levels[l - 1], &D = h->levels[l];
@@ -496,6 +498,9 @@ plh_status plh_orb_extract_batch_dev(plh_orb* h, const uint8_t* d_imgs, int batc
   PLH_LAUNCH_CHECK();
   prof_mark(h, 3, s);
   h->lastImgs = d_imgs; h->lastStride = (long long)frame_stride; h->lastBatch = batch;
+  if (!h->doneEv) PLH_HIP(hipEventCreateWithFlags(&h->doneEv, hipEventDisableTiming));
+  PLH_HIP(hipEventRecord(h->doneEv, s));
+  h->doneValid = true;
   return PLH_OK;
 }
 
@@ -522,7 +527,7 @@ static plh_status check_status(plh_orb* h) {
 plh_status plh_orb_status(plh_orb* h, int* flags) {
   if (!h || !flags) return PLH_ERR_INVALID;
   PLH_HIP(hipSetDevice(h->device));
-  PLH_HIP(hipStreamSynchronize(h->lastStream));
+  if (h->doneValid) PLH_HIP(hipEventSynchronize(h->doneEv));
   PLH_HIP(hipMemcpy(flags, h->dStatus, sizeof(int), hipMemcpyDeviceToHost));
   return PLH_OK;
 }

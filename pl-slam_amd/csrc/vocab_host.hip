@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cstdlib>
 #include <string>
+#include <charconv>
 #include <vector>
 
 #include "plh_common.h"
@@ -58,7 +59,11 @@ inline bool parse_int(const char*& p, long& v) {
   if (*p == '-') { neg = true; p++; }
   if (*p < '0' || *p > '9') return false;
   long r = 0;
-  while (*p >= '0' && *p <= '9') r = r * 10 + (*p++ - '0');
+  int digits = 0;
+  while (*p >= '0' && *p <= '9') {
+    if (++digits > 18) return false;   // no field of a vocabulary file comes near: a run of digits this long is a corrupt file
+    r = r * 10 + (*p++ - '0');
+  }
   v = neg ? -r : r;
   return true;
 }
@@ -92,11 +97,16 @@ plh_status parse_text(const char* path, RawTree& t) {
       t.desc.push_back((uint8_t)b);
     }
     skip_blanks(p);
-    char* e = nullptr;
-    t.weight.push_back(std::strtod(p, &e));      // `ssnode >> weight` reads a double (WordValue)
-    if (e == p) { set_error("plh_vocab_load_text: %s: node %zu has no weight", path, nid); return PLH_ERR_INVALID; }
-    p = e;
-    while (*p && *p != '\n') p++;
+    // `ssnode >> weight` reads a double (WordValue) from THIS line: the field must not be taken from the next line (strtod
+    // skips line feeds) nor depend on the process locale (from_chars never does)
+    const char* le = p;
+    while (*le && *le != '\n') le++;
+    double w = 0.0;
+    if (*p == '+') p++;
+    const std::from_chars_result fr = std::from_chars(p, le, w);
+    if (fr.ec != std::errc() || fr.ptr == p) { set_error("plh_vocab_load_text: %s: node %zu has no weight", path, nid); return PLH_ERR_INVALID; }
+    t.weight.push_back(w);
+    p = le;
   }
   return PLH_OK;
 }
@@ -276,7 +286,8 @@ plh_status plh_vocab_save_binary(const plh_vocab* v, const char* path) {
     std::fwrite(&w, 4, 1, f);
     std::fwrite(&leaf, 1, 1, f);
   }
-  const bool ok = std::fclose(f) == 0;
+  const bool wrote = std::ferror(f) == 0;   // a full disk shows up in the stream's error flag, not necessarily in fclose()
+  const bool ok = (std::fclose(f) == 0) && wrote;
   if (!ok) { set_error("plh_vocab_save_binary: write to %s failed", path); return PLH_ERR_INVALID; }
   return PLH_OK;
 }

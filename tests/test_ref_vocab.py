@@ -188,6 +188,21 @@ def _create_and_errors(P, S, lib, tmp_path):
         P.ORBVocabulary(lib=lib).loadFromTextFile(str(bad))           # k out of range: the reference rejects it too
     with pytest.raises(P.PlhError):
         P.ORBVocabulary(lib=lib).loadFromTextFile(str(tmp_path / "missing.txt"))
+    node = "0 1 " + " ".join(["7"] * 32)
+    short = tmp_path / "noweight.txt"                                 # a node line without its weight must not borrow the next line's
+    short.write_text("4 2 0 0\n" + node + "\n" + node + " 0.5\n")   # first field as the weight (strtod would skip the line feed)
+    with pytest.raises(P.PlhError, match="no weight"):
+        P.ORBVocabulary(lib=lib).loadFromTextFile(str(short))
+    digits = tmp_path / "digits.txt"                                  # a run of digits no field can hold is refused, not wrapped around
+    digits.write_text("4 2 0 0\n0 1 " + "9" * 40 + " " + " ".join(["7"] * 31) + " 0.5\n")
+    with pytest.raises(P.PlhError):
+        P.ORBVocabulary(lib=lib).loadFromTextFile(str(digits))
+    ok = tmp_path / "exp.txt"                                         # exponent and sign forms of `ostream << double` still load
+    ok.write_text("4 2 0 0\n" + node + " 1e-05\n" + node + " +2.5\n")
+    v = P.ORBVocabulary(lib=lib)
+    v.loadFromTextFile(str(ok))
+    assert list(v.arrays()["weight"][1:3]) == [1e-05, 2.5]
+    v.close()
     with pytest.raises(P.PlhError):
         P.ORBVocabulary(lib=lib).loadFromBinaryFile(_files("k5L3")["A"])   # a text file is not a binary vocabulary
 

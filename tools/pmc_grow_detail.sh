@@ -1,5 +1,6 @@
 #!/bin/bash
 # where do k_lsd_grow's cycles go at full residency (6144 frames in ONE launch = 6 wavefronts per SIMD)?  Two PMC passes.
+export PLH_GROW_MW_WAVES=0   # these profiles are about the one-wavefront-per-frame kernels (small batches would run k_lsd_grow_mw)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-6144}

@@ -1,5 +1,6 @@
 #!/bin/bash
 # average latency of k_lsd_grow's memory operations (SQ_INST_LEVEL_* / SQ_INSTS_*), lone wavefronts (256 frames) vs full residency (6144)
+export PLH_GROW_MW_WAVES=0   # these profiles are about the one-wavefront-per-frame kernels (small batches would run k_lsd_grow_mw)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for B in 256 6144; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # memory-side view of k_lsd_grow, lone wavefronts (256 frames) vs full residency (6144): L1->L2 read latency, address translation, L2 hit rate
+export PLH_GROW_MW_WAVES=0   # these profiles are about the one-wavefront-per-frame kernels (small batches would run k_lsd_grow_mw)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 PA="TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum"

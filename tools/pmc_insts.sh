@@ -1,5 +1,6 @@
 #!/bin/bash
 # Instruction-issue budget per kernel (SQ counters, one pass): which kernels own the SIMD issue slots.
+export PLH_GROW_MW_WAVES=0   # these profiles are about the one-wavefront-per-frame kernels (small batches would run k_lsd_grow_mw)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-256}

@@ -1,5 +1,6 @@
 #!/bin/bash
 # LDS bank conflicts per kernel: SQ_LDS_BANK_CONFLICT (cycles lost) against SQ_LDS_IDX_ACTIVE (cycles the LDS index unit is busy)
+export PLH_GROW_MW_WAVES=0   # these profiles are about the one-wavefront-per-frame kernels (small batches would run k_lsd_grow_mw)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-256}

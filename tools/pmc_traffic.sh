@@ -2,6 +2,7 @@
 # HBM traffic of the front-end kernels from the L2 memory-side counters (MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"):
 # FETCH_SIZE and WRITE_SIZE do not fit one pass (3 + 2 TCC slots of 4) -> two separate --pmc runs, kernel trace only.
 # Run on the GPU box:  bash tools/pmc_traffic.sh [batch]   -> gpurun_out/pmc/{fetch,write}/... + gpurun_out/pmc/traffic.json
+export PLH_GROW_MW_WAVES=0   # these profiles are about the one-wavefront-per-frame kernels (small batches would run k_lsd_grow_mw)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ROOT=$PWD
