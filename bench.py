@@ -26,7 +26,9 @@ One JSON line on stdout (rank 0) with, besides the contract fields,
                    and the literal configs[4] share of 4096 / 8 = 512 frames per GPU;
   "streaming":     (N = 1) the PCIe-inclusive rate described above;
   "latency_ms_single_frame": (N = 1) one Frame() worth of extraction through the host-buffer entry points, ORB and lines on
-                   two threads as Frame.cc:224-227 runs them.
+                   two threads as Frame.cc:224-227 runs them;
+  "verified":      the records the timed steps left behind for the first 64 frames of the batch (and of each secondary batch),
+                   compared bit for bit with the CPU oracle on the same frames; a mismatch makes the run exit non-zero.
 """
 import argparse
 import json
@@ -124,6 +126,98 @@ def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, budget_s=2
             "single_thread_ms_per_frame": round(per * 1e3, 1),
             "sample": "%d synthetic %dx%d frames (ORB + remap + LSD/LBD + BoW + SearchByBoW + SearchDouble), oracle/ restatement "
                       "(g++ -O2 -ffp-contract=off, no OpenCV SIMD), %d host threads x %d frames" % (done, cols, rows, cores, per_thread)}
+
+
+def oracle_records(O, V, frames, voc, nfeatures, nlevels, nlines, K, D):
+    """Everything one step produces for `frames` (consecutive frames of a batch), from the CPU oracle, on all host cores:
+    per frame keypoints / rBRIEF / FeatureVector nodes / words / BowVector / keylines / LBD / line equations, and per
+    consecutive pair the SearchByBoW and SearchDouble match lists.  The checker of `verify_records`, nothing else."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    L = O.lib()
+    L.plo_bow_transform.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.plo_bow_transform.restype = None
+    L.plo_bow_vector.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.plo_bow_vector.restype = C.c_int
+    rows, cols = frames[0].shape
+    undist = K is not None and D is not None and any(D)
+    if undist:
+        mx = np.zeros((rows, cols), np.float32)
+        my = np.zeros((rows, cols), np.float32)
+        Kf, Df = np.asarray(K, np.float32), np.asarray(D, np.float32)
+        L.plo_undistort_maps(O._p(Kf), O._p(Df), cols, rows, O._p(mx), O._p(my))
+    ww = voc.word_weight()
+
+    def one(img):
+        orb = O.OrbOracle(nfeatures, 1.2, nlevels, 20, 7)
+        kps, desc = orb.extract(img)
+        src = img
+        if undist:
+            src = np.zeros_like(img)
+            L.plo_remap_linear_u8(O._p(img), cols, rows, cols, O._p(mx), O._p(my), O._p(src), cols)
+        kl, ldesc, fn = O.line_extract(src, nlines, 0.0)
+        n = len(desc)
+        nid = np.zeros(max(n, 1), np.int32)
+        word = np.zeros(max(n, 1), np.int32)
+        L.plo_bow_transform(O._p(desc), n, O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id),
+                            O._p(voc.weight), voc.L, 4, O._p(nid), O._p(word))
+        bw, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        m = L.plo_bow_vector(O._p(word), n, O._p(ww), 0, 0, O._p(bw), O._p(bv), max(n, 1))
+        return dict(kps=kps, desc=desc, nid=nid[:n], word=word[:n], bow_word=bw[:m], bow_value=bv[:m], kl=kl, ldesc=ldesc, lfn=fn)
+
+    def pair(ab):
+        a, b = ab
+        valid = np.ones(len(a["desc"]), np.uint8)
+        a1, a2 = np.ascontiguousarray(a["kps"]["angle"]), np.ascontiguousarray(b["kps"]["angle"])
+        m = np.zeros(max(len(b["desc"]), 1), np.int32)
+        c = L.plo_orb_search_by_bow(O._p(a["desc"]), O._p(a1), O._p(a["nid"]), O._p(valid), len(a["desc"]), O._p(b["desc"]), O._p(a2),
+                                    O._p(b["nid"]), len(b["desc"]), 50, 0.7, 1, O._p(m))
+        ml = np.zeros(max(len(a["ldesc"]), 1), np.int32)
+        cl = L.plo_line_search_double(O._p(a["ldesc"]), len(a["ldesc"]), O._p(b["ldesc"]), len(b["ldesc"]), 50.0, 0.7, O._p(ml))
+        return dict(m_orb=m[:len(b["desc"])], nm_orb=c, m_line=ml[:len(a["ldesc"])], nm_line=cl)
+
+    with ThreadPoolExecutor(min(os.cpu_count() or 1, len(frames))) as ex:
+        recs = list(ex.map(one, list(frames)))
+        pairs = list(ex.map(pair, list(zip(recs[:-1], recs[1:]))))
+    return recs, pairs
+
+
+def verify_records(res, recs, pairs):
+    """Compare the first len(recs) frames of a step's results (FrontEnd*.results()) with the oracle's: every record, bit for bit.
+    Returns {"frames", "exact", "mismatches"}."""
+    bad = []
+    for b, r in enumerate(recs):
+        n, nl = int(res["n"][b]), int(res["nl"][b])
+        if n != len(r["desc"]):
+            bad.append("frame %d: %d keypoints vs %d" % (b, n, len(r["desc"])))
+            continue
+        for f in r["kps"].dtype.names:
+            if not (res["kps"][b, :n][f] == r["kps"][f]).all():
+                bad.append("frame %d: keypoint field %s" % (b, f))
+        if not (res["desc"][b, :n] == r["desc"]).all():
+            bad.append("frame %d: rBRIEF descriptors" % b)
+        if not ((res["nid"][b, :n] == r["nid"]).all() and (res["word"][b, :n] == r["word"]).all()):
+            bad.append("frame %d: FeatureVector nodes / words" % b)
+        m = len(r["bow_word"])
+        if not (int(res["bow_n"][b]) == m and (res["bow_word"][b, :m] == r["bow_word"]).all() and (res["bow_value"][b, :m] == r["bow_value"]).all()):
+            bad.append("frame %d: BowVector" % b)
+        if nl != len(r["kl"]):
+            bad.append("frame %d: %d keylines vs %d" % (b, nl, len(r["kl"])))
+            continue
+        for f in r["kl"].dtype.names:
+            if not (res["kl"][b, :nl][f] == r["kl"][f]).all():
+                bad.append("frame %d: keyline field %s" % (b, f))
+        if not ((res["ldesc"][b, :nl] == r["ldesc"]).all() and (res["lfn"][b, :nl] == r["lfn"]).all()):
+            bad.append("frame %d: LBD descriptors / line equations" % b)
+    for b, q in enumerate(pairs):
+        if not (int(res["nm_orb"][b]) == q["nm_orb"] and (res["m_orb"][b, :len(q["m_orb"])] == q["m_orb"]).all()):
+            bad.append("pair %d -> %d: SearchByBoW matches" % (b, b + 1))
+        if not (int(res["nm_line"][b]) == q["nm_line"] and (res["m_line"][b, :len(q["m_line"])] == q["m_line"]).all()):
+            bad.append("pair %d -> %d: SearchDouble matches" % (b, b + 1))
+    return {"frames": len(recs), "pairs": len(pairs), "exact": not bad, "mismatches": bad[:8],
+            "what": "every record of the first %d frames of the timed batch (keypoints, rBRIEF, FeatureVector, BowVector, keylines, LBD, "
+                    "line equations) and the match lists of their %d consecutive pairs, compared bit for bit with the CPU oracle on the "
+                    "same frames" % (len(recs), len(pairs))}
 
 
 class Workload:
@@ -234,8 +328,8 @@ def single_frame_latency(P, torch, dev, frames, nfeatures, nlevels, nlines, K, D
     out["orb"] = round(timed(orb, reps), 3)
     out["line"] = round(timed(line, reps), 3)
     out["total"] = round(timed(both, reps), 3)
-    out["note"] = ("host-buffer calls on one %dx%d frame, %d ORB / %d lines, two host threads (Frame.cc:224-227); one wavefront walks the "
-                   "frame's LSD region growing, see DESIGN.md 'single-frame latency'" % (cols, rows, nfeatures, nlines))
+    out["note"] = ("host-buffer calls on one %dx%d frame, %d ORB / %d lines, two host threads (Frame.cc:224-227); the frame's LSD region growing runs as "
+                   "optimistic transactions on eight wavefronts (k_lsd_grow_mw), see DESIGN.md 'single-frame latency'" % (cols, rows, nfeatures, nlines))
     orb.close()
     line.close()
     return out
@@ -257,6 +351,8 @@ def main():
     ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: records gathered to rank 0 or to every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the N = 1 secondary / streaming / latency legs")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed batch's records with the CPU oracle")
+    ap.add_argument("--verify-frames", type=int, default=64, help="frames of the timed batch compared with the oracle (rank 0)")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # 1-rank RCCL communicator: rehearses the N > 1 path
     ap.add_argument("--serial", action="store_true", help="ORB and line halves on one stream (no overlap); used for PMC runs")
     args = ap.parse_args()
@@ -353,9 +449,11 @@ def main():
         dt = float(t.item())
 
     result_line = None
+    failed_verification = []
     if rank == 0:
         t1 = W.kernel_totals()
         per_ms_timed = [ms / max(n, 1) for ms, n in t1]   # HIP events on the launch streams, over the timed region
+        res = fe.results()   # what the timed steps left in the result buffers (before anything else runs over them)
         # one more pass with both halves on one stream: per-kernel durations without interference between the halves
         fe.overlap = False
         for _ in range(2):
@@ -364,7 +462,15 @@ def main():
         t2 = W.kernel_totals()
         per_ms = [(b[0] - a[0]) / max(b[1] - a[1], 1) for a, b in zip(t1, t2)]
         fe.overlap = not args.serial
-        res = fe.results()
+        verified = None
+        if not args.no_verify:
+            # self-verification: what the timed kernels left in the result buffers, against the oracle on the same frames
+            O = _util.oracle()
+            O.build()
+            nv = min(args.verify_frames, Bp)
+            recs, pairs = oracle_records(O, V, W.frames[:nv], voc, args.nfeatures, args.nlevels, args.nlines,
+                                         TUM1_K if W.tum else None, TUM1_D if W.tum else None)
+            verified = verify_records(res, recs, pairs)
         alg = W.algorithmic_bytes(res)
         dom = int(np.argmax(per_ms))
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame, and the
@@ -435,6 +541,7 @@ def main():
             "roofline": r_dom,
             "roofline_fast": r_fast,
             "pmc_provenance": pmc_note,
+            "verified": verified,
         }
         if gathering:
             tr = {}
@@ -453,6 +560,8 @@ def main():
             out["rccl"] = {"version": comm.rccl_version(), "gather": args.gather, "channel_transports": tr,
                            "bytes_per_rank_per_step": int(sum(b.numel() * b.element_size() for part in recv["send"] for b in part))}
         W.set_profiling(False)
+        if verified is not None and not verified["exact"]:
+            failed_verification.append("timed batch: %s" % verified["mismatches"])
 
     # ---- N = 1 extras (rank 0 only, after the timed region; none of this is in `value`)
     if rank == 0 and world == 1 and not args.no_extras:
@@ -518,10 +627,16 @@ def main():
                     tk = W2.kernel_totals()
                     pm2 = [ms / max(n, 1) for ms, n in tk]
                     res2 = W2.fe.results()
+                    ver2 = None
+                    if not args.no_verify:
+                        recs2, pairs2 = oracle_records(_util.oracle(), V, W2.frames[:min(args.verify_frames, W2.Bp)], voc, 2000, 8, 200, None, None)
+                        ver2 = verify_records(res2, recs2, pairs2)
+                        if not ver2["exact"]:
+                            failed_verification.append("secondary %s: %s" % (label, ver2["mismatches"]))
                     alg2 = W2.algorithmic_bytes(res2)
                     d2 = int(np.argmax(pm2))
                     sec[label] = {"value": round(b2 * 3 / dt2, 1), "ms_per_step": round(dt2 / 3 * 1e3, 3), "steps": 3, "batch": b2, "nsplit": ns2,
-                                  "mean_keypoints_per_frame": round(float(res2["n"].mean()), 1),
+                                  "mean_keypoints_per_frame": round(float(res2["n"].mean()), 1), "verified": ver2,
                                   "roofline": roof(d2, pm2[d2], "HIP events, extra pass with both halves on one stream", W2.Bp, alg2),
                                   "roofline_fast": roof(1, pm2[1], "HIP events, extra pass with both halves on one stream", W2.Bp, alg2)}
                     W2.close()
@@ -565,6 +680,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed_verification:   # a fast kernel whose results differ from the reference's is not done
+        sys.stderr.write("bench.py: records differ from the oracle: %s\n" % "; ".join(failed_verification))
+        sys.exit(1)
 
 
 import ctypes as _C  # noqa: E402

@@ -35,7 +35,7 @@ struct GrowCtx {
 #endif
 };
 #if defined(PLH_GROW_PROF)
-__device__ unsigned long long g_grow_prof[32];   // [16..31]: k_lsd_grow_mw (transactions, retired unused, reruns, wait / scan / run / commit cycles)
+__device__ unsigned long long g_grow_prof[40];   // [16..31]: k_lsd_grow_mw (transactions, retired unused, reruns, wait / scan / run / commit cycles); [32..]: rare-path lanes
 #if defined(HIPEMU) || PLH_GROW_PROF + 0 >= 3
 #define PF_NOW() 0ull
 #else
@@ -243,6 +243,7 @@ __device__ __forceinline__ unsigned long long lsd_aligned_mask(const GrowCtx& c,
   if (d > 270.f) d = fabsf(d - 360.f);
   unsigned long long r = wballot(d < t.lo);
   const unsigned long long ex = ((~r & wballot(d <= t.hi)) | nearFold) & act;   // d >= lo  <=>  !(d < lo): angles are finite
+  PF_ADD(c, 32, __popcll(act)); PF_ADD(c, 33, __popcll(ex));   // lanes decided by the reference's fastAtan2 arithmetic / by its double form
   if (ex) {
     bool e = false;
     if (LSD_INV_BALLOT(c, ex)) e = lsd_aligned((double)thF * kDegToRads, (double)aF * kDegToRads, t.prec);
@@ -821,8 +822,8 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;   // packed coordinates x | y << 16
   float* segs = a.segs + (long long)b * a.arenaStride;
 #if defined(PLH_GROW_PROF)
-  unsigned long long pfv[16];
-  for (int i = 0; i < 16; i++) pfv[i] = 0;
+  unsigned long long pfv[40];
+  for (int i = 0; i < 40; i++) pfv[i] = 0;
   c.pf = pfv;
   const unsigned long long pfStart = PF_NOW();
 #endif
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
 #if defined(PLH_GROW_PROF)
   pfv[0] = PF_NOW() - pfStart;
   if (lane == 0)
-    for (int i = 0; i < 16; i++) atomicAdd(&g_grow_prof[i], pfv[i]);
+    for (int i = 0; i < 40; i++) atomicAdd(&g_grow_prof[i], pfv[i]);
 #endif
 }
 
@@ -1267,6 +1268,7 @@ __device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArg
     if (lane == 0) gs.d[0] = radSq;
     cnt = lsd_reduce_radius_step<true>(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
     if (cnt < 2) { t.emit = false; break; }
+    PF_ADD(c, 7, 1);
     lsd_region2rect(c, cnt, (double)regAngS * kDegToRads, a.prec, rec);
   }
   t.finCnt = cnt;
@@ -1347,7 +1349,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       const int gb = badM ? min((__ffsll((long long)badM) - 1) >> 3, nb) : nb;   // posts in front of the first failure
       if (has && isAcc && g < gb) ch.P[idx] = p | LSD_USED;
       h += gb;
-      PF_ADD(ch, 12, gb);
+      PF_ADD(ch, 34, gb);
       if (gb == nb) continue;
       // post h failed: run it again below (general path handles both forms)
     }
@@ -1425,7 +1427,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       PF_ADD(ch, 10, PF_NOW() - pr0);
       MW_TRACE(threadIdx.x >> 6, lane, 9, h);   // ... ends
     }
-    PF_ADD(ch, 13, 1);
+    PF_ADD(ch, 35, 1);
     PLH_WAVE_SYNC();
     if (!inl && ((fl & 1u) || asmLen > 3))
       if (lane == 0) sh.ctl[MWC_RET + wv] += 1;   // the owner may reuse the log's space (only the lock holder writes these)
@@ -1499,8 +1501,8 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   float* segs = a.segs + (long long)b * a.arenaStride;
   const int nOrd = a.nOrdered[b];
 #if defined(PLH_GROW_PROF)
-  unsigned long long pfv[32];
-  for (int i = 0; i < 32; i++) pfv[i] = 0;
+  unsigned long long pfv[40];
+  for (int i = 0; i < 40; i++) pfv[i] = 0;
   c.pf = pfv;
   const unsigned long long pfStart = PF_NOW();
 #endif
@@ -1704,7 +1706,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
 #if defined(PLH_GROW_PROF)
   pfv[0] = PF_NOW() - pfStart;
   if (lane == 0)
-    for (int i = 0; i < 32; i++) atomicAdd(&g_grow_prof[i], pfv[i]);
+    for (int i = 0; i < 40; i++) atomicAdd(&g_grow_prof[i], pfv[i]);
 #endif
 }
 
@@ -2220,14 +2222,14 @@ extern "C" __attribute__((visibility("default"))) int plh_debug_mw_trace(unsigne
   return (int)n;
 }
 #endif
-extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsigned long long* out32, int reset) {
+extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsigned long long* out40, int reset) {
 #if defined(HIPEMU)
-  memcpy(out32, g_grow_prof, sizeof(g_grow_prof));
+  memcpy(out40, g_grow_prof, sizeof(g_grow_prof));
   if (reset) memset(g_grow_prof, 0, sizeof(g_grow_prof));
 #else
-  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_grow_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out40, HIP_SYMBOL(g_grow_prof), sizeof(unsigned long long) * 40) != hipSuccess) return 1;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[40] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_grow_prof), z, sizeof(z)) != hipSuccess) return 1;
   }
 #endif

@@ -1,0 +1,161 @@
+"""GPU soak: hundreds of DISTINCT frames per frame shape against the oracle -- the exactness of region growing rests on rare
+paths (the +-0.05 degree band in which a lane falls back to the reference's fastAtan2 arithmetic, the speculative resolve with
+rollback, the transactions of the multi-wavefront kernel), which a handful of frames barely touch.  Content: textured scenes of
+several densities, low-contrast scenes, white and smooth noise, large flat gradients whose norm sits at LSD's threshold,
+sawtooth ramps (regions of thousands of pixels), and the three real 640x480 images the reference ships (masks/*.png,
+Tracking.cc:83-84) used both as images and as masks.  Every frame: LSD segments, KeyLines, LBD bytes, line equations, ORB
+keypoints and rBRIEF descriptors, bit for bit, with one wavefront per frame and with several."""
+import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import _util
+
+pytestmark = pytest.mark.gpu
+
+N_SOAK = int(os.environ.get("PLSLAM_SOAK_FRAMES", "256"))
+
+
+def _masks():
+    g = np.load(os.path.join(_util.ROOT, "tests", "golden", "ref_masks.npz"))
+    return [np.unpackbits(g[k])[:480 * 640].reshape(480, 640).astype(np.uint8) * 255 for k in ("mask", "tum_mask")]
+
+
+def _box3(img):
+    p = np.pad(img.astype(np.int32), 1, mode="edge")
+    acc = sum(p[dy:dy + img.shape[0], dx:dx + img.shape[1]] for dy in range(3) for dx in range(3))
+    return np.floor(acc / 9.0 + 0.5).astype(np.uint8)
+
+
+def soak_frames(S, rows, cols, count):
+    """`count` distinct frames of mixed content (deterministic)."""
+    rng = np.random.RandomState(rows * 7 + cols)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    out, seen = [], set()
+    masks = _masks() if (rows, cols) == (480, 640) else []
+    k = 0
+    while len(out) < count:
+        kind = k % 8
+        seed = 7000 + k
+        if kind in (0, 1):     # textured scenes, sparse to busy
+            img = S.make_frame(seed, rows, cols, n_rect=int(rng.randint(10, 400)), n_line=int(rng.randint(5, 200)))
+        elif kind == 2:        # low contrast: most gradients near LSD's threshold
+            img = (S.make_frame(seed, rows, cols, n_rect=120, n_line=60).astype(np.int32) // int(rng.randint(4, 12)) + 100).astype(np.uint8)
+        elif kind == 3:        # white noise / smooth noise
+            img = rng.randint(0, 256, (rows, cols)).astype(np.uint8)
+            if k % 16 >= 8:
+                img = _box3(_box3(img))
+        elif kind == 4:        # one flat gradient over the whole image, norm around rho = 5.2 (slope 5 .. 9 grey levels per pixel pair)
+            a, ang = rng.uniform(2.0, 5.0), rng.uniform(0, np.pi)
+            img = np.clip(128 + a * ((xx - cols / 2) * np.cos(ang) + (yy - rows / 2) * np.sin(ang)) * 0.02 * rng.uniform(0.5, 40), 0, 255).astype(np.uint8)
+        elif kind == 5:        # sawtooth ramps: huge regions, wide rectangles, refine() / reduce_region_radius() chains
+            period, slope = int(rng.randint(12, 90)), int(rng.randint(2, 9))
+            ang = rng.uniform(0, np.pi)
+            t = (xx * np.cos(ang) + yy * np.sin(ang))
+            img = ((np.floor(t) % period) * slope % 256).astype(np.uint8)
+            img[::7, ::5] += 1
+        elif kind == 6 and masks:   # the reference's real images, as they are and blended into a scene
+            m = masks[(k // 8) % len(masks)]
+            img = m if (k // 16) % 2 == 0 else (m // 2 + S.make_frame(seed, rows, cols) // 2).astype(np.uint8)
+            if (k // 32) % 2:
+                img = np.roll(img, int(rng.randint(1, 200)), axis=1)
+        else:                  # scene + noise of random strength
+            img = np.clip(S.make_frame(seed, rows, cols).astype(np.int32) + rng.randint(-int(rng.randint(1, 40)), 41, (rows, cols)), 0, 255).astype(np.uint8)
+        k += 1
+        key = img.tobytes()
+        if key in seen:        # (a saturated gradient can repeat)
+            continue
+        seen.add(key)
+        out.append(np.ascontiguousarray(img))
+    return np.stack(out)
+
+
+def _oracle_all(O, frames, nfeat):
+    def one(img):
+        orb = O.OrbOracle(nfeat, 1.2, 8, 20, 7)
+        kps, desc = orb.extract(img)
+        kl, ld, fn = O.line_extract(img, 200, 0.0)
+        return kps, desc, kl, ld, fn, O.lsd_detect(img)
+    with ThreadPoolExecutor(os.cpu_count() or 1) as ex:
+        return list(ex.map(one, list(frames)))
+
+
+def _gpu_lines(P, frames, waves, lib=None):
+    import torch
+    B, rows, cols = frames.shape
+    ex = P.LINEextractor(1, 1.2, 200, 0.0, rows=rows, cols=cols, max_batch=B, lib=lib)
+    ex.set_grow_waves(waves)
+    cap = ex.capacity
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_kl = torch.zeros((B, cap, 17), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_fn = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    ex.extract_batch_dev(d_img, B, rows * cols, d_kl, d_desc, d_fn, d_n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ex.status() == 0
+    n = d_n.cpu().numpy()
+    kl = d_kl.cpu().numpy().view(np.uint8).reshape(B, cap, 68).copy().view(P.KL_DTYPE).reshape(B, cap)
+    segs = [ex.read_segments(b) for b in range(B)]
+    out = [(kl[b, :n[b]], d_desc[b, :n[b]].cpu().numpy(), d_fn[b, :n[b]].cpu().numpy(), segs[b]) for b in range(B)]
+    ex.close()
+    return out
+
+
+@pytest.mark.parametrize("rows,cols,nfeat", [(480, 640, 1000), (376, 1241, 2000)], ids=["640x480", "1241x376"])
+def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat):
+    import torch
+    frames = soak_frames(synth, rows, cols, N_SOAK)
+    assert len({f.tobytes() for f in frames}) == N_SOAK          # distinct
+    ref = _oracle_all(oracle, frames, nfeat)
+    nseg = sum(len(r[5]) for r in ref)
+    # lines: one wavefront per frame (k_lsd_grow), the automatic choice (k_lsd_grow_mw for this batch size), and four per frame
+    for waves in (0, -1, 4):
+        got = _gpu_lines(plslam, frames, waves)
+        for b, ((kl, ld, fn, sg), r) in enumerate(zip(got, ref)):
+            assert len(sg) == len(r[5]) and (sg == r[5]).all(), "waves %d, frame %d: LSD segments differ from the oracle" % (waves, b)
+            assert len(kl) == len(r[2]) and all((kl[f] == r[2][f]).all() for f in r[2].dtype.names), "waves %d, frame %d: KeyLines" % (waves, b)
+            assert (ld == r[3]).all() and (fn == r[4]).all(), "waves %d, frame %d: LBD / line equations" % (waves, b)
+    # ORB on the same frames
+    ex = plslam.ORBextractor(nfeat, 1.2, 8, 20, 7, rows=rows, cols=cols, max_batch=N_SOAK)
+    cap = ex.capacity
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_kps = torch.zeros((N_SOAK, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((N_SOAK, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((N_SOAK,), dtype=torch.int32, device=dev)
+    ex.extract_batch_dev(d_img, N_SOAK, rows * cols, d_kps, d_desc, d_n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ex.status() == 0
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(N_SOAK, cap, 28).copy().view(plslam.KP_DTYPE).reshape(N_SOAK, cap)
+    desc = d_desc.cpu().numpy()
+    ex.close()
+    nkp = 0
+    for b, r in enumerate(ref):
+        assert n[b] == len(r[0]), "frame %d: %d keypoints vs %d" % (b, n[b], len(r[0]))
+        for f in r[0].dtype.names:
+            assert (kps[b, :n[b]][f] == r[0][f]).all(), "frame %d: keypoint field %s" % (b, f)
+        assert (desc[b, :n[b]] == r[1]).all(), "frame %d: rBRIEF" % b
+        nkp += int(n[b])
+    # what the soak exercised: counters of the profiling build (same sources, -DPLH_GROW_PROF=1), when it was built
+    prof = os.path.join(_util.ROOT, "pl-slam_amd", "libplslam_hip_prof.so")
+    cover = ""
+    if os.path.exists(prof):
+        L = plslam.load(prof)
+        out = (C.c_ulonglong * 40)()
+        for waves in (0, -1):
+            L.plh_debug_grow_prof(out, 1)
+            got = _gpu_lines(plslam, frames, waves, lib=prof)
+            L.plh_debug_grow_prof(out, 0)
+            assert all(len(g[3]) == len(r[5]) and (g[3] == r[5]).all() for g, r in zip(got, ref))
+            cover += ("  [waves %d] steps %d, accepted pixels %d, resolve passes %d, mispredictions %d, lanes decided by fastAtan2 %d "
+                      "(of them by the double form %d), region2rect calls %d, refine %d, reduce-radius steps %d, transactions %d "
+                      "(re-run: own %d, at commit %d)\n" % (waves, out[8], out[9], out[12], out[13], out[32], out[33], out[14], out[15], out[7],
+                                                             out[16], out[18], out[24]))
+    print("\nsoak %dx%d: %d distinct frames, %d LSD segments and %d ORB keypoints bit-exact (waves 0 / auto / 4)\n%s"
+          % (cols, rows, N_SOAK, nseg, nkp, cover))

@@ -42,7 +42,7 @@ def main():
     fn = torch.zeros((B, cap, 3), dtype=torch.float64, device="cuda")
     nl = torch.zeros((B,), dtype=torch.int32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 40)()
     le.extract_batch_dev(d, B, 480 * 640, kl, ld, fn, nl, s)
     torch.cuda.synchronize()
     if prof:

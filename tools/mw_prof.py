@@ -25,7 +25,7 @@ cap = le.capacity
 bufs = [torch.zeros((B, cap, 17), dtype=torch.float32, device="cuda"), torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
         torch.zeros((B, cap, 3), dtype=torch.float64, device="cuda"), torch.zeros((B,), dtype=torch.int32, device="cuda")]
 s = torch.cuda.current_stream().cuda_stream
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 40)()
 N = ["total", "rect px", "grow", "grow:load", "grow:resolve", "rect", "refine", "#reduce", "#steps", "#accepted", "#cands", "#grow calls",
      "#passes", "#mispred", "#rect", "#refine", "#txn", "#unused", "#rerun", "wait turn", "scan", "wait seed", "run", "commit"]
 for W in [int(x) for x in a.waves.split(",")]:
@@ -44,7 +44,7 @@ for W in [int(x) for x in a.waves.split(",")]:
     cnt = lambda k: out[k] / nf           # per frame
     print("   grow %.0f rect %.0f refine %.0f validate+unmark %.0f post %.0f (us per wavefront); rects %.0f refines %.0f predicted-unused %.0f; drain re-runs: accepted pixel used %.0f, assumed pixel free %.0f (predicted-unused %.0f) per frame" %
           (cyc(2), cyc(5), cyc(6), cyc(26), cyc(27), cnt(14), cnt(15), cnt(28), cnt(29), cnt(30), cnt(31)))
-    print("   drain: %.0f posts committed in inline batches, %.0f one by one; re-runs took %.0f us per wavefront" % (cnt(12), cnt(13), cyc(10)))
+    print("   drain: %.0f posts committed in inline batches, %.0f one by one; re-runs took %.0f us per wavefront" % (cnt(34), cnt(35), cyc(10)))
     print("waves %2d: extract %.2f ms | per wavefront (us): total %.0f  run %.0f  idle %.0f  drain %.0f  scan %.0f | per frame: txn %.0f unused %.0f "
           "rerun own %.0f drain %.0f  drain sessions %.0f  steps %.0f accepted %.0f grow-calls %.0f" %
           (W, dt * 1e3, cyc(0), cyc(22) if W else cyc(2) + cyc(5) + cyc(6), cyc(19), cyc(23), cyc(20), cnt(16), cnt(17), cnt(18), cnt(24), cnt(25),
