@@ -223,12 +223,17 @@ def verify_records(res, recs, pairs):
 class Workload:
     """One resident batch + the pipelined front end over it."""
 
-    def __init__(self, P, S, V, PL, torch, dev, rank, batch, nsplit, rows, cols, nfeatures, nlevels, nlines, unique, voc, serial=False):
+    def __init__(self, P, S, V, PL, torch, dev, rank, batch, nsplit, rows, cols, nfeatures, nlevels, nlines, unique, voc, serial=False,
+                 shard=None):
         self.P, self.torch, self.dev = P, torch, dev
         self.B, self.rows, self.cols, self.nfeatures, self.nlevels, self.nlines = batch, rows, cols, nfeatures, nlevels, nlines
         self.tum = (rows, cols) == (480, 640)
         K, D = (TUM1_K, TUM1_D) if self.tum else (None, None)     # KITTI: zero distortion -> no remap (Frame.cc:917-921)
-        self.frames = S.make_frames(2 + 100000 * rank, batch, rows, cols, unique=unique)
+        if shard is None:     # weak scaling: every rank has its own batch
+            self.frames = S.make_frames(2 + 100000 * rank, batch, rows, cols, unique=unique)
+        else:                 # strong scaling: this rank's contiguous shard of ONE job of `total` frames
+            r, n, total = shard
+            self.frames = np.ascontiguousarray(S.make_frames(2, total, rows, cols, unique=unique)[r * (total // n):(r + 1) * (total // n)])
         self.d_imgs = torch.from_numpy(self.frames).to(dev)
         self.fe = PL.FrontEndPipelined(P, voc, batch, rows, cols, nfeatures, nlevels, nlines, 0.0, K, D, device=dev.index, nsplit=nsplit)
         self.fe.overlap = not serial
@@ -349,6 +354,10 @@ def main():
     ap.add_argument("--nlines", type=int, default=200)
     ap.add_argument("--unique", type=int, default=32, help="distinct rasterised frames (the rest are cheap variants)")
     ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: records gathered to rank 0 or to every rank")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch frames per GPU; strong: --total frames in all, contiguous shards of total / N per rank "
+                         "(BASELINE configs[4]: --scaling strong --total 4096 --rows 376 --cols 1241)")
+    ap.add_argument("--total", type=int, default=4096, help="--scaling strong: frames of the whole job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the N = 1 secondary / streaming / latency legs")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed batch's records with the CPU oracle")
@@ -382,12 +391,24 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # barrier + max-over-ranks + id exchange
 
+    strong = args.scaling == "strong"
+    if strong:
+        # the literal configs[4] job: a fixed set of frames, rank r owns the contiguous shard [r, r + 1) * total / N, one gather
+        if args.total % world:
+            raise SystemExit("--total %d is not a multiple of the %d ranks" % (args.total, world))
+        args.batch = args.total // world
+        if (args.rows, args.cols) == (376, 1241) and args.nfeatures == 1000:
+            args.nfeatures = 2000          # KITTI00-02.yaml
+        if args.nsplit == 4:               # (the default) sub-batches of at least 1024 frames
+            args.nsplit = max(1, min(4, args.batch // 1024))
+        while args.batch % args.nsplit:
+            args.nsplit -= 1
     P, S = _util.plslam(), _util.synth()
     V = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
     PL = _util._load("plslam_amd_pipeline", os.path.join(ROOT, "pl-slam_amd", "pipeline.py"))
     voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=S, idf=True)
     W = Workload(P, S, V, PL, torch, dev, rank, args.batch, args.nsplit, args.rows, args.cols, args.nfeatures, args.nlevels, args.nlines,
-                 args.unique, voc, serial=args.serial)
+                 args.unique, voc, serial=args.serial, shard=(rank, world, args.total) if strong else None)
     fe, B, Bp, rows, cols = W.fe, W.B, W.Bp, W.rows, W.cols
 
     comm = comm_stream = None
@@ -518,7 +539,7 @@ def main():
             "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "host_enqueue_ms_per_step": [round(v, 2) for v in host_ms],   # how far the host runs ahead of the GPU (launch queues)
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%dx%d mono, %d-level pyramid, %d ORB / %d lines (%s parameters), batch %d frames/GPU resident in HBM "
                                    "(%d sub-batches of %d pipelined, consecutive steps overlap, nothing crosses PCIe in the timed region); "
                                    "extract + ComputeBoW + SearchByBoW + line SearchDouble per consecutive frame pair"
@@ -533,7 +554,8 @@ def main():
                                  "minThFAST -- a stress case, real TUM frames are sparser" % args.unique,
                        "vocabulary": "synthetic k=10 L=6, idf-like weights (ORBvoc.bin is not in the mount)",
                        "streams": "line chain on a high-priority stream, ORB + BoW + SearchByBoW on a second stream" if not args.serial else "one stream",
-                       "parallelism": "frames sharded 1 batch/GPU" + (
+                       "parallelism": ("one job of %d frames, contiguous shards of %d per GPU" % (args.total, B) if strong else
+                                       "frames sharded 1 batch/GPU") + (
                            ", records gathered %s through plh_gather_records (RCCL, one grouped launch per sub-batch on a communication "
                            "stream)" % ("to rank 0" if args.gather == "root" else "to every rank") if gathering else "")},
             "kernel_ms_per_launch": {NAMES[k]: round(per_ms[k], 4) for k in range(8)},

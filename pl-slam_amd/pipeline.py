@@ -183,6 +183,12 @@ class FrontEndPipelined:
         self.dev = torch.device("cuda", device)
         self.parts = [FrontEndBatch(P, vocab, self.Bp, rows, cols, nfeatures, nlevels, n_lines, min_line_length, K, D, device)
                       for _ in range(nsplit)]
+        # The library picks the wavefronts per frame of LSD's region growing by the size of ONE launch; here `nsplit` launches
+        # are resident together, so the choice goes by the frames resident in all of them: from 2048 on one wavefront per frame
+        # fills the GPU (tools/mw_sweep.py), and the transactions of the multi-wavefront kernel would only add instructions.
+        if batch >= 2048:
+            for p in self.parts:
+                p.line.set_grow_waves(0)
         self.ev_start = torch.cuda.Event()
 
     @property
