@@ -584,6 +584,67 @@ PLH_API plh_status plh_line_kernel_ms(plh_line* h, int stage, double* total_ms, 
 /* parity taps */
 PLH_API plh_status plh_line_read_segments(plh_line* h, int b, float* out_xyxy, int cap, int* n_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batch front end: the host side of the throughput path (what Frame::Frame(), Frame.cc:193-276, and Tracking's
+ * frame-to-frame matching do per frame, for a batch of independent frames resident in device memory).
+ * One step = ORBextractor + undistort / LINEextractor + Frame::ComputeBoW per frame, ORBmatcher::SearchByBoW and
+ * LSDmatcher::SearchDouble between frame b and frame b + 1 (the last frame of a sub-batch is matched against its first).
+ * The handle owns `nsplit` sub-batches (extractor handles, record buffers, a high-priority stream for the line chain and a
+ * second one for the ORB chain, events); a sub-batch depends on its own previous step only, so un-joined steps overlap.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct plh_frontend plh_frontend;
+
+typedef struct plh_frontend_params {
+  int32_t rows, cols;
+  plh_orb_params orb;              /* ORBextractor(nFeatures, fScaleFactor, nLevels, fIniThFAST, fMinThFAST), Tracking.cc:96-131 */
+  plh_line_params line;            /* LINEextractor(1, scale, nLSDFeature, min_line_length) */
+  int32_t undistort;               /* 1: remap with K / D in front of LSD (Frame.cc:220-222) */
+  float K[4], D[5];
+  int32_t bow_levelsup;            /* Frame::ComputeBoW: 4 (Frame.cc:911) */
+  int32_t orb_th_low;              /* ORBmatcher::TH_LOW = 50 */
+  float orb_nnratio;               /* ORBmatcher(0.7, true) of TrackReferenceKeyFrame (Tracking.cc:1151) */
+  int32_t orb_check_orientation;
+  float line_th, line_nnratio;     /* LSDmatcher::SearchDouble: TH_LOW = 50, mfNNratio */
+  int32_t external_records;        /* 1: the caller supplies the record buffers (plh_frontend_bind_records) */
+} plh_frontend_params;
+
+/* Device pointers of one sub-batch's records, frames [first, first + frames) of the batch.  Per-frame arrays have
+ * frames + 1 slots where a successor is matched (slot `frames` = copy of slot 0): kps, desc, n, nid, word, bow_*, kl, ldesc,
+ * lfn (frames + 1 slots as well), nl.  m_orb[frames][orb_capacity] = SearchByBoW's vpMapPointMatches index per feature of
+ * the successor (-1: none), m_line[frames][line_capacity] = SearchDouble's match per line of the frame. */
+typedef struct plh_frontend_records {
+  int32_t first, frames, orb_capacity, line_capacity;
+  plh_keypoint* kps; uint8_t* desc; int32_t* n;
+  int32_t *nid, *word, *bow_word; double* bow_value; int32_t* bow_n;
+  plh_keyline* kl; uint8_t* ldesc; double* lfn; int32_t* nl;
+  int32_t *m_orb, *nm_orb, *m_line, *nm_line;
+} plh_frontend_records;
+
+PLH_API plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* voc, int batch, int nsplit, int device,
+                                       plh_frontend** out);
+PLH_API plh_status plh_frontend_destroy(plh_frontend* fe);
+PLH_API int plh_frontend_parts(const plh_frontend* fe);
+/* the sub-batch's extractor handles (profiling, plh_line_set_grow_waves, ...) and its record buffers */
+PLH_API plh_status plh_frontend_handles(plh_frontend* fe, int part, plh_orb** orb, plh_line** line);
+PLH_API plh_status plh_frontend_records_of(plh_frontend* fe, int part, plh_frontend_records* out);
+/* external_records = 1: the buffers of a sub-batch (every pointer set, sized by first / frames / capacities of
+ * plh_frontend_records_of, which reports the capacities with null pointers until they are bound) */
+PLH_API plh_status plh_frontend_bind_records(plh_frontend* fe, int part, const plh_frontend_records* r);
+/* Enqueue one pass over d_imgs[batch] (u8, frame_stride bytes apart) behind `stream`; join = 1 makes `stream` wait for it
+ * (plh_frontend_join does that later).  overlap = 0 runs both halves of every sub-batch on `stream` itself. */
+PLH_API plh_status plh_frontend_step(plh_frontend* fe, const uint8_t* d_imgs, size_t frame_stride, void* stream, int join);
+PLH_API plh_status plh_frontend_join(plh_frontend* fe, void* stream);
+PLH_API plh_status plh_frontend_set_overlap(plh_frontend* fe, int on);
+/* RCCL gather of every sub-batch's records (n, kps, desc, nl, kl, ldesc, lfn: PLH_FRONTEND_GATHERED blocks each, sizes from
+ * plh_frontend_gather_bytes) on `comm_stream`, as soon as that sub-batch is done; recv[parts * PLH_FRONTEND_GATHERED] device
+ * buffers of world x bytes each on receiving ranks (root = -1: all ranks), NULL elsewhere.  A sub-batch's next step waits
+ * for its own gather only. */
+#define PLH_FRONTEND_GATHERED 7
+PLH_API plh_status plh_frontend_gather(plh_frontend* fe, plh_comm* comm, int root, void* const* recv, void* comm_stream);
+PLH_API plh_status plh_frontend_gather_bytes(const plh_frontend* fe, int part, size_t bytes[PLH_FRONTEND_GATHERED]);
+/* Waits for everything enqueued; flags = OR of the extractors' capacity flags (ORB in bits 0-7, lines in bits 8-15). */
+PLH_API plh_status plh_frontend_status(plh_frontend* fe, int* flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,22 @@ class LineParams(C.Structure):
                 ("min_line_length", C.c_double)]
 
 
+class FrontendParams(C.Structure):   # plh_frontend_params
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("orb", OrbParams), ("line", LineParams), ("undistort", C.c_int32),
+                ("K", C.c_float * 4), ("D", C.c_float * 5), ("bow_levelsup", C.c_int32), ("orb_th_low", C.c_int32),
+                ("orb_nnratio", C.c_float), ("orb_check_orientation", C.c_int32), ("line_th", C.c_float), ("line_nnratio", C.c_float),
+                ("external_records", C.c_int32)]
+
+
+class FrontendRecords(C.Structure):   # plh_frontend_records
+    _fields_ = [("first", C.c_int32), ("frames", C.c_int32), ("orb_capacity", C.c_int32), ("line_capacity", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("kps", "desc", "n", "nid", "word", "bow_word", "bow_value", "bow_n", "kl", "ldesc", "lfn", "nl",
+                                          "m_orb", "nm_orb", "m_line", "nm_line")]
+
+
+FRONTEND_GATHERED = 7   # PLH_FRONTEND_GATHERED: n, kps, desc, nl, kl, ldesc, lfn
+
+
 _V, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SIGS = {
     "plh_last_error": ([], C.c_char_p),
@@ -95,6 +111,18 @@ _SIGS = {
     "plh_line_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
     "plh_line_set_grow_waves": ([_V, _I], _I),
+    "plh_frontend_create": ([_V, _V, _I, _I, _I, _V], _I),
+    "plh_frontend_destroy": ([_V], _I),
+    "plh_frontend_parts": ([_V], _I),
+    "plh_frontend_handles": ([_V, _I, _V, _V], _I),
+    "plh_frontend_records_of": ([_V, _I, _V], _I),
+    "plh_frontend_bind_records": ([_V, _I, _V], _I),
+    "plh_frontend_step": ([_V, _V, _Z, _V, _I], _I),
+    "plh_frontend_join": ([_V, _V], _I),
+    "plh_frontend_set_overlap": ([_V, _I], _I),
+    "plh_frontend_gather": ([_V, _V, _I, _V, _V], _I),
+    "plh_frontend_gather_bytes": ([_V, _I, _V], _I),
+    "plh_frontend_status": ([_V, _V], _I),
     "plh_orb_search_for_triangulation_batch_dev": ([_V] * 10 + [_I, _I, _V, _F, _F, _V, _V, _I, _I, _I, _V, _V, _V], _I),
     "plh_orb_search_by_bow_kfkf_batch_dev": ([_V] * 10 + [_I, _I, _I, _F, _I, _V, _V, _V], _I),
     "plh_orb_search_by_projection_kf_batch_dev": ([_V, _V, _V, _I, _I, _V, _V, _V, _V, _I, _V, _V, _I] + [_V] * 6 +

@@ -167,61 +167,117 @@ class FrontEndBatch:
                     nm_line=self.nm_line.cpu().numpy())
 
 
+class _Borrowed:
+    """An extractor handle owned by a plh_frontend, seen through the per-handle API (profiling, status, grow waves)."""
+
+    def __init__(self, cls, lib, h, capacity):
+        self._obj = cls.__new__(cls)
+        self._obj.lib, self._obj.h, self._obj.capacity = lib, h, capacity
+        self._obj.close = lambda: None          # the front end destroys it
+
+    def __getattr__(self, k):
+        return getattr(self._obj, k)
+
+
+class _Part:
+    pass
+
+
 class FrontEndPipelined:
-    """The same front end over `nsplit` sub-batches, each with its own extractor handles and stream pair.
-    LSD region growing is latency-bound (one wavefront per frame) while every other kernel is a dense streaming
-    kernel: with the sub-batches staggered, the dense kernels of one run underneath the region growing of another,
-    and -- because a sub-batch only depends on its own previous step -- consecutive steps overlap as well (the
-    batches of a video stream are independent).  `step(..., join=True)` restores strict step-by-step completion on
-    the caller's stream (needed when the results are consumed there, e.g. by an RCCL gather)."""
+    """The same front end over `nsplit` sub-batches, each with its own extractor handles and stream pair -- a binding of the
+    library's plh_frontend_* (csrc/frontend_host.hip: the sub-batch handles, the stream pairs with the line chain on the
+    high-priority one, the events and the per-sub-batch gather live in C++; a C++ host calls the same four functions).
+    LSD region growing is latency-bound while every other kernel is a dense streaming kernel: with the sub-batches staggered,
+    the dense kernels of one run underneath the region growing of another, and -- because a sub-batch only depends on its
+    own previous step -- consecutive steps overlap as well (the batches of a video stream are independent).
+    `step(..., join=True)` restores strict step-by-step completion on the caller's stream.  The record buffers are torch
+    tensors bound to the handle (external_records), so that the results are visible to Python without a copy."""
+
+    GATHERED = ("n", "kps", "desc", "nl", "kl", "ldesc", "lfn")   # the records a tracker on another GPU needs (SURVEY 8e)
 
     def __init__(self, P, vocab, batch, rows=480, cols=640, nfeatures=1000, nlevels=8, n_lines=200, min_line_length=0.0,
                  K=None, D=None, device=0, nsplit=2):
         import torch
         assert batch % nsplit == 0
-        self.torch, self.B, self.nsplit, self.Bp = torch, batch, nsplit, batch // nsplit
+        self.torch, self.P, self.B, self.nsplit, self.Bp = torch, P, batch, nsplit, batch // nsplit
         self.dev = torch.device("cuda", device)
-        self.parts = [FrontEndBatch(P, vocab, self.Bp, rows, cols, nfeatures, nlevels, n_lines, min_line_length, K, D, device)
-                      for _ in range(nsplit)]
-        # The library picks the wavefronts per frame of LSD's region growing by the size of ONE launch; here `nsplit` launches
-        # are resident together, so the choice goes by the frames resident in all of them: from 2048 on one wavefront per frame
-        # fills the GPU (tools/mw_sweep.py), and the transactions of the multi-wavefront kernel would only add instructions.
-        if batch >= 2048:
-            for p in self.parts:
-                p.line.set_grow_waves(0)
-        self.ev_start = torch.cuda.Event()
+        self.lib = L = P.load()
+        if getattr(vocab, "_plh_handle", None) is None or vocab._plh_handle.device != device:
+            hv = P.ORBVocabulary(device=device)
+            parent, leaf = vocab.tree_arrays()
+            hv.create(vocab.k, vocab.L, parent, leaf, vocab.node_desc, vocab.weight64)
+            vocab._plh_handle = hv
+        self.hvoc = vocab._plh_handle
+        fp = P.FrontendParams()
+        fp.rows, fp.cols = rows, cols
+        fp.orb = P.OrbParams(nfeatures, 1.2, nlevels, 20, 7)
+        fp.line = P.LineParams(1, 1.2, n_lines, min_line_length)
+        und = K is not None and D is not None and any(float(d) != 0.0 for d in D)
+        fp.undistort = int(und)
+        if und:
+            fp.K = (C.c_float * 4)(*[float(v) for v in K])
+            fp.D = (C.c_float * 5)(*[float(v) for v in D])
+        fp.bow_levelsup, fp.orb_th_low, fp.orb_nnratio, fp.orb_check_orientation = 4, 50, 0.7, 1
+        fp.line_th, fp.line_nnratio = 50.0, 0.7
+        fp.external_records = 1
+        h = C.c_void_p()
+        P._check(L, L.plh_frontend_create(C.byref(fp), self.hvoc.h, batch, nsplit, device, C.byref(h)), "plh_frontend_create")
+        self.h = h
+        self._overlap = True
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)
+        self.parts = []
+        for k in range(nsplit):
+            r = P.FrontendRecords()
+            P._check(L, L.plh_frontend_records_of(self.h, k, C.byref(r)), "plh_frontend_records_of")
+            pt = _Part()
+            pt.B, pt.ocap, pt.lcap = r.frames, r.orb_capacity, r.line_capacity
+            B, B1, oc, lc = pt.B, pt.B + 1, pt.ocap, pt.lcap
+            pt.kps, pt.desc, pt.n = z((B1, oc, 7), torch.float32), z((B1, oc, 32), torch.uint8), z((B1,), torch.int32)
+            pt.nid, pt.word, pt.bow_word = z((B1, oc), torch.int32), z((B1, oc), torch.int32), z((B1, oc), torch.int32)
+            pt.bow_value, pt.bow_n = z((B1, oc), torch.float64), z((B1,), torch.int32)
+            pt.kl, pt.ldesc, pt.lfn, pt.nl = z((B1, lc, 17), torch.float32), z((B1, lc, 32), torch.uint8), z((B1, lc, 3), torch.float64), z((B1,), torch.int32)
+            pt.m_orb, pt.nm_orb = z((B, oc), torch.int32), z((B,), torch.int32)
+            pt.m_line, pt.nm_line = z((B, lc), torch.int32), z((B,), torch.int32)
+            for name in ("kps", "desc", "n", "nid", "word", "bow_word", "bow_value", "bow_n", "kl", "ldesc", "lfn", "nl", "m_orb", "nm_orb",
+                         "m_line", "nm_line"):
+                setattr(r, name, getattr(pt, name).data_ptr())
+            P._check(L, L.plh_frontend_bind_records(self.h, k, C.byref(r)), "plh_frontend_bind_records")
+            ho, hl = C.c_void_p(), C.c_void_p()
+            P._check(L, L.plh_frontend_handles(self.h, k, C.byref(ho), C.byref(hl)), "plh_frontend_handles")
+            pt.orb = _Borrowed(P.ORBextractor, L, ho, oc)
+            pt.line = _Borrowed(P.LINEextractor, L, hl, lc)
+            self.parts.append(pt)
 
     @property
     def overlap(self):
-        return self.parts[0].overlap
+        return self._overlap
 
     @overlap.setter
     def overlap(self, v):
-        for p in self.parts:
-            p.overlap = v
+        self._overlap = bool(v)
+        self.P._check(self.lib, self.lib.plh_frontend_set_overlap(self.h, int(bool(v))), "plh_frontend_set_overlap")
 
     def close(self):
-        for p in self.parts:
-            p.close()
+        if getattr(self, "h", None):
+            self.lib.plh_frontend_destroy(self.h)
+            self.h = None
         self.parts = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def step(self, d_imgs, join=True):
         main = self.torch.cuda.current_stream(self.dev)
-        self.ev_start.record(main)
-        Bp = self.Bp
-        for k, p in enumerate(self.parts):      # critical-path (line) chains first, then the ORB chains
-            p.enqueue_line(d_imgs[k * Bp:(k + 1) * Bp], main, self.ev_start)
-        for k, p in enumerate(self.parts):
-            p.enqueue_orb(d_imgs[k * Bp:(k + 1) * Bp], main, self.ev_start)
-        if join:
-            self.join()
+        rows_cols = d_imgs.shape[1] * d_imgs.shape[2]
+        self.P._check(self.lib, self.lib.plh_frontend_step(self.h, self.P._p(d_imgs), rows_cols, C.c_void_p(main.cuda_stream), int(join)),
+                      "plh_frontend_step")
 
     def join(self):
         main = self.torch.cuda.current_stream(self.dev)
-        for p in self.parts:
-            p.join(main)
-
-    GATHERED = ("n", "kps", "desc", "nl", "kl", "ldesc", "lfn")   # the records a tracker on another GPU needs (SURVEY 8e)
+        self.P._check(self.lib, self.lib.plh_frontend_join(self.h, C.c_void_p(main.cuda_stream)), "plh_frontend_join")
 
     def alloc_gather_buffers(self, world, receives=True):
         """Per sub-batch: the send views (this rank's records) and, on receiving ranks, buffers for `world` ranks' records."""
@@ -234,21 +290,34 @@ class FrontEndPipelined:
 
     def gather(self, comm_stream, comm, root, bufs):
         """N > 1: the fixed-stride records of every sub-batch go over RCCL on `comm_stream` as soon as that sub-batch is done
-        (plh_gather_records: one grouped launch per sub-batch; root = -1 all ranks receive, else only `root`), without joining
-        the step: a sub-batch's next step waits only for its own gather (which reads its buffers), so the xGMI traffic overlaps
-        with the compute of the other sub-batches."""
-        t = self.torch
-        for p, sv, rv in zip(self.parts, bufs["send"], bufs["recv"]):
-            if p.overlap:
-                comm_stream.wait_event(p.ev_line)
-                comm_stream.wait_event(p.ev_orb)
-            else:
-                comm_stream.wait_stream(t.cuda.current_stream(self.dev))
-            comm.gather(list(zip(sv, rv)), root=root, stream=comm_stream.cuda_stream)
-            if p.ev_free is None:
-                p.ev_free = t.cuda.Event()
-            p.ev_free.record(comm_stream)
+        (plh_frontend_gather -> plh_gather_records: one grouped launch per sub-batch; root = -1 all ranks receive, else only
+        `root`), without joining the step: a sub-batch's next step waits only for its own gather."""
+        if not self._overlap:
+            comm_stream.wait_stream(self.torch.cuda.current_stream(self.dev))
+        ptrs = (C.c_void_p * (self.nsplit * self.P.FRONTEND_GATHERED))()
+        for i, rv in enumerate(bufs["recv"]):
+            for k, t in enumerate(rv):
+                ptrs[i * self.P.FRONTEND_GATHERED + k] = t.data_ptr() if t is not None else None
+        self.P._check(self.lib, self.lib.plh_frontend_gather(self.h, comm.h, root, ptrs, C.c_void_p(comm_stream.cuda_stream)),
+                      "plh_frontend_gather")
 
     def results(self):
-        rs = [p.results() for p in self.parts]
+        """Host copies of everything one step produced (synchronises; raises if a fixed-capacity buffer overflowed)."""
+        t, P = self.torch, self.P
+        t.cuda.synchronize(self.dev)
+        f = C.c_int(0)
+        P._check(self.lib, self.lib.plh_frontend_status(self.h, C.byref(f)), "plh_frontend_status")
+        if f.value:
+            raise P.PlhError("front end: a fixed-capacity buffer overflowed or a launch was abandoned (flags 0x%x)" % f.value)
+        rs = []
+        for p in self.parts:
+            B = p.B
+            kps = p.kps[:B].cpu().numpy().view(np.uint8).reshape(B, p.ocap, 28).copy().view(P.KP_DTYPE).reshape(B, p.ocap)
+            kl = p.kl[:B].cpu().numpy().view(np.uint8).reshape(B, p.lcap, 68).copy().view(P.KL_DTYPE).reshape(B, p.lcap)
+            rs.append(dict(n=p.n[:B].cpu().numpy(), kps=kps, desc=p.desc[:B].cpu().numpy(), nid=p.nid[:B].cpu().numpy(),
+                           word=p.word[:B].cpu().numpy(), bow_word=p.bow_word[:B].cpu().numpy(),
+                           bow_value=p.bow_value[:B].cpu().numpy(), bow_n=p.bow_n[:B].cpu().numpy(),
+                           nl=p.nl[:B].cpu().numpy(), kl=kl, ldesc=p.ldesc[:B].cpu().numpy(), lfn=p.lfn[:B].cpu().numpy(),
+                           m_orb=p.m_orb.cpu().numpy(), nm_orb=p.nm_orb.cpu().numpy(), m_line=p.m_line.cpu().numpy(),
+                           nm_line=p.nm_line.cpu().numpy()))
         return {k: np.concatenate([r[k] for r in rs], axis=0) for k in rs[0]}

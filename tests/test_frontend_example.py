@@ -1,0 +1,152 @@
+"""examples/batch_frontend.cc -- a plain C++ host that drives the whole batch front end through plh_frontend_* (the C++ side
+of the throughput path: sub-batches, stream pairs, events live in the library) -- built by __graft_entry__.build() and run
+here on the GPU; everything it writes is compared with the oracle, record by record."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _util
+from test_line import TUM1_D, TUM1_K
+
+
+def _entry():
+    sys.path.insert(0, _util.ROOT)
+    import __graft_entry__ as g
+    return g
+
+
+def test_example_builds_and_links():
+    g = _entry()
+    exe = g.build_examples()
+    assert os.access(exe, os.X_OK)
+    out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
+    for sym in ("plh_frontend_create", "plh_frontend_step", "plh_frontend_join", "plh_frontend_records_of", "plh_frontend_status",
+                "plh_vocab_load_text"):
+        assert sym in out, sym
+
+
+def _read_out(path, P):
+    raw = open(path, "rb").read()
+    hdr = np.frombuffer(raw, np.int32, 4, 0)
+    off = 16
+    parts = []
+    for _ in range(int(hdr[1])):
+        first, B, oc, lc = [int(v) for v in np.frombuffer(raw, np.int32, 4, off)]
+        off += 16
+
+        def take(dtype, count, shape):
+            nonlocal off
+            a = np.frombuffer(raw, dtype, count, off).reshape(shape)
+            off += a.nbytes
+            return a
+        r = {"first": first, "B": B}
+        r["n"] = take(np.int32, B, (B,))
+        r["kps"] = take(np.uint8, B * oc * 28, (B, oc, 28)).copy().view(P.KP_DTYPE).reshape(B, oc)
+        r["desc"] = take(np.uint8, B * oc * 32, (B, oc, 32))
+        r["nid"] = take(np.int32, B * oc, (B, oc))
+        r["word"] = take(np.int32, B * oc, (B, oc))
+        r["bow_n"] = take(np.int32, B, (B,))
+        r["bow_word"] = take(np.int32, B * oc, (B, oc))
+        r["bow_value"] = take(np.float64, B * oc, (B, oc))
+        r["nl"] = take(np.int32, B, (B,))
+        r["kl"] = take(np.uint8, B * lc * 68, (B, lc, 68)).copy().view(P.KL_DTYPE).reshape(B, lc)
+        r["ldesc"] = take(np.uint8, B * lc * 32, (B, lc, 32))
+        r["lfn"] = take(np.float64, B * lc * 3, (B, lc, 3))
+        r["nm_orb"] = take(np.int32, B, (B,))
+        r["m_orb"] = take(np.int32, B * oc, (B, oc))
+        r["nm_line"] = take(np.int32, B, (B,))
+        r["m_line"] = take(np.int32, B * lc, (B, lc))
+        parts.append(r)
+    assert off == len(raw)
+    return parts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("undist", [False, True])
+def test_cpp_host_matches_the_oracle(plslam, oracle, synth, tmp_path, undist):
+    g = _entry()
+    exe = g.build_examples()
+    sys.path.insert(0, _util.ROOT)
+    import bench
+    V = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    B, ns, rows, cols, nfeat, nlines = 12, 3, 480, 640, 1000, 200
+    frames = synth.make_frames(900 + int(undist), B, rows, cols)
+    voc = V.Vocabulary.synthetic(31, k=10, L=4, synth=synth, idf=True)
+    fbin, vtxt, out = str(tmp_path / "frames.bin"), str(tmp_path / "voc.txt"), str(tmp_path / "out.bin")
+    frames.tofile(fbin)
+    voc.save_text(vtxt)
+    voc = V.Vocabulary.load_text(vtxt)      # the weights as the text file holds them (what the C++ host loads)
+    cmd = [exe, fbin, str(rows), str(cols), str(B), str(ns), str(nfeat), str(nlines), "3", out, vtxt]
+    K, D = (TUM1_K, TUM1_D) if undist else (None, None)
+    if undist:
+        cmd += ["%r" % v for v in K + D]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "frames/s" in run.stdout
+    parts = _read_out(out, plslam)
+    assert sum(p["B"] for p in parts) == B and [p["first"] for p in parts] == [0, 4, 8]
+    for p in parts:
+        idx = list(range(p["first"], p["first"] + p["B"])) + [p["first"]]     # the last frame of a sub-batch is matched against its first
+        recs, pairs = bench.oracle_records(oracle, V, frames[idx], voc, nfeat, 8, nlines, K, D)
+        ver = bench.verify_records(p, recs[:-1], pairs)
+        assert ver["exact"], ver["mismatches"]
+        assert ver["frames"] == p["B"] and ver["pairs"] == p["B"]
+
+
+def test_emu_frontend_matches_the_oracle(plslam, oracle, synth, emu_lib):
+    """plh_frontend_* on the emulator build (CPU): two sub-batches, records in the library's own buffers (host memory there),
+    every record against the oracle -- the host logic (slot copies, successor matching, sub-batch offsets) without a GPU."""
+    import ctypes as C
+    sys.path.insert(0, _util.ROOT)
+    import bench
+    P = plslam
+    V = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    L = P.load(emu_lib)
+    B, ns, rows, cols, nfeat, nlines, nlev = 4, 2, 120, 160, 300, 40, 4
+    frames = np.ascontiguousarray(synth.make_frames(77, B, rows, cols))
+    voc = V.Vocabulary.synthetic(31, k=6, L=3, synth=synth, idf=True)
+    hv = P.ORBVocabulary(lib=emu_lib)
+    parent, leaf = voc.tree_arrays()
+    hv.create(voc.k, voc.L, parent, leaf, voc.node_desc, voc.weight64)
+    fp = P.FrontendParams()
+    fp.rows, fp.cols = rows, cols
+    fp.orb = P.OrbParams(nfeat, 1.2, nlev, 20, 7)
+    fp.line = P.LineParams(1, 1.2, nlines, 0.0)
+    fp.bow_levelsup, fp.orb_th_low, fp.orb_nnratio, fp.orb_check_orientation, fp.line_th, fp.line_nnratio = 4, 50, 0.7, 1, 50.0, 0.7
+    h = C.c_void_p()
+    P._check(L, L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)), "plh_frontend_create")
+    try:
+        assert L.plh_frontend_parts(h) == ns
+        P._check(L, L.plh_frontend_step(h, P._p(frames), rows * cols, None, 1), "plh_frontend_step")
+        f = C.c_int(-1)
+        P._check(L, L.plh_frontend_status(h, C.byref(f)), "plh_frontend_status")
+        assert f.value == 0
+        for part in range(ns):
+            r = P.FrontendRecords()
+            P._check(L, L.plh_frontend_records_of(h, part, C.byref(r)), "plh_frontend_records_of")
+            Bp, oc, lc = r.frames, r.orb_capacity, r.line_capacity
+            assert r.first == part * (B // ns) and Bp == B // ns
+
+            def arr(ptr, dtype, shape):
+                n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+                return np.frombuffer((C.c_uint8 * n).from_address(ptr), np.uint8).view(dtype).reshape(shape).copy()
+            res = dict(n=arr(r.n, np.int32, (Bp,)), kps=arr(r.kps, np.uint8, (Bp, oc, 28)).view(P.KP_DTYPE).reshape(Bp, oc),
+                       desc=arr(r.desc, np.uint8, (Bp, oc, 32)), nid=arr(r.nid, np.int32, (Bp, oc)), word=arr(r.word, np.int32, (Bp, oc)),
+                       bow_n=arr(r.bow_n, np.int32, (Bp,)), bow_word=arr(r.bow_word, np.int32, (Bp, oc)),
+                       bow_value=arr(r.bow_value, np.float64, (Bp, oc)), nl=arr(r.nl, np.int32, (Bp,)),
+                       kl=arr(r.kl, np.uint8, (Bp, lc, 68)).view(P.KL_DTYPE).reshape(Bp, lc), ldesc=arr(r.ldesc, np.uint8, (Bp, lc, 32)),
+                       lfn=arr(r.lfn, np.float64, (Bp, lc, 3)), nm_orb=arr(r.nm_orb, np.int32, (Bp,)), m_orb=arr(r.m_orb, np.int32, (Bp, oc)),
+                       nm_line=arr(r.nm_line, np.int32, (Bp,)), m_line=arr(r.m_line, np.int32, (Bp, lc)))
+            idx = list(range(r.first, r.first + Bp)) + [r.first]
+            recs, pairs = bench.oracle_records(oracle, V, frames[idx], voc, nfeat, nlev, nlines, None, None)
+            ver = bench.verify_records(res, recs[:-1], pairs)
+            assert ver["exact"], ver["mismatches"]
+        bad = P.FrontendParams()
+        assert L.plh_frontend_create(C.byref(bad), hv.h, 3, 2, 0, C.byref(C.c_void_p())) != 0      # batch not a multiple of nsplit
+        assert L.plh_frontend_bind_records(h, 0, C.byref(P.FrontendRecords())) != 0                   # not created for external records
+    finally:
+        L.plh_frontend_destroy(h)
+        hv.close()
