@@ -566,6 +566,15 @@ PLH_API plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, i
 PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride,
                                               const uint8_t* d_mask, plh_keyline* d_keylines, uint8_t* d_desc,
                                               double* d_linefn, int32_t* d_n, void* stream);
+/* The refine level of the cv::LineSegmentDetector behind LSDDetector::detect (LineExtractor.cpp:39-40).
+ * PLH_LSD_REFINE_STD (default): region2rect + refine(), what the line_descriptor twin in the reference's tree creates
+ * (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:149, createLineSegmentDetector() with its default).
+ * PLH_LSD_REFINE_ADV: additionally rect_improve() -- a rectangle is kept only if its NFA says it is meaningful, after up to five
+ * kinds of adjustment -- which is what the SYSTEM opencv_contrib LSDDetector (the one LineExtractor.cpp actually links) passes as
+ * published for 3.x.  A maintainer picks the one his OpenCV build uses. */
+#define PLH_LSD_REFINE_STD 0
+#define PLH_LSD_REFINE_ADV 1
+PLH_API plh_status plh_line_set_refine(plh_line* h, int level);
 /* Wavefronts per frame of LSD's region growing (cv::LineSegmentDetector's region_grow / refine loop, the sequential core
  * of LINEextractor::operator(), LineExtractor.cpp:40).  -1 (default): by batch size -- small batches (the per-frame call of
  * Frame.cc:224-227) run several wavefronts per frame as optimistic transactions with in-order commit, large batches one

@@ -233,9 +233,14 @@ void plo_lbd_compute(const uint8_t* img, int w, int h, size_t step, const plo_ke
 // (the reference throws std::runtime_error).  The caller passes mask == NULL for "empty Mat".
 int plo_line_extract(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask, unsigned nLSDFeature,
                      double min_line_length, plo_keyline* keylines, uint8_t* desc, double* linefn, int cap) {
+  return plo_line_extract_ex(img, rows, cols, step, mask, nLSDFeature, min_line_length, keylines, desc, linefn, cap, 0);
+}
+// ... with the refine level of the LineSegmentDetector behind LSDDetector (0 = LSD_REFINE_STD, 1 = LSD_REFINE_ADV; lsd.cc)
+int plo_line_extract_ex(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask, unsigned nLSDFeature,
+                        double min_line_length, plo_keyline* keylines, uint8_t* desc, double* linefn, int cap, int refine) {
   if (!img || rows <= 0 || cols <= 0) return 0;
   std::vector<float> segs((size_t)4 * 20000);
-  int ns = plo_lsd_detect(img, cols, rows, step, segs.data(), 20000);
+  int ns = plo_lsd_detect_ex(img, cols, rows, step, segs.data(), 20000, refine);
   if (ns > 20000) ns = 20000;
   std::vector<plo_keyline> kls(std::max(ns, 1));
   int n = plo_keylines_from_segments(segs.data(), ns, cols, rows, mask, (size_t)cols, kls.data());

@@ -1,5 +1,6 @@
 // ORACLE (test infrastructure) -- CPU restatement of cv::LineSegmentDetector (LSD_REFINE_STD, default
-// parameters) as called by cv::line_descriptor::LSDDetector::detect, which LINEextractor::operator() uses
+// parameters; LSD_REFINE_ADV -- rect_improve / rect_nfa / nfa on top of it -- behind the `refine` argument of the _ex entry
+// points) as called by cv::line_descriptor::LSDDetector::detect, which LINEextractor::operator() uses
 // (reference src/LineExtractor.cpp:39-40; in-tree twin of the wrapper:
 // Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:105-215, LSD created at :149).
 // The detector itself lives in OpenCV imgproc (lsd.cpp), NOT under /root/reference and absent from this image:
@@ -11,6 +12,14 @@
 //     scale_x = 1/0.8 exactly (cv::resize called with dsize = Size(), fx = fy = 0.8);
 //   * cos/sin of float arguments inside region growing = correctly rounded float ((float)cos((double)a));
 //   * no FMA contraction.
+// Which refine level the reference actually runs: the twin in the tree (LSDDetector_custom.cpp:149) creates the detector with
+// the default (LSD_REFINE_STD); src/LineExtractor.cpp:39-40 however calls the SYSTEM opencv_contrib line_descriptor, whose
+// LSDDetector::detectImpl -- as published for 3.x -- passes cv::LSD_REFINE_ADV.  Neither binary is in this image: both levels
+// are restated, STD is the default (what the in-tree source says), ADV is selectable end to end (plh_line_set_refine).
+// The ADV functions are restated WITH the published code's quirks, which decide which rectangles survive: the integer
+// divisions of the scan-line steps and the `tailp->p.x` read where a y is meant (rect_nfa), and the first term of nfa()'s
+// log1term being (n + 1) rather than log_gamma(n + 1).
+#include <cfloat>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -245,8 +254,176 @@ struct Lsd {
     return true;
   }
 
+  // ---- LSD_REFINE_ADV -------------------------------------------------------------------------------------------
+  double LOG_NT = 0;
+
+  static double log_gamma_windschitl(double x) {
+    return 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+  }
+  static double log_gamma_lanczos(double x) {
+    static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5);
+    double b = 0;
+    for (int n = 0; n < 7; ++n) {
+      a -= std::log(x + double(n));
+      b += q[n] * std::pow(x, double(n));
+    }
+    return a + std::log(b);
+  }
+  static double log_gamma(double x) { return x > 15.0 ? log_gamma_windschitl(x) : log_gamma_lanczos(x); }
+  static bool double_equal(double a, double b) {
+    if (a == b) return true;
+    const double abs_diff = std::fabs(a - b), aa = std::fabs(a), bb = std::fabs(b);
+    double abs_max = aa > bb ? aa : bb;
+    if (abs_max < DBL_MIN) abs_max = DBL_MIN;
+    return (abs_diff / abs_max) <= (100.0 * DBL_EPSILON);   // RELATIVE_ERROR_FACTOR
+  }
+
+  // nfa(n, k, p) = -log10(NT * binomial tail B(n, k, p))
+  double nfa(int n, int k, double p) const {
+    if (n == 0 || k == 0) return -LOG_NT;
+    if (n == k) return -LOG_NT - double(n) * std::log10(p);
+    const double p_term = p / (1 - p);
+    const double log1term = (double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1) + double(k) * std::log(p) +
+                            (double(n - k)) * std::log(1.0 - p);
+    double term = std::exp(log1term);
+    if (double_equal(term, 0)) {
+      if (k > n * p) return -log1term / M_LN10 - LOG_NT;
+      return -LOG_NT;
+    }
+    double bin_tail = term;
+    const double tolerance = 0.1;
+    for (int i = k + 1; i <= n; ++i) {
+      const double bin_term = double(n - i + 1) / double(i);
+      const double mult_term = bin_term * p_term;
+      term *= mult_term;
+      bin_tail += term;
+      if (bin_term < 1) {
+        const double err = term * ((1 - std::pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
+        if (err < tolerance * std::fabs(-std::log10(bin_tail) - LOG_NT) * bin_tail) break;
+      }
+    }
+    return -std::log10(bin_tail) - LOG_NT;
+  }
+
+  struct Edge { int x, y; bool taken; };
+
+  // points of the rectangle, scan line by scan line, and how many of them are aligned with it
+  double rect_nfa(const Rect& rec) const {
+    int total_pts = 0, alg_pts = 0;
+    const double half_width = rec.width / 2.0;
+    const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+    Edge o[4];
+    o[0] = {int(rec.x1 - dyhw), int(rec.y1 + dxhw), false};
+    o[1] = {int(rec.x2 - dyhw), int(rec.y2 + dxhw), false};
+    o[2] = {int(rec.x2 + dyhw), int(rec.y2 - dxhw), false};
+    o[3] = {int(rec.x1 + dyhw), int(rec.y1 - dxhw), false};
+    std::sort(o, o + 4, [](const Edge& a, const Edge& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });   // AsmallerB_XoverY
+    Edge *min_y = &o[0], *max_y = &o[0];
+    for (unsigned i = 1; i < 4; ++i) {
+      if (min_y->y > o[i].y) min_y = &o[i];
+      if (max_y->y < o[i].y) max_y = &o[i];
+    }
+    min_y->taken = true;
+    Edge* leftmost = nullptr;
+    for (unsigned i = 0; i < 4; ++i)
+      if (!o[i].taken) {
+        if (!leftmost) leftmost = &o[i];
+        else if (leftmost->x > o[i].x) leftmost = &o[i];
+      }
+    leftmost->taken = true;
+    Edge* rightmost = nullptr;
+    for (unsigned i = 0; i < 4; ++i)
+      if (!o[i].taken) {
+        if (!rightmost) rightmost = &o[i];
+        else if (rightmost->x < o[i].x) rightmost = &o[i];
+      }
+    rightmost->taken = true;
+    Edge* tailp = nullptr;
+    for (unsigned i = 0; i < 4; ++i)
+      if (!o[i].taken) {
+        if (!tailp) tailp = &o[i];
+        else if (tailp->x > o[i].x) tailp = &o[i];
+      }
+    tailp->taken = true;
+    // (integer divisions, and tailp->x where the published code means a y: as published)
+    const double flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
+    const double slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->x) : 0;
+    const double frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
+    const double srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->x) : 0;
+    double lstep = flstep, rstep = frstep;
+    double left_x = min_y->x, right_x = min_y->x;
+    const int min_iter = min_y->y, max_iter = max_y->y;
+    for (int y = min_iter; y <= max_iter; ++y) {
+      if (y >= 0 && y < h) {
+        for (int x = int(left_x); x <= int(right_x); ++x) {
+          if (x < 0 || x >= w) continue;
+          ++total_pts;
+          if (isAligned(x, y, rec.theta, rec.prec)) ++alg_pts;
+        }
+      }
+      if (y >= leftmost->y) lstep = slstep;
+      if (y >= rightmost->y) rstep = srstep;
+      left_x += lstep;
+      right_x += rstep;
+    }
+    g_stats[7]++;
+    return nfa(total_pts, alg_pts, rec.p);
+  }
+
+  double rect_improve(Rect& rec, double LOG_EPS) const {
+    const double delta = 0.5, delta_2 = delta / 2.0;
+    double log_nfa = rect_nfa(rec);
+    if (log_nfa > LOG_EPS) return log_nfa;
+    Rect r = rec;                                   // finer precision
+    for (int n = 0; n < 5; ++n) {
+      r.p /= 2;
+      r.prec = r.p * M_PI;
+      const double v = rect_nfa(r);
+      if (v > log_nfa) { log_nfa = v; rec = r; }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;                                        // reduce width
+    for (unsigned n = 0; n < 5; ++n)
+      if ((r.width - delta) >= 0.5) {
+        r.width -= delta;
+        const double v = rect_nfa(r);
+        if (v > log_nfa) { rec = r; log_nfa = v; }
+      }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;                                        // reduce one side
+    for (unsigned n = 0; n < 5; ++n)
+      if ((r.width - delta) >= 0.5) {
+        r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+        r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+        r.width -= delta;
+        const double v = rect_nfa(r);
+        if (v > log_nfa) { rec = r; log_nfa = v; }
+      }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;                                        // reduce the other side
+    for (unsigned n = 0; n < 5; ++n)
+      if ((r.width - delta) >= 0.5) {
+        r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+        r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+        r.width -= delta;
+        const double v = rect_nfa(r);
+        if (v > log_nfa) { rec = r; log_nfa = v; }
+      }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;                                        // finer precision again
+    for (unsigned n = 0; n < 5; ++n)
+      if ((r.width - delta) >= 0.5) {
+        r.p /= 2;
+        r.prec = r.p * M_PI;
+        const double v = rect_nfa(r);
+        if (v > log_nfa) { rec = r; log_nfa = v; }
+      }
+    return log_nfa;
+  }
+
   // flsd
-  int run(const uint8_t* src, int sw, int sh, size_t sstep, float* segs, int cap) {
+  int run(const uint8_t* src, int sw, int sh, size_t sstep, float* segs, int cap, int refine_level = 0) {
     const double prec = M_PI * kAngTh / 180;
     const double p = kAngTh / 180;
     const double rho = kQuant / std::sin(prec);
@@ -261,8 +438,9 @@ struct Lsd {
     img.assign((size_t)w * h, 0);
     plo_resize_linear_u8_scale(g.data(), sw, sh, sw, img.data(), w, h, w, kScale, kScale);
     ll_angle(rho);
-    const double LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
+    LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     const size_t min_reg_size = size_t(-LOG_NT / std::log10(p));
+    const double LOG_EPS = 0;
     used.assign((size_t)w * h, 0);
     std::vector<RegionPoint> reg;
     int n = 0;
@@ -275,6 +453,10 @@ struct Lsd {
         Rect rec;
         region2rect(reg, reg_angle, prec, p, rec);
         if (!refine(reg, reg_angle, prec, p, rec, kDensityTh)) continue;
+        if (refine_level >= 1) {   // LSD_REFINE_ADV: the rectangle has to be meaningful (NFA), after up to five kinds of adjustment
+          const double log_nfa = rect_improve(rec, LOG_EPS);
+          if (log_nfa <= LOG_EPS) continue;
+        }
         rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
         rec.x1 /= kScale; rec.y1 /= kScale; rec.x2 /= kScale; rec.y2 /= kScale; rec.width /= kScale;
         if (n < cap) {
@@ -296,11 +478,22 @@ void plo_lsd_stats(long* out8, int reset) {
   for (int i = 0; i < 8; i++) { out8[i] = g_stats[i]; if (reset) g_stats[i] = 0; }
 }
 
-int plo_lsd_detect(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap) {
+int plo_lsd_detect_ex(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap, int refine) {
   if (w < 8 || h < 8) return 0;
   Lsd lsd;
-  return lsd.run(img, w, h, step, segs_xyxy, cap);
+  return lsd.run(img, w, h, step, segs_xyxy, cap, refine);
 }
+int plo_lsd_detect(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap) {
+  return plo_lsd_detect_ex(img, w, h, step, segs_xyxy, cap, 0);
+}
+
+// known-answer taps of the ADV functions: nfa(n, k, p) for an image of w x h (LOG_NT), log_gamma
+double plo_lsd_nfa(int w, int h, int n, int k, double p) {
+  Lsd lsd;
+  lsd.LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
+  return lsd.nfa(n, k, p);
+}
+double plo_lsd_log_gamma(double x) { return Lsd::log_gamma(x); }
 
 // taps for stage-wise parity: the scaled 8-bit image, angle (double, NOTDEF = -1024) and seed order
 int plo_lsd_stage_taps(const uint8_t* img, int w, int h, size_t step, uint8_t* scaled, double* angles, double* modgrad,

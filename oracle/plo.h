@@ -128,6 +128,9 @@ int  plo_vocab_parse_bin(const char* path, int32_t header[4], int32_t* parent, u
 
 /* ---- Line extractor (reference src/LineExtractor.cpp + contrib LSDDetector / BinaryDescriptor) ---- */
 int  plo_lsd_detect(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap);  /* cv::LineSegmentDetector (STD) */
+int  plo_lsd_detect_ex(const uint8_t* img, int w, int h, size_t step, float* segs_xyxy, int cap, int refine);   /* 1: LSD_REFINE_ADV */
+double plo_lsd_nfa(int w, int h, int n, int k, double p);   /* nfa() for an image of w x h scaled pixels */
+double plo_lsd_log_gamma(double x);
 int  plo_lsd_stage_taps(const uint8_t* img, int w, int h, size_t step, uint8_t* scaled, double* angles, double* modgrad,
                         int32_t* ordered, int* sw_out, int* sh_out);
 int  plo_keylines_from_segments(const float* segs, int n, int w, int h, const uint8_t* mask, size_t mstep,
@@ -137,6 +140,8 @@ void plo_lbd_compute(const uint8_t* img, int w, int h, size_t step, const plo_ke
 int  plo_line_extract(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask,
                       unsigned n_lsd_feature, double min_line_length,
                       plo_keyline* keylines, uint8_t* desc, double* linefn, int cap);           /* LINEextractor::operator() */
+int  plo_line_extract_ex(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask, unsigned n_lsd_feature,
+                         double min_line_length, plo_keyline* keylines, uint8_t* desc, double* linefn, int cap, int refine);
 
 /* ---- Windowed (grid) searches of the tracking front end (reference src/Frame.cc, ORBmatcher.cc, LSDmatcher.cpp;
  *      oracle/frame_search.cc).  gp = {mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv};

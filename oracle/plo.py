@@ -64,9 +64,13 @@ _SIGS = {
     "plo_line_search_double": ([_V, _I, _V, _I, _F, _F, _V], _I),
     "plo_orb_search_by_bow": ([_V, _V, _V, _V, _I, _V, _V, _V, _I, _I, _F, _I, _V], _I),
     "plo_lsd_detect": ([_V, _I, _I, _Z, _V, _I], _I),
+    "plo_lsd_detect_ex": ([_V, _I, _I, _Z, _V, _I, _I], _I),
+    "plo_lsd_nfa": ([_I, _I, _I, _I, _D], _D),
+    "plo_lsd_log_gamma": ([_D], _D),
     "plo_keylines_from_segments": ([_V, _I, _I, _I, _V, _Z, _V], _I),
     "plo_lbd_compute": ([_V, _I, _I, _Z, _V, _I, _V, _V], None),
     "plo_line_extract": ([_V, _I, _I, _Z, _V, _U, _D, _V, _V, _V, _I], _I),
+    "plo_line_extract_ex": ([_V, _I, _I, _Z, _V, _U, _D, _V, _V, _V, _I, _I], _I),
 }
 
 
@@ -180,11 +184,11 @@ def knn2(q, t):
     return idx, dist
 
 
-def lsd_detect(img, cap=20000):
+def lsd_detect(img, cap=20000, refine=0):
     """cv::LineSegmentDetector(LSD_REFINE_STD).detect -> float32 [n,4] (x1,y1,x2,y2)."""
     img = np.ascontiguousarray(img, np.uint8)
     segs = np.zeros((cap, 4), np.float32)
-    n = lib().plo_lsd_detect(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(segs), cap)
+    n = lib().plo_lsd_detect_ex(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(segs), cap, int(refine))
     return segs[:min(n, cap)].copy()
 
 
@@ -205,7 +209,7 @@ def lsd_stage_taps(img):
     return scaled, ang, mod, order
 
 
-def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None):
+def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None, refine=0):
     """LINEextractor::operator() -> (keylines[KL_DTYPE], desc[n,32], linefn[n,3])."""
     img = np.ascontiguousarray(img, np.uint8)
     cap = n_lsd_feature + 1
@@ -216,8 +220,8 @@ def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None):
         mask = np.ascontiguousarray(mask, np.uint8)
         if mask.shape != img.shape:
             raise ValueError("Mask error while detecting lines")
-    n = lib().plo_line_extract(_p(img), img.shape[0], img.shape[1], img.shape[1], _p(mask), n_lsd_feature,
-                               float(min_line_length), _p(kl), _p(desc), _p(fn), cap)
+    n = lib().plo_line_extract_ex(_p(img), img.shape[0], img.shape[1], img.shape[1], _p(mask), n_lsd_feature,
+                                  float(min_line_length), _p(kl), _p(desc), _p(fn), cap, int(refine))
     if n < 0:
         raise RuntimeError("oracle line capacity")
     return kl[:n].copy(), desc[:n].copy(), fn[:n].copy()

@@ -111,6 +111,7 @@ _SIGS = {
     "plh_line_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
     "plh_line_set_grow_waves": ([_V, _I], _I),
+    "plh_line_set_refine": ([_V, _I], _I),
     "plh_frontend_create": ([_V, _V, _I, _I, _I, _V], _I),
     "plh_frontend_destroy": ([_V], _I),
     "plh_frontend_parts": ([_V], _I),
@@ -1096,6 +1097,10 @@ class LINEextractor:
         _check(self.lib, self.lib.plh_line_extract_batch_dev(self.h, _p(d_imgs), batch, frame_stride, _p(d_mask), _p(d_keylines),
                                                              _p(d_desc), _p(d_linefn), _p(d_n), C.c_void_p(stream)),
                "plh_line_extract_batch_dev")
+
+    def set_refine(self, level):
+        """cv::LineSegmentDetector's refine level: 0 = LSD_REFINE_STD (default), 1 = LSD_REFINE_ADV (NFA-validated rectangles)."""
+        _check(self.lib, self.lib.plh_line_set_refine(self.h, int(level)), "plh_line_set_refine")
 
     def set_grow_waves(self, waves):
         """Wavefronts per frame of LSD's region growing: -1 automatic (by batch size), 0 one, 2..16 that many; same segments."""

@@ -222,6 +222,8 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   }
   const double LOG_NT = 5 * (std::log10(double(a.sw)) + std::log10(double(a.sh))) / 2 + std::log10(11.0);
   a.minRegSize = (int)(size_t)(-LOG_NT / std::log10(a.p));
+  a.logNT = LOG_NT;
+  a.refineAdv = 0;
   a.segCap = (a.sw * a.sh) / std::max(a.minRegSize, 1) + 16;
   a.nFeature = (int)p->n_lsd_feature;
   a.minLineLength = p->min_line_length;
@@ -541,6 +543,15 @@ plh_status plh_line_status(plh_line* h, int* flags) {
   PLH_HIP(hipMemcpy(flags, h->dStatus, 4, hipMemcpyDeviceToHost));
   if ((*flags & 16) && h->dMwMark)   // an abandoned launch leaves private marks behind: the planes must be zero between transactions
     PLH_HIP(hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride));
+  return PLH_OK;
+}
+
+plh_status plh_line_set_refine(plh_line* h, int level) {
+  if (!h || (level != PLH_LSD_REFINE_STD && level != PLH_LSD_REFINE_ADV)) {
+    set_error("plh_line_set_refine: level must be PLH_LSD_REFINE_STD (0) or PLH_LSD_REFINE_ADV (1)");
+    return PLH_ERR_INVALID;
+  }
+  h->a.refineAdv = level == PLH_LSD_REFINE_ADV ? 1 : 0;
   return PLH_OK;
 }
 

@@ -81,6 +81,8 @@ struct LineDeviceArgs {
   float alignCin2, alignCout2;   // cos^2(prec -+ 0.05 degrees): the direction pre-test of region growing (lsd_grow.hip, lsd_classify)
   int alignFast;
   int minRegSize;
+  int refineAdv;            // 1: LSD_REFINE_ADV (rect_improve / NFA behind refine()), plh_line_set_refine
+  double logNT;             // 5 (log10 sw + log10 sh) / 2 + log10 11, flsd()'s LOG_NT
   // selection
   int nFeature;             // nLSDFeature
   double minLineLength;

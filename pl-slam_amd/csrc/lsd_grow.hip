@@ -72,6 +72,7 @@ __device__ unsigned g_mw_trace_n;
 #define PF_ADD(c, k, v) ((void)sizeof(v))
 #define MW_TRACE(wv, lane, kind, arg) ((void)0)
 #endif
+constexpr int LSD_GS_D = 9;      // GrowState::d: tolerance of the call | rectangle x1 y1 x2 y2 width | its theta, cos, sin (LSD_REFINE_ADV)
 constexpr int LSD_RING = 512;    // 2 KiB; the chain buffer T (1.5 KiB) aliases it (never live at the same time)
 constexpr int LSD_PTS = 8;      // queue points examined per step (8 points x 8 neighbours = 64 lanes)
 constexpr unsigned LSD_USED = LSD_REC_USED;   // `used` mark: bit 31 of the record word (LsdPix::q holds the record word)
@@ -164,7 +165,7 @@ __device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return (unsig
 // Per-wavefront state that lives in LDS rather than in registers (uniform values the compiler would keep in VGPRs):
 // the parameters of the current region_grow() call, the fitted rectangle, and the first-step prefetch tables.
 struct GrowState {
-  double* d;          // [0] prec of the call, [1..5] rectangle x1 y1 x2 y2 width
+  double* d;          // [0] prec of the call, [1..5] rectangle x1 y1 x2 y2 width, [6..8] its theta, dx, dy (LSD_GS_D doubles)
   uint32_t* u;        // [0] seed (packed), [1] seed q, [2..4] bits of seed angle (degrees), cos, sin
   const LsdPix* fstPx;      // [64] neighbour records of the batch's seeds (lane group t = seed t)
   const uint32_t* fstIdx;   // [64] linear index, 0xffffffff = out of bounds / no seed
@@ -725,6 +726,7 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     rec[2] = x + l_max * dx; rec[3] = y + l_max * dy;
     const double width = w_max - w_min;
     rec[4] = width < 1.0 ? 1.0 : width;
+    rec[5] = theta; rec[6] = dx; rec[7] = dy;   // (read by rect_nfa only)
   }
   PLH_WAVE_SYNC();
 }
@@ -734,6 +736,218 @@ __device__ __forceinline__ double dist_sq(double x1, double y1, double x2, doubl
 }
 __device__ __forceinline__ double rect_density(int cnt, const double* r) {
   return (double)cnt / (sqrt(dist_sq(r[0], r[1], r[2], r[3])) * r[4]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSD_REFINE_ADV (cv::LineSegmentDetector created with LSD_REFINE_ADV, what the system opencv_contrib LSDDetector behind
+// src/LineExtractor.cpp:39-40 passes as published; oracle/lsd.cc restates it with the published code's quirks): a rectangle
+// is kept only if its number of false alarms says it is meaningful, after up to five kinds of adjustment.
+//   nfa()          -log10(NT x binomial tail), Lanczos / Windschitl log-gamma
+//   rect_nfa()     the pixels of the rectangle scan line by scan line, how many of them are aligned with it
+//   rect_improve() finer precision, narrower, one side in, the other side in, finer precision again
+// ---------------------------------------------------------------------------------------------
+struct LsdAdvRect {
+  double x1, y1, x2, y2, width, theta, dx, dy, prec, p;
+};
+
+__device__ __attribute__((noinline)) double lsd_log_gamma(double x) {
+  if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+  const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+  double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
+  double b = 0;
+  for (int n = 0; n < 7; ++n) {
+    a -= log(x + double(n));
+    b += q[n] * pow(x, double(n));
+  }
+  return a + log(b);
+}
+
+__device__ __attribute__((noinline)) double lsd_nfa(int n, int k, double p, double logNT) {
+  if (n == 0 || k == 0) return -logNT;
+  if (n == k) return -logNT - double(n) * log10(p);
+  const double p_term = p / (1 - p);
+  // (n + 1) where the original algorithm has log_gamma(n + 1): as published (oracle/lsd.cc)
+  const double log1term = (double(n) + 1) - lsd_log_gamma(double(k) + 1) - lsd_log_gamma(double(n - k) + 1) + double(k) * log(p) +
+                          (double(n - k)) * log(1.0 - p);
+  double term = exp(log1term);
+  {
+    // double_equal(term, 0)
+    const double aa = fabs(term);
+    const double abs_max = aa < 2.2250738585072014e-308 ? 2.2250738585072014e-308 : aa;
+    if (term == 0.0 || (aa / abs_max) <= (100.0 * 2.2204460492503131e-16)) {
+      if (k > n * p) return -log1term / 2.30258509299404568402 - logNT;
+      return -logNT;
+    }
+  }
+  double bin_tail = term;
+  const double tolerance = 0.1;
+  for (int i = k + 1; i <= n; ++i) {
+    const double bin_term = double(n - i + 1) / double(i);
+    const double mult_term = bin_term * p_term;
+    term *= mult_term;
+    bin_tail += term;
+    if (bin_term < 1) {
+      const double err = term * ((1 - pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
+      if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) break;
+    }
+  }
+  return -log10(bin_tail) - logNT;
+}
+
+// rect_nfa(): the scan-line bounds advance by integer steps from an integer start, so the bounds of row j are a closed form
+// (exact in any order): one lane per row computes its span, a wave scan numbers the pixels, and the lanes then test 64
+// pixels at a time.  Row spans and offsets of a 64-row chunk live in the (dead) ring.
+struct LsdNfaCtx {   // what rect_nfa reads of the wavefront's context (by value: the call is out of line)
+  const uint32_t* P;
+  const LsdAngleEntry* A;
+  uint32_t* ring;
+  int spitch, sw, sh, lane;
+};
+__device__ __attribute__((noinline)) double lsd_rect_nfa(const LsdNfaCtx c, const LsdAdvRect r, double logNT) {
+  const int lane = c.lane;
+  const double hw = r.width / 2.0, dyhw = r.dy * hw, dxhw = r.dx * hw;
+  int ox[4] = {(int)(r.x1 - dyhw), (int)(r.x2 - dyhw), (int)(r.x2 + dyhw), (int)(r.x1 + dyhw)};
+  int oy[4] = {(int)(r.y1 + dxhw), (int)(r.y2 + dxhw), (int)(r.y2 - dxhw), (int)(r.y1 - dxhw)};
+  // std::sort by (x, y) ascending: a sorting network on four elements
+#define LSD_CSWAP(i, j)                                                          \
+  if (ox[j] < ox[i] || (ox[j] == ox[i] && oy[j] < oy[i])) {                      \
+    const int tx = ox[i], ty = oy[i];                                            \
+    ox[i] = ox[j]; oy[i] = oy[j]; ox[j] = tx; oy[j] = ty;                        \
+  }
+  LSD_CSWAP(0, 1) LSD_CSWAP(2, 3) LSD_CSWAP(0, 2) LSD_CSWAP(1, 3) LSD_CSWAP(1, 2)
+#undef LSD_CSWAP
+  int iMin = 0, iMax = 0;
+  for (int i = 1; i < 4; ++i) {
+    if (oy[iMin] > oy[i]) iMin = i;
+    if (oy[iMax] < oy[i]) iMax = i;
+  }
+  unsigned taken = 1u << iMin;
+  int iL = -1, iR = -1, iT = -1;
+  for (int i = 0; i < 4; ++i)
+    if (!((taken >> i) & 1u)) { if (iL < 0) iL = i; else if (ox[iL] > ox[i]) iL = i; }
+  taken |= 1u << iL;
+  for (int i = 0; i < 4; ++i)
+    if (!((taken >> i) & 1u)) { if (iR < 0) iR = i; else if (ox[iR] < ox[i]) iR = i; }
+  taken |= 1u << iR;
+  for (int i = 0; i < 4; ++i)
+    if (!((taken >> i) & 1u)) { if (iT < 0) iT = i; else if (ox[iT] > ox[i]) iT = i; }
+  const int mx = ox[iMin], my = oy[iMin], lx = ox[iL], ly = oy[iL], rx = ox[iR], ry = oy[iR], tx = ox[iT];
+  // integer divisions, and the tail point's x where a y is meant: as published
+  const long long fl = (my != ly) ? (mx - lx) / (my - ly) : 0, sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
+  const long long fr = (my != ry) ? (mx - rx) / (my - ry) : 0, sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
+  const int yMin = my, yMax = oy[iMax];
+  const long long aL = max(0, ly - yMin), aR = max(0, ry - yMin);   // rows that still advance by the first step
+  int* rowX = (int*)c.ring;          // [64] first column of the row's span
+  int* rowOff = rowX + 64;           // [65] pixels in front of the row (chunk-relative), [64] = all
+  int total = 0, alg = 0;
+  for (int y0 = yMin; y0 <= yMax; y0 += 64) {
+    const long long j = (long long)(y0 - yMin) + lane;
+    const int y = y0 + lane;
+    int cnt = 0, xl = 0;
+    if (y <= yMax && y >= 0 && y < c.sh) {
+      const long long jl = j < aL ? j : aL, jr = j < aR ? j : aR;
+      const long long left = mx + fl * jl + sl * (j - jl), right = mx + fr * jr + sr * (j - jr);
+      const long long a = left < 0 ? 0 : left, b = right > c.sw - 1 ? c.sw - 1 : right;
+      if (b >= a) { cnt = (int)(b - a + 1); xl = (int)a; }
+    }
+    // exclusive scan of the row spans
+    int inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(inc, d);
+      if (lane >= d) inc += v;
+    }
+    const int chunkTotal = (int)bcast_u32((unsigned)inc, 63);
+    PLH_WAVE_SYNC();
+    rowX[lane] = xl; rowOff[lane] = inc - cnt;
+    if (lane == 0) rowOff[64] = chunkTotal;
+    PLH_WAVE_SYNC();
+    for (int base = 0; base < chunkTotal; base += 64) {
+      const int i = base + lane;
+      bool ok = false;
+      if (i < chunkTotal) {
+        int lo = 0, hi = 64;           // last row whose offset is <= i (rows with no pixels share their successor's offset)
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (rowOff[mid] <= i) lo = mid; else hi = mid;
+        }
+        const int x = rowX[lo] + (i - rowOff[lo]), yy = y0 + lo;
+        const unsigned rec = c.P[__umul24((unsigned)yy, (unsigned)c.spitch) + (unsigned)x];
+        if (rec & LSD_REC_DEF) ok = lsd_aligned(r.theta, (double)c.A[rec & LSD_REC_IDX].angf * kDegToRads, r.prec);
+      }
+      alg += __popcll(__ballot(ok));
+    }
+    total += chunkTotal;
+    PLH_WAVE_SYNC();
+  }
+  return lsd_nfa(total, alg, r.p, logNT);
+}
+
+// rect_improve(); rec (LDS) = x1 y1 x2 y2 width theta dx dy.  Returns whether the rectangle is kept (log_nfa > LOG_EPS = 0); the
+// improved rectangle is written back.
+__device__ __attribute__((noinline)) bool lsd_rect_improve(const GrowCtx& c, double* rec, double prec, double p, double logNT) {
+  LsdAdvRect R;
+  R.x1 = rec[0]; R.y1 = rec[1]; R.x2 = rec[2]; R.y2 = rec[3]; R.width = rec[4]; R.theta = rec[5]; R.dx = rec[6]; R.dy = rec[7];
+  R.prec = prec; R.p = p;
+  PLH_WAVE_SYNC();   // (the ring is about to be reused)
+  LsdNfaCtx nc;
+  nc.P = c.P; nc.A = c.A; nc.ring = c.ring; nc.spitch = c.spitch; nc.sw = c.sw; nc.sh = c.sh; nc.lane = c.lane;
+  const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = 0.0;
+  double log_nfa = lsd_rect_nfa(nc, R, logNT);
+  bool changed = false;
+  if (!(log_nfa > LOG_EPS)) {
+    LsdAdvRect r = R;
+    for (int n = 0; n < 5; ++n) {          // finer precision
+      r.p /= 2;
+      r.prec = r.p * kPI;
+      const double v = lsd_rect_nfa(nc, r, logNT);
+      if (v > log_nfa) { log_nfa = v; R = r; changed = true; }
+    }
+  }
+  if (!(log_nfa > LOG_EPS)) {
+    LsdAdvRect r = R;
+    for (int n = 0; n < 5; ++n)            // reduce width
+      if ((r.width - delta) >= 0.5) {
+        r.width -= delta;
+        const double v = lsd_rect_nfa(nc, r, logNT);
+        if (v > log_nfa) { R = r; log_nfa = v; changed = true; }
+      }
+  }
+  if (!(log_nfa > LOG_EPS)) {
+    LsdAdvRect r = R;
+    for (int n = 0; n < 5; ++n)            // reduce one side
+      if ((r.width - delta) >= 0.5) {
+        r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+        r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+        r.width -= delta;
+        const double v = lsd_rect_nfa(nc, r, logNT);
+        if (v > log_nfa) { R = r; log_nfa = v; changed = true; }
+      }
+  }
+  if (!(log_nfa > LOG_EPS)) {
+    LsdAdvRect r = R;
+    for (int n = 0; n < 5; ++n)            // reduce the other side
+      if ((r.width - delta) >= 0.5) {
+        r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+        r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+        r.width -= delta;
+        const double v = lsd_rect_nfa(nc, r, logNT);
+        if (v > log_nfa) { R = r; log_nfa = v; changed = true; }
+      }
+  }
+  if (!(log_nfa > LOG_EPS)) {
+    LsdAdvRect r = R;
+    for (int n = 0; n < 5; ++n)            // finer precision again
+      if ((r.width - delta) >= 0.5) {
+        r.p /= 2;
+        r.prec = r.p * kPI;
+        const double v = lsd_rect_nfa(nc, r, logNT);
+        if (v > log_nfa) { R = r; log_nfa = v; changed = true; }
+      }
+  }
+  PLH_WAVE_SYNC();
+  if (changed && c.lane == 0) { rec[0] = R.x1; rec[1] = R.y1; rec[2] = R.x2; rec[3] = R.y2; rec[4] = R.width; }
+  PLH_WAVE_SYNC();
+  return log_nfa > LOG_EPS;
 }
 
 // One iteration of reduce_region_radius(): drop every point farther than sqrt(radSq) from reg[0].
@@ -803,6 +1017,7 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
 #else
 #define PLH_GROW_ATTR
 #endif
+template <bool ADV>
 __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned char* smem) {
   const int b = blockIdx.x, lane = threadIdx.x;
   GrowCtx c;
@@ -868,7 +1083,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   int* batchSk = (int*)(fstPk + 64);                   // [8] scan lane of the batch's t-th seed
   GrowState gs;
   gs.d = (double*)(batchSk + 8);
-  gs.u = (uint32_t*)(gs.d + 6);
+  gs.u = (uint32_t*)(gs.d + LSD_GS_D);
   gs.fstPx = fstPx; gs.fstIdx = fstIdx; gs.fstPk = fstPk;
   double* rec = gs.d + 1;
   for (int sbase = 0; sbase < nOrd; sbase += 64) {
@@ -1020,6 +1235,9 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
           PF_ADD(c, 6, PF_NOW() - pg2);
           break;
         }
+        if constexpr (ADV) {   // LSD_REFINE_ADV: the rectangle has to be meaningful (NFA), after up to five kinds of adjustment
+          if (emit) emit = lsd_rect_improve(c, rec, a.prec, a.p, a.logNT);
+        }
         if (!emit) continue;
         if (lane == 0 && nseg < a.segCap) {
           segs[nseg * 4 + 0] = (float)((rec[0] + 0.5) / 0.8); segs[nseg * 4 + 1] = (float)((rec[1] + 0.5) / 0.8);
@@ -1076,7 +1294,7 @@ constexpr int MW_PEND_WORDS = 16;   // a posted transaction (MwPost)
 // A wait that lasts this many polls (some seconds) cannot be a wait for work: the kernel gives up instead of hanging the GPU
 // -- every wavefront leaves at its next wait, status bit 4 (16) reports it and the frame's segments are void.
 constexpr unsigned MW_SPIN_LIMIT = 1u << 26;
-constexpr int MW_WAVE_LDS = LSD_RING * 4 + 6 * 8 + 8 * 4 + MW_ASM_CAP * 4 + 16;   // per wavefront: ring (aliased by T) + GrowState + assumed-used list + its count
+constexpr int MW_WAVE_LDS = LSD_RING * 4 + (LSD_GS_D + 1) * 8 + 8 * 4 + MW_ASM_CAP * 4 + 16;   // per wavefront: ring (aliased by T) + GrowState + assumed-used list + its count
 
 #if defined(HIPEMU)
 __device__ __forceinline__ int mw_ld(const int* p) { return *(volatile const int*)p; }
@@ -1166,8 +1384,8 @@ struct MwTxn {
 
 // One transaction: the body of flsd()'s loop for one seed (oracle/lsd.cc:269-285; lsd_grow_frame's phase loop), with the
 // region queues of its phases laid end to end so that the log keeps every pixel it ever accepted.
-__device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, uint32_t* regBase, uint32_t seedPk,
-                            unsigned seedRec, unsigned sAngBits, unsigned sCxBits, unsigned sSyBits) {
+__device__ MwTxn lsd_txn_mw_core(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, uint32_t* regBase, uint32_t seedPk,
+                                 unsigned seedRec, unsigned sAngBits, unsigned sCxBits, unsigned sSyBits) {
   const int lane = c.lane;
   double* rec = gs.d + 1;
   MwTxn t;
@@ -1276,6 +1494,16 @@ __device__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArg
   return t;
 }
 
+template <bool ADV>
+__device__ __forceinline__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, uint32_t* regBase, uint32_t seedPk,
+                                            unsigned seedRec, unsigned sAngBits, unsigned sCxBits, unsigned sSyBits) {
+  MwTxn t = lsd_txn_mw_core(c, gs, a, regBase, seedPk, seedRec, sAngBits, sCxBits, sSyBits);
+  if constexpr (ADV) {   // LSD_REFINE_ADV: reads the (immutable) level-line field only, so it is part of the transaction's tail
+    if (t.emit && !t.conflict) t.emit = lsd_rect_improve(c, gs.d + 1, a.prec, a.p, a.logNT);
+  }
+  return t;
+}
+
 // A posted transaction: 16 words in LDS, ring slot = sequence number mod MW_N.
 //   w[0]  flags: bit 0 has a log (0: the seed was used already, or is predicted to be), bit 1 ran against a possibly stale map,
 //         bit 2 segment, bit 3 INLINE; bits 8-15 wavefront; bits 16-23 pixels taken for used on an older claim;
@@ -1311,6 +1539,7 @@ __device__ __forceinline__ void mw_segment(const double* rec, float seg[4]) {   
 // one LDS round trip for the posts, one load of all their records; a pixel an older post of the batch publishes counts as
 // used for the younger ones (compared lane against lane); everything in front of the first post that fails is committed
 // with one store per pixel.
+template <bool ADV>
 __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
                          uint32_t* drainReg, float* segs) {
   const int lane = ch.lane, g = lane >> 3, j = lane & 7;
@@ -1408,7 +1637,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       ch.hTag = (unsigned)h % 65535u + 1u;
       ch.hWin = 0;   // nothing older is in flight: no claim is believed
       if (!(seedRec & LSD_USED)) {
-        const MwTxn t = lsd_txn_mw(ch, gs, a, drainReg, seedPk, seedRec, bcast_u32(q0.z, 0), bcast_u32(q0.w, 0), bcast_u32(q1.x, 0));
+        const MwTxn t = lsd_txn_mw<ADV>(ch, gs, a, drainReg, seedPk, seedRec, bcast_u32(q0.z, 0), bcast_u32(q0.w, 0), bcast_u32(q1.x, 0));
         grow_lane_fence<true>();
         for (int i = lane; i < t.finCnt; i += 64) {
           const uint32_t li = pk_lin(ch, drainReg[t.finBase + i]);
@@ -1444,6 +1673,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
 }
 
 // take the drain lock if there is something to commit and nobody is at it; returns whether anything was done
+template <bool ADV>
 __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
                              uint32_t* drainReg, float* segs) {
   bool did = false;
@@ -1456,7 +1686,7 @@ __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceA
     mw_acquire();
     const unsigned long long pd0 = PF_NOW();
     MW_TRACE(wvTrace, ch.lane, 5, h);   // drain session begins at head h
-    mw_drain(ch, gs, a, sh, frameReg, drainReg, segs);
+    mw_drain<ADV>(ch, gs, a, sh, frameReg, drainReg, segs);
     MW_TRACE(wvTrace, ch.lane, 6, mw_ld(&sh.ctl[MWC_HEAD]));   // ... ends
     PF_ADD(ch, 23, PF_NOW() - pd0); PF_ADD(ch, 25, 1);
     if (ch.lane == 0) mw_st(&sh.ctl[MWC_DLOCK], 0);
@@ -1466,6 +1696,7 @@ __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceA
   return did;
 }
 
+template <bool ADV>
 __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsigned char* smem) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, W = (int)(blockDim.x >> 6);
   MwShared sh;
@@ -1489,13 +1720,13 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   c.M = frameMark + (long long)wv * a.mwMarkStride;
   c.H = a.mwHint + (long long)b * a.mwMarkStride;   // (mwMarkStride 16-bit tags)
   c.hTag = 1; c.hWin = 0;
-  c.asmList = (uint32_t*)(wsm + LSD_RING * 4 + 6 * 8 + 8 * 4);
+  c.asmList = (uint32_t*)(wsm + LSD_RING * 4 + (LSD_GS_D + 1) * 8 + 8 * 4);
   c.asmCnt = c.asmList + MW_ASM_CAP;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
   GrowState gs;
   gs.d = (double*)(wsm + LSD_RING * 4);
-  gs.u = (uint32_t*)(gs.d + 6);
+  gs.u = (uint32_t*)(gs.d + LSD_GS_D + 1);
   gs.fstPx = nullptr; gs.fstIdx = nullptr; gs.fstPk = nullptr;
   const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;
   float* segs = a.segs + (long long)b * a.arenaStride;
@@ -1572,7 +1803,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     if (s < 0) {
       if (done && pop >= push && head >= push) break;   // every seed handed out and committed
       const unsigned long long pw0 = PF_NOW();
-      if (mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs)) { polls = 0; continue; }
+      if (mw_try_drain<ADV>(ch, gs, a, sh, frameReg, drainReg, segs)) { polls = 0; continue; }
       int stop = 0;
       MW_TRACE(wv, lane, 7, (pop < push ? 1 : 0) | (off > S ? 2 : 0) | (pop - head >= a.mwLag ? 4 : 0) | (done ? 8 : 0));   // nothing to do: why
       if (lane == 0) { stop = mw_give_up(ctl, polls, a.status); mw_pause(); }
@@ -1611,7 +1842,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       }
       const unsigned long long pt0 = PF_NOW();
       MW_TRACE(wv, lane, 2, s);   // run begins
-      const MwTxn t = lsd_txn_mw(c, gs, a, regBase + off, seedPk, seedRec, ent.y, ent.z, ent.w);
+      const MwTxn t = lsd_txn_mw<ADV>(c, gs, a, regBase + off, seedPk, seedRec, ent.y, ent.z, ent.w);
       grow_lane_fence<true>();
       MW_TRACE(wv, lane, 3, t.logLen);   // run ends
       // through: take the private marks back (the plane is clean for the next transaction) and look once more whether an
@@ -1694,7 +1925,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     // (and a wavefront with nothing else to do always does).
     {
       const int hd = mw_ld_u(&ctl[MWC_HEAD]);
-      if (s == hd || s - hd >= a.mwDrainGap) mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs);
+      if (s == hd || s - hd >= a.mwDrainGap) mw_try_drain<ADV>(ch, gs, a, sh, frameReg, drainReg, segs);
     }
   }
   __syncthreads();
@@ -1733,21 +1964,35 @@ __device__ __forceinline__ float seg_length(const float e[4]) {
 // the latency of its own instruction stream.
 __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame(a, smem);
+  lsd_grow_frame<false>(a, smem);
 }
 __global__ void __launch_bounds__(64) k_lsd_grow_lone(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame(a, smem);
+  lsd_grow_frame<false>(a, smem);
+}
+// LSD_REFINE_ADV (plh_line_set_refine): the same with rect_improve() behind refine(); its own kernels, so that the builds above
+// keep their registers
+__global__ void __launch_bounds__(64) k_lsd_grow_adv(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  lsd_grow_frame<true>(a, smem);
 }
 
 // up to 8 wavefronts per frame: 256 registers to spare; 9 .. 16: half of that (the workgroup is 1024 threads)
 __global__ void __launch_bounds__(512) k_lsd_grow_mw(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame_mw(a, smem);
+  lsd_grow_frame_mw<false>(a, smem);
 }
 __global__ void __launch_bounds__(1024) k_lsd_grow_mw16(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame_mw(a, smem);
+  lsd_grow_frame_mw<false>(a, smem);
+}
+__global__ void __launch_bounds__(512) k_lsd_grow_mw_adv(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  lsd_grow_frame_mw<true>(a, smem);
+}
+__global__ void __launch_bounds__(1024) k_lsd_grow_mw16_adv(LineDeviceArgs a) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  lsd_grow_frame_mw<true>(a, smem);
 }
 
 __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
@@ -2186,16 +2431,26 @@ void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
       if (!asked) {
         (void)lds_request(k_lsd_grow_mw, 160u * 1024u, "k_lsd_grow_mw");
         (void)lds_request(k_lsd_grow_mw16, 160u * 1024u, "k_lsd_grow_mw16");
+        (void)lds_request(k_lsd_grow_mw_adv, 160u * 1024u, "k_lsd_grow_mw_adv");
+        (void)lds_request(k_lsd_grow_mw16_adv, 160u * 1024u, "k_lsd_grow_mw16_adv");
         asked = true;
       }
     }
     // (the roomy build holds three wavefronts per SIMD: beyond two per SIMD over the whole GPU take the 128-register one)
-    if (a.mwWaves <= 8 && (long long)a.batch * a.mwWaves <= 2048) hipLaunchKernelGGL(k_lsd_grow_mw, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
-    else hipLaunchKernelGGL(k_lsd_grow_mw16, dim3(a.batch), dim3(64 * a.mwWaves), ldsMw, s, a);
+    const bool roomy = a.mwWaves <= 8 && (long long)a.batch * a.mwWaves <= 2048;
+    const dim3 g(a.batch), b(64 * a.mwWaves);
+    if (a.refineAdv) {
+      if (roomy) hipLaunchKernelGGL(k_lsd_grow_mw_adv, g, b, ldsMw, s, a);
+      else hipLaunchKernelGGL(k_lsd_grow_mw16_adv, g, b, ldsMw, s, a);
+    } else {
+      if (roomy) hipLaunchKernelGGL(k_lsd_grow_mw, g, b, ldsMw, s, a);
+      else hipLaunchKernelGGL(k_lsd_grow_mw16, g, b, ldsMw, s, a);
+    }
     return;
   }
   const size_t lds = lsd_grow_lds_bytes(a.spitch, a.sh);
-  if (a.batch <= 8) hipLaunchKernelGGL(k_lsd_grow_lone, dim3(a.batch), dim3(64), lds, s, a);
+  if (a.refineAdv) hipLaunchKernelGGL(k_lsd_grow_adv, dim3(a.batch), dim3(64), lds, s, a);
+  else if (a.batch <= 8) hipLaunchKernelGGL(k_lsd_grow_lone, dim3(a.batch), dim3(64), lds, s, a);
   else hipLaunchKernelGGL(k_lsd_grow, dim3(a.batch), dim3(64), lds, s, a);
 }
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s) {
@@ -2238,7 +2493,7 @@ extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsign
 #endif
 size_t lsd_grow_lds_bytes(int spitch, int sh) {   // ring + scan table + first-step records + batch index
   (void)spitch; (void)sh;
-  return (size_t)LSD_RING * 4 + 5 * 64 * 4 + 64 * (16 + 4 + 4) + 8 * 4 + 6 * 8 + 8 * 4;
+  return (size_t)LSD_RING * 4 + 5 * 64 * 4 + 64 * (16 + 4 + 4) + 8 * 4 + LSD_GS_D * 8 + 8 * 4;
 }
 
 }  // namespace plh

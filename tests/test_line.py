@@ -91,6 +91,52 @@ def test_oracle_line_extract_invariants(oracle, synth):
     assert len(km) == (~both_out).sum()
 
 
+def test_oracle_lsd_refine_adv_known_answers(oracle, synth):
+    """LSD_REFINE_ADV (oracle/lsd.cc): nfa() against values computed by hand here, and what the level does to a frame."""
+    import math
+    L = oracle.lib()
+    w, h = 512, 384
+    logNT = 5 * (math.log10(w) + math.log10(h)) / 2 + math.log10(11.0)
+    p = 0.125
+    # trivial cases of the published code: no points / no aligned points -> -log NT; all points aligned -> -log NT - n log10 p
+    assert L.plo_lsd_nfa(w, h, 0, 0, p) == -logNT and L.plo_lsd_nfa(w, h, 17, 0, p) == -logNT
+    assert L.plo_lsd_nfa(w, h, 40, 40, p) == -logNT - 40.0 * math.log10(p)
+    # log_gamma: Lanczos below 15, Windschitl above; both within 1e-9 of ln Gamma
+    for x in (1.0, 2.0, 5.0, 11.5, 15.0, 15.5, 40.0, 300.0):
+        assert abs(L.plo_lsd_log_gamma(x) - math.lgamma(x)) < 1e-9 * max(1.0, abs(math.lgamma(x))), x
+    assert abs(L.plo_lsd_log_gamma(5.0) - math.log(24.0)) < 1e-12           # Gamma(5) = 4!
+    # general case, by hand: the published first term is (n + 1) -- NOT log Gamma(n + 1) --, then the tail is summed until the
+    # remaining terms are below 10 % of it
+    def nfa_published(n, k):
+        log1 = (n + 1.0) - math.lgamma(k + 1.0) - math.lgamma(n - k + 1.0) + k * math.log(p) + (n - k) * math.log(1.0 - p)
+        term = math.exp(log1)
+        if term == 0.0:                 # double_equal(term, 0): the first term underflows
+            return -log1 / math.log(10.0) - logNT if k > n * p else -logNT
+        tail = term
+        for i in range(k + 1, n + 1):
+            bin_term = (n - i + 1.0) / i
+            mult = bin_term * p / (1 - p)
+            term *= mult
+            tail += term
+            if bin_term < 1:
+                err = term * ((1 - mult ** (n - i + 1.0)) / (1 - mult) - 1)
+                if err < 0.1 * abs(-math.log10(tail) - logNT) * tail:
+                    break
+        return -math.log10(tail) - logNT
+    for n, k in ((20, 10), (60, 25), (200, 60), (200, 40), (1000, 180)):
+        assert abs(L.plo_lsd_nfa(w, h, n, k, p) - nfa_published(n, k)) < 1e-9 * max(1.0, abs(nfa_published(n, k))), (n, k)
+    # ... which is NOT the binomial tail of the original algorithm (documented quirk): 20 points, 10 aligned
+    true_tail = sum(math.comb(20, i) * p ** i * (1 - p) ** (20 - i) for i in range(10, 21))
+    assert abs(L.plo_lsd_nfa(w, h, 20, 10, p) - (-math.log10(true_tail) - logNT)) > 1.0
+    # on a frame: ADV only ever removes or adjusts STD's rectangles
+    img = synth.make_frame(3, 240, 320)
+    std, adv = oracle.lsd_detect(img), oracle.lsd_detect(img, refine=1)
+    assert 0 < len(adv) <= len(std)
+    sstd = {tuple(x) for x in std}
+    assert sum(tuple(x) in sstd for x in adv) >= 0.9 * len(adv)
+    assert len(oracle.lsd_detect(np.full((120, 160), 128, np.uint8), refine=1)) == 0
+
+
 def test_oracle_lbd_determinism_and_norm(oracle, synth):
     img = synth.make_frame(22, 240, 320, n_rect=120, n_line=60)
     kl, desc, _ = oracle.line_extract(img, 30, 0.0)
@@ -174,6 +220,26 @@ def test_emu_line_multi_wavefront_growing(plslam, oracle, synth, emu_lib, waves)
     with pytest.raises(plslam.PlhError):
         ex.set_grow_waves(17)
     ex.close(); ex2.close()
+
+
+def test_emu_line_refine_adv(plslam, oracle, synth, emu_lib):
+    """plh_line_set_refine(PLH_LSD_REFINE_ADV): rect_improve / rect_nfa / nfa behind refine(), one wavefront per frame and four."""
+    img = synth.make_frame(9, 120, 160, n_rect=40, n_line=20)
+    rs = oracle.lsd_detect(img, refine=1)
+    rk, rd, rf = oracle.line_extract(img, 50, 0.0, refine=1)
+    assert 0 < len(rs) < len(oracle.lsd_detect(img))      # the level does something on this frame
+    for waves in (0, 4):
+        ex = plslam.LINEextractor(1, 1.2, 50, 0.0, rows=120, cols=160, max_batch=1, lib=emu_lib)
+        ex.set_refine(1)
+        ex.set_grow_waves(waves)
+        kl, desc, fn = ex(img)
+        gs = ex.read_segments(0)
+        assert ex.status() == 0
+        assert len(gs) == len(rs) and (gs == rs).all(), waves
+        assert _exact(kl, desc, fn, rk, rd, rf), waves
+        with pytest.raises(plslam.PlhError):
+            ex.set_refine(2)
+        ex.close()
 
 
 def test_emu_line_edge_cases(plslam, emu_lib):
@@ -261,6 +327,54 @@ def test_gpu_line_grow_waves_batch(plslam, oracle, synth, waves, B):
             rk, rd, rf = oracle.line_extract(frames[b], 200, 0.0)
             _match(kl[b, :n[b]], desc[b, :n[b]], fn[b, :n[b]], rk, rd, rf, "seed %d frame %d" % (seed, b))
     ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", [0, -1, 4])
+def test_gpu_line_refine_adv(plslam, oracle, synth, waves):
+    """LSD_REFINE_ADV on the GPU (k_lsd_grow_adv / k_lsd_grow_mw_adv) equals the oracle's ADV level: single frames of several
+    kinds, and a batch through the device entry point."""
+    import torch
+    rng = np.random.RandomState(11)
+    imgs = [synth.make_frame(61, 480, 640), synth.make_frame(62, 480, 640, n_rect=20, n_line=10), _sawtooth(480, 640, period=42, slope=6),
+            rng.randint(0, 256, (480, 640)).astype(np.uint8), synth.make_frame(63, 480, 640, n_rect=400, n_line=200)]
+    ex = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=480, cols=640, max_batch=1)
+    ex.set_refine(1)
+    ex.set_grow_waves(waves)
+    nstd = nadv = 0
+    for k, img in enumerate(imgs):
+        rk, rd, rf = oracle.line_extract(img, 200, 0.0, refine=1)
+        rs = oracle.lsd_detect(img, refine=1)
+        kl, desc, fn = ex(img)
+        gs = ex.read_segments(0)
+        assert ex.status() == 0
+        assert len(gs) == len(rs) and (gs == rs).all(), "image %d: LSD segments (ADV) differ from the oracle" % k
+        _match(kl, desc, fn, rk, rd, rf, "ADV image %d" % k)
+        nstd += len(oracle.lsd_detect(img)); nadv += len(rs)
+    ex.close()
+    assert nadv < nstd
+    B = 16
+    frames = synth.make_frames(70, B, 240, 320)
+    exb = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=240, cols=320, max_batch=B)
+    exb.set_refine(1)
+    exb.set_grow_waves(waves)
+    cap = exb.capacity
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_kl = torch.zeros((B, cap, 17), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_fn = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    exb.extract_batch_dev(d_img, B, 240 * 320, d_kl, d_desc, d_fn, d_n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert exb.status() == 0
+    n = d_n.cpu().numpy()
+    kl = d_kl.cpu().numpy().view(np.uint8).reshape(B, cap, 68).copy().view(plslam.KL_DTYPE).reshape(B, cap)
+    desc, fn = d_desc.cpu().numpy(), d_fn.cpu().numpy()
+    for b in range(B):
+        rk, rd, rf = oracle.line_extract(frames[b], 200, 0.0, refine=1)
+        _match(kl[b, :n[b]], desc[b, :n[b]], fn[b, :n[b]], rk, rd, rf, "ADV batch frame %d" % b)
+    exb.close()
 
 
 @pytest.mark.gpu
