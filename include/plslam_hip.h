@@ -64,6 +64,12 @@ typedef struct plh_keyline {
 PLH_API const char* plh_last_error(void);     /* thread-local message of the last failing call */
 PLH_API const char* plh_version(void);
 PLH_API int plh_device_count(void);
+/* Device-side self test: every gfx950 instruction the kernels use through a shim (wave votes and broadcasts, byte permutes,
+ * packed dot products, the hand-scheduled walk of LSD's region growing, ...) is run next to its portable description over all
+ * 64 lanes and compared (pl-slam_amd/csrc/plh_shims.h, selftest.hip).  *failing_checks = 0 on a device / toolchain where the
+ * instructions do what the descriptions say; per_shim[plh_selftest_shims()] (optional) = mismatching lanes per shim. */
+PLH_API plh_status plh_selftest(int device, int* failing_checks, int32_t* per_shim, int per_shim_cap);
+PLH_API int plh_selftest_shims(void);
 
 /* ---------------------------------------------------------------------------------------------
  * ORB extractor  (replaces ORB_SLAM2::ORBextractor, include/ORBextractor.h:45-111)

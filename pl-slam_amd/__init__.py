@@ -112,6 +112,8 @@ _SIGS = {
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
     "plh_line_set_grow_waves": ([_V, _I], _I),
     "plh_line_set_refine": ([_V, _I], _I),
+    "plh_selftest": ([_I, _V, _V, _I], _I),
+    "plh_selftest_shims": ([], _I),
     "plh_frontend_create": ([_V, _V, _I, _I, _I, _V], _I),
     "plh_frontend_destroy": ([_V], _I),
     "plh_frontend_parts": ([_V], _I),

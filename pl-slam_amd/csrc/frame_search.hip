@@ -21,11 +21,7 @@
 
 namespace plh {
 
-#if defined(HIPEMU)
-#define FS_WAVE_SYNC() hipemu::wave_barrier()
-#else
-#define FS_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#endif
+#define FS_WAVE_SYNC() PLH_WAVE_SYNC()
 
 constexpr int GCOLS = PLH_GRID_COLS, GROWS = PLH_GRID_ROWS, GCELLS = PLH_GRID_CELLS;
 

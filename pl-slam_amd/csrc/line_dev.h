@@ -5,12 +5,6 @@
 
 namespace plh {
 
-#if defined(HIPEMU)
-#define PLH_WAVE_SYNC() hipemu::wave_barrier()
-#else
-#define PLH_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#endif
-
 constexpr double kPI = 3.14159265358979323846;
 constexpr double kDegToRads = kPI / 180;
 constexpr double k3_2PI = 3 * kPI / 2, k2PI = 2 * kPI;
@@ -49,17 +43,6 @@ __device__ __forceinline__ unsigned lsd_rec_q(uint32_t rec) {
   const int gx = (int)(rec & 1023u) - LSD_GRAD_MAX, gy = (int)((rec >> LSD_ANGLE_PITCH_LOG2) & 1023u) - LSD_GRAD_MAX;
   return (unsigned)(__mul24(gx, gx) + __mul24(gy, gy));
 }
-
-// uniform-lane broadcast of a double: v_readlane (SGPR) on hardware, a shuffle under emulation
-#if defined(HIPEMU)
-__device__ __forceinline__ double bcast_f64(double v, int l) { return __shfl(v, l); }
-#else
-__device__ __forceinline__ double bcast_f64(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
-#endif
 
 // packed int16 pair (used for the Sobel dx,dy image of LBD)
 __device__ __forceinline__ uint32_t pack_g(int gx, int gy) { return ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16); }

@@ -74,42 +74,9 @@ __global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
 // row sums per v_dot2_u32_u16.  For the latter the row sums are stored transposed (hT[column][row], pitch 13 dwords:
 // conflict-free for the 64 columns of a wavefront) so that vertically adjacent sums share a dword; a thread then owns
 // one column and four rows and writes its four pixels as bytes (64 lanes = 64 consecutive bytes of a row per store).
-__device__ __forceinline__ unsigned plh_udot4_l(unsigned a, unsigned b, unsigned c) {
-#if defined(HIPEMU)
-  for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
-  return c;
-#else
-  return __builtin_amdgcn_udot4(a, b, c, false);
-#endif
-}
-__device__ __forceinline__ unsigned plh_udot2_l(unsigned a, unsigned b, unsigned c) {
-#if defined(HIPEMU)
-  return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c;
-#else
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  u16x2 x, y;
-  __builtin_memcpy(&x, &a, 4);
-  __builtin_memcpy(&y, &b, 4);
-  return __builtin_amdgcn_udot2(x, y, c, false);
-#endif
-}
-// bytes 2,3 of lo and of hi as two halves (a >> 16 of two accumulators), and min(., 255) on both halves
-__device__ __forceinline__ unsigned hi_halves_sat255(unsigned hi, unsigned lo) {
-#if defined(HIPEMU)
-  return min(lo >> 16, 255u) | (min(hi >> 16, 255u) << 16);
-#else
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  const unsigned p = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-  u16x2 x, y;
-  const unsigned cap = 0x00ff00ffu;
-  __builtin_memcpy(&x, &p, 4);
-  __builtin_memcpy(&y, &cap, 4);
-  const u16x2 r = __builtin_elementwise_min(x, y);
-  unsigned o;
-  __builtin_memcpy(&o, &r, 4);
-  return o;
-#endif
-}
+__device__ __forceinline__ unsigned plh_udot4_l(unsigned a, unsigned b, unsigned c) { return plh_udot4(a, b, c); }
+__device__ __forceinline__ unsigned plh_udot2_l(unsigned a, unsigned b, unsigned c) { return plh_udot2(a, b, c); }
+// (hi_halves_sat255: bytes 2, 3 of two accumulators as two halves, saturated at 255 -- plh_shims.h)
 
 template <int R>
 __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst,
@@ -342,22 +309,7 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   if (threadIdx.x == 0 && threadIdx.y == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);
 }
 
-// bit k of v as 0 / -1 (v_bfe_i32 with width 1)
-__device__ __forceinline__ int plh_sbfe1(unsigned v, int k) {
-#if defined(HIPEMU)
-  return -(int)((v >> k) & 1u);
-#else
-  return __builtin_amdgcn_sbfe((int)v, (unsigned)k, 1u);
-#endif
-}
-// v_sqrt_f32 (1 ulp) where an estimate is all that is needed
-__device__ __forceinline__ float plh_sqrt_approx(float x) {
-#if defined(HIPEMU)
-  return sqrtf(x);
-#else
-  return __builtin_amdgcn_sqrtf(x);
-#endif
-}
+// (plh_sbfe1, plh_sqrt_approx: plh_shims.h)
 
 // Seed ordering: stable counting sort of the DEFINED pixels of a frame by bin (descending), raster order inside a bin.
 // A frame is cut into LSD_ORDER_CHUNKS contiguous raster chunks; the sort is four launches of small blocks

@@ -122,9 +122,7 @@ __device__ __forceinline__ void grow_unmark(const GrowCtx& c, uint32_t idx, unsi
 template <bool MW>
 __device__ __forceinline__ void grow_lane_fence() {
   if constexpr (MW) {
-#if !defined(HIPEMU)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#endif
+    wave_fence();
     PLH_WAVE_SYNC();
   } else {
     __syncthreads();
@@ -152,15 +150,7 @@ __device__ __forceinline__ uint32_t reg_get(const GrowCtx& c, int i, int cnt) {
   return (cnt - i <= LSD_RING) ? c.ring[i & (LSD_RING - 1)] : c.reg[i];
 }
 
-#if defined(HIPEMU)
-__device__ __forceinline__ float bcast_f32(float v, int l) { return __shfl(v, l); }
-__device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return __shfl(v, l); }
-#else
-__device__ __forceinline__ float bcast_f32(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-__device__ __forceinline__ unsigned bcast_u32(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
-#endif
+// (bcast_u32 / bcast_f32 / bcast_f64 -- v_readlane with a uniform lane -- and every other instruction shim: plh_shims.h)
 
 // Per-wavefront state that lives in LDS rather than in registers (uniform values the compiler would keep in VGPRs):
 // the parameters of the current region_grow() call, the fitted rectangle, and the first-step prefetch tables.
@@ -227,13 +217,7 @@ __device__ __forceinline__ bool lsd_aligned_f(float thF, float aF, const LsdTol&
   return r;
 }
 
-// A wave mask used as a per-lane predicate: the SGPR pair feeds v_cndmask / exec directly (no v_cmp), the emulator
-// tests the lane's bit.
-#if defined(HIPEMU)
-#define LSD_INV_BALLOT(c, m) ((((m) >> (c).lane) & 1ull) != 0)
-#else
-#define LSD_INV_BALLOT(c, m) __builtin_amdgcn_inverse_ballot_w64(m)
-#endif
+#define LSD_INV_BALLOT(c, m) PLH_INV_BALLOT(m)   // a wave mask as a per-lane predicate (plh_shims.h)
 
 // lsd_aligned_f for a whole step, as wave masks: every compare result is used as the 64-bit mask it already is and the
 // set logic runs on the scalar unit.  `act` = lanes whose answer matters; only they can trigger the exact double path.
@@ -260,9 +244,6 @@ __device__ __forceinline__ unsigned long long lsd_aligned_mask(const GrowCtx& c,
 // dividend min(|x|, |y|) is either 0 or at least 2^-48 (every term is a float of magnitude >= 4e-8 -- the cosine at the
 // float next to pi/2 -- so a sum is a multiple of 2^-48).  Same operations, same roundings, same result.
 __device__ __forceinline__ float lsd_atan2_deg(float y, float x) {
-#if defined(HIPEMU)
-  return fast_atan2_deg(y, x);
-#else
   const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
   const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
   const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
@@ -270,93 +251,22 @@ __device__ __forceinline__ float lsd_atan2_deg(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
   const bool swap = !(ax >= ay);
   const float num = swap ? ax : ay, den = (swap ? ay : ax) + 2.2204460492503131e-16f;
-  float r = __builtin_amdgcn_rcpf(den);
-  r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
-  float q = num * r;
-  q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
-  const float c = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+  const float c = div_normal(num, den);   // (plh_shims.h: the division without v_div_scale / v_div_fixup; plh_selftest compares it with `/`)
   const float c2 = c * c;
   float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
   if (swap) a = 90.f - a;
   if (x < 0) a = 180.f - a;
   if (y < 0) a = 360.f - a;
   return a;
-#endif
 }
 
 // The walk of lsd_resolve: the predicted-accepted lanes of mask P in lane order; lane k adds its (cos, sin) to the running
 // sums of every lane behind it and cancels its later duplicates (same pixel examined from another queue point).  On return
 // acc = the lanes walked, canc = the duplicates dropped (possibly with lanes outside the candidate set: only ever used
-// masked).  Hand-scheduled because it runs once per accepted pixel (130 k times per frame) and the per-lane updates are
-// cheapest under EXEC = "lanes behind k", which the scalar unit produces in one instruction (s_lshl_b64 exec, -2, k): the
-// compare then needs no mask and the adds no selects -- 6 VALU + 6 SALU instructions per pixel where the compiled form had
-// 8 + 9 (the set of walked lanes is P & ~canc afterwards; the loop branches on the SCC of its last mask update).  Wait states (gfx940 family: an SGPR written by v_readlane may be read by a VALU instruction no sooner than the
-// third instruction after it) are kept by the order of the instructions.
-__device__ __forceinline__ void lsd_walk(const GrowCtx& c, unsigned long long P, bool mayDup, uint32_t nidx, float cs, float sn,
-                                         float& preX, float& preY, unsigned long long& accOut,
-                                         unsigned long long& cancOut) {
-  unsigned long long m = P, canc = 0;
-#if defined(HIPEMU)
-  while (m) {
-    const int k = __ffsll((long long)m) - 1;
-    m &= ~(1ull << k);
-    const unsigned long long above = ~1ull << k;
-    if (mayDup) {
-      const unsigned long long dup = wballot(nidx == bcast_u32(nidx, k)) & above;
-      m &= ~dup;
-      canc |= dup;
-    }
-    const float ck = bcast_f32(cs, k), sk = bcast_f32(sn, k);
-    if ((above >> c.lane) & 1ull) { preX += ck; preY += sk; }
-  }
-#else
-  unsigned long long saved;
-  int k;
-  unsigned t0;
-  float t1, t2;
-  if (mayDup) {
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n"
-        "lsdwalk%=:\n\t"
-        "s_ff1_i32_b64 %[k], %[m]\n\t"
-        "s_bitset0_b64 %[m], %[k]\n\t"
-        "v_readlane_b32 %[t0], %[nidx], %[k]\n\t"
-        "v_readlane_b32 %[t1], %[cs], %[k]\n\t"
-        "v_readlane_b32 %[t2], %[sn], %[k]\n\t"
-        "s_lshl_b64 exec, -2, %[k]\n\t"
-        "v_cmp_eq_u32_e32 vcc, %[t0], %[nidx]\n\t"
-        "v_add_f32_e32 %[px], %[t1], %[px]\n\t"
-        "v_add_f32_e32 %[py], %[t2], %[py]\n\t"
-        "s_or_b64 %[canc], %[canc], vcc\n\t"
-        "s_andn2_b64 %[m], %[m], vcc\n\t"      // SCC = lanes left to walk
-        "s_cbranch_scc1 lsdwalk%=\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [m] "+s"(m), [canc] "+s"(canc), [px] "+v"(preX), [py] "+v"(preY), [k] "=&s"(k),
-          [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(saved)
-        : [nidx] "v"(nidx), [cs] "v"(cs), [sn] "v"(sn)
-        : "vcc", "scc");
-  } else {
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n"
-        "lsdwalk%=:\n\t"
-        "s_ff1_i32_b64 %[k], %[m]\n\t"
-        "s_bitset0_b64 %[m], %[k]\n\t"
-        "v_readlane_b32 %[t1], %[cs], %[k]\n\t"
-        "v_readlane_b32 %[t2], %[sn], %[k]\n\t"
-        "s_lshl_b64 exec, -2, %[k]\n\t"
-        "s_cmp_lg_u64 %[m], 0\n\t"
-        "v_add_f32_e32 %[px], %[t1], %[px]\n\t"
-        "v_add_f32_e32 %[py], %[t2], %[py]\n\t"
-        "s_cbranch_scc1 lsdwalk%=\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [m] "+s"(m), [px] "+v"(preX), [py] "+v"(preY), [k] "=&s"(k), [t1] "=&s"(t1),
-          [t2] "=&s"(t2), [sv] "=&s"(saved)
-        : [cs] "v"(cs), [sn] "v"(sn)
-        : "scc");
-  }
-#endif
-  accOut = P & ~canc;   // the lanes walked: predicted, and not cancelled by an earlier walked lane
-  cancOut = canc;
+// masked).  Both forms -- the hand-scheduled gfx950 loop and the plain one that says what it computes -- are in plh_shims.h.
+__device__ __forceinline__ void lsd_walk(const GrowCtx&, unsigned long long P, bool mayDup, uint32_t nidx, float cs, float sn,
+                                         float& preX, float& preY, unsigned long long& accOut, unsigned long long& cancOut) {
+  plh::lsd_walk(P, mayDup, nidx, cs, sn, preX, preY, accOut, cancOut);
 }
 
 // Which way does a candidate's decision go, judged by directions instead of fastAtan2 values?  The reference compares the
@@ -1296,28 +1206,14 @@ constexpr int MW_PEND_WORDS = 16;   // a posted transaction (MwPost)
 constexpr unsigned MW_SPIN_LIMIT = 1u << 26;
 constexpr int MW_WAVE_LDS = LSD_RING * 4 + (LSD_GS_D + 1) * 8 + 8 * 4 + MW_ASM_CAP * 4 + 16;   // per wavefront: ring (aliased by T) + GrowState + assumed-used list + its count
 
-#if defined(HIPEMU)
-__device__ __forceinline__ int mw_ld(const int* p) { return *(volatile const int*)p; }
-__device__ __forceinline__ void mw_st(int* p, int v) { *(volatile int*)p = v; }
-__device__ __forceinline__ int mw_cas(int* p, int cmp, int v) { const int o = *p; if (o == cmp) *p = v; return o; }
-__device__ __forceinline__ void mw_pause() { hipemu::spin_yield(); }
-__device__ __forceinline__ void mw_release() {}
-__device__ __forceinline__ void mw_acquire() {}
-#else
-__device__ __forceinline__ int mw_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void mw_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ int mw_cas(int* p, int cmp, int v) {
-  __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  return cmp;
-}
-__device__ __forceinline__ void mw_pause() { __builtin_amdgcn_s_sleep(8); }
+// the control words in LDS, the pause of a polling loop and the two fences: plh_shims.h (lds_*, spin_pause, wg_release, wg_acquire)
+__device__ __forceinline__ int mw_ld(const int* p) { return lds_load(p); }
+__device__ __forceinline__ void mw_st(int* p, int v) { lds_store(p, v); }
+__device__ __forceinline__ int mw_cas(int* p, int cmp, int v) { return lds_cas(p, cmp, v); }
+__device__ __forceinline__ void mw_pause() { spin_pause(); }
 // publish: this wavefront's global stores are complete (L1 / L2 of its CU) before the LDS word that hands them over
-__device__ __forceinline__ void mw_release() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ void mw_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-#endif
+__device__ __forceinline__ void mw_release() { wg_release(); }
+__device__ __forceinline__ void mw_acquire() { wg_acquire(); }
 
 __device__ __forceinline__ bool mw_give_up(int* ctl, unsigned& polls, int* status) {
   if (++polls > MW_SPIN_LIMIT) {
@@ -2104,31 +2000,9 @@ __device__ __forceinline__ unsigned ld4_any(const uint8_t* p) {
   return m ? (unsigned)(((((unsigned long long)ap[1]) << 32) | lo) >> (8 * m)) : lo;
 }
 
-// packed 16-bit lanes (v_pk_add_u16 / v_pk_sub_i16 / v_pk_mad_u16, v_perm_b32, v_alignbyte_b32) with plain twins for the emulator
-#if defined(HIPEMU)
-__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16); }
-__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
-__device__ __forceinline__ unsigned pk_twice_plus16(unsigned a, unsigned b) { return pk_add16(pk_add16(a, a), b); }
-__device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) {
-  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
-  unsigned r = 0;
-  for (int i = 0; i < 4; i++) {
-    const unsigned c = (sel >> (8 * i)) & 255u;
-    r |= (c <= 7u ? (unsigned)((v >> (8 * c)) & 255u) : 0u) << (8 * i);
-  }
-  return r;
-}
-__device__ __forceinline__ unsigned align_b32(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * sh)); }
-#else
-typedef unsigned short pk_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pk_u16x2 pk_of(unsigned a) { pk_u16x2 v; __builtin_memcpy(&v, &a, 4); return v; }
-__device__ __forceinline__ unsigned pk_to(pk_u16x2 v) { unsigned a; __builtin_memcpy(&a, &v, 4); return a; }
-__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return pk_to(pk_of(a) + pk_of(b)); }
-__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return pk_to(pk_of(a) - pk_of(b)); }
-__device__ __forceinline__ unsigned pk_twice_plus16(unsigned a, unsigned b) { const pk_u16x2 two = {2, 2}; return pk_to(pk_of(a) * two + pk_of(b)); }
-__device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ unsigned align_b32(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
-#endif
+// packed 16-bit lanes (v_pk_add_u16 / v_pk_sub_i16 / v_pk_mad_u16: pk_add16, pk_sub16, pk_twice_plus16), v_perm_b32, v_alignbyte_b32: plh_shims.h
+__device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) { return plh_perm(hi, lo, sel); }
+__device__ __forceinline__ unsigned align_b32(unsigned hi, unsigned lo, unsigned sh) { return plh_alignbyte(hi, lo, sh); }
 
 // One thread per 4 adjacent pixels.  Columns x-1 .. x+4 of the three rows come from three aligned dwords per row and one
 // v_alignbyte pair; the sums are taken on pairs of columns in packed 16-bit lanes: the vertical smoothing r0 + 2 r1 + r2
@@ -2198,14 +2072,6 @@ __device__ const unsigned char c_lbd_comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0
                                                  2, 4, 2, 5, 2, 6, 2, 7, 2, 8, 3, 4, 3, 5, 3, 6, 3, 7, 3, 8, 4, 5, 4, 6,
                                                  4, 7, 4, 8, 5, 6, 5, 7, 5, 8, 6, 7, 6, 8, 7, 8};
 
-// v_fract_f32 (x - floor(x), exact for x >= 0) with a plain twin for the emulator
-__device__ __forceinline__ float plh_fract(float x) {
-#if defined(HIPEMU)
-  return x - floorf(x);
-#else
-  return __builtin_amdgcn_fractf(x);
-#endif
-}
 // clamp((int)(short)roundf(v), 0, hi) of the walk (binary_descriptor_custom.cpp:1117-1124) for |v| < 32767, where the cast
 // to short is the identity: everything below zero clamps to 0, and for c >= 0 roundf(c) = trunc(c) + (fract(c) >= 0.5).
 __device__ __forceinline__ int lbd_coord(float v, int hi) {

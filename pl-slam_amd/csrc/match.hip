@@ -13,12 +13,6 @@
 
 namespace plh {
 
-#if defined(HIPEMU)
-#define PLH_WAVE_SYNC() hipemu::wave_barrier()
-#else
-#define PLH_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#endif
-
 struct Desc256 {
   unsigned long long w[4];
 };
@@ -159,23 +153,7 @@ __global__ void __launch_bounds__(256) k_line_mutual(const int32_t* m1, const in
 // Phase B (wave 0): KeyFrame features in that order, strictly sequential because of the greedy
 // "already matched" skip (ORBmatcher.cc:240); the 64 lanes scan the Frame candidates of the node.
 // ---------------------------------------------------------------------------------------------
-// min over the wavefront, result uniform.  Hardware: row_shr 1/2/4/8 + row_bcast 15/31 DPP steps (register-to-register,
-// no LDS crossbar round trips) and one v_readlane; the emulator uses the butterfly.
-__device__ __forceinline__ int wave_min_i32(int v) {
-#if defined(HIPEMU)
-  for (int s = 32; s >= 1; s >>= 1) v = min(v, __shfl_xor(v, s));
-  return v;
-#else
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x111, 0xf, 0xf, false));   // row_shr:1
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x112, 0xf, 0xf, false));   // row_shr:2
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x114, 0xf, 0xf, false));   // row_shr:4
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x118, 0xf, 0xf, false));   // row_shr:8: lane 15 of a row = row min
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
-  v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
-  return __builtin_amdgcn_readlane(v, 63);
-#endif
-}
-
+// (wave_min_i32: DPP row steps on the hardware, plh_shims.h)
 __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1,
                                                        const uint8_t* valid1, const int* n1Arr, const uint8_t* desc2,
                                                        const float* angle2, const int32_t* node2, const int* n2Arr, int cap,

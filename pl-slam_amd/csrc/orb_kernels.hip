@@ -50,11 +50,7 @@ __device__ __forceinline__ const uint8_t* level_ptr(const OrbDeviceArgs& a, cons
 }
 
 __device__ __forceinline__ unsigned align_bytes_u(unsigned hi, unsigned lo, int sh) {   // bytes sh..sh+3 of {hi:lo}, sh in 0..3
-#if defined(HIPEMU)
-  return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * sh));
-#else
-  return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)sh);   // one v_alignbyte_b32 instead of a 64-bit shift
-#endif
+  return plh_alignbyte(hi, lo, (unsigned)sh);   // one v_alignbyte_b32 instead of a 64-bit shift
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -68,46 +64,7 @@ __device__ __forceinline__ unsigned align_bytes_u(unsigned hi, unsigned lo, int 
 // ---------------------------------------------------------------------------------------------
 constexpr int PYR_ROWS = 4;
 
-// v_perm_b32 / v_dot2_u32_u16 / v_alignbyte_b32 with plain-C++ twins for the emulator build
-#if defined(HIPEMU)
-__device__ __forceinline__ unsigned plh_perm(unsigned hi, unsigned lo, unsigned sel) {   // byte i of the result = byte sel[i] of {hi:lo}; 0x0c -> 0
-  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
-  unsigned r = 0;
-  for (int i = 0; i < 4; i++) {
-    const unsigned c = (sel >> (8 * i)) & 255u;
-    r |= (c <= 7u ? (unsigned)((v >> (8 * c)) & 255u) : 0u) << (8 * i);
-  }
-  return r;
-}
-__device__ __forceinline__ unsigned plh_udot2(unsigned a, unsigned b, unsigned c) { return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c; }
-__device__ __forceinline__ unsigned plh_udot4(unsigned a, unsigned b, unsigned c) {
-  for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
-  return c;
-}
-__device__ __forceinline__ unsigned plh_pk_min_u16(unsigned a, unsigned b) {
-  return min(a & 0xffffu, b & 0xffffu) | (min(a >> 16, b >> 16) << 16);
-}
-#else
-__device__ __forceinline__ unsigned plh_perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ unsigned plh_udot2(unsigned a, unsigned b, unsigned c) {
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  u16x2 x, y;
-  __builtin_memcpy(&x, &a, 4);
-  __builtin_memcpy(&y, &b, 4);
-  return __builtin_amdgcn_udot2(x, y, c, false);
-}
-__device__ __forceinline__ unsigned plh_udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
-__device__ __forceinline__ unsigned plh_pk_min_u16(unsigned a, unsigned b) {
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  u16x2 x, y;
-  __builtin_memcpy(&x, &a, 4);
-  __builtin_memcpy(&y, &b, 4);
-  const u16x2 r = __builtin_elementwise_min(x, y);   // v_pk_min_u16
-  unsigned o;
-  __builtin_memcpy(&o, &r, 4);
-  return o;
-}
-#endif
+// (v_perm_b32 / v_dot2_u32_u16 / v_dot4_u32_u8 / v_pk_min_u16: plh_perm, plh_udot2, plh_udot4, plh_pk_min_u16 of plh_shims.h)
 // dot4 / dot2 operands from tap weights (byte / half 0 = lowest address)
 constexpr unsigned w4(unsigned a, unsigned b, unsigned c, unsigned d) { return a | (b << 8) | (c << 16) | (d << 24); }
 constexpr unsigned w2(unsigned lo, unsigned hi) { return lo | (hi << 16); }
@@ -335,11 +292,7 @@ __device__ __forceinline__ int fast_arc_side(int sv, int ns, const int p[16]) {
 //      the cell uses: "hi" if the cell has a survivor at iniThFAST, else the minThFAST fallback (ORBextractor.cc:808-816).
 // Tile column c holds level column xa + c with xa = (x0 & ~3) - 4, so pixel groups are dword aligned in the tile.
 constexpr int FAST_QCAP = 320;   // per-wave queue of (pixel, side) pairs that passed the quick test (63 + 2 * 128 + slack)
-#if defined(HIPEMU)
-#define ORB_WAVE_SYNC() hipemu::wave_barrier()
-#else
-#define ORB_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#endif
+#define ORB_WAVE_SYNC() PLH_WAVE_SYNC()
 
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p) { return *reinterpret_cast<const unsigned*>(p); }
 __device__ __forceinline__ unsigned align_bytes(unsigned hi, unsigned lo, int sh) {   // bytes sh..sh+3 of {hi:lo}

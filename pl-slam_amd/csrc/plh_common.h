@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "../../include/plslam_hip.h"
+#include "plh_shims.h"
 
 #define PLH_WAVE 64
 
@@ -58,28 +59,9 @@ inline plh_status lds_request(K kernel, size_t bytes, const char* who) {
 template <typename T>
 static inline T align_up(T v, T a) { return (v + a - 1) / a * a; }
 
-// ---- device helpers ----
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
-
+// ---- device helpers ----  (lane_id, wballot, PLH_INV_BALLOT, the broadcasts and every other instruction shim: plh_shims.h)
 // cvRound: round-half-to-even (v_cvt_i32_f32 with the default RNE mode / v_rndne)
 __device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
-
-// Wave vote that returns the compare mask itself (HIP's __ballot materialises the predicate as an int first:
-// v_cndmask + v_cmp, 8 issue cycles per vote on gfx950).  Feed it direct comparisons and combine the masks with
-// scalar logic.
-#if defined(HIPEMU)
-__device__ __forceinline__ unsigned long long wballot(bool p) { return __ballot(p); }
-#else
-__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-#endif
-
-// A wave mask used as a per-lane predicate: the SGPR pair feeds exec / v_cndmask directly (no v_cmp); the emulator tests
-// the lane's bit.
-#if defined(HIPEMU)
-#define PLH_INV_BALLOT(m) ((((m) >> plh::lane_id()) & 1ull) != 0)
-#else
-#define PLH_INV_BALLOT(m) __builtin_amdgcn_inverse_ballot_w64(m)
-#endif
 
 // number of set bits of a wave mask below this lane (v_mbcnt_lo + v_mbcnt_hi)
 __device__ __forceinline__ int mbcnt64(unsigned long long m) {

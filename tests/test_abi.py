@@ -99,3 +99,28 @@ def test_emu_status_query(plslam, synth, emu_lib):
 @pytest.mark.gpu
 def test_gpu_status_query(plslam, synth):
     _status_case(plslam, synth, None)
+
+
+def _selftest(P, lib):
+    import ctypes as C
+    L = P.load(lib)
+    n = L.plh_selftest_shims()
+    per = (C.c_int32 * n)()
+    bad = C.c_int(-1)
+    assert L.plh_selftest(0, C.byref(bad), per, n) == 0, L.plh_last_error()
+    return bad.value, list(per)
+
+
+def test_emu_selftest_entry_point(plslam, emu_lib):
+    bad, per = _selftest(plslam, emu_lib)      # the emulator build has only the portable twins: nothing can differ
+    assert bad == 0 and len(per) == 20 and not any(per)
+
+
+@pytest.mark.gpu
+def test_gpu_instruction_shims_match_their_descriptions(plslam):
+    """plh_selftest: every gfx950 instruction the kernels reach through plh_shims.h (wave votes incl. inverse_ballot with bits in
+    both mask halves, readlane broadcasts from every lane, v_perm / v_alignbyte / v_dot4 / v_dot2 / packed 16-bit, v_fract,
+    the division without v_div_scale, the hand-scheduled walk of LSD's region growing) against its portable twin, 4096 rounds
+    x 64 lanes each -- the class of bug the CPU emulator cannot see, caught in seconds."""
+    bad, per = _selftest(plslam, None)
+    assert bad == 0, "shims that differ (mismatching lanes per shim): %s" % per
