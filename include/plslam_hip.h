@@ -462,6 +462,21 @@ PLH_API plh_status plh_line_search_by_projection_ml(const plh_keyline* kl, const
                                                     const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned,
                                                     int* nmatches, int device);
 
+/* Back-end searches, host-buffer forms (LoopClosing / LocalMapping call sites; arrays as in the *_batch_dev forms). */
+PLH_API plh_status plh_orb_search_by_bow_kfkf(const plh_keypoint* kps1, const uint8_t* desc1, const int32_t* node1,
+                                              const uint8_t* valid1, int n1, const plh_keypoint* kps2, const uint8_t* desc2,
+                                              const int32_t* node2, const uint8_t* valid2, int n2, int th_low, float nnratio,
+                                              int check_ori, int32_t* matches12, int* nmatches, int device);
+PLH_API plh_status plh_orb_search_by_projection_sim3(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                                     const float* scale_factors, int nlevels, uint8_t* occupied, int nq,
+                                                     const uint8_t* q_valid, const float* q_uv, const int32_t* q_level,
+                                                     const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int th_low,
+                                                     int32_t* assigned, int* nmatches, int device);
+PLH_API plh_status plh_orb_fuse_search(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                       const float* scale_factors, const float* inv_level_sigma2, int nlevels, int nq,
+                                       const uint8_t* q_valid, const float* q_uv, const int32_t* q_level, const uint8_t* q_desc,
+                                       float th, int th_low, int32_t* best_idx, int* nfound, int device);
+
 /* ---------------------------------------------------------------------------------------------
  * Frame / map post-processing either side of the matching path
  * ------------------------------------------------------------------------------------------- */

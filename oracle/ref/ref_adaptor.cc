@@ -11,8 +11,10 @@
 // ComputeImageBounds, both grid assignments -- and the two initialisation matchers on constructed frames.  The tracking searches
 // (SearchByProjection x3, SearchByBoW) are driven by ref_frame.cc's own harness functions, which in this build instantiate the
 // adaptor ORBmatcher / LSDmatcher.  TEST INFRASTRUCTURE ONLY.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #define private public
@@ -125,6 +127,188 @@ int adx_search_double(void* h1, void* h2, float nnratio, int32_t* matches12) {
   const int n = matcher.SearchDouble(f1, f2, m);
   for (int i = 0; i < f1.NL && i < (int)m.size(); i++) matches12[i] = m[i];
   return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Back-end call sites on real KeyFrame / MapPoint objects: every function builds the scene TWICE and runs the reference's own
+// method (ORBmatcherCPU = src/ORBmatcher.cc) on one copy and the adaptor overload (ORBmatcher, GPU) on the other; the caller
+// compares what the two left behind.  Poses may rotate: both sides use the same cv::Mat algebra.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct BackScene {
+  Map map; KeyFrameDatabase db;
+  Frame f;
+  KeyFrame* kf = nullptr;
+  std::vector<std::unique_ptr<MapPoint> > pts;
+  ~BackScene() { delete kf; }
+};
+// view[24] as in oracle/plo.h: R (9), t (3), unused (3), fx fy cx cy, unused (4), log scale factor [23]
+void build_kf(BackScene& s, const void* kps28, const uint8_t* desc, int n, const float gp[6], const float T16[16], const float K4[4], int nlevels,
+              float scale, ORBVocabulary* voc) {
+  Frame& f = s.f;
+  Frame::mnMinX = gp[0]; Frame::mnMinY = gp[1]; Frame::mnMaxX = gp[2]; Frame::mnMaxY = gp[3];
+  Frame::mfGridElementWidthInv = gp[4]; Frame::mfGridElementHeightInv = gp[5];
+  Frame::fx = K4[0]; Frame::fy = K4[1]; Frame::cx = K4[2]; Frame::cy = K4[3];
+  f.N = n;
+  f.mvKeysUn.resize(n);
+  if (n > 0) std::memcpy(f.mvKeysUn.data(), kps28, (size_t)n * 28);
+  f.mvKeys = f.mvKeysUn;
+  f.mDescriptors = cv::Mat(n > 0 ? n : 1, 32, CV_8U);
+  if (n > 0) std::memcpy(f.mDescriptors.data, desc, (size_t)n * 32);
+  f.mvuRight.assign(n, -1.f);
+  f.mvDepth.assign(n, -1.f);
+  f.mvpMapPoints.assign(n, nullptr);
+  f.mvbOutlier.assign(n, false);
+  f.mnScaleLevels = nlevels;
+  f.mfScaleFactor = scale;
+  f.mfLogScaleFactor = std::log(scale);
+  f.mvScaleFactors.resize(nlevels); f.mvLevelSigma2.resize(nlevels); f.mvInvLevelSigma2.resize(nlevels);
+  f.mvScaleFactors[0] = 1.f; f.mvLevelSigma2[0] = 1.f;
+  for (int i = 1; i < nlevels; i++) { f.mvScaleFactors[i] = f.mvScaleFactors[i - 1] * scale; f.mvLevelSigma2[i] = f.mvScaleFactors[i] * f.mvScaleFactors[i]; }
+  for (int i = 0; i < nlevels; i++) f.mvInvLevelSigma2[i] = 1.0f / f.mvLevelSigma2[i];
+  f.mbf = 0.f;
+  f.mK = cv::Mat::eye(3, 3, CV_32F);
+  f.mK.at<float>(0, 0) = K4[0]; f.mK.at<float>(1, 1) = K4[1]; f.mK.at<float>(0, 2) = K4[2]; f.mK.at<float>(1, 2) = K4[3];
+  f.mpORBvocabulary = voc;
+  f.AssignFeaturesToGrid();
+  cv::Mat T(4, 4, CV_32F);
+  for (int i = 0; i < 16; i++) T.at<float>(i / 4, i % 4) = T16[i];
+  f.SetPose(T);
+  s.kf = new KeyFrame(f, &s.map, &s.db);
+}
+MapPoint* add_point(BackScene& s, const float* pos, const float* normal, float dmin, float dmax, const uint8_t* desc, int nobs, long id) {
+  cv::Mat P(3, 1, CV_32F);
+  for (int k = 0; k < 3; k++) P.at<float>(k) = pos[k];
+  s.pts.emplace_back(new MapPoint(P, s.kf, &s.map));
+  MapPoint* p = s.pts.back().get();
+  p->mNormalVector = cv::Mat(3, 1, CV_32F);
+  for (int k = 0; k < 3; k++) p->mNormalVector.at<float>(k) = normal[k];
+  p->mfMinDistance = dmin; p->mfMaxDistance = dmax;
+  if (desc) { p->mDescriptor = cv::Mat(1, 32, CV_8U); std::memcpy(p->mDescriptor.data, desc, 32); }
+  p->nObs = nobs;
+  p->mnId = (unsigned long)id;
+  return p;
+}
+}  // namespace
+
+// ORBmatcher(0.75, true).SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (LoopClosing.cc:360).  The KeyFrame holds
+// n keypoints; vpMatched[idx] starts with a (dummy) point where matched0[idx] is set.  out_*[idx] = id of the candidate point now
+// in vpMatched[idx] (-1: none, -2: the dummy that was there).  Returns nmatches of the adaptor; *n_ref = the reference's.
+int adx_loop_search_by_projection(const void* kps28, const uint8_t* desc, int n, const float gp[6], const float T16[16], const float K4[4],
+                                  int nlevels, float scale, const float S16[16], const uint8_t* matched0, int npts, const float* pos,
+                                  const float* normal, const float* dmin, const float* dmax, const uint8_t* mp_desc, int th,
+                                  int32_t* out_ref, int32_t* out_hip, int* n_ref) {
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    BackScene s;
+    build_kf(s, kps28, desc, n, gp, T16, K4, nlevels, scale, nullptr);
+    const float z3[3] = {0, 0, 1};
+    std::vector<MapPoint*> vpMatched(n, nullptr), cand(npts);
+    for (int i = 0; i < n; i++)
+      if (matched0[i]) vpMatched[i] = add_point(s, z3, z3, 0.f, 1e9f, nullptr, 1, -2);
+    for (int i = 0; i < npts; i++) cand[i] = add_point(s, pos + 3 * i, normal + 3 * i, dmin[i], dmax[i], mp_desc + (size_t)i * 32, 1, i);
+    cv::Mat Scw(4, 4, CV_32F);
+    for (int i = 0; i < 16; i++) Scw.at<float>(i / 4, i % 4) = S16[i];
+    int32_t* out = side == 0 ? out_ref : out_hip;
+    if (side == 0) { ORBmatcherCPU m(0.75f, true); res[0] = m.SearchByProjection(s.kf, Scw, cand, vpMatched, th); }
+    else { ORBmatcher m(0.75f, true); res[1] = m.SearchByProjection(s.kf, Scw, cand, vpMatched, th); }
+    for (int i = 0; i < n; i++) out[i] = vpMatched[i] ? (int32_t)(long)vpMatched[i]->mnId : -1;
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
+// ORBmatcher().Fuse(pKF, vpMapPoints, th) (LocalMapping.cc:1545).  The KeyFrame already holds a point with kf_obs[idx] observations
+// at keypoint idx where kf_obs[idx] > 0; candidate i has cand_obs[i] observations.  What the call leaves behind, per side:
+// kf_point[idx] = id of the point now at keypoint idx (candidates: their index; originals: -2 - idx; -1: none), cand_state[i] =
+// bit 0 isBad, bit 1 IsInKeyFrame(pKF), bits 8.. = Observations().  Returns nFused of the adaptor; *n_ref the reference's.
+int adx_local_mapping_fuse(const void* kps28, const uint8_t* desc, int n, const float gp[6], const float T16[16], const float K4[4], int nlevels,
+                           float scale, const int32_t* kf_obs, int npts, const float* pos, const float* normal, const float* dmin,
+                           const float* dmax, const uint8_t* mp_desc, const int32_t* cand_obs, const int32_t* order, int norder, float th,
+                           int32_t* kf_point_ref, int32_t* cand_state_ref, int32_t* kf_point_hip, int32_t* cand_state_hip, int* n_ref) {
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    BackScene s;
+    build_kf(s, kps28, desc, n, gp, T16, K4, nlevels, scale, nullptr);
+    const float z3[3] = {0, 0, 1};
+    for (int i = 0; i < n; i++)
+      if (kf_obs[i] > 0) {
+        MapPoint* p = add_point(s, z3, z3, 0.f, 1e9f, nullptr, 0, -2 - i);
+        // real observations: the point is seen by this KeyFrame at i (Replace() walks them), plus anonymous ones for the count
+        p->AddObservation(s.kf, i);
+        s.kf->AddMapPoint(p, i);
+        p->nObs = kf_obs[i];
+      }
+    std::vector<MapPoint*> cand(npts);
+    for (int i = 0; i < npts; i++) cand[i] = add_point(s, pos + 3 * i, normal + 3 * i, dmin[i], dmax[i], mp_desc + (size_t)i * 32, cand_obs[i], i);
+    std::vector<MapPoint*> list(norder);   // the list handed to Fuse: candidates by index, -1 = NULL, repeats allowed
+    for (int k = 0; k < norder; k++) list[k] = order[k] >= 0 ? cand[order[k]] : nullptr;
+    if (side == 0) { ORBmatcherCPU m; res[0] = m.Fuse(s.kf, list, th); }
+    else { ORBmatcher m; res[1] = m.Fuse(s.kf, list, th); }
+    int32_t* kp = side == 0 ? kf_point_ref : kf_point_hip;
+    int32_t* cs = side == 0 ? cand_state_ref : cand_state_hip;
+    for (int i = 0; i < n; i++) { MapPoint* p = s.kf->GetMapPoint(i); kp[i] = p ? (int32_t)(long)p->mnId : -1; }
+    for (int i = 0; i < npts; i++)
+      cs[i] = (cand[i]->isBad() ? 1 : 0) | (cand[i]->IsInKeyFrame(s.kf) ? 2 : 0) | (cand[i]->Observations() << 8);
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
+// ORBmatcher(0.8).Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (LoopClosing.cc:595).  The KeyFrame holds a point at keypoint idx where
+// kf_has[idx].  replace_*[i] = id of the KeyFrame point candidate i is to replace (-2 - idx) or -1; kf_point_*[idx] as in the other
+// Fuse.  Returns nFused of the adaptor; *n_ref the reference's.
+int adx_loop_fuse(const void* kps28, const uint8_t* desc, int n, const float gp[6], const float T16[16], const float K4[4], int nlevels,
+                  float scale, const float S16[16], const uint8_t* kf_has, int npts, const float* pos, const float* normal, const float* dmin,
+                  const float* dmax, const uint8_t* mp_desc, float th, int32_t* replace_ref, int32_t* kf_point_ref, int32_t* replace_hip,
+                  int32_t* kf_point_hip, int* n_ref) {
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    BackScene s;
+    build_kf(s, kps28, desc, n, gp, T16, K4, nlevels, scale, nullptr);
+    const float z3[3] = {0, 0, 1};
+    for (int i = 0; i < n; i++)
+      if (kf_has[i]) { MapPoint* p = add_point(s, z3, z3, 0.f, 1e9f, nullptr, 1, -2 - i); s.kf->AddMapPoint(p, i); }
+    std::vector<MapPoint*> cand(npts), repl(npts, nullptr);
+    for (int i = 0; i < npts; i++) cand[i] = add_point(s, pos + 3 * i, normal + 3 * i, dmin[i], dmax[i], mp_desc + (size_t)i * 32, 1, i);
+    cv::Mat Scw(4, 4, CV_32F);
+    for (int i = 0; i < 16; i++) Scw.at<float>(i / 4, i % 4) = S16[i];
+    if (side == 0) { ORBmatcherCPU m(0.8f); res[0] = m.Fuse(s.kf, Scw, cand, th, repl); }
+    else { ORBmatcher m(0.8f); res[1] = m.Fuse(s.kf, Scw, cand, th, repl); }
+    int32_t* rp = side == 0 ? replace_ref : replace_hip;
+    int32_t* kp = side == 0 ? kf_point_ref : kf_point_hip;
+    for (int i = 0; i < npts; i++) rp[i] = repl[i] ? (int32_t)(long)repl[i]->mnId : -1;
+    for (int i = 0; i < n; i++) { MapPoint* p = s.kf->GetMapPoint(i); kp[i] = p ? (int32_t)(long)p->mnId : -1; }
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
+// ORBmatcher(0.75, true).SearchByBoW(pKF1, pKF2, vpMatches12) (LoopClosing.cc:282) with a real vocabulary (DBoW2 text file) behind
+// KeyFrame::ComputeBoW.  has1 / has2: the feature carries a MapPoint.  out_*[i1] = feature of KeyFrame 2 whose point was paired, -1.
+int adx_loop_search_by_bow(const char* voc_path, const void* kps1, const uint8_t* desc1, const uint8_t* has1, int n1, const void* kps2,
+                           const uint8_t* desc2, const uint8_t* has2, int n2, const float gp[6], int32_t* out_ref, int32_t* out_hip,
+                           int* n_ref) {
+  ORBVocabulary voc;
+  if (!voc.loadFromTextFile(voc_path)) return -1;
+  const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, K4[4] = {500, 500, 320, 240};
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    BackScene a, b;
+    build_kf(a, kps1, desc1, n1, gp, I16, K4, 8, 1.2f, &voc);
+    build_kf(b, kps2, desc2, n2, gp, I16, K4, 8, 1.2f, &voc);
+    a.kf->ComputeBoW(); b.kf->ComputeBoW();
+    const float z3[3] = {0, 0, 1};
+    for (int i = 0; i < n1; i++) if (has1[i]) { MapPoint* p = add_point(a, z3, z3, 0, 1e9f, nullptr, 1, i); a.kf->AddMapPoint(p, i); }
+    for (int i = 0; i < n2; i++) if (has2[i]) { MapPoint* p = add_point(b, z3, z3, 0, 1e9f, nullptr, 1, i); b.kf->AddMapPoint(p, i); }
+    std::vector<MapPoint*> m12;
+    if (side == 0) { ORBmatcherCPU m(0.75f, true); res[0] = m.SearchByBoW(a.kf, b.kf, m12); }
+    else { ORBmatcher m(0.75f, true); res[1] = m.SearchByBoW(a.kf, b.kf, m12); }
+    int32_t* out = side == 0 ? out_ref : out_hip;
+    for (int i = 0; i < n1; i++) out[i] = (i < (int)m12.size() && m12[i]) ? (int32_t)(long)m12[i]->mnId : -1;
+  }
+  *n_ref = res[0];
+  return res[1];
 }
 
 // the static helpers

@@ -184,6 +184,57 @@ inline int LineSearchByProjection(const std::vector<cv::line_descriptor::KeyLine
   return nmatches;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Back-end searches (LoopClosing / LocalMapping).  The pose algebra and the pre-checks of every map point stay with the
+// caller, in the reference's own expressions; a query carries what is left: validity, projection, predicted level, descriptor.
+// ---------------------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (ORBmatcher.cc:574-709): match12[i1] = feature of pKF2 or -1
+inline int SearchByBoWKFKF(const std::vector<cv::KeyPoint>& keysUn1, const cv::Mat& desc1, const std::vector<int32_t>& node1,
+                           const std::vector<uchar>& valid1, const std::vector<cv::KeyPoint>& keysUn2, const cv::Mat& desc2,
+                           const std::vector<int32_t>& node2, const std::vector<uchar>& valid2, float nnratio, bool checkOri,
+                           std::vector<int>& match12, int TH_LOW = 50, int device = 0) {
+  match12.assign(keysUn1.size(), -1);
+  if (keysUn1.empty() || keysUn2.empty()) return 0;
+  cv::Mat d1 = desc1.isContinuous() ? desc1 : desc1.clone(), d2 = desc2.isContinuous() ? desc2 : desc2.clone();
+  int nmatches = 0;
+  check(plh_orb_search_by_bow_kfkf(reinterpret_cast<const plh_keypoint*>(keysUn1.data()), d1.ptr<uchar>(), node1.data(), valid1.data(),
+                                   (int)keysUn1.size(), reinterpret_cast<const plh_keypoint*>(keysUn2.data()), d2.ptr<uchar>(), node2.data(),
+                                   valid2.data(), (int)keysUn2.size(), TH_LOW, nnratio, checkOri ? 1 : 0, match12.data(), &nmatches, device));
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:329-453): occupied[idx] =
+// vpMatched[idx] != NULL (in/out); assigned[idx] = query whose MapPoint goes to vpMatched[idx], or -1
+inline int SearchByProjectionSim3(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& desc, const plh_grid_params& gp,
+                                  const std::vector<float>& scaleFactors, std::vector<uchar>& occupied, const ProjQueries& q, float th,
+                                  std::vector<int>& assigned, int TH_LOW = 50, int device = 0) {
+  assigned.assign(keysUn.size(), -1);
+  if (keysUn.empty() || q.valid.empty()) return 0;
+  cv::Mat d = desc.isContinuous() ? desc : desc.clone(), qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nmatches = 0;
+  check(plh_orb_search_by_projection_sim3(reinterpret_cast<const plh_keypoint*>(keysUn.data()), d.ptr<uchar>(), (int)keysUn.size(), &gp,
+                                          scaleFactors.data(), (int)scaleFactors.size(), occupied.data(), (int)q.valid.size(),
+                                          q.valid.data(), q.pos.data(), q.level.data(), qd.ptr<uchar>(), q.hasObs.data(), th, TH_LOW,
+                                          assigned.data(), &nmatches, device));
+  return nmatches;
+}
+
+// The search inside ORBmatcher::Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:914-1061; invLevelSigma2 = pKF->mvInvLevelSigma2) and
+// Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1063-1197; no chi-square gate: pass an empty invLevelSigma2): bestIdx[query]
+inline int FuseSearch(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& desc, const plh_grid_params& gp,
+                      const std::vector<float>& scaleFactors, const std::vector<float>& invLevelSigma2, const ProjQueries& q, float th,
+                      std::vector<int>& bestIdx, int TH_LOW = 50, int device = 0) {
+  bestIdx.assign(q.valid.size(), -1);
+  if (keysUn.empty() || q.valid.empty()) return 0;
+  cv::Mat d = desc.isContinuous() ? desc : desc.clone(), qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nfound = 0;
+  check(plh_orb_fuse_search(reinterpret_cast<const plh_keypoint*>(keysUn.data()), d.ptr<uchar>(), (int)keysUn.size(), &gp,
+                            scaleFactors.data(), invLevelSigma2.empty() ? NULL : invLevelSigma2.data(), (int)scaleFactors.size(),
+                            (int)q.valid.size(), q.valid.data(), q.pos.data(), q.level.data(), qd.ptr<uchar>(), th, TH_LOW, bestIdx.data(),
+                            &nfound, device));
+  return nfound;
+}
+
 }  // namespace hip
 }  // namespace ORB_SLAM2
 

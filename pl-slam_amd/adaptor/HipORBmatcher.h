@@ -25,6 +25,8 @@
 #include <ORBmatcher.h>   // the reference's include/ORBmatcher.h, found on the include path
 #undef ORBmatcher
 
+#include <cmath>
+#include <set>
 #include <stdexcept>
 
 #include "HipMatchers.h"
@@ -38,6 +40,7 @@ class ORBmatcher : public ORBmatcherCPU {
   // every overload that is not re-declared below stays visible
   using ORBmatcherCPU::SearchByProjection;
   using ORBmatcherCPU::SearchByBoW;
+  using ORBmatcherCPU::Fuse;
 
   static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return hip::DescriptorDistance(a, b); }
 
@@ -134,6 +137,202 @@ class ORBmatcher : public ORBmatcherCPU {
     return n;
   }
 
+  // LoopClosing::ComputeSim3 (LoopClosing.cc:239-375): ORBmatcher(0.75, true).SearchByBoW(mpCurrentKF, pKF, vvpMapPointMatches[i])
+  int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));
+    std::vector<uchar> v1(vpMapPoints1.size()), v2(vpMapPoints2.size());
+    for (size_t i = 0; i < v1.size(); i++) v1[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();   // :612-616
+    for (size_t i = 0; i < v2.size(); i++) v2[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();   // :630-634
+    std::vector<int> m12;
+    const int n = hip::SearchByBoWKFKF(pKF1->mvKeysUn, pKF1->mDescriptors, hip::NodeOfFeature(pKF1->mFeatVec, pKF1->N), v1, pKF2->mvKeysUn,
+                                       pKF2->mDescriptors, hip::NodeOfFeature(pKF2->mFeatVec, pKF2->N), v2, mfNNratio, mbCheckOrientation,
+                                       m12, TH_LOW);
+    for (size_t i = 0; i < m12.size(); i++)
+      if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];
+    return n;
+  }
+
+  // LoopClosing::ComputeSim3 (LoopClosing.cc:360): ORBmatcher(0.75, true).SearchByProjection(mpCurrentKF, mScw, mvpLoopMapPoints,
+  // mvpCurrentMatchedPoints, 10).  The Sim3 decomposition, the projection and every pre-check of the loop (:337-395) are the
+  // reference's own expressions; the window search with its level band, best distance and TH_LOW runs on the GPU.
+  int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th) {
+    RequireMonocularKF(pKF);
+    const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+    const int nq = (int)vpPoints.size();
+    hip::ProjQueries q;
+    q.valid.assign(nq, 0); q.hasObs.assign(nq, 1); q.pos.assign(2 * (size_t)nq, 0.f); q.level.assign(nq, 0); q.aux.assign(nq, 0.f);
+    q.desc = cv::Mat::zeros(nq ? nq : 1, 32, CV_8U);
+    for (int iMP = 0; iMP < nq; iMP++) {
+      MapPoint* pMP = vpPoints[iMP];
+      if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+      cv::Mat p3Dw = pMP->GetWorldPos();
+      cv::Mat p3Dc = Rcw * p3Dw + tcw;
+      if (p3Dc.at<float>(2) < 0.0) continue;
+      const float invz = 1 / p3Dc.at<float>(2);
+      const float x = p3Dc.at<float>(0) * invz;
+      const float y = p3Dc.at<float>(1) * invz;
+      const float u = fx * x + cx;
+      const float v = fy * y + cy;
+      if (!pKF->IsInImage(u, v)) continue;
+      const float maxDistance = pMP->GetMaxDistanceInvariance();
+      const float minDistance = pMP->GetMinDistanceInvariance();
+      cv::Mat PO = p3Dw - Ow;
+      const float dist = cv::norm(PO);
+      if (dist < minDistance || dist > maxDistance) continue;
+      cv::Mat Pn = pMP->GetNormal();
+      if (PO.dot(Pn) < 0.5 * dist) continue;
+      const cv::Mat dMP = pMP->GetDescriptor();
+      if (dMP.empty()) continue;                                   // (:431: no candidate is ever compared)
+      q.valid[iMP] = 1;
+      q.pos[2 * iMP] = u; q.pos[2 * iMP + 1] = v;
+      q.level[iMP] = pMP->PredictScale(dist, pKF);
+      std::memcpy(q.desc.ptr<uchar>(iMP), dMP.ptr<uchar>(0), 32);
+    }
+    std::vector<uchar> occupied(vpMatched.size());
+    for (size_t i = 0; i < vpMatched.size(); i++) occupied[i] = vpMatched[i] != NULL;
+    std::vector<int> assigned;
+    if (pKF->N == 0 || nq == 0) return 0;
+    const int nmatches = hip::SearchByProjectionSim3(pKF->mvKeysUn, pKF->mDescriptors, FrameGrid(), pKF->mvScaleFactors, occupied, q, (float)th,
+                                                     assigned, TH_LOW);
+    for (size_t i = 0; i < assigned.size() && i < vpMatched.size(); i++)
+      if (assigned[i] >= 0) vpMatched[i] = vpPoints[assigned[i]];
+    return nmatches;
+  }
+
+  // LocalMapping::SearchInNeighbors (LocalMapping.cc:1535-1573): ORBmatcher().Fuse(pKFi, vpMapPointMatches).  The search for the
+  // best keypoint of every map point does not depend on what the loop does to the map, so it runs first, for all points, on the
+  // GPU; the loop then runs in the reference's order with the reference's own tests (a point can turn bad, or enter the KeyFrame,
+  // through an earlier iteration's Replace / AddObservation) and its replace / add logic (:1029-1058).
+  int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0) {
+    RequireMonocularKF(pKF);
+    cv::Mat Rcw = pKF->GetRotation();
+    cv::Mat tcw = pKF->GetTranslation();
+    const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+    cv::Mat Ow = pKF->GetCameraCenter();
+    const int nMPs = (int)vpMapPoints.size();
+    hip::ProjQueries q;
+    q.valid.assign(nMPs, 0); q.hasObs.assign(nMPs, 1); q.pos.assign(2 * (size_t)nMPs, 0.f); q.level.assign(nMPs, 0); q.aux.assign(nMPs, 0.f);
+    q.desc = cv::Mat::zeros(nMPs ? nMPs : 1, 32, CV_8U);
+    for (int i = 0; i < nMPs; i++) {
+      MapPoint* pMP = vpMapPoints[i];
+      if (!pMP) continue;
+      cv::Mat p3Dw = pMP->GetWorldPos();
+      cv::Mat p3Dc = Rcw * p3Dw + tcw;
+      if (p3Dc.at<float>(2) < 0.0f) continue;
+      const float invz = 1 / p3Dc.at<float>(2);
+      const float x = p3Dc.at<float>(0) * invz;
+      const float y = p3Dc.at<float>(1) * invz;
+      const float u = fx * x + cx;
+      const float v = fy * y + cy;
+      if (!pKF->IsInImage(u, v)) continue;
+      const float maxDistance = pMP->GetMaxDistanceInvariance();
+      const float minDistance = pMP->GetMinDistanceInvariance();
+      cv::Mat PO = p3Dw - Ow;
+      const float dist3D = cv::norm(PO);
+      if (dist3D < minDistance || dist3D > maxDistance) continue;
+      cv::Mat Pn = pMP->GetNormal();
+      if (PO.dot(Pn) < 0.5 * dist3D) continue;
+      const cv::Mat dMP = pMP->GetDescriptor();
+      if (dMP.empty()) continue;
+      q.valid[i] = 1;
+      q.pos[2 * i] = u; q.pos[2 * i + 1] = v;
+      q.level[i] = pMP->PredictScale(dist3D, pKF);
+      std::memcpy(q.desc.ptr<uchar>(i), dMP.ptr<uchar>(0), 32);
+    }
+    std::vector<int> bestIdx(nMPs, -1);
+    if (pKF->N > 0 && nMPs > 0)
+      hip::FuseSearch(pKF->mvKeysUn, pKF->mDescriptors, FrameGrid(), pKF->mvScaleFactors, pKF->mvInvLevelSigma2, q, th, bestIdx, TH_LOW);
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+      MapPoint* pMP = vpMapPoints[i];
+      if (!pMP) continue;
+      if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;          // (as it stands when the loop gets here)
+      if (!q.valid[i] || bestIdx[i] < 0) continue;
+      MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) {
+          if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+          else pMPinKF->Replace(pMP);
+        }
+      } else {
+        pMP->AddObservation(pKF, bestIdx[i]);
+        pKF->AddMapPoint(pMP, bestIdx[i]);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
+  // LoopClosing::SearchAndFuse (LoopClosing.cc:589-599): ORBmatcher(0.8).Fuse(pKF, cvScw, mvpLoopMapPoints, 4, vpReplacePoints).  As
+  // above: the searches first (no chi-square gate in this overload, :1150-1170), then the loop in the reference's order.
+  int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) {
+    RequireMonocularKF(pKF);
+    const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+    const int nPoints = (int)vpPoints.size();
+    hip::ProjQueries q;
+    q.valid.assign(nPoints, 0); q.hasObs.assign(nPoints, 1); q.pos.assign(2 * (size_t)nPoints, 0.f); q.level.assign(nPoints, 0);
+    q.aux.assign(nPoints, 0.f);
+    q.desc = cv::Mat::zeros(nPoints ? nPoints : 1, 32, CV_8U);
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+      MapPoint* pMP = vpPoints[iMP];
+      if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+      cv::Mat p3Dw = pMP->GetWorldPos();
+      cv::Mat p3Dc = Rcw * p3Dw + tcw;
+      if (p3Dc.at<float>(2) < 0.0f) continue;
+      const float invz = 1.0 / p3Dc.at<float>(2);
+      const float x = p3Dc.at<float>(0) * invz;
+      const float y = p3Dc.at<float>(1) * invz;
+      const float u = fx * x + cx;
+      const float v = fy * y + cy;
+      if (!pKF->IsInImage(u, v)) continue;
+      const float maxDistance = pMP->GetMaxDistanceInvariance();
+      const float minDistance = pMP->GetMinDistanceInvariance();
+      cv::Mat PO = p3Dw - Ow;
+      const float dist3D = cv::norm(PO);
+      if (dist3D < minDistance || dist3D > maxDistance) continue;
+      cv::Mat Pn = pMP->GetNormal();
+      if (PO.dot(Pn) < 0.5 * dist3D) continue;
+      const cv::Mat dMP = pMP->GetDescriptor();
+      if (dMP.empty()) continue;
+      q.valid[iMP] = 1;
+      q.pos[2 * iMP] = u; q.pos[2 * iMP + 1] = v;
+      q.level[iMP] = pMP->PredictScale(dist3D, pKF);
+      std::memcpy(q.desc.ptr<uchar>(iMP), dMP.ptr<uchar>(0), 32);
+    }
+    std::vector<int> bestIdx(nPoints, -1);
+    if (pKF->N > 0 && nPoints > 0)
+      hip::FuseSearch(pKF->mvKeysUn, pKF->mDescriptors, FrameGrid(), pKF->mvScaleFactors, std::vector<float>(), q, th, bestIdx, TH_LOW);
+    int nFused = 0;
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+      if (!q.valid[iMP] || bestIdx[iMP] < 0) continue;
+      MapPoint* pMP = vpPoints[iMP];
+      MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[iMP]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+      } else {
+        pMP->AddObservation(pKF, bestIdx[iMP]);
+        pKF->AddMapPoint(pMP, bestIdx[iMP]);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
   // MonocularInitialization
   int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
                               int windowSize = 10) {
@@ -152,6 +351,10 @@ class ORBmatcher : public ORBmatcherCPU {
   static void RequireMonocular(const Frame& F) {
     for (size_t i = 0; i < F.mvuRight.size(); i++)
       if (F.mvuRight[i] > 0) ThrowStereo();
+  }
+  static void RequireMonocularKF(const KeyFrame* pKF) {
+    for (size_t i = 0; i < pKF->mvuRight.size(); i++)
+      if (pKF->mvuRight[i] >= 0) ThrowStereo();
   }
   static plh_grid_params FrameGrid() {
     return hip::GridParams(Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, Frame::mfGridElementWidthInv,

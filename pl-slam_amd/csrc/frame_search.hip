@@ -1031,6 +1031,77 @@ plh_status plh_orb_search_by_projection_frame(const plh_keypoint* kps_un, const 
                           q_hasobs, th, 0.f, mode, check_ori, assigned, nmatches, device);
 }
 
+// ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:329-453) on one KeyFrame, host
+// buffers: see plh_orb_search_by_projection_sim3_batch_dev.
+plh_status plh_orb_search_by_projection_sim3(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                             const float* scale_factors, int nlevels, uint8_t* occupied, int nq,
+                                             const uint8_t* q_valid, const float* q_uv, const int32_t* q_level, const uint8_t* q_desc,
+                                             const uint8_t* q_hasobs, float th, int th_low, int32_t* assigned, int* nmatches,
+                                             int device) {
+  if (n < 0 || nq < 0 || !nmatches || !gp || !scale_factors || (n > 0 && (!kps_un || !desc || !occupied || !assigned)) ||
+      (nq > 0 && (!q_valid || !q_uv || !q_level || !q_desc || !q_hasobs)))
+    return PLH_ERR_INVALID;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
+  *nmatches = 0;
+  if (n == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  Stage s;
+  plh_keypoint* dk = s.up(kps_un, n); uint8_t* dd = s.up(desc, (size_t)n * 32); uint8_t* docc = s.up(occupied, n);
+  const int32_t ns[2] = {n, nq};
+  int32_t* dn = s.up(ns, 2);
+  uint8_t* qv = s.up(q_valid, nq); float* qx = s.up(q_uv, (size_t)nq * 2); int32_t* ql = s.up(q_level, nq);
+  uint8_t* qd = s.up(q_desc, (size_t)nq * 32); uint8_t* qh = s.up(q_hasobs, nq);
+  int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(n);
+  int32_t* da = s.alloc<int32_t>(n); int32_t* dc = s.alloc<int32_t>(1);
+  STAGE_OK(s);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, nullptr);
+  if (st == PLH_OK)
+    st = plh_orb_search_by_projection_sim3_batch_dev(dk, dd, dn, n, 1, gp, dcs, dci, scale_factors, nlevels, docc, dn + 1, nq, qv, qx, ql, qd,
+                                                     qh, th, th_low, da, dc, nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(assigned, da, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(occupied, docc, (size_t)n, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
+// The search inside ORBmatcher::Fuse(pKF, vpMapPoints, th) / Fuse(pKF, Scw, ...) (ORBmatcher.cc:914-1197) on one KeyFrame, host
+// buffers: see plh_orb_fuse_search_batch_dev.  best_idx[nq] = keypoint the query settles on, or -1.
+plh_status plh_orb_fuse_search(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                               const float* scale_factors, const float* inv_level_sigma2, int nlevels, int nq, const uint8_t* q_valid,
+                               const float* q_uv, const int32_t* q_level, const uint8_t* q_desc, float th, int th_low,
+                               int32_t* best_idx, int* nfound, int device) {
+  if (n < 0 || nq < 0 || !nfound || !gp || !scale_factors || (n > 0 && (!kps_un || !desc)) ||
+      (nq > 0 && (!q_valid || !q_uv || !q_level || !q_desc || !best_idx)))
+    return PLH_ERR_INVALID;
+  for (int i = 0; i < nq; i++) best_idx[i] = -1;
+  *nfound = 0;
+  if (n == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  Stage s;
+  plh_keypoint* dk = s.up(kps_un, n); uint8_t* dd = s.up(desc, (size_t)n * 32);
+  const int32_t ns[2] = {n, nq};
+  int32_t* dn = s.up(ns, 2);
+  uint8_t* qv = s.up(q_valid, nq); float* qx = s.up(q_uv, (size_t)nq * 2); int32_t* ql = s.up(q_level, nq);
+  uint8_t* qd = s.up(q_desc, (size_t)nq * 32);
+  int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(n);
+  int32_t* db = s.alloc<int32_t>(nq); int32_t* dc = s.alloc<int32_t>(1);
+  STAGE_OK(s);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, nullptr);
+  const float noGate[16] = {0};   // inv_level_sigma2 == NULL: no chi-square gate (the Sim3 overload of Fuse): e2 * 0 never exceeds it
+  if (st == PLH_OK)
+    st = plh_orb_fuse_search_batch_dev(dk, dd, dn, n, 1, gp, dcs, dci, scale_factors, inv_level_sigma2 ? inv_level_sigma2 : noGate, nlevels,
+                                       dn + 1, nq, qv, qx, ql, qd, th, th_low, db, dc, nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(best_idx, db, (size_t)nq * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nfound, dc, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
 static plh_status host_proj_lines(int variant, const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
                                   const plh_grid_params* gp, uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_seg,
                                   const float* q_aux, const uint8_t* q_desc, const uint8_t* q_hasobs, float th, float nnratio,

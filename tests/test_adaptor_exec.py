@@ -268,3 +268,149 @@ def test_adaptor_executes_initialization_matchers_emu(plslam, synth, oracle, emu
 @pytest.mark.gpu
 def test_adaptor_executes_initialization_matchers(plslam, synth, oracle):
     _initialization_matchers(plslam, synth, oracle, LIB_HIP, 480, 640, 1000)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Back-end call sites (LoopClosing / LocalMapping) behind the class names: the adaptor overloads against the reference's own
+# methods (ORBmatcherCPU = src/ORBmatcher.cc), both on real KeyFrame / MapPoint objects built from the same arrays, poses with
+# rotation and scale (oracle/ref/ref_adaptor.cc: adx_loop_search_by_projection, adx_local_mapping_fuse, adx_loop_search_by_bow).
+# ------------------------------------------------------------------------------------------------------------------------------
+def _rot(ax, ay, az):
+    cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return (Rz @ Ry @ Rx).astype(np.float32)
+
+
+def _backend_scene(P, seed, n=700, npts=900, sim3_scale=1.0):
+    """A KeyFrame (keypoints over a 640x480 image on 8 levels, descriptors, pose) and candidate map points: most of them sit where
+    a keypoint looks (projection within a pixel or two, descriptor a few bits off, distance range that predicts the keypoint's
+    level), the rest are behind the camera, outside the image, out of range, facing away, or carry a foreign descriptor."""
+    rng = np.random.RandomState(seed)
+    K4 = np.array([517.3, 516.5, 318.6, 255.3], np.float32)
+    gp = np.array([0.0, 0.0, 640.0, 480.0, 64 / 640.0, 48 / 480.0], np.float32)
+    kps = np.zeros(n, P.KP_DTYPE)
+    kps["x"] = rng.uniform(5, 635, n).astype(np.float32)
+    kps["y"] = rng.uniform(5, 475, n).astype(np.float32)
+    kps["octave"] = rng.randint(0, 8, n)
+    kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    kps["size"] = 31.0 * 1.2 ** kps["octave"]
+    kps["response"] = rng.uniform(20, 200, n).astype(np.float32)
+    kps["class_id"] = -1
+    desc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    R = _rot(0.05, -0.12, 0.03)
+    t = np.array([0.3, -0.2, 0.5], np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3], T[:3, 3] = R, t
+    S = np.eye(4, dtype=np.float32)
+    S[:3, :3], S[:3, 3] = sim3_scale * R, sim3_scale * t      # the function divides both by the scale again
+    Ow = -(R.T @ t)
+    pos, normal = np.zeros((npts, 3), np.float32), np.zeros((npts, 3), np.float32)
+    dmin, dmax = np.zeros(npts, np.float32), np.zeros(npts, np.float32)
+    mdesc = np.zeros((npts, 32), np.uint8)
+    for i in range(npts):
+        k = rng.randint(0, n)
+        z = rng.uniform(2.0, 12.0)
+        u, v = kps["x"][k] + rng.uniform(-2.5, 2.5), kps["y"][k] + rng.uniform(-2.5, 2.5)
+        Xc = np.array([(u - K4[2]) / K4[0] * z, (v - K4[3]) / K4[1] * z, z])
+        kind = rng.randint(0, 12)
+        if kind == 0: Xc[2] = -Xc[2]                              # behind the camera
+        if kind == 1: Xc[0] += 3 * z                              # outside the image
+        Xw = R.T.astype(np.float64) @ (Xc - t)
+        PO = Xw - Ow
+        d = np.linalg.norm(PO)
+        pos[i] = Xw
+        normal[i] = (PO / d if kind != 2 else -PO / d)            # 2: seen from behind
+        lvl = int(kps["octave"][k])
+        dmax[i] = d * 1.2 ** (lvl - 0.5) if kind != 3 else d * 0.5   # 3: beyond the invariance region
+        dmin[i] = dmax[i] / 1.2 ** 8 * 0.8
+        dd = desc[k].copy()
+        flips = rng.randint(0, 256, rng.randint(0, 40 if kind != 4 else 160))   # 4: a descriptor too far off
+        for b in flips:
+            dd[b >> 3] ^= 1 << (b & 7)
+        mdesc[i] = dd
+    return dict(K4=K4, gp=gp, kps=kps, desc=desc, T=T, S=S, pos=pos, normal=normal, dmin=dmin, dmax=dmax, mdesc=mdesc, rng=rng)
+
+
+def _backend_calls(P, S, path, tmp_path):
+    G, R = _lib(path)
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(V)
+    n_ref = C.c_int(0)
+    # ---- LoopClosing: SearchByProjection(pKF, Scw, vpPoints, vpMatched, th)
+    for seed, scale, th in ((11, 1.0, 10), (12, 1.7, 10), (13, 0.6, 4)):
+        sc = _backend_scene(P, seed, sim3_scale=scale)
+        n, npts = len(sc["kps"]), len(sc["pos"])
+        matched0 = (sc["rng"].uniform(size=n) < 0.15).astype(np.uint8)
+        o_ref, o_hip = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        R.adx_loop_search_by_projection.argtypes = [V, V, I, V, V, V, I, F, V, V, I, V, V, V, V, V, I, V, V, V]
+        nm = R.adx_loop_search_by_projection(p(sc["kps"]), p(sc["desc"]), n, p(sc["gp"]), p(sc["T"]), p(sc["K4"]), 8, 1.2, p(sc["S"]),
+                                             p(matched0), npts, p(sc["pos"]), p(sc["normal"]), p(sc["dmin"]), p(sc["dmax"]), p(sc["mdesc"]),
+                                             th, p(o_ref), p(o_hip), C.byref(n_ref))
+        assert nm == n_ref.value and nm > 100, (seed, nm, n_ref.value)
+        assert (o_ref == o_hip).all(), "SearchByProjection(KF, Scw) seed %d: vpMatched differs from the reference's" % seed
+    # ---- LocalMapping: Fuse(pKF, vpMapPoints, th)
+    for seed, th in ((21, 3.0), (22, 3.0), (23, 6.0)):
+        sc = _backend_scene(P, seed)
+        n, npts = len(sc["kps"]), len(sc["pos"])
+        rng = sc["rng"]
+        kf_obs = np.where(rng.uniform(size=n) < 0.4, rng.randint(1, 9, n), 0).astype(np.int32)
+        cand_obs = rng.randint(0, 9, npts).astype(np.int32)
+        order = np.concatenate([rng.permutation(npts), rng.randint(0, npts, 60), -np.ones(15)]).astype(np.int32)   # repeats and NULLs
+        rng.shuffle(order)
+        outs = [np.zeros(n, np.int32), np.zeros(npts, np.int32), np.zeros(n, np.int32), np.zeros(npts, np.int32)]
+        R.adx_local_mapping_fuse.argtypes = [V, V, I, V, V, V, I, F, V, I, V, V, V, V, V, V, V, I, F, V, V, V, V, V]
+        nf = R.adx_local_mapping_fuse(p(sc["kps"]), p(sc["desc"]), n, p(sc["gp"]), p(sc["T"]), p(sc["K4"]), 8, 1.2, p(kf_obs), npts,
+                                      p(sc["pos"]), p(sc["normal"]), p(sc["dmin"]), p(sc["dmax"]), p(sc["mdesc"]), p(cand_obs), p(order),
+                                      len(order), th, p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), C.byref(n_ref))
+        assert nf == n_ref.value and nf > 100, (seed, nf, n_ref.value)
+        assert (outs[0] == outs[2]).all(), "Fuse seed %d: the KeyFrame's map points differ from the reference's" % seed
+        assert (outs[1] == outs[3]).all(), "Fuse seed %d: isBad / IsInKeyFrame / Observations of the candidates differ" % seed
+        assert (outs[1] & 1).sum() > 10 and (outs[0] >= 0).sum() > (kf_obs > 0).sum()     # points were replaced and added
+    # ---- LoopClosing: Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
+    for seed, scale, th in ((41, 1.0, 4.0), (42, 1.4, 4.0), (43, 0.8, 8.0)):
+        sc = _backend_scene(P, seed, sim3_scale=scale)
+        n, npts = len(sc["kps"]), len(sc["pos"])
+        kf_has = (sc["rng"].uniform(size=n) < 0.5).astype(np.uint8)
+        outs = [np.zeros(npts, np.int32), np.zeros(n, np.int32), np.zeros(npts, np.int32), np.zeros(n, np.int32)]
+        R.adx_loop_fuse.argtypes = [V, V, I, V, V, V, I, F, V, V, I, V, V, V, V, V, F, V, V, V, V, V]
+        nf = R.adx_loop_fuse(p(sc["kps"]), p(sc["desc"]), n, p(sc["gp"]), p(sc["T"]), p(sc["K4"]), 8, 1.2, p(sc["S"]), p(kf_has), npts,
+                             p(sc["pos"]), p(sc["normal"]), p(sc["dmin"]), p(sc["dmax"]), p(sc["mdesc"]), th, p(outs[0]), p(outs[1]), p(outs[2]),
+                             p(outs[3]), C.byref(n_ref))
+        assert nf == n_ref.value and nf > 100, (seed, nf, n_ref.value)
+        assert (outs[0] == outs[2]).all(), "Fuse(Scw) seed %d: vpReplacePoint differs from the reference's" % seed
+        assert (outs[1] == outs[3]).all(), "Fuse(Scw) seed %d: the KeyFrame's map points differ from the reference's" % seed
+        assert (outs[0] != -1).sum() > 20 and (outs[1] >= 0).sum() > 20      # replacements proposed and points added
+    # ---- LoopClosing: SearchByBoW(pKF1, pKF2, vpMatches12)
+    VM = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    voc = VM.Vocabulary.synthetic(41, k=10, L=4, synth=S)
+    vpath = str(tmp_path / "voc.txt")
+    voc.save_text(vpath)
+    for seed in (31, 32):
+        a, b, _ = S.make_descriptor_sets(seed, 800, flip_p=0.06)
+        rng = np.random.RandomState(seed)
+        def kps_of(m):
+            k = np.zeros(m, P.KP_DTYPE)
+            k["x"], k["y"] = rng.uniform(5, 635, m).astype(np.float32), rng.uniform(5, 475, m).astype(np.float32)
+            k["octave"], k["angle"], k["class_id"] = rng.randint(0, 8, m), rng.uniform(0, 360, m).astype(np.float32), -1
+            return k
+        k1, k2 = kps_of(len(a)), kps_of(len(b))
+        k2["angle"] = (k1["angle"][np.argsort(np.argsort(rng.uniform(size=len(b))))] + 10).astype(np.float32) % 360
+        h1, h2 = (rng.uniform(size=len(a)) < 0.8).astype(np.uint8), (rng.uniform(size=len(b)) < 0.8).astype(np.uint8)
+        o_ref, o_hip = np.zeros(len(a), np.int32), np.zeros(len(a), np.int32)
+        gp = np.array([0.0, 0.0, 640.0, 480.0, 0.1, 0.1], np.float32)
+        R.adx_loop_search_by_bow.argtypes = [C.c_char_p, V, V, V, I, V, V, V, I, V, V, V, V]
+        nm = R.adx_loop_search_by_bow(vpath.encode(), p(k1), p(a), p(h1), len(a), p(k2), p(b), p(h2), len(b), p(gp), p(o_ref), p(o_hip),
+                                      C.byref(n_ref))
+        assert nm == n_ref.value and nm >= 0, (seed, nm, n_ref.value)
+        assert (o_ref == o_hip).all(), "SearchByBoW(KF, KF) seed %d differs from the reference's" % seed
+        assert (o_ref >= 0).sum() > 50
+
+
+def test_adaptor_executes_backend_searches_emu(plslam, synth, emu_lib, tmp_path):
+    _backend_calls(plslam, synth, LIB_EMU, tmp_path)
+
+
+@pytest.mark.gpu
+def test_adaptor_executes_backend_searches(plslam, synth, tmp_path):
+    _backend_calls(plslam, synth, LIB_HIP, tmp_path)
