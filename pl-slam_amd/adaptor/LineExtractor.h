@@ -27,7 +27,7 @@ class LINEextractor {
   typedef cv::line_descriptor::KeyLine KeyLine;
 
   LINEextractor(int _numOctaves, float _scale, unsigned int _nLSDFeature, double _min_line_length, int device = 0)
-      : mDevice(device), mHandle(nullptr), mRows(0), mCols(0), mHasUndist(false) {
+      : mDevice(device), mHandle(nullptr), mRows(0), mCols(0), mHasUndist(false), mRefine(PLH_LSD_REFINE_STD), mGrowWaves(-1) {
     static_assert(sizeof(KeyLine) == sizeof(plh_keyline), "KeyLine must be the 68-byte POD plh_keyline mirrors");
     mParams.num_octaves = _numOctaves;
     mParams.scale = _scale;
@@ -55,6 +55,19 @@ class LINEextractor {
     for (int i = 0; i < 5; i++) mD[i] = D[i];
     mHasUndist = true;
     if (mHandle) check(plh_line_set_undistort(mHandle, mK, mD));
+  }
+
+  // The refine level of the cv::LineSegmentDetector behind LSDDetector::detect: PLH_LSD_REFINE_STD (default; what the twin in the
+  // reference's tree creates, LSDDetector_custom.cpp:149) or PLH_LSD_REFINE_ADV (what upstream opencv_contrib 3.x passes) -- pick
+  // the one the OpenCV build behind src/LineExtractor.cpp:39 uses.
+  void SetRefine(int level) {
+    mRefine = level;
+    if (mHandle) check(plh_line_set_refine(mHandle, mRefine));
+  }
+  // Wavefronts per frame of LSD's region growing: -1 automatic, 0 one, 2..16 that many (same segments either way)
+  void SetGrowWaves(int waves) {
+    mGrowWaves = waves;
+    if (mHandle) check(plh_line_set_grow_waves(mHandle, mGrowWaves));
   }
 
   void operator()(cv::InputArray _image, cv::InputArray _mask, std::vector<KeyLine>& _keylines, cv::OutputArray _descriptors,
@@ -98,6 +111,8 @@ class LINEextractor {
     mHandle = nullptr;
     check(plh_line_create(&mParams, mDevice, rows, cols, 1, &mHandle));
     if (mHasUndist) check(plh_line_set_undistort(mHandle, mK, mD));
+    check(plh_line_set_refine(mHandle, mRefine));
+    check(plh_line_set_grow_waves(mHandle, mGrowWaves));
     mRows = rows;
     mCols = cols;
   }
@@ -110,6 +125,7 @@ class LINEextractor {
   plh_line* mHandle;
   int mRows, mCols;
   bool mHasUndist;
+  int mRefine, mGrowWaves;
   float mK[4], mD[5];
   std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
