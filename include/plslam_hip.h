@@ -467,6 +467,11 @@ PLH_API plh_status plh_orb_search_by_bow_kfkf(const plh_keypoint* kps1, const ui
                                               const uint8_t* valid1, int n1, const plh_keypoint* kps2, const uint8_t* desc2,
                                               const int32_t* node2, const uint8_t* valid2, int n2, int th_low, float nnratio,
                                               int check_ori, int32_t* matches12, int* nmatches, int device);
+PLH_API plh_status plh_orb_search_by_projection_kf(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                                   const float* scale_factors, int nlevels, uint8_t* occupied, int nq,
+                                                   const uint8_t* q_valid, const float* q_uv, const int32_t* q_level,
+                                                   const float* q_angle, const uint8_t* q_desc, float th, int orb_dist,
+                                                   int check_ori, int32_t* assigned, int* nmatches, int device);
 PLH_API plh_status plh_orb_search_by_projection_sim3(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
                                                      const float* scale_factors, int nlevels, uint8_t* occupied, int nq,
                                                      const uint8_t* q_valid, const float* q_uv, const int32_t* q_level,

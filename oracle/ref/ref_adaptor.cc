@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <set>
 #include <vector>
 
 #define private public
@@ -250,6 +251,43 @@ int adx_local_mapping_fuse(const void* kps28, const uint8_t* desc, int n, const 
     for (int i = 0; i < n; i++) { MapPoint* p = s.kf->GetMapPoint(i); kp[i] = p ? (int32_t)(long)p->mnId : -1; }
     for (int i = 0; i < npts; i++)
       cs[i] = (cand[i]->isBad() ? 1 : 0) | (cand[i]->IsInKeyFrame(s.kf) ? 2 : 0) | (cand[i]->Observations() << 8);
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
+// Tracking::Relocalization's ORBmatcher(0.9, true).SearchByProjection(CurrentFrame, pKF, sFound, th, ORBdist).  The current frame =
+// kps / desc with pose Tc; the KeyFrame (identity pose) carries candidate point i at its keypoint i (n_kf of them: pos, ranges,
+// descriptor, kf_angle = its mvKeysUn[i].angle); found[i]: the point is in sAlreadyFound; cur_has[i2]: the frame already holds a point.
+// out_*[i2] = KeyFrame point now at frame keypoint i2 (-1 none, -2 the one that was there).
+int adx_relocalization_search(const void* kps28, const uint8_t* desc, int n, const float gp[6], const float Tc16[16], const float K4[4],
+                              int nlevels, float scale, const uint8_t* cur_has, int n_kf, const float* kf_angle, const float* pos,
+                              const float* dmin, const float* dmax, const uint8_t* mp_desc, const uint8_t* found, float th, int orb_dist,
+                              int32_t* out_ref, int32_t* out_hip, int* n_ref) {
+  int res[2] = {0, 0};
+  const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int side = 0; side < 2; side++) {
+    BackScene kfs, cur;
+    std::vector<cv::KeyPoint> kk(n_kf);
+    for (int i = 0; i < n_kf; i++) kk[i] = cv::KeyPoint(10.f + i % 600, 10.f + i % 400, 31.f, kf_angle[i], 50.f, 0, -1);
+    std::vector<uint8_t> kd((size_t)std::max(n_kf, 1) * 32, 0);
+    build_kf(kfs, kk.data(), kd.data(), n_kf, gp, I16, K4, nlevels, scale, nullptr);
+    build_kf(cur, kps28, desc, n, gp, Tc16, K4, nlevels, scale, nullptr);   // (its KeyFrame is not used: the Frame is)
+    Frame& F = cur.f;
+    const float z3[3] = {0, 0, 1};
+    for (int i = 0; i < n; i++)
+      if (cur_has[i]) F.mvpMapPoints[i] = add_point(cur, z3, z3, 0.f, 1e9f, nullptr, 1, -2);
+    std::set<MapPoint*> sFound;
+    for (int i = 0; i < n_kf; i++) {
+      MapPoint* p = add_point(kfs, pos + 3 * i, z3, dmin[i], dmax[i], mp_desc + (size_t)i * 32, 1, i);
+      kfs.kf->AddMapPoint(p, i);
+      if (found[i]) sFound.insert(p);
+    }
+    if (side == 0) { ORBmatcherCPU m(0.9f, true); res[0] = m.SearchByProjection(F, kfs.kf, sFound, th, orb_dist); }
+    else { ORBmatcher m(0.9f, true); res[1] = m.SearchByProjection(F, kfs.kf, sFound, th, orb_dist); }
+    int32_t* out = side == 0 ? out_ref : out_hip;
+    for (int i = 0; i < n; i++) out[i] = F.mvpMapPoints[i] ? (int32_t)(long)F.mvpMapPoints[i]->mnId : -1;
+    F.mvpMapPoints.assign(n, nullptr);
   }
   *n_ref = res[0];
   return res[1];

@@ -219,6 +219,22 @@ inline int SearchByProjectionSim3(const std::vector<cv::KeyPoint>& keysUn, const
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1587-1716): q.aux =
+// pKF->mvKeysUn[i].angle, occupied[i2] = CurrentFrame.mvpMapPoints[i2] != NULL (in/out)
+inline int SearchByProjectionKeyFrame(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& desc, const plh_grid_params& gp,
+                                      const std::vector<float>& scaleFactors, std::vector<uchar>& occupied, const ProjQueries& q, float th,
+                                      int ORBdist, bool checkOri, std::vector<int>& assigned, int device = 0) {
+  assigned.assign(keysUn.size(), -1);
+  if (keysUn.empty() || q.valid.empty()) return 0;
+  cv::Mat d = desc.isContinuous() ? desc : desc.clone(), qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nmatches = 0;
+  check(plh_orb_search_by_projection_kf(reinterpret_cast<const plh_keypoint*>(keysUn.data()), d.ptr<uchar>(), (int)keysUn.size(), &gp,
+                                        scaleFactors.data(), (int)scaleFactors.size(), occupied.data(), (int)q.valid.size(), q.valid.data(),
+                                        q.pos.data(), q.level.data(), q.aux.data(), qd.ptr<uchar>(), th, ORBdist, checkOri ? 1 : 0,
+                                        assigned.data(), &nmatches, device));
+  return nmatches;
+}
+
 // The search inside ORBmatcher::Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:914-1061; invLevelSigma2 = pKF->mvInvLevelSigma2) and
 // Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1063-1197; no chi-square gate: pass an empty invLevelSigma2): bestIdx[query]
 inline int FuseSearch(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& desc, const plh_grid_params& gp,

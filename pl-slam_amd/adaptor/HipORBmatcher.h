@@ -137,6 +137,57 @@ class ORBmatcher : public ORBmatcherCPU {
     return n;
   }
 
+  // Tracking::Relocalization (Tracking.cc: matcher2.SearchByProjection(mCurrentFrame, vpCandidateKFs[i], sFound, 10, 100) and the
+  // narrower second pass): the KeyFrame's map points projected with the current pose, in the reference's own expressions
+  // (:1591-1640); window lookup with the level band, best distance against ORBdist and the rotation histogram on the GPU.
+  int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) {
+    RequireMonocular(CurrentFrame);
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat Ow = -Rcw.t() * tcw;
+    const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+    const int nq = (int)vpMPs.size();
+    hip::ProjQueries q;
+    q.valid.assign(nq, 0); q.hasObs.assign(nq, 1); q.pos.assign(2 * (size_t)nq, 0.f); q.level.assign(nq, 0); q.aux.assign(nq, 0.f);
+    q.desc = cv::Mat::zeros(nq ? nq : 1, 32, CV_8U);
+    for (int i = 0; i < nq; i++) {
+      MapPoint* pMP = vpMPs[i];
+      if (!pMP) continue;
+      if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+      cv::Mat x3Dw = pMP->GetWorldPos();
+      cv::Mat x3Dc = Rcw * x3Dw + tcw;
+      const float xc = x3Dc.at<float>(0);
+      const float yc = x3Dc.at<float>(1);
+      const float invzc = 1.0 / x3Dc.at<float>(2);
+      const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+      const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+      if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+      if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+      cv::Mat PO = x3Dw - Ow;
+      float dist3D = cv::norm(PO);
+      const float maxDistance = pMP->GetMaxDistanceInvariance();
+      const float minDistance = pMP->GetMinDistanceInvariance();
+      if (dist3D < minDistance || dist3D > maxDistance) continue;
+      const cv::Mat dMP = pMP->GetDescriptor();
+      if (dMP.empty()) continue;
+      q.valid[i] = 1;
+      q.pos[2 * i] = u; q.pos[2 * i + 1] = v;
+      q.level[i] = pMP->PredictScale(dist3D, &CurrentFrame);
+      q.aux[i] = pKF->mvKeysUn[i].angle;
+      std::memcpy(q.desc.ptr<uchar>(i), dMP.ptr<uchar>(0), 32);
+    }
+    std::vector<uchar> occupied(CurrentFrame.N);
+    for (int i = 0; i < CurrentFrame.N; i++) occupied[i] = CurrentFrame.mvpMapPoints[i] != NULL;
+    std::vector<int> assigned;
+    if (CurrentFrame.N == 0 || nq == 0) return 0;
+    const int nmatches = hip::SearchByProjectionKeyFrame(CurrentFrame.mvKeysUn, CurrentFrame.mDescriptors, FrameGrid(),
+                                                         CurrentFrame.mvScaleFactors, occupied, q, th, ORBdist, mbCheckOrientation, assigned);
+    // `assigned` is the net effect of the assignments (:1671) and of the rotation-consistency pass that resets some of them (:1704)
+    for (int i = 0; i < CurrentFrame.N; i++)
+      if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[assigned[i]];
+    return nmatches;
+  }
+
   // LoopClosing::ComputeSim3 (LoopClosing.cc:239-375): ORBmatcher(0.75, true).SearchByBoW(mpCurrentKF, pKF, vvpMapPointMatches[i])
   int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
     const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();

@@ -1031,6 +1031,42 @@ plh_status plh_orb_search_by_projection_frame(const plh_keypoint* kps_un, const 
                           q_hasobs, th, 0.f, mode, check_ori, assigned, nmatches, device);
 }
 
+// ORBmatcher::SearchByProjection(Frame& Cur, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1587-1716, Tracking::Relocalization)
+// on one frame, host buffers: see plh_orb_search_by_projection_kf_batch_dev.
+plh_status plh_orb_search_by_projection_kf(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
+                                           const float* scale_factors, int nlevels, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                           const float* q_uv, const int32_t* q_level, const float* q_angle, const uint8_t* q_desc,
+                                           float th, int orb_dist, int check_ori, int32_t* assigned, int* nmatches, int device) {
+  if (n < 0 || nq < 0 || !nmatches || !gp || !scale_factors || (n > 0 && (!kps_un || !desc || !occupied || !assigned)) ||
+      (nq > 0 && (!q_valid || !q_uv || !q_level || !q_angle || !q_desc)))
+    return PLH_ERR_INVALID;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
+  *nmatches = 0;
+  if (n == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  Stage s;
+  plh_keypoint* dk = s.up(kps_un, n); uint8_t* dd = s.up(desc, (size_t)n * 32); uint8_t* docc = s.up(occupied, n);
+  const int32_t ns[2] = {n, nq};
+  int32_t* dn = s.up(ns, 2);
+  std::vector<uint8_t> ones((size_t)nq, 1);
+  uint8_t* qv = s.up(q_valid, nq); float* qx = s.up(q_uv, (size_t)nq * 2); int32_t* ql = s.up(q_level, nq);
+  float* qa = s.up(q_angle, nq); uint8_t* qd = s.up(q_desc, (size_t)nq * 32); uint8_t* qh = s.up(ones.data(), nq);
+  int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(n);
+  int32_t* da = s.alloc<int32_t>(n); int32_t* dc = s.alloc<int32_t>(1);
+  STAGE_OK(s);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, nullptr);
+  if (st == PLH_OK)
+    st = plh_orb_search_by_projection_kf_batch_dev(dk, dd, dn, n, 1, gp, dcs, dci, scale_factors, nlevels, docc, dn + 1, nq, qv, qx, ql, qa,
+                                                   qd, qh, th, orb_dist, check_ori, da, dc, nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(assigned, da, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(occupied, docc, (size_t)n, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
 // ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:329-453) on one KeyFrame, host
 // buffers: see plh_orb_search_by_projection_sim3_batch_dev.
 plh_status plh_orb_search_by_projection_sim3(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,

@@ -367,6 +367,21 @@ def _backend_calls(P, S, path, tmp_path):
         assert (outs[0] == outs[2]).all(), "Fuse seed %d: the KeyFrame's map points differ from the reference's" % seed
         assert (outs[1] == outs[3]).all(), "Fuse seed %d: isBad / IsInKeyFrame / Observations of the candidates differ" % seed
         assert (outs[1] & 1).sum() > 10 and (outs[0] >= 0).sum() > (kf_obs > 0).sum()     # points were replaced and added
+    # ---- Tracking::Relocalization: SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
+    for seed, th, odist in ((51, 10.0, 100), (52, 3.0, 64)):
+        sc = _backend_scene(P, seed)
+        n, npts = len(sc["kps"]), len(sc["pos"])
+        rng = sc["rng"]
+        cur_has = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+        found = (rng.uniform(size=npts) < 0.1).astype(np.uint8)
+        kf_angle = rng.uniform(0, 360, npts).astype(np.float32)
+        o_ref, o_hip = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        R.adx_relocalization_search.argtypes = [V, V, I, V, V, V, I, F, V, I, V, V, V, V, V, V, F, I, V, V, V]
+        nm = R.adx_relocalization_search(p(sc["kps"]), p(sc["desc"]), n, p(sc["gp"]), p(sc["T"]), p(sc["K4"]), 8, 1.2, p(cur_has), npts,
+                                         p(kf_angle), p(sc["pos"]), p(sc["dmin"]), p(sc["dmax"]), p(sc["mdesc"]), p(found), th, odist,
+                                         p(o_ref), p(o_hip), C.byref(n_ref))
+        assert nm == n_ref.value and nm > 30, (seed, nm, n_ref.value)
+        assert (o_ref == o_hip).all(), "relocalisation SearchByProjection seed %d: mvpMapPoints differ from the reference's" % seed
     # ---- LoopClosing: Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
     for seed, scale, th in ((41, 1.0, 4.0), (42, 1.4, 4.0), (43, 0.8, 8.0)):
         sc = _backend_scene(P, seed, sim3_scale=scale)
