@@ -467,6 +467,18 @@ PLH_API plh_status plh_orb_search_by_bow_kfkf(const plh_keypoint* kps1, const ui
                                               const uint8_t* valid1, int n1, const plh_keypoint* kps2, const uint8_t* desc2,
                                               const int32_t* node2, const uint8_t* valid2, int n2, int th_low, float nnratio,
                                               int check_ori, int32_t* matches12, int* nmatches, int device);
+PLH_API plh_status plh_orb_search_for_triangulation(const plh_keypoint* kps1, const uint8_t* desc1, const int32_t* node1,
+                                                    const uint8_t* has_mp1, int n1, const plh_keypoint* kps2, const uint8_t* desc2,
+                                                    const int32_t* node2, const uint8_t* has_mp2, int n2, const float F12[9],
+                                                    float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                                    int nlevels, int th_low, int check_ori, int32_t* matches12, int* nmatches,
+                                                    int device);
+PLH_API plh_status plh_orb_search_by_sim3(const plh_keypoint* kps1_un, const uint8_t* desc1, int n1, const plh_keypoint* kps2_un,
+                                          const uint8_t* desc2, int n2, const plh_grid_params* gp, const float* scale_factors,
+                                          int nlevels, const uint8_t* q12_valid, const float* q12_uv, const int32_t* q12_level,
+                                          const uint8_t* q12_desc, const uint8_t* q21_valid, const float* q21_uv,
+                                          const int32_t* q21_level, const uint8_t* q21_desc, float th, int th_high, int32_t* match12,
+                                          int* nfound, int device);
 PLH_API plh_status plh_orb_search_by_projection_kf(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
                                                    const float* scale_factors, int nlevels, uint8_t* occupied, int nq,
                                                    const uint8_t* q_valid, const float* q_uv, const int32_t* q_level,

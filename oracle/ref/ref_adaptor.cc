@@ -349,6 +349,83 @@ int adx_loop_search_by_bow(const char* voc_path, const void* kps1, const uint8_t
   return res[1];
 }
 
+// LoopClosing::ComputeSim3's ORBmatcher(0.75, true).SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (LoopClosing.cc:327).
+// KeyFrame k holds n_k keypoints at pose T_k; slot i carries a map point where has_k[i] (world position, invariance range,
+// descriptor).  pre12[i1] >= 0: vpMatches12[i1] enters as KeyFrame 2's point of that slot.  out_*[i1] = slot of the KeyFrame-2 point
+// in vpMatches12[i1] afterwards, -1 none.
+int adx_loop_search_by_sim3(const void* kps1, const uint8_t* desc1, int n1, const float T1[16], const uint8_t* has1, const float* pos1,
+                            const float* dmin1, const float* dmax1, const uint8_t* mdesc1, const void* kps2, const uint8_t* desc2, int n2,
+                            const float T2[16], const uint8_t* has2, const float* pos2, const float* dmin2, const float* dmax2,
+                            const uint8_t* mdesc2, const float gp[6], const float K4[4], float s12, const float R12[9], const float t12[3],
+                            const int32_t* pre12, float th, int32_t* out_ref, int32_t* out_hip, int* n_ref) {
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    BackScene a, b;
+    build_kf(a, kps1, desc1, n1, gp, T1, K4, 8, 1.2f, nullptr);
+    build_kf(b, kps2, desc2, n2, gp, T2, K4, 8, 1.2f, nullptr);
+    const float z3[3] = {0, 0, 1};
+    std::vector<MapPoint*> p2(n2, nullptr);
+    for (int i = 0; i < n1; i++)
+      if (has1[i]) { MapPoint* p = add_point(a, pos1 + 3 * i, z3, dmin1[i], dmax1[i], mdesc1 + (size_t)i * 32, 1, i); a.kf->AddMapPoint(p, i); }
+    for (int i = 0; i < n2; i++)
+      if (has2[i]) {
+        MapPoint* p = add_point(b, pos2 + 3 * i, z3, dmin2[i], dmax2[i], mdesc2 + (size_t)i * 32, 0, i);
+        b.kf->AddMapPoint(p, i);
+        p->AddObservation(b.kf, i);   // GetIndexInKeyFrame(pKF2) answers from the observations (:1233)
+        p2[i] = p;
+      }
+    std::vector<MapPoint*> m12(n1, nullptr);
+    for (int i = 0; i < n1; i++)
+      if (pre12[i] >= 0 && pre12[i] < n2) m12[i] = p2[pre12[i]];
+    cv::Mat R(3, 3, CV_32F), t(3, 1, CV_32F);
+    std::memcpy(R.data, R12, 36);
+    std::memcpy(t.data, t12, 12);
+    if (side == 0) { ORBmatcherCPU m(0.75f, true); res[0] = m.SearchBySim3(a.kf, b.kf, m12, s12, R, t, th); }
+    else { ORBmatcher m(0.75f, true); res[1] = m.SearchBySim3(a.kf, b.kf, m12, s12, R, t, th); }
+    int32_t* out = side == 0 ? out_ref : out_hip;
+    for (int i = 0; i < n1; i++) out[i] = m12[i] ? (int32_t)(long)m12[i]->mnId : -1;
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
+// LocalMapping::CreateNewMapPoints' ORBmatcher(0.6, false).SearchForTriangulation(pKF1, pKF2, F12, vMatchedIndices, false)
+// (LocalMapping.cc:385) with a real vocabulary behind KeyFrame::ComputeBoW and the two poses T1 / T2 (the epipole comes from them).
+// out_*[i1] = feature of KeyFrame 2 paired with feature i1, -1 none.
+int adx_local_mapping_triangulation(const char* voc_path, const void* kps1, const uint8_t* desc1, const uint8_t* has1, int n1,
+                                    const void* kps2, const uint8_t* desc2, const uint8_t* has2, int n2, const float gp[6],
+                                    const float T1[16], const float T2[16], const float K4[4], const float F12[9], int check_ori,
+                                    int32_t* out_ref, int32_t* out_hip, int* n_ref) {
+  ORBVocabulary voc;
+  if (!voc.loadFromTextFile(voc_path)) return -1;
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    BackScene a, b;
+    build_kf(a, kps1, desc1, n1, gp, T1, K4, 8, 1.2f, &voc);
+    build_kf(b, kps2, desc2, n2, gp, T2, K4, 8, 1.2f, &voc);
+    a.kf->ComputeBoW(); b.kf->ComputeBoW();
+    const float z3[3] = {0, 0, 1};
+    for (int i = 0; i < n1; i++) if (has1[i]) { MapPoint* p = add_point(a, z3, z3, 0, 1e9f, nullptr, 1, i); a.kf->AddMapPoint(p, i); }
+    for (int i = 0; i < n2; i++) if (has2[i]) { MapPoint* p = add_point(b, z3, z3, 0, 1e9f, nullptr, 1, i); b.kf->AddMapPoint(p, i); }
+    cv::Mat F(3, 3, CV_32F);
+    std::memcpy(F.data, F12, 36);
+    std::vector<std::pair<size_t, size_t> > pairs;
+    if (side == 0) { ORBmatcherCPU m(0.6f, check_ori != 0); res[0] = m.SearchForTriangulation(a.kf, b.kf, F, pairs, false); }
+    else { ORBmatcher m(0.6f, check_ori != 0); res[1] = m.SearchForTriangulation(a.kf, b.kf, F, pairs, false); }
+    int32_t* out = side == 0 ? out_ref : out_hip;
+    for (int i = 0; i < n1; i++) out[i] = -1;
+    size_t last = 0;
+    for (size_t k = 0; k < pairs.size(); k++) {
+      if (k && pairs[k].first <= last) return -2;   // vMatchedPairs is in index order
+      last = pairs[k].first;
+      out[pairs[k].first] = (int32_t)pairs[k].second;
+    }
+    if ((int)pairs.size() != res[side]) return -3;
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
 // the static helpers
 int adx_descriptor_distance(const uint8_t* a, const uint8_t* b) {
   cv::Mat ma(1, 32, CV_8U), mb(1, 32, CV_8U);

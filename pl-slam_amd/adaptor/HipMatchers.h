@@ -203,6 +203,45 @@ inline int SearchByBoWKFKF(const std::vector<cv::KeyPoint>& keysUn1, const cv::M
   return nmatches;
 }
 
+// ORBmatcher::SearchBySim3 (ORBmatcher.cc:1199-1439): q12 = KeyFrame 1's points projected into KeyFrame 2 (one query per keypoint slot of
+// KeyFrame 1), q21 the reverse; match12[i1] = keypoint of KeyFrame 2 both directions agree on, or -1
+inline int SearchBySim3(const std::vector<cv::KeyPoint>& keysUn1, const cv::Mat& desc1, const std::vector<cv::KeyPoint>& keysUn2,
+                        const cv::Mat& desc2, const plh_grid_params& gp, const std::vector<float>& scaleFactors, const ProjQueries& q12,
+                        const ProjQueries& q21, float th, std::vector<int>& match12, int TH_HIGH = 100, int device = 0) {
+  match12.assign(keysUn1.size(), -1);
+  if (keysUn1.empty() || keysUn2.empty()) return 0;
+  cv::Mat d1 = desc1.isContinuous() ? desc1 : desc1.clone(), d2 = desc2.isContinuous() ? desc2 : desc2.clone();
+  cv::Mat e12 = q12.desc.isContinuous() ? q12.desc : q12.desc.clone(), e21 = q21.desc.isContinuous() ? q21.desc : q21.desc.clone();
+  int nfound = 0;
+  check(plh_orb_search_by_sim3(reinterpret_cast<const plh_keypoint*>(keysUn1.data()), d1.ptr<uchar>(), (int)keysUn1.size(),
+                               reinterpret_cast<const plh_keypoint*>(keysUn2.data()), d2.ptr<uchar>(), (int)keysUn2.size(), &gp,
+                               scaleFactors.data(), (int)scaleFactors.size(), q12.valid.data(), q12.pos.data(), q12.level.data(),
+                               e12.ptr<uchar>(), q21.valid.data(), q21.pos.data(), q21.level.data(), e21.ptr<uchar>(), th, TH_HIGH,
+                               match12.data(), &nfound, device));
+  return nfound;
+}
+
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) (ORBmatcher.cc:720-912): match12[i1] = feature of pKF2 or -1
+inline int SearchForTriangulation(const std::vector<cv::KeyPoint>& keysUn1, const cv::Mat& desc1, const std::vector<int32_t>& node1,
+                                  const std::vector<uchar>& hasMP1, const std::vector<cv::KeyPoint>& keysUn2, const cv::Mat& desc2,
+                                  const std::vector<int32_t>& node2, const std::vector<uchar>& hasMP2, const cv::Mat& F12, float ex, float ey,
+                                  const std::vector<float>& scaleFactors2, const std::vector<float>& levelSigma2_2, bool checkOri,
+                                  std::vector<int>& match12, int TH_LOW = 50, int device = 0) {
+  match12.assign(keysUn1.size(), -1);
+  if (keysUn1.empty() || keysUn2.empty()) return 0;
+  cv::Mat d1 = desc1.isContinuous() ? desc1 : desc1.clone(), d2 = desc2.isContinuous() ? desc2 : desc2.clone();
+  float F[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) F[3 * r + c] = F12.at<float>(r, c);
+  int nmatches = 0;
+  check(plh_orb_search_for_triangulation(reinterpret_cast<const plh_keypoint*>(keysUn1.data()), d1.ptr<uchar>(), node1.data(), hasMP1.data(),
+                                         (int)keysUn1.size(), reinterpret_cast<const plh_keypoint*>(keysUn2.data()), d2.ptr<uchar>(),
+                                         node2.data(), hasMP2.data(), (int)keysUn2.size(), F, ex, ey, scaleFactors2.data(),
+                                         levelSigma2_2.data(), (int)scaleFactors2.size(), TH_LOW, checkOri ? 1 : 0, match12.data(), &nmatches,
+                                         device));
+  return nmatches;
+}
+
 // ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:329-453): occupied[idx] =
 // vpMatched[idx] != NULL (in/out); assigned[idx] = query whose MapPoint goes to vpMatched[idx], or -1
 inline int SearchByProjectionSim3(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& desc, const plh_grid_params& gp,

@@ -205,6 +205,107 @@ class ORBmatcher : public ORBmatcherCPU {
     return n;
   }
 
+  // LoopClosing::ComputeSim3 (LoopClosing.cc:327): ORBmatcher(0.75, true).SearchBySim3(mpCurrentKF, pKF, vpMapPointMatches, s, R, t, 7.5).
+  // Both transforms, the projections and every pre-check (:1206-1290, :1313-1365) are the reference's own expressions; the two window
+  // searches (level band l-1..l, TH_HIGH) and the agreement pass (:1421-1436) run on the GPU.
+  int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                   const cv::Mat& t12, const float th) {
+    RequireMonocularKF(pKF1);
+    RequireMonocularKF(pKF2);
+    const float &fx = pKF1->fx, &fy = pKF1->fy, &cx = pKF1->cx, &cy = pKF1->cy;
+    cv::Mat R1w = pKF1->GetRotation();
+    cv::Mat t1w = pKF1->GetTranslation();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat sR12 = s12 * R12;
+    cv::Mat sR21 = (1.0 / s12) * R12.t();
+    cv::Mat t21 = -sR21 * t12;
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int N1 = vpMapPoints1.size();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N2 = vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {
+      MapPoint* pMP = vpMatches12[i];
+      if (pMP) {
+        vbAlreadyMatched1[i] = true;
+        int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+        if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+      }
+    }
+    hip::ProjQueries q[2];
+    for (int dir = 0; dir < 2; dir++) {
+      const std::vector<MapPoint*>& pts = dir == 0 ? vpMapPoints1 : vpMapPoints2;
+      const std::vector<bool>& done = dir == 0 ? vbAlreadyMatched1 : vbAlreadyMatched2;
+      KeyFrame* pTo = dir == 0 ? pKF2 : pKF1;
+      const int n = (int)pts.size();
+      hip::ProjQueries& Q = q[dir];
+      Q.valid.assign(n, 0); Q.hasObs.assign(n, 1); Q.pos.assign(2 * (size_t)n, 0.f); Q.level.assign(n, 0); Q.aux.assign(n, 0.f);
+      Q.desc = cv::Mat::zeros(n ? n : 1, 32, CV_8U);
+      for (int i = 0; i < n; i++) {
+        MapPoint* pMP = pts[i];
+        if (!pMP || done[i]) continue;
+        if (pMP->isBad()) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat pTarget;   // the point in the other KeyFrame's camera
+        if (dir == 0) { cv::Mat p3Dc1 = R1w * p3Dw + t1w; pTarget = sR21 * p3Dc1 + t21; }
+        else { cv::Mat p3Dc2 = R2w * p3Dw + t2w; pTarget = sR12 * p3Dc2 + t12; }
+        if (pTarget.at<float>(2) < 0.0) continue;
+        const float invz = 1.0 / pTarget.at<float>(2);
+        const float x = pTarget.at<float>(0) * invz;
+        const float y = pTarget.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pTo->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        const float dist3D = cv::norm(pTarget);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const cv::Mat dMP = pMP->GetDescriptor();
+        if (dMP.empty()) continue;   // no candidate can lower bestDist from INT_MAX (:1283-1284)
+        Q.valid[i] = 1;
+        Q.pos[2 * i] = u; Q.pos[2 * i + 1] = v;
+        Q.level[i] = pMP->PredictScale(dist3D, pTo);
+        std::memcpy(Q.desc.ptr<uchar>(i), dMP.ptr<uchar>(0), 32);
+      }
+    }
+    std::vector<int> m12;
+    const int nFound = hip::SearchBySim3(pKF1->mvKeysUn, pKF1->mDescriptors, pKF2->mvKeysUn, pKF2->mDescriptors, FrameGrid(),
+                                         pKF1->mvScaleFactors, q[0], q[1], th, m12, TH_HIGH);
+    for (int i1 = 0; i1 < N1 && i1 < (int)m12.size(); i1++)
+      if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];
+    return nFound;
+  }
+
+  // LocalMapping::CreateNewMapPoints (LocalMapping.cc:339-398): ORBmatcher(0.6, false).SearchForTriangulation(mpCurrentKeyFrame, pKF2,
+  // F12, vMatchedIndices, false).  The epipole is the reference's own expression (:727-735); the per-node scan with the epipole and
+  // epipolar-line gates and the first-come claims on pKF2's features (in FeatureVector order) run on the GPU.
+  int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                             const bool bOnlyStereo) {
+    RequireMonocularKF(pKF1);
+    RequireMonocularKF(pKF2);
+    vMatchedPairs.clear();
+    if (bOnlyStereo) return 0;   // monocular KeyFrames hold no stereo feature: the reference skips every idx1 (:778-780)
+    cv::Mat Cw = pKF1->GetCameraCenter();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat C2 = R2w * Cw + t2w;
+    const float invz = 1.0f / C2.at<float>(2);
+    const float ex = pKF2->fx * C2.at<float>(0) * invz + pKF2->cx;
+    const float ey = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
+    std::vector<uchar> has1(pKF1->N), has2(pKF2->N);
+    for (int i = 0; i < pKF1->N; i++) has1[i] = pKF1->GetMapPoint(i) != NULL;
+    for (int i = 0; i < pKF2->N; i++) has2[i] = pKF2->GetMapPoint(i) != NULL;
+    std::vector<int> m12;
+    const int n = hip::SearchForTriangulation(pKF1->mvKeysUn, pKF1->mDescriptors, hip::NodeOfFeature(pKF1->mFeatVec, pKF1->N), has1,
+                                              pKF2->mvKeysUn, pKF2->mDescriptors, hip::NodeOfFeature(pKF2->mFeatVec, pKF2->N), has2, F12, ex,
+                                              ey, pKF2->mvScaleFactors, pKF2->mvLevelSigma2, mbCheckOrientation, m12, TH_LOW);
+    vMatchedPairs.reserve(n);
+    for (size_t i = 0; i < m12.size(); i++)
+      if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+    return n;
+  }
+
   // LoopClosing::ComputeSim3 (LoopClosing.cc:360): ORBmatcher(0.75, true).SearchByProjection(mpCurrentKF, mScw, mvpLoopMapPoints,
   // mvpCurrentMatchedPoints, 10).  The Sim3 decomposition, the projection and every pre-check of the loop (:337-395) are the
   // reference's own expressions; the window search with its level band, best distance and TH_LOW runs on the GPU.

@@ -1031,6 +1031,48 @@ plh_status plh_orb_search_by_projection_frame(const plh_keypoint* kps_un, const 
                           q_hasobs, th, 0.f, mode, check_ori, assigned, nmatches, device);
 }
 
+// ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1199-1439) on two KeyFrames, host buffers: see
+// plh_orb_search_by_sim3_batch_dev.  q12_* has n1 rows (KeyFrame 1's points seen from KeyFrame 2), q21_* n2 rows.
+plh_status plh_orb_search_by_sim3(const plh_keypoint* kps1_un, const uint8_t* desc1, int n1, const plh_keypoint* kps2_un,
+                                  const uint8_t* desc2, int n2, const plh_grid_params* gp, const float* scale_factors, int nlevels,
+                                  const uint8_t* q12_valid, const float* q12_uv, const int32_t* q12_level, const uint8_t* q12_desc,
+                                  const uint8_t* q21_valid, const float* q21_uv, const int32_t* q21_level, const uint8_t* q21_desc,
+                                  float th, int th_high, int32_t* match12, int* nfound, int device) {
+  if (n1 < 0 || n2 < 0 || !nfound || !gp || !scale_factors || (n1 > 0 && (!kps1_un || !desc1 || !match12 || !q12_valid || !q12_uv ||
+      !q12_level || !q12_desc)) || (n2 > 0 && (!kps2_un || !desc2 || !q21_valid || !q21_uv || !q21_level || !q21_desc)))
+    return PLH_ERR_INVALID;
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  *nfound = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  const size_t cap = (size_t)std::max(n1, n2);
+  Stage s;
+  plh_keypoint* k1 = s.up(kps1_un, n1, cap); uint8_t* d1 = s.up(desc1, (size_t)n1 * 32, cap * 32);
+  plh_keypoint* k2 = s.up(kps2_un, n2, cap); uint8_t* d2 = s.up(desc2, (size_t)n2 * 32, cap * 32);
+  const int32_t ns[2] = {n1, n2};
+  int32_t* dn = s.up(ns, 2);
+  uint8_t* v12 = s.up(q12_valid, n1, cap); float* u12 = s.up(q12_uv, (size_t)n1 * 2, cap * 2); int32_t* l12 = s.up(q12_level, n1, cap);
+  uint8_t* e12 = s.up(q12_desc, (size_t)n1 * 32, cap * 32);
+  uint8_t* v21 = s.up(q21_valid, n2, cap); float* u21 = s.up(q21_uv, (size_t)n2 * 2, cap * 2); int32_t* l21 = s.up(q21_level, n2, cap);
+  uint8_t* e21 = s.up(q21_desc, (size_t)n2 * 32, cap * 32);
+  int32_t* cs1 = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* ci1 = s.alloc<int32_t>(cap);
+  int32_t* cs2 = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* ci2 = s.alloc<int32_t>(cap);
+  int32_t* m1 = s.alloc<int32_t>(cap); int32_t* m2 = s.alloc<int32_t>(cap); int32_t* m12 = s.alloc<int32_t>(cap);
+  int32_t* dc = s.alloc<int32_t>(1);
+  STAGE_OK(s);
+  plh_status st = plh_frame_assign_grid_batch_dev(k1, dn, (int)cap, 1, gp, cs1, ci1, nullptr);
+  if (st == PLH_OK) st = plh_frame_assign_grid_batch_dev(k2, dn + 1, (int)cap, 1, gp, cs2, ci2, nullptr);
+  if (st == PLH_OK)
+    st = plh_orb_search_by_sim3_batch_dev(k1, d1, dn, cs1, ci1, k2, d2, dn + 1, cs2, ci2, (int)cap, 1, gp, scale_factors, nlevels, v12, u12,
+                                          l12, e12, v21, u21, l21, e21, th, th_high, m1, m2, m12, dc, nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(match12, m12, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nfound, dc, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
 // ORBmatcher::SearchByProjection(Frame& Cur, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1587-1716, Tracking::Relocalization)
 // on one frame, host buffers: see plh_orb_search_by_projection_kf_batch_dev.
 plh_status plh_orb_search_by_projection_kf(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,

@@ -787,4 +787,45 @@ plh_status plh_orb_search_by_bow_kfkf(const plh_keypoint* kps1, const uint8_t* d
   return PLH_OK;
 }
 
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) on host buffers: see
+// plh_orb_search_for_triangulation_batch_dev.
+plh_status plh_orb_search_for_triangulation(const plh_keypoint* kps1, const uint8_t* desc1, const int32_t* node1, const uint8_t* has_mp1,
+                                            int n1, const plh_keypoint* kps2, const uint8_t* desc2, const int32_t* node2,
+                                            const uint8_t* has_mp2, int n2, const float F12[9], float ex, float ey,
+                                            const float* scale_factors2, const float* level_sigma2_2, int nlevels, int th_low,
+                                            int check_ori, int32_t* matches12, int* nmatches, int device) {
+  if (n1 < 0 || n2 < 0 || !nmatches || (n1 > 0 && !matches12)) return PLH_ERR_INVALID;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  *nmatches = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (!kps1 || !desc1 || !node1 || !has_mp1 || !kps2 || !desc2 || !node2 || !has_mp2 || !F12 || !scale_factors2 || !level_sigma2_2)
+    return PLH_ERR_INVALID;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  const int cap = std::max(n1, n2);
+  DevBuf k1, d1, o1, v1, k2, d2, o2, v2, dn, dm, dc;
+  PLH_HIP(k1.alloc((size_t)cap * sizeof(plh_keypoint))); PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(o1.alloc((size_t)cap * 4)); PLH_HIP(v1.alloc(cap));
+  PLH_HIP(k2.alloc((size_t)cap * sizeof(plh_keypoint))); PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(o2.alloc((size_t)cap * 4)); PLH_HIP(v2.alloc(cap));
+  PLH_HIP(dn.alloc(8)); PLH_HIP(dm.alloc((size_t)cap * 4)); PLH_HIP(dc.alloc(4));
+  const int32_t ns[2] = {n1, n2};
+  PLH_HIP(hipMemcpy(k1.p, kps1, (size_t)n1 * sizeof(plh_keypoint), hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(d1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(o1.p, node1, (size_t)n1 * 4, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(v1.p, has_mp1, (size_t)n1, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(k2.p, kps2, (size_t)n2 * sizeof(plh_keypoint), hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(d2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(o2.p, node2, (size_t)n2 * 4, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(v2.p, has_mp2, (size_t)n2, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
+  plh_status st = plh_orb_search_for_triangulation_batch_dev(
+      k1.as<plh_keypoint>(), d1.as<uint8_t>(), o1.as<int32_t>(), v1.as<uint8_t>(), dn.as<int32_t>(), k2.as<plh_keypoint>(), d2.as<uint8_t>(),
+      o2.as<int32_t>(), v2.as<uint8_t>(), dn.as<int32_t>() + 1, cap, 1, F12, ex, ey, scale_factors2, level_sigma2_2, nlevels, th_low,
+      check_ori, dm.as<int32_t>(), dc.as<int32_t>(), nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(matches12, dm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nmatches, dc.p, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
 }  // extern "C"

@@ -333,6 +333,66 @@ def _backend_scene(P, seed, n=700, npts=900, sim3_scale=1.0):
     return dict(K4=K4, gp=gp, kps=kps, desc=desc, T=T, S=S, pos=pos, normal=normal, dmin=dmin, dmax=dmax, mdesc=mdesc, rng=rng)
 
 
+def _sim3_scene(P, seed, s12, n=600):
+    """Two KeyFrames related by a similarity (p_c1 = s12 R12 p_c2 + t12).  Slot i of KeyFrame 1 carries a point that KeyFrame 2 sees
+    near its keypoint pair[i]; slot pair[i] of KeyFrame 2 mostly carries one that KeyFrame 1 sees near keypoint i (the two searches
+    agree), sometimes near another keypoint (they do not); some points are behind the camera, outside the image, out of range."""
+    rng = np.random.RandomState(seed)
+    K4 = np.array([517.3, 516.5, 318.6, 255.3], np.float32)
+    gp = np.array([0.0, 0.0, 640.0, 480.0, 64 / 640.0, 48 / 480.0], np.float32)
+    def kf():
+        k = np.zeros(n, P.KP_DTYPE)
+        k["x"], k["y"] = rng.uniform(5, 635, n).astype(np.float32), rng.uniform(5, 475, n).astype(np.float32)
+        k["octave"], k["angle"] = rng.randint(0, 8, n), rng.uniform(0, 360, n).astype(np.float32)
+        k["size"], k["response"], k["class_id"] = 31.0 * 1.2 ** k["octave"], rng.uniform(20, 200, n).astype(np.float32), -1
+        return k, rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    (k1, d1), (k2, d2) = kf(), kf()
+    def pose(a, t):
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3], T[:3, 3] = _rot(*a), t
+        return T
+    T1, T2 = pose((0.05, -0.12, 0.03), (0.3, -0.2, 0.5)), pose((-0.2, 0.3, 0.1), (-1.0, 0.4, 0.2))
+    R12, t12 = _rot(0.02, 0.05, -0.04), np.array([0.2, -0.1, 0.15], np.float32)
+    pair = rng.permutation(n)
+    inv = np.argsort(pair)
+    def points(kt, dt, target, to1):
+        """points whose image in the *other* KeyFrame is near that KeyFrame's keypoint target[i]"""
+        pos, dmin, dmax = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        md = np.zeros((n, 32), np.uint8)
+        for i in range(n):
+            k = int(target[i]) if rng.uniform() < 0.8 else rng.randint(0, n)
+            z = rng.uniform(2.0, 12.0)
+            u, v = kt["x"][k] + rng.uniform(-2.5, 2.5), kt["y"][k] + rng.uniform(-2.5, 2.5)
+            Xt = np.array([(u - K4[2]) / K4[0] * z, (v - K4[3]) / K4[1] * z, z])       # in the other KeyFrame's camera
+            kind = rng.randint(0, 14)
+            if kind == 0: Xt[2] = -Xt[2]
+            if kind == 1: Xt[0] += 3 * z
+            d = np.linalg.norm(Xt)
+            if to1:      # the point belongs to KeyFrame 2: camera 1 -> camera 2 -> world through T2
+                Xc = (R12.T.astype(np.float64) @ (Xt - t12)) / s12
+                Xw = T2[:3, :3].T.astype(np.float64) @ (Xc - T2[:3, 3])
+            else:        # the point belongs to KeyFrame 1: camera 2 -> camera 1 -> world through T1
+                Xc = s12 * (R12.astype(np.float64) @ Xt) + t12
+                Xw = T1[:3, :3].T.astype(np.float64) @ (Xc - T1[:3, 3])
+            pos[i] = Xw
+            lvl = int(kt["octave"][k])
+            dmax[i] = d * 1.2 ** (lvl - 0.5) if kind != 3 else d * 0.5
+            dmin[i] = dmax[i] / 1.2 ** 8 * 0.8
+            dd = dt[k].copy()
+            for b in rng.randint(0, 256, rng.randint(0, 40 if kind != 4 else 160)):
+                dd[b >> 3] ^= 1 << (b & 7)
+            md[i] = dd
+        return pos, dmin, dmax, md
+    pts1 = points(k2, d2, pair, False)       # KeyFrame 1's points look at KeyFrame 2's keypoints
+    pts2 = points(k1, d1, inv, True)
+    has1, has2 = (rng.uniform(size=n) < 0.85).astype(np.uint8), (rng.uniform(size=n) < 0.85).astype(np.uint8)
+    pre = np.full(n, -1, np.int32)
+    for i in np.nonzero(rng.uniform(size=n) < 0.08)[0]:
+        j = rng.randint(0, n)
+        if has2[j]: pre[i] = j
+    return dict(K4=K4, gp=gp, k1=k1, d1=d1, k2=k2, d2=d2, T1=T1, T2=T2, R12=R12, t12=t12, pts1=pts1, pts2=pts2, has1=has1, has2=has2, pre=pre)
+
+
 def _backend_calls(P, S, path, tmp_path):
     G, R = _lib(path)
     p = lambda a: np.ascontiguousarray(a).ctypes.data_as(V)
@@ -396,6 +456,17 @@ def _backend_calls(P, S, path, tmp_path):
         assert (outs[0] == outs[2]).all(), "Fuse(Scw) seed %d: vpReplacePoint differs from the reference's" % seed
         assert (outs[1] == outs[3]).all(), "Fuse(Scw) seed %d: the KeyFrame's map points differ from the reference's" % seed
         assert (outs[0] != -1).sum() > 20 and (outs[1] >= 0).sum() > 20      # replacements proposed and points added
+    # ---- LoopClosing::ComputeSim3: SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)
+    for seed, s12, th in ((61, 1.0, 7.5), (62, 1.4, 7.5), (63, 0.7, 3.0)):
+        sc = _sim3_scene(P, seed, s12)
+        n = len(sc["k1"])
+        o_ref, o_hip = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        R.adx_loop_search_by_sim3.argtypes = [V, V, I, V, V, V, V, V, V, V, V, I, V, V, V, V, V, V, V, V, F, V, V, V, F, V, V, V]
+        nf = R.adx_loop_search_by_sim3(p(sc["k1"]), p(sc["d1"]), n, p(sc["T1"]), p(sc["has1"]), *[p(x) for x in sc["pts1"]], p(sc["k2"]),
+                                       p(sc["d2"]), n, p(sc["T2"]), p(sc["has2"]), *[p(x) for x in sc["pts2"]], p(sc["gp"]), p(sc["K4"]),
+                                       s12, p(sc["R12"]), p(sc["t12"]), p(sc["pre"]), th, p(o_ref), p(o_hip), C.byref(n_ref))
+        assert nf == n_ref.value and nf > 100, (seed, nf, n_ref.value)
+        assert (o_ref == o_hip).all(), "SearchBySim3 seed %d: vpMatches12 differs from the reference's" % seed
     # ---- LoopClosing: SearchByBoW(pKF1, pKF2, vpMatches12)
     VM = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
     voc = VM.Vocabulary.synthetic(41, k=10, L=4, synth=S)
@@ -420,6 +491,29 @@ def _backend_calls(P, S, path, tmp_path):
         assert nm == n_ref.value and nm >= 0, (seed, nm, n_ref.value)
         assert (o_ref == o_hip).all(), "SearchByBoW(KF, KF) seed %d differs from the reference's" % seed
         assert (o_ref >= 0).sum() > 50
+    # ---- LocalMapping::CreateNewMapPoints: SearchForTriangulation(pKF1, pKF2, F12, vMatchedIndices, false)
+    for seed, chk in ((35, 0), (36, 1)):
+        a, b, perm = S.make_descriptor_sets(seed, 800, flip_p=0.06)
+        rng = np.random.RandomState(seed)
+        k1 = np.zeros(len(a), P.KP_DTYPE)
+        k1["x"], k1["y"] = rng.uniform(60, 620, len(a)).astype(np.float32), rng.uniform(20, 460, len(a)).astype(np.float32)
+        k1["octave"], k1["angle"], k1["class_id"] = rng.randint(0, 8, len(a)), rng.uniform(0, 360, len(a)).astype(np.float32), -1
+        k2 = k1[perm].copy() if len(perm) == len(b) else k1[:len(b)].copy()
+        k2["x"] = (k2["x"] - rng.uniform(2, 40, len(b))).astype(np.float32)              # disparity along the epipolar line
+        k2["y"] = (k2["y"] + rng.uniform(-3.0, 3.0, len(b))).astype(np.float32)          # some violate the 3.84 sigma^2 gate
+        k2["angle"] = ((k2["angle"] + rng.choice([5.0, 5.0, 5.0, 90.0], len(b))) % 360).astype(np.float32)
+        h1, h2 = (rng.uniform(size=len(a)) < 0.3).astype(np.uint8), (rng.uniform(size=len(b)) < 0.3).astype(np.uint8)
+        T1 = np.eye(4, dtype=np.float32)
+        T2 = np.eye(4, dtype=np.float32); T2[:3, 3] = (-0.4, 0.0, 0.35)     # the epipole lands inside the image: its gate is exercised
+        F12 = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)            # l = (0, -1, y1): distance^2 = (y2 - y1)^2
+        K4 = np.array([500, 500, 320, 240], np.float32)
+        gp = np.array([0.0, 0.0, 640.0, 480.0, 0.1, 0.1], np.float32)
+        o_ref, o_hip = np.zeros(len(a), np.int32), np.zeros(len(a), np.int32)
+        R.adx_local_mapping_triangulation.argtypes = [C.c_char_p, V, V, V, I, V, V, V, I, V, V, V, V, V, I, V, V, V]
+        nm = R.adx_local_mapping_triangulation(vpath.encode(), p(k1), p(a), p(h1), len(a), p(k2), p(b), p(h2), len(b), p(gp), p(T1), p(T2),
+                                               p(K4), p(F12), chk, p(o_ref), p(o_hip), C.byref(n_ref))
+        assert nm == n_ref.value and nm > 50, (seed, nm, n_ref.value)
+        assert (o_ref == o_hip).all(), "SearchForTriangulation seed %d differs from the reference's" % seed
 
 
 def test_adaptor_executes_backend_searches_emu(plslam, synth, emu_lib, tmp_path):
