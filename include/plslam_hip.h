@@ -473,6 +473,12 @@ PLH_API plh_status plh_orb_search_for_triangulation(const plh_keypoint* kps1, co
                                                     float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
                                                     int nlevels, int th_low, int check_ori, int32_t* matches12, int* nmatches,
                                                     int device);
+PLH_API plh_status plh_line_frame_bfmatch(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, float th, float nnratio,
+                                          int32_t* matches12, int device);
+PLH_API plh_status plh_line_fuse_search(const plh_keyline* kl, const uint8_t* cand_desc, int nl, const float* scale_factors_line,
+                                        int nlevels, int nq, const uint8_t* q_valid, const float* q_seg, const int32_t* q_level,
+                                        const uint8_t* q_desc, float th, float cos_th, int th_low, int32_t* best_idx, int* nfound,
+                                        int device);
 PLH_API plh_status plh_orb_search_by_sim3(const plh_keypoint* kps1_un, const uint8_t* desc1, int n1, const plh_keypoint* kps2_un,
                                           const uint8_t* desc2, int n2, const plh_grid_params* gp, const float* scale_factors,
                                           int nlevels, const uint8_t* q12_valid, const float* q12_uv, const int32_t* q12_level,

@@ -426,6 +426,125 @@ int adx_local_mapping_triangulation(const char* voc_path, const void* kps1, cons
   return res[1];
 }
 
+// ---- the line side of LocalMapping, on real KeyFrame / MapLine objects ----
+namespace {
+// a KeyFrame that also holds nl keylines (68-byte KeyLine records) with their LBD descriptors; 8 line levels with factor `lscale`
+void build_kf_lines(BackScene& s, const void* kps28, const uint8_t* desc, int n, const void* kl68, const uint8_t* ldesc, int nl,
+                    const float gp[6], const float T16[16], const float K4[4], float lscale) {
+  Frame& f = s.f;
+  f.NL = nl;
+  f.mvKeylinesUn.resize(nl);
+  if (nl > 0) std::memcpy((void*)f.mvKeylinesUn.data(), kl68, (size_t)nl * 68);
+  f.mLdesc = cv::Mat(nl > 0 ? nl : 0, 32, CV_8U);
+  if (nl > 0) std::memcpy(f.mLdesc.data, ldesc, (size_t)nl * 32);
+  f.mvKeyLineFunctions.assign(nl, Eigen::Vector3d(0, 0, 1));
+  f.mvpMapLines.assign(nl, nullptr);
+  f.mvbLineOutlier.assign(nl, false);
+  f.mnScaleLevelsLine = 8;
+  f.mfScaleFactorLine = lscale;
+  f.mfLogScaleFactorLine = std::log(lscale);
+  f.mvScaleFactorsLine.assign(8, 1.f);
+  for (int i = 1; i < 8; i++) f.mvScaleFactorsLine[i] = f.mvScaleFactorsLine[i - 1] * lscale;
+  build_kf(s, kps28, desc, n, gp, T16, K4, 8, 1.2f, nullptr);
+}
+struct LineScene : BackScene { std::vector<std::unique_ptr<MapLine> > lines; };
+MapLine* add_line(LineScene& s, const float* p6, const float* normal3, float dmin, float dmax, const uint8_t* ldesc, int nobs, long id) {
+  Vector6d P;
+  for (int k = 0; k < 6; k++) P(k) = p6[k];
+  s.lines.emplace_back(new MapLine(P, s.kf, &s.map));
+  MapLine* l = s.lines.back().get();
+  l->mNormalVector = Eigen::Vector3d(normal3[0], normal3[1], normal3[2]);
+  l->mfMinDistance = dmin; l->mfMaxDistance = dmax;
+  if (ldesc) { l->mLDescriptor = cv::Mat(1, 32, CV_8U); std::memcpy(l->mLDescriptor.data, ldesc, 32); }
+  l->nObs = nobs;
+  l->mnId = (unsigned long)id;
+  return l;
+}
+}  // namespace
+
+// LSDmatcher().SearchForTriangulation between two KeyFrames' lines (LocalMapping.cc:679 / :961).  mode 0: the vector<pair> overload;
+// 1: the vector<int> overload with isDouble = true; 2: the same with isDouble = false.  has1 / has2: the line carries a MapLine.
+// out_*[i] = line of KeyFrame 2 paired with line i, -1 none.
+int adx_local_mapping_line_triangulation(const void* kl1, const uint8_t* ld1, const uint8_t* has1, int n1, const void* kl2,
+                                         const uint8_t* ld2, const uint8_t* has2, int n2, int mode, int32_t* out_ref, int32_t* out_hip,
+                                         int* n_ref) {
+  const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, K4[4] = {500, 500, 320, 240};
+  const float gp[6] = {0, 0, 640, 480, 0.1f, 0.1f}, z6[6] = {0, 0, 1, 0, 0, 2}, z3[3] = {0, 0, 1};
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    LineScene a, b;
+    build_kf_lines(a, nullptr, nullptr, 0, kl1, ld1, n1, gp, I16, K4, 1.2f);
+    build_kf_lines(b, nullptr, nullptr, 0, kl2, ld2, n2, gp, I16, K4, 1.2f);
+    for (int i = 0; i < n1; i++) if (has1[i]) a.kf->AddMapLine(add_line(a, z6, z3, 0, 1e9f, nullptr, 1, i), i);
+    for (int i = 0; i < n2; i++) if (has2[i]) b.kf->AddMapLine(add_line(b, z6, z3, 0, 1e9f, nullptr, 1, i), i);
+    int32_t* out = side == 0 ? out_ref : out_hip;
+    for (int i = 0; i < n1; i++) out[i] = -1;
+    std::vector<std::pair<size_t, size_t> > pairs;
+    std::vector<int> vec;
+    int r;
+    if (side == 0) {
+      LSDmatcherCPU m;
+      r = mode == 0 ? m.SearchForTriangulation(a.kf, b.kf, pairs) : m.SearchForTriangulation(a.kf, b.kf, vec, mode == 1);
+    } else {
+      LSDmatcher m;
+      r = mode == 0 ? m.SearchForTriangulation(a.kf, b.kf, pairs) : m.SearchForTriangulation(a.kf, b.kf, vec, mode == 1);
+    }
+    res[side] = r;
+    if (mode == 0) {
+      for (size_t k = 0; k < pairs.size(); k++) {
+        if (k && pairs[k].first <= pairs[k - 1].first) return -2;
+        out[pairs[k].first] = (int32_t)pairs[k].second;
+      }
+      if ((int)pairs.size() != r) return -3;
+    } else {
+      if ((int)vec.size() != n1) return -4;
+      for (int i = 0; i < n1; i++) out[i] = vec[i];
+    }
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
+// LSDmatcher().Fuse(pKF, vpMapLines, th) (LocalMapping.cc:1600).  The KeyFrame holds nl keylines (and n ORB rows: the reference reads
+// the candidates' descriptor rows from pKF->mDescriptors, LSDmatcher.cpp:963); it already holds a MapLine with kf_obs[idx]
+// observations at line idx where kf_obs[idx] > 0.  Candidate i: endpoints pos6, normal, invariance range, LBD descriptor, cand_obs[i]
+// observations; `order` is the list handed to Fuse (-1 = NULL, repeats allowed).  What the call leaves behind, per side:
+// kf_line[idx] = id of the MapLine now at line idx (candidates: index; originals: -2 - idx; -1 none), cand_state[i] = bit 0 isBad,
+// bit 1 IsInKeyFrame(pKF), bits 8.. Observations().
+int adx_local_mapping_line_fuse(const void* kps28, const uint8_t* desc, int n, const void* kl68, const uint8_t* ldesc, int nl,
+                                const float gp[6], const float T16[16], const float K4[4], float lscale, const int32_t* kf_obs, int nc,
+                                const float* pos6, const float* normal, const float* dmin, const float* dmax, const uint8_t* cdesc,
+                                const int32_t* cand_obs, const int32_t* order, int norder, float th, int32_t* kf_line_ref,
+                                int32_t* cand_state_ref, int32_t* kf_line_hip, int32_t* cand_state_hip, int* n_ref) {
+  int res[2] = {0, 0};
+  const float z6[6] = {0, 0, 1, 0, 0, 2}, z3[3] = {0, 0, 1};
+  for (int side = 0; side < 2; side++) {
+    LineScene s;
+    build_kf_lines(s, kps28, desc, n, kl68, ldesc, nl, gp, T16, K4, lscale);
+    for (int i = 0; i < nl; i++)
+      if (kf_obs[i] > 0) {
+        MapLine* l = add_line(s, z6, z3, 0.f, 1e9f, ldesc + (size_t)i * 32, 0, -2 - i);
+        l->AddObservation(s.kf, i);
+        s.kf->AddMapLine(l, i);
+        l->nObs = kf_obs[i];
+      }
+    std::vector<MapLine*> cand(nc);
+    for (int i = 0; i < nc; i++)
+      cand[i] = add_line(s, pos6 + 6 * i, normal + 3 * i, dmin[i], dmax[i], cdesc + (size_t)i * 32, cand_obs[i], i);
+    std::vector<MapLine*> list(norder);
+    for (int k = 0; k < norder; k++) list[k] = order[k] >= 0 ? cand[order[k]] : nullptr;
+    if (side == 0) { LSDmatcherCPU m; res[0] = m.Fuse(s.kf, list, th); }
+    else { LSDmatcher m; res[1] = m.Fuse(s.kf, list, th); }
+    int32_t* kp = side == 0 ? kf_line_ref : kf_line_hip;
+    int32_t* cs = side == 0 ? cand_state_ref : cand_state_hip;
+    for (int i = 0; i < nl; i++) { MapLine* l = s.kf->GetMapLine(i); kp[i] = l ? (int32_t)(long)l->mnId : -1; }
+    for (int i = 0; i < nc; i++)
+      cs[i] = (cand[i]->isBad() ? 1 : 0) | (cand[i]->IsInKeyFrame(s.kf) ? 2 : 0) | (cand[i]->Observations() << 8);
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
 // the static helpers
 int adx_descriptor_distance(const uint8_t* a, const uint8_t* b) {
   cv::Mat ma(1, 32, CV_8U), mb(1, 32, CV_8U);

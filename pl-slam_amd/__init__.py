@@ -114,6 +114,8 @@ _SIGS = {
     "plh_line_set_refine": ([_V, _I], _I),
     "plh_orb_search_by_bow_kfkf": ([_V, _V, _V, _V, _I, _V, _V, _V, _V, _I, _I, _F, _I, _V, _V, _I], _I),
     "plh_orb_search_for_triangulation": ([_V, _V, _V, _V, _I, _V, _V, _V, _V, _I, _V, _F, _F, _V, _V, _I, _I, _I, _V, _V, _I], _I),
+    "plh_line_frame_bfmatch": ([_V, _I, _V, _I, _F, _F, _V, _I], _I),
+    "plh_line_fuse_search": ([_V, _V, _I, _V, _I, _I, _V, _V, _V, _V, _F, _F, _I, _V, _V, _I], _I),
     "plh_orb_search_by_sim3": ([_V, _V, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V, _V, _I], _I),
     "plh_orb_search_by_projection_kf": ([_V, _V, _I, _V, _V, _I, _V, _I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _I], _I),
     "plh_orb_search_by_projection_sim3": ([_V, _V, _I, _V, _V, _I, _V, _I, _V, _V, _V, _V, _V, _F, _I, _V, _V, _I], _I),

@@ -6,10 +6,14 @@
 //     LSDmatcher::SearchDouble(Frame&, Frame&, vector<int>&)                :427-460                     (Tracking.cc:711)
 //     LSDmatcher::SearchDouble(KeyFrame*, Frame&)                           :375-425                     (Tracking.cc:1159)
 //     LSDmatcher::DescriptorDistance                                        :654-670
+// and the back end's (LocalMapping):
+//     LSDmatcher::SearchForTriangulation(pKF1, pKF2, vector<pair>&)         :672-725                     (LocalMapping.cc:679)
+//     LSDmatcher::SearchForTriangulation(pKF1, pKF2, vector<int>&, isDouble) :727-778                    (LocalMapping.cc:961)
+//     LSDmatcher::Fuse(pKF, vpMapLines, th)                                 :860-1002                    (LocalMapping.cc:1600,1627)
 // Same construction as adaptor/HipORBmatcher.h: the reference's own class is read as LSDmatcherCPU, the class below derives
-// from it and inherits everything it does not re-declare (SearchForTriangulation*, Fuse, ...); the maintainer compiles
+// from it and inherits everything it does not re-declare (SearchForTriangulationNew, ...); the maintainer compiles
 // src/LSDmatcher.cpp with -DORBmatcher=ORBmatcherCPU -DLSDmatcher=LSDmatcherCPU.  The reference's debugging pictures
-// (matchResultTrack.jpg, :67 / :171 / :422) are not written.
+// (matchResultTrack.jpg, :67 / :171 / :422; matchResultLocalMapping.jpg, :723 / :776) are not written.
 #ifndef PLSLAM_HIP_ADAPTOR_LSDMATCHER_H
 #define PLSLAM_HIP_ADAPTOR_LSDMATCHER_H
 
@@ -118,6 +122,125 @@ class LSDmatcher : public LSDmatcherCPU {
       nmatches++;
     }
     return nmatches;
+  }
+
+  // LocalMapping::CreateNewMapLines (LocalMapping.cc:679): mutual nearest LBD descriptors at TH_LOW between two KeyFrames, kept
+  // where neither line carries a MapLine (:692-708)
+  int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs) {
+    vMatchedPairs.clear();
+    if (pKF1->mLineDescriptors.rows == 0 || pKF2->mLineDescriptors.rows == 0) return 0;
+    std::vector<int> m12;
+    hip::SearchDouble(pKF1->mLineDescriptors, pKF2->mLineDescriptors, m12, mfNNratio, (float)TH_LOW);
+    int nmatches = 0;
+    for (size_t i = 0; i < m12.size(); i++) {
+      if (m12[i] < 0) continue;
+      if (pKF1->GetMapLine(i) || pKF2->GetMapLine(m12[i])) continue;
+      vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+      nmatches++;
+    }
+    return nmatches;
+  }
+
+  // LocalMapping::CreateNewMapLines2 (LocalMapping.cc:961): as above at TH_HIGH into a per-line vector; isDouble = false keeps the
+  // one-directional nearest neighbours (:744-760)
+  int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<int>& vMatchedPairs, bool isDouble) {
+    vMatchedPairs.clear();
+    vMatchedPairs.resize(pKF1->NL, -1);
+    if (pKF1->mLineDescriptors.rows == 0 || pKF2->mLineDescriptors.rows == 0) return 0;
+    std::vector<int> m12;
+    if (isDouble) hip::SearchDouble(pKF1->mLineDescriptors, pKF2->mLineDescriptors, m12, mfNNratio, (float)TH_HIGH);
+    else hip::FrameBFMatch(pKF1->mLineDescriptors, pKF2->mLineDescriptors, m12, mfNNratio, (float)TH_HIGH);
+    int nmatches = 0;
+    for (size_t i = 0; i < m12.size() && i < vMatchedPairs.size(); i++) {
+      if (m12[i] < 0) continue;
+      if (pKF1->GetMapLine(i) || pKF2->GetMapLine(m12[i])) continue;
+      vMatchedPairs[i] = m12[i];
+      nmatches++;
+    }
+    return nmatches;
+  }
+
+  // LocalMapping::SearchLineInNeighbors (LocalMapping.cc:1600, :1627).  As ORBmatcher::Fuse in HipORBmatcher.h: the search for the best
+  // line of every MapLine does not depend on what the loop does to the map, so it runs first, on the GPU, for every line up to the
+  // first one with an endpoint behind the camera (the reference leaves the function there with `return false`, :893-894); the loop
+  // then runs in the reference's order with the reference's own tests and its replace / add logic (:975-997).  Candidates' descriptor
+  // rows are read from pKF->mDescriptors as the reference does (:963); rows it does not have (the reference reads past the matrix)
+  // are zeros here.
+  int Fuse(KeyFrame* pKF, const std::vector<MapLine*>& vpMapLines, float th = 3.0) {
+    cv::Mat Rcw = pKF->GetRotation();
+    cv::Mat tcw = pKF->GetTranslation();
+    const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+    cv::Mat Ow = pKF->GetCameraCenter();
+    const int nMLs = (int)vpMapLines.size();
+    const int nLevels = (int)pKF->mvScaleFactorsLine.size();
+    hip::ProjQueries q;
+    q.valid.assign(nMLs, 0); q.hasObs.assign(nMLs, 1); q.pos.assign(4 * (size_t)nMLs, 0.f); q.level.assign(nMLs, 0); q.aux.assign(nMLs, 0.f);
+    q.desc = cv::Mat::zeros(nMLs ? nMLs : 1, 32, CV_8U);
+    int stopAt = nMLs;   // the query at which the reference returns
+    for (int i = 0; i < nMLs; i++) {
+      MapLine* pML = vpMapLines[i];
+      if (!pML) continue;
+      Vector6d P = pML->GetWorldPos();
+      cv::Mat SP = (cv::Mat_<float>(3, 1) << P(0), P(1), P(2));
+      cv::Mat EP = (cv::Mat_<float>(3, 1) << P(3), P(4), P(5));
+      const cv::Mat SPc = Rcw * SP + tcw;
+      const float &SPcX = SPc.at<float>(0), &SPcY = SPc.at<float>(1), &SPcZ = SPc.at<float>(2);
+      const cv::Mat EPc = Rcw * EP + tcw;
+      const float &EPcX = EPc.at<float>(0), &EPcY = EPc.at<float>(1), &EPcZ = EPc.at<float>(2);
+      if (SPcZ < 0.0f || EPcZ < 0.0f) { q.aux[i] = 1.f; continue; }   // (the return happens only if the loop gets here unskipped)
+      const float invz1 = 1.0f / SPcZ;
+      const float u1 = fx * SPcX * invz1 + cx;
+      const float v1 = fy * SPcY * invz1 + cy;
+      if (!pKF->IsInImage(u1, v1)) continue;
+      const float invz2 = 1.0f / EPcZ;
+      const float u2 = fx * EPcX * invz2 + cx;
+      const float v2 = fy * EPcY * invz2 + cy;
+      if (!pKF->IsInImage(u2, v2)) continue;
+      const float maxDistance = pML->GetMaxDistanceInvariance();
+      const float minDistance = pML->GetMinDistanceInvariance();
+      const cv::Mat OM = 0.5 * (SP + EP) - Ow;
+      const float dist = cv::norm(OM);
+      if (dist < minDistance || dist > maxDistance) continue;
+      Eigen::Vector3d Pn = pML->GetNormal();
+      cv::Mat pn = (cv::Mat_<float>(3, 1) << Pn(0), Pn(1), Pn(2));
+      if (OM.dot(pn) < 0.5 * dist) continue;
+      int nPredictedLevel = pML->PredictScale(dist, pKF->mfLogScaleFactorLine);
+      if (nPredictedLevel < 0 || nPredictedLevel >= nLevels) continue;   // (the reference indexes mvScaleFactorsLine out of range here)
+      cv::Mat CurrentLineDesc = pML->mLDescriptor;
+      if (CurrentLineDesc.empty()) continue;
+      q.valid[i] = 1;
+      q.pos[4 * i] = u1; q.pos[4 * i + 1] = v1; q.pos[4 * i + 2] = u2; q.pos[4 * i + 3] = v2;
+      q.level[i] = nPredictedLevel;
+      std::memcpy(q.desc.ptr<uchar>(i), CurrentLineDesc.ptr<uchar>(0), 32);
+    }
+    (void)stopAt;
+    std::vector<int> bestIdx(nMLs, -1);
+    if (pKF->NL > 0 && nMLs > 0) {
+      cv::Mat cand = cv::Mat::zeros(pKF->NL, 32, CV_8U);
+      const int rows = std::min(pKF->NL, pKF->mDescriptors.rows);
+      if (rows > 0 && pKF->mDescriptors.cols == 32) pKF->mDescriptors.rowRange(0, rows).copyTo(cand.rowRange(0, rows));
+      hip::LineFuseSearch(pKF->mvKeyLines, cand, pKF->mvScaleFactorsLine, q, th, bestIdx, 0.998f, TH_LOW);
+    }
+    int nFused = 0;
+    for (int i = 0; i < nMLs; i++) {
+      MapLine* pML = vpMapLines[i];
+      if (!pML) continue;
+      if (pML->isBad() || pML->IsInKeyFrame(pKF)) continue;           // (as it stands when the loop gets here)
+      if (q.aux[i] != 0.f) return false;                               // :893-894
+      if (!q.valid[i] || bestIdx[i] < 0) continue;
+      MapLine* pMLinKF = pKF->GetMapLine(bestIdx[i]);
+      if (pMLinKF) {
+        if (!pMLinKF->isBad()) {
+          if (pMLinKF->Observations() > pML->Observations()) pML->Replace(pMLinKF);
+          else pMLinKF->Replace(pML);
+        }
+      } else {
+        pML->AddObservation(pKF, bestIdx[i]);
+        pKF->AddMapLine(pML, bestIdx[i]);
+      }
+      nFused++;
+    }
+    return nFused;
   }
 
  protected:

@@ -79,6 +79,15 @@ inline int SearchDouble(const cv::Mat& ldesc1, const cv::Mat& ldesc2, std::vecto
   return nmatches;
 }
 
+// LSDmatcher::FrameBFMatch(ldesc1, ldesc2, LineMatches, TH) (LSDmatcher.cpp:462-486): one direction, no mutual check
+inline void FrameBFMatch(const cv::Mat& ldesc1, const cv::Mat& ldesc2, std::vector<int>& LineMatches, float nnratio, float TH,
+                         int device = 0) {
+  LineMatches.assign(ldesc1.rows, -1);
+  if (ldesc1.rows == 0 || ldesc2.rows == 0) return;
+  cv::Mat d1 = ldesc1.isContinuous() ? ldesc1 : ldesc1.clone(), d2 = ldesc2.isContinuous() ? ldesc2 : ldesc2.clone();
+  check(plh_line_frame_bfmatch(d1.ptr<uchar>(), d1.rows, d2.ptr<uchar>(), d2.rows, TH, nnratio, LineMatches.data(), device));
+}
+
 // cv::BFMatcher(NORM_HAMMING, false).knnMatch(q, t, matches, 2) (LSDmatcher.cpp:468-469, 494-495)
 inline void knnMatch2(const cv::Mat& q, const cv::Mat& t, std::vector<std::vector<cv::DMatch> >& matches, int device = 0) {
   matches.clear();
@@ -287,6 +296,21 @@ inline int FuseSearch(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& de
                             scaleFactors.data(), invLevelSigma2.empty() ? NULL : invLevelSigma2.data(), (int)scaleFactors.size(),
                             (int)q.valid.size(), q.valid.data(), q.pos.data(), q.level.data(), qd.ptr<uchar>(), th, TH_LOW, bestIdx.data(),
                             &nfound, device));
+  return nfound;
+}
+
+// The search inside LSDmatcher::Fuse(pKF, vpMapLines, th) (LSDmatcher.cpp:860-1002) with KeyFrame::GetLinesInArea (KeyFrame.cc:647-683):
+// q.pos = 4 floats per query (u1, v1, u2, v2); candDesc = the matrix the reference reads the candidates' rows from
+inline int LineFuseSearch(const std::vector<cv::line_descriptor::KeyLine>& keylines, const cv::Mat& candDesc,
+                          const std::vector<float>& scaleFactorsLine, const ProjQueries& q, float th, std::vector<int>& bestIdx,
+                          float cosTH = 0.998f, int TH_LOW = 50, int device = 0) {
+  bestIdx.assign(q.valid.size(), -1);
+  if (keylines.empty() || q.valid.empty()) return 0;
+  cv::Mat d = candDesc.isContinuous() ? candDesc : candDesc.clone(), qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nfound = 0;
+  check(plh_line_fuse_search(reinterpret_cast<const plh_keyline*>(keylines.data()), d.ptr<uchar>(), (int)keylines.size(),
+                             scaleFactorsLine.data(), (int)scaleFactorsLine.size(), (int)q.valid.size(), q.valid.data(), q.pos.data(),
+                             q.level.data(), qd.ptr<uchar>(), th, cosTH, TH_LOW, bestIdx.data(), &nfound, device));
   return nfound;
 }
 

@@ -9,10 +9,10 @@
 // How it coexists with the rest of the reference (plslam_hip_dropin.h, force-included into every translation unit): the
 // reference's own header is read here, once, under another class name (ORBmatcher -> ORBmatcherCPU), which also sets its
 // include guard, so every later `#include "ORBmatcher.h"` in the tree is a no-op; the class below derives from it, re-declares
-// the overloads above and inherits every other method (KeyFrame-KeyFrame BoW, SearchForTriangulation, Fuse, SearchBySim3, the
-// relocalisation / loop-closing projections) from the reference's src/ORBmatcher.cc, which the maintainer keeps compiling with
-// -DORBmatcher=ORBmatcherCPU -DLSDmatcher=LSDmatcherCPU (one line in CMakeLists.txt).  The back-end
-// methods have GPU entry points too (plh_orb_*_batch_dev); moving one over is a matter of adding its overload here.
+// the overloads above -- and the back end's: SearchByBoW(KeyFrame*, KeyFrame*) :574-709, SearchForTriangulation :720-912, both
+// Fuse :914-1197, SearchBySim3 :1199-1439, the loop-closing :329-453 and relocalisation :1587-1716 SearchByProjection -- and
+// inherits the helpers from the reference's src/ORBmatcher.cc, which the maintainer keeps compiling with
+// -DORBmatcher=ORBmatcherCPU -DLSDmatcher=LSDmatcherCPU (one line in CMakeLists.txt).
 #ifndef PLSLAM_HIP_ADAPTOR_ORBMATCHER_H
 #define PLSLAM_HIP_ADAPTOR_ORBMATCHER_H
 

@@ -1232,4 +1232,33 @@ plh_status plh_line_search_by_projection_ml(const plh_keyline* kl, const uint8_t
                          assigned, nmatches, device);
 }
 
+// The search inside LSDmatcher::Fuse(pKF, vpMapLines, th) on one KeyFrame, host buffers: see plh_line_fuse_search_batch_dev.
+plh_status plh_line_fuse_search(const plh_keyline* kl, const uint8_t* cand_desc, int nl, const float* scale_factors_line, int nlevels,
+                                int nq, const uint8_t* q_valid, const float* q_seg, const int32_t* q_level, const uint8_t* q_desc,
+                                float th, float cos_th, int th_low, int32_t* best_idx, int* nfound, int device) {
+  if (nl < 0 || nq < 0 || !nfound || !scale_factors_line || (nl > 0 && (!kl || !cand_desc)) ||
+      (nq > 0 && (!q_valid || !q_seg || !q_level || !q_desc || !best_idx)))
+    return PLH_ERR_INVALID;
+  for (int i = 0; i < nq; i++) best_idx[i] = -1;
+  *nfound = 0;
+  if (nl == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  Stage s;
+  plh_keyline* dk = s.up(kl, nl); uint8_t* dd = s.up(cand_desc, (size_t)nl * 32);
+  const int32_t ns[2] = {nl, nq};
+  int32_t* dn = s.up(ns, 2);
+  uint8_t* qv = s.up(q_valid, nq); float* qs = s.up(q_seg, (size_t)nq * 4); int32_t* ql = s.up(q_level, nq);
+  uint8_t* qd = s.up(q_desc, (size_t)nq * 32);
+  int32_t* db = s.alloc<int32_t>(nq); int32_t* dc = s.alloc<int32_t>(1);
+  STAGE_OK(s);
+  plh_status st = plh_line_fuse_search_batch_dev(dk, dd, dn, nl, 1, scale_factors_line, nlevels, dn + 1, nq, qv, qs, ql, qd, th, cos_th,
+                                                 th_low, db, dc, nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(best_idx, db, (size_t)nq * 4, hipMemcpyDeviceToHost));
+  PLH_HIP(hipMemcpy(nfound, dc, 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
 }  // extern "C"

@@ -787,6 +787,33 @@ plh_status plh_orb_search_by_bow_kfkf(const plh_keypoint* kps1, const uint8_t* d
   return PLH_OK;
 }
 
+// LSDmatcher::FrameBFMatch(ldesc1, ldesc2, LineMatches, TH) (LSDmatcher.cpp:462-486): the one-directional matcher on host buffers.
+plh_status plh_line_frame_bfmatch(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, float th, float nnratio,
+                                  int32_t* matches12, int device) {
+  if (n1 < 0 || n2 < 0 || (n1 > 0 && (!ldesc1 || !matches12)) || (n2 > 0 && !ldesc2)) return PLH_ERR_INVALID;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  const int cap = std::max(n1, n2);
+  DevBuf d1, d2, dn, di, dd, dm;
+  PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(dn.alloc(8));
+  PLH_HIP(di.alloc((size_t)cap * 8)); PLH_HIP(dd.alloc((size_t)cap * 8)); PLH_HIP(dm.alloc((size_t)cap * 4));
+  const int32_t ns[2] = {n1, n2};
+  PLH_HIP(hipMemcpy(d1.p, ldesc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(d2.p, ldesc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
+  plh_status st = plh_hamming_knn2_batch_dev(d1.as<uint8_t>(), dn.as<int32_t>(), cap, d2.as<uint8_t>(), dn.as<int32_t>() + 1, cap, 1,
+                                             di.as<int32_t>(), dd.as<int32_t>(), nullptr);
+  if (st == PLH_OK)
+    st = plh_line_bfmatch_batch_dev(di.as<int32_t>(), dd.as<int32_t>(), dn.as<int32_t>(), dn.as<int32_t>() + 1, cap, 1, th, nnratio,
+                                    dm.as<int32_t>(), nullptr);
+  if (st != PLH_OK) return st;
+  PLH_HIP(hipDeviceSynchronize());
+  PLH_HIP(hipMemcpy(matches12, dm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  return PLH_OK;
+}
+
 // ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) on host buffers: see
 // plh_orb_search_for_triangulation_batch_dev.
 plh_status plh_orb_search_for_triangulation(const plh_keypoint* kps1, const uint8_t* desc1, const int32_t* node1, const uint8_t* has_mp1,

@@ -393,6 +393,63 @@ def _sim3_scene(P, seed, s12, n=600):
     return dict(K4=K4, gp=gp, k1=k1, d1=d1, k2=k2, d2=d2, T1=T1, T2=T2, R12=R12, t12=t12, pts1=pts1, pts2=pts2, has1=has1, has2=has2, pre=pre)
 
 
+def _line_fuse_scene(P, seed, n=500, nl=260, nc=400, behind_at=None):
+    """A KeyFrame with nl keylines (and n ORB rows) and nc candidate MapLines: most project onto a keyline (endpoints within a pixel,
+    predicted level = the keyline's octave, descriptor a few bits from the row the reference compares with -- the ORB row of the
+    line's index, LSDmatcher.cpp:963), the rest fail one of the gates.  behind_at: position in the list of a line with an endpoint
+    behind the camera (the reference returns there)."""
+    rng = np.random.RandomState(seed)
+    K4 = np.array([517.3, 516.5, 318.6, 255.3], np.float32)
+    gp = np.array([0.0, 0.0, 640.0, 480.0, 64 / 640.0, 48 / 480.0], np.float32)
+    kps = np.zeros(n, P.KP_DTYPE)
+    kps["x"], kps["y"] = rng.uniform(5, 635, n).astype(np.float32), rng.uniform(5, 475, n).astype(np.float32)
+    kps["octave"], kps["class_id"] = rng.randint(0, 8, n), -1
+    desc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    kl = np.zeros(nl, P.KL_DTYPE)
+    mx, my = rng.uniform(80, 560, nl), rng.uniform(80, 400, nl)
+    ang, half = rng.uniform(0, np.pi, nl), rng.uniform(20, 70, nl)
+    kl["startPointX"], kl["startPointY"] = mx - half * np.cos(ang), my - half * np.sin(ang)
+    kl["endPointX"], kl["endPointY"] = mx + half * np.cos(ang), my + half * np.sin(ang)
+    kl["pt_x"], kl["pt_y"] = (kl["startPointX"] + kl["endPointX"]) / 2, (kl["startPointY"] + kl["endPointY"]) / 2
+    kl["octave"], kl["lineLength"], kl["class_id"] = rng.randint(0, 3, nl), 2 * half, np.arange(nl)
+    kl["angle"] = ang
+    ldesc = rng.randint(0, 256, (nl, 32)).astype(np.uint8)
+    T = np.eye(4, dtype=np.float32)
+    R, t = _rot(0.04, -0.1, 0.02), np.array([0.2, -0.1, 0.4], np.float32)
+    T[:3, :3], T[:3, 3] = R, t
+    Ow = -(R.T @ t)
+    pos6, normal = np.zeros((nc, 6), np.float32), np.zeros((nc, 3), np.float32)
+    dmin, dmax, cdesc = np.zeros(nc, np.float32), np.zeros(nc, np.float32), np.zeros((nc, 32), np.uint8)
+    back = lambda u, v, z: R.T.astype(np.float64) @ (np.array([(u - K4[2]) / K4[0] * z, (v - K4[3]) / K4[1] * z, z]) - t)
+    for i in range(nc):
+        k = rng.randint(0, nl)
+        kind = rng.randint(0, 12)
+        j = rng.uniform(-1.0, 1.0, 4) * (1.0 if kind != 5 else 12.0)                # 5: direction off by more than acos(0.998)
+        z1, z2 = rng.uniform(2.0, 10.0), rng.uniform(2.0, 10.0)
+        u1, v1, u2, v2 = kl["startPointX"][k] + j[0], kl["startPointY"][k] + j[1], kl["endPointX"][k] + j[2], kl["endPointY"][k] + j[3]
+        if kind == 1: u1 += 900                                                     # start point outside the image
+        S3, E3 = back(u1, v1, z1), back(u2, v2, z2)
+        OM = 0.5 * (S3 + E3) - Ow
+        d = np.linalg.norm(OM)
+        pos6[i, :3], pos6[i, 3:] = S3, E3
+        normal[i] = OM / d if kind != 2 else -OM / d
+        lvl = int(kl["octave"][k]) + (1 if kind == 6 else 0)                        # 6: predicted level one above the keyline's
+        dmax[i] = d * 1.2 ** (lvl - 0.5) if kind != 3 else d * 0.5
+        dmin[i] = dmax[i] / 1.2 ** 8 * 0.8
+        dd = desc[k].copy()
+        for b in rng.randint(0, 256, rng.randint(0, 40 if kind != 4 else 160)):
+            dd[b >> 3] ^= 1 << (b & 7)
+        cdesc[i] = dd
+    order = np.r_[rng.permutation(nc), rng.randint(0, nc, 40), [-1, -1]].astype(np.int32)
+    rng.shuffle(order)
+    if behind_at is not None:
+        i = int(order[behind_at])
+        S3, E3 = back(300, 200, 3.0), back(320, 230, -2.0)
+        pos6[i, :3], pos6[i, 3:] = S3, E3
+    return dict(K4=K4, gp=gp, kps=kps, desc=desc, kl=kl, ldesc=ldesc, T=T, pos6=pos6, normal=normal, dmin=dmin, dmax=dmax, cdesc=cdesc,
+                order=order, rng=rng)
+
+
 def _backend_calls(P, S, path, tmp_path):
     G, R = _lib(path)
     p = lambda a: np.ascontiguousarray(a).ctypes.data_as(V)
@@ -456,6 +513,36 @@ def _backend_calls(P, S, path, tmp_path):
         assert (outs[0] == outs[2]).all(), "Fuse(Scw) seed %d: vpReplacePoint differs from the reference's" % seed
         assert (outs[1] == outs[3]).all(), "Fuse(Scw) seed %d: the KeyFrame's map points differ from the reference's" % seed
         assert (outs[0] != -1).sum() > 20 and (outs[1] >= 0).sum() > 20      # replacements proposed and points added
+    # ---- LocalMapping::CreateNewMapLines: LSDmatcher::SearchForTriangulation, both overloads
+    for seed, mode in ((71, 0), (72, 1), (73, 2)):
+        a, b, _ = S.make_descriptor_sets(seed, 300, flip_p=0.05)
+        rng = np.random.RandomState(seed)
+        k1, k2 = np.zeros(len(a), P.KL_DTYPE), np.zeros(len(b), P.KL_DTYPE)
+        h1, h2 = (rng.uniform(size=len(a)) < 0.3).astype(np.uint8), (rng.uniform(size=len(b)) < 0.3).astype(np.uint8)
+        o_ref, o_hip = np.zeros(len(a), np.int32), np.zeros(len(a), np.int32)
+        R.adx_local_mapping_line_triangulation.argtypes = [V, V, V, I, V, V, V, I, I, V, V, V]
+        nm = R.adx_local_mapping_line_triangulation(p(k1), p(a), p(h1), len(a), p(k2), p(b), p(h2), len(b), mode, p(o_ref), p(o_hip),
+                                                    C.byref(n_ref))
+        assert nm == n_ref.value and nm > 30, (seed, mode, nm, n_ref.value)
+        assert (o_ref == o_hip).all(), "LSDmatcher::SearchForTriangulation mode %d differs from the reference's" % mode
+    # ---- LocalMapping::SearchLineInNeighbors: LSDmatcher::Fuse(pKF, vpMapLines, th)
+    for seed, th, behind in ((81, 3.0, None), (82, 6.0, 380)):
+        sc = _line_fuse_scene(P, seed, behind_at=behind)
+        n, nl, nc = len(sc["kps"]), len(sc["kl"]), len(sc["pos6"])
+        rng = sc["rng"]
+        kf_obs = np.where(rng.uniform(size=nl) < 0.5, rng.randint(1, 6, nl), 0).astype(np.int32)
+        cand_obs = rng.randint(1, 6, nc).astype(np.int32)
+        outs = [np.zeros(nl, np.int32), np.zeros(nc, np.int32), np.zeros(nl, np.int32), np.zeros(nc, np.int32)]
+        R.adx_local_mapping_line_fuse.argtypes = [V, V, I, V, V, I, V, V, V, F, V, I, V, V, V, V, V, V, V, I, F, V, V, V, V, V]
+        nf = R.adx_local_mapping_line_fuse(p(sc["kps"]), p(sc["desc"]), n, p(sc["kl"]), p(sc["ldesc"]), nl, p(sc["gp"]), p(sc["T"]),
+                                           p(sc["K4"]), 1.2, p(kf_obs), nc, p(sc["pos6"]), p(sc["normal"]), p(sc["dmin"]), p(sc["dmax"]),
+                                           p(sc["cdesc"]), p(cand_obs), p(sc["order"]), len(sc["order"]), th, p(outs[0]), p(outs[1]),
+                                           p(outs[2]), p(outs[3]), C.byref(n_ref))
+        assert nf == n_ref.value, (seed, nf, n_ref.value)
+        assert (nf == 0) if behind is not None else (nf > 100), (seed, nf)      # `return false` after the line behind the camera
+        assert (outs[0] == outs[2]).all(), "LSDmatcher::Fuse seed %d: the KeyFrame's map lines differ from the reference's" % seed
+        assert (outs[1] == outs[3]).all(), "LSDmatcher::Fuse seed %d: isBad / IsInKeyFrame / Observations of the candidates differ" % seed
+        assert (outs[1] & 1).sum() > 10 and (outs[0] >= 0).sum() > 20                     # lines were replaced and added
     # ---- LoopClosing::ComputeSim3: SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)
     for seed, s12, th in ((61, 1.0, 7.5), (62, 1.4, 7.5), (63, 0.7, 3.0)):
         sc = _sim3_scene(P, seed, s12)
