@@ -541,11 +541,17 @@ __device__ __forceinline__ double lsd_chain_add(const GrowCtx& c, double acc, in
 
 // region2rect() + get_theta().  The weighted sums are accumulated in region order (lsd_chain_add) so the doubles
 // are bit-identical to the sequential reference; the extents are min/max (exact).
-// double sincos out of line: the library routine's argument reduction is register hungry, and k_lsd_grow's occupancy
-// is bounded by its VGPR count
+// cos / sin of the rectangle angle (theta in [0, 3 pi)): head + tail evaluation (plh_common.h), out of line (inlined twice it
+// costs the kernel registers it does not have): 60 instructions instead of the library routine's 153, 2 300 times per frame,
+// and as close to the host libm as the library routine is (either differs from glibc in 3.1 % of the values, by one unit in the
+// last place; line extractor 141.1 -> 139.3 ms per 6144 frames).
 __device__ __attribute__((noinline)) D2 lsd_sincos(double t) {
   D2 r;
-  sincos(t, &r.y, &r.x);   // x = cos, y = sin
+#if defined(PLH_LIB_SINCOS)
+  sincos(t, &r.y, &r.x);
+#else
+  sincos_head_tail(t, r.y, r.x);   // x = cos, y = sin
+#endif
   return r;
 }
 

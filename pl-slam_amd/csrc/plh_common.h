@@ -128,6 +128,37 @@ __device__ __forceinline__ void sincos_0_2pi(double ad, double& s, double& c) {
   s = (k & 2) ? -s0 : s0;
   c = ((k + 1) & 2) ? -c0 : c0;
 }
+// sin / cos of a double in [0, 3 pi] for results that stay doubles (region2rect's rectangle direction): reduction to head + tail
+// (x + y, the two-step form of the classic pi/2 reduction) and the classic kernels *with* the tail.  Against the host libm
+// (glibc) on 2^24 arguments of the form float-degrees x pi/180 (+ pi): 3.1 % of the values differ, by one unit in the last
+// place -- exactly the share by which the device library's sincos differs (tools/ubench/sincos_ulp.hip,
+// profiles/r03_sincos_ulp.txt); 60 instructions against the library's 153 + call.
+__device__ __forceinline__ void sincos_head_tail(double ad, double& s, double& c) {
+  const double kd = (double)(int)(ad * 0.63661977236758138 + 0.5);
+  const int k = (int)kd;
+  const double t = __builtin_fma(-kd, 1.57079632673412561417e+00, ad);   // 33-bit head of pi/2: exact
+  double w = kd * 6.07710050630396597660e-11;                            // next 33 bits
+  const double r = t - w;
+  w = __builtin_fma(kd, 2.02226624879595063154e-21, -((t - r) - w));     // the rest, and what the subtraction above lost
+  const double x = r - w;
+  const double y = (r - x) - w;
+  const double z = x * x, v = z * x;
+  const double rs = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sp = x - ((z * (0.5 * y - v * rs) - y) - v * -1.66666666666666324348e-01);
+  const double rc =
+      z * (4.16666666666666019037e-02 +
+           z * (-1.38888888888741095749e-03 +
+                z * (2.48015872894767294178e-05 +
+                     z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, ww = 1.0 - hz;
+  const double cp = ww + (((1.0 - ww) - hz) + (z * rc - x * y));
+  const bool swap = (k & 1) != 0;
+  const double s0 = swap ? cp : sp, c0 = swap ? sp : cp;
+  s = (k & 2) ? -s0 : s0;
+  c = ((k + 1) & 2) ? -c0 : c0;
+}
 __device__ __forceinline__ bool float_round_is_safe(double v) {
   unsigned long long u;
   __builtin_memcpy(&u, &v, 8);
