@@ -1729,13 +1729,14 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     c.hTag = (unsigned)s % 65535u + 1u;
     for (;;) {
       mw_acquire();
-      const unsigned seedRec = bcast_u32(c.P[seedLin], 0);
+      const unsigned seedRecL = c.P[seedLin], seedHintL = (unsigned)c.H[seedLin];   // one round trip for both
+      const unsigned seedRec = bcast_u32(seedRecL, 0);
       if (seedRec & LSD_USED) {   // swallowed by a committed region: certain, marks are never taken back once committed
         PF_ADD(c, 17, 1);
         break;
       }
       c.hWin = (unsigned)max(s - mw_ld_u(&ctl[MWC_HEAD]), 0);
-      if (grow_older_claim(c, bcast_u32((unsigned)c.H[seedLin], 0))) {
+      if (grow_older_claim(c, bcast_u32(seedHintL, 0))) {
         // an older transaction in flight holds the seed: predicted to be swallowed -- nothing to run, the commit checks
         PF_ADD(c, 28, 1);
         pFlags = 2u | 8u | ((unsigned)wv << 8) | (1u << 16);
