@@ -230,18 +230,16 @@ inline int SearchBySim3(const std::vector<cv::KeyPoint>& keysUn1, const cv::Mat&
   return nfound;
 }
 
-// ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) (ORBmatcher.cc:720-912): match12[i1] = feature of pKF2 or -1
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) (ORBmatcher.cc:720-912): F = F12 row-major;
+// match12[i1] = feature of pKF2 or -1
 inline int SearchForTriangulation(const std::vector<cv::KeyPoint>& keysUn1, const cv::Mat& desc1, const std::vector<int32_t>& node1,
                                   const std::vector<uchar>& hasMP1, const std::vector<cv::KeyPoint>& keysUn2, const cv::Mat& desc2,
-                                  const std::vector<int32_t>& node2, const std::vector<uchar>& hasMP2, const cv::Mat& F12, float ex, float ey,
+                                  const std::vector<int32_t>& node2, const std::vector<uchar>& hasMP2, const float F[9], float ex, float ey,
                                   const std::vector<float>& scaleFactors2, const std::vector<float>& levelSigma2_2, bool checkOri,
                                   std::vector<int>& match12, int TH_LOW = 50, int device = 0) {
   match12.assign(keysUn1.size(), -1);
   if (keysUn1.empty() || keysUn2.empty()) return 0;
   cv::Mat d1 = desc1.isContinuous() ? desc1 : desc1.clone(), d2 = desc2.isContinuous() ? desc2 : desc2.clone();
-  float F[9];
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) F[3 * r + c] = F12.at<float>(r, c);
   int nmatches = 0;
   check(plh_orb_search_for_triangulation(reinterpret_cast<const plh_keypoint*>(keysUn1.data()), d1.ptr<uchar>(), node1.data(), hasMP1.data(),
                                          (int)keysUn1.size(), reinterpret_cast<const plh_keypoint*>(keysUn2.data()), d2.ptr<uchar>(),

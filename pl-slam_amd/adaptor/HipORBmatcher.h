@@ -297,8 +297,11 @@ class ORBmatcher : public ORBmatcherCPU {
     for (int i = 0; i < pKF1->N; i++) has1[i] = pKF1->GetMapPoint(i) != NULL;
     for (int i = 0; i < pKF2->N; i++) has2[i] = pKF2->GetMapPoint(i) != NULL;
     std::vector<int> m12;
+    float F[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) F[3 * r + c] = F12.at<float>(r, c);
     const int n = hip::SearchForTriangulation(pKF1->mvKeysUn, pKF1->mDescriptors, hip::NodeOfFeature(pKF1->mFeatVec, pKF1->N), has1,
-                                              pKF2->mvKeysUn, pKF2->mDescriptors, hip::NodeOfFeature(pKF2->mFeatVec, pKF2->N), has2, F12, ex,
+                                              pKF2->mvKeysUn, pKF2->mDescriptors, hip::NodeOfFeature(pKF2->mFeatVec, pKF2->N), has2, F, ex,
                                               ey, pKF2->mvScaleFactors, pKF2->mvLevelSigma2, mbCheckOrientation, m12, TH_LOW);
     vMatchedPairs.reserve(n);
     for (size_t i = 0; i < m12.size(); i++)
