@@ -374,11 +374,11 @@ static int mw_waves_for(const plh_line* h, int batch) {
     if (e) forced = atoi(e);
   }
   if (forced >= 0) return forced == 1 ? 0 : std::min(forced, 16);
-  // measured on MI355X, 640 x 480 (tools/mw_sweep.py, profiles/r03_mw_sweep.txt): 1 frame 45 -> 16 ms with 8 wavefronts (16: the
-  // same), 512 frames 58 -> 28 ms with 8, 1024 frames 64 -> 41 ms with 4; from 2048 frames on one wavefront per frame is as fast
-  if (batch <= 8) return 16;   // a live tracker's frame: 13.5 -> 13.0 ms (profiles/r03_mw_lag_sweep.txt)
-  if (batch <= 512) return 8;
-  if (batch <= 1024) return 4;
+  // measured on MI355X, 640 x 480 (tools/mw_sweep.py, profiles/r03_mw_sweep.txt), region growing per launch: 1 frame 44.6 ms with
+  // one wavefront, 13.5 with 8, 12.9 with 16; 512 frames 58.0 -> 26.8 with 8 (16: 39.7); 1024 frames 64.5 -> 49.4 with 8 (4: 65.7);
+  // from 2048 frames on one wavefront per frame is as fast
+  if (batch <= 8) return 16;
+  if (batch <= 1024) return 8;
   return 0;
 }
 
