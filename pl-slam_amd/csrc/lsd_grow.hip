@@ -1496,10 +1496,23 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
     if (!inl && ((fl & 1u) || asmLen)) {
       const uint32_t* log = frameReg + (long long)wv * a.mwRegStride + bcast_u32(q1.y, 0);
       const int logLen = (int)bcast_u32(q1.z, 0), finBase = (int)bcast_u32(q1.w, 0), finCnt = (int)bcast_u32(q2.x, 0);
+      // a log of up to 64 pixels whose final region lies inside it (nearly all): every lane keeps its pixel's record from the
+      // validation, so that publishing is a store and not another two dependent fetches
+      const bool oneGo = logLen <= 64 && finBase + finCnt <= logLen;
+      uint32_t myIdx = 0;
+      unsigned myRec = 0;
+      if (oneGo && lane < logLen && (fl & 3u)) {
+        myIdx = pk_lin(ch, log[lane]);
+        myRec = ch.P[myIdx];
+      }
       if (fl & 2u) {
-        for (int base = 0; base < logLen; base += 64) {
-          const int i = base + lane;
-          if (i < logLen) bad = bad || (ch.P[pk_lin(ch, log[i])] & LSD_USED) != 0u;
+        if (oneGo) {
+          bad = lane < logLen && (myRec & LSD_USED) != 0u;
+        } else {
+          for (int base = 0; base < logLen; base += 64) {
+            const int i = base + lane;
+            if (i < logLen) bad = bad || (ch.P[pk_lin(ch, log[i])] & LSD_USED) != 0u;
+          }
         }
 #if defined(PLH_GROW_PROF)
         if (__ballot(bad) != 0ull) PF_ADD(ch, 29, 1);
@@ -1519,8 +1532,13 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
         bad = __ballot(bad || badA) != 0ull;
       }
       if (!bad) {
-        if (fl & 1u)
-          for (int i = lane; i < finCnt; i += 64) ch.P[pk_lin(ch, log[finBase + i])] |= LSD_USED;
+        if (fl & 1u) {
+          if (oneGo) {
+            if (lane >= finBase && lane < finBase + finCnt) ch.P[myIdx] = myRec | LSD_USED;
+          } else {
+            for (int i = lane; i < finCnt; i += 64) ch.P[pk_lin(ch, log[finBase + i])] |= LSD_USED;
+          }
+        }
         if ((fl & 4u) && lane == 0 && nseg < a.segCap) {
           segs[nseg * 4 + 0] = __uint_as_float(q2.y); segs[nseg * 4 + 1] = __uint_as_float(q2.z);
           segs[nseg * 4 + 2] = __uint_as_float(q2.w); segs[nseg * 4 + 3] = __uint_as_float(q3.x);
