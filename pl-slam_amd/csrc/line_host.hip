@@ -377,7 +377,8 @@ static int mw_waves_for(const plh_line* h, int batch) {
   // measured on MI355X, 640 x 480 (tools/mw_sweep.py, profiles/r03_mw_sweep.txt), region growing per launch: 1 frame 44.6 ms with
   // one wavefront, 13.5 with 8, 12.9 with 16; 512 frames 58.0 -> 26.8 with 8 (16: 39.7); 1024 frames 64.5 -> 49.4 with 8 (4: 65.7);
   // from 2048 frames on one wavefront per frame is as fast
-  if (batch <= 8) return 16;
+  // (16 wavefronts: 12.9 ms of region growing for a lone frame, but 14.2 against 13.9 ms in the tracker's call, where the ORB
+  // extractor's kernels run beside it: profiles/r03_bench_full.json history)
   if (batch <= 1024) return 8;
   return 0;
 }
