@@ -1748,6 +1748,13 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     for (;;) {
       mw_acquire();
       const unsigned seedRecL = c.P[seedLin], seedHintL = (unsigned)c.H[seedLin];   // one round trip for both
+      // ... and for the committed records of the seed's eight neighbours (lanes 0 - 7), see below
+      unsigned nbRec = 0u;
+      {
+        const int k = (lane & 7) + ((lane & 7) >= 4 ? 1 : 0);   // 0 .. 8 without the centre
+        const int nx = pk_x(seedPk) + k % 3 - 1, ny = pk_y(seedPk) + k / 3 - 1;
+        if (lane < 8 && nx >= 0 && ny >= 0 && nx < c.sw && ny < c.sh) nbRec = c.P[__umul24((unsigned)ny, (unsigned)c.spitch) + (unsigned)nx];
+      }
       const unsigned seedRec = bcast_u32(seedRecL, 0);
       if (seedRec & LSD_USED) {   // swallowed by a committed region: certain, marks are never taken back once committed
         PF_ADD(c, 17, 1);
@@ -1759,6 +1766,19 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
         PF_ADD(c, 28, 1);
         pFlags = 2u | 8u | ((unsigned)wv << 8) | (1u << 16);
         pMode = 1;
+        break;
+      }
+      if (wballot(rec_is_candidate(nbRec)) == 0ull) {
+        // No neighbour of the seed is both defined and free in the COMMITTED map (2 200 of a frame's 8 200 regions): region_grow()
+        // can accept nothing, whatever the angles, and nothing can change that -- committed marks stay, undefined pixels stay
+        // undefined.  The region is the seed alone and is dropped for its size: post exactly that, without running it.  (The commit
+        // still checks that the seed itself has not been taken by an older transaction, like for any other accepted pixel.)
+        PF_ADD(c, 36, 1);
+        if (lane == 0) { c.ring[0] = seedPk; c.H[seedLin] = (uint16_t)c.hTag; }
+        PLH_WAVE_SYNC();
+        pAcc = 1; pAsm = 0;
+        pFlags = 1u | (spec ? 2u : 0u) | 8u | ((unsigned)wv << 8) | (1u << 24);
+        pMode = 2;
         break;
       }
       const unsigned long long pt0 = PF_NOW();
