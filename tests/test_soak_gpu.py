@@ -83,11 +83,13 @@ def _oracle_all(O, frames, nfeat):
         return list(ex.map(one, list(frames)))
 
 
-def _gpu_lines(P, frames, waves, lib=None):
+def _gpu_lines(P, frames, waves, lib=None, refine=0):
     import torch
     B, rows, cols = frames.shape
     ex = P.LINEextractor(1, 1.2, 200, 0.0, rows=rows, cols=cols, max_batch=B, lib=lib)
     ex.set_grow_waves(waves)
+    if refine:
+        ex.set_refine(refine)
     cap = ex.capacity
     dev = torch.device("cuda", 0)
     d_img = torch.from_numpy(frames).to(dev)
@@ -159,3 +161,25 @@ def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat):
                                                              out[16], out[18], out[24]))
     print("\nsoak %dx%d: %d distinct frames, %d LSD segments and %d ORB keypoints bit-exact (waves 0 / auto / 4)\n%s"
           % (cols, rows, N_SOAK, nseg, nkp, cover))
+
+
+def test_soak_refine_adv(plslam, oracle, synth):
+    """The same kind of content with cv::LSD_REFINE_ADV (rect_improve / rect_nfa / nfa on every kept rectangle): 128 distinct
+    640x480 frames, one wavefront per frame and the automatic multi-wavefront choice, against the oracle's ADV restatement."""
+    n = min(N_SOAK, 128)
+    frames = soak_frames(synth, 480, 640, n)
+
+    def one(img):
+        kl, ld, fn = oracle.line_extract(img, 200, 0.0, refine=1)
+        return kl, ld, fn, oracle.lsd_detect(img, refine=1), len(oracle.lsd_detect(img))
+    with ThreadPoolExecutor(os.cpu_count() or 1) as ex:
+        ref = list(ex.map(one, list(frames)))
+    nadv, nstd = sum(len(r[3]) for r in ref), sum(r[4] for r in ref)
+    assert 0 < nadv < nstd                      # the NFA gate does remove rectangles on this content
+    for waves in (0, -1):
+        got = _gpu_lines(plslam, frames, waves, refine=1)
+        for b, ((kl, ld, fn, sg), r) in enumerate(zip(got, ref)):
+            assert len(sg) == len(r[3]) and (sg == r[3]).all(), "ADV, waves %d, frame %d: LSD segments differ from the oracle" % (waves, b)
+            assert len(kl) == len(r[0]) and all((kl[f] == r[0][f]).all() for f in r[0].dtype.names), "ADV, waves %d, frame %d: KeyLines" % (waves, b)
+            assert (ld == r[1]).all() and (fn == r[2]).all(), "ADV, waves %d, frame %d: LBD / line equations" % (waves, b)
+    print("\nsoak LSD_REFINE_ADV 640x480: %d distinct frames, %d segments (STD: %d) bit-exact (waves 0 / auto)" % (n, nadv, nstd))
