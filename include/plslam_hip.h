@@ -462,7 +462,19 @@ PLH_API plh_status plh_line_search_by_projection_ml(const plh_keyline* kl, const
                                                     const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned,
                                                     int* nmatches, int device);
 
-/* Back-end searches, host-buffer forms (LoopClosing / LocalMapping call sites; arrays as in the *_batch_dev forms). */
+/* Back-end searches, host-buffer forms: one call = the search of one reference call (arrays as in the *_batch_dev forms above;
+ * stage over PCIe, block until done).  What each replaces, and who calls it in the reference:
+ *   plh_orb_search_by_bow_kfkf         ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)      src/ORBmatcher.cc:574-709    LoopClosing.cc:282
+ *   plh_orb_search_for_triangulation   ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, pairs, false) :720-912 (+ :154-173)      LocalMapping.cc:385
+ *   plh_orb_fuse_search                the search inside ORBmatcher::Fuse(pKF, vpMapPoints, th)          :914-1061                  LocalMapping.cc:1545, 1573
+ *                                      and Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (NULL sigma2)   :1063-1197                 LoopClosing.cc:595
+ *   plh_orb_search_by_projection_sim3  ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) :329-453                   LoopClosing.cc:360
+ *   plh_orb_search_by_sim3             ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) :1199-1439              LoopClosing.cc:327
+ *   plh_orb_search_by_projection_kf    ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) :1587-1716    Tracking::Relocalization
+ *   plh_line_frame_bfmatch             LSDmatcher::FrameBFMatch(ldesc1, ldesc2, LineMatches, TH)   src/LSDmatcher.cpp:462-486       (SearchForTriangulation, isDouble = false)
+ *   plh_line_fuse_search               the search inside LSDmatcher::Fuse(pKF, vpMapLines, th)           :860-1002                  LocalMapping.cc:1600, 1627
+ * (LSDmatcher::SearchForTriangulation's mutual forms, :672-778, are plh_line_search_double at TH_LOW / TH_HIGH.)
+ * The adaptor overloads that keep the reference's signatures around them: pl-slam_amd/adaptor/HipORBmatcher.h, HipLSDmatcher.h. */
 PLH_API plh_status plh_orb_search_by_bow_kfkf(const plh_keypoint* kps1, const uint8_t* desc1, const int32_t* node1,
                                               const uint8_t* valid1, int n1, const plh_keypoint* kps2, const uint8_t* desc2,
                                               const int32_t* node2, const uint8_t* valid2, int n2, int th_low, float nnratio,
