@@ -141,7 +141,14 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
   plh_frontend* fe = new (std::nothrow) plh_frontend();
   if (!fe) return PLH_ERR_ALLOC;
   fe->p = *p; fe->voc = voc; fe->device = device; fe->batch = batch; fe->nsplit = nsplit; fe->Bp = batch / nsplit;
-  fe->parts.resize(nsplit);
+  try {   // nothing may throw across the C ABI: the host containers are sized here, once
+    fe->parts.resize(nsplit);
+    fe->allocs.reserve((size_t)nsplit * 20);
+  } catch (const std::bad_alloc&) {
+    delete fe;
+    set_error("plh_frontend_create: out of host memory");
+    return PLH_ERR_ALLOC;
+  }
   FE_HIP(hipEventCreateWithFlags(&fe->evStart, hipEventDisableTiming));
   int prLo = 0, prHi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);   // (least, greatest): greatest is the numerically lower one
