@@ -631,6 +631,11 @@ PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs
 #define PLH_LSD_REFINE_STD 0
 #define PLH_LSD_REFINE_ADV 1
 PLH_API plh_status plh_line_set_refine(plh_line* h, int level);
+/* Scheduling hooks around the region-growing launch of the following plh_line_extract_batch_dev calls (hipEvent_t, owned by the
+ * caller, NULL = none): the launch waits for wait_before; record_after is recorded behind it.  No counterpart in the reference
+ * (Frame.cc:224-227 runs its two extractors on two threads); used by plh_frontend_* for small resident batches. */
+PLH_API plh_status plh_line_set_grow_events(plh_line* h, void* wait_before, void* record_after);
+
 /* Wavefronts per frame of LSD's region growing (cv::LineSegmentDetector's region_grow / refine loop, the sequential core
  * of LINEextractor::operator(), LineExtractor.cpp:40).  -1 (default): by batch size -- small batches (the per-frame call of
  * Frame.cc:224-227) run several wavefronts per frame as optimistic transactions with in-order commit, large batches one

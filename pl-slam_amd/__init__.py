@@ -110,6 +110,7 @@ _SIGS = {
     "plh_line_extract": ([_V, _V, _I, _I, _Z, _V, _V, _V, _V, _I, _V], _I),
     "plh_line_extract_batch_dev": ([_V, _V, _I, _Z, _V, _V, _V, _V, _V, _V], _I),
     "plh_line_read_segments": ([_V, _I, _V, _I, _V], _I),
+    "plh_line_set_grow_events": ([_V, _V, _V], _I),
     "plh_line_set_grow_waves": ([_V, _I], _I),
     "plh_line_set_refine": ([_V, _I], _I),
     "plh_orb_search_by_bow_kfkf": ([_V, _V, _V, _V, _I, _V, _V, _V, _V, _I, _I, _F, _I, _V, _V, _I], _I),

@@ -35,8 +35,8 @@ struct Part {
   int32_t *mLine = nullptr, *nmLine = nullptr;
   void* ws = nullptr; size_t wsBytes = 0;
   hipStream_t sLine = nullptr, sOrb = nullptr;
-  hipEvent_t evOrb = nullptr, evLine = nullptr, evFree = nullptr;
-  bool freeValid = false, ran = false;
+  hipEvent_t evOrb = nullptr, evLine = nullptr, evFree = nullptr, evGrow = nullptr;
+  bool freeValid = false, ran = false, growValid = false;
 };
 
 }  // namespace
@@ -47,6 +47,7 @@ struct plh_frontend {
   int device = 0, batch = 0, nsplit = 0, Bp = 0;
   bool overlap = true;
   std::vector<Part> parts;
+  bool around = false;   // small resident batch: the ORB chain runs around region growing, not underneath it (see plh_frontend_step)
   hipEvent_t evStart = nullptr;
   std::vector<void*> allocs;
 };
@@ -77,6 +78,7 @@ plh_status enqueue_line(plh_frontend* fe, Part& pt, const uint8_t* imgs, size_t 
   const int B = pt.B;
   plh_status st = plh_line_extract_batch_dev(pt.line, imgs, B, stride, nullptr, pt.kl, pt.ldesc, pt.lfn, pt.nl, s);
   if (st != PLH_OK) return st;
+  pt.growValid = fe->around && fe->overlap;
   // slot B := frame 0
   PLH_HIP(hipMemcpyAsync(pt.kl + (size_t)B * pt.lcap, pt.kl, (size_t)pt.lcap * sizeof(plh_keyline), hipMemcpyDeviceToDevice, s));
   PLH_HIP(hipMemcpyAsync(pt.ldesc + (size_t)B * pt.lcap * 32, pt.ldesc, (size_t)pt.lcap * 32, hipMemcpyDeviceToDevice, s));
@@ -92,6 +94,7 @@ plh_status enqueue_orb(plh_frontend* fe, Part& pt, const uint8_t* imgs, size_t s
   hipStream_t s = fe->overlap ? pt.sOrb : main;
   if (fe->overlap) PLH_HIP(hipStreamWaitEvent(s, fe->evStart, 0));
   if (pt.freeValid) PLH_HIP(hipStreamWaitEvent(s, pt.evFree, 0));
+  if (fe->around && fe->overlap && pt.growValid) PLH_HIP(hipStreamWaitEvent(s, pt.evGrow, 0));   // behind the previous step's region growing
   const int B = pt.B;
   plh_status st = plh_orb_extract_batch_dev(pt.orb, imgs, B, stride, pt.kps, pt.desc, pt.n, s);
   if (st != PLH_OK) return st;
@@ -122,7 +125,7 @@ plh_status plh_frontend_destroy(plh_frontend* fe) {
     if (pt.line) plh_line_destroy(pt.line);
     if (pt.sLine) (void)hipStreamDestroy(pt.sLine);
     if (pt.sOrb) (void)hipStreamDestroy(pt.sOrb);
-    for (hipEvent_t e : {pt.evOrb, pt.evLine, pt.evFree})
+    for (hipEvent_t e : {pt.evOrb, pt.evLine, pt.evFree, pt.evGrow})
       if (e) (void)hipEventDestroy(e);
   }
   for (void* p : fe->allocs) (void)hipFree(p);
@@ -160,6 +163,7 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     if (p->undistort) FE_TRY(plh_line_set_undistort(pt.line, p->K, p->D));
     // the wavefronts per frame of LSD's region growing go by the frames resident in ALL sub-batches (they run together)
     if (batch >= 2048) FE_TRY(plh_line_set_grow_waves(pt.line, 0));
+    fe->around = batch <= 1024;   // (where plh_line runs several wavefronts per frame: mw_waves_for in line_host.hip)
     pt.ocap = plh_orb_capacity(pt.orb); pt.lcap = plh_line_capacity(pt.line);
     const size_t B1 = (size_t)pt.B + 1, oc = (size_t)pt.ocap, lc = (size_t)pt.lcap;
     FE_TRY(dev_alloc(fe, &pt.valid, (size_t)pt.B * oc, true));
@@ -183,6 +187,8 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     FE_HIP(hipEventCreateWithFlags(&pt.evOrb, hipEventDisableTiming));
     FE_HIP(hipEventCreateWithFlags(&pt.evLine, hipEventDisableTiming));
     FE_HIP(hipEventCreateWithFlags(&pt.evFree, hipEventDisableTiming));
+    FE_HIP(hipEventCreateWithFlags(&pt.evGrow, hipEventDisableTiming));
+    if (fe->around) FE_TRY(plh_line_set_grow_events(pt.line, pt.evOrb, pt.evGrow));
   }
   *out = fe;
   return PLH_OK;
@@ -252,6 +258,22 @@ plh_status plh_frontend_step(plh_frontend* fe, const uint8_t* d_imgs, size_t fra
   PLH_HIP(hipSetDevice(fe->device));
   hipStream_t main = (hipStream_t)stream;
   PLH_HIP(hipEventRecord(fe->evStart, main));
+  if (fe->around) {
+    // Small resident batch: region growing runs several wavefronts per frame (k_lsd_grow_mw) whose 128-register build fills the
+    // register file of every SIMD, so nothing runs beside it (measured: two streams = one stream).  The ORB chain of a step is
+    // therefore placed AROUND region growing: it starts behind the previous step's region growing -- next to that step's
+    // KeyLine / LBD tail and this step's image preparation, which do share the GPU -- and this step's region growing waits for it.
+    for (Part& pt : fe->parts) {
+      const plh_status st = enqueue_orb(fe, pt, d_imgs + (size_t)pt.first * frame_stride, frame_stride, main);
+      if (st != PLH_OK) return st;
+      pt.ran = true;
+    }
+    for (Part& pt : fe->parts) {
+      const plh_status st = enqueue_line(fe, pt, d_imgs + (size_t)pt.first * frame_stride, frame_stride, main);
+      if (st != PLH_OK) return st;
+    }
+    return join ? plh_frontend_join(fe, stream) : PLH_OK;
+  }
   // the critical-path (line) chains of all sub-batches first, then the ORB chains
   for (Part& pt : fe->parts) {
     const plh_status st = enqueue_line(fe, pt, d_imgs + (size_t)pt.first * frame_stride, frame_stride, main);

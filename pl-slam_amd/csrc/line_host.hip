@@ -76,6 +76,7 @@ struct plh_line {
   int growWaves = -1;          // plh_line_set_grow_waves
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
+  hipEvent_t growGate = nullptr, growDone = nullptr;   // caller's events around the region-growing launch (plh_line_set_grow_events)
   hipEvent_t doneEv = nullptr;   // recorded behind the last kernel of every extract call: plh_line_status (and a workspace
                                  // re-allocation) waits on it -- the caller's stream may be gone by then
   bool doneValid = false;
@@ -423,6 +424,17 @@ static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int wave
   return PLH_OK;
 }
 
+// A scheduler's hooks around the region-growing launch of the next plh_line_extract_batch_dev calls (events owned by the caller,
+// NULL = none): the launch waits for `wait_before`, `record_after` is recorded behind it.  plh_frontend uses them for small resident
+// batches, where the multi-wavefront kernel fills every SIMD's register file and nothing can run beside it: the ORB chain is
+// placed around region growing instead of underneath it.
+plh_status plh_line_set_grow_events(plh_line* h, void* wait_before, void* record_after) {
+  if (!h) return PLH_ERR_INVALID;
+  h->growGate = (hipEvent_t)wait_before;
+  h->growDone = (hipEvent_t)record_after;
+  return PLH_OK;
+}
+
 plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride, const uint8_t* d_mask,
                                       plh_keyline* d_keylines, uint8_t* d_desc, double* d_linefn, int32_t* d_n, void* stream) {
   if (!h || !d_imgs || !d_keylines || !d_desc || !d_linefn || !d_n || batch <= 0 || batch > h->maxBatch ||
@@ -466,8 +478,10 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   PLH_LAUNCH_CHECK();
   line_prof_mark(h, 0, s);
   line_prof_mark(h, 1, s);
+  if (h->growGate) PLH_HIP(hipStreamWaitEvent(s, h->growGate, 0));
   launch_lsd_grow(a, s);
   PLH_LAUNCH_CHECK();
+  if (h->growDone) PLH_HIP(hipEventRecord(h->growDone, s));
   line_prof_mark(h, 1, s);
   line_prof_mark(h, 2, s);
   launch_keylines(a, d_keylines, d_linefn, d_n, s);
