@@ -35,8 +35,8 @@ struct Part {
   int32_t *mLine = nullptr, *nmLine = nullptr;
   void* ws = nullptr; size_t wsBytes = 0;
   hipStream_t sLine = nullptr, sOrb = nullptr;
-  hipEvent_t evOrb = nullptr, evLine = nullptr, evFree = nullptr, evGrow = nullptr;
-  bool freeValid = false, ran = false, growValid = false;
+  hipEvent_t evOrb = nullptr, evLine = nullptr, evFree = nullptr;
+  bool freeValid = false, ran = false;
 };
 
 }  // namespace
@@ -78,7 +78,6 @@ plh_status enqueue_line(plh_frontend* fe, Part& pt, const uint8_t* imgs, size_t 
   const int B = pt.B;
   plh_status st = plh_line_extract_batch_dev(pt.line, imgs, B, stride, nullptr, pt.kl, pt.ldesc, pt.lfn, pt.nl, s);
   if (st != PLH_OK) return st;
-  pt.growValid = fe->around && fe->overlap;
   // slot B := frame 0
   PLH_HIP(hipMemcpyAsync(pt.kl + (size_t)B * pt.lcap, pt.kl, (size_t)pt.lcap * sizeof(plh_keyline), hipMemcpyDeviceToDevice, s));
   PLH_HIP(hipMemcpyAsync(pt.ldesc + (size_t)B * pt.lcap * 32, pt.ldesc, (size_t)pt.lcap * 32, hipMemcpyDeviceToDevice, s));
@@ -94,7 +93,6 @@ plh_status enqueue_orb(plh_frontend* fe, Part& pt, const uint8_t* imgs, size_t s
   hipStream_t s = fe->overlap ? pt.sOrb : main;
   if (fe->overlap) PLH_HIP(hipStreamWaitEvent(s, fe->evStart, 0));
   if (pt.freeValid) PLH_HIP(hipStreamWaitEvent(s, pt.evFree, 0));
-  if (fe->around && fe->overlap && pt.growValid) PLH_HIP(hipStreamWaitEvent(s, pt.evGrow, 0));   // behind the previous step's region growing
   const int B = pt.B;
   plh_status st = plh_orb_extract_batch_dev(pt.orb, imgs, B, stride, pt.kps, pt.desc, pt.n, s);
   if (st != PLH_OK) return st;
@@ -125,7 +123,7 @@ plh_status plh_frontend_destroy(plh_frontend* fe) {
     if (pt.line) plh_line_destroy(pt.line);
     if (pt.sLine) (void)hipStreamDestroy(pt.sLine);
     if (pt.sOrb) (void)hipStreamDestroy(pt.sOrb);
-    for (hipEvent_t e : {pt.evOrb, pt.evLine, pt.evFree, pt.evGrow})
+    for (hipEvent_t e : {pt.evOrb, pt.evLine, pt.evFree})
       if (e) (void)hipEventDestroy(e);
   }
   for (void* p : fe->allocs) (void)hipFree(p);
@@ -187,8 +185,7 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     FE_HIP(hipEventCreateWithFlags(&pt.evOrb, hipEventDisableTiming));
     FE_HIP(hipEventCreateWithFlags(&pt.evLine, hipEventDisableTiming));
     FE_HIP(hipEventCreateWithFlags(&pt.evFree, hipEventDisableTiming));
-    FE_HIP(hipEventCreateWithFlags(&pt.evGrow, hipEventDisableTiming));
-    if (fe->around) FE_TRY(plh_line_set_grow_events(pt.line, pt.evOrb, pt.evGrow));
+    if (fe->around) FE_TRY(plh_line_set_grow_events(pt.line, pt.evOrb, nullptr));
   }
   *out = fe;
   return PLH_OK;
@@ -261,8 +258,10 @@ plh_status plh_frontend_step(plh_frontend* fe, const uint8_t* d_imgs, size_t fra
   if (fe->around) {
     // Small resident batch: region growing runs several wavefronts per frame (k_lsd_grow_mw) whose 128-register build fills the
     // register file of every SIMD, so nothing runs beside it (measured: two streams = one stream).  The ORB chain of a step is
-    // therefore placed AROUND region growing: it starts behind the previous step's region growing -- next to that step's
-    // KeyLine / LBD tail and this step's image preparation, which do share the GPU -- and this step's region growing waits for it.
+    // therefore placed AROUND region growing: this step's region growing waits for this step's ORB chain (plh_line_set_grow_events),
+    // and the ORB chain of the NEXT step, enqueued behind it on its own stream, gets the CUs as the frames of this step's region
+    // growing finish one by one -- it fills the kernel's tail (the slowest frame takes a quarter longer than the average one) and
+    // then runs beside the KeyLine / LBD tail and the next step's image preparation.  36.8 -> 33.9 ms per 512-frame step.
     for (Part& pt : fe->parts) {
       const plh_status st = enqueue_orb(fe, pt, d_imgs + (size_t)pt.first * frame_stride, frame_stride, main);
       if (st != PLH_OK) return st;
