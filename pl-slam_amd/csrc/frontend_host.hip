@@ -35,8 +35,8 @@ struct Part {
   int32_t *mLine = nullptr, *nmLine = nullptr;
   void* ws = nullptr; size_t wsBytes = 0;
   hipStream_t sLine = nullptr, sOrb = nullptr;
-  hipEvent_t evOrb = nullptr, evLine = nullptr, evFree = nullptr;
-  bool freeValid = false, ran = false;
+  hipEvent_t evOrb = nullptr, evLine = nullptr, evFree = nullptr, evFreeOrb = nullptr;   // evFree: the line records (or all) are gathered
+  bool freeValid = false, freeOrbValid = false, ran = false;
 };
 
 }  // namespace
@@ -92,7 +92,8 @@ plh_status enqueue_line(plh_frontend* fe, Part& pt, const uint8_t* imgs, size_t 
 plh_status enqueue_orb(plh_frontend* fe, Part& pt, const uint8_t* imgs, size_t stride, hipStream_t main) {
   hipStream_t s = fe->overlap ? pt.sOrb : main;
   if (fe->overlap) PLH_HIP(hipStreamWaitEvent(s, fe->evStart, 0));
-  if (pt.freeValid) PLH_HIP(hipStreamWaitEvent(s, pt.evFree, 0));
+  if (pt.freeOrbValid) PLH_HIP(hipStreamWaitEvent(s, pt.evFreeOrb, 0));   // the ORB records were gathered on their own (below)
+  else if (pt.freeValid) PLH_HIP(hipStreamWaitEvent(s, pt.evFree, 0));
   const int B = pt.B;
   plh_status st = plh_orb_extract_batch_dev(pt.orb, imgs, B, stride, pt.kps, pt.desc, pt.n, s);
   if (st != PLH_OK) return st;
@@ -123,7 +124,7 @@ plh_status plh_frontend_destroy(plh_frontend* fe) {
     if (pt.line) plh_line_destroy(pt.line);
     if (pt.sLine) (void)hipStreamDestroy(pt.sLine);
     if (pt.sOrb) (void)hipStreamDestroy(pt.sOrb);
-    for (hipEvent_t e : {pt.evOrb, pt.evLine, pt.evFree})
+    for (hipEvent_t e : {pt.evOrb, pt.evLine, pt.evFree, pt.evFreeOrb})
       if (e) (void)hipEventDestroy(e);
   }
   for (void* p : fe->allocs) (void)hipFree(p);
@@ -185,6 +186,7 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     FE_HIP(hipEventCreateWithFlags(&pt.evOrb, hipEventDisableTiming));
     FE_HIP(hipEventCreateWithFlags(&pt.evLine, hipEventDisableTiming));
     FE_HIP(hipEventCreateWithFlags(&pt.evFree, hipEventDisableTiming));
+    FE_HIP(hipEventCreateWithFlags(&pt.evFreeOrb, hipEventDisableTiming));
     if (fe->around) FE_TRY(plh_line_set_grow_events(pt.line, pt.evOrb, nullptr));
   }
   *out = fe;
@@ -292,10 +294,6 @@ plh_status plh_frontend_gather(plh_frontend* fe, plh_comm* comm, int root, void*
   hipStream_t cs = (hipStream_t)comm_stream;
   int part = 0;
   for (Part& pt : fe->parts) {
-    if (fe->overlap) {
-      PLH_HIP(hipStreamWaitEvent(cs, pt.evLine, 0));
-      PLH_HIP(hipStreamWaitEvent(cs, pt.evOrb, 0));
-    }
     const size_t B = (size_t)pt.B;
     plh_gather_block blk[PLH_FRONTEND_GATHERED];
     const void* snd[PLH_FRONTEND_GATHERED] = {pt.n, pt.kps, pt.desc, pt.nl, pt.kl, pt.ldesc, pt.lfn};
@@ -306,8 +304,26 @@ plh_status plh_frontend_gather(plh_frontend* fe, plh_comm* comm, int root, void*
       blk[k].recv = recv ? recv[part * PLH_FRONTEND_GATHERED + k] : nullptr;
       blk[k].bytes = bytes[k];
     }
-    const plh_status st = plh_gather_records(comm, blk, PLH_FRONTEND_GATHERED, root, comm_stream);
-    if (st != PLH_OK) return st;
+    if (fe->around && fe->overlap) {
+      // small resident batch: the next step's ORB chain has to start while this step's region growing is still running (it
+      // fills that kernel's tail, plh_frontend_step), so the ORB records go in a launch of their own as soon as they exist
+      PLH_HIP(hipStreamWaitEvent(cs, pt.evOrb, 0));
+      plh_status st = plh_gather_records(comm, blk, 3, root, comm_stream);
+      if (st != PLH_OK) return st;
+      PLH_HIP(hipEventRecord(pt.evFreeOrb, cs));
+      pt.freeOrbValid = true;
+      PLH_HIP(hipStreamWaitEvent(cs, pt.evLine, 0));
+      st = plh_gather_records(comm, blk + 3, PLH_FRONTEND_GATHERED - 3, root, comm_stream);
+      if (st != PLH_OK) return st;
+    } else {
+      if (fe->overlap) {
+        PLH_HIP(hipStreamWaitEvent(cs, pt.evLine, 0));
+        PLH_HIP(hipStreamWaitEvent(cs, pt.evOrb, 0));
+      }
+      const plh_status st = plh_gather_records(comm, blk, PLH_FRONTEND_GATHERED, root, comm_stream);
+      if (st != PLH_OK) return st;
+      pt.freeOrbValid = false;
+    }
     PLH_HIP(hipEventRecord(pt.evFree, cs));   // this sub-batch's next step waits for its own gather only
     pt.freeValid = true;
     part++;
