@@ -527,6 +527,17 @@ def main():
             "launches": args.nsplit, "achieved": round(alg[dom] * B / (dt / args.steps) / 1e9, 1), "unit": "GB/s",
             "frac": round(alg[dom] * B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
             "what": "algorithmic bytes of the dominant kernel over a whole step / ms_per_step (lower bound of its share of the step)"}
+        if NAMES[dom] in insts:
+            # what the dominant kernel is actually bound by: the instructions its wavefronts issue.  All of a step's
+            # launches of it over the step time, against the VALU issue peak; `wait_share` = s_waitcnt cycles / wave cycles (SQ counters)
+            i_d = insts[NAMES[dom]]
+            gi = i_d["valu"] * B / (dt / args.steps) / 1e9
+            r_dom["valu_issue"] = {"achieved": round(gi, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+                                   "frac": round(gi / VALU_PEAK_GINST, 4), "valu_wave_instructions_per_frame": i_d["valu"],
+                                   "salu_wave_instructions_per_frame": i_d.get("salu"),
+                                   "wait_share_lone_wavefronts": round(i_d["wait_any"] / i_d["wave_cycles"], 3) if i_d.get("wave_cycles") else None,
+                                   "what": "the kernel's VALU wave-instructions of a whole step / ms_per_step; the whole front end issues "
+                                           "%.2f M VALU per frame" % (ij.get("total_valu", 0) / 1e6)}
         r_fast = roof(1, per_ms[1], "HIP events, extra pass after the timed region with both halves on one stream")
         if "k_fast_strips" in insts and per_ms[1] > 0:
             # the bound this kernel actually runs against: VALU issue: wave64 VALU instructions per second against
@@ -563,6 +574,12 @@ def main():
             "roofline": r_dom,
             "roofline_fast": r_fast,
             "pmc_provenance": pmc_note,
+            "front_end_valu_issue": ({"achieved": round(ij["total_valu"] * world * B * args.steps / dt / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1),
+                                      "unit": "G wave-instructions/s", "frac": round(ij["total_valu"] * B * args.steps / dt / 1e9 / VALU_PEAK_GINST, 4),
+                                      "valu_wave_instructions_per_frame": ij["total_valu"],
+                                      "what": "all kernels' VALU wave-instructions per frame (SQ counters of this build) x frames/s per GPU "
+                                              "against 1024 SIMDs x 2.4 GHz / 4.2 cycles: how close the front end runs to its own instruction floor"}
+                                     if insts and ij.get("total_valu") else None),
             "verified": verified,
         }
         if gathering:
