@@ -630,7 +630,19 @@ PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs
  * published for 3.x.  A maintainer picks the one his OpenCV build uses. */
 #define PLH_LSD_REFINE_STD 0
 #define PLH_LSD_REFINE_ADV 1
+/* What a new handle starts with.  Chosen when the library is BUILT (-DPLH_LSD_REFINE_DEFAULT=PLH_LSD_REFINE_ADV), so that a
+ * drop-in for a reference build whose OpenCV runs LSD_REFINE_ADV does not inherit STD unknowingly;
+ * plh_lsd_refine_default() reports the choice of the loaded library. */
+#ifndef PLH_LSD_REFINE_DEFAULT
+#define PLH_LSD_REFINE_DEFAULT PLH_LSD_REFINE_STD
+#endif
+PLH_API int plh_lsd_refine_default(void);
 PLH_API plh_status plh_line_set_refine(plh_line* h, int level);
+/* The density screen of region growing (on by default): the density decisions of refine() / reduce_region_radius() are taken
+ * from a float bracket of the rectangle's density whenever the bracket is clear, the exact rectangle is evaluated only when it
+ * straddles the threshold or is itself needed.  on = 0 evaluates the exact rectangle for every decision: identical segments
+ * (asserted by the tests), the instruction stream of rounds 1-3 -- an A/B and test switch, no counterpart in the reference. */
+PLH_API plh_status plh_line_set_screen(plh_line* h, int on);
 /* Scheduling hooks around the region-growing launch of the following plh_line_extract_batch_dev calls (hipEvent_t, owned by the
  * caller, NULL = none): the launch waits for wait_before; record_after is recorded behind it.  No counterpart in the reference
  * (Frame.cc:224-227 runs its two extractors on two threads); used by plh_frontend_* for small resident batches. */
@@ -641,6 +653,10 @@ PLH_API plh_status plh_line_set_grow_events(plh_line* h, void* wait_before, void
  * Frame.cc:224-227) run several wavefronts per frame as optimistic transactions with in-order commit, large batches one
  * wavefront per frame; 0: always one; n in 2..16: always n.  The segments are identical in every setting. */
 PLH_API plh_status plh_line_set_grow_waves(plh_line* h, int waves);
+/* Tuning of the several-wavefronts-per-frame schedule (same segments for any value): run_ahead = how many seeds a wavefront may
+ * start ahead of the commits (1..448, default 448), drain_gap = posted transactions that make a wavefront commit (>= 1, default
+ * 8).  Values <= 0 restore the defaults. */
+PLH_API plh_status plh_line_set_grow_tuning(plh_line* h, int run_ahead, int drain_gap);
 /* Capacity flags of the most recent extract call (see plh_orb_status; a handle carries ONE call in flight: the flags are
  * cleared in stream order by the next call on it).  bit 2: LSD produced more segments than the
  * segment list holds (|scaled pixels| / min_reg_size + 16 -- a hard bound, so never expected).  bit 4 (16): the
@@ -676,6 +692,8 @@ typedef struct plh_frontend_params {
   int32_t orb_check_orientation;
   float line_th, line_nnratio;     /* LSDmatcher::SearchDouble: TH_LOW = 50, mfNNratio */
   int32_t external_records;        /* 1: the caller supplies the record buffers (plh_frontend_bind_records) */
+  int32_t lsd_refine;              /* PLH_LSD_REFINE_STD / PLH_LSD_REFINE_ADV for every sub-batch's LINEextractor; -1: the library's
+                                      default (PLH_LSD_REFINE_DEFAULT) */
 } plh_frontend_params;
 
 /* Device pointers of one sub-batch's records, frames [first, first + frames) of the batch.  Per-frame arrays have

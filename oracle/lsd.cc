@@ -355,12 +355,13 @@ struct Lsd {
     double left_x = min_y->x, right_x = min_y->x;
     const int min_iter = min_y->y, max_iter = max_y->y;
     for (int y = min_iter; y <= max_iter; ++y) {
-      if (y >= 0 && y < h) {
-        for (int x = int(left_x); x <= int(right_x); ++x) {
-          if (x < 0 || x >= w) continue;
-          ++total_pts;
-          if (isAligned(x, y, rec.theta, rec.prec)) ++alg_pts;
-        }
+      // as published (OpenCV 3.x lsd.cpp rect_nfa): a scan line outside the image is skipped BEFORE the step update, so the
+      // spans do not advance on it (rounds 2-3 restated this with the update applied to skipped rows as well)
+      if (y < 0 || y >= h) continue;
+      for (int x = int(left_x); x <= int(right_x); ++x) {
+        if (x < 0 || x >= w) continue;
+        ++total_pts;
+        if (isAligned(x, y, rec.theta, rec.prec)) ++alg_pts;
       }
       if (y >= leftmost->y) lstep = slstep;
       if (y >= rightmost->y) rstep = srstep;

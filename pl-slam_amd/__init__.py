@@ -45,7 +45,7 @@ class FrontendParams(C.Structure):   # plh_frontend_params
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("orb", OrbParams), ("line", LineParams), ("undistort", C.c_int32),
                 ("K", C.c_float * 4), ("D", C.c_float * 5), ("bow_levelsup", C.c_int32), ("orb_th_low", C.c_int32),
                 ("orb_nnratio", C.c_float), ("orb_check_orientation", C.c_int32), ("line_th", C.c_float), ("line_nnratio", C.c_float),
-                ("external_records", C.c_int32)]
+                ("external_records", C.c_int32), ("lsd_refine", C.c_int32)]
 
 
 class FrontendRecords(C.Structure):   # plh_frontend_records
@@ -113,6 +113,9 @@ _SIGS = {
     "plh_line_set_grow_events": ([_V, _V, _V], _I),
     "plh_line_set_grow_waves": ([_V, _I], _I),
     "plh_line_set_refine": ([_V, _I], _I),
+    "plh_line_set_screen": ([_V, _I], _I),
+    "plh_line_set_grow_tuning": ([_V, _I, _I], _I),
+    "plh_lsd_refine_default": ([], _I),
     "plh_orb_search_by_bow_kfkf": ([_V, _V, _V, _V, _I, _V, _V, _V, _V, _I, _I, _F, _I, _V, _V, _I], _I),
     "plh_orb_search_for_triangulation": ([_V, _V, _V, _V, _I, _V, _V, _V, _V, _I, _V, _F, _F, _V, _V, _I, _I, _I, _V, _V, _I], _I),
     "plh_line_frame_bfmatch": ([_V, _I, _V, _I, _F, _F, _V, _I], _I),
@@ -1112,6 +1115,14 @@ class LINEextractor:
     def set_refine(self, level):
         """cv::LineSegmentDetector's refine level: 0 = LSD_REFINE_STD (default), 1 = LSD_REFINE_ADV (NFA-validated rectangles)."""
         _check(self.lib, self.lib.plh_line_set_refine(self.h, int(level)), "plh_line_set_refine")
+
+    def set_screen(self, on):
+        """Density screen of region growing (default on); off = the exact rectangle for every decision.  Same segments."""
+        _check(self.lib, self.lib.plh_line_set_screen(self.h, int(bool(on))), "plh_line_set_screen")
+
+    def set_grow_tuning(self, run_ahead=0, drain_gap=0):
+        """Schedule of the several-wavefronts-per-frame region growing (<= 0: defaults 448 / 8).  Same segments."""
+        _check(self.lib, self.lib.plh_line_set_grow_tuning(self.h, int(run_ahead), int(drain_gap)), "plh_line_set_grow_tuning")
 
     def set_grow_waves(self, waves):
         """Wavefronts per frame of LSD's region growing: -1 automatic (by batch size), 0 one, 2..16 that many; same segments."""

@@ -85,7 +85,7 @@ plh_status enqueue_line(plh_frontend* fe, Part& pt, const uint8_t* imgs, size_t 
   st = plh_line_search_double_batch_dev(pt.ldesc, pt.nl, pt.ldesc + (size_t)pt.lcap * 32, pt.nl + 1, pt.lcap, B, fe->p.line_th,
                                         fe->p.line_nnratio, pt.mLine, pt.nmLine, pt.ws, pt.wsBytes, s);
   if (st != PLH_OK) return st;
-  if (fe->overlap) PLH_HIP(hipEventRecord(pt.evLine, s));
+  PLH_HIP(hipEventRecord(pt.evLine, s));   // on whichever stream ran the chain: plh_frontend_gather waits for it in every mode
   return PLH_OK;
 }
 
@@ -107,7 +107,7 @@ plh_status enqueue_orb(plh_frontend* fe, Part& pt, const uint8_t* imgs, size_t s
                                           pt.nid + pt.ocap, pt.n + 1, pt.ocap, B, fe->p.orb_th_low, fe->p.orb_nnratio,
                                           fe->p.orb_check_orientation, pt.mOrb, pt.nmOrb, s);
   if (st != PLH_OK) return st;
-  if (fe->overlap) PLH_HIP(hipEventRecord(pt.evOrb, s));
+  PLH_HIP(hipEventRecord(pt.evOrb, s));
   return PLH_OK;
 }
 
@@ -160,9 +160,12 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     FE_TRY(plh_orb_create(&p->orb, device, p->rows, p->cols, pt.B, &pt.orb));
     FE_TRY(plh_line_create(&p->line, device, p->rows, p->cols, pt.B, &pt.line));
     if (p->undistort) FE_TRY(plh_line_set_undistort(pt.line, p->K, p->D));
-    // the wavefronts per frame of LSD's region growing go by the frames resident in ALL sub-batches (they run together)
-    if (batch >= 2048) FE_TRY(plh_line_set_grow_waves(pt.line, 0));
-    fe->around = batch <= 1024;   // (where plh_line runs several wavefronts per frame: mw_waves_for in line_host.hip)
+    // ONE quantity decides both the wavefronts per frame of LSD's region growing and the schedule that goes with them: the
+    // frames resident in ALL sub-batches (they run together).  Up to 1024: eight wavefronts per frame (k_lsd_grow_mw) and the
+    // ORB chain around region growing (plh_frontend_step); above: one wavefront per frame, the ORB chain underneath.
+    fe->around = batch <= 1024;
+    FE_TRY(plh_line_set_grow_waves(pt.line, fe->around ? 8 : 0));
+    if (p->lsd_refine >= 0) FE_TRY(plh_line_set_refine(pt.line, p->lsd_refine));
     pt.ocap = plh_orb_capacity(pt.orb); pt.lcap = plh_line_capacity(pt.line);
     const size_t B1 = (size_t)pt.B + 1, oc = (size_t)pt.ocap, lc = (size_t)pt.lcap;
     FE_TRY(dev_alloc(fe, &pt.valid, (size_t)pt.B * oc, true));
@@ -291,6 +294,7 @@ plh_status plh_frontend_step(plh_frontend* fe, const uint8_t* d_imgs, size_t fra
 // The records a tracker on another GPU needs, per sub-batch: n, kps, desc, nl, kl, ldesc, lfn.
 plh_status plh_frontend_gather(plh_frontend* fe, plh_comm* comm, int root, void* const* recv, void* comm_stream) {
   if (!fe || !comm) return PLH_ERR_INVALID;
+  PLH_HIP(hipSetDevice(fe->device));
   hipStream_t cs = (hipStream_t)comm_stream;
   int part = 0;
   for (Part& pt : fe->parts) {
@@ -304,6 +308,7 @@ plh_status plh_frontend_gather(plh_frontend* fe, plh_comm* comm, int root, void*
       blk[k].recv = recv ? recv[part * PLH_FRONTEND_GATHERED + k] : nullptr;
       blk[k].bytes = bytes[k];
     }
+    if (!pt.ran) { set_error("plh_frontend_gather: no step has been enqueued"); return PLH_ERR_INVALID; }
     if (fe->around && fe->overlap) {
       // small resident batch: the next step's ORB chain has to start while this step's region growing is still running (it
       // fills that kernel's tail, plh_frontend_step), so the ORB records go in a launch of their own as soon as they exist
@@ -316,10 +321,9 @@ plh_status plh_frontend_gather(plh_frontend* fe, plh_comm* comm, int root, void*
       st = plh_gather_records(comm, blk + 3, PLH_FRONTEND_GATHERED - 3, root, comm_stream);
       if (st != PLH_OK) return st;
     } else {
-      if (fe->overlap) {
-        PLH_HIP(hipStreamWaitEvent(cs, pt.evLine, 0));
-        PLH_HIP(hipStreamWaitEvent(cs, pt.evOrb, 0));
-      }
+      // (with overlap off both chains ran on the caller's stream: the events were recorded there)
+      PLH_HIP(hipStreamWaitEvent(cs, pt.evLine, 0));
+      PLH_HIP(hipStreamWaitEvent(cs, pt.evOrb, 0));
       const plh_status st = plh_gather_records(comm, blk, PLH_FRONTEND_GATHERED, root, comm_stream);
       if (st != PLH_OK) return st;
       pt.freeOrbValid = false;

@@ -20,6 +20,8 @@ void launch_lsd_angle_table(LsdAngleEntry* tab, hipStream_t s);
 void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s);
 size_t lsd_order_work_u32();
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s);
+plh_status lsd_grow_request_lds();
+void launch_lsd_rects(const LineDeviceArgs& a, hipStream_t s);
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s);
 void launch_sobel(const LineDeviceArgs& a, hipStream_t s);
 void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, const float* coef, uint8_t* desc, hipStream_t s);
@@ -74,6 +76,7 @@ struct plh_line {
   long long mwHintFrames = 0;
   long long mwWaveSlots = 0;   // (frame, wavefront) pairs the two buffers hold
   int growWaves = -1;          // plh_line_set_grow_waves
+  int mwLag = 448, mwDrainGap = 8;   // plh_line_set_grow_tuning
   unsigned int* dQmax = nullptr;
   int *dNOrdered = nullptr, *dNSegs = nullptr, *dStatus = nullptr;
   hipEvent_t growGate = nullptr, growDone = nullptr;   // caller's events around the region-growing launch (plh_line_set_grow_events)
@@ -224,7 +227,10 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   const double LOG_NT = 5 * (std::log10(double(a.sw)) + std::log10(double(a.sh))) / 2 + std::log10(11.0);
   a.minRegSize = (int)(size_t)(-LOG_NT / std::log10(a.p));
   a.logNT = LOG_NT;
-  a.refineAdv = 0;
+  a.refineAdv = PLH_LSD_REFINE_DEFAULT == PLH_LSD_REFINE_ADV ? 1 : 0;
+  a.screen = 1;
+  a.screenLo = (float)(a.densityTh * (1.0 - 2e-5));
+  a.screenHi = (float)(a.densityTh * (1.0 + 2e-5));
   a.segCap = (a.sw * a.sh) / std::max(a.minRegSize, 1) + 16;
   a.nFeature = (int)p->n_lsd_feature;
   a.minLineLength = p->min_line_length;
@@ -299,6 +305,10 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   TRYHIP(hipMemcpy(h->dCoef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 #undef TRYHIP
+  if (lsd_grow_request_lds() != PLH_OK) {   // per kernel and device (hipSetDevice(device) above)
+    plh_line_destroy(h);
+    return PLH_ERR_INVALID;
+  }
   h->a.angleTab = angle_table_acquire(device);
   if (!h->a.angleTab) {
     set_error("plh_line_create: the ll_angle table could not be built on device %d", device);
@@ -367,13 +377,17 @@ plh_status plh_line_set_undistort(plh_line* h, const float K[4], const float D[5
 
 // Wavefronts per frame for k_lsd_grow's launch: small batches leave most of the 1024 SIMDs idle with one wavefront per
 // frame, so a frame gets several (k_lsd_grow_mw: optimistic transactions, in-order commit -- same segments); large batches
-// fill the GPU with frames and keep one wavefront each.  PLH_GROW_MW_WAVES overrides (0 = never, n = always n; tuning aid).
+// fill the GPU with frames and keep one wavefront each.  plh_line_set_grow_waves overrides (0 / 1 = never, n = always n).
 static int mw_waves_for(const plh_line* h, int batch) {
   int forced = h->growWaves;
+#if defined(HIPEMU) || defined(PLH_GROW_PROF)
+  // the CPU emulator build (tests/hipemu: a frame with eight fiber wavefronts costs four times the wall clock of two) and the
+  // counter build of tools/ take the count from the environment; the product build has no such knob
   if (forced < 0) {
     const char* e = getenv("PLH_GROW_MW_WAVES");
     if (e) forced = atoi(e);
   }
+#endif
   if (forced >= 0) return forced == 1 ? 0 : std::min(forced, 16);
   // measured on MI355X, 640 x 480 (tools/mw_sweep.py, profiles/r03_mw_sweep.txt), region growing per launch: 1 frame 44.6 ms with
   // one wavefront, 13.5 with 8, 12.9 with 16; 512 frames 58.0 -> 26.8 with 8 (16: 39.7); 1024 frames 64.5 -> 49.4 with 8 (4: 65.7);
@@ -388,12 +402,8 @@ static plh_status mw_reserve(plh_line* h, LineDeviceArgs& a, int batch, int wave
   a.mwWaves = waves;
   a.mwRegStride = 5 * a.scaledStride;   // posted logs | three regions of a running transaction | reduce_region_radius scratch
   a.mwMarkStride = a.scaledStride;
-  {
-    const char* e = getenv("PLH_GROW_MW_LAG");   // tuning aid
-    a.mwLag = std::min(std::max(e ? atoi(e) : 448, 1), 448);   // below the ring of posted transactions (512) by more than the wavefronts' own
-    const char* g = getenv("PLH_GROW_MW_GAP");
-    a.mwDrainGap = std::max(g ? atoi(g) : 8, 1);
-  }
+  a.mwLag = h->mwLag;   // (at most 448: below the ring of posted transactions, 512, by more than the wavefronts' own)
+  a.mwDrainGap = h->mwDrainGap;
   const long long slots = (long long)batch * (waves + 1);
   if (slots > h->mwWaveSlots) {
     if (h->doneValid) PLH_HIP(hipEventSynchronize(h->doneEv));   // earlier launches may still use the old buffers
@@ -484,6 +494,8 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   if (h->growDone) PLH_HIP(hipEventRecord(h->growDone, s));
   line_prof_mark(h, 1, s);
   line_prof_mark(h, 2, s);
+  launch_lsd_rects(a, s);   // the kept regions' rectangles (and LSD_REFINE_ADV's rect_improve), one lane per region
+  PLH_LAUNCH_CHECK();
   launch_keylines(a, d_keylines, d_linefn, d_n, s);
   PLH_LAUNCH_CHECK();
   line_prof_mark(h, 2, s);
@@ -545,7 +557,10 @@ plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, int cols,
   int stf = 0;
   PLH_HIP(hipMemcpy(&stf, h->dStatus, 4, hipMemcpyDeviceToHost));
   if (stf) {
-    if ((stf & 16) && h->dMwMark) (void)hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride);
+    if ((stf & 16) && h->dMwMark) {
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride);
+    }
     set_error("line kernels reported a capacity overflow or an abandoned launch (flags 0x%x)", stf);
     return PLH_ERR_CAPACITY;
   }
@@ -557,8 +572,10 @@ plh_status plh_line_status(plh_line* h, int* flags) {
   PLH_HIP(hipSetDevice(h->device));
   if (h->doneValid) PLH_HIP(hipEventSynchronize(h->doneEv));
   PLH_HIP(hipMemcpy(flags, h->dStatus, 4, hipMemcpyDeviceToHost));
-  if ((*flags & 16) && h->dMwMark)   // an abandoned launch leaves private marks behind: the planes must be zero between transactions
+  if ((*flags & 16) && h->dMwMark) {   // an abandoned launch leaves private marks behind: the planes must be zero between transactions
+    PLH_HIP(hipDeviceSynchronize());   // nothing of this device may still be running on the planes (error path: cost is no concern)
     PLH_HIP(hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride));
+  }
   return PLH_OK;
 }
 
@@ -568,6 +585,21 @@ plh_status plh_line_set_refine(plh_line* h, int level) {
     return PLH_ERR_INVALID;
   }
   h->a.refineAdv = level == PLH_LSD_REFINE_ADV ? 1 : 0;
+  return PLH_OK;
+}
+
+int plh_lsd_refine_default(void) { return PLH_LSD_REFINE_DEFAULT; }
+
+plh_status plh_line_set_screen(plh_line* h, int on) {
+  if (!h) return PLH_ERR_INVALID;
+  h->a.screen = on ? 1 : 0;
+  return PLH_OK;
+}
+
+plh_status plh_line_set_grow_tuning(plh_line* h, int run_ahead, int drain_gap) {
+  if (!h) return PLH_ERR_INVALID;
+  h->mwLag = run_ahead <= 0 ? 448 : std::min(run_ahead, 448);
+  h->mwDrainGap = drain_gap <= 0 ? 8 : drain_gap;
   return PLH_OK;
 }
 

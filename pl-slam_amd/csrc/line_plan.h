@@ -81,7 +81,11 @@ struct LineDeviceArgs {
   float alignCin2, alignCout2;   // cos^2(prec -+ 0.05 degrees): the direction pre-test of region growing (lsd_grow.hip, lsd_classify)
   int alignFast;
   int minRegSize;
-  int refineAdv;            // 1: LSD_REFINE_ADV (rect_improve / NFA behind refine()), plh_line_set_refine
+  // the density screen of region growing (lsd_density_screen, lsd_grow.hip): 0.7 (1 -+ 2e-5) as floats; screen = 0 evaluates the
+  // exact rectangle for every decision (the path every undecided region takes anyway: same segments; an A/B and test switch)
+  float screenLo, screenHi;
+  int screen;
+  int refineAdv;            // 1: LSD_REFINE_ADV (rect_improve / NFA on the kept regions' rectangles, k_lsd_rects), plh_line_set_refine
   double logNT;             // 5 (log10 sw + log10 sh) / 2 + log10 11, flsd()'s LOG_NT
   // selection
   int nFeature;             // nLSDFeature

@@ -1,16 +1,8 @@
 // Line kernels, stage 2: LSD region growing / rectangle fit, KeyLine selection, Sobel pack, LBD.
 // See line_kernels.hip for the overview and the reference citations.
-#include "line_dev.h"
+#include "lsd_rect_dev.h"
 
 namespace plh {
-
-struct LsdRect {
-  double x1, y1, x2, y2, width;
-};
-
-struct alignas(16) D2 {
-  double x, y;
-};
 
 struct GrowCtx {
   uint32_t* P;                 // level-line records of the scaled image (LSD_REC_*: table index | DEF | USED = region growing's mark)
@@ -162,16 +154,7 @@ struct GrowState {
   const uint32_t* fstPk;    // [64] packed coordinates
 };
 
-// isAligned() of cv::LineSegmentDetector for a defined pixel: |theta - a| folded at 3pi/2, compared with prec.
-__device__ __forceinline__ bool lsd_aligned(double theta, double a, double prec) {
-  double n_theta = theta - a;
-  if (n_theta < 0) n_theta = -n_theta;
-  if (n_theta > k3_2PI) {
-    n_theta -= k2PI;
-    if (n_theta < 0) n_theta = -n_theta;
-  }
-  return n_theta <= prec;
-}
+// (isAligned() of cv::LineSegmentDetector for a defined pixel -- lsd_aligned -- is in lsd_rect_dev.h)
 
 // The same test decided in float degrees whenever the angles are clearly inside / outside the tolerance; only the
 // pixels within 2e-3 degrees of a decision boundary (tolerance or the 270-degree fold) take the exact double path.
@@ -516,13 +499,6 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   return cnt;
 }
 
-__device__ __forceinline__ double angle_diff_signed(double a, double b) {
-  double diff = a - b;
-  while (diff <= -kPI) diff += k2PI;
-  while (diff > kPI) diff -= k2PI;
-  return diff;
-}
-
 // Sequential double sums of up to three series at once.  Every lane has stored its three terms for element
 // base+lane into c.T ([3][64], zero beyond the end); lane ch < 3 then adds series ch in element order from LDS,
 // so the three dependent v_add_f64 chains of the reference run side by side in three lanes, one add per element
@@ -545,15 +521,7 @@ __device__ __forceinline__ double lsd_chain_add(const GrowCtx& c, double acc, in
 // costs the kernel registers it does not have): 60 instructions instead of the library routine's 153, 2 300 times per frame,
 // and as close to the host libm as the library routine is (either differs from glibc in 3.1 % of the values, by one unit in the
 // last place; line extractor 141.1 -> 139.3 ms per 6144 frames).
-__device__ __attribute__((noinline)) D2 lsd_sincos(double t) {
-  D2 r;
-#if defined(PLH_LIB_SINCOS)
-  sincos(t, &r.y, &r.x);
-#else
-  sincos_head_tail(t, r.y, r.x);   // x = cos, y = sin
-#endif
-  return r;
-}
+__device__ __attribute__((noinline)) D2 lsd_sincos(double t) { return lsd_sincos_inl(t); }   // x = cos, y = sin
 
 __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, double prec, double* rec) {
   const int lane = c.lane;
@@ -594,11 +562,7 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
     acc = lsd_chain_add(c, acc, min(64, cnt - base));
   }
   const double Ixx = bcast_f64(acc, 0), Iyy = bcast_f64(acc, 1), Ixy = bcast_f64(acc, 2);
-  const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-  double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
-                                         : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
-  theta *= kDegToRads;
-  if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += kPI;
+  const double theta = lsd_rect_theta(Ixx, Iyy, Ixy, reg_angle, prec);
   const D2 cs = lsd_sincos(theta);
   const double dx = cs.x, dy = cs.y;
   double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
@@ -647,223 +611,137 @@ __device__ void lsd_region2rect(const GrowCtx& c, int cnt, double reg_angle, dou
   PLH_WAVE_SYNC();
 }
 
-__device__ __forceinline__ double dist_sq(double x1, double y1, double x2, double y2) {
-  return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
-}
 __device__ __forceinline__ double rect_density(int cnt, const double* r) {
   return (double)cnt / (sqrt(dist_sq(r[0], r[1], r[2], r[3])) * r[4]);
 }
 
 // ---------------------------------------------------------------------------------------------
-// LSD_REFINE_ADV (cv::LineSegmentDetector created with LSD_REFINE_ADV, what the system opencv_contrib LSDDetector behind
-// src/LineExtractor.cpp:39-40 passes as published; oracle/lsd.cc restates it with the published code's quirks): a rectangle
-// is kept only if its number of false alarms says it is meaningful, after up to five kinds of adjustment.
-//   nfa()          -log10(NT x binomial tail), Lanczos / Windschitl log-gamma
-//   rect_nfa()     the pixels of the rectangle scan line by scan line, how many of them are aligned with it
-//   rect_improve() finer precision, narrower, one side in, the other side in, finer precision again
+// The density screen.  What region growing needs from region2rect() is, nearly always, one bit: is the region's density
+// cnt / (length x width) of its rectangle at least densityTh?  (refine() and reduce_region_radius() only run when it is not, and
+// the rectangle of a region that is kept changes no mark.)  The exact rectangle costs a wavefront ~800 instructions -- two
+// passes of sequential double sums on 3 of 64 lanes, two divisions, sqrt, sincos -- for a decision that is rarely close.  So
+// the wavefront first brackets the exact density with float arithmetic in any order (~200 instructions, one gather):
+//   * weights sqrt(gx^2 + gy^2) from the record's table index (the common factor 1/2 of modgrad cancels in the centroid and
+//     in the direction), raw moments about the seed in float, summed through LDS;
+//   * the direction from the same fastAtan2 formula on the float inertia terms, cos / sin by v_cos / v_sin;
+//   * extents L~, W~ of the region about the float centroid along that direction.
+// Error budget (R = region radius <= L~, all in pixels / radians):
+//   - the exact theta is fastAtan2 of float casts of double inertia terms; ours is fastAtan2 of float terms whose relative
+//     error is <= 2e-6 x (raw trace / eigenvalue gap) -- the screen gives up unless that is <= 1e-4 -- so the two arguments
+//     agree to 1e-4 and the results to 1e-4 rad, EXCEPT across the polynomial's octant seam (|x| = |y|: a jump of 0.019
+//     degrees) and the |Ixx| > |Iyy| choice of formula (both formulas give the same direction to twice the polynomial's
+//     error, 0.019 degrees, or its opposite -- a rotation by pi leaves length and width alone).  delta = 5e-4 rad covers all
+//     of it (3.4e-4 + 1e-4 + v_sin / v_cos 1e-5) without looking at which case applies;
+//   - a rotation of the axes by delta moves an extent by at most delta x (the other extent); float rounding of the
+//     coordinates, the centroid and the products moves it by < 1e-5 x (L~ + W~ + 1).
+// Hence  L* in [L~ - a, L~ + a],  W* in [W~ - b, W~ + b]  with a = delta W~ + eps, b = delta L~ + eps, and the exact density
+// lies between cnt / ((L~ + a) max(W~ + b, 1)) and cnt / ((L~ - a) max(W~ - b, 1)).  Verdict +1 / -1 only when the whole
+// bracket lies on one side of densityTh (with 2e-5 of slack for the float products); 0 = undecided: the caller evaluates the
+// exact rectangle, as it always did.  Either way the decisions taken are the reference's, so the segments are; the exact
+// rectangle of a kept region is evaluated later, one lane per region (k_lsd_rects).  A -DPLH_GROW_PROF build checks every
+// verdict against the exact density (counter 39 = contradictions: must stay 0; tools/grow_prof.py, tests/test_soak_gpu.py).
 // ---------------------------------------------------------------------------------------------
-struct LsdAdvRect {
-  double x1, y1, x2, y2, width, theta, dx, dy, prec, p;
-};
+constexpr float LSD_SCREEN_DELTA = 5e-4f;
+constexpr int LSD_SCREEN_MAX = 4096;   // beyond this the float sums' own error grows with the count: not screened (rare)
 
-__device__ __attribute__((noinline)) double lsd_log_gamma(double x) {
-  if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
-  const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
-  double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
-  double b = 0;
-  for (int n = 0; n < 7; ++n) {
-    a -= log(x + double(n));
-    b += q[n] * pow(x, double(n));
-  }
-  return a + log(b);
-}
+__device__ __forceinline__ float screen_f(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ float screen_sum4(const uint4 v) { return (screen_f(v.x) + screen_f(v.y)) + (screen_f(v.z) + screen_f(v.w)); }
+__device__ __forceinline__ float screen_max4(const uint4 v) { return fmaxf(fmaxf(screen_f(v.x), screen_f(v.y)), fmaxf(screen_f(v.z), screen_f(v.w))); }
 
-__device__ __attribute__((noinline)) double lsd_nfa(int n, int k, double p, double logNT) {
-  if (n == 0 || k == 0) return -logNT;
-  if (n == k) return -logNT - double(n) * log10(p);
-  const double p_term = p / (1 - p);
-  // (n + 1) where the original algorithm has log_gamma(n + 1): as published (oracle/lsd.cc)
-  const double log1term = (double(n) + 1) - lsd_log_gamma(double(k) + 1) - lsd_log_gamma(double(n - k) + 1) + double(k) * log(p) +
-                          (double(n - k)) * log(1.0 - p);
-  double term = exp(log1term);
-  {
-    // double_equal(term, 0)
-    const double aa = fabs(term);
-    const double abs_max = aa < 2.2250738585072014e-308 ? 2.2250738585072014e-308 : aa;
-    if (term == 0.0 || (aa / abs_max) <= (100.0 * 2.2204460492503131e-16)) {
-      if (k > n * p) return -log1term / 2.30258509299404568402 - logNT;
-      return -logNT;
-    }
-  }
-  double bin_tail = term;
-  const double tolerance = 0.1;
-  for (int i = k + 1; i <= n; ++i) {
-    const double bin_term = double(n - i + 1) / double(i);
-    const double mult_term = bin_term * p_term;
-    term *= mult_term;
-    bin_tail += term;
-    if (bin_term < 1) {
-      const double err = term * ((1 - pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
-      if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) break;
-    }
-  }
-  return -log10(bin_tail) - logNT;
-}
-
-// rect_nfa(): the scan-line bounds advance by integer steps from an integer start, so the bounds of row j are a closed form
-// (exact in any order): one lane per row computes its span, a wave scan numbers the pixels, and the lanes then test 64
-// pixels at a time.  Row spans and offsets of a 64-row chunk live in the (dead) ring.
-struct LsdNfaCtx {   // what rect_nfa reads of the wavefront's context (by value: the call is out of line)
-  const uint32_t* P;
-  const LsdAngleEntry* A;
-  uint32_t* ring;
-  int spitch, sw, sh, lane;
-};
-__device__ __attribute__((noinline)) double lsd_rect_nfa(const LsdNfaCtx c, const LsdAdvRect r, double logNT) {
+// `fromRing`: the queue is as region_grow() left it (its newest LSD_RING entries mirrored in LDS); false after
+// reduce_region_radius() has permuted it in global memory.
+template <bool MW>
+__device__ __forceinline__ int lsd_density_screen(const GrowCtx& c, int cnt, bool fromRing, float thLo, float thHi) {
+  if (cnt > LSD_SCREEN_MAX) return 0;
   const int lane = c.lane;
-  const double hw = r.width / 2.0, dyhw = r.dy * hw, dxhw = r.dx * hw;
-  int ox[4] = {(int)(r.x1 - dyhw), (int)(r.x2 - dyhw), (int)(r.x2 + dyhw), (int)(r.x1 + dyhw)};
-  int oy[4] = {(int)(r.y1 + dxhw), (int)(r.y2 + dxhw), (int)(r.y2 - dxhw), (int)(r.y1 - dxhw)};
-  // std::sort by (x, y) ascending: a sorting network on four elements
-#define LSD_CSWAP(i, j)                                                          \
-  if (ox[j] < ox[i] || (ox[j] == ox[i] && oy[j] < oy[i])) {                      \
-    const int tx = ox[i], ty = oy[i];                                            \
-    ox[i] = ox[j]; oy[i] = oy[j]; ox[j] = tx; oy[j] = ty;                        \
-  }
-  LSD_CSWAP(0, 1) LSD_CSWAP(2, 3) LSD_CSWAP(0, 2) LSD_CSWAP(1, 3) LSD_CSWAP(1, 2)
-#undef LSD_CSWAP
-  int iMin = 0, iMax = 0;
-  for (int i = 1; i < 4; ++i) {
-    if (oy[iMin] > oy[i]) iMin = i;
-    if (oy[iMax] < oy[i]) iMax = i;
-  }
-  unsigned taken = 1u << iMin;
-  int iL = -1, iR = -1, iT = -1;
-  for (int i = 0; i < 4; ++i)
-    if (!((taken >> i) & 1u)) { if (iL < 0) iL = i; else if (ox[iL] > ox[i]) iL = i; }
-  taken |= 1u << iL;
-  for (int i = 0; i < 4; ++i)
-    if (!((taken >> i) & 1u)) { if (iR < 0) iR = i; else if (ox[iR] < ox[i]) iR = i; }
-  taken |= 1u << iR;
-  for (int i = 0; i < 4; ++i)
-    if (!((taken >> i) & 1u)) { if (iT < 0) iT = i; else if (ox[iT] > ox[i]) iT = i; }
-  const int mx = ox[iMin], my = oy[iMin], lx = ox[iL], ly = oy[iL], rx = ox[iR], ry = oy[iR], tx = ox[iT];
-  // integer divisions, and the tail point's x where a y is meant: as published
-  const long long fl = (my != ly) ? (mx - lx) / (my - ly) : 0, sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
-  const long long fr = (my != ry) ? (mx - rx) / (my - ry) : 0, sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
-  const int yMin = my, yMax = oy[iMax];
-  const long long aL = max(0, ly - yMin), aR = max(0, ry - yMin);   // rows that still advance by the first step
-  int* rowX = (int*)c.ring;          // [64] first column of the row's span
-  int* rowOff = rowX + 64;           // [65] pixels in front of the row (chunk-relative), [64] = all
-  int total = 0, alg = 0;
-  for (int y0 = yMin; y0 <= yMax; y0 += 64) {
-    const long long j = (long long)(y0 - yMin) + lane;
-    const int y = y0 + lane;
-    int cnt = 0, xl = 0;
-    if (y <= yMax && y >= 0 && y < c.sh) {
-      const long long jl = j < aL ? j : aL, jr = j < aR ? j : aR;
-      const long long left = mx + fl * jl + sl * (j - jl), right = mx + fr * jr + sr * (j - jr);
-      const long long a = left < 0 ? 0 : left, b = right > c.sw - 1 ? c.sw - 1 : right;
-      if (b >= a) { cnt = (int)(b - a + 1); xl = (int)a; }
-    }
-    // exclusive scan of the row spans
-    int inc = cnt;
-    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(inc, d);
-      if (lane >= d) inc += v;
-    }
-    const int chunkTotal = (int)bcast_u32((unsigned)inc, 63);
-    PLH_WAVE_SYNC();
-    rowX[lane] = xl; rowOff[lane] = inc - cnt;
-    if (lane == 0) rowOff[64] = chunkTotal;
-    PLH_WAVE_SYNC();
-    for (int base = 0; base < chunkTotal; base += 64) {
-      const int i = base + lane;
-      bool ok = false;
-      if (i < chunkTotal) {
-        int lo = 0, hi = 64;           // last row whose offset is <= i (rows with no pixels share their successor's offset)
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (rowOff[mid] <= i) lo = mid; else hi = mid;
-        }
-        const int x = rowX[lo] + (i - rowOff[lo]), yy = y0 + lo;
-        const unsigned rec = c.P[__umul24((unsigned)yy, (unsigned)c.spitch) + (unsigned)x];
-        if (rec & LSD_REC_DEF) ok = lsd_aligned(r.theta, (double)c.A[rec & LSD_REC_IDX].angf * kDegToRads, r.prec);
-      }
-      alg += __popcll(__ballot(ok));
-    }
-    total += chunkTotal;
-    PLH_WAVE_SYNC();
-  }
-  return lsd_nfa(total, alg, r.p, logNT);
-}
-
-// rect_improve(); rec (LDS) = x1 y1 x2 y2 width theta dx dy.  Returns whether the rectangle is kept (log_nfa > LOG_EPS = 0); the
-// improved rectangle is written back.
-__device__ __attribute__((noinline)) bool lsd_rect_improve(const GrowCtx& c, double* rec, double prec, double p, double logNT) {
-  LsdAdvRect R;
-  R.x1 = rec[0]; R.y1 = rec[1]; R.x2 = rec[2]; R.y2 = rec[3]; R.width = rec[4]; R.theta = rec[5]; R.dx = rec[6]; R.dy = rec[7];
-  R.prec = prec; R.p = p;
-  PLH_WAVE_SYNC();   // (the ring is about to be reused)
-  LsdNfaCtx nc;
-  nc.P = c.P; nc.A = c.A; nc.ring = c.ring; nc.spitch = c.spitch; nc.sw = c.sw; nc.sh = c.sh; nc.lane = c.lane;
-  const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = 0.0;
-  double log_nfa = lsd_rect_nfa(nc, R, logNT);
-  bool changed = false;
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n) {          // finer precision
-      r.p /= 2;
-      r.prec = r.p * kPI;
-      const double v = lsd_rect_nfa(nc, r, logNT);
-      if (v > log_nfa) { log_nfa = v; R = r; changed = true; }
-    }
-  }
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n)            // reduce width
-      if ((r.width - delta) >= 0.5) {
-        r.width -= delta;
-        const double v = lsd_rect_nfa(nc, r, logNT);
-        if (v > log_nfa) { R = r; log_nfa = v; changed = true; }
-      }
-  }
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n)            // reduce one side
-      if ((r.width - delta) >= 0.5) {
-        r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
-        r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
-        r.width -= delta;
-        const double v = lsd_rect_nfa(nc, r, logNT);
-        if (v > log_nfa) { R = r; log_nfa = v; changed = true; }
-      }
-  }
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n)            // reduce the other side
-      if ((r.width - delta) >= 0.5) {
-        r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
-        r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
-        r.width -= delta;
-        const double v = lsd_rect_nfa(nc, r, logNT);
-        if (v > log_nfa) { R = r; log_nfa = v; changed = true; }
-      }
-  }
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n)            // finer precision again
-      if ((r.width - delta) >= 0.5) {
-        r.p /= 2;
-        r.prec = r.p * kPI;
-        const double v = lsd_rect_nfa(nc, r, logNT);
-        if (v > log_nfa) { R = r; log_nfa = v; changed = true; }
-      }
-  }
+  const bool inRing = fromRing && cnt <= LSD_RING;   // the whole queue is still in its LDS mirror
+  if (!inRing || cnt > 64) grow_lane_fence<MW>();   // the queue in global memory is read below: stores of all lanes visible
   PLH_WAVE_SYNC();
-  if (changed && c.lane == 0) { rec[0] = R.x1; rec[1] = R.y1; rec[2] = R.x2; rec[3] = R.y2; rec[4] = R.width; }
-  PLH_WAVE_SYNC();
-  return log_nfa > LOG_EPS;
+  const uint32_t seedPk = bcast_u32(inRing ? c.ring[0] : c.reg[0], 0);
+  const int x0 = pk_x(seedPk), y0 = pk_y(seedPk);
+  float S[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // sums of w, w x, w y, w x x, w y y, w x y (x, y relative to the seed)
+  uint32_t p0 = seedPk;
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    const bool on = i < cnt;
+    uint32_t p = seedPk;
+    if (on) p = inRing ? c.ring[i] : c.reg[i];
+    if (base == 0) p0 = p;
+    const unsigned rec = c.P[pk_lin(c, p)];   // (lanes beyond the end read the seed's record; their weight is zero)
+    const float w = on ? plh_sqrt_approx((float)lsd_rec_q(rec)) : 0.f;
+    const float dx = (float)(pk_x(p) - x0), dy = (float)(pk_y(p) - y0);
+    const float wx = w * dx, wy = w * dy;
+    S[0] += w; S[1] += wx; S[2] += wy;
+    S[3] = __builtin_fmaf(wx, dx, S[3]); S[4] = __builtin_fmaf(wy, dy, S[4]); S[5] = __builtin_fmaf(wx, dy, S[5]);
+  }
+  float* F = reinterpret_cast<float*>(c.T);   // 512 floats: the ring, dead from here on (region_grow() restarts it)
+  {
+    PLH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 6; k++) F[64 * k + lane] = S[k];
+    PLH_WAVE_SYNC();
+    const int s = lane >> 3, j = lane & 7;
+    float t = 0.f;
+    if (s < 6) {
+      const uint4* q = reinterpret_cast<const uint4*>(F + 64 * s + 8 * j);
+      t = screen_sum4(q[0]) + screen_sum4(q[1]);
+    }
+    PLH_WAVE_SYNC();
+    F[lane] = t;   // series s: eight partial sums at [8 s, 8 s + 8)
+    PLH_WAVE_SYNC();
+    float u = 0.f;
+    if (lane < 6) {
+      const uint4* q = reinterpret_cast<const uint4*>(F + 8 * lane);
+      u = screen_sum4(q[0]) + screen_sum4(q[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) S[k] = bcast_f32(u, k);
+  }
+  const float inv = 1.0f / S[0];
+  const float mx = S[1] * inv, my = S[2] * inv;
+  const float Ixx = S[4] - S[2] * my, Iyy = S[3] - S[1] * mx, Ixy = S[1] * my - S[5];
+  const float d = Ixx - Iyy, g = sqrtf(d * d + 4.f * (Ixy * Ixy));
+  // conditioning of the direction: float error of the inertia terms (2e-6 of the raw trace) against the eigenvalue gap
+  if (!(2e-6f * (S[3] + S[4]) <= 1e-4f * g)) return 0;   // (also catches NaN)
+  const float thDeg = fabsf(Ixx) > fabsf(Iyy) ? fast_atan2_deg(-0.5f * (d + g), Ixy) : fast_atan2_deg(Ixy, -0.5f * (g - d));
+  const float turns = thDeg * (1.0f / 360.0f);
+  const float cs = cos_turns(turns), sn = sin_turns(turns);
+  float E[4] = {0.f, 0.f, 0.f, 0.f};   // max l, max -l, max w, max -w (the reference's extremes start at 0)
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    uint32_t p = p0;
+    if (base > 0 && i < cnt) p = c.reg[i];
+    if (i < cnt) {
+      const float rx = (float)(pk_x(p) - x0) - mx, ry = (float)(pk_y(p) - y0) - my;
+      const float l = __builtin_fmaf(ry, sn, rx * cs), w = __builtin_fmaf(ry, cs, -(rx * sn));
+      E[0] = fmaxf(E[0], l); E[1] = fmaxf(E[1], -l); E[2] = fmaxf(E[2], w); E[3] = fmaxf(E[3], -w);
+    }
+  }
+  {
+    PLH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 4; k++) F[64 * k + lane] = E[k];
+    PLH_WAVE_SYNC();
+    const float t = screen_max4(*reinterpret_cast<const uint4*>(F + 4 * lane));   // lane (s, j): series s = lane >> 4
+    PLH_WAVE_SYNC();
+    F[lane] = t;   // series s: sixteen partial maxima at [16 s, 16 s + 16)
+    PLH_WAVE_SYNC();
+    float u = 0.f;
+    if (lane < 4) {
+      const uint4* q = reinterpret_cast<const uint4*>(F + 16 * lane);
+      u = fmaxf(fmaxf(screen_max4(q[0]), screen_max4(q[1])), fmaxf(screen_max4(q[2]), screen_max4(q[3])));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) E[k] = bcast_f32(u, k);
+    PLH_WAVE_SYNC();
+  }
+  const float L = E[0] + E[1], W = E[2] + E[3];
+  const float eps = 1e-5f * (L + W + 1.0f);
+  const float a = LSD_SCREEN_DELTA * W + eps, b = LSD_SCREEN_DELTA * L + eps;
+  const float n = (float)cnt;
+  if (n >= thHi * ((L + a) * fmaxf(W + b, 1.0f))) return 1;
+  if (n < thLo * (fmaxf(L - a, 0.f) * fmaxf(W - b, 1.0f))) return -1;
+  return 0;
 }
 
 // One iteration of reduce_region_radius(): drop every point farther than sqrt(radSq) from reg[0].
@@ -919,6 +797,162 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
   return K;
 }
 
+// What a transaction -- the body of flsd()'s loop for one seed that is free at its turn (oracle/lsd.cc run(): region_grow ->
+// region2rect -> refine [-> region_grow -> region2rect -> reduce_region_radius]) -- leaves behind.  The rectangle itself is
+// not part of it: a region that is kept goes to the frame's log and k_lsd_rects evaluates its rectangle (lsd_rects.hip).
+struct LsdTxn {
+  int logLen;            // several wavefronts per frame: pixels ever accepted, base[0 .. logLen)
+  int finBase, finCnt;   // the pixels still marked at the end (the final region): base[finBase .. finBase + finCnt)
+  float ang;             // reg_angle of the final region's region_grow() in float degrees: what its region2rect() takes
+  bool keep;             // the final region is a line-support region
+  bool conflict;         // several wavefronts per frame: the run met a committed mark on a pixel it holds -- not the reference's
+                         // course, to be run again
+};
+
+// One transaction.  The caller has put the seed into gs (d[0] = tolerance, u[0..4]) and c.reg at the start of free queue space.
+// One wavefront per frame (MW = false): marks in the records, every phase reuses the queue.  Several (MW = true): private marks,
+// the queues of the phases laid end to end so that the log keeps every pixel ever accepted, reduce_region_radius() on a copy.
+// Where flsd() looks at the density of a rectangle the wavefront asks lsd_density_screen() first and evaluates the exact
+// rectangle only if the bracket straddles the threshold -- or if the rectangle itself is needed next: refine() takes its
+// width, reduce_region_radius() its end points.  Inside reduce_region_radius()'s loop only the decision is.
+template <bool MW>
+__device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, int firstGrp, bool dirtyFst) {
+  const int lane = c.lane;
+  double* rec = gs.d + 1;
+  uint32_t* const base = c.reg;
+  LsdTxn t;
+  t.keep = false; t.conflict = false; t.finBase = 0; t.ang = 0.f;
+  float regAngF;
+  const unsigned long long pg0 = PF_NOW();
+  int cnt = lsd_region_grow<MW>(c, gs, firstGrp, dirtyFst, a.minRegSize, &regAngF, &t.conflict);
+  PF_ADD(c, 2, PF_NOW() - pg0);
+  t.logLen = cnt; t.finCnt = cnt;
+  if constexpr (MW) {
+    if (bcast_u32(*c.asmCnt, 0) > (unsigned)MW_ASM_CAP) t.conflict = true;   // more predictions than the list holds: not this time
+  }
+  if (t.conflict || cnt < a.minRegSize) return t;   // (a region below the minimum is dropped, its pixels stay used)
+  int phase = 0, cnt1 = 0;
+  bool fromRing = true;
+  float angS = regAngF;
+  for (;;) {
+    const unsigned long long pg1 = PF_NOW();
+    const int v = a.screen ? lsd_density_screen<MW>(c, cnt, fromRing, a.screenLo, a.screenHi) : 0;
+    bool dense = v > 0;
+    bool exact = v == 0 || (v < 0 && phase < 2);
+#if defined(PLH_GROW_PROF)
+    exact = true;   // every verdict is checked against the exact density
+    PF_ADD(c, 37, v > 0); PF_ADD(c, 38, v < 0);
+#endif
+    if (exact) {
+      grow_lane_fence<MW>();   // queue stores visible to every lane
+      PF_ADD(c, 14, 1); PF_ADD(c, 1, cnt);
+      lsd_region2rect(c, cnt, (double)angS * kDegToRads, a.prec, rec);
+      const bool d2 = !(rect_density(cnt, rec) < a.densityTh);
+      PF_ADD(c, 39, v != 0 && d2 != dense);
+      dense = d2;
+    }
+    PF_ADD(c, 5, PF_NOW() - pg1);
+    if (dense) { t.keep = true; break; }
+    const unsigned long long pg2 = PF_NOW();
+    if (phase == 0) {
+      // refine(): tolerance from the angle spread near the seed, everything un-marked, grown again
+      PF_ADD(c, 15, 1);
+      const uint32_t cPk = c.reg[0];
+      const double xc = (double)pk_x(cPk), yc = (double)pk_y(cPk);
+      const uint32_t cLin = pk_lin(c, cPk);
+      const unsigned rec0 = c.P[cLin];
+      const LsdAngleEntry* e0 = c.A + (rec0 & LSD_REC_IDX);
+      const float ang0 = e0->angf, sx0 = e0->seedx, sy0 = e0->seedy;
+      const double ang_c = (double)ang0 * kDegToRads, width = rec[4];
+      double acc = 0;
+      int n = 0;
+      bool overtaken = false;
+      for (int b0 = 0; b0 < cnt; b0 += 64) {
+        const int i = b0 + lane;
+        bool flag = false;
+        double ang_d = 0;
+        if (i < cnt) {
+          const uint32_t p = c.reg[i];
+          const uint32_t li = pk_lin(c, p);
+          const unsigned rp = c.P[li];
+          if constexpr (MW) {
+            overtaken = overtaken || (rp & LSD_USED) != 0u;
+            c.M[li] = 0; c.H[li] = 0;
+          } else {
+            c.P[li] = rp & ~LSD_USED;
+          }
+          if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < width) {
+            flag = true;
+            ang_d = angle_diff_signed((double)c.A[rp & LSD_REC_IDX].angf * kDegToRads, ang_c);
+          }
+        }
+        n += __popcll(__ballot(flag));
+        PLH_WAVE_SYNC();
+        c.T[lane] = ang_d; c.T[64 + lane] = ang_d * ang_d; c.T[128 + lane] = 0.0;
+        PLH_WAVE_SYNC();
+        acc = lsd_chain_add(c, acc, min(64, cnt - b0));
+      }
+      if constexpr (MW) {
+        if (__ballot(overtaken) != 0ull) { t.conflict = true; PF_ADD(c, 6, PF_NOW() - pg2); return t; }
+      }
+      const double sum = bcast_f64(acc, 0), s_sum = bcast_f64(acc, 1);
+      const double mean_angle = sum / (double)n;
+      PLH_WAVE_SYNC();
+      if (lane == 0) {   // parameters of the second region_grow()
+        gs.d[0] = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+        gs.u[0] = cPk; gs.u[1] = rec0 & ~LSD_USED;
+        gs.u[2] = __float_as_uint(ang0); gs.u[3] = __float_as_uint(sx0); gs.u[4] = __float_as_uint(sy0);
+      }
+      grow_lane_fence<MW>();
+      cnt1 = cnt;
+      if constexpr (MW) c.reg = base + cnt1;   // the first region stays in the log
+      cnt = lsd_region_grow<MW>(c, gs, -1, false, 2, &regAngF, &t.conflict);
+      t.finCnt = cnt;
+      if constexpr (MW) {
+        t.logLen = cnt1 + cnt; t.finBase = cnt1;
+        if (bcast_u32(*c.asmCnt, 0) > (unsigned)MW_ASM_CAP) t.conflict = true;
+      }
+      PF_ADD(c, 6, PF_NOW() - pg2);
+      if (t.conflict || cnt < 2) return t;
+      angS = regAngF;
+      phase = 1; fromRing = true;
+      continue;
+    }
+    if (phase == 1) {
+      // reduce_region_radius() starts: the radius from the end points of the exact rectangle (evaluated above: a verdict
+      // other than "dense" takes the exact path in this phase), carried in LDS (gs.d[0] is free now)
+      const uint32_t cPk = c.reg[0];
+      const double xc = (double)pk_x(cPk), yc = (double)pk_y(cPk);
+      if constexpr (MW) {   // it permutes and drops queue entries: it works on a copy, the log keeps the grown region
+        uint32_t* cp = c.reg + cnt;
+        for (int i = lane; i < cnt; i += 64) cp[i] = c.reg[i];
+        grow_lane_fence<true>();
+        c.reg = cp;
+        t.finBase = cnt1 + cnt;
+      }
+      const double r1 = dist_sq(xc, yc, rec[0], rec[1]), r2 = dist_sq(xc, yc, rec[2], rec[3]);
+      PLH_WAVE_SYNC();
+      if (lane == 0) gs.d[0] = r1 > r2 ? r1 : r2;
+      PLH_WAVE_SYNC();
+      phase = 2;
+    }
+    {   // one step of reduce_region_radius()
+      const uint32_t oPk = c.reg[0];
+      const double radSq = gs.d[0] * (0.75 * 0.75);
+      PLH_WAVE_SYNC();
+      if (lane == 0) gs.d[0] = radSq;
+      cnt = lsd_reduce_radius_step<MW>(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
+      t.finCnt = cnt;
+      PF_ADD(c, 7, 1);
+      PF_ADD(c, 6, PF_NOW() - pg2);
+      if (cnt < 2) break;
+      fromRing = false;
+    }
+  }
+  t.finCnt = cnt; t.ang = angS;
+  return t;
+}
+
 // flsd(): one wavefront per frame, seeds in pseudo-order, sequential semantics.
 // VGPR budget: 64 registers = 8 wavefronts per SIMD.  The kernel needs 74 (6 per SIMD); capped at 64 the compiler spills six
 // values that live across region_grow() calls (a few scratch accesses per call, none inside the step loop), and the two extra
@@ -933,7 +967,6 @@ __device__ int lsd_reduce_radius_step(const GrowCtx& c, int cnt, double xc, doub
 #else
 #define PLH_GROW_ATTR
 #endif
-template <bool ADV>
 __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned char* smem) {
   const int b = blockIdx.x, lane = threadIdx.x;
   GrowCtx c;
@@ -985,7 +1018,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   const int grp = lane >> 3, nbr = lane & 7;
   const int nbq = nbr < 4 ? nbr : nbr + 1;
   const int ndy = nbq / 3 - 1, ndx = nbq - (nbq / 3) * 3 - 1;
-  int nseg = 0;
+  int nseg = 0, logOff = 0;   // segment slots handed out; words of the frame's log (a.reg) taken by the kept regions
   // LDS tables that keep the seed scan and the prefetched neighbourhoods out of the registers (the wavefront's VGPR
   // count decides how many frames are resident): the 64 seeds of a scan, and per lane the first-step record
   uint32_t* tabP = (uint32_t*)(smem + LSD_RING * 4);   // packed coordinates
@@ -1001,7 +1034,6 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   gs.d = (double*)(batchSk + 8);
   gs.u = (uint32_t*)(gs.d + LSD_GS_D);
   gs.fstPx = fstPx; gs.fstIdx = fstIdx; gs.fstPk = fstPk;
-  double* rec = gs.d + 1;
   for (int sbase = 0; sbase < nOrd; sbase += 64) {
     // 64 seeds per scan: one coalesced load + one parallel `used` test; the survivors' own records (angle, seed
     // cos/sin) are fetched by their scan lanes, all at once
@@ -1058,7 +1090,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
         // marks may have changed since the scan / the neighbourhood prefetch: re-read them (one round trip)
         if (dirtySeed) seedQ = c.P[seed];
         if (seedQ & LSD_USED) continue;   // swallowed by a region grown since the scan
-        // region_grow -> region2rect -> [refine: tighter tolerance, re-grow -> region2rect -> reduce_region_radius]
+        // region_grow -> [density] -> refine: tighter tolerance, re-grow -> [density] -> reduce_region_radius (lsd_txn)
         PLH_WAVE_SYNC();
         if (lane == 0) {
           gs.d[0] = a.prec;
@@ -1066,99 +1098,16 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
           gs.u[2] = __float_as_uint(tabA[sk]); gs.u[3] = __float_as_uint(tabC[sk]); gs.u[4] = __float_as_uint(tabS[sk]);
         }
         PLH_WAVE_SYNC();
-        int phase = 0;
-        bool emit = false;
-        for (;;) {
-          float regAngF;
-          const unsigned long long pg0 = PF_NOW();
-          int cnt = lsd_region_grow<false>(c, gs, phase == 0 ? t : -1, dirtyFst, phase == 0 ? a.minRegSize : 2, &regAngF);
-          dirtySeed = true; dirtyFst = true;
-          const unsigned long long pg1 = PF_NOW();
-          PF_ADD(c, 2, pg1 - pg0);
-          if (cnt < (phase == 0 ? a.minRegSize : 2)) break;
-          const double reg_angle = (double)regAngF * kDegToRads;
-          __syncthreads();   // queue stores visible to every lane
-          PF_ADD(c, 14, 1); PF_ADD(c, 1, cnt);
-          lsd_region2rect(c, cnt, reg_angle, a.prec, rec);
-          const unsigned long long pg2 = PF_NOW();
-          PF_ADD(c, 5, pg2 - pg1);
-          double density = rect_density(cnt, rec);
-          if (!(density < a.densityTh)) { emit = true; break; }
-          const uint32_t cPk = c.reg[0];   // refine() and reduce_region_radius() work around reg[0]
-          const double xc = (double)pk_x(cPk), yc = (double)pk_y(cPk);
-          if (phase == 0) {   // refine(): tolerance from the angle spread near the seed, everything un-marked
-            PF_ADD(c, 15, 1);
-            const uint32_t cLin = pk_lin(c, cPk);
-            const unsigned rec0 = c.P[cLin];
-            const LsdAngleEntry* e0 = c.A + (rec0 & LSD_REC_IDX);
-            const float ang0 = e0->angf, sx0 = e0->seedx, sy0 = e0->seedy;
-            const double ang_c = (double)ang0 * kDegToRads, width = rec[4];
-            double acc = 0;
-            int n = 0;
-            for (int base = 0; base < cnt; base += 64) {
-              const int i = base + lane;
-              bool flag = false;
-              double ang_d = 0;
-              if (i < cnt) {
-                const uint32_t p = c.reg[i];
-                const uint32_t li = pk_lin(c, p);
-                const unsigned rp = c.P[li];
-                c.P[li] = rp & ~LSD_USED;
-                if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < width) {
-                  flag = true;
-                  ang_d = angle_diff_signed((double)c.A[rp & LSD_REC_IDX].angf * kDegToRads, ang_c);
-                }
-              }
-              n += __popcll(__ballot(flag));
-              PLH_WAVE_SYNC();
-              c.T[lane] = ang_d; c.T[64 + lane] = ang_d * ang_d; c.T[128 + lane] = 0.0;
-              PLH_WAVE_SYNC();
-              acc = lsd_chain_add(c, acc, min(64, cnt - base));
-            }
-            const double sum = bcast_f64(acc, 0), s_sum = bcast_f64(acc, 1);
-            const double mean_angle = sum / (double)n;
-            PLH_WAVE_SYNC();
-            if (lane == 0) {   // parameters of the second region_grow()
-              gs.d[0] = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-              gs.u[0] = cPk; gs.u[1] = rec0 & ~LSD_USED;
-              gs.u[2] = __float_as_uint(ang0); gs.u[3] = __float_as_uint(sx0); gs.u[4] = __float_as_uint(sy0);
-            }
-            phase = 1;
-            __syncthreads();
-            PF_ADD(c, 6, PF_NOW() - pg2);
-            continue;
-          }
-          // reduce_region_radius(); the squared radius is carried in LDS (gs.d[0] is free now), the centre and the region
-          // angle are recomputed, so that only the point count stays in registers across region2rect
-          {
-            const double r1 = dist_sq(xc, yc, rec[0], rec[1]), r2 = dist_sq(xc, yc, rec[2], rec[3]);
-            PLH_WAVE_SYNC();
-            if (lane == 0) gs.d[0] = r1 > r2 ? r1 : r2;
-            PLH_WAVE_SYNC();
-          }
-          emit = true;
-          const float regAngS = bcast_f32(regAngF, 0);
-          while (rect_density(cnt, rec) < a.densityTh) {
-            const uint32_t oPk = c.reg[0];
-            const double radSq = gs.d[0] * (0.75 * 0.75);
-            PLH_WAVE_SYNC();
-            if (lane == 0) gs.d[0] = radSq;
-            cnt = lsd_reduce_radius_step<false>(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
-            if (cnt < 2) { emit = false; break; }
-            PF_ADD(c, 7, 1); PF_ADD(c, 1, cnt);
-            lsd_region2rect(c, cnt, (double)regAngS * kDegToRads, a.prec, rec);
-          }
-          PF_ADD(c, 6, PF_NOW() - pg2);
-          break;
-        }
-        if constexpr (ADV) {   // LSD_REFINE_ADV: the rectangle has to be meaningful (NFA), after up to five kinds of adjustment
-          if (emit) emit = lsd_rect_improve(c, rec, a.prec, a.p, a.logNT);
-        }
-        if (!emit) continue;
-        if (lane == 0 && nseg < a.segCap) {
-          segs[nseg * 4 + 0] = (float)((rec[0] + 0.5) / 0.8); segs[nseg * 4 + 1] = (float)((rec[1] + 0.5) / 0.8);
-          segs[nseg * 4 + 2] = (float)((rec[2] + 0.5) / 0.8); segs[nseg * 4 + 3] = (float)((rec[3] + 0.5) / 0.8);
-        }
+        const LsdTxn tx = lsd_txn<false>(c, gs, a, t, dirtyFst);
+        dirtySeed = true; dirtyFst = true;
+        if (!tx.keep) continue;
+        // a line-support region: its pixels stay where they are -- the queue moves on behind them -- and its segment slot
+        // says where (LsdRegionEntry); k_lsd_rects puts the segment there.  The kept regions are disjoint sets of marked
+        // pixels and a queue only ever holds marked pixels outside them, so log + queue fit the frame's pixel count.
+        if (lane == 0 && nseg < a.segCap)
+          reinterpret_cast<uint4*>(segs)[nseg] = uint4{(unsigned)logOff, (unsigned)tx.finCnt, __float_as_uint(tx.ang), 0u};
+        logOff += tx.finCnt;
+        c.reg += tx.finCnt;
         nseg++;
       }
     }
@@ -1204,7 +1153,7 @@ constexpr int MW_N = 512;    // ring of posted transactions (power of two): boun
 constexpr int MW_F = 128;    // seed FIFO (power of two)
 constexpr int MW_LOW = 24;   // a wavefront that finds fewer seeds queued refills the FIFO
 constexpr int MW_MAX_WAVES = 16;
-enum { MWC_CURSOR = 0, MWC_LOCK, MWC_PUSH, MWC_POP, MWC_HEAD, MWC_DONE, MWC_NSEG, MWC_ABORT, MWC_DLOCK, MWC_RET = 16,
+enum { MWC_CURSOR = 0, MWC_LOCK, MWC_PUSH, MWC_POP, MWC_HEAD, MWC_DONE, MWC_NSEG, MWC_ABORT, MWC_DLOCK, MWC_LOGOFF, MWC_RET = 16,
        MWC_WORDS = MWC_RET + MW_MAX_WAVES };
 constexpr int MW_PEND_WORDS = 16;   // a posted transaction (MwPost)
 // A wait that lasts this many polls (some seconds) cannot be a wait for work: the kernel gives up instead of hanging the GPU
@@ -1277,144 +1226,30 @@ __device__ void mw_scan(const GrowCtx& c, int* ctl, uint4* fifo, const uint32_t*
   if (lane == 0) mw_st(&ctl[MWC_CURSOR], cursor);
 }
 
-struct MwTxn {
-  int logLen;            // pixels ever accepted: regBase[0 .. logLen)
-  int finBase, finCnt;   // the pixels still marked at the end (the final region): regBase[finBase .. finBase + finCnt)
-  bool emit;             // a segment came out (its rectangle is in gs.d[1 .. 5])
-  bool conflict;         // the run met a committed mark on a pixel it holds: not the reference's course, to be run again
-};
-
-// One transaction: the body of flsd()'s loop for one seed (oracle/lsd.cc:269-285; lsd_grow_frame's phase loop), with the
-// region queues of its phases laid end to end so that the log keeps every pixel it ever accepted.
-__device__ MwTxn lsd_txn_mw_core(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, uint32_t* regBase, uint32_t seedPk,
-                                 unsigned seedRec, unsigned sAngBits, unsigned sCxBits, unsigned sSyBits) {
-  const int lane = c.lane;
-  double* rec = gs.d + 1;
-  MwTxn t;
-  t.emit = false; t.conflict = false;
+// One transaction of the multi-wavefront kernel: lsd_txn<true> for the seed, its log at regBase.
+__device__ LsdTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, uint32_t* regBase, uint32_t seedPk,
+                             unsigned seedRec, unsigned sAngBits, unsigned sCxBits, unsigned sSyBits) {
   c.reg = regBase;
   PLH_WAVE_SYNC();
-  if (lane == 0) {
+  if (c.lane == 0) {
     gs.d[0] = a.prec;
     gs.u[0] = seedPk; gs.u[1] = seedRec; gs.u[2] = sAngBits; gs.u[3] = sCxBits; gs.u[4] = sSyBits;
     *c.asmCnt = 0;
   }
   PLH_WAVE_SYNC();
-  float regAngF;
-  const unsigned long long pg0 = PF_NOW();
-  int cnt = lsd_region_grow<true>(c, gs, -1, false, a.minRegSize, &regAngF, &t.conflict);
-  const unsigned long long pg1 = PF_NOW();
-  PF_ADD(c, 2, pg1 - pg0);
-  t.logLen = cnt; t.finBase = 0; t.finCnt = cnt;
-  if (bcast_u32(*c.asmCnt, 0) > (unsigned)MW_ASM_CAP) t.conflict = true;   // more predictions than the list holds: not this time
-  if (t.conflict || cnt < a.minRegSize) return t;   // (a region below the minimum is dropped, its pixels stay used)
-  grow_lane_fence<true>();
-  lsd_region2rect(c, cnt, (double)regAngF * kDegToRads, a.prec, rec);
-  PF_ADD(c, 5, PF_NOW() - pg1); PF_ADD(c, 14, 1);
-  if (!(rect_density(cnt, rec) < a.densityTh)) { t.emit = true; return t; }
-  const unsigned long long pg2 = PF_NOW();
-  PF_ADD(c, 15, 1);
-  // refine(): tolerance from the angle spread near the seed, everything un-marked, grown again
-  const int cnt1 = cnt;
-  const uint32_t cPk = c.reg[0];
-  const double xc = (double)pk_x(cPk), yc = (double)pk_y(cPk);
-  {
-    const uint32_t cLin = pk_lin(c, cPk);
-    const unsigned rec0 = c.P[cLin];
-    const LsdAngleEntry* e0 = c.A + (rec0 & LSD_REC_IDX);
-    const float ang0 = e0->angf, sx0 = e0->seedx, sy0 = e0->seedy;
-    const double ang_c = (double)ang0 * kDegToRads, width = rec[4];
-    double acc = 0;
-    int n = 0;
-    bool overtaken = false;
-    for (int base = 0; base < cnt; base += 64) {
-      const int i = base + lane;
-      bool flag = false;
-      double ang_d = 0;
-      if (i < cnt) {
-        const uint32_t p = c.reg[i];
-        const uint32_t li = pk_lin(c, p);
-        const unsigned rp = c.P[li];
-        overtaken = overtaken || (rp & LSD_USED) != 0u;
-        c.M[li] = 0; c.H[li] = 0;
-        if (sqrt(dist_sq(xc, yc, (double)pk_x(p), (double)pk_y(p))) < width) {
-          flag = true;
-          ang_d = angle_diff_signed((double)c.A[rp & LSD_REC_IDX].angf * kDegToRads, ang_c);
-        }
-      }
-      n += __popcll(__ballot(flag));
-      PLH_WAVE_SYNC();
-      c.T[lane] = ang_d; c.T[64 + lane] = ang_d * ang_d; c.T[128 + lane] = 0.0;
-      PLH_WAVE_SYNC();
-      acc = lsd_chain_add(c, acc, min(64, cnt - base));
-    }
-    if (__ballot(overtaken) != 0ull) { t.conflict = true; PF_ADD(c, 6, PF_NOW() - pg2); return t; }
-    const double sum = bcast_f64(acc, 0), s_sum = bcast_f64(acc, 1);
-    const double mean_angle = sum / (double)n;
-    PLH_WAVE_SYNC();
-    if (lane == 0) {
-      gs.d[0] = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-      gs.u[0] = cPk; gs.u[1] = rec0 & ~LSD_USED;
-      gs.u[2] = __float_as_uint(ang0); gs.u[3] = __float_as_uint(sx0); gs.u[4] = __float_as_uint(sy0);
-    }
-  }
-  grow_lane_fence<true>();
-  c.reg = regBase + cnt1;   // the first region stays in the log
-  cnt = lsd_region_grow<true>(c, gs, -1, false, 2, &regAngF, &t.conflict);
-  t.logLen = cnt1 + cnt; t.finBase = cnt1; t.finCnt = cnt;
-  if (bcast_u32(*c.asmCnt, 0) > (unsigned)MW_ASM_CAP) t.conflict = true;
-  if (t.conflict || cnt < 2) { PF_ADD(c, 6, PF_NOW() - pg2); return t; }
-  grow_lane_fence<true>();
-  lsd_region2rect(c, cnt, (double)regAngF * kDegToRads, a.prec, rec);
-  if (!(rect_density(cnt, rec) < a.densityTh)) { t.emit = true; PF_ADD(c, 6, PF_NOW() - pg2); return t; }
-  // reduce_region_radius() permutes and drops queue entries: it works on a copy, the log keeps the grown region
-  {
-    uint32_t* cp = c.reg + cnt;
-    for (int i = lane; i < cnt; i += 64) cp[i] = c.reg[i];
-    grow_lane_fence<true>();
-    c.reg = cp;
-    t.finBase = cnt1 + cnt;
-    const double r1 = dist_sq(xc, yc, rec[0], rec[1]), r2 = dist_sq(xc, yc, rec[2], rec[3]);
-    PLH_WAVE_SYNC();
-    if (lane == 0) gs.d[0] = r1 > r2 ? r1 : r2;
-    PLH_WAVE_SYNC();
-  }
-  t.emit = true;
-  const float regAngS = bcast_f32(regAngF, 0);
-  while (rect_density(cnt, rec) < a.densityTh) {
-    const uint32_t oPk = c.reg[0];
-    const double radSq = gs.d[0] * (0.75 * 0.75);
-    PLH_WAVE_SYNC();
-    if (lane == 0) gs.d[0] = radSq;
-    cnt = lsd_reduce_radius_step<true>(c, cnt, (double)pk_x(oPk), (double)pk_y(oPk), radSq);
-    if (cnt < 2) { t.emit = false; break; }
-    PF_ADD(c, 7, 1);
-    lsd_region2rect(c, cnt, (double)regAngS * kDegToRads, a.prec, rec);
-  }
-  t.finCnt = cnt;
-  PF_ADD(c, 6, PF_NOW() - pg2);
-  return t;
-}
-
-template <bool ADV>
-__device__ __forceinline__ MwTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, uint32_t* regBase, uint32_t seedPk,
-                                            unsigned seedRec, unsigned sAngBits, unsigned sCxBits, unsigned sSyBits) {
-  MwTxn t = lsd_txn_mw_core(c, gs, a, regBase, seedPk, seedRec, sAngBits, sCxBits, sSyBits);
-  if constexpr (ADV) {   // LSD_REFINE_ADV: reads the (immutable) level-line field only, so it is part of the transaction's tail
-    if (t.emit && !t.conflict) t.emit = lsd_rect_improve(c, gs.d + 1, a.prec, a.p, a.logNT);
-  }
-  return t;
+  return lsd_txn<true>(c, gs, a, -1, false);
 }
 
 // A posted transaction: 16 words in LDS, ring slot = sequence number mod MW_N.
 //   w[0]  flags: bit 0 has a log (0: the seed was used already, or is predicted to be), bit 1 ran against a possibly stale map,
-//         bit 2 segment, bit 3 INLINE; bits 8-15 wavefront; bits 16-23 pixels taken for used on an older claim;
+//         bit 2 the final region is kept (a segment), bit 3 INLINE; bits 8-15 wavefront; bits 16-23 pixels taken for used on an older claim;
 //         bits 24-31 (inline form) pixels accepted
 //   w[1..4]  seed (packed coordinates, angle, seed cos / sin bits): to run it again
 //   inline form (a region that was dropped for its size, never refined -- four transactions in five): w[5..12] = the accepted
 //         pixels, then the assumed ones (packed coordinates; at most 8 together): nothing of it lies in global memory
 //   general form: w[5] log offset in the wavefront's arena, w[6] log length, w[7] / w[8] first / count of the final region,
-//         w[9..12] segment, w[13..15] up to 3 assumed pixels (more: in the arena behind the log)
+//         w[9] region angle of a kept region (bits of the float; the commit copies the region to the frame's log and
+//         writes its LsdRegionEntry), w[13..15] up to 3 assumed pixels (more: in the arena behind the log)
 struct MwPost {
   unsigned w[MW_PEND_WORDS];
 };
@@ -1428,11 +1263,6 @@ struct MwShared {
   MwPost* pend;    // [MW_N]
 };
 
-__device__ __forceinline__ void mw_segment(const double* rec, float seg[4]) {   // flsd(): + 0.5, / SCALE
-  seg[0] = (float)((rec[0] + 0.5) / 0.8); seg[1] = (float)((rec[1] + 0.5) / 0.8);
-  seg[2] = (float)((rec[2] + 0.5) / 0.8); seg[3] = (float)((rec[3] + 0.5) / 0.8);
-}
-
 // Commit the posted transactions at the head of the sequence, in order, for as long as there are any (caller holds
 // MWC_DLOCK).  `ch` is the drain context: a log arena and a mark plane of its own (slot W of the frame) for the transactions
 // that have to be run again.
@@ -1441,12 +1271,14 @@ __device__ __forceinline__ void mw_segment(const double* rec, float seg[4]) {   
 // one LDS round trip for the posts, one load of all their records; a pixel an older post of the batch publishes counts as
 // used for the younger ones (compared lane against lane); everything in front of the first post that fails is committed
 // with one store per pixel.
-template <bool ADV>
+// A kept region goes to the frame's log (frameLog: the one-wavefront kernel's queue area, free here) and its LsdRegionEntry into
+// the next segment slot, exactly as the one-wavefront kernel leaves them; k_lsd_rects evaluates the rectangles.
 __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
-                         uint32_t* drainReg, float* segs) {
+                         uint32_t* drainReg, float* segs, uint32_t* frameLog) {
   const int lane = ch.lane, g = lane >> 3, j = lane & 7;
   int h = mw_ld_u(&sh.ctl[MWC_HEAD]);
   int nseg = mw_ld_u(&sh.ctl[MWC_NSEG]);
+  int logOff = mw_ld_u(&sh.ctl[MWC_LOGOFF]);
   const int h0 = h;
   for (;;) {
     // ---- the inline posts among the next eight sequence numbers
@@ -1499,10 +1331,11 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       // a log of up to 64 pixels whose final region lies inside it (nearly all): every lane keeps its pixel's record from the
       // validation, so that publishing is a store and not another two dependent fetches
       const bool oneGo = logLen <= 64 && finBase + finCnt <= logLen;
-      uint32_t myIdx = 0;
+      uint32_t myIdx = 0, myPk = 0;
       unsigned myRec = 0;
       if (oneGo && lane < logLen && (fl & 3u)) {
-        myIdx = pk_lin(ch, log[lane]);
+        myPk = log[lane];
+        myIdx = pk_lin(ch, myPk);
         myRec = ch.P[myIdx];
       }
       if (fl & 2u) {
@@ -1539,11 +1372,17 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
             for (int i = lane; i < finCnt; i += 64) ch.P[pk_lin(ch, log[finBase + i])] |= LSD_USED;
           }
         }
-        if ((fl & 4u) && lane == 0 && nseg < a.segCap) {
-          segs[nseg * 4 + 0] = __uint_as_float(q2.y); segs[nseg * 4 + 1] = __uint_as_float(q2.z);
-          segs[nseg * 4 + 2] = __uint_as_float(q2.w); segs[nseg * 4 + 3] = __uint_as_float(q3.x);
+        if (fl & 4u) {
+          if (oneGo) {
+            if (lane >= finBase && lane < finBase + finCnt) frameLog[logOff + lane - finBase] = myPk;
+          } else {
+            for (int i = lane; i < finCnt; i += 64) frameLog[logOff + i] = log[finBase + i];
+          }
+          if (lane == 0 && nseg < a.segCap)   // (every lane read the same post: q2.y is the region angle in all of them)
+            reinterpret_cast<uint4*>(segs)[nseg] = uint4{(unsigned)logOff, (unsigned)finCnt, q2.y, 0u};
+          nseg++;
+          logOff += finCnt;
         }
-        nseg += (fl >> 2) & 1u;
       }
     }
     if (bad) {
@@ -1557,20 +1396,19 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       ch.hTag = (unsigned)h % 65535u + 1u;
       ch.hWin = 0;   // nothing older is in flight: no claim is believed
       if (!(seedRec & LSD_USED)) {
-        const MwTxn t = lsd_txn_mw<ADV>(ch, gs, a, drainReg, seedPk, seedRec, bcast_u32(q0.z, 0), bcast_u32(q0.w, 0), bcast_u32(q1.x, 0));
+        const LsdTxn t = lsd_txn_mw(ch, gs, a, drainReg, seedPk, seedRec, bcast_u32(q0.z, 0), bcast_u32(q0.w, 0), bcast_u32(q1.x, 0));
         grow_lane_fence<true>();
         for (int i = lane; i < t.finCnt; i += 64) {
           const uint32_t li = pk_lin(ch, drainReg[t.finBase + i]);
           ch.P[li] |= LSD_USED;
           ch.M[li] = 0;
         }
-        if (t.emit) {
-          if (lane == 0 && nseg < a.segCap) {
-            float sg[4];
-            mw_segment(gs.d + 1, sg);
-            segs[nseg * 4 + 0] = sg[0]; segs[nseg * 4 + 1] = sg[1]; segs[nseg * 4 + 2] = sg[2]; segs[nseg * 4 + 3] = sg[3];
-          }
+        if (t.keep) {
+          for (int i = lane; i < t.finCnt; i += 64) frameLog[logOff + i] = drainReg[t.finBase + i];
+          if (lane == 0 && nseg < a.segCap)
+            reinterpret_cast<uint4*>(segs)[nseg] = uint4{(unsigned)logOff, (unsigned)t.finCnt, __float_as_uint(t.ang), 0u};
           nseg++;
+          logOff += t.finCnt;
         }
       }
       PF_ADD(ch, 10, PF_NOW() - pr0);
@@ -1586,6 +1424,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
     mw_release();   // the USED bits are in place before `head` says so: a transaction that starts as the oldest trusts them
     if (lane == 0) {
       mw_st(&sh.ctl[MWC_NSEG], nseg);
+      mw_st(&sh.ctl[MWC_LOGOFF], logOff);
       mw_st(&sh.ctl[MWC_HEAD], h);
     }
   }
@@ -1593,9 +1432,8 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
 }
 
 // take the drain lock if there is something to commit and nobody is at it; returns whether anything was done
-template <bool ADV>
 __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
-                             uint32_t* drainReg, float* segs) {
+                             uint32_t* drainReg, float* segs, uint32_t* frameLog) {
   bool did = false;
   const int wvTrace = (int)(threadIdx.x >> 6);
   (void)wvTrace;
@@ -1606,7 +1444,7 @@ __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceA
     mw_acquire();
     const unsigned long long pd0 = PF_NOW();
     MW_TRACE(wvTrace, ch.lane, 5, h);   // drain session begins at head h
-    mw_drain<ADV>(ch, gs, a, sh, frameReg, drainReg, segs);
+    mw_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog);
     MW_TRACE(wvTrace, ch.lane, 6, mw_ld(&sh.ctl[MWC_HEAD]));   // ... ends
     PF_ADD(ch, 23, PF_NOW() - pd0); PF_ADD(ch, 25, 1);
     if (ch.lane == 0) mw_st(&sh.ctl[MWC_DLOCK], 0);
@@ -1616,7 +1454,6 @@ __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceA
   return did;
 }
 
-template <bool ADV>
 __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsigned char* smem) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, W = (int)(blockDim.x >> 6);
   MwShared sh;
@@ -1650,6 +1487,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   gs.fstPx = nullptr; gs.fstIdx = nullptr; gs.fstPk = nullptr;
   const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;
   float* segs = a.segs + (long long)b * a.arenaStride;
+  uint32_t* const frameLog = a.reg + (long long)b * a.arenaStride;   // the kept regions, in commit order (k_lsd_rects reads them)
   const int nOrd = a.nOrdered[b];
 #if defined(PLH_GROW_PROF)
   unsigned long long pfv[40];
@@ -1723,7 +1561,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     if (s < 0) {
       if (done && pop >= push && head >= push) break;   // every seed handed out and committed
       const unsigned long long pw0 = PF_NOW();
-      if (mw_try_drain<ADV>(ch, gs, a, sh, frameReg, drainReg, segs)) { polls = 0; continue; }
+      if (mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog)) { polls = 0; continue; }
       int stop = 0;
       MW_TRACE(wv, lane, 7, (pop < push ? 1 : 0) | (off > S ? 2 : 0) | (pop - head >= a.mwLag ? 4 : 0) | (done ? 8 : 0));   // nothing to do: why
       if (lane == 0) { stop = mw_give_up(ctl, polls, a.status); mw_pause(); }
@@ -1742,7 +1580,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     unsigned pFlags = 8u;   // the seed was used already: nothing to check, nothing to do
     int pMode = 0;          // 1: predicted unused, 2: inline, 3: general
     unsigned pGen[4] = {0u, 0u, 0u, 0u};   // general form: off, logLen, finBase, finCnt
-    float pSeg[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned pAng = 0u;     // general form, kept region: its region angle (float bits)
     int pAcc = 0, pAsm = 0;
     c.hTag = (unsigned)s % 65535u + 1u;
     for (;;) {
@@ -1783,7 +1621,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       }
       const unsigned long long pt0 = PF_NOW();
       MW_TRACE(wv, lane, 2, s);   // run begins
-      const MwTxn t = lsd_txn_mw<ADV>(c, gs, a, regBase + off, seedPk, seedRec, ent.y, ent.z, ent.w);
+      const LsdTxn t = lsd_txn_mw(c, gs, a, regBase + off, seedPk, seedRec, ent.y, ent.z, ent.w);
       grow_lane_fence<true>();
       MW_TRACE(wv, lane, 3, t.logLen);   // run ends
       // through: take the private marks back (the plane is clean for the next transaction) and look once more whether an
@@ -1792,7 +1630,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       const unsigned long long pv0 = PF_NOW();
       const int asmLen = (int)bcast_u32(*c.asmCnt, 0);
       // a region that was dropped for its size without a refine() is all in the LDS mirror of its queue: its post goes inline
-      const bool inl = !t.emit && t.finBase == 0 && t.finCnt == t.logLen && t.logLen + asmLen <= MW_INLINE_MAX;
+      const bool inl = !t.keep && t.finBase == 0 && t.finCnt == t.logLen && t.logLen + asmLen <= MW_INLINE_MAX;
       bool bad = t.conflict;
       if (!bad) {
         for (int base = 0; base < t.logLen; base += 64) {
@@ -1823,10 +1661,10 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       } else {
         for (int i = lane; i < t.finCnt; i += 64) c.M[pk_lin(c, log[t.finBase + i])] = 0;
         const int used = max(t.logLen, t.finBase + t.finCnt);
-        pFlags = 1u | (spec ? 2u : 0u) | (t.emit ? 4u : 0u) | ((unsigned)wv << 8) | ((unsigned)asmLen << 16);
+        pFlags = 1u | (spec ? 2u : 0u) | (t.keep ? 4u : 0u) | ((unsigned)wv << 8) | ((unsigned)asmLen << 16);
         pMode = 3;
         pGen[0] = (unsigned)off; pGen[1] = (unsigned)t.logLen; pGen[2] = (unsigned)t.finBase; pGen[3] = (unsigned)t.finCnt;
-        if (t.emit) mw_segment(gs.d + 1, pSeg);
+        pAng = __float_as_uint(t.ang);
         if (asmLen <= 3) {
           off += used;
         } else {
@@ -1850,7 +1688,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
         else if (k < pAcc + pAsm) pw = c.asmList[k - pAcc];
       } else if (pMode == 3) {
         if (lane < MWP_SEG) pw = lane == MWP_OFF ? pGen[0] : (lane == MWP_LOGLEN ? pGen[1] : (lane == MWP_FINBASE ? pGen[2] : pGen[3]));
-        else if (lane < MWP_ASM) pw = __float_as_uint(lane == MWP_SEG ? pSeg[0] : (lane == MWP_SEG + 1 ? pSeg[1] : (lane == MWP_SEG + 2 ? pSeg[2] : pSeg[3])));
+        else if (lane < MWP_ASM) pw = lane == MWP_SEG ? pAng : 0u;
         else if (lane - MWP_ASM < min(pAsm, 3)) pw = c.asmList[lane - MWP_ASM];
       }
       MW_TRACE(wv, lane, 4, pMode);   // posting
@@ -1866,7 +1704,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     // (and a wavefront with nothing else to do always does).
     {
       const int hd = mw_ld_u(&ctl[MWC_HEAD]);
-      if (s == hd || s - hd >= a.mwDrainGap) mw_try_drain<ADV>(ch, gs, a, sh, frameReg, drainReg, segs);
+      if (s == hd || s - hd >= a.mwDrainGap) mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog);
     }
   }
   __syncthreads();
@@ -1905,35 +1743,23 @@ __device__ __forceinline__ float seg_length(const float e[4]) {
 // the latency of its own instruction stream.
 __global__ void __launch_bounds__(64) PLH_GROW_ATTR k_lsd_grow(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame<false>(a, smem);
+  lsd_grow_frame(a, smem);
 }
 __global__ void __launch_bounds__(64) k_lsd_grow_lone(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame<false>(a, smem);
+  lsd_grow_frame(a, smem);
 }
-// LSD_REFINE_ADV (plh_line_set_refine): the same with rect_improve() behind refine(); its own kernels, so that the builds above
-// keep their registers
-__global__ void __launch_bounds__(64) k_lsd_grow_adv(LineDeviceArgs a) {
-  HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame<true>(a, smem);
-}
+// (LSD_REFINE_ADV needs no build of its own any more: rect_improve() reads the immutable level-line field only and decides
+// nothing that region growing depends on, so it runs with the rectangles in k_lsd_rects)
 
 // up to 8 wavefronts per frame: 256 registers to spare; 9 .. 16: half of that (the workgroup is 1024 threads)
 __global__ void __launch_bounds__(512) k_lsd_grow_mw(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame_mw<false>(a, smem);
+  lsd_grow_frame_mw(a, smem);
 }
 __global__ void __launch_bounds__(1024) k_lsd_grow_mw16(LineDeviceArgs a) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame_mw<false>(a, smem);
-}
-__global__ void __launch_bounds__(512) k_lsd_grow_mw_adv(LineDeviceArgs a) {
-  HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame_mw<true>(a, smem);
-}
-__global__ void __launch_bounds__(1024) k_lsd_grow_mw16_adv(LineDeviceArgs a) {
-  HIP_DYNAMIC_SHARED(unsigned char, smem)
-  lsd_grow_frame_mw<true>(a, smem);
+  lsd_grow_frame_mw(a, smem);
 }
 
 __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
@@ -1944,7 +1770,7 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = min(a.nSegs[b], a.segCap);
   const float* segs = a.segs + (long long)b * a.arenaStride;
-  unsigned long long* keys = (unsigned long long*)(a.reg + (long long)b * a.arenaStride);   // scratch (free after k_lsd_grow)
+  unsigned long long* keys = (unsigned long long*)(a.reg + (long long)b * a.arenaStride);   // scratch (free after k_lsd_rects)
   if (tid == 0) s_valid = 0;
   __syncthreads();
   int myValid = 0;
@@ -2337,32 +2163,25 @@ size_t lsd_grow_lds_bytes(int spitch, int sh);
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s) {
   if (a.mwWaves > 0) {
     const size_t ldsMw = (size_t)MWC_WORDS * 4 + (size_t)MW_N * (4 + MW_PEND_WORDS * 4) + (size_t)MW_F * 16 + (size_t)a.mwWaves * MW_WAVE_LDS;
-    if (ldsMw > 64u * 1024u) {   // beyond 64 KiB the dynamic LDS has to be requested per kernel (once)
-      static bool asked = false;
-      if (!asked) {
-        (void)lds_request(k_lsd_grow_mw, 160u * 1024u, "k_lsd_grow_mw");
-        (void)lds_request(k_lsd_grow_mw16, 160u * 1024u, "k_lsd_grow_mw16");
-        (void)lds_request(k_lsd_grow_mw_adv, 160u * 1024u, "k_lsd_grow_mw_adv");
-        (void)lds_request(k_lsd_grow_mw16_adv, 160u * 1024u, "k_lsd_grow_mw16_adv");
-        asked = true;
-      }
-    }
+    // (beyond 64 KiB the dynamic LDS has to be requested per kernel and device: plh_line_create does, lsd_grow_request_lds)
     // (the roomy build holds three wavefronts per SIMD: beyond two per SIMD over the whole GPU take the 128-register one)
     const bool roomy = a.mwWaves <= 8 && (long long)a.batch * a.mwWaves <= 2048;
     const dim3 g(a.batch), b(64 * a.mwWaves);
-    if (a.refineAdv) {
-      if (roomy) hipLaunchKernelGGL(k_lsd_grow_mw_adv, g, b, ldsMw, s, a);
-      else hipLaunchKernelGGL(k_lsd_grow_mw16_adv, g, b, ldsMw, s, a);
-    } else {
-      if (roomy) hipLaunchKernelGGL(k_lsd_grow_mw, g, b, ldsMw, s, a);
-      else hipLaunchKernelGGL(k_lsd_grow_mw16, g, b, ldsMw, s, a);
-    }
+    if (roomy) hipLaunchKernelGGL(k_lsd_grow_mw, g, b, ldsMw, s, a);
+    else hipLaunchKernelGGL(k_lsd_grow_mw16, g, b, ldsMw, s, a);
     return;
   }
   const size_t lds = lsd_grow_lds_bytes(a.spitch, a.sh);
-  if (a.refineAdv) hipLaunchKernelGGL(k_lsd_grow_adv, dim3(a.batch), dim3(64), lds, s, a);
-  else if (a.batch <= 8) hipLaunchKernelGGL(k_lsd_grow_lone, dim3(a.batch), dim3(64), lds, s, a);
+  if (a.batch <= 8) hipLaunchKernelGGL(k_lsd_grow_lone, dim3(a.batch), dim3(64), lds, s, a);
   else hipLaunchKernelGGL(k_lsd_grow, dim3(a.batch), dim3(64), lds, s, a);
+}
+// The multi-wavefront kernels with more than ~11 wavefronts per frame need more than 64 KiB of dynamic LDS, which has to be
+// asked for per kernel on the CURRENT device: once per handle at create time (not behind a process-wide flag -- a second GPU in
+// the same process would never get it).
+plh_status lsd_grow_request_lds() {
+  plh_status st = lds_request(k_lsd_grow_mw, 160u * 1024u, "k_lsd_grow_mw");
+  if (st == PLH_OK) st = lds_request(k_lsd_grow_mw16, 160u * 1024u, "k_lsd_grow_mw16");
+  return st;
 }
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s) {
   hipLaunchKernelGGL(k_keylines, dim3(a.batch), dim3(256), (size_t)a.outCap * 8 + 64, s, a, kl, fn, n);

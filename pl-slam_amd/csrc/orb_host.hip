@@ -256,11 +256,15 @@ plh_status build_plan(plh_orb* h) {
     // strips: consecutive cells of one cell row (same y0) -> one k_fast_strips block
     for (int ci = L.cellBase; ci < (int)h->cells.size();) {
       int cj = ci;   // at most ~FAST_STRIP_MAX_W columns per strip: small LDS tiles keep >= 5 blocks per CU resident
-      static const int stripW = [] {   // tuning knob for experiments (plan time only)
+#if defined(PLH_GROW_PROF)
+      static const int stripW = [] {   // tuning knob of the counter build (tools/, profiles/r02_fast_strip_width_sweep.txt)
         const char* e = getenv("PLH_FAST_STRIP_W");
         const int v = e ? atoi(e) : 0;
         return v >= 64 && v <= 1000 ? v : FAST_STRIP_MAX_W;
       }();
+#else
+      const int stripW = FAST_STRIP_MAX_W;
+#endif
       while (cj < (int)h->cells.size() && h->cells[cj].y0 == h->cells[ci].y0 &&
              (cj == ci || h->cells[cj].x0 + h->cells[cj].cw - h->cells[ci].x0 <= stripW)) cj++;
       OrbStrip st;

@@ -68,6 +68,10 @@ __device__ __forceinline__ float fract(float x) { return x - floorf(x); }
 __device__ __forceinline__ float sqrt_approx(float x) { return sqrtf(x); }
 // IEEE float division for operands whose quotient and reciprocal stay in the normal range (lsd_atan2_deg, lsd_grow.hip)
 __device__ __forceinline__ float div_normal(float num, float den) { return num / den; }
+// sin / cos of an angle given in turns (1.0 = 360 degrees), |turns| <= 256: estimates (absolute error of a few 1e-6) for
+// callers that carry their own error bound (lsd_density_screen, lsd_grow.hip)                          (v_sin_f32, v_cos_f32)
+__device__ __forceinline__ float sin_turns(float t) { return sinf(t * 6.28318530717958647692f); }
+__device__ __forceinline__ float cos_turns(float t) { return cosf(t * 6.28318530717958647692f); }
 // words in LDS shared by the wavefronts of a workgroup (k_lsd_grow_mw): relaxed, workgroup scope
 __device__ __forceinline__ int lds_load(const int* p) { return *(volatile const int*)p; }
 __device__ __forceinline__ void lds_store(int* p, int v) { *(volatile int*)p = v; }
@@ -149,10 +153,26 @@ __device__ __forceinline__ float div_normal(float num, float den) {
   q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
   return __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
 }
-__device__ __forceinline__ int lds_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ float sin_turns(float t) { return __builtin_amdgcn_sinf(t); }
+__device__ __forceinline__ float cos_turns(float t) { return __builtin_amdgcn_cosf(t); }
+// The handshakes of k_lsd_grow_mw publish plain LDS stores (a post, FIFO entries) by a later store to a control word and read
+// them after loading that word.  The hardware keeps a wavefront's LDS operations in order; what has to be pinned is the
+// COMPILER's order of the plain accesses around the relaxed atomic -- a wavefront-scope fence does exactly that and emits no
+// instruction (a workgroup-scope release would also drain the wavefront's global stores: s_waitcnt vmcnt(0) on every control
+// word; the places that do hand over global memory say so with wg_release / wg_acquire).
+__device__ __forceinline__ int lds_load(const int* p) {
+  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return v;
+}
+__device__ __forceinline__ void lds_store(int* p, int v) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ int lds_cas(int* p, int cmp, int v) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __hip_atomic_compare_exchange_strong(p, &cmp, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   return cmp;
 }
 
@@ -252,6 +272,8 @@ __device__ __forceinline__ int plh_sbfe1(unsigned v, int k) { return shim::sbfe1
 __device__ __forceinline__ float plh_fract(float x) { return shim::fract(x); }
 __device__ __forceinline__ float plh_sqrt_approx(float x) { return shim::sqrt_approx(x); }
 using shim::div_normal;
+using shim::sin_turns;
+using shim::cos_turns;
 using shim::lds_load;
 using shim::lds_store;
 using shim::lds_cas;

@@ -7,7 +7,7 @@
 namespace plh {
 
 enum { ST_BALLOT = 0, ST_INV_BALLOT, ST_BCAST32, ST_BCAST64, ST_WAVE_MIN, ST_PERM, ST_ALIGNBYTE, ST_UDOT4, ST_UDOT2, ST_PK_MIN, ST_PK_ADD,
-       ST_PK_SUB, ST_PK_MAD, ST_SAT255, ST_SBFE1, ST_FRACT, ST_SQRT, ST_DIV, ST_WALK, ST_WALK_DUP, ST_COUNT };
+       ST_PK_SUB, ST_PK_MAD, ST_SAT255, ST_SBFE1, ST_FRACT, ST_SQRT, ST_DIV, ST_WALK, ST_WALK_DUP, ST_TURNS, ST_COUNT };
 
 __device__ __forceinline__ unsigned long long st_mix(unsigned long long z) {   // splitmix64
   z += 0x9E3779B97F4A7C15ull;
@@ -76,6 +76,11 @@ __global__ void __launch_bounds__(64) k_shim_selftest(int* failures, int rounds)
       const float num = big * fr, den = big + 2.2204460492503131e-16f;
       bad[ST_DIV] += __float_as_uint(hw::div_normal(num, den)) != __float_as_uint(ref::div_normal(num, den));
     }
+    {
+      // sin / cos of an angle in turns: estimates, the caller (lsd_density_screen) budgets 1e-5 of absolute error
+      const float t = (float)(a >> 8) * (1.0f / 16777216.0f) * ((it & 1) ? 1.f : 1.5f);
+      bad[ST_TURNS] += !(fabsf(hw::sin_turns(t) - ref::sin_turns(t)) <= 4e-6f) || !(fabsf(hw::cos_turns(t) - ref::cos_turns(t)) <= 4e-6f);
+    }
     // the walk of lsd_resolve, with and without duplicate pixels
     {
       const unsigned long long P = mask & u1;
@@ -123,7 +128,7 @@ plh_status plh_selftest(int device, int* failing_checks, int32_t* per_shim, int 
   PLH_HIP(hipFree(d));
   static const char* names[ST_COUNT] = {"wballot", "inv_ballot", "bcast_u32/f32", "bcast_f64", "wave_min_i32", "perm", "alignbyte", "udot4",
                                         "udot2", "pk_min_u16", "pk_add16", "pk_sub16", "pk_twice_plus16", "hi_halves_sat255", "sbfe1", "fract",
-                                        "sqrt_approx", "div_normal", "lsd_walk", "lsd_walk (duplicates)"};
+                                        "sqrt_approx", "div_normal", "lsd_walk", "lsd_walk (duplicates)", "sin_turns / cos_turns"};
   int total = 0;
   for (int k = 0; k < ST_COUNT; k++) {
     if (per_shim && k < per_shim_cap) per_shim[k] = h[k];

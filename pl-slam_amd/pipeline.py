@@ -196,7 +196,7 @@ class FrontEndPipelined:
     GATHERED = ("n", "kps", "desc", "nl", "kl", "ldesc", "lfn")   # the records a tracker on another GPU needs
 
     def __init__(self, P, vocab, batch, rows=480, cols=640, nfeatures=1000, nlevels=8, n_lines=200, min_line_length=0.0,
-                 K=None, D=None, device=0, nsplit=2):
+                 K=None, D=None, device=0, nsplit=2, lsd_refine=-1):
         import torch
         assert batch % nsplit == 0
         self.torch, self.P, self.B, self.nsplit, self.Bp = torch, P, batch, nsplit, batch // nsplit
@@ -220,6 +220,7 @@ class FrontEndPipelined:
         fp.bow_levelsup, fp.orb_th_low, fp.orb_nnratio, fp.orb_check_orientation = 4, 50, 0.7, 1
         fp.line_th, fp.line_nnratio = 50.0, 0.7
         fp.external_records = 1
+        fp.lsd_refine = int(lsd_refine)   # -1: the library's default (PLH_LSD_REFINE_DEFAULT), 0 STD, 1 ADV
         h = C.c_void_p()
         P._check(L, L.plh_frontend_create(C.byref(fp), self.hvoc.h, batch, nsplit, device, C.byref(h)), "plh_frontend_create")
         self.h = h

@@ -113,7 +113,7 @@ def _selftest(P, lib):
 
 def test_emu_selftest_entry_point(plslam, emu_lib):
     bad, per = _selftest(plslam, emu_lib)      # the emulator build has only the portable twins: nothing can differ
-    assert bad == 0 and len(per) == 20 and not any(per)
+    assert bad == 0 and len(per) == 21 and not any(per)
 
 
 @pytest.mark.gpu
