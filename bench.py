@@ -21,14 +21,20 @@ One JSON line on stdout (rank 0) with, besides the contract fields,
                    launch stream over the timed region, against the 8 TB/s HBM peak;
   "roofline_fast": the same for the FAST kernel the north star sets its 60 % goal on, plus its VALU-issue roofline (the
                    bound it really runs against);
-  "cpu_baseline":  the CPU oracle (from-scratch restatement, kind "port") on this box's host cores, bounded sample;
+  "cpu_baseline":  the CPU oracle (from-scratch restatement, kind "port") on this box's host cores -- one native thread, one per
+                   physical core, one per hardware thread (oracle/frontend.cc: std::thread shards) -- bounded sample;
   "secondary":     (N = 1) the KITTI 1241x376 / 2000-feature workload of BASELINE configs[4]: one GPU's resident-batch rate,
                    and the literal configs[4] share of 4096 / 8 = 512 frames per GPU;
   "streaming":     (N = 1) the PCIe-inclusive rate described above;
   "latency_ms_single_frame": (N = 1) one Frame() worth of extraction through the host-buffer entry points, ORB and lines on
                    two threads as Frame.cc:224-227 runs them;
-  "verified":      the records the timed steps left behind for the first 64 frames of the batch (and of each secondary batch),
-                   compared bit for bit with the CPU oracle on the same frames; a mismatch makes the run exit non-zero.
+  "verified":      the records the timed steps left behind for the first 16 frames of EVERY sub-batch (and of each secondary
+                   batch), compared bit for bit with the CPU oracle on the same frames; with N > 1 every rank verifies its own
+                   batch and the line carries the per-rank verdicts; a mismatch makes the run exit non-zero.
+  "secondary.refine_adv": (N = 1) the same workload with cv::LSD_REFINE_ADV (`--refine adv` makes it the headline): resident
+                   rate, the 512-frame share, one-frame latency, verified, its own roofline.
+`--frames <dir | file>` replaces the synthetic frames by real ones (raw 8-bit planes or PGM, pl-slam_amd/frames_io.py), with
+the TUM1 / KITTI00-02 camera picked by --rows / --cols.
 """
 import argparse
 import json
@@ -64,71 +70,74 @@ def level_sizes(rows, cols, nlevels):
     return out
 
 
-def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, budget_s=20.0):
-    """The oracle on all host cores: per frame ORB + (remap) + lines + BoW transform + both matchers against the
-    previous frame of the same worker (ctypes releases the GIL, so threads run in parallel)."""
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo; falls back to os.cpu_count()."""
+    try:
+        seen, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or (os.cpu_count() or 1)
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=0, budget_s=8.0):
+    """The oracle on the host cores, natively threaded (oracle/frontend.cc plo_frontend_batch: one std::thread per worker, each
+    with its own ORB handle and buffers): per frame ORB + (remap) + lines + BoW transform + both matchers against the worker's
+    previous frame -- the work of one product step per frame.  Three legs: one thread, one per physical core, one per hardware
+    thread; `value` is the best of them."""
     import ctypes as C
-    from concurrent.futures import ThreadPoolExecutor
-    cores = os.cpu_count() or 1
     L = O.lib()
-    L.plo_bow_transform.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    L.plo_bow_transform.restype = None
-    L.plo_bow_vector.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
-    L.plo_bow_vector.restype = C.c_int
-    rows, cols = frames[0].shape
-    mx = np.zeros((rows, cols), np.float32)
-    my = np.zeros((rows, cols), np.float32)
-    Kf, Df = np.asarray(K, np.float32), np.asarray(D, np.float32)
-    L.plo_undistort_maps(O._p(Kf), O._p(Df), cols, rows, O._p(mx), O._p(my))
-    ww = voc.word_weight()
+    L.plo_frontend_batch.restype = C.c_double
+    L.plo_frontend_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + \
+                                    [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    frames = np.ascontiguousarray(frames)
+    n, rows, cols = frames.shape
+    mx = my = None
+    if K is not None and D is not None and any(D):
+        mx = np.zeros((rows, cols), np.float32)
+        my = np.zeros((rows, cols), np.float32)
+        L.plo_undistort_maps(O._p(np.asarray(K, np.float32)), O._p(np.asarray(D, np.float32)), cols, rows, O._p(mx), O._p(my))
+    ww = np.ascontiguousarray(voc.word_weight(), np.float64)
 
-    def one_frame(orb, img, prev):
-        kps, desc = orb.extract(img)
-        und = np.zeros_like(img)
-        L.plo_remap_linear_u8(O._p(img), cols, rows, cols, O._p(mx), O._p(my), O._p(und), cols)
-        kl, ldesc, fn = O.line_extract(und, nlines, 0.0)
-        n = len(desc)
-        nid = np.zeros(max(n, 1), np.int32)
-        word = np.zeros(max(n, 1), np.int32)
-        L.plo_bow_transform(O._p(desc), n, O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id),
-                            O._p(voc.weight), voc.L, 4, O._p(nid), O._p(word))
-        bw, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
-        L.plo_bow_vector(O._p(word), n, O._p(ww), 0, 0, O._p(bw), O._p(bv), max(n, 1))
-        cur = (desc, np.ascontiguousarray(kps["angle"]), nid, ldesc)
-        if prev is not None:
-            pd, pa, pn, pl = prev
-            valid = np.ones(len(pd), np.uint8)
-            m = np.zeros(max(n, 1), np.int32)
-            L.plo_orb_search_by_bow(O._p(pd), O._p(pa), O._p(pn), O._p(valid), len(pd), O._p(desc), O._p(cur[1]), O._p(nid), n,
-                                    50, 0.7, 1, O._p(m))
-            ml = np.zeros(max(len(pl), 1), np.int32)
-            L.plo_line_search_double(O._p(pl), len(pl), O._p(ldesc), len(ldesc), 50.0, 0.7, O._p(ml))
-        return cur
+    def run(threads, per_thread):
+        chk = C.c_ulonglong(0)
+        dt = L.plo_frontend_batch(O._p(frames), n, rows, cols, nfeatures, nlevels, nlines, int(refine), O._p(mx), O._p(my),
+                                  O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id), O._p(voc.weight),
+                                  O._p(ww), voc.L, threads, per_thread, C.byref(chk))
+        return threads * per_thread / dt, dt
 
-    orbs = [O.OrbOracle(nfeatures, 1.2, nlevels, 20, 7) for _ in range(cores)]
-    t0 = time.perf_counter()
-    one_frame(orbs[0], frames[0], one_frame(orbs[0], frames[1 % len(frames)], None))
-    per = (time.perf_counter() - t0) / 2
-    per_thread = int(max(2, min(48, budget_s / max(per, 1e-4))))
-    nf = len(frames)
-
-    def work(t):
-        prev = None
-        for k in range(per_thread):
-            prev = one_frame(orbs[t], frames[(t * per_thread + k) % nf], prev)
-        return per_thread
-
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        done = sum(ex.map(work, range(cores)))
-    dt = time.perf_counter() - t0
-    return {"value": round(done / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "single_thread_ms_per_frame": round(per * 1e3, 1),
-            "sample": "%d synthetic %dx%d frames (ORB + remap + LSD/LBD + BoW + SearchByBoW + SearchDouble), oracle/ restatement "
-                      "(g++ -O2 -ffp-contract=off, no OpenCV SIMD), %d host threads x %d frames" % (done, cols, rows, cores, per_thread)}
+    hw, phys = os.cpu_count() or 1, physical_cores()
+    r1, dt1 = run(1, 3)
+    per = dt1 / 3
+    legs = {"1": {"threads": 1, "frames_per_s": round(r1, 2), "ms_per_frame": round(per * 1e3, 2)}}
+    best, best_threads = r1, 1
+    for name, th in (("physical_cores", phys), ("hardware_threads", hw)):
+        if th <= 1 or str(th) in legs:
+            continue
+        per_thread = int(max(3, min(32, budget_s / max(per, 1e-4))))
+        r, dt = run(th, per_thread)
+        legs[str(th)] = {"threads": th, "which": name, "frames_per_s": round(r, 2), "frames": th * per_thread, "seconds": round(dt, 2),
+                         "parallel_efficiency": round(r / (r1 * th), 3)}
+        if r > best:
+            best, best_threads = r, th
+    return {"value": round(best, 2), "unit": "frames/s", "cores": best_threads, "kind": "port", "physical_cores": phys,
+            "hardware_threads": hw, "legs": legs, "single_thread_ms_per_frame": round(per * 1e3, 1),
+            "sample": "synthetic %dx%d frames (ORB + remap + LSD%s/LBD + BoW + SearchByBoW + SearchDouble per frame), oracle/ restatement "
+                      "(g++ -O2 -ffp-contract=off, no OpenCV SIMD), native std::thread shards (oracle/frontend.cc); cores = the thread "
+                      "count of the best leg" % (cols, rows, " (LSD_REFINE_ADV)" if refine else "")}
 
 
-def oracle_records(O, V, frames, voc, nfeatures, nlevels, nlines, K, D):
+def oracle_records(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=0):
     """Everything one step produces for `frames` (consecutive frames of a batch), from the CPU oracle, on all host cores:
     per frame keypoints / rBRIEF / FeatureVector nodes / words / BowVector / keylines / LBD / line equations, and per
     consecutive pair the SearchByBoW and SearchDouble match lists.  The checker of `verify_records`, nothing else."""
@@ -155,7 +164,7 @@ def oracle_records(O, V, frames, voc, nfeatures, nlevels, nlines, K, D):
         if undist:
             src = np.zeros_like(img)
             L.plo_remap_linear_u8(O._p(img), cols, rows, cols, O._p(mx), O._p(my), O._p(src), cols)
-        kl, ldesc, fn = O.line_extract(src, nlines, 0.0)
+        kl, ldesc, fn = O.line_extract(src, nlines, 0.0, refine=refine)
         n = len(desc)
         nid = np.zeros(max(n, 1), np.int32)
         word = np.zeros(max(n, 1), np.int32)
@@ -182,11 +191,12 @@ def oracle_records(O, V, frames, voc, nfeatures, nlevels, nlines, K, D):
     return recs, pairs
 
 
-def verify_records(res, recs, pairs):
-    """Compare the first len(recs) frames of a step's results (FrontEnd*.results()) with the oracle's: every record, bit for bit.
-    Returns {"frames", "exact", "mismatches"}."""
+def verify_records(res, recs, pairs, first=0):
+    """Compare frames [first, first + len(recs)) of a step's results (FrontEnd*.results()) with the oracle's: every record, bit for
+    bit; pairs[i] = frame first + i -> first + i + 1.  Returns the list of mismatches (empty = exact)."""
     bad = []
-    for b, r in enumerate(recs):
+    for i, r in enumerate(recs):
+        b = first + i
         n, nl = int(res["n"][b]), int(res["nl"][b])
         if n != len(r["desc"]):
             bad.append("frame %d: %d keypoints vs %d" % (b, n, len(r["desc"])))
@@ -209,33 +219,56 @@ def verify_records(res, recs, pairs):
                 bad.append("frame %d: keyline field %s" % (b, f))
         if not ((res["ldesc"][b, :nl] == r["ldesc"]).all() and (res["lfn"][b, :nl] == r["lfn"]).all()):
             bad.append("frame %d: LBD descriptors / line equations" % b)
-    for b, q in enumerate(pairs):
+    for i, q in enumerate(pairs):
+        b = first + i
         if not (int(res["nm_orb"][b]) == q["nm_orb"] and (res["m_orb"][b, :len(q["m_orb"])] == q["m_orb"]).all()):
             bad.append("pair %d -> %d: SearchByBoW matches" % (b, b + 1))
         if not (int(res["nm_line"][b]) == q["nm_line"] and (res["m_line"][b, :len(q["m_line"])] == q["m_line"]).all()):
             bad.append("pair %d -> %d: SearchDouble matches" % (b, b + 1))
-    return {"frames": len(recs), "pairs": len(pairs), "exact": not bad, "mismatches": bad[:8],
-            "what": "every record of the first %d frames of the timed batch (keypoints, rBRIEF, FeatureVector, BowVector, keylines, LBD, "
-                    "line equations) and the match lists of their %d consecutive pairs, compared bit for bit with the CPU oracle on the "
-                    "same frames" % (len(recs), len(pairs))}
+    return bad
+
+
+def verify_batch(O, V, W, res, voc, per_part):
+    """The records of the first `per_part` frames of EVERY sub-batch of workload W (what its last steps left behind), against the
+    oracle on the same frames.  {"frames", "pairs", "exact", "mismatches", ...}."""
+    nv = min(per_part, W.Bp)
+    bad, nf, npairs = [], 0, 0
+    for k in range(W.nsplit):
+        first = k * W.Bp
+        recs, pairs = oracle_records(O, V, W.frames[first:first + nv], voc, W.nfeatures, W.nlevels, W.nlines, W.K, W.D, refine=W.refine)
+        bad += verify_records(res, recs, pairs, first)
+        nf += len(recs)
+        npairs += len(pairs)
+    return {"frames": nf, "pairs": npairs, "sub_batches": W.nsplit, "exact": not bad, "mismatches": bad[:8],
+            "what": "every record of the first %d frames of each of the %d sub-batches of the timed batch (keypoints, rBRIEF, FeatureVector, "
+                    "BowVector, keylines, LBD, line equations) and the match lists of their consecutive pairs, compared bit for bit with "
+                    "the CPU oracle on the same frames" % (nv, W.nsplit)}
 
 
 class Workload:
     """One resident batch + the pipelined front end over it."""
 
     def __init__(self, P, S, V, PL, torch, dev, rank, batch, nsplit, rows, cols, nfeatures, nlevels, nlines, unique, voc, serial=False,
-                 shard=None):
+                 shard=None, refine=0, screen=True, real=None):
         self.P, self.torch, self.dev = P, torch, dev
         self.B, self.rows, self.cols, self.nfeatures, self.nlevels, self.nlines = batch, rows, cols, nfeatures, nlevels, nlines
         self.tum = (rows, cols) == (480, 640)
         K, D = (TUM1_K, TUM1_D) if self.tum else (None, None)     # KITTI: zero distortion -> no remap (Frame.cc:917-921)
-        if shard is None:     # weak scaling: every rank has its own batch
+        self.K, self.D, self.refine = K, D, int(refine)
+        if real is not None:  # real frames (--frames): the sequence, cycled to fill the batch; rank r starts r batches in
+            idx = (np.arange(batch) + (rank * batch if shard is None else shard[0] * batch)) % len(real)
+            self.frames = np.ascontiguousarray(real[idx])
+        elif shard is None:   # weak scaling: every rank has its own batch
             self.frames = S.make_frames(2 + 100000 * rank, batch, rows, cols, unique=unique)
         else:                 # strong scaling: this rank's contiguous shard of ONE job of `total` frames
             r, n, total = shard
             self.frames = np.ascontiguousarray(S.make_frames(2, total, rows, cols, unique=unique)[r * (total // n):(r + 1) * (total // n)])
         self.d_imgs = torch.from_numpy(self.frames).to(dev)
-        self.fe = PL.FrontEndPipelined(P, voc, batch, rows, cols, nfeatures, nlevels, nlines, 0.0, K, D, device=dev.index, nsplit=nsplit)
+        self.fe = PL.FrontEndPipelined(P, voc, batch, rows, cols, nfeatures, nlevels, nlines, 0.0, K, D, device=dev.index, nsplit=nsplit,
+                                       lsd_refine=self.refine)
+        if not screen:        # A/B switch: the exact rectangle behind every density decision (rounds 1-3)
+            for part in self.fe.parts:
+                part.line.set_screen(0)
         self.fe.overlap = not serial
         self.serial = serial
         self.nsplit, self.Bp = nsplit, self.fe.Bp
@@ -310,12 +343,13 @@ def load_profile_json(name):
     return {}
 
 
-def single_frame_latency(P, torch, dev, frames, nfeatures, nlevels, nlines, K, D, reps=12):
+def single_frame_latency(P, torch, dev, frames, nfeatures, nlevels, nlines, K, D, reps=12, refine=0):
     """One Frame() worth of extraction through the host-buffer entry points (plh_orb_extract / plh_line_extract: H2D, kernels,
     D2H, blocking), ORB and lines on two host threads as Frame.cc:224-227 runs ExtractORB / ExtractLSD."""
     rows, cols = frames[0].shape
     orb = P.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, rows=rows, cols=cols, max_batch=1, device=dev.index)
     line = P.LINEextractor(1, 1.2, nlines, 0.0, rows=rows, cols=cols, max_batch=1, device=dev.index, K=K, D=D)
+    line.set_refine(refine)
     out = {}
 
     def timed(fn, n):
@@ -358,10 +392,16 @@ def main():
                     help="weak: --batch frames per GPU; strong: --total frames in all, contiguous shards of total / N per rank "
                          "(BASELINE configs[4]: --scaling strong --total 4096 --rows 376 --cols 1241)")
     ap.add_argument("--total", type=int, default=4096, help="--scaling strong: frames of the whole job")
+    ap.add_argument("--refine", choices=["std", "adv", "default"], default="default",
+                    help="cv::LineSegmentDetector's refine level of the headline: LSD_REFINE_STD, LSD_REFINE_ADV, or the library's "
+                         "build-time default (PLH_LSD_REFINE_DEFAULT; the other level is reported under `secondary`)")
+    ap.add_argument("--no-screen", action="store_true", help="A/B: region growing without the density screen (same records)")
+    ap.add_argument("--frames", default=None, help="real frames instead of synthetic ones: a raw / PGM file or a directory of them "
+                                                   "(rows x cols 8-bit planes; pl-slam_amd/frames_io.py), cycled to fill the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the N = 1 secondary / streaming / latency legs")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed batch's records with the CPU oracle")
-    ap.add_argument("--verify-frames", type=int, default=64, help="frames of the timed batch compared with the oracle (rank 0)")
+    ap.add_argument("--verify-frames", type=int, default=16, help="frames of EVERY sub-batch of the timed batch compared with the oracle (on every rank)")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # 1-rank RCCL communicator: rehearses the N > 1 path
     ap.add_argument("--serial", action="store_true", help="ORB and line halves on one stream (no overlap); used for PMC runs")
     args = ap.parse_args()
@@ -407,8 +447,17 @@ def main():
     V = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
     PL = _util._load("plslam_amd_pipeline", os.path.join(ROOT, "pl-slam_amd", "pipeline.py"))
     voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=S, idf=True)
+    lib_default = int(P.load().plh_lsd_refine_default())
+    refine = {"std": 0, "adv": 1, "default": lib_default}[args.refine]
+    real = None
+    if args.frames:
+        FIO = _util._load("plslam_amd_frames_io", os.path.join(ROOT, "pl-slam_amd", "frames_io.py"))
+        real = FIO.load_frames(args.frames, args.rows, args.cols)
+        if (args.rows, args.cols) == (376, 1241) and args.nfeatures == 1000:
+            args.nfeatures = 2000          # KITTI00-02.yaml
     W = Workload(P, S, V, PL, torch, dev, rank, args.batch, args.nsplit, args.rows, args.cols, args.nfeatures, args.nlevels, args.nlines,
-                 args.unique, voc, serial=args.serial, shard=(rank, world, args.total) if strong else None)
+                 args.unique, voc, serial=args.serial, shard=(rank, world, args.total) if strong else None, refine=refine,
+                 screen=not args.no_screen, real=real)
     fe, B, Bp, rows, cols = W.fe, W.B, W.Bp, W.rows, W.cols
 
     comm = comm_stream = None
@@ -471,10 +520,26 @@ def main():
 
     result_line = None
     failed_verification = []
+    t1 = W.kernel_totals() if rank == 0 else None
+    res = fe.results()   # what the timed steps left in the result buffers (before anything else runs over them)
+    verified = None
+    if not args.no_verify:
+        # self-verification, on EVERY rank: what the timed kernels left in the result buffers, against the oracle on the same
+        # frames -- the first --verify-frames frames of each sub-batch
+        O = _util.oracle()
+        O.build()
+        verified = verify_batch(O, V, W, res, voc, args.verify_frames)
+        if world > 1:   # a scaling run is a parity run: rank 0 reports every rank's verdict
+            mine = {"rank": rank, "exact": verified["exact"], "frames": verified["frames"], "pairs": verified["pairs"],
+                    "mismatches": verified["mismatches"]}
+            allv = [None] * world
+            dist.all_gather_object(allv, mine)
+            verified = dict(verified, per_rank=allv, exact=all(v["exact"] for v in allv),
+                            frames=sum(v["frames"] for v in allv), pairs=sum(v["pairs"] for v in allv))
+    if verified is not None and not verified["exact"]:   # (every rank: a rank whose records differ exits non-zero as well)
+        failed_verification.append("timed batch: %s" % (verified.get("per_rank") or verified["mismatches"]))
     if rank == 0:
-        t1 = W.kernel_totals()
         per_ms_timed = [ms / max(n, 1) for ms, n in t1]   # HIP events on the launch streams, over the timed region
-        res = fe.results()   # what the timed steps left in the result buffers (before anything else runs over them)
         # one more pass with both halves on one stream: per-kernel durations without interference between the halves
         fe.overlap = False
         for _ in range(2):
@@ -483,26 +548,18 @@ def main():
         t2 = W.kernel_totals()
         per_ms = [(b[0] - a[0]) / max(b[1] - a[1], 1) for a, b in zip(t1, t2)]
         fe.overlap = not args.serial
-        verified = None
-        if not args.no_verify:
-            # self-verification: what the timed kernels left in the result buffers, against the oracle on the same frames
-            O = _util.oracle()
-            O.build()
-            nv = min(args.verify_frames, Bp)
-            recs, pairs = oracle_records(O, V, W.frames[:nv], voc, args.nfeatures, args.nlevels, args.nlines,
-                                         TUM1_K if W.tum else None, TUM1_D if W.tum else None)
-            verified = verify_records(res, recs, pairs)
         alg = W.algorithmic_bytes(res)
         dom = int(np.argmax(per_ms))
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame, and the
         # SQ instruction counters (tools/pmc_insts.sh -> profiles/r02_insts.json): collected on the headline workload only
-        headline = W.tum and args.nfeatures == 1000
+        headline = W.tum and args.nfeatures == 1000 and real is None
         # PMC figures are a property of a build: they are reported only when the file carries this library's build id
         build = P.load().plh_version().decode().split("build ")[-1].strip()
-        tj, ij = load_profile_json("hbm_traffic.json"), load_profile_json("r03_insts.json")
-        traffic = tj.get("kernels", {}) if headline and tj.get("build") == build else {}
-        insts = ij.get("kernels", {}) if headline and ij.get("build") == build else {}
-        pmc_note = {"library_build": build, "hbm_traffic.json": tj.get("build"), "r03_insts.json": ij.get("build"),
+        tj, ij = load_profile_json("hbm_traffic.json"), (load_profile_json("r04_insts.json") or load_profile_json("r03_insts.json"))
+        pmc_ok = headline and refine == 0 and not args.no_screen
+        traffic = tj.get("kernels", {}) if pmc_ok and tj.get("build") == build else {}
+        insts = ij.get("kernels", {}) if pmc_ok and ij.get("build") == build else {}
+        pmc_note = {"library_build": build, "hbm_traffic.json": tj.get("build"), "insts.json": ij.get("build"),
                     "note": "PMC-derived fields (roofline.traffic, valu_issue) are null unless the profile was collected on this build"}
         pmc_names = {1: ["k_fast_strips"], 5: ["k_lsd_grow"], 0: ["k_pyr_down"], 2: ["k_octree"], 3: ["k_orient_brief"]}
 
@@ -550,17 +607,22 @@ def main():
             "value": round(world * B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "host_enqueue_ms_per_step": [round(v, 2) for v in host_ms],   # how far the host runs ahead of the GPU (launch queues)
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "real frames" if real is not None else "synthetic",
             "config": {"workload": "%dx%d mono, %d-level pyramid, %d ORB / %d lines (%s parameters), batch %d frames/GPU resident in HBM "
                                    "(%d sub-batches of %d pipelined, consecutive steps overlap, nothing crosses PCIe in the timed region); "
                                    "extract + ComputeBoW + SearchByBoW + line SearchDouble per consecutive frame pair"
                                    % (cols, rows, args.nlevels, args.nfeatures, args.nlines, "TUM1.yaml" if W.tum else "KITTI00-02.yaml",
                                       B, args.nsplit, Bp),
+                       "lsd_refine": {"level": "LSD_REFINE_ADV" if refine else "LSD_REFINE_STD", "library_default": "LSD_REFINE_ADV" if lib_default else "LSD_REFINE_STD",
+                                      "note": "which level the reference's system opencv_contrib LSDDetector runs cannot be checked in this image "
+                                              "(INTEGRATION.md section 2); the other level is measured under secondary.refine_%s" % ("std" if refine else "adv")},
+                       "density_screen": not args.no_screen,
                        "mean_keypoints_per_frame": round(float(res["n"].mean()), 1), "mean_keylines_per_frame": round(float(res["nl"].mean()), 1),
                        "mean_orb_matches_per_pair": round(float(res["nm_orb"].mean()), 1),
                        "mean_line_matches_per_pair": round(float(res["nm_line"].mean()), 1),
                        "mean_bow_words_per_frame": round(float(res["bow_n"].mean()), 1),
-                       "frames": "%d rasterised synthetic frames per GPU + cheap variants (row shift, exposure); busy by construction: "
+                       "frames": ("%d real frames from %s, cycled to fill the batch" % (len(real), os.path.basename(args.frames.rstrip("/")))) if real is not None else
+                                 "%d rasterised synthetic frames per GPU + cheap variants (row shift, exposure); busy by construction: "
                                  "~2/3 of the 0.8x-scaled pixels end up in LSD regions, ~10%% of the pyramid pixels are FAST corners at "
                                  "minThFAST -- a stress case, real TUM frames are sparser" % args.unique,
                        "vocabulary": "synthetic k=10 L=6, idf-like weights (ORBvoc.bin is not in the mount)",
@@ -599,8 +661,6 @@ def main():
             out["rccl"] = {"version": comm.rccl_version(), "gather": args.gather, "channel_transports": tr,
                            "bytes_per_rank_per_step": int(sum(b.numel() * b.element_size() for part in recv["send"] for b in part))}
         W.set_profiling(False)
-        if verified is not None and not verified["exact"]:
-            failed_verification.append("timed batch: %s" % verified["mismatches"])
 
     # ---- N = 1 extras (rank 0 only, after the timed region; none of this is in `value`)
     if rank == 0 and world == 1 and not args.no_extras:
@@ -648,15 +708,16 @@ def main():
         torch.cuda.empty_cache()
         try:
             out["latency_ms_single_frame"] = single_frame_latency(P, torch, dev, lat_frames, args.nfeatures, args.nlevels, args.nlines,
-                                                                  TUM1_K if W.tum else None, TUM1_D if W.tum else None)
+                                                                  TUM1_K if W.tum else None, TUM1_D if W.tum else None, refine=refine)
         except Exception as e:
             out["latency_ms_single_frame"] = {"error": repr(e)[:200]}
         # secondary workload: KITTI 1241x376 / 2000 features (BASELINE configs[4]'s frame shape)
         if headline:
             try:
                 sec = {}
-                for label, b2, ns2 in (("resident_6144", 6144, 4), ("configs4_share_512", 512, 1)):
-                    W2 = Workload(P, S, V, PL, torch, dev, rank, b2, ns2, 376, 1241, 2000, 8, 200, 16, voc)
+                def leg(b2, ns2, r2, c2, nf2, uniq2, refine2, label):
+                    """One resident-batch leg after the timed region: rate, verified, per-kernel rooflines."""
+                    W2 = Workload(P, S, V, PL, torch, dev, rank, b2, ns2, r2, c2, nf2, 8, 200, uniq2, voc, refine=refine2, screen=not args.no_screen)
                     n2 = 3 if b2 > 1024 else 8   # the small share needs a few steps to reach its steady state
                     dt2 = W2.run(n2, 1 if b2 > 1024 else 2)
                     W2.set_profiling(True)
@@ -669,24 +730,46 @@ def main():
                     res2 = W2.fe.results()
                     ver2 = None
                     if not args.no_verify:
-                        recs2, pairs2 = oracle_records(_util.oracle(), V, W2.frames[:min(args.verify_frames, W2.Bp)], voc, 2000, 8, 200, None, None)
-                        ver2 = verify_records(res2, recs2, pairs2)
+                        ver2 = verify_batch(_util.oracle(), V, W2, res2, voc, args.verify_frames)
                         if not ver2["exact"]:
                             failed_verification.append("secondary %s: %s" % (label, ver2["mismatches"]))
                     alg2 = W2.algorithmic_bytes(res2)
                     d2 = int(np.argmax(pm2))
-                    sec[label] = {"value": round(b2 * n2 / dt2, 1), "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2, "batch": b2, "nsplit": ns2,
-                                  "mean_keypoints_per_frame": round(float(res2["n"].mean()), 1), "verified": ver2,
-                                  "roofline": roof(d2, pm2[d2], "HIP events, extra pass with both halves on one stream", W2.Bp, alg2),
-                                  "roofline_fast": roof(1, pm2[1], "HIP events, extra pass with both halves on one stream", W2.Bp, alg2)}
+                    r = {"value": round(b2 * n2 / dt2, 1), "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2, "batch": b2, "nsplit": ns2,
+                         "mean_keypoints_per_frame": round(float(res2["n"].mean()), 1), "mean_keylines_per_frame": round(float(res2["nl"].mean()), 1),
+                         "verified": ver2,
+                         "roofline": roof(d2, pm2[d2], "HIP events, extra pass with both halves on one stream", W2.Bp, alg2),
+                         "roofline_fast": roof(1, pm2[1], "HIP events, extra pass with both halves on one stream", W2.Bp, alg2),
+                         "kernel_ms_per_launch": {NAMES[k]: round(pm2[k], 4) for k in range(8)}}
                     W2.close()
                     del W2
                     torch.cuda.empty_cache()
+                    return r
+
+                sec = {}
+                for label, b2, ns2 in (("resident_6144", 6144, 4), ("configs4_share_512", 512, 1)):
+                    sec[label] = leg(b2, ns2, 376, 1241, 2000, 16, refine, label)
+                # the other refine level of cv::LineSegmentDetector on the headline workload (which one the reference's OpenCV runs is
+                # a property of that build: INTEGRATION.md section 2)
+                other = 1 - refine
+                oname = "refine_adv" if other else "refine_std"
+                ro = {"level": "LSD_REFINE_ADV" if other else "LSD_REFINE_STD", "unit": "frames/s",
+                      "resident_6144": leg(6144, 4, 480, 640, 1000, args.unique, other, oname + " resident_6144"),
+                      "share_512": leg(512, 1, 480, 640, 1000, args.unique, other, oname + " share_512")}
+                ro["value"] = ro["resident_6144"]["value"]
+                ro["vs_headline"] = round(ro["value"] / out["value"], 3)
+                ro["verified"] = ro["resident_6144"]["verified"]
+                ro["roofline"] = ro["resident_6144"]["roofline"]
+                try:
+                    ro["latency_ms_single_frame"] = single_frame_latency(P, torch, dev, lat_frames, args.nfeatures, args.nlevels, args.nlines,
+                                                                         TUM1_K, TUM1_D, reps=8, refine=other)
+                except Exception as e:
+                    ro["latency_ms_single_frame"] = {"error": repr(e)[:200]}
                 out["secondary"] = {"workload": "1241x376 mono (KITTI00-02.yaml: 2000 ORB, 8 levels, no distortion) + 200 lines, same pipeline; "
                                                 "BASELINE configs[4] shards 4096 such frames over 8 GPUs = 512 per GPU",
                                     "unit": "frames/s", "value": sec["resident_6144"]["value"], "ms_per_step": sec["resident_6144"]["ms_per_step"],
                                     "roofline": sec["resident_6144"]["roofline"], "resident_6144": sec["resident_6144"],
-                                    "configs4_share_512": sec["configs4_share_512"],
+                                    "configs4_share_512": sec["configs4_share_512"], oname: ro,
                                     "note": "512 resident frames cannot fill the GPU with one wavefront per frame, so region growing runs 8 "
                                             "wavefronts per frame there (k_lsd_grow_mw, same segments): the per-GPU rate of the literal configs[4] "
                                             "job is the configs4_share_512 figure, the 6144-frame one is what a GPU sustains on a long sequence"}
@@ -700,10 +783,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0)
             O = _util.oracle()
             O.build()
-            fr = S.make_frames(2, 64, rows, cols, unique=min(args.unique, 64))
+            fr = real[:64] if real is not None else S.make_frames(2, 64, rows, cols, unique=min(args.unique, 64))
             out["cpu_baseline"] = cpu_baseline(O, V, fr, voc, args.nfeatures, args.nlevels, args.nlines,
                                                TUM1_K if (rows, cols) == (480, 640) else KITTI_K,
-                                               TUM1_D if (rows, cols) == (480, 640) else [0, 0, 0, 0, 0])
+                                               TUM1_D if (rows, cols) == (480, 640) else [0, 0, 0, 0, 0], refine=refine)
         result_line = json.dumps(out)
     if comm is not None:
         comm.close()

@@ -143,6 +143,12 @@ int  plo_line_extract(const uint8_t* img, int rows, int cols, size_t step, const
 int  plo_line_extract_ex(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask, unsigned n_lsd_feature,
                          double min_line_length, plo_keyline* keylines, uint8_t* desc, double* linefn, int cap, int refine);
 
+/* ---- the whole front end of a batch of frames on std::threads: bench.py's cpu_baseline leg (oracle/frontend.cc) ---- */
+double plo_frontend_batch(const uint8_t* frames, int n, int rows, int cols, int nfeatures, int nlevels, int nlines, int refine,
+                          const float* mapx, const float* mapy, const uint8_t* node_desc, const int32_t* child_start,
+                          const int32_t* child_count, const int32_t* word_id, const float* weight, const double* word_weight, int L,
+                          int nthreads, int per_thread, unsigned long long* checksum);
+
 /* ---- Windowed (grid) searches of the tracking front end (reference src/Frame.cc, ORBmatcher.cc, LSDmatcher.cpp;
  *      oracle/frame_search.cc).  gp = {mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv};
  *      grid = CSR over 64 x 48 cells, cell (ix, iy) -> ix*48 + iy. ---- */

@@ -83,13 +83,13 @@ def _oracle_all(O, frames, nfeat):
         return list(ex.map(one, list(frames)))
 
 
-def _gpu_lines(P, frames, waves, lib=None, refine=0):
+def _gpu_lines(P, frames, waves, lib=None, refine=0, screen=1, K=None, D=None, mask=None):
     import torch
     B, rows, cols = frames.shape
-    ex = P.LINEextractor(1, 1.2, 200, 0.0, rows=rows, cols=cols, max_batch=B, lib=lib)
+    ex = P.LINEextractor(1, 1.2, 200, 0.0, rows=rows, cols=cols, max_batch=B, lib=lib, K=K, D=D)
     ex.set_grow_waves(waves)
-    if refine:
-        ex.set_refine(refine)
+    ex.set_refine(refine)
+    ex.set_screen(screen)
     cap = ex.capacity
     dev = torch.device("cuda", 0)
     d_img = torch.from_numpy(frames).to(dev)
@@ -97,7 +97,8 @@ def _gpu_lines(P, frames, waves, lib=None, refine=0):
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_fn = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev)
     d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
-    ex.extract_batch_dev(d_img, B, rows * cols, d_kl, d_desc, d_fn, d_n, torch.cuda.current_stream().cuda_stream)
+    d_mask = torch.from_numpy(np.ascontiguousarray(mask)).to(dev) if mask is not None else None
+    ex.extract_batch_dev(d_img, B, rows * cols, d_kl, d_desc, d_fn, d_n, torch.cuda.current_stream().cuda_stream, d_mask=d_mask)
     torch.cuda.synchronize()
     assert ex.status() == 0
     n = d_n.cpu().numpy()
@@ -115,11 +116,12 @@ def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat):
     assert len({f.tobytes() for f in frames}) == N_SOAK          # distinct
     ref = _oracle_all(oracle, frames, nfeat)
     nseg = sum(len(r[5]) for r in ref)
-    # lines: one wavefront per frame (k_lsd_grow), the automatic choice (k_lsd_grow_mw for this batch size), and four per frame
-    for waves in (0, -1, 4):
-        got = _gpu_lines(plslam, frames, waves)
+    # lines: one wavefront per frame (k_lsd_grow), the automatic choice (k_lsd_grow_mw for this batch size), four per frame, and
+    # one per frame with the density screen off (the exact rectangle behind every decision, as in rounds 1-3)
+    for waves, screen in ((0, 1), (-1, 1), (4, 1), (0, 0)):
+        got = _gpu_lines(plslam, frames, waves, screen=screen)
         for b, ((kl, ld, fn, sg), r) in enumerate(zip(got, ref)):
-            assert len(sg) == len(r[5]) and (sg == r[5]).all(), "waves %d, frame %d: LSD segments differ from the oracle" % (waves, b)
+            assert len(sg) == len(r[5]) and (sg == r[5]).all(), "waves %d, screen %d, frame %d: LSD segments differ from the oracle" % (waves, screen, b)
             assert len(kl) == len(r[2]) and all((kl[f] == r[2][f]).all() for f in r[2].dtype.names), "waves %d, frame %d: KeyLines" % (waves, b)
             assert (ld == r[3]).all() and (fn == r[4]).all(), "waves %d, frame %d: LBD / line equations" % (waves, b)
     # ORB on the same frames
@@ -155,31 +157,49 @@ def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat):
             got = _gpu_lines(plslam, frames, waves, lib=prof)
             L.plh_debug_grow_prof(out, 0)
             assert all(len(g[3]) == len(r[5]) and (g[3] == r[5]).all() for g, r in zip(got, ref))
+            # the density screen: every verdict of the counter build is checked against the exact density in the kernel
+            assert out[39] == 0, "waves %d: %d verdicts of the density screen contradict the exact density" % (waves, out[39])
             cover += ("  [waves %d] steps %d, accepted pixels %d, resolve passes %d, mispredictions %d, lanes decided by fastAtan2 %d "
-                      "(of them by the double form %d), region2rect calls %d, refine %d, reduce-radius steps %d, transactions %d "
-                      "(re-run: own %d, at commit %d)\n" % (waves, out[8], out[9], out[12], out[13], out[32], out[33], out[14], out[15], out[7],
-                                                             out[16], out[18], out[24]))
+                      "(of them by the double form %d), density decisions %d (screen: dense %d, sparse %d, undecided %d, contradicted %d), "
+                      "refine %d, reduce-radius steps %d, transactions %d (re-run: own %d, at commit %d)\n"
+                      % (waves, out[8], out[9], out[12], out[13], out[32], out[33], out[14], out[37], out[38], out[14] - out[37] - out[38],
+                         out[39], out[15], out[7], out[16], out[18], out[24]))
     print("\nsoak %dx%d: %d distinct frames, %d LSD segments and %d ORB keypoints bit-exact (waves 0 / auto / 4)\n%s"
           % (cols, rows, N_SOAK, nseg, nkp, cover))
 
 
-def test_soak_refine_adv(plslam, oracle, synth):
+@pytest.mark.parametrize("rows,cols,und", [(480, 640, False), (376, 1241, False), (480, 640, True)], ids=["640x480", "1241x376", "640x480-undistort-mask"])
+def test_soak_refine_adv(plslam, oracle, synth, rows, cols, und):
     """The same kind of content with cv::LSD_REFINE_ADV (rect_improve / rect_nfa / nfa on every kept rectangle): 128 distinct
-    640x480 frames, one wavefront per frame and the automatic multi-wavefront choice, against the oracle's ADV restatement."""
+    frames per shape -- 640x480, 1241x376, and 640x480 behind the TUM1 undistortion with one of the reference's masks -- one
+    wavefront per frame and the automatic multi-wavefront choice, against the oracle's ADV restatement."""
     n = min(N_SOAK, 128)
-    frames = soak_frames(synth, 480, 640, n)
+    frames = soak_frames(synth, rows, cols, n)
+    K, D, mask = None, None, None
+    src = frames
+    if und:
+        K = [517.306408, 516.469215, 318.643040, 255.313989]           # Examples/Monocular/TUM1.yaml:8-17
+        D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+        mask = _masks()[1]
+        mx = np.zeros((rows, cols), np.float32)
+        my = np.zeros((rows, cols), np.float32)
+        oracle.lib().plo_undistort_maps(oracle._p(np.asarray(K, np.float32)), oracle._p(np.asarray(D, np.float32)), cols, rows, oracle._p(mx), oracle._p(my))
+        src = np.zeros_like(frames)
+        for i in range(n):
+            oracle.lib().plo_remap_linear_u8(oracle._p(frames[i]), cols, rows, cols, oracle._p(mx), oracle._p(my), oracle._p(src[i]), cols)
 
     def one(img):
-        kl, ld, fn = oracle.line_extract(img, 200, 0.0, refine=1)
+        kl, ld, fn = oracle.line_extract(img, 200, 0.0, mask, refine=1)
         return kl, ld, fn, oracle.lsd_detect(img, refine=1), len(oracle.lsd_detect(img))
     with ThreadPoolExecutor(os.cpu_count() or 1) as ex:
-        ref = list(ex.map(one, list(frames)))
+        ref = list(ex.map(one, list(src)))
     nadv, nstd = sum(len(r[3]) for r in ref), sum(r[4] for r in ref)
     assert 0 < nadv < nstd                      # the NFA gate does remove rectangles on this content
     for waves in (0, -1):
-        got = _gpu_lines(plslam, frames, waves, refine=1)
+        got = _gpu_lines(plslam, frames, waves, refine=1, K=K, D=D, mask=mask)
         for b, ((kl, ld, fn, sg), r) in enumerate(zip(got, ref)):
             assert len(sg) == len(r[3]) and (sg == r[3]).all(), "ADV, waves %d, frame %d: LSD segments differ from the oracle" % (waves, b)
             assert len(kl) == len(r[0]) and all((kl[f] == r[0][f]).all() for f in r[0].dtype.names), "ADV, waves %d, frame %d: KeyLines" % (waves, b)
             assert (ld == r[1]).all() and (fn == r[2]).all(), "ADV, waves %d, frame %d: LBD / line equations" % (waves, b)
-    print("\nsoak LSD_REFINE_ADV 640x480: %d distinct frames, %d segments (STD: %d) bit-exact (waves 0 / auto)" % (n, nadv, nstd))
+    print("\nsoak LSD_REFINE_ADV %dx%d%s: %d distinct frames, %d segments (STD: %d) bit-exact (waves 0 / auto)"
+          % (cols, rows, " (TUM1 undistortion, tum_mask)" if und else "", n, nadv, nstd))
