@@ -18,6 +18,13 @@
 #include <string>
 #include <vector>
 
+// Which refine level of cv::LineSegmentDetector the LSDDetector of YOUR opencv_contrib runs is a property of that build
+// (src/LineExtractor.cpp:39-40 links the system module; upstream 3.x passes LSD_REFINE_ADV, the twin in the reference's tree
+// LSD_REFINE_STD).  A drop-in must not pick silently: the build of the SLAM system says which, e.g.
+//     add_definitions(-DPLH_LSD_REFINE_DEFAULT=1)   # 0 = LSD_REFINE_STD, 1 = LSD_REFINE_ADV
+#ifndef PLH_LSD_REFINE_DEFAULT
+#error "define PLH_LSD_REFINE_DEFAULT (0: LSD_REFINE_STD, 1: LSD_REFINE_ADV) for the LSDDetector your OpenCV build uses -- INTEGRATION.md section 2"
+#endif
 #include "plslam_hip.h"
 
 namespace ORB_SLAM2 {
@@ -27,7 +34,7 @@ class LINEextractor {
   typedef cv::line_descriptor::KeyLine KeyLine;
 
   LINEextractor(int _numOctaves, float _scale, unsigned int _nLSDFeature, double _min_line_length, int device = 0)
-      : mDevice(device), mHandle(nullptr), mRows(0), mCols(0), mHasUndist(false), mRefine(PLH_LSD_REFINE_STD), mGrowWaves(-1) {
+      : mDevice(device), mHandle(nullptr), mRows(0), mCols(0), mHasUndist(false), mRefine(PLH_LSD_REFINE_DEFAULT), mGrowWaves(-1) {
     static_assert(sizeof(KeyLine) == sizeof(plh_keyline), "KeyLine must be the 68-byte POD plh_keyline mirrors");
     mParams.num_octaves = _numOctaves;
     mParams.scale = _scale;
@@ -57,9 +64,9 @@ class LINEextractor {
     if (mHandle) check(plh_line_set_undistort(mHandle, mK, mD));
   }
 
-  // The refine level of the cv::LineSegmentDetector behind LSDDetector::detect: PLH_LSD_REFINE_STD (default; what the twin in the
-  // reference's tree creates, LSDDetector_custom.cpp:149) or PLH_LSD_REFINE_ADV (what upstream opencv_contrib 3.x passes) -- pick
-  // the one the OpenCV build behind src/LineExtractor.cpp:39 uses.
+  // The refine level of the cv::LineSegmentDetector behind LSDDetector::detect: PLH_LSD_REFINE_STD (what the twin in the
+  // reference's tree creates, LSDDetector_custom.cpp:149) or PLH_LSD_REFINE_ADV (what upstream opencv_contrib 3.x passes).  The
+  // extractor starts with the level the build chose (PLH_LSD_REFINE_DEFAULT, above); this overrides it at run time.
   void SetRefine(int level) {
     mRefine = level;
     if (mHandle) check(plh_line_set_refine(mHandle, mRefine));

@@ -46,9 +46,13 @@ def test_adaptor_header_typechecks(hdr, tmp_path):
                        '         ORB_SLAM2::hip::LineSearchByProjection(kl, d, fn, gp, occ, q, 8.f, 0.7f, true, asg); }\n')
     inc = [os.path.join(_util.ROOT, "pl-slam_amd", "adaptor"), os.path.join(_util.ROOT, "include"),
            os.path.join(_util.ROOT, "tests", "cv_stub")]
-    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-Wall"] + ["-I" + i for i in inc] + [str(src)]
+    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-DPLH_LSD_REFINE_DEFAULT=1"] + ["-I" + i for i in inc] + [str(src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    if hdr == "LineExtractor.h":   # the drop-in does not pick cv::LineSegmentDetector's refine level silently: the build must
+        cmd.remove("-DPLH_LSD_REFINE_DEFAULT=1")
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode != 0 and "PLH_LSD_REFINE_DEFAULT" in r.stderr
 
 
 def test_library_exports_every_declared_symbol(plslam):

@@ -81,8 +81,9 @@ def test_cpp_host_matches_the_oracle(plslam, oracle, synth, tmp_path, undist):
     voc = V.Vocabulary.load_text(vtxt)      # the weights as the text file holds them (what the C++ host loads)
     cmd = [exe, fbin, str(rows), str(cols), str(B), str(ns), str(nfeat), str(nlines), "3", out, vtxt]
     K, D = (TUM1_K, TUM1_D) if undist else (None, None)
-    if undist:
-        cmd += ["%r" % v for v in K + D]
+    # (without a camera on the command line the example takes the one of the frame size -- TUM1 with its distortion for
+    # 640x480 -- so the undistorted case says so: zero distortion = no remap, Frame.cc:917-921)
+    cmd += ["%r" % v for v in (K + D if undist else TUM1_K + [0.0] * 5)]
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "frames/s" in run.stdout
@@ -91,9 +92,67 @@ def test_cpp_host_matches_the_oracle(plslam, oracle, synth, tmp_path, undist):
     for p in parts:
         idx = list(range(p["first"], p["first"] + p["B"])) + [p["first"]]     # the last frame of a sub-batch is matched against its first
         recs, pairs = bench.oracle_records(oracle, V, frames[idx], voc, nfeat, 8, nlines, K, D)
-        ver = bench.verify_records(p, recs[:-1], pairs)
-        assert ver["exact"], ver["mismatches"]
-        assert ver["frames"] == p["B"] and ver["pairs"] == p["B"]
+        bad = bench.verify_records(p, recs[:-1], pairs)
+        assert not bad, bad
+        assert len(recs) - 1 == p["B"] and len(pairs) == p["B"]
+
+
+@pytest.mark.gpu
+def test_cpp_host_on_real_frames_pgm_and_refine_adv(plslam, oracle, synth, tmp_path):
+    """Real images end to end: the reference's masks/tum_mask.png and masks/mask.png (the only real 640x480 images it ships;
+    Tracking.cc:83-84) and shifted copies, written as PGM files, through `batch_frontend <directory>` -- the TUM1 camera is
+    picked from the frame size -- with --refine adv; every record against the oracle (ADV)."""
+    g = _entry()
+    exe = g.build_examples()
+    sys.path.insert(0, _util.ROOT)
+    import bench
+    V = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    FIO = _util._load("plslam_amd_frames_io", os.path.join(_util.ROOT, "pl-slam_amd", "frames_io.py"))
+    gm = np.load(os.path.join(_util.ROOT, "tests", "golden", "ref_masks.npz"))
+    base = [np.unpackbits(gm[k])[:480 * 640].reshape(480, 640).astype(np.uint8) * 255 for k in ("tum_mask", "mask")]
+    scene = synth.make_frame(5, 480, 640)
+    imgs = []
+    for i in range(8):   # the masks as they are, shifted, and blended into a scene (grey levels, not only 0 / 255)
+        m = np.roll(base[i % 2], 17 * (i // 2), axis=1)
+        imgs.append(m if i < 4 else (m // 2 + scene // 2).astype(np.uint8))
+    d = tmp_path / "seq"
+    d.mkdir()
+    for i, im in enumerate(imgs):
+        FIO.write_pgm(str(d / ("frame_%03d.pgm" % i)), im)
+    frames = FIO.load_frames(str(d), 480, 640)
+    assert frames.shape == (8, 480, 640) and all((frames[i] == imgs[i]).all() for i in range(8))
+    voc = V.Vocabulary.synthetic(31, k=10, L=4, synth=synth, idf=True)
+    vtxt, out = str(tmp_path / "voc.txt"), str(tmp_path / "out.bin")
+    voc.save_text(vtxt)
+    voc = V.Vocabulary.load_text(vtxt)
+    cmd = [exe, str(d), "480", "640", "8", "2", "1000", "200", "2", out, vtxt, "--refine", "adv"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "TUM1" in run.stdout and "LSD_REFINE_ADV" in run.stdout
+    parts = _read_out(out, plslam)
+    for p in parts:
+        idx = list(range(p["first"], p["first"] + p["B"])) + [p["first"]]
+        recs, pairs = bench.oracle_records(oracle, V, frames[idx], voc, 1000, 8, 200, TUM1_K, TUM1_D, refine=1)
+        bad = bench.verify_records(p, recs[:-1], pairs)
+        assert not bad, bad
+    assert sum(int(p["nl"].sum()) for p in parts) > 50      # lines were found on the real images
+
+
+def test_frames_io_roundtrip(tmp_path):
+    FIO = _util._load("plslam_amd_frames_io", os.path.join(_util.ROOT, "pl-slam_amd", "frames_io.py"))
+    rng = np.random.RandomState(3)
+    a = rng.randint(0, 256, (5, 30, 40)).astype(np.uint8)
+    FIO.write_pgm(str(tmp_path / "b.pgm"), a[0])
+    (tmp_path / "c.pgm").write_bytes(b"P5\n# a comment\n40 30\n# another\n255\n" + a[1].tobytes())
+    a[2:].tofile(str(tmp_path / "d.bin"))
+    got = FIO.load_frames(str(tmp_path), 30, 40)
+    assert got.shape == (5, 30, 40) and (got == a).all()
+    assert (FIO.tile_frames(got, 12)[7] == a[2]).all()
+    with pytest.raises(ValueError):
+        FIO.load_frames(str(tmp_path / "b.pgm"), 31, 40)
+    (tmp_path / "e.pgm").write_bytes(b"P2\n1 1\n255\n0\n")
+    with pytest.raises(ValueError):
+        FIO.read_pgm(str(tmp_path / "e.pgm"))
 
 
 def test_emu_frontend_matches_the_oracle(plslam, oracle, synth, emu_lib):
@@ -116,6 +175,7 @@ def test_emu_frontend_matches_the_oracle(plslam, oracle, synth, emu_lib):
     fp.orb = P.OrbParams(nfeat, 1.2, nlev, 20, 7)
     fp.line = P.LineParams(1, 1.2, nlines, 0.0)
     fp.bow_levelsup, fp.orb_th_low, fp.orb_nnratio, fp.orb_check_orientation, fp.line_th, fp.line_nnratio = 4, 50, 0.7, 1, 50.0, 0.7
+    fp.lsd_refine = -1   # the library's default (PLH_LSD_REFINE_DEFAULT = STD)
     h = C.c_void_p()
     P._check(L, L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)), "plh_frontend_create")
     try:
@@ -142,8 +202,8 @@ def test_emu_frontend_matches_the_oracle(plslam, oracle, synth, emu_lib):
                        nm_line=arr(r.nm_line, np.int32, (Bp,)), m_line=arr(r.m_line, np.int32, (Bp, lc)))
             idx = list(range(r.first, r.first + Bp)) + [r.first]
             recs, pairs = bench.oracle_records(oracle, V, frames[idx], voc, nfeat, nlev, nlines, None, None)
-            ver = bench.verify_records(res, recs[:-1], pairs)
-            assert ver["exact"], ver["mismatches"]
+            mism = bench.verify_records(res, recs[:-1], pairs)
+            assert not mism, mism
         bad = P.FrontendParams()
         assert L.plh_frontend_create(C.byref(bad), hv.h, 3, 2, 0, C.byref(C.c_void_p())) != 0      # batch not a multiple of nsplit
         assert L.plh_frontend_bind_records(h, 0, C.byref(P.FrontendRecords())) != 0                   # not created for external records
