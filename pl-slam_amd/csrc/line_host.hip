@@ -288,7 +288,9 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   // per-frame block, hot parts first: segments | region queue | level-line records | seed list | scratch | ordering counters
   const long long offSegs = 0, offReg = align_up<long long>((long long)a.segCap * 4, 64), offPix = offReg + a.scaledStride,
                   offOrd = offPix + a.scaledStride, offScr = offOrd + a.scaledStride, offWork = offScr + a.scaledStride,
-                  blockWords = offWork + (long long)lsd_order_work_u32();
+                  offPark = offWork + align_up<long long>((long long)lsd_order_work_u32(), 64),
+                  blockWords = offPark + align_up<long long>(3LL * a.segCap + 2, 64);
+  // (`ordered` and `scr` are adjacent on purpose: after region growing k_lsd_rects keeps one double per kept pixel across both)
   a.arenaStride = align_up<long long>(blockWords, blockWords >= (1 << 18) ? (1 << 19) : (1 << 14));   // 2 MiB (64 KiB for small frames)
   TRYHIP(hipMalloc((void**)&h->dArena, B * (size_t)a.arenaStride * 4));
   TRYHIP(hipMalloc((void**)&h->dDxdy, B * a.fullStride * 4));
@@ -316,7 +318,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
     return PLH_ERR_ALLOC;
   }
   a.angleTab = h->a.angleTab;
-  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dArena + offPix; a.ordered = h->dArena + offOrd; a.reg = h->dArena + offReg; a.scr = h->dArena + offScr; a.orderWork = h->dArena + offWork;
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dArena + offPix; a.ordered = h->dArena + offOrd; a.reg = h->dArena + offReg; a.scr = h->dArena + offScr; a.orderWork = h->dArena + offWork; a.park = h->dArena + offPark;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = reinterpret_cast<float*>(h->dArena + offSegs); a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
   *out = h;

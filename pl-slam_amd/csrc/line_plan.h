@@ -85,6 +85,7 @@ struct LineDeviceArgs {
   // exact rectangle for every decision (the path every undecided region takes anyway: same segments; an A/B and test switch)
   float screenLo, screenHi;
   int screen;
+  uint32_t* park;           // LSD_REFINE_ADV: per frame [0] count, then {slot, log_nfa} of the rectangles k_lsd_rects_adv leaves to k_lsd_improve
   int refineAdv;            // 1: LSD_REFINE_ADV (rect_improve / NFA on the kept regions' rectangles, k_lsd_rects), plh_line_set_refine
   double logNT;             // 5 (log10 sw + log10 sh) / 2 + log10 11, flsd()'s LOG_NT
   // selection

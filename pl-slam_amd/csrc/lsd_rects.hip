@@ -11,17 +11,15 @@
 // loop about equally long.
 //
 // LSD_REFINE_ADV (rect_improve / rect_nfa / nfa, lsd_rect_dev.h) reads the immutable level-line field only and decides only
-// whether the segment is kept: it runs here as well, in two phases -- the first rect_nfa() of every rectangle in the lanes that
-// computed it; the rectangles it does not pass (about one in ten) are collected and improved densely packed, one lane each --
-// followed by a stable compaction of the surviving segments.
+// whether the segment is kept: it runs here as well, in two kernels -- the first rect_nfa() of every rectangle in the lane that
+// computed it (k_lsd_rects_adv); the rectangles it does not pass (about one in ten) are parked and improved by k_lsd_improve,
+// the five variants of each rect_improve() stage side by side -- followed by a stable compaction of the surviving segments.
 #include "lsd_rect_dev.h"
 
 namespace plh {
 
 constexpr int RC_CHUNK = 4096;   // entries sorted and evaluated at a time
 constexpr int RC_BINS = 128;
-constexpr int RC_IMP_WORDS = 20;   // a rectangle waiting for rect_improve(): 9 doubles (x1 y1 x2 y2 width theta dx dy log_nfa) + its slot;
-                                   // the list starts 2 words into the frame's scratch area (word 0 = the count)
 constexpr uint32_t RC_DROPPED = 0xffffffffu;   // first word of a slot whose rectangle LSD_REFINE_ADV rejected (a NaN: never a coordinate)
 
 struct RcFrame {
@@ -35,82 +33,6 @@ __device__ __forceinline__ int rc_size_class(unsigned cnt) {
   const unsigned c = cnt < 4u ? 4u : cnt;
   const int l = 31 - __clz((int)c);
   return min(4 * (l - 2) + (int)((c >> (l - 2)) & 3u), RC_BINS - 1);
-}
-
-__device__ __forceinline__ double rc_weight(const RcFrame& f, uint32_t p) {   // modgrad of a packed pixel
-  return f.A[f.P[__umul24(p >> 16, (unsigned)f.spitch) + (p & 0xffffu)] & LSD_REC_IDX].modgrad;
-}
-
-// region2rect() + get_theta() for one region, one lane: oracle/lsd.cc region2rect; the same expressions in the same order as
-// lsd_region2rect (lsd_grow.hip), whose three-lane chains add exactly these terms in exactly this order.
-// rec = x1 y1 x2 y2 width theta dx dy.
-__device__ __forceinline__ void rc_region2rect(const RcFrame& f, const uint32_t* reg, int cnt, double reg_angle, double prec, double rec[8]) {
-  double sx = 0, sy = 0, sum = 0;
-  int i = 0;
-  for (; i + 4 <= cnt; i += 4) {   // four gathers in flight, the adds in order
-    uint32_t p[4];
-    double w[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) p[k] = reg[i + k];
-#pragma unroll
-    for (int k = 0; k < 4; k++) w[k] = rc_weight(f, p[k]);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      sx += (double)(int)(p[k] & 0xffffu) * w[k];
-      sy += (double)(int)(p[k] >> 16) * w[k];
-      sum += w[k];
-    }
-  }
-  for (; i < cnt; i++) {
-    const uint32_t p = reg[i];
-    const double w = rc_weight(f, p);
-    sx += (double)(int)(p & 0xffffu) * w;
-    sy += (double)(int)(p >> 16) * w;
-    sum += w;
-  }
-  const double x = sx / sum, y = sy / sum;
-  double Ixx = 0, Iyy = 0, Ixy = 0;
-  i = 0;
-  for (; i + 4 <= cnt; i += 4) {
-    uint32_t p[4];
-    double w[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) p[k] = reg[i + k];
-#pragma unroll
-    for (int k = 0; k < 4; k++) w[k] = rc_weight(f, p[k]);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const double ddx = (double)(int)(p[k] & 0xffffu) - x, ddy = (double)(int)(p[k] >> 16) - y;
-      Ixx += ddy * ddy * w[k];
-      Iyy += ddx * ddx * w[k];
-      Ixy += -(ddx * ddy * w[k]);   // Ixy -= v  ==  Ixy += -v
-    }
-  }
-  for (; i < cnt; i++) {
-    const uint32_t p = reg[i];
-    const double w = rc_weight(f, p);
-    const double ddx = (double)(int)(p & 0xffffu) - x, ddy = (double)(int)(p >> 16) - y;
-    Ixx += ddy * ddy * w;
-    Iyy += ddx * ddx * w;
-    Ixy += -(ddx * ddy * w);
-  }
-  const double theta = lsd_rect_theta(Ixx, Iyy, Ixy, reg_angle, prec);
-  const D2 cs = lsd_sincos_inl(theta);
-  const double dx = cs.x, dy = cs.y;
-  double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
-  for (i = 0; i < cnt; i++) {
-    const uint32_t p = reg[i];
-    const double rdx = (double)(int)(p & 0xffffu) - x, rdy = (double)(int)(p >> 16) - y;
-    const double l = rdx * dx + rdy * dy;
-    const double w = -rdx * dy + rdy * dx;
-    l_max = fmax(l_max, l); l_min = fmin(l_min, l);
-    w_max = fmax(w_max, w); w_min = fmin(w_min, w);
-  }
-  rec[0] = x + l_min * dx; rec[1] = y + l_min * dy;
-  rec[2] = x + l_max * dx; rec[3] = y + l_max * dy;
-  const double width = w_max - w_min;
-  rec[4] = width < 1.0 ? 1.0 : width;
-  rec[5] = theta; rec[6] = dx; rec[7] = dy;
 }
 
 // rect_nfa() (oracle/lsd.cc rect_nfa, with the published code's quirks: integer scan-line steps, the tail point's x where a y is
@@ -166,61 +88,115 @@ __device__ __attribute__((noinline)) double rc_rect_nfa(const RcFrame& f, const 
   return lsd_nfa(total, alg, r.p, logNT);
 }
 
-// rect_improve() after its first rect_nfa() (log_nfa, which was not above LOG_EPS = 0): finer precision, narrower, one side in,
-// the other side in, finer precision again (oracle/lsd.cc rect_improve).  Returns whether the rectangle is kept.
-__device__ __attribute__((noinline)) bool rc_rect_improve(const RcFrame& f, LsdAdvRect& R, double log_nfa, double logNT) {
-  const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = 0.0;
-  {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n) {          // finer precision
-      r.p /= 2;
-      r.prec = r.p * kPI;
-      const double v = rc_rect_nfa(f, r, logNT);
-      if (v > log_nfa) { log_nfa = v; R = r; }
+// ---------------------------------------------------------------------------------------------
+// The kernels.  One block (4 wavefronts) per frame.
+//   1. weights: one coalesced pass over the frame's log computes every kept pixel's modgrad -- sqrt((gx^2 + gy^2) / 4.0) from the
+//      record's table index, the expression the table itself was filled with (line_kernels.hip k_lsd_angle_table) -- into W
+//      (doubles, the seed-list + scratch areas of the frame's block: both are free after region growing);
+//   2. the entries are sorted by size class (largest first), 64 consecutive ones go to the lanes of a wavefront;
+//   3. the wavefront stages its 64 regions' pixels and weights through LDS, RC_K per lane at a time -- loaded 8 regions x 8
+//      consecutive pixels per instruction (a lane per region reading its own stream would touch 64 cache lines per load and
+//      leave the kernel bound by the texture addresser: 5.3 ms per 1536 frames in the first version of this file, r04_screen_ab_v1)
+//      -- and every lane adds its own region's terms from LDS in region order.  Rows of the staging tiles are padded with
+//      zero terms, which the sums absorb exactly (+0.0; the accumulators are never -0.0), as lsd_chain_add does.
+// ---------------------------------------------------------------------------------------------
+constexpr int RC_K = 8;
+constexpr int RC_PITCH = RC_K + 1;
+
+struct RcStage {   // one wavefront's part of the block's LDS
+  uint32_t* p;     // [64][RC_PITCH] packed pixels
+  double* w;       // [64][RC_PITCH] weights
+  uint32_t* off;   // [64] log offset of lane r's region
+  int* cnt;        // [64] its pixel count (0: the lane has no region)
+};
+
+template <bool WITH_W>
+__device__ __forceinline__ void rc_stage(const RcStage& st, const uint32_t* log, const double* W, int lane, int c) {
+  uint32_t pv[8];
+  double wv[8];
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const int r = 8 * g + (lane >> 3), idx = c * RC_K + (lane & 7);
+    const bool valid = idx < st.cnt[r];
+    const uint32_t a = st.off[r] + (uint32_t)idx;
+    pv[g] = valid ? log[a] : 0u;
+    if (WITH_W) wv[g] = valid ? W[a] : 0.0;
+  }
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const int r = 8 * g + (lane >> 3), k = lane & 7;
+    st.p[r * RC_PITCH + k] = pv[g];
+    if (WITH_W) st.w[r * RC_PITCH + k] = wv[g];
+  }
+}
+
+// region2rect() + get_theta() of the 64 regions of a wavefront (lane = region; cnt 0 = none): oracle/lsd.cc region2rect, the same
+// expressions in the same order as lsd_region2rect (lsd_grow.hip).  rec = x1 y1 x2 y2 width theta dx dy.
+__device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uint32_t* log, const double* W, int lane, uint32_t myOff, int myCnt,
+                                                    double reg_angle, double prec, double rec[8]) {
+  PLH_WAVE_SYNC();
+  st.off[lane] = myOff; st.cnt[lane] = myCnt;
+  int maxCnt = myCnt;
+  for (int m = 32; m >= 1; m >>= 1) maxCnt = max(maxCnt, __shfl_xor(maxCnt, m));
+  PLH_WAVE_SYNC();
+  const int chunks = (maxCnt + RC_K - 1) / RC_K;
+  const uint32_t* sp = st.p + lane * RC_PITCH;
+  const double* sw = st.w + lane * RC_PITCH;
+  double sx = 0, sy = 0, sum = 0;
+  for (int c = 0; c < chunks; c++) {
+    rc_stage<true>(st, log, W, lane, c);
+    PLH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < RC_K; k++) {
+      const uint32_t p = sp[k];
+      const double w = sw[k];
+      sx += (double)(int)(p & 0xffffu) * w;
+      sy += (double)(int)(p >> 16) * w;
+      sum += w;
     }
+    PLH_WAVE_SYNC();
   }
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n)            // reduce width
-      if ((r.width - delta) >= 0.5) {
-        r.width -= delta;
-        const double v = rc_rect_nfa(f, r, logNT);
-        if (v > log_nfa) { R = r; log_nfa = v; }
+  const double x = sx / sum, y = sy / sum;
+  double Ixx = 0, Iyy = 0, Ixy = 0;
+  for (int c = 0; c < chunks; c++) {
+    rc_stage<true>(st, log, W, lane, c);
+    PLH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < RC_K; k++) {
+      const uint32_t p = sp[k];
+      const double w = sw[k];
+      const double ddx = (double)(int)(p & 0xffffu) - x, ddy = (double)(int)(p >> 16) - y;
+      Ixx += ddy * ddy * w;
+      Iyy += ddx * ddx * w;
+      Ixy += -(ddx * ddy * w);   // Ixy -= v  ==  Ixy += -v
+    }
+    PLH_WAVE_SYNC();
+  }
+  const double theta = lsd_rect_theta(Ixx, Iyy, Ixy, reg_angle, prec);
+  const D2 cs = lsd_sincos_inl(theta);
+  const double dx = cs.x, dy = cs.y;
+  double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+  for (int c = 0; c < chunks; c++) {
+    rc_stage<false>(st, log, W, lane, c);
+    PLH_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < RC_K; k++) {
+      if (c * RC_K + k < myCnt) {
+        const uint32_t p = sp[k];
+        const double rdx = (double)(int)(p & 0xffffu) - x, rdy = (double)(int)(p >> 16) - y;
+        const double l = rdx * dx + rdy * dy;
+        const double w = -rdx * dy + rdy * dx;
+        l_max = fmax(l_max, l); l_min = fmin(l_min, l);
+        w_max = fmax(w_max, w); w_min = fmin(w_min, w);
       }
+    }
+    PLH_WAVE_SYNC();
   }
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n)            // reduce one side
-      if ((r.width - delta) >= 0.5) {
-        r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
-        r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
-        r.width -= delta;
-        const double v = rc_rect_nfa(f, r, logNT);
-        if (v > log_nfa) { R = r; log_nfa = v; }
-      }
-  }
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n)            // reduce the other side
-      if ((r.width - delta) >= 0.5) {
-        r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
-        r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
-        r.width -= delta;
-        const double v = rc_rect_nfa(f, r, logNT);
-        if (v > log_nfa) { R = r; log_nfa = v; }
-      }
-  }
-  if (!(log_nfa > LOG_EPS)) {
-    LsdAdvRect r = R;
-    for (int n = 0; n < 5; ++n)            // finer precision again
-      if ((r.width - delta) >= 0.5) {
-        r.p /= 2;
-        r.prec = r.p * kPI;
-        const double v = rc_rect_nfa(f, r, logNT);
-        if (v > log_nfa) { R = r; log_nfa = v; }
-      }
-  }
-  return log_nfa > LOG_EPS;
+  rec[0] = x + l_min * dx; rec[1] = y + l_min * dy;
+  rec[2] = x + l_max * dx; rec[3] = y + l_max * dy;
+  const double width = w_max - w_min;
+  rec[4] = width < 1.0 ? 1.0 : width;
+  rec[5] = theta; rec[6] = dx; rec[7] = dy;
 }
 
 __device__ __forceinline__ void rc_store_segment(uint4* slot, const double* rec) {
@@ -229,26 +205,41 @@ __device__ __forceinline__ void rc_store_segment(uint4* slot, const double* rec)
   *slot = uint4{__float_as_uint(sg[0]), __float_as_uint(sg[1]), __float_as_uint(sg[2]), __float_as_uint(sg[3])};
 }
 
-// One block per frame.  ADV = false: LSD_REFINE_STD, every rectangle is a segment.  ADV = true: the rectangle's first rect_nfa()
-// as well; a rectangle that passes is a segment, the others are parked (imp: rectangle, log_nfa, slot; imp's first word counts
-// them) for k_lsd_improve.
+// ADV = false: LSD_REFINE_STD, every rectangle is a segment.  ADV = true: the rectangle's first rect_nfa() as well; a rectangle
+// that passes is a segment, the others are parked for k_lsd_improve: slot -- which keeps its entry -- and log_nfa in the frame's
+// park list.
 template <bool ADV>
 __device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
   __shared__ uint32_t s_order[RC_CHUNK];
   __shared__ int s_hist[RC_BINS];
-  __shared__ int s_nImp;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_nPark;
+  __shared__ __attribute__((aligned(16))) double s_w[4 * 64 * RC_PITCH];
+  __shared__ uint32_t s_p[4 * 64 * RC_PITCH];
+  __shared__ uint32_t s_off[4 * 64];
+  __shared__ int s_cnt[4 * 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = min(a.nSegs[b], a.segCap);
   uint4* ent = reinterpret_cast<uint4*>(a.segs + (long long)b * a.arenaStride);
   const uint32_t* log = a.reg + (long long)b * a.arenaStride;
+  double* W = reinterpret_cast<double*>(a.ordered + (long long)b * a.arenaStride);   // `ordered` and `scr` are adjacent: one double per pixel
   RcFrame f;
   f.P = a.pix + (long long)b * a.arenaStride; f.A = a.angleTab; f.spitch = a.spitch; f.sw = a.sw; f.sh = a.sh;
-  uint32_t* imp = a.scr + (long long)b * a.arenaStride;   // (the scratch area is free by now)
-  const int impCap = (int)((a.scaledStride - 2) / RC_IMP_WORDS);
-  if (tid == 0) s_nImp = 0;
+  uint32_t* park = a.park + (long long)b * a.arenaStride;   // [0] count, then {slot, log_nfa (2 words)} per parked rectangle: segCap of them fit
+  if (tid == 0) s_nPark = 0;
+  if (n > 0) {   // 1. the weights of all kept pixels, one coalesced pass over the log
+    const uint4 last = ent[n - 1];
+    const int logTotal = (int)(last.x + last.y);
+    for (int j = tid; j < logTotal; j += 256) {
+      const uint32_t p = log[j];
+      W[j] = q_modgrad(lsd_rec_q(f.P[__umul24(p >> 16, (unsigned)f.spitch) + (p & 0xffffu)]));
+    }
+  }
+  __syncthreads();
+  RcStage st;
+  st.p = s_p + wv * 64 * RC_PITCH; st.w = s_w + wv * 64 * RC_PITCH; st.off = s_off + wv * 64; st.cnt = s_cnt + wv * 64;
   for (int c0 = 0; c0 < n; c0 += RC_CHUNK) {
     const int m = min(RC_CHUNK, n - c0);
-    // counting sort of the chunk's entries by size class, the largest first (they set the pace of their wavefront)
+    // 2. counting sort of the chunk's entries by size class, the largest first (they set the pace of their wavefront)
     for (int i = tid; i < RC_BINS; i += 256) s_hist[i] = 0;
     __syncthreads();
     for (int i = tid; i < m; i += 256) atomicAdd(&s_hist[rc_size_class(ent[c0 + i].y)], 1);
@@ -260,11 +251,15 @@ __device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
     __syncthreads();
     for (int i = tid; i < m; i += 256) s_order[atomicAdd(&s_hist[rc_size_class(ent[c0 + i].y)], 1)] = (uint32_t)(c0 + i);
     __syncthreads();
-    for (int k = tid; k < m; k += 256) {
-      const int slot = (int)s_order[k];
-      const uint4 e = ent[slot];   // LsdRegionEntry
+    // 3. 64 sorted entries per wavefront at a time
+    for (int base = wv * 64; base < m; base += 256) {
+      const int k = base + lane;
+      int slot = -1;
+      uint4 e = uint4{0u, 0u, 0u, 0u};
+      if (k < m) { slot = (int)s_order[k]; e = ent[slot]; }   // LsdRegionEntry
       double rec[8];
-      rc_region2rect(f, log + e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+      rc_wave_region2rect(st, log, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+      if (slot < 0) continue;
       if constexpr (!ADV) {
         rc_store_segment(&ent[slot], rec);
       } else {
@@ -274,62 +269,148 @@ __device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
         const double log_nfa = rc_rect_nfa(f, R, a.logNT);
         if (log_nfa > 0.0) {
           rc_store_segment(&ent[slot], rec);
-        } else {
-          const int q = atomicAdd(&s_nImp, 1);
-          if (q < impCap) {   // improved by k_lsd_improve, densely packed
-            double* it = reinterpret_cast<double*>(imp + 2 + (long long)q * RC_IMP_WORDS);
-#pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) it[k2] = rec[k2];
-            it[8] = log_nfa;
-            imp[2 + (long long)q * RC_IMP_WORDS + 18] = (uint32_t)slot;
-          } else {            // (no room to park it: a frame of nothing but minimal rejected regions)
-            if (rc_rect_improve(f, R, log_nfa, a.logNT)) {
-              rec[0] = R.x1; rec[1] = R.y1; rec[2] = R.x2; rec[3] = R.y2;
-              rc_store_segment(&ent[slot], rec);
-            } else {
-              ent[slot] = uint4{RC_DROPPED, 0u, 0u, 0u};
-            }
-          }
+        } else {   // rect_improve(): k_lsd_improve, five variants at a time (the slot keeps its entry, the rectangle is evaluated again there)
+          const int q = atomicAdd(&s_nPark, 1);
+          uint32_t lw[2];
+          __builtin_memcpy(lw, &log_nfa, 8);
+          park[2 + 3 * q] = (uint32_t)slot;
+          park[2 + 3 * q + 1] = lw[0];
+          park[2 + 3 * q + 2] = lw[1];
         }
       }
     }
     __syncthreads();
   }
   if constexpr (ADV) {
-    if (tid == 0) imp[0] = (uint32_t)min(s_nImp, impCap);
+    if (tid == 0) park[0] = (uint32_t)s_nPark;
   }
 }
 __global__ void __launch_bounds__(256) k_lsd_rects(LineDeviceArgs a) { lsd_rects_frame<false>(a); }
 __global__ void __launch_bounds__(256) k_lsd_rects_adv(LineDeviceArgs a) { lsd_rects_frame<true>(a); }
 
-// LSD_REFINE_ADV, second half: rect_improve() of the parked rectangles, one lane each, then a stable compaction of the frame's
-// surviving segments.  One block per frame.
+// One variant of rect_improve(): the rectangle R after `m` iterations (1 .. 5) of stage `stage`'s loop body.  The loops modify
+// their rectangle whether or not the variant is accepted, so the five variants of a stage follow from the stage's starting
+// rectangle alone and can be evaluated side by side.  Returns false when the loop's width gate stops before iteration m.
+__device__ __forceinline__ bool rc_variant(int stage, int m, LsdAdvRect& r) {
+  const double delta = 0.5, delta_2 = delta / 2.0;
+  if (stage == 0) {          // finer precision (no gate)
+    for (int j = 0; j < m; j++) { r.p /= 2; r.prec = r.p * kPI; }
+    return true;
+  }
+  for (int j = 0; j < m; j++) {
+    if (!((r.width - delta) >= 0.5)) return false;
+    if (stage == 1) {        // reduce width
+      r.width -= delta;
+    } else if (stage == 2) { // reduce one side
+      r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+      r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+      r.width -= delta;
+    } else if (stage == 3) { // reduce the other side
+      r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+      r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+      r.width -= delta;
+    } else {                 // finer precision again
+      r.p /= 2;
+      r.prec = r.p * kPI;
+    }
+  }
+  return true;
+}
+
+// LSD_REFINE_ADV, second half: rect_improve() of the parked rectangles (oracle/lsd.cc rect_improve), then a stable compaction
+// of the frame's surviving segments.  One block per frame; per stage every (rectangle, iteration) pair is one lane's task --
+// 5 x the rectangles' parallelism, and a lane never runs more than one rect_nfa() in a row -- and the rectangle's owner then
+// replays the loop's `if (v > log_nfa)` over the five values in order.
+constexpr int RC_IMP = 256;   // rectangles improved at a time
 __global__ void __launch_bounds__(256) k_lsd_improve(LineDeviceArgs a) {
   __shared__ int s_wave[4];
+  __shared__ __attribute__((aligned(16))) double s_R[RC_IMP * 10];   // x1 y1 x2 y2 width theta dx dy prec p
+  __shared__ double s_nfa[RC_IMP];
+  __shared__ double s_v[RC_IMP * 5];
+  __shared__ unsigned char s_ok[RC_IMP * 5], s_active[RC_IMP];
+  __shared__ __attribute__((aligned(16))) double s_w[4 * 64 * RC_PITCH];
+  __shared__ uint32_t s_p[4 * 64 * RC_PITCH];
+  __shared__ uint32_t s_off[4 * 64];
+  __shared__ int s_cnt[4 * 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = min(a.nSegs[b], a.segCap);
   uint4* ent = reinterpret_cast<uint4*>(a.segs + (long long)b * a.arenaStride);
   RcFrame f;
   f.P = a.pix + (long long)b * a.arenaStride; f.A = a.angleTab; f.spitch = a.spitch; f.sw = a.sw; f.sh = a.sh;
-  const uint32_t* imp = a.scr + (long long)b * a.arenaStride;
-  const int nImp = n > 0 ? (int)imp[0] : 0;
-  for (int q = tid; q < nImp; q += 256) {
-    const double* it = reinterpret_cast<const double*>(imp + 2 + (long long)q * RC_IMP_WORDS);
-    const int slot = (int)imp[2 + (long long)q * RC_IMP_WORDS + 18];
-    LsdAdvRect R;
-    R.x1 = it[0]; R.y1 = it[1]; R.x2 = it[2]; R.y2 = it[3]; R.width = it[4]; R.theta = it[5]; R.dx = it[6]; R.dy = it[7];
-    R.prec = a.prec; R.p = a.p;
-    if (rc_rect_improve(f, R, it[8], a.logNT)) {
-      const double rec[4] = {R.x1, R.y1, R.x2, R.y2};
-      rc_store_segment(&ent[slot], rec);
-    } else {
-      ent[slot] = uint4{RC_DROPPED, 0u, 0u, 0u};
+  const double* W = reinterpret_cast<const double*>(a.ordered + (long long)b * a.arenaStride);   // (k_lsd_rects_adv's weights)
+  const uint32_t* log = a.reg + (long long)b * a.arenaStride;
+  const uint32_t* park = a.park + (long long)b * a.arenaStride;
+  const int nPark = n > 0 ? (int)park[0] : 0;
+  const int lane = tid & 63, wv = tid >> 6;
+  RcStage st;
+  st.p = s_p + wv * 64 * RC_PITCH; st.w = s_w + wv * 64 * RC_PITCH; st.off = s_off + wv * 64; st.cnt = s_cnt + wv * 64;
+  for (int base = 0; base < nPark; base += RC_IMP) {
+    const int na = min(RC_IMP, nPark - base);
+    int slot = -1;
+    {   // the parked rectangles again (64 per wavefront, as k_lsd_rects_adv evaluated them), into LDS
+      uint4 e = uint4{0u, 0u, 0u, 0u};
+      double lnfa = 0;
+      if (tid < na) {
+        const uint32_t* pk = park + 2 + 3 * (base + tid);
+        slot = (int)pk[0];
+        const uint32_t lw[2] = {pk[1], pk[2]};
+        __builtin_memcpy(&lnfa, lw, 8);
+        e = ent[slot];
+      }
+      if (wv * 64 < na) {
+        double rec[8];
+        rc_wave_region2rect(st, log, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+        if (tid < na) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) s_R[tid * 10 + k] = rec[k];
+          s_R[tid * 10 + 8] = a.prec; s_R[tid * 10 + 9] = a.p;
+          s_nfa[tid] = lnfa;
+          s_active[tid] = 1;
+        }
+      }
     }
+    __syncthreads();
+    for (int stage = 0; stage < 5; stage++) {
+      for (int t = tid; t < na * 5; t += 256) {
+        const int i = t / 5, m = t - 5 * i + 1;
+        bool ok = false;
+        double v = 0;
+        if (s_active[i]) {
+          LsdAdvRect r;
+          const double* q = s_R + i * 10;
+          r.x1 = q[0]; r.y1 = q[1]; r.x2 = q[2]; r.y2 = q[3]; r.width = q[4]; r.theta = q[5]; r.dx = q[6]; r.dy = q[7]; r.prec = q[8]; r.p = q[9];
+          ok = rc_variant(stage, m, r);
+          if (ok) v = rc_rect_nfa(f, r, a.logNT);
+        }
+        s_v[t] = v;
+        s_ok[t] = ok ? 1 : 0;
+      }
+      __syncthreads();
+      if (tid < na && s_active[tid]) {   // the loop's accept rule over the stage's variants, in order
+        double log_nfa = s_nfa[tid];
+        int best = 0;
+        for (int m = 1; m <= 5; m++)
+          if (s_ok[tid * 5 + m - 1] && s_v[tid * 5 + m - 1] > log_nfa) { log_nfa = s_v[tid * 5 + m - 1]; best = m; }
+        if (best) {
+          LsdAdvRect r;
+          double* q = s_R + tid * 10;
+          r.x1 = q[0]; r.y1 = q[1]; r.x2 = q[2]; r.y2 = q[3]; r.width = q[4]; r.theta = q[5]; r.dx = q[6]; r.dy = q[7]; r.prec = q[8]; r.p = q[9];
+          (void)rc_variant(stage, best, r);
+          q[0] = r.x1; q[1] = r.y1; q[2] = r.x2; q[3] = r.y2; q[4] = r.width; q[8] = r.prec; q[9] = r.p;
+          s_nfa[tid] = log_nfa;
+        }
+        if (log_nfa > 0.0) s_active[tid] = 0;   // LOG_EPS: meaningful, the remaining stages are skipped
+      }
+      __syncthreads();
+    }
+    if (tid < na) {
+      if (s_nfa[tid] > 0.0) rc_store_segment(&ent[slot], s_R + tid * 10);
+      else ent[slot] = uint4{RC_DROPPED, 0u, 0u, 0u};
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // stable compaction of the surviving segments (a slot moves down or stays: chunks in order never overwrite unread input)
   int outBase = 0;
-  const int lane = tid & 63, wv = tid >> 6;
   for (int c0 = 0; c0 < n; c0 += 256) {
     const int i = c0 + tid;
     uint4 v = uint4{RC_DROPPED, 0u, 0u, 0u};
