@@ -68,6 +68,7 @@ struct plh_line {
   int rszTP = 0, rszTR = 0;   // k_resize_u8 source tile of a 256 x 16 output block (pitch in bytes, rows)
   // device buffers
   uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dMask = nullptr;
+  void* dAdv = nullptr;   // LSD_REFINE_ADV: maxBatch x segCap LsdAdvRec (144 bytes each), allocated by the first extract call at that level
   uint32_t *dArena = nullptr, *dDxdy = nullptr;   // dArena: per-frame blocks (line_plan.h, arenaStride)
   // multi-wavefront region growing (small batches): transaction logs and private mark planes, allocated on first use
   uint32_t* dMwReg = nullptr;
@@ -170,7 +171,7 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark, h->dMwHint,
+  void* ptrs[] = {h->dAdv, h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark, h->dMwHint,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -289,7 +290,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   const long long offSegs = 0, offReg = align_up<long long>((long long)a.segCap * 4, 64), offPix = offReg + a.scaledStride,
                   offOrd = offPix + a.scaledStride, offScr = offOrd + a.scaledStride, offWork = offScr + a.scaledStride,
                   offPark = offWork + align_up<long long>((long long)lsd_order_work_u32(), 64),
-                  blockWords = offPark + align_up<long long>(3LL * a.segCap + 2, 64);
+                  blockWords = offPark + align_up<long long>(2LL * a.segCap + 2, 64);
   // (`ordered` and `scr` are adjacent on purpose: after region growing k_lsd_rects keeps one double per kept pixel across both)
   a.arenaStride = align_up<long long>(blockWords, blockWords >= (1 << 18) ? (1 << 19) : (1 << 14));   // 2 MiB (64 KiB for small frames)
   TRYHIP(hipMalloc((void**)&h->dArena, B * (size_t)a.arenaStride * 4));
@@ -468,6 +469,14 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
       const plh_status st = mw_reserve(h, a, batch, waves);
       if (st != PLH_OK) return st;
     }
+  }
+  if (a.refineAdv) {
+    if (!h->dAdv && hipMalloc(&h->dAdv, (size_t)h->maxBatch * a.segCap * 144) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("plh_line_extract: cannot allocate the LSD_REFINE_ADV rectangle records (%d frames x %d)", h->maxBatch, a.segCap);
+      return PLH_ERR_ALLOC;
+    }
+    a.adv = reinterpret_cast<LsdAdvRec*>(h->dAdv);
   }
   PLH_HIP(hipMemsetAsync(h->dStatus, 0, 4, s));   // capacity flags of this call only (plh_line_status)
   if (h->hasUndistort) {

@@ -39,6 +39,7 @@ struct RemapTap {
   uint32_t wts;   // wx0 | wx1 << 8 | wy0 << 16 | wy1 << 24
 };
 
+struct LsdAdvRec;   // lsd_rect_dev.h
 struct LineDeviceArgs {
   // geometry
   int w, h;                 // full-resolution image
@@ -85,7 +86,9 @@ struct LineDeviceArgs {
   // exact rectangle for every decision (the path every undecided region takes anyway: same segments; an A/B and test switch)
   float screenLo, screenHi;
   int screen;
-  uint32_t* park;           // LSD_REFINE_ADV: per frame [0] count, then {slot, log_nfa} of the rectangles k_lsd_rects_adv leaves to k_lsd_improve
+  uint32_t* park;           // LSD_REFINE_ADV: per frame [0], [1] = lengths of two lists of slots (segCap words each, from word 2): the
+                            // rectangles still in rect_improve(), read from one list and written to the other stage by stage
+  LsdAdvRec* adv;           // LSD_REFINE_ADV: segCap records per frame (lsd_rect_dev.h), allocated when the level is first used
   int refineAdv;            // 1: LSD_REFINE_ADV (rect_improve / NFA on the kept regions' rectangles, k_lsd_rects), plh_line_set_refine
   double logNT;             // 5 (log10 sw + log10 sh) / 2 + log10 11, flsd()'s LOG_NT
   // selection

@@ -122,4 +122,130 @@ struct LsdRegionEntry {
   uint32_t logOff, cnt, angBits, pad;
 };
 
+// ---------------------------------------------------------------------------------------------
+// LSD_REFINE_ADV on the kept regions' rectangles (lsd_rects.hip computes them, lsd_adv.hip improves them).  rect_improve()
+// reads the immutable level-line field only and decides only whether the segment is kept, so it runs per rectangle, not per
+// frame -- and in kernels of two kinds, because its two halves want opposite things from the machine:
+//   * rect_nfa()'s scan of the rectangle's pixels is a chain of dependent gathers: light kernels, many wavefronts resident;
+//   * nfa() is a few thousand instructions of double-precision library math (log, exp, pow, sinh) per evaluation and no memory:
+//     heavy kernels (> 200 registers), one lane per evaluation.
+// Between them a rectangle lives in an LsdAdvRec (a lazily allocated buffer of segCap records per frame).
+// ---------------------------------------------------------------------------------------------
+struct alignas(16) LsdAdvRec {
+  double r[10];          // x1 y1 x2 y2 width theta dx dy prec p: the rectangle rect_improve() currently holds
+  double log_nfa;        // its log_nfa
+  int cnt[5][2];         // (total, aligned) pixel counts of the current stage's variants m = 1 .. 5; [0] also serves the first rect_nfa()
+  unsigned char ok[8];   // [m - 1]: variant m exists (the loops' width gate)
+};
+
+constexpr uint32_t RC_DROPPED = 0xffffffffu;   // first word of a slot whose rectangle LSD_REFINE_ADV rejected (a NaN: never a coordinate)
+
+struct RcFrame {
+  const uint32_t* P;
+  const LsdAngleEntry* A;
+  int spitch, sw, sh;
+};
+
+__device__ __forceinline__ LsdAdvRect lsd_adv_load(const double* q) {
+  LsdAdvRect r;
+  r.x1 = q[0]; r.y1 = q[1]; r.x2 = q[2]; r.y2 = q[3]; r.width = q[4]; r.theta = q[5]; r.dx = q[6]; r.dy = q[7]; r.prec = q[8]; r.p = q[9];
+  return r;
+}
+
+// The pixel counts of rect_nfa() (oracle/lsd.cc rect_nfa, with the published code's quirks: integer scan-line steps, the tail
+// point's x where a y is meant).  The scan-line bounds advance by integer steps from an integer start, so row y's span is a
+// closed form of the number of rows walked before it; rows outside the image are skipped before the step update (`continue`),
+// so they do not count.  Four pixels in flight per lane (record, then its angle from the gradient table).
+__device__ __forceinline__ void lsd_rect_counts(const RcFrame& f, const LsdAdvRect& r, int& totalOut, int& algOut) {
+  const double hw = r.width / 2.0, dyhw = r.dy * hw, dxhw = r.dx * hw;
+  int ox[4] = {(int)(r.x1 - dyhw), (int)(r.x2 - dyhw), (int)(r.x2 + dyhw), (int)(r.x1 + dyhw)};
+  int oy[4] = {(int)(r.y1 + dxhw), (int)(r.y2 + dxhw), (int)(r.y2 - dxhw), (int)(r.y1 - dxhw)};
+  // std::sort by (x, y) ascending: a sorting network on four elements
+#define LSD_CSWAP(i, j)                                                          \
+  if (ox[j] < ox[i] || (ox[j] == ox[i] && oy[j] < oy[i])) {                      \
+    const int tx = ox[i], ty = oy[i];                                            \
+    ox[i] = ox[j]; oy[i] = oy[j]; ox[j] = tx; oy[j] = ty;                        \
+  }
+  LSD_CSWAP(0, 1) LSD_CSWAP(2, 3) LSD_CSWAP(0, 2) LSD_CSWAP(1, 3) LSD_CSWAP(1, 2)
+#undef LSD_CSWAP
+  int iMin = 0, iMax = 0;
+  for (int i = 1; i < 4; ++i) {
+    if (oy[iMin] > oy[i]) iMin = i;
+    if (oy[iMax] < oy[i]) iMax = i;
+  }
+  unsigned taken = 1u << iMin;
+  int iL = -1, iR = -1, iT = -1;
+  for (int i = 0; i < 4; ++i)
+    if (!((taken >> i) & 1u)) { if (iL < 0) iL = i; else if (ox[iL] > ox[i]) iL = i; }
+  taken |= 1u << iL;
+  for (int i = 0; i < 4; ++i)
+    if (!((taken >> i) & 1u)) { if (iR < 0) iR = i; else if (ox[iR] < ox[i]) iR = i; }
+  taken |= 1u << iR;
+  for (int i = 0; i < 4; ++i)
+    if (!((taken >> i) & 1u)) { if (iT < 0) iT = i; else if (ox[iT] > ox[i]) iT = i; }
+  const int mx = ox[iMin], my = oy[iMin], lx = ox[iL], ly = oy[iL], rx = ox[iR], ry = oy[iR], tx = ox[iT];
+  // integer divisions, and the tail point's x where a y is meant: as published
+  const long long fl = (my != ly) ? (mx - lx) / (my - ly) : 0, sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
+  const long long fr = (my != ry) ? (mx - rx) / (my - ry) : 0, sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
+  const int yA = max(my, 0), yB = min(oy[iMax], f.sh - 1);   // the scan lines inside the image
+  int total = 0, alg = 0;
+  for (int y = yA; y <= yB; ++y) {
+    // steps taken in front of row y: one per row of [yA, y), the first kind for the rows above the left (right) corner
+    const long long j = (long long)(y - yA);
+    long long nl = (long long)min(y, ly) - yA, nr = (long long)min(y, ry) - yA;
+    nl = nl < 0 ? 0 : nl; nr = nr < 0 ? 0 : nr;
+    const long long left = mx + fl * nl + sl * (j - nl), right = mx + fr * nr + sr * (j - nr);
+    const int xa = (int)(left < 0 ? 0 : left), xb = (int)(right > f.sw - 1 ? f.sw - 1 : right);
+    const uint32_t* row = f.P + __umul24((unsigned)y, (unsigned)f.spitch);
+    if (xb >= xa) total += xb - xa + 1;
+    for (int x = xa; x <= xb; x += 4) {
+      unsigned rec[4];
+      float ang[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) rec[k] = x + k <= xb ? row[x + k] : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; k++) ang[k] = (rec[k] & LSD_REC_DEF) ? f.A[rec[k] & LSD_REC_IDX].angf : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if ((rec[k] & LSD_REC_DEF) && lsd_aligned(r.theta, (double)ang[k] * kDegToRads, r.prec)) ++alg;
+    }
+  }
+  totalOut = total; algOut = alg;
+}
+
+// One variant of rect_improve(): the rectangle R after `m` iterations (1 .. 5) of stage `stage`'s loop body.  The loops modify
+// their rectangle whether or not the variant is accepted, so the five variants of a stage follow from the stage's starting
+// rectangle alone and can be evaluated side by side.  Returns false when the loop's width gate stops before iteration m.
+__device__ __forceinline__ bool lsd_adv_variant(int stage, int m, LsdAdvRect& r) {
+  const double delta = 0.5, delta_2 = delta / 2.0;
+  if (stage == 0) {          // finer precision (no gate)
+    for (int j = 0; j < m; j++) { r.p /= 2; r.prec = r.p * kPI; }
+    return true;
+  }
+  for (int j = 0; j < m; j++) {
+    if (!((r.width - delta) >= 0.5)) return false;
+    if (stage == 1) {        // reduce width
+      r.width -= delta;
+    } else if (stage == 2) { // reduce one side
+      r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+      r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+      r.width -= delta;
+    } else if (stage == 3) { // reduce the other side
+      r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+      r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+      r.width -= delta;
+    } else {                 // finer precision again
+      r.p /= 2;
+      r.prec = r.p * kPI;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ void lsd_store_segment(uint4* slot, const double* rec) {
+  float sg[4];
+  lsd_segment_of(rec, sg);
+  *slot = uint4{__float_as_uint(sg[0]), __float_as_uint(sg[1]), __float_as_uint(sg[2]), __float_as_uint(sg[3])};
+}
+
 }  // namespace plh
