@@ -286,13 +286,15 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
 #define TRYHIP(x) do { if ((x) != hipSuccess) { set_error("plh_line_create: %s failed (batch %d)", #x, max_batch); plh_line_destroy(h); return PLH_ERR_ALLOC; } } while (0)
   TRYHIP(hipMalloc((void**)&h->dTmpA, B * a.fullStride));
   TRYHIP(hipMalloc((void**)&h->dScaled, B * a.scaledStride));
-  // per-frame block, hot parts first: segments | region queue | level-line records | seed list | scratch | ordering counters
+  // per-frame block, hot parts first: segments | region queue / log | level-line records | seed list | scratch | ordering counters |
+  // squared gradient norms of the log | LSD_REFINE_ADV work lists
   const long long offSegs = 0, offReg = align_up<long long>((long long)a.segCap * 4, 64), offPix = offReg + a.scaledStride,
                   offOrd = offPix + a.scaledStride, offScr = offOrd + a.scaledStride, offWork = offScr + a.scaledStride,
-                  offPark = offWork + align_up<long long>((long long)lsd_order_work_u32(), 64),
+                  offRegq = offWork + align_up<long long>((long long)lsd_order_work_u32(), 64), offPark = offRegq + a.scaledStride,
                   blockWords = offPark + align_up<long long>(2LL * a.segCap + 2, 64);
-  // (`ordered` and `scr` are adjacent on purpose: after region growing k_lsd_rects keeps one double per kept pixel across both)
-  a.arenaStride = align_up<long long>(blockWords, blockWords >= (1 << 18) ? (1 << 19) : (1 << 14));   // 2 MiB (64 KiB for small frames)
+  // one contiguous block per frame (a region-growing wavefront touches few translation fragments); blocks 256 KiB aligned (64 KiB
+  // for small frames) -- round 2's 2 MiB alignment bought nothing measurable and would round this block from 4.4 to 6 MiB
+  a.arenaStride = align_up<long long>(blockWords, blockWords >= (1 << 18) ? (1 << 16) : (1 << 14));
   TRYHIP(hipMalloc((void**)&h->dArena, B * (size_t)a.arenaStride * 4));
   TRYHIP(hipMalloc((void**)&h->dDxdy, B * a.fullStride * 4));
   TRYHIP(hipMalloc((void**)&h->dQmax, B * 4));
@@ -319,7 +321,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
     return PLH_ERR_ALLOC;
   }
   a.angleTab = h->a.angleTab;
-  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dArena + offPix; a.ordered = h->dArena + offOrd; a.reg = h->dArena + offReg; a.scr = h->dArena + offScr; a.orderWork = h->dArena + offWork; a.park = h->dArena + offPark;
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dArena + offPix; a.ordered = h->dArena + offOrd; a.reg = h->dArena + offReg; a.regq = h->dArena + offRegq; a.scr = h->dArena + offScr; a.orderWork = h->dArena + offWork; a.park = h->dArena + offPark;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = reinterpret_cast<float*>(h->dArena + offSegs); a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
   *out = h;
@@ -471,12 +473,16 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
     }
   }
   if (a.refineAdv) {
-    if (!h->dAdv && hipMalloc(&h->dAdv, (size_t)h->maxBatch * a.segCap * 144) != hipSuccess) {
+    const size_t recBytes = align_up<size_t>((size_t)h->maxBatch * a.segCap * 144, 256);
+    if (!h->dAdv && hipMalloc(&h->dAdv, recBytes + (size_t)h->maxBatch * a.scaledStride * 4) != hipSuccess) {
       (void)hipGetLastError();
       set_error("plh_line_extract: cannot allocate the LSD_REFINE_ADV rectangle records (%d frames x %d)", h->maxBatch, a.segCap);
       return PLH_ERR_ALLOC;
     }
     a.adv = reinterpret_cast<LsdAdvRec*>(h->dAdv);
+    a.advAng = reinterpret_cast<float*>(static_cast<uint8_t*>(h->dAdv) + recBytes);
+  } else {
+    a.adv = nullptr; a.advAng = nullptr;
   }
   PLH_HIP(hipMemsetAsync(h->dStatus, 0, 4, s));   // capacity flags of this call only (plh_line_status)
   if (h->hasUndistort) {

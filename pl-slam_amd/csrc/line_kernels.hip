@@ -303,6 +303,16 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
     uint4 o4;
     o4.x = rec[0]; o4.y = rec[1]; o4.z = rec[2]; o4.w = rec[3];
     *reinterpret_cast<uint4*>(o) = o4;
+    if (a.advAng) {   // LSD_REFINE_ADV: the level-line angle itself (what the table holds for the pixel's gradient; NOTDEF = -1024)
+      float an[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int gx = (int)(rec[k] & 1023u) - LSD_GRAD_MAX, gy = (int)((rec[k] >> LSD_ANGLE_PITCH_LOG2) & 1023u) - LSD_GRAD_MAX;
+        an[k] = (rec[k] & LSD_REC_DEF) ? fast_atan2_deg((float)gx, (float)(-gy)) : -1024.f;
+      }
+      float* ao = a.advAng + (long long)b * a.scaledStride + (__mul24(y, a.spitch) + x4);
+      *reinterpret_cast<uint4*>(ao) = uint4{__float_as_uint(an[0]), __float_as_uint(an[1]), __float_as_uint(an[2]), __float_as_uint(an[3])};
+    }
     if (qmax) atomicMax(&s_max, qmax);
   }
   __syncthreads();

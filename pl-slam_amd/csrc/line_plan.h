@@ -63,7 +63,8 @@ struct LineDeviceArgs {
   uint8_t* scaled;          // 0.8x image, pitch spitch
   uint32_t* pix;            // level-line record per scaled pixel (LSD_REC_*), pitch spitch
   uint32_t* ordered;        // seed list (packed coordinates x | y << 16), bins descending / raster inside a bin
-  uint32_t* reg;            // region point queue
+  uint32_t* reg;            // region point queue; behind region growing: the frame's log of kept regions (packed coordinates)
+  uint32_t* regq;           // beside every log entry: gx^2 + gy^2 of the pixel (what its region2rect() weight is the root of)
   uint32_t* scr;            // scratch of the same size
   uint32_t* orderWork;      // seed ordering: per frame counts / offsets [16 chunks][1024 bins] + the 1024 bin thresholds (line_kernels.hip)
   unsigned int* qmax;       // per frame max(gx^2+gy^2) over defined pixels
@@ -89,6 +90,8 @@ struct LineDeviceArgs {
   uint32_t* park;           // LSD_REFINE_ADV: per frame [0], [1] = lengths of two lists of slots (segCap words each, from word 2): the
                             // rectangles still in rect_improve(), read from one list and written to the other stage by stage
   LsdAdvRec* adv;           // LSD_REFINE_ADV: segCap records per frame (lsd_rect_dev.h), allocated when the level is first used
+  float* advAng;            // LSD_REFINE_ADV: level-line angle per scaled pixel in float degrees (-1024 = NOTDEF), written by k_lsd_grad:
+                            // rect_nfa()'s scan reads one float per pixel instead of record -> table; scaledStride floats per frame
   int refineAdv;            // 1: LSD_REFINE_ADV (rect_improve / NFA on the kept regions' rectangles, k_lsd_rects), plh_line_set_refine
   double logNT;             // 5 (log10 sw + log10 sh) / 2 + log10 11, flsd()'s LOG_NT
   // selection

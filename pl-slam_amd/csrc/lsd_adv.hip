@@ -2,8 +2,8 @@
 // (cv::LineSegmentDetector created with LSD_REFINE_ADV: what the system opencv_contrib LSDDetector behind
 // src/LineExtractor.cpp:39-40 passes as published; oracle/lsd.cc rect_improve / rect_nfa / nfa).
 //
-// k_lsd_rects_adv (lsd_rects.hip) has left every kept region's rectangle and the pixel counts of its first rect_nfa() in an
-// LsdAdvRec.  From there:
+// k_lsd_rects_adv (lsd_rects.hip) has left every kept region's rectangle in an LsdAdvRec.  From there:
+//   k_adv_scan(-1)               light   the pixel counts of every rectangle's first rect_nfa(), one lane each
 //   k_adv_first                  heavy   nfa() of every rectangle; meaningful -> segment, else -> the frame's work list
 //   5 x { k_adv_scan(stage)      light   the pixel counts of the stage's five variants of every listed rectangle, one lane each
 //         k_adv_select(stage) }  heavy   their nfa(), one lane each; the loop's accept rule in order; meaningful -> segment,
@@ -50,13 +50,23 @@ __global__ void __launch_bounds__(256) k_adv_first(LineDeviceArgs a) {
   if (tid == 0) f.park[0] = (uint32_t)s_n;
 }
 
+// stage -1: the rectangles as region2rect() left them, all n of the frame; stage 0 .. 4: variant m of every listed rectangle
 __global__ void __launch_bounds__(256) k_adv_scan(LineDeviceArgs a, int stage) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const AdvFrame f = adv_frame(a, b);
+  RcFrame rf;
+  rf.ang = a.advAng + (long long)b * a.scaledStride; rf.spitch = a.spitch; rf.sw = a.sw; rf.sh = a.sh;
+  if (stage < 0) {
+    for (int i = tid; i < f.n; i += 256) {
+      LsdAdvRec* ar = f.rec + i;
+      int total, alg;
+      lsd_rect_counts(rf, lsd_adv_load(ar->r), total, alg);
+      ar->cnt[0][0] = total; ar->cnt[0][1] = alg;
+    }
+    return;
+  }
   const uint32_t* list = f.park + 2 + (stage & 1) * a.segCap;
   const int na = f.n > 0 ? (int)f.park[stage & 1] : 0;
-  RcFrame rf;
-  rf.P = a.pix + (long long)b * a.arenaStride; rf.A = a.angleTab; rf.spitch = a.spitch; rf.sw = a.sw; rf.sh = a.sh;
   for (int t = tid; t < na * 5; t += 256) {
     const int q = t / 5, m = t - 5 * q + 1;
     LsdAdvRec* ar = f.rec + list[q];
@@ -143,6 +153,7 @@ __global__ void __launch_bounds__(256) k_adv_compact(LineDeviceArgs a) {
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s) {
   const dim3 g(a.batch), b(256);
+  hipLaunchKernelGGL(k_adv_scan, g, b, 0, s, a, -1);
   hipLaunchKernelGGL(k_adv_first, g, b, 0, s, a);
   for (int stage = 0; stage < 5; stage++) {
     hipLaunchKernelGGL(k_adv_scan, g, b, 0, s, a, stage);

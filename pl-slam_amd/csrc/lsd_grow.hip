@@ -8,6 +8,8 @@ struct GrowCtx {
   uint32_t* P;                 // level-line records of the scaled image (LSD_REC_*: table index | DEF | USED = region growing's mark)
   const LsdAngleEntry* A;      // per-device table of everything a gradient determines (line_plan.h)
   uint32_t* reg;       // region queue (global memory); entries are packed coordinates x | y << 16
+  uint32_t* regq;      // one wavefront per frame: gx^2 + gy^2 of the queue's pixels, written beside reg for the region that is kept
+                       // (k_lsd_rects takes region2rect()'s weights from it); null in the multi-wavefront kernel (the commit writes it)
   uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
   uint8_t* M;          // multi-wavefront build only: this wavefront's private `used` marks, one byte per pixel (k_lsd_grow_mw)
   uint16_t* H;         // ... and the frame's claim hints, shared by its wavefronts: tag of the transaction that last marked the pixel
@@ -650,6 +652,10 @@ __device__ __forceinline__ float screen_max4(const uint4 v) { return fmaxf(fmaxf
 
 // `fromRing`: the queue is as region_grow() left it (its newest LSD_RING entries mirrored in LDS); false after
 // reduce_region_radius() has permuted it in global memory.
+// (one wavefront per frame: regq of a region the screen did not walk -- screen off, or more than LSD_SCREEN_MAX pixels)
+__device__ __forceinline__ void lsd_fill_regq(const GrowCtx& c, int cnt) {
+  for (int i = c.lane; i < cnt; i += 64) c.regq[i] = lsd_rec_q(c.P[pk_lin(c, c.reg[i])]);
+}
 template <bool MW>
 __device__ __forceinline__ int lsd_density_screen(const GrowCtx& c, int cnt, bool fromRing, float thLo, float thHi) {
   if (cnt > LSD_SCREEN_MAX) return 0;
@@ -668,7 +674,11 @@ __device__ __forceinline__ int lsd_density_screen(const GrowCtx& c, int cnt, boo
     if (on) p = inRing ? c.ring[i] : c.reg[i];
     if (base == 0) p0 = p;
     const unsigned rec = c.P[pk_lin(c, p)];   // (lanes beyond the end read the seed's record; their weight is zero)
-    const float w = on ? plh_sqrt_approx((float)lsd_rec_q(rec)) : 0.f;
+    const unsigned q = lsd_rec_q(rec);
+    if constexpr (!MW) {
+      if (on) c.regq[i] = q;   // beside the queue: if this region is kept, k_lsd_rects needs no record of it again
+    }
+    const float w = on ? plh_sqrt_approx((float)q) : 0.f;
     const float dx = (float)(pk_x(p) - x0), dy = (float)(pk_y(p) - y0);
     const float wx = w * dx, wy = w * dy;
     S[0] += w; S[1] += wx; S[2] += wy;
@@ -852,7 +862,13 @@ __device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const
       dense = d2;
     }
     PF_ADD(c, 5, PF_NOW() - pg1);
-    if (dense) { t.keep = true; break; }
+    if (dense) {
+      t.keep = true;
+      if constexpr (!MW) {
+        if (!a.screen || cnt > LSD_SCREEN_MAX) { grow_lane_fence<MW>(); lsd_fill_regq(c, cnt); }
+      }
+      break;
+    }
     const unsigned long long pg2 = PF_NOW();
     if (phase == 0) {
       // refine(): tolerance from the angle spread near the seed, everything un-marked, grown again
@@ -980,6 +996,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   c.P = a.pix + (long long)b * a.arenaStride;
   c.A = a.angleTab;
   c.reg = a.reg + (long long)b * a.arenaStride;
+  c.regq = a.regq + (long long)b * a.arenaStride;
   c.scr = a.scr + (long long)b * a.arenaStride;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
@@ -1108,6 +1125,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
           reinterpret_cast<uint4*>(segs)[nseg] = uint4{(unsigned)logOff, (unsigned)tx.finCnt, __float_as_uint(tx.ang), 0u};
         logOff += tx.finCnt;
         c.reg += tx.finCnt;
+        c.regq += tx.finCnt;
         nseg++;
       }
     }
@@ -1274,7 +1292,7 @@ struct MwShared {
 // A kept region goes to the frame's log (frameLog: the one-wavefront kernel's queue area, free here) and its LsdRegionEntry into
 // the next segment slot, exactly as the one-wavefront kernel leaves them; k_lsd_rects evaluates the rectangles.
 __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
-                         uint32_t* drainReg, float* segs, uint32_t* frameLog) {
+                         uint32_t* drainReg, float* segs, uint32_t* frameLog, uint32_t* frameLogQ) {
   const int lane = ch.lane, g = lane >> 3, j = lane & 7;
   int h = mw_ld_u(&sh.ctl[MWC_HEAD]);
   int nseg = mw_ld_u(&sh.ctl[MWC_NSEG]);
@@ -1374,9 +1392,16 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
         }
         if (fl & 4u) {
           if (oneGo) {
-            if (lane >= finBase && lane < finBase + finCnt) frameLog[logOff + lane - finBase] = myPk;
+            if (lane >= finBase && lane < finBase + finCnt) {
+              frameLog[logOff + lane - finBase] = myPk;
+              frameLogQ[logOff + lane - finBase] = lsd_rec_q(myRec);
+            }
           } else {
-            for (int i = lane; i < finCnt; i += 64) frameLog[logOff + i] = log[finBase + i];
+            for (int i = lane; i < finCnt; i += 64) {
+              const uint32_t pk = log[finBase + i];
+              frameLog[logOff + i] = pk;
+              frameLogQ[logOff + i] = lsd_rec_q(ch.P[pk_lin(ch, pk)]);
+            }
           }
           if (lane == 0 && nseg < a.segCap)   // (every lane read the same post: q2.y is the region angle in all of them)
             reinterpret_cast<uint4*>(segs)[nseg] = uint4{(unsigned)logOff, (unsigned)finCnt, q2.y, 0u};
@@ -1404,7 +1429,11 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
           ch.M[li] = 0;
         }
         if (t.keep) {
-          for (int i = lane; i < t.finCnt; i += 64) frameLog[logOff + i] = drainReg[t.finBase + i];
+          for (int i = lane; i < t.finCnt; i += 64) {
+            const uint32_t pk = drainReg[t.finBase + i];
+            frameLog[logOff + i] = pk;
+            frameLogQ[logOff + i] = lsd_rec_q(ch.P[pk_lin(ch, pk)]);
+          }
           if (lane == 0 && nseg < a.segCap)
             reinterpret_cast<uint4*>(segs)[nseg] = uint4{(unsigned)logOff, (unsigned)t.finCnt, __float_as_uint(t.ang), 0u};
           nseg++;
@@ -1433,7 +1462,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
 
 // take the drain lock if there is something to commit and nobody is at it; returns whether anything was done
 __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs& a, const MwShared& sh, uint32_t* frameReg,
-                             uint32_t* drainReg, float* segs, uint32_t* frameLog) {
+                             uint32_t* drainReg, float* segs, uint32_t* frameLog, uint32_t* frameLogQ) {
   bool did = false;
   const int wvTrace = (int)(threadIdx.x >> 6);
   (void)wvTrace;
@@ -1444,7 +1473,7 @@ __device__ bool mw_try_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceA
     mw_acquire();
     const unsigned long long pd0 = PF_NOW();
     MW_TRACE(wvTrace, ch.lane, 5, h);   // drain session begins at head h
-    mw_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog);
+    mw_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog, frameLogQ);
     MW_TRACE(wvTrace, ch.lane, 6, mw_ld(&sh.ctl[MWC_HEAD]));   // ... ends
     PF_ADD(ch, 23, PF_NOW() - pd0); PF_ADD(ch, 25, 1);
     if (ch.lane == 0) mw_st(&sh.ctl[MWC_DLOCK], 0);
@@ -1473,6 +1502,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   c.A = a.angleTab;
   uint32_t* const regBase = frameReg + (long long)wv * a.mwRegStride;
   c.reg = regBase;
+  c.regq = nullptr;
   c.scr = regBase + 4 * S;
   c.M = frameMark + (long long)wv * a.mwMarkStride;
   c.H = a.mwHint + (long long)b * a.mwMarkStride;   // (mwMarkStride 16-bit tags)
@@ -1488,6 +1518,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;
   float* segs = a.segs + (long long)b * a.arenaStride;
   uint32_t* const frameLog = a.reg + (long long)b * a.arenaStride;   // the kept regions, in commit order (k_lsd_rects reads them)
+  uint32_t* const frameLogQ = a.regq + (long long)b * a.arenaStride;  // ... and gx^2 + gy^2 of their pixels
   const int nOrd = a.nOrdered[b];
 #if defined(PLH_GROW_PROF)
   unsigned long long pfv[40];
@@ -1561,7 +1592,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     if (s < 0) {
       if (done && pop >= push && head >= push) break;   // every seed handed out and committed
       const unsigned long long pw0 = PF_NOW();
-      if (mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog)) { polls = 0; continue; }
+      if (mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog, frameLogQ)) { polls = 0; continue; }
       int stop = 0;
       MW_TRACE(wv, lane, 7, (pop < push ? 1 : 0) | (off > S ? 2 : 0) | (pop - head >= a.mwLag ? 4 : 0) | (done ? 8 : 0));   // nothing to do: why
       if (lane == 0) { stop = mw_give_up(ctl, polls, a.status); mw_pause(); }
@@ -1704,7 +1735,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     // (and a wavefront with nothing else to do always does).
     {
       const int hd = mw_ld_u(&ctl[MWC_HEAD]);
-      if (s == hd || s - hd >= a.mwDrainGap) mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog);
+      if (s == hd || s - hd >= a.mwDrainGap) mw_try_drain(ch, gs, a, sh, frameReg, drainReg, segs, frameLog, frameLogQ);
     }
   }
   __syncthreads();

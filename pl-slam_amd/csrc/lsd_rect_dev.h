@@ -141,8 +141,7 @@ struct alignas(16) LsdAdvRec {
 constexpr uint32_t RC_DROPPED = 0xffffffffu;   // first word of a slot whose rectangle LSD_REFINE_ADV rejected (a NaN: never a coordinate)
 
 struct RcFrame {
-  const uint32_t* P;
-  const LsdAngleEntry* A;
+  const float* ang;   // level-line angle per pixel, float degrees, -1024 = NOTDEF (LineDeviceArgs::advAng)
   int spitch, sw, sh;
 };
 
@@ -155,7 +154,7 @@ __device__ __forceinline__ LsdAdvRect lsd_adv_load(const double* q) {
 // The pixel counts of rect_nfa() (oracle/lsd.cc rect_nfa, with the published code's quirks: integer scan-line steps, the tail
 // point's x where a y is meant).  The scan-line bounds advance by integer steps from an integer start, so row y's span is a
 // closed form of the number of rows walked before it; rows outside the image are skipped before the step update (`continue`),
-// so they do not count.  Four pixels in flight per lane (record, then its angle from the gradient table).
+// so they do not count.  One float per pixel from the angle plane k_lsd_grad writes for this level (no record -> table chain).
 __device__ __forceinline__ void lsd_rect_counts(const RcFrame& f, const LsdAdvRect& r, int& totalOut, int& algOut) {
   const double hw = r.width / 2.0, dyhw = r.dy * hw, dxhw = r.dx * hw;
   int ox[4] = {(int)(r.x1 - dyhw), (int)(r.x2 - dyhw), (int)(r.x2 + dyhw), (int)(r.x1 + dyhw)};
@@ -185,29 +184,26 @@ __device__ __forceinline__ void lsd_rect_counts(const RcFrame& f, const LsdAdvRe
     if (!((taken >> i) & 1u)) { if (iT < 0) iT = i; else if (ox[iT] > ox[i]) iT = i; }
   const int mx = ox[iMin], my = oy[iMin], lx = ox[iL], ly = oy[iL], rx = ox[iR], ry = oy[iR], tx = ox[iT];
   // integer divisions, and the tail point's x where a y is meant: as published
-  const long long fl = (my != ly) ? (mx - lx) / (my - ly) : 0, sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
-  const long long fr = (my != ry) ? (mx - rx) / (my - ry) : 0, sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
+  // (int arithmetic: corners lie within a rectangle's width of the image, |coordinates| < 2^15, so steps x rows stay below 2^31)
+  const int fl = (my != ly) ? (mx - lx) / (my - ly) : 0, sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
+  const int fr = (my != ry) ? (mx - rx) / (my - ry) : 0, sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
   const int yA = max(my, 0), yB = min(oy[iMax], f.sh - 1);   // the scan lines inside the image
   int total = 0, alg = 0;
   for (int y = yA; y <= yB; ++y) {
     // steps taken in front of row y: one per row of [yA, y), the first kind for the rows above the left (right) corner
-    const long long j = (long long)(y - yA);
-    long long nl = (long long)min(y, ly) - yA, nr = (long long)min(y, ry) - yA;
-    nl = nl < 0 ? 0 : nl; nr = nr < 0 ? 0 : nr;
-    const long long left = mx + fl * nl + sl * (j - nl), right = mx + fr * nr + sr * (j - nr);
-    const int xa = (int)(left < 0 ? 0 : left), xb = (int)(right > f.sw - 1 ? f.sw - 1 : right);
-    const uint32_t* row = f.P + __umul24((unsigned)y, (unsigned)f.spitch);
+    const int j = y - yA;
+    const int nl = max(min(y, ly) - yA, 0), nr = max(min(y, ry) - yA, 0);
+    const int left = mx + fl * nl + sl * (j - nl), right = mx + fr * nr + sr * (j - nr);
+    const int xa = max(left, 0), xb = min(right, f.sw - 1);
+    const float* row = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
     if (xb >= xa) total += xb - xa + 1;
-    for (int x = xa; x <= xb; x += 4) {
-      unsigned rec[4];
-      float ang[4];
+    for (int x = xa; x <= xb; x += 4) {   // four independent loads in flight
+      float an[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) rec[k] = x + k <= xb ? row[x + k] : 0u;
-#pragma unroll
-      for (int k = 0; k < 4; k++) ang[k] = (rec[k] & LSD_REC_DEF) ? f.A[rec[k] & LSD_REC_IDX].angf : 0.f;
+      for (int k = 0; k < 4; k++) an[k] = x + k <= xb ? row[x + k] : -1024.f;
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        if ((rec[k] & LSD_REC_DEF) && lsd_aligned(r.theta, (double)ang[k] * kDegToRads, r.prec)) ++alg;
+        if (an[k] >= 0.f && lsd_aligned(r.theta, (double)an[k] * kDegToRads, r.prec)) ++alg;
     }
   }
   totalOut = total; algOut = alg;

@@ -11,8 +11,8 @@
 // loop about equally long.
 //
 // LSD_REFINE_ADV (rect_improve / rect_nfa / nfa, lsd_rect_dev.h) reads the immutable level-line field only and decides only
-// whether the segment is kept: k_lsd_rects_adv leaves the rectangle and the pixel counts of its first rect_nfa() in an LsdAdvRec,
-// and lsd_adv.hip runs nfa() / rect_improve() on them (light scan kernels and heavy nfa kernels alternating, the five variants
+// whether the segment is kept: k_lsd_rects_adv leaves the rectangle in an LsdAdvRec, and lsd_adv.hip runs rect_nfa() / nfa() /
+// rect_improve() on them (light scan kernels and heavy nfa kernels alternating, the five variants
 // of each rect_improve() stage side by side), followed by a stable compaction of the surviving segments.
 #include "lsd_rect_dev.h"
 
@@ -30,15 +30,16 @@ __device__ __forceinline__ int rc_size_class(unsigned cnt) {
 
 // ---------------------------------------------------------------------------------------------
 // The kernels.  One block (4 wavefronts) per frame.
-//   1. weights (k_lsd_weights): one coalesced pass over the frame's log computes every kept pixel's modgrad -- sqrt((gx^2 + gy^2) / 4.0) from the
-//      record's table index, the expression the table itself was filled with (line_kernels.hip k_lsd_angle_table) -- into W
-//      (doubles, the seed-list + scratch areas of the frame's block: both are free after region growing);
-//   2. the entries are sorted by size class (largest first), 64 consecutive ones go to the lanes of a wavefront;
-//   3. the wavefront stages its 64 regions' pixels and weights through LDS, RC_K per lane at a time -- loaded 8 regions x 8
-//      consecutive pixels per instruction (a lane per region reading its own stream would touch 64 cache lines per load and
-//      leave the kernel bound by the texture addresser: 5.3 ms per 1536 frames in the first version of this file, r04_screen_ab_v1)
-//      -- and every lane adds its own region's terms from LDS in region order.  Rows of the staging tiles are padded with
-//      zero terms, which the sums absorb exactly (+0.0; the accumulators are never -0.0), as lsd_chain_add does.
+//   1. the entries are sorted by size class (largest first), 64 consecutive ones go to the lanes of a wavefront;
+//   2. the wavefront stages its 64 regions' pixels through LDS, RC_K per lane at a time: packed coordinates from the frame's log
+//      and gx^2 + gy^2 from the array beside it (written by region growing, which had the record in hand), loaded 8 regions x 8
+//      consecutive entries per instruction -- a lane per region reading its own stream touches 64 cache lines per load and left
+//      the first version of this file bound by the texture addresser (5.3 ms per 1536 frames, profiles/r04_screen_ab_v1...) --
+//      and the weight sqrt((gx^2 + gy^2) / 4.0), the expression the gradient table was filled with, is evaluated in the staging
+//      step, where all 64 lanes work; the next chunk's loads are in flight while a chunk is added up;
+//   3. every lane adds its own region's terms from LDS in region order.  Rows of the staging tiles are padded with zero terms,
+//      which the sums absorb exactly (+0.0; the accumulators are never -0.0), as lsd_chain_add does.
+// No record, no table entry is read here: the level-line field stays with region growing.
 // ---------------------------------------------------------------------------------------------
 constexpr int RC_K = 8;
 constexpr int RC_PITCH = RC_K + 1;
@@ -49,31 +50,35 @@ struct RcStage {   // one wavefront's part of the block's LDS
   uint32_t* off;   // [64] log offset of lane r's region
   int* cnt;        // [64] its pixel count (0: the lane has no region)
 };
+struct RcLoad {    // one chunk's entries on their way from global memory to the staging tiles
+  uint32_t p[8], q[8];
+};
 
 template <bool WITH_W>
-__device__ __forceinline__ void rc_stage(const RcStage& st, const uint32_t* log, const double* W, int lane, int c) {
-  uint32_t pv[8];
-  double wv[8];
+__device__ __forceinline__ void rc_load(const RcStage& st, const uint32_t* log, const uint32_t* logq, int lane, int c, RcLoad& L) {
 #pragma unroll
   for (int g = 0; g < 8; g++) {
     const int r = 8 * g + (lane >> 3), idx = c * RC_K + (lane & 7);
     const bool valid = idx < st.cnt[r];
     const uint32_t a = st.off[r] + (uint32_t)idx;
-    pv[g] = valid ? log[a] : 0u;
-    if (WITH_W) wv[g] = valid ? W[a] : 0.0;
+    L.p[g] = valid ? log[a] : 0u;
+    if (WITH_W) L.q[g] = valid ? logq[a] : 0u;
   }
+}
+template <bool WITH_W>
+__device__ __forceinline__ void rc_put(const RcStage& st, int lane, const RcLoad& L) {
 #pragma unroll
   for (int g = 0; g < 8; g++) {
     const int r = 8 * g + (lane >> 3), k = lane & 7;
-    st.p[r * RC_PITCH + k] = pv[g];
-    if (WITH_W) st.w[r * RC_PITCH + k] = wv[g];
+    st.p[r * RC_PITCH + k] = L.p[g];
+    if (WITH_W) st.w[r * RC_PITCH + k] = q_modgrad(L.q[g]);   // (q = 0 for the padding: weight +0.0)
   }
 }
 
 // region2rect() + get_theta() of the 64 regions of a wavefront (lane = region; cnt 0 = none): oracle/lsd.cc region2rect, the same
 // expressions in the same order as lsd_region2rect (lsd_grow.hip).  rec = x1 y1 x2 y2 width theta dx dy.
-__device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uint32_t* log, const double* W, int lane, uint32_t myOff, int myCnt,
-                                                    double reg_angle, double prec, double rec[8]) {
+__device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uint32_t* log, const uint32_t* logq, int lane, uint32_t myOff,
+                                                    int myCnt, double reg_angle, double prec, double rec[8]) {
   PLH_WAVE_SYNC();
   st.off[lane] = myOff; st.cnt[lane] = myCnt;
   int maxCnt = myCnt;
@@ -82,10 +87,13 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
   const int chunks = (maxCnt + RC_K - 1) / RC_K;
   const uint32_t* sp = st.p + lane * RC_PITCH;
   const double* sw = st.w + lane * RC_PITCH;
+  RcLoad L;
   double sx = 0, sy = 0, sum = 0;
+  rc_load<true>(st, log, logq, lane, 0, L);
   for (int c = 0; c < chunks; c++) {
-    rc_stage<true>(st, log, W, lane, c);
+    rc_put<true>(st, lane, L);
     PLH_WAVE_SYNC();
+    if (c + 1 < chunks) rc_load<true>(st, log, logq, lane, c + 1, L);
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
       const uint32_t p = sp[k];
@@ -98,9 +106,11 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
   }
   const double x = sx / sum, y = sy / sum;
   double Ixx = 0, Iyy = 0, Ixy = 0;
+  rc_load<true>(st, log, logq, lane, 0, L);
   for (int c = 0; c < chunks; c++) {
-    rc_stage<true>(st, log, W, lane, c);
+    rc_put<true>(st, lane, L);
     PLH_WAVE_SYNC();
+    if (c + 1 < chunks) rc_load<true>(st, log, logq, lane, c + 1, L);
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
       const uint32_t p = sp[k];
@@ -116,9 +126,11 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
   const D2 cs = lsd_sincos_inl(theta);
   const double dx = cs.x, dy = cs.y;
   double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+  rc_load<false>(st, log, logq, lane, 0, L);
   for (int c = 0; c < chunks; c++) {
-    rc_stage<false>(st, log, W, lane, c);
+    rc_put<false>(st, lane, L);
     PLH_WAVE_SYNC();
+    if (c + 1 < chunks) rc_load<false>(st, log, logq, lane, c + 1, L);
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
       if (c * RC_K + k < myCnt) {
@@ -139,8 +151,8 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
   rec[5] = theta; rec[6] = dx; rec[7] = dy;
 }
 
-// ADV = false: LSD_REFINE_STD, every rectangle is a segment.  ADV = true: the rectangle goes to its slot's LsdAdvRec together
-// with the pixel counts of its first rect_nfa(); lsd_adv.hip takes it from there.
+// ADV = false: LSD_REFINE_STD, every rectangle is a segment.  ADV = true: the rectangle goes to its slot's LsdAdvRec; lsd_adv.hip
+// takes it from there.
 template <bool ADV>
 __device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
   __shared__ uint32_t s_order[RC_CHUNK];
@@ -153,15 +165,12 @@ __device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
   const int n = min(a.nSegs[b], a.segCap);
   uint4* ent = reinterpret_cast<uint4*>(a.segs + (long long)b * a.arenaStride);
   const uint32_t* log = a.reg + (long long)b * a.arenaStride;
-  double* W = reinterpret_cast<double*>(a.ordered + (long long)b * a.arenaStride);   // `ordered` and `scr` are adjacent: one double per pixel
-  RcFrame f;
-  f.P = a.pix + (long long)b * a.arenaStride; f.A = a.angleTab; f.spitch = a.spitch; f.sw = a.sw; f.sh = a.sh;
-  // (1. the weights of all kept pixels: k_lsd_weights, launched in front of this kernel)
+  const uint32_t* logq = a.regq + (long long)b * a.arenaStride;
   RcStage st;
   st.p = s_p + wv * 64 * RC_PITCH; st.w = s_w + wv * 64 * RC_PITCH; st.off = s_off + wv * 64; st.cnt = s_cnt + wv * 64;
   for (int c0 = 0; c0 < n; c0 += RC_CHUNK) {
     const int m = min(RC_CHUNK, n - c0);
-    // 2. counting sort of the chunk's entries by size class, the largest first (they set the pace of their wavefront)
+    // 1. counting sort of the chunk's entries by size class, the largest first (they set the pace of their wavefront)
     for (int i = tid; i < RC_BINS; i += 256) s_hist[i] = 0;
     __syncthreads();
     for (int i = tid; i < m; i += 256) atomicAdd(&s_hist[rc_size_class(ent[c0 + i].y)], 1);
@@ -173,59 +182,32 @@ __device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
     __syncthreads();
     for (int i = tid; i < m; i += 256) s_order[atomicAdd(&s_hist[rc_size_class(ent[c0 + i].y)], 1)] = (uint32_t)(c0 + i);
     __syncthreads();
-    // 3. 64 sorted entries per wavefront at a time
+    // 2., 3. 64 sorted entries per wavefront at a time
     for (int base = wv * 64; base < m; base += 256) {
       const int k = base + lane;
       int slot = -1;
       uint4 e = uint4{0u, 0u, 0u, 0u};
       if (k < m) { slot = (int)s_order[k]; e = ent[slot]; }   // LsdRegionEntry
       double rec[8];
-      rc_wave_region2rect(st, log, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+      rc_wave_region2rect(st, log, logq, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
       if (slot < 0) continue;
       if constexpr (!ADV) {
         lsd_store_segment(&ent[slot], rec);
-      } else {   // the rectangle and the pixel counts of its first rect_nfa() go to the slot's LsdAdvRec; nfa() itself is k_adv_first's
+      } else {
         LsdAdvRec* ar = a.adv + (long long)b * a.segCap + slot;
 #pragma unroll
         for (int k2 = 0; k2 < 8; k2++) ar->r[k2] = rec[k2];
         ar->r[8] = a.prec; ar->r[9] = a.p;
-        int total, alg;
-        lsd_rect_counts(f, lsd_adv_load(ar->r), total, alg);
-        ar->cnt[0][0] = total; ar->cnt[0][1] = alg;
       }
     }
     __syncthreads();
   }
-}
-// 1. of the list above, as a kernel of its own: a block per 1024 log positions and frame, four consecutive pixels per thread --
-// inside the per-frame block of lsd_rects_frame the pass was 400 dependent iterations per thread (log -> record -> sqrt -> store).
-__global__ void __launch_bounds__(256) k_lsd_weights(LineDeviceArgs a) {
-  const int b = blockIdx.y;
-  const int n = min(a.nSegs[b], a.segCap);
-  if (n <= 0) return;
-  const uint4* ent = reinterpret_cast<const uint4*>(a.segs + (long long)b * a.arenaStride);
-  const uint4 last = ent[n - 1];
-  const int logTotal = (int)(last.x + last.y);
-  const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (j0 >= logTotal) return;
-  const uint32_t* log = a.reg + (long long)b * a.arenaStride;
-  const uint32_t* P = a.pix + (long long)b * a.arenaStride;
-  double* W = reinterpret_cast<double*>(a.ordered + (long long)b * a.arenaStride);
-  const uint4 p4 = *reinterpret_cast<const uint4*>(log + j0);   // (the log area is a multiple of 256 words: reading past logTotal stays inside it)
-  const uint32_t pp[4] = {p4.x, p4.y, p4.z, p4.w};
-  unsigned rec[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) rec[k] = j0 + k < logTotal ? P[__umul24(pp[k] >> 16, (unsigned)a.spitch) + (pp[k] & 0xffffu)] : 0u;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (j0 + k < logTotal) W[j0 + k] = q_modgrad(lsd_rec_q(rec[k]));
 }
 __global__ void __launch_bounds__(256) k_lsd_rects(LineDeviceArgs a) { lsd_rects_frame<false>(a); }
 __global__ void __launch_bounds__(256) k_lsd_rects_adv(LineDeviceArgs a) { lsd_rects_frame<true>(a); }
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s);   // lsd_adv.hip
 void launch_lsd_rects(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_lsd_weights, dim3((unsigned)((a.spitch * a.sh + 1023) / 1024), (unsigned)a.batch), dim3(256), 0, s, a);
   if (!a.refineAdv) {
     hipLaunchKernelGGL(k_lsd_rects, dim3(a.batch), dim3(256), 0, s, a);
     return;

@@ -8,7 +8,7 @@ O=gpurun_out/r4b
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_line.py -m gpu -x -q --timeout 600 2>&1 | tail -4 | tee $O/tests_line.txt
-timeout 900 python -m pytest tests/test_soak_gpu.py -m gpu -x -q -s --timeout 800 -k "refine_adv" 2>&1 | grep -v amdgpu.ids | tail -8 | tee $O/tests_soak_adv.txt
+timeout 900 python -m pytest tests/test_soak_gpu.py -m gpu -x -q -s --timeout 800 2>&1 | grep -v amdgpu.ids | tail -8 | tee $O/tests_soak_adv.txt
 for flag in "" "--no-screen" "--refine adv"; do
 echo -n "[$flag] headline: " | tee -a $O/ab.txt
 timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --no-verify $flag 2>/dev/null | tail -1 | python -c "
