@@ -286,15 +286,16 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
 #define TRYHIP(x) do { if ((x) != hipSuccess) { set_error("plh_line_create: %s failed (batch %d)", #x, max_batch); plh_line_destroy(h); return PLH_ERR_ALLOC; } } while (0)
   TRYHIP(hipMalloc((void**)&h->dTmpA, B * a.fullStride));
   TRYHIP(hipMalloc((void**)&h->dScaled, B * a.scaledStride));
-  // per-frame block, hot parts first: segments | region queue / log | level-line records | seed list | scratch | ordering counters |
-  // squared gradient norms of the log | LSD_REFINE_ADV work lists
-  const long long offSegs = 0, offReg = align_up<long long>((long long)a.segCap * 4, 64), offPix = offReg + a.scaledStride,
-                  offOrd = offPix + a.scaledStride, offScr = offOrd + a.scaledStride, offWork = offScr + a.scaledStride,
-                  offRegq = offWork + align_up<long long>((long long)lsd_order_work_u32(), 64), offPark = offRegq + a.scaledStride,
+  // per-frame block, hot parts first: segments | region queue / log | gradient norms of the log (+ reduce_region_radius scratch) |
+  // level-line records | seed list | ordering counters | LSD_REFINE_ADV work lists
+  const long long offSegs = 0, offReg = align_up<long long>((long long)a.segCap * 4, 64), offRegq = offReg + a.scaledStride,
+                  offPix = offRegq + a.scaledStride, offOrd = offPix + a.scaledStride, offWork = offOrd + a.scaledStride,
+                  offPark = offWork + align_up<long long>((long long)lsd_order_work_u32(), 64),
                   blockWords = offPark + align_up<long long>(2LL * a.segCap + 2, 64);
-  // one contiguous block per frame (a region-growing wavefront touches few translation fragments); blocks 256 KiB aligned (64 KiB
-  // for small frames) -- round 2's 2 MiB alignment bought nothing measurable and would round this block from 4.4 to 6 MiB
-  a.arenaStride = align_up<long long>(blockWords, blockWords >= (1 << 18) ? (1 << 16) : (1 << 14));
+  // one contiguous block per frame, 2 MiB aligned (64 KiB for small frames): a wavefront's scattered accesses stay inside one or
+  // two translation fragments.  (Measured again in round 4: with 256 KiB alignment the seed scatter k_lsd_bin_scatter took 2.82
+  // instead of 2.05 ms per 1536 frames and k_lsd_grow 69.4 instead of 68.0, profiles/r04_screen_ab_v4_logq_256k_alignment.txt.)
+  a.arenaStride = align_up<long long>(blockWords, blockWords >= (1 << 18) ? (1 << 19) : (1 << 14));   // 2 MiB (64 KiB for small frames)
   TRYHIP(hipMalloc((void**)&h->dArena, B * (size_t)a.arenaStride * 4));
   TRYHIP(hipMalloc((void**)&h->dDxdy, B * a.fullStride * 4));
   TRYHIP(hipMalloc((void**)&h->dQmax, B * 4));
@@ -321,7 +322,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
     return PLH_ERR_ALLOC;
   }
   a.angleTab = h->a.angleTab;
-  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dArena + offPix; a.ordered = h->dArena + offOrd; a.reg = h->dArena + offReg; a.regq = h->dArena + offRegq; a.scr = h->dArena + offScr; a.orderWork = h->dArena + offWork; a.park = h->dArena + offPark;
+  a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dArena + offPix; a.ordered = h->dArena + offOrd; a.reg = h->dArena + offReg; a.regq = h->dArena + offRegq; a.orderWork = h->dArena + offWork; a.park = h->dArena + offPark;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = reinterpret_cast<float*>(h->dArena + offSegs); a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
   *out = h;

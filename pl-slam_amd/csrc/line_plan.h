@@ -65,7 +65,6 @@ struct LineDeviceArgs {
   uint32_t* ordered;        // seed list (packed coordinates x | y << 16), bins descending / raster inside a bin
   uint32_t* reg;            // region point queue; behind region growing: the frame's log of kept regions (packed coordinates)
   uint32_t* regq;           // beside every log entry: gx^2 + gy^2 of the pixel (what its region2rect() weight is the root of)
-  uint32_t* scr;            // scratch of the same size
   uint32_t* orderWork;      // seed ordering: per frame counts / offsets [16 chunks][1024 bins] + the 1024 bin thresholds (line_kernels.hip)
   unsigned int* qmax;       // per frame max(gx^2+gy^2) over defined pixels
   int* nOrdered;            // per frame

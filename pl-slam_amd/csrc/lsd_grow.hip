@@ -10,7 +10,7 @@ struct GrowCtx {
   uint32_t* reg;       // region queue (global memory); entries are packed coordinates x | y << 16
   uint32_t* regq;      // one wavefront per frame: gx^2 + gy^2 of the queue's pixels, written beside reg for the region that is kept
                        // (k_lsd_rects takes region2rect()'s weights from it); null in the multi-wavefront kernel (the commit writes it)
-  uint32_t* scr;       // scratch of the same size (reduce_region_radius compaction)
+  uint32_t* scr;       // scratch of the queue's size (reduce_region_radius compaction)
   uint8_t* M;          // multi-wavefront build only: this wavefront's private `used` marks, one byte per pixel (k_lsd_grow_mw)
   uint16_t* H;         // ... and the frame's claim hints, shared by its wavefronts: tag of the transaction that last marked the pixel
   unsigned hTag;       // this transaction's tag, (sequence number mod 65535) + 1
@@ -997,7 +997,8 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   c.A = a.angleTab;
   c.reg = a.reg + (long long)b * a.arenaStride;
   c.regq = a.regq + (long long)b * a.arenaStride;
-  c.scr = a.scr + (long long)b * a.arenaStride;
+  c.scr = c.regq;   // reduce_region_radius()'s scratch (at most one word per queue entry) is the queue's own part of regq: whatever
+                    // a reduce step leaves there is rewritten by the next density decision on the permuted queue (or at keep time)
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
   const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;   // packed coordinates x | y << 16
@@ -1126,6 +1127,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
         logOff += tx.finCnt;
         c.reg += tx.finCnt;
         c.regq += tx.finCnt;
+        c.scr = c.regq;
         nseg++;
       }
     }
