@@ -19,6 +19,8 @@
 // The ADV functions are restated WITH the published code's quirks, which decide which rectangles survive: the integer
 // divisions of the scan-line steps and the `tailp->p.x` read where a y is meant (rect_nfa), and the first term of nfa()'s
 // log1term being (n + 1) rather than log_gamma(n + 1).
+#include <quadmath.h>
+
 #include <cfloat>
 #include <algorithm>
 #include <cmath>
@@ -187,7 +189,13 @@ struct Lsd {
     x /= sum;
     y /= sum;
     double theta = get_theta(reg, x, y, reg_angle, prec);
-    double dx = std::cos(theta), dy = std::sin(theta);
+    // PINNED (extended in round 4): cos / sin of the rectangle angle are the CORRECTLY ROUNDED doubles -- what the C
+    // library of the reference's build returns differs from build to build in the last bit (glibc >= 2.28 is not correctly
+    // rounded).  113-bit libquadmath, rounded to double (tools/sincos_cr_check.c counts the arguments whose 113-bit value sits
+    // close enough to a tie for that second rounding to matter: none).
+    __float128 qs, qc;
+    sincosq((__float128)theta, &qs, &qc);
+    const double dx = (double)qc, dy = (double)qs;
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
     for (size_t i = 0; i < reg.size(); ++i) {
       double regdx = double(reg[i].x) - x, regdy = double(reg[i].y) - y;

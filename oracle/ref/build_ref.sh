@@ -38,7 +38,7 @@ echo "built $OUT/libmisc_ref.so"
 LD=$REF/Thirdparty/line_descriptor
 g++ -O2 -std=c++14 -fPIC -shared -w -ffp-contract=off -fno-fast-math -I "$HERE/stub" -I "$REF/include" -I "$LD/include" \
   -o "$OUT/libline_ref.so" "$HERE/ref_line.cc" "$REF/src/LineExtractor.cpp" "$LD/src/LSDDetector_custom.cpp" \
-  "$LD/src/binary_descriptor_custom.cpp" "$HERE/../img_ops.cc" "$HERE/../lsd.cc"
+  "$LD/src/binary_descriptor_custom.cpp" "$HERE/../img_ops.cc" "$HERE/../lsd.cc" -lquadmath
 echo "built $OUT/libline_ref.so"
 # The oracle's grid / descriptor helpers the matcher harnesses lean on, compiled apart (slam_stub.h is force-included
 # into the reference's translation units only).
@@ -71,5 +71,5 @@ g++ -O2 -std=c++14 -fPIC -shared -w -pthread -ffp-contract=off -fno-fast-math -D
   "$REF/src/LSDmatcher.cpp" "$REF/src/MapPoint.cc" "$REF/src/MapLine.cpp" \
   "$REF/src/lineIterator.cpp" "$REF/src/ORBextractor.cc" "$REF/src/LineExtractor.cpp" "$LD/src/LSDDetector_custom.cpp" \
   "$LD/src/binary_descriptor_custom.cpp" "$D/DBoW2/FORB.cpp" "$D/DBoW2/BowVector.cpp" "$D/DBoW2/FeatureVector.cpp" \
-  "$D/DBoW2/ScoringObject.cpp" "$D/DUtils/Random.cpp" "$D/DUtils/Timestamp.cpp" $PLO_OBJS "$OUT/plo_lsd.o"
+  "$D/DBoW2/ScoringObject.cpp" "$D/DUtils/Random.cpp" "$D/DUtils/Timestamp.cpp" $PLO_OBJS "$OUT/plo_lsd.o" -lquadmath
 echo "built $OUT/libframe_ref.so"

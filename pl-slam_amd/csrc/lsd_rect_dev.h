@@ -5,6 +5,7 @@
 // kernels produce the same doubles, which are the oracle's (oracle/lsd.cc region2rect, get_theta, nfa).
 #pragma once
 #include "line_dev.h"
+#include "plh_sincos_cr.h"
 
 namespace plh {
 
@@ -44,14 +45,10 @@ __device__ __forceinline__ double lsd_rect_theta(double Ixx, double Iyy, double 
   return theta;
 }
 
-// cos / sin of the rectangle angle (theta in [0, 3 pi)), x = cos, y = sin
+// cos / sin of the rectangle angle (theta in [0, 3 pi)), x = cos, y = sin: correctly rounded (plh_sincos_cr.h)
 __device__ __forceinline__ D2 lsd_sincos_inl(double t) {
   D2 r;
-#if defined(PLH_LIB_SINCOS)
-  sincos(t, &r.y, &r.x);
-#else
-  sincos_head_tail(t, r.y, r.x);
-#endif
+  sincos_cr(t, r.y, r.x);
   return r;
 }
 

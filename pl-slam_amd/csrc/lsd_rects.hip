@@ -36,10 +36,11 @@ __device__ __forceinline__ int rc_size_class(unsigned cnt) {
 //      consecutive entries per instruction -- a lane per region reading its own stream touches 64 cache lines per load and left
 //      the first version of this file bound by the texture addresser (5.3 ms per 1536 frames, profiles/r04_screen_ab_v1...) --
 //      and the weight sqrt((gx^2 + gy^2) / 4.0), the expression the gradient table was filled with, is evaluated in the staging
-//      step, where all 64 lanes work; the next chunk's loads are in flight while a chunk is added up;
+//      step of the first pass, where all 64 lanes work, and kept in W (a double per log entry, over the dead record plane) for
+//      the second; the next chunk's loads are in flight while a chunk is added up;
 //   3. every lane adds its own region's terms from LDS in region order.  Rows of the staging tiles are padded with zero terms,
 //      which the sums absorb exactly (+0.0; the accumulators are never -0.0), as lsd_chain_add does.
-// No record, no table entry is read here: the level-line field stays with region growing.
+// No record, no table entry is read here: the level-line field stays with region growing (its plane is reused for W).
 // ---------------------------------------------------------------------------------------------
 constexpr int RC_K = 8;
 constexpr int RC_PITCH = RC_K + 1;
@@ -52,33 +53,42 @@ struct RcStage {   // one wavefront's part of the block's LDS
 };
 struct RcLoad {    // one chunk's entries on their way from global memory to the staging tiles
   uint32_t p[8], q[8];
+  double w[8];     // (the second pass: the weights the first pass left in W)
 };
 
-template <bool WITH_W>
-__device__ __forceinline__ void rc_load(const RcStage& st, const uint32_t* log, const uint32_t* logq, int lane, int c, RcLoad& L) {
+// MODE 0: coordinates only (extents); 1: coordinates + gx^2 + gy^2, the weight is evaluated and left in W (first pass);
+// 2: coordinates + the weight from W (second pass: sqrt once per pixel, not twice)
+template <int MODE>
+__device__ __forceinline__ void rc_load(const RcStage& st, const uint32_t* log, const uint32_t* logq, double* W, int lane, int c, RcLoad& L) {
 #pragma unroll
   for (int g = 0; g < 8; g++) {
     const int r = 8 * g + (lane >> 3), idx = c * RC_K + (lane & 7);
     const bool valid = idx < st.cnt[r];
     const uint32_t a = st.off[r] + (uint32_t)idx;
     L.p[g] = valid ? log[a] : 0u;
-    if (WITH_W) L.q[g] = valid ? logq[a] : 0u;
+    if (MODE == 1) L.q[g] = valid ? logq[a] : 0u;
+    if (MODE == 2) L.w[g] = valid ? W[a] : 0.0;
   }
 }
-template <bool WITH_W>
-__device__ __forceinline__ void rc_put(const RcStage& st, int lane, const RcLoad& L) {
+template <int MODE>
+__device__ __forceinline__ void rc_put(const RcStage& st, double* W, int lane, int c, const RcLoad& L) {
 #pragma unroll
   for (int g = 0; g < 8; g++) {
     const int r = 8 * g + (lane >> 3), k = lane & 7;
     st.p[r * RC_PITCH + k] = L.p[g];
-    if (WITH_W) st.w[r * RC_PITCH + k] = q_modgrad(L.q[g]);   // (q = 0 for the padding: weight +0.0)
+    if (MODE == 1) {
+      const double w = q_modgrad(L.q[g]);   // (q = 0 for the padding: weight +0.0)
+      st.w[r * RC_PITCH + k] = w;
+      if (c * RC_K + k < st.cnt[r]) W[st.off[r] + (uint32_t)(c * RC_K + k)] = w;
+    }
+    if (MODE == 2) st.w[r * RC_PITCH + k] = L.w[g];
   }
 }
 
 // region2rect() + get_theta() of the 64 regions of a wavefront (lane = region; cnt 0 = none): oracle/lsd.cc region2rect, the same
 // expressions in the same order as lsd_region2rect (lsd_grow.hip).  rec = x1 y1 x2 y2 width theta dx dy.
-__device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uint32_t* log, const uint32_t* logq, int lane, uint32_t myOff,
-                                                    int myCnt, double reg_angle, double prec, double rec[8]) {
+__device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uint32_t* log, const uint32_t* logq, double* W, int lane,
+                                                    uint32_t myOff, int myCnt, double reg_angle, double prec, double rec[8]) {
   PLH_WAVE_SYNC();
   st.off[lane] = myOff; st.cnt[lane] = myCnt;
   int maxCnt = myCnt;
@@ -89,11 +99,11 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
   const double* sw = st.w + lane * RC_PITCH;
   RcLoad L;
   double sx = 0, sy = 0, sum = 0;
-  rc_load<true>(st, log, logq, lane, 0, L);
+  rc_load<1>(st, log, logq, W, lane, 0, L);
   for (int c = 0; c < chunks; c++) {
-    rc_put<true>(st, lane, L);
+    rc_put<1>(st, W, lane, c, L);
     PLH_WAVE_SYNC();
-    if (c + 1 < chunks) rc_load<true>(st, log, logq, lane, c + 1, L);
+    if (c + 1 < chunks) rc_load<1>(st, log, logq, W, lane, c + 1, L);
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
       const uint32_t p = sp[k];
@@ -106,11 +116,12 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
   }
   const double x = sx / sum, y = sy / sum;
   double Ixx = 0, Iyy = 0, Ixy = 0;
-  rc_load<true>(st, log, logq, lane, 0, L);
+  PLH_WAVE_SYNC();   // (the wavefront's own stores to W are read back: a wavefront observes its earlier stores)
+  rc_load<2>(st, log, logq, W, lane, 0, L);
   for (int c = 0; c < chunks; c++) {
-    rc_put<true>(st, lane, L);
+    rc_put<2>(st, W, lane, c, L);
     PLH_WAVE_SYNC();
-    if (c + 1 < chunks) rc_load<true>(st, log, logq, lane, c + 1, L);
+    if (c + 1 < chunks) rc_load<2>(st, log, logq, W, lane, c + 1, L);
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
       const uint32_t p = sp[k];
@@ -126,11 +137,11 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
   const D2 cs = lsd_sincos_inl(theta);
   const double dx = cs.x, dy = cs.y;
   double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
-  rc_load<false>(st, log, logq, lane, 0, L);
+  rc_load<0>(st, log, logq, W, lane, 0, L);
   for (int c = 0; c < chunks; c++) {
-    rc_put<false>(st, lane, L);
+    rc_put<0>(st, W, lane, c, L);
     PLH_WAVE_SYNC();
-    if (c + 1 < chunks) rc_load<false>(st, log, logq, lane, c + 1, L);
+    if (c + 1 < chunks) rc_load<0>(st, log, logq, W, lane, c + 1, L);
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
       if (c * RC_K + k < myCnt) {
@@ -166,6 +177,8 @@ __device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
   uint4* ent = reinterpret_cast<uint4*>(a.segs + (long long)b * a.arenaStride);
   const uint32_t* log = a.reg + (long long)b * a.arenaStride;
   const uint32_t* logq = a.regq + (long long)b * a.arenaStride;
+  double* W = reinterpret_cast<double*>(a.pix + (long long)b * a.arenaStride);   // the records and the seed list behind them are dead by now:
+                                                                                // one double per log entry fits (pix | ordered are adjacent)
   RcStage st;
   st.p = s_p + wv * 64 * RC_PITCH; st.w = s_w + wv * 64 * RC_PITCH; st.off = s_off + wv * 64; st.cnt = s_cnt + wv * 64;
   for (int c0 = 0; c0 < n; c0 += RC_CHUNK) {
@@ -189,7 +202,7 @@ __device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
       uint4 e = uint4{0u, 0u, 0u, 0u};
       if (k < m) { slot = (int)s_order[k]; e = ent[slot]; }   // LsdRegionEntry
       double rec[8];
-      rc_wave_region2rect(st, log, logq, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+      rc_wave_region2rect(st, log, logq, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
       if (slot < 0) continue;
       if constexpr (!ADV) {
         lsd_store_segment(&ent[slot], rec);

@@ -102,7 +102,8 @@ PLH_HD void sincos_cr(double ad, double& s, double& c) {
   const double y = (r - x) - w;                                          // r = x + y to ~2^-110
   // ---- quick phase
   const double ax = x < 0 ? -x : x;
-  const int j = (int)(ax * 128.0 + 0.5);
+  int j = (int)(ax * 128.0 + 0.5);
+  j = j < 0 ? 0 : (j > 101 ? 101 : j);   // (a NaN argument -- a lane without a region -- must not index outside the table)
   const double xk = (double)j * 0.0078125;
   const double sg = x < 0 ? -1.0 : 1.0;           // sin is odd, cos even: work on |r| = sg (x + y)
   const double d0 = ax - xk;                      // exact
