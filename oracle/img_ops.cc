@@ -300,6 +300,28 @@ int plo_fast9_16(const uint8_t* img, int w, int h, size_t step, int threshold, i
   return n;
 }
 
+// cv::pyrDown(src8u, dst, Size(dw, dh)) (imgproc pyramids.cpp, pyrDown_<FixPtCast<uchar, 8>>; BORDER_DEFAULT = REFLECT_101): the
+// 5 x 5 kernel [1 4 6 4 1] x [1 4 6 4 1] centred on source pixel (2x, 2y), integer sums, (v + 128) >> 8.  Called by
+// LSDDetector::computeGaussianPyramid (LSDDetector_custom.cpp:56-73) and BinaryDescriptor::computeGaussianPyramid
+// (binary_descriptor_custom.cpp:350-370) with dst = Size(cols / ratio, rows / ratio); OpenCV asserts |2 dw - w| <= 2 and
+// |2 dh - h| <= 2 (returns -1 here).  OpenCV source absent from /root/reference: PARITY UNPINNED (oracle/plo.h).
+int plo_pyr_down_u8(const uint8_t* src, int w, int h, size_t sstep, uint8_t* dst, int dw, int dh, size_t dstep) {
+  if (std::abs(dw * 2 - w) > 2 || std::abs(dh * 2 - h) > 2 || dw <= 0 || dh <= 0) return -1;
+  static const int k5[5] = {1, 4, 6, 4, 1};
+  for (int y = 0; y < dh; y++)
+    for (int x = 0; x < dw; x++) {
+      int v = 0;
+      for (int ky = 0; ky < 5; ky++) {
+        const uint8_t* row = src + (size_t)reflect101(2 * y + ky - 2, h) * sstep;
+        int r = 0;
+        for (int kx = 0; kx < 5; kx++) r += k5[kx] * row[reflect101(2 * x + kx - 2, w)];
+        v += k5[ky] * r;
+      }
+      dst[(size_t)y * dstep + x] = (uint8_t)((v + 128) >> 8);
+    }
+  return 0;
+}
+
 // cv::Sobel(src8u, dst, CV_16S, 1,0,3) and (0,1,3), BORDER_REFLECT_101 (binary_descriptor_custom.cpp:395-396).
 void plo_sobel3_s16(const uint8_t* src, int w, int h, size_t sstep, int16_t* dx, int16_t* dy) {
   auto P = [&](int y, int x) -> int { return src[(size_t)reflect101(y, h) * sstep + reflect101(x, w)]; };

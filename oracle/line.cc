@@ -39,9 +39,11 @@ inline int cv_round_f(float v) { return (int)lrintf(v); }
 
 extern "C" {
 
-// LSDDetector::detectImpl, single octave (scale int -> 1, numOctaves 1): Vec4f -> KeyLine + mask filter.
-int plo_keylines_from_segments(const float* segs, int n, int w, int h, const uint8_t* mask, size_t mstep,
-                               plo_keyline* out) {
+// LSDDetector::detectImpl's KeyLine fill for the segments of ONE octave (LSDDetector_custom.cpp:161-199): w x h = that octave's
+// image, octaveScale = pow((float)scale, octaveIdx), class ids continue from class0; the mask (full resolution, mstep pitch) is
+// looked up at the scaled end points (:202-213).  Returns the number of KeyLines written.
+static int keylines_of_octave(const float* segs, int n, int w, int h, int octave, float octaveScale, int class0, const uint8_t* mask,
+                              size_t mstep, plo_keyline* out) {
   int m = 0;
   for (int k = 0; k < n; k++) {
     float e[4] = {segs[k * 4], segs[k * 4 + 1], segs[k * 4 + 2], segs[k * 4 + 3]};
@@ -55,7 +57,6 @@ int plo_keylines_from_segments(const float* segs, int n, int w, int h, const uin
     if (e[3] < 0) e[3] = 0;
     if (e[3] >= h) e[3] = (float)h - 1.0f;
     plo_keyline kl;
-    const float octaveScale = 1.0f;   // pow((float)1, 0)
     kl.startPointX = e[0] * octaveScale; kl.startPointY = e[1] * octaveScale;
     kl.endPointX = e[2] * octaveScale;   kl.endPointY = e[3] * octaveScale;
     kl.sPointInOctaveX = e[0]; kl.sPointInOctaveY = e[1];
@@ -65,8 +66,8 @@ int plo_keylines_from_segments(const float* segs, int n, int w, int h, const uin
     const int x1 = cv_round_f(e[0]), y1 = cv_round_f(e[1]), x2 = cv_round_f(e[2]), y2 = cv_round_f(e[3]);
     kl.numOfPixels = std::max(std::abs(x2 - x1), std::abs(y2 - y1)) + 1;
     kl.angle = (float)std::atan2((double)(kl.endPointY - kl.startPointY), (double)(kl.endPointX - kl.startPointX));
-    kl.class_id = k;
-    kl.octave = 0;
+    kl.class_id = class0 + k;
+    kl.octave = octave;
     kl.size = (kl.endPointX - kl.startPointX) * (kl.endPointY - kl.startPointY);
     kl.response = kl.lineLength / (float)std::max(w, h);
     kl.pt_x = (kl.endPointX + kl.startPointX) / 2;
@@ -82,15 +83,33 @@ int plo_keylines_from_segments(const float* segs, int n, int w, int h, const uin
   return m;
 }
 
+// LSDDetector::detectImpl, single octave (scale int -> 1, numOctaves 1): Vec4f -> KeyLine + mask filter.
+int plo_keylines_from_segments(const float* segs, int n, int w, int h, const uint8_t* mask, size_t mstep,
+                               plo_keyline* out) {
+  return keylines_of_octave(segs, n, w, h, 0, 1.0f, 0, mask, mstep, out);
+}
+
+struct OctaveGrad {   // dxImg_vector[o] / dyImg_vector[o] and images_sizes[o] of BinaryDescriptor::computeSobel
+  std::vector<int16_t> dx, dy;
+  int w, h;
+};
+static void lbd_compute_octaves(const std::vector<OctaveGrad>& oct, const plo_keyline* kls, int n, uint8_t* desc32, float* desc_float72);
+
 // BinaryDescriptor::compute on one octave: GaussianBlur 5x5 sigma 1 -> Sobel dx/dy (int16) -> computeLBD ->
 // 32-byte binary conversion.  desc_float72 (optional) receives the 72-float LBD.
 void plo_lbd_compute(const uint8_t* img, int w, int h, size_t step, const plo_keyline* kls, int n, uint8_t* desc32,
                      float* desc_float72) {
   std::vector<uint8_t> blur((size_t)w * h);
   plo_gaussian_blur_u8(img, w, h, step, blur.data(), w, 5, 1.0);
-  std::vector<int16_t> dxImg((size_t)w * h), dyImg((size_t)w * h);
-  plo_sobel3_s16(blur.data(), w, h, w, dxImg.data(), dyImg.data());
+  std::vector<OctaveGrad> oct(1);
+  oct[0].w = w; oct[0].h = h;
+  oct[0].dx.resize((size_t)w * h); oct[0].dy.resize((size_t)w * h);
+  plo_sobel3_s16(blur.data(), w, h, w, oct[0].dx.data(), oct[0].dy.data());
+  lbd_compute_octaves(oct, kls, n, desc32, desc_float72);
+}
 
+// computeLBD (binary_descriptor_custom.cpp:1026-1372): every line on the gradient images of ITS octave (:1080-1104)
+static void lbd_compute_octaves(const std::vector<OctaveGrad>& oct, const plo_keyline* kls, int n, uint8_t* desc32, float* desc_float72) {
   // constructor weights (note the integer divisions in the originals)
   double gaussCoefL[WIDTH_OF_BAND * 3], gaussCoefG[NUM_OF_BANDS * WIDTH_OF_BAND];
   {
@@ -107,12 +126,14 @@ void plo_lbd_compute(const uint8_t* img, int w, int h, size_t step, const plo_ke
   const short heightOfLSP = (short)(WIDTH_OF_BAND * NUM_OF_BANDS);
   const short descriptor_size = NUM_OF_BANDS * 8;
   const short halfHeight = (heightOfLSP - 1) / 2;
-  const short realWidth = (short)w;
-  const short imageWidth = realWidth - 1;
-  const short imageHeight = (short)(h - 1);
 
   for (int li = 0; li < n; li++) {
     const plo_keyline& L = kls[li];
+    const OctaveGrad& G = oct[(size_t)L.octave];
+    const int16_t *dxImg = G.dx.data(), *dyImg = G.dy.data();
+    const short realWidth = (short)G.w;
+    const short imageWidth = realWidth - 1;
+    const short imageHeight = (short)(G.h - 1);
     float pgdLBandSum[NUM_OF_BANDS] = {0}, ngdLBandSum[NUM_OF_BANDS] = {0}, pgdL2BandSum[NUM_OF_BANDS] = {0},
           ngdL2BandSum[NUM_OF_BANDS] = {0}, pgdOBandSum[NUM_OF_BANDS] = {0}, ngdOBandSum[NUM_OF_BANDS] = {0},
           pgdO2BandSum[NUM_OF_BANDS] = {0}, ngdO2BandSum[NUM_OF_BANDS] = {0};
@@ -238,12 +259,49 @@ int plo_line_extract(const uint8_t* img, int rows, int cols, size_t step, const 
 // ... with the refine level of the LineSegmentDetector behind LSDDetector (0 = LSD_REFINE_STD, 1 = LSD_REFINE_ADV; lsd.cc)
 int plo_line_extract_ex(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask, unsigned nLSDFeature,
                         double min_line_length, plo_keyline* keylines, uint8_t* desc, double* linefn, int cap, int refine) {
+  return plo_line_extract_oct(img, rows, cols, step, mask, 1, 1.2f, nLSDFeature, min_line_length, keylines, desc, linefn, cap, refine);
+}
+
+// ... and with LINEextractor's numOctaves / scale (LineExtractor.cpp:5-24, 39-40).  What the reference does with them:
+//   * lsd->detect(image, keylines, scale, numOctaves, mask) takes `int scale`: the float truncates (1.2 -> 1, 2.0 -> 2);
+//   * computeGaussianPyramid pyrDown()s to Size(cols / scale, rows / scale) per octave, and cv::pyrDown asserts
+//     |2 dst - src| <= 2 per axis: with more than one octave only (int)scale == 2 gets past it (-3 here: the reference throws);
+//   * BinaryDescriptor::computeImpl then sizes its per-line vectors by the highest octave and erases the unused slots while it
+//     iterates over them (binary_descriptor_custom.cpp:617-626): with three or more octaves a slot is skipped, a default-constructed
+//     line is described and the map lookup behind it runs off the end -- undefined behaviour (-4 here).
+// So the one multi-octave configuration with defined behaviour is numOctaves == 2 with scale in [2, 3): octave 1 is pyrDown of the
+// image (detection) resp. of the 5x5-blurred image (description), half size, octaveScale 2.
+int plo_line_extract_oct(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask, int numOctaves, float scale,
+                         unsigned nLSDFeature, double min_line_length, plo_keyline* keylines, uint8_t* desc, double* linefn, int cap,
+                         int refine) {
   if (!img || rows <= 0 || cols <= 0) return 0;
-  std::vector<float> segs((size_t)4 * 20000);
-  int ns = plo_lsd_detect_ex(img, cols, rows, step, segs.data(), 20000, refine);
-  if (ns > 20000) ns = 20000;
-  std::vector<plo_keyline> kls(std::max(ns, 1));
-  int n = plo_keylines_from_segments(segs.data(), ns, cols, rows, mask, (size_t)cols, kls.data());
+  if (numOctaves < 1) return -3;
+  if (numOctaves > 2) return -4;
+  const int iscale = (int)scale;
+  std::vector<std::vector<uint8_t>> pyr((size_t)numOctaves);
+  std::vector<int> pw((size_t)numOctaves), ph((size_t)numOctaves);
+  pw[0] = cols; ph[0] = rows;
+  pyr[0].resize((size_t)rows * cols);
+  for (int y = 0; y < rows; y++) memcpy(&pyr[0][(size_t)y * cols], img + (size_t)y * step, (size_t)cols);
+  for (int o = 1; o < numOctaves; o++) {
+    if (iscale <= 0) return -3;
+    pw[o] = pw[o - 1] / iscale; ph[o] = ph[o - 1] / iscale;
+    pyr[o].resize((size_t)std::max(pw[o], 0) * std::max(ph[o], 0));
+    if (plo_pyr_down_u8(pyr[o - 1].data(), pw[o - 1], ph[o - 1], (size_t)pw[o - 1], pyr[o].data(), pw[o], ph[o], (size_t)pw[o]) != 0) return -3;
+  }
+  std::vector<plo_keyline> kls;
+  int class0 = 0;
+  for (int o = 0; o < numOctaves; o++) {
+    std::vector<float> segs((size_t)4 * 20000);
+    int ns = plo_lsd_detect_ex(pyr[o].data(), pw[o], ph[o], (size_t)pw[o], segs.data(), 20000, refine);
+    if (ns > 20000) ns = 20000;
+    std::vector<plo_keyline> ko((size_t)std::max(ns, 1));
+    const float octaveScale = (float)std::pow((float)iscale, o);
+    const int m = keylines_of_octave(segs.data(), ns, pw[o], ph[o], o, octaveScale, class0, mask, (size_t)cols, ko.data());
+    kls.insert(kls.end(), ko.begin(), ko.begin() + m);
+    class0 += ns;   // (class_counter runs over every detected segment, masked or not)
+  }
+  int n = (int)kls.size();
   kls.resize(n);
   // sort(_keylines, sort_lines_by_response()) -- PINNED stable
   std::stable_sort(kls.begin(), kls.end(), [](const plo_keyline& a, const plo_keyline& b) { return a.response > b.response; });
@@ -263,7 +321,27 @@ int plo_line_extract_ex(const uint8_t* img, int rows, int cols, size_t step, con
   if (keep > cap) return -2;
   kls.resize(keep);
   for (int i = 0; i < keep; i++) kls[i].class_id = i;
-  plo_lbd_compute(img, cols, rows, step, kls.data(), keep, desc, nullptr);
+  {   // BinaryDescriptor::compute -> computeSobel(image, highest octave + 1): GaussianBlur 5x5 sigma 1, pyrDown by reductionRatio = 2
+      // per further octave (binary_descriptor_custom.cpp:350-398), Sobel of every level
+    int top = 0;
+    for (int i = 0; i < keep; i++) top = std::max(top, (int)kls[i].octave);
+    std::vector<OctaveGrad> oct((size_t)top + 1);
+    std::vector<uint8_t> cur((size_t)rows * cols);
+    plo_gaussian_blur_u8(img, cols, rows, step, cur.data(), cols, 5, 1.0);
+    int cw = cols, ch = rows;
+    for (int o = 0; o <= top; o++) {
+      if (o > 0) {
+        const int nw = cw / 2, nh = ch / 2;
+        std::vector<uint8_t> nxt((size_t)nw * nh);
+        if (plo_pyr_down_u8(cur.data(), cw, ch, (size_t)cw, nxt.data(), nw, nh, (size_t)nw) != 0) return -3;
+        cur.swap(nxt); cw = nw; ch = nh;
+      }
+      oct[o].w = cw; oct[o].h = ch;
+      oct[o].dx.resize((size_t)cw * ch); oct[o].dy.resize((size_t)cw * ch);
+      plo_sobel3_s16(cur.data(), cw, ch, (size_t)cw, oct[o].dx.data(), oct[o].dy.data());
+    }
+    lbd_compute_octaves(oct, kls.data(), keep, desc, nullptr);
+  }
   for (int i = 0; i < keep; i++) {
     const plo_keyline& k = kls[i];
     // sp x ep with homogeneous 1.0, normalised by sqrt(l0^2 + l1^2) (Eigen Vector3d)

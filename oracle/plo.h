@@ -82,6 +82,7 @@ int   plo_fast_score(const uint8_t* center, size_t step, int threshold);      /*
 int   plo_fast9_16(const uint8_t* img, int w, int h, size_t step, int threshold, int nonmax,
                    plo_keypoint* out, int cap);                               /* cv::FAST TYPE_9_16; returns count */
 void  plo_sobel3_s16(const uint8_t* src, int w, int h, size_t sstep, int16_t* dx, int16_t* dy); /* cv::Sobel ksize 3 */
+int   plo_pyr_down_u8(const uint8_t* src, int w, int h, size_t sstep, uint8_t* dst, int dw, int dh, size_t dstep); /* cv::pyrDown; -1: OpenCV's size assertion */
 void  plo_undistort_maps(const float K[4], const float D[5], int w, int h, float* mapx, float* mapy);
 void  plo_remap_linear_u8(const uint8_t* src, int w, int h, size_t sstep, const float* mapx, const float* mapy,
                           uint8_t* dst, size_t dstep);                        /* cv::remap INTER_LINEAR, BORDER_CONSTANT 0 */
@@ -148,6 +149,12 @@ double plo_frontend_batch(const uint8_t* frames, int n, int rows, int cols, int 
                           const float* mapx, const float* mapy, const uint8_t* node_desc, const int32_t* child_start,
                           const int32_t* child_count, const int32_t* word_id, const float* weight, const double* word_weight, int L,
                           int nthreads, int per_thread, unsigned long long* checksum);
+
+/* LINEextractor(numOctaves, scale, ...): -3 = the reference throws (cv::pyrDown's size assertion: more than one octave needs
+ * (int)scale == 2), -4 = undefined behaviour in the reference (three or more octaves); oracle/line.cc */
+int  plo_line_extract_oct(const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask, int num_octaves, float scale,
+                          unsigned n_lsd_feature, double min_line_length, plo_keyline* keylines, uint8_t* desc, double* linefn, int cap,
+                          int refine);
 
 /* ---- Windowed (grid) searches of the tracking front end (reference src/Frame.cc, ORBmatcher.cc, LSDmatcher.cpp;
  *      oracle/frame_search.cc).  gp = {mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv};

@@ -71,6 +71,8 @@ _SIGS = {
     "plo_lbd_compute": ([_V, _I, _I, _Z, _V, _I, _V, _V], None),
     "plo_line_extract": ([_V, _I, _I, _Z, _V, _U, _D, _V, _V, _V, _I], _I),
     "plo_line_extract_ex": ([_V, _I, _I, _Z, _V, _U, _D, _V, _V, _V, _I, _I], _I),
+    "plo_line_extract_oct": ([_V, _I, _I, _Z, _V, _I, _F, _U, _D, _V, _V, _V, _I, _I], _I),
+    "plo_pyr_down_u8": ([_V, _I, _I, _Z, _V, _I, _I, _Z], _I),
 }
 
 
@@ -209,8 +211,12 @@ def lsd_stage_taps(img):
     return scaled, ang, mod, order
 
 
-def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None, refine=0):
-    """LINEextractor::operator() -> (keylines[KL_DTYPE], desc[n,32], linefn[n,3])."""
+class ReferenceThrows(RuntimeError):
+    """The reference raises (cv::pyrDown's size assertion) or runs into undefined behaviour for this configuration."""
+
+
+def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None, refine=0, num_octaves=1, scale=1.2):
+    """LINEextractor(num_octaves, scale, ...)::operator() -> (keylines[KL_DTYPE], desc[n,32], linefn[n,3])."""
     img = np.ascontiguousarray(img, np.uint8)
     cap = n_lsd_feature + 1
     kl = np.zeros(cap, KL_DTYPE)
@@ -220,8 +226,11 @@ def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None, refine=
         mask = np.ascontiguousarray(mask, np.uint8)
         if mask.shape != img.shape:
             raise ValueError("Mask error while detecting lines")
-    n = lib().plo_line_extract_ex(_p(img), img.shape[0], img.shape[1], img.shape[1], _p(mask), n_lsd_feature,
-                                  float(min_line_length), _p(kl), _p(desc), _p(fn), cap, int(refine))
+    n = lib().plo_line_extract_oct(_p(img), img.shape[0], img.shape[1], img.shape[1], _p(mask), int(num_octaves), float(scale),
+                                   n_lsd_feature, float(min_line_length), _p(kl), _p(desc), _p(fn), cap, int(refine))
+    if n in (-3, -4):
+        raise ReferenceThrows("LINEextractor(numOctaves %d, scale %g): %s" % (
+            num_octaves, scale, "cv::pyrDown's size assertion fails" if n == -3 else "undefined behaviour in BinaryDescriptor::computeImpl"))
     if n < 0:
         raise RuntimeError("oracle line capacity")
     return kl[:n].copy(), desc[:n].copy(), fn[:n].copy()

@@ -39,12 +39,12 @@ for f in "$REF/src/ORBmatcher.cc" "$REF/src/LSDmatcher.cpp"; do
 done
 wait
 if [ -f "$ROOT/pl-slam_amd/libplslam_hip.so" ]; then
-  g++ -shared -pthread -o "$OUT/libadaptor_hip.so" "$OBJ"/*.o $PLO_OBJS -L "$ROOT/pl-slam_amd" -lplslam_hip \
+  g++ -shared -pthread -o "$OUT/libadaptor_hip.so" "$OBJ"/*.o $PLO_OBJS -L "$ROOT/pl-slam_amd" -lplslam_hip -lquadmath \
     -Wl,-rpath,'$ORIGIN/../../pl-slam_amd' -Wl,-rpath,/opt/rocm/lib
   echo "built $OUT/libadaptor_hip.so"
 fi
 EMU="$ROOT/tests/hipemu/_build"
 if [ -f "$EMU/libplslam_emu.so" ]; then
-  g++ -shared -pthread -o "$OUT/libadaptor_emu.so" "$OBJ"/*.o $PLO_OBJS -L "$EMU" -lplslam_emu -Wl,-rpath,'$ORIGIN/../../tests/hipemu/_build'
+  g++ -shared -pthread -o "$OUT/libadaptor_emu.so" "$OBJ"/*.o $PLO_OBJS -L "$EMU" -lplslam_emu -lquadmath -Wl,-rpath,'$ORIGIN/../../tests/hipemu/_build'
   echo "built $OUT/libadaptor_emu.so"
 fi

@@ -23,7 +23,8 @@ void* ref_line_create(int num_octaves, float scale, unsigned n_features, double 
 }
 void ref_line_destroy(void* h) { delete static_cast<ORB_SLAM2::LINEextractor*>(h); }
 
-// returns the number of keylines (or -1 if cap is too small)
+// returns the number of keylines (-1 if cap is too small, -3 if the reference threw -- cv::pyrDown's size assertion with more than
+// one octave and (int)scale != 2)
 int ref_line_extract(void* h, const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask, size_t mstep,
                      plo_keyline* kls, uint8_t* desc, double* linefn, int cap) {
   ORB_SLAM2::LINEextractor* ex = static_cast<ORB_SLAM2::LINEextractor*>(h);
@@ -31,7 +32,11 @@ int ref_line_extract(void* h, const uint8_t* img, int rows, int cols, size_t ste
   if (mask) m = cv::Mat(rows, cols, CV_8UC1, const_cast<uint8_t*>(mask), mstep);
   std::vector<cv::line_descriptor::KeyLine> k;
   std::vector<Eigen::Vector3d> fn;
-  (*ex)(image, m, k, d, fn);
+  try {
+    (*ex)(image, m, k, d, fn);
+  } catch (const std::exception&) {
+    return -3;
+  }
   const int n = (int)k.size();
   if (n > cap) return -1;
   for (int i = 0; i < n; i++) {

@@ -429,7 +429,6 @@ inline void undistortPoints(const Mat& src, Mat& dst, const Mat& K, const Mat& D
 }
 inline bool solve(const Mat&, const Mat&, Mat&, int = 0) { stub_unreachable("cv::solve"); }
 inline void cvtColor(const Mat&, Mat&, int) { stub_unreachable("cv::cvtColor"); }
-inline void pyrDown(const Mat&, Mat&, Size = Size()) { stub_unreachable("cv::pyrDown (numOctaves is 1 on this path)"); }
 inline double threshold(const Mat&, Mat&, double, double, int) { stub_unreachable("cv::threshold"); }
 inline Mat abs(const Mat&) { stub_unreachable("cv::abs(Mat)"); }
 inline void add(const Mat&, const Mat&, Mat&) { stub_unreachable("cv::add"); }
@@ -470,6 +469,15 @@ inline void GaussianBlur(const Mat& src, Mat& dst, Size k, double sx, double = 0
   plo_gaussian_blur_u8(src.data, src.cols, src.rows, src.step, tmp.data, tmp.step, k.width, sx);
   dst.create(src.rows, src.cols, src.type());
   for (int r = 0; r < src.rows; r++) std::memcpy(dst.data + (size_t)r * dst.step, tmp.data + (size_t)r * tmp.step, src.cols);
+}
+// cv::pyrDown(src8u, dst, dsize): the oracle's restatement; OpenCV's size assertion (|2 dsize - ssize| <= 2) becomes the exception
+// it throws.  dst may be src (LSDDetector_custom.cpp:69): the result gets a buffer of its own, as Mat::create does for a new size.
+inline void pyrDown(const Mat& src, Mat& dst, Size dsize = Size()) {
+  if (dsize.width == 0 && dsize.height == 0) dsize = Size((src.cols + 1) / 2, (src.rows + 1) / 2);
+  Mat tmp(std::max(dsize.height, 1), std::max(dsize.width, 1), src.type());
+  if (plo_pyr_down_u8(src.data, src.cols, src.rows, src.step, tmp.data, dsize.width, dsize.height, tmp.step) != 0)
+    throw std::runtime_error("cv::pyrDown: (-215) std::abs(dsize.width*2 - ssize.width) <= 2 && std::abs(dsize.height*2 - ssize.height) <= 2");
+  dst = tmp;
 }
 inline void FAST(const Mat& img, std::vector<KeyPoint>& kps, int threshold, bool nonmax) {
   std::vector<plo_keypoint> out((size_t)img.rows * img.cols + 1);

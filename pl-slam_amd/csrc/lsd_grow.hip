@@ -970,13 +970,14 @@ __device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const
 }
 
 // flsd(): one wavefront per frame, seeds in pseudo-order, sequential semantics.
-// VGPR budget: 64 registers = 8 wavefronts per SIMD.  The kernel needs 74 (6 per SIMD); capped at 64 the compiler spills six
-// values that live across region_grow() calls (a few scratch accesses per call, none inside the step loop), and the two extra
-// wave slots -- for more frames or for the dense kernels of the other sub-batches -- are worth 3 - 4 % on the whole front end
-// (profiles/r02_waves_per_simd.txt; at the start of round 2, with 30 % more instructions everywhere else, they were worth nothing).
-// -DPLH_GROW_WAVES=0 builds the spill-free 74-register version.
+// VGPR budget.  Rounds 2-3 built this kernel for 64 registers = 8 wavefronts per SIMD (it needed 74; six values spilled around
+// region_grow() calls; the two extra wave slots were worth 3 - 4 % on the whole front end, profiles/r02_waves_per_simd.txt).  With
+// round 4's density screen inlined between the region_grow() calls the 64-register build spills 144 bytes, part of it on paths
+// every region takes, and the 72-register build (7 wavefronts per SIMD: 7168 frames resident, more than the bench's 6144) is
+// 3.7 % faster on the whole front end, 7 % on the kernel alone (profiles/r04_grow_waves_8_vs_7.txt).
+// -DPLH_GROW_WAVES=0 builds without a cap.
 #ifndef PLH_GROW_WAVES
-#define PLH_GROW_WAVES 8
+#define PLH_GROW_WAVES 7
 #endif
 #if PLH_GROW_WAVES > 0
 #define PLH_GROW_ATTR __attribute__((amdgpu_waves_per_eu(PLH_GROW_WAVES)))

@@ -306,14 +306,17 @@ def line_mask(S, seed, rows, cols):
     return m
 
 
-def reference_lines(R, P, img, nf, min_len, mask=None):
-    h = R.ref_line_create(1, 1.2, nf, min_len)
+def reference_lines(R, P, img, nf, min_len, mask=None, num_octaves=1, scale=1.2):
+    """The reference's LINEextractor(num_octaves, scale, nf, min_len)::operator(); None when it throws (cv::pyrDown's assertion)."""
+    h = R.ref_line_create(num_octaves, scale, nf, min_len)
     try:
         cap = nf + 8
         kl, desc, fn = np.zeros(cap, P.KL_DTYPE), np.zeros((cap, 32), np.uint8), np.zeros((cap, 3))
         img = np.ascontiguousarray(img)
         mp = p(mask) if mask is not None else None
         n = R.ref_line_extract(h, p(img), img.shape[0], img.shape[1], img.shape[1], mp, img.shape[1], p(kl), p(desc), p(fn), cap)
+        if n == -3:
+            return None
         assert n >= 0
     finally:
         R.ref_line_destroy(h)

@@ -2,7 +2,10 @@
 // (pi / 180) for every float f in [0, 360] and theta + pi -- against the host's evaluation of the same source, which
 // tools/sincos_cr_check.c has proven equal to the correctly rounded value on all of them (profiles/r04_sincos_cr.txt).  Host and device
 // results are compared through per-block 64-bit sums of the result bits (s + 3 c), 1 M arguments per block: any differing value shows.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o sincos_cr_dev tools/ubench/sincos_cr_dev.hip && ./sincos_cr_dev
+// The host half is compiled by g++ (tools/ubench/sincos_cr_host.cc): hipcc's host pass cannot read the header's __device__ tables.
+//   g++ -O2 -march=x86-64-v3 -ffp-contract=off -std=c++17 -c -o /tmp/sincos_cr_host.o tools/ubench/sincos_cr_host.cc
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -c -o /tmp/sincos_cr_dev.o tools/ubench/sincos_cr_dev.hip
+//   hipcc -o sincos_cr_dev /tmp/sincos_cr_dev.o /tmp/sincos_cr_host.o -lpthread
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -18,7 +21,9 @@ static constexpr double kDegToRads = kPI / 180;
 static constexpr uint32_t kLast = 0x43B40000u;   // 360.0f
 static constexpr uint32_t kBlock = 1u << 20;
 
-__host__ __device__ inline unsigned long long one(uint32_t bits) {
+extern "C" void sincos_cr_host_sums(unsigned long long* out, uint32_t nblk, uint32_t block, uint32_t last);
+
+__device__ inline unsigned long long one(uint32_t bits) {
   float f;
   memcpy(&f, &bits, 4);
   const double t1 = (double)f * kDegToRads;
@@ -50,20 +55,7 @@ int main() {
   if (hipMalloc((void**)&d, nblk * 8) != hipSuccess || hipMemset(d, 0, nblk * 8) != hipSuccess) return 2;
   hipLaunchKernelGGL(k_sums, dim3(nblk), dim3(256), 0, nullptr, d);
   std::vector<unsigned long long> dev(nblk), host(nblk, 0);
-  const unsigned nt = std::max(1u, std::thread::hardware_concurrency());
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nt; t++)
-    th.emplace_back([&, t] {
-      for (uint32_t b = t; b < nblk; b += nt) {
-        unsigned long long acc = 0;
-        for (uint32_t i = 0; i < kBlock; i++) {
-          const uint32_t bits = b * kBlock + i;
-          if (bits <= kLast) acc += one(bits);
-        }
-        host[b] = acc;
-      }
-    });
-  for (auto& x : th) x.join();
+  sincos_cr_host_sums(host.data(), nblk, kBlock, kLast);
   if (hipMemcpy(dev.data(), d, nblk * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   unsigned bad = 0;
   for (uint32_t b = 0; b < nblk; b++) bad += dev[b] != host[b];
