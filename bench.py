@@ -249,7 +249,7 @@ class Workload:
     """One resident batch + the pipelined front end over it."""
 
     def __init__(self, P, S, V, PL, torch, dev, rank, batch, nsplit, rows, cols, nfeatures, nlevels, nlines, unique, voc, serial=False,
-                 shard=None, refine=0, screen=True, real=None):
+                 shard=None, refine=0, screen=True, real=None, grow_waves=-1):
         self.P, self.torch, self.dev = P, torch, dev
         self.B, self.rows, self.cols, self.nfeatures, self.nlevels, self.nlines = batch, rows, cols, nfeatures, nlevels, nlines
         self.tum = (rows, cols) == (480, 640)
@@ -269,6 +269,9 @@ class Workload:
         if not screen:        # A/B switch: the exact rectangle behind every density decision (rounds 1-3)
             for part in self.fe.parts:
                 part.line.set_screen(0)
+        if grow_waves >= 0:
+            for part in self.fe.parts:
+                part.line.set_grow_waves(grow_waves)
         self.fe.overlap = not serial
         self.serial = serial
         self.nsplit, self.Bp = nsplit, self.fe.Bp
@@ -396,6 +399,8 @@ def main():
                     help="cv::LineSegmentDetector's refine level of the headline: LSD_REFINE_STD, LSD_REFINE_ADV, or the library's "
                          "build-time default (PLH_LSD_REFINE_DEFAULT; the other level is reported under `secondary`)")
     ap.add_argument("--no-screen", action="store_true", help="A/B: region growing without the density screen (same records)")
+    ap.add_argument("--grow-waves", type=int, default=-1, help="wavefronts per frame of LSD's region growing (-1: the front end's choice "
+                                                                "by resident frames; 0: one; 2..16); used by the PMC scripts on small batches")
     ap.add_argument("--frames", default=None, help="real frames instead of synthetic ones: a raw / PGM file or a directory of them "
                                                    "(rows x cols 8-bit planes; pl-slam_amd/frames_io.py), cycled to fill the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -457,7 +462,7 @@ def main():
             args.nfeatures = 2000          # KITTI00-02.yaml
     W = Workload(P, S, V, PL, torch, dev, rank, args.batch, args.nsplit, args.rows, args.cols, args.nfeatures, args.nlevels, args.nlines,
                  args.unique, voc, serial=args.serial, shard=(rank, world, args.total) if strong else None, refine=refine,
-                 screen=not args.no_screen, real=real)
+                 screen=not args.no_screen, real=real, grow_waves=args.grow_waves)
     fe, B, Bp, rows, cols = W.fe, W.B, W.Bp, W.rows, W.cols
 
     comm = comm_stream = None

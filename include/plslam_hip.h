@@ -599,7 +599,9 @@ PLH_API plh_status plh_gather_records(plh_comm* c, const plh_gather_block* block
 typedef struct plh_line plh_line;
 
 typedef struct plh_line_params {   /* LINEextractor(numOctaves, scale, nLSDFeature, min_line_length) */
-  int32_t num_octaves;             /* only 1 is supported (the reference's int scale truncates 1.2 -> 1) */
+  int32_t num_octaves;             /* 1, or 2 with scale in [2, 3): what the reference itself can run -- LSDDetector::detect takes an
+                                      int scale (1.2 -> 1), cv::pyrDown then asserts unless (int)scale == 2, and three or more
+                                      octaves are undefined behaviour in BinaryDescriptor::computeImpl (refused: PLH_ERR_INVALID) */
   float scale;
   uint32_t n_lsd_feature;
   double min_line_length;

@@ -22,6 +22,8 @@ size_t lsd_order_work_u32();
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s);
 plh_status lsd_grow_request_lds();
 void launch_lsd_rects(const LineDeviceArgs& a, hipStream_t s);
+void launch_pyr_down5(const uint8_t* src, long long sStride, int sw, int sh, uint8_t* dst, long long dStride, int dw, int dh, int batch,
+                      hipStream_t s);
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s);
 void launch_sobel(const LineDeviceArgs& a, hipStream_t s);
 void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, const float* coef, uint8_t* desc, hipStream_t s);
@@ -62,6 +64,8 @@ void angle_table_release(int device) {
 
 struct plh_line {
   plh_line_params p;
+  plh_line* oct1 = nullptr;      // LINEextractor(numOctaves = 2): the plan of the second octave (half size, one octave), owned
+  uint8_t* dOctImg = nullptr;    // ... and its detection image, pyrDown of the (undistorted) frame
   int device, rows, cols, maxBatch;
   LineDeviceArgs a;   // template (pointers filled at create)
   int taps075[7], taps1[7];
@@ -171,7 +175,11 @@ extern "C" {
 plh_status plh_line_destroy(plh_line* h) {
   if (!h) return PLH_OK;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->dAdv, h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark, h->dMwHint,
+  if (h->oct1) {
+    h->oct1->doneEv = nullptr;   // (the parent's event, shared)
+    plh_line_destroy(h->oct1);
+  }
+  void* ptrs[] = {h->dOctImg, h->dAdv, h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark, h->dMwHint,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -189,8 +197,23 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
     set_error("plh_line_create: invalid argument");
     return PLH_ERR_INVALID;
   }
-  if (p->num_octaves != 1) {
-    set_error("plh_line_create: only numOctaves == 1 is supported (the reference's int scale truncates to 1)");
+  // LINEextractor(numOctaves, scale, ...): what the reference does with more than one octave (oracle/line.cc plo_line_extract_oct):
+  // lsd->detect() takes `int scale` (1.2 -> 1, 2.0 -> 2) and pyrDown()s to Size(cols / scale, rows / scale), which cv::pyrDown
+  // accepts only for (int)scale == 2 (it throws otherwise); with three or more octaves BinaryDescriptor::computeImpl runs into
+  // undefined behaviour (it erases from the per-line vectors it iterates over).  The one defined multi-octave configuration --
+  // two octaves, scale in [2, 3) -- is supported; the others are refused here, where the reference throws or is undefined.
+  if (p->num_octaves < 1 || p->num_octaves > 2) {
+    set_error("plh_line_create: numOctaves %d: the reference's behaviour is undefined for three or more octaves "
+              "(binary_descriptor_custom.cpp:617-626); 1 and 2 are supported", p->num_octaves);
+    return PLH_ERR_INVALID;
+  }
+  if (p->num_octaves == 2 && (int)p->scale != 2) {
+    set_error("plh_line_create: numOctaves 2 with scale %g: the reference throws (cv::pyrDown asserts |2 dst - src| <= 2: LSDDetector::detect "
+              "takes an int scale, only (int)scale == 2 passes)", (double)p->scale);
+    return PLH_ERR_INVALID;
+  }
+  if (p->num_octaves == 2 && (rows < 32 || cols < 32)) {
+    set_error("plh_line_create: two octaves need an image of at least 32 x 32");
     return PLH_ERR_INVALID;
   }
   int ndev = 0;
@@ -322,6 +345,22 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
     return PLH_ERR_ALLOC;
   }
   a.angleTab = h->a.angleTab;
+  if (p->num_octaves == 2) {   // the second octave: a one-octave plan of its own for the half-size image
+    plh_line_params p1 = *p;
+    p1.num_octaves = 1;
+    const plh_status st1 = plh_line_create(&p1, device, rows / 2, cols / 2, max_batch, &h->oct1);
+    if (st1 != PLH_OK) { plh_line_destroy(h); return st1; }
+    if (hipMalloc((void**)&h->dOctImg, B * (size_t)h->oct1->a.fullStride) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("plh_line_create: cannot allocate the second octave's images");
+      plh_line_destroy(h);
+      return PLH_ERR_ALLOC;
+    }
+    const LineDeviceArgs& a1 = h->oct1->a;
+    a.segs1 = a1.segs; a.nSegs1 = a1.nSegs; a.arena1Stride = a1.arenaStride; a.segCap1 = a1.segCap; a.w1 = a1.w; a.h1 = a1.h;
+    a.octScale1 = 2.0f;   // pow((float)(int)scale, 1)
+    a.dxdy1 = a1.dxdy; a.full1Stride = a1.fullStride;
+  }
   a.tmpA = h->dTmpA; a.scaled = h->dScaled; a.pix = h->dArena + offPix; a.ordered = h->dArena + offOrd; a.reg = h->dArena + offReg; a.regq = h->dArena + offRegq; a.orderWork = h->dArena + offWork; a.park = h->dArena + offPark;
   a.qmax = h->dQmax; a.nOrdered = h->dNOrdered; a.segs = reinterpret_cast<float*>(h->dArena + offSegs); a.nSegs = h->dNSegs; a.dxdy = h->dDxdy;
   a.xtab = h->dXtab; a.ytab = h->dYtab; a.status = h->dStatus;
@@ -451,6 +490,55 @@ plh_status plh_line_set_grow_events(plh_line* h, void* wait_before, void* record
   return PLH_OK;
 }
 
+// What a launch sequence needs besides the plan: the multi-wavefront workspace for this batch size, the LSD_REFINE_ADV buffers.
+static plh_status line_prepare(plh_line* h, LineDeviceArgs& a, int batch) {
+  const int waves = mw_waves_for(h, batch);
+  if (waves > 0) {
+    const plh_status st = mw_reserve(h, a, batch, waves);
+    if (st != PLH_OK) return st;
+  }
+  if (a.refineAdv) {
+    const size_t recBytes = align_up<size_t>((size_t)h->maxBatch * a.segCap * 144, 256);
+    if (!h->dAdv && hipMalloc(&h->dAdv, recBytes + (size_t)h->maxBatch * a.scaledStride * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("plh_line_extract: cannot allocate the LSD_REFINE_ADV rectangle records (%d frames x %d)", h->maxBatch, a.segCap);
+      return PLH_ERR_ALLOC;
+    }
+    a.adv = reinterpret_cast<LsdAdvRec*>(h->dAdv);
+    a.advAng = reinterpret_cast<float*>(static_cast<uint8_t*>(h->dAdv) + recBytes);
+  } else {
+    a.adv = nullptr; a.advAng = nullptr;
+  }
+  return PLH_OK;
+}
+
+// cv::LineSegmentDetector::detect on one octave's images: 7x7 sigma 0.75 blur -> 0.8x resize -> level-line field -> seed order ->
+// region growing -> the kept regions' rectangles (and LSD_REFINE_ADV's rect_improve).  Leaves the segments in the plan's arena.
+// `top`: the caller's octave (profiling marks and the scheduler's events around region growing belong to it).
+static plh_status line_lsd_stages(plh_line* h, const LineDeviceArgs& a, const uint8_t* src, long long srcStride, int batch, hipStream_t s,
+                                  bool top) {
+  if (top) line_prof_mark(h, 0, s);
+  launch_blur7(src, srcStride, a.w, h->dTmpA, a.fullStride, a.w, a.w, a.h, batch, h->taps075, s);
+  PLH_LAUNCH_CHECK();
+  launch_resize(h->dTmpA, a.fullStride, a.w, a.w, a.h, h->dScaled, a.scaledStride, a.spitch, a.sw, a.sh, batch, h->dXtab, h->dYtab,
+                h->rszTP, h->rszTR, s);
+  PLH_LAUNCH_CHECK();
+  PLH_HIP(hipMemsetAsync(h->dQmax, 0, (size_t)batch * 4, s));
+  launch_lsd_grad(a, s);
+  PLH_LAUNCH_CHECK();
+  launch_lsd_order(a, s);
+  PLH_LAUNCH_CHECK();
+  if (top) { line_prof_mark(h, 0, s); line_prof_mark(h, 1, s); }
+  if (top && h->growGate) PLH_HIP(hipStreamWaitEvent(s, h->growGate, 0));
+  launch_lsd_grow(a, s);
+  PLH_LAUNCH_CHECK();
+  if (top && h->growDone) PLH_HIP(hipEventRecord(h->growDone, s));
+  if (top) line_prof_mark(h, 1, s);
+  launch_lsd_rects(a, s);   // one lane per region
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
 plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int batch, size_t frame_stride, const uint8_t* d_mask,
                                       plh_keyline* d_keylines, uint8_t* d_desc, double* d_linefn, int32_t* d_n, void* stream) {
   if (!h || !d_imgs || !d_keylines || !d_desc || !d_linefn || !d_n || batch <= 0 || batch > h->maxBatch ||
@@ -466,25 +554,8 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   a.mask = d_mask;
   const uint8_t* src = d_imgs;
   long long srcStride = (long long)frame_stride;
-  {
-    const int waves = mw_waves_for(h, batch);
-    if (waves > 0) {
-      const plh_status st = mw_reserve(h, a, batch, waves);
-      if (st != PLH_OK) return st;
-    }
-  }
-  if (a.refineAdv) {
-    const size_t recBytes = align_up<size_t>((size_t)h->maxBatch * a.segCap * 144, 256);
-    if (!h->dAdv && hipMalloc(&h->dAdv, recBytes + (size_t)h->maxBatch * a.scaledStride * 4) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("plh_line_extract: cannot allocate the LSD_REFINE_ADV rectangle records (%d frames x %d)", h->maxBatch, a.segCap);
-      return PLH_ERR_ALLOC;
-    }
-    a.adv = reinterpret_cast<LsdAdvRec*>(h->dAdv);
-    a.advAng = reinterpret_cast<float*>(static_cast<uint8_t*>(h->dAdv) + recBytes);
-  } else {
-    a.adv = nullptr; a.advAng = nullptr;
-  }
+  plh_status st = line_prepare(h, a, batch);
+  if (st != PLH_OK) return st;
   PLH_HIP(hipMemsetAsync(h->dStatus, 0, 4, s));   // capacity flags of this call only (plh_line_status)
   if (h->hasUndistort) {
     a.remap = h->dMap; a.undist = h->dUndist;
@@ -492,43 +563,46 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
     PLH_LAUNCH_CHECK();
     src = h->dUndist; srcStride = a.fullStride;
   }
-  // LSD: 7x7 sigma 0.75 blur -> 0.8x resize -> level-line field -> seed order -> region growing
-  line_prof_mark(h, 0, s);
-  launch_blur7(src, srcStride, a.w, h->dTmpA, a.fullStride, a.w, a.w, a.h, batch, h->taps075, s);
-  PLH_LAUNCH_CHECK();
-  launch_resize(h->dTmpA, a.fullStride, a.w, a.w, a.h, h->dScaled, a.scaledStride, a.spitch, a.sw, a.sh, batch, h->dXtab, h->dYtab,
-                h->rszTP, h->rszTR, s);
-  PLH_LAUNCH_CHECK();
-  PLH_HIP(hipMemsetAsync(h->dQmax, 0, (size_t)batch * 4, s));
-  launch_lsd_grad(a, s);
-  PLH_LAUNCH_CHECK();
-  launch_lsd_order(a, s);
-  PLH_LAUNCH_CHECK();
-  line_prof_mark(h, 0, s);
-  line_prof_mark(h, 1, s);
-  if (h->growGate) PLH_HIP(hipStreamWaitEvent(s, h->growGate, 0));
-  launch_lsd_grow(a, s);
-  PLH_LAUNCH_CHECK();
-  if (h->growDone) PLH_HIP(hipEventRecord(h->growDone, s));
-  line_prof_mark(h, 1, s);
+  st = line_lsd_stages(h, a, src, srcStride, batch, s, true);
+  if (st != PLH_OK) return st;
+  plh_line* h1 = h->oct1;
+  LineDeviceArgs a1;
+  if (h1) {   // second octave: pyrDown of the frame, the same LSD stages on its own plan (same refine level, wavefronts, flags word)
+    a1 = h1->a;
+    a1.batch = batch;
+    a1.refineAdv = a.refineAdv; a1.screen = a.screen;
+    a1.status = h->dStatus;
+    h1->growWaves = h->growWaves; h1->mwLag = h->mwLag; h1->mwDrainGap = h->mwDrainGap;
+    st = line_prepare(h1, a1, batch);
+    if (st != PLH_OK) return st;
+    launch_pyr_down5(src, srcStride, a.w, a.h, h->dOctImg, a1.fullStride, a1.w, a1.h, batch, s);
+    PLH_LAUNCH_CHECK();
+    st = line_lsd_stages(h1, a1, h->dOctImg, a1.fullStride, batch, s, false);
+    if (st != PLH_OK) return st;
+  }
   line_prof_mark(h, 2, s);
-  launch_lsd_rects(a, s);   // the kept regions' rectangles (and LSD_REFINE_ADV's rect_improve), one lane per region
-  PLH_LAUNCH_CHECK();
   launch_keylines(a, d_keylines, d_linefn, d_n, s);
   PLH_LAUNCH_CHECK();
   line_prof_mark(h, 2, s);
   line_prof_mark(h, 3, s);
-  // LBD: 5x5 sigma 1 blur -> Sobel -> band descriptor
+  // LBD: 5x5 sigma 1 blur -> Sobel -> band descriptor (per further octave: pyrDown of the blurred image, Sobel)
   launch_blur7(src, srcStride, a.w, h->dTmpA, a.fullStride, a.w, a.w, a.h, batch, h->taps1, s);
   PLH_LAUNCH_CHECK();
   launch_sobel(a, s);
   PLH_LAUNCH_CHECK();
+  if (h1) {
+    launch_pyr_down5(h->dTmpA, a.fullStride, a.w, a.h, h1->dTmpA, a1.fullStride, a1.w, a1.h, batch, s);
+    PLH_LAUNCH_CHECK();
+    launch_sobel(a1, s);
+    PLH_LAUNCH_CHECK();
+  }
   launch_lbd(a, d_keylines, d_n, h->dCoef, d_desc, s);
   PLH_LAUNCH_CHECK();
   line_prof_mark(h, 3, s);
   if (!h->doneEv) PLH_HIP(hipEventCreateWithFlags(&h->doneEv, hipEventDisableTiming));
   PLH_HIP(hipEventRecord(h->doneEv, s));
   h->doneValid = true;
+  if (h1) { h1->doneEv = h->doneEv; h1->doneValid = true; }   // (a workspace re-allocation of the second octave waits on it too)
   return PLH_OK;
 }
 

@@ -319,6 +319,34 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   if (threadIdx.x == 0 && threadIdx.y == 0 && s_max > 0) atomicMax(&a.qmax[b], s_max);
 }
 
+// cv::pyrDown(8U): 5 x 5 kernel [1 4 6 4 1] x [1 4 6 4 1] centred on source pixel (2x, 2y), REFLECT_101, (v + 128) >> 8
+// (LSDDetector::computeGaussianPyramid / BinaryDescriptor::computeGaussianPyramid with numOctaves = 2; oracle/img_ops.cc
+// plo_pyr_down_u8).  One thread per output pixel: the second octave is a configuration no shipped YAML uses.
+__global__ void __launch_bounds__(256) k_pyr_down5_u8(const uint8_t* src, long long sStride, int sw, int sh, uint8_t* dst, long long dStride,
+                                                      int dw, int dh) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+  if (x >= dw || y >= dh) return;
+  const uint8_t* S = src + (long long)b * sStride;
+  const int k5[5] = {1, 4, 6, 4, 1};
+  int xs[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) xs[k] = refl101(2 * x + k - 2, sw);
+  int v = 0;
+#pragma unroll
+  for (int ky = 0; ky < 5; ky++) {
+    const uint8_t* row = S + (long long)refl101(2 * y + ky - 2, sh) * sw;
+    int r = 0;
+#pragma unroll
+    for (int kx = 0; kx < 5; kx++) r += k5[kx] * (int)row[xs[kx]];
+    v += k5[ky] * r;
+  }
+  dst[(long long)b * dStride + (long long)y * dw + x] = (uint8_t)((v + 128) >> 8);
+}
+void launch_pyr_down5(const uint8_t* src, long long sStride, int sw, int sh, uint8_t* dst, long long dStride, int dw, int dh, int batch,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_pyr_down5_u8, dim3((dw + 63) / 64, (dh + 3) / 4, batch), dim3(256), 0, s, src, sStride, sw, sh, dst, dStride, dw, dh);
+}
+
 // (plh_sbfe1, plh_sqrt_approx: plh_shims.h)
 
 // Seed ordering: stable counting sort of the DEFINED pixels of a frame by bin (descending), raster order inside a bin.

@@ -106,6 +106,16 @@ struct LineDeviceArgs {
   uint8_t* mwMark;
   uint16_t* mwHint;         // per frame: claim hints shared by its wavefronts (mwMarkStride 16-bit tags, cleared by the kernel)
   long long mwRegStride, mwMarkStride;
+  // LINEextractor(numOctaves = 2, scale in [2, 3)): the second octave -- pyrDown of the frame (detection) and of the 5x5-blurred
+  // frame (description), half size; its LSD runs on a plan of its own (plh_line::oct1), k_keylines / k_lbd read both.  All zero /
+  // null with one octave.
+  const float* segs1;       // octave 1's segments [frame][segCap1][4], frames arena1Stride words apart
+  const int* nSegs1;
+  long long arena1Stride;
+  int segCap1, w1, h1;      // octave 1's segment capacity and image size
+  float octScale1;          // pow((float)(int)scale, 1) = 2
+  const uint32_t* dxdy1;    // Sobel of octave 1's blurred image, pitch w1, frames full1Stride apart
+  long long full1Stride;
   int mwWaves;              // wavefronts per frame of this launch (0: k_lsd_grow / k_lsd_grow_lone)
   int mwLag;                // a wavefront starts no transaction further than this ahead of the commits
   int mwDrainGap;           // a wavefront that posted tries to commit when the commits are this far behind it (or it is the oldest)

@@ -1796,26 +1796,51 @@ __global__ void __launch_bounds__(1024) k_lsd_grow_mw16(LineDeviceArgs a) {
   lsd_grow_frame_mw(a, smem);
 }
 
+// One item of the frame's detection list: octave 0's segments first, then octave 1's (LSDDetector_custom.cpp:161-199 walks the
+// octaves in this order; with one octave n1 = 0).  Loads the segment, clamps it to its octave's image (checkLineExtremes) and says
+// which octave it came from.
+struct KlFrame {
+  const float *segs0, *segs1;
+  int n0, n1, w0, h0, w1, h1;
+  float scale1;
+};
+__device__ __forceinline__ int kl_item(const KlFrame& f, int i, float e[4], int& w, int& h, float& scale) {
+  const bool o1 = i >= f.n0;
+  const float* sg = o1 ? f.segs1 + (i - f.n0) * 4 : f.segs0 + i * 4;
+  e[0] = sg[0]; e[1] = sg[1]; e[2] = sg[2]; e[3] = sg[3];
+  w = o1 ? f.w1 : f.w0; h = o1 ? f.h1 : f.h0; scale = o1 ? f.scale1 : 1.0f;
+  clamp_extremes(e, w, h);
+  return o1 ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   unsigned long long* sel = (unsigned long long*)smem;   // [outCap]
   __shared__ unsigned long long s_red[4];
   __shared__ int s_valid, s_keep;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int n = min(a.nSegs[b], a.segCap);
-  const float* segs = a.segs + (long long)b * a.arenaStride;
+  KlFrame f;
+  f.segs0 = a.segs + (long long)b * a.arenaStride;
+  f.n0 = min(a.nSegs[b], a.segCap);
+  f.w0 = a.w; f.h0 = a.h;
+  f.segs1 = a.segs1 ? a.segs1 + (long long)b * a.arena1Stride : nullptr;
+  f.n1 = a.segs1 ? min(a.nSegs1[b], a.segCap1) : 0;
+  f.w1 = a.w1; f.h1 = a.h1; f.scale1 = a.octScale1;
+  const int n = f.n0 + f.n1;
   unsigned long long* keys = (unsigned long long*)(a.reg + (long long)b * a.arenaStride);   // scratch (free after k_lsd_rects)
   if (tid == 0) s_valid = 0;
   __syncthreads();
   int myValid = 0;
   for (int i = tid; i < n; i += 256) {
-    float e[4] = {segs[i * 4], segs[i * 4 + 1], segs[i * 4 + 2], segs[i * 4 + 3]};
-    clamp_extremes(e, a.w, a.h);
+    float e[4], sc;
+    int w, h;
+    kl_item(f, i, e, w, h, sc);
     bool valid = true;
-    if (a.mask) {   // drop only if BOTH endpoints lie on mask == 0
-      if (a.mask[(long long)(int)e[1] * a.w + (int)e[0]] == 0 && a.mask[(long long)(int)e[3] * a.w + (int)e[2]] == 0) valid = false;
+    if (a.mask) {   // drop only if BOTH endpoints lie on mask == 0 (looked up at the full-resolution end points)
+      const float sx = e[0] * sc, sy = e[1] * sc, ex = e[2] * sc, ey = e[3] * sc;
+      if (a.mask[(long long)(int)sy * a.w + (int)sx] == 0 && a.mask[(long long)(int)ey * a.w + (int)ex] == 0) valid = false;
     }
-    const float response = seg_length(e) / (float)max(a.w, a.h);
+    const float response = seg_length(e) / (float)max(w, h);
     keys[i] = valid ? (((unsigned long long)__float_as_uint(response) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i)) : 0ull;
     myValid += valid;
   }
@@ -1852,8 +1877,9 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
     else { total = nv; index = nv; }
     auto lenOf = [&](int k) -> float {
       const int i = (int)(0xffffffffu - (unsigned)(sel[k] & 0xffffffffull));
-      float e[4] = {segs[i * 4], segs[i * 4 + 1], segs[i * 4 + 2], segs[i * 4 + 3]};
-      clamp_extremes(e, a.w, a.h);
+      float e[4], sc;
+      int w, h;
+      kl_item(f, i, e, w, h, sc);
       return seg_length(e);
     };
     if (total >= 1 && (double)lenOf(total - 1) < a.minLineLength) {
@@ -1870,19 +1896,20 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
   const int keep = s_keep;
   for (int k = tid; k < keep; k += 256) {
     const int i = (int)(0xffffffffu - (unsigned)(sel[k] & 0xffffffffull));
-    float e[4] = {segs[i * 4], segs[i * 4 + 1], segs[i * 4 + 2], segs[i * 4 + 3]};
-    clamp_extremes(e, a.w, a.h);
+    float e[4], sc;
+    int w, h;
+    const int oct = kl_item(f, i, e, w, h, sc);
     plh_keyline kl;
-    kl.startPointX = e[0]; kl.startPointY = e[1]; kl.endPointX = e[2]; kl.endPointY = e[3];
+    kl.startPointX = e[0] * sc; kl.startPointY = e[1] * sc; kl.endPointX = e[2] * sc; kl.endPointY = e[3] * sc;
     kl.sPointInOctaveX = e[0]; kl.sPointInOctaveY = e[1]; kl.ePointInOctaveX = e[2]; kl.ePointInOctaveY = e[3];
     kl.lineLength = seg_length(e);
     const int x1 = cv_round(e[0]), y1 = cv_round(e[1]), x2 = cv_round(e[2]), y2 = cv_round(e[3]);
     kl.numOfPixels = max(abs(x2 - x1), abs(y2 - y1)) + 1;
     kl.angle = (float)atan2((double)(kl.endPointY - kl.startPointY), (double)(kl.endPointX - kl.startPointX));
     kl.class_id = k;
-    kl.octave = 0;
+    kl.octave = oct;
     kl.size = (kl.endPointX - kl.startPointX) * (kl.endPointY - kl.startPointY);
-    kl.response = kl.lineLength / (float)max(a.w, a.h);
+    kl.response = kl.lineLength / (float)max(w, h);
     kl.pt_x = (kl.endPointX + kl.startPointX) / 2;
     kl.pt_y = (kl.endPointY + kl.startPointY) / 2;
     outKl[(long long)b * a.outCap + k] = kl;
@@ -1999,12 +2026,15 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
   const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   if (li >= nOut[b]) return;
   const plh_keyline L = kls[(long long)b * a.outCap + li];
-  const uint32_t* D = a.dxdy + (long long)b * a.fullStride;
+  // the gradient images of the line's octave (binary_descriptor_custom.cpp:1080-1104)
+  const bool oct1 = L.octave != 0;
+  const uint32_t* D = oct1 ? a.dxdy1 + (long long)b * a.full1Stride : a.dxdy + (long long)b * a.fullStride;
+  const int imgW = oct1 ? a.w1 : a.w, imgH = oct1 ? a.h1 : a.h;
   const short lengthOfLSP = (short)L.numOfPixels;
   const short halfWidth = (lengthOfLSP - 1) / 2;
   const short halfHeight = (LBD_ROWS - 1) / 2;
-  const int imageWidth = a.w - 1, imageHeight = a.h - 1;
-  const bool wide = a.w >= 16384 || a.h >= 16384;   // walk coordinates can leave the range of a short
+  const int imageWidth = imgW - 1, imageHeight = imgH - 1;
+  const bool wide = imgW >= 16384 || imgH >= 16384;   // walk coordinates can leave the range of a short
   const float midX = (float)(0.5 * (L.sPointInOctaveX + L.ePointInOctaveX));
   const float midY = (float)(0.5 * (L.sPointInOctaveY + L.ePointInOctaveY));
   // (float)cos / (float)sin of the double angle: the short evaluation on |angle| in [0, pi] (cos is even, sin is odd, and so
@@ -2051,7 +2081,7 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
       const int yCor = wide ? lbd_coord_wide(sCorY, imageHeight) : lbd_coord(sCorY, imageHeight);
       sCorX += dL0;
       sCorY += dL1;
-      return (uint32_t)(__mul24(yCor, a.w) + xCor);   // 32-bit offset: the 64-bit multiply-add of a long long index is a quarter-rate instruction
+      return (uint32_t)(__mul24(yCor, imgW) + xCor);   // 32-bit offset: the 64-bit multiply-add of a long long index is a quarter-rate instruction
     };
     if (fabsf(dL0) <= fabsf(dL1)) {
       // Steep line: the 63 rows of one walk step are neighbours along an image row, a gather touches a few cache lines.  The

@@ -250,8 +250,58 @@ def test_emu_line_edge_cases(plslam, emu_lib):
     assert len(kl) == 0
     with pytest.raises(plslam.PlhError):                   # mask size mismatch is the reference's runtime_error
         ex(np.zeros((64, 96), np.uint8), mask=np.zeros((10, 10), np.uint8))
-    with pytest.raises(plslam.PlhError):
-        plslam.LINEextractor(2, 1.2, 20, 0.0, rows=64, cols=96, lib=emu_lib)   # numOctaves != 1 unsupported
+    for no, sc in ((2, 1.2), (2, 3.0), (3, 2.0), (0, 1.2)):   # what the reference itself cannot run: cv::pyrDown's assertion
+        with pytest.raises(plslam.PlhError):                  # ((int)scale != 2), undefined behaviour (three octaves)
+            plslam.LINEextractor(no, sc, 20, 0.0, rows=64, cols=96, lib=emu_lib)
+    ex.close()
+
+
+@pytest.mark.parametrize("seed,rows,cols,refine,masked", [(7, 120, 160, 0, False), (8, 121, 163, 1, True)])
+def test_emu_line_two_octaves(plslam, oracle, synth, emu_lib, seed, rows, cols, refine, masked):
+    """LINEextractor(numOctaves = 2, scale = 2): the second octave's Gaussian pyramid level, its LSD, KeyLines of both octaves in
+    one response order, LBD on the gradient images of each line's octave -- every record equal to the oracle's."""
+    img = synth.make_frame(seed, rows, cols, n_rect=40, n_line=20)
+    mask = None
+    if masked:
+        mask = np.full((rows, cols), 255, np.uint8)
+        mask[20:90, 30:120] = 0
+    rk, rd, rf = oracle.line_extract(img, 60, 0.0, mask, refine=refine, num_octaves=2, scale=2.0)
+    assert (rk["octave"] == 1).sum() > 5 and (rk["octave"] == 0).sum() > 5
+    ex = plslam.LINEextractor(2, 2.0, 60, 0.0, rows=rows, cols=cols, max_batch=1, lib=emu_lib)
+    ex.set_refine(refine)
+    kl, desc, fn = ex(img, mask)
+    assert ex.status() == 0
+    ex.close()
+    assert _exact(kl, desc, fn, rk, rd, rf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,refine,waves", [(480, 640, 0, -1), (376, 1241, 1, 0), (203, 405, 0, 4)])
+def test_gpu_line_two_octaves(plslam, oracle, synth, rows, cols, refine, waves):
+    """Two octaves on the GPU: one frame through the host-buffer call and a batch of four through the device entry point."""
+    import torch
+    frames = np.stack([synth.make_frame(40 + i, rows, cols) for i in range(4)])
+    ref = [oracle.line_extract(f, 200, 0.0, refine=refine, num_octaves=2, scale=2.0) for f in frames]
+    ex = plslam.LINEextractor(2, 2.0, 200, 0.0, rows=rows, cols=cols, max_batch=4)
+    ex.set_refine(refine)
+    ex.set_grow_waves(waves)
+    kl, desc, fn = ex(frames[0])
+    _match(kl, desc, fn, *ref[0], "two octaves, one frame")
+    cap = ex.capacity
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_kl = torch.zeros((4, cap, 17), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((4, cap, 32), dtype=torch.uint8, device=dev)
+    d_fn = torch.zeros((4, cap, 3), dtype=torch.float64, device=dev)
+    d_n = torch.zeros((4,), dtype=torch.int32, device=dev)
+    ex.extract_batch_dev(d_img, 4, rows * cols, d_kl, d_desc, d_fn, d_n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ex.status() == 0
+    n = d_n.cpu().numpy()
+    klb = d_kl.cpu().numpy().view(np.uint8).reshape(4, cap, 68).copy().view(plslam.KL_DTYPE).reshape(4, cap)
+    for b in range(4):
+        _match(klb[b, :n[b]], d_desc[b, :n[b]].cpu().numpy(), d_fn[b, :n[b]].cpu().numpy(), *ref[b], "two octaves, batch frame %d" % b)
+        assert (ref[b][0]["octave"] == 1).sum() > 0
     ex.close()
 
 

@@ -62,6 +62,11 @@ def _inputs(synth, g):
     return img, mask
 
 
+def _octaves(g):
+    """(numOctaves, scale) of a golden file: the two-octave cases carry them, the others are LINEextractor(1, 1.2, ...)."""
+    return (int(g["num_octaves"]), float(g["scale"])) if "num_octaves" in g.files else (1, 1.2)
+
+
 def test_golden_files_present():
     assert len(GOLDEN) >= 3
 
@@ -70,7 +75,8 @@ def test_golden_files_present():
 def test_oracle_reproduces_reference_lines(oracle, synth, path):
     g = np.load(path)
     img, mask = _inputs(synth, g)
-    kl, desc, fn = oracle.line_extract(img, int(g["nfeatures"]), float(g["min_len"]), mask)
+    no, sc = _octaves(g)
+    kl, desc, fn = oracle.line_extract(img, int(g["nfeatures"]), float(g["min_len"]), mask, num_octaves=no, scale=sc)
     _same(kl, desc, fn, g["keylines"], g["desc"], g["linefn"], "oracle")
 
 
@@ -88,13 +94,36 @@ def test_reference_lines_live(oracle, plslam, synth):
         _same(kl, desc, fn, rk, rd, rf, "oracle vs live reference (seed %d)" % seed)
 
 
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (no /root/reference on this machine)")
+def test_reference_two_octaves_live(oracle, plslam, synth):
+    """LINEextractor(numOctaves = 2, ...) of the reference itself (its LineExtractor.cpp, LSDDetector_custom.cpp's Gaussian pyramid
+    and octave loop, binary_descriptor_custom.cpp's per-octave Sobel / LBD) against the oracle's restatement -- and what the
+    reference does with the other configurations: with (int)scale != 2 its cv::pyrDown call asserts (the oracle reports the same)."""
+    G = _gen()
+    R = G.ref_line_lib()
+    for seed, rows, cols, nf, min_len, scale in [(2, 480, 640, 200, 0.0, 2.0), (5, 376, 1241, 150, 0.0, 2.0), (7, 121, 161, 60, 8.0, 2.9)]:
+        img = synth.make_frame(seed, rows, cols)
+        rk, rd, rf = G.reference_lines(R, plslam, img, nf, min_len, num_octaves=2, scale=scale)
+        assert (rk["octave"] == 1).sum() > 0 and (rk["octave"] == 0).sum() > 0
+        kl, desc, fn = oracle.line_extract(img, nf, min_len, num_octaves=2, scale=scale)
+        _same(kl, desc, fn, rk, rd, rf, "two octaves: oracle vs live reference (seed %d)" % seed)
+    img = synth.make_frame(3, 120, 160)
+    for scale in (1.2, 3.0):      # pyrDown(Size(cols / (int)scale, ...)): OpenCV's size assertion
+        assert G.reference_lines(R, plslam, img, 50, 0.0, num_octaves=2, scale=scale) is None
+        with pytest.raises(oracle.ReferenceThrows):
+            oracle.line_extract(img, 50, 0.0, num_octaves=2, scale=scale)
+    with pytest.raises(oracle.ReferenceThrows):   # three octaves: undefined behaviour in the reference, not run there
+        oracle.line_extract(img, 50, 0.0, num_octaves=3, scale=2.0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[9:-4] for p in GOLDEN])
 def test_gpu_reproduces_reference_lines(plslam, synth, path):
     g = np.load(path)
     img, mask = _inputs(synth, g)
     rows, cols = int(g["rows"]), int(g["cols"])
-    le = plslam.LINEextractor(1, 1.2, int(g["nfeatures"]), float(g["min_len"]), rows=rows, cols=cols, max_batch=1, device=0)
+    no, sc = _octaves(g)
+    le = plslam.LINEextractor(no, sc, int(g["nfeatures"]), float(g["min_len"]), rows=rows, cols=cols, max_batch=1, device=0)
     try:
         kl, desc, fn = le(img, mask)
     finally:

@@ -284,6 +284,10 @@ LINE_CASES = [   # name, frame seed, rows, cols, nLSDFeature, min_line_length, m
     ("s4_403x200_mask", 4, 200, 403, 120, 0.0, True),
     ("kitti_1241x376", 1000, 376, 1241, 200, 0.0, False),     # BASELINE configs[4]'s frame shape
 ]
+LINE_OCTAVE_CASES = [   # LINEextractor(numOctaves = 2, scale = 2.x): name, frame seed, rows, cols, nLSDFeature, min_line_length, masked, scale
+    ("oct2_s6_640x480", 6, 480, 640, 200, 0.0, False, 2.0),
+    ("oct2_s8_405x203_mask", 8, 203, 405, 120, 12.0, True, 2.5),   # odd sizes: pyrDown to floor(w / 2) x floor(h / 2); (int)2.5 == 2
+]
 
 
 def ref_line_lib():
@@ -332,6 +336,13 @@ def gen_lines(S, out):
         np.savez_compressed(os.path.join(out, "ref_line_%s.npz" % name), seed=seed, rows=rows, cols=cols, nfeatures=nf,
                             min_len=min_len, masked=masked, keylines=kl, desc=desc, linefn=fn)
         print("lines", name, "keylines", len(kl))
+    for name, seed, rows, cols, nf, min_len, masked, scale in LINE_OCTAVE_CASES:
+        img = S.make_frame(seed, rows, cols)
+        mask = line_mask(S, seed, rows, cols) if masked else None
+        kl, desc, fn = reference_lines(R, P, img, nf, min_len, mask, num_octaves=2, scale=scale)
+        np.savez_compressed(os.path.join(out, "ref_line_%s.npz" % name), seed=seed, rows=rows, cols=cols, nfeatures=nf,
+                            min_len=min_len, masked=masked, num_octaves=2, scale=scale, keylines=kl, desc=desc, linefn=fn)
+        print("lines", name, "keylines", len(kl), "of them in octave 1:", int((kl["octave"] == 1).sum()))
 
 
 # ---------------------------------------------------------------------------------------------------------------

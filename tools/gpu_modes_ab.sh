@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 4, measurement box: A/B (screen on / off / ADV), the default bench line, PMC calibration of the counters' access patterns.
+# A/B of the modes of one build: A/B (screen on / off / ADV), the default bench line, PMC calibration of the counters' access patterns.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ROOT=$PWD
-O=gpurun_out/r4c
+O=gpurun_out/modes
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 for flag in "" "--no-screen" "--refine adv"; do
@@ -15,7 +15,7 @@ done
 timeout 1500 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/r4c/bench.json'))
+d=json.load(open('gpurun_out/modes/bench.json'))
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline', d['roofline']['frac'], d['roofline']['ms_per_launch'], d['roofline'].get('ms_per_launch_alone'), 'verified', d.get('verified',{}).get('exact'), d.get('verified',{}).get('frames'))
 print('latency', {k: v for k, v in d.get('latency_ms_single_frame', {}).items() if k != 'note'})
 s=d.get('secondary',{})

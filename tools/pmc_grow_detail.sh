@@ -1,6 +1,6 @@
 #!/bin/bash
 # where do k_lsd_grow's cycles go at full residency (6144 frames in ONE launch = 6 wavefronts per SIMD)?  Two PMC passes.
-export PLH_GROW_MW_WAVES=0   # these profiles are about the one-wavefront-per-frame kernels (small batches would run k_lsd_grow_mw)
+GW="--grow-waves 0"   # these profiles are about the one-wavefront-per-frame kernels (small batches would run k_lsd_grow_mw)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-6144}
@@ -9,7 +9,7 @@ P2="SQ_WAVES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_IFETC
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R/gpurun_out/pmcgrow$i -o o -- python $R/bench.py --steps 1 --warmup 1 --batch $B --nsplit 1 --no-cpu-baseline --no-extras --serial > /dev/null 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R/gpurun_out/pmcgrow$i -o o -- python $R/bench.py --steps 1 --warmup 1 --batch $B --nsplit 1 --no-cpu-baseline --no-extras --serial $GW > /dev/null 2>&1
 done
 python - <<PY
 import csv, collections
