@@ -56,7 +56,7 @@ TUM1_K = [517.306408, 516.469215, 318.643040, 255.313989]        # Examples/Mono
 TUM1_D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]    # TUM1.yaml:13-17
 KITTI_K = [718.856, 718.856, 607.1928, 185.2157]                  # Examples/Monocular/KITTI00-02.yaml:8-11
 NAMES = ["k_pyr_down x7", "k_fast_strips", "k_octree", "k_orient_brief", "line prep (remap/blur/resize/grad/order)",
-         "k_lsd_grow", "k_keylines", "LBD (blur+sobel+k_lbd)"]
+         "k_lsd_grow", "k_lsd_rects + k_keylines", "LBD (blur+sobel+k_lbd)"]
 
 
 def level_sizes(rows, cols, nlevels):

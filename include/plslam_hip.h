@@ -666,7 +666,8 @@ PLH_API plh_status plh_line_set_grow_tuning(plh_line* h, int run_ahead, int drai
  * call's lines are void; the handle's workspace is re-initialised by this query. */
 PLH_API plh_status plh_line_status(plh_line* h, int* flags);
 /* Per-stage device time (HIP events on the caller's stream): 0 = image prep + level-line field + seed order,
- * 1 = LSD region growing (k_lsd_grow), 2 = KeyLine selection, 3 = LBD (blur + Sobel + descriptor). */
+ * 1 = LSD region growing (k_lsd_grow), 2 = the kept regions' rectangles (k_lsd_rects; LSD_REFINE_ADV's rect_improve; a second
+ * octave's whole LSD) + KeyLine selection, 3 = LBD (blur + Sobel + descriptor). */
 PLH_API plh_status plh_line_set_profiling(plh_line* h, int on);
 PLH_API plh_status plh_line_kernel_ms(plh_line* h, int stage, double* total_ms, int* intervals);
 /* parity taps */

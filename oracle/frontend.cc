@@ -10,6 +10,8 @@
 //     Frame::ComputeBoW                            src/Frame.cc:906-913                plo_bow_transform, plo_bow_vector
 //     ORBmatcher::SearchByBoW, LSDmatcher::SearchDouble against the worker's previous frame (Tracking.cc:1151-1159)
 // It is a timing harness: the results are discarded (a checksum keeps the calls alive), parity lives in tests/.
+#include <malloc.h>
+
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -94,6 +96,13 @@ double plo_frontend_batch(const uint8_t* frames, int n, int rows, int cols, int 
   FrontendJob J{frames, n, rows, cols, nfeatures, nlevels, nlines, refine, mapx, mapy, node_desc, child_start, child_count, word_id,
                 weight, word_weight, L};
   if (nthreads < 1) nthreads = 1;
+  // The oracle's stages allocate their images and tables per call (tens of MB per frame, std::vector).  With glibc's defaults
+  // every such block is its own mmap / munmap and page-faults in afresh: hundreds of threads then queue on the process's address-
+  // space lock and the timing measures the kernel's mm, not the oracle (round 4's first native run: 9.7 % parallel efficiency on
+  // 128 cores).  Keep the blocks in the threads' malloc arenas instead.
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 64 << 20);
   std::vector<unsigned long long> sums((size_t)nthreads, 0);
   const auto t0 = std::chrono::steady_clock::now();
   if (nthreads == 1) {

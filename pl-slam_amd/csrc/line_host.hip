@@ -533,7 +533,7 @@ static plh_status line_lsd_stages(plh_line* h, const LineDeviceArgs& a, const ui
   launch_lsd_grow(a, s);
   PLH_LAUNCH_CHECK();
   if (top && h->growDone) PLH_HIP(hipEventRecord(h->growDone, s));
-  if (top) line_prof_mark(h, 1, s);
+  if (top) { line_prof_mark(h, 1, s); line_prof_mark(h, 2, s); }   // stage 2 = rectangles (+ a second octave's LSD) + KeyLine selection
   launch_lsd_rects(a, s);   // one lane per region
   PLH_LAUNCH_CHECK();
   return PLH_OK;
@@ -580,7 +580,6 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
     st = line_lsd_stages(h1, a1, h->dOctImg, a1.fullStride, batch, s, false);
     if (st != PLH_OK) return st;
   }
-  line_prof_mark(h, 2, s);
   launch_keylines(a, d_keylines, d_linefn, d_n, s);
   PLH_LAUNCH_CHECK();
   line_prof_mark(h, 2, s);
