@@ -90,12 +90,30 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
+def cpu_quota():
+    """CPUs the container may use at a time: cgroup v2 cpu.max or v1 cfs quota / period; None when unlimited or unreadable."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=0, budget_s=8.0):
     """The oracle on the host cores, natively threaded (oracle/frontend.cc plo_frontend_batch: one std::thread per worker, each
     with its own ORB handle and buffers): per frame ORB + (remap) + lines + BoW transform + both matchers against the worker's
-    previous frame -- the work of one product step per frame.  Three legs: one thread, one per physical core, one per hardware
-    thread; `value` is the best of them."""
+    previous frame -- the work of one product step per frame.  Legs: one thread, one per physical core, one per hardware thread,
+    and -- when the container is given fewer CPUs than the host has (a cgroup quota, or simply measured: CPU seconds / wall
+    seconds of the physical-core leg) -- one per CPU it really gets; `value` is the best of them.  `cores_busy` = the process's
+    CPU seconds over the leg's wall seconds: the cores that actually ran the threads."""
     import ctypes as C
+    import resource
     L = O.lib()
     L.plo_frontend_batch.restype = C.c_double
     L.plo_frontend_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + \
@@ -111,27 +129,41 @@ def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=0, 
 
     def run(threads, per_thread):
         chk = C.c_ulonglong(0)
+        u0 = resource.getrusage(resource.RUSAGE_SELF)
         dt = L.plo_frontend_batch(O._p(frames), n, rows, cols, nfeatures, nlevels, nlines, int(refine), O._p(mx), O._p(my),
                                   O._p(voc.node_desc), O._p(voc.child_start), O._p(voc.child_count), O._p(voc.word_id), O._p(voc.weight),
                                   O._p(ww), voc.L, threads, per_thread, C.byref(chk))
-        return threads * per_thread / dt, dt
+        u1 = resource.getrusage(resource.RUSAGE_SELF)
+        busy = ((u1.ru_utime - u0.ru_utime) + (u1.ru_stime - u0.ru_stime)) / max(dt, 1e-9)
+        return threads * per_thread / dt, dt, busy
 
-    hw, phys = os.cpu_count() or 1, physical_cores()
-    r1, dt1 = run(1, 3)
+    hw, phys, quota = os.cpu_count() or 1, physical_cores(), cpu_quota()
+    r1, dt1, _ = run(1, 3)
     per = dt1 / 3
     legs = {"1": {"threads": 1, "frames_per_s": round(r1, 2), "ms_per_frame": round(per * 1e3, 2)}}
     best, best_threads = r1, 1
-    for name, th in (("physical_cores", phys), ("hardware_threads", hw)):
+    todo = [("physical_cores", phys), ("hardware_threads", hw)]
+    if quota is not None and quota < phys:
+        todo.insert(0, ("cgroup_cpu_quota", max(1, int(round(quota)))))
+    granted = None
+    while todo:
+        name, th = todo.pop(0)
         if th <= 1 or str(th) in legs:
             continue
-        per_thread = int(max(3, min(32, budget_s / max(per, 1e-4))))
-        r, dt = run(th, per_thread)
+        per_thread = int(max(3, min(32, budget_s * min(th, granted or th) / th / max(per, 1e-4))))
+        r, dt, busy = run(th, per_thread)
         legs[str(th)] = {"threads": th, "which": name, "frames_per_s": round(r, 2), "frames": th * per_thread, "seconds": round(dt, 2),
-                         "parallel_efficiency": round(r / (r1 * th), 3)}
+                         "cores_busy": round(busy, 1), "parallel_efficiency": round(r / (r1 * th), 3),
+                         "efficiency_per_busy_core": round(r / (r1 * max(busy, 1.0)), 3)}
         if r > best:
             best, best_threads = r, th
+        if name == "physical_cores" and granted is None and busy < 0.6 * th:
+            # the threads were runnable but ran on `busy` cores: the container gets fewer CPUs than the host shows
+            granted = max(1, int(round(busy)))
+            todo.insert(0, ("cores_granted_measured", granted))
     return {"value": round(best, 2), "unit": "frames/s", "cores": best_threads, "kind": "port", "physical_cores": phys,
-            "hardware_threads": hw, "legs": legs, "single_thread_ms_per_frame": round(per * 1e3, 1),
+            "hardware_threads": hw, "cgroup_cpu_quota": quota, "cores_granted_measured": granted, "legs": legs,
+            "single_thread_ms_per_frame": round(per * 1e3, 1),
             "sample": "synthetic %dx%d frames (ORB + remap + LSD%s/LBD + BoW + SearchByBoW + SearchDouble per frame), oracle/ restatement "
                       "(g++ -O2 -ffp-contract=off, no OpenCV SIMD), native std::thread shards (oracle/frontend.cc); cores = the thread "
                       "count of the best leg" % (cols, rows, " (LSD_REFINE_ADV)" if refine else "")}

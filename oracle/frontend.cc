@@ -100,9 +100,11 @@ double plo_frontend_batch(const uint8_t* frames, int n, int rows, int cols, int 
   // every such block is its own mmap / munmap and page-faults in afresh: hundreds of threads then queue on the process's address-
   // space lock and the timing measures the kernel's mm, not the oracle (round 4's first native run: 9.7 % parallel efficiency on
   // 128 cores).  Keep the blocks in the threads' malloc arenas instead.
-  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  // (glibc refuses an mmap threshold above HEAP_MAX_SIZE / 2 = 32 MiB, and setting any of these switches its own adaptive
+  // threshold off: the first version of this asked for 1 GiB, was refused, and left every block >= 128 KiB on mmap.)
+  mallopt(M_MMAP_THRESHOLD, 32 << 20);
   mallopt(M_TRIM_THRESHOLD, 1 << 30);
-  mallopt(M_TOP_PAD, 64 << 20);
+  mallopt(M_TOP_PAD, 16 << 20);
   std::vector<unsigned long long> sums((size_t)nthreads, 0);
   const auto t0 = std::chrono::steady_clock::now();
   if (nthreads == 1) {
