@@ -231,7 +231,7 @@ plh_status plh_line_create(const plh_line_params* p, int device, int rows, int c
   a.sw = (int)lrint(cols * 0.8); a.sh = (int)lrint(rows * 0.8);
   a.spitch = align_up(a.sw, 64);
   a.fullStride = align_up<long long>((long long)cols * rows, 256);
-  a.scaledStride = align_up<long long>((long long)a.spitch * a.sh, 256);
+  a.scaledStride = align_up<long long>((long long)a.spitch * lsd_rec_rows(a.sh), 256);   // (the record plane is made of 4 x 4 blocks)
   // flsd() constants
   const double ANG_TH = 22.5, QUANT = 2.0;
   a.prec = M_PI * ANG_TH / 180;

@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
   const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
   if (threadIdx.x == 0 && threadIdx.y == 0) s_max = 0;
   __syncthreads();
-  if (x4 < a.spitch && y < a.sh) {
+  if (x4 < a.spitch && y < lsd_rec_rows(a.sh)) {   // (the rows that only pad the last band of blocks get NOTDEF records)
     const uint8_t* I = a.scaled + (long long)b * a.scaledStride;
     // pixels x4 .. x4+4 of rows y and y+1 (the row below the last one and the dword beyond the pitch are never used)
     unsigned long long r0 = 0, r1 = 0;
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
       rec[k] = def ? ((uint32_t)(((gy + LSD_GRAD_MAX) << LSD_ANGLE_PITCH_LOG2) + gx + LSD_GRAD_MAX) | LSD_REC_DEF) : 0u;
       if (def) qmax = max(qmax, q);
     }
-    uint32_t* o = a.pix + (long long)b * a.arenaStride + (__mul24(y, a.spitch) + x4);   // pitch is a multiple of 64: 16-byte aligned
+    uint32_t* o = a.pix + (long long)b * a.arenaStride + lsd_rec_index((unsigned)x4, (unsigned)y, (unsigned)a.spitch);   // four pixels of a block row: 16-byte aligned
     uint4 o4;
     o4.x = rec[0]; o4.y = rec[1]; o4.z = rec[2]; o4.w = rec[3];
     *reinterpret_cast<uint4*>(o) = o4;
@@ -408,9 +408,10 @@ __global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
   // order is irrelevant here, so every lane takes 4 consecutive pixels (16-byte loads / stores; chunk bounds are
   // multiples of 64)
   for (int base = c0; base < c1; base += 256) {
-    const int i = base + lane * 4;
+    const int i = base + lane * 4;   // raster index (the bins are written in raster order: the scatter's order)
     if (i < c1) {
-      const uint4 q4 = *reinterpret_cast<const uint4*>(Q + i);
+      const int iy = i / a.spitch, ix = i - iy * a.spitch;
+      const uint4 q4 = *reinterpret_cast<const uint4*>(Q + lsd_rec_index((unsigned)ix, (unsigned)iy, (unsigned)a.spitch));
       const unsigned qq[4] = {q4.x, q4.y, q4.z, q4.w};
       unsigned bb[4];
 #pragma unroll

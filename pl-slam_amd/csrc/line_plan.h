@@ -29,6 +29,21 @@ struct LsdAngleEntry {
 };
 // level-line record of a pixel of the 0.8x image (u32): table index | DEF (gradient above the threshold) | USED (region growing's mark)
 constexpr uint32_t LSD_REC_IDX = 0x000fffffu, LSD_REC_DEF = 0x40000000u, LSD_REC_USED = 0x80000000u;
+// Where the record of pixel (x, y) lies in a frame's record plane: 4 x 4-pixel blocks of 64 bytes, blocks in row-major order
+// (round 4).  Region growing reads 3 x 3 neighbourhoods along segments of every direction; in a row-major plane a region that
+// advances by a row touches a new 128-byte line for every row, and at full residency (768 frames per 4 MiB L2) that line comes
+// from HBM: the step waits for it.  Two side-by-side blocks are one such line (8 x 4 pixels), a block is one 64-byte sector.
+// Four pixels x .. x+3 of a row (x a multiple of 4) are still 16 contiguous bytes.  The pitch is a multiple of 64; the plane
+// holds lsd_rec_rows(sh) rows.
+#if defined(__HIPCC__) || defined(__HIP__)
+#define PLH_REC_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
+#else
+#define PLH_REC_HD inline
+#endif
+PLH_REC_HD uint32_t lsd_rec_index(uint32_t x, uint32_t y, uint32_t spitch) {
+  return (y >> 2) * (spitch << 2) + ((((x & ~3u) + (y & 3u)) << 2) | (x & 3u));
+}
+PLH_REC_HD int lsd_rec_rows(int sh) { return (sh + 3) & ~3; }
 // cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with a fixed map (Frame.cc:220-222) reduced to what depends on the map alone:
 // per output pixel the offset of the top-left byte of a 2 x 2 source block that lies inside the image, and the four axis
 // weights (0..32, one byte each: column 0, column 1, row 0, row 1) of that block.  A tap of the reference that falls
@@ -61,7 +76,7 @@ struct LineDeviceArgs {
   uint8_t* undist;          // remapped frames (== img when no undistortion), pitch w
   uint8_t* tmpA;            // full-res scratch plane (blur output), pitch w
   uint8_t* scaled;          // 0.8x image, pitch spitch
-  uint32_t* pix;            // level-line record per scaled pixel (LSD_REC_*), pitch spitch
+  uint32_t* pix;            // level-line record per scaled pixel (LSD_REC_*), at lsd_rec_index(x, y, spitch)
   uint32_t* ordered;        // seed list (packed coordinates x | y << 16), bins descending / raster inside a bin
   uint32_t* reg;            // region point queue; behind region growing: the frame's log of kept regions (packed coordinates)
   uint32_t* regq;           // beside every log entry: gx^2 + gy^2 of the pixel (what its region2rect() weight is the root of)

@@ -20,6 +20,7 @@ struct GrowCtx {
   uint32_t* ring;      // LDS mirror of the newest LSD_RING queue entries
   double* T;           // LDS [3][64] doubles: lane -> chain transposition buffer of the sequential double sums
   int spitch, sw, sh, lane;
+  uint32_t nullIdx;   // record index of pixel (sw - 1, 0): never defined, never marked -- what a lane with nothing to examine loads
   unsigned qThresh;
   double precDef;             // the launch's tolerance and its direction-test margins (host: plh_line_create)
   float cin2Def, cout2Def;
@@ -138,7 +139,7 @@ __device__ __forceinline__ LsdPix lsd_null_px(unsigned rec) {
 __device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xffffu); }
 __device__ __forceinline__ int pk_y(uint32_t p) { return (int)(p >> 16); }
 // rows and pitch are below 2^16 (plh_line_create): one v_mad_u32_u24 (a 32-bit v_mul_lo / 64-bit v_mad are quarter rate)
-__device__ __forceinline__ uint32_t pk_lin(const GrowCtx& c, uint32_t p) { return __umul24((unsigned)pk_y(p), (unsigned)c.spitch) + (unsigned)pk_x(p); }
+__device__ __forceinline__ uint32_t pk_lin(const GrowCtx& c, uint32_t p) { return lsd_rec_index((unsigned)pk_x(p), (unsigned)pk_y(p), (unsigned)c.spitch); }   // index of the pixel's record (and of its marks / claim tags)
 
 __device__ __forceinline__ uint32_t reg_get(const GrowCtx& c, int i, int cnt) {
   return (cnt - i <= LSD_RING) ? c.ring[i & (LSD_RING - 1)] : c.reg[i];
@@ -396,7 +397,7 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint3
   // y + dy <= sh - 1 always hold, only the -1 side can leave the image.
   const int xx = pk_x(p) + dx, yy = pk_y(p) + dy;
   const bool inb = q < cnt && (xx | yy) >= 0;
-  nidx = inb ? __umul24((unsigned)yy, (unsigned)c.spitch) + (unsigned)xx : (uint32_t)(c.sw - 1);   // (sw-1, 0): never defined, never marked
+  nidx = inb ? lsd_rec_index((unsigned)xx, (unsigned)yy, (unsigned)c.spitch) : c.nullIdx;   // (sw-1, 0): never defined, never marked
   npk = (uint32_t)xx | ((uint32_t)yy << 16);
   return inb;
 }
@@ -1001,6 +1002,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   c.scr = c.regq;   // reduce_region_radius()'s scratch (at most one word per queue entry) is the queue's own part of regq: whatever
                     // a reduce step leaves there is rewritten by the next density decision on the permuted queue (or at keep time)
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
+  c.nullIdx = lsd_rec_index((unsigned)(a.sw - 1), 0u, (unsigned)a.spitch);
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
   const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;   // packed coordinates x | y << 16
   float* segs = a.segs + (long long)b * a.arenaStride;
@@ -1015,7 +1017,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
     // latency mode (a handful of frames, one lone wavefront each): every step of the walk below waits for one dependent
     // record fetch, so pull the frame's records through this XCD's L2 once, with all loads in flight, before it starts
     const uint4* P4 = reinterpret_cast<const uint4*>(c.P);
-    const int n16 = (a.spitch * a.sh) >> 2;   // the pitch is a multiple of 64
+    const int n16 = (a.spitch * lsd_rec_rows(a.sh)) >> 2;   // the pitch is a multiple of 64
     unsigned acc = 0;
     for (int i = lane; i < n16; i += 64 * 8) {
 #pragma unroll
@@ -1092,7 +1094,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
         LsdPix px = lsd_null_px(0u);
         uint32_t nidx = 0xffffffffu;
         if (grp < nb && xx >= 0 && xx < c.sw && yy >= 0 && yy < c.sh) {
-          nidx = __umul24((unsigned)yy, (unsigned)c.spitch) + (unsigned)xx;
+          nidx = lsd_rec_index((unsigned)xx, (unsigned)yy, (unsigned)c.spitch);
           const unsigned rec = c.P[nidx];
           px = (rec & LSD_REC_DEF) ? lsd_fetch_px(c.A, rec) : lsd_null_px(rec);   // every defined pixel: a mark may be taken back by refine()
         }
@@ -1316,7 +1318,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       const int nAcc = (int)(flags >> 24), nAsm = (int)((flags >> 16) & 255u);
       const bool has = g < nb && j < nAcc + nAsm, isAcc = j < nAcc, spec = (flags & 2u) != 0u;
       const uint32_t pk = has ? sh.pend[slot].w[MWP_PIX + j] : 0u;
-      const uint32_t idx = has ? pk_lin(ch, pk) : (uint32_t)(ch.sw - 1);   // (sw - 1, 0): never defined, never marked
+      const uint32_t idx = has ? pk_lin(ch, pk) : ch.nullIdx;   // (sw - 1, 0): never defined, never marked
       const unsigned p = ch.P[idx];
       const bool usedNow = (p & LSD_USED) != 0u;
       // pixels published by an older post of the batch
@@ -1513,6 +1515,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   c.asmList = (uint32_t*)(wsm + LSD_RING * 4 + (LSD_GS_D + 1) * 8 + 8 * 4);
   c.asmCnt = c.asmList + MW_ASM_CAP;
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
+  c.nullIdx = lsd_rec_index((unsigned)(a.sw - 1), 0u, (unsigned)a.spitch);
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
   GrowState gs;
   gs.d = (double*)(wsm + LSD_RING * 4);
@@ -1537,7 +1540,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   for (int i = tid; i < MWC_WORDS + MW_N; i += (int)blockDim.x) ctl[i] = 0;   // control words and sequence tags
   {   // no claims yet (the plane holds the previous launch's)
     uint4* H4 = reinterpret_cast<uint4*>(c.H);
-    const int n16 = (a.spitch * a.sh) >> 3;   // 16-byte stores of eight tags; the pitch is a multiple of 64
+    const int n16 = (a.spitch * lsd_rec_rows(a.sh)) >> 3;   // 16-byte stores of eight tags; the pitch is a multiple of 64
     for (int i = tid; i < n16; i += (int)blockDim.x) H4[i] = uint4{0u, 0u, 0u, 0u};
     mw_release();
   }
@@ -1545,7 +1548,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
     // a handful of frames: pull the frame's records and the table entries they point to through this XCD's L2, all loads
     // in flight, before the dependent fetches of region growing start (as k_lsd_grow_lone does)
     const uint4* P4 = reinterpret_cast<const uint4*>(c.P);
-    const int n16 = (a.spitch * a.sh) >> 2;
+    const int n16 = (a.spitch * lsd_rec_rows(a.sh)) >> 2;
     unsigned acc = 0;
     for (int i = tid; i < n16; i += (int)blockDim.x * 4) {
 #pragma unroll
@@ -1625,7 +1628,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       {
         const int k = (lane & 7) + ((lane & 7) >= 4 ? 1 : 0);   // 0 .. 8 without the centre
         const int nx = pk_x(seedPk) + k % 3 - 1, ny = pk_y(seedPk) + k / 3 - 1;
-        if (lane < 8 && nx >= 0 && ny >= 0 && nx < c.sw && ny < c.sh) nbRec = c.P[__umul24((unsigned)ny, (unsigned)c.spitch) + (unsigned)nx];
+        if (lane < 8 && nx >= 0 && ny >= 0 && nx < c.sw && ny < c.sh) nbRec = c.P[lsd_rec_index((unsigned)nx, (unsigned)ny, (unsigned)c.spitch)];
       }
       const unsigned seedRec = bcast_u32(seedRecL, 0);
       if (seedRec & LSD_USED) {   // swallowed by a committed region: certain, marks are never taken back once committed
