@@ -10,6 +10,11 @@ rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1800 python -m pytest tests -m gpu -x -q --timeout 900 2>&1 | grep -v amdgpu.ids | grep -E "passed|failed|error|Error" | tail -5 | tee $O/tests.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.txt
+# the PMC profiles first: the bench line only carries PMC-derived fields (roofline.traffic, valu_issue) if they were collected on
+# the build it runs, and it reads them from profiles/
+bash tools/pmc_traffic.sh 1536 > $O/pmc_traffic.log 2>&1; tail -3 $O/pmc_traffic.log; cp gpurun_out/pmc/traffic.json $O/hbm_traffic.json 2>/dev/null && cp $O/hbm_traffic.json profiles/hbm_traffic.json
+bash tools/pmc_insts.sh 1536 > $O/pmc_insts.txt 2>&1; head -12 $O/pmc_insts.txt; cp gpurun_out/pmcinst/insts.json $O/insts.json 2>/dev/null && cp $O/insts.json profiles/r04_insts.json
+bash tools/pmc_grow_detail.sh > $O/pmc_grow_detail.txt 2>&1; tail -12 $O/pmc_grow_detail.txt
 timeout 1500 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
 python - <<'PY'
 import json
@@ -38,7 +43,5 @@ f=$(find "$ROOT/$O/stats_share" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$ROOT/$O/kernel_stats_share512.csv" && head -5 "$f" | cut -c1-160
 rm -rf "$ROOT/$O/stats_share"
 cd "$ROOT"
-bash tools/pmc_traffic.sh 1536 > $O/pmc_traffic.log 2>&1; tail -3 $O/pmc_traffic.log; cp gpurun_out/pmc/traffic.json $O/hbm_traffic.json 2>/dev/null
-bash tools/pmc_insts.sh 1536 > $O/pmc_insts.txt 2>&1; head -12 $O/pmc_insts.txt; cp gpurun_out/pmcinst/insts.json $O/insts.json 2>/dev/null
-bash tools/pmc_grow_detail.sh > $O/pmc_grow_detail.txt 2>&1; tail -12 $O/pmc_grow_detail.txt
+timeout 700 bash tools/pmc_grow_mem.sh 6144 > $O/pmc_grow_mem.txt 2>&1; grep k_lsd_grow $O/pmc_grow_mem.txt | cut -c1-200
 exit 0
