@@ -369,7 +369,9 @@ void launch_pyr_down5(const uint8_t* src, long long sStride, int sw, int sh, uin
 // thresholds decide it.
 constexpr int LSD_ORDER_CHUNKS = 16;
 constexpr int LSD_ORDER_WORK = LSD_ORDER_CHUNKS * LSD_NBINS + LSD_NBINS + 8;   // u32 per frame: counts / offsets, then thresholds (+ pad)
-__device__ __forceinline__ int lsd_order_chunk(int npix) { return ((npix + LSD_ORDER_CHUNKS - 1) / LSD_ORDER_CHUNKS + 63) / 64 * 64; }
+// pixels per chunk: whole bands of four rows (the record plane is made of 4 x 4 blocks: k_lsd_bin_hist reads whole sectors), a
+// multiple of 64 because the pitch is
+__device__ __forceinline__ int lsd_order_chunk(int spitch, int sh) { return ((((sh + LSD_ORDER_CHUNKS - 1) / LSD_ORDER_CHUNKS) + 3) & ~3) * spitch; }
 __device__ __forceinline__ double lsd_bin_coef(unsigned qmax) {
   return qmax > 0 ? (double)(LSD_NBINS - 1) / sqrt((double)(int)qmax / 4.0) : 0.0;
 }
@@ -398,19 +400,20 @@ __global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
   const uint32_t* Q = a.pix + (long long)b * a.arenaStride;      // level-line records (k_lsd_grad)
   uint32_t* BIN = a.reg + (long long)b * a.arenaStride;          // bin + 1 per pixel, 0 = NOTDEF (scratch)
   uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
-  const int npix = a.spitch * a.sh;
-  const int chunk = lsd_order_chunk(npix);
-  const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
+  const int chunk = lsd_order_chunk(a.spitch, a.sh);
+  const int c0 = wv * chunk, c1 = min(a.spitch * lsd_rec_rows(a.sh), c0 + chunk);   // whole bands (rows beyond sh are skipped below)
   for (int i = lane; i < LSD_NBINS + 1; i += 64) binLo[i] = work[LSD_ORDER_CHUNKS * LSD_NBINS + i];
   for (int i = lane; i < LSD_NBINS; i += 64) hist[i] = 0;
   const float coefF = (float)(lsd_bin_coef(a.qmax[b]) * 0.5);   // sqrt(q / 4) = sqrt(q) / 2
   __syncthreads();
-  // order is irrelevant here, so every lane takes 4 consecutive pixels (16-byte loads / stores; chunk bounds are
-  // multiples of 64)
-  for (int base = c0; base < c1; base += 256) {
-    const int i = base + lane * 4;   // raster index (the bins are written in raster order: the scatter's order)
-    if (i < c1) {
-      const int iy = i / a.spitch, ix = i - iy * a.spitch;
+  // order is irrelevant here: a wavefront takes 64 columns of a band of four rows at a time -- 16 whole blocks of the record
+  // plane, 1 KiB of consecutive sectors; lane = block * 4 + row reads the 16 bytes of its block row and writes the four bins in
+  // raster order (the scatter's order)
+  for (int base = c0; base < c1; base += 256) {   // 256 pixels = 64 columns x 4 rows of the band
+    const int band = base / (4 * a.spitch), x0 = (base - band * 4 * a.spitch) >> 2;   // (the chunk starts on a band; spitch % 64 == 0)
+    const int iy = band * 4 + (lane & 3), ix = x0 + (lane >> 2) * 4;
+    const int i = iy * a.spitch + ix;
+    if (iy < a.sh) {
       const uint4 q4 = *reinterpret_cast<const uint4*>(Q + lsd_rec_index((unsigned)ix, (unsigned)iy, (unsigned)a.spitch));
       const unsigned qq[4] = {q4.x, q4.y, q4.z, q4.w};
       unsigned bb[4];
@@ -479,7 +482,7 @@ __global__ void __launch_bounds__(64) k_lsd_bin_scatter(LineDeviceArgs a) {
   uint32_t* ord = a.ordered + (long long)b * a.arenaStride;
   const uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
   const int npix = a.spitch * a.sh;
-  const int chunk = lsd_order_chunk(npix);
+  const int chunk = lsd_order_chunk(a.spitch, a.sh);
   const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
   if (c0 >= c1) return;
   for (int i = lane; i < LSD_NBINS; i += 64) cur[i] = (int)work[wv * LSD_NBINS + i];
