@@ -3,9 +3,9 @@
 // src/LineExtractor.cpp:39-40 passes as published; oracle/lsd.cc rect_improve / rect_nfa / nfa).
 //
 // k_lsd_rects_adv (lsd_rects.hip) has left every kept region's rectangle in an LsdAdvRec.  From there:
-//   k_adv_scan(-1)               light   the pixel counts of every rectangle's first rect_nfa(), one lane each
+//   k_adv_scan_first             light   the pixel counts of every rectangle's first rect_nfa(), eight lanes each
 //   k_adv_first                  heavy   nfa() of every rectangle; meaningful -> segment, else -> the frame's work list
-//   5 x { k_adv_scan(stage)      light   the pixel counts of the stage's five variants of every listed rectangle, one lane each
+//   5 x { k_adv_scan(stage)      light   the pixel counts of the stage's five variants of every listed rectangle, eight lanes each
 //         k_adv_select(stage) }  heavy   their nfa(), one lane each; the loop's accept rule in order; meaningful -> segment,
 //                                        rejected after the last stage -> dropped, else -> the other work list
 //   k_adv_compact                light   stable compaction of the surviving segments, nSegs
@@ -50,32 +50,49 @@ __global__ void __launch_bounds__(256) k_adv_first(LineDeviceArgs a) {
   if (tid == 0) f.park[0] = (uint32_t)s_n;
 }
 
-// stage -1: the rectangles as region2rect() left them, all n of the frame; stage 0 .. 4: variant m of every listed rectangle
-__global__ void __launch_bounds__(256) k_adv_scan(LineDeviceArgs a, int stage) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+// k_adv_scan_first: the rectangles as region2rect() left them, all n of the frame; k_adv_scan(stage 0 .. 4): variant m of every
+// listed rectangle.
+// Eight lanes per rectangle (lsd_rect_counts_g8): 32 rectangles per pass of the block.
+// (two kernels: the first scan walks every rectangle of the frame and should not carry the registers of the variants' doubles)
+__global__ void __launch_bounds__(256) k_adv_scan_first(LineDeviceArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x, grp = tid >> 3, j = tid & 7;
   const AdvFrame f = adv_frame(a, b);
   RcFrame rf;
   rf.ang = a.advAng + (long long)b * a.scaledStride; rf.spitch = a.spitch; rf.sw = a.sw; rf.sh = a.sh;
-  if (stage < 0) {
-    for (int i = tid; i < f.n; i += 256) {
-      LsdAdvRec* ar = f.rec + i;
-      int total, alg;
-      lsd_rect_counts(rf, lsd_adv_load(ar->r), total, alg);
-      ar->cnt[0][0] = total; ar->cnt[0][1] = alg;
-    }
-    return;
+  for (int base = 0; base < f.n; base += 32) {   // (uniform over the block: the shuffles below are executed by whole wavefronts)
+    const int i = base + grp;
+    const bool on = i < f.n;
+    LsdAdvRec* ar = f.rec + (on ? i : 0);
+    LsdAdvRect r = LsdAdvRect();
+    if (on) r = lsd_adv_load(ar->r);
+    int total, alg;
+    lsd_rect_counts_g8(rf, r, on, j, total, alg);
+    alg += __shfl_xor(alg, 1); alg += __shfl_xor(alg, 2); alg += __shfl_xor(alg, 4);
+    if (on && j == 0) { ar->cnt[0][0] = total; ar->cnt[0][1] = alg; }
   }
+}
+__global__ void __launch_bounds__(256) k_adv_scan(LineDeviceArgs a, int stage) {
+  const int b = blockIdx.x, tid = threadIdx.x, grp = tid >> 3, j = tid & 7;
+  const AdvFrame f = adv_frame(a, b);
+  RcFrame rf;
+  rf.ang = a.advAng + (long long)b * a.scaledStride; rf.spitch = a.spitch; rf.sw = a.sw; rf.sh = a.sh;
   const uint32_t* list = f.park + 2 + (stage & 1) * a.segCap;
   const int na = f.n > 0 ? (int)f.park[stage & 1] : 0;
-  for (int t = tid; t < na * 5; t += 256) {
-    const int q = t / 5, m = t - 5 * q + 1;
-    LsdAdvRec* ar = f.rec + list[q];
-    LsdAdvRect r = lsd_adv_load(ar->r);
-    const bool ok = lsd_adv_variant(stage, m, r);
-    int total = 0, alg = 0;
-    if (ok) lsd_rect_counts(rf, r, total, alg);
-    ar->cnt[m - 1][0] = total; ar->cnt[m - 1][1] = alg;
-    ar->ok[m - 1] = ok ? 1 : 0;
+  for (int base = 0; base < na * 5; base += 32) {
+    const int t = base + grp;
+    const bool on = t < na * 5;
+    const int q = on ? t / 5 : 0, m = on ? t - 5 * q + 1 : 1;
+    LsdAdvRec* ar = f.rec + (on ? list[q] : 0);
+    LsdAdvRect r = LsdAdvRect();
+    bool ok = false;
+    if (on) { r = lsd_adv_load(ar->r); ok = lsd_adv_variant(stage, m, r); }
+    int total, alg;
+    lsd_rect_counts_g8(rf, r, ok, j, total, alg);
+    alg += __shfl_xor(alg, 1); alg += __shfl_xor(alg, 2); alg += __shfl_xor(alg, 4);
+    if (on && j == 0) {
+      ar->cnt[m - 1][0] = total; ar->cnt[m - 1][1] = alg;
+      ar->ok[m - 1] = ok ? 1 : 0;
+    }
   }
 }
 
@@ -153,7 +170,7 @@ __global__ void __launch_bounds__(256) k_adv_compact(LineDeviceArgs a) {
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s) {
   const dim3 g(a.batch), b(256);
-  hipLaunchKernelGGL(k_adv_scan, g, b, 0, s, a, -1);
+  hipLaunchKernelGGL(k_adv_scan_first, g, b, 0, s, a);
   hipLaunchKernelGGL(k_adv_first, g, b, 0, s, a);
   for (int stage = 0; stage < 5; stage++) {
     hipLaunchKernelGGL(k_adv_scan, g, b, 0, s, a, stage);

@@ -152,7 +152,10 @@ __device__ __forceinline__ LsdAdvRect lsd_adv_load(const double* q) {
 // point's x where a y is meant).  The scan-line bounds advance by integer steps from an integer start, so row y's span is a
 // closed form of the number of rows walked before it; rows outside the image are skipped before the step update (`continue`),
 // so they do not count.  One float per pixel from the angle plane k_lsd_grad writes for this level (no record -> table chain).
-__device__ __forceinline__ void lsd_rect_counts(const RcFrame& f, const LsdAdvRect& r, int& totalOut, int& algOut) {
+struct LsdScanGeom {   // what the scan of a rectangle's rows needs: the top corner's x, the rows of the left / right corners, the steps
+  int mx, ly, ry, fl, sl, fr, sr, yA, yB;
+};
+__device__ __forceinline__ LsdScanGeom lsd_scan_geom(const RcFrame& f, const LsdAdvRect& r) {
   const double hw = r.width / 2.0, dyhw = r.dy * hw, dxhw = r.dx * hw;
   int ox[4] = {(int)(r.x1 - dyhw), (int)(r.x2 - dyhw), (int)(r.x2 + dyhw), (int)(r.x1 + dyhw)};
   int oy[4] = {(int)(r.y1 + dxhw), (int)(r.y2 + dxhw), (int)(r.y2 - dxhw), (int)(r.y1 - dxhw)};
@@ -182,25 +185,50 @@ __device__ __forceinline__ void lsd_rect_counts(const RcFrame& f, const LsdAdvRe
   const int mx = ox[iMin], my = oy[iMin], lx = ox[iL], ly = oy[iL], rx = ox[iR], ry = oy[iR], tx = ox[iT];
   // integer divisions, and the tail point's x where a y is meant: as published
   // (int arithmetic: corners lie within a rectangle's width of the image, |coordinates| < 2^15, so steps x rows stay below 2^31)
-  const int fl = (my != ly) ? (mx - lx) / (my - ly) : 0, sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
-  const int fr = (my != ry) ? (mx - rx) / (my - ry) : 0, sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
-  const int yA = max(my, 0), yB = min(oy[iMax], f.sh - 1);   // the scan lines inside the image
+  LsdScanGeom g;
+  g.mx = mx; g.ly = ly; g.ry = ry;
+  g.fl = (my != ly) ? (mx - lx) / (my - ly) : 0; g.sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
+  g.fr = (my != ry) ? (mx - rx) / (my - ry) : 0; g.sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
+  g.yA = max(my, 0); g.yB = min(oy[iMax], f.sh - 1);   // the scan lines inside the image
+  return g;
+}
+// the span of scan line y (yA <= y <= yB), clipped to the image; empty when xb < xa
+__device__ __forceinline__ void lsd_scan_span(const LsdScanGeom& g, int sw, int y, int& xa, int& xb) {
+  // steps taken in front of row y: one per row of [yA, y), the first kind for the rows above the left (right) corner
+  const int j = y - g.yA;
+  const int nl = max(min(y, g.ly) - g.yA, 0), nr = max(min(y, g.ry) - g.yA, 0);
+  const int left = g.mx + g.fl * nl + g.sl * (j - nl), right = g.mx + g.fr * nr + g.sr * (j - nr);
+  xa = max(left, 0); xb = min(right, sw - 1);
+}
+__device__ __forceinline__ bool lsd_aligned_deg(double theta, float angDeg, double prec) {
+  return angDeg >= 0.f && lsd_aligned(theta, (double)angDeg * kDegToRads, prec);
+}
+// EIGHT LANES per rectangle: lane j of the group takes pixel xa + j (+ 8, + 16, ...) of every scan line, so that a group reads
+// runs of consecutive floats (one cache line per scan line and group where a lane per rectangle touched 64 lines per load), two
+// scan lines in flight at a time.  `on`: the group has a rectangle (uniform in the group).  totalOut is the rectangle's pixel
+// count (the same in all eight lanes), algOut THIS LANE's share of the aligned pixels: the caller adds the eight up.  The counts
+// are sums over pixels, so how the pixels are dealt to lanes does not matter.
+__device__ __forceinline__ void lsd_rect_counts_g8(const RcFrame& f, const LsdAdvRect& r, bool on, int j, int& totalOut, int& algOut) {
   int total = 0, alg = 0;
-  for (int y = yA; y <= yB; ++y) {
-    // steps taken in front of row y: one per row of [yA, y), the first kind for the rows above the left (right) corner
-    const int j = y - yA;
-    const int nl = max(min(y, ly) - yA, 0), nr = max(min(y, ry) - yA, 0);
-    const int left = mx + fl * nl + sl * (j - nl), right = mx + fr * nr + sr * (j - nr);
-    const int xa = max(left, 0), xb = min(right, f.sw - 1);
-    const float* row = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
-    if (xb >= xa) total += xb - xa + 1;
-    for (int x = xa; x <= xb; x += 4) {   // four independent loads in flight
-      float an[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) an[k] = x + k <= xb ? row[x + k] : -1024.f;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (an[k] >= 0.f && lsd_aligned(r.theta, (double)an[k] * kDegToRads, r.prec)) ++alg;
+  if (on) {
+    const LsdScanGeom g = lsd_scan_geom(f, r);
+    for (int y = g.yA; y <= g.yB; y += 2) {
+      int xa0, xb0, xa1 = 1, xb1 = 0;
+      lsd_scan_span(g, f.sw, y, xa0, xb0);
+      if (y + 1 <= g.yB) lsd_scan_span(g, f.sw, y + 1, xa1, xb1);
+      if (xb0 >= xa0) total += xb0 - xa0 + 1;
+      if (xb1 >= xa1) total += xb1 - xa1 + 1;
+      const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
+      const float* row1 = row0 + f.spitch;
+      float a0 = -1024.f, a1 = -1024.f;   // NOTDEF
+      if (xa0 + j <= xb0) a0 = row0[xa0 + j];
+      if (xa1 + j <= xb1) a1 = row1[xa1 + j];
+      if (lsd_aligned_deg(r.theta, a0, r.prec)) ++alg;
+      if (lsd_aligned_deg(r.theta, a1, r.prec)) ++alg;
+      for (int x = xa0 + 8 + j; x <= xb0; x += 8)
+        if (lsd_aligned_deg(r.theta, row0[x], r.prec)) ++alg;
+      for (int x = xa1 + 8 + j; x <= xb1; x += 8)
+        if (lsd_aligned_deg(r.theta, row1[x], r.prec)) ++alg;
     }
   }
   totalOut = total; algOut = alg;
