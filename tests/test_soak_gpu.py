@@ -173,7 +173,7 @@ def test_soak_refine_adv(plslam, oracle, synth, rows, cols, und):
     """The same kind of content with cv::LSD_REFINE_ADV (rect_improve / rect_nfa / nfa on every kept rectangle): 128 distinct
     frames per shape -- 640x480, 1241x376, and 640x480 behind the TUM1 undistortion with one of the reference's masks -- one
     wavefront per frame and the automatic multi-wavefront choice, against the oracle's ADV restatement."""
-    n = min(N_SOAK, 128)
+    n = min(N_SOAK, int(os.environ.get("PLSLAM_SOAK_ADV_FRAMES", "128")))   # (the oracle's nfa() is the slow side: 128 by default)
     frames = soak_frames(synth, rows, cols, n)
     K, D, mask = None, None, None
     src = frames
