@@ -57,17 +57,10 @@ class FrontEndBatch:
         self.ws = z((self.ws_bytes,), torch.uint8)
         # the line chain is the critical path (image prep -> region growing -> LBD): high priority, so that its
         # streaming kernels are dispatched first and the ORB kernels fill in underneath the region growing
-        import os
-        mode = os.environ.get("PLSLAM_PIPE", "")            # scheduling experiments (tools/gpu_pipe_modes.sh); default: two streams per part
-        self.line_stream = torch.cuda.Stream(device=self.dev, priority=0 if mode == "eqprio0" else -1)
-        if mode == "same":          # one stream per part: line chain, then the ORB chain
-            self.orb_stream = self.line_stream
-        elif mode == "shared_orb":  # every part's ORB chain on one low-priority stream
-            if not hasattr(FrontEndBatch, "_shared_orb"):
-                FrontEndBatch._shared_orb = torch.cuda.Stream(device=self.dev, priority=0)
-            self.orb_stream = FrontEndBatch._shared_orb
-        else:
-            self.orb_stream = torch.cuda.Stream(device=self.dev, priority=-1 if mode == "eqprio" else 0)
+        # (other layouts -- equal priorities, one stream per part, one ORB stream for all parts -- were measured in rounds 2 and 3
+        # and stay within the run-to-run spread or lose)
+        self.line_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+        self.orb_stream = torch.cuda.Stream(device=self.dev, priority=0)
         self.ev_start = torch.cuda.Event()
         self.ev_orb = torch.cuda.Event()
         self.ev_line = torch.cuda.Event()
