@@ -105,7 +105,7 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=0, budget_s=8.0):
+def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=None, budget_s=8.0):
     """The oracle on the host cores, natively threaded (oracle/frontend.cc plo_frontend_batch: one std::thread per worker, each
     with its own ORB handle and buffers): per frame ORB + (remap) + lines + BoW transform + both matchers against the worker's
     previous frame -- the work of one product step per frame.  Legs: one thread, one per physical core, one per hardware thread,
@@ -120,6 +120,7 @@ def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=0, 
                                     [C.c_int, C.c_int, C.c_int, C.c_void_p]
     frames = np.ascontiguousarray(frames)
     n, rows, cols = frames.shape
+    refine = O.REFERENCE_REFINE if refine is None else int(refine)   # None: the reference's level (LSD_REFINE_ADV, oracle/plo.py)
     mx = my = None
     if K is not None and D is not None and any(D):
         mx = np.zeros((rows, cols), np.float32)
@@ -169,7 +170,7 @@ def cpu_baseline(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=0, 
                       "count of the best leg" % (cols, rows, " (LSD_REFINE_ADV)" if refine else "")}
 
 
-def oracle_records(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=0):
+def oracle_records(O, V, frames, voc, nfeatures, nlevels, nlines, K, D, refine=None):
     """Everything one step produces for `frames` (consecutive frames of a batch), from the CPU oracle, on all host cores:
     per frame keypoints / rBRIEF / FeatureVector nodes / words / BowVector / keylines / LBD / line equations, and per
     consecutive pair the SearchByBoW and SearchDouble match lists.  The checker of `verify_records`, nothing else."""

@@ -134,7 +134,8 @@ int main(int argc, char** argv) {
   CHECK(plh_vocab_load_text(argv[10], 0, &voc));
 
   plh_frontend_params p;
-  std::memset(&p, 0, sizeof(p));
+  std::memset(&p, 0, sizeof(p));   // (lsd_refine = 0 = PLH_FRONTEND_REFINE_LIBRARY: the library's default)
+  p.struct_size = (uint32_t)sizeof(p);
   p.rows = rows; p.cols = cols;
   p.orb.nfeatures = nfeatures; p.orb.scale_factor = 1.2f; p.orb.nlevels = 8; p.orb.ini_th_fast = 20; p.orb.min_th_fast = 7;
   p.line.num_octaves = 1; p.line.scale = 1.2f; p.line.n_lsd_feature = (uint32_t)nlines; p.line.min_line_length = 0.0;
@@ -151,7 +152,7 @@ int main(int argc, char** argv) {
   } else if (rows == 376 && cols == 1241) {  // Examples/Monocular/KITTI00-02.yaml: zero distortion, no remap (Frame.cc:917-921)
     std::printf("camera: KITTI00-02.yaml\n");
   }
-  p.lsd_refine = refine;
+  p.lsd_refine = refine < 0 ? PLH_FRONTEND_REFINE_LIBRARY : 1 + refine;
   std::printf("cv::LineSegmentDetector refine level: %s\n",
               (refine < 0 ? plh_lsd_refine_default() : refine) == PLH_LSD_REFINE_ADV ? "LSD_REFINE_ADV" : "LSD_REFINE_STD");
   p.bow_levelsup = 4; p.orb_th_low = 50; p.orb_nnratio = 0.7f; p.orb_check_orientation = 1; p.line_th = 50.f; p.line_nnratio = 0.7f;

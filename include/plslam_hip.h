@@ -625,18 +625,20 @@ PLH_API plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs
                                               const uint8_t* d_mask, plh_keyline* d_keylines, uint8_t* d_desc,
                                               double* d_linefn, int32_t* d_n, void* stream);
 /* The refine level of the cv::LineSegmentDetector behind LSDDetector::detect (LineExtractor.cpp:39-40).
- * PLH_LSD_REFINE_STD (default): region2rect + refine(), what the line_descriptor twin in the reference's tree creates
- * (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:149, createLineSegmentDetector() with its default).
- * PLH_LSD_REFINE_ADV: additionally rect_improve() -- a rectangle is kept only if its NFA says it is meaningful, after up to five
- * kinds of adjustment -- which is what the SYSTEM opencv_contrib LSDDetector (the one LineExtractor.cpp actually links) passes as
- * published for 3.x.  A maintainer picks the one his OpenCV build uses. */
+ * PLH_LSD_REFINE_ADV (the library's default since round 5): region2rect + refine() + rect_improve() -- a rectangle is kept only
+ * if its NFA says it is meaningful, after up to five kinds of adjustment.  This is what the SYSTEM opencv_contrib LSDDetector
+ * passes as published for 3.x (createLineSegmentDetector(LSD_REFINE_ADV)), and the system module is the one LineExtractor.cpp
+ * links (include/auxiliar.h:11-16 includes <opencv2/line_descriptor/descriptor.hpp>; the twin in the tree is commented out).
+ * PLH_LSD_REFINE_STD: without rect_improve(): what the un-linked line_descriptor twin in the reference's tree creates
+ * (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:149, createLineSegmentDetector() with its default).  A maintainer
+ * whose OpenCV build differs picks the other one. */
 #define PLH_LSD_REFINE_STD 0
 #define PLH_LSD_REFINE_ADV 1
-/* What a new handle starts with.  Chosen when the library is BUILT (-DPLH_LSD_REFINE_DEFAULT=PLH_LSD_REFINE_ADV), so that a
- * drop-in for a reference build whose OpenCV runs LSD_REFINE_ADV does not inherit STD unknowingly;
- * plh_lsd_refine_default() reports the choice of the loaded library. */
+/* What a new handle starts with.  Chosen when the library is BUILT (-DPLH_LSD_REFINE_DEFAULT=PLH_LSD_REFINE_STD for the other
+ * one), so that a drop-in does not inherit a level unknowingly; plh_lsd_refine_default() reports the
+ * choice of the loaded library. */
 #ifndef PLH_LSD_REFINE_DEFAULT
-#define PLH_LSD_REFINE_DEFAULT PLH_LSD_REFINE_STD
+#define PLH_LSD_REFINE_DEFAULT PLH_LSD_REFINE_ADV
 #endif
 PLH_API int plh_lsd_refine_default(void);
 PLH_API plh_status plh_line_set_refine(plh_line* h, int level);
@@ -655,6 +657,10 @@ PLH_API plh_status plh_line_set_grow_events(plh_line* h, void* wait_before, void
  * Frame.cc:224-227) run several wavefronts per frame as optimistic transactions with in-order commit, large batches one
  * wavefront per frame; 0: always one; n in 2..16: always n.  The segments are identical in every setting. */
 PLH_API plh_status plh_line_set_grow_waves(plh_line* h, int waves);
+/* Allocates now what the first plh_line_extract_batch_dev call with `batch` frames would allocate at the current settings (the
+ * several-wavefronts-per-frame workspace: ~36 MB per 640x480 frame at 8 wavefronts; LSD_REFINE_ADV's records), so that a host
+ * that builds its pipeline up front sees PLH_ERR_ALLOC here and not at its first step.  plh_frontend_create calls it. */
+PLH_API plh_status plh_line_reserve(plh_line* h, int batch);
 /* Tuning of the several-wavefronts-per-frame schedule (same segments for any value): run_ahead = how many seeds a wavefront may
  * start ahead of the commits (1..448, default 448), drain_gap = posted transactions that make a wavefront commit (>= 1, default
  * 8).  Values <= 0 restore the defaults. */
@@ -683,7 +689,16 @@ PLH_API plh_status plh_line_read_segments(plh_line* h, int b, float* out_xyxy, i
  * ------------------------------------------------------------------------------------------- */
 typedef struct plh_frontend plh_frontend;
 
+/* plh_frontend_params::lsd_refine.  0 -- what a zero-initialised struct holds -- is the LIBRARY's default, so that the usual C
+ * idiom does not silently force a level; the two explicit levels are 1 + PLH_LSD_REFINE_*. */
+#define PLH_FRONTEND_REFINE_LIBRARY 0
+#define PLH_FRONTEND_REFINE_STD 1
+#define PLH_FRONTEND_REFINE_ADV 2
+
 typedef struct plh_frontend_params {
+  uint32_t struct_size;            /* sizeof(plh_frontend_params) of the header the caller was compiled against: plh_frontend_create
+                                      refuses any other value instead of reading past an older caller's struct (ABI break of
+                                      round 5) */
   int32_t rows, cols;
   plh_orb_params orb;              /* ORBextractor(nFeatures, fScaleFactor, nLevels, fIniThFAST, fMinThFAST), Tracking.cc:96-131 */
   plh_line_params line;            /* LINEextractor(1, scale, nLSDFeature, min_line_length) */
@@ -695,8 +710,8 @@ typedef struct plh_frontend_params {
   int32_t orb_check_orientation;
   float line_th, line_nnratio;     /* LSDmatcher::SearchDouble: TH_LOW = 50, mfNNratio */
   int32_t external_records;        /* 1: the caller supplies the record buffers (plh_frontend_bind_records) */
-  int32_t lsd_refine;              /* PLH_LSD_REFINE_STD / PLH_LSD_REFINE_ADV for every sub-batch's LINEextractor; -1: the library's
-                                      default (PLH_LSD_REFINE_DEFAULT) */
+  int32_t lsd_refine;              /* PLH_FRONTEND_REFINE_LIBRARY (0: the library's default, plh_lsd_refine_default()),
+                                      PLH_FRONTEND_REFINE_STD, PLH_FRONTEND_REFINE_ADV: every sub-batch's LINEextractor */
 } plh_frontend_params;
 
 /* Device pointers of one sub-batch's records, frames [first, first + frames) of the batch.  Per-frame arrays have

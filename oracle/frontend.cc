@@ -116,6 +116,13 @@ double plo_frontend_batch(const uint8_t* frames, int n, int rows, int cols, int 
     for (auto& x : th) x.join();
   }
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  // back to glibc's documented defaults (128 KiB thresholds, no padding) and the arenas' free tops returned: the tuning above is
+  // for this call, not for whatever the process measures afterwards.  (glibc's adaptive mmap threshold stays off once
+  // any of these has been set; the static defaults are what it starts from.)
+  mallopt(M_MMAP_THRESHOLD, 128 << 10);
+  mallopt(M_TRIM_THRESHOLD, 128 << 10);
+  mallopt(M_TOP_PAD, 0);
+  malloc_trim(0);
   unsigned long long s = 0;
   for (unsigned long long v : sums) s += v;
   if (checksum) *checksum = s;

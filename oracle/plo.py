@@ -19,16 +19,30 @@ KL_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), (
 assert KP_DTYPE.itemsize == 28 and KL_DTYPE.itemsize == 68
 
 
+def _stale():
+    if not os.path.exists(_SO):
+        return True
+    t = os.path.getmtime(_SO)
+    deps = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cc", ".h", "Makefile"))]
+    deps.append(os.path.join(_HERE, "..", "include", "plh_orb_pattern.inc"))
+    return any(os.path.getmtime(f) > t for f in deps if os.path.exists(f))
+
+
 def build(force=False):
-    """Compile the oracle with g++ (make).  Rebuilds when a source is newer than the .so."""
-    stale = not os.path.exists(_SO)
-    if not stale:
-        t = os.path.getmtime(_SO)
-        deps = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cc", ".h", "Makefile"))]
-        deps.append(os.path.join(_HERE, "..", "include", "plh_orb_pattern.inc"))
-        stale = any(os.path.getmtime(f) > t for f in deps if os.path.exists(f))
-    if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    """Compile the oracle with g++ (make).  Rebuilds when a source is newer than the .so.  Safe to call from several processes
+    at once (the ranks of a multi-GPU bench.py each verify their own batch): the check and the make run under an exclusive file
+    lock, so a second caller waits and then finds the library fresh instead of dlopen()ing a half-written file."""
+    if not (force or _stale()):
+        return _SO
+    import fcntl
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    with open(os.path.join(os.path.dirname(_SO), ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if force or _stale():
+                subprocess.check_call(["make", "-C", _HERE, "-s"])
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return _SO
 
 
@@ -186,8 +200,21 @@ def knn2(q, t):
     return idx, dist
 
 
-def lsd_detect(img, cap=20000, refine=0):
-    """cv::LineSegmentDetector(LSD_REFINE_STD).detect -> float32 [n,4] (x1,y1,x2,y2)."""
+# The refine level of the cv::LineSegmentDetector the reference runs: src/LineExtractor.cpp:39-40 creates the SYSTEM
+# opencv_contrib LSDDetector (include/auxiliar.h:11-16 includes <opencv2/line_descriptor/descriptor.hpp>; the twin under
+# Thirdparty/line_descriptor is commented out there), and the published 3.x module creates its detector with
+# cv::LSD_REFINE_ADV.  `refine=None` below means this level; 0 / 1 select LSD_REFINE_STD (what the un-linked twin creates,
+# LSDDetector_custom.cpp:149 -- the goldens ref_line_* come from that twin) / LSD_REFINE_ADV explicitly.
+REFERENCE_REFINE = 1
+
+
+def _refine(level):
+    return REFERENCE_REFINE if level is None else int(level)
+
+
+def lsd_detect(img, cap=20000, refine=None):
+    """cv::LineSegmentDetector(refine).detect -> float32 [n,4] (x1,y1,x2,y2); refine=None: REFERENCE_REFINE (LSD_REFINE_ADV)."""
+    refine = _refine(refine)
     img = np.ascontiguousarray(img, np.uint8)
     segs = np.zeros((cap, 4), np.float32)
     n = lib().plo_lsd_detect_ex(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(segs), cap, int(refine))
@@ -215,8 +242,10 @@ class ReferenceThrows(RuntimeError):
     """The reference raises (cv::pyrDown's size assertion) or runs into undefined behaviour for this configuration."""
 
 
-def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None, refine=0, num_octaves=1, scale=1.2):
-    """LINEextractor(num_octaves, scale, ...)::operator() -> (keylines[KL_DTYPE], desc[n,32], linefn[n,3])."""
+def line_extract(img, n_lsd_feature=200, min_line_length=0.0, mask=None, refine=None, num_octaves=1, scale=1.2):
+    """LINEextractor(num_octaves, scale, ...)::operator() -> (keylines[KL_DTYPE], desc[n,32], linefn[n,3]); refine=None:
+    REFERENCE_REFINE (LSD_REFINE_ADV, see above)."""
+    refine = _refine(refine)
     img = np.ascontiguousarray(img, np.uint8)
     cap = n_lsd_feature + 1
     kl = np.zeros(cap, KL_DTYPE)

@@ -17,7 +17,7 @@ OUT="$HERE/../_ref"
 mkdir -p "$OUT"
 [ -f "$OUT/plo_frame_search.o" ] || bash "$HERE/build_ref.sh" "$REF"
 PLO_OBJS="$OUT/plo_frame_search.o $OUT/plo_match.o $OUT/plo_img_ops.o $OUT/plo_lsd.o"
-FLAGS="-O2 -std=c++14 -fPIC -w -pthread -ffp-contract=off -fno-fast-math -DPLH_LSD_REFINE_DEFAULT=0 -DPLO_REAL_FRAME -DPLO_REAL_KEYFRAME -DMAP_H -DCONVERTER_H -DLOCALMAPPING_H -DKEYFRAMEDATABASE_H"
+FLAGS="-O2 -std=c++14 -fPIC -w -pthread -ffp-contract=off -fno-fast-math -DPLH_LSD_REFINE_DEFAULT=1 -DPLO_REAL_FRAME -DPLO_REAL_KEYFRAME -DMAP_H -DCONVERTER_H -DLOCALMAPPING_H -DKEYFRAMEDATABASE_H"
 INC="-I $ROOT/pl-slam_amd/adaptor -I $ROOT/include -I $HERE/stub -I $HERE/stub/eigen3 -I $LD/include -I $REF/include -I $REF -include $HERE/frame_stub.h"
 # what the maintainer adds to every translation unit of the reference
 DROPIN="-include $ROOT/pl-slam_amd/adaptor/plslam_hip_dropin.h"

@@ -49,6 +49,9 @@ void* adx_tracker_create(int nfeatures, float scale, int nlevels, int ini_th, in
   t->line = new LINEextractor(1, 1.2f, (unsigned)nlines, min_line_length);
   return t;
 }
+// LINEextractor::SetRefine: cv::LineSegmentDetector's level (the harness is built with -DPLH_LSD_REFINE_DEFAULT=1, LSD_REFINE_ADV;
+// the goldens of the reference's un-linked twin are LSD_REFINE_STD)
+void adx_tracker_set_refine(void* h, int level) { ((Tracker*)h)->line->SetRefine(level); }
 void adx_tracker_destroy(void* h) {
   Tracker* t = (Tracker*)h;
   delete t->orb;

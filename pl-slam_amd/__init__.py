@@ -42,7 +42,7 @@ class LineParams(C.Structure):
 
 
 class FrontendParams(C.Structure):   # plh_frontend_params
-    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("orb", OrbParams), ("line", LineParams), ("undistort", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("rows", C.c_int32), ("cols", C.c_int32), ("orb", OrbParams), ("line", LineParams), ("undistort", C.c_int32),
                 ("K", C.c_float * 4), ("D", C.c_float * 5), ("bow_levelsup", C.c_int32), ("orb_th_low", C.c_int32),
                 ("orb_nnratio", C.c_float), ("orb_check_orientation", C.c_int32), ("line_th", C.c_float), ("line_nnratio", C.c_float),
                 ("external_records", C.c_int32), ("lsd_refine", C.c_int32)]
@@ -113,6 +113,7 @@ _SIGS = {
     "plh_line_set_grow_events": ([_V, _V, _V], _I),
     "plh_line_set_grow_waves": ([_V, _I], _I),
     "plh_line_set_refine": ([_V, _I], _I),
+    "plh_line_reserve": ([_V, _I], _I),
     "plh_line_set_screen": ([_V, _I], _I),
     "plh_line_set_grow_tuning": ([_V, _I, _I], _I),
     "plh_lsd_refine_default": ([], _I),

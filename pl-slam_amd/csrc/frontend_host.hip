@@ -138,6 +138,16 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     set_error("plh_frontend_create: invalid argument (batch %d must be a positive multiple of nsplit %d)", batch, nsplit);
     return PLH_ERR_INVALID;
   }
+  if (p->struct_size != sizeof(plh_frontend_params)) {   // a caller compiled against another header: do not read its struct
+    set_error("plh_frontend_create: plh_frontend_params::struct_size is %u, this library's struct has %zu bytes (set it to "
+              "sizeof(plh_frontend_params); a mismatch means the caller was built against another plslam_hip.h)",
+              p->struct_size, sizeof(plh_frontend_params));
+    return PLH_ERR_INVALID;
+  }
+  if (p->lsd_refine != PLH_FRONTEND_REFINE_LIBRARY && p->lsd_refine != PLH_FRONTEND_REFINE_STD && p->lsd_refine != PLH_FRONTEND_REFINE_ADV) {
+    set_error("plh_frontend_create: lsd_refine must be PLH_FRONTEND_REFINE_LIBRARY (0), _STD (1) or _ADV (2)");
+    return PLH_ERR_INVALID;
+  }
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   PLH_HIP(hipSetDevice(device));
   plh_frontend* fe = new (std::nothrow) plh_frontend();
@@ -163,9 +173,12 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     // ONE quantity decides both the wavefronts per frame of LSD's region growing and the schedule that goes with them: the
     // frames resident in ALL sub-batches (they run together).  Up to 1024: eight wavefronts per frame (k_lsd_grow_mw) and the
     // ORB chain around region growing (plh_frontend_step); above: one wavefront per frame, the ORB chain underneath.
+    // (-1 = the extractor's own choice by batch size -- plh_line_set_grow_waves: 8 up to 1024 frames, measured; the sub-batch is at
+    // most the resident batch, so it takes the multi-wavefront kernel exactly when `around` is set)
     fe->around = batch <= 1024;
-    FE_TRY(plh_line_set_grow_waves(pt.line, fe->around ? 8 : 0));
-    if (p->lsd_refine >= 0) FE_TRY(plh_line_set_refine(pt.line, p->lsd_refine));
+    FE_TRY(plh_line_set_grow_waves(pt.line, fe->around ? -1 : 0));
+    if (p->lsd_refine != PLH_FRONTEND_REFINE_LIBRARY) FE_TRY(plh_line_set_refine(pt.line, p->lsd_refine - 1));   // (1 + PLH_LSD_REFINE_*)
+    FE_TRY(plh_line_reserve(pt.line, pt.B));   // workspace now: an out-of-memory condition belongs to create, not to the first step
     pt.ocap = plh_orb_capacity(pt.orb); pt.lcap = plh_line_capacity(pt.line);
     const size_t B1 = (size_t)pt.B + 1, oc = (size_t)pt.ocap, lc = (size_t)pt.lcap;
     FE_TRY(dev_alloc(fe, &pt.valid, (size_t)pt.B * oc, true));

@@ -22,6 +22,8 @@ size_t lsd_order_work_u32();
 void launch_lsd_grow(const LineDeviceArgs& a, hipStream_t s);
 plh_status lsd_grow_request_lds();
 void launch_lsd_rects(const LineDeviceArgs& a, hipStream_t s);
+void launch_lsd_lgamma_table(double* t, int n, hipStream_t s);
+size_t lsd_adv_rec_bytes();
 void launch_pyr_down5(const uint8_t* src, long long sStride, int sw, int sh, uint8_t* dst, long long dStride, int dw, int dh, int batch,
                       hipStream_t s);
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s);
@@ -72,7 +74,8 @@ struct plh_line {
   int rszTP = 0, rszTR = 0;   // k_resize_u8 source tile of a 256 x 16 output block (pitch in bytes, rows)
   // device buffers
   uint8_t *dUndist = nullptr, *dTmpA = nullptr, *dScaled = nullptr, *dMask = nullptr;
-  void* dAdv = nullptr;   // LSD_REFINE_ADV: maxBatch x segCap LsdAdvRec (144 bytes each), allocated by the first extract call at that level
+  void* dAdv = nullptr;   // LSD_REFINE_ADV: maxBatch x segCap LsdAdvRec + the angle planes, allocated by the first extract call at that level
+  double* dLgamma = nullptr;   // ... and lsd_log_gamma(i), i = 1 .. sw sh + 1 (nfa()'s arguments are integers: lsd_rect_dev.h)
   uint32_t *dArena = nullptr, *dDxdy = nullptr;   // dArena: per-frame blocks (line_plan.h, arenaStride)
   // multi-wavefront region growing (small batches): transaction logs and private mark planes, allocated on first use
   uint32_t* dMwReg = nullptr;
@@ -179,7 +182,7 @@ plh_status plh_line_destroy(plh_line* h) {
     h->oct1->doneEv = nullptr;   // (the parent's event, shared)
     plh_line_destroy(h->oct1);
   }
-  void* ptrs[] = {h->dOctImg, h->dAdv, h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark, h->dMwHint,
+  void* ptrs[] = {h->dOctImg, h->dAdv, h->dLgamma, h->dUndist, h->dTmpA, h->dScaled, h->dMask, h->dArena, h->dDxdy, h->dQmax, h->dMwReg, h->dMwMark, h->dMwHint,
                   h->dNOrdered, h->dNSegs, h->dStatus, h->dMap, h->dCoef, h->dXtab, h->dYtab, h->dImgs, h->dDesc,
                   h->dKl, h->dFn, h->dN};
   for (void* p : ptrs)
@@ -490,25 +493,46 @@ plh_status plh_line_set_grow_events(plh_line* h, void* wait_before, void* record
   return PLH_OK;
 }
 
-// What a launch sequence needs besides the plan: the multi-wavefront workspace for this batch size, the LSD_REFINE_ADV buffers.
-static plh_status line_prepare(plh_line* h, LineDeviceArgs& a, int batch) {
+// What a launch sequence needs besides the plan: the multi-wavefront workspace for this batch size, the LSD_REFINE_ADV buffers
+// (the log_gamma table is filled on `s`, in front of the kernels that read it).
+static plh_status line_prepare(plh_line* h, LineDeviceArgs& a, int batch, hipStream_t s) {
   const int waves = mw_waves_for(h, batch);
   if (waves > 0) {
     const plh_status st = mw_reserve(h, a, batch, waves);
     if (st != PLH_OK) return st;
   }
   if (a.refineAdv) {
-    const size_t recBytes = align_up<size_t>((size_t)h->maxBatch * a.segCap * 144, 256);
+    const size_t recBytes = align_up<size_t>((size_t)h->maxBatch * a.segCap * lsd_adv_rec_bytes(), 256);
     if (!h->dAdv && hipMalloc(&h->dAdv, recBytes + (size_t)h->maxBatch * a.scaledStride * 4) != hipSuccess) {
       (void)hipGetLastError();
       set_error("plh_line_extract: cannot allocate the LSD_REFINE_ADV rectangle records (%d frames x %d)", h->maxBatch, a.segCap);
       return PLH_ERR_ALLOC;
     }
+    if (!h->dLgamma) {
+      const int n = a.sw * a.sh + 2;   // a rectangle counts at most every pixel of the scaled image: arguments 1 .. sw sh + 1
+      if (hipMalloc((void**)&h->dLgamma, (size_t)n * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("plh_line_extract: cannot allocate the log_gamma table (%d entries)", n);
+        return PLH_ERR_ALLOC;
+      }
+      launch_lsd_lgamma_table(h->dLgamma, n, s);
+      PLH_LAUNCH_CHECK();
+    }
     a.adv = reinterpret_cast<LsdAdvRec*>(h->dAdv);
     a.advAng = reinterpret_cast<float*>(static_cast<uint8_t*>(h->dAdv) + recBytes);
+    a.lgamma = h->dLgamma;
   } else {
-    a.adv = nullptr; a.advAng = nullptr;
+    a.adv = nullptr; a.advAng = nullptr; a.lgamma = nullptr;
   }
+  return PLH_OK;
+}
+
+// An abandoned multi-wavefront launch (status bit 4) leaves private marks behind; the planes must be zero between transactions.
+// Both octaves: the second one shares the parent's status word but has mark planes of its own.
+static plh_status line_reset_mw_marks(plh_line* h) {
+  PLH_HIP(hipDeviceSynchronize());   // nothing of this device may still be running on the planes (error path: cost is no concern)
+  for (plh_line* q = h; q; q = q->oct1)
+    if (q->dMwMark) PLH_HIP(hipMemset(q->dMwMark, 0, (size_t)q->mwWaveSlots * q->a.scaledStride));
   return PLH_OK;
 }
 
@@ -554,7 +578,7 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
   a.mask = d_mask;
   const uint8_t* src = d_imgs;
   long long srcStride = (long long)frame_stride;
-  plh_status st = line_prepare(h, a, batch);
+  plh_status st = line_prepare(h, a, batch, s);
   if (st != PLH_OK) return st;
   PLH_HIP(hipMemsetAsync(h->dStatus, 0, 4, s));   // capacity flags of this call only (plh_line_status)
   if (h->hasUndistort) {
@@ -573,7 +597,7 @@ plh_status plh_line_extract_batch_dev(plh_line* h, const uint8_t* d_imgs, int ba
     a1.refineAdv = a.refineAdv; a1.screen = a.screen;
     a1.status = h->dStatus;
     h1->growWaves = h->growWaves; h1->mwLag = h->mwLag; h1->mwDrainGap = h->mwDrainGap;
-    st = line_prepare(h1, a1, batch);
+    st = line_prepare(h1, a1, batch, s);
     if (st != PLH_OK) return st;
     launch_pyr_down5(src, srcStride, a.w, a.h, h->dOctImg, a1.fullStride, a1.w, a1.h, batch, s);
     PLH_LAUNCH_CHECK();
@@ -648,10 +672,7 @@ plh_status plh_line_extract(plh_line* h, const uint8_t* img, int rows, int cols,
   int stf = 0;
   PLH_HIP(hipMemcpy(&stf, h->dStatus, 4, hipMemcpyDeviceToHost));
   if (stf) {
-    if ((stf & 16) && h->dMwMark) {
-      (void)hipDeviceSynchronize();
-      (void)hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride);
-    }
+    if (stf & 16) (void)line_reset_mw_marks(h);
     set_error("line kernels reported a capacity overflow or an abandoned launch (flags 0x%x)", stf);
     return PLH_ERR_CAPACITY;
   }
@@ -663,10 +684,26 @@ plh_status plh_line_status(plh_line* h, int* flags) {
   PLH_HIP(hipSetDevice(h->device));
   if (h->doneValid) PLH_HIP(hipEventSynchronize(h->doneEv));
   PLH_HIP(hipMemcpy(flags, h->dStatus, 4, hipMemcpyDeviceToHost));
-  if ((*flags & 16) && h->dMwMark) {   // an abandoned launch leaves private marks behind: the planes must be zero between transactions
-    PLH_HIP(hipDeviceSynchronize());   // nothing of this device may still be running on the planes (error path: cost is no concern)
-    PLH_HIP(hipMemset(h->dMwMark, 0, (size_t)h->mwWaveSlots * h->a.scaledStride));
+  if (*flags & 16) return line_reset_mw_marks(h);   // an abandoned launch: the workspace of both octaves is re-initialised
+  return PLH_OK;
+}
+
+// Allocate now what plh_line_extract_batch_dev would allocate on its first call with `batch` frames at the current settings (refine
+// level, wavefronts per frame): the multi-wavefront workspace is tens of GB for a thousand KITTI frames, and a host that builds its
+// pipeline up front wants an out-of-memory condition at create time, not at the first step.
+plh_status plh_line_reserve(plh_line* h, int batch) {
+  if (!h || batch <= 0 || batch > h->maxBatch) {
+    set_error("plh_line_reserve: invalid argument (batch %d, plan max %d)", batch, h ? h->maxBatch : 0);
+    return PLH_ERR_INVALID;
   }
+  PLH_HIP(hipSetDevice(h->device));
+  for (plh_line* q = h; q; q = q->oct1) {
+    if (q != h) { q->growWaves = h->growWaves; q->a.refineAdv = h->a.refineAdv; }
+    LineDeviceArgs a = q->a;
+    const plh_status st = line_prepare(q, a, batch, h->stream);
+    if (st != PLH_OK) return st;
+  }
+  PLH_HIP(hipStreamSynchronize(h->stream));   // (the log_gamma table, if it was filled just now)
   return PLH_OK;
 }
 

@@ -101,8 +101,9 @@ struct LineDeviceArgs {
   // exact rectangle for every decision (the path every undecided region takes anyway: same segments; an A/B and test switch)
   float screenLo, screenHi;
   int screen;
-  uint32_t* park;           // LSD_REFINE_ADV: per frame [0], [1] = lengths of two lists of slots (segCap words each, from word 2): the
-                            // rectangles still in rect_improve(), read from one list and written to the other stage by stage
+  uint32_t* park;           // per frame 2 + 2 segCap words: [0] = length of LSD_REFINE_ADV's work list; from word 2: k_lsd_rects' size-class
+                            // order of the kept regions (segCap words), then the work list (slots of the rectangles in rect_improve())
+  const double* lgamma;     // LSD_REFINE_ADV: lsd_log_gamma(i) for i = 1 .. sw sh + 1 (every argument nfa() can have), per handle
   LsdAdvRec* adv;           // LSD_REFINE_ADV: segCap records per frame (lsd_rect_dev.h), allocated when the level is first used
   float* advAng;            // LSD_REFINE_ADV: level-line angle per scaled pixel in float degrees (-1024 = NOTDEF), written by k_lsd_grad:
                             // rect_nfa()'s scan reads one float per pixel instead of record -> table; scaledStride floats per frame

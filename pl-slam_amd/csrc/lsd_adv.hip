@@ -2,17 +2,22 @@
 // (cv::LineSegmentDetector created with LSD_REFINE_ADV: what the system opencv_contrib LSDDetector behind
 // src/LineExtractor.cpp:39-40 passes as published; oracle/lsd.cc rect_improve / rect_nfa / nfa).
 //
-// k_lsd_rects_adv (lsd_rects.hip) has left every kept region's rectangle in an LsdAdvRec.  From there:
-//   k_adv_scan_first             light   the pixel counts of every rectangle's first rect_nfa(), eight lanes each
-//   k_adv_first                  heavy   nfa() of every rectangle; meaningful -> segment, else -> the frame's work list
-//   5 x { k_adv_scan(stage)      light   the pixel counts of the stage's five variants of every listed rectangle, eight lanes each
-//         k_adv_select(stage) }  heavy   their nfa(), one lane each; the loop's accept rule in order; meaningful -> segment,
-//                                        rejected after the last stage -> dropped, else -> the other work list
-//   k_adv_compact                light   stable compaction of the surviving segments, nSegs
-// One block per frame everywhere; a frame's kernels are ordered by the stream.  Why the five variants of a stage are independent:
-// lsd_adv_variant (lsd_rect_dev.h).  Why two kinds of kernels: nfa() needs > 200 registers for its library math, and a kernel
-// that also walks the rectangles' pixels with that register budget ran one wavefront per SIMD on dependent gathers (the first two
-// versions of this stage: profiles/r04_kernel_stats_adv_v2.csv).
+// k_lsd_rects_adv (lsd_rects.hip) has left every kept region's rectangle in an LsdAdvRec.  From there (round 5: three launches
+// of one-wavefront blocks instead of thirteen of 256-thread blocks):
+//   k_adv_first     every rectangle's first rect_nfa(): the pixel counts eight lanes per rectangle, then nfa() one lane per
+//                   rectangle; meaningful -> segment, else -> the frame's work list
+//   k_adv_improve   rect_improve() of the listed rectangles, eight lanes per rectangle through all five stages: a stage's five
+//                   variants follow from its starting rectangle alone (lsd_adv_variant, lsd_rect_dev.h), so their pixel counts
+//                   are taken one after the other by the eight lanes (the two "finer precision" stages share one walk:
+//                   lsd_rect_counts_g8_prec5), their nfa() side by side in five of the eight lanes, and the loop's
+//                   `if (v > log_nfa)` is replayed in order; meaningful -> segment, rejected after the last stage -> dropped
+//   k_adv_compact   stable compaction of the surviving segments, nSegs
+// Rectangles are independent of each other: nothing here is ordered except the compaction.
+//
+// History (profiles/r04_kernel_stats_adv_*.csv, r05_adv_*): round 4 ran scan and nfa() in separate kernels per stage because nfa()
+// with its two log_gamma() evaluations needed 194 registers; thirteen launches of block-per-frame kernels, each of which had to
+// find a CU with four free wave slots beside the region-growing wavefronts of the other sub-batches (10 ms alone, 60 - 70 ms on
+// the line chain inside the pipeline).  With log_gamma() a table lookup (LineDeviceArgs::lgamma) one kernel holds both halves.
 #include "lsd_rect_dev.h"
 
 namespace plh {
@@ -21,162 +26,182 @@ struct AdvFrame {
   int n;
   uint4* ent;
   LsdAdvRec* rec;
-  uint32_t* park;   // [0], [1]: lengths of the two work lists; list k at park + 2 + k * segCap
+  uint32_t* count;   // length of the work list (zeroed by k_lsd_rects_sort)
+  uint32_t* list;    // slots of the rectangles that go on to rect_improve(), in no particular order
 };
 __device__ __forceinline__ AdvFrame adv_frame(const LineDeviceArgs& a, int b) {
   AdvFrame f;
   f.n = min(a.nSegs[b], a.segCap);
   f.ent = reinterpret_cast<uint4*>(a.segs + (long long)b * a.arenaStride);
   f.rec = a.adv + (long long)b * a.segCap;
-  f.park = a.park + (long long)b * a.arenaStride;
+  uint32_t* park = a.park + (long long)b * a.arenaStride;
+  f.count = park;                 // park[0]
+  f.list = park + 2 + a.segCap;   // (the first segCap words behind park[2] hold k_lsd_rects' size-class order)
   return f;
 }
-
-__global__ void __launch_bounds__(256) k_adv_first(LineDeviceArgs a) {
-  __shared__ int s_n;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const AdvFrame f = adv_frame(a, b);
-  uint32_t* list = f.park + 2;
-  if (tid == 0) s_n = 0;
-  __syncthreads();
-  for (int i = tid; i < f.n; i += 256) {
-    LsdAdvRec* ar = f.rec + i;
-    const double v = lsd_nfa(ar->cnt[0][0], ar->cnt[0][1], a.p, a.logNT);
-    ar->log_nfa = v;
-    if (v > 0.0) lsd_store_segment(&f.ent[i], ar->r);          // LOG_EPS = 0: meaningful as it is
-    else list[atomicAdd(&s_n, 1)] = (uint32_t)i;               // rect_improve()
-  }
-  __syncthreads();
-  if (tid == 0) f.park[0] = (uint32_t)s_n;
-}
-
-// k_adv_scan_first: the rectangles as region2rect() left them, all n of the frame; k_adv_scan(stage 0 .. 4): variant m of every
-// listed rectangle.
-// Eight lanes per rectangle (lsd_rect_counts_g8): 32 rectangles per pass of the block.
-// (two kernels: the first scan walks every rectangle of the frame and should not carry the registers of the variants' doubles)
-__global__ void __launch_bounds__(256) k_adv_scan_first(LineDeviceArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x, grp = tid >> 3, j = tid & 7;
-  const AdvFrame f = adv_frame(a, b);
+__device__ __forceinline__ RcFrame adv_field(const LineDeviceArgs& a, int b) {
   RcFrame rf;
   rf.ang = a.advAng + (long long)b * a.scaledStride; rf.spitch = a.spitch; rf.sw = a.sw; rf.sh = a.sh;
-  for (int base = 0; base < f.n; base += 32) {   // (uniform over the block: the shuffles below are executed by whole wavefronts)
-    const int i = base + grp;
-    const bool on = i < f.n;
-    LsdAdvRec* ar = f.rec + (on ? i : 0);
-    LsdAdvRect r = LsdAdvRect();
-    if (on) r = lsd_adv_load(ar->r);
-    int total, alg;
-    lsd_rect_counts_g8(rf, r, on, j, total, alg);
-    alg += __shfl_xor(alg, 1); alg += __shfl_xor(alg, 2); alg += __shfl_xor(alg, 4);
-    if (on && j == 0) { ar->cnt[0][0] = total; ar->cnt[0][1] = alg; }
-  }
+  return rf;
 }
-__global__ void __launch_bounds__(256) k_adv_scan(LineDeviceArgs a, int stage) {
-  const int b = blockIdx.x, tid = threadIdx.x, grp = tid >> 3, j = tid & 7;
+// sum over the eight lanes of a rectangle's group
+__device__ __forceinline__ int adv_sum8(int v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+  return v;
+}
+
+constexpr int ADV_FIRST_GROUPS = 24;     // one-wavefront blocks per frame (64 rectangles per pass each)
+constexpr int ADV_IMPROVE_GROUPS = 32;   // ... (8 rectangles per pass each)
+
+// lsd_log_gamma(i) for i = 1 .. n - 1 (t[0] is never read)
+__global__ void __launch_bounds__(256) k_lsd_lgamma_table(double* t, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) t[i] = i >= 1 ? lsd_log_gamma((double)i) : 0.0;
+}
+size_t lsd_adv_rec_bytes() { return kLsdAdvRecBytes; }   // (line_host.hip sizes the per-frame record buffer)
+void launch_lsd_lgamma_table(double* t, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_lsd_lgamma_table, dim3((n + 255) / 256), dim3(256), 0, s, t, n);
+}
+
+__global__ void __launch_bounds__(64) k_adv_first(LineDeviceArgs a) {
+  __shared__ int s_tot[64], s_alg[64];
+  const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7;
   const AdvFrame f = adv_frame(a, b);
-  RcFrame rf;
-  rf.ang = a.advAng + (long long)b * a.scaledStride; rf.spitch = a.spitch; rf.sw = a.sw; rf.sh = a.sh;
-  const uint32_t* list = f.park + 2 + (stage & 1) * a.segCap;
-  const int na = f.n > 0 ? (int)f.park[stage & 1] : 0;
-  for (int base = 0; base < na * 5; base += 32) {
-    const int t = base + grp;
-    const bool on = t < na * 5;
-    const int q = on ? t / 5 : 0, m = on ? t - 5 * q + 1 : 1;
-    LsdAdvRec* ar = f.rec + (on ? list[q] : 0);
-    LsdAdvRect r = LsdAdvRect();
-    bool ok = false;
-    if (on) { r = lsd_adv_load(ar->r); ok = lsd_adv_variant(stage, m, r); }
-    int total, alg;
-    lsd_rect_counts_g8(rf, r, ok, j, total, alg);
-    alg += __shfl_xor(alg, 1); alg += __shfl_xor(alg, 2); alg += __shfl_xor(alg, 4);
-    if (on && j == 0) {
-      ar->cnt[m - 1][0] = total; ar->cnt[m - 1][1] = alg;
-      ar->ok[m - 1] = ok ? 1 : 0;
+  const RcFrame rf = adv_field(a, b);
+  for (int base = (int)blockIdx.x * 64; base < f.n; base += 64 * ADV_FIRST_GROUPS) {
+    // the pixel counts of 64 rectangles, eight at a time, eight lanes each (lsd_rect_counts_g8)
+    for (int it = 0; it < 8; it++) {
+      const int i = base + it * 8 + grp;
+      const bool on = i < f.n;
+      LsdAdvRect r = LsdAdvRect();
+      if (on) r = lsd_adv_load(f.rec[i].r);
+      int total, alg;
+      lsd_rect_counts_g8(rf, r, on, j, total, alg);
+      alg = adv_sum8(alg);
+      if (j == 0) { s_tot[it * 8 + grp] = total; s_alg[it * 8 + grp] = alg; }
     }
-  }
-}
-
-constexpr int ADV_GROUP = 256;   // rectangles selected at a time (5 evaluations each)
-__global__ void __launch_bounds__(256) k_adv_select(LineDeviceArgs a, int stage) {
-  __shared__ double s_v[ADV_GROUP * 5];
-  __shared__ int s_n;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const AdvFrame f = adv_frame(a, b);
-  const uint32_t* list = f.park + 2 + (stage & 1) * a.segCap;
-  uint32_t* next = f.park + 2 + ((stage + 1) & 1) * a.segCap;
-  const int na = f.n > 0 ? (int)f.park[stage & 1] : 0;
-  if (tid == 0) s_n = 0;
-  __syncthreads();
-  for (int base = 0; base < na; base += ADV_GROUP) {
-    const int ng = min(ADV_GROUP, na - base);
-    for (int t = tid; t < ng * 5; t += 256) {   // one evaluation per lane and pass
-      const int q = t / 5, m = t - 5 * q + 1;
-      const LsdAdvRec* ar = f.rec + list[base + q];
-      double v = 0;
-      if (ar->ok[m - 1]) {
-        double p = ar->r[9];
-        if (stage == 0 || stage == 4)
-          for (int j = 0; j < m; j++) p /= 2;   // (the variant's p: the two precision stages halve it per iteration)
-        v = lsd_nfa(ar->cnt[m - 1][0], ar->cnt[m - 1][1], p, a.logNT);
+    PLH_WAVE_SYNC();
+    // nfa(): one lane per rectangle
+    const int i = base + lane;
+    if (i < f.n) {
+      LsdAdvRec* ar = f.rec + i;
+      const double v = lsd_nfa(s_tot[lane], s_alg[lane], a.p, a.logNT, a.lgamma);
+      if (v > 0.0) {
+        lsd_store_segment(&f.ent[i], ar->r);                       // LOG_EPS = 0: meaningful as it is
+      } else {
+        ar->log_nfa = v;
+        f.list[atomicAdd(f.count, 1u)] = (uint32_t)i;              // rect_improve()
       }
-      s_v[t] = v;
     }
-    __syncthreads();
-    if (tid < ng) {   // the loop's `if (v > log_nfa)` over the stage's variants, in order
-      const int slot = (int)list[base + tid];
-      LsdAdvRec* ar = f.rec + slot;
-      double log_nfa = ar->log_nfa;
+    PLH_WAVE_SYNC();
+  }
+}
+
+__global__ void __launch_bounds__(64) k_adv_improve(LineDeviceArgs a) {
+  const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7, g0 = lane & ~7;
+  const AdvFrame f = adv_frame(a, b);
+  const RcFrame rf = adv_field(a, b);
+  const int na = f.n > 0 ? (int)*f.count : 0;
+  for (int base = (int)blockIdx.x * 8; base < na; base += 8 * ADV_IMPROVE_GROUPS) {   // (uniform: the shuffles below are executed by the whole wavefront)
+    const int q = base + grp;
+    bool active = q < na;
+    const int slot = active ? (int)f.list[q] : 0;
+    LsdAdvRect r = LsdAdvRect();
+    double log_nfa = 0.0;
+    if (active) { r = lsd_adv_load(f.rec[slot].r); log_nfa = f.rec[slot].log_nfa; }
+    for (int stage = 0; stage < 5; stage++) {
+      if (!__any(active)) break;
+      // (total, aligned) pixel counts of the stage's variants m = 1 .. 5, the same in all eight lanes of the group
+      int tot[5], alg[5];
+      bool ok[5];
+      if (stage == 0 || stage == 4) {   // finer precision: one rectangle, five tolerances
+        LsdAdvRect rv = r;
+        double prec[5];
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+          ok[m] = active && lsd_adv_variant(stage, 1, rv);   // (one more iteration each: rv after m + 1 of them)
+          prec[m] = rv.prec;
+        }
+        int total;
+        lsd_rect_counts_g8_prec5(rf, r, ok[0], j, prec, total, alg);   // (the gate of stage 4 does not move: all five or none)
+#pragma unroll
+        for (int m = 0; m < 5; m++) { tot[m] = total; alg[m] = adv_sum8(alg[m]); }
+      } else {
+#pragma unroll 1
+        for (int m = 0; m < 5; m++) {
+          LsdAdvRect rv = r;
+          const bool okm = active && lsd_adv_variant(stage, m + 1, rv);
+          int total, al;
+          lsd_rect_counts_g8(rf, rv, okm, j, total, al);
+          al = adv_sum8(al);
+          // (m is a loop counter, not a constant: the arrays are written through selects so that they stay in registers)
+#pragma unroll
+          for (int k = 0; k < 5; k++)
+            if (k == m) { ok[k] = okm; tot[k] = total; alg[k] = al; }
+        }
+      }
+      // nfa() of variant j + 1 in lane j < 5 of the group
+      double v = 0.0;
+      {
+        int myTot = 0, myAlg = 0;
+        bool myOk = false;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+          if (k == j) { myTot = tot[k]; myAlg = alg[k]; myOk = ok[k]; }
+        if (myOk) {
+          double p = r.p;
+          if (stage == 0 || stage == 4)
+            for (int k = 0; k <= j; k++) p /= 2;   // (the variant's p: the two precision stages halve it per iteration)
+          v = lsd_nfa(myTot, myAlg, p, a.logNT, a.lgamma);
+        }
+      }
+      // the loop's `if (v > log_nfa)` over the stage's variants, in order (every lane of the group replays it)
       int best = 0;
-      for (int m = 1; m <= 5; m++)
-        if (ar->ok[m - 1] && s_v[tid * 5 + m - 1] > log_nfa) { log_nfa = s_v[tid * 5 + m - 1]; best = m; }
-      if (best) {
-        LsdAdvRect r = lsd_adv_load(ar->r);
-        (void)lsd_adv_variant(stage, best, r);
-        ar->r[0] = r.x1; ar->r[1] = r.y1; ar->r[2] = r.x2; ar->r[3] = r.y2; ar->r[4] = r.width; ar->r[8] = r.prec; ar->r[9] = r.p;
-        ar->log_nfa = log_nfa;
+#pragma unroll
+      for (int m = 0; m < 5; m++) {
+        const double vm = __shfl(v, g0 + m);
+        if (ok[m] && vm > log_nfa) { log_nfa = vm; best = m + 1; }
       }
-      if (log_nfa > 0.0) lsd_store_segment(&f.ent[slot], ar->r);            // meaningful: the remaining stages are skipped
-      else if (stage == 4) f.ent[slot] = uint4{RC_DROPPED, 0u, 0u, 0u};     // log_nfa <= LOG_EPS after all five: no segment
-      else next[atomicAdd(&s_n, 1)] = (uint32_t)slot;
+      if (best) (void)lsd_adv_variant(stage, best, r);
+      if (active) {
+        if (log_nfa > 0.0) {   // meaningful: the remaining stages are skipped
+          if (j == 0) {
+            const double rec[4] = {r.x1, r.y1, r.x2, r.y2};
+            lsd_store_segment(&f.ent[slot], rec);
+          }
+          active = false;
+        } else if (stage == 4) {   // log_nfa <= LOG_EPS after all five: no segment
+          if (j == 0) f.ent[slot] = uint4{RC_DROPPED, 0u, 0u, 0u};
+          active = false;
+        }
+      }
     }
-    __syncthreads();
   }
-  if (tid == 0) f.park[(stage + 1) & 1] = (uint32_t)s_n;
 }
 
-// stable compaction of the surviving segments (a slot moves down or stays: chunks in order never overwrite unread input)
-__global__ void __launch_bounds__(256) k_adv_compact(LineDeviceArgs a) {
-  __shared__ int s_wave[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// stable compaction of the surviving segments, one wavefront per frame (a slot moves down or stays: chunks in order never
+// overwrite unread input)
+__global__ void __launch_bounds__(64) k_adv_compact(LineDeviceArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   const AdvFrame f = adv_frame(a, b);
   int outBase = 0;
-  for (int c0 = 0; c0 < f.n; c0 += 256) {
-    const int i = c0 + tid;
+  for (int c0 = 0; c0 < f.n; c0 += 64) {
+    const int i = c0 + lane;
     uint4 v = uint4{RC_DROPPED, 0u, 0u, 0u};
     if (i < f.n) v = f.ent[i];
     const bool valid = v.x != RC_DROPPED;
     const unsigned long long bm = __ballot(valid);
-    if (lane == 0) s_wave[wv] = __popcll(bm);
-    __syncthreads();
-    int off = __popcll(bm & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wv; w++) off += s_wave[w];
-    const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if (valid) f.ent[outBase + off] = v;
-    outBase += tot;
-    __syncthreads();
+    PLH_WAVE_SYNC();   // (all loads of the chunk are done before a lane stores into it)
+    if (valid) f.ent[outBase + __popcll(bm & ((1ull << lane) - 1ull))] = v;
+    outBase += __popcll(bm);
   }
-  if (tid == 0) a.nSegs[b] = outBase;
+  if (lane == 0) a.nSegs[b] = outBase;
 }
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s) {
-  const dim3 g(a.batch), b(256);
-  hipLaunchKernelGGL(k_adv_scan_first, g, b, 0, s, a);
-  hipLaunchKernelGGL(k_adv_first, g, b, 0, s, a);
-  for (int stage = 0; stage < 5; stage++) {
-    hipLaunchKernelGGL(k_adv_scan, g, b, 0, s, a, stage);
-    hipLaunchKernelGGL(k_adv_select, g, b, 0, s, a, stage);
-  }
-  hipLaunchKernelGGL(k_adv_compact, g, b, 0, s, a);
+  hipLaunchKernelGGL(k_adv_first, dim3(ADV_FIRST_GROUPS, a.batch), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_adv_improve, dim3(ADV_IMPROVE_GROUPS, a.batch), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_adv_compact, dim3(a.batch), dim3(64), 0, s, a);
 }
 
 }  // namespace plh

@@ -1816,10 +1816,17 @@ __device__ __forceinline__ int kl_item(const KlFrame& f, int i, float e[4], int&
   return o1 ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
+// One wavefront per frame (round 5): a 256-thread block needs a free wave slot and 96 registers on all four SIMDs of one CU at the
+// same moment, which the region-growing wavefronts of the other sub-batches rarely leave -- 0.6 ms alone, 17 ms inside the
+// pipeline on the line chain's critical path; a lone wavefront goes wherever one slot is free.
+#ifndef PLH_KL_THREADS
+#define PLH_KL_THREADS 64
+#endif
+constexpr int KL_THREADS = PLH_KL_THREADS;
+__global__ void __launch_bounds__(KL_THREADS) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   unsigned long long* sel = (unsigned long long*)smem;   // [outCap]
-  __shared__ unsigned long long s_red[4];
+  __shared__ unsigned long long s_red[KL_THREADS / 64];
   __shared__ int s_valid, s_keep;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   KlFrame f;
@@ -1834,7 +1841,7 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
   if (tid == 0) s_valid = 0;
   __syncthreads();
   int myValid = 0;
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += KL_THREADS) {
     float e[4], sc;
     int w, h;
     kl_item(f, i, e, w, h, sc);
@@ -1854,7 +1861,7 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
   int K = 0;
   for (int k = 0; k < a.outCap; k++) {
     unsigned long long best = 0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += KL_THREADS) {
       const unsigned long long v = keys[i];
       if (v < prev && v > best) best = v;
     }
@@ -1866,7 +1873,7 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
     if (lane == 0) s_red[wv] = best;
     __syncthreads();
     best = s_red[0];
-    for (int w = 1; w < 4; w++) best = s_red[w] > best ? s_red[w] : best;
+    for (int w = 1; w < KL_THREADS / 64; w++) best = s_red[w] > best ? s_red[w] : best;
     if (best == 0) break;
     if (tid == 0) sel[k] = best;
     prev = best;
@@ -1897,7 +1904,7 @@ __global__ void __launch_bounds__(256) k_keylines(LineDeviceArgs a, plh_keyline*
   }
   __syncthreads();
   const int keep = s_keep;
-  for (int k = tid; k < keep; k += 256) {
+  for (int k = tid; k < keep; k += KL_THREADS) {
     const int i = (int)(0xffffffffu - (unsigned)(sel[k] & 0xffffffffull));
     float e[4], sc;
     int w, h;
@@ -2251,7 +2258,7 @@ plh_status lsd_grow_request_lds() {
   return st;
 }
 void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* n, hipStream_t s) {
-  hipLaunchKernelGGL(k_keylines, dim3(a.batch), dim3(256), (size_t)a.outCap * 8 + 64, s, a, kl, fn, n);
+  hipLaunchKernelGGL(k_keylines, dim3(a.batch), dim3(KL_THREADS), (size_t)a.outCap * 8 + 64, s, a, kl, fn, n);
 }
 void launch_sobel(const LineDeviceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_sobel_pack, dim3((a.w + 1023) / 1024, a.h, a.batch), dim3(256), 0, s, a);

@@ -74,12 +74,17 @@ __device__ __attribute__((noinline)) static double lsd_log_gamma(double x) {
   return a + log(b);
 }
 
-__device__ __attribute__((noinline)) static double lsd_nfa(int n, int k, double p, double logNT) {
+// nfa()'s log_gamma() is only ever asked for integers -- k + 1 and n - k + 1 with n, k pixel counts of a rectangle, at most the
+// scaled image's pixel count -- so the handle keeps lsd_log_gamma(i) for every i it can be asked for (LineDeviceArgs::lgamma,
+// filled once by k_lsd_lgamma_table with the function above: the same doubles).  Round 4 evaluated the two calls per nfa():
+// Lanczos below 15 (seven log + pow pairs: every well-aligned rectangle, where n - k is small) or Windschitl (log, sinh, pow) --
+// most of a 194-register kernel.  What is left is log(p), log(1 - p), exp, the tail loop and log10.
+__device__ __forceinline__ double lsd_nfa(int n, int k, double p, double logNT, const double* lgamma) {
   if (n == 0 || k == 0) return -logNT;
   if (n == k) return -logNT - double(n) * log10(p);
   const double p_term = p / (1 - p);
   // (n + 1) where the original algorithm has log_gamma(n + 1): as published (oracle/lsd.cc)
-  const double log1term = (double(n) + 1) - lsd_log_gamma(double(k) + 1) - lsd_log_gamma(double(n - k) + 1) + double(k) * log(p) +
+  const double log1term = (double(n) + 1) - lgamma[k + 1] - lgamma[n - k + 1] + double(k) * log(p) +
                           (double(n - k)) * log(1.0 - p);
   double term = exp(log1term);
   {
@@ -122,18 +127,16 @@ struct LsdRegionEntry {
 // ---------------------------------------------------------------------------------------------
 // LSD_REFINE_ADV on the kept regions' rectangles (lsd_rects.hip computes them, lsd_adv.hip improves them).  rect_improve()
 // reads the immutable level-line field only and decides only whether the segment is kept, so it runs per rectangle, not per
-// frame -- and in kernels of two kinds, because its two halves want opposite things from the machine:
-//   * rect_nfa()'s scan of the rectangle's pixels is a chain of dependent gathers: light kernels, many wavefronts resident;
-//   * nfa() is a few thousand instructions of double-precision library math (log, exp, pow, sinh) per evaluation and no memory:
-//     heavy kernels (> 200 registers), one lane per evaluation.
-// Between them a rectangle lives in an LsdAdvRec (a lazily allocated buffer of segCap records per frame).
+// frame.  Its two halves: rect_nfa()'s scan of the rectangle's pixels (eight lanes per rectangle along the scan lines, one float
+// per pixel) and nfa() (one lane per evaluation; with log_gamma() from the handle's table it is log, exp and a short tail loop).
+// Between the kernels a rectangle lives in an LsdAdvRec (a lazily allocated buffer of segCap records per frame).
 // ---------------------------------------------------------------------------------------------
 struct alignas(16) LsdAdvRec {
-  double r[10];          // x1 y1 x2 y2 width theta dx dy prec p: the rectangle rect_improve() currently holds
-  double log_nfa;        // its log_nfa
-  int cnt[5][2];         // (total, aligned) pixel counts of the current stage's variants m = 1 .. 5; [0] also serves the first rect_nfa()
-  unsigned char ok[8];   // [m - 1]: variant m exists (the loops' width gate)
+  double r[10];          // x1 y1 x2 y2 width theta dx dy prec p: the rectangle as region2rect() left it (k_lsd_rects_adv)
+  double log_nfa;        // its log_nfa (k_adv_first), for the rectangles that go on to rect_improve() (k_adv_improve)
 };
+constexpr size_t kLsdAdvRecBytes = 96;   // line_host.hip sizes the per-frame buffer with this
+static_assert(sizeof(LsdAdvRec) == kLsdAdvRecBytes, "LsdAdvRec: the host's allocation and the kernels' indexing must agree");
 
 constexpr uint32_t RC_DROPPED = 0xffffffffu;   // first word of a slot whose rectangle LSD_REFINE_ADV rejected (a NaN: never a coordinate)
 
@@ -232,6 +235,55 @@ __device__ __forceinline__ void lsd_rect_counts_g8(const RcFrame& f, const LsdAd
     }
   }
   totalOut = total; algOut = alg;
+}
+
+// The same scan for the two "finer precision" stages of rect_improve(): their five variants share the rectangle and differ in
+// the tolerance only (p / 2^m, prec = p pi), so ONE walk over the pixels counts all five: the folded angle difference of a
+// pixel is computed once (lsd_aligned's own expressions) and compared with the five tolerances.
+__device__ __forceinline__ double lsd_fold_diff(double theta, float angDeg) {   // lsd_aligned()'s n_theta; +inf for NOTDEF
+  if (!(angDeg >= 0.f)) return __builtin_inf();
+  double n_theta = theta - (double)angDeg * kDegToRads;
+  if (n_theta < 0) n_theta = -n_theta;
+  if (n_theta > k3_2PI) {
+    n_theta -= k2PI;
+    if (n_theta < 0) n_theta = -n_theta;
+  }
+  return n_theta;
+}
+__device__ __forceinline__ void lsd_rect_counts_g8_prec5(const RcFrame& f, const LsdAdvRect& r, bool on, int j, const double prec[5],
+                                                         int& totalOut, int alg[5]) {
+  int total = 0;
+#pragma unroll
+  for (int m = 0; m < 5; m++) alg[m] = 0;
+  if (on) {
+    const LsdScanGeom g = lsd_scan_geom(f, r);
+    for (int y = g.yA; y <= g.yB; y += 2) {   // two scan lines in flight, as lsd_rect_counts_g8
+      int xa0, xb0, xa1 = 1, xb1 = 0;
+      lsd_scan_span(g, f.sw, y, xa0, xb0);
+      if (y + 1 <= g.yB) lsd_scan_span(g, f.sw, y + 1, xa1, xb1);
+      if (xb0 >= xa0) total += xb0 - xa0 + 1;
+      if (xb1 >= xa1) total += xb1 - xa1 + 1;
+      const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
+      const float* row1 = row0 + f.spitch;
+      float a0 = -1024.f, a1 = -1024.f;   // NOTDEF
+      if (xa0 + j <= xb0) a0 = row0[xa0 + j];
+      if (xa1 + j <= xb1) a1 = row1[xa1 + j];
+      const double d0 = lsd_fold_diff(r.theta, a0), d1 = lsd_fold_diff(r.theta, a1);
+#pragma unroll
+      for (int m = 0; m < 5; m++) alg[m] += (d0 <= prec[m] ? 1 : 0) + (d1 <= prec[m] ? 1 : 0);
+      for (int x = xa0 + 8 + j; x <= xb0; x += 8) {
+        const double d = lsd_fold_diff(r.theta, row0[x]);
+#pragma unroll
+        for (int m = 0; m < 5; m++) alg[m] += d <= prec[m] ? 1 : 0;
+      }
+      for (int x = xa1 + 8 + j; x <= xb1; x += 8) {
+        const double d = lsd_fold_diff(r.theta, row1[x]);
+#pragma unroll
+        for (int m = 0; m < 5; m++) alg[m] += d <= prec[m] ? 1 : 0;
+      }
+    }
+  }
+  totalOut = total;
 }
 
 // One variant of rect_improve(): the rectangle R after `m` iterations (1 .. 5) of stage `stage`'s loop body.  The loops modify

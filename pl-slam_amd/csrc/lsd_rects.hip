@@ -12,13 +12,11 @@
 //
 // LSD_REFINE_ADV (rect_improve / rect_nfa / nfa, lsd_rect_dev.h) reads the immutable level-line field only and decides only
 // whether the segment is kept: k_lsd_rects_adv leaves the rectangle in an LsdAdvRec, and lsd_adv.hip runs rect_nfa() / nfa() /
-// rect_improve() on them (light scan kernels and heavy nfa kernels alternating, the five variants
-// of each rect_improve() stage side by side), followed by a stable compaction of the surviving segments.
+// rect_improve() on them, followed by a stable compaction of the surviving segments.
 #include "lsd_rect_dev.h"
 
 namespace plh {
 
-constexpr int RC_CHUNK = 4096;   // entries sorted and evaluated at a time
 constexpr int RC_BINS = 128;
 
 // floor(log2) of the size and its next two bits: sizes within a class differ by less than a quarter
@@ -29,7 +27,7 @@ __device__ __forceinline__ int rc_size_class(unsigned cnt) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The kernels.  One block (4 wavefronts) per frame.
+// The kernels (k_lsd_rects_sort, k_lsd_rects[_adv] below).
 //   1. the entries are sorted by size class (largest first), 64 consecutive ones go to the lanes of a wavefront;
 //   2. the wavefront stages its 64 regions' pixels through LDS, RC_K per lane at a time: packed coordinates from the frame's log
 //      and gx^2 + gy^2 from the array beside it (written by region growing, which had the record in hand), loaded 8 regions x 8
@@ -164,68 +162,78 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
 
 // ADV = false: LSD_REFINE_STD, every rectangle is a segment.  ADV = true: the rectangle goes to its slot's LsdAdvRec; lsd_adv.hip
 // takes it from there.
-template <bool ADV>
-__device__ __forceinline__ void lsd_rects_frame(const LineDeviceArgs& a) {
-  __shared__ uint32_t s_order[RC_CHUNK];
+// Round 5: two kernels.  The one-block-per-frame form (256 threads, 46.6 KB of LDS, 170 registers) could not be placed on a CU
+// whose LDS the region-growing wavefronts of the other sub-batches hold (24 x 5 KiB of 160): alone 2.0 ms per 1536 frames, inside
+// the pipeline 16 ms on the line chain's critical path.  k_lsd_rects_sort leaves the size-class order in the frame's park area
+// (a light block per frame, 512 bytes of LDS); k_lsd_rects_sums runs ONE WAVEFRONT per block (7.4 KB of LDS) on 64 consecutive
+// entries of that order, RC_GROUPS blocks per frame taking the groups round robin (the largest regions first, so the blocks of a
+// frame end together).  Which lane evaluates a region changes nothing about its sums.
+constexpr int RC_GROUPS = 32;
+
+__global__ void __launch_bounds__(256) k_lsd_rects_sort(LineDeviceArgs a) {
   __shared__ int s_hist[RC_BINS];
-  __shared__ __attribute__((aligned(16))) double s_w[4 * 64 * RC_PITCH];
-  __shared__ uint32_t s_p[4 * 64 * RC_PITCH];
-  __shared__ uint32_t s_off[4 * 64];
-  __shared__ int s_cnt[4 * 64];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = min(a.nSegs[b], a.segCap);
+  const uint4* ent = reinterpret_cast<const uint4*>(a.segs + (long long)b * a.arenaStride);
+  uint32_t* order = a.park + (long long)b * a.arenaStride + 2;   // (line_plan.h: park = [list length, -, order[segCap], work list[segCap]])
+  if (tid == 0) order[-2] = 0u;   // park[0]: LSD_REFINE_ADV's work list starts empty (k_adv_first appends, lsd_adv.hip)
+  for (int i = tid; i < RC_BINS; i += 256) s_hist[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[rc_size_class(ent[i].y)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = RC_BINS - 1; k >= 0; k--) { const int c = s_hist[k]; s_hist[k] = acc; acc += c; }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) order[atomicAdd(&s_hist[rc_size_class(ent[i].y)], 1)] = (uint32_t)i;
+}
+
+template <bool ADV>
+__device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
+  __shared__ __attribute__((aligned(16))) double s_w[64 * RC_PITCH];
+  __shared__ uint32_t s_p[64 * RC_PITCH];
+  __shared__ uint32_t s_off[64];
+  __shared__ int s_cnt[64];
+  const int b = blockIdx.y, lane = threadIdx.x;
   const int n = min(a.nSegs[b], a.segCap);
   uint4* ent = reinterpret_cast<uint4*>(a.segs + (long long)b * a.arenaStride);
   const uint32_t* log = a.reg + (long long)b * a.arenaStride;
   const uint32_t* logq = a.regq + (long long)b * a.arenaStride;
+  const uint32_t* order = a.park + (long long)b * a.arenaStride + 2;
   double* W = reinterpret_cast<double*>(a.pix + (long long)b * a.arenaStride);   // the records and the seed list behind them are dead by now:
                                                                                 // one double per log entry fits (pix | ordered are adjacent)
   RcStage st;
-  st.p = s_p + wv * 64 * RC_PITCH; st.w = s_w + wv * 64 * RC_PITCH; st.off = s_off + wv * 64; st.cnt = s_cnt + wv * 64;
-  for (int c0 = 0; c0 < n; c0 += RC_CHUNK) {
-    const int m = min(RC_CHUNK, n - c0);
-    // 1. counting sort of the chunk's entries by size class, the largest first (they set the pace of their wavefront)
-    for (int i = tid; i < RC_BINS; i += 256) s_hist[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < m; i += 256) atomicAdd(&s_hist[rc_size_class(ent[c0 + i].y)], 1);
-    __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      for (int k = RC_BINS - 1; k >= 0; k--) { const int c = s_hist[k]; s_hist[k] = acc; acc += c; }
-    }
-    __syncthreads();
-    for (int i = tid; i < m; i += 256) s_order[atomicAdd(&s_hist[rc_size_class(ent[c0 + i].y)], 1)] = (uint32_t)(c0 + i);
-    __syncthreads();
-    // 2., 3. 64 sorted entries per wavefront at a time
-    for (int base = wv * 64; base < m; base += 256) {
-      const int k = base + lane;
-      int slot = -1;
-      uint4 e = uint4{0u, 0u, 0u, 0u};
-      if (k < m) { slot = (int)s_order[k]; e = ent[slot]; }   // LsdRegionEntry
-      double rec[8];
-      rc_wave_region2rect(st, log, logq, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
-      if (slot < 0) continue;
-      if constexpr (!ADV) {
-        lsd_store_segment(&ent[slot], rec);
-      } else {
-        LsdAdvRec* ar = a.adv + (long long)b * a.segCap + slot;
+  st.p = s_p; st.w = s_w; st.off = s_off; st.cnt = s_cnt;
+  for (int base = (int)blockIdx.x * 64; base < n; base += 64 * RC_GROUPS) {
+    const int k = base + lane;
+    int slot = -1;
+    uint4 e = uint4{0u, 0u, 0u, 0u};
+    if (k < n) { slot = (int)order[k]; e = ent[slot]; }   // LsdRegionEntry
+    double rec[8];
+    rc_wave_region2rect(st, log, logq, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+    if (slot < 0) continue;
+    if constexpr (!ADV) {
+      lsd_store_segment(&ent[slot], rec);
+    } else {
+      LsdAdvRec* ar = a.adv + (long long)b * a.segCap + slot;
 #pragma unroll
-        for (int k2 = 0; k2 < 8; k2++) ar->r[k2] = rec[k2];
-        ar->r[8] = a.prec; ar->r[9] = a.p;
-      }
+      for (int k2 = 0; k2 < 8; k2++) ar->r[k2] = rec[k2];
+      ar->r[8] = a.prec; ar->r[9] = a.p;
     }
-    __syncthreads();
   }
 }
-__global__ void __launch_bounds__(256) k_lsd_rects(LineDeviceArgs a) { lsd_rects_frame<false>(a); }
-__global__ void __launch_bounds__(256) k_lsd_rects_adv(LineDeviceArgs a) { lsd_rects_frame<true>(a); }
+__global__ void __launch_bounds__(64) k_lsd_rects(LineDeviceArgs a) { lsd_rects_group<false>(a); }
+__global__ void __launch_bounds__(64) k_lsd_rects_adv(LineDeviceArgs a) { lsd_rects_group<true>(a); }
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s);   // lsd_adv.hip
 void launch_lsd_rects(const LineDeviceArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_lsd_rects_sort, dim3(a.batch), dim3(256), 0, s, a);
   if (!a.refineAdv) {
-    hipLaunchKernelGGL(k_lsd_rects, dim3(a.batch), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_lsd_rects, dim3(RC_GROUPS, a.batch), dim3(64), 0, s, a);
     return;
   }
-  hipLaunchKernelGGL(k_lsd_rects_adv, dim3(a.batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_lsd_rects_adv, dim3(RC_GROUPS, a.batch), dim3(64), 0, s, a);
   launch_lsd_adv(a, s);
 }
 

@@ -202,6 +202,7 @@ class FrontEndPipelined:
             vocab._plh_handle = hv
         self.hvoc = vocab._plh_handle
         fp = P.FrontendParams()
+        fp.struct_size = C.sizeof(P.FrontendParams)
         fp.rows, fp.cols = rows, cols
         fp.orb = P.OrbParams(nfeatures, 1.2, nlevels, 20, 7)
         fp.line = P.LineParams(1, 1.2, n_lines, min_line_length)
@@ -213,7 +214,9 @@ class FrontEndPipelined:
         fp.bow_levelsup, fp.orb_th_low, fp.orb_nnratio, fp.orb_check_orientation = 4, 50, 0.7, 1
         fp.line_th, fp.line_nnratio = 50.0, 0.7
         fp.external_records = 1
-        fp.lsd_refine = int(lsd_refine)   # -1: the library's default (PLH_LSD_REFINE_DEFAULT), 0 STD, 1 ADV
+        # this binding's argument: -1 = the library's default (plh_lsd_refine_default()), 0 = LSD_REFINE_STD, 1 = LSD_REFINE_ADV;
+        # the C struct: PLH_FRONTEND_REFINE_LIBRARY = 0 (what a zeroed struct holds), _STD = 1, _ADV = 2
+        fp.lsd_refine = 0 if int(lsd_refine) < 0 else 1 + int(lsd_refine)
         h = C.c_void_p()
         P._check(L, L.plh_frontend_create(C.byref(fp), self.hvoc.h, batch, nsplit, device, C.byref(h)), "plh_frontend_create")
         self.h = h

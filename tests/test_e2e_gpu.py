@@ -17,7 +17,8 @@ KITTI_D = [0.0, 0.0, 0.0, 0.0, 0.0]                   # :13-16 (rectified sequen
 
 @pytest.mark.parametrize("rows,cols,nfeat,K,D,seed", [(480, 640, 1000, TUM1_K, TUM1_D, 500), (376, 1241, 2000, KITTI_K, KITTI_D, 1500)],
                          ids=["tum1_640x480_1000", "kitti_1241x376_2000"])
-def test_front_end_batch_vs_oracle(plslam, oracle, synth, rows, cols, nfeat, K, D, seed):
+@pytest.mark.parametrize("refine", [None, 0], ids=["default-adv", "std"])   # cv::LineSegmentDetector's level: the library's default
+def test_front_end_batch_vs_oracle(plslam, oracle, synth, rows, cols, nfeat, K, D, seed, refine):   # (LSD_REFINE_ADV) and STD
     """The whole batch front end against the oracle, stage by stage, on both frame shapes the north star names:
     TUM1 (Examples/Monocular/TUM1.yaml: 640x480, 1000 features, distorted) and KITTI 00-02
     (Examples/Monocular/KITTI00-02.yaml:8-51: 1241x376, 2000 features, 4 quad-tree roots, no distortion)."""
@@ -28,6 +29,8 @@ def test_front_end_batch_vs_oracle(plslam, oracle, synth, rows, cols, nfeat, K, 
     frames = synth.make_frames(seed, B, rows, cols)
     voc = V.Vocabulary.synthetic(102, k=10, L=6, synth=synth, idf=True)
     fe = PL.FrontEndBatch(plslam, voc, B, rows, cols, nfeat, 8, 200, 0.0, K, D)
+    if refine is not None:
+        fe.line.set_refine(refine)
     d = torch.from_numpy(frames).cuda()
     fe.step(d)
     fe.step(d)          # second pass over the same buffers: results must not depend on stale state
@@ -56,7 +59,7 @@ def test_front_end_batch_vs_oracle(plslam, oracle, synth, rows, cols, nfeat, K, 
         bw, bv = np.zeros(n, np.int32), np.zeros(n, np.float64)      # mBowVec (TF_IDF / L1_NORM like ORBvoc)
         m = L.plo_bow_vector(O._p(word), n, O._p(voc.word_weight()), 0, 0, O._p(bw), O._p(bv), n)
         assert r["bow_n"][b] == m and (r["bow_word"][b, :m] == bw[:m]).all() and (r["bow_value"][b, :m] == bv[:m]).all()
-        lk, ld, lf, _ = _oracle_line(O, frames[b], 200, 0.0, *((K, D) if any(D) else (None, None)))
+        lk, ld, lf, _ = _oracle_line(O, frames[b], 200, 0.0, *((K, D) if any(D) else (None, None)), refine=refine)
         nl = r["nl"][b]
         _match(r["kl"][b, :nl], r["ldesc"][b, :nl], r["lfn"][b, :nl], lk, ld, lf, "frame %d" % b)
         ref.append((rk, rd, nid, ld))

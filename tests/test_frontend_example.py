@@ -170,13 +170,22 @@ def test_emu_frontend_matches_the_oracle(plslam, oracle, synth, emu_lib):
     hv = P.ORBVocabulary(lib=emu_lib)
     parent, leaf = voc.tree_arrays()
     hv.create(voc.k, voc.L, parent, leaf, voc.node_desc, voc.weight64)
-    fp = P.FrontendParams()
+    fp = P.FrontendParams()   # zero-initialised, as a C caller's memset leaves it: lsd_refine = 0 = PLH_FRONTEND_REFINE_LIBRARY
     fp.rows, fp.cols = rows, cols
     fp.orb = P.OrbParams(nfeat, 1.2, nlev, 20, 7)
     fp.line = P.LineParams(1, 1.2, nlines, 0.0)
     fp.bow_levelsup, fp.orb_th_low, fp.orb_nnratio, fp.orb_check_orientation, fp.line_th, fp.line_nnratio = 4, 50, 0.7, 1, 50.0, 0.7
-    fp.lsd_refine = -1   # the library's default (PLH_LSD_REFINE_DEFAULT = STD)
+    assert fp.lsd_refine == 0 and L.plh_lsd_refine_default() == 1   # ... which is the library's default: LSD_REFINE_ADV
     h = C.c_void_p()
+    # a caller compiled against another header (no / a different struct_size) is refused, not read past its struct
+    assert L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)) == 1 and not h.value  # PLH_ERR_INVALID
+    assert b"struct_size" in L.plh_last_error()
+    fp.struct_size = C.sizeof(P.FrontendParams) - 4
+    assert L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)) == 1 and not h.value  # PLH_ERR_INVALID
+    fp.struct_size = C.sizeof(P.FrontendParams)
+    fp.lsd_refine = 7
+    assert L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)) == 1 and not h.value  # PLH_ERR_INVALID
+    fp.lsd_refine = 0
     P._check(L, L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)), "plh_frontend_create")
     try:
         assert L.plh_frontend_parts(h) == ns

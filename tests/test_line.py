@@ -15,7 +15,9 @@ TUM1_K = [517.306408, 516.469215, 318.643040, 255.313989]           # Examples/M
 TUM1_D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]       # TUM1.yaml:13-17
 
 
-def _oracle_line(O, img, nf, minlen, K=None, D=None, mask=None):
+def _oracle_line(O, img, nf, minlen, K=None, D=None, mask=None, refine=None):
+    """(keylines, LBD, line equations, LSD segments) of the oracle; refine=None: the reference's level = the library's default
+    (LSD_REFINE_ADV, oracle/plo.py REFERENCE_REFINE)."""
     src = img
     if K is not None:
         rows, cols = img.shape
@@ -26,7 +28,7 @@ def _oracle_line(O, img, nf, minlen, K=None, D=None, mask=None):
         O.lib().plo_undistort_maps(O._p(Kf), O._p(Df), cols, rows, O._p(mx), O._p(my))
         src = np.zeros_like(img)
         O.lib().plo_remap_linear_u8(O._p(img), cols, rows, cols, O._p(mx), O._p(my), O._p(src), cols)
-    return O.line_extract(src, nf, minlen, mask) + (O.lsd_detect(src),)
+    return O.line_extract(src, nf, minlen, mask, refine=refine) + (O.lsd_detect(src, refine=refine),)
 
 
 def _exact(kl, desc, fn, rk, rd, rf):
@@ -130,7 +132,7 @@ def test_oracle_lsd_refine_adv_known_answers(oracle, synth):
     assert abs(L.plo_lsd_nfa(w, h, 20, 10, p) - (-math.log10(true_tail) - logNT)) > 1.0
     # on a frame: ADV only ever removes or adjusts STD's rectangles
     img = synth.make_frame(3, 240, 320)
-    std, adv = oracle.lsd_detect(img), oracle.lsd_detect(img, refine=1)
+    std, adv = oracle.lsd_detect(img, refine=0), oracle.lsd_detect(img, refine=1)
     assert 0 < len(adv) <= len(std)
     sstd = {tuple(x) for x in std}
     assert sum(tuple(x) in sstd for x in adv) >= 0.9 * len(adv)
@@ -160,6 +162,20 @@ def test_emu_line_extract(plslam, oracle, synth, emu_lib, seed, rows, cols, nf, 
     gs = ex.read_segments(0)
     ex.close()
     assert len(gs) == len(rs) and (gs == rs).all()
+    assert _exact(kl, desc, fn, rk, rd, rf)
+
+
+def test_emu_line_extract_refine_std(plslam, oracle, synth, emu_lib):
+    """plh_line_set_refine(PLH_LSD_REFINE_STD): the level of the un-linked twin in the reference's tree (the default is ADV)."""
+    img = synth.make_frame(7, 120, 160, n_rect=40, n_line=20)
+    rk, rd, rf, rs = _oracle_line(oracle, img, 50, 0.0, refine=0)
+    ex = plslam.LINEextractor(1, 1.2, 50, 0.0, rows=120, cols=160, max_batch=1, lib=emu_lib)
+    assert plslam.load(emu_lib).plh_lsd_refine_default() == 1
+    ex.set_refine(0)
+    kl, desc, fn = ex(img)
+    gs = ex.read_segments(0)
+    ex.close()
+    assert len(gs) == len(rs) and (gs == rs).all() and len(rs) > len(oracle.lsd_detect(img, refine=1))
     assert _exact(kl, desc, fn, rk, rd, rf)
 
 
@@ -227,7 +243,7 @@ def test_emu_line_refine_adv(plslam, oracle, synth, emu_lib):
     img = synth.make_frame(9, 120, 160, n_rect=40, n_line=20)
     rs = oracle.lsd_detect(img, refine=1)
     rk, rd, rf = oracle.line_extract(img, 50, 0.0, refine=1)
-    assert 0 < len(rs) < len(oracle.lsd_detect(img))      # the level does something on this frame
+    assert 0 < len(rs) < len(oracle.lsd_detect(img, refine=0))      # the level does something on this frame
     for waves in (0, 4):
         ex = plslam.LINEextractor(1, 1.2, 50, 0.0, rows=120, cols=160, max_batch=1, lib=emu_lib)
         ex.set_refine(1)
@@ -310,13 +326,16 @@ def test_gpu_line_two_octaves(plslam, oracle, synth, rows, cols, refine, waves):
 @pytest.mark.parametrize("seed,rows,cols,nf,minlen,undist", [(1, 480, 640, 200, 0.0, False), (2, 480, 640, 200, 20.0, True),
                                                             (1000, 376, 1241, 200, 0.0, False), (5, 480, 640, 50, 0.0, False),
                                                             (6, 240, 320, 100, 0.0, "outside")])
-def test_gpu_line_extract(plslam, oracle, synth, seed, rows, cols, nf, minlen, undist):
+@pytest.mark.parametrize("refine", [None, 0], ids=["default-adv", "std"])
+def test_gpu_line_extract(plslam, oracle, synth, seed, rows, cols, nf, minlen, undist, refine):
     img = synth.make_frame(seed, rows, cols)
     K, D = (TUM1_K, TUM1_D) if undist else (None, None)
     if undist == "outside":   # principal point off the image: a fifth of the map leaves the frame
         K, D = [300.0, 300.0, 40.0, 190.0], [0.4, -0.9, 0.01, -0.008, 1.1]
-    rk, rd, rf, rs = _oracle_line(oracle, img, nf, minlen, K, D)
+    rk, rd, rf, rs = _oracle_line(oracle, img, nf, minlen, K, D, refine=refine)
     ex = plslam.LINEextractor(1, 1.2, nf, minlen, rows=rows, cols=cols, max_batch=1, K=K, D=D)
+    if refine is not None:   # (None: what a new handle runs -- the library's default, LSD_REFINE_ADV)
+        ex.set_refine(refine)
     kl, desc, fn = ex(img)
     gs = ex.read_segments(0)
     ex.close()
@@ -328,8 +347,9 @@ def test_gpu_line_extract(plslam, oracle, synth, seed, rows, cols, nf, minlen, u
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("refine", [1, 0], ids=["adv", "std"])
 @pytest.mark.parametrize("waves", [0, 2, 3, 4, 8, 16])
-def test_gpu_line_grow_waves(plslam, oracle, synth, waves):
+def test_gpu_line_grow_waves(plslam, oracle, synth, waves, refine):
     """Region growing with `waves` wavefronts per frame (k_lsd_grow_mw; 0 = k_lsd_grow_lone): segments, KeyLines and LBD bytes
     equal the oracle's on textured, sparse, sawtooth (huge regions) and white-noise frames, repeatedly (the schedule of the
     transactions differs from run to run, the result must not)."""
@@ -339,8 +359,9 @@ def test_gpu_line_grow_waves(plslam, oracle, synth, waves):
             synth.make_frame(33, 480, 640)]
     ex = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=480, cols=640, max_batch=1)
     ex.set_grow_waves(waves)
+    ex.set_refine(refine)
     for k, img in enumerate(imgs):
-        rk, rd, rf, rs = _oracle_line(oracle, img, 200, 0.0)
+        rk, rd, rf, rs = _oracle_line(oracle, img, 200, 0.0, refine=refine)
         for rep in range(3):
             kl, desc, fn = ex(img)
             gs = ex.read_segments(0)
@@ -400,7 +421,7 @@ def test_gpu_line_refine_adv(plslam, oracle, synth, waves):
         assert ex.status() == 0
         assert len(gs) == len(rs) and (gs == rs).all(), "image %d: LSD segments (ADV) differ from the oracle" % k
         _match(kl, desc, fn, rk, rd, rf, "ADV image %d" % k)
-        nstd += len(oracle.lsd_detect(img)); nadv += len(rs)
+        nstd += len(oracle.lsd_detect(img, refine=0)); nadv += len(rs)
     ex.close()
     assert nadv < nstd
     B = 16
@@ -467,6 +488,7 @@ def test_gpu_line_golden(plslam, synth):
         rows, cols = int(g["rows"]), int(g["cols"])
         img = synth.make_frame(int(g["seed"]), rows, cols, n_rect=int(g["n_rect"]), n_line=int(g["n_line"]))
         ex = plslam.LINEextractor(1, 1.2, int(g["nfeature"]), float(g["minlen"]), rows=rows, cols=cols, max_batch=1)
+        ex.set_refine(int(g["refine"]) if "refine" in g.files else 0)   # line_adv_*: LSD_REFINE_ADV; the files of rounds 1-4: STD
         kl, desc, fn = ex(img)
         gs = ex.read_segments(0)
         ex.close()

@@ -147,8 +147,9 @@ def test_oracle_matches_golden_lines(oracle, synth, path):
     g = np.load(path)
     img = synth.make_frame(int(g["seed"]), int(g["rows"]), int(g["cols"]), n_rect=int(g["n_rect"]), n_line=int(g["n_line"]))
     assert int(img.astype(np.int64).sum()) == int(g["img_sum"])          # the generator itself is pinned
-    segs = oracle.lsd_detect(img)
-    kl, desc, fn = oracle.line_extract(img, int(g["nfeature"]), float(g["minlen"]))
+    refine = int(g["refine"]) if "refine" in g.files else 0      # (files of rounds 1-4: LSD_REFINE_STD; line_adv_*: LSD_REFINE_ADV)
+    segs = oracle.lsd_detect(img, refine=refine)
+    kl, desc, fn = oracle.line_extract(img, int(g["nfeature"]), float(g["minlen"]), refine=refine)
     assert segs.shape == g["segs"].shape and (segs == g["segs"]).all()
     assert len(kl) == len(g["keylines"]) and all((kl[f] == g["keylines"][f]).all() for f in kl.dtype.names)
     assert (desc == g["desc"]).all() and (fn == g["linefn"]).all()

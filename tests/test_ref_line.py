@@ -15,7 +15,11 @@ an unqualified call that resolves to the double ::atan2 or to the float overload
 form and round; the library built here takes the float overload, so `angle` may differ by one float ulp (it does for
 ~15 % of the lines).  Everything downstream of it (the LBD bytes) is identical.
 
-tools/gen_golden_ref.py committed the reference outputs as tests/golden/ref_line_*.npz."""
+tools/gen_golden_ref.py committed the reference outputs as tests/golden/ref_line_*.npz.
+
+The twin creates its cv::LineSegmentDetector with the default refine level (LSD_REFINE_STD, LSDDetector_custom.cpp:149), so
+everything here runs LSD_REFINE_STD explicitly (refine=0 / set_refine(0)); the SYSTEM module LineExtractor.cpp really links passes
+LSD_REFINE_ADV, which is the library's and the oracle's default and is covered by tests/test_line.py and tests/test_soak_gpu.py."""
 import glob
 import importlib.util
 import os
@@ -76,7 +80,7 @@ def test_oracle_reproduces_reference_lines(oracle, synth, path):
     g = np.load(path)
     img, mask = _inputs(synth, g)
     no, sc = _octaves(g)
-    kl, desc, fn = oracle.line_extract(img, int(g["nfeatures"]), float(g["min_len"]), mask, num_octaves=no, scale=sc)
+    kl, desc, fn = oracle.line_extract(img, int(g["nfeatures"]), float(g["min_len"]), mask, refine=0, num_octaves=no, scale=sc)
     _same(kl, desc, fn, g["keylines"], g["desc"], g["linefn"], "oracle")
 
 
@@ -90,7 +94,7 @@ def test_reference_lines_live(oracle, plslam, synth):
         #  element MORE than it holds and describes that uninitialised KeyLine, LineExtractor.cpp:48-64 -- not exercised)
         img = synth.make_frame(seed, rows, cols)
         rk, rd, rf = G.reference_lines(R, plslam, img, nf, min_len)
-        kl, desc, fn = oracle.line_extract(img, nf, min_len)
+        kl, desc, fn = oracle.line_extract(img, nf, min_len, refine=0)
         _same(kl, desc, fn, rk, rd, rf, "oracle vs live reference (seed %d)" % seed)
 
 
@@ -105,7 +109,7 @@ def test_reference_two_octaves_live(oracle, plslam, synth):
         img = synth.make_frame(seed, rows, cols)
         rk, rd, rf = G.reference_lines(R, plslam, img, nf, min_len, num_octaves=2, scale=scale)
         assert (rk["octave"] == 1).sum() > 0 and (rk["octave"] == 0).sum() > 0
-        kl, desc, fn = oracle.line_extract(img, nf, min_len, num_octaves=2, scale=scale)
+        kl, desc, fn = oracle.line_extract(img, nf, min_len, refine=0, num_octaves=2, scale=scale)
         _same(kl, desc, fn, rk, rd, rf, "two octaves: oracle vs live reference (seed %d)" % seed)
     img = synth.make_frame(3, 120, 160)
     for scale in (1.2, 3.0):      # pyrDown(Size(cols / (int)scale, ...)): OpenCV's size assertion
@@ -125,6 +129,7 @@ def test_gpu_reproduces_reference_lines(plslam, synth, path):
     no, sc = _octaves(g)
     le = plslam.LINEextractor(no, sc, int(g["nfeatures"]), float(g["min_len"]), rows=rows, cols=cols, max_batch=1, device=0)
     try:
+        le.set_refine(0)   # the twin's level (see the module docstring)
         kl, desc, fn = le(img, mask)
     finally:
         le.close()

@@ -73,17 +73,17 @@ def soak_frames(S, rows, cols, count):
     return np.stack(out)
 
 
-def _oracle_all(O, frames, nfeat):
+def _oracle_all(O, frames, nfeat, refine):
     def one(img):
         orb = O.OrbOracle(nfeat, 1.2, 8, 20, 7)
         kps, desc = orb.extract(img)
-        kl, ld, fn = O.line_extract(img, 200, 0.0)
-        return kps, desc, kl, ld, fn, O.lsd_detect(img)
+        kl, ld, fn = O.line_extract(img, 200, 0.0, refine=refine)
+        return kps, desc, kl, ld, fn, O.lsd_detect(img, refine=refine)
     with ThreadPoolExecutor(os.cpu_count() or 1) as ex:
         return list(ex.map(one, list(frames)))
 
 
-def _gpu_lines(P, frames, waves, lib=None, refine=0, screen=1, K=None, D=None, mask=None):
+def _gpu_lines(P, frames, waves, refine, lib=None, screen=1, K=None, D=None, mask=None):
     import torch
     B, rows, cols = frames.shape
     ex = P.LINEextractor(1, 1.2, 200, 0.0, rows=rows, cols=cols, max_batch=B, lib=lib, K=K, D=D)
@@ -109,17 +109,21 @@ def _gpu_lines(P, frames, waves, lib=None, refine=0, screen=1, K=None, D=None, m
     return out
 
 
+# refine: cv::LineSegmentDetector's level.  1 = LSD_REFINE_ADV is what the reference's linked opencv_contrib runs and the
+# library's default (round 5); 0 = LSD_REFINE_STD, what the un-linked twin in its tree would run.  Both get the full soak.
+@pytest.mark.parametrize("refine", [1, 0], ids=["adv", "std"])
 @pytest.mark.parametrize("rows,cols,nfeat", [(480, 640, 1000), (376, 1241, 2000)], ids=["640x480", "1241x376"])
-def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat):
+def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat, refine):
     import torch
     frames = soak_frames(synth, rows, cols, N_SOAK)
     assert len({f.tobytes() for f in frames}) == N_SOAK          # distinct
-    ref = _oracle_all(oracle, frames, nfeat)
+    assert plslam.load().plh_lsd_refine_default() == 1           # a new handle runs LSD_REFINE_ADV unless told otherwise
+    ref = _oracle_all(oracle, frames, nfeat, refine)
     nseg = sum(len(r[5]) for r in ref)
     # lines: one wavefront per frame (k_lsd_grow), the automatic choice (k_lsd_grow_mw for this batch size), four per frame, and
     # one per frame with the density screen off (the exact rectangle behind every decision, as in rounds 1-3)
     for waves, screen in ((0, 1), (-1, 1), (4, 1), (0, 0)):
-        got = _gpu_lines(plslam, frames, waves, screen=screen)
+        got = _gpu_lines(plslam, frames, waves, refine, screen=screen)
         for b, ((kl, ld, fn, sg), r) in enumerate(zip(got, ref)):
             assert len(sg) == len(r[5]) and (sg == r[5]).all(), "waves %d, screen %d, frame %d: LSD segments differ from the oracle" % (waves, screen, b)
             assert len(kl) == len(r[2]) and all((kl[f] == r[2][f]).all() for f in r[2].dtype.names), "waves %d, frame %d: KeyLines" % (waves, b)
@@ -154,7 +158,7 @@ def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat):
         out = (C.c_ulonglong * 40)()
         for waves in (0, -1):
             L.plh_debug_grow_prof(out, 1)
-            got = _gpu_lines(plslam, frames, waves, lib=prof)
+            got = _gpu_lines(plslam, frames, waves, refine, lib=prof)
             L.plh_debug_grow_prof(out, 0)
             assert all(len(g[3]) == len(r[5]) and (g[3] == r[5]).all() for g, r in zip(got, ref))
             # the density screen: every verdict of the counter build is checked against the exact density in the kernel
@@ -164,16 +168,16 @@ def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat):
                       "refine %d, reduce-radius steps %d, transactions %d (re-run: own %d, at commit %d)\n"
                       % (waves, out[8], out[9], out[12], out[13], out[32], out[33], out[14], out[37], out[38], out[14] - out[37] - out[38],
                          out[39], out[15], out[7], out[16], out[18], out[24]))
-    print("\nsoak %dx%d: %d distinct frames, %d LSD segments and %d ORB keypoints bit-exact (waves 0 / auto / 4)\n%s"
-          % (cols, rows, N_SOAK, nseg, nkp, cover))
+    print("\nsoak %dx%d %s: %d distinct frames, %d LSD segments and %d ORB keypoints bit-exact (waves 0 / auto / 4)\n%s"
+          % (cols, rows, "LSD_REFINE_ADV" if refine else "LSD_REFINE_STD", N_SOAK, nseg, nkp, cover))
 
 
 @pytest.mark.parametrize("rows,cols,und", [(480, 640, False), (376, 1241, False), (480, 640, True)], ids=["640x480", "1241x376", "640x480-undistort-mask"])
 def test_soak_refine_adv(plslam, oracle, synth, rows, cols, und):
-    """The same kind of content with cv::LSD_REFINE_ADV (rect_improve / rect_nfa / nfa on every kept rectangle): 128 distinct
-    frames per shape -- 640x480, 1241x376, and 640x480 behind the TUM1 undistortion with one of the reference's masks -- one
-    wavefront per frame and the automatic multi-wavefront choice, against the oracle's ADV restatement."""
-    n = min(N_SOAK, int(os.environ.get("PLSLAM_SOAK_ADV_FRAMES", "128")))   # (the oracle's nfa() is the slow side: 128 by default)
+    """cv::LSD_REFINE_ADV (rect_improve / rect_nfa / nfa on every kept rectangle) once more with STD's segment count beside it --
+    640x480, 1241x376, and 640x480 behind the TUM1 undistortion with one of the reference's masks -- one wavefront per frame and
+    the automatic multi-wavefront choice, against the oracle's ADV restatement.  As many frames as the main soak (round 5)."""
+    n = min(N_SOAK, int(os.environ.get("PLSLAM_SOAK_ADV_FRAMES", str(N_SOAK))))
     frames = soak_frames(synth, rows, cols, n)
     K, D, mask = None, None, None
     src = frames
@@ -190,13 +194,13 @@ def test_soak_refine_adv(plslam, oracle, synth, rows, cols, und):
 
     def one(img):
         kl, ld, fn = oracle.line_extract(img, 200, 0.0, mask, refine=1)
-        return kl, ld, fn, oracle.lsd_detect(img, refine=1), len(oracle.lsd_detect(img))
+        return kl, ld, fn, oracle.lsd_detect(img, refine=1), len(oracle.lsd_detect(img, refine=0))
     with ThreadPoolExecutor(os.cpu_count() or 1) as ex:
         ref = list(ex.map(one, list(src)))
     nadv, nstd = sum(len(r[3]) for r in ref), sum(r[4] for r in ref)
     assert 0 < nadv < nstd                      # the NFA gate does remove rectangles on this content
     for waves in (0, -1):
-        got = _gpu_lines(plslam, frames, waves, refine=1, K=K, D=D, mask=mask)
+        got = _gpu_lines(plslam, frames, waves, 1, K=K, D=D, mask=mask)
         for b, ((kl, ld, fn, sg), r) in enumerate(zip(got, ref)):
             assert len(sg) == len(r[3]) and (sg == r[3]).all(), "ADV, waves %d, frame %d: LSD segments differ from the oracle" % (waves, b)
             assert len(kl) == len(r[0]) and all((kl[f] == r[0][f]).all() for f in r[0].dtype.names), "ADV, waves %d, frame %d: KeyLines" % (waves, b)

@@ -3,7 +3,7 @@
 
 The oracle is a restatement, so these vectors pin the ORACLE (regression) and the GPU path against
 it; they are not outputs of the reference binary (which cannot be built here: OpenCV absent).
-    python tools/gen_golden.py
+    python tools/gen_golden.py [substring]      (only the cases whose name contains `substring`)
 """
 import os
 import sys
@@ -18,9 +18,16 @@ O, S = _util.oracle(), _util.synth()
 O.build()
 G = os.path.join(ROOT, "tests", "golden")
 os.makedirs(G, exist_ok=True)
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
+
+
+def wanted(name):
+    return ONLY in name
 
 
 def orb_case(name, seed, rows, cols, nf, nl=8, ini=20, mn=7, **kw):
+    if not wanted(name):
+        return
     img = S.make_frame(seed, rows, cols, **kw)
     o = O.OrbOracle(nf, 1.2, nl, ini, mn)
     kps, desc = o.extract(img)
@@ -40,22 +47,32 @@ orb_case("orb_small_160x120", 7, 120, 160, 200, nl=3, n_rect=40, n_line=20)
 
 
 # ---- line extractor (LSD + KeyLine selection + LBD): segments, keylines, descriptors, line equations
-def line_case(name, seed, rows, cols, nf, minlen=0.0, **kw):
+# refine: cv::LineSegmentDetector's level (0 = LSD_REFINE_STD, 1 = LSD_REFINE_ADV = the reference's, oracle/plo.py REFERENCE_REFINE);
+# the files of rounds 1-4 carry no `refine` field and are LSD_REFINE_STD
+def line_case(name, seed, rows, cols, nf, minlen=0.0, refine=0, **kw):
+    if not wanted(name):
+        return
     img = S.make_frame(seed, rows, cols, **kw)
-    segs = O.lsd_detect(img)
-    kl, desc, fn = O.line_extract(img, nf, minlen)
+    segs = O.lsd_detect(img, refine=refine)
+    kl, desc, fn = O.line_extract(img, nf, minlen, refine=refine)
+    extra = dict(refine=refine) if refine else {}
     np.savez_compressed(os.path.join(G, name + ".npz"), seed=seed, rows=rows, cols=cols, nfeature=nf, minlen=minlen,
                         n_rect=kw.get("n_rect", 400), n_line=kw.get("n_line", 200), img_sum=int(img.astype(np.int64).sum()),
-                        segs=segs, keylines=kl, desc=desc, linefn=fn)
+                        segs=segs, keylines=kl, desc=desc, linefn=fn, **extra)
     print(name, len(segs), len(kl))
 
 
 line_case("line_s1_640x480", 1, 480, 640, 200)
 line_case("line_small_160x120", 7, 120, 160, 50, n_rect=40, n_line=20)
+line_case("line_adv_s1_640x480", 1, 480, 640, 200, refine=1)
+line_case("line_adv_kitti_1241x376", 1000, 376, 1241, 200, refine=1)
+line_case("line_adv_small_160x120", 7, 120, 160, 50, refine=1, n_rect=40, n_line=20)
 
 
 # ---- Hamming matchers on the S3 descriptor sets: knn2 table checksum, SearchDouble, SearchByBoW
 def match_case(name, seed, n):
+    if not wanted(name):
+        return
     import ctypes as C
     a, b, perm = S.make_descriptor_sets(seed, n, 0.08)
     idx, dist = O.knn2(a, b)
