@@ -28,11 +28,16 @@ One JSON line on stdout (rank 0) with, besides the contract fields,
   "streaming":     (N = 1) the PCIe-inclusive rate described above;
   "latency_ms_single_frame": (N = 1) one Frame() worth of extraction through the host-buffer entry points, ORB and lines on
                    two threads as Frame.cc:224-227 runs them;
-  "verified":      the records the timed steps left behind for the first 16 frames of EVERY sub-batch (and of each secondary
-                   batch), compared bit for bit with the CPU oracle on the same frames; with N > 1 every rank verifies its own
+  "verified":      the records the timed steps left behind for EVERY frame of one sub-batch (which one rotates with the hour of the
+                   run: 1536 of the 6144 frames) and the first 16 frames of every other sub-batch (and of each secondary batch),
+                   compared bit for bit with the CPU oracle on the same frames; with N > 1 every rank verifies its own
                    batch and the line carries the per-rank verdicts; a mismatch makes the run exit non-zero.
-  "secondary.refine_adv": (N = 1) the same workload with cv::LSD_REFINE_ADV (`--refine adv` makes it the headline): resident
-                   rate, the 512-frame share, one-frame latency, verified, its own roofline.
+  "secondary.refine_std": (N = 1) the same workload with cv::LSD_REFINE_STD -- the level of the un-linked twin in the reference's
+                   tree; the headline runs LSD_REFINE_ADV, what the linked opencv_contrib LSDDetector creates (`--refine std`
+                   makes STD the headline and reports ADV here): resident rate, the 512-frame share, one-frame latency, verified,
+                   its own roofline.
+  "box":           a fixed VALU probe (tools/ubench/valu_rate, 50 ms) and the clocks / power cap rocm-smi reports in front of the
+                   timed region: what a number from another box has to be normalised with.
 `--frames <dir | file>` replaces the synthetic frames by real ones (raw 8-bit planes or PGM, pl-slam_amd/frames_io.py), with
 the TUM1 / KITTI00-02 camera picked by --rows / --cols.
 """
@@ -261,21 +266,53 @@ def verify_records(res, recs, pairs, first=0):
     return bad
 
 
-def verify_batch(O, V, W, res, voc, per_part):
-    """The records of the first `per_part` frames of EVERY sub-batch of workload W (what its last steps left behind), against the
-    oracle on the same frames.  {"frames", "pairs", "exact", "mismatches", ...}."""
+def verify_batch(O, V, W, res, voc, per_part, full_part=None):
+    """The records workload W's last steps left behind, against the oracle on the same frames: EVERY frame of sub-batch `full_part`
+    (None: none) and the first `per_part` frames of every other sub-batch.  {"frames", "pairs", "exact", "mismatches", ...}."""
     nv = min(per_part, W.Bp)
     bad, nf, npairs = [], 0, 0
     for k in range(W.nsplit):
         first = k * W.Bp
-        recs, pairs = oracle_records(O, V, W.frames[first:first + nv], voc, W.nfeatures, W.nlevels, W.nlines, W.K, W.D, refine=W.refine)
+        cnt = W.Bp if k == full_part else nv
+        recs, pairs = oracle_records(O, V, W.frames[first:first + cnt], voc, W.nfeatures, W.nlevels, W.nlines, W.K, W.D, refine=W.refine)
         bad += verify_records(res, recs, pairs, first)
         nf += len(recs)
         npairs += len(pairs)
-    return {"frames": nf, "pairs": npairs, "sub_batches": W.nsplit, "exact": not bad, "mismatches": bad[:8],
-            "what": "every record of the first %d frames of each of the %d sub-batches of the timed batch (keypoints, rBRIEF, FeatureVector, "
+    full = "" if full_part is None else "every frame of sub-batch %d (%d frames; the sub-batch rotates with the hour of the run) and " % (full_part, W.Bp)
+    return {"frames": nf, "pairs": npairs, "sub_batches": W.nsplit, "full_sub_batch": full_part, "exact": not bad, "mismatches": bad[:8],
+            "what": "every record of %sthe first %d frames of each %ssub-batch of the timed batch (keypoints, rBRIEF, FeatureVector, "
                     "BowVector, keylines, LBD, line equations) and the match lists of their consecutive pairs, compared bit for bit with "
-                    "the CPU oracle on the same frames" % (nv, W.nsplit)}
+                    "the CPU oracle on the same frames" % (full, nv, "other " if full else "")}
+
+
+def box_probe(P, device):
+    """What a rate measured on another box has to be normalised with (the driver's number is taken on a box the builder
+    never sees): a fixed VALU-only launch timed by the library (plh_box_probe: 4096 x 256 threads x 20480 x 64 multiply-adds, ~40 ms on
+    an MI355X at full clocks; first run from the power state the GPU was in, second at running clocks) and what rocm-smi says about
+    clocks and the power cap.  Best effort: missing tools leave fields out, never fail the run."""
+    import ctypes as C
+    import subprocess
+    out = {"what": "fixed VALU-only launch (plh_box_probe, 4096 x 256 threads x 20480 iterations x 64 mads) timed in front of the warm-up; "
+                   "rates from boxes whose probe_ms differ compare after scaling by it"}
+    try:
+        ms = (C.c_float * 2)()
+        if P.load().plh_box_probe(int(device), 20480, ms) == 0:
+            out["probe_ms_first"], out["probe_ms"] = round(float(ms[0]), 3), round(float(ms[1]), 3)
+    except Exception as e:   # noqa: BLE001
+        out["probe_error"] = str(e)[:120]
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--showmaxpower", "--showpower"], capture_output=True, text=True,
+                             timeout=20).stdout
+        import re
+        for key, pat in (("sclk_mhz", r"sclk clock level: \S+ \((\d+)Mhz\)"), ("mclk_mhz", r"mclk clock level: \S+ \((\d+)Mhz\)"),
+                         ("power_cap_w", r"Max Graphics Package Power \(W\): ([0-9.]+)"),
+                         ("power_w", r"Current Socket Graphics Package Power \(W\): ([0-9.]+)")):
+            m = re.search(pat, txt)
+            if m:
+                out[key] = float(m.group(1))
+    except Exception:   # noqa: BLE001
+        pass
+    return out
 
 
 class Workload:
@@ -440,6 +477,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the N = 1 secondary / streaming / latency legs")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed batch's records with the CPU oracle")
     ap.add_argument("--verify-frames", type=int, default=16, help="frames of EVERY sub-batch of the timed batch compared with the oracle (on every rank)")
+    ap.add_argument("--verify-full", choices=["rotate", "none"], default="rotate",
+                    help="additionally compare EVERY frame of one sub-batch of the timed batch (which one rotates with the hour of the run)")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # 1-rank RCCL communicator: rehearses the N > 1 path
     ap.add_argument("--serial", action="store_true", help="ORB and line halves on one stream (no overlap); used for PMC runs")
     args = ap.parse_args()
@@ -532,6 +571,7 @@ def main():
         if gathering:
             fe.gather(comm_stream, comm, root, recv)
 
+    box = box_probe(P, dev.index) if rank == 0 else None   # in front of the warm-up: untimed, and the GPU is idle around it
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -566,7 +606,9 @@ def main():
         # frames -- the first --verify-frames frames of each sub-batch
         O = _util.oracle()
         O.build()
-        verified = verify_batch(O, V, W, res, voc, args.verify_frames)
+        # one sub-batch in full (rotating with the hour, so that successive runs cover all of them), 16 frames of the others
+        full_part = None if args.verify_full == "none" else (int(time.time() // 3600) + rank) % W.nsplit
+        verified = verify_batch(O, V, W, res, voc, args.verify_frames, full_part)
         if world > 1:   # a scaling run is a parity run: rank 0 reports every rank's verdict
             mine = {"rank": rank, "exact": verified["exact"], "frames": verified["frames"], "pairs": verified["pairs"],
                     "mismatches": verified["mismatches"]}
@@ -681,6 +723,7 @@ def main():
                                               "against 1024 SIMDs x 2.4 GHz / 4.2 cycles: how close the front end runs to its own instruction floor"}
                                      if insts and ij.get("total_valu") else None),
             "verified": verified,
+            "box": box,
         }
         if gathering:
             tr = {}

@@ -70,6 +70,10 @@ PLH_API int plh_device_count(void);
  * instructions do what the descriptions say; per_shim[plh_selftest_shims()] (optional) = mismatching lanes per shim. */
 PLH_API plh_status plh_selftest(int device, int* failing_checks, int32_t* per_shim, int per_shim_cap);
 PLH_API int plh_selftest_shims(void);
+/* A fixed VALU-only launch (4096 x 256 threads x iters x 64 multiply-adds), timed twice with HIP events: ms[0] from whatever
+ * power state the GPU was in, ms[1] at its running clocks.  bench.py reports it in front of the timed region so that rates
+ * measured on different boxes can be normalised (no counterpart in the reference). */
+PLH_API plh_status plh_box_probe(int device, int iters, float ms[2]);
 
 /* ---------------------------------------------------------------------------------------------
  * ORB extractor  (replaces ORB_SLAM2::ORBextractor, include/ORBextractor.h:45-111)

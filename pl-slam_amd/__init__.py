@@ -127,6 +127,7 @@ _SIGS = {
     "plh_orb_fuse_search": ([_V, _V, _I, _V, _V, _V, _I, _I, _V, _V, _V, _V, _F, _I, _V, _V, _I], _I),
     "plh_selftest": ([_I, _V, _V, _I], _I),
     "plh_selftest_shims": ([], _I),
+    "plh_box_probe": ([_I, _I, _V], _I),
     "plh_frontend_create": ([_V, _V, _I, _I, _I, _V], _I),
     "plh_frontend_destroy": ([_V], _I),
     "plh_frontend_parts": ([_V], _I),

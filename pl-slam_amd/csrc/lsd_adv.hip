@@ -27,7 +27,8 @@ struct AdvFrame {
   uint4* ent;
   LsdAdvRec* rec;
   uint32_t* count;   // length of the work list (zeroed by k_lsd_rects_sort)
-  uint32_t* list;    // slots of the rectangles that go on to rect_improve(), in no particular order
+  const uint32_t* order;   // the frame's slots by region size class, largest first (k_lsd_rects_sort)
+  uint32_t* list;    // slots of the rectangles that go on to rect_improve(): runs of similar size (appended 64 at a time in `order`)
 };
 __device__ __forceinline__ AdvFrame adv_frame(const LineDeviceArgs& a, int b) {
   AdvFrame f;
@@ -36,7 +37,8 @@ __device__ __forceinline__ AdvFrame adv_frame(const LineDeviceArgs& a, int b) {
   f.rec = a.adv + (long long)b * a.segCap;
   uint32_t* park = a.park + (long long)b * a.arenaStride;
   f.count = park;                 // park[0]
-  f.list = park + 2 + a.segCap;   // (the first segCap words behind park[2] hold k_lsd_rects' size-class order)
+  f.order = park + 2;
+  f.list = park + 2 + a.segCap;
   return f;
 }
 __device__ __forceinline__ RcFrame adv_field(const LineDeviceArgs& a, int b) {
@@ -64,40 +66,71 @@ void launch_lsd_lgamma_table(double* t, int n, hipStream_t s) {
 }
 
 __global__ void __launch_bounds__(64) k_adv_first(LineDeviceArgs a) {
-  __shared__ int s_tot[64], s_alg[64];
+  __shared__ LsdScanGeom s_geom[64];
+  __shared__ int s_tot[64], s_alg[64], s_slot[64];
   const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7;
   const AdvFrame f = adv_frame(a, b);
   const RcFrame rf = adv_field(a, b);
-  for (int base = (int)blockIdx.x * 64; base < f.n; base += 64 * ADV_FIRST_GROUPS) {
-    // the pixel counts of 64 rectangles, eight at a time, eight lanes each (lsd_rect_counts_g8)
+  const LsdAlignTol tol0 = lsd_align_tol(0.0, a.prec);   // (every rectangle starts with the launch's tolerance; theta per rectangle)
+  // The frame's rectangles in k_lsd_rects' size-class order, cut into chunks of eight: the eight that walk side by side below take
+  // about equally long (in slot order the longest of eight set the pace, 2 x the mean).  The chunks go to the frame's blocks
+  // round robin, so that every block gets large and small ones; a block takes eight chunks (64 rectangles) per pass.
+  const int nChunks = (f.n + 7) >> 3;
+  for (int c0 = (int)blockIdx.x; c0 < nChunks; c0 += 8 * ADV_FIRST_GROUPS) {
+    // the pass's rectangles: lane (it, pos) -> position pos of chunk c0 + it x blocks.  Their scan geometry, one lane each (the
+    // corner sort is as long as a walk: not eight times per rectangle):
+    const int k = (c0 + (lane >> 3) * ADV_FIRST_GROUPS) * 8 + (lane & 7);
+    const int mine = k < f.n ? (int)f.order[k] : -1;
+    {
+      s_slot[lane] = mine;
+      s_geom[lane] = mine >= 0 ? lsd_scan_geom(rf, lsd_adv_load(f.rec[mine].r)) : lsd_scan_none();
+    }
+    PLH_WAVE_SYNC();
+    // their pixel counts, eight rectangles at a time, eight lanes each (lsd_rect_counts_g8)
     for (int it = 0; it < 8; it++) {
-      const int i = base + it * 8 + grp;
-      const bool on = i < f.n;
-      LsdAdvRect r = LsdAdvRect();
-      if (on) r = lsd_adv_load(f.rec[i].r);
+      const int i = s_slot[it * 8 + grp];
+      LsdAlignTol t = tol0;
+      if (i >= 0) { t.theta = f.rec[i].r[5]; t.thDeg = (float)(t.theta * (180.0 / kPI)); }
       int total, alg;
-      lsd_rect_counts_g8(rf, r, on, j, total, alg);
+      lsd_rect_counts_g8(rf, s_geom[it * 8 + grp], t, j, total, alg);
       alg = adv_sum8(alg);
       if (j == 0) { s_tot[it * 8 + grp] = total; s_alg[it * 8 + grp] = alg; }
     }
     PLH_WAVE_SYNC();
     // nfa(): one lane per rectangle
-    const int i = base + lane;
-    if (i < f.n) {
-      LsdAdvRec* ar = f.rec + i;
+    bool again = false;
+    if (mine >= 0) {
+      LsdAdvRec* ar = f.rec + mine;
       const double v = lsd_nfa(s_tot[lane], s_alg[lane], a.p, a.logNT, a.lgamma);
       if (v > 0.0) {
-        lsd_store_segment(&f.ent[i], ar->r);                       // LOG_EPS = 0: meaningful as it is
+        lsd_store_segment(&f.ent[mine], ar->r);                    // LOG_EPS = 0: meaningful as it is
       } else {
         ar->log_nfa = v;
-        f.list[atomicAdd(f.count, 1u)] = (uint32_t)i;              // rect_improve()
+        again = true;                                              // rect_improve()
       }
+    }
+    {   // the wavefront's rectangles that go on, as one run of the work list (one atomic per wavefront)
+      const unsigned long long bm = __ballot(again);
+      unsigned at = 0;
+      if (lane == 0 && bm) at = atomicAdd(f.count, (unsigned)__popcll(bm));
+      at = bcast_u32(at, 0);
+      if (again) f.list[at + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)mine;
     }
     PLH_WAVE_SYNC();
   }
 }
 
-__global__ void __launch_bounds__(64) k_adv_improve(LineDeviceArgs a) {
+#ifndef PLH_ADV_IMPROVE_WAVES
+#define PLH_ADV_IMPROVE_WAVES 0
+#endif
+#if PLH_ADV_IMPROVE_WAVES > 0
+#define PLH_ADV_IMPROVE_ATTR __attribute__((amdgpu_waves_per_eu(PLH_ADV_IMPROVE_WAVES)))
+#else
+#define PLH_ADV_IMPROVE_ATTR
+#endif
+__global__ void __launch_bounds__(64) PLH_ADV_IMPROVE_ATTR k_adv_improve(LineDeviceArgs a) {
+  __shared__ LsdScanGeom s_geom[8 * 5];   // [rectangle of the pass][variant]
+  __shared__ int s_ok[8 * 5];
   const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7, g0 = lane & ~7;
   const AdvFrame f = adv_frame(a, b);
   const RcFrame rf = adv_field(a, b);
@@ -111,33 +144,50 @@ __global__ void __launch_bounds__(64) k_adv_improve(LineDeviceArgs a) {
     if (active) { r = lsd_adv_load(f.rec[slot].r); log_nfa = f.rec[slot].log_nfa; }
     for (int stage = 0; stage < 5; stage++) {
       if (!__any(active)) break;
-      // (total, aligned) pixel counts of the stage's variants m = 1 .. 5, the same in all eight lanes of the group
+      const bool precStage = stage == 0 || stage == 4;   // finer precision: one rectangle, five tolerances
+      // lane j < 5 of the group: variant j + 1 of its rectangle -- whether the loop's width gate lets it exist, and its scan geometry
+      // (the two precision stages walk the rectangle itself: one geometry, lane 0's)
+      PLH_WAVE_SYNC();
+      if (j < 5) {
+        LsdAdvRect rv = r;
+        const bool okv = active && lsd_adv_variant(stage, j + 1, rv);
+        s_ok[grp * 5 + j] = okv ? 1 : 0;
+        s_geom[grp * 5 + j] = okv ? lsd_scan_geom(rf, precStage ? r : rv) : lsd_scan_none();
+      }
+      PLH_WAVE_SYNC();
+      // (total, aligned) pixel counts of the variants m = 1 .. 5, the same in all eight lanes of the group
       int tot[5], alg[5];
       bool ok[5];
-      if (stage == 0 || stage == 4) {   // finer precision: one rectangle, five tolerances
-        LsdAdvRect rv = r;
-        double prec[5];
 #pragma unroll
-        for (int m = 0; m < 5; m++) {
-          ok[m] = active && lsd_adv_variant(stage, 1, rv);   // (one more iteration each: rv after m + 1 of them)
-          prec[m] = rv.prec;
+      for (int m = 0; m < 5; m++) ok[m] = s_ok[grp * 5 + m] != 0;
+      if (precStage) {
+        LsdAlignTol5 t5;
+        t5.theta = r.theta; t5.thDeg = (float)(r.theta * (180.0 / kPI));
+        {
+          LsdAdvRect rv = r;
+#pragma unroll
+          for (int m = 0; m < 5; m++) {
+            rv.p /= 2; rv.prec = rv.p * kPI;   // (lsd_adv_variant's iteration)
+            t5.prec[m] = rv.prec;
+            const float pd = (float)(rv.prec * (180.0 / kPI));
+            t5.lo[m] = pd - 1e-3f; t5.hi[m] = pd + 1e-3f;
+          }
         }
         int total;
-        lsd_rect_counts_g8_prec5(rf, r, ok[0], j, prec, total, alg);   // (the gate of stage 4 does not move: all five or none)
+        lsd_rect_counts_g8_prec5(rf, s_geom[grp * 5], t5, j, total, alg);   // (the gate of stage 4 does not move: all five or none)
 #pragma unroll
         for (int m = 0; m < 5; m++) { tot[m] = total; alg[m] = adv_sum8(alg[m]); }
       } else {
+        const LsdAlignTol t = lsd_align_tol(r.theta, r.prec);
 #pragma unroll 1
         for (int m = 0; m < 5; m++) {
-          LsdAdvRect rv = r;
-          const bool okm = active && lsd_adv_variant(stage, m + 1, rv);
           int total, al;
-          lsd_rect_counts_g8(rf, rv, okm, j, total, al);
+          lsd_rect_counts_g8(rf, s_geom[grp * 5 + m], t, j, total, al);
           al = adv_sum8(al);
           // (m is a loop counter, not a constant: the arrays are written through selects so that they stay in registers)
 #pragma unroll
           for (int k = 0; k < 5; k++)
-            if (k == m) { ok[k] = okm; tot[k] = total; alg[k] = al; }
+            if (k == m) { tot[k] = total; alg[k] = al; }
         }
       }
       // nfa() of variant j + 1 in lane j < 5 of the group
@@ -150,7 +200,7 @@ __global__ void __launch_bounds__(64) k_adv_improve(LineDeviceArgs a) {
           if (k == j) { myTot = tot[k]; myAlg = alg[k]; myOk = ok[k]; }
         if (myOk) {
           double p = r.p;
-          if (stage == 0 || stage == 4)
+          if (precStage)
             for (int k = 0; k <= j; k++) p /= 2;   // (the variant's p: the two precision stages halve it per iteration)
           v = lsd_nfa(myTot, myAlg, p, a.logNT, a.lgamma);
         }

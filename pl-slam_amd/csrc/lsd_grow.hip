@@ -1816,19 +1816,24 @@ __device__ __forceinline__ int kl_item(const KlFrame& f, int i, float e[4], int&
   return o1 ? 1 : 0;
 }
 
-// One wavefront per frame (round 5): a 256-thread block needs a free wave slot and 96 registers on all four SIMDs of one CU at the
-// same moment, which the region-growing wavefronts of the other sub-batches rarely leave -- 0.6 ms alone, 17 ms inside the
-// pipeline on the line chain's critical path; a lone wavefront goes wherever one slot is free.
-#ifndef PLH_KL_THREADS
-#define PLH_KL_THREADS 64
-#endif
-constexpr int KL_THREADS = PLH_KL_THREADS;
+// KeyLine selection, ONE WAVEFRONT per frame (round 5).  Rounds 1-4 ran a 256-thread block per frame that found the outCap best
+// keys by outCap passes over ALL n keys: 0.6 ms alone, but such a block needs a free wave slot and 96 registers on all four SIMDs of
+// one CU at the same moment, which the region-growing wavefronts of the other sub-batches rarely leave (17 ms inside the pipeline,
+// on the line chain's critical path).  Now: the keys' responses go into a 256-bin histogram, the bins from the top that hold the
+// first outCap keys give a candidate set (a few hundred of the ~1500 keys), and every candidate's rank among the candidates -- the
+// number of larger keys; keys are unique -- is its place in the selection.  Same order as the repeated arg-max: (response
+// descending, detection index ascending).  More candidates than KL_CAND (a frame whose lines all have one length): the old loop.
+constexpr int KL_THREADS = 64, KL_BINS = 256, KL_CAND = 1024;
+__device__ __forceinline__ int kl_bin(unsigned long long key) {   // monotone in the key's response (a length over the image's larger side: < 1.5)
+  return min(KL_BINS - 1, (int)(__uint_as_float((unsigned)(key >> 32)) * 170.0f));
+}
 __global__ void __launch_bounds__(KL_THREADS) k_keylines(LineDeviceArgs a, plh_keyline* outKl, double* outFn, int* nOut) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   unsigned long long* sel = (unsigned long long*)smem;   // [outCap]
-  __shared__ unsigned long long s_red[KL_THREADS / 64];
+  __shared__ unsigned long long s_cand[KL_CAND];
+  __shared__ int s_hist[KL_BINS];
   __shared__ int s_valid, s_keep;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid;
   KlFrame f;
   f.segs0 = a.segs + (long long)b * a.arenaStride;
   f.n0 = min(a.nSegs[b], a.segCap);
@@ -1838,7 +1843,7 @@ __global__ void __launch_bounds__(KL_THREADS) k_keylines(LineDeviceArgs a, plh_k
   f.w1 = a.w1; f.h1 = a.h1; f.scale1 = a.octScale1;
   const int n = f.n0 + f.n1;
   unsigned long long* keys = (unsigned long long*)(a.reg + (long long)b * a.arenaStride);   // scratch (free after k_lsd_rects)
-  if (tid == 0) s_valid = 0;
+  for (int i = tid; i < KL_BINS; i += KL_THREADS) s_hist[i] = 0;
   __syncthreads();
   int myValid = 0;
   for (int i = tid; i < n; i += KL_THREADS) {
@@ -1851,34 +1856,78 @@ __global__ void __launch_bounds__(KL_THREADS) k_keylines(LineDeviceArgs a, plh_k
       if (a.mask[(long long)(int)sy * a.w + (int)sx] == 0 && a.mask[(long long)(int)ey * a.w + (int)ex] == 0) valid = false;
     }
     const float response = seg_length(e) / (float)max(w, h);
-    keys[i] = valid ? (((unsigned long long)__float_as_uint(response) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i)) : 0ull;
+    const unsigned long long key = valid ? (((unsigned long long)__float_as_uint(response) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i)) : 0ull;
+    keys[i] = key;
+    if (valid) atomicAdd(&s_hist[KL_BINS - 1 - kl_bin(key)], 1);   // (stored from the top: bin 0 holds the largest responses)
     myValid += valid;
   }
-  if (myValid) atomicAdd(&s_valid, myValid);
+  int nValid = myValid;
+  for (int m = 32; m >= 1; m >>= 1) nValid += __shfl_xor(nValid, m);
   __syncthreads();
-  // top-(outCap) by (response desc, detection index asc): repeated arg-max below the previous pick
-  unsigned long long prev = ~0ull;
-  int K = 0;
-  for (int k = 0; k < a.outCap; k++) {
-    unsigned long long best = 0;
-    for (int i = tid; i < n; i += KL_THREADS) {
-      const unsigned long long v = keys[i];
-      if (v < prev && v > best) best = v;
+  // the first (reversed) bin at which the count from the top reaches outCap: every key above it is selected for sure, the keys
+  // of that bin compete for the remaining places
+  int tRev = KL_BINS - 1;
+  {
+    const int h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2], h3 = s_hist[4 * lane + 3];
+    int incl = h0 + h1 + h2 + h3;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
     }
-    for (int m = 32; m >= 1; m >>= 1) {
-      const unsigned long long o = __shfl_xor(best, m);
-      best = o > best ? o : best;
+    const int before = incl - (h0 + h1 + h2 + h3);
+    int mine = 4 * KL_BINS;   // (no bin of this lane reaches outCap)
+    if (before < a.outCap && incl >= a.outCap) {
+      int c = before + h0;
+      mine = 4 * lane;
+      if (c < a.outCap) { c += h1; mine = 4 * lane + 1; }
+      if (c < a.outCap) { c += h2; mine = 4 * lane + 2; }
+      if (c < a.outCap) mine = 4 * lane + 3;
     }
-    __syncthreads();
-    if (lane == 0) s_red[wv] = best;
-    __syncthreads();
-    best = s_red[0];
-    for (int w = 1; w < KL_THREADS / 64; w++) best = s_red[w] > best ? s_red[w] : best;
-    if (best == 0) break;
-    if (tid == 0) sel[k] = best;
-    prev = best;
-    K++;
+    for (int m = 32; m >= 1; m >>= 1) mine = min(mine, __shfl_xor(mine, m));
+    if (mine < KL_BINS) tRev = mine;   // (fewer valid keys than outCap: every one is a candidate)
   }
+  // the candidates, in no particular order
+  int C = 0;
+  for (int i0 = 0; i0 < n; i0 += KL_THREADS) {
+    const int i = i0 + lane;
+    const unsigned long long key = i < n ? keys[i] : 0ull;
+    const bool cand = key != 0ull && KL_BINS - 1 - kl_bin(key) <= tRev;
+    const unsigned long long bm = __ballot(cand);
+    const int at = C + __popcll(bm & ((1ull << lane) - 1ull));
+    if (cand && at < KL_CAND) s_cand[at] = key;
+    C += __popcll(bm);
+  }
+  __syncthreads();
+  int K = min(nValid, a.outCap);
+  if (C <= KL_CAND) {
+    // rank = number of larger candidates
+    for (int m = lane; m < C; m += KL_THREADS) {
+      const unsigned long long key = s_cand[m];
+      int rank = 0;
+      for (int x = 0; x < C; x++) rank += s_cand[x] > key ? 1 : 0;
+      if (rank < a.outCap) sel[rank] = key;
+    }
+  } else {
+    // top-(outCap) by (response desc, detection index asc): repeated arg-max below the previous pick, over all keys
+    unsigned long long prev = ~0ull;
+    K = 0;
+    for (int k = 0; k < a.outCap; k++) {
+      unsigned long long best = 0;
+      for (int i = tid; i < n; i += KL_THREADS) {
+        const unsigned long long v = keys[i];
+        if (v < prev && v > best) best = v;
+      }
+      for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = __shfl_xor(best, m);
+        best = o > best ? o : best;
+      }
+      if (best == 0) break;
+      if (tid == 0) sel[k] = best;
+      prev = best;
+      K++;
+    }
+  }
+  if (tid == 0) s_valid = nValid;
   __syncthreads();
   if (tid == 0) {   // LineExtractor.cpp:44-64
     const int nv = s_valid;

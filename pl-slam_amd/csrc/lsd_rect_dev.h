@@ -152,9 +152,9 @@ __device__ __forceinline__ LsdAdvRect lsd_adv_load(const double* q) {
 }
 
 // The pixel counts of rect_nfa() (oracle/lsd.cc rect_nfa, with the published code's quirks: integer scan-line steps, the tail
-// point's x where a y is meant).  The scan-line bounds advance by integer steps from an integer start, so row y's span is a
-// closed form of the number of rows walked before it; rows outside the image are skipped before the step update (`continue`),
-// so they do not count.  One float per pixel from the angle plane k_lsd_grad writes for this level (no record -> table chain).
+// point's x where a y is meant).  The scan-line bounds advance by integer steps from an integer start; rows outside the image
+// are skipped before the step update (`continue`), so they do not count (LsdScanWalk below).  One float per pixel from the angle
+// plane k_lsd_grad writes for this level (no record -> table chain).
 struct LsdScanGeom {   // what the scan of a rectangle's rows needs: the top corner's x, the rows of the left / right corners, the steps
   int mx, ly, ry, fl, sl, fr, sr, yA, yB;
 };
@@ -195,91 +195,132 @@ __device__ __forceinline__ LsdScanGeom lsd_scan_geom(const RcFrame& f, const Lsd
   g.yA = max(my, 0); g.yB = min(oy[iMax], f.sh - 1);   // the scan lines inside the image
   return g;
 }
-// the span of scan line y (yA <= y <= yB), clipped to the image; empty when xb < xa
-__device__ __forceinline__ void lsd_scan_span(const LsdScanGeom& g, int sw, int y, int& xa, int& xb) {
-  // steps taken in front of row y: one per row of [yA, y), the first kind for the rows above the left (right) corner
-  const int j = y - g.yA;
-  const int nl = max(min(y, g.ly) - g.yA, 0), nr = max(min(y, g.ry) - g.yA, 0);
-  const int left = g.mx + g.fl * nl + g.sl * (j - nl), right = g.mx + g.fr * nr + g.sr * (j - nr);
-  xa = max(left, 0); xb = min(right, sw - 1);
+// (an empty geometry: no scan line at all -- what a lane group without a rectangle walks)
+__device__ __forceinline__ LsdScanGeom lsd_scan_none() {
+  LsdScanGeom g;
+  g.mx = 0; g.ly = 0; g.ry = 0; g.fl = 0; g.sl = 0; g.fr = 0; g.sr = 0; g.yA = 1; g.yB = 0;
+  return g;
 }
 __device__ __forceinline__ bool lsd_aligned_deg(double theta, float angDeg, double prec) {
   return angDeg >= 0.f && lsd_aligned(theta, (double)angDeg * kDegToRads, prec);
 }
-// EIGHT LANES per rectangle: lane j of the group takes pixel xa + j (+ 8, + 16, ...) of every scan line, so that a group reads
-// runs of consecutive floats (one cache line per scan line and group where a lane per rectangle touched 64 lines per load), two
-// scan lines in flight at a time.  `on`: the group has a rectangle (uniform in the group).  totalOut is the rectangle's pixel
-// count (the same in all eight lanes), algOut THIS LANE's share of the aligned pixels: the caller adds the eight up.  The counts
-// are sums over pixels, so how the pixels are dealt to lanes does not matter.
-__device__ __forceinline__ void lsd_rect_counts_g8(const RcFrame& f, const LsdAdvRect& r, bool on, int j, int& totalOut, int& algOut) {
-  int total = 0, alg = 0;
-  if (on) {
-    const LsdScanGeom g = lsd_scan_geom(f, r);
-    for (int y = g.yA; y <= g.yB; y += 2) {
-      int xa0, xb0, xa1 = 1, xb1 = 0;
-      lsd_scan_span(g, f.sw, y, xa0, xb0);
-      if (y + 1 <= g.yB) lsd_scan_span(g, f.sw, y + 1, xa1, xb1);
-      if (xb0 >= xa0) total += xb0 - xa0 + 1;
-      if (xb1 >= xa1) total += xb1 - xa1 + 1;
-      const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
-      const float* row1 = row0 + f.spitch;
-      float a0 = -1024.f, a1 = -1024.f;   // NOTDEF
-      if (xa0 + j <= xb0) a0 = row0[xa0 + j];
-      if (xa1 + j <= xb1) a1 = row1[xa1 + j];
-      if (lsd_aligned_deg(r.theta, a0, r.prec)) ++alg;
-      if (lsd_aligned_deg(r.theta, a1, r.prec)) ++alg;
-      for (int x = xa0 + 8 + j; x <= xb0; x += 8)
-        if (lsd_aligned_deg(r.theta, row0[x], r.prec)) ++alg;
-      for (int x = xa1 + 8 + j; x <= xb1; x += 8)
-        if (lsd_aligned_deg(r.theta, row1[x], r.prec)) ++alg;
+
+// isAligned() of a pixel against a rectangle, decided in float degrees wherever that is safe.  The reference folds |theta - a| at
+// 3 pi / 2 and compares with prec in double.  The float difference of the two angles in degrees is off by < 2e-4 degrees (rounding
+// of theta to a float below 540, of the subtraction), so more than 1e-3 degrees away from the tolerance the float verdict is the
+// double one; only the lanes inside that band take lsd_aligned() itself (rare).  Near the
+// fold (a difference of 270 degrees) either side is "not aligned" for every tolerance below 89 degrees (rect_improve's are at most
+// 22.5), and NOTDEF (-1024) is more than 664 degrees from any theta: no special cases.
+struct LsdAlignTol {
+  double theta, prec;
+  float thDeg, lo, hi;
+};
+__device__ __forceinline__ LsdAlignTol lsd_align_tol(double theta, double prec) {
+  LsdAlignTol t;
+  t.theta = theta; t.prec = prec;
+  t.thDeg = (float)(theta * (180.0 / kPI));
+  const float pd = (float)(prec * (180.0 / kPI));
+  t.lo = pd - 1e-3f; t.hi = pd + 1e-3f;
+  return t;
+}
+__device__ __forceinline__ float lsd_fold_deg(float thDeg, float angDeg) {   // the folded difference in float degrees
+  const float d = fabsf(thDeg - angDeg);
+  return d > 270.f ? fabsf(d - 360.f) : d;
+}
+
+// The walk over a rectangle's scan lines, EIGHT LANES per rectangle: lane j of the group takes pixel xa + j (+ 8, + 16, ...) of
+// every scan line, so that a group reads runs of consecutive floats (one cache line per scan line and group where a lane per
+// rectangle touched 64 lines per load), two scan lines per trip.  The published loop advances its bounds AFTER a scan line -- by
+// the first kind of step while the line lies above the left (right) corner, by the second kind from that corner's line on -- and
+// only on lines inside the image (`continue` in front of the update): the walk starts at the first line inside the image and does
+// exactly that.  The geometry is uniform in the group (computed once per rectangle by ONE lane and handed over through LDS by
+// value: the corner sort is ~500 instructions).  Loads are unconditional (clamped addresses, the value replaced by NOTDEF where the
+// lane has no pixel) and the alignment test has no branch except the one around the rare exact path: round 5's first version of
+// this loop compiled to ~200 instructions per pair of scan lines, this one to ~60.
+// totalOut is the rectangle's pixel count (the same in all eight lanes), algOut THIS LANE's share of the aligned pixels: the
+// caller adds the eight up.  The counts are sums over pixels, so how the pixels are dealt to lanes does not matter.
+__device__ __forceinline__ void lsd_rect_counts_g8(const RcFrame& f, const LsdScanGeom g, const LsdAlignTol& t, int j, int& totalOut, int& algOut) {
+  const int ly = g.ly, ry = g.ry, fl = g.fl, sl = g.sl, fr = g.fr, sr = g.sr, yB = g.yB, xMax = f.sw - 1;
+  int left = g.mx, right = g.mx, total = 0, alg = 0;
+#pragma clang loop unroll(disable) vectorize(disable)
+  for (int y = g.yA; y <= yB; y += 2) {
+    const int xa0 = max(left, 0), n0 = max(min(right, xMax) - xa0 + 1, 0);
+    left += y < ly ? fl : sl; right += y < ry ? fr : sr;
+    const bool two = y + 1 <= yB;
+    const int xa1 = max(left, 0), n1 = two ? max(min(right, xMax) - xa1 + 1, 0) : 0;
+    left += two ? (y + 1 < ly ? fl : sl) : 0; right += two ? (y + 1 < ry ? fr : sr) : 0;
+    total += n0 + n1;
+    const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
+    const float* row1 = row0 + (two ? f.spitch : 0);
+    const int nmax = max(n0, n1);
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int k = j; k < nmax; k += 8) {
+      const float v0 = row0[min(xa0 + k, xMax)], v1 = row1[min(xa1 + k, xMax)];
+      const float d0 = lsd_fold_deg(t.thDeg, k < n0 ? v0 : -1024.f), d1 = lsd_fold_deg(t.thDeg, k < n1 ? v1 : -1024.f);
+      bool r0 = d0 < t.lo, r1 = d1 < t.lo;
+      const bool m0 = !r0 && d0 <= t.hi, m1 = !r1 && d1 <= t.hi;
+      if (m0 || m1) {   // within 1e-3 degrees of the tolerance (rare): the reference's own arithmetic
+        if (m0) r0 = lsd_aligned_deg(t.theta, v0, t.prec);   // (no wave vote here: the lane groups' loops are not in step)
+        if (m1) r1 = lsd_aligned_deg(t.theta, v1, t.prec);
+      }
+      alg += (r0 ? 1 : 0) + (r1 ? 1 : 0);
     }
   }
   totalOut = total; algOut = alg;
 }
 
-// The same scan for the two "finer precision" stages of rect_improve(): their five variants share the rectangle and differ in
-// the tolerance only (p / 2^m, prec = p pi), so ONE walk over the pixels counts all five: the folded angle difference of a
-// pixel is computed once (lsd_aligned's own expressions) and compared with the five tolerances.
-__device__ __forceinline__ double lsd_fold_diff(double theta, float angDeg) {   // lsd_aligned()'s n_theta; +inf for NOTDEF
-  if (!(angDeg >= 0.f)) return __builtin_inf();
-  double n_theta = theta - (double)angDeg * kDegToRads;
+// The same walk for the two "finer precision" stages of rect_improve(): their five variants share the rectangle and differ in
+// the tolerance only (p / 2^m, prec = p pi, descending), so ONE walk counts all five: the folded difference of a pixel is formed
+// once and compared with the five tolerances; a pixel within 1e-3 degrees of any of them takes lsd_aligned()'s own expressions.
+struct LsdAlignTol5 {
+  double theta, prec[5];
+  float thDeg, lo[5], hi[5];
+};
+__device__ __forceinline__ int lsd_aligned5(const LsdAlignTol5& t, float v, int alg[5]) {   // returns 1 when the pixel is in a margin
+  const float d = lsd_fold_deg(t.thDeg, v);
+  int inLo = 0, inHi = 0;
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    const int a = d < t.lo[m] ? 1 : 0;
+    alg[m] += a; inLo += a; inHi += d <= t.hi[m] ? 1 : 0;
+  }
+  return inLo != inHi ? 1 : 0;
+}
+__device__ __forceinline__ void lsd_aligned5_exact(const LsdAlignTol5& t, float v, int alg[5]) {   // undo the float verdicts, add the exact ones
+  const float d = lsd_fold_deg(t.thDeg, v);
+  double n_theta = t.theta - (double)v * kDegToRads;   // lsd_aligned()'s n_theta (v is a defined angle here: |d| < 23)
   if (n_theta < 0) n_theta = -n_theta;
   if (n_theta > k3_2PI) {
     n_theta -= k2PI;
     if (n_theta < 0) n_theta = -n_theta;
   }
-  return n_theta;
+#pragma unroll
+  for (int m = 0; m < 5; m++) alg[m] += (n_theta <= t.prec[m] ? 1 : 0) - (d < t.lo[m] ? 1 : 0);
 }
-__device__ __forceinline__ void lsd_rect_counts_g8_prec5(const RcFrame& f, const LsdAdvRect& r, bool on, int j, const double prec[5],
-                                                         int& totalOut, int alg[5]) {
-  int total = 0;
+__device__ __forceinline__ void lsd_rect_counts_g8_prec5(const RcFrame& f, const LsdScanGeom g, const LsdAlignTol5& t, int j, int& totalOut, int alg[5]) {
+  const int ly = g.ly, ry = g.ry, fl = g.fl, sl = g.sl, fr = g.fr, sr = g.sr, yB = g.yB, xMax = f.sw - 1;
+  int left = g.mx, right = g.mx, total = 0;
 #pragma unroll
   for (int m = 0; m < 5; m++) alg[m] = 0;
-  if (on) {
-    const LsdScanGeom g = lsd_scan_geom(f, r);
-    for (int y = g.yA; y <= g.yB; y += 2) {   // two scan lines in flight, as lsd_rect_counts_g8
-      int xa0, xb0, xa1 = 1, xb1 = 0;
-      lsd_scan_span(g, f.sw, y, xa0, xb0);
-      if (y + 1 <= g.yB) lsd_scan_span(g, f.sw, y + 1, xa1, xb1);
-      if (xb0 >= xa0) total += xb0 - xa0 + 1;
-      if (xb1 >= xa1) total += xb1 - xa1 + 1;
-      const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
-      const float* row1 = row0 + f.spitch;
-      float a0 = -1024.f, a1 = -1024.f;   // NOTDEF
-      if (xa0 + j <= xb0) a0 = row0[xa0 + j];
-      if (xa1 + j <= xb1) a1 = row1[xa1 + j];
-      const double d0 = lsd_fold_diff(r.theta, a0), d1 = lsd_fold_diff(r.theta, a1);
-#pragma unroll
-      for (int m = 0; m < 5; m++) alg[m] += (d0 <= prec[m] ? 1 : 0) + (d1 <= prec[m] ? 1 : 0);
-      for (int x = xa0 + 8 + j; x <= xb0; x += 8) {
-        const double d = lsd_fold_diff(r.theta, row0[x]);
-#pragma unroll
-        for (int m = 0; m < 5; m++) alg[m] += d <= prec[m] ? 1 : 0;
-      }
-      for (int x = xa1 + 8 + j; x <= xb1; x += 8) {
-        const double d = lsd_fold_diff(r.theta, row1[x]);
-#pragma unroll
-        for (int m = 0; m < 5; m++) alg[m] += d <= prec[m] ? 1 : 0;
+#pragma clang loop unroll(disable) vectorize(disable)
+  for (int y = g.yA; y <= yB; y += 2) {
+    const int xa0 = max(left, 0), n0 = max(min(right, xMax) - xa0 + 1, 0);
+    left += y < ly ? fl : sl; right += y < ry ? fr : sr;
+    const bool two = y + 1 <= yB;
+    const int xa1 = max(left, 0), n1 = two ? max(min(right, xMax) - xa1 + 1, 0) : 0;
+    left += two ? (y + 1 < ly ? fl : sl) : 0; right += two ? (y + 1 < ry ? fr : sr) : 0;
+    total += n0 + n1;
+    const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
+    const float* row1 = row0 + (two ? f.spitch : 0);
+    const int nmax = max(n0, n1);
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int k = j; k < nmax; k += 8) {
+      float v0 = row0[min(xa0 + k, xMax)], v1 = row1[min(xa1 + k, xMax)];
+      v0 = k < n0 ? v0 : -1024.f; v1 = k < n1 ? v1 : -1024.f;
+      const int m0 = lsd_aligned5(t, v0, alg), m1 = lsd_aligned5(t, v1, alg);
+      if (m0 | m1) {
+        if (m0) lsd_aligned5_exact(t, v0, alg);
+        if (m1) lsd_aligned5_exact(t, v1, alg);
       }
     }
   }

@@ -160,6 +160,85 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
   rec[5] = theta; rec[6] = dx; rec[7] = dy;
 }
 
+// The same rectangle for ONE region by a whole wavefront -- for the few regions of a frame that are hundreds or thousands of pixels:
+// in the lane-per-region form above such a region keeps its lane (and with it the wavefront) busy for cnt / RC_K dependent
+// trips to global memory per pass, and the kernel's duration is that one wavefront's.  Here 64 consecutive log entries are
+// loaded at once, every lane forms its element's terms (the products of the reference, rounded as there), and lanes 0 .. 2 add
+// the three series from LDS in element order -- lsd_region2rect's scheme (lsd_grow.hip), the same doubles as one lane adding them.
+// T: [3][64] doubles of LDS.  The result is uniform over the wavefront.
+__device__ __forceinline__ double rc_chain_add(const double* T, int lane, double acc, int n) {
+  const int ch = min(lane, 2);
+  const D2* row = reinterpret_cast<const D2*>(T + ch * 64);
+  const int n2 = ((n + 7) >> 3) << 2;   // (the terms behind the end are +0.0: exact, the accumulators are never -0.0)
+  for (int l = 0; l < n2; l += 4) {
+    const D2 v0 = row[l], v1 = row[l + 1], v2 = row[l + 2], v3 = row[l + 3];
+    acc += v0.x; acc += v0.y; acc += v1.x; acc += v1.y;
+    acc += v2.x; acc += v2.y; acc += v3.x; acc += v3.y;
+  }
+  return acc;
+}
+__device__ __forceinline__ double rc_wave_max(double v) {
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ void rc_region2rect_by_wave(double* T, const uint32_t* log, const uint32_t* logq, int lane, uint32_t off, int cnt,
+                                                       double reg_angle, double prec, double rec[8]) {
+  double acc = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    double w = 0, wx = 0, wy = 0;
+    if (i < cnt) {
+      const uint32_t p = log[off + (uint32_t)i];
+      w = q_modgrad(logq[off + (uint32_t)i]);
+      wx = (double)(int)(p & 0xffffu) * w;
+      wy = (double)(int)(p >> 16) * w;
+    }
+    PLH_WAVE_SYNC();
+    T[lane] = wx; T[64 + lane] = wy; T[128 + lane] = w;
+    PLH_WAVE_SYNC();
+    acc = rc_chain_add(T, lane, acc, min(64, cnt - base));
+  }
+  const double sum = bcast_f64(acc, 2);
+  const double x = bcast_f64(acc, 0) / sum, y = bcast_f64(acc, 1) / sum;
+  acc = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    double a = 0, b = 0, cc = 0;
+    if (i < cnt) {
+      const uint32_t p = log[off + (uint32_t)i];
+      const double w = q_modgrad(logq[off + (uint32_t)i]);
+      const double ddx = (double)(int)(p & 0xffffu) - x, ddy = (double)(int)(p >> 16) - y;
+      a = ddy * ddy * w;
+      b = ddx * ddx * w;
+      cc = -(ddx * ddy * w);   // Ixy -= v  ==  Ixy += -v
+    }
+    PLH_WAVE_SYNC();
+    T[lane] = a; T[64 + lane] = b; T[128 + lane] = cc;
+    PLH_WAVE_SYNC();
+    acc = rc_chain_add(T, lane, acc, min(64, cnt - base));
+  }
+  const double Ixx = bcast_f64(acc, 0), Iyy = bcast_f64(acc, 1), Ixy = bcast_f64(acc, 2);
+  const double theta = lsd_rect_theta(Ixx, Iyy, Ixy, reg_angle, prec);
+  const D2 cs = lsd_sincos_inl(theta);
+  const double dx = cs.x, dy = cs.y;
+  double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+  for (int i = lane; i < cnt; i += 64) {
+    const uint32_t p = log[off + (uint32_t)i];
+    const double rdx = (double)(int)(p & 0xffffu) - x, rdy = (double)(int)(p >> 16) - y;
+    const double l = rdx * dx + rdy * dy;
+    const double w = -rdx * dy + rdy * dx;
+    l_max = fmax(l_max, l); l_min = fmin(l_min, l);
+    w_max = fmax(w_max, w); w_min = fmin(w_min, w);
+  }
+  l_max = rc_wave_max(l_max); l_min = -rc_wave_max(-l_min);   // (extremes: exact in any order)
+  w_max = rc_wave_max(w_max); w_min = -rc_wave_max(-w_min);
+  rec[0] = x + l_min * dx; rec[1] = y + l_min * dy;
+  rec[2] = x + l_max * dx; rec[3] = y + l_max * dy;
+  const double width = w_max - w_min;
+  rec[4] = width < 1.0 ? 1.0 : width;
+  rec[5] = theta; rec[6] = dx; rec[7] = dy;
+}
+
 // ADV = false: LSD_REFINE_STD, every rectangle is a segment.  ADV = true: the rectangle goes to its slot's LsdAdvRec; lsd_adv.hip
 // takes it from there.
 // Round 5: two kernels.  The one-block-per-frame form (256 threads, 46.6 KB of LDS, 170 registers) could not be placed on a CU
@@ -168,7 +247,16 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
 // (a light block per frame, 512 bytes of LDS); k_lsd_rects_sums runs ONE WAVEFRONT per block (7.4 KB of LDS) on 64 consecutive
 // entries of that order, RC_GROUPS blocks per frame taking the groups round robin (the largest regions first, so the blocks of a
 // frame end together).  Which lane evaluates a region changes nothing about its sums.
-constexpr int RC_GROUPS = 32;
+#ifndef PLH_RC_GROUPS
+#define PLH_RC_GROUPS 32
+#endif
+constexpr int RC_GROUPS = PLH_RC_GROUPS;
+// regions of this size class and above (>= 512 pixels: a few dozen per busy frame) are evaluated one per wavefront, the rest one
+// per lane (64 regions of similar size per wavefront)
+#ifndef PLH_RC_BIG_LOG2
+#define PLH_RC_BIG_LOG2 9
+#endif
+constexpr int RC_BIG_CLASS = 4 * (PLH_RC_BIG_LOG2 - 2);
 
 __global__ void __launch_bounds__(256) k_lsd_rects_sort(LineDeviceArgs a) {
   __shared__ int s_hist[RC_BINS];
@@ -183,7 +271,10 @@ __global__ void __launch_bounds__(256) k_lsd_rects_sort(LineDeviceArgs a) {
   __syncthreads();
   if (tid == 0) {
     int acc = 0;
-    for (int k = RC_BINS - 1; k >= 0; k--) { const int c = s_hist[k]; s_hist[k] = acc; acc += c; }
+    for (int k = RC_BINS - 1; k >= 0; k--) {
+      if (k == RC_BIG_CLASS - 1) order[-1] = (uint32_t)acc;   // park[1]: how many entries lie in the classes above (the order's head)
+      const int c = s_hist[k]; s_hist[k] = acc; acc += c;
+    }
   }
   __syncthreads();
   for (int i = tid; i < n; i += 256) order[atomicAdd(&s_hist[rc_size_class(ent[i].y)], 1)] = (uint32_t)i;
@@ -205,14 +296,7 @@ __device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
                                                                                 // one double per log entry fits (pix | ordered are adjacent)
   RcStage st;
   st.p = s_p; st.w = s_w; st.off = s_off; st.cnt = s_cnt;
-  for (int base = (int)blockIdx.x * 64; base < n; base += 64 * RC_GROUPS) {
-    const int k = base + lane;
-    int slot = -1;
-    uint4 e = uint4{0u, 0u, 0u, 0u};
-    if (k < n) { slot = (int)order[k]; e = ent[slot]; }   // LsdRegionEntry
-    double rec[8];
-    rc_wave_region2rect(st, log, logq, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
-    if (slot < 0) continue;
+  auto put = [&](int slot, const double* rec) {
     if constexpr (!ADV) {
       lsd_store_segment(&ent[slot], rec);
     } else {
@@ -221,6 +305,25 @@ __device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
       for (int k2 = 0; k2 < 8; k2++) ar->r[k2] = rec[k2];
       ar->r[8] = a.prec; ar->r[9] = a.p;
     }
+  };
+  // the head of the order: one big region per wavefront at a time (the blocks of a frame take them round robin) ...
+  const int nBig = min((int)order[-1], n);
+  for (int k = (int)blockIdx.x; k < nBig; k += RC_GROUPS) {
+    const int slot = (int)order[k];
+    const uint4 e = ent[slot];   // LsdRegionEntry (uniform)
+    double rec[8];
+    rc_region2rect_by_wave(s_w, log, logq, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+    if (lane == 0) put(slot, rec);
+  }
+  // ... then the rest, 64 consecutive entries of the order per wavefront, one region per lane
+  for (int base = nBig + (int)blockIdx.x * 64; base < n; base += 64 * RC_GROUPS) {
+    const int k = base + lane;
+    int slot = -1;
+    uint4 e = uint4{0u, 0u, 0u, 0u};
+    if (k < n) { slot = (int)order[k]; e = ent[slot]; }   // LsdRegionEntry
+    double rec[8];
+    rc_wave_region2rect(st, log, logq, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+    if (slot >= 0) put(slot, rec);
   }
 }
 __global__ void __launch_bounds__(64) k_lsd_rects(LineDeviceArgs a) { lsd_rects_group<false>(a); }

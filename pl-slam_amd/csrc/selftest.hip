@@ -102,6 +102,27 @@ __global__ void __launch_bounds__(64) k_shim_selftest(int* failures, int rounds)
 }
 #endif
 
+// A fixed amount of VALU work (independent 32-bit multiply-add chains, no memory): 4096 blocks x 256 threads x `iters` x 64
+// operations.  Its duration depends on the box's CU count, clocks and power state only -- what bench.py reports beside a measured
+// rate so that numbers from different boxes can be compared (plh_box_probe).
+__global__ void __launch_bounds__(256) k_box_probe(unsigned* sink, int iters) {
+  unsigned a[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = threadIdx.x * 2654435761u + blockIdx.x + (unsigned)i;
+  const unsigned m = (unsigned)iters | 3u;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) a[i] = a[i] * m + (unsigned)r;
+    }
+  }
+  unsigned x = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) x ^= a[i];
+  if (x == 0x12345678u) *sink = x;
+}
+
 }  // namespace plh
 
 using namespace plh;
@@ -143,5 +164,29 @@ plh_status plh_selftest(int device, int* failing_checks, int32_t* per_shim, int 
 }
 
 int plh_selftest_shims(void) { return ST_COUNT; }
+
+// bench.py's box normaliser: the duration of a fixed VALU-only launch (k_box_probe), twice -- the first run finds the GPU in
+// whatever power state it is in, the second one at its running clocks.
+plh_status plh_box_probe(int device, int iters, float ms[2]) {
+  if (!ms || iters <= 0) return PLH_ERR_INVALID;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  PLH_HIP(hipSetDevice(device));
+  unsigned* d = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  PLH_HIP(hipMalloc((void**)&d, 4));
+  PLH_HIP(hipEventCreate(&e0));
+  PLH_HIP(hipEventCreate(&e1));
+  for (int k = 0; k < 2; k++) {
+    PLH_HIP(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_box_probe, dim3(4096), dim3(256), 0, nullptr, d, iters);
+    PLH_HIP(hipEventRecord(e1, nullptr));
+    PLH_HIP(hipEventSynchronize(e1));
+    PLH_HIP(hipEventElapsedTime(&ms[k], e0, e1));
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  return PLH_OK;
+}
 
 }  // extern "C"

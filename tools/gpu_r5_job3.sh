@@ -7,7 +7,7 @@ O=gpurun_out/r5j3
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 if [ "${TESTS:-1}" = 1 ]; then
-  timeout 1500 python -m pytest tests -m gpu -x -q --timeout 1200 2>&1 | grep -v "amdgpu.ids\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -15 | tee $O/tests.txt
+  timeout 1500 python -m pytest ${TESTSEL:-tests} -m gpu -x -q --timeout 1200 2>&1 | grep -v "amdgpu.ids\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -15 | tee $O/tests.txt
 fi
 show='import json,sys
 d=json.loads(sys.stdin.read()); k=d["kernel_ms_per_launch"]; t=d.get("kernel_ms_per_launch_timed_region") or {}
@@ -28,4 +28,5 @@ for t in ab_r4 .; do
   printf "share512 adv %-6s: " $t | tee -a $O/ab.txt
   (cd $t && timeout 600 python bench.py --refine adv --batch 512 --nsplit 1 --rows 376 --cols 1241 --nfeatures 2000 --steps 8 --warmup 2 --no-cpu-baseline --no-extras --no-verify 2>/dev/null | tail -1 | python -c "$show") | tee -a $O/ab.txt
 done
+bash tools/pmc_insts.sh 256 > $O/pmcinst.txt 2>&1
 exit 0

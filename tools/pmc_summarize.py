@@ -3,7 +3,7 @@
 
 Units and corrections (MI355X_MICROARCH.md, "HBM"): both counters are reported in KiB of memory-side (fabric) traffic of
 the L2, Infinity-Cache hits included.  On gfx950 FETCH_SIZE tallies a 128-byte request at 64 bytes.  Calibrated on this code
-base's own access patterns (tools/ubench/pmc_patterns.hip, profiles/r04_pmc_calibration.json, buffers far beyond the Infinity
+base's own access patterns (tools/ubench/pmc_patterns.hip, profiles/r05_pmc_calibration.json, buffers far beyond the Infinity
 Cache): consecutive-lane streams of 16-byte, 4-byte AND 1-byte loads all coalesce into 128-byte requests -> x 2.0; random 4-byte
 gathers issue one 64-byte request per load and are counted at face value -> x 1.0.  A kernel gets the correction of the pattern
 that dominates its reads (GATHER_KERNELS below); `fetch_x1` and `fetch_x2` give both readings.  WRITE_SIZE calibrates exactly on
@@ -41,7 +41,7 @@ def main():
     # the library build the counters were collected on: bench.py reports them only for the same build
     out = {"batch": batch, "unit": "bytes per frame per launch",
            "fetch_correction": {"streams (16-, 4-, 1-byte consecutive lanes)": 2.0, "random 4-byte gathers": 1.0,
-                                "calibration": "profiles/r04_pmc_calibration.json (tools/pmc_calibrate.sh)", "gather_kernels": list(GATHER_KERNELS)},
+                                "calibration": "profiles/r05_pmc_calibration.json (tools/pmc_calibrate.sh)", "gather_kernels": list(GATHER_KERNELS)},
            "build": g._lib_id(g.LIB), "kernels": {}}
     steps = max(fc.get("k_lsd_grow", 0), wc.get("k_lsd_grow", 0), 1)   # one launch per front-end step
     for k in sorted(set(fetch) | set(write)):
