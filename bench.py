@@ -631,12 +631,12 @@ def main():
         alg = W.algorithmic_bytes(res)
         dom = int(np.argmax(per_ms))
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame, and the
-        # SQ instruction counters (tools/pmc_insts.sh -> profiles/r02_insts.json): collected on the headline workload only
+        # SQ instruction counters (tools/pmc_insts.sh -> profiles/r05_insts.json): collected on the headline workload only
         headline = W.tum and args.nfeatures == 1000 and real is None
         # PMC figures are a property of a build: they are reported only when the file carries this library's build id
         build = P.load().plh_version().decode().split("build ")[-1].strip()
-        tj, ij = load_profile_json("hbm_traffic.json"), (load_profile_json("r04_insts.json") or load_profile_json("r03_insts.json"))
-        pmc_ok = headline and refine == 0 and not args.no_screen
+        tj, ij = load_profile_json("hbm_traffic.json"), load_profile_json("r05_insts.json")
+        pmc_ok = headline and refine == lib_default and not args.no_screen   # (the profiles are collected at the library's default level)
         traffic = tj.get("kernels", {}) if pmc_ok and tj.get("build") == build else {}
         insts = ij.get("kernels", {}) if pmc_ok and ij.get("build") == build else {}
         pmc_note = {"library_build": build, "hbm_traffic.json": tj.get("build"), "insts.json": ij.get("build"),
@@ -694,8 +694,10 @@ def main():
                                    % (cols, rows, args.nlevels, args.nfeatures, args.nlines, "TUM1.yaml" if W.tum else "KITTI00-02.yaml",
                                       B, args.nsplit, Bp),
                        "lsd_refine": {"level": "LSD_REFINE_ADV" if refine else "LSD_REFINE_STD", "library_default": "LSD_REFINE_ADV" if lib_default else "LSD_REFINE_STD",
-                                      "note": "which level the reference's system opencv_contrib LSDDetector runs cannot be checked in this image "
-                                              "(INTEGRATION.md section 2); the other level is measured under secondary.refine_%s" % ("std" if refine else "adv")},
+                                      "note": "src/LineExtractor.cpp:39-40 links the system opencv_contrib LSDDetector, which creates its detector with "
+                                              "LSD_REFINE_ADV as published (no OpenCV binary in this image to check; INTEGRATION.md section 2); the "
+                                              "un-linked twin in the reference's tree would run STD; the other level is measured under "
+                                              "secondary.refine_%s" % ("std" if refine else "adv")},
                        "density_screen": not args.no_screen,
                        "mean_keypoints_per_frame": round(float(res["n"].mean()), 1), "mean_keylines_per_frame": round(float(res["nl"].mean()), 1),
                        "mean_orb_matches_per_pair": round(float(res["nm_orb"].mean()), 1),
@@ -792,6 +794,15 @@ def main():
                                                                   TUM1_K if W.tum else None, TUM1_D if W.tum else None, refine=refine)
         except Exception as e:
             out["latency_ms_single_frame"] = {"error": repr(e)[:200]}
+        if headline and isinstance(out["latency_ms_single_frame"], dict) and "error" not in out["latency_ms_single_frame"]:
+            # ... and the other frame shape the north star names, at both refine levels
+            try:
+                kf = S.make_frames(2, 4, 376, 1241, unique=4)
+                for lvl, name in ((refine, "kitti_1241x376"), (1 - refine, "kitti_1241x376_refine_%s" % ("std" if refine else "adv"))):
+                    r2 = single_frame_latency(P, torch, dev, kf, 2000, 8, 200, None, None, reps=6, refine=lvl)
+                    out["latency_ms_single_frame"][name] = {k: v for k, v in r2.items() if k != "note"}
+            except Exception as e:
+                out["latency_ms_single_frame"]["kitti_1241x376"] = {"error": repr(e)[:200]}
         # secondary workload: KITTI 1241x376 / 2000 features (BASELINE configs[4]'s frame shape)
         if headline:
             try:

@@ -8,8 +8,9 @@
 //                   rectangle; meaningful -> segment, else -> the frame's work list
 //   k_adv_improve   rect_improve() of the listed rectangles, eight lanes per rectangle through all five stages: a stage's five
 //                   variants follow from its starting rectangle alone (lsd_adv_variant, lsd_rect_dev.h), so their pixel counts
-//                   are taken one after the other by the eight lanes (the two "finer precision" stages share one walk:
-//                   lsd_rect_counts_g8_prec5), their nfa() side by side in five of the eight lanes, and the loop's
+//                   are taken in ONE walk by the eight lanes (lsd_rect_counts_g8_prec5: one rectangle, five tolerances;
+//                   lsd_rect_counts_g8_var5: five narrowed rectangles, every pixel loaded and tested once), their nfa() side by
+//                   side in five of the eight lanes, and the loop's
 //                   `if (v > log_nfa)` is replayed in order; meaningful -> segment, rejected after the last stage -> dropped
 //   k_adv_compact   stable compaction of the surviving segments, nSegs
 // Rectangles are independent of each other: nothing here is ordered except the compaction.
@@ -120,15 +121,7 @@ __global__ void __launch_bounds__(64) k_adv_first(LineDeviceArgs a) {
   }
 }
 
-#ifndef PLH_ADV_IMPROVE_WAVES
-#define PLH_ADV_IMPROVE_WAVES 0
-#endif
-#if PLH_ADV_IMPROVE_WAVES > 0
-#define PLH_ADV_IMPROVE_ATTR __attribute__((amdgpu_waves_per_eu(PLH_ADV_IMPROVE_WAVES)))
-#else
-#define PLH_ADV_IMPROVE_ATTR
-#endif
-__global__ void __launch_bounds__(64) PLH_ADV_IMPROVE_ATTR k_adv_improve(LineDeviceArgs a) {
+__global__ void __launch_bounds__(64) k_adv_improve(LineDeviceArgs a) {
   __shared__ LsdScanGeom s_geom[8 * 5];   // [rectangle of the pass][variant]
   __shared__ int s_ok[8 * 5];
   const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7, g0 = lane & ~7;
@@ -177,18 +170,11 @@ __global__ void __launch_bounds__(64) PLH_ADV_IMPROVE_ATTR k_adv_improve(LineDev
         lsd_rect_counts_g8_prec5(rf, s_geom[grp * 5], t5, j, total, alg);   // (the gate of stage 4 does not move: all five or none)
 #pragma unroll
         for (int m = 0; m < 5; m++) { tot[m] = total; alg[m] = adv_sum8(alg[m]); }
-      } else {
+      } else {   // a width stage: the five variants in one walk
         const LsdAlignTol t = lsd_align_tol(r.theta, r.prec);
-#pragma unroll 1
-        for (int m = 0; m < 5; m++) {
-          int total, al;
-          lsd_rect_counts_g8(rf, s_geom[grp * 5 + m], t, j, total, al);
-          al = adv_sum8(al);
-          // (m is a loop counter, not a constant: the arrays are written through selects so that they stay in registers)
+        lsd_rect_counts_g8_var5(rf, s_geom + grp * 5, t, j, tot, alg);
 #pragma unroll
-          for (int k = 0; k < 5; k++)
-            if (k == m) { tot[k] = total; alg[k] = al; }
-        }
+        for (int m = 0; m < 5; m++) alg[m] = adv_sum8(alg[m]);
       }
       // nfa() of variant j + 1 in lane j < 5 of the group
       double v = 0.0;

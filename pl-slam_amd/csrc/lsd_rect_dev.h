@@ -269,6 +269,72 @@ __device__ __forceinline__ void lsd_rect_counts_g8(const RcFrame& f, const LsdSc
   totalOut = total; algOut = alg;
 }
 
+// ONE walk for the five variants of a width stage of rect_improve() (reduce width / one side / the other side): the variants are
+// the stage's rectangle narrowed by 0.5 .. 2.5 pixels, so their scan lines and spans nearly coincide -- but each has its own corner
+// sort, its own integer steps and its own first and last scan line, so each keeps its own walk (left / right bounds advanced on its
+// own lines only); what is shared is the pixel: a scan line's union span is loaded once, its pixels are tested for alignment once
+// (same theta, same tolerance in these stages) and counted for every variant whose span holds them.  Same counts as five separate
+// walks, a third of the loads -- and the walks, not nfa(), are what k_adv_improve's duration is made of
+// (profiles/r05_rects_improve_alone_variants.txt).  gs: the five geometries in LDS (lsd_scan_none() for a variant the width gate
+// stopped).
+struct LsdVar5Line {   // one scan line of the five variants: their spans (empty: xa = 1, xb = 0) and the union of the non-empty ones
+  int xa[5], xb[5], ua, ub;
+};
+__device__ __forceinline__ void lsd_var5_line(const LsdScanGeom* gs, int y, int xMax, int left[5], int right[5], int tot[5], LsdVar5Line& L) {
+  L.ua = 1 << 30; L.ub = -1;   // (no span on this line: ua + j stays far above ub)
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    const LsdScanGeom g = gs[m];
+    const bool on = y >= g.yA && y <= g.yB;   // one of this variant's scan lines
+    const int a0 = max(left[m], 0), b0 = min(right[m], xMax);
+    const bool some = on && b0 >= a0;
+    L.xa[m] = some ? a0 : 1; L.xb[m] = some ? b0 : 0;
+    tot[m] += some ? b0 - a0 + 1 : 0;
+    left[m] += on ? (y < g.ly ? g.fl : g.sl) : 0;
+    right[m] += on ? (y < g.ry ? g.fr : g.sr) : 0;
+    L.ua = some ? min(L.ua, a0) : L.ua; L.ub = some ? max(L.ub, b0) : L.ub;
+  }
+}
+__device__ __forceinline__ void lsd_var5_count(const LsdAlignTol& t, const LsdVar5Line& L, int x, float v, int alg[5]) {
+  const float d = lsd_fold_deg(t.thDeg, v);
+  bool r = d < t.lo;
+  if (!r && d <= t.hi) r = lsd_aligned_deg(t.theta, v, t.prec);   // within 1e-3 degrees of the tolerance (rare): the reference's own arithmetic
+#pragma unroll
+  for (int m = 0; m < 5; m++) alg[m] += (r && x >= L.xa[m] && x <= L.xb[m]) ? 1 : 0;
+}
+__device__ __forceinline__ void lsd_rect_counts_g8_var5(const RcFrame& f, const LsdScanGeom* gs, const LsdAlignTol& t, int j, int tot[5], int alg[5]) {
+  const int xMax = f.sw - 1;
+  int left[5], right[5];
+  int yLo = 1 << 30, yHi = -1;
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    const LsdScanGeom g = gs[m];
+    left[m] = g.mx; right[m] = g.mx; tot[m] = 0; alg[m] = 0;
+    if (g.yA <= g.yB) { yLo = min(yLo, g.yA); yHi = max(yHi, g.yB); }
+  }
+#pragma clang loop unroll(disable) vectorize(disable)
+  for (int y = yLo; y <= yHi; y += 2) {   // two scan lines per trip to memory
+    LsdVar5Line L0, L1;
+    lsd_var5_line(gs, y, xMax, left, right, tot, L0);
+    L1.ua = 1 << 30; L1.ub = -1;
+#pragma unroll
+    for (int m = 0; m < 5; m++) { L1.xa[m] = 1; L1.xb[m] = 0; }
+    if (y + 1 <= yHi) lsd_var5_line(gs, y + 1, xMax, left, right, tot, L1);
+    const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
+    const float* row1 = row0 + f.spitch;
+    const int x0 = L0.ua + j, x1 = L1.ua + j;
+    float v0 = -1024.f, v1 = -1024.f;   // NOTDEF
+    if (x0 <= L0.ub) v0 = row0[x0];
+    if (x1 <= L1.ub) v1 = row1[x1];
+    lsd_var5_count(t, L0, x0, v0, alg);   // (a lane without a pixel: NOTDEF is aligned with nothing)
+    lsd_var5_count(t, L1, x1, v1, alg);
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int x = x0 + 8; x <= L0.ub; x += 8) lsd_var5_count(t, L0, x, row0[x], alg);
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int x = x1 + 8; x <= L1.ub; x += 8) lsd_var5_count(t, L1, x, row1[x], alg);
+  }
+}
+
 // The same walk for the two "finer precision" stages of rect_improve(): their five variants share the rectangle and differ in
 // the tolerance only (p / 2^m, prec = p pi, descending), so ONE walk counts all five: the folded difference of a pixel is formed
 // once and compared with the five tolerances; a pixel within 1e-3 degrees of any of them takes lsd_aligned()'s own expressions.

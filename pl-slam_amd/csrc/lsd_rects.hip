@@ -247,16 +247,10 @@ __device__ __forceinline__ void rc_region2rect_by_wave(double* T, const uint32_t
 // (a light block per frame, 512 bytes of LDS); k_lsd_rects_sums runs ONE WAVEFRONT per block (7.4 KB of LDS) on 64 consecutive
 // entries of that order, RC_GROUPS blocks per frame taking the groups round robin (the largest regions first, so the blocks of a
 // frame end together).  Which lane evaluates a region changes nothing about its sums.
-#ifndef PLH_RC_GROUPS
-#define PLH_RC_GROUPS 32
-#endif
-constexpr int RC_GROUPS = PLH_RC_GROUPS;
+constexpr int RC_GROUPS = 32;
 // regions of this size class and above (>= 512 pixels: a few dozen per busy frame) are evaluated one per wavefront, the rest one
 // per lane (64 regions of similar size per wavefront)
-#ifndef PLH_RC_BIG_LOG2
-#define PLH_RC_BIG_LOG2 9
-#endif
-constexpr int RC_BIG_CLASS = 4 * (PLH_RC_BIG_LOG2 - 2);
+constexpr int RC_BIG_CLASS = 4 * (9 - 2);
 
 __global__ void __launch_bounds__(256) k_lsd_rects_sort(LineDeviceArgs a) {
   __shared__ int s_hist[RC_BINS];

@@ -9,7 +9,7 @@ P2="SQ_WAVES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_IFETC
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R/gpurun_out/pmcgrow$i -o o -- python $R/bench.py --steps 1 --warmup 1 --batch $B --nsplit 1 --no-cpu-baseline --no-extras --serial $GW > /dev/null 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R/gpurun_out/pmcgrow$i -o o -- python $R/bench.py --steps 1 --warmup 1 --batch $B --nsplit 1 --no-cpu-baseline --no-extras --no-verify --serial $GW > /dev/null 2>&1
 done
 python - <<PY
 import csv, collections

@@ -4,7 +4,7 @@ GW="--grow-waves 0"   # these profiles are about the one-wavefront-per-frame ker
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for B in 256 6144; do
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM --kernel-trace --output-format csv -d $R/gpurun_out/pmclat$B -o o -- python $R/bench.py --steps 1 --warmup 1 --batch $B --nsplit 1 --no-cpu-baseline --no-extras --serial $GW > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM --kernel-trace --output-format csv -d $R/gpurun_out/pmclat$B -o o -- python $R/bench.py --steps 1 --warmup 1 --batch $B --nsplit 1 --no-cpu-baseline --no-extras --no-verify --serial $GW > /dev/null 2>&1
   python - <<PY
 import csv, collections
 f="$R/gpurun_out/pmclat$B/o_counter_collection.csv"

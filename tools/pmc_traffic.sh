@@ -13,7 +13,7 @@ cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$ROOT/gpurun_out/pmc/$d" -o pmc -- \
-    python "$ROOT/bench.py" --steps 2 --warmup 1 --batch $B --nsplit 1 --no-cpu-baseline --no-extras --serial $GW > "$ROOT/gpurun_out/pmc/$d.log" 2>&1
+    python "$ROOT/bench.py" --steps 2 --warmup 1 --batch $B --nsplit 1 --no-cpu-baseline --no-extras --no-verify --serial $GW > "$ROOT/gpurun_out/pmc/$d.log" 2>&1
 done
 cd "$ROOT"
 python tools/pmc_summarize.py gpurun_out/pmc $B | tee gpurun_out/pmc/traffic.json
