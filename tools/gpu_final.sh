@@ -19,13 +19,13 @@ timeout 1500 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/final/bench.json'))
-print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline', d['roofline']['frac'], d['roofline']['ms_per_launch'], d['roofline'].get('ms_per_launch_alone'), 'verified', d.get('verified',{}).get('exact'), d.get('verified',{}).get('frames'))
+print('value', d['value'], d['config']['lsd_refine']['level'], 'box', (d.get('box') or {}).get('probe_ms'), 'ms/step', d['ms_per_step'], 'roofline', d['roofline']['frac'], d['roofline']['ms_per_launch'], d['roofline'].get('ms_per_launch_alone'), 'verified', d.get('verified',{}).get('exact'), d.get('verified',{}).get('frames'))
 print('kernels', d['kernel_ms_per_launch'])
 print('latency', {k: v for k, v in d.get('latency_ms_single_frame', {}).items() if k != 'note'})
 s=d.get('secondary',{})
 print('secondary', s.get('value'), 'share512', s.get('configs4_share_512',{}).get('value'), s.get('error'))
-a=s.get('refine_adv',{})
-print('adv', a.get('value'), a.get('vs_headline'), 'share', a.get('share_512',{}).get('value'), 'lat', {k: v for k, v in (a.get('latency_ms_single_frame') or {}).items() if k != 'note'}, 'ver', (a.get('verified') or {}).get('exact'))
+a=s.get('refine_std',{}) or s.get('refine_adv',{})
+print('other level', a.get('level'), a.get('value'), a.get('vs_headline'), 'share', a.get('share_512',{}).get('value'), 'lat', {k: v for k, v in (a.get('latency_ms_single_frame') or {}).items() if k != 'note'}, 'ver', (a.get('verified') or {}).get('exact'))
 c=d.get('cpu_baseline',{})
 print('streaming', d.get('streaming',{}).get('value'), 'cpu', c.get('value'), c.get('cores'), c.get('legs'))
 PY
@@ -43,5 +43,5 @@ f=$(find "$ROOT/$O/stats_share" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$ROOT/$O/kernel_stats_share512.csv" && head -5 "$f" | cut -c1-160
 rm -rf "$ROOT/$O/stats_share"
 cd "$ROOT"
-timeout 700 bash tools/pmc_grow_mem.sh 6144 > $O/pmc_grow_mem.txt 2>&1; grep k_lsd_grow $O/pmc_grow_mem.txt | cut -c1-200
+[ "${GROWMEM:-0}" = 1 ] && timeout 700 bash tools/pmc_grow_mem.sh 6144 > $O/pmc_grow_mem.txt 2>&1; grep k_lsd_grow $O/pmc_grow_mem.txt | cut -c1-200
 exit 0
