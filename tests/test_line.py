@@ -480,6 +480,39 @@ def test_gpu_line_batch_and_mask(plslam, oracle, synth):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("refine", [1, 0], ids=["adv", "std"])
+def test_gpu_keylines_thousands_of_equal_lines(plslam, oracle, refine):
+    """KeyLine selection when the responses do not separate the lines: a lattice of identical squares gives thousands of segments
+    of a handful of distinct lengths, so the candidate set of k_keylines' histogram step exceeds its LDS list and the selection
+    falls back to the repeated arg-max over all keys -- the order among equal responses is the detection index, as in the
+    reference's stable sort (LineExtractor.cpp:43)."""
+    rows, cols = 480, 640
+    img = np.full((rows, cols), 30, np.uint8)
+    for y in range(6, rows - 18, 20):
+        for x in range(6, cols - 18, 20):
+            img[y:y + 12, x:x + 12] = 220
+    rs = oracle.lsd_detect(img, refine=refine)
+    # k_keylines' candidates: the 256-bin histogram of the responses (length / 640 x 170), bins from the top until 201 keys are in
+    length = np.hypot(rs[:, 0] - rs[:, 2], rs[:, 1] - rs[:, 3]).astype(np.float32)
+    bins = np.minimum(255, (length / np.float32(cols) * np.float32(170.0)).astype(int))
+    cand, cum = 0, 0
+    for b in sorted(set(bins.tolist()), reverse=True):
+        cum += int((bins == b).sum())
+        cand = cum
+        if cum >= 201:
+            break
+    assert cand > 1024, (len(rs), cand)   # more candidates than the kernel's LDS list holds: the fallback runs
+    rk, rd, rf = oracle.line_extract(img, 200, 0.0, refine=refine)
+    ex = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=rows, cols=cols, max_batch=1)
+    ex.set_refine(refine)
+    kl, desc, fn = ex(img)
+    gs = ex.read_segments(0)
+    ex.close()
+    assert len(gs) == len(rs) and (gs == rs).all()
+    _match(kl, desc, fn, rk, rd, rf, "lattice of squares, refine %d" % refine)
+
+
+@pytest.mark.gpu
 def test_gpu_line_golden(plslam, synth):
     """GPU vs the committed golden vectors (tests/golden/line_*.npz, tools/gen_golden.py)."""
     import glob
