@@ -124,3 +124,32 @@ def test_gpu_instruction_shims_match_their_descriptions(plslam):
     x 64 lanes each -- the class of bug the CPU emulator cannot see, caught in seconds."""
     bad, per = _selftest(plslam, None)
     assert bad == 0, "shims that differ (mismatching lanes per shim): %s" % per
+
+
+def test_box_probe_and_line_reserve_need_a_device_or_fail_cleanly(plslam):
+    """The two entry points of round 5 are exported and fail like every other one without a GPU (no CPU fallback)."""
+    import torch
+    L = plslam.load()
+    ms = (C.c_float * 2)()
+    assert L.plh_box_probe(0, 0, ms) == 1            # PLH_ERR_INVALID: iters <= 0
+    assert L.plh_line_reserve(None, 1) == 1          # PLH_ERR_INVALID: no handle
+    if not torch.cuda.is_available():
+        assert L.plh_box_probe(0, 16, ms) == 2       # PLH_ERR_NO_DEVICE
+
+
+@pytest.mark.gpu
+def test_gpu_box_probe_and_line_reserve(plslam, oracle, synth):
+    """plh_box_probe: a fixed VALU launch whose duration scales with its iteration count (the box normaliser of bench.py);
+    plh_line_reserve: the workspace of a batch at create time -- the extraction that follows is the oracle's."""
+    L = plslam.load()
+    ms1, ms2 = (C.c_float * 2)(), (C.c_float * 2)()
+    assert L.plh_box_probe(0, 1024, ms1) == 0 and L.plh_box_probe(0, 4096, ms2) == 0
+    assert ms1[1] > 0 and 3.0 < ms2[1] / ms1[1] < 5.0, (ms1[1], ms2[1])
+    img = synth.make_frame(21, 240, 320, n_rect=120, n_line=60)
+    ex = plslam.LINEextractor(1, 1.2, 100, 0.0, rows=240, cols=320, max_batch=4)
+    assert L.plh_line_reserve(ex.h, 5) == 1          # beyond the plan
+    plslam._check(L, L.plh_line_reserve(ex.h, 4), "plh_line_reserve")
+    kl, desc, fn = ex(img)
+    ex.close()
+    rk, rd, rf = oracle.line_extract(img, 100, 0.0)
+    assert len(kl) == len(rk) and all((kl[f] == rk[f]).all() for f in rk.dtype.names) and (desc == rd).all() and (fn == rf).all()
