@@ -396,7 +396,9 @@ __global__ void __launch_bounds__(256) k_lsd_bin_thresholds(LineDeviceArgs a) {
 __global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
   __shared__ unsigned binLo[LSD_NBINS + 8];
   __shared__ int hist[LSD_NBINS];
-  const int wv = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int b = blockIdx.y, lane = threadIdx.x;
+  // (a block takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ...: launch_lsd_order picks the blocks per frame by batch size)
+  for (int wv = blockIdx.x; wv < LSD_ORDER_CHUNKS; wv += gridDim.x) {
   const uint32_t* Q = a.pix + (long long)b * a.arenaStride;      // level-line records (k_lsd_grad)
   uint32_t* BIN = a.reg + (long long)b * a.arenaStride;          // bin + 1 per pixel, 0 = NOTDEF (scratch)
   uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
@@ -435,6 +437,8 @@ __global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
   }
   __syncthreads();
   for (int i = lane; i < LSD_NBINS; i += 64) work[wv * LSD_NBINS + i] = (uint32_t)hist[i];
+  __syncthreads();
+  }
 }
 
 // counts[chunk][bin] -> offsets[chunk][bin] in place: bins descending, chunks ascending inside a bin.  Thread t owns the
@@ -477,14 +481,15 @@ __global__ void __launch_bounds__(256) k_lsd_bin_scan(LineDeviceArgs a) {
 
 __global__ void __launch_bounds__(64) k_lsd_bin_scatter(LineDeviceArgs a) {
   __shared__ int cur[LSD_NBINS];   // next list position of every bin for this chunk
-  const int wv = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int b = blockIdx.y, lane = threadIdx.x;
+  for (int wv = blockIdx.x; wv < LSD_ORDER_CHUNKS; wv += gridDim.x) {
   const uint32_t* BIN = a.reg + (long long)b * a.arenaStride;
   uint32_t* ord = a.ordered + (long long)b * a.arenaStride;
   const uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
   const int npix = a.spitch * a.sh;
   const int chunk = lsd_order_chunk(a.spitch, a.sh);
   const int c0 = wv * chunk, c1 = min(npix, c0 + chunk);
-  if (c0 >= c1) return;
+  if (c0 >= c1) break;   // (chunks are in raster order: nothing behind an empty one)
   for (int i = lane; i < LSD_NBINS; i += 64) cur[i] = (int)work[wv * LSD_NBINS + i];
   __syncthreads();
   const unsigned long long lt = lanemask_lt();
@@ -540,6 +545,8 @@ __global__ void __launch_bounds__(64) k_lsd_bin_scatter(LineDeviceArgs a) {
     b1 = fetch(base + 256);
     rank_group(mask(b2, base + 128));
   }
+  __syncthreads();   // (the next chunk reloads `cur`)
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,11 +597,13 @@ void launch_lsd_grad(const LineDeviceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lsd_grad, dim3((a.spitch + 255) / 256, (a.sh + 3) / 4, a.batch), dim3(64, 4), 0, s, a);
 }
 size_t lsd_order_work_u32() { return (size_t)LSD_ORDER_WORK; }
+int lsd_blocks_per_frame(int batch, int lo, int hi);   // lsd_rects.hip
 void launch_lsd_order(const LineDeviceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lsd_bin_thresholds, dim3(LSD_NBINS / 256, a.batch), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_lsd_bin_hist, dim3(LSD_ORDER_CHUNKS, a.batch), dim3(64), 0, s, a);
+  const int groups = lsd_blocks_per_frame(a.batch, 4, LSD_ORDER_CHUNKS);   // (lsd_rects.hip: few fat blocks per frame at large batches)
+  hipLaunchKernelGGL(k_lsd_bin_hist, dim3(groups, a.batch), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_lsd_bin_scan, dim3(a.batch), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_lsd_bin_scatter, dim3(LSD_ORDER_CHUNKS, a.batch), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_lsd_bin_scatter, dim3(groups, a.batch), dim3(64), 0, s, a);
 }
 
 }  // namespace plh

@@ -53,8 +53,10 @@ __device__ __forceinline__ int adv_sum8(int v) {
   return v;
 }
 
-constexpr int ADV_FIRST_GROUPS = 24;     // one-wavefront blocks per frame (64 rectangles per pass each)
-constexpr int ADV_IMPROVE_GROUPS = 32;   // ... (8 rectangles per pass each)
+// one-wavefront blocks per frame, by batch size (lsd_blocks_per_frame, lsd_rects.hip): k_adv_first 24 .. 4 (64 rectangles per pass each),
+// k_adv_improve 32 .. 6 (8 rectangles per pass each)
+constexpr int ADV_FIRST_MAX = 24, ADV_FIRST_MIN = 4, ADV_IMPROVE_MAX = 32, ADV_IMPROVE_MIN = 6;
+int lsd_blocks_per_frame(int batch, int lo, int hi);
 
 // lsd_log_gamma(i) for i = 1 .. n - 1 (t[0] is never read)
 __global__ void __launch_bounds__(256) k_lsd_lgamma_table(double* t, int n) {
@@ -77,10 +79,10 @@ __global__ void __launch_bounds__(64) k_adv_first(LineDeviceArgs a) {
   // about equally long (in slot order the longest of eight set the pace, 2 x the mean).  The chunks go to the frame's blocks
   // round robin, so that every block gets large and small ones; a block takes eight chunks (64 rectangles) per pass.
   const int nChunks = (f.n + 7) >> 3;
-  for (int c0 = (int)blockIdx.x; c0 < nChunks; c0 += 8 * ADV_FIRST_GROUPS) {
+  for (int c0 = (int)blockIdx.x; c0 < nChunks; c0 += 8 * (int)gridDim.x) {
     // the pass's rectangles: lane (it, pos) -> position pos of chunk c0 + it x blocks.  Their scan geometry, one lane each (the
     // corner sort is as long as a walk: not eight times per rectangle):
-    const int k = (c0 + (lane >> 3) * ADV_FIRST_GROUPS) * 8 + (lane & 7);
+    const int k = (c0 + (lane >> 3) * (int)gridDim.x) * 8 + (lane & 7);
     const int mine = k < f.n ? (int)f.order[k] : -1;
     {
       s_slot[lane] = mine;
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(64) k_adv_improve(LineDeviceArgs a) {
   const AdvFrame f = adv_frame(a, b);
   const RcFrame rf = adv_field(a, b);
   const int na = f.n > 0 ? (int)*f.count : 0;
-  for (int base = (int)blockIdx.x * 8; base < na; base += 8 * ADV_IMPROVE_GROUPS) {   // (uniform: the shuffles below are executed by the whole wavefront)
+  for (int base = (int)blockIdx.x * 8; base < na; base += 8 * (int)gridDim.x) {   // (uniform: the shuffles below are executed by the whole wavefront)
     const int q = base + grp;
     bool active = q < na;
     const int slot = active ? (int)f.list[q] : 0;
@@ -235,8 +237,8 @@ __global__ void __launch_bounds__(64) k_adv_compact(LineDeviceArgs a) {
 }
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_adv_first, dim3(ADV_FIRST_GROUPS, a.batch), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(k_adv_improve, dim3(ADV_IMPROVE_GROUPS, a.batch), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_adv_first, dim3(lsd_blocks_per_frame(a.batch, ADV_FIRST_MIN, ADV_FIRST_MAX), a.batch), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_adv_improve, dim3(lsd_blocks_per_frame(a.batch, ADV_IMPROVE_MIN, ADV_IMPROVE_MAX), a.batch), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_adv_compact, dim3(a.batch), dim3(64), 0, s, a);
 }
 

@@ -13,6 +13,9 @@
 // LSD_REFINE_ADV (rect_improve / rect_nfa / nfa, lsd_rect_dev.h) reads the immutable level-line field only and decides only
 // whether the segment is kept: k_lsd_rects_adv leaves the rectangle in an LsdAdvRec, and lsd_adv.hip runs rect_nfa() / nfa() /
 // rect_improve() on them, followed by a stable compaction of the surviving segments.
+#include <algorithm>
+#include <cstdlib>
+
 #include "lsd_rect_dev.h"
 
 namespace plh {
@@ -245,9 +248,9 @@ __device__ __forceinline__ void rc_region2rect_by_wave(double* T, const uint32_t
 // whose LDS the region-growing wavefronts of the other sub-batches hold (24 x 5 KiB of 160): alone 2.0 ms per 1536 frames, inside
 // the pipeline 16 ms on the line chain's critical path.  k_lsd_rects_sort leaves the size-class order in the frame's park area
 // (a light block per frame, 512 bytes of LDS); k_lsd_rects_sums runs ONE WAVEFRONT per block (7.4 KB of LDS) on 64 consecutive
-// entries of that order, RC_GROUPS blocks per frame taking the groups round robin (the largest regions first, so the blocks of a
+// entries of that order, a few blocks per frame (launch_lsd_rects) taking the groups round robin (the largest regions first, so the blocks of a
 // frame end together).  Which lane evaluates a region changes nothing about its sums.
-constexpr int RC_GROUPS = 32;
+constexpr int RC_GROUPS_MAX = 32, RC_GROUPS_MIN = 4;   // blocks per frame: launch_lsd_rects picks by batch size (below)
 // regions of this size class and above (>= 512 pixels: a few dozen per busy frame) are evaluated one per wavefront, the rest one
 // per lane (64 regions of similar size per wavefront)
 constexpr int RC_BIG_CLASS = 4 * (9 - 2);
@@ -302,7 +305,7 @@ __device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
   };
   // the head of the order: one big region per wavefront at a time (the blocks of a frame take them round robin) ...
   const int nBig = min((int)order[-1], n);
-  for (int k = (int)blockIdx.x; k < nBig; k += RC_GROUPS) {
+  for (int k = (int)blockIdx.x; k < nBig; k += (int)gridDim.x) {
     const int slot = (int)order[k];
     const uint4 e = ent[slot];   // LsdRegionEntry (uniform)
     double rec[8];
@@ -310,7 +313,7 @@ __device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
     if (lane == 0) put(slot, rec);
   }
   // ... then the rest, 64 consecutive entries of the order per wavefront, one region per lane
-  for (int base = nBig + (int)blockIdx.x * 64; base < n; base += 64 * RC_GROUPS) {
+  for (int base = nBig + (int)blockIdx.x * 64; base < n; base += 64 * (int)gridDim.x) {
     const int k = base + lane;
     int slot = -1;
     uint4 e = uint4{0u, 0u, 0u, 0u};
@@ -324,13 +327,26 @@ __global__ void __launch_bounds__(64) k_lsd_rects(LineDeviceArgs a) { lsd_rects_
 __global__ void __launch_bounds__(64) k_lsd_rects_adv(LineDeviceArgs a) { lsd_rects_group<true>(a); }
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s);   // lsd_adv.hip
+// One-wavefront blocks per frame for the rectangle / LSD_REFINE_ADV kernels: as many as it takes to put ~ 4096 wavefronts on the GPU
+// (a lone frame: `hi` blocks, its regions side by side), but no more -- every resident block holds its LDS tile and a wave slot while
+// it waits for memory, and LDS is what the two halves of the front end share on a CU: at 1536 frames per launch 32 blocks per frame
+// instead of 4 cost k_lsd_rects 2.1 -> 4.7 ms alone and THE WHOLE FRONT END 3.5 % (profiles/r05_blocks_per_frame_ab.txt).
+int lsd_blocks_per_frame(int batch, int lo, int hi) {
+#if defined(HIPEMU) || defined(PLH_GROW_PROF)
+  // the CPU emulator build (and the counter build of tools/) can ask for the large-batch shape on a small batch, so that the tests
+  // walk the several-chunks-per-block paths; the product build has no such knob
+  if (getenv("PLH_BLOCKS_PER_FRAME_MIN")) return lo;
+#endif
+  return std::max(lo, std::min(hi, 4096 / std::max(batch, 1)));
+}
 void launch_lsd_rects(const LineDeviceArgs& a, hipStream_t s) {
+  const int groups = lsd_blocks_per_frame(a.batch, RC_GROUPS_MIN, RC_GROUPS_MAX);
   hipLaunchKernelGGL(k_lsd_rects_sort, dim3(a.batch), dim3(256), 0, s, a);
   if (!a.refineAdv) {
-    hipLaunchKernelGGL(k_lsd_rects, dim3(RC_GROUPS, a.batch), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_lsd_rects, dim3(groups, a.batch), dim3(64), 0, s, a);
     return;
   }
-  hipLaunchKernelGGL(k_lsd_rects_adv, dim3(RC_GROUPS, a.batch), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_lsd_rects_adv, dim3(groups, a.batch), dim3(64), 0, s, a);
   launch_lsd_adv(a, s);
 }
 

@@ -179,6 +179,22 @@ def test_emu_line_extract_refine_std(plslam, oracle, synth, emu_lib):
     assert _exact(kl, desc, fn, rk, rd, rf)
 
 
+@pytest.mark.parametrize("refine", [1, 0], ids=["adv", "std"])
+def test_emu_line_few_blocks_per_frame(plslam, oracle, synth, emu_lib, refine, monkeypatch):
+    """The launch shape of large batches -- a few one-wavefront blocks per frame in the seed ordering, k_lsd_rects and the LSD_REFINE_ADV
+    kernels, each looping over several chunks (lsd_blocks_per_frame) -- on a small frame: the same records."""
+    monkeypatch.setenv("PLH_BLOCKS_PER_FRAME_MIN", "1")
+    img = synth.make_frame(9, 118, 203, n_rect=40, n_line=20)
+    rk, rd, rf, rs = _oracle_line(oracle, img, 40, 0.0, refine=refine)
+    ex = plslam.LINEextractor(1, 1.2, 40, 0.0, rows=118, cols=203, max_batch=1, lib=emu_lib)
+    ex.set_refine(refine)
+    kl, desc, fn = ex(img)
+    gs = ex.read_segments(0)
+    ex.close()
+    assert len(gs) == len(rs) and (gs == rs).all() and len(rs) > 40
+    assert _exact(kl, desc, fn, rk, rd, rf)
+
+
 def _sawtooth(rows, cols, period=40, slope=6):
     """Ramps of constant gradient: every tooth is ONE region of period x rows aligned pixels -- thousands of queue entries, far
     beyond the 512-entry LDS mirror of the region queue (the k_lsd_grow paths that read the queue back from global memory),
