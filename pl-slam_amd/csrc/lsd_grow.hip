@@ -25,6 +25,7 @@ struct GrowCtx {
   double precDef;             // the launch's tolerance and its direction-test margins (host: plh_line_create)
   float cin2Def, cout2Def;
   int fastDef;
+  float loDef, hiDef;         // lsd_tol(precDef)'s float band, evaluated once per wavefront: a seed's first region_grow() takes it from here
 #if defined(PLH_GROW_PROF)
   unsigned long long* pf;   // per-wave phase counters (debug build only, tools/grow_prof.py)
 #endif
@@ -155,6 +156,14 @@ struct GrowState {
   const LsdPix* fstPx;      // [64] neighbour records of the batch's seeds (lane group t = seed t)
   const uint32_t* fstIdx;   // [64] linear index, 0xffffffff = out of bounds / no seed
   const uint32_t* fstPk;    // [64] packed coordinates
+};
+
+// A seed as flsd() hands it to its first region_grow(): wave-uniform values (scalar registers).  refine()'s second call takes its
+// parameters from GrowState instead (lane 0 writes them).
+struct LsdSeed {
+  uint32_t pk;          // packed coordinates
+  unsigned q;           // its record (not marked)
+  float ang, cx, sy;    // its level-line angle in degrees, (float)cos / (float)sin of the double angle
 };
 
 // (isAligned() of cv::LineSegmentDetector for a defined pixel -- lsd_aligned -- is in lsd_rect_dev.h)
@@ -410,23 +419,38 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint3
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
 // reference's float fastAtan2 result; evaluated only if the region has at least minCnt pixels).  All lanes hold identical
 // (uniform) state.
+// `firstCall` (a literal at both call sites): a seed's first region_grow() -- the seed comes in `sd` and the tolerance is the launch's, with
+// everything lsd_tol() would derive from it in the context; gs is not read.  (Round 4 handed every call its parameters through LDS:
+// lane 0 stores, everybody loads, v_readlane -- five dependent LDS round trips, an f64 multiply and, in the 72-register build, two
+// reloads from scratch for each of a frame's 8 k calls, three in four of which end after one step.)  refine()'s call: parameters in gs.
 template <bool MW>
-__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, int firstGrp, bool dirtyFst,
-                                               int minCnt, float* regAngOut, bool* conflictOut = nullptr) {
+__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, const LsdSeed& sd, int firstGrp, bool dirtyFst,
+                                               int minCnt, float* regAngOut, bool* conflictOut, const bool firstCall) {
   const int lane = c.lane, g = lane >> 3;
-  // the call's parameters come from LDS (uniform): nothing of the caller's state has to stay in registers across the loop
-  const uint32_t seedPk = bcast_u32(gs.u[0], 0);
-  const unsigned seedQ = bcast_u32(gs.u[1], 0);
-  LsdTol tol = lsd_tol(bcast_f64(gs.d[0], 0));
-  if (tol.prec == c.precDef) {   // the launch's tolerance: margins from the host
+  uint32_t seedPk;
+  unsigned seedQ;
+  float regAngF, sumdx, sumdy;
+  LsdTol tol;
+  if (firstCall) {
+    seedPk = sd.pk; seedQ = sd.q; regAngF = sd.ang; sumdx = sd.cx; sumdy = sd.sy;
+    tol.prec = c.precDef; tol.lo = c.loDef; tol.hi = c.hiDef;
+    tol.cin2 = __builtin_inff(); tol.cout2 = -1.f; tol.posT = -__builtin_inff();
     if (c.fastDef) { tol.cin2 = c.cin2Def; tol.cout2 = c.cout2Def; tol.posT = 0.f; }
   } else {
-    const LsdMargins mg = lsd_tol_margins(tol.prec);   // results of a call come back in vector registers: make them scalar again
-    if (bcast_u32((unsigned)mg.fast, 0) != 0u) { tol.cin2 = bcast_f32(mg.cin2, 0); tol.cout2 = bcast_f32(mg.cout2, 0); tol.posT = 0.f; }
+    // uniform values from LDS: nothing of the caller's state has to stay in registers across the loop
+    seedPk = bcast_u32(gs.u[0], 0);
+    seedQ = bcast_u32(gs.u[1], 0);
+    regAngF = bcast_f32(__uint_as_float(gs.u[2]), 0); sumdx = bcast_f32(__uint_as_float(gs.u[3]), 0);
+    sumdy = bcast_f32(__uint_as_float(gs.u[4]), 0);
+    tol = lsd_tol(bcast_f64(gs.d[0], 0));
+    if (tol.prec == c.precDef) {   // the launch's tolerance: margins from the host
+      if (c.fastDef) { tol.cin2 = c.cin2Def; tol.cout2 = c.cout2Def; tol.posT = 0.f; }
+    } else {
+      const LsdMargins mg = lsd_tol_margins(tol.prec);   // results of a call come back in vector registers: make them scalar again
+      if (bcast_u32((unsigned)mg.fast, 0) != 0u) { tol.cin2 = bcast_f32(mg.cin2, 0); tol.cout2 = bcast_f32(mg.cout2, 0); tol.posT = 0.f; }
+    }
   }
   bool angValid = true;   // before the first accept reg_angle is the seed's own angle
-  float regAngF = bcast_f32(__uint_as_float(gs.u[2]), 0), sumdx = bcast_f32(__uint_as_float(gs.u[3]), 0),
-        sumdy = bcast_f32(__uint_as_float(gs.u[4]), 0);
   const uint32_t seed = pk_lin(c, seedPk);
   PLH_WAVE_SYNC();
   if (lane == 0) {
@@ -440,13 +464,21 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
   if (firstGrp >= 0) {
     const unsigned long long pt1 = PF_NOW_FINE();
     // the seed's 8 neighbours were prefetched into LDS by lane group firstGrp; their marks may have changed since
+    // (table addresses from an opaque copy of the lane number: as loop invariants of the whole kernel they end up in scratch)
     LsdCand first;
-    first.nidx = gs.fstIdx[lane];
+    const int l1 = (int)plh_opaque_u32((unsigned)lane);
+    first.nidx = gs.fstIdx[l1];
     first.inb = g == firstGrp && first.nidx != 0xffffffffu;
     if (!first.inb) first.nidx = 0;
-    first.npk = gs.fstPk[lane];
-    first.px = gs.fstPx[lane];
-    if (dirtyFst && first.inb) first.px.q = c.P[first.nidx];
+    first.npk = gs.fstPk[l1];
+    first.px = gs.fstPx[l1];
+    // (the LDS value is made opaque first: left alone, the compiler merges its read with the global one below into ONE flat load
+    // through a selected generic pointer -- whose aperture word the 72-register build keeps in scratch, a reload per seed)
+    first.px.q = plh_opaque_u32(first.px.q);
+    if (dirtyFst) {
+      const unsigned q1 = c.P[first.nidx];
+      if (first.inb) first.px.q = q1;
+    }
     // one signed compare on the record word covers "not marked and above the gradient threshold" (the table values were
     // fetched with the neighbourhood for every DEFINED pixel, so a pixel that refine() un-marked in between has them too)
     const unsigned long long candM = wballot(first.inb) & wballot(rec_is_candidate(first.px.q));
@@ -660,7 +692,8 @@ __device__ __forceinline__ void lsd_fill_regq(const GrowCtx& c, int cnt) {
 template <bool MW>
 __device__ __forceinline__ int lsd_density_screen(const GrowCtx& c, int cnt, bool fromRing, float thLo, float thHi) {
   if (cnt > LSD_SCREEN_MAX) return 0;
-  const int lane = c.lane;
+  const int lane = (int)plh_opaque_u32((unsigned)c.lane);   // (per-lane queue addresses formed here, per call: hoisted out of the
+                                                            // transaction loop they are 64-bit pairs the 72-register build keeps in scratch)
   const bool inRing = fromRing && cnt <= LSD_RING;   // the whole queue is still in its LDS mirror
   if (!inRing || cnt > 64) grow_lane_fence<MW>();   // the queue in global memory is read below: stores of all lanes visible
   PLH_WAVE_SYNC();
@@ -820,14 +853,15 @@ struct LsdTxn {
                          // course, to be run again
 };
 
-// One transaction.  The caller has put the seed into gs (d[0] = tolerance, u[0..4]) and c.reg at the start of free queue space.
+// One transaction for seed `sd` (its first region_grow() runs at the launch's tolerance; gs.u / gs.d[0] are refine()'s way of
+// handing over the second call's).  The caller has put c.reg at the start of free queue space.
 // One wavefront per frame (MW = false): marks in the records, every phase reuses the queue.  Several (MW = true): private marks,
 // the queues of the phases laid end to end so that the log keeps every pixel ever accepted, reduce_region_radius() on a copy.
 // Where flsd() looks at the density of a rectangle the wavefront asks lsd_density_screen() first and evaluates the exact
 // rectangle only if the bracket straddles the threshold -- or if the rectangle itself is needed next: refine() takes its
 // width, reduce_region_radius() its end points.  Inside reduce_region_radius()'s loop only the decision is.
 template <bool MW>
-__device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, int firstGrp, bool dirtyFst) {
+__device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, const LsdSeed& sd, int firstGrp, bool dirtyFst) {
   const int lane = c.lane;
   double* rec = gs.d + 1;
   uint32_t* const base = c.reg;
@@ -835,7 +869,7 @@ __device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const
   t.keep = false; t.conflict = false; t.finBase = 0; t.ang = 0.f;
   float regAngF;
   const unsigned long long pg0 = PF_NOW();
-  int cnt = lsd_region_grow<MW>(c, gs, firstGrp, dirtyFst, a.minRegSize, &regAngF, &t.conflict);
+  int cnt = lsd_region_grow<MW>(c, gs, sd, firstGrp, dirtyFst, a.minRegSize, &regAngF, &t.conflict, true);
   PF_ADD(c, 2, PF_NOW() - pg0);
   t.logLen = cnt; t.finCnt = cnt;
   if constexpr (MW) {
@@ -923,7 +957,7 @@ __device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const
       grow_lane_fence<MW>();
       cnt1 = cnt;
       if constexpr (MW) c.reg = base + cnt1;   // the first region stays in the log
-      cnt = lsd_region_grow<MW>(c, gs, -1, false, 2, &regAngF, &t.conflict);
+      cnt = lsd_region_grow<MW>(c, gs, sd, -1, false, 2, &regAngF, &t.conflict, false);
       t.finCnt = cnt;
       if constexpr (MW) {
         t.logLen = cnt1 + cnt; t.finBase = cnt1;
@@ -1004,6 +1038,7 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   c.nullIdx = lsd_rec_index((unsigned)(a.sw - 1), 0u, (unsigned)a.spitch);
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
+  { const LsdTol t0 = lsd_tol(a.prec); c.loDef = bcast_f32(t0.lo, 0); c.hiDef = bcast_f32(t0.hi, 0); }
   const uint32_t* ord = a.ordered + (long long)b * a.arenaStride;   // packed coordinates x | y << 16
   float* segs = a.segs + (long long)b * a.arenaStride;
 #if defined(PLH_GROW_PROF)
@@ -1042,15 +1077,13 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
   int nseg = 0, logOff = 0;   // segment slots handed out; words of the frame's log (a.reg) taken by the kept regions
   // LDS tables that keep the seed scan and the prefetched neighbourhoods out of the registers (the wavefront's VGPR
   // count decides how many frames are resident): the 64 seeds of a scan, and per lane the first-step record
-  uint32_t* tabP = (uint32_t*)(smem + LSD_RING * 4);   // packed coordinates
-  uint32_t* tabQ = tabP + 64;
-  float* tabA = (float*)(tabQ + 64);                   // angle, seed cos / sin
-  float* tabC = tabA + 64;
-  float* tabS = tabC + 64;
+  uint4* tabX = (uint4*)(smem + LSD_RING * 4);         // [64] per seed: packed coordinates, record, bits of the angle and of the seed cos: one
+                                                       // 16-byte LDS read per seed
+  float* tabS = (float*)(tabX + 64);                   // [64] ... and the seed sin
   LsdPix* fstPx = (LsdPix*)(tabS + 64);                // [64] neighbour records of the batch's seeds (lane group t = seed t)
   uint32_t* fstIdx = (uint32_t*)(fstPx + 64);          // [64] linear index, 0xffffffff = out of bounds / no seed
   uint32_t* fstPk = fstIdx + 64;
-  int* batchSk = (int*)(fstPk + 64);                   // [8] scan lane of the batch's t-th seed
+  int* batchSk = (int*)(fstPk + 64);                   // [8] (unused since round 5: the batch's scan lanes travel in a scalar register pair)
   GrowState gs;
   gs.d = (double*)(batchSk + 8);
   gs.u = (uint32_t*)(gs.d + LSD_GS_D);
@@ -1073,23 +1106,24 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
         sAng = __uint_as_float(e0.x); sCx = __uint_as_float(e0.w); sSy = e->seedy;
       }
       PLH_WAVE_SYNC();
-      tabP[lane] = seedP; tabQ[lane] = sRec; tabA[lane] = sAng; tabC[lane] = sCx; tabS[lane] = sSy;
+      tabX[lane] = uint4{seedP, sRec, __float_as_uint(sAng), __float_as_uint(sCx)}; tabS[lane] = sSy;
       PLH_WAVE_SYNC();
     }
     bool dirtySeed = false, dirtyFst = false;   // a region has been grown since this scan / since fst was fetched
     while (fm) {
       // up to 8 surviving seeds at a time: lane group t prefetches the 8 neighbours of the t-th of them
       int nb = 0;
+      unsigned long long skPack = 0;   // scan lane of the batch's t-th seed in byte t (a scalar register pair, not an LDS table)
       {
         int mySk = 0;
         for (; nb < 8 && fm; nb++) {
           const int k = __ffsll((long long)fm) - 1;
           fm &= fm - 1;
           if (grp == nb) mySk = k;
+          skPack |= (unsigned long long)k << (8 * nb);
         }
         PLH_WAVE_SYNC();
-        if (nbr == 0) batchSk[grp] = mySk;
-        const uint32_t sp = tabP[mySk];
+        const uint32_t sp = tabX[mySk].x;
         const int xx = pk_x(sp) + ndx, yy = pk_y(sp) + ndy;
         LsdPix px = lsd_null_px(0u);
         uint32_t nidx = 0xffffffffu;
@@ -1103,23 +1137,22 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
       }
       dirtyFst = false;
       for (int t = 0; t < nb; t++) {
-        const int sk = (int)bcast_u32((unsigned)batchSk[t], 0);
-        uint32_t seedPk = bcast_u32(tabP[sk], 0);
+        const int sk = (int)((skPack >> (8 * t)) & 63ull);
+        const uint4 sx = tabX[sk];
+        const float ss = tabS[sk];
+        uint32_t seedPk = bcast_u32(sx.x, 0);
         uint32_t seed = pk_lin(c, seedPk);
-        unsigned seedQ = bcast_u32(tabQ[sk], 0);
+        unsigned seedQ = bcast_u32(sx.y, 0);
+        LsdSeed sd;   // (the scan's table values with the same LDS round trip, whether or not the seed survives the test below)
+        sd.pk = seedPk; sd.ang = __uint_as_float(bcast_u32(sx.z, 0)); sd.cx = __uint_as_float(bcast_u32(sx.w, 0)); sd.sy = bcast_f32(ss, 0);
         PLH_WAVE_SYNC();
         // marks may have changed since the scan / the neighbourhood prefetch: re-read them (one round trip)
         if (dirtySeed) seedQ = c.P[seed];
         if (seedQ & LSD_USED) continue;   // swallowed by a region grown since the scan
+        sd.q = bcast_u32(seedQ, 0);
         // region_grow -> [density] -> refine: tighter tolerance, re-grow -> [density] -> reduce_region_radius (lsd_txn)
         PLH_WAVE_SYNC();
-        if (lane == 0) {
-          gs.d[0] = a.prec;
-          gs.u[0] = seedPk; gs.u[1] = seedQ;
-          gs.u[2] = __float_as_uint(tabA[sk]); gs.u[3] = __float_as_uint(tabC[sk]); gs.u[4] = __float_as_uint(tabS[sk]);
-        }
-        PLH_WAVE_SYNC();
-        const LsdTxn tx = lsd_txn<false>(c, gs, a, t, dirtyFst);
+        const LsdTxn tx = lsd_txn<false>(c, gs, a, sd, t, dirtyFst);
         dirtySeed = true; dirtyFst = true;
         if (!tx.keep) continue;
         // a line-support region: its pixels stay where they are -- the queue moves on behind them -- and its segment slot
@@ -1254,13 +1287,12 @@ __device__ LsdTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceAr
                              unsigned seedRec, unsigned sAngBits, unsigned sCxBits, unsigned sSyBits) {
   c.reg = regBase;
   PLH_WAVE_SYNC();
-  if (c.lane == 0) {
-    gs.d[0] = a.prec;
-    gs.u[0] = seedPk; gs.u[1] = seedRec; gs.u[2] = sAngBits; gs.u[3] = sCxBits; gs.u[4] = sSyBits;
-    *c.asmCnt = 0;
-  }
+  if (c.lane == 0) *c.asmCnt = 0;
   PLH_WAVE_SYNC();
-  return lsd_txn<true>(c, gs, a, -1, false);
+  LsdSeed sd;   // (lane 0's values, as when they went through LDS)
+  sd.pk = bcast_u32(seedPk, 0); sd.q = bcast_u32(seedRec, 0);
+  sd.ang = __uint_as_float(bcast_u32(sAngBits, 0)); sd.cx = __uint_as_float(bcast_u32(sCxBits, 0)); sd.sy = __uint_as_float(bcast_u32(sSyBits, 0));
+  return lsd_txn<true>(c, gs, a, sd, -1, false);
 }
 
 // A posted transaction: 16 words in LDS, ring slot = sequence number mod MW_N.
@@ -1517,6 +1549,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
   c.spitch = a.spitch; c.sw = a.sw; c.sh = a.sh; c.lane = lane; c.qThresh = a.qThresh;
   c.nullIdx = lsd_rec_index((unsigned)(a.sw - 1), 0u, (unsigned)a.spitch);
   c.precDef = a.prec; c.cin2Def = a.alignCin2; c.cout2Def = a.alignCout2; c.fastDef = a.alignFast;
+  { const LsdTol t0 = lsd_tol(a.prec); c.loDef = bcast_f32(t0.lo, 0); c.hiDef = bcast_f32(t0.hi, 0); }
   GrowState gs;
   gs.d = (double*)(wsm + LSD_RING * 4);
   gs.u = (uint32_t*)(gs.d + LSD_GS_D + 1);

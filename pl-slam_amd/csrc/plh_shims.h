@@ -244,6 +244,9 @@ __device__ __forceinline__ void wg_release() {   // this wavefront's global stor
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// the identity, with the value's origin hidden from the optimiser (no instruction): keeps a load from being merged with another one
+// through a selected pointer, or a loop-invariant derived from the value from being hoisted into a register the build has to spill
+__device__ __forceinline__ unsigned plh_opaque_u32(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 #else
 namespace shim = ref;
 #define PLH_WAVE_SYNC() hipemu::wave_barrier()
@@ -251,6 +254,7 @@ __device__ __forceinline__ void spin_pause() { hipemu::spin_yield(); }   // the 
 __device__ __forceinline__ void wave_fence() {}
 __device__ __forceinline__ void wg_release() {}
 __device__ __forceinline__ void wg_acquire() {}
+__device__ __forceinline__ unsigned plh_opaque_u32(unsigned v) { return v; }
 #endif
 
 using shim::wballot;
