@@ -419,12 +419,13 @@ __device__ __forceinline__ bool lsd_addr(const GrowCtx& c, int i, int cnt, uint3
 // Returns the region size; regAngF = final reg_angle in degrees (reg_angle = regAngF * DEG_TO_RADS, exactly the
 // reference's float fastAtan2 result; evaluated only if the region has at least minCnt pixels).  All lanes hold identical
 // (uniform) state.
+// `fstQ` (dirtyFst only): lane group firstGrp's records of the seed's neighbours as they are now.
 // `firstCall` (a literal at both call sites): a seed's first region_grow() -- the seed comes in `sd` and the tolerance is the launch's, with
 // everything lsd_tol() would derive from it in the context; gs is not read.  (Round 4 handed every call its parameters through LDS:
 // lane 0 stores, everybody loads, v_readlane -- five dependent LDS round trips, an f64 multiply and, in the 72-register build, two
 // reloads from scratch for each of a frame's 8 k calls, three in four of which end after one step.)  refine()'s call: parameters in gs.
 template <bool MW>
-__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, const LsdSeed& sd, int firstGrp, bool dirtyFst,
+__device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState& gs, const LsdSeed& sd, int firstGrp, bool dirtyFst, unsigned fstQ,
                                                int minCnt, float* regAngOut, bool* conflictOut, const bool firstCall) {
   const int lane = c.lane, g = lane >> 3;
   uint32_t seedPk;
@@ -472,13 +473,9 @@ __device__ __forceinline__ int lsd_region_grow(const GrowCtx& c, const GrowState
     if (!first.inb) first.nidx = 0;
     first.npk = gs.fstPk[l1];
     first.px = gs.fstPx[l1];
-    // (the LDS value is made opaque first: left alone, the compiler merges its read with the global one below into ONE flat load
-    // through a selected generic pointer -- whose aperture word the 72-register build keeps in scratch, a reload per seed)
-    first.px.q = plh_opaque_u32(first.px.q);
-    if (dirtyFst) {
-      const unsigned q1 = c.P[first.nidx];
-      if (first.inb) first.px.q = q1;
-    }
+    // (marks may have changed since the prefetch: the caller re-read the records of lane group firstGrp -- fstQ -- in the same round
+    // trip as the seed's own)
+    if (dirtyFst && first.inb) first.px.q = fstQ;
     // one signed compare on the record word covers "not marked and above the gradient threshold" (the table values were
     // fetched with the neighbourhood for every DEFINED pixel, so a pixel that refine() un-marked in between has them too)
     const unsigned long long candM = wballot(first.inb) & wballot(rec_is_candidate(first.px.q));
@@ -861,7 +858,7 @@ struct LsdTxn {
 // rectangle only if the bracket straddles the threshold -- or if the rectangle itself is needed next: refine() takes its
 // width, reduce_region_radius() its end points.  Inside reduce_region_radius()'s loop only the decision is.
 template <bool MW>
-__device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, const LsdSeed& sd, int firstGrp, bool dirtyFst) {
+__device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const LineDeviceArgs& a, const LsdSeed& sd, int firstGrp, bool dirtyFst, unsigned fstQ) {
   const int lane = c.lane;
   double* rec = gs.d + 1;
   uint32_t* const base = c.reg;
@@ -869,7 +866,7 @@ __device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const
   t.keep = false; t.conflict = false; t.finBase = 0; t.ang = 0.f;
   float regAngF;
   const unsigned long long pg0 = PF_NOW();
-  int cnt = lsd_region_grow<MW>(c, gs, sd, firstGrp, dirtyFst, a.minRegSize, &regAngF, &t.conflict, true);
+  int cnt = lsd_region_grow<MW>(c, gs, sd, firstGrp, dirtyFst, fstQ, a.minRegSize, &regAngF, &t.conflict, true);
   PF_ADD(c, 2, PF_NOW() - pg0);
   t.logLen = cnt; t.finCnt = cnt;
   if constexpr (MW) {
@@ -957,7 +954,7 @@ __device__ __forceinline__ LsdTxn lsd_txn(GrowCtx& c, const GrowState& gs, const
       grow_lane_fence<MW>();
       cnt1 = cnt;
       if constexpr (MW) c.reg = base + cnt1;   // the first region stays in the log
-      cnt = lsd_region_grow<MW>(c, gs, sd, -1, false, 2, &regAngF, &t.conflict, false);
+      cnt = lsd_region_grow<MW>(c, gs, sd, -1, false, 0u, 2, &regAngF, &t.conflict, false);
       t.finCnt = cnt;
       if constexpr (MW) {
         t.logLen = cnt1 + cnt; t.finBase = cnt1;
@@ -1146,13 +1143,19 @@ __device__ __forceinline__ void lsd_grow_frame(const LineDeviceArgs& a, unsigned
         LsdSeed sd;   // (the scan's table values with the same LDS round trip, whether or not the seed survives the test below)
         sd.pk = seedPk; sd.ang = __uint_as_float(bcast_u32(sx.z, 0)); sd.cx = __uint_as_float(bcast_u32(sx.w, 0)); sd.sy = bcast_f32(ss, 0);
         PLH_WAVE_SYNC();
-        // marks may have changed since the scan / the neighbourhood prefetch: re-read them (one round trip)
+        // marks may have changed since the scan / the neighbourhood prefetch: re-read the seed's record and, in lane group t, its
+        // neighbours' -- ONE round trip for both (round 4 made two: the neighbours' only after the seed had passed)
+        unsigned fstQ = 0u;
+        if (dirtyFst) {
+          const uint32_t fi = fstIdx[lane];
+          if (grp == t && fi != 0xffffffffu) fstQ = c.P[fi];
+        }
         if (dirtySeed) seedQ = c.P[seed];
         if (seedQ & LSD_USED) continue;   // swallowed by a region grown since the scan
         sd.q = bcast_u32(seedQ, 0);
         // region_grow -> [density] -> refine: tighter tolerance, re-grow -> [density] -> reduce_region_radius (lsd_txn)
         PLH_WAVE_SYNC();
-        const LsdTxn tx = lsd_txn<false>(c, gs, a, sd, t, dirtyFst);
+        const LsdTxn tx = lsd_txn<false>(c, gs, a, sd, t, dirtyFst, fstQ);
         dirtySeed = true; dirtyFst = true;
         if (!tx.keep) continue;
         // a line-support region: its pixels stay where they are -- the queue moves on behind them -- and its segment slot
@@ -1292,7 +1295,7 @@ __device__ LsdTxn lsd_txn_mw(GrowCtx& c, const GrowState& gs, const LineDeviceAr
   LsdSeed sd;   // (lane 0's values, as when they went through LDS)
   sd.pk = bcast_u32(seedPk, 0); sd.q = bcast_u32(seedRec, 0);
   sd.ang = __uint_as_float(bcast_u32(sAngBits, 0)); sd.cx = __uint_as_float(bcast_u32(sCxBits, 0)); sd.sy = __uint_as_float(bcast_u32(sSyBits, 0));
-  return lsd_txn<true>(c, gs, a, sd, -1, false);
+  return lsd_txn<true>(c, gs, a, sd, -1, false, 0u);
 }
 
 // A posted transaction: 16 words in LDS, ring slot = sequence number mod MW_N.
