@@ -417,6 +417,52 @@ def test_gpu_line_grow_waves_batch(plslam, oracle, synth, waves, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("refine", [1, 0], ids=["adv", "std"])
+@pytest.mark.parametrize("rows,cols,B", [(376, 1241, 512), (480, 640, 320)], ids=["1241x376x512", "640x480x320"])
+def test_gpu_line_mw16_many_frames(plslam, oracle, synth, rows, cols, B, refine):
+    """The launch shape of BASELINE configs[4]'s per-GPU share: hundreds of frames with the AUTOMATIC wavefront policy, i.e.
+    batch x 8 wavefronts > 2048, which launch_lsd_grow() serves with the 128-register build k_lsd_grow_mw16 (the default soak
+    stops at 256 x 8 = 2048 = the roomy k_lsd_grow_mw).  Distinct frames of the soak's mix, both refine levels, every LSD segment,
+    KeyLine, LBD byte and line equation against the oracle."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from test_soak_gpu import soak_frames
+    assert B * 8 > 2048
+    frames = soak_frames(synth, rows, cols, B)
+
+    def one(img):
+        return oracle.line_extract(img, 200, 0.0, refine=refine) + (oracle.lsd_detect(img, refine=refine),)
+    with ThreadPoolExecutor(os.cpu_count() or 1) as pool:
+        ref = list(pool.map(one, list(frames)))
+    ex = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=rows, cols=cols, max_batch=B)
+    ex.set_refine(refine)           # (grow waves stay automatic: 8 per frame for <= 1024 frames)
+    cap = ex.capacity
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_kl = torch.zeros((B, cap, 17), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_fn = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    nseg = 0
+    for rep in range(2):            # (the schedule of the transactions differs from run to run, the result must not)
+        d_n.zero_()
+        ex.extract_batch_dev(d_img, B, rows * cols, d_kl, d_desc, d_fn, d_n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ex.status() == 0
+        n = d_n.cpu().numpy()
+        kl = d_kl.cpu().numpy().view(np.uint8).reshape(B, cap, 68).copy().view(plslam.KL_DTYPE).reshape(B, cap)
+        desc, fn = d_desc.cpu().numpy(), d_fn.cpu().numpy()
+        for b in range(B):
+            rk, rd, rf, rs = ref[b]
+            gs = ex.read_segments(b)
+            assert len(gs) == len(rs) and (gs == rs).all(), "run %d, frame %d: LSD segments differ from the oracle" % (rep, b)
+            _match(kl[b, :n[b]], desc[b, :n[b]], fn[b, :n[b]], rk, rd, rf, "run %d, frame %d" % (rep, b))
+            nseg += len(rs)
+    ex.close()
+    print("\nmw16 %dx%d x %d frames, refine %d: %d segments bit-exact over 2 runs" % (cols, rows, B, refine, nseg))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("waves", [0, -1, 4])
 def test_gpu_line_refine_adv(plslam, oracle, synth, waves):
     """LSD_REFINE_ADV on the GPU (k_lsd_grow_adv / k_lsd_grow_mw_adv) equals the oracle's ADV level: single frames of several
