@@ -295,6 +295,14 @@ PLH_API plh_status plh_vocab_read(const plh_vocab* v, uint8_t* node_desc, int32_
 PLH_API plh_status plh_vocab_transform_batch_dev(const plh_vocab* v, const uint8_t* d_desc, const int32_t* d_n, int cap, int batch,
                                                  int levelsup, int32_t* d_nid, int32_t* d_word, int32_t* d_bow_word,
                                                  double* d_bow_value, int32_t* d_bow_n, void* stream);
+/* The same for ONE frame on host buffers: the body of the drop-in ORBVocabulary::transform(features, v, fv, levelsup)
+ * (pl-slam_amd/adaptor/ORBVocabulary.h) behind Frame::ComputeBoW (Frame.cc:906-913) and KeyFrame::ComputeBoW (KeyFrame.cc:76-83).
+ * desc: n x 32 bytes (mDescriptors, n <= 8192).  nid[i] / word[i]: FeatureVector node (-1 = stopped word) and word id of feature i;
+ * bow_word / bow_value (room for n entries): the *bow_n distinct words in ascending order with their normalised weights (the
+ * BowVector's std::map order and doubles).  Stages through the calling thread's own arena and stream: the tracking and the
+ * local-mapping thread may call it concurrently on one handle. */
+PLH_API plh_status plh_vocab_transform(const plh_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* nid, int32_t* word,
+                                       int32_t* bow_word, double* bow_value, int* bow_n);
 
 /* ---------------------------------------------------------------------------------------------
  * Windowed (grid) searches  (Frame::AssignFeaturesToGrid*, GetFeaturesInArea*, ORBmatcher::SearchForInitialization /

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 #define private public   // AssignFeaturesToGrid / AssignFeaturesToGridForLine are private members
@@ -411,6 +412,58 @@ int ref_track_reference_keyframe(const char* voc_path, const plo_keypoint* kps1,
   const int nm = matcher.SearchByBoW(&kf, fc, m);
   for (int j = 0; j < n2; j++) matches21[j] = (j < (int)m.size() && m[j]) ? (int32_t)m[j]->mnId : -1;
   return nm;
+}
+
+
+// Frame::ComputeBoW (src/Frame.cc:906-913) and KeyFrame::ComputeBoW (src/KeyFrame.cc:76-83) on a real Frame / KeyFrame with a real
+// ORBVocabulary loaded from `voc_path` (text or, binary != 0, DBoW2's binary format).  In libframe_ref.so ORBVocabulary is the
+// reference's typedef of DBoW2::TemplatedVocabulary; in libadaptor_{hip,emu}.so (PLO_ADAPTOR_BUILD) it is the product's drop-in class
+// (pl-slam_amd/adaptor/ORBVocabulary.h) and the SAME two methods run the descent on the GPU.  Outputs: the Frame's BowVector as
+// (word, value) in map order, its FeatureVector flattened in map order (fv_node[k], fv_feat[k] per listed feature), and whether the
+// KeyFrame's two members equal the Frame's.  Returns the BowVector's size, -1 if the file does not load; *n_fv = listed features.
+int ref_compute_bow(const char* voc_path, int binary, const uint8_t* desc, int n, int32_t* bow_word, double* bow_value, int32_t* fv_node,
+                    int32_t* fv_feat, int* n_fv, int* kf_equal, int* is_adaptor_class) {
+  ORBVocabulary voc;
+  if (!(binary ? voc.loadFromBinaryFile(voc_path) : voc.loadFromTextFile(voc_path))) return -1;
+  typedef DBoW2::TemplatedVocabulary<DBoW2::FORB::TDescriptor, DBoW2::FORB> RefVoc;
+  *is_adaptor_class = (std::is_base_of<RefVoc, ORBVocabulary>::value && !std::is_same<RefVoc, ORBVocabulary>::value) ? 1 : 0;
+  Frame f;
+  f.N = n;
+  f.mvKeysUn.assign(n, cv::KeyPoint());
+  f.mvKeys = f.mvKeysUn;
+  f.mDescriptors = cv::Mat(n > 0 ? n : 1, 32, CV_8U);
+  if (n > 0) std::memcpy(f.mDescriptors.data, desc, (size_t)n * 32);
+  if (n == 0) f.mDescriptors = f.mDescriptors.rowRange(0, 0);
+  f.mpORBvocabulary = &voc;
+  f.mvpMapPoints.assign(n, nullptr);
+  f.mvbOutlier.assign(n, false);
+  f.mTcw = cv::Mat::eye(4, 4, CV_32F);
+  f.ComputeBoW();
+  int k = 0;
+  for (DBoW2::BowVector::const_iterator it = f.mBowVec.begin(); it != f.mBowVec.end(); ++it, ++k) {
+    bow_word[k] = (int32_t)it->first;
+    bow_value[k] = it->second;
+  }
+  int m = 0;
+  for (DBoW2::FeatureVector::const_iterator it = f.mFeatVec.begin(); it != f.mFeatVec.end(); ++it)
+    for (size_t j = 0; j < it->second.size(); j++, m++) {
+      fv_node[m] = (int32_t)it->first;
+      fv_feat[m] = (int32_t)it->second[j];
+    }
+  *n_fv = m;
+  Map map; KeyFrameDatabase db;
+  KeyFrame kf(f, &map, &db);      // copies mBowVec / mFeatVec ...
+  kf.mBowVec.clear();              // ... so empty them: KeyFrame::ComputeBoW only runs on an empty vector (KeyFrame.cc:78)
+  kf.mFeatVec.clear();
+  kf.ComputeBoW();
+  *kf_equal = (kf.mBowVec == f.mBowVec && kf.mFeatVec == f.mFeatVec) ? 1 : 0;
+  // a second vocabulary object given the first one's tree (operator=) and a second call on the same frame's descriptors
+  ORBVocabulary voc2;
+  voc2 = voc;
+  DBoW2::BowVector v2; DBoW2::FeatureVector fv2;
+  voc2.transform(Converter::toDescriptorVector(f.mDescriptors), v2, fv2, 4);
+  if (!(v2 == f.mBowVec && fv2 == f.mFeatVec)) *kf_equal = 0;
+  return k;
 }
 
 }  // extern "C"

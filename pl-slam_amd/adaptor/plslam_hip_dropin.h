@@ -4,6 +4,9 @@
 //   * ORB_SLAM2::ORBextractor / LINEextractor are declared here first, under the reference's own include guards, so the
 //     `#include "ORBextractor.h"` / `"LineExtractor.h"` of include/Frame.h, KeyFrame.h and Tracking.h (which always resolve to
 //     their sibling files, whatever the -I order) have nothing left to declare;
+//   * ORB_SLAM2::ORBVocabulary becomes a class derived from the reference's DBoW2::TemplatedVocabulary whose
+//     transform(features, BowVector&, FeatureVector&, levelsup) -- Frame::ComputeBoW, KeyFrame::ComputeBoW -- runs on the GPU
+//     (ORBVocabulary.h, same guard trick; everything else of the vocabulary stays the reference's host code);
 //   * ORB_SLAM2::ORBmatcher / LSDmatcher become classes derived from the reference's own (read once under the names
 //     ORBmatcherCPU / LSDmatcherCPU), with the tracking-path searches re-declared on top of the C ABI.
 // src/ORBextractor.cc and src/LineExtractor.cpp leave the build; src/ORBmatcher.cc and src/LSDmatcher.cpp stay in it, compiled
@@ -13,6 +16,7 @@
 #ifdef __cplusplus
 #include "ORBextractor.h"
 #include "LineExtractor.h"
+#include "ORBVocabulary.h"
 #if !defined(ORBmatcher) && !defined(LSDmatcher)
 #include "HipORBmatcher.h"
 #include "HipLSDmatcher.h"

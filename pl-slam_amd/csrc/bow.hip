@@ -11,6 +11,7 @@
 //                     run by repeated addition and sums the norm sequentially in word order: bit-identical doubles.
 #include "plh_common.h"
 #include "vocab.h"
+#include "plh_stage.h"
 
 namespace plh {
 
@@ -197,4 +198,40 @@ extern "C" plh_status plh_vocab_transform_batch_dev(const plh_vocab* v, const ui
   if (!d_bow_word && !d_bow_value && !d_bow_n) return PLH_OK;   // FeatureVector only
   return plh_bow_vector_batch_dev(d_word, d_n, cap, batch, v->dWordWeight, v->weighting, v->scoring, d_bow_word, d_bow_value,
                                   d_bow_n, stream);
+}
+
+// Frame::ComputeBoW / KeyFrame::ComputeBoW for ONE frame on host buffers (Frame.cc:906-913, KeyFrame.cc:76-83): what the drop-in
+// ORBVocabulary::transform(features, v, fv, levelsup) calls (pl-slam_amd/adaptor/ORBVocabulary.h).  desc = n rows of 32 bytes
+// (mDescriptors); nid[i] = FeatureVector node of feature i or -1 (stopped word), word[i] its word id; bow_word / bow_value (n
+// entries of room) receive the *bow_n distinct words in ascending order with their normalised weights.  Thread-safe for concurrent
+// callers on one handle (the tracking and the local-mapping thread both call ComputeBoW): the staging is the calling thread's own.
+extern "C" plh_status plh_vocab_transform(const plh_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* nid, int32_t* word,
+                                          int32_t* bow_word, double* bow_value, int* bow_n) {
+  if (!v || n < 0 || !bow_n || (n > 0 && (!desc || !nid || !word || !bow_word || !bow_value))) {
+    set_error("plh_vocab_transform: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  *bow_n = 0;
+  if (n == 0) return PLH_OK;
+  if (n > 8192) { set_error("plh_vocab_transform: %d features (at most 8192 per frame)", n); return PLH_ERR_CAPACITY; }
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  Stager st;
+  const size_t N = (size_t)n;
+  plh_status rc = st.begin(v->device, Stager::padded(N * 32) + 4 * Stager::padded(N * 4) + Stager::padded(N * 8) + 2 * 256);
+  if (rc != PLH_OK) return rc;
+  const int32_t n32 = n;
+  const uint8_t* dDesc = st.in(desc, N * 32);
+  const int32_t* dN = st.in(&n32, 1);
+  int32_t* dNid = st.out(nid, N);
+  int32_t* dWord = st.out(word, N);
+  int32_t* dBw = st.out(bow_word, N);
+  double* dBv = st.out(bow_value, N);
+  int32_t bn = 0;
+  int32_t* dBn = st.out(&bn, 1);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_vocab_transform_batch_dev(v, dDesc, dN, n, 1, levelsup, dNid, dWord, dBw, dBv, dBn, st.stream());
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *bow_n = bn;
+  return PLH_OK;
 }

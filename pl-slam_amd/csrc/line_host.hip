@@ -554,6 +554,18 @@ static plh_status line_lsd_stages(plh_line* h, const LineDeviceArgs& a, const ui
   PLH_LAUNCH_CHECK();
   if (top) { line_prof_mark(h, 0, s); line_prof_mark(h, 1, s); }
   if (top && h->growGate) PLH_HIP(hipStreamWaitEvent(s, h->growGate, 0));
+#if defined(PLH_GROW_PROF) && !defined(HIPEMU)
+  if (getenv("PLH_PROF_LOG_ALLOC")) {   // counter build only: where the buffers of this launch lie (to place a GPU fault address)
+    const struct { const char* name; const void* p; size_t n; } bufs[] = {
+        {"arena", h->dArena, (size_t)h->maxBatch * (size_t)a.arenaStride * 4}, {"mwReg", h->dMwReg, (size_t)h->mwWaveSlots * (size_t)a.mwRegStride * 4},
+        {"mwMark", h->dMwMark, (size_t)h->mwWaveSlots * (size_t)a.mwMarkStride}, {"mwHint", h->dMwHint, (size_t)h->mwHintFrames * (size_t)a.mwMarkStride * 2},
+        {"scaled", h->dScaled, (size_t)h->maxBatch * (size_t)a.scaledStride}, {"tmpA", h->dTmpA, (size_t)h->maxBatch * (size_t)a.fullStride},
+        {"dxdy", h->dDxdy, (size_t)h->maxBatch * (size_t)a.fullStride * 4}, {"angleTab", a.angleTab, ((size_t)LSD_ANGLE_ROWS << LSD_ANGLE_PITCH_LOG2) * sizeof(LsdAngleEntry)},
+        {"adv", h->dAdv, 0}, {"lgamma", h->dLgamma, 0}, {"status", h->dStatus, 64}};
+    for (const auto& b : bufs) fprintf(stderr, "PLHBUF %-8s %p .. %p (%zu bytes)\n", b.name, b.p, (const void*)((const char*)b.p + b.n), b.n);
+    fprintf(stderr, "PLHBUF batch %d waves %d arenaStride %lld mwRegStride %lld mwMarkStride %lld\n", batch, a.mwWaves, a.arenaStride, a.mwRegStride, a.mwMarkStride);
+  }
+#endif
   launch_lsd_grow(a, s);
   PLH_LAUNCH_CHECK();
   if (top && h->growDone) PLH_HIP(hipEventRecord(h->growDone, s));

@@ -11,6 +11,9 @@ linked to libplslam_hip.so (GPU box, `-m gpu`) or to the emulator build of the s
     SearchLocalLines, TrackWithMotionModel, TrackReferenceKeyFrame) on real Frame / KeyFrame / MapPoint / MapLine objects, with
     `ORBmatcher` / `LSDmatcher` now being the adaptor classes; results equal tests/golden/ref_track.npz, which the reference's own
     src/ORBmatcher.cc / src/LSDmatcher.cpp produced.
+  * test_adaptor_executes_compute_bow: Frame::ComputeBoW / KeyFrame::ComputeBoW with `ORBVocabulary` being the drop-in class
+    (adaptor/ORBVocabulary.h: the reference's loaders, the GPU's transform); BowVector doubles and FeatureVector lists equal what the
+    same methods leave over the reference's own DBoW2 (tests/golden/ref_computebow.npz).
   * test_adaptor_executes_initialization_matchers: SearchForInitialization and SearchDouble on two constructed Frames vs the oracle.
 The libraries are built in the build container (the reference is not on the GPU box) and travel with the snapshot."""
 import ctypes as C
@@ -230,6 +233,44 @@ def test_adaptor_executes_tracking_searches_emu(plslam, synth, emu_lib):
 def test_adaptor_executes_tracking_searches(plslam, synth):
     G = _gen()
     _tracking_searches(plslam, synth, LIB_HIP, G.TRACK_CASES, G.BOWTRACK_CASES)
+
+
+def _compute_bow(S, path, cases, live_reference):
+    """Frame::ComputeBoW and KeyFrame::ComputeBoW (src/Frame.cc:906-913, src/KeyFrame.cc:76-83) as the reference compiled them, with
+    `ORBVocabulary` being the product's drop-in class (pl-slam_amd/adaptor/ORBVocabulary.h: the reference's loaders build the host
+    tree, transform() descends on the device): mBowVec -- words and DOUBLES, `==` -- and mFeatVec -- node ids and per-node feature lists
+    in order -- equal what the same two methods leave over the reference's own DBoW2 (tests/golden/ref_computebow.npz, made by
+    libframe_ref.so; with /root/reference built here that library is also run live beside it)."""
+    import tempfile
+    G, R = _lib(path)
+    VM = _util._load("plslam_amd_vocab", os.path.join(_util.ROOT, "pl-slam_amd", "vocab.py"))
+    g = np.load(os.path.join(GOLD, "ref_computebow.npz"))
+    ref_path = os.path.join(_util.ROOT, "oracle", "_ref", "libframe_ref.so")
+    Rref = G.ref_frame_lib() if (live_reference and os.path.exists(ref_path)) else None
+    for seed, k, Lv, stop, idf, n, binary, sc, wt in cases:
+        voc, desc = G.computebow_inputs(S, VM, seed, k, Lv, stop, idf, n)
+        bw, bv, fn, ff, eq, adp = G.reference_computebow(R, voc, desc, binary, sc, wt, tempfile.gettempdir())
+        assert adp == 1, "ORBVocabulary in this library is not the drop-in class"
+        what = "ComputeBoW case %d" % seed
+        assert len(bw) == len(g["w_%d" % seed]) and (bw == g["w_%d" % seed]).all(), what + ": BowVector words"
+        assert (bv == g["v_%d" % seed]).all(), what + ": BowVector values (doubles compared with ==)"
+        assert len(ff) == len(g["ff_%d" % seed]) and (fn == g["fn_%d" % seed]).all() and (ff == g["ff_%d" % seed]).all(), what + ": FeatureVector"
+        assert eq == 1, what + ": KeyFrame::ComputeBoW / a copied vocabulary disagree with Frame::ComputeBoW"
+        if Rref is not None:
+            rw, rv, rn, rf, req, radp = G.reference_computebow(Rref, voc, desc, binary, sc, wt, tempfile.gettempdir())
+            assert radp == 0 and req == 1
+            assert (rw == bw).all() and (rv == bv).all() and (rn == fn).all() and (rf == ff).all(), what + ": live reference"
+
+
+def test_adaptor_executes_compute_bow_emu(synth, emu_lib):
+    G = _gen()
+    _compute_bow(synth, LIB_EMU, [c for c in G.COMPUTEBOW_CASES if c[5] <= 900], True)
+
+
+@pytest.mark.gpu
+def test_adaptor_executes_compute_bow(synth):
+    G = _gen()
+    _compute_bow(synth, LIB_HIP, G.COMPUTEBOW_CASES, False)
 
 
 def _initialization_matchers(P, S, O, path, rows, cols, nfeat):

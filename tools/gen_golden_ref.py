@@ -1130,6 +1130,71 @@ def gen_track(S, out):
         print("reference-keyframe search", seed, "matched", c, "of", n)
     np.savez_compressed(os.path.join(out, "ref_track.npz"), **g)
 
+# ---------------------------------------------------------------------------------------------------------------
+# Frame::ComputeBoW / KeyFrame::ComputeBoW on a real Frame with a real ORBVocabulary (oracle/ref/ref_frame.cc: ref_compute_bow);
+# the same harness function in libadaptor_*.so runs them through the product's drop-in ORBVocabulary class.
+# ---------------------------------------------------------------------------------------------------------------
+COMPUTEBOW_CASES = [   # seed, k, L, stop fraction, idf-like weights, n descriptors, binary file, scoring, weighting
+    (701, 10, 4, 0.02, True, 1500, False, 0, 0), (702, 8, 3, 0.0, False, 400, False, 0, 0), (703, 10, 5, 0.01, True, 2000, True, 0, 0),
+    (704, 9, 3, 0.05, True, 1, False, 0, 0), (705, 10, 4, 0.0, True, 700, False, 1, 1), (706, 6, 4, 0.1, True, 900, True, 5, 3),
+]
+
+
+def write_binary_voc(voc, path, scoring, weighting):
+    """DBoW2's binary vocabulary (TemplatedVocabulary::saveToBinaryFile, :1511-1536): u32 nodes, u32 41, k L scoring weighting,
+    then per non-root node u32 parent, 32 descriptor bytes, f32 weight, u8 is_leaf."""
+    parent, leaf = voc.tree_arrays()
+    with open(path, "wb") as f:
+        f.write(np.array([voc.n_nodes, 41], np.uint32).tobytes())
+        f.write(np.array([voc.k, voc.L, scoring, weighting], np.int32).tobytes())
+        for i in range(1, voc.n_nodes):
+            f.write(np.uint32(parent[i]).tobytes() + voc.node_desc[i].tobytes() + np.float32(voc.weight64[i]).tobytes() +
+                    np.uint8(leaf[i]).tobytes())
+
+
+def computebow_inputs(S, VM, seed, k, Lv, stop, idf, n):
+    voc = VM.Vocabulary.synthetic(seed, k=k, L=Lv, synth=S, stop_fraction=stop, idf=idf)
+    a, _, _ = S.make_descriptor_sets(seed + 1, max(n, 2))
+    first_leaf = (k ** Lv - 1) // (k - 1)
+    rng = S.SplitMix64(seed + 2)
+    pick = rng.randint(max(n // 2, 1), first_leaf, voc.n_nodes)
+    noisy = voc.node_desc[pick] ^ np.packbits((rng.uniform(len(pick) * 256) < 0.04).reshape(-1, 256), axis=1, bitorder="little")
+    desc = np.ascontiguousarray(np.concatenate([a[: n - n // 2], noisy[: n // 2]]), np.uint8)[:n]
+    return voc, desc
+
+
+def reference_computebow(R, voc, desc, binary, scoring, weighting, tmpdir):
+    """(BowVector words, values, FeatureVector nodes, features, KeyFrame / copied vocabulary agree, ORBVocabulary is the adaptor class)"""
+    path = os.path.join(tmpdir, "cbow_%d_%d.%s" % (os.getpid(), len(voc.node_desc), "bin" if binary else "txt"))
+    if binary:
+        write_binary_voc(voc, path, scoring, weighting)
+    else:
+        voc.save_text(path, scoring, weighting)
+    n = len(desc)
+    bw, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+    fn, ff = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    nfv, eq, adp = C.c_int(0), C.c_int(0), C.c_int(0)
+    R.ref_compute_bow.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+    c = R.ref_compute_bow(path.encode(), 1 if binary else 0, p(desc), n, p(bw), p(bv), p(fn), p(ff), C.byref(nfv), C.byref(eq), C.byref(adp))
+    os.remove(path)
+    assert c >= 0, "the reference did not load %s" % path
+    return bw[:c].copy(), bv[:c].copy(), fn[:nfv.value].copy(), ff[:nfv.value].copy(), eq.value, adp.value
+
+
+def gen_computebow(S, out):
+    import tempfile
+    R = ref_frame_lib()
+    VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
+    g = {}
+    for seed, k, Lv, stop, idf, n, binary, sc, wt in COMPUTEBOW_CASES:
+        voc, desc = computebow_inputs(S, VM, seed, k, Lv, stop, idf, n)
+        bw, bv, fn, ff, eq, adp = reference_computebow(R, voc, desc, binary, sc, wt, tempfile.gettempdir())
+        assert eq == 1 and adp == 0
+        g["w_%d" % seed], g["v_%d" % seed], g["fn_%d" % seed], g["ff_%d" % seed] = bw, bv, fn, ff
+        print("ComputeBoW", seed, "words", len(bw), "listed features", len(ff), "of", n)
+    np.savez_compressed(os.path.join(out, "ref_computebow.npz"), **g)
+
+
 def main():
     S = _util.synth()
     VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
@@ -1156,6 +1221,7 @@ def main():
     gen_framegrid(S, out)
     gen_frustum(S, out)
     gen_track(S, out)
+    gen_computebow(S, out)
 
 
 if __name__ == "__main__":
