@@ -525,6 +525,55 @@ PLH_API plh_status plh_orb_fuse_search(const plh_keypoint* kps_un, const uint8_t
                                        float th, int th_low, int32_t* best_idx, int* nfound, int device);
 
 /* ---------------------------------------------------------------------------------------------
+ * Resident frames (round 6): what the searches read from one Frame / KeyFrame, uploaded ONCE.
+ *
+ * A tracked frame is searched two to four times (Tracking.cc:1321-1357 TrackWithMotionModel or :1151-1159 TrackReferenceKeyFrame,
+ * :1792-1855 SearchLocalPoints / SearchLocalLines, and again as the last frame of the next one); the host-buffer forms above
+ * upload mvKeysUn + mDescriptors (60 KB) and rebuild the grid of Frame::AssignFeaturesToGrid inside every call.  A resident handle
+ * holds them on the device -- plh_frame_points: mvKeysUn, mDescriptors, the 64 x 48 grid (Frame.cc:278-293), optionally the
+ * FeatureVector node of every feature (after ComputeBoW); plh_frame_lines: mvKeylinesUn, mLdesc, mvKeyLineFunctions, the line grid
+ * (Frame.cc:295-320) -- and the *_resident forms stage the queries only (the calling thread's arena and stream).  Handles are
+ * immutable after creation (set_nodes once, before the first SearchByBoW): any number of threads may search one concurrently.
+ * Arguments and results are those of the host-buffer forms of the same name.  The adaptor classes keep an LRU of handles keyed by
+ * Frame::mnId (pl-slam_amd/adaptor/HipMatchers.h: hip::FrameResidency).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct plh_frame_points plh_frame_points;
+typedef struct plh_frame_lines plh_frame_lines;
+PLH_API plh_status plh_frame_points_create(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp, int device,
+                                           plh_frame_points** out);
+PLH_API plh_status plh_frame_points_set_nodes(plh_frame_points* f, const int32_t* node);   /* node[i] = FeatureVector node of feature i, -1 = none */
+PLH_API plh_status plh_frame_points_destroy(plh_frame_points* f);
+PLH_API int plh_frame_points_count(const plh_frame_points* f);
+PLH_API plh_status plh_frame_lines_create(const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
+                                          const plh_grid_params* gp, int device, plh_frame_lines** out);
+PLH_API plh_status plh_frame_lines_destroy(plh_frame_lines* f);
+PLH_API int plh_frame_lines_count(const plh_frame_lines* f);
+PLH_API plh_status plh_orb_search_by_projection_mp_resident(const plh_frame_points* f, const float* scale_factors, int nlevels,
+                                                            uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_xy,
+                                                            const int32_t* q_level, const float* q_viewcos, const uint8_t* q_desc,
+                                                            const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned,
+                                                            int* nmatches);
+PLH_API plh_status plh_orb_search_by_projection_frame_resident(const plh_frame_points* f, const float* scale_factors, int nlevels,
+                                                               uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_uv,
+                                                               const int32_t* q_octave, const float* q_angle, const uint8_t* q_desc,
+                                                               const uint8_t* q_hasobs, float th, int mode, int check_ori,
+                                                               int32_t* assigned, int* nmatches);
+PLH_API plh_status plh_orb_search_for_initialization_resident(const plh_frame_points* f1, const plh_frame_points* f2, float* prev_matched,
+                                                              int window_size, float nnratio, int check_ori, int32_t* matches12,
+                                                              int* nmatches);
+PLH_API plh_status plh_orb_search_by_bow_resident(const plh_frame_points* kf, const uint8_t* valid1, const plh_frame_points* f, int th_low,
+                                                  float nnratio, int check_ori, int32_t* matches21, int* nmatches);
+PLH_API plh_status plh_line_search_by_projection_frame_resident(const plh_frame_lines* f, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                                                const float* q_seg, const float* q_length, const uint8_t* q_desc,
+                                                                const uint8_t* q_hasobs, float th, int32_t* assigned, int* nmatches);
+PLH_API plh_status plh_line_search_by_projection_ml_resident(const plh_frame_lines* f, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                                             const float* q_seg, const float* q_viewcos, const uint8_t* q_desc,
+                                                             const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned,
+                                                             int* nmatches);
+PLH_API plh_status plh_line_search_double_resident(const plh_frame_lines* l1, const plh_frame_lines* l2, float th, float nnratio,
+                                                   int32_t* matches12, int* nmatches);
+
+/* ---------------------------------------------------------------------------------------------
  * Frame / map post-processing either side of the matching path
  * ------------------------------------------------------------------------------------------- */
 /* Frame::UndistortKeyPoints (Frame.cc:915-945): cv::undistortPoints(pts, pts, K, D, noArray(), K) on every keypoint,

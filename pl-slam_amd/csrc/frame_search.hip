@@ -18,6 +18,8 @@
 #include <vector>
 
 #include "plh_common.h"
+#include "plh_stage.h"
+#include "frame_resident.h"
 
 namespace plh {
 
@@ -918,28 +920,27 @@ plh_status plh_line_search_by_projection_ml_batch_dev(const plh_keyline* d_kl, c
 // Frame constructor, a caller that keeps frames resident uses the *_batch_dev entry points instead.
 extern "C++" {
 namespace {
-struct Stage {   // RAII device staging of host arrays
-  std::vector<void*> ptrs;
-  hipError_t err = hipSuccess;
-  ~Stage() { for (void* p : ptrs) (void)hipFree(p); }
+// Staging of a call's host arrays through the calling thread's arena (plh_stage.h): every array is packed into the pinned mirror,
+// ONE copy takes them up, the kernels run on the thread's own stream, one copy brings the results back.  (Rounds 1-5: a hipMalloc
+// and a blocking copy per array, the null stream, a device-wide synchronisation, a hipFree per array.)
+struct Stage {
+  Stager st;
+  plh_status rc;
+  explicit Stage(int device) : rc(st.begin(device)) {}
   template <typename T> T* up(const T* host, size_t count, size_t alloc_count = 0) {
-    void* d = nullptr;
-    const size_t bytes = std::max(std::max(count, alloc_count), (size_t)1) * sizeof(T);
-    if (err == hipSuccess) err = hipMalloc(&d, bytes);
-    if (err != hipSuccess) return nullptr;
-    ptrs.push_back(d);
-    if (count && host) err = hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice);
-    else if (err == hipSuccess) err = hipMemset(d, 0, bytes);
-    return reinterpret_cast<T*>(d);
+    if (rc != PLH_OK) return nullptr;
+    return (count && host) ? st.in(host, count, alloc_count) : st.scratch_zero<T>(std::max(std::max(count, alloc_count), (size_t)1));
   }
-  template <typename T> T* alloc(size_t count) { return up<T>(nullptr, 0, count); }
+  template <typename T> T* alloc(size_t count) { return rc == PLH_OK ? st.scratch_zero<T>(std::max(count, (size_t)1)) : nullptr; }
+  void fetch_bytes(void* dst, const void* d, size_t bytes) { if (bytes) st.fetch(static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(d), bytes); }
+  hipStream_t stream() const { return st.stream(); }
+  plh_status ready() { return rc != PLH_OK ? rc : st.upload(); }
+  plh_status finish() { return st.download(); }
 };
-#define STAGE_OK(st)                                                                     \
-  do {                                                                                   \
-    if ((st).err != hipSuccess) {                                                        \
-      plh::set_error("%s:%d staging -> %s", __FILE__, __LINE__, hipGetErrorString((st).err)); \
-      return PLH_ERR_HIP;                                                                \
-    }                                                                                    \
+#define STAGE_OK(s)                          \
+  do {                                       \
+    const plh_status rc__ = (s).ready();     \
+    if (rc__ != PLH_OK) return rc__;         \
   } while (0)
 }  // namespace
 }  // extern "C++"
@@ -955,9 +956,8 @@ plh_status plh_orb_search_for_initialization(const plh_keypoint* kps1, const uin
   *nmatches = 0;
   if (n1 == 0 || n2 == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
   const int cap = std::max(n1, n2);
-  Stage s;
+  Stage s(device);
   plh_keypoint* dk1 = s.up(kps1, n1, cap); uint8_t* dd1 = s.up(desc1, (size_t)n1 * 32, (size_t)cap * 32);
   plh_keypoint* dk2 = s.up(kps2, n2, cap); uint8_t* dd2 = s.up(desc2, (size_t)n2 * 32, (size_t)cap * 32);
   const int32_t ns[2] = {n1, n2};
@@ -966,16 +966,15 @@ plh_status plh_orb_search_for_initialization(const plh_keypoint* kps1, const uin
   int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(cap);
   int32_t* dm = s.alloc<int32_t>(cap); int32_t* dc = s.alloc<int32_t>(1);
   STAGE_OK(s);
-  plh_status st = plh_frame_assign_grid_batch_dev(dk2, dn + 1, cap, 1, gp2, dcs, dci, nullptr);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk2, dn + 1, cap, 1, gp2, dcs, dci, s.stream());
   if (st == PLH_OK)
     st = plh_orb_search_for_initialization_batch_dev(dk1, dd1, dn, dk2, dd2, dn + 1, cap, 1, gp2, dcs, dci, dpm, window_size, nnratio,
-                                                     check_ori, dm, dc, nullptr);
+                                                     check_ori, dm, dc, s.stream());
   if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(matches12, dm, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(prev_matched, dpm, (size_t)n1 * 8, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
-  return PLH_OK;
+  s.fetch_bytes(matches12, dm, (size_t)n1 * 4);
+  s.fetch_bytes(prev_matched, dpm, (size_t)n1 * 8);
+  s.fetch_bytes(nmatches, dc, 4);
+  return s.finish();
 }
 
 static plh_status host_proj_points(int variant, const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
@@ -990,8 +989,7 @@ static plh_status host_proj_points(int variant, const plh_keypoint* kps_un, cons
   *nmatches = 0;
   if (n == 0 || nq == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
-  Stage s;
+  Stage s(device);
   plh_keypoint* dk = s.up(kps_un, n); uint8_t* dd = s.up(desc, (size_t)n * 32); uint8_t* docc = s.up(occupied, n);
   const int32_t ns[2] = {n, nq};
   int32_t* dn = s.up(ns, 2);
@@ -1000,16 +998,15 @@ static plh_status host_proj_points(int variant, const plh_keypoint* kps_un, cons
   int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(n);
   int32_t* da = s.alloc<int32_t>(n); int32_t* dc = s.alloc<int32_t>(1);
   STAGE_OK(s);
-  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, nullptr);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, s.stream());
   if (st == PLH_OK)
     st = launch_proj_points(variant, dk, dd, dn, n, 1, gp, dcs, dci, scale_factors, nlevels, docc, dn + 1, nq, qv, qx, ql, qa, qd, qh,
-                            th, nnratio, mode, check_ori, da, dc, nullptr, "plh_orb_search_by_projection");
+                            th, nnratio, mode, check_ori, da, dc, s.stream(), "plh_orb_search_by_projection");
   if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(assigned, da, (size_t)n * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(occupied, docc, (size_t)n, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
-  return PLH_OK;
+  s.fetch_bytes(assigned, da, (size_t)n * 4);
+  s.fetch_bytes(occupied, docc, (size_t)n);
+  s.fetch_bytes(nmatches, dc, 4);
+  return s.finish();
 }
 
 plh_status plh_orb_search_by_projection_mp(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp,
@@ -1045,9 +1042,8 @@ plh_status plh_orb_search_by_sim3(const plh_keypoint* kps1_un, const uint8_t* de
   *nfound = 0;
   if (n1 == 0 || n2 == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
   const size_t cap = (size_t)std::max(n1, n2);
-  Stage s;
+  Stage s(device);
   plh_keypoint* k1 = s.up(kps1_un, n1, cap); uint8_t* d1 = s.up(desc1, (size_t)n1 * 32, cap * 32);
   plh_keypoint* k2 = s.up(kps2_un, n2, cap); uint8_t* d2 = s.up(desc2, (size_t)n2 * 32, cap * 32);
   const int32_t ns[2] = {n1, n2};
@@ -1061,16 +1057,15 @@ plh_status plh_orb_search_by_sim3(const plh_keypoint* kps1_un, const uint8_t* de
   int32_t* m1 = s.alloc<int32_t>(cap); int32_t* m2 = s.alloc<int32_t>(cap); int32_t* m12 = s.alloc<int32_t>(cap);
   int32_t* dc = s.alloc<int32_t>(1);
   STAGE_OK(s);
-  plh_status st = plh_frame_assign_grid_batch_dev(k1, dn, (int)cap, 1, gp, cs1, ci1, nullptr);
-  if (st == PLH_OK) st = plh_frame_assign_grid_batch_dev(k2, dn + 1, (int)cap, 1, gp, cs2, ci2, nullptr);
+  plh_status st = plh_frame_assign_grid_batch_dev(k1, dn, (int)cap, 1, gp, cs1, ci1, s.stream());
+  if (st == PLH_OK) st = plh_frame_assign_grid_batch_dev(k2, dn + 1, (int)cap, 1, gp, cs2, ci2, s.stream());
   if (st == PLH_OK)
     st = plh_orb_search_by_sim3_batch_dev(k1, d1, dn, cs1, ci1, k2, d2, dn + 1, cs2, ci2, (int)cap, 1, gp, scale_factors, nlevels, v12, u12,
-                                          l12, e12, v21, u21, l21, e21, th, th_high, m1, m2, m12, dc, nullptr);
+                                          l12, e12, v21, u21, l21, e21, th, th_high, m1, m2, m12, dc, s.stream());
   if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(match12, m12, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nfound, dc, 4, hipMemcpyDeviceToHost));
-  return PLH_OK;
+  s.fetch_bytes(match12, m12, (size_t)n1 * 4);
+  s.fetch_bytes(nfound, dc, 4);
+  return s.finish();
 }
 
 // ORBmatcher::SearchByProjection(Frame& Cur, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1587-1716, Tracking::Relocalization)
@@ -1086,8 +1081,7 @@ plh_status plh_orb_search_by_projection_kf(const plh_keypoint* kps_un, const uin
   *nmatches = 0;
   if (n == 0 || nq == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
-  Stage s;
+  Stage s(device);
   plh_keypoint* dk = s.up(kps_un, n); uint8_t* dd = s.up(desc, (size_t)n * 32); uint8_t* docc = s.up(occupied, n);
   const int32_t ns[2] = {n, nq};
   int32_t* dn = s.up(ns, 2);
@@ -1097,16 +1091,15 @@ plh_status plh_orb_search_by_projection_kf(const plh_keypoint* kps_un, const uin
   int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(n);
   int32_t* da = s.alloc<int32_t>(n); int32_t* dc = s.alloc<int32_t>(1);
   STAGE_OK(s);
-  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, nullptr);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, s.stream());
   if (st == PLH_OK)
     st = plh_orb_search_by_projection_kf_batch_dev(dk, dd, dn, n, 1, gp, dcs, dci, scale_factors, nlevels, docc, dn + 1, nq, qv, qx, ql, qa,
-                                                   qd, qh, th, orb_dist, check_ori, da, dc, nullptr);
+                                                   qd, qh, th, orb_dist, check_ori, da, dc, s.stream());
   if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(assigned, da, (size_t)n * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(occupied, docc, (size_t)n, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
-  return PLH_OK;
+  s.fetch_bytes(assigned, da, (size_t)n * 4);
+  s.fetch_bytes(occupied, docc, (size_t)n);
+  s.fetch_bytes(nmatches, dc, 4);
+  return s.finish();
 }
 
 // ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:329-453) on one KeyFrame, host
@@ -1123,8 +1116,7 @@ plh_status plh_orb_search_by_projection_sim3(const plh_keypoint* kps_un, const u
   *nmatches = 0;
   if (n == 0 || nq == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
-  Stage s;
+  Stage s(device);
   plh_keypoint* dk = s.up(kps_un, n); uint8_t* dd = s.up(desc, (size_t)n * 32); uint8_t* docc = s.up(occupied, n);
   const int32_t ns[2] = {n, nq};
   int32_t* dn = s.up(ns, 2);
@@ -1133,16 +1125,15 @@ plh_status plh_orb_search_by_projection_sim3(const plh_keypoint* kps_un, const u
   int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(n);
   int32_t* da = s.alloc<int32_t>(n); int32_t* dc = s.alloc<int32_t>(1);
   STAGE_OK(s);
-  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, nullptr);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, s.stream());
   if (st == PLH_OK)
     st = plh_orb_search_by_projection_sim3_batch_dev(dk, dd, dn, n, 1, gp, dcs, dci, scale_factors, nlevels, docc, dn + 1, nq, qv, qx, ql, qd,
-                                                     qh, th, th_low, da, dc, nullptr);
+                                                     qh, th, th_low, da, dc, s.stream());
   if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(assigned, da, (size_t)n * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(occupied, docc, (size_t)n, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
-  return PLH_OK;
+  s.fetch_bytes(assigned, da, (size_t)n * 4);
+  s.fetch_bytes(occupied, docc, (size_t)n);
+  s.fetch_bytes(nmatches, dc, 4);
+  return s.finish();
 }
 
 // The search inside ORBmatcher::Fuse(pKF, vpMapPoints, th) / Fuse(pKF, Scw, ...) (ORBmatcher.cc:914-1197) on one KeyFrame, host
@@ -1158,8 +1149,7 @@ plh_status plh_orb_fuse_search(const plh_keypoint* kps_un, const uint8_t* desc, 
   *nfound = 0;
   if (n == 0 || nq == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
-  Stage s;
+  Stage s(device);
   plh_keypoint* dk = s.up(kps_un, n); uint8_t* dd = s.up(desc, (size_t)n * 32);
   const int32_t ns[2] = {n, nq};
   int32_t* dn = s.up(ns, 2);
@@ -1168,16 +1158,15 @@ plh_status plh_orb_fuse_search(const plh_keypoint* kps_un, const uint8_t* desc, 
   int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(n);
   int32_t* db = s.alloc<int32_t>(nq); int32_t* dc = s.alloc<int32_t>(1);
   STAGE_OK(s);
-  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, nullptr);
+  plh_status st = plh_frame_assign_grid_batch_dev(dk, dn, n, 1, gp, dcs, dci, s.stream());
   const float noGate[16] = {0};   // inv_level_sigma2 == NULL: no chi-square gate (the Sim3 overload of Fuse): e2 * 0 never exceeds it
   if (st == PLH_OK)
     st = plh_orb_fuse_search_batch_dev(dk, dd, dn, n, 1, gp, dcs, dci, scale_factors, inv_level_sigma2 ? inv_level_sigma2 : noGate, nlevels,
-                                       dn + 1, nq, qv, qx, ql, qd, th, th_low, db, dc, nullptr);
+                                       dn + 1, nq, qv, qx, ql, qd, th, th_low, db, dc, s.stream());
   if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(best_idx, db, (size_t)nq * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nfound, dc, 4, hipMemcpyDeviceToHost));
-  return PLH_OK;
+  s.fetch_bytes(best_idx, db, (size_t)nq * 4);
+  s.fetch_bytes(nfound, dc, 4);
+  return s.finish();
 }
 
 static plh_status host_proj_lines(int variant, const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
@@ -1191,8 +1180,7 @@ static plh_status host_proj_lines(int variant, const plh_keyline* kl, const uint
   *nmatches = 0;
   if (nl == 0 || nq == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
-  Stage s;
+  Stage s(device);
   const int itemCap = nl * PLH_GRID_COLS;
   plh_keyline* dk = s.up(kl, nl); uint8_t* dd = s.up(ldesc, (size_t)nl * 32); double* dfn = s.up(linefn, (size_t)nl * 3);
   uint8_t* docc = s.up(occupied, nl);
@@ -1203,16 +1191,15 @@ static plh_status host_proj_lines(int variant, const plh_keyline* kl, const uint
   int32_t* dcs = s.alloc<int32_t>(PLH_GRID_CELLS + 1); int32_t* dci = s.alloc<int32_t>(itemCap);
   int32_t* da = s.alloc<int32_t>(nl); int32_t* dc = s.alloc<int32_t>(1);
   STAGE_OK(s);
-  plh_status st = plh_frame_assign_grid_lines_batch_dev(dk, dn, nl, 1, gp, dcs, dci, itemCap, nullptr);
+  plh_status st = plh_frame_assign_grid_lines_batch_dev(dk, dn, nl, 1, gp, dcs, dci, itemCap, s.stream());
   if (st == PLH_OK)
     st = launch_proj_lines(variant, dk, dd, dfn, dn, nl, 1, gp, dcs, dci, itemCap, docc, dn + 1, nq, qv, qs, qa, qd, qh, th, nnratio, da,
-                           dc, nullptr, "plh_line_search_by_projection");
+                           dc, s.stream(), "plh_line_search_by_projection");
   if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(assigned, da, (size_t)nl * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(occupied, docc, (size_t)nl, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc, 4, hipMemcpyDeviceToHost));
-  return PLH_OK;
+  s.fetch_bytes(assigned, da, (size_t)nl * 4);
+  s.fetch_bytes(occupied, docc, (size_t)nl);
+  s.fetch_bytes(nmatches, dc, 4);
+  return s.finish();
 }
 
 plh_status plh_line_search_by_projection_frame(const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl,
@@ -1243,8 +1230,7 @@ plh_status plh_line_fuse_search(const plh_keyline* kl, const uint8_t* cand_desc,
   *nfound = 0;
   if (nl == 0 || nq == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
-  Stage s;
+  Stage s(device);
   plh_keyline* dk = s.up(kl, nl); uint8_t* dd = s.up(cand_desc, (size_t)nl * 32);
   const int32_t ns[2] = {nl, nq};
   int32_t* dn = s.up(ns, 2);
@@ -1253,12 +1239,235 @@ plh_status plh_line_fuse_search(const plh_keyline* kl, const uint8_t* cand_desc,
   int32_t* db = s.alloc<int32_t>(nq); int32_t* dc = s.alloc<int32_t>(1);
   STAGE_OK(s);
   plh_status st = plh_line_fuse_search_batch_dev(dk, dd, dn, nl, 1, scale_factors_line, nlevels, dn + 1, nq, qv, qs, ql, qd, th, cos_th,
-                                                 th_low, db, dc, nullptr);
+                                                 th_low, db, dc, s.stream());
   if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(best_idx, db, (size_t)nq * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nfound, dc, 4, hipMemcpyDeviceToHost));
+  s.fetch_bytes(best_idx, db, (size_t)nq * 4);
+  s.fetch_bytes(nfound, dc, 4);
+  return s.finish();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident frames (round 6): frame_resident.h.  create = one upload + the grid kernel; the *_resident searches stage the
+// queries only (the calling thread's arena) and read keypoints, descriptors and grid where they already lie.
+// ---------------------------------------------------------------------------------------------------------------------
+plh_status plh_frame_points_create(const plh_keypoint* kps_un, const uint8_t* desc, int n, const plh_grid_params* gp, int device,
+                                   plh_frame_points** out) {
+  if (!out || n < 0 || !gp || (n > 0 && (!kps_un || !desc))) { set_error("plh_frame_points_create: invalid argument"); return PLH_ERR_INVALID; }
+  if (n > 6000) { set_error("plh_frame_points_create: %d keypoints (the searches hold at most 6000 per frame)", n); return PLH_ERR_CAPACITY; }
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  plh_frame_points* f = new plh_frame_points();
+  f->device = device; f->n = n; f->gp = *gp;
+  const size_t N = (size_t)std::max(n, 1);
+  const size_t oK = 0, oD = Stager::padded(N * sizeof(plh_keypoint)), oN = oD + Stager::padded(N * 32), oS = oN + 256,
+               oI = oS + Stager::padded((PLH_GRID_CELLS + 1) * 4), oO = oI + Stager::padded(N * 4), total = oO + Stager::padded(N * 4);
+  if (hipMalloc((void**)&f->block, total) != hipSuccess) {
+    (void)hipGetLastError();
+    delete f;
+    set_error("plh_frame_points_create: cannot allocate %zu bytes", total);
+    return PLH_ERR_ALLOC;
+  }
+  f->kps = (plh_keypoint*)(f->block + oK); f->desc = f->block + oD; f->dn = (int32_t*)(f->block + oN);
+  f->cellStart = (int32_t*)(f->block + oS); f->cellItems = (int32_t*)(f->block + oI); f->node = (int32_t*)(f->block + oO);
+  hipStream_t s = st.stream();
+  const int32_t n32 = n;
+  hipError_t e = hipMemcpyAsync(f->dn, &n32, 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(f->kps, kps_un, (size_t)n * sizeof(plh_keypoint), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(f->desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(f->cellStart, 0, (PLH_GRID_CELLS + 1) * 4, s);
+  if (e == hipSuccess) rc = plh_frame_assign_grid_batch_dev(f->kps, f->dn, (int)N, 1, gp, f->cellStart, f->cellItems, s);
+  if (e == hipSuccess && rc == PLH_OK) e = hipStreamSynchronize(s);   // (the host arrays are the caller's: copied when this returns)
+  if (e != hipSuccess || rc != PLH_OK) {
+    if (e != hipSuccess) { set_error("plh_frame_points_create: %s", hipGetErrorString(e)); rc = PLH_ERR_HIP; }
+    (void)hipFree(f->block);
+    delete f;
+    return rc;
+  }
+  *out = f;
   return PLH_OK;
+}
+// Frame::ComputeBoW's FeatureVector as one node id per feature (-1: the feature is in no node -- a stopped word): what
+// SearchByBoW walks.  (Immutable otherwise: set it before the frame is searched by plh_orb_search_by_bow_resident.)
+plh_status plh_frame_points_set_nodes(plh_frame_points* f, const int32_t* node) {
+  if (!f || (f->n > 0 && !node)) return PLH_ERR_INVALID;
+  PLH_HIP(hipSetDevice(f->device));
+  if (f->n) PLH_HIP(hipMemcpy(f->node, node, (size_t)f->n * 4, hipMemcpyHostToDevice));
+  f->hasNodes = true;
+  return PLH_OK;
+}
+plh_status plh_frame_points_destroy(plh_frame_points* f) {
+  if (!f) return PLH_OK;
+  (void)hipSetDevice(f->device);
+  (void)hipFree(f->block);
+  delete f;
+  return PLH_OK;
+}
+int plh_frame_points_count(const plh_frame_points* f) { return f ? f->n : 0; }
+
+plh_status plh_frame_lines_create(const plh_keyline* kl, const uint8_t* ldesc, const double* linefn, int nl, const plh_grid_params* gp,
+                                  int device, plh_frame_lines** out) {
+  if (!out || nl < 0 || !gp || (nl > 0 && (!kl || !ldesc || !linefn))) { set_error("plh_frame_lines_create: invalid argument"); return PLH_ERR_INVALID; }
+  if (nl > 8000) { set_error("plh_frame_lines_create: %d lines (the searches hold at most 8000 per frame)", nl); return PLH_ERR_CAPACITY; }
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  plh_frame_lines* f = new plh_frame_lines();
+  const size_t N = (size_t)std::max(nl, 1);
+  f->device = device; f->nl = nl; f->gp = *gp; f->itemCap = (int)N * PLH_GRID_COLS;
+  const size_t oK = 0, oD = Stager::padded(N * sizeof(plh_keyline)), oF = oD + Stager::padded(N * 32), oN = oF + Stager::padded(N * 24),
+               oS = oN + 256, oI = oS + Stager::padded((PLH_GRID_CELLS + 1) * 4), total = oI + Stager::padded((size_t)f->itemCap * 4);
+  if (hipMalloc((void**)&f->block, total) != hipSuccess) {
+    (void)hipGetLastError();
+    delete f;
+    set_error("plh_frame_lines_create: cannot allocate %zu bytes", total);
+    return PLH_ERR_ALLOC;
+  }
+  f->kl = (plh_keyline*)(f->block + oK); f->ldesc = f->block + oD; f->fn = (double*)(f->block + oF); f->dn = (int32_t*)(f->block + oN);
+  f->cellStart = (int32_t*)(f->block + oS); f->cellItems = (int32_t*)(f->block + oI);
+  hipStream_t s = st.stream();
+  const int32_t n32 = nl;
+  hipError_t e = hipMemcpyAsync(f->dn, &n32, 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && nl) e = hipMemcpyAsync(f->kl, kl, (size_t)nl * sizeof(plh_keyline), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && nl) e = hipMemcpyAsync(f->ldesc, ldesc, (size_t)nl * 32, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && nl) e = hipMemcpyAsync(f->fn, linefn, (size_t)nl * 24, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(f->cellStart, 0, (PLH_GRID_CELLS + 1) * 4, s);
+  if (e == hipSuccess) rc = plh_frame_assign_grid_lines_batch_dev(f->kl, f->dn, (int)N, 1, gp, f->cellStart, f->cellItems, f->itemCap, s);
+  if (e == hipSuccess && rc == PLH_OK) e = hipStreamSynchronize(s);
+  if (e != hipSuccess || rc != PLH_OK) {
+    if (e != hipSuccess) { set_error("plh_frame_lines_create: %s", hipGetErrorString(e)); rc = PLH_ERR_HIP; }
+    (void)hipFree(f->block);
+    delete f;
+    return rc;
+  }
+  *out = f;
+  return PLH_OK;
+}
+plh_status plh_frame_lines_destroy(plh_frame_lines* f) {
+  if (!f) return PLH_OK;
+  (void)hipSetDevice(f->device);
+  (void)hipFree(f->block);
+  delete f;
+  return PLH_OK;
+}
+int plh_frame_lines_count(const plh_frame_lines* f) { return f ? f->nl : 0; }
+
+static plh_status resident_proj_points(int variant, const plh_frame_points* f, const float* scale_factors, int nlevels, uint8_t* occupied,
+                                       int nq, const uint8_t* q_valid, const float* q_xy, const int32_t* q_level, const float* q_aux,
+                                       const uint8_t* q_desc, const uint8_t* q_hasobs, float th, float nnratio, int mode, int check_ori,
+                                       int32_t* assigned, int* nmatches, const char* who) {
+  if (!f || nq < 0 || !nmatches || !scale_factors || (f->n > 0 && (!occupied || !assigned)) ||
+      (nq > 0 && (!q_valid || !q_xy || !q_level || !q_aux || !q_desc || !q_hasobs)))
+    return PLH_ERR_INVALID;
+  const int n = f->n;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
+  *nmatches = 0;
+  if (n == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  Stager st;
+  plh_status rc = st.begin(f->device);
+  if (rc != PLH_OK) return rc;
+  uint8_t* docc = st.inout(occupied, (size_t)n);
+  int32_t* da = st.out(assigned, (size_t)n);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  const int32_t nq32 = nq;
+  const int32_t* dnq = st.in(&nq32, 1);
+  const uint8_t* qv = st.in(q_valid, (size_t)nq); const float* qx = st.in(q_xy, (size_t)nq * 2); const int32_t* ql = st.in(q_level, (size_t)nq);
+  const float* qa = st.in(q_aux, (size_t)nq); const uint8_t* qd = st.in(q_desc, (size_t)nq * 32); const uint8_t* qh = st.in(q_hasobs, (size_t)nq);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = launch_proj_points(variant, f->kps, f->desc, f->dn, n, 1, &f->gp, f->cellStart, f->cellItems, scale_factors, nlevels, docc, dnq, nq, qv,
+                          qx, ql, qa, qd, qh, th, nnratio, mode, check_ori, da, dc, st.stream(), who);
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
+  return PLH_OK;
+}
+plh_status plh_orb_search_by_projection_mp_resident(const plh_frame_points* f, const float* scale_factors, int nlevels, uint8_t* occupied,
+                                                    int nq, const uint8_t* q_valid, const float* q_xy, const int32_t* q_level,
+                                                    const float* q_viewcos, const uint8_t* q_desc, const uint8_t* q_hasobs, float th,
+                                                    float nnratio, int32_t* assigned, int* nmatches) {
+  return resident_proj_points(0, f, scale_factors, nlevels, occupied, nq, q_valid, q_xy, q_level, q_viewcos, q_desc, q_hasobs, th, nnratio,
+                              0, 0, assigned, nmatches, "plh_orb_search_by_projection_mp_resident");
+}
+plh_status plh_orb_search_by_projection_frame_resident(const plh_frame_points* f, const float* scale_factors, int nlevels,
+                                                       uint8_t* occupied, int nq, const uint8_t* q_valid, const float* q_uv,
+                                                       const int32_t* q_octave, const float* q_angle, const uint8_t* q_desc,
+                                                       const uint8_t* q_hasobs, float th, int mode, int check_ori, int32_t* assigned,
+                                                       int* nmatches) {
+  if (mode < 0 || mode > 2) return PLH_ERR_INVALID;
+  return resident_proj_points(1, f, scale_factors, nlevels, occupied, nq, q_valid, q_uv, q_octave, q_angle, q_desc, q_hasobs, th, 0.f, mode,
+                              check_ori, assigned, nmatches, "plh_orb_search_by_projection_frame_resident");
+}
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) on two resident frames.
+plh_status plh_orb_search_for_initialization_resident(const plh_frame_points* f1, const plh_frame_points* f2, float* prev_matched,
+                                                      int window_size, float nnratio, int check_ori, int32_t* matches12, int* nmatches) {
+  if (!f1 || !f2 || !nmatches || (f1->n > 0 && (!prev_matched || !matches12)) || f1->device != f2->device) return PLH_ERR_INVALID;
+  const int n1 = f1->n, n2 = f2->n;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  *nmatches = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  const int cap = std::max(n1, n2);
+  Stager st;
+  plh_status rc = st.begin(f1->device);
+  if (rc != PLH_OK) return rc;
+  float* dpm = st.inout(prev_matched, (size_t)n1 * 2, (size_t)cap * 2);
+  int32_t* dm = st.out(matches12, (size_t)n1, (size_t)cap);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_orb_search_for_initialization_batch_dev(f1->kps, f1->desc, f1->dn, f2->kps, f2->desc, f2->dn, cap, 1, &f2->gp, f2->cellStart,
+                                                   f2->cellItems, dpm, window_size, nnratio, check_ori, dm, dc, st.stream());
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
+  return PLH_OK;
+}
+
+static plh_status resident_proj_lines(int variant, const plh_frame_lines* f, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                      const float* q_seg, const float* q_aux, const uint8_t* q_desc, const uint8_t* q_hasobs, float th,
+                                      float nnratio, int32_t* assigned, int* nmatches, const char* who) {
+  if (!f || nq < 0 || !nmatches || (f->nl > 0 && (!occupied || !assigned)) || (nq > 0 && (!q_valid || !q_seg || !q_aux || !q_desc || !q_hasobs)))
+    return PLH_ERR_INVALID;
+  const int nl = f->nl;
+  for (int i = 0; i < nl; i++) assigned[i] = -1;
+  *nmatches = 0;
+  if (nl == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  Stager st;
+  plh_status rc = st.begin(f->device);
+  if (rc != PLH_OK) return rc;
+  uint8_t* docc = st.inout(occupied, (size_t)nl);
+  int32_t* da = st.out(assigned, (size_t)nl);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  const int32_t nq32 = nq;
+  const int32_t* dnq = st.in(&nq32, 1);
+  const uint8_t* qv = st.in(q_valid, (size_t)nq); const float* qs = st.in(q_seg, (size_t)nq * 4); const float* qa = st.in(q_aux, (size_t)nq);
+  const uint8_t* qd = st.in(q_desc, (size_t)nq * 32); const uint8_t* qh = st.in(q_hasobs, (size_t)nq);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = launch_proj_lines(variant, f->kl, f->ldesc, f->fn, f->dn, nl, 1, &f->gp, f->cellStart, f->cellItems, f->itemCap, docc, dnq, nq, qv, qs,
+                         qa, qd, qh, th, nnratio, da, dc, st.stream(), who);
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
+  return PLH_OK;
+}
+plh_status plh_line_search_by_projection_frame_resident(const plh_frame_lines* f, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                                        const float* q_seg, const float* q_length, const uint8_t* q_desc,
+                                                        const uint8_t* q_hasobs, float th, int32_t* assigned, int* nmatches) {
+  return resident_proj_lines(1, f, occupied, nq, q_valid, q_seg, q_length, q_desc, q_hasobs, th, 0.f, assigned, nmatches,
+                             "plh_line_search_by_projection_frame_resident");
+}
+plh_status plh_line_search_by_projection_ml_resident(const plh_frame_lines* f, uint8_t* occupied, int nq, const uint8_t* q_valid,
+                                                     const float* q_seg, const float* q_viewcos, const uint8_t* q_desc,
+                                                     const uint8_t* q_hasobs, float th, float nnratio, int32_t* assigned, int* nmatches) {
+  return resident_proj_lines(0, f, occupied, nq, q_valid, q_seg, q_viewcos, q_desc, q_hasobs, th, nnratio, assigned, nmatches,
+                             "plh_line_search_by_projection_ml_resident");
 }
 
 }  // extern "C"

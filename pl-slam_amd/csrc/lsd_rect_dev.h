@@ -13,10 +13,18 @@ struct alignas(16) D2 {
   double x, y;
 };
 
+// angle_diff_signed() of lsd.cpp: `a -= b; while (a <= -pi) a += 2 pi; while (a > pi) a -= 2 pi;`.  Every caller in the kernels
+// hands in two angles of [0, 3 pi] (level-line angles, region angles, theta + pi), so |a - b| <= 3 pi and each loop body runs at
+// most twice: the loops are written as that many conditional steps -- the same additions in the same order, selects instead of
+// EXEC-masked loops.  (Round 6: a data-dependent loop here put a divergent join block right in front of the out-of-line sincos call of
+// region2rect(), and ROCm 7.2's register allocator placed the copies that save caller-saved registers around that call IN FRONT of the
+// join block's EXEC restore -- profiles/r06_prof_build_mw16_fault_root_cause.txt; tools/isa_exec_split_check.py watches for the shape.)
 __device__ __forceinline__ double angle_diff_signed(double a, double b) {
   double diff = a - b;
-  while (diff <= -kPI) diff += k2PI;
-  while (diff > kPI) diff -= k2PI;
+  diff = (diff <= -kPI) ? diff + k2PI : diff;
+  diff = (diff <= -kPI) ? diff + k2PI : diff;
+  diff = (diff > kPI) ? diff - k2PI : diff;
+  diff = (diff > kPI) ? diff - k2PI : diff;
   return diff;
 }
 

@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "plh_common.h"
+#include "plh_stage.h"
+#include "frame_resident.h"
 
 namespace plh {
 
@@ -522,23 +524,17 @@ plh_status plh_hamming_knn2_dev(const uint8_t* d_q, int nq, const uint8_t* d_t, 
 plh_status plh_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist, int device) {
   if (nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) return PLH_ERR_INVALID;
   if (nq == 0) return PLH_OK;
-  PLH_HIP(hipSetDevice(device));
-  uint8_t *dq = nullptr, *dt = nullptr;
-  int32_t *di = nullptr, *dd = nullptr;
-  PLH_HIP(hipMalloc((void**)&dq, (size_t)nq * 32));
-  PLH_HIP(hipMalloc((void**)&dt, (size_t)std::max(nt, 1) * 32));
-  PLH_HIP(hipMalloc((void**)&di, (size_t)nq * 8));
-  PLH_HIP(hipMalloc((void**)&dd, (size_t)nq * 8));
-  PLH_HIP(hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice));
-  if (nt) PLH_HIP(hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice));
-  plh_status st = plh_hamming_knn2_dev(dq, nq, dt, nt, di, dd, nullptr);
-  if (st == PLH_OK) {
-    PLH_HIP(hipDeviceSynchronize());
-    PLH_HIP(hipMemcpy(idx, di, (size_t)nq * 8, hipMemcpyDeviceToHost));
-    PLH_HIP(hipMemcpy(dist, dd, (size_t)nq * 8, hipMemcpyDeviceToHost));
-  }
-  (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(di); (void)hipFree(dd);
-  return st;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  const uint8_t* dq = st.in(q, (size_t)nq * 32);
+  const uint8_t* dt = nt ? st.in(t, (size_t)nt * 32) : st.scratch<uint8_t>(32);
+  int32_t* di = st.out(idx, (size_t)nq * 2);
+  int32_t* dd = st.out(dist, (size_t)nq * 2);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  if ((rc = plh_hamming_knn2_dev(dq, nq, dt, nt, di, dd, st.stream())) != PLH_OK) return rc;
+  return st.download();
 }
 
 plh_status plh_line_bfmatch_batch_dev(const int32_t* d_idx, const int32_t* d_dist, const int32_t* d_nq, const int32_t* d_nt,
@@ -673,17 +669,8 @@ plh_status plh_orb_search_for_triangulation_batch_dev(const plh_keypoint* d_kps1
   return PLH_OK;
 }
 
-// ---- host-buffer conveniences (one call = one reference call; stage over PCIe, block until done) ----
-extern "C++" {
-namespace {
-struct DevBuf {   // RAII device allocation
-  void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
-  template <typename T> T* as() { return reinterpret_cast<T*>(p); }
-};
-}  // namespace
-}  // extern "C++"
+// ---- host-buffer conveniences: one call = one reference call.  The arrays go through the calling thread's staging arena
+// (plh_stage.h: one packed copy up, the thread's own stream, one copy back) ----
 
 // LSDmatcher::SearchDouble(Frame&, Frame&, vector<int>&) on two mLdesc matrices (LSDmatcher.cpp:427-460).
 plh_status plh_line_search_double(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, float th, float nnratio,
@@ -693,22 +680,24 @@ plh_status plh_line_search_double(const uint8_t* ldesc1, int n1, const uint8_t* 
   *nmatches = 0;
   if (n1 == 0 || n2 == 0) return PLH_OK;   // reference: `if(ldesc1.rows == 0 || ldesc2.rows == 0) return 0;`
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
   const int cap = std::max(n1, n2);
-  DevBuf d1, d2, dn, dm, dc, ws;
   const size_t wsb = plh_line_search_double_workspace(cap, 1);
-  PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(dn.alloc(8));
-  PLH_HIP(dm.alloc((size_t)cap * 4)); PLH_HIP(dc.alloc(4)); PLH_HIP(ws.alloc(wsb));
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  const uint8_t* d1 = st.in(ldesc1, (size_t)n1 * 32);
+  const uint8_t* d2 = st.in(ldesc2, (size_t)n2 * 32);
   const int32_t ns[2] = {n1, n2};
-  PLH_HIP(hipMemcpy(d1.p, ldesc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(d2.p, ldesc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
-  plh_status st = plh_line_search_double_batch_dev(d1.as<uint8_t>(), dn.as<int32_t>(), d2.as<uint8_t>(), dn.as<int32_t>() + 1, cap, 1,
-                                                   th, nnratio, dm.as<int32_t>(), dc.as<int32_t>(), ws.p, wsb, nullptr);
-  if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(matches12, dm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc.p, 4, hipMemcpyDeviceToHost));
+  const int32_t* dn = st.in(ns, 2);
+  int32_t* dm = st.out(matches12, (size_t)n1, (size_t)cap);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  void* ws = st.scratch<uint8_t>(wsb);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_line_search_double_batch_dev(d1, dn, d2, dn + 1, cap, 1, th, nnratio, dm, dc, ws, wsb, st.stream());
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
   return PLH_OK;
 }
 
@@ -722,28 +711,23 @@ plh_status plh_orb_search_by_bow(const uint8_t* desc1, const float* angle1, cons
   if (n1 == 0 || n2 == 0) return PLH_OK;
   if (!desc1 || !angle1 || !node1 || !valid1 || !desc2 || !angle2 || !node2) return PLH_ERR_INVALID;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
   const int cap = std::max(n1, n2);
-  DevBuf d1, a1, k1, v1, d2, a2, k2, dn, dm, dc;
-  PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(a1.alloc((size_t)cap * 4)); PLH_HIP(k1.alloc((size_t)cap * 4)); PLH_HIP(v1.alloc(cap));
-  PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(a2.alloc((size_t)cap * 4)); PLH_HIP(k2.alloc((size_t)cap * 4));
-  PLH_HIP(dn.alloc(8)); PLH_HIP(dm.alloc((size_t)cap * 4)); PLH_HIP(dc.alloc(4));
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  const uint8_t* d1 = st.in(desc1, (size_t)n1 * 32); const float* a1 = st.in(angle1, (size_t)n1); const int32_t* k1 = st.in(node1, (size_t)n1);
+  const uint8_t* v1 = st.in(valid1, (size_t)n1);
+  const uint8_t* d2 = st.in(desc2, (size_t)n2 * 32); const float* a2 = st.in(angle2, (size_t)n2); const int32_t* k2 = st.in(node2, (size_t)n2);
   const int32_t ns[2] = {n1, n2};
-  PLH_HIP(hipMemcpy(d1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(a1.p, angle1, (size_t)n1 * 4, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(k1.p, node1, (size_t)n1 * 4, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(v1.p, valid1, (size_t)n1, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(d2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(a2.p, angle2, (size_t)n2 * 4, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(k2.p, node2, (size_t)n2 * 4, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
-  plh_status st = plh_orb_search_by_bow_batch_dev(d1.as<uint8_t>(), a1.as<float>(), k1.as<int32_t>(), v1.as<uint8_t>(), dn.as<int32_t>(),
-                                                  d2.as<uint8_t>(), a2.as<float>(), k2.as<int32_t>(), dn.as<int32_t>() + 1, cap, 1, th_low,
-                                                  nnratio, check_ori, dm.as<int32_t>(), dc.as<int32_t>(), nullptr);
-  if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(matches21, dm.p, (size_t)n2 * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc.p, 4, hipMemcpyDeviceToHost));
+  const int32_t* dn = st.in(ns, 2);
+  int32_t* dm = st.out(matches21, (size_t)n2, (size_t)cap);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_orb_search_by_bow_batch_dev(d1, a1, k1, v1, dn, d2, a2, k2, dn + 1, cap, 1, th_low, nnratio, check_ori, dm, dc, st.stream());
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
   return PLH_OK;
 }
 
@@ -760,30 +744,24 @@ plh_status plh_orb_search_by_bow_kfkf(const plh_keypoint* kps1, const uint8_t* d
   if (n1 == 0 || n2 == 0) return PLH_OK;
   if (!kps1 || !desc1 || !node1 || !valid1 || !kps2 || !desc2 || !node2 || !valid2) return PLH_ERR_INVALID;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
   const int cap = std::max(n1, n2);
-  DevBuf k1, d1, o1, v1, k2, d2, o2, v2, dn, dm, dc;
-  PLH_HIP(k1.alloc((size_t)cap * sizeof(plh_keypoint))); PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(o1.alloc((size_t)cap * 4)); PLH_HIP(v1.alloc(cap));
-  PLH_HIP(k2.alloc((size_t)cap * sizeof(plh_keypoint))); PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(o2.alloc((size_t)cap * 4)); PLH_HIP(v2.alloc(cap));
-  PLH_HIP(dn.alloc(8)); PLH_HIP(dm.alloc((size_t)cap * 4)); PLH_HIP(dc.alloc(4));
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  const plh_keypoint* k1 = st.in(kps1, (size_t)n1); const uint8_t* d1 = st.in(desc1, (size_t)n1 * 32); const int32_t* o1 = st.in(node1, (size_t)n1);
+  const uint8_t* v1 = st.in(valid1, (size_t)n1);
+  const plh_keypoint* k2 = st.in(kps2, (size_t)n2); const uint8_t* d2 = st.in(desc2, (size_t)n2 * 32); const int32_t* o2 = st.in(node2, (size_t)n2);
+  const uint8_t* v2 = st.in(valid2, (size_t)n2);
   const int32_t ns[2] = {n1, n2};
-  PLH_HIP(hipMemcpy(k1.p, kps1, (size_t)n1 * sizeof(plh_keypoint), hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(d1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(o1.p, node1, (size_t)n1 * 4, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(v1.p, valid1, (size_t)n1, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(k2.p, kps2, (size_t)n2 * sizeof(plh_keypoint), hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(d2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(o2.p, node2, (size_t)n2 * 4, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(v2.p, valid2, (size_t)n2, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
-  plh_status st = plh_orb_search_by_bow_kfkf_batch_dev(d1.as<uint8_t>(), k1.as<plh_keypoint>(), o1.as<int32_t>(), v1.as<uint8_t>(),
-                                                       dn.as<int32_t>(), d2.as<uint8_t>(), k2.as<plh_keypoint>(), o2.as<int32_t>(),
-                                                       v2.as<uint8_t>(), dn.as<int32_t>() + 1, cap, 1, th_low, nnratio, check_ori,
-                                                       dm.as<int32_t>(), dc.as<int32_t>(), nullptr);
-  if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(matches12, dm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc.p, 4, hipMemcpyDeviceToHost));
+  const int32_t* dn = st.in(ns, 2);
+  int32_t* dm = st.out(matches12, (size_t)n1, (size_t)cap);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_orb_search_by_bow_kfkf_batch_dev(d1, k1, o1, v1, dn, d2, k2, o2, v2, dn + 1, cap, 1, th_low, nnratio, check_ori, dm, dc, st.stream());
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
   return PLH_OK;
 }
 
@@ -794,24 +772,22 @@ plh_status plh_line_frame_bfmatch(const uint8_t* ldesc1, int n1, const uint8_t* 
   for (int i = 0; i < n1; i++) matches12[i] = -1;
   if (n1 == 0 || n2 == 0) return PLH_OK;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
   const int cap = std::max(n1, n2);
-  DevBuf d1, d2, dn, di, dd, dm;
-  PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(dn.alloc(8));
-  PLH_HIP(di.alloc((size_t)cap * 8)); PLH_HIP(dd.alloc((size_t)cap * 8)); PLH_HIP(dm.alloc((size_t)cap * 4));
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  const uint8_t* d1 = st.in(ldesc1, (size_t)n1 * 32);
+  const uint8_t* d2 = st.in(ldesc2, (size_t)n2 * 32);
   const int32_t ns[2] = {n1, n2};
-  PLH_HIP(hipMemcpy(d1.p, ldesc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(d2.p, ldesc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
-  plh_status st = plh_hamming_knn2_batch_dev(d1.as<uint8_t>(), dn.as<int32_t>(), cap, d2.as<uint8_t>(), dn.as<int32_t>() + 1, cap, 1,
-                                             di.as<int32_t>(), dd.as<int32_t>(), nullptr);
-  if (st == PLH_OK)
-    st = plh_line_bfmatch_batch_dev(di.as<int32_t>(), dd.as<int32_t>(), dn.as<int32_t>(), dn.as<int32_t>() + 1, cap, 1, th, nnratio,
-                                    dm.as<int32_t>(), nullptr);
-  if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(matches12, dm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-  return PLH_OK;
+  const int32_t* dn = st.in(ns, 2);
+  int32_t* di = st.scratch<int32_t>((size_t)cap * 2);
+  int32_t* dd = st.scratch<int32_t>((size_t)cap * 2);
+  int32_t* dm = st.out(matches12, (size_t)n1, (size_t)cap);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_hamming_knn2_batch_dev(d1, dn, cap, d2, dn + 1, cap, 1, di, dd, st.stream());
+  if (rc == PLH_OK) rc = plh_line_bfmatch_batch_dev(di, dd, dn, dn + 1, cap, 1, th, nnratio, dm, st.stream());
+  if (rc != PLH_OK) return rc;
+  return st.download();
 }
 
 // ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) on host buffers: see
@@ -828,30 +804,79 @@ plh_status plh_orb_search_for_triangulation(const plh_keypoint* kps1, const uint
   if (!kps1 || !desc1 || !node1 || !has_mp1 || !kps2 || !desc2 || !node2 || !has_mp2 || !F12 || !scale_factors2 || !level_sigma2_2)
     return PLH_ERR_INVALID;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  PLH_HIP(hipSetDevice(device));
   const int cap = std::max(n1, n2);
-  DevBuf k1, d1, o1, v1, k2, d2, o2, v2, dn, dm, dc;
-  PLH_HIP(k1.alloc((size_t)cap * sizeof(plh_keypoint))); PLH_HIP(d1.alloc((size_t)cap * 32)); PLH_HIP(o1.alloc((size_t)cap * 4)); PLH_HIP(v1.alloc(cap));
-  PLH_HIP(k2.alloc((size_t)cap * sizeof(plh_keypoint))); PLH_HIP(d2.alloc((size_t)cap * 32)); PLH_HIP(o2.alloc((size_t)cap * 4)); PLH_HIP(v2.alloc(cap));
-  PLH_HIP(dn.alloc(8)); PLH_HIP(dm.alloc((size_t)cap * 4)); PLH_HIP(dc.alloc(4));
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  const plh_keypoint* k1 = st.in(kps1, (size_t)n1); const uint8_t* d1 = st.in(desc1, (size_t)n1 * 32); const int32_t* o1 = st.in(node1, (size_t)n1);
+  const uint8_t* v1 = st.in(has_mp1, (size_t)n1);
+  const plh_keypoint* k2 = st.in(kps2, (size_t)n2); const uint8_t* d2 = st.in(desc2, (size_t)n2 * 32); const int32_t* o2 = st.in(node2, (size_t)n2);
+  const uint8_t* v2 = st.in(has_mp2, (size_t)n2);
   const int32_t ns[2] = {n1, n2};
-  PLH_HIP(hipMemcpy(k1.p, kps1, (size_t)n1 * sizeof(plh_keypoint), hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(d1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(o1.p, node1, (size_t)n1 * 4, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(v1.p, has_mp1, (size_t)n1, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(k2.p, kps2, (size_t)n2 * sizeof(plh_keypoint), hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(d2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(o2.p, node2, (size_t)n2 * 4, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(v2.p, has_mp2, (size_t)n2, hipMemcpyHostToDevice));
-  PLH_HIP(hipMemcpy(dn.p, ns, 8, hipMemcpyHostToDevice));
-  plh_status st = plh_orb_search_for_triangulation_batch_dev(
-      k1.as<plh_keypoint>(), d1.as<uint8_t>(), o1.as<int32_t>(), v1.as<uint8_t>(), dn.as<int32_t>(), k2.as<plh_keypoint>(), d2.as<uint8_t>(),
-      o2.as<int32_t>(), v2.as<uint8_t>(), dn.as<int32_t>() + 1, cap, 1, F12, ex, ey, scale_factors2, level_sigma2_2, nlevels, th_low,
-      check_ori, dm.as<int32_t>(), dc.as<int32_t>(), nullptr);
-  if (st != PLH_OK) return st;
-  PLH_HIP(hipDeviceSynchronize());
-  PLH_HIP(hipMemcpy(matches12, dm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-  PLH_HIP(hipMemcpy(nmatches, dc.p, 4, hipMemcpyDeviceToHost));
+  const int32_t* dn = st.in(ns, 2);
+  int32_t* dm = st.out(matches12, (size_t)n1, (size_t)cap);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_orb_search_for_triangulation_batch_dev(k1, d1, o1, v1, dn, k2, d2, o2, v2, dn + 1, cap, 1, F12, ex, ey, scale_factors2,
+                                                  level_sigma2_2, nlevels, th_low, check_ori, dm, dc, st.stream());
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
+  return PLH_OK;
+}
+
+// ---- resident frames (frame_resident.h): the two-frame matchers of the tracking path on frames that already lie on the device ----
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) (ORBmatcher.cc:187-327): kf / f carry their FeatureVector
+// nodes (plh_frame_points_set_nodes); valid1[i] = the KeyFrame's feature i holds a non-bad MapPoint.
+plh_status plh_orb_search_by_bow_resident(const plh_frame_points* kf, const uint8_t* valid1, const plh_frame_points* f, int th_low,
+                                          float nnratio, int check_ori, int32_t* matches21, int* nmatches) {
+  if (!kf || !f || !nmatches || (f->n > 0 && !matches21) || kf->device != f->device) return PLH_ERR_INVALID;
+  const int n1 = kf->n, n2 = f->n;
+  for (int j = 0; j < n2; j++) matches21[j] = -1;
+  *nmatches = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (!valid1 || !kf->hasNodes || !f->hasNodes) { set_error("plh_orb_search_by_bow_resident: a frame has no FeatureVector nodes (plh_frame_points_set_nodes)"); return PLH_ERR_INVALID; }
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  const int cap = std::max(n1, n2);
+  Stager st;
+  plh_status rc = st.begin(f->device);
+  if (rc != PLH_OK) return rc;
+  const uint8_t* v1 = st.in(valid1, (size_t)n1);
+  int32_t* dm = st.out(matches21, (size_t)n2, (size_t)cap);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_orb_search_by_bow_kp_batch_dev(kf->desc, kf->kps, kf->node, v1, kf->dn, f->desc, f->kps, f->node, f->dn, cap, 1, th_low, nnratio,
+                                          check_ori, dm, dc, st.stream());
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
+  return PLH_OK;
+}
+// LSDmatcher::SearchDouble(Frame&, Frame&, LineMatches) / (KeyFrame*, Frame&) (LSDmatcher.cpp:375-460) on two resident line sets.
+plh_status plh_line_search_double_resident(const plh_frame_lines* l1, const plh_frame_lines* l2, float th, float nnratio, int32_t* matches12,
+                                           int* nmatches) {
+  if (!l1 || !l2 || !nmatches || (l1->nl > 0 && !matches12) || l1->device != l2->device) return PLH_ERR_INVALID;
+  const int n1 = l1->nl, n2 = l2->nl;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  *nmatches = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  const int cap = std::max(n1, n2);
+  const size_t wsb = plh_line_search_double_workspace(cap, 1);
+  Stager st;
+  plh_status rc = st.begin(l1->device);
+  if (rc != PLH_OK) return rc;
+  int32_t* dm = st.out(matches12, (size_t)n1, (size_t)cap);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  void* ws = st.scratch<uint8_t>(wsb);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_line_search_double_batch_dev(l1->ldesc, l1->dn, l2->ldesc, l2->dn, cap, 1, th, nnratio, dm, dc, ws, wsb, st.stream());
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
   return PLH_OK;
 }
 

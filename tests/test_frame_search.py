@@ -431,53 +431,152 @@ def test_gpu_large_local_map(plslam, oracle, synth):
     _large_local_map(plslam, oracle, synth, None, nq_total=20000, n=2000)
 
 
-@pytest.mark.gpu
-def test_gpu_host_buffer_forms(plslam, oracle, synth):
-    """The one-call-per-reference-call entry points (host buffers, grid rebuilt inside) agree with the oracle."""
-    P, O, S, L = plslam, oracle, synth, _olib(oracle)
-    H = P.load()
+def _host_buffer_forms(P, O, S, lib, n=1500, nl=180):
+    """The one-call-per-reference-call entry points (host buffers through the calling thread's staging arena, grid rebuilt inside)
+    agree with the oracle -- and so do the RESIDENT forms (round 6: plh_frame_points / plh_frame_lines hold keypoints, descriptors
+    and grid on the device; a search uploads its queries only), called twice on the same handles."""
+    L = _olib(O)
+    H = P.load(lib)
     gp = _gp(P)
     g = _gpa(P, gp)
-    f1, f2, _, _ = make_frame_pair(P, S, 51, 1500, nl=180)
+    f1, f2, _, _ = make_frame_pair(P, S, 51, n, nl=nl)
     (cs, ci), (lcs, lci) = _oracle_grids(O, P, f2, gp)
     n1, n2, nl = len(f1["kps"]), len(f2["kps"]), len(f2["keylines"])
     p = P._p
+    # resident handles of both frames
+    H.plh_frame_points_create.argtypes = [V, V, I, V, I, V]
+    H.plh_frame_lines_create.argtypes = [V, V, V, I, V, I, V]
+    H.plh_frame_points_destroy.argtypes = [V]
+    H.plh_frame_lines_destroy.argtypes = [V]
+    H.plh_frame_points_count.argtypes = [V]
+    R1, R2, RL2, RL1 = V(), V(), V(), V()
+    P._check(H, H.plh_frame_points_create(p(f1["kps"]), p(f1["desc"]), n1, C.byref(gp), 0, C.byref(R1)), "resident points 1")
+    P._check(H, H.plh_frame_points_create(p(f2["kps"]), p(f2["desc"]), n2, C.byref(gp), 0, C.byref(R2)), "resident points 2")
+    P._check(H, H.plh_frame_lines_create(p(f2["keylines"]), p(f2["ldesc"]), p(f2["linefn"]), nl, C.byref(gp), 0, C.byref(RL2)), "resident lines 2")
+    P._check(H, H.plh_frame_lines_create(p(f1["keylines"]), p(f1["ldesc"]), p(f1["linefn"]), len(f1["keylines"]), C.byref(gp), 0, C.byref(RL1)),
+             "resident lines 1")
+    assert H.plh_frame_points_count(R2) == n2
+    cnt = C.c_int(0)
     # SearchForInitialization
     prev = np.stack([f1["kps"]["x"], f1["kps"]["y"]], 1).astype(np.float32)
     rp, ref = prev.copy(), np.zeros(n1, np.int32)
     rc = L.plo_orb_search_for_initialization(O._p(f1["kps"]), O._p(f1["desc"]), n1, O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g),
                                              O._p(cs), O._p(ci), O._p(rp), 100, 0.9, 1, O._p(ref))
     H.plh_orb_search_for_initialization.argtypes = [V, V, I, V, V, I, V, V, I, F, I, V, V, I]
-    got, cnt = np.zeros(n1, np.int32), C.c_int(0)
-    P._check(H, H.plh_orb_search_for_initialization(p(f1["kps"]), p(f1["desc"]), n1, p(f2["kps"]), p(f2["desc"]), n2, C.byref(gp),
-                                                    p(prev), 100, 0.9, 1, p(got), C.byref(cnt), 0), "init")
-    assert cnt.value == rc and (got == ref).all() and (prev == rp).all() and rc > 100
+    H.plh_orb_search_for_initialization_resident.argtypes = [V, V, V, I, F, I, V, V]
+    for form in ("host", "resident", "resident"):
+        got, pm = np.full(n1, 7, np.int32), prev.copy()
+        if form == "host":
+            P._check(H, H.plh_orb_search_for_initialization(p(f1["kps"]), p(f1["desc"]), n1, p(f2["kps"]), p(f2["desc"]), n2, C.byref(gp),
+                                                            p(pm), 100, 0.9, 1, p(got), C.byref(cnt), 0), "init")
+        else:
+            P._check(H, H.plh_orb_search_for_initialization_resident(R1, R2, p(pm), 100, 0.9, 1, p(got), C.byref(cnt)), "init resident")
+        assert cnt.value == rc and (got == ref).all() and (pm == rp).all() and rc > n // 15, form
     # ORB SearchByProjection(Cur, Last)
     q = _queries_points(P, S, 901, f1, f2, "frame")
-    occ = np.zeros(n2, np.uint8)
-    ro, ra = occ.copy(), np.zeros(n2, np.int32)
+    ro, ra = np.zeros(n2, np.uint8), np.zeros(n2, np.int32)
     rc = L.plo_orb_search_by_projection_frame(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(cs), O._p(ci), O._p(SCALE), O._p(ro),
                                               n1, O._p(q["valid"]), O._p(q["uv"]), O._p(q["octave"]), O._p(q["angle"]), O._p(q["desc"]),
                                               O._p(q["hasobs"]), 15.0, 0, 1, O._p(ra))
     H.plh_orb_search_by_projection_frame.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, F, I, I, V, V, I]
-    got = np.zeros(n2, np.int32)
-    P._check(H, H.plh_orb_search_by_projection_frame(p(f2["kps"]), p(f2["desc"]), n2, C.byref(gp), p(SCALE), len(SCALE), p(occ), n1,
-                                                     p(q["valid"]), p(q["uv"]), p(q["octave"]), p(q["angle"]), p(q["desc"]),
-                                                     p(q["hasobs"]), 15.0, 0, 1, p(got), C.byref(cnt), 0), "proj frame")
-    assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > 300
-    # LSD SearchByProjection(F, MapLines)
-    q = _queries_lines(P, S, 951, f1, "ml")
-    occ = np.zeros(nl, np.uint8)
-    ro, ra = occ.copy(), np.zeros(nl, np.int32)
-    rc = L.plo_line_search_by_projection_ml(O._p(f2["keylines"]), O._p(f2["ldesc"]), O._p(f2["linefn"]), nl, O._p(g), O._p(lcs), O._p(lci),
-                                            O._p(ro), len(q["valid"]), O._p(q["valid"]), O._p(q["seg"]), O._p(q["viewcos"]),
-                                            O._p(q["desc"]), O._p(q["hasobs"]), 3.0, 0.9, O._p(ra))
+    H.plh_orb_search_by_projection_frame_resident.argtypes = [V, V, I, V, I, V, V, V, V, V, V, F, I, I, V, V]
+    for form in ("host", "resident", "resident"):
+        got, occ = np.full(n2, 7, np.int32), np.zeros(n2, np.uint8)
+        if form == "host":
+            P._check(H, H.plh_orb_search_by_projection_frame(p(f2["kps"]), p(f2["desc"]), n2, C.byref(gp), p(SCALE), len(SCALE), p(occ), n1,
+                                                             p(q["valid"]), p(q["uv"]), p(q["octave"]), p(q["angle"]), p(q["desc"]),
+                                                             p(q["hasobs"]), 15.0, 0, 1, p(got), C.byref(cnt), 0), "proj frame")
+        else:
+            P._check(H, H.plh_orb_search_by_projection_frame_resident(R2, p(SCALE), len(SCALE), p(occ), n1, p(q["valid"]), p(q["uv"]),
+                                                                      p(q["octave"]), p(q["angle"]), p(q["desc"]), p(q["hasobs"]), 15.0, 0, 1,
+                                                                      p(got), C.byref(cnt)), "proj frame resident")
+        assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > n // 5, form
+    # ORB SearchByProjection(F, MapPoints)
+    q = _queries_points(P, S, 903, f1, f2, "mp")
+    occ0 = (S.SplitMix64(6).uniform(n2) < 0.1).astype(np.uint8)
+    ro, ra = occ0.copy(), np.zeros(n2, np.int32)
+    rc = L.plo_orb_search_by_projection_mp(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(cs), O._p(ci), O._p(SCALE), O._p(ro), n1,
+                                           O._p(q["valid"]), O._p(q["xy"]), O._p(q["level"]), O._p(q["viewcos"]), O._p(q["desc"]),
+                                           O._p(q["hasobs"]), 3.0, 0.8, O._p(ra))
+    H.plh_orb_search_by_projection_mp.argtypes = [V, V, I, V, V, I, V, I, V, V, V, V, V, V, F, F, V, V, I]
+    H.plh_orb_search_by_projection_mp_resident.argtypes = [V, V, I, V, I, V, V, V, V, V, V, F, F, V, V]
+    for form in ("host", "resident"):
+        got, occ = np.full(n2, 7, np.int32), occ0.copy()
+        if form == "host":
+            P._check(H, H.plh_orb_search_by_projection_mp(p(f2["kps"]), p(f2["desc"]), n2, C.byref(gp), p(SCALE), len(SCALE), p(occ), n1,
+                                                          p(q["valid"]), p(q["xy"]), p(q["level"]), p(q["viewcos"]), p(q["desc"]), p(q["hasobs"]),
+                                                          3.0, 0.8, p(got), C.byref(cnt), 0), "proj mp")
+        else:
+            P._check(H, H.plh_orb_search_by_projection_mp_resident(R2, p(SCALE), len(SCALE), p(occ), n1, p(q["valid"]), p(q["xy"]), p(q["level"]),
+                                                                   p(q["viewcos"]), p(q["desc"]), p(q["hasobs"]), 3.0, 0.8, p(got),
+                                                                   C.byref(cnt)), "proj mp resident")
+        assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > n // 10, form
+    # LSD SearchByProjection(F, MapLines) and (Cur, Last)
     H.plh_line_search_by_projection_ml.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, F, F, V, V, I]
-    got = np.zeros(nl, np.int32)
-    P._check(H, H.plh_line_search_by_projection_ml(p(f2["keylines"]), p(f2["ldesc"]), p(f2["linefn"]), nl, C.byref(gp), p(occ),
-                                                   len(q["valid"]), p(q["valid"]), p(q["seg"]), p(q["viewcos"]), p(q["desc"]),
-                                                   p(q["hasobs"]), 3.0, 0.9, p(got), C.byref(cnt), 0), "line ml")
-    assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > 30
+    H.plh_line_search_by_projection_ml_resident.argtypes = [V, V, I, V, V, V, V, V, F, F, V, V]
+    H.plh_line_search_by_projection_frame.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, F, V, V, I]
+    H.plh_line_search_by_projection_frame_resident.argtypes = [V, V, I, V, V, V, V, V, F, V, V]
+    for variant in ("ml", "frame"):
+        q = _queries_lines(P, S, 951, f1, variant)
+        aux = q["viewcos"] if variant == "ml" else q["length"]
+        ro, ra = np.zeros(nl, np.uint8), np.zeros(nl, np.int32)
+        if variant == "ml":
+            rc = L.plo_line_search_by_projection_ml(O._p(f2["keylines"]), O._p(f2["ldesc"]), O._p(f2["linefn"]), nl, O._p(g), O._p(lcs),
+                                                    O._p(lci), O._p(ro), len(q["valid"]), O._p(q["valid"]), O._p(q["seg"]), O._p(aux),
+                                                    O._p(q["desc"]), O._p(q["hasobs"]), 3.0, 0.9, O._p(ra))
+        else:
+            rc = L.plo_line_search_by_projection_frame(O._p(f2["keylines"]), O._p(f2["ldesc"]), O._p(f2["linefn"]), nl, O._p(g), O._p(lcs),
+                                                       O._p(lci), O._p(ro), len(q["valid"]), O._p(q["valid"]), O._p(q["seg"]), O._p(aux),
+                                                       O._p(q["desc"]), O._p(q["hasobs"]), 12.0, O._p(ra))
+        for form in ("host", "resident", "resident"):
+            got, occ = np.full(nl, 7, np.int32), np.zeros(nl, np.uint8)
+            a = (p(f2["keylines"]), p(f2["ldesc"]), p(f2["linefn"]), nl, C.byref(gp)) if form == "host" else (RL2,)
+            qa = (p(occ), len(q["valid"]), p(q["valid"]), p(q["seg"]), p(aux), p(q["desc"]), p(q["hasobs"]))
+            if variant == "ml":
+                fn = H.plh_line_search_by_projection_ml if form == "host" else H.plh_line_search_by_projection_ml_resident
+                P._check(H, fn(*a, *qa, 3.0, 0.9, p(got), C.byref(cnt), *((0,) if form == "host" else ())), "line ml " + form)
+            else:
+                fn = H.plh_line_search_by_projection_frame if form == "host" else H.plh_line_search_by_projection_frame_resident
+                P._check(H, fn(*a, *qa, 12.0, p(got), C.byref(cnt), *((0,) if form == "host" else ())), "line frame " + form)
+            assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > nl // 8, (variant, form)
+    # LSDmatcher::SearchDouble: resident == host form (the host form is held to the reference by tests/test_ref_lsdmatcher.py)
+    H.plh_line_search_double.argtypes = [V, I, V, I, F, F, V, V, I]
+    H.plh_line_search_double_resident.argtypes = [V, V, F, F, V, V]
+    nl1 = len(f1["keylines"])
+    mh, mr, ch, cr = np.zeros(max(nl1, 1), np.int32), np.full(max(nl1, 1), 7, np.int32), C.c_int(0), C.c_int(0)
+    P._check(H, H.plh_line_search_double(p(f1["ldesc"]), nl1, p(f2["ldesc"]), nl, 50.0, 0.7, p(mh), C.byref(ch), 0), "search double")
+    P._check(H, H.plh_line_search_double_resident(RL1, RL2, 50.0, 0.7, p(mr), C.byref(cr)), "search double resident")
+    assert ch.value == cr.value and (mh[:nl1] == mr[:nl1]).all() and ch.value > nl // 8
+    # ORBmatcher::SearchByBoW(KF, F): resident == host form (held to the reference by tests/test_ref_orbmatcher.py)
+    rng = S.SplitMix64(77)
+    node1 = rng.randint(n1, 0, 60).astype(np.int32)
+    node2 = rng.randint(n2, 0, 60).astype(np.int32)
+    node2[rng.uniform(n2) < 0.05] = -1
+    valid1 = (rng.uniform(n1) < 0.8).astype(np.uint8)
+    H.plh_frame_points_set_nodes.argtypes = [V, V]
+    P._check(H, H.plh_frame_points_set_nodes(R1, p(node1)), "set nodes 1")
+    P._check(H, H.plh_frame_points_set_nodes(R2, p(node2)), "set nodes 2")
+    H.plh_orb_search_by_bow.argtypes = [V, V, V, V, I, V, V, V, I, I, F, I, V, V, I]
+    H.plh_orb_search_by_bow_resident.argtypes = [V, V, V, I, F, I, V, V]
+    a1, a2 = np.ascontiguousarray(f1["kps"]["angle"]), np.ascontiguousarray(f2["kps"]["angle"])
+    mh, mr = np.zeros(n2, np.int32), np.full(n2, 7, np.int32)
+    P._check(H, H.plh_orb_search_by_bow(p(f1["desc"]), p(a1), p(node1), p(valid1), n1, p(f2["desc"]), p(a2), p(node2), n2, 50, 0.7, 1, p(mh),
+                                        C.byref(ch), 0), "bow")
+    P._check(H, H.plh_orb_search_by_bow_resident(R1, p(valid1), R2, 50, 0.7, 1, p(mr), C.byref(cr)), "bow resident")
+    assert ch.value == cr.value and (mh == mr).all()
+    for h in (R1, R2):
+        H.plh_frame_points_destroy(h)
+    for h in (RL1, RL2):
+        H.plh_frame_lines_destroy(h)
+
+
+def test_emu_host_buffer_and_resident_forms(plslam, oracle, synth, emu_lib):
+    _host_buffer_forms(plslam, oracle, synth, emu_lib, n=500, nl=90)
+
+
+@pytest.mark.gpu
+def test_gpu_host_buffer_forms(plslam, oracle, synth):
+    _host_buffer_forms(plslam, oracle, synth, None)
 
 
 # ------------------------------------------------------------------ UndistortKeyPoints / ComputeDistinctiveDescriptors

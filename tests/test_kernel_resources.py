@@ -56,3 +56,39 @@ def test_waiting_kernels_of_the_line_chain_hold_little_lds(res):
     assert res["k_lsd_rects"]["group_segment_fixed_size"] <= 8 * 1024 and res["k_lsd_rects_adv"]["group_segment_fixed_size"] <= 8 * 1024
     assert res["k_adv_first"]["group_segment_fixed_size"] <= 4 * 1024 and res["k_adv_improve"]["group_segment_fixed_size"] <= 2 * 1024
     assert res["k_keylines"]["group_segment_fixed_size"] <= 10 * 1024
+
+
+# ---- the miscompilation behind round 5's "memory access fault" of the counter build (profiles/r06_prof_build_mw16_fault_root_cause.txt):
+# vector writes the register allocator placed in front of a join block's EXEC restore.  tools/isa_exec_split_check.py finds the shape in
+# the ISA; the excerpt of the faulting build is kept as a fixture so that the detector itself is tested.
+import isa_exec_split_check as ISA   # noqa: E402
+
+
+def _excerpt():
+    ins = []
+    for ln in open(os.path.join(_util.ROOT, "tests", "golden", "r05_counter_build_mw16_join_block.s")):
+        m = ISA.INS.match(ln)
+        if m:
+            ins.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    return ins
+
+
+def test_detector_finds_the_round5_miscompilation():
+    hits = ISA.scan(_excerpt())
+    texts = sorted(t for _, t, _, _ in hits)
+    # the constant 1 (region growing's private mark), two more constants and a 64-bit copy, re-materialised above `s_or_b64 exec, exec, s[0:1]`
+    assert texts == ["v_mov_b32_e32 v46, 1", "v_mov_b32_e32 v51, 0x100", "v_mov_b32_e32 v84, 0xffffff80", "v_mov_b64_e32 v[68:69], v[36:37]"], texts
+
+
+@pytest.mark.parametrize("lib", ["libplslam_hip.so", "libplslam_hip_prof.so"])
+def test_no_vector_write_in_front_of_a_join_blocks_exec_restore(lib):
+    import tempfile
+    path = os.path.join(_util.ROOT, "pl-slam_amd", lib)
+    if not os.path.exists(path):
+        pytest.skip(lib + " not built")
+    bad = []
+    with tempfile.TemporaryDirectory() as td:
+        for co in ISA.code_objects(path, td):
+            for name, ins in ISA.functions(co):
+                bad += [(name, "+0x%x" % (a - ins[0][0]), t) for a, t, _, _ in ISA.scan(ins)]
+    assert not bad, bad

@@ -156,10 +156,11 @@ def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat, refine):
     if os.path.exists(prof):
         L = plslam.load(prof)
         out = (C.c_ulonglong * 40)()
-        # (the counter build keeps to the roomy multi-wavefront kernel, batch x wavefronts <= 2048: at the default size that is the
-        # automatic choice; its 128-register kernel spills 752 bytes per lane and faulted at 1024 frames x 8 on round 5's last build,
-        # profiles/r05_prof_build_mw16_fault.txt -- the product build of that kernel is what the schedules above ran)
-        for waves in (0, -1 if N_SOAK * 8 <= 2048 else max(2, 2048 // N_SOAK)):
+        # (round 5's last build faulted here at 1024 frames x 8 wavefronts: the counter build's 128-register kernel k_lsd_grow_mw16 had
+        # been miscompiled -- the register allocator had put the re-materialised constant of region growing's private mark in front of
+        # a join block's EXEC restore, profiles/r06_prof_build_mw16_fault_root_cause.txt; fixed at the source, and
+        # tests/test_kernel_resources.py scans both libraries' ISA for the shape -- so the automatic policy runs again at any size)
+        for waves in (0, -1):
             L.plh_debug_grow_prof(out, 1)
             got = _gpu_lines(plslam, frames, waves, refine, lib=prof)
             L.plh_debug_grow_prof(out, 0)
