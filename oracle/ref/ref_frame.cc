@@ -17,6 +17,7 @@
 //   TrackReferenceKeyFrame's search: Frame / KeyFrame::ComputeBoW with a real ORBVocabulary, then the real SearchByBoW(pKF, F)
 // Not reachable without OpenCV proper: the constructors (remap, extractor threads), UndistortKeyPoints (cv::undistortPoints),
 // the stereo code.  TEST INFRASTRUCTURE ONLY.
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -48,9 +49,34 @@ struct RefKF {   // owner of the keyframe handed to MapPoint / MapLine construct
   RefKF() : kf(make_keyframe(f, map, db)) {}
   ~RefKF() { delete kf; }
 };
+// Wall-clock timing of the matcher / ComputeBoW call inside a harness function (tools/adaptor_latency.py: the SAME call through the
+// reference's CPU code in libframe_ref.so and through the adaptor in libadaptor_hip.so).  ref_set_timing(reps) makes every harness
+// function below run its call 1 + reps times, the state the call modifies restored in front of each run; ref_get_timing() returns the
+// microseconds of each run (run 0 is the cold one: first touch of the frame).  reps = 0 (default): one run, as the tests expect.
+int g_reps = 0;
+std::vector<double> g_us;
+template <class Restore, class Call>
+int timed(Restore restore, Call call) {
+  g_us.clear();
+  int r = 0;
+  for (int k = 0; k <= g_reps; k++) {
+    restore();
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    r = call();
+    g_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return r;
+}
 }  // namespace
 
 extern "C" {
+
+void ref_set_timing(int reps) { g_reps = reps < 0 ? 0 : reps; }
+int ref_get_timing(double* out, int cap) {
+  const int n = (int)g_us.size() < cap ? (int)g_us.size() : cap;
+  for (int i = 0; i < n; i++) out[i] = g_us[i];
+  return n;
+}
 
 void* ref_frame_create(const plo_keypoint* kps, int n, const plo_keyline* kl, const double* fn, int nl, const float gp[6]) {
   Frame* f = new Frame();
@@ -249,7 +275,7 @@ int ref_track_local_points(void* h, const uint8_t* desc, const float view[24], i
   int nm = 0;
   if (nToMatch > 0) {
     ORBmatcher matcher(0.8);
-    nm = matcher.SearchByProjection(f, local, th);
+    nm = timed([&] { f.mvpMapPoints = before; }, [&] { return matcher.SearchByProjection(f, local, th); });
   }
   for (int i = 0; i < n; i++) {
     MapPoint* p = f.mvpMapPoints[i];
@@ -300,7 +326,7 @@ int ref_track_local_lines(void* h, const uint8_t* ldesc, const float view[24], c
   int nm = 0;
   if (nToMatch > 0) {
     LSDmatcher matcher;
-    nm = matcher.SearchByProjection(f, local, th);
+    nm = timed([&] { f.mvpMapLines = before; }, [&] { return matcher.SearchByProjection(f, local, th); });
   }
   for (int i = 0; i < nl; i++) {
     MapLine* p = f.mvpMapLines[i];
@@ -358,7 +384,7 @@ int ref_track_last_frame(void* h, const uint8_t* desc, const float view[24], int
     last.mvpMapPoints[i] = p;
   }
   ORBmatcher matcher(0.9, true);
-  const int nm = matcher.SearchByProjection(cur, last, th, true);
+  const int nm = timed([&] { cur.mvpMapPoints = before; }, [&] { return matcher.SearchByProjection(cur, last, th, true); });
   for (int i = 0; i < n; i++) {
     MapPoint* p = cur.mvpMapPoints[i];
     assigned[i] = (p && p != before[i]) ? (int32_t)p->mnId : -1;
@@ -409,7 +435,7 @@ int ref_track_reference_keyframe(const char* voc_path, const plo_keypoint* kps1,
   }
   ORBmatcher matcher(nnratio, check_ori != 0);
   std::vector<MapPoint*> m;
-  const int nm = matcher.SearchByBoW(&kf, fc, m);
+  const int nm = timed([&] {}, [&] { return matcher.SearchByBoW(&kf, fc, m); });
   for (int j = 0; j < n2; j++) matches21[j] = (j < (int)m.size() && m[j]) ? (int32_t)m[j]->mnId : -1;
   return nm;
 }
@@ -438,7 +464,7 @@ int ref_compute_bow(const char* voc_path, int binary, const uint8_t* desc, int n
   f.mvpMapPoints.assign(n, nullptr);
   f.mvbOutlier.assign(n, false);
   f.mTcw = cv::Mat::eye(4, 4, CV_32F);
-  f.ComputeBoW();
+  timed([&] { f.mBowVec.clear(); f.mFeatVec.clear(); }, [&] { f.ComputeBoW(); return 0; });
   int k = 0;
   for (DBoW2::BowVector::const_iterator it = f.mBowVec.begin(); it != f.mBowVec.end(); ++it, ++k) {
     bow_word[k] = (int32_t)it->first;

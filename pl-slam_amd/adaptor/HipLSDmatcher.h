@@ -62,8 +62,10 @@ class LSDmatcher : public LSDmatcherCPU {
       occupied[i] = CurrentFrame.mvpMapLines[i] && CurrentFrame.mvpMapLines[i]->Observations() > 0;
     if (CurrentFrame.NL == 0 || n == 0) return 0;
     std::vector<int> assigned;
-    const int nmatches = hip::LineSearchByProjection(CurrentFrame.mvKeylinesUn, CurrentFrame.mLdesc, CurrentFrame.mvKeyLineFunctions,
-                                                     FrameGrid(), occupied, q, th, mfNNratio, true, assigned);
+    // (round 6: the frame's lines, LBD rows, line equations and line grid are resident on the device, hip::FrameResidency)
+    const std::shared_ptr<hip::ResidentLines> rl = hip::FrameResidency::Instance().Lines(
+        CurrentFrame.mnId, CurrentFrame.mvKeylinesUn, CurrentFrame.mLdesc, CurrentFrame.mvKeyLineFunctions, FrameGrid());
+    const int nmatches = hip::LineSearchByProjectionResident(rl->h, occupied, q, th, mfNNratio, true, assigned);
     for (int i = 0; i < CurrentFrame.NL; i++)
       if (assigned[i] >= 0) CurrentFrame.mvpMapLines[i] = LastFrame.mvpMapLines[assigned[i]];
     return nmatches;
@@ -89,8 +91,9 @@ class LSDmatcher : public LSDmatcherCPU {
     for (int i = 0; i < F.NL; i++) occupied[i] = F.mvpMapLines[i] && F.mvpMapLines[i]->Observations() > 0;
     if (F.NL == 0 || n == 0) return 0;
     std::vector<int> assigned;
-    const int nmatches = hip::LineSearchByProjection(F.mvKeylinesUn, F.mLdesc, F.mvKeyLineFunctions, FrameGrid(), occupied, q, th,
-                                                     mfNNratio, false, assigned);
+    const std::shared_ptr<hip::ResidentLines> rl =
+        hip::FrameResidency::Instance().Lines(F.mnId, F.mvKeylinesUn, F.mLdesc, F.mvKeyLineFunctions, FrameGrid());
+    const int nmatches = hip::LineSearchByProjectionResident(rl->h, occupied, q, th, mfNNratio, false, assigned);
     for (int i = 0; i < F.NL; i++)
       if (assigned[i] >= 0) F.mvpMapLines[i] = vpMapLines[assigned[i]];
     return nmatches;
@@ -100,7 +103,11 @@ class LSDmatcher : public LSDmatcherCPU {
   int SearchDouble(Frame& InitialFrame, Frame& CurrentFrame, std::vector<int>& LineMatches) {
     LineMatches = std::vector<int>(InitialFrame.NL, -1);
     if (InitialFrame.mLdesc.rows == 0 || CurrentFrame.mLdesc.rows == 0) return 0;
-    return hip::SearchDouble(InitialFrame.mLdesc, CurrentFrame.mLdesc, LineMatches, mfNNratio, (float)TH_LOW);
+    const std::shared_ptr<hip::ResidentLines> r1 = hip::FrameResidency::Instance().Lines(
+        InitialFrame.mnId, InitialFrame.mvKeylinesUn, InitialFrame.mLdesc, InitialFrame.mvKeyLineFunctions, FrameGrid());
+    const std::shared_ptr<hip::ResidentLines> r2 = hip::FrameResidency::Instance().Lines(
+        CurrentFrame.mnId, CurrentFrame.mvKeylinesUn, CurrentFrame.mLdesc, CurrentFrame.mvKeyLineFunctions, FrameGrid());
+    return hip::SearchDoubleResident(r1->h, r2->h, LineMatches, mfNNratio, (float)TH_LOW);
   }
 
   // TrackReferenceKeyFrame: mutual matches between the KeyFrame's and the Frame's lines; a match hands the KeyFrame's

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "plslam_hip.h"
+#include "HipResidency.h"
 
 namespace ORB_SLAM2 {
 namespace hip {
@@ -190,6 +191,67 @@ inline int LineSearchByProjection(const std::vector<cv::line_descriptor::KeyLine
     check(plh_line_search_by_projection_ml(kl, d.ptr<uchar>(), fn, (int)keylinesUn.size(), &gp, occupied.data(), (int)q.valid.size(),
                                            q.valid.data(), q.pos.data(), q.aux.data(), qd.ptr<uchar>(), q.hasObs.data(), th, nnratio,
                                            assigned.data(), &nmatches, device));
+  return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same tracking-path searches on RESIDENT frames (round 6, HipResidency.h): keypoints, descriptors and grid already lie on the
+// device; the call uploads its queries only.  Arguments as above without the frame-side arrays.
+// ---------------------------------------------------------------------------------------------------------------
+inline int SearchByProjectionResident(const plh_frame_points* f, const std::vector<float>& scaleFactors, std::vector<uchar>& occupied,
+                                      const ProjQueries& q, float th, float nnratio, std::vector<int>& assigned) {
+  assigned.assign(plh_frame_points_count(f), -1);
+  cv::Mat qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nmatches = 0;
+  check(plh_orb_search_by_projection_mp_resident(f, scaleFactors.data(), (int)scaleFactors.size(), occupied.data(), (int)q.valid.size(),
+                                                 q.valid.data(), q.pos.data(), q.level.data(), q.aux.data(), qd.ptr<uchar>(),
+                                                 q.hasObs.data(), th, nnratio, assigned.data(), &nmatches));
+  return nmatches;
+}
+inline int SearchByProjectionLastFrameResident(const plh_frame_points* f, const std::vector<float>& scaleFactors, std::vector<uchar>& occupied,
+                                               const ProjQueries& q, float th, int mode, bool checkOri, std::vector<int>& assigned) {
+  assigned.assign(plh_frame_points_count(f), -1);
+  cv::Mat qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nmatches = 0;
+  check(plh_orb_search_by_projection_frame_resident(f, scaleFactors.data(), (int)scaleFactors.size(), occupied.data(), (int)q.valid.size(),
+                                                    q.valid.data(), q.pos.data(), q.level.data(), q.aux.data(), qd.ptr<uchar>(),
+                                                    q.hasObs.data(), th, mode, checkOri ? 1 : 0, assigned.data(), &nmatches));
+  return nmatches;
+}
+inline int SearchForInitializationResident(const plh_frame_points* f1, const plh_frame_points* f2, std::vector<cv::Point2f>& vbPrevMatched,
+                                           std::vector<int>& vnMatches12, int windowSize, float nnratio, bool checkOri) {
+  vnMatches12.assign(plh_frame_points_count(f1), -1);
+  int nmatches = 0;
+  check(plh_orb_search_for_initialization_resident(f1, f2, reinterpret_cast<float*>(vbPrevMatched.data()), windowSize, nnratio,
+                                                   checkOri ? 1 : 0, vnMatches12.data(), &nmatches));
+  return nmatches;
+}
+// kf / f carry their FeatureVector nodes (FrameResidency::Points(..., &node))
+inline int SearchByBoWResident(const plh_frame_points* kf, const std::vector<uchar>& validKF, const plh_frame_points* f, float nnratio,
+                               bool checkOri, std::vector<int>& matchKF, int TH_LOW = 50) {
+  matchKF.assign(plh_frame_points_count(f), -1);
+  int nmatches = 0;
+  check(plh_orb_search_by_bow_resident(kf, validKF.data(), f, TH_LOW, nnratio, checkOri ? 1 : 0, matchKF.data(), &nmatches));
+  return nmatches;
+}
+inline int LineSearchByProjectionResident(const plh_frame_lines* f, std::vector<uchar>& occupied, const ProjQueries& q, float th,
+                                          float nnratio, bool lastFrame, std::vector<int>& assigned) {
+  assigned.assign(plh_frame_lines_count(f), -1);
+  cv::Mat qd = q.desc.isContinuous() ? q.desc : q.desc.clone();
+  int nmatches = 0;
+  if (lastFrame)
+    check(plh_line_search_by_projection_frame_resident(f, occupied.data(), (int)q.valid.size(), q.valid.data(), q.pos.data(), q.aux.data(),
+                                                       qd.ptr<uchar>(), q.hasObs.data(), th, assigned.data(), &nmatches));
+  else
+    check(plh_line_search_by_projection_ml_resident(f, occupied.data(), (int)q.valid.size(), q.valid.data(), q.pos.data(), q.aux.data(),
+                                                    qd.ptr<uchar>(), q.hasObs.data(), th, nnratio, assigned.data(), &nmatches));
+  return nmatches;
+}
+inline int SearchDoubleResident(const plh_frame_lines* l1, const plh_frame_lines* l2, std::vector<int>& LineMatches, float nnratio,
+                                float TH_LOW = 50.f) {
+  LineMatches.assign(plh_frame_lines_count(l1), -1);
+  int nmatches = 0;
+  check(plh_line_search_double_resident(l1, l2, TH_LOW, nnratio, LineMatches.data(), &nmatches));
   return nmatches;
 }
 

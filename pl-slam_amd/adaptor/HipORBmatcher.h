@@ -66,8 +66,10 @@ class ORBmatcher : public ORBmatcherCPU {
     for (int i = 0; i < F.N; i++) occupied[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0;
     std::vector<int> assigned;
     if (F.N == 0 || n == 0) return 0;
-    const int nmatches = hip::SearchByProjection(F.mvKeysUn, F.mDescriptors, FrameGrid(), F.mvScaleFactors, occupied, q, th, mfNNratio,
-                                                 assigned);
+    // (round 6: the frame's keypoints, descriptors and grid are resident on the device -- hip::FrameResidency -- the call uploads the
+    // queries only; SearchLocalPoints searches the frame TrackWithMotionModel / TrackReferenceKeyFrame has just searched)
+    const std::shared_ptr<hip::ResidentPoints> rf = hip::FrameResidency::Instance().Points(F.mnId, F.mvKeysUn, F.mDescriptors, FrameGrid());
+    const int nmatches = hip::SearchByProjectionResident(rf->h, F.mvScaleFactors, occupied, q, th, mfNNratio, assigned);
     for (int i = 0; i < F.N; i++)
       if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
     return nmatches;
@@ -113,9 +115,10 @@ class ORBmatcher : public ORBmatcherCPU {
       occupied[i] = CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0;
     std::vector<int> assigned;
     if (CurrentFrame.N == 0 || n == 0) return 0;
-    const int nmatches = hip::SearchByProjectionLastFrame(CurrentFrame.mvKeysUn, CurrentFrame.mDescriptors, FrameGrid(),
-                                                          CurrentFrame.mvScaleFactors, occupied, q, th, bForward ? 1 : bBackward ? 2 : 0,
-                                                          mbCheckOrientation, assigned);
+    const std::shared_ptr<hip::ResidentPoints> rf =
+        hip::FrameResidency::Instance().Points(CurrentFrame.mnId, CurrentFrame.mvKeysUn, CurrentFrame.mDescriptors, FrameGrid());
+    const int nmatches = hip::SearchByProjectionLastFrameResident(rf->h, CurrentFrame.mvScaleFactors, occupied, q, th,
+                                                                  bForward ? 1 : bBackward ? 2 : 0, mbCheckOrientation, assigned);
     // :1548 assigns, the rotation-consistency pass (:1567-1580) resets the rejected ones to NULL: `assigned` is the net effect,
     // `occupied` tells which of the previously empty slots stayed empty
     for (int i = 0; i < CurrentFrame.N; i++)
@@ -130,8 +133,14 @@ class ORBmatcher : public ORBmatcherCPU {
     std::vector<uchar> valid(vpMapPointsKF.size());
     for (size_t i = 0; i < valid.size(); i++) valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
     std::vector<int> matchKF;
-    const int n = hip::SearchByBoW(pKF->mDescriptors, pKF->mvKeysUn, hip::NodeOfFeature(pKF->mFeatVec, pKF->N), valid, F.mDescriptors,
-                                   F.mvKeys, hip::NodeOfFeature(F.mFeatVec, F.N), mfNNratio, mbCheckOrientation, matchKF, TH_LOW);
+    if (pKF->N == 0 || F.N == 0) return 0;
+    // (a KeyFrame answers to the id of the Frame it was made from: same features; every frame tracked against it finds it resident.
+    // The angles SearchByBoW compares are those of mvKeysUn / mvKeys alike: undistortion moves pt only.)
+    const std::vector<int32_t> nodeKF = hip::NodeOfFeature(pKF->mFeatVec, pKF->N), nodeF = hip::NodeOfFeature(F.mFeatVec, F.N);
+    const std::shared_ptr<hip::ResidentPoints> rk =
+        hip::FrameResidency::Instance().Points(pKF->mnFrameId, pKF->mvKeysUn, pKF->mDescriptors, FrameGrid(), &nodeKF);
+    const std::shared_ptr<hip::ResidentPoints> rf = hip::FrameResidency::Instance().Points(F.mnId, F.mvKeysUn, F.mDescriptors, FrameGrid(), &nodeF);
+    const int n = hip::SearchByBoWResident(rk->h, valid, rf->h, mfNNratio, mbCheckOrientation, matchKF, TH_LOW);
     for (int j = 0; j < F.N; j++)
       if (matchKF[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[matchKF[j]];
     return n;
@@ -491,8 +500,10 @@ class ORBmatcher : public ORBmatcherCPU {
   // MonocularInitialization
   int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
                               int windowSize = 10) {
-    return hip::SearchForInitialization(F1.mvKeysUn, F1.mDescriptors, F2.mvKeysUn, F2.mDescriptors, FrameGrid(), vbPrevMatched,
-                                        vnMatches12, windowSize, mfNNratio, mbCheckOrientation);
+    // (F1 is the initial frame of every attempt until the initialiser succeeds: it stays resident)
+    const std::shared_ptr<hip::ResidentPoints> r1 = hip::FrameResidency::Instance().Points(F1.mnId, F1.mvKeysUn, F1.mDescriptors, FrameGrid());
+    const std::shared_ptr<hip::ResidentPoints> r2 = hip::FrameResidency::Instance().Points(F2.mnId, F2.mvKeysUn, F2.mDescriptors, FrameGrid());
+    return hip::SearchForInitializationResident(r1->h, r2->h, vbPrevMatched, vnMatches12, windowSize, mfNNratio, mbCheckOrientation);
   }
 
  protected:
