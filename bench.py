@@ -478,7 +478,11 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed batch's records with the CPU oracle")
     ap.add_argument("--verify-frames", type=int, default=16, help="frames of EVERY sub-batch of the timed batch compared with the oracle (on every rank)")
     ap.add_argument("--verify-full", choices=["rotate", "none"], default="rotate",
-                    help="additionally compare EVERY frame of one sub-batch of the timed batch (which one rotates with the hour of the run)")
+                    help="additionally compare EVERY frame of one sub-batch of the timed batch (--verify-full-part says which)")
+    ap.add_argument("--verify-full-part", type=int, default=-1,
+                    help="the sub-batch compared in full: 0 .. nsplit-1 (on rank r: part + r, modulo nsplit); -1 (default) derives it from "
+                         "--steps and --warmup, so that a command line always verifies the same part and CI cycles through all of them "
+                         "by varying it; reported as verified.full_sub_batch")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # 1-rank RCCL communicator: rehearses the N > 1 path
     ap.add_argument("--serial", action="store_true", help="ORB and line halves on one stream (no overlap); used for PMC runs")
     args = ap.parse_args()
@@ -606,8 +610,9 @@ def main():
         # frames -- the first --verify-frames frames of each sub-batch
         O = _util.oracle()
         O.build()
-        # one sub-batch in full (rotating with the hour, so that successive runs cover all of them), 16 frames of the others
-        full_part = None if args.verify_full == "none" else (int(time.time() // 3600) + rank) % W.nsplit
+        # one sub-batch in full (--verify-full-part), 16 frames of the others
+        # (round 5 picked the part from the wall clock: which frames a run verified was not reproducible -- ADVICE r5)
+        full_part = None if args.verify_full == "none" else ((args.verify_full_part if args.verify_full_part >= 0 else args.steps + args.warmup) + rank) % W.nsplit
         verified = verify_batch(O, V, W, res, voc, args.verify_frames, full_part)
         if world > 1:   # a scaling run is a parity run: rank 0 reports every rank's verdict
             mine = {"rank": rank, "exact": verified["exact"], "frames": verified["frames"], "pairs": verified["pairs"],
@@ -867,9 +872,79 @@ def main():
                                             "job is the configs4_share_512 figure, the 6144-frame one is what a GPU sustains on a long sequence"}
             except Exception as e:
                 out["secondary"] = {"error": repr(e)[:300]}
+        # the tracker's per-frame searches (TrackWithMotionModel + SearchLocalPoints / SearchLocalLines) as a resident batch: what a
+        # running tracker calls for EVERY frame (SearchByBoW, which the headline times, only after a keyframe or a loss)
+        if headline:
+            try:
+                TB = _util._load("plslam_tracking_bench", os.path.join(ROOT, "tools", "tracking_bench.py"))
+                tr = TB.run(pairs=1024, distinct=32, steps=5, warmup=1, quiet=True)
+                if not args.no_verify and not tr["verified"]["exact"]:
+                    failed_verification.append("secondary tracking: the searches differ from the oracle chain")
+                out.setdefault("secondary", {})["tracking"] = tr
+            except Exception as e:
+                out.setdefault("secondary", {})["tracking"] = {"error": repr(e)[:300]}
         out["extras_seconds"] = round(time.perf_counter() - extras_t0, 1)
     else:
         W.close()
+
+    # ---- N > 1: the literal BASELINE configs[4] job in the same line as the weak-scaling headline: 4096 frames of
+    # 1241x376 / 2000 ORB / 200 lines as ONE job, rank r owns the contiguous shard [r, r + 1) * 4096 / N, records gathered to rank 0.
+    # A curve over N from `value` alone is linear by construction (every rank brings its own 6144 frames); this one is strong scaling.
+    if (world > 1 or (args.force_dist and not args.no_extras)) and not strong and real is None:
+        sleg = None
+        try:
+            tot = 4096
+            b2 = tot // world
+            ns2 = max(1, min(4, b2 // 1024))
+            while b2 % ns2:
+                ns2 -= 1
+            W2 = Workload(P, S, V, PL, torch, dev, rank, b2, ns2, 376, 1241, 2000, 8, 200, 16, voc, shard=(rank, world, tot), refine=refine,
+                          screen=not args.no_screen)
+            recv2 = W2.fe.alloc_gather_buffers(world, receives=(root < 0 or rank == root))
+
+            def step2():
+                W2.fe.step(W2.d_imgs, join=False)
+                W2.fe.gather(comm_stream, comm, root, recv2)
+            for _ in range(2):
+                step2()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            ts = time.perf_counter()
+            n2 = 6
+            for _ in range(n2):
+                step2()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            dt2 = time.perf_counter() - ts
+            if world > 1:
+                t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            ver2 = None
+            if not args.no_verify:
+                ver2 = verify_batch(_util.oracle(), V, W2, W2.fe.results(), voc, 4)
+                ok2 = ver2["exact"]
+                if world > 1:
+                    allok = [None] * world
+                    dist.all_gather_object(allok, bool(ok2))
+                    ok2 = all(allok)
+                if not ok2:
+                    failed_verification.append("configs4_strong: records differ from the oracle")
+                ver2 = {"frames_per_rank": ver2["frames"], "exact": bool(ok2)}
+            sleg = {"value": round(tot * n2 / dt2, 1), "unit": "frames/s", "scaling": "strong", "n_gpus": world, "total_frames": tot,
+                    "frames_per_gpu": b2, "sub_batches": ns2, "steps": n2, "ms_per_step": round(dt2 / n2 * 1e3, 3), "gather": args.gather,
+                    "verified": ver2,
+                    "workload": "BASELINE configs[4]: 4096 frames of 1241x376 (KITTI00-02.yaml: 2000 ORB, 8 levels) + 200 lines as one job, "
+                                "contiguous shards, records gathered over RCCL"}
+            W2.close()
+        except Exception as e:
+            sleg = {"error": repr(e)[:300]}
+        if rank == 0:
+            out.setdefault("secondary", {})["configs4_strong"] = sleg
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0)

@@ -152,7 +152,7 @@ int main(int argc, char** argv) {
   } else if (rows == 376 && cols == 1241) {  // Examples/Monocular/KITTI00-02.yaml: zero distortion, no remap (Frame.cc:917-921)
     std::printf("camera: KITTI00-02.yaml\n");
   }
-  p.lsd_refine = refine < 0 ? PLH_FRONTEND_REFINE_LIBRARY : 1 + refine;
+  p.lsd_refine = refine < 0 ? PLH_FRONTEND_REFINE_LIBRARY : (refine ? PLH_FRONTEND_REFINE_ADV : PLH_FRONTEND_REFINE_STD);
   std::printf("cv::LineSegmentDetector refine level: %s\n",
               (refine < 0 ? plh_lsd_refine_default() : refine) == PLH_LSD_REFINE_ADV ? "LSD_REFINE_ADV" : "LSD_REFINE_STD");
   p.bow_levelsup = 4; p.orb_th_low = 50; p.orb_nnratio = 0.7f; p.orb_check_orientation = 1; p.line_th = 50.f; p.line_nnratio = 0.7f;

@@ -446,6 +446,12 @@ PLH_API plh_status plh_line_search_by_projection_ml_batch_dev(
     const uint8_t* d_q_desc, const uint8_t* d_q_hasobs, float th, float nnratio, int32_t* d_assigned, int32_t* d_nmatches,
     void* stream);
 
+/* The projection searches above run as a prepass (one lane per query: candidates, Hamming distances, the few best per query -- every
+ * query of every frame in parallel) and an ordered resolve (one wavefront per frame replays the reference's order on those short
+ * lists, 64 queries at a time).  on = 1 selects the one-wavefront-per-frame kernels of rounds 1-5 instead (identical results; an A/B and
+ * test switch, process-wide, not for concurrent use). */
+PLH_API plh_status plh_debug_set_proj_serial(int on);
+
 /* Host-buffer forms: one call = one reference call on one frame (they stage over PCIe, rebuild the frame's grid on the
  * device and block).  Arrays as in the *_batch_dev forms, without padding. */
 PLH_API plh_status plh_orb_search_for_initialization(const plh_keypoint* kps1, const uint8_t* desc1, int n1,
@@ -751,10 +757,13 @@ PLH_API plh_status plh_line_read_segments(plh_line* h, int b, float* out_xyxy, i
 typedef struct plh_frontend plh_frontend;
 
 /* plh_frontend_params::lsd_refine.  0 -- what a zero-initialised struct holds -- is the LIBRARY's default, so that the usual C
- * idiom does not silently force a level; the two explicit levels are 1 + PLH_LSD_REFINE_*. */
+ * idiom does not silently force a level.  The two explicit levels carry a tag in bits 8.. so that they overlap NEITHER
+ * PLH_LSD_REFINE_STD / _ADV (0 / 1: the plh_line_set_refine values, which round 4 also took here) NOR round 5's 1 / 2: a caller that
+ * assigns PLH_LSD_REFINE_ADV (1) to this field out of habit got LSD_REFINE_STD from round 5's encoding without a word;
+ * now 1 and 2 are refused by plh_frontend_create (PLH_ERR_INVALID, with the reason in plh_last_error()). */
 #define PLH_FRONTEND_REFINE_LIBRARY 0
-#define PLH_FRONTEND_REFINE_STD 1
-#define PLH_FRONTEND_REFINE_ADV 2
+#define PLH_FRONTEND_REFINE_STD 0x100   /* 0x100 | PLH_LSD_REFINE_STD */
+#define PLH_FRONTEND_REFINE_ADV 0x101   /* 0x100 | PLH_LSD_REFINE_ADV */
 
 typedef struct plh_frontend_params {
   uint32_t struct_size;            /* sizeof(plh_frontend_params) of the header the caller was compiled against: plh_frontend_create

@@ -580,6 +580,475 @@ __global__ void __launch_bounds__(64) k_search_proj_lines(int variant, const plh
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Round 6: the projection searches as PREPASS + ORDERED RESOLVE.
+//
+// k_search_proj_points / k_search_proj_lines above walk a frame's queries with ONE wavefront, each query a chain of five dependent
+// global round trips (query -> grid cells -> items -> keypoints -> descriptors): 2.7 us per query, 16 ms for the 6000 points of a local
+// map -- a frame searched by a live tracker (Tracking.cc:1792-1800) took eight times as long as on the CPU, and a resident batch
+// ran one wavefront per SIMD.  What is order dependent in the reference loops is only WHICH candidates are still free when a query
+// takes its turn; the candidates of a query and their Hamming distances are not.  So:
+//   * prepass (k_proj_points_prepass / k_proj_lines_prepass): one LANE per query, every query of every frame in parallel: enumerate the
+//     window in the reference's order, apply every test that depends on the query and the candidate alone (level band, window,
+//     direction, length ratio, chi-square gate, the INITIAL occupancy), and keep the PROJ_TOPK best candidates in (distance,
+//     enumeration order) order.  The reference's (best, second best) are the first two FREE entries of that order (strict `<` in its
+//     scan: the first of equal distances wins -- a stable insertion reproduces it), so a short list is all a query needs unless
+//     nearly all of it has been taken by earlier queries (flag `truncated`: more candidates existed than the list holds).
+//   * resolve (k_proj_resolve): one wavefront per frame takes the queries 64 at a time, one per lane: every lane evaluates its list
+//     against the current occupancy; a lane whose best or second best is claimed by an EARLIER accepting lane of the same round (or
+//     whose truncated list ran out) must wait; everything in front of the first such lane is committed at once, then the round
+//     repeats from there.  A list that ran out is re-evaluated exactly by the one-wavefront code (slow path: rare).
+// Same assignments as the sequential kernels, which stay as the oracle's peers for A/B (plh_debug_set_proj_serial) and serve
+// frames whose capacity does not fit the 13-bit index of a list entry.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef PLH_PROJ_TOPK
+#define PLH_PROJ_TOPK 8   // (tests build the emulator once with 2: nearly every contended query then takes the slow path)
+#endif
+constexpr int PROJ_TOPK = PLH_PROJ_TOPK;
+constexpr uint32_t PROJ_EMPTY = 0xffffffffu, PROJ_TRUNC = 0x40000000u;
+struct ProjTop {
+  uint32_t e[PROJ_TOPK];   // idx | dist << 13 | level << 22 (| PROJ_TRUNC in e[0]); PROJ_EMPTY = no entry
+};
+__device__ __forceinline__ uint32_t proj_entry(int idx, int dist, int level) { return (uint32_t)idx | ((uint32_t)dist << 13) | ((uint32_t)(level & 15) << 22); }
+__device__ __forceinline__ int proj_idx(uint32_t e) { return (int)(e & 0x1fffu); }
+__device__ __forceinline__ int proj_dist(uint32_t e) { return (int)((e >> 13) & 0x1ffu); }
+__device__ __forceinline__ int proj_level(uint32_t e) { return (int)((e >> 22) & 15u); }
+// stable insertion: an entry goes in front of the first one with a LARGER distance (equal distances keep their order of arrival)
+__device__ __forceinline__ void proj_insert(uint32_t (&top)[PROJ_TOPK], bool& trunc, int idx, int dist, int level) {
+  const uint32_t ne = proj_entry(idx, dist, level);
+  if (top[PROJ_TOPK - 1] != PROJ_EMPTY && dist >= proj_dist(top[PROJ_TOPK - 1])) { trunc = true; return; }
+  if (top[PROJ_TOPK - 1] != PROJ_EMPTY) trunc = true;   // the last entry is pushed out
+  uint32_t carry = ne;
+  bool placed = false;
+#pragma unroll
+  for (int k = 0; k < PROJ_TOPK; k++) {
+    const uint32_t cur = top[k];
+    if (!placed && (cur == PROJ_EMPTY || dist < proj_dist(cur))) placed = true;
+    if (placed) { top[k] = carry; carry = cur; }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_proj_points_prepass(int variant, const plh_keypoint* kps, const uint8_t* desc, const int* nArr, int cap,
+                                                             plh_grid_params g, const int32_t* csAll, const int32_t* ciAll, ScaleTab sf,
+                                                             ScaleTab invSig2, const uint8_t* occupiedAll, const int* nqArr, int qcap,
+                                                             const uint8_t* qValid, const float* qXY, const int32_t* qLevel, const float* qAux,
+                                                             const uint8_t* qDesc, float th, int mode, int nlevels, ProjTop* out) {
+  const int pair = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= qcap) return;
+  const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
+  uint32_t top[PROJ_TOPK];
+#pragma unroll
+  for (int k = 0; k < PROJ_TOPK; k++) top[k] = PROJ_EMPTY;
+  bool trunc = false;
+  const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
+  bool live = q < nq && qValid[qo + q] != 0;
+  int lvl = 0;
+  float x = 0.f, y = 0.f, radius = 0.f;
+  int minL = 0, maxL = 0;
+  if (live) {
+    x = qXY[(qo + q) * 2]; y = qXY[(qo + q) * 2 + 1];
+    lvl = qLevel[qo + q];
+    live = lvl >= 0 && lvl < nlevels;
+  }
+  if (live) {
+    if (variant == 0) {
+      float r = qAux[qo + q] > 0.998 ? 2.5 : 4.0;   // RadiusByViewingCos
+      if (th != 1.0) r *= th;
+      radius = r * sf.v[lvl];
+      minL = lvl - 1; maxL = lvl;
+    } else if (variant == 1) {
+      if (x < g.min_x || x > g.max_x || y < g.min_y || y > g.max_y) live = false;
+      radius = th * sf.v[lvl];
+      if (mode == 1) { minL = lvl; maxL = -1; }
+      else if (mode == 2) { minL = 0; maxL = lvl; }
+      else { minL = lvl - 1; maxL = lvl + 1; }
+    } else {
+      radius = th * sf.v[lvl];
+      minL = lvl - 1; maxL = lvl;
+    }
+  }
+  if (live) {
+    const CellWin w = cell_window(g, x, y, radius);
+    if (w.ok) {
+      const plh_keypoint* K = kps + o;
+      const uint8_t* D = desc + o * 32;
+      const int32_t* cs = csAll + (long long)pair * (GCELLS + 1);
+      const int32_t* ci = ciAll + o;
+      const unsigned long long* qd = reinterpret_cast<const unsigned long long*>(qDesc + (qo + q) * 32);
+      const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+      const bool bCheckLevels = (minL > 0) || (maxL >= 0);
+      for (int ix = w.x0; ix <= w.x1; ix++) {
+        const int s = cs[ix * GROWS + w.y0], e = cs[ix * GROWS + w.y1 + 1];
+        for (int j = s; j < e; j++) {
+          const int id = ci[j];
+          if (id < 0 || id >= n) continue;
+          const plh_keypoint kp = K[id];
+          if (bCheckLevels) {
+            if (kp.octave < minL) continue;
+            if (maxL >= 0 && kp.octave > maxL) continue;
+          }
+          const float distx = kp.x - x, disty = kp.y - y;
+          if (!(fabsf(distx) < radius && fabsf(disty) < radius)) continue;
+          if (variant == 2) {   // reprojection error gate (monocular): e2 * mvInvLevelSigma2[kpLevel] > 5.99
+            const float ex = x - kp.x, ey = y - kp.y;
+            const float e2 = ex * ex + ey * ey;
+            if (e2 * invSig2.v[kp.octave & 15] > 5.99) continue;
+          } else if (occupiedAll[o + id]) {
+            continue;   // taken before the call: never a candidate (occupancy only ever grows while the queries are walked)
+          }
+          const unsigned long long* dd = reinterpret_cast<const unsigned long long*>(D + (long long)id * 32);
+          const int d = __popcll(q0 ^ dd[0]) + __popcll(q1 ^ dd[1]) + __popcll(q2 ^ dd[2]) + __popcll(q3 ^ dd[3]);
+          proj_insert(top, trunc, id, d, kp.octave);
+        }
+      }
+    }
+  }
+  if (trunc && top[0] != PROJ_EMPTY) top[0] |= PROJ_TRUNC;
+  ProjTop t;
+#pragma unroll
+  for (int k = 0; k < PROJ_TOPK; k++) t.e[k] = top[k];
+  out[qo + q] = t;
+}
+
+__global__ void __launch_bounds__(256) k_proj_lines_prepass(int variant, const plh_keyline* kls, const uint8_t* ldesc, const double* fnAll,
+                                                            const int* nArr, int cap, plh_grid_params g, const int32_t* csAll,
+                                                            const int32_t* ciAll, int itemCap, const uint8_t* occupiedAll, const int* nqArr,
+                                                            int qcap, const uint8_t* qValid, const float* qSeg, const float* qAux,
+                                                            const uint8_t* qDesc, float th, ProjTop* out) {
+  const int pair = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= qcap) return;
+  const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
+  uint32_t top[PROJ_TOPK];
+#pragma unroll
+  for (int k = 0; k < PROJ_TOPK; k++) top[k] = PROJ_EMPTY;
+  bool trunc = false;
+  const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
+  if (q < nq && qValid[qo + q]) {
+    const plh_keyline* K = kls + o;
+    const uint8_t* D = ldesc + o * 32;
+    const double* fn = fnAll + o * 3;
+    const int32_t* cs = csAll + (long long)pair * (GCELLS + 1);
+    const int32_t* ci = ciAll + (long long)pair * itemCap;
+    const float* sg = qSeg + (qo + q) * 4;
+    const float x1 = sg[0], y1 = sg[1], x2 = sg[2], y2 = sg[3];
+    float r, TH;
+    if (variant == 0) {
+      r = qAux[qo + q] > 0.998 ? 5.0 : 8.0;   // LSDmatcher::RadiusByViewingCos
+      if (th != 1.0) r *= th;
+      TH = 0.998f;
+    } else {
+      r = th;
+      TH = 0.96f;
+    }
+    const float xs[3] = {x1, (float)((x1 + x2) / 2.0), x2};
+    const float ys[3] = {y1, (float)((y1 + y2) / 2.0), y2};
+    float delta1x = x1 - x2, delta1y = y1 - y2;
+    const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
+    delta1x /= norm_delta1;
+    delta1y /= norm_delta1;
+    const unsigned long long* qd = reinterpret_cast<const unsigned long long*>(qDesc + (qo + q) * 32);
+    const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+    const float la = qAux[qo + q];
+    // the same line sits in several cells and is probed from three points: GetFeaturesInAreaForLine lists it once, at its first
+    // passing probe.  A line that is in the top list is recognised by its index; one that is not (it was rejected for its distance, or
+    // pushed out) would be rejected again, so that test is all the de-duplication the list needs -- except for the `truncated` flag,
+    // which a second visit must not set on its own: the small bitmap remembers the lines already counted.
+    uint32_t seenLo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // lines 0 .. 255 (a frame keeps nLSDFeature + 1 = 201); beyond: conservative
+    for (int i = 0; i < 3; i++) {
+      const CellWin w = cell_window(g, xs[i], ys[i], r);
+      if (!w.ok) continue;
+      for (int ix = w.x0; ix <= w.x1; ix++) {
+        const int s = cs[ix * GROWS + w.y0], e = cs[ix * GROWS + w.y1 + 1];
+        for (int j = s; j < e; j++) {
+          const int id = ci[j];
+          if (id < 0 || id >= n) continue;
+          if (id < 256 && ((seenLo[id >> 5] >> (id & 31)) & 1u)) continue;
+          bool dup = false;
+#pragma unroll
+          for (int k = 0; k < PROJ_TOPK; k++) dup = dup || (top[k] != PROJ_EMPTY && proj_idx(top[k]) == id);
+          if (dup) continue;
+          const plh_keyline k = K[id];
+          float delta2x = k.startPointX - k.endPointX, delta2y = k.startPointY - k.endPointY;
+          const float norm_delta2 = sqrtf(delta2x * delta2x + delta2y * delta2y);
+          delta2x /= norm_delta2;
+          delta2y /= norm_delta2;
+          const float CosSita = fabsf(delta1x * delta2x + delta1y * delta2y);
+          if (CosSita < TH) continue;
+          const float dist = (float)(fn[id * 3 + 0] * (double)xs[i] + fn[id * 3 + 1] * (double)ys[i] + fn[id * 3 + 2]);
+          if (!(fabsf(dist) < r)) continue;
+          if (id < 256) {
+#pragma unroll
+            for (int wd = 0; wd < 8; wd++)
+              if (wd == (id >> 5)) seenLo[wd] |= 1u << (id & 31);
+          }
+          if (occupiedAll[o + id]) continue;
+          if (variant == 1) {
+            const float lb = k.lineLength;
+            const float max_ = fmaxf(la, lb), min_ = fminf(la, lb);
+            if (min_ / max_ < 0.75) continue;
+          }
+          const unsigned long long* dd = reinterpret_cast<const unsigned long long*>(D + (long long)id * 32);
+          const int d = __popcll(q0 ^ dd[0]) + __popcll(q1 ^ dd[1]) + __popcll(q2 ^ dd[2]) + __popcll(q3 ^ dd[3]);
+          proj_insert(top, trunc, id, d, k.octave);
+        }
+      }
+    }
+  }
+  if (trunc && top[0] != PROJ_EMPTY) top[0] |= PROJ_TRUNC;
+  ProjTop t;
+#pragma unroll
+  for (int k = 0; k < PROJ_TOPK; k++) t.e[k] = top[k];
+  out[qo + q] = t;
+}
+
+// The exact scan of ONE query against the current occupancy, by the whole wavefront (the loops of k_search_proj_points /
+// k_search_proj_lines): the slow path of the resolve.  Returns the packed best / second (PROJ_EMPTY = none) in all lanes.
+struct ProjPick { uint32_t best, second; };
+__device__ ProjPick proj_slow_points(int variant, const plh_keypoint* K, const uint8_t* D, const plh_grid_params& g, const int32_t* cs,
+                                     const int32_t* ci, const ScaleTab& sf, const ScaleTab& invSig2, const unsigned char* occ, int* list,
+                                     int* dist, float x, float y, int lvl, float aux, const uint8_t* qd, float th, int mode, int lane) {
+  float radius;
+  int minL, maxL;
+  if (variant == 0) {
+    float r = aux > 0.998 ? 2.5 : 4.0;
+    if (th != 1.0) r *= th;
+    radius = r * sf.v[lvl];
+    minL = lvl - 1; maxL = lvl;
+  } else if (variant == 1) {
+    radius = th * sf.v[lvl];
+    if (mode == 1) { minL = lvl; maxL = -1; }
+    else if (mode == 2) { minL = 0; maxL = lvl; }
+    else { minL = lvl - 1; maxL = lvl + 1; }
+  } else {
+    radius = th * sf.v[lvl];
+    minL = lvl - 1; maxL = lvl;
+  }
+  ProjPick p{PROJ_EMPTY, PROJ_EMPTY};
+  FS_WAVE_SYNC();
+  const int Kc = collect_points(K, g, cs, ci, x, y, radius, minL, maxL, list, lane);
+  if (Kc == 0) return p;
+  FS_WAVE_SYNC();
+  for (int t = lane; t < Kc; t += 64) dist[t] = hamming_rows(qd, D + (long long)list[t] * 32);
+  FS_WAVE_SYNC();
+  int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, idx2 = -1;
+  for (int t = 0; t < Kc; t++) {
+    const int idx = list[t];
+    if (occ[idx]) continue;
+    if (variant == 2) {
+      const float ex = x - K[idx].x, ey = y - K[idx].y;
+      const float e2 = ex * ex + ey * ey;
+      if (e2 * invSig2.v[K[idx].octave & 15] > 5.99) continue;
+    }
+    const int d = dist[t];
+    if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; idx2 = bestIdx; bestLevel = K[idx].octave; bestIdx = idx; }
+    else if (d < bestDist2) { bestLevel2 = K[idx].octave; bestDist2 = d; idx2 = idx; }
+  }
+  FS_WAVE_SYNC();
+  if (bestIdx >= 0) p.best = proj_entry(bestIdx, bestDist, bestLevel);
+  if (idx2 >= 0) p.second = proj_entry(idx2, bestDist2, bestLevel2);
+  return p;
+}
+__device__ ProjPick proj_slow_lines(int variant, const plh_keyline* K, const uint8_t* D, const double* fn, const plh_grid_params& g,
+                                    const int32_t* cs, const int32_t* ci, const unsigned char* occ, unsigned char* seen, int* list, int* dist,
+                                    const float* sg, float aux, const uint8_t* qd, float th, int lane) {
+  float r, TH;
+  if (variant == 0) {
+    r = aux > 0.998 ? 5.0 : 8.0;
+    if (th != 1.0) r *= th;
+    TH = 0.998f;
+  } else {
+    r = th;
+    TH = 0.96f;
+  }
+  ProjPick p{PROJ_EMPTY, PROJ_EMPTY};
+  FS_WAVE_SYNC();
+  const int Kc = collect_lines(K, fn, g, cs, ci, sg[0], sg[1], sg[2], sg[3], r, TH, list, seen, lane);
+  if (Kc == 0) return p;
+  for (int t = lane; t < Kc; t += 64) dist[t] = hamming_rows(qd, D + (long long)list[t] * 32);
+  FS_WAVE_SYNC();
+  int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, idx2 = -1;
+  for (int t = 0; t < Kc; t++) {
+    const int idx = list[t];
+    if (occ[idx]) continue;
+    const int d = dist[t];
+    if (variant == 1) {
+      const float la = aux, lb = K[idx].lineLength;
+      const float max_ = fmaxf(la, lb), min_ = fminf(la, lb);
+      if (min_ / max_ < 0.75) continue;
+      if (d < bestDist) { bestDist = d; bestIdx = idx; bestLevel = K[idx].octave; }
+    } else {
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; idx2 = bestIdx; bestLevel = K[idx].octave; bestIdx = idx; }
+      else if (d < bestDist2) { bestLevel2 = K[idx].octave; bestDist2 = d; idx2 = idx; }
+    }
+  }
+  FS_WAVE_SYNC();
+  if (bestIdx >= 0) p.best = proj_entry(bestIdx, bestDist, bestLevel);
+  if (idx2 >= 0) p.second = proj_entry(idx2, bestDist2, bestLevel2);
+  return p;
+}
+
+// The ordered resolve.  kind 0: points, kind 1: lines (what the slow path needs); variant as in the sequential kernels.
+// LDS: list[cap] claim/dist[cap] asg[cap] pushIdx[qLds] (int) + occ[cap] seen[cap] pushBin[qLds] (u8) + hist[32] (int)
+struct ProjFrame {
+  const plh_keypoint* kps; const uint8_t* desc;             // points
+  const plh_keyline* kls; const double* fn; int itemCap;    // lines (desc = LBD rows)
+  const int32_t* cs; const int32_t* ci;
+};
+__global__ void __launch_bounds__(64) k_proj_resolve(int kind, int variant, ProjFrame F, const int* nArr, int cap, plh_grid_params g, ScaleTab sf,
+                                                     ScaleTab invSig2, uint8_t* occupiedAll, const int* nqArr, int qcap, const uint8_t* qValid,
+                                                     const float* qPos, const int32_t* qLevel, const float* qAux, const uint8_t* qDesc,
+                                                     const uint8_t* qHasObs, float th, float nnratio, int mode, int checkOri, int distTh,
+                                                     int nlevels, int qLds, const ProjTop* tops, int32_t* assignedAll, int32_t* nmatchesOut) {
+  HIP_DYNAMIC_SHARED(unsigned char, smem)
+  int* list = (int*)smem;
+  int* claim = list + cap;          // doubles as dist[] of the slow path (never live at the same time)
+  int* asg = claim + cap;
+  int* pushIdx = asg + cap;
+  int* hist = pushIdx + qLds;
+  unsigned char* occ = (unsigned char*)(hist + 32);
+  unsigned char* seen = occ + cap;
+  unsigned char* pushBin = seen + cap;
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
+  const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
+  const bool perQuery = kind == 0 && variant == 2;   // Fuse: no occupancy, one answer per query
+  const bool needSecond = variant == 0;
+  const int posW = kind == 0 ? 2 : 4;
+  for (int i = lane; i < cap; i += 64) {
+    asg[i] = -1; claim[i] = 0x7fffffff; seen[i] = 0;
+    occ[i] = perQuery ? 0 : (i < n ? occupiedAll[o + i] : 1);
+  }
+  for (int i = lane; i < qLds; i += 64) pushBin[i] = 255;
+  if (lane < 32) hist[lane] = 0;
+  FS_WAVE_SYNC();
+  const plh_keypoint* K = F.kps ? F.kps + o : nullptr;
+  const plh_keyline* KL = F.kls ? F.kls + o : nullptr;
+  const uint8_t* D = F.desc + o * 32;
+  const double* fn = F.fn ? F.fn + o * 3 : nullptr;
+  const int32_t* cs = F.cs + (long long)pair * (GCELLS + 1);
+  const int32_t* ci = F.ci + (kind == 0 ? o : (long long)pair * F.itemCap);
+  int nmatches = 0;
+  for (int base = 0; base < nq; base += 64) {
+    const int q = base + lane;
+    uint32_t top[PROJ_TOPK];
+    bool trunc = false;
+    unsigned char hasobs = 0;
+    if (q < nq) {
+      const ProjTop t = tops[qo + q];
+#pragma unroll
+      for (int k = 0; k < PROJ_TOPK; k++) top[k] = t.e[k];
+      if (top[0] != PROJ_EMPTY) { trunc = (top[0] & PROJ_TRUNC) != 0u; top[0] &= ~PROJ_TRUNC; }
+      hasobs = qHasObs[qo + q];
+    } else {
+#pragma unroll
+      for (int k = 0; k < PROJ_TOPK; k++) top[k] = PROJ_EMPTY;
+    }
+    if (perQuery) {   // the prepass applied every test: the first entry is the answer
+      const bool hit = top[0] != PROJ_EMPTY && proj_dist(top[0]) <= distTh;
+      if (q < qcap && q < nq) assignedAll[qo + q] = hit ? proj_idx(top[0]) : -1;
+      nmatches += __popcll(__ballot(hit));
+      continue;
+    }
+    unsigned long long active = __ballot(top[0] != PROJ_EMPTY);
+    uint32_t slowBest = PROJ_EMPTY, slowSecond = PROJ_EMPTY;   // a lane whose list ran out gets its picks from the slow path
+    bool haveSlow = false;
+    while (active) {
+      const bool on = ((active >> lane) & 1ull) != 0ull;
+      // first two free entries of my list (or the slow path's picks)
+      uint32_t b = PROJ_EMPTY, s2 = PROJ_EMPTY;
+      bool ranOut = false;
+      if (on) {
+        if (haveSlow) {
+          b = slowBest; s2 = slowSecond;
+        } else {
+#pragma unroll
+          for (int k = 0; k < PROJ_TOPK; k++) {
+            const uint32_t e = top[k];
+            if (e == PROJ_EMPTY) continue;
+            if (occ[proj_idx(e)]) continue;
+            if (b == PROJ_EMPTY) b = e;
+            else if (s2 == PROJ_EMPTY) s2 = e;
+          }
+          ranOut = trunc && (b == PROJ_EMPTY || (needSecond && s2 == PROJ_EMPTY));
+        }
+      }
+      bool accept = on && !ranOut && b != PROJ_EMPTY && proj_dist(b) <= distTh;
+      if (accept && needSecond && s2 != PROJ_EMPTY && proj_level(b) == proj_level(s2) && (float)proj_dist(b) > nnratio * (float)proj_dist(s2)) accept = false;
+      // an accepting lane whose map element has observations takes its keypoint away from the later lanes of this round
+      FS_WAVE_SYNC();
+      if (accept && hasobs) atomicMin(&claim[proj_idx(b)], lane);
+      FS_WAVE_SYNC();
+      bool blocked = on && ranOut;
+      if (on && !ranOut) {
+        if (b != PROJ_EMPTY && claim[proj_idx(b)] < lane) blocked = true;
+        if (needSecond && s2 != PROJ_EMPTY && claim[proj_idx(s2)] < lane) blocked = true;
+      }
+      FS_WAVE_SYNC();
+      if (accept && hasobs) claim[proj_idx(b)] = 0x7fffffff;
+      FS_WAVE_SYNC();
+      const unsigned long long blockedM = __ballot(blocked) & active;
+      const int first = blockedM ? __ffsll((long long)blockedM) - 1 : 64;
+      const unsigned long long commitM = active & (first >= 64 ? ~0ull : ((1ull << first) - 1ull));
+      const bool mine = ((commitM >> lane) & 1ull) != 0ull;
+      if (mine && accept) {
+        const int bi = proj_idx(b);
+        atomicMax(&asg[bi], q);               // a later query overwrites an earlier one whose map element has no observation
+        if (hasobs) occ[bi] = 1;
+        if (kind == 0 && variant == 1 && checkOri && qLds) {
+          const int bin = rot_bin(qAux[qo + q], K[bi].angle);
+          pushBin[q] = (unsigned char)bin;
+          pushIdx[q] = bi;
+          atomicAdd(&hist[bin], 1);
+        }
+      }
+      nmatches += __popcll(__ballot(mine && accept));
+      active &= ~commitM;
+      haveSlow = haveSlow && !mine;
+      FS_WAVE_SYNC();
+      if (first < 64 && commitM == 0ull) {
+        // the lowest waiting lane has nothing in front of it: what blocks it is its own list, which ran out.  Scan its window again,
+        // exactly, against the occupancy as it stands (the whole wavefront works for that one query).
+        const int qs = base + first;
+        ProjPick pk;
+        if (kind == 0)
+          pk = proj_slow_points(variant, K, D, g, cs, ci, sf, invSig2, occ, list, claim, qPos[(qo + qs) * 2], qPos[(qo + qs) * 2 + 1],
+                                qLevel[qo + qs], qAux[qo + qs], qDesc + (qo + qs) * 32, th, mode, lane);
+        else
+          pk = proj_slow_lines(variant, KL, D, fn, g, cs, ci, occ, seen, list, claim, qPos + (qo + qs) * 4, qAux[qo + qs], qDesc + (qo + qs) * 32, th,
+                               lane);
+        FS_WAVE_SYNC();
+        for (int i = lane; i < cap; i += 64) claim[i] = 0x7fffffff;   // (the slow path used it as dist[])
+        FS_WAVE_SYNC();
+        if (lane == first) { slowBest = pk.best; slowSecond = pk.second; haveSlow = true; trunc = false; }
+        if (pk.best == PROJ_EMPTY) {   // nothing free in its window: the query is through
+          active &= ~(1ull << first);
+          if (lane == first) haveSlow = false;
+        }
+      }
+    }
+    (void)posW;
+  }
+  FS_WAVE_SYNC();
+  if (kind == 0 && variant == 1 && checkOri && qLds) {
+    int ind1, ind2, ind3;
+    const int myHist = lane < 30 ? hist[lane] : 0;
+    three_maxima_lanes(myHist, ind1, ind2, ind3);
+    int removed = 0;
+    for (int q = lane; q < nq; q += 64) {
+      const int b = pushBin[q];
+      if (b != 255 && b != ind1 && b != ind2 && b != ind3) { asg[pushIdx[q]] = -1; occ[pushIdx[q]] = 0; removed++; }   // mvpMapPoints[..] = NULL
+    }
+    nmatches -= wave_sum(removed);
+  }
+  FS_WAVE_SYNC();
+  if (!perQuery)
+    for (int i = lane; i < cap; i += 64) {
+      assignedAll[o + i] = i < n ? asg[i] : -1;
+      if (i < n) occupiedAll[o + i] = occ[i];
+    }
+  if (lane == 0) nmatchesOut[pair] = nmatches;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // The search inside LSDmatcher::Fuse (reference src/LSDmatcher.cpp:860-1002) with KeyFrame::GetLinesInArea
 // (src/KeyFrame.cc:647-683): brute force over the KeyFrame's lines -- lanes take the lines, the minimum of
 // (distance, line index) over the wave is the reference's first best.  One wave per frame walks the queries.
@@ -656,6 +1125,9 @@ __global__ void __launch_bounds__(64) k_sim3_agree(const int* n1Arr, const int* 
 }
 
 namespace {
+// A/B and test switch: 1 = the one-wavefront-per-frame kernels of rounds 1-5 (k_search_proj_points / k_search_proj_lines), 0 = prepass +
+// ordered resolve (default).  Same assignments either way (tests/test_frame_search.py runs both against the oracle).
+bool g_proj_serial = false;
 bool scale_tab(const float* sf, int nlevels, ScaleTab* t) {
   if (!sf || nlevels <= 0 || nlevels > 16) return false;
   for (int i = 0; i < 16; i++) t->v[i] = i < nlevels ? sf[i] : 0.f;
@@ -664,6 +1136,11 @@ bool scale_tab(const float* sf, int nlevels, ScaleTab* t) {
 }  // namespace
 
 extern "C" {
+
+plh_status plh_debug_set_proj_serial(int on) {
+  g_proj_serial = on != 0;
+  return PLH_OK;
+}
 
 plh_status plh_frame_assign_grid_batch_dev(const plh_keypoint* d_kps_un, const int32_t* d_n, int cap, int batch,
                                            const plh_grid_params* gp, int32_t* d_cell_start, int32_t* d_cell_items,
@@ -735,6 +1212,28 @@ static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, 
   if (q_lds > 12000) {
     set_error("%s: invalid argument (qcap <= 12000 with check_ori)", who);
     return PLH_ERR_INVALID;
+  }
+  if (!g_proj_serial) {
+    // round 6: prepass (a lane per query, all frames in parallel) + ordered resolve (a wavefront per frame): see k_proj_resolve
+    ProjTop* tops = nullptr;
+    const size_t bytes = (size_t)pairs * qcap * sizeof(ProjTop);
+    PLH_HIP(hipMallocAsync((void**)&tops, bytes, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_proj_points_prepass, dim3((qcap + 255) / 256, pairs), dim3(256), 0, (hipStream_t)stream, variant, d_kps_un, d_desc,
+                       (const int*)d_n, cap, *gp, d_cs, d_ci, sf, is2, (const uint8_t*)d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy,
+                       d_q_level, d_q_aux, d_q_desc, th, mode, nlevels, tops);
+    const size_t lds = (size_t)cap * (3 * 4 + 2) + (size_t)q_lds * (4 + 1) + 128 + 64;
+    ProjFrame F{d_kps_un, d_desc, nullptr, nullptr, 0, d_cs, d_ci};
+    plh_status st = lds_request(k_proj_resolve, lds, who);
+    if (st == PLH_OK) {
+      hipLaunchKernelGGL(k_proj_resolve, dim3(pairs), dim3(64), lds, (hipStream_t)stream, 0, variant, F, (const int*)d_n, cap, *gp, sf, is2,
+                         d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy, d_q_level, d_q_aux, d_q_desc, d_q_hasobs, th, nnratio, mode,
+                         check_ori, dist_th, nlevels, q_lds, (const ProjTop*)tops, d_assigned, d_nmatches);
+    }
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(tops, (hipStream_t)stream);
+    if (st != PLH_OK) return st;
+    if (le != hipSuccess) { set_error("%s: kernel launch -> %s", who, hipGetErrorString(le)); return PLH_ERR_HIP; }
+    return PLH_OK;
   }
   const size_t lds = (size_t)cap * (3 * 4 + 1) + (size_t)q_lds * (4 + 1) + 64;
   if (lds_request(k_search_proj_points, lds, who) != PLH_OK) return PLH_ERR_INVALID;
@@ -881,6 +1380,28 @@ static plh_status launch_proj_lines(int variant, const plh_keyline* d_kl, const 
       item_cap < cap) {
     set_error("%s: invalid argument (cap in 1..8000)", who);
     return PLH_ERR_INVALID;
+  }
+  if (!g_proj_serial) {
+    ProjTop* tops = nullptr;
+    PLH_HIP(hipMallocAsync((void**)&tops, (size_t)pairs * qcap * sizeof(ProjTop), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_proj_lines_prepass, dim3((qcap + 255) / 256, pairs), dim3(256), 0, (hipStream_t)stream, variant, d_kl, d_ldesc, d_linefn,
+                       (const int*)d_nl, cap, *gp, d_cs, d_ci, item_cap, (const uint8_t*)d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_seg,
+                       d_q_aux, d_q_desc, th, tops);
+    const size_t lds2 = (size_t)cap * (3 * 4 + 2) + 128 + 64;
+    ScaleTab none;
+    for (int i = 0; i < 16; i++) none.v[i] = 0.f;
+    ProjFrame F{nullptr, d_ldesc, d_kl, d_linefn, item_cap, d_cs, d_ci};
+    plh_status st = lds_request(k_proj_resolve, lds2, who);
+    if (st == PLH_OK) {
+      hipLaunchKernelGGL(k_proj_resolve, dim3(pairs), dim3(64), lds2, (hipStream_t)stream, 1, variant, F, (const int*)d_nl, cap, *gp, none, none,
+                         d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_seg, (const int32_t*)nullptr, d_q_aux, d_q_desc, d_q_hasobs, th, nnratio,
+                         0, 0, 80, 16, 0, (const ProjTop*)tops, d_assigned, d_nmatches);
+    }
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(tops, (hipStream_t)stream);
+    if (st != PLH_OK) return st;
+    if (le != hipSuccess) { set_error("%s: kernel launch -> %s", who, hipGetErrorString(le)); return PLH_ERR_HIP; }
+    return PLH_OK;
   }
   const size_t lds = (size_t)cap * (3 * 4 + 2) + 64;
   if (lds_request(k_search_proj_lines, lds, who) != PLH_OK) return PLH_ERR_INVALID;

@@ -145,7 +145,8 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     return PLH_ERR_INVALID;
   }
   if (p->lsd_refine != PLH_FRONTEND_REFINE_LIBRARY && p->lsd_refine != PLH_FRONTEND_REFINE_STD && p->lsd_refine != PLH_FRONTEND_REFINE_ADV) {
-    set_error("plh_frontend_create: lsd_refine must be PLH_FRONTEND_REFINE_LIBRARY (0), _STD (1) or _ADV (2)");
+    set_error("plh_frontend_create: lsd_refine = %d: must be PLH_FRONTEND_REFINE_LIBRARY (0), PLH_FRONTEND_REFINE_STD (0x100) or "
+              "PLH_FRONTEND_REFINE_ADV (0x101) -- not a PLH_LSD_REFINE_* value, and not round 5's 1 / 2", (int)p->lsd_refine);
     return PLH_ERR_INVALID;
   }
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
@@ -177,7 +178,7 @@ plh_status plh_frontend_create(const plh_frontend_params* p, const plh_vocab* vo
     // most the resident batch, so it takes the multi-wavefront kernel exactly when `around` is set)
     fe->around = batch <= 1024;
     FE_TRY(plh_line_set_grow_waves(pt.line, fe->around ? -1 : 0));
-    if (p->lsd_refine != PLH_FRONTEND_REFINE_LIBRARY) FE_TRY(plh_line_set_refine(pt.line, p->lsd_refine - 1));   // (1 + PLH_LSD_REFINE_*)
+    if (p->lsd_refine != PLH_FRONTEND_REFINE_LIBRARY) FE_TRY(plh_line_set_refine(pt.line, p->lsd_refine & 0xff));   // (0x100 | PLH_LSD_REFINE_*)
     FE_TRY(plh_line_reserve(pt.line, pt.B));   // workspace now: an out-of-memory condition belongs to create, not to the first step
     pt.ocap = plh_orb_capacity(pt.orb); pt.lcap = plh_line_capacity(pt.line);
     const size_t B1 = (size_t)pt.B + 1, oc = (size_t)pt.ocap, lc = (size_t)pt.lcap;

@@ -515,8 +515,17 @@ static plh_status line_prepare(plh_line* h, LineDeviceArgs& a, int batch, hipStr
         set_error("plh_line_extract: cannot allocate the log_gamma table (%d entries)", n);
         return PLH_ERR_ALLOC;
       }
+      // filled ONCE and synchronously (a later extract on another stream must not find a table that is still being written, and a
+      // failed fill must not leave a pointer behind that every later call would take for a filled table -- ADVICE r5)
       launch_lsd_lgamma_table(h->dLgamma, n, s);
-      PLH_LAUNCH_CHECK();
+      hipError_t le = hipGetLastError();
+      if (le == hipSuccess) le = hipStreamSynchronize(s);
+      if (le != hipSuccess) {
+        (void)hipFree(h->dLgamma);
+        h->dLgamma = nullptr;
+        set_error("plh_line_extract: filling the log_gamma table failed: %s", hipGetErrorString(le));
+        return PLH_ERR_HIP;
+      }
     }
     a.adv = reinterpret_cast<LsdAdvRec*>(h->dAdv);
     a.advAng = reinterpret_cast<float*>(static_cast<uint8_t*>(h->dAdv) + recBytes);

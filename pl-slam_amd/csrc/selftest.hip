@@ -171,21 +171,32 @@ plh_status plh_box_probe(int device, int iters, float ms[2]) {
   if (!ms || iters <= 0) return PLH_ERR_INVALID;
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   PLH_HIP(hipSetDevice(device));
+  // (a private non-blocking stream: the legacy null stream would serialise with every blocking stream of the process; everything
+  // acquired here is released on every path -- ADVICE r5)
   unsigned* d = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  PLH_HIP(hipMalloc((void**)&d, 4));
-  PLH_HIP(hipEventCreate(&e0));
-  PLH_HIP(hipEventCreate(&e1));
-  for (int k = 0; k < 2; k++) {
-    PLH_HIP(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL(k_box_probe, dim3(4096), dim3(256), 0, nullptr, d, iters);
-    PLH_HIP(hipEventRecord(e1, nullptr));
-    PLH_HIP(hipEventSynchronize(e1));
-    PLH_HIP(hipEventElapsedTime(&ms[k], e0, e1));
+  hipStream_t st = nullptr;
+  hipError_t e = hipMalloc((void**)&d, 4);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  for (int k = 0; k < 2 && e == hipSuccess; k++) {
+    e = hipEventRecord(e0, st);
+    if (e != hipSuccess) break;
+    hipLaunchKernelGGL(k_box_probe, dim3(4096), dim3(256), 0, st, d, iters);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms[k], e0, e1);
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(d);
+  if (st) (void)hipStreamDestroy(st);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (d) (void)hipFree(d);
+  if (e != hipSuccess) {
+    set_error("plh_box_probe: %s", hipGetErrorString(e));
+    return PLH_ERR_HIP;
+  }
   return PLH_OK;
 }
 

@@ -215,8 +215,8 @@ class FrontEndPipelined:
         fp.line_th, fp.line_nnratio = 50.0, 0.7
         fp.external_records = 1
         # this binding's argument: -1 = the library's default (plh_lsd_refine_default()), 0 = LSD_REFINE_STD, 1 = LSD_REFINE_ADV;
-        # the C struct: PLH_FRONTEND_REFINE_LIBRARY = 0 (what a zeroed struct holds), _STD = 1, _ADV = 2
-        fp.lsd_refine = 0 if int(lsd_refine) < 0 else 1 + int(lsd_refine)
+        # the C struct: PLH_FRONTEND_REFINE_LIBRARY = 0 (what a zeroed struct holds), _STD = 0x100, _ADV = 0x101
+        fp.lsd_refine = 0 if int(lsd_refine) < 0 else 0x100 | int(lsd_refine)
         h = C.c_void_p()
         P._check(L, L.plh_frontend_create(C.byref(fp), self.hvoc.h, batch, nsplit, device, C.byref(h)), "plh_frontend_create")
         self.h = h

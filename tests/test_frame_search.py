@@ -618,3 +618,73 @@ def test_emu_undistort_and_distinctive(plslam, oracle, synth, emu_lib):
 @pytest.mark.gpu
 def test_gpu_undistort_and_distinctive(plslam, oracle, synth):
     _check_post(plslam, oracle, synth, None, [2000, 1000, 0, 1], [1, 2, 3, 5, 8, 0, 33, 64, 65, 200, 700])
+
+
+# ------------------------------------------------------------------ round 6: prepass + ordered resolve against the one-wavefront kernels
+def _contention_queries(P, S, seed, f_last, f_cur, variant, dup, spread):
+    """Queries that fight for the same keypoints: every last-frame feature `dup` times (jittered by `spread` pixels), a third of the
+    map elements without observations (a later query overwrites their assignment), descriptors lightly corrupted so that the ratio
+    test of the map-point form decides both ways."""
+    rng = S.SplitMix64(seed)
+    q0 = _queries_points(P, S, seed + 1, f_last, f_cur, variant)
+    n = len(q0["valid"])
+    idx = np.concatenate([np.arange(n)] * dup)
+    rng_perm = np.argsort(rng.uniform(len(idx)), kind="stable")
+    idx = idx[rng_perm]
+    q = {k: np.ascontiguousarray(v[idx]) for k, v in q0.items()}
+    key = "xy" if variant == "mp" else "uv"
+    q[key] = (q[key] + rng.uniform(len(idx) * 2, -spread, spread).reshape(-1, 2)).astype(np.float32)
+    q["hasobs"] = (rng.uniform(len(idx)) < 0.66).astype(np.uint8)
+    flip = rng.uniform(len(idx)) < 0.5
+    q["desc"][flip] ^= (rng.randint(int(flip.sum()) * 32, 0, 256).astype(np.uint8).reshape(-1, 32) & 0x03)
+    return q
+
+
+def _parallel_equals_serial(P, O, S, lib, n, nl, dups):
+    H = P.load(lib)
+    H.plh_debug_set_proj_serial.argtypes = [I]
+    gp = _gp(P)
+    try:
+        for seed, dup in dups:
+            f1, f2, _, _ = make_frame_pair(P, S, seed, n, nl=nl, move=3.0)
+            fs = P.FrameSearch(gp, SCALE, [f2, f2], lib=lib)
+            occ0 = (S.SplitMix64(seed + 9).uniform(len(f2["kps"])) < 0.15).astype(np.uint8)
+            locc0 = (S.SplitMix64(seed + 10).uniform(len(f2["keylines"])) < 0.15).astype(np.uint8)
+            qm = [_contention_queries(P, S, seed + 20 + k, f1, f2, "mp", dup, 3.0 + 4 * k) for k in range(2)]
+            qf = [_contention_queries(P, S, seed + 30 + k, f1, f2, "frame", dup, 2.0 + 6 * k) for k in range(2)]
+            ql = []
+            for k in range(2):
+                base = _queries_lines(P, S, seed + 40 + k, f1, "ml")
+                rep = np.concatenate([np.arange(len(base["valid"]))] * dup)
+                qq = {kk: np.ascontiguousarray(v[rep]) for kk, v in base.items()}
+                qq["hasobs"] = (S.SplitMix64(seed + 50 + k).uniform(len(rep)) < 0.6).astype(np.uint8)
+                qq["length"] = np.ascontiguousarray(f1["keylines"]["lineLength"][rep].astype(np.float32))
+                ql.append(qq)
+            res = {}
+            for serial in (1, 0):
+                H.plh_debug_set_proj_serial(serial)
+                out = [fs.SearchByProjectionMapPoints(qm, [occ0, occ0], th=3.0, nnratio=0.8),
+                       fs.SearchByProjectionMapPoints(qm, [occ0, occ0], th=1.0, nnratio=0.9),
+                       fs.SearchByProjectionLastFrame(qf, [occ0, occ0], th=15.0, mode=0, checkOri=True),
+                       fs.SearchByProjectionLastFrame(qf, [occ0, occ0], th=7.0, mode=1, checkOri=False),
+                       fs.SearchByProjectionKeyFrame([dict(q, level=q["octave"]) for q in qf], [occ0, occ0], th=10.0, ORBdist=64, checkOri=True),
+                       fs.SearchByProjectionSim3([dict(q, level=q["octave"]) for q in qf], [occ0, occ0], th=10, TH_LOW=50),
+                       fs.FuseSearch([dict(q, level=q["octave"]) for q in qf], np.float32(1.0) / (SCALE * SCALE), th=3.0, TH_LOW=50),
+                       fs.LineSearchByProjectionMapLines(ql, [locc0, locc0], th=3.0, nnratio=0.9),
+                       fs.LineSearchByProjectionLastFrame(ql, [locc0, locc0], th=12.0)]
+                res[serial] = out
+            for k, (a, b) in enumerate(zip(res[1], res[0])):
+                for u, v in zip(a, b):
+                    assert (np.asarray(u) == np.asarray(v)).all(), "search %d, seed %d, %d-fold queries: prepass + resolve differs from the sequential kernel" % (k, seed, dup)
+            assert res[0][0][1].min() > 0 and res[0][2][1].min() > 0 and res[0][7][1].min() > 0
+    finally:
+        H.plh_debug_set_proj_serial(0)
+
+
+def test_emu_proj_prepass_resolve_equals_sequential(plslam, oracle, synth, emu_lib):
+    _parallel_equals_serial(plslam, oracle, synth, emu_lib, 300, 60, [(71, 1), (72, 5), (73, 13)])
+
+
+@pytest.mark.gpu
+def test_gpu_proj_prepass_resolve_equals_sequential(plslam, oracle, synth):
+    _parallel_equals_serial(plslam, oracle, synth, None, 1500, 200, [(81, 1), (82, 4), (83, 13), (84, 40)])

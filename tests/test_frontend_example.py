@@ -183,8 +183,10 @@ def test_emu_frontend_matches_the_oracle(plslam, oracle, synth, emu_lib):
     fp.struct_size = C.sizeof(P.FrontendParams) - 4
     assert L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)) == 1 and not h.value  # PLH_ERR_INVALID
     fp.struct_size = C.sizeof(P.FrontendParams)
-    fp.lsd_refine = 7
-    assert L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)) == 1 and not h.value  # PLH_ERR_INVALID
+    for wrong in (7, 1, 2):   # 1 = PLH_LSD_REFINE_ADV assigned out of habit (round 4's encoding), 1 / 2 = round 5's: refused, not guessed
+        fp.lsd_refine = wrong
+        assert L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)) == 1 and not h.value  # PLH_ERR_INVALID
+        assert b"PLH_FRONTEND_REFINE" in L.plh_last_error()
     fp.lsd_refine = 0
     P._check(L, L.plh_frontend_create(C.byref(fp), hv.h, B, ns, 0, C.byref(h)), "plh_frontend_create")
     try:

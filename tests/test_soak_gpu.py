@@ -164,7 +164,9 @@ def test_soak_distinct_frames(plslam, oracle, synth, rows, cols, nfeat, refine):
             L.plh_debug_grow_prof(out, 1)
             got = _gpu_lines(plslam, frames, waves, refine, lib=prof)
             L.plh_debug_grow_prof(out, 0)
-            assert all(len(g[3]) == len(r[5]) and (g[3] == r[5]).all() for g, r in zip(got, ref))
+            bad = [b for b, (g, r) in enumerate(zip(got, ref)) if not (len(g[3]) == len(r[5]) and (g[3] == r[5]).all())]
+            assert not bad, "counter build, waves %d: LSD segments of %d frames differ from the oracle (first: frame %d, %d vs %d segments)" % (
+                waves, len(bad), bad[0], len(got[bad[0]][3]), len(ref[bad[0]][5]))
             # the density screen: every verdict of the counter build is checked against the exact density in the kernel
             assert out[39] == 0, "waves %d: %d verdicts of the density screen contradict the exact density" % (waves, out[39])
             cover += ("  [waves %d] steps %d, accepted pixels %d, resolve passes %d, mispredictions %d, lanes decided by fastAtan2 %d "
