@@ -687,4 +687,4 @@ def test_emu_proj_prepass_resolve_equals_sequential(plslam, oracle, synth, emu_l
 
 @pytest.mark.gpu
 def test_gpu_proj_prepass_resolve_equals_sequential(plslam, oracle, synth):
-    _parallel_equals_serial(plslam, oracle, synth, None, 1500, 200, [(81, 1), (82, 4), (83, 13), (84, 40)])
+    _parallel_equals_serial(plslam, oracle, synth, None, 900, 200, [(81, 1), (82, 4), (83, 13)])   # (13 x 900 < 12000: the bound of the forms with a rotation histogram)
