@@ -1229,6 +1229,21 @@ __device__ __forceinline__ void mw_pause() { spin_pause(); }
 __device__ __forceinline__ void mw_release() { wg_release(); }
 __device__ __forceinline__ void mw_acquire() { wg_acquire(); }
 
+// -DPLH_MW_JITTER (a stress build for tests / tools, never the product): pseudo-random pauses at the hand-over points of the protocol, so
+// that interleavings a timing-stable build never produces are exercised (round 6: the counter build of k_lsd_grow_mw16 -- much slower per
+// transaction -- disagreed with the product on a handful of the soak's frames, different ones from run to run).
+#if defined(PLH_MW_JITTER) && !defined(HIPEMU)
+__device__ __forceinline__ void mw_jitter(unsigned salt) {
+  const unsigned t = (unsigned)__builtin_amdgcn_s_memtime() * 2654435761u + salt * 40503u;
+  const unsigned k = (t >> 13) & 15u;
+  if (k < 6u) {
+    for (unsigned i = 0; i <= ((t >> 20) & 31u); i++) __builtin_amdgcn_s_sleep(64);
+  }
+}
+#else
+__device__ __forceinline__ void mw_jitter(unsigned) {}
+#endif
+
 __device__ __forceinline__ bool mw_give_up(int* ctl, unsigned& polls, int* status) {
   if (++polls > MW_SPIN_LIMIT) {
     mw_st(&ctl[MWC_ABORT], 1);
@@ -1375,6 +1390,7 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
       // post h failed: run it again below (general path handles both forms)
     }
     // ---- one post, general path
+    mw_jitter((unsigned)h + 101u);
     const MwPost* e = &sh.pend[h & (MW_N - 1)];
     const uint4* e4 = reinterpret_cast<const uint4*>(e);
     const uint4 q0 = e4[0], q1 = e4[1], q2 = e4[2], q3 = e4[3];
@@ -1643,6 +1659,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       continue;
     }
     polls = 0;
+    mw_jitter((unsigned)s);
     MW_TRACE(wv, lane, 1, s);   // popped
     // ---- the transaction
     const uint32_t seedPk = ent.x;
@@ -1696,6 +1713,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
       MW_TRACE(wv, lane, 2, s);   // run begins
       const LsdTxn t = lsd_txn_mw(c, gs, a, regBase + off, seedPk, seedRec, ent.y, ent.z, ent.w);
       grow_lane_fence<true>();
+      mw_jitter((unsigned)s + 211u);
       MW_TRACE(wv, lane, 3, t.logLen);   // run ends
       // through: take the private marks back (the plane is clean for the next transaction) and look once more whether an
       // older transaction has committed a pixel of the log meanwhile
@@ -1764,6 +1782,7 @@ __device__ __forceinline__ void lsd_grow_frame_mw(const LineDeviceArgs& a, unsig
         else if (lane < MWP_ASM) pw = lane == MWP_SEG ? pAng : 0u;
         else if (lane - MWP_ASM < min(pAsm, 3)) pw = c.asmList[lane - MWP_ASM];
       }
+      mw_jitter((unsigned)s + 17u);
       MW_TRACE(wv, lane, 4, pMode);   // posting
       if (!(pFlags & 8u)) mw_release();   // a log in global memory is complete before its post is visible
       if (lane < MW_PEND_WORDS) sh.pend[s & (MW_N - 1)].w[lane] = pw;

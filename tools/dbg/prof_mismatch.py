@@ -11,7 +11,8 @@ import test_soak_gpu as T
 P, S = _util.plslam(), _util.synth()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 frames = T.soak_frames(S, 480, 640, N)
-prof = os.path.join(ROOT, "pl-slam_amd", "libplslam_hip_prof.so")
+prof = os.path.join(ROOT, "pl-slam_amd", sys.argv[2] if len(sys.argv) > 2 else "libplslam_hip_prof.so")
+print("library under test:", os.path.basename(prof), flush=True)
 
 
 def segs(fr, waves, lib):
@@ -24,7 +25,7 @@ print("product: automatic == one wavefront per frame on %d of %d frames" % (sum(
 for run in range(3):
     got = segs(frames, -1, prof)
     bad = [i for i, (a, b) in enumerate(zip(got, ref)) if not (len(a) == len(b) and (a == b).all())]
-    print("counter build, %d x 8 (k_lsd_grow_mw16), run %d: %d frames differ: %s" % (N, run, len(bad), bad), flush=True)
+    print("build under test, %d x 8 (k_lsd_grow_mw16), run %d: %d frames differ: %s" % (N, run, len(bad), bad), flush=True)
     for i in bad[:2]:
         a, b = got[i], ref[i]
         if len(a) == len(b):
@@ -36,10 +37,10 @@ bad = []
 for k in range(0, N, 256):
     got = segs(frames[k:k + 256], -1, prof)
     bad += [k + i for i, (a, b) in enumerate(zip(got, ref[k:k + 256])) if not (len(a) == len(b) and (a == b).all())]
-print("counter build, %d x (256 x 8) (k_lsd_grow_mw, the roomy compile): %d frames differ: %s" % (N // 256, len(bad), bad), flush=True)
+print("build under test, %d x (256 x 8) (k_lsd_grow_mw, the roomy compile): %d frames differ: %s" % (N // 256, len(bad), bad), flush=True)
 got = segs(frames, 0, prof)
 bad = [i for i, (a, b) in enumerate(zip(got, ref)) if not (len(a) == len(b) and (a == b).all())]
-print("counter build, one wavefront per frame (k_lsd_grow): %d frames differ: %s" % (len(bad), bad), flush=True)
+print("build under test, one wavefront per frame (k_lsd_grow): %d frames differ: %s" % (len(bad), bad), flush=True)
 for rep in range(3):
     got = segs(frames, -1, None)
     bad = [i for i, (a, b) in enumerate(zip(got, ref)) if not (len(a) == len(b) and (a == b).all())]
