@@ -138,6 +138,68 @@ __global__ void __launch_bounds__(256) k_project_points(const plh_frame_view* vi
   front[o] = fr; uv[o * 2] = u; uv[o * 2 + 1] = w;
 }
 
+// The gates the back end's pose-driven searches apply to every map point between the transform and the window lookup
+// (plh_map_point_gates): the loops of ORBmatcher.cc:1591-1640 (relocalisation), :337-395 (loop closing), :945-975 / :1096-1128 (both
+// Fuse overloads), :1206-1290 / :1313-1365 (SearchBySim3, both directions), one thread per map point.
+__global__ void __launch_bounds__(256) k_map_point_gates(plh_point_gates g, int n, const float* pos, const float* normal,
+                                                         const float* minDist, const float* maxDist, uint8_t* valid, float* uv, int* level) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint8_t ok = 0;
+  float u = 0.f, w = 0.f;
+  int lvl = 0;
+  if (valid[i]) {
+    const plh_frame_view& v = g.view;
+    const float P[3] = {pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]};
+    float Pc[3];
+    to_camera(v, P, Pc);
+    if (g.flags & PLH_GATE_SECOND) {   // pTarget = sR21 * p3Dc1 + t21: a second gemm on the rounded camera point
+      float Q[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double s = (double)g.R2[r * 3] * (double)Pc[0];
+        s += (double)g.R2[r * 3 + 1] * (double)Pc[1];
+        s += (double)g.R2[r * 3 + 2] * (double)Pc[2];
+        Q[r] = (float)(s + (double)g.t2[r]);
+      }
+      Pc[0] = Q[0]; Pc[1] = Q[1]; Pc[2] = Q[2];
+    }
+    bool in = !((g.flags & PLH_GATE_Z) && Pc[2] < 0.0f);
+    if (in) {
+      const float invz = (g.flags & PLH_GATE_INVZ_DOUBLE) ? (float)(1.0 / (double)Pc[2]) : 1.0f / Pc[2];
+      if (g.flags & PLH_GATE_UV_NORMALISED) {
+        const float x = Pc[0] * invz;
+        const float y = Pc[1] * invz;
+        u = v.fx * x + v.cx;
+        w = v.fy * y + v.cy;
+      } else {
+        u = v.fx * Pc[0] * invz + v.cx;
+        w = v.fy * Pc[1] * invz + v.cy;
+      }
+      if (g.flags & PLH_GATE_KEYFRAME_BOUNDS) in = u >= v.min_x && u < v.max_x && w >= v.min_y && w < v.max_y;   // KeyFrame::IsInImage
+      else in = !(u < v.min_x || u > v.max_x) && !(w < v.min_y || w > v.max_y);
+    }
+    if (in) {
+      const float PO[3] = {P[0] - v.Ow[0], P[1] - v.Ow[1], P[2] - v.Ow[2]};
+      const float dist = (g.flags & PLH_GATE_DIST_OF_TARGET) ? norm3(Pc) : norm3(PO);
+      in = !(dist < minDist[i] || dist > maxDist[i]);
+      if (in && (g.flags & PLH_GATE_NORMAL)) {
+        const float N[3] = {normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]};
+        in = !(dot3(PO, N) < 0.5 * (double)dist);
+      }
+      if (in) {
+        int nScale = predict_scale(maxDist[i], dist, v.log_scale_factor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= v.n_scale_levels) nScale = v.n_scale_levels - 1;
+        lvl = nScale;
+        ok = 1;
+      }
+    }
+  }
+  if (!ok) { u = 0.f; w = 0.f; }
+  valid[i] = ok; uv[i * 2] = u; uv[i * 2 + 1] = w; level[i] = lvl;
+}
+
 __global__ void __launch_bounds__(256) k_frustum_points(const plh_frame_view* views, const int* nArr, int qcap, const float* pos,
                                                         const float* normal, const float* minDist, const float* maxDist,
                                                         float cosLimit, uint8_t* valid, float* uv, int* level, float* viewcos) {
@@ -307,6 +369,46 @@ plh_status plh_frame_project_points_batch_dev(const plh_frame_view* d_views, int
                      d_pos, form, d_front, d_uv);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
+}
+
+
+plh_status plh_map_point_gates_dev(const plh_point_gates* gates, int n, const float* d_pos, const float* d_normal, const float* d_min_dist,
+                                   const float* d_max_dist, uint8_t* d_valid, float* d_uv, int32_t* d_level, void* stream) {
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  if (!gates || n <= 0 || !d_pos || !d_min_dist || !d_max_dist || !d_valid || !d_uv || !d_level ||
+      ((gates->flags & PLH_GATE_NORMAL) && !d_normal)) {
+    set_error("plh_map_point_gates_dev: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(k_map_point_gates, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *gates, n, d_pos, d_normal, d_min_dist,
+                     d_max_dist, d_valid, d_uv, (int*)d_level);
+  PLH_LAUNCH_CHECK();
+  return PLH_OK;
+}
+
+plh_status plh_map_point_gates(const plh_point_gates* gates, int n, const float* pos, const float* normal, const float* min_dist,
+                               const float* max_dist, uint8_t* valid, float* uv, int32_t* level, int device) {
+  if (!gates || n < 0 || (n > 0 && (!pos || !min_dist || !max_dist || !valid || !uv || !level)) ||
+      (n > 0 && (gates->flags & PLH_GATE_NORMAL) && !normal)) {
+    set_error("plh_map_point_gates: invalid argument");
+    return PLH_ERR_INVALID;
+  }
+  if (n == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  Stager st;
+  const size_t N = (size_t)n;
+  plh_status rc = st.begin(device, 2 * Stager::padded(N * 12) + 3 * Stager::padded(N * 4) + Stager::padded(N) + Stager::padded(N * 8));
+  if (rc != PLH_OK) return rc;
+  const float* dPos = st.in(pos, N * 3);
+  const float* dNormal = (gates->flags & PLH_GATE_NORMAL) ? st.in(normal, N * 3) : nullptr;
+  const float* dMin = st.in(min_dist, N);
+  const float* dMax = st.in(max_dist, N);
+  uint8_t* dValid = st.inout(valid, N);
+  float* dUv = st.out(uv, N * 2);
+  int32_t* dLevel = st.out(level, N);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  if ((rc = plh_map_point_gates_dev(gates, n, dPos, dNormal, dMin, dMax, dValid, dUv, dLevel, st.stream())) != PLH_OK) return rc;
+  return st.download();
 }
 
 }  // extern "C"

@@ -1220,6 +1220,14 @@ constexpr int MW_PEND_WORDS = 16;   // a posted transaction (MwPost)
 constexpr unsigned MW_SPIN_LIMIT = 1u << 26;
 constexpr int MW_WAVE_LDS = LSD_RING * 4 + (LSD_GS_D + 1) * 8 + 8 * 4 + MW_ASM_CAP * 4 + 16;   // per wavefront: ring (aliased by T) + GrowState + assumed-used list + its count
 
+// -DPLH_MW_PARANOID (a checking build for tools, never the product): the commit re-runs EVERY posted transaction against the committed
+// map -- the run the sequential algorithm makes at that point -- publishes that run, and compares it with what was posted whenever the
+// post passed the commit's validation: [0] validated inline posts compared ([10]: general posts -- kept or refined regions), [1] of them different (the protocol's claim is that this is 0),
+// [2..9] the first offender: frame, sequence number, seed, flags, posted final count, exact final count, posted keep, exact keep.
+#if defined(PLH_MW_PARANOID)
+__device__ unsigned g_mw_paranoid[16];
+#endif
+
 // the control words in LDS, the pause of a polling loop and the two fences: plh_shims.h (lds_*, spin_pause, wg_release, wg_acquire)
 __device__ __forceinline__ int mw_ld(const int* p) { return lds_load(p); }
 __device__ __forceinline__ void mw_st(int* p, int v) { lds_store(p, v); }
@@ -1363,7 +1371,12 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
     const unsigned flags = rdy ? sh.pend[slot].w[MWP_FLAGS] : 0u;
     const unsigned long long inlM = wballot(rdy && (flags & 8u) != 0u && j == 0);
     const unsigned long long gap = ~inlM & 0x0101010101010101ull;
+#if defined(PLH_MW_PARANOID) && PLH_MW_PARANOID + 0 == 1
+    const int nb = 0;   // every post goes through the general path below, one by one
+    (void)gap;
+#else
     const int nb = gap ? (__ffsll((long long)gap) - 1) >> 3 : 8;   // leading inline posts
+#endif
     if (nb > 0) {
       const int nAcc = (int)(flags >> 24), nAsm = (int)((flags >> 16) & 255u);
       const bool has = g < nb && j < nAcc + nAsm, isAcc = j < nAcc, spec = (flags & 2u) != 0u;
@@ -1399,6 +1412,59 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
     const bool inl = (fl & 8u) != 0u;
     const int wv = (int)((fl >> 8) & 255u);
     bool bad = inl;   // an inline post gets here only when the batch found it invalid
+#if defined(PLH_MW_PARANOID)
+    // the exact run of post h against the committed map, compared with what was posted (before anything of it is published)
+    auto paranoid = [&](bool validated) {
+      int pFin = 0;
+      bool pKeep = false;
+      if (inl) {
+        // validity of an inline post as the batch path would judge it (its pixels travel in the post)
+        const int nAcc = (int)(fl >> 24), nAsm = (int)((fl >> 16) & 255u);
+        const unsigned w5[8] = {q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x};
+        bool ib = false;
+        for (int k = 0; k < nAcc + nAsm && k < 8; k++) {
+          const bool u = (ch.P[pk_lin(ch, w5[k])] & LSD_USED) != 0u;
+          if ((fl & 2u) && (k < nAcc ? u : !u)) ib = true;
+        }
+        validated = !ib;
+        pFin = nAcc;
+      } else if ((fl & 1u) || asmLen) {
+        pFin = (fl & 1u) ? (int)bcast_u32(q2.x, 0) : 0;
+        pKeep = (fl & 4u) != 0u;
+      } else {
+        validated = false;   // a retired seed: nothing was run
+      }
+      const uint32_t seedPk2 = bcast_u32(q0.y, 0);
+      const unsigned seedRec2 = bcast_u32(ch.P[pk_lin(ch, seedPk2)], 0);
+      if (validated && !(seedRec2 & LSD_USED) && (inl ? (fl >> 24) != 0u : (fl & 1u) != 0u)) {
+        ch.hTag = (unsigned)h % 65535u + 1u;
+        ch.hWin = 0;
+        const LsdTxn t2 = lsd_txn_mw(ch, gs, a, drainReg, seedPk2, seedRec2, bcast_u32(q0.z, 0), bcast_u32(q0.w, 0), bcast_u32(q1.x, 0));
+        grow_lane_fence<true>();
+        bool diff = t2.finCnt != pFin || t2.keep != pKeep;
+        if (!diff) {
+          if (inl) {
+            const unsigned w5[8] = {q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x};
+            for (int k = 0; k < pFin && k < 8; k++) diff = diff || drainReg[t2.finBase + k] != w5[k];
+          } else {
+            const uint32_t* plog = frameReg + (long long)wv * a.mwRegStride + bcast_u32(q1.y, 0) + (int)bcast_u32(q1.w, 0);
+            bool d = false;
+            for (int i = lane; i < pFin; i += 64) d = d || plog[i] != drainReg[t2.finBase + i];
+            diff = __ballot(d) != 0ull || (pKeep && q2.y != __float_as_uint(t2.ang));
+          }
+        }
+        for (int i = lane; i < t2.finCnt; i += 64) ch.M[pk_lin(ch, drainReg[t2.finBase + i])] = 0;   // (a re-run below marks them again)
+        grow_lane_fence<true>();
+        if (lane == 0) {
+          atomicAdd(&g_mw_paranoid[inl ? 0 : 10], 1u);
+          if (diff && atomicAdd(&g_mw_paranoid[1], 1u) == 0u) {
+            g_mw_paranoid[2] = blockIdx.x; g_mw_paranoid[3] = (unsigned)h; g_mw_paranoid[4] = seedPk2; g_mw_paranoid[5] = fl;
+            g_mw_paranoid[6] = (unsigned)pFin; g_mw_paranoid[7] = (unsigned)t2.finCnt; g_mw_paranoid[8] = pKeep; g_mw_paranoid[9] = t2.keep;
+          }
+        }
+      }
+    };
+#endif
     if (!inl && ((fl & 1u) || asmLen)) {
       const uint32_t* log = frameReg + (long long)wv * a.mwRegStride + bcast_u32(q1.y, 0);
       const int logLen = (int)bcast_u32(q1.z, 0), finBase = (int)bcast_u32(q1.w, 0), finCnt = (int)bcast_u32(q2.x, 0);
@@ -1438,6 +1504,12 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
 #endif
         bad = __ballot(bad || badA) != 0ull;
       }
+#if defined(PLH_MW_PARANOID)
+      paranoid(!bad);
+#if PLH_MW_PARANOID + 0 == 1
+      bad = true;
+#endif
+#endif
       if (!bad) {
         if (fl & 1u) {
           if (oneGo) {
@@ -1466,6 +1538,12 @@ __device__ void mw_drain(GrowCtx& ch, const GrowState& gs, const LineDeviceArgs&
         }
       }
     }
+#if defined(PLH_MW_PARANOID)
+    if (inl || !((fl & 1u) || asmLen)) paranoid(!bad);
+#if PLH_MW_PARANOID + 0 == 1
+    bad = true;   // publish the exact run in every case (-DPLH_MW_PARANOID=2: compare only, the post is published the usual way)
+#endif
+#endif
     if (bad) {
       // an older transaction took a pixel this one accepted (or left one this one counted on): run it again here --
       // everything older is committed, so this is the reference's run
@@ -2385,6 +2463,18 @@ extern "C" __attribute__((visibility("default"))) int plh_debug_mw_trace(unsigne
   return (int)n;
 }
 #endif
+#endif
+#if defined(PLH_MW_PARANOID) && !defined(HIPEMU)
+extern "C" __attribute__((visibility("default"))) int plh_debug_mw_paranoid(unsigned* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mw_paranoid), 64) != hipSuccess) return 1;
+  if (reset) {
+    unsigned z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mw_paranoid), z, 64) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+#if defined(PLH_GROW_PROF)
 extern "C" __attribute__((visibility("default"))) int plh_debug_grow_prof(unsigned long long* out40, int reset) {
 #if defined(HIPEMU)
   memcpy(out40, g_grow_prof, sizeof(g_grow_prof));
