@@ -624,6 +624,41 @@ PLH_API plh_status plh_frame_is_in_frustum_lines_batch_dev(const plh_frame_view*
                                                            const float* d_pos6, const float* d_normal, const float* d_min_dist,
                                                            const float* d_max_dist, float viewing_cos_limit, uint8_t* d_valid,
                                                            float* d_seg, int32_t* d_level, float* d_viewcos, void* stream);
+/* The gates the back end's pose-driven searches apply to every map point between the pose transform and the window lookup -- the loops
+ * in front of the searches of ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) ORBmatcher.cc:1591-1640,
+ * SearchByProjection(KeyFrame*, Scw, ...) :337-395, Fuse(KeyFrame*, vpMapPoints, th) :945-975, Fuse(KeyFrame*, Scw, ...) :1096-1128 and
+ * SearchBySim3 :1206-1290, :1313-1365 -- for all map points of a call at once:
+ *     Pc = Rcw*P + tcw                       (one gemm, double accumulation; PLH_GATE_SECOND: then Pc = R2*Pc + t2, SearchBySim3's sR21 / t21)
+ *     PLH_GATE_Z: skip when Pc.z < 0
+ *     invz = 1 / Pc.z in float, or (float)(1.0 / z) with PLH_GATE_INVZ_DOUBLE
+ *     u = fx*Pc.x*invz + cx, or x = Pc.x*invz; u = fx*x + cx with PLH_GATE_UV_NORMALISED
+ *     inside [min, max] (Frame: u < min || u > max skips) or, PLH_GATE_KEYFRAME_BOUNDS, KeyFrame::IsInImage (min <= u < max)
+ *     dist = |P - Ow| (cv::norm, double accumulation), or |Pc| with PLH_GATE_DIST_OF_TARGET;  min_dist_inv <= dist <= max_dist_inv
+ *           (what MapPoint::GetMinDistanceInvariance / GetMaxDistanceInvariance return: 0.8f*mfMinDistance, 1.2f*mfMaxDistance)
+ *     PLH_GATE_NORMAL: (P - Ow) . normal >= 0.5*dist
+ *     max_dist (mfMaxDistance itself, may be NULL): level = MapPoint::PredictScale(dist, pKF / pF) = ceil(logf(max_dist / dist) /
+ *           log_scale_factor) clamped to [0, n_scale_levels).  mfMaxDistance is a protected member: a host that reaches the map through
+ *           the reference's classes passes NULL and calls pMP->PredictScale(dist[i], ..) on the points that pass (dist is returned).
+ * valid[i] (in: the caller's map-side gates -- isBad(), already found, an empty descriptor; out: those && the gates above), uv, level
+ * are q_valid / q_uv / q_level of plh_orb_search_by_projection_kf / _sim3, plh_orb_fuse_search and plh_orb_search_by_sim3. */
+#define PLH_GATE_Z 1
+#define PLH_GATE_INVZ_DOUBLE 2
+#define PLH_GATE_UV_NORMALISED 4
+#define PLH_GATE_KEYFRAME_BOUNDS 8
+#define PLH_GATE_DIST_OF_TARGET 16
+#define PLH_GATE_NORMAL 32
+#define PLH_GATE_SECOND 64
+typedef struct plh_point_gates {
+  plh_frame_view view;     /* pose, intrinsics, image bounds, mfLogScaleFactor / mnScaleLevels of the camera searched in */
+  float R2[9], t2[3];      /* PLH_GATE_SECOND */
+  int32_t flags;           /* PLH_GATE_* */
+} plh_point_gates;
+PLH_API plh_status plh_map_point_gates(const plh_point_gates* gates, int n, const float* pos, const float* normal, const float* min_dist_inv,
+                                       const float* max_dist_inv, const float* max_dist, uint8_t* valid, float* uv, float* dist,
+                                       int32_t* level, int device);
+PLH_API plh_status plh_map_point_gates_dev(const plh_point_gates* gates, int n, const float* d_pos, const float* d_normal,
+                                           const float* d_min_dist_inv, const float* d_max_dist_inv, const float* d_max_dist,
+                                           uint8_t* d_valid, float* d_uv, float* d_dist, int32_t* d_level, void* stream);
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:249-314) / MapLine twin (MapLine.cpp:256-330) for many map
  * elements at once: set s owns the descriptor rows [d_offsets[s], d_offsets[s+1]) of d_desc (32 bytes each, <= 1024 rows);
  * d_best[s] = row (relative to the set) with the least median Hamming distance to the others, -1 for an empty set. */

@@ -793,3 +793,60 @@ extern "C" void plo_frame_project_points(const float view[24], int form, int n, 
     }
   }
 }
+
+// The gates in front of the back end's pose-driven searches, one restatement with the differences between the five loops as flags
+// (reference src/ORBmatcher.cc: relocalisation SearchByProjection :1591-1640 = flags 2; loop-closing SearchByProjection :337-395 =
+// 1|4|8|32; Fuse(pKF, vpMapPoints) :945-975 = 1|4|8|32; Fuse(pKF, Scw, ..) :1096-1128 = 1|2|4|8|32; SearchBySim3 :1206-1290 /
+// :1313-1365 = 1|2|4|8|16|64).  Flag values = PLH_GATE_* of include/plslam_hip.h.  valid: in = the caller's map-side gates.
+extern "C" void plo_map_point_gates(const float view[24], int nlevels, const float R2t2[12], int flags, int n, const float* pos,
+                                    const float* normal, const float* min_dist_inv, const float* max_dist_inv, const float* max_dist,
+                                    uint8_t* valid, float* uv, float* dist_out, int32_t* level) {
+  View v;
+  memcpy(&v, view, sizeof(v));
+  for (int i = 0; i < n; i++) {
+    const bool pre = valid[i] != 0;
+    valid[i] = 0; uv[2 * i] = uv[2 * i + 1] = 0.f; level[i] = 0; dist_out[i] = 0.f;
+    if (!pre) continue;
+    const float* P = pos + 3 * i;
+    float Pc[3];
+    to_camera(v, P, Pc);                       // cv::Mat p3Dc = Rcw*p3Dw + tcw
+    if (flags & 64) {                          // cv::Mat p3Dc2 = sR21*p3Dc1 + t21
+      View w2;
+      memcpy(w2.R, R2t2, 9 * sizeof(float));
+      memcpy(w2.t, R2t2 + 9, 3 * sizeof(float));
+      float Q[3];
+      to_camera(w2, Pc, Q);
+      Pc[0] = Q[0]; Pc[1] = Q[1]; Pc[2] = Q[2];
+    }
+    if ((flags & 1) && Pc[2] < 0.0f) continue;
+    const float invz = (flags & 2) ? (float)(1.0 / Pc[2]) : 1 / Pc[2];
+    float u, w;
+    if (flags & 4) {
+      const float x = Pc[0] * invz;
+      const float y = Pc[1] * invz;
+      u = v.fx * x + v.cx;
+      w = v.fy * y + v.cy;
+    } else {
+      u = v.fx * Pc[0] * invz + v.cx;
+      w = v.fy * Pc[1] * invz + v.cy;
+    }
+    if (flags & 8) {
+      if (!(u >= v.minX && u < v.maxX && w >= v.minY && w < v.maxY)) continue;   // KeyFrame::IsInImage
+    } else {
+      if (u < v.minX || u > v.maxX) continue;
+      if (w < v.minY || w > v.maxY) continue;
+    }
+    const float PO[3] = {P[0] - v.Ow[0], P[1] - v.Ow[1], P[2] - v.Ow[2]};
+    const float dist = (flags & 16) ? norm3(Pc) : norm3(PO);
+    if (dist < min_dist_inv[i] || dist > max_dist_inv[i]) continue;   // Get{Min,Max}DistanceInvariance()
+    if ((flags & 32) && dot3(PO, normal + 3 * i) < 0.5 * dist) continue;
+    int nScale = 0;
+    if (max_dist) {
+      const float ratio = max_dist[i] / dist;    // MapPoint::PredictScale(dist, pKF | pF) (MapPoint.cc:394-424: both clamp)
+      nScale = (int)ceilf(logf(ratio) / v.logScale);
+      if (nScale < 0) nScale = 0;
+      else if (nScale >= nlevels) nScale = nlevels - 1;
+    }
+    valid[i] = 1; uv[2 * i] = u; uv[2 * i + 1] = w; level[i] = nScale; dist_out[i] = dist;
+  }
+}

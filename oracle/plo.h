@@ -241,6 +241,9 @@ int  plo_orb_search_by_projection_kf(const plo_keypoint* kps_un, const uint8_t* 
  * invz = 1 / z in float, x = X*invz, u = fx*x + cx; form 2: Fuse(Scw) :1096-1108, SearchBySim3 :1253-1267 -- as form 1 with
  * invz = (float)(1.0 / z).  Camera coordinates = `R*P + t` as one double-accumulated gemm (see plo_frame_is_in_frustum_*). */
 void plo_frame_project_points(const float view[24], int form, int n, const float* pos, uint8_t* front, float* uv);
+void plo_map_point_gates(const float view[24], int nlevels, const float R2t2[12], int flags, int n, const float* pos, const float* normal,
+                         const float* min_dist_inv, const float* max_dist_inv, const float* max_dist, uint8_t* valid, float* uv,
+                         float* dist_out, int32_t* level);
 void plo_frame_is_in_frustum_points(const float view[24], int nlevels, int n, const float* pos, const float* normal,
                                     const float* min_dist, const float* max_dist, float viewing_cos_limit, uint8_t* valid,
                                     float* uv, int32_t* level, float* viewcos);

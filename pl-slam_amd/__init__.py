@@ -692,6 +692,36 @@ def project_points(views, positions, form, device=0, lib=None):
     return [(f[b, :len(x)].copy(), u[b, :len(x)].copy()) for b, x in enumerate(positions)]
 
 
+GATES_DTYPE = np.dtype([("view", VIEW_DTYPE), ("R2", np.float32, 9), ("t2", np.float32, 3), ("flags", np.int32)])   # == plh_point_gates
+GATE_Z, GATE_INVZ_DOUBLE, GATE_UV_NORMALISED, GATE_KEYFRAME_BOUNDS, GATE_DIST_OF_TARGET, GATE_NORMAL, GATE_SECOND = 1, 2, 4, 8, 16, 32, 64
+
+
+def map_point_gates(view, flags, pos, normal, min_dist_inv, max_dist_inv, max_dist=None, pre=None, R2=None, t2=None, device=0, lib=None):
+    """plh_map_point_gates (host buffers): the gates between the pose transform and the window lookup of the back end's pose-driven
+    searches, for all map points of one call.  view: one VIEW_DTYPE record.  Returns (valid u8[n], uv [n, 2], dist [n], level [n])."""
+    L = load(lib)
+    n = len(pos)
+    g = np.zeros(1, GATES_DTYPE)
+    g["view"][0] = np.asarray(view, VIEW_DTYPE).reshape(())
+    g["flags"][0] = int(flags)
+    if R2 is not None:
+        g["R2"][0] = np.asarray(R2, np.float32).reshape(9)
+        g["t2"][0] = np.asarray(t2, np.float32).reshape(3)
+    m = max(n, 1)
+    valid = np.ones(m, np.uint8) if pre is None else np.ascontiguousarray(pre, np.uint8).copy()
+    uv, dist, level = np.zeros((m, 2), np.float32), np.zeros(m, np.float32), np.zeros(m, np.int32)
+    f32 = lambda a, w: np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1, w) if w > 1 else np.asarray(a, np.float32).reshape(-1))
+    a_pos, a_min, a_max = f32(pos, 3), f32(min_dist_inv, 1), f32(max_dist_inv, 1)
+    a_nrm = f32(normal, 3) if normal is not None else None
+    a_raw = f32(max_dist, 1) if max_dist is not None else None
+    L.plh_map_point_gates.argtypes = [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I]
+    L.plh_map_point_gates.restype = _I
+    _check(L, L.plh_map_point_gates(_p(g), n, _p(a_pos), _p(a_nrm) if a_nrm is not None else None, _p(a_min), _p(a_max),
+                                    _p(a_raw) if a_raw is not None else None, _p(valid), _p(uv), _p(dist), _p(level), int(device)),
+           "plh_map_point_gates")
+    return valid[:n], uv[:n], dist[:n], level[:n]
+
+
 def is_in_frustum(views, elems, viewing_cos_limit, lines=False, device=0, lib=None):
     """Frame::isInFrustum for the local map of a batch of frames.  views: VIEW_DTYPE[P]; elems: per frame
     dict(pos [n,3] (points) or [n,6] (lines), normal [n,3], min_dist [n], max_dist [n]).  Returns per frame

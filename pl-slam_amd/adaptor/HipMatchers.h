@@ -142,6 +142,54 @@ struct ProjQueries {
   cv::Mat desc;                  // n x 32 CV_8U: GetDescriptor() of every query
 };
 
+// The back end's pose-driven searches (relocalisation / loop-closing SearchByProjection, both Fuse overloads, SearchBySim3) walk the map
+// points of the call and gate every one between the pose transform and the window lookup (ORBmatcher.cc:1591-1640, 337-395, 945-975,
+// 1096-1128, 1206-1290, 1313-1365).  What only the host can answer -- isBad(), "already found", an empty descriptor -- stays in the
+// adaptor's loop, which also copies what the gates read from the MapPoint; the arithmetic (transform, projection, image bounds, distance
+// range, viewing angle) runs for all points in one call of plh_map_point_gates.
+struct MapPointGateArrays {
+  std::vector<uchar> pre;                  // the map-side gates
+  std::vector<float> pos, normal;          // GetWorldPos(), GetNormal() (3 floats each)
+  std::vector<float> minInv, maxInv;       // GetMinDistanceInvariance(), GetMaxDistanceInvariance()
+  void assign(size_t n) { pre.assign(n, 0); pos.assign(3 * n, 0.f); normal.assign(3 * n, 0.f); minInv.assign(n, 0.f); maxInv.assign(n, 0.f); }
+  void set(size_t i, const cv::Mat& worldPos, const cv::Mat& normalVec, float minDistInv, float maxDistInv) {
+    pre[i] = 1;
+    for (int k = 0; k < 3; k++) pos[3 * i + k] = worldPos.at<float>(k);
+    if (!normalVec.empty())
+      for (int k = 0; k < 3; k++) normal[3 * i + k] = normalVec.at<float>(k);
+    minInv[i] = minDistInv; maxInv[i] = maxDistInv;
+  }
+};
+inline void PutMat(float* dst, const cv::Mat& m, int rows, int cols) {
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < cols; c++) dst[r * cols + c] = m.at<float>(r, c);
+}
+// the camera searched in: pose (Ow may be empty when the distance is the camera point's), intrinsics, image bounds
+inline plh_point_gates PointGates(int flags, const cv::Mat& Rcw, const cv::Mat& tcw, const cv::Mat& Ow, float fx, float fy, float cx, float cy,
+                                  float minX, float minY, float maxX, float maxY) {
+  plh_point_gates g;
+  std::memset(&g, 0, sizeof(g));
+  PutMat(g.view.Rcw, Rcw, 3, 3);
+  PutMat(g.view.tcw, tcw, 3, 1);
+  if (!Ow.empty()) PutMat(g.view.Ow, Ow, 3, 1);
+  g.view.fx = fx; g.view.fy = fy; g.view.cx = cx; g.view.cy = cy;
+  g.view.min_x = minX; g.view.min_y = minY; g.view.max_x = maxX; g.view.max_y = maxY;
+  g.view.log_scale_factor = 1.f; g.view.n_scale_levels = 1;   // (PredictScale stays with the MapPoint: mfMaxDistance is protected)
+  g.flags = flags;
+  return g;
+}
+// q.valid = pre && gates, q.pos = (u, v); dist[i] = the distance PredictScale wants, for the points that passed
+inline void MapPointGates(const plh_point_gates& g, const MapPointGateArrays& a, ProjQueries& q, std::vector<float>& dist, int device = 0) {
+  const int n = (int)a.pre.size();
+  q.valid = a.pre;
+  q.pos.assign(2 * (size_t)n, 0.f);
+  q.level.assign(n, 0);
+  dist.assign(n, 0.f);
+  if (n == 0) return;
+  check(plh_map_point_gates(&g, n, a.pos.data(), a.normal.data(), a.minInv.data(), a.maxInv.data(), NULL, q.valid.data(), q.pos.data(),
+                            dist.data(), q.level.data(), device));
+}
+
 // ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th).  occupied[idx] = F.mvpMapPoints[idx] != NULL &&
 // Observations() > 0 (in/out).  assigned[idx] = query whose MapPoint the reference stores in F.mvpMapPoints[idx], or -1.
 inline int SearchByProjection(const std::vector<cv::KeyPoint>& keysUn, const cv::Mat& desc, const plh_grid_params& gp,

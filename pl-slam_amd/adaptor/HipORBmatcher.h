@@ -157,34 +157,26 @@ class ORBmatcher : public ORBmatcherCPU {
     const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
     const int nq = (int)vpMPs.size();
     hip::ProjQueries q;
-    q.valid.assign(nq, 0); q.hasObs.assign(nq, 1); q.pos.assign(2 * (size_t)nq, 0.f); q.level.assign(nq, 0); q.aux.assign(nq, 0.f);
+    q.hasObs.assign(nq, 1); q.aux.assign(nq, 0.f);
     q.desc = cv::Mat::zeros(nq ? nq : 1, 32, CV_8U);
+    hip::MapPointGateArrays in;
+    in.assign(nq);
     for (int i = 0; i < nq; i++) {
       MapPoint* pMP = vpMPs[i];
       if (!pMP) continue;
       if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
-      cv::Mat x3Dw = pMP->GetWorldPos();
-      cv::Mat x3Dc = Rcw * x3Dw + tcw;
-      const float xc = x3Dc.at<float>(0);
-      const float yc = x3Dc.at<float>(1);
-      const float invzc = 1.0 / x3Dc.at<float>(2);
-      const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
-      const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
-      if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
-      if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
-      cv::Mat PO = x3Dw - Ow;
-      float dist3D = cv::norm(PO);
-      const float maxDistance = pMP->GetMaxDistanceInvariance();
-      const float minDistance = pMP->GetMinDistanceInvariance();
-      if (dist3D < minDistance || dist3D > maxDistance) continue;
       const cv::Mat dMP = pMP->GetDescriptor();
       if (dMP.empty()) continue;
-      q.valid[i] = 1;
-      q.pos[2 * i] = u; q.pos[2 * i + 1] = v;
-      q.level[i] = pMP->PredictScale(dist3D, &CurrentFrame);
+      in.set(i, pMP->GetWorldPos(), cv::Mat(), pMP->GetMinDistanceInvariance(), pMP->GetMaxDistanceInvariance());
       q.aux[i] = pKF->mvKeysUn[i].angle;
       std::memcpy(q.desc.ptr<uchar>(i), dMP.ptr<uchar>(0), 32);
     }
+    // :1614-1636: no depth gate, invzc in double, u = fx*xc*invzc + cx, the frame's bounds, |x3Dw - Ow| in the invariance range
+    std::vector<float> dist;
+    hip::MapPointGates(hip::PointGates(PLH_GATE_INVZ_DOUBLE, Rcw, tcw, Ow, CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy,
+                                       CurrentFrame.mnMinX, CurrentFrame.mnMinY, CurrentFrame.mnMaxX, CurrentFrame.mnMaxY), in, q, dist);
+    for (int i = 0; i < nq; i++)
+      if (q.valid[i]) q.level[i] = vpMPs[i]->PredictScale(dist[i], &CurrentFrame);
     std::vector<uchar> occupied(CurrentFrame.N);
     for (int i = 0; i < CurrentFrame.N; i++) occupied[i] = CurrentFrame.mvpMapPoints[i] != NULL;
     std::vector<int> assigned;
@@ -249,34 +241,31 @@ class ORBmatcher : public ORBmatcherCPU {
       KeyFrame* pTo = dir == 0 ? pKF2 : pKF1;
       const int n = (int)pts.size();
       hip::ProjQueries& Q = q[dir];
-      Q.valid.assign(n, 0); Q.hasObs.assign(n, 1); Q.pos.assign(2 * (size_t)n, 0.f); Q.level.assign(n, 0); Q.aux.assign(n, 0.f);
+      Q.hasObs.assign(n, 1); Q.aux.assign(n, 0.f);
       Q.desc = cv::Mat::zeros(n ? n : 1, 32, CV_8U);
+      hip::MapPointGateArrays in;
+      in.assign(n);
       for (int i = 0; i < n; i++) {
         MapPoint* pMP = pts[i];
         if (!pMP || done[i]) continue;
         if (pMP->isBad()) continue;
-        cv::Mat p3Dw = pMP->GetWorldPos();
-        cv::Mat pTarget;   // the point in the other KeyFrame's camera
-        if (dir == 0) { cv::Mat p3Dc1 = R1w * p3Dw + t1w; pTarget = sR21 * p3Dc1 + t21; }
-        else { cv::Mat p3Dc2 = R2w * p3Dw + t2w; pTarget = sR12 * p3Dc2 + t12; }
-        if (pTarget.at<float>(2) < 0.0) continue;
-        const float invz = 1.0 / pTarget.at<float>(2);
-        const float x = pTarget.at<float>(0) * invz;
-        const float y = pTarget.at<float>(1) * invz;
-        const float u = fx * x + cx;
-        const float v = fy * y + cy;
-        if (!pTo->IsInImage(u, v)) continue;
-        const float maxDistance = pMP->GetMaxDistanceInvariance();
-        const float minDistance = pMP->GetMinDistanceInvariance();
-        const float dist3D = cv::norm(pTarget);
-        if (dist3D < minDistance || dist3D > maxDistance) continue;
         const cv::Mat dMP = pMP->GetDescriptor();
         if (dMP.empty()) continue;   // no candidate can lower bestDist from INT_MAX (:1283-1284)
-        Q.valid[i] = 1;
-        Q.pos[2 * i] = u; Q.pos[2 * i + 1] = v;
-        Q.level[i] = pMP->PredictScale(dist3D, pTo);
+        in.set(i, pMP->GetWorldPos(), cv::Mat(), pMP->GetMinDistanceInvariance(), pMP->GetMaxDistanceInvariance());
         std::memcpy(Q.desc.ptr<uchar>(i), dMP.ptr<uchar>(0), 32);
       }
+      // :1232-1268 / :1312-1348: into the point's own camera, then into the other one by the similarity; depth gate, invz in double,
+      // x = X*invz, pTo->IsInImage, |p3Dc| of the target camera in the invariance range
+      plh_point_gates g = hip::PointGates(PLH_GATE_Z | PLH_GATE_INVZ_DOUBLE | PLH_GATE_UV_NORMALISED | PLH_GATE_KEYFRAME_BOUNDS |
+                                              PLH_GATE_DIST_OF_TARGET | PLH_GATE_SECOND,
+                                          dir == 0 ? R1w : R2w, dir == 0 ? t1w : t2w, cv::Mat(), fx, fy, cx, cy, pTo->mnMinX, pTo->mnMinY,
+                                          pTo->mnMaxX, pTo->mnMaxY);
+      hip::PutMat(g.R2, dir == 0 ? sR21 : sR12, 3, 3);
+      hip::PutMat(g.t2, dir == 0 ? t21 : t12, 3, 1);
+      std::vector<float> dist;
+      hip::MapPointGates(g, in, Q, dist);
+      for (int i = 0; i < n; i++)
+        if (Q.valid[i]) Q.level[i] = pts[i]->PredictScale(dist[i], pTo);
     }
     std::vector<int> m12;
     const int nFound = hip::SearchBySim3(pKF1->mvKeysUn, pKF1->mDescriptors, pKF2->mvKeysUn, pKF2->mDescriptors, FrameGrid(),
@@ -333,34 +322,24 @@ class ORBmatcher : public ORBmatcherCPU {
     spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
     const int nq = (int)vpPoints.size();
     hip::ProjQueries q;
-    q.valid.assign(nq, 0); q.hasObs.assign(nq, 1); q.pos.assign(2 * (size_t)nq, 0.f); q.level.assign(nq, 0); q.aux.assign(nq, 0.f);
+    q.hasObs.assign(nq, 1); q.aux.assign(nq, 0.f);
     q.desc = cv::Mat::zeros(nq ? nq : 1, 32, CV_8U);
+    hip::MapPointGateArrays in;
+    in.assign(nq);
     for (int iMP = 0; iMP < nq; iMP++) {
       MapPoint* pMP = vpPoints[iMP];
       if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-      cv::Mat p3Dw = pMP->GetWorldPos();
-      cv::Mat p3Dc = Rcw * p3Dw + tcw;
-      if (p3Dc.at<float>(2) < 0.0) continue;
-      const float invz = 1 / p3Dc.at<float>(2);
-      const float x = p3Dc.at<float>(0) * invz;
-      const float y = p3Dc.at<float>(1) * invz;
-      const float u = fx * x + cx;
-      const float v = fy * y + cy;
-      if (!pKF->IsInImage(u, v)) continue;
-      const float maxDistance = pMP->GetMaxDistanceInvariance();
-      const float minDistance = pMP->GetMinDistanceInvariance();
-      cv::Mat PO = p3Dw - Ow;
-      const float dist = cv::norm(PO);
-      if (dist < minDistance || dist > maxDistance) continue;
-      cv::Mat Pn = pMP->GetNormal();
-      if (PO.dot(Pn) < 0.5 * dist) continue;
       const cv::Mat dMP = pMP->GetDescriptor();
       if (dMP.empty()) continue;                                   // (:431: no candidate is ever compared)
-      q.valid[iMP] = 1;
-      q.pos[2 * iMP] = u; q.pos[2 * iMP + 1] = v;
-      q.level[iMP] = pMP->PredictScale(dist, pKF);
+      in.set(iMP, pMP->GetWorldPos(), pMP->GetNormal(), pMP->GetMinDistanceInvariance(), pMP->GetMaxDistanceInvariance());
       std::memcpy(q.desc.ptr<uchar>(iMP), dMP.ptr<uchar>(0), 32);
     }
+    // :362-395: depth gate, invz in float, x = X*invz, pKF->IsInImage, |p3Dw - Ow| in the invariance range, viewing angle under 60 degrees
+    std::vector<float> dist;
+    hip::MapPointGates(hip::PointGates(PLH_GATE_Z | PLH_GATE_UV_NORMALISED | PLH_GATE_KEYFRAME_BOUNDS | PLH_GATE_NORMAL, Rcw, tcw, Ow, fx, fy, cx,
+                                       cy, pKF->mnMinX, pKF->mnMinY, pKF->mnMaxX, pKF->mnMaxY), in, q, dist);
+    for (int iMP = 0; iMP < nq; iMP++)
+      if (q.valid[iMP]) q.level[iMP] = vpPoints[iMP]->PredictScale(dist[iMP], pKF);
     std::vector<uchar> occupied(vpMatched.size());
     for (size_t i = 0; i < vpMatched.size(); i++) occupied[i] = vpMatched[i] != NULL;
     std::vector<int> assigned;
@@ -384,34 +363,24 @@ class ORBmatcher : public ORBmatcherCPU {
     cv::Mat Ow = pKF->GetCameraCenter();
     const int nMPs = (int)vpMapPoints.size();
     hip::ProjQueries q;
-    q.valid.assign(nMPs, 0); q.hasObs.assign(nMPs, 1); q.pos.assign(2 * (size_t)nMPs, 0.f); q.level.assign(nMPs, 0); q.aux.assign(nMPs, 0.f);
+    q.hasObs.assign(nMPs, 1); q.aux.assign(nMPs, 0.f);
     q.desc = cv::Mat::zeros(nMPs ? nMPs : 1, 32, CV_8U);
+    hip::MapPointGateArrays in;
+    in.assign(nMPs);
     for (int i = 0; i < nMPs; i++) {
       MapPoint* pMP = vpMapPoints[i];
       if (!pMP) continue;
-      cv::Mat p3Dw = pMP->GetWorldPos();
-      cv::Mat p3Dc = Rcw * p3Dw + tcw;
-      if (p3Dc.at<float>(2) < 0.0f) continue;
-      const float invz = 1 / p3Dc.at<float>(2);
-      const float x = p3Dc.at<float>(0) * invz;
-      const float y = p3Dc.at<float>(1) * invz;
-      const float u = fx * x + cx;
-      const float v = fy * y + cy;
-      if (!pKF->IsInImage(u, v)) continue;
-      const float maxDistance = pMP->GetMaxDistanceInvariance();
-      const float minDistance = pMP->GetMinDistanceInvariance();
-      cv::Mat PO = p3Dw - Ow;
-      const float dist3D = cv::norm(PO);
-      if (dist3D < minDistance || dist3D > maxDistance) continue;
-      cv::Mat Pn = pMP->GetNormal();
-      if (PO.dot(Pn) < 0.5 * dist3D) continue;
       const cv::Mat dMP = pMP->GetDescriptor();
       if (dMP.empty()) continue;
-      q.valid[i] = 1;
-      q.pos[2 * i] = u; q.pos[2 * i + 1] = v;
-      q.level[i] = pMP->PredictScale(dist3D, pKF);
+      in.set(i, pMP->GetWorldPos(), pMP->GetNormal(), pMP->GetMinDistanceInvariance(), pMP->GetMaxDistanceInvariance());
       std::memcpy(q.desc.ptr<uchar>(i), dMP.ptr<uchar>(0), 32);
     }
+    // :945-975: depth gate, invz in float, x = X*invz, pKF->IsInImage, |p3Dw - Ow| in the invariance range, viewing angle under 60 degrees
+    std::vector<float> dist;
+    hip::MapPointGates(hip::PointGates(PLH_GATE_Z | PLH_GATE_UV_NORMALISED | PLH_GATE_KEYFRAME_BOUNDS | PLH_GATE_NORMAL, Rcw, tcw, Ow, fx, fy, cx,
+                                       cy, pKF->mnMinX, pKF->mnMinY, pKF->mnMaxX, pKF->mnMaxY), in, q, dist);
+    for (int i = 0; i < nMPs; i++)
+      if (q.valid[i]) q.level[i] = vpMapPoints[i]->PredictScale(dist[i], pKF);
     std::vector<int> bestIdx(nMPs, -1);
     if (pKF->N > 0 && nMPs > 0)
       hip::FuseSearch(pKF->mvKeysUn, pKF->mDescriptors, FrameGrid(), pKF->mvScaleFactors, pKF->mvInvLevelSigma2, q, th, bestIdx, TH_LOW);
@@ -449,35 +418,24 @@ class ORBmatcher : public ORBmatcherCPU {
     const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
     const int nPoints = (int)vpPoints.size();
     hip::ProjQueries q;
-    q.valid.assign(nPoints, 0); q.hasObs.assign(nPoints, 1); q.pos.assign(2 * (size_t)nPoints, 0.f); q.level.assign(nPoints, 0);
-    q.aux.assign(nPoints, 0.f);
+    q.hasObs.assign(nPoints, 1); q.aux.assign(nPoints, 0.f);
     q.desc = cv::Mat::zeros(nPoints ? nPoints : 1, 32, CV_8U);
+    hip::MapPointGateArrays in;
+    in.assign(nPoints);
     for (int iMP = 0; iMP < nPoints; iMP++) {
       MapPoint* pMP = vpPoints[iMP];
       if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-      cv::Mat p3Dw = pMP->GetWorldPos();
-      cv::Mat p3Dc = Rcw * p3Dw + tcw;
-      if (p3Dc.at<float>(2) < 0.0f) continue;
-      const float invz = 1.0 / p3Dc.at<float>(2);
-      const float x = p3Dc.at<float>(0) * invz;
-      const float y = p3Dc.at<float>(1) * invz;
-      const float u = fx * x + cx;
-      const float v = fy * y + cy;
-      if (!pKF->IsInImage(u, v)) continue;
-      const float maxDistance = pMP->GetMaxDistanceInvariance();
-      const float minDistance = pMP->GetMinDistanceInvariance();
-      cv::Mat PO = p3Dw - Ow;
-      const float dist3D = cv::norm(PO);
-      if (dist3D < minDistance || dist3D > maxDistance) continue;
-      cv::Mat Pn = pMP->GetNormal();
-      if (PO.dot(Pn) < 0.5 * dist3D) continue;
       const cv::Mat dMP = pMP->GetDescriptor();
       if (dMP.empty()) continue;
-      q.valid[iMP] = 1;
-      q.pos[2 * iMP] = u; q.pos[2 * iMP + 1] = v;
-      q.level[iMP] = pMP->PredictScale(dist3D, pKF);
+      in.set(iMP, pMP->GetWorldPos(), pMP->GetNormal(), pMP->GetMinDistanceInvariance(), pMP->GetMaxDistanceInvariance());
       std::memcpy(q.desc.ptr<uchar>(iMP), dMP.ptr<uchar>(0), 32);
     }
+    // :1096-1128: as the other overload with invz in double
+    std::vector<float> dist;
+    hip::MapPointGates(hip::PointGates(PLH_GATE_Z | PLH_GATE_INVZ_DOUBLE | PLH_GATE_UV_NORMALISED | PLH_GATE_KEYFRAME_BOUNDS | PLH_GATE_NORMAL, Rcw,
+                                       tcw, Ow, fx, fy, cx, cy, pKF->mnMinX, pKF->mnMinY, pKF->mnMaxX, pKF->mnMaxY), in, q, dist);
+    for (int iMP = 0; iMP < nPoints; iMP++)
+      if (q.valid[iMP]) q.level[iMP] = vpPoints[iMP]->PredictScale(dist[iMP], pKF);
     std::vector<int> bestIdx(nPoints, -1);
     if (pKF->N > 0 && nPoints > 0)
       hip::FuseSearch(pKF->mvKeysUn, pKF->mDescriptors, FrameGrid(), pKF->mvScaleFactors, std::vector<float>(), q, th, bestIdx, TH_LOW);

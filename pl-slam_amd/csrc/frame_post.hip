@@ -5,6 +5,7 @@
 // Both are exact: the iteration runs in double with the reference's operation order (no FMA contraction), the median
 // selection is integer.
 #include "plh_common.h"
+#include "plh_stage.h"
 
 namespace plh {
 
@@ -142,11 +143,12 @@ __global__ void __launch_bounds__(256) k_project_points(const plh_frame_view* vi
 // (plh_map_point_gates): the loops of ORBmatcher.cc:1591-1640 (relocalisation), :337-395 (loop closing), :945-975 / :1096-1128 (both
 // Fuse overloads), :1206-1290 / :1313-1365 (SearchBySim3, both directions), one thread per map point.
 __global__ void __launch_bounds__(256) k_map_point_gates(plh_point_gates g, int n, const float* pos, const float* normal,
-                                                         const float* minDist, const float* maxDist, uint8_t* valid, float* uv, int* level) {
+                                                         const float* minInv, const float* maxInv, const float* maxRaw, uint8_t* valid,
+                                                         float* uv, float* distOut, int* level) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint8_t ok = 0;
-  float u = 0.f, w = 0.f;
+  float u = 0.f, w = 0.f, dOut = 0.f;
   int lvl = 0;
   if (valid[i]) {
     const plh_frame_view& v = g.view;
@@ -182,22 +184,25 @@ __global__ void __launch_bounds__(256) k_map_point_gates(plh_point_gates g, int 
     if (in) {
       const float PO[3] = {P[0] - v.Ow[0], P[1] - v.Ow[1], P[2] - v.Ow[2]};
       const float dist = (g.flags & PLH_GATE_DIST_OF_TARGET) ? norm3(Pc) : norm3(PO);
-      in = !(dist < minDist[i] || dist > maxDist[i]);
+      in = !(dist < minInv[i] || dist > maxInv[i]);
       if (in && (g.flags & PLH_GATE_NORMAL)) {
         const float N[3] = {normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]};
         in = !(dot3(PO, N) < 0.5 * (double)dist);
       }
       if (in) {
-        int nScale = predict_scale(maxDist[i], dist, v.log_scale_factor);
-        if (nScale < 0) nScale = 0;
-        else if (nScale >= v.n_scale_levels) nScale = v.n_scale_levels - 1;
-        lvl = nScale;
+        if (maxRaw) {
+          int nScale = predict_scale(maxRaw[i], dist, v.log_scale_factor);
+          if (nScale < 0) nScale = 0;
+          else if (nScale >= v.n_scale_levels) nScale = v.n_scale_levels - 1;
+          lvl = nScale;
+        }
+        dOut = dist;
         ok = 1;
       }
     }
   }
   if (!ok) { u = 0.f; w = 0.f; }
-  valid[i] = ok; uv[i * 2] = u; uv[i * 2 + 1] = w; level[i] = lvl;
+  valid[i] = ok; uv[i * 2] = u; uv[i * 2 + 1] = w; distOut[i] = dOut; level[i] = lvl;
 }
 
 __global__ void __launch_bounds__(256) k_frustum_points(const plh_frame_view* views, const int* nArr, int qcap, const float* pos,
@@ -372,23 +377,25 @@ plh_status plh_frame_project_points_batch_dev(const plh_frame_view* d_views, int
 }
 
 
-plh_status plh_map_point_gates_dev(const plh_point_gates* gates, int n, const float* d_pos, const float* d_normal, const float* d_min_dist,
-                                   const float* d_max_dist, uint8_t* d_valid, float* d_uv, int32_t* d_level, void* stream) {
+plh_status plh_map_point_gates_dev(const plh_point_gates* gates, int n, const float* d_pos, const float* d_normal,
+                                   const float* d_min_dist_inv, const float* d_max_dist_inv, const float* d_max_dist, uint8_t* d_valid,
+                                   float* d_uv, float* d_dist, int32_t* d_level, void* stream) {
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
-  if (!gates || n <= 0 || !d_pos || !d_min_dist || !d_max_dist || !d_valid || !d_uv || !d_level ||
+  if (!gates || n <= 0 || !d_pos || !d_min_dist_inv || !d_max_dist_inv || !d_valid || !d_uv || !d_dist || !d_level ||
       ((gates->flags & PLH_GATE_NORMAL) && !d_normal)) {
     set_error("plh_map_point_gates_dev: invalid argument");
     return PLH_ERR_INVALID;
   }
-  hipLaunchKernelGGL(k_map_point_gates, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *gates, n, d_pos, d_normal, d_min_dist,
-                     d_max_dist, d_valid, d_uv, (int*)d_level);
+  hipLaunchKernelGGL(k_map_point_gates, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *gates, n, d_pos, d_normal,
+                     d_min_dist_inv, d_max_dist_inv, d_max_dist, d_valid, d_uv, d_dist, (int*)d_level);
   PLH_LAUNCH_CHECK();
   return PLH_OK;
 }
 
-plh_status plh_map_point_gates(const plh_point_gates* gates, int n, const float* pos, const float* normal, const float* min_dist,
-                               const float* max_dist, uint8_t* valid, float* uv, int32_t* level, int device) {
-  if (!gates || n < 0 || (n > 0 && (!pos || !min_dist || !max_dist || !valid || !uv || !level)) ||
+plh_status plh_map_point_gates(const plh_point_gates* gates, int n, const float* pos, const float* normal, const float* min_dist_inv,
+                               const float* max_dist_inv, const float* max_dist, uint8_t* valid, float* uv, float* dist, int32_t* level,
+                               int device) {
+  if (!gates || n < 0 || (n > 0 && (!pos || !min_dist_inv || !max_dist_inv || !valid || !uv || !dist || !level)) ||
       (n > 0 && (gates->flags & PLH_GATE_NORMAL) && !normal)) {
     set_error("plh_map_point_gates: invalid argument");
     return PLH_ERR_INVALID;
@@ -397,17 +404,19 @@ plh_status plh_map_point_gates(const plh_point_gates* gates, int n, const float*
   if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
   Stager st;
   const size_t N = (size_t)n;
-  plh_status rc = st.begin(device, 2 * Stager::padded(N * 12) + 3 * Stager::padded(N * 4) + Stager::padded(N) + Stager::padded(N * 8));
+  plh_status rc = st.begin(device, 2 * Stager::padded(N * 12) + 5 * Stager::padded(N * 4) + Stager::padded(N) + Stager::padded(N * 8));
   if (rc != PLH_OK) return rc;
   const float* dPos = st.in(pos, N * 3);
   const float* dNormal = (gates->flags & PLH_GATE_NORMAL) ? st.in(normal, N * 3) : nullptr;
-  const float* dMin = st.in(min_dist, N);
-  const float* dMax = st.in(max_dist, N);
+  const float* dMin = st.in(min_dist_inv, N);
+  const float* dMax = st.in(max_dist_inv, N);
+  const float* dRaw = max_dist ? st.in(max_dist, N) : nullptr;
   uint8_t* dValid = st.inout(valid, N);
   float* dUv = st.out(uv, N * 2);
+  float* dDist = st.out(dist, N);
   int32_t* dLevel = st.out(level, N);
   if ((rc = st.upload()) != PLH_OK) return rc;
-  if ((rc = plh_map_point_gates_dev(gates, n, dPos, dNormal, dMin, dMax, dValid, dUv, dLevel, st.stream())) != PLH_OK) return rc;
+  if ((rc = plh_map_point_gates_dev(gates, n, dPos, dNormal, dMin, dMax, dRaw, dValid, dUv, dDist, dLevel, st.stream())) != PLH_OK) return rc;
   return st.download();
 }
 

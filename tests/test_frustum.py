@@ -209,3 +209,63 @@ def test_emu_projection(plslam, oracle, synth, emu_lib):
 @pytest.mark.gpu
 def test_gpu_projection(plslam, oracle, synth):
     _device_project(plslam, oracle, synth, None)
+
+
+# ---- the gates in front of the back end's pose-driven searches (plh_map_point_gates)
+GATE_FORMS = {"relocalisation": 2, "loop_closing": 1 | 4 | 8 | 32, "fuse": 1 | 4 | 8 | 32, "fuse_sim3": 1 | 2 | 4 | 8 | 32,
+              "search_by_sim3": 1 | 2 | 4 | 8 | 16 | 64}
+
+
+def _oracle_gates(O, view, nlv, flags, R2t2, pos, normal, dmin, dmax, raw, pre):
+    L = O.lib()
+    L.plo_map_point_gates.argtypes = [V, I, V, I, I, V, V, V, V, V, V, V, V, V]
+    L.plo_map_point_gates.restype = None
+    n = len(pos)
+    m = max(n, 1)
+    valid = np.ascontiguousarray(pre, np.uint8).copy() if n else np.zeros(1, np.uint8)
+    uv, dist, level = np.zeros((m, 2), np.float32), np.zeros(m, np.float32), np.zeros(m, np.int32)
+    L.plo_map_point_gates(O._p(view), nlv, O._p(R2t2), flags, n, O._p(pos), O._p(normal), O._p(dmin), O._p(dmax),
+                          O._p(raw) if raw is not None else None, O._p(valid), O._p(uv), O._p(dist), O._p(level))
+    return valid[:n], uv[:n], dist[:n], level[:n]
+
+
+def _gate_case(G, S, P, TF, seed, n):
+    view, nlv = G.frustum_view(S, P, TF, seed, False, rotate=True)
+    e = G.frustum_elems(S, seed, n, view, 0)
+    rng = np.random.RandomState(seed)
+    # a similarity close to the identity as the second transform (SearchBySim3's sR21 / t21)
+    a = rng.uniform(-0.05, 0.05, 3)
+    Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+    Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+    R2 = (rng.uniform(0.9, 1.1) * Rx @ Ry).astype(np.float32)
+    t2 = rng.uniform(-0.1, 0.1, 3).astype(np.float32)
+    raw = np.ascontiguousarray(e["max_dist"], np.float32)
+    dmin = (np.float32(0.8) * np.ascontiguousarray(e["min_dist"], np.float32)).astype(np.float32)
+    dmax = (np.float32(1.2) * raw).astype(np.float32)
+    pre = (rng.uniform(size=n) < 0.9).astype(np.uint8)
+    return view, nlv, e, np.concatenate([R2.reshape(9), t2]).astype(np.float32), dmin, dmax, raw, pre
+
+
+def _device_gates(P, O, S, lib, sizes):
+    G = _gen()
+    TF = G._test_module("test_frame_search")
+    passed = 0
+    for k, n in enumerate(sizes):
+        view, nlv, e, R2t2, dmin, dmax, raw, pre = _gate_case(G, S, P, TF, 80 + k, n)
+        rec = _view_record(P, view, nlv)
+        for name, flags in GATE_FORMS.items():
+            for with_raw in (True, False):
+                ref = _oracle_gates(O, view, nlv, flags, R2t2, e["pos"], e["normal"], dmin, dmax, raw if with_raw else None, pre)
+                got = P.map_point_gates(rec, flags, e["pos"], e["normal"], dmin, dmax, raw if with_raw else None, pre, R2t2[:9], R2t2[9:], lib=lib)
+                assert _same(ref, got), "%s, %d points, raw %s" % (name, n, with_raw)
+                passed += int(ref[0].sum())
+    assert passed > 0   # (the gates do let points through on this content)
+
+
+def test_emu_map_point_gates(plslam, oracle, synth, emu_lib):
+    _device_gates(plslam, oracle, synth, emu_lib, [600, 0, 1, 65])
+
+
+@pytest.mark.gpu
+def test_gpu_map_point_gates(plslam, oracle, synth):
+    _device_gates(plslam, oracle, synth, None, [6000, 0, 1, 257, 2048])
