@@ -616,6 +616,15 @@ typedef struct plh_frame_view {
  * d_front / d_uv are what goes into q_valid (together with the caller's map-side flags) and q_uv of the searches. */
 PLH_API plh_status plh_frame_project_points_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap,
                                                       const float* d_pos, int form, uint8_t* d_front, float* d_uv, void* stream);
+/* plh_orb_search_by_projection_frame_resident with the projection of ORBmatcher.cc:1474-1484 on the device as well (form 0 above): the
+ * queries are the WORLD positions of the last frame's map points (q_world: 3 floats each) and `view` holds the current pose and
+ * intrinsics; q_valid = the caller's map-side gates (pMP && !mvbOutlier[i] && a descriptor), `!(invzc < 0)` is added here.  One
+ * staging round trip per TrackWithMotionModel search; no cv::Mat arithmetic per map point on the host. */
+PLH_API plh_status plh_orb_search_by_projection_frame_resident_world(const plh_frame_points* f, const float* scale_factors, int nlevels,
+                                                                     uint8_t* occupied, int nq, const plh_frame_view* view,
+                                                                     const uint8_t* q_valid, const float* q_world, const int32_t* q_octave,
+                                                                     const float* q_angle, const uint8_t* q_desc, const uint8_t* q_hasobs,
+                                                                     float th, int mode, int check_ori, int32_t* assigned, int* nmatches);
 PLH_API plh_status plh_frame_is_in_frustum_points_batch_dev(const plh_frame_view* d_views, int frames, const int32_t* d_nq, int qcap,
                                                             const float* d_pos, const float* d_normal, const float* d_min_dist,
                                                             const float* d_max_dist, float viewing_cos_limit, uint8_t* d_valid,

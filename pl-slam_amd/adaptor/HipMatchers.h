@@ -266,6 +266,18 @@ inline int SearchByProjectionLastFrameResident(const plh_frame_points* f, const 
                                                     q.hasObs.data(), th, mode, checkOri ? 1 : 0, assigned.data(), &nmatches));
   return nmatches;
 }
+// ... the same search with the projection on the device: q.pos holds WORLD positions (3 floats per query), `view` the current pose
+inline int SearchByProjectionLastFrameResidentWorld(const plh_frame_points* f, const std::vector<float>& scaleFactors, std::vector<uchar>& occupied,
+                                                    const plh_frame_view& view, const ProjQueries& q, float th, int mode, bool checkOri,
+                                                    std::vector<int>& assigned) {
+  const int n = plh_frame_points_count(f), nq = (int)q.valid.size();
+  assigned.assign(n, -1);
+  int nm = 0;
+  check(plh_orb_search_by_projection_frame_resident_world(f, scaleFactors.data(), (int)scaleFactors.size(), occupied.data(), nq, &view,
+                                                          q.valid.data(), q.pos.data(), q.level.data(), q.aux.data(), q.desc.ptr<uchar>(),
+                                                          q.hasObs.data(), th, mode, checkOri ? 1 : 0, assigned.data(), &nm));
+  return nm;
+}
 inline int SearchForInitializationResident(const plh_frame_points* f1, const plh_frame_points* f2, std::vector<cv::Point2f>& vbPrevMatched,
                                            std::vector<int>& vnMatches12, int windowSize, float nnratio, bool checkOri) {
   vnMatches12.assign(plh_frame_points_count(f1), -1);

@@ -89,26 +89,21 @@ class ORBmatcher : public ORBmatcherCPU {
     const bool bForward = tlc.at<float>(2) > CurrentFrame.mb && !bMono;
     const bool bBackward = -tlc.at<float>(2) > CurrentFrame.mb && !bMono;
     const int n = LastFrame.N;
-    hip::ProjQueries q;
-    q.valid.assign(n, 0); q.hasObs.assign(n, 0); q.pos.assign(2 * (size_t)n, 0.f); q.level.assign(n, 0); q.aux.assign(n, 0.f);
+    hip::ProjQueries q;   // (q.pos: the WORLD position of every query, the projection of :1474-1484 runs in front of the search on the device)
+    q.valid.assign(n, 0); q.hasObs.assign(n, 0); q.pos.assign(3 * (size_t)n, 0.f); q.level.assign(n, 0); q.aux.assign(n, 0.f);
     q.desc = cv::Mat::zeros(n ? n : 1, 32, CV_8U);
     for (int i = 0; i < n; i++) {
       MapPoint* pMP = LastFrame.mvpMapPoints[i];
       if (!pMP || LastFrame.mvbOutlier[i]) continue;
-      cv::Mat x3Dw = pMP->GetWorldPos();
-      cv::Mat x3Dc = Rcw * x3Dw + tcw;
-      const float xc = x3Dc.at<float>(0);
-      const float yc = x3Dc.at<float>(1);
-      const float invzc = 1.0 / x3Dc.at<float>(2);
-      if (invzc < 0) continue;
-      q.valid[i] = !pMP->GetDescriptor().empty();   // (no descriptor: never matches, ORBmatcher.cc:1530-1531)
-      q.pos[2 * i] = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
-      q.pos[2 * i + 1] = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+      const cv::Mat d = pMP->GetDescriptor();
+      if (d.empty()) continue;                    // (no descriptor: never matches, ORBmatcher.cc:1530-1531)
+      const cv::Mat x3Dw = pMP->GetWorldPos();
+      q.valid[i] = 1;
+      for (int k = 0; k < 3; k++) q.pos[3 * i + k] = x3Dw.at<float>(k);
       q.level[i] = LastFrame.mvKeys[i].octave;
       q.aux[i] = LastFrame.mvKeysUn[i].angle;
       q.hasObs[i] = pMP->Observations() > 0;
-      const cv::Mat d = pMP->GetDescriptor();
-      if (d.data) std::memcpy(q.desc.ptr<uchar>(i), d.ptr<uchar>(0), 32);
+      std::memcpy(q.desc.ptr<uchar>(i), d.ptr<uchar>(0), 32);
     }
     std::vector<uchar> occupied(CurrentFrame.N);          // :1518-1520
     for (int i = 0; i < CurrentFrame.N; i++)
@@ -117,8 +112,10 @@ class ORBmatcher : public ORBmatcherCPU {
     if (CurrentFrame.N == 0 || n == 0) return 0;
     const std::shared_ptr<hip::ResidentPoints> rf =
         hip::FrameResidency::Instance().Points(CurrentFrame.mnId, CurrentFrame.mvKeysUn, CurrentFrame.mDescriptors, FrameGrid());
-    const int nmatches = hip::SearchByProjectionLastFrameResident(rf->h, CurrentFrame.mvScaleFactors, occupied, q, th,
-                                                                  bForward ? 1 : bBackward ? 2 : 0, mbCheckOrientation, assigned);
+    const plh_point_gates cam = hip::PointGates(0, Rcw, tcw, cv::Mat(), CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy,
+                                                CurrentFrame.mnMinX, CurrentFrame.mnMinY, CurrentFrame.mnMaxX, CurrentFrame.mnMaxY);
+    const int nmatches = hip::SearchByProjectionLastFrameResidentWorld(rf->h, CurrentFrame.mvScaleFactors, occupied, cam.view, q, th,
+                                                                       bForward ? 1 : bBackward ? 2 : 0, mbCheckOrientation, assigned);
     // :1548 assigns, the rotation-consistency pass (:1567-1580) resets the rejected ones to NULL: `assigned` is the net effect,
     // `occupied` tells which of the previously empty slots stayed empty
     for (int i = 0; i < CurrentFrame.N; i++)

@@ -1923,6 +1923,56 @@ plh_status plh_orb_search_by_projection_frame_resident(const plh_frame_points* f
   return resident_proj_points(1, f, scale_factors, nlevels, occupied, nq, q_valid, q_uv, q_octave, q_angle, q_desc, q_hasobs, th, 0.f, mode,
                               check_ori, assigned, nmatches, "plh_orb_search_by_projection_frame_resident");
 }
+// ... with the projection of :1474-1484 on the device as well: the queries arrive as world positions (MapPoint::GetWorldPos of the last
+// frame's points) and the current pose; q_valid = the caller's map-side gates (pMP && !mvbOutlier[i] && a descriptor), to which the
+// projection adds `!(invzc < 0)`.
+__global__ void __launch_bounds__(256) k_and_bytes(uint8_t* a, const uint8_t* b, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = a[i] && b[i];
+}
+plh_status plh_orb_search_by_projection_frame_resident_world(const plh_frame_points* f, const float* scale_factors, int nlevels,
+                                                             uint8_t* occupied, int nq, const plh_frame_view* view, const uint8_t* q_valid,
+                                                             const float* q_world, const int32_t* q_octave, const float* q_angle,
+                                                             const uint8_t* q_desc, const uint8_t* q_hasobs, float th, int mode,
+                                                             int check_ori, int32_t* assigned, int* nmatches) {
+  const char* who = "plh_orb_search_by_projection_frame_resident_world";
+  if (!f || nq < 0 || !nmatches || !scale_factors || !view || mode < 0 || mode > 2 || (f->n > 0 && (!occupied || !assigned)) ||
+      (nq > 0 && (!q_valid || !q_world || !q_octave || !q_angle || !q_desc || !q_hasobs))) {
+    set_error("%s: invalid argument", who);
+    return PLH_ERR_INVALID;
+  }
+  const int n = f->n;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
+  *nmatches = 0;
+  if (n == 0 || nq == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  Stager st;
+  plh_status rc = st.begin(f->device);
+  if (rc != PLH_OK) return rc;
+  uint8_t* docc = st.inout(occupied, (size_t)n);
+  int32_t* da = st.out(assigned, (size_t)n);
+  int32_t nm = 0;
+  int32_t* dc = st.out(&nm, 1);
+  const int32_t nq32 = nq;
+  const int32_t* dnq = st.in(&nq32, 1);
+  const plh_frame_view* dview = st.in(view, 1);
+  uint8_t* qv = const_cast<uint8_t*>(st.in(q_valid, (size_t)nq));   // (the arena's copy: the projection's verdict is folded into it)
+  const float* qw = st.in(q_world, (size_t)nq * 3);
+  const int32_t* ql = st.in(q_octave, (size_t)nq);
+  const float* qa = st.in(q_angle, (size_t)nq); const uint8_t* qd = st.in(q_desc, (size_t)nq * 32); const uint8_t* qh = st.in(q_hasobs, (size_t)nq);
+  float* quv = st.scratch<float>((size_t)nq * 2);
+  uint8_t* qfront = st.scratch<uint8_t>((size_t)nq);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  if ((rc = plh_frame_project_points_batch_dev(dview, 1, dnq, nq, qw, 0, qfront, quv, st.stream())) != PLH_OK) return rc;
+  hipLaunchKernelGGL(k_and_bytes, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)st.stream(), qv, (const uint8_t*)qfront, nq);
+  PLH_LAUNCH_CHECK();
+  rc = launch_proj_points(1, f->kps, f->desc, f->dn, n, 1, &f->gp, f->cellStart, f->cellItems, scale_factors, nlevels, docc, dnq, nq, qv, quv, ql,
+                          qa, qd, qh, th, 0.f, mode, check_ori, da, dc, st.stream(), who);
+  if (rc != PLH_OK) return rc;
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
+  return PLH_OK;
+}
 // ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) on two resident frames.
 plh_status plh_orb_search_for_initialization_resident(const plh_frame_points* f1, const plh_frame_points* f2, float* prev_matched,
                                                       int window_size, float nnratio, int check_ori, int32_t* matches12, int* nmatches) {
