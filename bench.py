@@ -511,6 +511,7 @@ def main():
                          "--steps and --warmup, so that a command line always verifies the same part and CI cycles through all of them "
                          "by varying it; reported as verified.full_sub_batch")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # 1-rank RCCL communicator: rehearses the N > 1 path
+    ap.add_argument("--strong-leg", action="store_true", help=argparse.SUPPRESS)   # with --force-dist --no-extras: only the configs[4] strong-scaling leg
     ap.add_argument("--serial", action="store_true", help="ORB and line halves on one stream (no overlap); used for PMC runs")
     args = ap.parse_args()
 
@@ -663,11 +664,11 @@ def main():
         alg = W.algorithmic_bytes(res)
         dom = int(np.argmax(per_ms))
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh -> profiles/hbm_traffic.json), bytes per frame, and the
-        # SQ instruction counters (tools/pmc_insts.sh -> profiles/r05_insts.json): collected on the headline workload only
+        # SQ instruction counters (tools/pmc_insts.sh -> profiles/sq_insts.json; round 5 wrote r05_insts.json): collected on the headline workload only
         headline = W.tum and args.nfeatures == 1000 and real is None
         # PMC figures are a property of a build: they are reported only when the file carries this library's build id
         build = P.load().plh_version().decode().split("build ")[-1].strip()
-        tj, ij = load_profile_json("hbm_traffic.json"), load_profile_json("r05_insts.json")
+        tj, ij = load_profile_json("hbm_traffic.json"), (load_profile_json("sq_insts.json") or load_profile_json("r05_insts.json"))
         pmc_ok = headline and refine == lib_default and not args.no_screen   # (the profiles are collected at the library's default level)
         traffic = tj.get("kernels", {}) if pmc_ok and tj.get("build") == build else {}
         insts = ij.get("kernels", {}) if pmc_ok and ij.get("build") == build else {}
@@ -933,7 +934,7 @@ def main():
     # ---- N > 1: the literal BASELINE configs[4] job in the same line as the weak-scaling headline: 4096 frames of
     # 1241x376 / 2000 ORB / 200 lines as ONE job, rank r owns the contiguous shard [r, r + 1) * 4096 / N, records gathered to rank 0.
     # A curve over N from `value` alone is linear by construction (every rank brings its own 6144 frames); this one is strong scaling.
-    if (world > 1 or (args.force_dist and not args.no_extras)) and not strong and real is None:
+    if (world > 1 or (args.force_dist and (args.strong_leg or not args.no_extras))) and not strong and real is None:
         sleg = None
         try:
             tot = 4096
