@@ -448,8 +448,9 @@ PLH_API plh_status plh_line_search_by_projection_ml_batch_dev(
 
 /* The projection searches above run as a prepass (one lane per query: candidates, Hamming distances, the few best per query -- every
  * query of every frame in parallel) and an ordered resolve (one wavefront per frame replays the reference's order on those short
- * lists, 64 queries at a time).  on = 1 selects the one-wavefront-per-frame kernels of rounds 1-5 instead (identical results; an A/B and
- * test switch, process-wide, not for concurrent use). */
+ * lists, 64 queries at a time).  on = 1 selects the one-wavefront-per-frame kernels of rounds 1-5 instead, on = 2 the prepass + resolve
+ * with the candidate lists cut to two entries (contended queries then run out of list and take the slow path); identical results; an
+ * A/B and test switch, process-wide, not for concurrent use. */
 PLH_API plh_status plh_debug_set_proj_serial(int on);
 
 /* Host-buffer forms: one call = one reference call on one frame (they stage over PCIe, rebuild the frame's grid on the

@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(64) k_search_proj_lines(int variant, const plh
 // frames whose capacity does not fit the 13-bit index of a list entry.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef PLH_PROJ_TOPK
-#define PLH_PROJ_TOPK 8   // (tests build the emulator once with 2: nearly every contended query then takes the slow path)
+#define PLH_PROJ_TOPK 8   // (plh_debug_set_proj_serial(2) cuts the lists to 2 at run time: nearly every contended query then takes the slow path)
 #endif
 constexpr int PROJ_TOPK = PLH_PROJ_TOPK;
 constexpr uint32_t PROJ_EMPTY = 0xffffffffu, PROJ_TRUNC = 0x40000000u;
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(256) k_proj_points_prepass(int variant, const 
                                                              plh_grid_params g, const int32_t* csAll, const int32_t* ciAll, ScaleTab sf,
                                                              ScaleTab invSig2, const uint8_t* occupiedAll, const int* nqArr, int qcap,
                                                              const uint8_t* qValid, const float* qXY, const int32_t* qLevel, const float* qAux,
-                                                             const uint8_t* qDesc, float th, int mode, int nlevels, ProjTop* out) {
+                                                             const uint8_t* qDesc, float th, int mode, int nlevels, ProjTop* out, int keep) {
   const int pair = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
   if (q >= qcap) return;
   const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
@@ -702,6 +702,9 @@ __global__ void __launch_bounds__(256) k_proj_points_prepass(int variant, const 
       }
     }
   }
+#pragma unroll
+  for (int k = 1; k < PROJ_TOPK; k++)   // (test switch plh_debug_set_proj_serial(2): a list of `keep` entries, so that lists run out)
+    if (k >= keep && top[k] != PROJ_EMPTY) { top[k] = PROJ_EMPTY; trunc = true; }
   if (trunc && top[0] != PROJ_EMPTY) top[0] |= PROJ_TRUNC;
   ProjTop t;
 #pragma unroll
@@ -713,7 +716,7 @@ __global__ void __launch_bounds__(256) k_proj_lines_prepass(int variant, const p
                                                             const int* nArr, int cap, plh_grid_params g, const int32_t* csAll,
                                                             const int32_t* ciAll, int itemCap, const uint8_t* occupiedAll, const int* nqArr,
                                                             int qcap, const uint8_t* qValid, const float* qSeg, const float* qAux,
-                                                            const uint8_t* qDesc, float th, ProjTop* out) {
+                                                            const uint8_t* qDesc, float th, ProjTop* out, int keep) {
   const int pair = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
   if (q >= qcap) return;
   const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
@@ -793,6 +796,9 @@ __global__ void __launch_bounds__(256) k_proj_lines_prepass(int variant, const p
       }
     }
   }
+#pragma unroll
+  for (int k = 1; k < PROJ_TOPK; k++)   // (test switch plh_debug_set_proj_serial(2): a list of `keep` entries, so that lists run out)
+    if (k >= keep && top[k] != PROJ_EMPTY) { top[k] = PROJ_EMPTY; trunc = true; }
   if (trunc && top[0] != PROJ_EMPTY) top[0] |= PROJ_TRUNC;
   ProjTop t;
 #pragma unroll
@@ -1127,7 +1133,9 @@ __global__ void __launch_bounds__(64) k_sim3_agree(const int* n1Arr, const int* 
 namespace {
 // A/B and test switch: 1 = the one-wavefront-per-frame kernels of rounds 1-5 (k_search_proj_points / k_search_proj_lines), 0 = prepass +
 // ordered resolve (default).  Same assignments either way (tests/test_frame_search.py runs both against the oracle).
+// 2 = prepass + resolve with the candidate lists cut to two entries: contended queries run out of list and take the slow path (tests).
 bool g_proj_serial = false;
+int g_proj_keep = PROJ_TOPK;
 bool scale_tab(const float* sf, int nlevels, ScaleTab* t) {
   if (!sf || nlevels <= 0 || nlevels > 16) return false;
   for (int i = 0; i < 16; i++) t->v[i] = i < nlevels ? sf[i] : 0.f;
@@ -1138,7 +1146,8 @@ bool scale_tab(const float* sf, int nlevels, ScaleTab* t) {
 extern "C" {
 
 plh_status plh_debug_set_proj_serial(int on) {
-  g_proj_serial = on != 0;
+  g_proj_serial = on == 1;
+  g_proj_keep = on == 2 ? 2 : PROJ_TOPK;
   return PLH_OK;
 }
 
@@ -1220,7 +1229,7 @@ static plh_status launch_proj_points(int variant, const plh_keypoint* d_kps_un, 
     PLH_HIP(hipMallocAsync((void**)&tops, bytes, (hipStream_t)stream));
     hipLaunchKernelGGL(k_proj_points_prepass, dim3((qcap + 255) / 256, pairs), dim3(256), 0, (hipStream_t)stream, variant, d_kps_un, d_desc,
                        (const int*)d_n, cap, *gp, d_cs, d_ci, sf, is2, (const uint8_t*)d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_xy,
-                       d_q_level, d_q_aux, d_q_desc, th, mode, nlevels, tops);
+                       d_q_level, d_q_aux, d_q_desc, th, mode, nlevels, tops, g_proj_keep);
     const size_t lds = (size_t)cap * (3 * 4 + 2) + (size_t)q_lds * (4 + 1) + 128 + 64;
     ProjFrame F{d_kps_un, d_desc, nullptr, nullptr, 0, d_cs, d_ci};
     plh_status st = lds_request(k_proj_resolve, lds, who);
@@ -1386,7 +1395,7 @@ static plh_status launch_proj_lines(int variant, const plh_keyline* d_kl, const 
     PLH_HIP(hipMallocAsync((void**)&tops, (size_t)pairs * qcap * sizeof(ProjTop), (hipStream_t)stream));
     hipLaunchKernelGGL(k_proj_lines_prepass, dim3((qcap + 255) / 256, pairs), dim3(256), 0, (hipStream_t)stream, variant, d_kl, d_ldesc, d_linefn,
                        (const int*)d_nl, cap, *gp, d_cs, d_ci, item_cap, (const uint8_t*)d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_seg,
-                       d_q_aux, d_q_desc, th, tops);
+                       d_q_aux, d_q_desc, th, tops, g_proj_keep);
     const size_t lds2 = (size_t)cap * (3 * 4 + 2) + 128 + 64;
     ScaleTab none;
     for (int i = 0; i < 16; i++) none.v[i] = 0.f;

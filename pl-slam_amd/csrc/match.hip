@@ -150,13 +150,18 @@ __global__ void __launch_bounds__(256) k_line_mutual(const int32_t* m1, const in
 }
 
 // ---------------------------------------------------------------------------------------------
-// SearchByBoW.  One block per pair.  Phase A (256 threads): stable rank-sort of both feature sets
+// SearchByBoW.  One block per pair.  Phase A (all threads): stable rank-sort of both feature sets
 // by (node id, feature index) == iteration order of DBoW2::FeatureVector (std::map<node, vector<idx>>).
-// Phase B (wave 0): KeyFrame features in that order, strictly sequential because of the greedy
-// "already matched" skip (ORBmatcher.cc:240); the 64 lanes scan the Frame candidates of the node.
+// Phase B: KeyFrame features in that order, sequential because of the greedy "already matched" skip
+// (ORBmatcher.cc:240) -- but only WITHIN a node: a KeyFrame feature's candidates are the Frame features under the same
+// node, so a claim made under one node is never read under another.  The nodes of a pair (some hundred, a dozen features
+// each) are dealt to the block's wavefronts round-robin (round 6; rounds 1 - 5 walked all of a pair's features on wave 0:
+// 3.6 ms for one pair of 1000 features, which is what a tracker pays in TrackReferenceKeyFrame); the 64 lanes scan the
+// Frame candidates of the node.  The rotation histogram only counts (ComputeThreeMaxima reads the bins' sizes), so it is
+// summed over the wavefronts at the end.
 // ---------------------------------------------------------------------------------------------
 // (wave_min_i32: DPP row steps on the hardware, plh_shims.h)
-__global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1,
+__global__ void __launch_bounds__(1024) k_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1,
                                                        const uint8_t* valid1, const int* n1Arr, const uint8_t* desc2,
                                                        const float* angle2, const int32_t* node2, const int* n2Arr, int cap,
                                                        int angStride, int thLow, float nnratio, int checkOri, int32_t* matches21,
@@ -171,12 +176,17 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
   unsigned short* ord2 = ord1 + cap;
   unsigned short* rlo = ord2 + cap;      // per sorted position of set 1: [rlo, rhi) = sorted positions of set 2 with
   unsigned short* rhi = rlo + cap;       // the same node (empty for invalid / unusable features)
-  unsigned char* bin2 = (unsigned char*)(rhi + cap);
+  unsigned short* gs = rhi + cap;        // [cap + 1] first sorted position of every node group of set 1
+  unsigned char* bin2 = (unsigned char*)(gs + cap + 2);
+  __shared__ int s_part[1024];
+  __shared__ int s_groups, s_nm, s_hist[32];
 
-  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int pair = blockIdx.x, tid = threadIdx.x, T = (int)blockDim.x;
   const int n1 = max(0, min(n1Arr[pair], cap)), n2 = max(0, min(n2Arr[pair], cap));
   const long long o = (long long)pair * cap;
-  for (int i = tid; i < cap; i += 256) {
+  if (tid < 32) s_hist[tid] = 0;
+  if (tid == 0) { s_nm = 0; s_groups = 0; }
+  for (int i = tid; i < cap; i += T) {
     nd1[i] = i < n1 ? node1[o + i] : -1;
     nd2[i] = i < n2 ? node2[o + i] : -1;
     m2[i] = -1;
@@ -185,7 +195,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
   }
   __syncthreads();
   // invalid nodes (< 0) sort to the end: key = node<0 ? INT_MAX : node
-  for (int i = tid; i < n1; i += 256) {
+  for (int i = tid; i < n1; i += T) {
     const int k = nd1[i] < 0 ? INT_MAX : nd1[i];
     int r = 0;
     for (int j = 0; j < n1; j++) {
@@ -194,7 +204,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     }
     ord1[r] = (unsigned short)i;
   }
-  for (int i = tid; i < n2; i += 256) {
+  for (int i = tid; i < n2; i += T) {
     const int k = nd2[i] < 0 ? INT_MAX : nd2[i];
     int r = 0;
     for (int j = 0; j < n2; j++) {
@@ -206,7 +216,7 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
   }
   __syncthreads();
   // candidate ranges of every KeyFrame feature, in parallel: the sequential walk below then only reads them
-  for (int r1 = tid; r1 < n1; r1 += 256) {
+  for (int r1 = tid; r1 < n1; r1 += T) {
     const int i = ord1[r1];
     const int nd = nd1[i];
     int lo = 0, hi2 = 0;
@@ -220,10 +230,39 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     rlo[r1] = (unsigned short)lo;
     rhi[r1] = (unsigned short)hi2;
   }
+  // the node groups of set 1: sorted positions where the node changes (each thread a contiguous chunk, counts scanned by wave 0)
+  const int chunk = (n1 + T - 1) / T, c0 = min(tid * chunk, n1), c1 = min(c0 + chunk, n1);
+  {
+    int cnt = 0;
+    for (int r1 = c0; r1 < c1; r1++) cnt += r1 == 0 || nd1[ord1[r1]] != nd1[ord1[r1 - 1]];
+    s_part[tid] = cnt;
+  }
   __syncthreads();
-  if (tid >= 64) return;
+  if (tid < 64) {
+    const int per = (T + 63) / 64;
+    int sum = 0;
+    for (int k = 0; k < per; k++) sum += tid * per + k < T ? s_part[tid * per + k] : 0;
+    int incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if (tid >= d) incl += v;
+    }
+    int run = incl - sum;
+    for (int k = 0; k < per; k++)
+      if (tid * per + k < T) { const int c = s_part[tid * per + k]; s_part[tid * per + k] = run; run += c; }
+    if (tid == 63) s_groups = incl;
+  }
+  __syncthreads();
+  {
+    int g = s_part[tid];
+    for (int r1 = c0; r1 < c1; r1++)
+      if (r1 == 0 || nd1[ord1[r1]] != nd1[ord1[r1 - 1]]) gs[g++] = (unsigned short)r1;
+    if (tid == 0) gs[s_groups] = (unsigned short)n1;
+  }
+  __syncthreads();
+  const int nGroups = s_groups;
 
-  const int lane = tid;
+  const int lane = tid & 63, wv = tid >> 6, nWaves = T >> 6;
   const float factor = 1.0f / 30;
   int myHist = 0;      // lane b < 30 holds rotHist[b].size()
   int nmatches = 0;
@@ -238,12 +277,12 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     float a1;
     Desc256 dk, df;
   };
-  auto fetch = [&](int r1, Pre& p) {
+  auto fetch = [&](int r1, int rEnd, Pre& p) {   // position r1 of the group that ends at rEnd
     const int rr = min(r1, max(n1 - 1, 0));
     p.i = ord1[rr];
     p.lo = rlo[rr];
-    p.hi = r1 < n1 ? (int)rhi[rr] : 0;
-    if (r1 >= n1) p.lo = 0;
+    p.hi = r1 < rEnd ? (int)rhi[rr] : 0;
+    if (r1 >= rEnd) p.lo = 0;
     p.f = ord2[min(p.lo + lane, max(n2 - 1, 0))];
     p.dk = load_desc(D1 + (long long)p.i * 32);
     p.df = load_desc(D2 + (long long)p.f * 32);
@@ -294,16 +333,26 @@ __global__ void __launch_bounds__(256) k_search_by_bow(const uint8_t* desc1, con
     }
   };
   if (n1 > 0 && n2 > 0) {
-    Pre A, B;
-    fetch(0, A);
-    for (int r1 = 0; r1 < n1; r1 += 2) {
-      fetch(r1 + 1, B);
-      step(A);
-      fetch(r1 + 2, A);
-      step(B);
+    for (int g = wv; g < nGroups; g += nWaves) {
+      const int rBeg = gs[g], rEnd = gs[g + 1];
+      Pre A, B;
+      fetch(rBeg, rEnd, A);
+      for (int r1 = rBeg; r1 < rEnd; r1 += 2) {
+        fetch(r1 + 1, rEnd, B);
+        step(A);
+        fetch(r1 + 2, rEnd, A);
+        step(B);
+      }
     }
   }
   PLH_WAVE_SYNC();
+  // the wavefronts' counts into one histogram; wave 0 finishes
+  if (checkOri && lane < 30 && myHist) atomicAdd(&s_hist[lane], myHist);
+  if (lane == 0 && nmatches) atomicAdd(&s_nm, nmatches);
+  __syncthreads();
+  if (wv != 0) return;
+  myHist = lane < 30 ? s_hist[lane] : 0;
+  nmatches = s_nm;
   if (checkOri) {   // ComputeThreeMaxima over the 30 bins
     int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
     for (int b = 0; b < 30; b++) {
@@ -471,7 +520,9 @@ __global__ void __launch_bounds__(256) k_search_triangulation(const plh_keypoint
 
 static size_t tri_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
 
-static size_t bow_lds_bytes(int cap) { return (size_t)cap * (5 * 4 + 4 * 2 + 1) + 64; }
+static size_t bow_lds_bytes(int cap) { return (size_t)cap * (5 * 4 + 5 * 2 + 1) + 64 + 8; }
+// wavefronts per pair: a lone pair (a tracker's TrackReferenceKeyFrame) gets sixteen to deal its nodes to, a resident batch four
+static int bow_threads(int pairs) { return pairs >= 1024 ? 256 : (pairs >= 128 ? 512 : 1024); }
 
 
 }  // namespace plh
@@ -592,7 +643,7 @@ plh_status plh_orb_search_by_bow_batch_dev(const uint8_t* d_desc1, const float* 
     return PLH_ERR_INVALID;
   }
   if (lds_request(k_search_by_bow, bow_lds_bytes(cap), "SearchByBoW") != PLH_OK) return PLH_ERR_INVALID;
-  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1, d_angle1,
+  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(bow_threads(pairs)), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1, d_angle1,
                      d_node1, d_valid1, (const int*)d_n1, d_desc2, d_angle2, d_node2, (const int*)d_n2, cap, 1, th_low, nnratio,
                      check_ori, d_matches21, d_nmatches, (const uint8_t*)nullptr, 0);
   PLH_LAUNCH_CHECK();
@@ -613,7 +664,7 @@ plh_status plh_orb_search_by_bow_kp_batch_dev(const uint8_t* d_desc1, const plh_
   }
   static_assert(sizeof(plh_keypoint) == 28, "plh_keypoint layout");
   if (lds_request(k_search_by_bow, bow_lds_bytes(cap), "SearchByBoW") != PLH_OK) return PLH_ERR_INVALID;
-  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
+  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(bow_threads(pairs)), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
                      reinterpret_cast<const float*>(d_kps1) + 3, d_node1, d_valid1, (const int*)d_n1, d_desc2,
                      reinterpret_cast<const float*>(d_kps2) + 3, d_node2, (const int*)d_n2, cap, 7, th_low, nnratio, check_ori,
                      d_matches21, d_nmatches, (const uint8_t*)nullptr, 0);
@@ -634,7 +685,7 @@ plh_status plh_orb_search_by_bow_kfkf_batch_dev(const uint8_t* d_desc1, const pl
     return PLH_ERR_INVALID;
   }
   if (lds_request(k_search_by_bow, bow_lds_bytes(cap), "SearchByBoW") != PLH_OK) return PLH_ERR_INVALID;
-  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(256), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
+  hipLaunchKernelGGL(k_search_by_bow, dim3(pairs), dim3(bow_threads(pairs)), bow_lds_bytes(cap), (hipStream_t)stream, d_desc1,
                      reinterpret_cast<const float*>(d_kps1) + 3, d_node1, d_valid1, (const int*)d_n1, d_desc2,
                      reinterpret_cast<const float*>(d_kps2) + 3, d_node2, (const int*)d_n2, cap, 7, th_low, nnratio, check_ori,
                      d_matches12, d_nmatches, d_valid2, 1);

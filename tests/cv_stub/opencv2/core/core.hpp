@@ -21,6 +21,8 @@ class Mat {
   void create(int rows, int cols, int type);
   Mat rowRange(int a, int b) const; void copyTo(OutputArray m) const;
   template <typename T> T* ptr(int r = 0); template <typename T> const T* ptr(int r = 0) const;
+  template <typename T> T& at(int i); template <typename T> const T& at(int i) const;
+  template <typename T> T& at(int r, int c); template <typename T> const T& at(int r, int c) const;
 };
 struct Point2f { float x, y; };
 class KeyPoint { public: Point2f pt; float size, angle, response; int octave, class_id; };

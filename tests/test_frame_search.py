@@ -661,7 +661,7 @@ def _parallel_equals_serial(P, O, S, lib, n, nl, dups):
                 qq["length"] = np.ascontiguousarray(f1["keylines"]["lineLength"][rep].astype(np.float32))
                 ql.append(qq)
             res = {}
-            for serial in (1, 0):
+            for serial in (1, 0, 2):   # 2: candidate lists of two entries -- contended queries run out of list and take the slow path
                 H.plh_debug_set_proj_serial(serial)
                 out = [fs.SearchByProjectionMapPoints(qm, [occ0, occ0], th=3.0, nnratio=0.8),
                        fs.SearchByProjectionMapPoints(qm, [occ0, occ0], th=1.0, nnratio=0.9),
@@ -673,9 +673,11 @@ def _parallel_equals_serial(P, O, S, lib, n, nl, dups):
                        fs.LineSearchByProjectionMapLines(ql, [locc0, locc0], th=3.0, nnratio=0.9),
                        fs.LineSearchByProjectionLastFrame(ql, [locc0, locc0], th=12.0)]
                 res[serial] = out
-            for k, (a, b) in enumerate(zip(res[1], res[0])):
-                for u, v in zip(a, b):
-                    assert (np.asarray(u) == np.asarray(v)).all(), "search %d, seed %d, %d-fold queries: prepass + resolve differs from the sequential kernel" % (k, seed, dup)
+            for mode in (0, 2):
+                for k, (a, b) in enumerate(zip(res[1], res[mode])):
+                    for u, v in zip(a, b):
+                        assert (np.asarray(u) == np.asarray(v)).all(), ("search %d, seed %d, %d-fold queries: prepass + resolve (mode %d) differs from "
+                                                                        "the sequential kernel" % (k, seed, dup, mode))
             assert res[0][0][1].min() > 0 and res[0][2][1].min() > 0 and res[0][7][1].min() > 0
     finally:
         H.plh_debug_set_proj_serial(0)
