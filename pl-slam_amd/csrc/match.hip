@@ -161,6 +161,8 @@ __global__ void __launch_bounds__(256) k_line_mutual(const int32_t* m1, const in
 // summed over the wavefronts at the end.
 // ---------------------------------------------------------------------------------------------
 // (wave_min_i32: DPP row steps on the hardware, plh_shims.h)
+constexpr int BOW_K = 4;        // candidates kept per KeyFrame feature of a small node group
+constexpr int BOW_SMALL = 64;   // a node group is small if its candidate range is no wider than this
 __global__ void __launch_bounds__(1024) k_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1,
                                                        const uint8_t* valid1, const int* n1Arr, const uint8_t* desc2,
                                                        const float* angle2, const int32_t* node2, const int* n2Arr, int cap,
@@ -172,12 +174,14 @@ __global__ void __launch_bounds__(1024) k_search_by_bow(const uint8_t* desc1, co
   int* snode2 = nd2 + cap;               // node id by sorted position (set 2)
   int* m2 = snode2 + cap;                // Frame feature -> KeyFrame feature
   float* ang2 = (float*)(m2 + cap);      // angle of the Frame's keypoints (read at every accepted match)
-  unsigned short* ord1 = (unsigned short*)(ang2 + cap);
+  unsigned* tops = (unsigned*)(ang2 + cap);   // [cap][BOW_K] the best candidates of a KeyFrame feature (small node groups)
+  unsigned short* ord1 = (unsigned short*)(tops + (size_t)cap * BOW_K);
   unsigned short* ord2 = ord1 + cap;
   unsigned short* rlo = ord2 + cap;      // per sorted position of set 1: [rlo, rhi) = sorted positions of set 2 with
   unsigned short* rhi = rlo + cap;       // the same node (empty for invalid / unusable features)
   unsigned short* gs = rhi + cap;        // [cap + 1] first sorted position of every node group of set 1
   unsigned char* bin2 = (unsigned char*)(gs + cap + 2);
+  unsigned char* gbig = bin2 + cap;      // per node group: its candidate range is wider than a wavefront (BOW_SMALL)
   __shared__ int s_part[1024];
   __shared__ int s_groups, s_nm, s_hist[32];
 
@@ -261,13 +265,100 @@ __global__ void __launch_bounds__(1024) k_search_by_bow(const uint8_t* desc1, co
   }
   __syncthreads();
   const int nGroups = s_groups;
-
-  const int lane = tid & 63, wv = tid >> 6, nWaves = T >> 6;
   const float factor = 1.0f / 30;
-  int myHist = 0;      // lane b < 30 holds rotHist[b].size()
-  int nmatches = 0;
   const uint8_t* D1 = desc1 + o * 32;
   const uint8_t* D2 = desc2 + o * 32;
+  int nmatches = 0;
+  // ---- small node groups (candidate range <= BOW_SMALL: all of them with a real vocabulary -- 10^2 nodes four levels up, a dozen
+  // features each): the distances do not depend on the matching state, so every KeyFrame feature first gets the BOW_K best candidates
+  // of its node in (distance, position) order, all features in parallel; the reference's (best, second best) are the first two FREE
+  // entries of that order (strict `<` in its scan: the first of equal distances wins).  Then ONE LANE per group replays the group's
+  // features in order on the lists -- LDS reads only; a list that was cut and has fewer than two free entries left is re-evaluated
+  // exactly over the node's candidates.
+  for (int g = tid; g < nGroups; g += T) {
+    int big = 0;
+    for (int r1 = gs[g]; r1 < gs[g + 1]; r1++) big |= (int)rhi[r1] - (int)rlo[r1] > BOW_SMALL;
+    gbig[g] = (unsigned char)big;
+  }
+  for (int r1 = tid; r1 < n1; r1 += T) {
+    const int lo = rlo[r1], hi2 = rhi[r1];
+    unsigned top[BOW_K];
+#pragma unroll
+    for (int k = 0; k < BOW_K; k++) top[k] = 0xffffffffu;
+    bool cut = false;
+    if (lo < hi2 && hi2 - lo <= BOW_SMALL) {
+      const Desc256 dk = load_desc(D1 + (long long)ord1[r1] * 32);
+      for (int c = lo; c < hi2; c++) {
+        const int f = ord2[c];
+        if (valid2 && !valid2[o + f]) continue;
+        const Desc256 df = load_desc(D2 + (long long)f * 32);
+        unsigned e = ((unsigned)hamming256(dk.w, df.w) << 16) | (unsigned)(c - lo);
+        if (top[BOW_K - 1] != 0xffffffffu) cut = true;   // one entry will not fit
+#pragma unroll
+        for (int k = 0; k < BOW_K; k++)
+          if (e < top[k]) { const unsigned t = top[k]; top[k] = e; e = t; }
+      }
+      if (cut && top[0] != 0xffffffffu) top[0] |= 0x80000000u;
+    }
+#pragma unroll
+    for (int k = 0; k < BOW_K; k++) tops[(size_t)r1 * BOW_K + k] = top[k];
+  }
+  __syncthreads();
+  for (int g = tid; g < nGroups; g += T) {
+    if (gbig[g]) continue;
+    for (int r1 = gs[g]; r1 < gs[g + 1]; r1++) {
+      const int lo = rlo[r1], hi2 = rhi[r1];
+      if (lo >= hi2) continue;
+      const int i = ord1[r1];
+      int b1 = 256, b2 = 256, bestC = -1, nfree = 0;
+      bool cut = false;
+#pragma unroll
+      for (int k = 0; k < BOW_K; k++) {
+        unsigned e = tops[(size_t)r1 * BOW_K + k];
+        if (e == 0xffffffffu || nfree == 2) continue;
+        if (k == 0) { cut = (e & 0x80000000u) != 0u; e &= 0x7fffffffu; }
+        const int c = lo + (int)(e & 0xffffu);
+        if (m2[ord2[c]] >= 0) continue;
+        if (nfree == 0) { b1 = (int)(e >> 16); bestC = c; }
+        else b2 = (int)(e >> 16);
+        nfree++;
+      }
+      if (cut && nfree < 2) {   // the list ran out: the reference's scan over what is still free under the node
+        const Desc256 dk = load_desc(D1 + (long long)i * 32);
+        b1 = 256; b2 = 256; bestC = -1;
+        for (int c = lo; c < hi2; c++) {
+          const int f = ord2[c];
+          if (m2[f] >= 0) continue;
+          if (valid2 && !valid2[o + f]) continue;
+          const Desc256 df = load_desc(D2 + (long long)f * 32);
+          const int d = hamming256(dk.w, df.w);
+          if (d < b1) { b2 = b1; b1 = d; bestC = c; }
+          else if (d < b2) { b2 = d; }
+        }
+      }
+      if (bestC < 0) continue;
+      if ((kfkf ? b1 < thLow : b1 <= thLow) && (float)b1 < nnratio * (float)b2) {
+        const int bestF = ord2[bestC];
+        int bin = 255;
+        if (checkOri) {
+          float rot = angle1[(o + i) * angStride] - ang2[bestF];
+          if (rot < 0.0f) rot += 360.0f;
+          bin = (int)roundf(rot * factor);
+          if (bin == 30) bin = 0;
+          atomicAdd(&s_hist[bin], 1);
+        }
+        m2[bestF] = i;
+        bin2[bestF] = (unsigned char)bin;
+        nmatches++;
+      }
+    }
+  }
+  if (nmatches) atomicAdd(&s_nm, nmatches);
+  nmatches = 0;
+  // ---- wide node groups (a vocabulary cut near its root: hundreds of features under one node), a wavefront per group
+
+  const int lane = tid & 63, wv = tid >> 6, nWaves = T >> 6;
+  int myHist = 0;      // lane b < 30 holds rotHist[b].size()
   // The walk is sequential (a match removes its Frame feature from every later search), but what a step READS from
   // global memory does not depend on the matching state: the KeyFrame descriptor, its angle and the first 64 candidate
   // descriptors of the NEXT feature are requested before the current one is decided.  Two named register sets take
@@ -333,7 +424,10 @@ __global__ void __launch_bounds__(1024) k_search_by_bow(const uint8_t* desc1, co
     }
   };
   if (n1 > 0 && n2 > 0) {
-    for (int g = wv; g < nGroups; g += nWaves) {
+    int nb = 0;   // wide groups so far
+    for (int g = 0; g < nGroups; g++) {
+      if (!gbig[g]) continue;
+      if (nb++ % nWaves != wv) continue;
       const int rBeg = gs[g], rEnd = gs[g + 1];
       Pre A, B;
       fetch(rBeg, rEnd, A);
@@ -520,7 +614,7 @@ __global__ void __launch_bounds__(256) k_search_triangulation(const plh_keypoint
 
 static size_t tri_lds_bytes(int cap) { return (size_t)cap * (4 * 4 + 2 * 2 + 1) + 64; }
 
-static size_t bow_lds_bytes(int cap) { return (size_t)cap * (5 * 4 + 5 * 2 + 1) + 64 + 8; }
+static size_t bow_lds_bytes(int cap) { return (size_t)cap * (5 * 4 + BOW_K * 4 + 5 * 2 + 2) + 64 + 8; }
 // wavefronts per pair: a lone pair (a tracker's TrackReferenceKeyFrame) gets sixteen to deal its nodes to, a resident batch four
 static int bow_threads(int pairs) { return pairs >= 1024 ? 256 : (pairs >= 128 ? 512 : 1024); }
 

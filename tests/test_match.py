@@ -29,6 +29,23 @@ def _bow_sets(synth, seed, n, nodes=100, valid_p=0.8):
     return kf, fr
 
 
+def _bow_sets_contended(synth, seed, n, nodes, protos=5):
+    """As _bow_sets, with every descriptor one of `protos` prototypes + at most two flipped bits: under a node many KeyFrame features
+    want the same few Frame features at equal or nearly equal distances -- the first-come claims decide, the candidate lists of the
+    prepass run out (round 6: k_search_by_bow's lane-per-group resolve and its exact fallback), ties go to the first in order."""
+    kf, fr = _bow_sets(synth, seed, n, nodes, valid_p=0.9)
+    rng = synth.SplitMix64(seed + 77)
+    base = kf["desc"][:protos].copy()
+    for d in (kf["desc"], fr["desc"]):
+        pick = rng.randint(len(d), 0, protos)
+        d[:] = base[pick]
+        for _ in range(2):
+            hit = rng.uniform(len(d)) < 0.5
+            byte, bit = rng.randint(len(d), 0, 32), rng.randint(len(d), 0, 8)
+            d[np.arange(len(d))[hit], byte[hit]] ^= (1 << bit[hit]).astype(np.uint8)
+    return kf, fr
+
+
 def _oracle_bow(O, kf, fr, th_low, nnratio, check):
     n1, n2 = len(kf["desc"]), len(fr["desc"])
     out = np.zeros(max(n2, 1), np.int32)
@@ -112,6 +129,13 @@ def test_emu_search_by_bow(plslam, oracle, synth, emu_lib):
         c, got = om.SearchByBoW(kf, fr)
         rc, ref = _oracle_bow(oracle, kf, fr, 50, 0.7, True)
         assert c == rc and (got == ref).all() and c > 10
+    for seed, n, nodes, nn in [(210, 300, 12, 0.7), (211, 300, 12, 1.01), (212, 120, 1, 1.01), (213, 500, 40, 1.01)]:
+        kf, fr = _bow_sets_contended(synth, seed, n, nodes)
+        omc = plslam.ORBmatcher(nn, True, lib=emu_lib)
+        c, got = omc.SearchByBoW(kf, fr)
+        rc, ref = _oracle_bow(oracle, kf, fr, 50, nn, True)
+        assert c == rc and (got == ref).all(), (seed, c, rc)
+        assert nn < 1 or c > 20
     om2 = plslam.ORBmatcher(0.9, False, lib=emu_lib)
     kf, fr = _bow_sets(synth, 203, 200, 10)
     c, got = om2.SearchByBoW(kf, fr)
@@ -158,6 +182,24 @@ def test_gpu_search_by_bow_2000(plslam, oracle, synth):
         rc, ref = _oracle_bow(oracle, kf, fr, 50, 0.7, True)
         assert cnt[p] == rc and (got[p, :len(fr["desc"])] == ref).all(), p
     assert cnt[0] > 500
+    # contended sets (a handful of prototype descriptors): first-come claims, exhausted candidate lists, ties; one pair alone (sixteen
+    # wavefronts per pair) and as a batch (four)
+    for nn in (0.7, 1.01):
+        omc = plslam.ORBmatcher(nn, True)
+        kfs, frs = [], []
+        for seed, n, nodes in [(310, 2000, 100), (311, 2000, 40), (312, 1000, 12), (313, 300, 1), (314, 2000, 700)]:
+            kf, fr = _bow_sets_contended(synth, seed, n, nodes)
+            kfs.append(kf); frs.append(fr)
+        for rep in (1, 40):   # 200 pairs: the 512-thread launch
+            got, cnt = omc.SearchByBoWBatch(kfs * rep, frs * rep)
+            for p, (kf, fr) in enumerate(zip(kfs * rep, frs * rep)):
+                if p >= 5 and p < len(kfs) * rep - 5:
+                    continue
+                rc, ref = _oracle_bow(oracle, kf, fr, 50, nn, True)
+                assert cnt[p] == rc and (got[p, :len(fr["desc"])] == ref).all(), (nn, rep, p)
+        c1, g1 = omc.SearchByBoW(kfs[0], frs[0])
+        rc, ref = _oracle_bow(oracle, kfs[0], frs[0], 50, nn, True)
+        assert c1 == rc and (g1 == ref).all()
 
 
 @pytest.mark.gpu
