@@ -169,13 +169,14 @@ __global__ void __launch_bounds__(1024) k_search_by_bow(const uint8_t* desc1, co
                                                        int angStride, int thLow, float nnratio, int checkOri, int32_t* matches21,
                                                        int32_t* nmatchesOut, const uint8_t* valid2, int kfkf) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
-  int* nd1 = (int*)smem;                 // node id per feature
+  unsigned* tops = (unsigned*)smem;      // [cap][BOW_K] the best candidates of a KeyFrame feature (small node groups); before that, the
+  unsigned long long* skey = (unsigned long long*)smem;   // sort keys of phase A (at most 2 cap - 1 of them: the same 16 cap bytes)
+  int* nd1 = (int*)(tops + (size_t)cap * BOW_K);   // node id per feature
   int* nd2 = nd1 + cap;
   int* snode2 = nd2 + cap;               // node id by sorted position (set 2)
   int* m2 = snode2 + cap;                // Frame feature -> KeyFrame feature
   float* ang2 = (float*)(m2 + cap);      // angle of the Frame's keypoints (read at every accepted match)
-  unsigned* tops = (unsigned*)(ang2 + cap);   // [cap][BOW_K] the best candidates of a KeyFrame feature (small node groups)
-  unsigned short* ord1 = (unsigned short*)(tops + (size_t)cap * BOW_K);
+  unsigned short* ord1 = (unsigned short*)(ang2 + cap);
   unsigned short* ord2 = ord1 + cap;
   unsigned short* rlo = ord2 + cap;      // per sorted position of set 1: [rlo, rhi) = sorted positions of set 2 with
   unsigned short* rhi = rlo + cap;       // the same node (empty for invalid / unusable features)
@@ -198,27 +199,33 @@ __global__ void __launch_bounds__(1024) k_search_by_bow(const uint8_t* desc1, co
     ang2[i] = (checkOri && i < n2) ? angle2[(o + i) * angStride] : 0.f;
   }
   __syncthreads();
-  // invalid nodes (< 0) sort to the end: key = node<0 ? INT_MAX : node
-  for (int i = tid; i < n1; i += T) {
-    const int k = nd1[i] < 0 ? INT_MAX : nd1[i];
-    int r = 0;
-    for (int j = 0; j < n1; j++) {
-      const int kj = nd1[j] < 0 ? INT_MAX : nd1[j];
-      r += (kj < k) || (kj == k && j < i);
+  // (node, feature index) order of both sets: bitonic sort of 64-bit keys node << 16 | index in LDS; invalid nodes (< 0) sort to the
+  // end (key INT_MAX).  Rounds 1 - 5 ranked every feature against all others -- O(n^2) on one CU: 350 of the 430 us a lone pair of
+  // 2000 features cost.
+  for (int set = 0; set < 2; set++) {
+    const int n = set ? n2 : n1;
+    const int* nd = set ? nd2 : nd1;
+    int np = 1;
+    while (np < n) np <<= 1;
+    for (int i = tid; i < np; i += T)
+      skey[i] = i < n ? ((unsigned long long)(unsigned)(nd[i] < 0 ? INT_MAX : nd[i]) << 16) | (unsigned long long)i : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (np >> 1); t += T) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+          const unsigned long long a = skey[i], b = skey[l];
+          if (((i & k) == 0) ? a > b : a < b) { skey[i] = b; skey[l] = a; }
+        }
+        __syncthreads();
+      }
+    for (int r = tid; r < n; r += T) {
+      const unsigned long long e = skey[r];
+      if (set) { ord2[r] = (unsigned short)(e & 0xffffu); snode2[r] = (int)(e >> 16); }
+      else ord1[r] = (unsigned short)(e & 0xffffu);
     }
-    ord1[r] = (unsigned short)i;
+    __syncthreads();
   }
-  for (int i = tid; i < n2; i += T) {
-    const int k = nd2[i] < 0 ? INT_MAX : nd2[i];
-    int r = 0;
-    for (int j = 0; j < n2; j++) {
-      const int kj = nd2[j] < 0 ? INT_MAX : nd2[j];
-      r += (kj < k) || (kj == k && j < i);
-    }
-    ord2[r] = (unsigned short)i;
-    snode2[r] = k;
-  }
-  __syncthreads();
   // candidate ranges of every KeyFrame feature, in parallel: the sequential walk below then only reads them
   for (int r1 = tid; r1 < n1; r1 += T) {
     const int i = ord1[r1];
