@@ -359,7 +359,7 @@ class Workload:
             self.frames = S.make_frames(2 + 100000 * rank, batch, rows, cols, unique=unique)
         else:                 # strong scaling: this rank's contiguous shard of ONE job of `total` frames
             r, n, total = shard
-            self.frames = np.ascontiguousarray(S.make_frames(2, total, rows, cols, unique=unique)[r * (total // n):(r + 1) * (total // n)])
+            self.frames = S.make_frames(2, total, rows, cols, unique=unique, first=r * (total // n), n=total // n)   # (only the shard is made)
         self.d_imgs = torch.from_numpy(self.frames).to(dev)
         self.fe = PL.FrontEndPipelined(P, voc, batch, rows, cols, nfeatures, nlevels, nlines, 0.0, K, D, device=dev.index, nsplit=nsplit,
                                        lsd_refine=self.refine)
@@ -899,6 +899,16 @@ def main():
                                     "note": "512 resident frames cannot fill the GPU with one wavefront per frame, so region growing runs 8 "
                                             "wavefronts per frame there (k_lsd_grow_mw, same segments): the per-GPU rate of the literal configs[4] "
                                             "job is the configs4_share_512 figure, the 6144-frame one is what a GPU sustains on a long sequence"}
+                # the N = 1 point of the strong-scaling configs[4] job (at N > 1 the same field is the sharded, gathered job, below)
+                try:
+                    s1 = leg(4096, 4, 376, 1241, 2000, 16, refine, "configs4_strong (N = 1)")
+                    out["secondary"]["configs4_strong"] = {
+                        "value": s1["value"], "unit": "frames/s", "scaling": "strong", "n_gpus": 1, "total_frames": 4096, "frames_per_gpu": 4096,
+                        "sub_batches": 4, "steps": s1["steps"], "ms_per_step": s1["ms_per_step"], "gather": None, "verified": s1["verified"],
+                        "workload": "BASELINE configs[4]: 4096 frames of 1241x376 (KITTI00-02.yaml: 2000 ORB, 8 levels) + 200 lines as one job; "
+                                    "one GPU: no gather (with --gpus N the same field holds the sharded job with its RCCL gather)"}
+                except Exception as e:
+                    out["secondary"]["configs4_strong"] = {"error": repr(e)[:300]}
                 # the headline workload on 1024 DISTINCT frames (cycled six times to the same 6144-frame batch): 1024 control-flow traces of
                 # region growing / FAST instead of the timed batch's 32
                 try:
@@ -942,9 +952,22 @@ def main():
             ns2 = max(1, min(4, b2 // 1024))
             while b2 % ns2:
                 ns2 -= 1
-            W2 = Workload(P, S, V, PL, torch, dev, rank, b2, ns2, 376, 1241, 2000, 8, 200, 16, voc, shard=(rank, world, tot), refine=refine,
-                          screen=not args.no_screen)
-            recv2 = W2.fe.alloc_gather_buffers(world, receives=(root < 0 or rank == root))
+            W2, recv2, err2 = None, None, None
+            try:
+                W2 = Workload(P, S, V, PL, torch, dev, rank, b2, ns2, 376, 1241, 2000, 8, 200, 16, voc, shard=(rank, world, tot), refine=refine,
+                              screen=not args.no_screen)
+                recv2 = W2.fe.alloc_gather_buffers(world, receives=(root < 0 or rank == root))
+            except Exception as e:   # noqa: BLE001
+                err2 = repr(e)[:300]
+            if world > 1:   # every rank enters the collectives below, or none does
+                flag = torch.tensor([0 if err2 is None else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()) and err2 is None:
+                    err2 = "another rank could not set the job up"
+            if err2 is not None:
+                if W2 is not None:
+                    W2.close()
+                raise RuntimeError(err2)
 
             def step2():
                 W2.fe.step(W2.d_imgs, join=False)

@@ -68,7 +68,24 @@ void launch_lsd_lgamma_table(double* t, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_lsd_lgamma_table, dim3((n + 255) / 256), dim3(256), 0, s, t, n);
 }
 
-__global__ void __launch_bounds__(64) k_adv_first(LineDeviceArgs a) {
+// Register budget of rect_improve(): the kernel wants 235 registers (two wavefronts per SIMD); built for three (168 registers, 248 bytes
+// of spill per lane) it runs as fast alone and leaves a third wave slot's worth of registers to whatever shares the SIMD inside the
+// pipeline: + 2.0 % on the headline in two same-job A/Bs, the same at four / 128 registers (profiles/r06_adv_improve_registers_ab.txt).
+// -DPLH_ADV_WAVES=n builds for n (0: no cap).
+#ifndef PLH_ADV_WAVES
+#define PLH_ADV_WAVES 3
+#endif
+#if PLH_ADV_WAVES > 0 && !defined(HIPEMU)
+#define PLH_ADV_ATTR __attribute__((amdgpu_waves_per_eu(PLH_ADV_WAVES)))
+#else
+#define PLH_ADV_ATTR
+#endif
+#if defined(PLH_ADVFIRST_WAVES) && !defined(HIPEMU)
+#define PLH_ADVFIRST_ATTR __attribute__((amdgpu_waves_per_eu(PLH_ADVFIRST_WAVES)))
+#else
+#define PLH_ADVFIRST_ATTR
+#endif
+__global__ void __launch_bounds__(64) PLH_ADVFIRST_ATTR k_adv_first(LineDeviceArgs a) {
   __shared__ LsdScanGeom s_geom[64];
   __shared__ int s_tot[64], s_alg[64], s_slot[64];
   const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7;
@@ -123,7 +140,7 @@ __global__ void __launch_bounds__(64) k_adv_first(LineDeviceArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(64) k_adv_improve(LineDeviceArgs a) {
+__global__ void __launch_bounds__(64) PLH_ADV_ATTR k_adv_improve(LineDeviceArgs a) {
   __shared__ LsdScanGeom s_geom[8 * 5];   // [rectangle of the pass][variant]
   __shared__ int s_ok[8 * 5];
   const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7, g0 = lane & ~7;

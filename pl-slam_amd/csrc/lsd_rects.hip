@@ -323,8 +323,13 @@ __device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
     if (slot >= 0) put(slot, rec);
   }
 }
-__global__ void __launch_bounds__(64) k_lsd_rects(LineDeviceArgs a) { lsd_rects_group<false>(a); }
-__global__ void __launch_bounds__(64) k_lsd_rects_adv(LineDeviceArgs a) { lsd_rects_group<true>(a); }
+#if defined(PLH_RECTS_WAVES) && !defined(HIPEMU)   // (A/B builds)
+#define PLH_RECTS_ATTR __attribute__((amdgpu_waves_per_eu(PLH_RECTS_WAVES)))
+#else
+#define PLH_RECTS_ATTR
+#endif
+__global__ void __launch_bounds__(64) PLH_RECTS_ATTR k_lsd_rects(LineDeviceArgs a) { lsd_rects_group<false>(a); }
+__global__ void __launch_bounds__(64) PLH_RECTS_ATTR k_lsd_rects_adv(LineDeviceArgs a) { lsd_rects_group<true>(a); }
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s);   // lsd_adv.hip
 // One-wavefront blocks per frame for the rectangle / LSD_REFINE_ADV kernels: as many as it takes to put ~ 4096 wavefronts on the GPU

@@ -79,22 +79,27 @@ def make_frame(seed, rows=480, cols=640, n_rect=400, n_line=200):
     return np.floor(acc / 9.0 + 0.5).astype(np.uint8)
 
 
-def make_frames(seed0, count, rows=480, cols=640, unique=None):
+def make_frames(seed0, count, rows=480, cols=640, unique=None, first=0, n=None):
     """`count` frames.  With `unique` < count only that many are rasterised; the rest are cheap,
-    distinct variants (cyclic shift of rows + small brightness offset) so no two frames are equal."""
+    distinct variants (cyclic shift of rows + small brightness offset) so no two frames are equal.
+    first / n: only frames [first, first + n) of the `count` are made (a rank's shard of one job: same frames as the whole)."""
     unique = count if unique is None else max(1, min(unique, count))
-    base = [make_frame(seed0 + i, rows, cols) for i in range(unique)]
     reps = -(-count // unique)
-    out = np.empty((count, rows, cols), dtype=np.uint8)
-    for i in range(count):
+    n = count - first if n is None else n
+    need = sorted({i // reps for i in range(first, first + n)})
+    made = {u: make_frame(seed0 + u, rows, cols) for u in need}
+    base = [made.get(u) for u in range(unique)]
+    out = np.empty((n, rows, cols), dtype=np.uint8)
+    for j in range(n):
+        i = first + j
         # consecutive indices are consecutive "camera poses" of the same scene (3-row shift + exposure change),
         # so frame-to-frame matching has real correspondences
         b = base[i // reps]
         k = i % reps
         if k == 0:
-            out[i] = b
+            out[j] = b
         else:
-            out[i] = np.clip(np.roll(b, (3 * k) % rows, axis=0).astype(np.int16) + (k % 7) - 3, 0, 255).astype(np.uint8)
+            out[j] = np.clip(np.roll(b, (3 * k) % rows, axis=0).astype(np.int16) + (k % 7) - 3, 0, 255).astype(np.uint8)
     return out
 
 

@@ -39,9 +39,13 @@ def test_region_growing_keeps_its_seven_wave_slots(res):
 
 
 def test_no_other_kernel_spills(res):
+    # round 6: k_adv_improve is BUILT for three wavefronts per SIMD (168 of the 235 registers it wants, 248 bytes of spill): as fast
+    # alone, + 1.3 - 2.0 % on the headline for the room it leaves the other sub-batches' wavefronts (profiles/r06_adv_improve_registers_ab.txt)
     bad = {k: (r["private_segment_fixed_size"], r["uses_dynamic_stack"]) for k, r in res.items()
-           if k not in ("k_lsd_grow", "k_lsd_grow_mw16") and (r["private_segment_fixed_size"] != 0 or r["uses_dynamic_stack"])}
+           if k not in ("k_lsd_grow", "k_lsd_grow_mw16", "k_adv_improve") and (r["private_segment_fixed_size"] != 0 or r["uses_dynamic_stack"])}
     assert not bad, bad
+    imp = res["k_adv_improve"]
+    assert _waves(imp) >= 3 and imp["private_segment_fixed_size"] <= 256 and not imp["uses_dynamic_stack"], imp
 
 
 def test_dense_kernels_run_eight_wavefronts_per_simd(res):
