@@ -229,6 +229,24 @@ def run(pairs=1024, distinct=32, steps=10, warmup=2, n=1000, nl=200, mapk=6, lin
                                                                                            local_points=nmatch[2] / nchk, local_lines=nmatch[3] / nchk)),
                cpu_baseline=dict(value=round(ncpu / t_cpu, 2) if t_cpu > 0 else None, unit="frames/s", cores=1, kind="port",
                                  sample="%d frames, the oracle chain (oracle/frame_search.cc) on one thread" % ncpu))
+    # what bounds it: the instruction streams of the prepass lanes.  SQ counters of the same build (tools/pmc_tracking.sh ->
+    # profiles/sq_insts_tracking.json), VALU wave-instructions per frame x frames/s against 1024 SIMDs x 2.4 GHz / 4.2 cycles
+    try:
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        pj = os.path.join(ROOT, "profiles", "sq_insts_tracking.json")
+        if os.path.exists(pj):
+            ij = json.load(open(pj))
+            if ij.get("build") == g._lib_id(g.LIB) and lib is None:
+                peak = 1024 * 2.4e9 / 4.2
+                valu = float(ij["total_valu"])
+                out["roofline"] = dict(bound="valu_issue", achieved=round(valu * out["value"] / 1e9, 1), peak=round(peak / 1e9, 1), unit="G wave-instructions/s",
+                                       frac=round(valu * out["value"] / peak, 4), valu_wave_instructions_per_frame=round(valu),
+                                       wait_share=round(float(ij["total_wait_any"]) / max(float(ij["total_wave_cycles"]), 1.0), 3),
+                                       per_kernel=ij["kernels"], build=ij.get("build"),
+                                       what="all kernels of a step; SQ counters of this build (tools/pmc_tracking.sh)")
+    except Exception as e:   # noqa: BLE001
+        out["roofline"] = {"error": repr(e)[:160]}
     return out
 
 
