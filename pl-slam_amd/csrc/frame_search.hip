@@ -806,6 +806,149 @@ __global__ void __launch_bounds__(256) k_proj_lines_prepass(int variant, const p
   out[qo + q] = t;
 }
 
+// Lines, small launches (at most PROJ_G8_MAX queries in all -- a tracker's call on one frame): EIGHT lanes per query.  A line query
+// probes three points with windows of many cells, and every occurrence of a keyline in them costs a 68-byte record, its line equation
+// and a descriptor row: one lane per query walks ~250 occurrences one after the other -- 250 us for the 200 map lines of ONE frame,
+// what made LSDmatcher::SearchByProjection through the adaptor as slow as the CPU.  (A resident batch has queries enough to fill the
+// GPU with one lane each, and there the eight-lane form's eightfold index scan costs 3 x the time: measured, 0.99 -> 3.06 ms per 1024
+// frames.)  The LINES are dealt to the query's eight lanes (keyline index mod 8): every lane walks all occurrences
+// (one index load each) but pays for its own lines only, so that all occurrences of a line meet in one lane -- "listed once, at its
+// first passing probe" stays a per-lane matter -- and keeps its best PROJ_TOPK by (distance, occurrence number); the occurrence
+// number IS the enumeration order of the reference's loops.  A lane's list is exact for its lines, so the PROJ_TOPK least heads of
+// the eight lists, taken one by one, are the one-lane form's list.
+constexpr int PROJ_LG = 8;   // lanes per line query
+constexpr long long PROJ_G8_MAX = 4096;   // queries of a launch up to which the eight-lane form is used
+__device__ __forceinline__ unsigned long long proj_key(int dist, unsigned seq, int id, int level) {
+  return ((unsigned long long)(unsigned)dist << 44) | ((unsigned long long)(seq & 0x7ffffffu) << 17) | ((unsigned long long)(unsigned)id << 4) |
+         (unsigned long long)(level & 15);
+}
+__device__ __forceinline__ int pkey_id(unsigned long long k) { return (int)((k >> 4) & 0x1fffu); }
+constexpr unsigned long long PKEY_EMPTY = ~0ull;
+__global__ void __launch_bounds__(256) k_proj_lines_prepass_g8(int variant, const plh_keyline* kls, const uint8_t* ldesc, const double* fnAll,
+                                                            const int* nArr, int cap, plh_grid_params g, const int32_t* csAll,
+                                                            const int32_t* ciAll, int itemCap, const uint8_t* occupiedAll, const int* nqArr,
+                                                            int qcap, const uint8_t* qValid, const float* qSeg, const float* qAux,
+                                                            const uint8_t* qDesc, float th, ProjTop* out, int keep) {
+  const int pair = blockIdx.y, q = blockIdx.x * (256 / PROJ_LG) + (int)(threadIdx.x / PROJ_LG), sub = (int)(threadIdx.x % PROJ_LG);
+  // (a group's eight lanes stay together through the shuffles of the merge: no early return)
+  const long long o = (long long)pair * cap, qo = (long long)pair * qcap;
+  unsigned long long top[PROJ_TOPK];
+#pragma unroll
+  for (int k = 0; k < PROJ_TOPK; k++) top[k] = PKEY_EMPTY;
+  bool trunc = false;
+  const int n = min(nArr[pair], cap), nq = min(nqArr[pair], qcap);
+  if (q < qcap && q < nq && qValid[qo + q]) {
+    const plh_keyline* K = kls + o;
+    const uint8_t* D = ldesc + o * 32;
+    const double* fn = fnAll + o * 3;
+    const int32_t* cs = csAll + (long long)pair * (GCELLS + 1);
+    const int32_t* ci = ciAll + (long long)pair * itemCap;
+    const float* sg = qSeg + (qo + q) * 4;
+    const float x1 = sg[0], y1 = sg[1], x2 = sg[2], y2 = sg[3];
+    float r, TH;
+    if (variant == 0) {
+      r = qAux[qo + q] > 0.998 ? 5.0 : 8.0;   // LSDmatcher::RadiusByViewingCos
+      if (th != 1.0) r *= th;
+      TH = 0.998f;
+    } else {
+      r = th;
+      TH = 0.96f;
+    }
+    const float xs[3] = {x1, (float)((x1 + x2) / 2.0), x2};
+    const float ys[3] = {y1, (float)((y1 + y2) / 2.0), y2};
+    float delta1x = x1 - x2, delta1y = y1 - y2;
+    const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
+    delta1x /= norm_delta1;
+    delta1y /= norm_delta1;
+    const unsigned long long* qd = reinterpret_cast<const unsigned long long*>(qDesc + (qo + q) * 32);
+    const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+    const float la = qAux[qo + q];
+    // The same line sits in several cells and is probed from three points: GetFeaturesInAreaForLine lists it once, at its first
+    // passing probe.  A line that is in the lane's list is recognised by its index, and one that is not (rejected for its distance, or
+    // pushed out) would be rejected again -- a later occurrence has the same distance and a larger number.  The small bitmap only keeps
+    // a second visit from setting `truncated` on its own.
+    uint32_t seenLo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // lines 0 .. 255 (a frame keeps nLSDFeature + 1 = 201); beyond: conservative
+    unsigned seqBase = 0u;   // occurrences in front of the current column: the same in the eight lanes
+    for (int i = 0; i < 3; i++) {
+      const CellWin w = cell_window(g, xs[i], ys[i], r);
+      if (!w.ok) continue;
+      for (int ix = w.x0; ix <= w.x1; ix++) {
+        const int s = cs[ix * GROWS + w.y0], e = cs[ix * GROWS + w.y1 + 1];
+        for (int j = s; j < e; j++) {
+          const int id = ci[j];
+          if (id < 0 || id >= n || (id & (PROJ_LG - 1)) != sub) continue;
+          if (id < 256 && ((seenLo[id >> 5] >> (id & 31)) & 1u)) continue;
+          bool dup = false;
+#pragma unroll
+          for (int k = 0; k < PROJ_TOPK; k++) dup = dup || (top[k] != PKEY_EMPTY && pkey_id(top[k]) == id);
+          if (dup) continue;
+          const plh_keyline k = K[id];
+          float delta2x = k.startPointX - k.endPointX, delta2y = k.startPointY - k.endPointY;
+          const float norm_delta2 = sqrtf(delta2x * delta2x + delta2y * delta2y);
+          delta2x /= norm_delta2;
+          delta2y /= norm_delta2;
+          const float CosSita = fabsf(delta1x * delta2x + delta1y * delta2y);
+          if (CosSita < TH) continue;
+          const float dist = (float)(fn[id * 3 + 0] * (double)xs[i] + fn[id * 3 + 1] * (double)ys[i] + fn[id * 3 + 2]);
+          if (!(fabsf(dist) < r)) continue;
+          if (id < 256) {
+#pragma unroll
+            for (int wd = 0; wd < 8; wd++)
+              if (wd == (id >> 5)) seenLo[wd] |= 1u << (id & 31);
+          }
+          if (occupiedAll[o + id]) continue;
+          if (variant == 1) {
+            const float lb = k.lineLength;
+            const float max_ = fmaxf(la, lb), min_ = fminf(la, lb);
+            if (min_ / max_ < 0.75) continue;
+          }
+          const unsigned long long* dd = reinterpret_cast<const unsigned long long*>(D + (long long)id * 32);
+          const int d = __popcll(q0 ^ dd[0]) + __popcll(q1 ^ dd[1]) + __popcll(q2 ^ dd[2]) + __popcll(q3 ^ dd[3]);
+          unsigned long long ne = proj_key(d, seqBase + (unsigned)(j - s), id, k.octave);
+          if (top[PROJ_TOPK - 1] != PKEY_EMPTY) trunc = true;   // one entry will not fit
+#pragma unroll
+          for (int kk = 0; kk < PROJ_TOPK; kk++)
+            if (ne < top[kk]) { const unsigned long long t = top[kk]; top[kk] = ne; ne = t; }
+        }
+        seqBase += (unsigned)max(e - s, 0);
+      }
+    }
+  }
+  // ---- merge of the group's eight lists: PROJ_TOPK times the least head (the trip count is the same for every group of the wavefront)
+  uint32_t fin[PROJ_TOPK];
+#pragma unroll
+  for (int k = 0; k < PROJ_TOPK; k++) {
+    unsigned long long m = top[0];
+#pragma unroll
+    for (int d = 1; d < PROJ_LG; d <<= 1) {
+      const unsigned long long other = __shfl_xor(m, d);
+      m = other < m ? other : m;
+    }
+    if (m != PKEY_EMPTY && top[0] == m) {    // keys are unique: exactly one lane of the group pops
+#pragma unroll
+      for (int kk = 0; kk + 1 < PROJ_TOPK; kk++) top[kk] = top[kk + 1];
+      top[PROJ_TOPK - 1] = PKEY_EMPTY;
+    }
+    fin[k] = m == PKEY_EMPTY ? PROJ_EMPTY : proj_entry(pkey_id(m), (int)(m >> 44), (int)(m & 15ull));
+  }
+  {   // more candidates than the list holds: a lane's own list overflowed, or something is left after the merge
+    bool anyTrunc = trunc || top[0] != PKEY_EMPTY;
+#pragma unroll
+    for (int d = 1; d < PROJ_LG; d <<= 1) anyTrunc = anyTrunc || (__shfl_xor((int)anyTrunc, d) != 0);
+    trunc = anyTrunc;
+  }
+#pragma unroll
+  for (int k = 1; k < PROJ_TOPK; k++)   // (test switch plh_debug_set_proj_serial(2): a list of `keep` entries, so that lists run out)
+    if (k >= keep && fin[k] != PROJ_EMPTY) { fin[k] = PROJ_EMPTY; trunc = true; }
+  if (trunc && fin[0] != PROJ_EMPTY) fin[0] |= PROJ_TRUNC;
+  if (sub == 0 && q < qcap) {
+    ProjTop t;
+#pragma unroll
+    for (int k = 0; k < PROJ_TOPK; k++) t.e[k] = fin[k];
+    out[qo + q] = t;
+  }
+}
+
 // The exact scan of ONE query against the current occupancy, by the whole wavefront (the loops of k_search_proj_points /
 // k_search_proj_lines): the slow path of the resolve.  Returns the packed best / second (PROJ_EMPTY = none) in all lanes.
 struct ProjPick { uint32_t best, second; };
@@ -1393,9 +1536,14 @@ static plh_status launch_proj_lines(int variant, const plh_keyline* d_kl, const 
   if (!g_proj_serial) {
     ProjTop* tops = nullptr;
     PLH_HIP(hipMallocAsync((void**)&tops, (size_t)pairs * qcap * sizeof(ProjTop), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_proj_lines_prepass, dim3((qcap + 255) / 256, pairs), dim3(256), 0, (hipStream_t)stream, variant, d_kl, d_ldesc, d_linefn,
-                       (const int*)d_nl, cap, *gp, d_cs, d_ci, item_cap, (const uint8_t*)d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_seg,
-                       d_q_aux, d_q_desc, th, tops, g_proj_keep);
+    if ((long long)pairs * qcap <= PROJ_G8_MAX)
+      hipLaunchKernelGGL(k_proj_lines_prepass_g8, dim3((qcap * PROJ_LG + 255) / 256, pairs), dim3(256), 0, (hipStream_t)stream, variant, d_kl, d_ldesc,
+                         d_linefn, (const int*)d_nl, cap, *gp, d_cs, d_ci, item_cap, (const uint8_t*)d_occupied, (const int*)d_nq, qcap, d_q_valid,
+                         d_q_seg, d_q_aux, d_q_desc, th, tops, g_proj_keep);
+    else
+      hipLaunchKernelGGL(k_proj_lines_prepass, dim3((qcap + 255) / 256, pairs), dim3(256), 0, (hipStream_t)stream, variant, d_kl, d_ldesc, d_linefn,
+                         (const int*)d_nl, cap, *gp, d_cs, d_ci, item_cap, (const uint8_t*)d_occupied, (const int*)d_nq, qcap, d_q_valid, d_q_seg,
+                         d_q_aux, d_q_desc, th, tops, g_proj_keep);
     const size_t lds2 = (size_t)cap * (3 * 4 + 2) + 128 + 64;
     ScaleTab none;
     for (int i = 0; i < 16; i++) none.v[i] = 0.f;

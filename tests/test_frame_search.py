@@ -679,6 +679,18 @@ def _parallel_equals_serial(P, O, S, lib, n, nl, dups):
                         assert (np.asarray(u) == np.asarray(v)).all(), ("search %d, seed %d, %d-fold queries: prepass + resolve (mode %d) differs from "
                                                                         "the sequential kernel" % (k, seed, dup, mode))
             assert res[0][0][1].min() > 0 and res[0][2][1].min() > 0 and res[0][7][1].min() > 0
+            # the line prepass has a small-launch form (eight lanes per query, at most 4096 queries per launch) and a batch form (one lane
+            # per query): the same frame and queries as a launch of enough pairs for the batch form, against the two-pair launch above
+            if dup == dups[-1][1]:
+                H.plh_debug_set_proj_serial(0)
+                npairs = 4096 // max(len(ql[0]["valid"]), 1) + 2
+                fsn = P.FrameSearch(gp, SCALE, [f2] * npairs, lib=lib)
+                big = [fsn.LineSearchByProjectionMapLines([ql[0]] * npairs, [locc0] * npairs, th=3.0, nnratio=0.9),
+                       fsn.LineSearchByProjectionLastFrame([ql[0]] * npairs, [locc0] * npairs, th=12.0)]
+                for k, (got, ref) in enumerate(zip(big, (res[0][7], res[0][8]))):
+                    for u, v in zip(got, ref):
+                        u, v = np.asarray(u), np.asarray(v)
+                        assert all((u[b] == v[0]).all() for b in range(npairs)), "line search %d: batch form differs from the small-launch form" % k
     finally:
         H.plh_debug_set_proj_serial(0)
 
