@@ -21,4 +21,6 @@ cpn soak_1024.txt soak_parity_1024_frames.txt
 { echo "# pytest -m gpu + smoke on the round-end box (tools/gpu_final.sh), build $(python -c 'import __graft_entry__ as g; print(g.source_id())')"; cat $F/tests.txt $F/smoke.txt; } > profiles/${R}_gpu_tests.txt
 [ -s $F/hbm_traffic.json ] && cp $F/hbm_traffic.json profiles/hbm_traffic.json
 [ -s $F/insts.json ] && cp $F/insts.json profiles/sq_insts.json
+[ -s $F/insts_tracking.json ] && cp $F/insts_tracking.json profiles/sq_insts_tracking.json
+cpn pmc_tracking.txt sq_instructions_tracking.txt
 exit 0

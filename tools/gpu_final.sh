@@ -23,6 +23,7 @@ if has pmc; then
 bash tools/pmc_traffic.sh 1536 > $O/pmc_traffic.log 2>&1; tail -3 $O/pmc_traffic.log; cp gpurun_out/pmc/traffic.json $O/hbm_traffic.json 2>/dev/null && cp $O/hbm_traffic.json profiles/hbm_traffic.json
 bash tools/pmc_insts.sh 1536 > $O/pmc_insts.txt 2>&1; head -12 $O/pmc_insts.txt; cp gpurun_out/pmcinst/insts.json $O/insts.json 2>/dev/null && cp $O/insts.json profiles/sq_insts.json
 bash tools/pmc_grow_detail.sh > $O/pmc_grow_detail.txt 2>&1; tail -12 $O/pmc_grow_detail.txt
+bash tools/pmc_tracking.sh 1024 > $O/pmc_tracking.txt 2>&1; head -10 $O/pmc_tracking.txt; cp gpurun_out/pmctrack/insts.json $O/insts_tracking.json 2>/dev/null && cp $O/insts_tracking.json profiles/sq_insts_tracking.json
 fi
 if has bench; then
 timeout 2400 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
