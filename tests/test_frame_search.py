@@ -491,6 +491,37 @@ def _host_buffer_forms(P, O, S, lib, n=1500, nl=180):
                                                                       p(q["octave"]), p(q["angle"]), p(q["desc"]), p(q["hasobs"]), 15.0, 0, 1,
                                                                       p(got), C.byref(cnt)), "proj frame resident")
         assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > n // 5, form
+    # ... and with the projection on the device (plh_orb_search_by_projection_frame_resident_world): world points behind and in front of a
+    # rotated pose; the oracle's projection (form 0) + the oracle's search on its (valid && front, uv) is the reference
+    rng = S.SplitMix64(905)
+    ang = 0.05
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = np.array([0.05, -0.02, 0.1], np.float32)
+    K4 = [520.0, 518.0, 320.0, 240.0]
+    z = rng.uniform(n1, 1.5, 9.0).astype(np.float32)
+    z[rng.uniform(n1) < 0.05] *= -1                      # some behind the camera: invzc < 0
+    uvw = q["uv"].astype(np.float64)
+    cam = np.stack([(uvw[:, 0] - K4[2]) / K4[0] * z, (uvw[:, 1] - K4[3]) / K4[1] * z, z], 1)
+    world = ((cam - tcw.astype(np.float64)) @ Rcw.astype(np.float64)).astype(np.float32)   # Rcw^T (cam - tcw)
+    view = np.concatenate([Rcw.reshape(9), tcw, np.zeros(3), K4, [0, 0, 640, 480], [np.log(np.float32(1.2))]]).astype(np.float32)
+    L.plo_frame_project_points.argtypes = [V, I, I, V, V, V]
+    front, uv2 = np.zeros(max(n1, 1), np.uint8), np.zeros((max(n1, 1), 2), np.float32)
+    L.plo_frame_project_points(O._p(view), 0, n1, O._p(world), O._p(front), O._p(uv2))
+    v2 = (q["valid"] & front[:n1]).astype(np.uint8)
+    ro, ra = np.zeros(n2, np.uint8), np.zeros(n2, np.int32)
+    rc = L.plo_orb_search_by_projection_frame(O._p(f2["kps"]), O._p(f2["desc"]), n2, O._p(g), O._p(cs), O._p(ci), O._p(SCALE), O._p(ro),
+                                              n1, O._p(v2), O._p(uv2), O._p(q["octave"]), O._p(q["angle"]), O._p(q["desc"]),
+                                              O._p(q["hasobs"]), 15.0, 0, 1, O._p(ra))
+    vrec = np.zeros(1, P.VIEW_DTYPE)
+    vrec["Rcw"][0], vrec["tcw"][0] = Rcw.reshape(9), tcw
+    vrec["fx"], vrec["fy"], vrec["cx"], vrec["cy"] = K4
+    vrec["max_x"], vrec["max_y"], vrec["log_scale_factor"], vrec["n_scale_levels"] = 640, 480, np.log(np.float32(1.2)), len(SCALE)
+    H.plh_orb_search_by_projection_frame_resident_world.argtypes = [V, V, I, V, I, V, V, V, V, V, V, V, F, I, I, V, V]
+    got, occ = np.full(n2, 7, np.int32), np.zeros(n2, np.uint8)
+    P._check(H, H.plh_orb_search_by_projection_frame_resident_world(R2, p(SCALE), len(SCALE), p(occ), n1, p(vrec), p(q["valid"]), p(world),
+                                                                    p(q["octave"]), p(q["angle"]), p(q["desc"]), p(q["hasobs"]), 15.0, 0, 1,
+                                                                    p(got), C.byref(cnt)), "proj frame resident world")
+    assert cnt.value == rc and (got == ra).all() and (occ == ro).all() and rc > n // 8 and 0 < int(front[:n1].sum()) < n1
     # ORB SearchByProjection(F, MapPoints)
     q = _queries_points(P, S, 903, f1, f2, "mp")
     occ0 = (S.SplitMix64(6).uniform(n2) < 0.1).astype(np.uint8)
