@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
   // (a block takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ...: launch_lsd_order picks the blocks per frame by batch size)
   for (int wv = blockIdx.x; wv < LSD_ORDER_CHUNKS; wv += gridDim.x) {
   const uint32_t* Q = a.pix + (long long)b * a.arenaStride;      // level-line records (k_lsd_grad)
-  uint32_t* BIN = a.reg + (long long)b * a.arenaStride;          // bin + 1 per pixel, 0 = NOTDEF (scratch)
+  uint16_t* BIN = reinterpret_cast<uint16_t*>(a.reg + (long long)b * a.arenaStride);   // bin + 1 per pixel, 0 = NOTDEF (scratch; 16 bits:
+                                                                                       // half the bytes between this kernel and the scatter)
   uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
   const int chunk = lsd_order_chunk(a.spitch, a.sh);
   const int c0 = wv * chunk, c1 = min(a.spitch * lsd_rec_rows(a.sh), c0 + chunk);   // whole bands (rows beyond sh are skipped below)
@@ -430,9 +431,9 @@ __global__ void __launch_bounds__(64) k_lsd_bin_hist(LineDeviceArgs a) {
           bb[k] = (unsigned)bin + 1u;
         }
       }
-      uint4 o4;
-      o4.x = bb[0]; o4.y = bb[1]; o4.z = bb[2]; o4.w = bb[3];
-      *reinterpret_cast<uint4*>(BIN + i) = o4;
+      uint2 o2;
+      o2.x = bb[0] | (bb[1] << 16); o2.y = bb[2] | (bb[3] << 16);
+      *reinterpret_cast<uint2*>(BIN + i) = o2;
     }
   }
   __syncthreads();
@@ -483,7 +484,7 @@ __global__ void __launch_bounds__(64) k_lsd_bin_scatter(LineDeviceArgs a) {
   __shared__ int cur[LSD_NBINS];   // next list position of every bin for this chunk
   const int b = blockIdx.y, lane = threadIdx.x;
   for (int wv = blockIdx.x; wv < LSD_ORDER_CHUNKS; wv += gridDim.x) {
-  const uint32_t* BIN = a.reg + (long long)b * a.arenaStride;
+  const uint16_t* BIN = reinterpret_cast<const uint16_t*>(a.reg + (long long)b * a.arenaStride);
   uint32_t* ord = a.ordered + (long long)b * a.arenaStride;
   const uint32_t* work = a.orderWork + (long long)b * a.arenaStride;
   const int npix = a.spitch * a.sh;
@@ -532,7 +533,7 @@ __global__ void __launch_bounds__(64) k_lsd_bin_scatter(LineDeviceArgs a) {
   // between if younger operations have been issued behind it.  Loads are unconditional (index clamped, value masked
   // afterwards) so that they sit in straight-line code.
   const int last = npix - 1;
-  auto fetch = [&](int g0) { return BIN[min(g0 + lane, last)]; };
+  auto fetch = [&](int g0) { return (unsigned)BIN[min(g0 + lane, last)]; };
   auto mask = [&](unsigned v, int g0) { return g0 + lane < c1 ? v : 0u; };
   unsigned b0 = fetch(c0), b1 = fetch(c0 + 64), b2;
   for (int base = c0; base < c1; base += 192) {

@@ -35,117 +35,125 @@ __device__ __forceinline__ int rc_size_class(unsigned cnt) {
 //   2. the wavefront stages its 64 regions' pixels through LDS, RC_K per lane at a time: packed coordinates from the frame's log
 //      and gx^2 + gy^2 from the array beside it (written by region growing, which had the record in hand), loaded 8 regions x 8
 //      consecutive entries per instruction -- a lane per region reading its own stream touches 64 cache lines per load and left
-//      the first version of this file bound by the texture addresser (5.3 ms per 1536 frames, profiles/r04_screen_ab_v1...) --
-//      and the weight sqrt((gx^2 + gy^2) / 4.0), the expression the gradient table was filled with, is evaluated in the staging
-//      step of the first pass, where all 64 lanes work, and kept in W (a double per log entry, over the dead record plane) for
-//      the second; the next chunk's loads are in flight while a chunk is added up;
+//      the first version of this file bound by the texture addresser (5.3 ms per 1536 frames, profiles/r04_screen_ab_v1...);
 //   3. every lane adds its own region's terms from LDS in region order.  Rows of the staging tiles are padded with zero terms,
 //      which the sums absorb exactly (+0.0; the accumulators are never -0.0), as lsd_chain_add does.
-// No record, no table entry is read here: the level-line field stays with region growing (its plane is reused for W).
+// No record, no table entry is read here: the level-line field stays with region growing.
+//
+// Round 6, second half -- the log is read in whole 64-byte sectors, once per pass.  Rounds 4 - 5 read a region's stream 8 entries
+// (32 bytes, anywhere in the log) per round trip and kept the weights of the first pass in a plane of doubles for the second: PMC
+// traffic 7.3 MB per frame for 0.12 M region pixels (profiles/hbm_traffic.json of build b6c019a1) -- every sector of the log came
+// in twice per pass (its two halves one round trip apart, with 6 000 wavefronts' streams through a 4 MB L2 in between) and the
+// weight plane cost 8 bytes written + 8 read per pixel.  Now a region's chunks are cut at ABSOLUTE multiples of 16 log entries (the
+// first chunk of a region starts up to 15 padding entries early), two chunks = one sector per stream are requested in the same
+// load phase, and the second pass takes gx^2 + gy^2 from the log again and evaluates the weight a second time -- the expression
+// the gradient table was filled with, q_modgrad(), on the lane that adds it -- instead of reading it back: 8 + 8 + 4 bytes per pixel
+// fetched once, nothing written but the rectangles, and 5.1 KB of LDS per wavefront instead of 7.4.
 // ---------------------------------------------------------------------------------------------
 constexpr int RC_K = 8;
 constexpr int RC_PITCH = RC_K + 1;
 
 struct RcStage {   // one wavefront's part of the block's LDS
   uint32_t* p;     // [64][RC_PITCH] packed pixels
-  double* w;       // [64][RC_PITCH] weights
-  uint32_t* off;   // [64] log offset of lane r's region
-  int* cnt;        // [64] its pixel count (0: the lane has no region)
+  uint32_t* q;     // [64][RC_PITCH] gx^2 + gy^2
+  uint32_t* off;   // [64] log offset of lane r's region, rounded down to a multiple of 16 entries (a sector of the log)
+  uint32_t* lohi;  // [64] the region's entries inside its padded stream: [lo, hi) = lo | hi << 16 (0: the lane has no region)
 };
-struct RcLoad {    // one chunk's entries on their way from global memory to the staging tiles
-  uint32_t p[8], q[8];
-  double w[8];     // (the second pass: the weights the first pass left in W)
+struct RcLoad {    // a pair of chunks (one sector per region and stream) on its way from global memory to the staging tiles
+  uint32_t p[16], q[16];
 };
 
-// MODE 0: coordinates only (extents); 1: coordinates + gx^2 + gy^2, the weight is evaluated and left in W (first pass);
-// 2: coordinates + the weight from W (second pass: sqrt once per pixel, not twice)
+// MODE 0: coordinates only (extents); 1: coordinates + gx^2 + gy^2.  Chunks c and c + 1 (c even) of all 64 regions.
 template <int MODE>
-__device__ __forceinline__ void rc_load(const RcStage& st, const uint32_t* log, const uint32_t* logq, double* W, int lane, int c, RcLoad& L) {
+__device__ __forceinline__ void rc_load(const RcStage& st, const uint32_t* log, const uint32_t* logq, int lane, int c, RcLoad& L) {
 #pragma unroll
   for (int g = 0; g < 8; g++) {
-    const int r = 8 * g + (lane >> 3), idx = c * RC_K + (lane & 7);
-    const bool valid = idx < st.cnt[r];
-    const uint32_t a = st.off[r] + (uint32_t)idx;
-    L.p[g] = valid ? log[a] : 0u;
-    if (MODE == 1) L.q[g] = valid ? logq[a] : 0u;
-    if (MODE == 2) L.w[g] = valid ? W[a] : 0.0;
+    const int r = 8 * g + (lane >> 3);
+    const uint32_t lh = st.lohi[r], base = st.off[r];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t j = (uint32_t)((c + h) * RC_K + (lane & 7));
+      const bool valid = j >= (lh & 0xffffu) && j < (lh >> 16);
+      const uint32_t a = base + j;
+      L.p[2 * g + h] = valid ? log[a] : 0u;
+      if (MODE == 1) L.q[2 * g + h] = valid ? logq[a] : 0u;
+    }
   }
 }
 template <int MODE>
-__device__ __forceinline__ void rc_put(const RcStage& st, double* W, int lane, int c, const RcLoad& L) {
+__device__ __forceinline__ void rc_put(const RcStage& st, int lane, int h, const RcLoad& L) {
 #pragma unroll
   for (int g = 0; g < 8; g++) {
     const int r = 8 * g + (lane >> 3), k = lane & 7;
-    st.p[r * RC_PITCH + k] = L.p[g];
-    if (MODE == 1) {
-      const double w = q_modgrad(L.q[g]);   // (q = 0 for the padding: weight +0.0)
-      st.w[r * RC_PITCH + k] = w;
-      if (c * RC_K + k < st.cnt[r]) W[st.off[r] + (uint32_t)(c * RC_K + k)] = w;
-    }
-    if (MODE == 2) st.w[r * RC_PITCH + k] = L.w[g];
+    st.p[r * RC_PITCH + k] = L.p[2 * g + h];
+    if (MODE == 1) st.q[r * RC_PITCH + k] = L.q[2 * g + h];   // (q = 0 for the padding: weight +0.0)
+  }
+}
+// One pass over the 64 regions' streams: `sum(c)` adds chunk c from the lane's row of the staging tiles.
+template <int MODE, typename F>
+__device__ __forceinline__ void rc_pass(const RcStage& st, const uint32_t* log, const uint32_t* logq, int lane, int chunks, F&& sum) {
+  RcLoad L;
+  rc_load<MODE>(st, log, logq, lane, 0, L);
+  for (int c = 0; c < chunks; c += 2) {
+    rc_put<MODE>(st, lane, 0, L);
+    PLH_WAVE_SYNC();
+    sum(c);
+    PLH_WAVE_SYNC();
+    if (c + 1 >= chunks) break;
+    rc_put<MODE>(st, lane, 1, L);
+    PLH_WAVE_SYNC();
+    if (c + 2 < chunks) rc_load<MODE>(st, log, logq, lane, c + 2, L);   // the next sectors are in flight while this chunk is added up
+    sum(c + 1);
+    PLH_WAVE_SYNC();
   }
 }
 
 // region2rect() + get_theta() of the 64 regions of a wavefront (lane = region; cnt 0 = none): oracle/lsd.cc region2rect, the same
 // expressions in the same order as lsd_region2rect (lsd_grow.hip).  rec = x1 y1 x2 y2 width theta dx dy.
-__device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uint32_t* log, const uint32_t* logq, double* W, int lane,
+__device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uint32_t* log, const uint32_t* logq, int lane,
                                                     uint32_t myOff, int myCnt, double reg_angle, double prec, double rec[8]) {
   PLH_WAVE_SYNC();
-  st.off[lane] = myOff; st.cnt[lane] = myCnt;
-  int maxCnt = myCnt;
-  for (int m = 32; m >= 1; m >>= 1) maxCnt = max(maxCnt, __shfl_xor(maxCnt, m));
+  const int myLo = myCnt > 0 ? (int)(myOff & 15u) : 0, myHi = myLo + myCnt;   // (regions of this path are < 512 pixels: hi < 2^16)
+  st.off[lane] = myOff & ~15u; st.lohi[lane] = (uint32_t)myLo | ((uint32_t)myHi << 16);
+  int maxHi = myHi;
+  for (int m = 32; m >= 1; m >>= 1) maxHi = max(maxHi, __shfl_xor(maxHi, m));
   PLH_WAVE_SYNC();
-  const int chunks = (maxCnt + RC_K - 1) / RC_K;
+  const int chunks = (maxHi + RC_K - 1) / RC_K;
   const uint32_t* sp = st.p + lane * RC_PITCH;
-  const double* sw = st.w + lane * RC_PITCH;
-  RcLoad L;
+  const uint32_t* sq = st.q + lane * RC_PITCH;
   double sx = 0, sy = 0, sum = 0;
-  rc_load<1>(st, log, logq, W, lane, 0, L);
-  for (int c = 0; c < chunks; c++) {
-    rc_put<1>(st, W, lane, c, L);
-    PLH_WAVE_SYNC();
-    if (c + 1 < chunks) rc_load<1>(st, log, logq, W, lane, c + 1, L);
+  rc_pass<1>(st, log, logq, lane, chunks, [&](int) {
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
       const uint32_t p = sp[k];
-      const double w = sw[k];
+      const double w = q_modgrad(sq[k]);
       sx += (double)(int)(p & 0xffffu) * w;
       sy += (double)(int)(p >> 16) * w;
       sum += w;
     }
-    PLH_WAVE_SYNC();
-  }
+  });
   const double x = sx / sum, y = sy / sum;
   double Ixx = 0, Iyy = 0, Ixy = 0;
-  PLH_WAVE_SYNC();   // (the wavefront's own stores to W are read back: a wavefront observes its earlier stores)
-  rc_load<2>(st, log, logq, W, lane, 0, L);
-  for (int c = 0; c < chunks; c++) {
-    rc_put<2>(st, W, lane, c, L);
-    PLH_WAVE_SYNC();
-    if (c + 1 < chunks) rc_load<2>(st, log, logq, W, lane, c + 1, L);
+  rc_pass<1>(st, log, logq, lane, chunks, [&](int) {
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
       const uint32_t p = sp[k];
-      const double w = sw[k];
+      const double w = q_modgrad(sq[k]);
       const double ddx = (double)(int)(p & 0xffffu) - x, ddy = (double)(int)(p >> 16) - y;
       Ixx += ddy * ddy * w;
       Iyy += ddx * ddx * w;
       Ixy += -(ddx * ddy * w);   // Ixy -= v  ==  Ixy += -v
     }
-    PLH_WAVE_SYNC();
-  }
+  });
   const double theta = lsd_rect_theta(Ixx, Iyy, Ixy, reg_angle, prec);
   const D2 cs = lsd_sincos_inl(theta);
   const double dx = cs.x, dy = cs.y;
   double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
-  rc_load<0>(st, log, logq, W, lane, 0, L);
-  for (int c = 0; c < chunks; c++) {
-    rc_put<0>(st, W, lane, c, L);
-    PLH_WAVE_SYNC();
-    if (c + 1 < chunks) rc_load<0>(st, log, logq, W, lane, c + 1, L);
+  rc_pass<0>(st, log, logq, lane, chunks, [&](int c) {
 #pragma unroll
     for (int k = 0; k < RC_K; k++) {
-      if (c * RC_K + k < myCnt) {
+      const int j = c * RC_K + k;
+      if (j >= myLo && j < myHi) {
         const uint32_t p = sp[k];
         const double rdx = (double)(int)(p & 0xffffu) - x, rdy = (double)(int)(p >> 16) - y;
         const double l = rdx * dx + rdy * dy;
@@ -154,8 +162,7 @@ __device__ __forceinline__ void rc_wave_region2rect(const RcStage& st, const uin
         w_max = fmax(w_max, w); w_min = fmin(w_min, w);
       }
     }
-    PLH_WAVE_SYNC();
-  }
+  });
   rec[0] = x + l_min * dx; rec[1] = y + l_min * dy;
   rec[2] = x + l_max * dx; rec[3] = y + l_max * dy;
   const double width = w_max - w_min;
@@ -279,20 +286,21 @@ __global__ void __launch_bounds__(256) k_lsd_rects_sort(LineDeviceArgs a) {
 
 template <bool ADV>
 __device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
-  __shared__ __attribute__((aligned(16))) double s_w[64 * RC_PITCH];
-  __shared__ uint32_t s_p[64 * RC_PITCH];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pq[2 * 64 * RC_PITCH];   // the staging tiles; rc_region2rect_by_wave's three
+  uint32_t* const s_p = s_pq;                                                  // series (3 x 64 doubles) lie over them
+  uint32_t* const s_q = s_pq + 64 * RC_PITCH;
+  double* const s_t = reinterpret_cast<double*>(s_pq);
+  static_assert(2 * 64 * RC_PITCH * 4 >= 3 * 64 * 8, "series buffer");
   __shared__ uint32_t s_off[64];
-  __shared__ int s_cnt[64];
+  __shared__ uint32_t s_lohi[64];
   const int b = blockIdx.y, lane = threadIdx.x;
   const int n = min(a.nSegs[b], a.segCap);
   uint4* ent = reinterpret_cast<uint4*>(a.segs + (long long)b * a.arenaStride);
   const uint32_t* log = a.reg + (long long)b * a.arenaStride;
   const uint32_t* logq = a.regq + (long long)b * a.arenaStride;
   const uint32_t* order = a.park + (long long)b * a.arenaStride + 2;
-  double* W = reinterpret_cast<double*>(a.pix + (long long)b * a.arenaStride);   // the records and the seed list behind them are dead by now:
-                                                                                // one double per log entry fits (pix | ordered are adjacent)
   RcStage st;
-  st.p = s_p; st.w = s_w; st.off = s_off; st.cnt = s_cnt;
+  st.p = s_p; st.q = s_q; st.off = s_off; st.lohi = s_lohi;
   auto put = [&](int slot, const double* rec) {
     if constexpr (!ADV) {
       lsd_store_segment(&ent[slot], rec);
@@ -309,7 +317,7 @@ __device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
     const int slot = (int)order[k];
     const uint4 e = ent[slot];   // LsdRegionEntry (uniform)
     double rec[8];
-    rc_region2rect_by_wave(s_w, log, logq, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+    rc_region2rect_by_wave(s_t, log, logq, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
     if (lane == 0) put(slot, rec);
   }
   // ... then the rest, 64 consecutive entries of the order per wavefront, one region per lane
@@ -319,7 +327,7 @@ __device__ __forceinline__ void lsd_rects_group(const LineDeviceArgs& a) {
     uint4 e = uint4{0u, 0u, 0u, 0u};
     if (k < n) { slot = (int)order[k]; e = ent[slot]; }   // LsdRegionEntry
     double rec[8];
-    rc_wave_region2rect(st, log, logq, W, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
+    rc_wave_region2rect(st, log, logq, lane, e.x, (int)e.y, (double)__uint_as_float(e.z) * kDegToRads, a.prec, rec);
     if (slot >= 0) put(slot, rec);
   }
 }
