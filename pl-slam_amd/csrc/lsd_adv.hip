@@ -85,10 +85,12 @@ void launch_lsd_lgamma_table(double* t, int n, hipStream_t s) {
 #else
 #define PLH_ADVFIRST_ATTR
 #endif
-__global__ void __launch_bounds__(64) PLH_ADVFIRST_ATTR k_adv_first(LineDeviceArgs a) {
+__global__ void __launch_bounds__(64) PLH_ADVFIRST_ATTR k_adv_first(LineDeviceArgs a, int perFrame) {
   __shared__ LsdScanGeom s_geom[64];
   __shared__ int s_tot[64], s_alg[64], s_slot[64];
-  const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7;
+  int blk, b;   // (plh_xcd_decode: the blocks of a frame walk one angle plane -- behind one L2)
+  if (!plh_xcd_decode(perFrame, a.batch, blk, b)) return;
+  const int lane = threadIdx.x, grp = lane >> 3, j = lane & 7;
   const AdvFrame f = adv_frame(a, b);
   const RcFrame rf = adv_field(a, b);
   const LsdAlignTol tol0 = lsd_align_tol(0.0, a.prec);   // (every rectangle starts with the launch's tolerance; theta per rectangle)
@@ -96,10 +98,10 @@ __global__ void __launch_bounds__(64) PLH_ADVFIRST_ATTR k_adv_first(LineDeviceAr
   // about equally long (in slot order the longest of eight set the pace, 2 x the mean).  The chunks go to the frame's blocks
   // round robin, so that every block gets large and small ones; a block takes eight chunks (64 rectangles) per pass.
   const int nChunks = (f.n + 7) >> 3;
-  for (int c0 = (int)blockIdx.x; c0 < nChunks; c0 += 8 * (int)gridDim.x) {
+  for (int c0 = blk; c0 < nChunks; c0 += 8 * perFrame) {
     // the pass's rectangles: lane (it, pos) -> position pos of chunk c0 + it x blocks.  Their scan geometry, one lane each (the
     // corner sort is as long as a walk: not eight times per rectangle):
-    const int k = (c0 + (lane >> 3) * (int)gridDim.x) * 8 + (lane & 7);
+    const int k = (c0 + (lane >> 3) * perFrame) * 8 + (lane & 7);
     const int mine = k < f.n ? (int)f.order[k] : -1;
     {
       s_slot[lane] = mine;
@@ -140,14 +142,16 @@ __global__ void __launch_bounds__(64) PLH_ADVFIRST_ATTR k_adv_first(LineDeviceAr
   }
 }
 
-__global__ void __launch_bounds__(64) PLH_ADV_ATTR k_adv_improve(LineDeviceArgs a) {
+__global__ void __launch_bounds__(64) PLH_ADV_ATTR k_adv_improve(LineDeviceArgs a, int perFrame) {
   __shared__ LsdScanGeom s_geom[8 * 5];   // [rectangle of the pass][variant]
   __shared__ int s_ok[8 * 5];
-  const int b = blockIdx.y, lane = threadIdx.x, grp = lane >> 3, j = lane & 7, g0 = lane & ~7;
+  int blk, b;
+  if (!plh_xcd_decode(perFrame, a.batch, blk, b)) return;
+  const int lane = threadIdx.x, grp = lane >> 3, j = lane & 7, g0 = lane & ~7;
   const AdvFrame f = adv_frame(a, b);
   const RcFrame rf = adv_field(a, b);
   const int na = f.n > 0 ? (int)*f.count : 0;
-  for (int base = (int)blockIdx.x * 8; base < na; base += 8 * (int)gridDim.x) {   // (uniform: the shuffles below are executed by the whole wavefront)
+  for (int base = blk * 8; base < na; base += 8 * perFrame) {   // (uniform: the shuffles below are executed by the whole wavefront)
     const int q = base + grp;
     bool active = q < na;
     const int slot = active ? (int)f.list[q] : 0;
@@ -254,8 +258,9 @@ __global__ void __launch_bounds__(64) k_adv_compact(LineDeviceArgs a) {
 }
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_adv_first, dim3(lsd_blocks_per_frame(a.batch, ADV_FIRST_MIN, ADV_FIRST_MAX), a.batch), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(k_adv_improve, dim3(lsd_blocks_per_frame(a.batch, ADV_IMPROVE_MIN, ADV_IMPROVE_MAX), a.batch), dim3(64), 0, s, a);
+  const int nf = lsd_blocks_per_frame(a.batch, ADV_FIRST_MIN, ADV_FIRST_MAX), ni = lsd_blocks_per_frame(a.batch, ADV_IMPROVE_MIN, ADV_IMPROVE_MAX);
+  hipLaunchKernelGGL(k_adv_first, dim3(plh_xcd_grid(nf, a.batch)), dim3(64), 0, s, a, nf);
+  hipLaunchKernelGGL(k_adv_improve, dim3(plh_xcd_grid(ni, a.batch)), dim3(64), 0, s, a, ni);
   hipLaunchKernelGGL(k_adv_compact, dim3(a.batch), dim3(64), 0, s, a);
 }
 

@@ -2134,7 +2134,9 @@ __device__ __forceinline__ unsigned align_b32(unsigned hi, unsigned lo, unsigned
 // dy = diff[c] + 2 diff[c + 1] + diff[c + 2] for the four outputs (two pairs each), re-paired into (dx, dy) dwords with
 // v_perm: 36 VALU instructions instead of 18 byte extractions and 4 x 11 scalar-lane additions.
 __global__ void __launch_bounds__(256) k_sobel_pack(LineDeviceArgs a) {
-  const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
+  int bx, y, b;   // (plh_xcd_decode_tiles: a block is a row and reads its two neighbours -- behind one L2 a frame is fetched once, not thrice)
+  if (!plh_xcd_decode_tiles((a.w + 1023) / 1024, a.h, a.batch, bx, y, b)) return;
+  const int x = (bx * 256 + threadIdx.x) * 4;
   if (x >= a.w) return;
   const uint8_t* S = a.tmpA + (long long)b * a.fullStride;
   const int ym = refl101(y - 1, a.h), yp = refl101(y + 1, a.h);
@@ -2215,7 +2217,9 @@ __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline*
   __shared__ float des[LBD_NUM_BANDS * 8];
   __shared__ float sq[LBD_NUM_BANDS * 8];
   __shared__ float scl[2];
-  const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  int li, b;   // (plh_xcd_decode: the bands of a frame's lines overlap -- one gradient plane behind one L2)
+  if (!plh_xcd_decode(a.outCap, a.batch, li, b)) return;
+  const int lane = threadIdx.x;
   if (li >= nOut[b]) return;
   const plh_keyline L = kls[(long long)b * a.outCap + li];
   // the gradient images of the line's octave (binary_descriptor_custom.cpp:1080-1104)
@@ -2443,10 +2447,10 @@ void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* 
   hipLaunchKernelGGL(k_keylines, dim3(a.batch), dim3(KL_THREADS), (size_t)a.outCap * 8 + 64, s, a, kl, fn, n);
 }
 void launch_sobel(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_sobel_pack, dim3((a.w + 1023) / 1024, a.h, a.batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_sobel_pack, dim3(plh_xcd_grid(((a.w + 1023) / 1024) * a.h, a.batch)), dim3(256), 0, s, a);
 }
 void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, const float* coef, uint8_t* desc, hipStream_t s) {
-  hipLaunchKernelGGL(k_lbd, dim3(a.outCap, a.batch), dim3(64), 0, s, a, kl, n, coef, desc);
+  hipLaunchKernelGGL(k_lbd, dim3(plh_xcd_grid(a.outCap, a.batch)), dim3(64), 0, s, a, kl, n, coef, desc);
 }
 #if defined(PLH_GROW_PROF)
 #if PLH_GROW_PROF + 0 >= 3 && !defined(HIPEMU)

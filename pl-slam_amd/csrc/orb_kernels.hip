@@ -922,15 +922,12 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
   uint8_t* const patchBuf = reinterpret_cast<uint8_t*>(patchW);
   const uint8_t* const blurT = reinterpret_cast<const uint8_t*>(blurW);
 
-  // XCD-aware decode (as k_fast_strips): block L runs on XCD (L % 8), and all keypoints of a frame go to one XCD, one after the
-  // other.  The 43 x 43 patches of a frame's ~1000 keypoints cover its pyramid about twice over; spread over the eight L2s as a
-  // (slot, frame) grid spreads them, every keypoint fetched its 43 rows x 1 - 2 sectors from HBM (4.9 MB per frame for 1.9 MB of
-  // patches, profiles/hbm_traffic.json of build b6c019a1); behind one L2 the frame's level images are fetched once.
-  const int L = blockIdx.x;
-  const int xcd = L & 7, qq = L >> 3;
-  const int slot = qq % a.selPerFrame;
-  const int b = (qq / a.selPerFrame) * 8 + xcd;
-  if (b >= a.batch) return;
+  // XCD-aware decode (plh_xcd_decode, plh_common.h): all keypoints of a frame go to one XCD, one after the other.  The 43 x 43 patches
+  // of a frame's ~1000 keypoints cover its pyramid about twice over; spread over the eight L2s as a (slot, frame) grid spreads them,
+  // every keypoint fetched its 43 rows x 1 - 2 sectors from HBM (4.9 MB per frame for 1.9 MB of patches, profiles/hbm_traffic.json
+  // of build b6c019a1); behind one L2 the frame's level images are fetched once (1.0 MB).
+  int slot, b;
+  if (!plh_xcd_decode(a.selPerFrame, a.batch, slot, b)) return;
   const int lane = threadIdx.x;
   const int* selCount = a.selCount + (long long)b * a.nlevels;
 
@@ -1129,8 +1126,7 @@ void launch_octree(const OrbDeviceArgs& a, int nodeCapMax, hipStream_t s) {
   hipLaunchKernelGGL(k_octree, grid, block, octree_lds_bytes(nodeCapMax), s, a, nodeCapMax);
 }
 void launch_orient_brief(const OrbDeviceArgs& a, plh_keypoint* kps, uint8_t* desc, int* nOut, int cap, hipStream_t s) {
-  const int groups = (a.batch + 7) / 8;
-  dim3 grid((unsigned)((long long)a.selPerFrame * groups * 8)), block(64);
+  dim3 grid(plh_xcd_grid(a.selPerFrame, a.batch)), block(64);
   hipLaunchKernelGGL(k_orient_brief, grid, block, 0, s, a, kps, desc, nOut, cap);
 }
 

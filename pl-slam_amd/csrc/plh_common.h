@@ -171,4 +171,30 @@ __device__ __forceinline__ int hamming256(const unsigned long long a[4], const u
   return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
 }
 
+// XCD-aware decode of a 1-D grid that stands for (blocks of a frame) x (frames).  Workgroups go to the eight XCDs round robin by
+// their linear id, and each XCD has an L2 of its own: a (x, frame) grid spreads the blocks of ONE frame over all eight, and whatever
+// those blocks share (the level images behind overlapping keypoint patches, the planes behind a frame's rectangles and line bands)
+// is fetched from HBM once per XCD that touches it.  Here block L runs on XCD (L % 8) and takes frame 8 (L / 8 / perFrame) + L % 8:
+// all blocks of a frame sit behind one L2 and are dispatched side by side.  Batches below eight frames keep the plain order (a lone
+// frame wants all 256 CUs).  plh_xcd_grid() is the matching grid size.
+__device__ __forceinline__ bool plh_xcd_decode(int perFrame, int batch, int& x, int& b) {
+  const int L = (int)blockIdx.x;
+  if (batch < 8) { x = L % perFrame; b = L / perFrame; return b < batch; }
+  const int q = L >> 3;
+  x = q % perFrame;
+  b = (q / perFrame) * 8 + (L & 7);
+  return b < batch;
+}
+// the same for a (tiles in x, tiles in y) x frames grid: neighbouring tiles of a stencil share their halo sectors behind one L2
+__device__ __forceinline__ bool plh_xcd_decode_tiles(int nx, int ny, int batch, int& bx, int& by, int& b) {
+  int t;
+  if (!plh_xcd_decode(nx * ny, batch, t, b)) return false;
+  by = t / nx;
+  bx = t - by * nx;
+  return true;
+}
+inline unsigned plh_xcd_grid(int perFrame, int batch) {
+  return batch < 8 ? (unsigned)(perFrame * batch) : (unsigned)((long long)perFrame * ((batch + 7) / 8) * 8);
+}
+
 }  // namespace plh

@@ -7,7 +7,7 @@ O=gpurun_out/job
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 if [ "${TESTS:-1}" = 1 ]; then
-timeout 1500 python -m pytest tests -m gpu -x -q --timeout 1200 2>&1 | grep -v amdgpu.ids | tail -5 | tee $O/tests.txt
+timeout 1500 python -m pytest tests -m gpu -x -q --timeout 1200 2>&1 | grep -v amdgpu.ids | grep -E "passed|failed|rror|FAIL" | tail -8 | tee $O/tests.txt
 fi
 if [ "${PMC:-1}" = 1 ]; then
 bash tools/pmc_traffic.sh 1536 > $O/pmc_traffic.log 2>&1; cp gpurun_out/pmc/traffic.json $O/traffic.json
