@@ -314,7 +314,11 @@ __global__ void __launch_bounds__(256) k_lsd_grad(LineDeviceArgs a) {
         const int gx = (int)(rec[k] & 1023u) - LSD_GRAD_MAX, gy = (int)((rec[k] >> LSD_ANGLE_PITCH_LOG2) & 1023u) - LSD_GRAD_MAX;
         an[k] = (rec[k] & LSD_REC_DEF) ? fast_atan2_deg((float)gx, (float)(-gy)) : -1024.f;
       }
+#if defined(PLH_ANG_TILED)   // (lsd_rect_dev.h rc_row / rc_at: the plane is made of the record plane's 4 x 4 blocks)
+      float* ao = a.advAng + (long long)b * a.scaledStride + lsd_rec_index((unsigned)x4, (unsigned)y, (unsigned)a.spitch);
+#else
       float* ao = a.advAng + (long long)b * a.scaledStride + (__mul24(y, a.spitch) + x4);
+#endif
       *reinterpret_cast<uint4*>(ao) = uint4{__float_as_uint(an[0]), __float_as_uint(an[1]), __float_as_uint(an[2]), __float_as_uint(an[3])};
     }
     if (qmax) atomicMax(&s_max, qmax);

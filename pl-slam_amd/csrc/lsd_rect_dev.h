@@ -152,6 +152,21 @@ struct RcFrame {
   const float* ang;   // level-line angle per pixel, float degrees, -1024 = NOTDEF (LineDeviceArgs::advAng)
   int spitch, sw, sh;
 };
+// rc_row(): where row y of the angle plane starts; rc_at(): pixel x of that row.  The plane is row-major.  A rectangle is scanned row
+// by row, a few pixels per row unless it is flat, so every scan line of a steep rectangle is a sector of its own for 3 - 5 floats; with
+// the plane in the record plane's 4 x 4-pixel blocks (lsd_rec_index, line_plan.h; -DPLH_ANG_TILED) four consecutive scan lines share
+// theirs: measured (profiles/r06b_angle_plane_tiled_ab.txt) k_adv_first 3.2 -> 1.9 MB and k_adv_improve 2.0 -> 1.7 MB of PMC traffic per
+// frame, but the three more address instructions per load make the walks dearer than the misses they save: the headline - 0.65 % in
+// two same-job A/Bs.  Not adopted; the switch stays for the next look at these kernels.
+#if defined(PLH_ANG_TILED)
+__device__ __forceinline__ const float* rc_row(const RcFrame& f, int y) {
+  return f.ang + (__umul24((unsigned)y >> 2, (unsigned)f.spitch << 2) + (((unsigned)y & 3u) << 2));
+}
+__device__ __forceinline__ float rc_at(const float* row, int x) { return row[(((unsigned)x >> 2) << 4) + ((unsigned)x & 3u)]; }
+#else
+__device__ __forceinline__ const float* rc_row(const RcFrame& f, int y) { return f.ang + __umul24((unsigned)y, (unsigned)f.spitch); }
+__device__ __forceinline__ float rc_at(const float* row, int x) { return row[x]; }
+#endif
 
 __device__ __forceinline__ LsdAdvRect lsd_adv_load(const double* q) {
   LsdAdvRect r;
@@ -258,12 +273,12 @@ __device__ __forceinline__ void lsd_rect_counts_g8(const RcFrame& f, const LsdSc
     const int xa1 = max(left, 0), n1 = two ? max(min(right, xMax) - xa1 + 1, 0) : 0;
     left += two ? (y + 1 < ly ? fl : sl) : 0; right += two ? (y + 1 < ry ? fr : sr) : 0;
     total += n0 + n1;
-    const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
-    const float* row1 = row0 + (two ? f.spitch : 0);
+    const float* row0 = rc_row(f, y);
+    const float* row1 = rc_row(f, two ? y + 1 : y);
     const int nmax = max(n0, n1);
 #pragma clang loop unroll(disable) vectorize(disable)
     for (int k = j; k < nmax; k += 8) {
-      const float v0 = row0[min(xa0 + k, xMax)], v1 = row1[min(xa1 + k, xMax)];
+      const float v0 = rc_at(row0, min(xa0 + k, xMax)), v1 = rc_at(row1, min(xa1 + k, xMax));
       const float d0 = lsd_fold_deg(t.thDeg, k < n0 ? v0 : -1024.f), d1 = lsd_fold_deg(t.thDeg, k < n1 ? v1 : -1024.f);
       bool r0 = d0 < t.lo, r1 = d1 < t.lo;
       const bool m0 = !r0 && d0 <= t.hi, m1 = !r1 && d1 <= t.hi;
@@ -328,18 +343,18 @@ __device__ __forceinline__ void lsd_rect_counts_g8_var5(const RcFrame& f, const 
 #pragma unroll
     for (int m = 0; m < 5; m++) { L1.xa[m] = 1; L1.xb[m] = 0; }
     if (y + 1 <= yHi) lsd_var5_line(gs, y + 1, xMax, left, right, tot, L1);
-    const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
-    const float* row1 = row0 + f.spitch;
+    const float* row0 = rc_row(f, y);
+    const float* row1 = rc_row(f, y + 1);   // (read only when the line y + 1 has a span: it exists then)
     const int x0 = L0.ua + j, x1 = L1.ua + j;
     float v0 = -1024.f, v1 = -1024.f;   // NOTDEF
-    if (x0 <= L0.ub) v0 = row0[x0];
-    if (x1 <= L1.ub) v1 = row1[x1];
+    if (x0 <= L0.ub) v0 = rc_at(row0, x0);
+    if (x1 <= L1.ub) v1 = rc_at(row1, x1);
     lsd_var5_count(t, L0, x0, v0, alg);   // (a lane without a pixel: NOTDEF is aligned with nothing)
     lsd_var5_count(t, L1, x1, v1, alg);
 #pragma clang loop unroll(disable) vectorize(disable)
-    for (int x = x0 + 8; x <= L0.ub; x += 8) lsd_var5_count(t, L0, x, row0[x], alg);
+    for (int x = x0 + 8; x <= L0.ub; x += 8) lsd_var5_count(t, L0, x, rc_at(row0, x), alg);
 #pragma clang loop unroll(disable) vectorize(disable)
-    for (int x = x1 + 8; x <= L1.ub; x += 8) lsd_var5_count(t, L1, x, row1[x], alg);
+    for (int x = x1 + 8; x <= L1.ub; x += 8) lsd_var5_count(t, L1, x, rc_at(row1, x), alg);
   }
 }
 
@@ -384,12 +399,12 @@ __device__ __forceinline__ void lsd_rect_counts_g8_prec5(const RcFrame& f, const
     const int xa1 = max(left, 0), n1 = two ? max(min(right, xMax) - xa1 + 1, 0) : 0;
     left += two ? (y + 1 < ly ? fl : sl) : 0; right += two ? (y + 1 < ry ? fr : sr) : 0;
     total += n0 + n1;
-    const float* row0 = f.ang + __umul24((unsigned)y, (unsigned)f.spitch);
-    const float* row1 = row0 + (two ? f.spitch : 0);
+    const float* row0 = rc_row(f, y);
+    const float* row1 = rc_row(f, two ? y + 1 : y);
     const int nmax = max(n0, n1);
 #pragma clang loop unroll(disable) vectorize(disable)
     for (int k = j; k < nmax; k += 8) {
-      float v0 = row0[min(xa0 + k, xMax)], v1 = row1[min(xa1 + k, xMax)];
+      float v0 = rc_at(row0, min(xa0 + k, xMax)), v1 = rc_at(row1, min(xa1 + k, xMax));
       v0 = k < n0 ? v0 : -1024.f; v1 = k < n1 ? v1 : -1024.f;
       const int m0 = lsd_aligned5(t, v0, alg), m1 = lsd_aligned5(t, v1, alg);
       if (m0 | m1) {

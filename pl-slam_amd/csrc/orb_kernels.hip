@@ -170,15 +170,17 @@ __device__ __forceinline__ void tap_unpack(const Tap4& t, int k, int& ofs, int& 
 __global__ void __launch_bounds__(256) k_pyr_down(PyrLaunch p) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   struct { int w, h, pitch; } S = {p.sW, p.sH, p.sPitch}, D = {p.dW, p.dH, p.dPitch};
-  const int b = blockIdx.z, tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
-  const int xb = (int)blockIdx.x * 256, yb = (int)blockIdx.y * 16;
+  int bx, by, b;   // (plh_xcd_decode_tiles: the source tiles of neighbouring blocks overlap -- a frame's blocks behind one L2)
+  if (!plh_xcd_decode_tiles(p.nbx, p.nby, p.batch, bx, by, b)) return;
+  const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+  const int xb = bx * 256, yb = by * 16;
   const uint8_t* src = p.src + (long long)b * p.srcStride;
   uint8_t* dst = p.dst + (long long)b * p.dstStride;
   const int TP = p.TP;
   const int x4 = xb + (int)threadIdx.x * 4;
   const int y0 = yb + (int)threadIdx.y * PYR_ROWS;
   // every table fetch of the block, independent of each other (the tables are padded, see the host plan)
-  const ResizeTap tileX = p.xt[p.xtile + (int)blockIdx.x], tileY = p.yt[p.ytile + (int)blockIdx.y];
+  const ResizeTap tileX = p.xt[p.xtile + bx], tileY = p.yt[p.ytile + by];
   const bool work = y0 < D.h && x4 < D.pitch;
   Tap4 tx4, ty4;
   tx4.lo = tx4.hi = ty4.lo = ty4.hi = uint4{0u, 0u, 0u, 0u};
@@ -1107,8 +1109,13 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
 // ---------------------------------------------------------------------------------------------
 void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds, const PyrLaunch* fast, hipStream_t s) {
   dim3 grid((pitch / 4 + 63) / 64, (h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), a.batch), block(64, 4);
-  if (fast) hipLaunchKernelGGL(k_pyr_down, grid, block, lds, s, *fast);
-  else hipLaunchKernelGGL(k_pyr_down_gather, grid, block, lds, s, a, l);
+  if (fast) {
+    PyrLaunch pl = *fast;
+    pl.nbx = (int)grid.x; pl.nby = (int)grid.y; pl.batch = a.batch;
+    hipLaunchKernelGGL(k_pyr_down, dim3(plh_xcd_grid(pl.nbx * pl.nby, a.batch)), block, lds, s, pl);
+  } else {
+    hipLaunchKernelGGL(k_pyr_down_gather, grid, block, lds, s, a, l);
+  }
 }
 size_t fast_strip_lds_bytes(int width, int ch) {   // image tile + score tile + corner bitmap of k_fast_strips (width = xEnd - x0)
   const size_t TP = (size_t)((width + 8 + 3 + 3) & ~3) + 4;
