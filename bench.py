@@ -757,6 +757,14 @@ def main():
                                       "what": "all kernels' VALU wave-instructions per frame (SQ counters of this build) x frames/s per GPU "
                                               "against 1024 SIMDs x 2.4 GHz / 4.2 cycles: how close the front end runs to its own instruction floor"}
                                      if insts and ij.get("total_valu") else None),
+            "front_end_traffic": (lambda tot: {
+                "pmc_bytes_per_frame": int(tot), "algorithmic_bytes_per_frame": int(sum(alg)), "ratio": round(tot / max(sum(alg), 1), 3),
+                "achieved": round(tot * B * args.steps / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(tot * B * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "what": "memory-side bytes of ALL kernels of a step per frame (PMC FETCH_SIZE / WRITE_SIZE of this build, "
+                        "profiles/hbm_traffic.json) against the algorithmic bytes of the stages (DESIGN.md 3), and that traffic at the "
+                        "measured rate against the HBM peak"})(
+                    sum(v["total"] * v.get("launches_per_step", 1) for v in traffic.values())) if traffic else None,
             "verified": verified,
             "box": box,
         }

@@ -175,11 +175,17 @@ __device__ __forceinline__ int hamming256(const unsigned long long a[4], const u
 // their linear id, and each XCD has an L2 of its own: a (x, frame) grid spreads the blocks of ONE frame over all eight, and whatever
 // those blocks share (the level images behind overlapping keypoint patches, the planes behind a frame's rectangles and line bands)
 // is fetched from HBM once per XCD that touches it.  Here block L runs on XCD (L % 8) and takes frame 8 (L / 8 / perFrame) + L % 8:
-// all blocks of a frame sit behind one L2 and are dispatched side by side.  Batches below eight frames keep the plain order (a lone
-// frame wants all 256 CUs).  plh_xcd_grid() is the matching grid size.
+// all blocks of a frame sit behind one L2 and are dispatched side by side.  Batches below PLH_XCD_MIN_BATCH frames keep the plain
+// order (a lone frame wants all 256 CUs, and nine frames would put two on one XCD and one on each of the others).  plh_xcd_grid() is
+// the matching grid size.
+#if defined(HIPEMU)
+constexpr int PLH_XCD_MIN_BATCH = 8;    // (the CPU emulator's small batches walk the decode too)
+#else
+constexpr int PLH_XCD_MIN_BATCH = 64;
+#endif
 __device__ __forceinline__ bool plh_xcd_decode(int perFrame, int batch, int& x, int& b) {
   const int L = (int)blockIdx.x;
-  if (batch < 8) { x = L % perFrame; b = L / perFrame; return b < batch; }
+  if (batch < PLH_XCD_MIN_BATCH) { x = L % perFrame; b = L / perFrame; return b < batch; }
   const int q = L >> 3;
   x = q % perFrame;
   b = (q / perFrame) * 8 + (L & 7);
@@ -194,7 +200,7 @@ __device__ __forceinline__ bool plh_xcd_decode_tiles(int nx, int ny, int batch, 
   return true;
 }
 inline unsigned plh_xcd_grid(int perFrame, int batch) {
-  return batch < 8 ? (unsigned)(perFrame * batch) : (unsigned)((long long)perFrame * ((batch + 7) / 8) * 8);
+  return batch < PLH_XCD_MIN_BATCH ? (unsigned)(perFrame * batch) : (unsigned)((long long)perFrame * ((batch + 7) / 8) * 8);
 }
 
 }  // namespace plh
