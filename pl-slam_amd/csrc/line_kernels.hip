@@ -26,9 +26,9 @@ namespace plh {
 // byte gathers are in flight together and the result leaves as one dword when the address allows.  The map is fixed per
 // camera, so everything that depends on it alone -- the fixed-point split of the coordinates, the border tests -- was
 // done once on the host (plh_line_set_undistort).
-__global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a) {
+__global__ void __launch_bounds__(256) k_remap_u8(LineDeviceArgs a, PlhXcdGrid xg) {
   int bx, by, b;   // (plh_xcd_decode_tiles: a frame's tiles behind one L2 -- the taps of neighbouring tiles share sectors)
-  if (!plh_xcd_decode_tiles((a.w + 255) / 256, (a.h + 3) / 4, a.batch, bx, by, b)) return;
+  if (!plh_xcd_decode_tiles(xg, bx, by, b)) return;
   const int x4 = (bx * 64 + threadIdx.x) * 4, y = by * 4 + threadIdx.y;
   if (x4 >= a.w || y >= a.h) return;
   const uint8_t* src = a.img + (long long)b * a.imgStride;
@@ -82,13 +82,13 @@ __device__ __forceinline__ unsigned plh_udot2_l(unsigned a, unsigned b, unsigned
 
 template <int R>
 __global__ void __launch_bounds__(256) k_blur7_u8(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst,
-                                                  long long dStride, int dPitch, int w, int h, int batch, BlurWeights bw) {
+                                                  long long dStride, int dPitch, int w, int h, PlhXcdGrid xg, BlurWeights bw) {
   constexpr int TW = 64, TH = 16, IH = TH + 2 * R, IP = TW + 8, IPD = IP / 4;   // 72-byte tile rows = 18 dwords
   constexpr int HP = 26;                                                        // u16 pitch of a transposed column of row sums (IH <= 22)
   __shared__ unsigned tin[IH * IPD + 1];
   __shared__ unsigned short hT[TW * HP];
   int bx, by, b;   // (plh_xcd_decode_tiles: the halo rows and columns of a tile are its neighbours' sectors -- one frame, one L2)
-  if (!plh_xcd_decode_tiles((w + TW - 1) / TW, (h + TH - 1) / TH, batch, bx, by, b)) return;
+  if (!plh_xcd_decode_tiles(xg, bx, by, b)) return;
   const int x0 = bx * TW, y0 = by * TH, tid = threadIdx.x;
   const uint8_t* S = src + (long long)b * sStride;
   const bool interior = x0 >= 4 && x0 + TW + 8 <= w;   // the aligned dword pairs stay inside the row
@@ -562,7 +562,8 @@ __global__ void __launch_bounds__(64) k_lsd_bin_scatter(LineDeviceArgs a) {
 // host-callable launchers (stage 1: image preparation + level-line field + seed ordering)
 // ---------------------------------------------------------------------------------------------
 void launch_remap(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_remap_u8, dim3(plh_xcd_grid(((a.w + 255) / 256) * ((a.h + 3) / 4), a.batch)), dim3(64, 4), 0, s, a);
+  const PlhXcdGrid xg = plh_xcd_make((a.w + 255) / 256, (a.h + 3) / 4, a.batch);
+  hipLaunchKernelGGL(k_remap_u8, dim3(plh_xcd_grid(xg)), dim3(64, 4), 0, s, a, xg);
 }
 void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* dst, long long dStride, int dPitch, int w, int h,
                   int batch, const int taps[7], hipStream_t s) {
@@ -580,11 +581,12 @@ void launch_blur7(const uint8_t* src, long long sStride, int sPitch, uint8_t* ds
   auto tap = [&](int i) -> unsigned { return (i >= 0 && i <= 2 * R) ? (unsigned)taps[3 - R + i] : 0u; };
   for (int odd = 0; odd < 2; odd++)
     for (int i = 0; i < 4; i++) bw.v[odd][i] = tap(2 * i - odd) | (tap(2 * i - odd + 1) << 16);
-  const dim3 grid(plh_xcd_grid(((w + 63) / 64) * ((h + 15) / 16), batch));
+  const PlhXcdGrid xg = plh_xcd_make((w + 63) / 64, (h + 15) / 16, batch);   // (64 x 16 = the kernel's TW x TH)
+  const dim3 grid(plh_xcd_grid(xg));
   if (R == 2)
-    hipLaunchKernelGGL(k_blur7_u8<2>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, batch, bw);
+    hipLaunchKernelGGL(k_blur7_u8<2>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, xg, bw);
   else
-    hipLaunchKernelGGL(k_blur7_u8<3>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, batch, bw);
+    hipLaunchKernelGGL(k_blur7_u8<3>, grid, dim3(256), 0, s, src, sStride, sPitch, dst, dStride, dPitch, w, h, xg, bw);
 }
 void launch_resize(const uint8_t* src, long long sStride, int sPitch, int sw, int sh, uint8_t* dst, long long dStride, int dPitch,
                    int dw, int dh, int batch, const ResizeTap* xtab, const ResizeTap* ytab, int tileTP, int tileTR, hipStream_t s) {

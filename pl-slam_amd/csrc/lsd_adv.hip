@@ -85,11 +85,12 @@ void launch_lsd_lgamma_table(double* t, int n, hipStream_t s) {
 #else
 #define PLH_ADVFIRST_ATTR
 #endif
-__global__ void __launch_bounds__(64) PLH_ADVFIRST_ATTR k_adv_first(LineDeviceArgs a, int perFrame) {
+__global__ void __launch_bounds__(64) PLH_ADVFIRST_ATTR k_adv_first(LineDeviceArgs a, PlhXcdGrid xg) {
   __shared__ LsdScanGeom s_geom[64];
   __shared__ int s_tot[64], s_alg[64], s_slot[64];
   int blk, b;   // (plh_xcd_decode: the blocks of a frame walk one angle plane -- behind one L2)
-  if (!plh_xcd_decode(perFrame, a.batch, blk, b)) return;
+  if (!plh_xcd_decode(xg, blk, b)) return;
+  const int perFrame = xg.perFrame;
   const int lane = threadIdx.x, grp = lane >> 3, j = lane & 7;
   const AdvFrame f = adv_frame(a, b);
   const RcFrame rf = adv_field(a, b);
@@ -142,11 +143,12 @@ __global__ void __launch_bounds__(64) PLH_ADVFIRST_ATTR k_adv_first(LineDeviceAr
   }
 }
 
-__global__ void __launch_bounds__(64) PLH_ADV_ATTR k_adv_improve(LineDeviceArgs a, int perFrame) {
+__global__ void __launch_bounds__(64) PLH_ADV_ATTR k_adv_improve(LineDeviceArgs a, PlhXcdGrid xg) {
   __shared__ LsdScanGeom s_geom[8 * 5];   // [rectangle of the pass][variant]
   __shared__ int s_ok[8 * 5];
   int blk, b;
-  if (!plh_xcd_decode(perFrame, a.batch, blk, b)) return;
+  if (!plh_xcd_decode(xg, blk, b)) return;
+  const int perFrame = xg.perFrame;
   const int lane = threadIdx.x, grp = lane >> 3, j = lane & 7, g0 = lane & ~7;
   const AdvFrame f = adv_frame(a, b);
   const RcFrame rf = adv_field(a, b);
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__(64) PLH_ADV_ATTR k_adv_improve(LineDeviceArgs 
         for (int m = 0; m < 5; m++) { tot[m] = total; alg[m] = adv_sum8(alg[m]); }
       } else {   // a width stage: the five variants in one walk
         const LsdAlignTol t = lsd_align_tol(r.theta, r.prec);
-        lsd_rect_counts_g8_var5(rf, s_geom + grp * 5, t, j, tot, alg);
+        lsd_rect_counts_g8_var5(rf, s_geom + grp * 5, t, j, g0, tot, alg);   // (tot[m]: lane m's own variant, read below by lane j == m)
 #pragma unroll
         for (int m = 0; m < 5; m++) alg[m] = adv_sum8(alg[m]);
       }
@@ -259,8 +261,9 @@ __global__ void __launch_bounds__(64) k_adv_compact(LineDeviceArgs a) {
 
 void launch_lsd_adv(const LineDeviceArgs& a, hipStream_t s) {
   const int nf = lsd_blocks_per_frame(a.batch, ADV_FIRST_MIN, ADV_FIRST_MAX), ni = lsd_blocks_per_frame(a.batch, ADV_IMPROVE_MIN, ADV_IMPROVE_MAX);
-  hipLaunchKernelGGL(k_adv_first, dim3(plh_xcd_grid(nf, a.batch)), dim3(64), 0, s, a, nf);
-  hipLaunchKernelGGL(k_adv_improve, dim3(plh_xcd_grid(ni, a.batch)), dim3(64), 0, s, a, ni);
+  const PlhXcdGrid xf = plh_xcd_make(nf, a.batch), xi = plh_xcd_make(ni, a.batch);
+  hipLaunchKernelGGL(k_adv_first, dim3(plh_xcd_grid(xf)), dim3(64), 0, s, a, xf);
+  hipLaunchKernelGGL(k_adv_improve, dim3(plh_xcd_grid(xi)), dim3(64), 0, s, a, xi);
   hipLaunchKernelGGL(k_adv_compact, dim3(a.batch), dim3(64), 0, s, a);
 }
 

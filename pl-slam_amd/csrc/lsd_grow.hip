@@ -2133,9 +2133,9 @@ __device__ __forceinline__ unsigned align_b32(unsigned hi, unsigned lo, unsigned
 // and the vertical difference r2 - r0 of six columns (three pairs each), then dx = smooth[c + 2] - smooth[c] and
 // dy = diff[c] + 2 diff[c + 1] + diff[c + 2] for the four outputs (two pairs each), re-paired into (dx, dy) dwords with
 // v_perm: 36 VALU instructions instead of 18 byte extractions and 4 x 11 scalar-lane additions.
-__global__ void __launch_bounds__(256) k_sobel_pack(LineDeviceArgs a) {
+__global__ void __launch_bounds__(256) k_sobel_pack(LineDeviceArgs a, PlhXcdGrid xg) {
   int bx, y, b;   // (plh_xcd_decode_tiles: a block is a row and reads its two neighbours -- behind one L2 a frame is fetched once, not thrice)
-  if (!plh_xcd_decode_tiles((a.w + 1023) / 1024, a.h, a.batch, bx, y, b)) return;
+  if (!plh_xcd_decode_tiles(xg, bx, y, b)) return;
   const int x = (bx * 256 + threadIdx.x) * 4;
   if (x >= a.w) return;
   const uint8_t* S = a.tmpA + (long long)b * a.fullStride;
@@ -2212,13 +2212,13 @@ __device__ __forceinline__ int lbd_coord_wide(float v, int hi) {   // images fro
 
 constexpr int LBD_TILE_PITCH = 20;   // dwords per row of the offset / value tile: 16 samples + pad (rows stay 16-byte aligned)
 __global__ void __launch_bounds__(64) k_lbd(LineDeviceArgs a, const plh_keyline* kls, const int* nOut, const float* coef,
-                                            uint8_t* desc) {
+                                            uint8_t* desc, PlhXcdGrid xg) {
   __shared__ float rows[4][64];                  // per support-region row: pL nL pO nO (after the global Gaussian)
   __shared__ float des[LBD_NUM_BANDS * 8];
   __shared__ float sq[LBD_NUM_BANDS * 8];
   __shared__ float scl[2];
   int li, b;   // (plh_xcd_decode: the bands of a frame's lines overlap -- one gradient plane behind one L2)
-  if (!plh_xcd_decode(a.outCap, a.batch, li, b)) return;
+  if (!plh_xcd_decode(xg, li, b)) return;
   const int lane = threadIdx.x;
   if (li >= nOut[b]) return;
   const plh_keyline L = kls[(long long)b * a.outCap + li];
@@ -2447,10 +2447,12 @@ void launch_keylines(const LineDeviceArgs& a, plh_keyline* kl, double* fn, int* 
   hipLaunchKernelGGL(k_keylines, dim3(a.batch), dim3(KL_THREADS), (size_t)a.outCap * 8 + 64, s, a, kl, fn, n);
 }
 void launch_sobel(const LineDeviceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_sobel_pack, dim3(plh_xcd_grid(((a.w + 1023) / 1024) * a.h, a.batch)), dim3(256), 0, s, a);
+  const PlhXcdGrid xg = plh_xcd_make((a.w + 1023) / 1024, a.h, a.batch);
+  hipLaunchKernelGGL(k_sobel_pack, dim3(plh_xcd_grid(xg)), dim3(256), 0, s, a, xg);
 }
 void launch_lbd(const LineDeviceArgs& a, const plh_keyline* kl, const int* n, const float* coef, uint8_t* desc, hipStream_t s) {
-  hipLaunchKernelGGL(k_lbd, dim3(plh_xcd_grid(a.outCap, a.batch)), dim3(64), 0, s, a, kl, n, coef, desc);
+  const PlhXcdGrid xg = plh_xcd_make(a.outCap, a.batch);
+  hipLaunchKernelGGL(k_lbd, dim3(plh_xcd_grid(xg)), dim3(64), 0, s, a, kl, n, coef, desc, xg);
 }
 #if defined(PLH_GROW_PROF)
 #if PLH_GROW_PROF + 0 >= 3 && !defined(HIPEMU)

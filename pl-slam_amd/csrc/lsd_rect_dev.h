@@ -300,24 +300,9 @@ __device__ __forceinline__ void lsd_rect_counts_g8(const RcFrame& f, const LsdSc
 // walks, a third of the loads -- and the walks, not nfa(), are what k_adv_improve's duration is made of
 // (profiles/r05_rects_improve_alone_variants.txt).  gs: the five geometries in LDS (lsd_scan_none() for a variant the width gate
 // stopped).
-struct LsdVar5Line {   // one scan line of the five variants: their spans (empty: xa = 1, xb = 0) and the union of the non-empty ones
+struct LsdVar5Line {   // one scan line of the five variants: their spans (empty: xa = 0xffff, xb = 0) and the union of the non-empty ones
   int xa[5], xb[5], ua, ub;
 };
-__device__ __forceinline__ void lsd_var5_line(const LsdScanGeom* gs, int y, int xMax, int left[5], int right[5], int tot[5], LsdVar5Line& L) {
-  L.ua = 1 << 30; L.ub = -1;   // (no span on this line: ua + j stays far above ub)
-#pragma unroll
-  for (int m = 0; m < 5; m++) {
-    const LsdScanGeom g = gs[m];
-    const bool on = y >= g.yA && y <= g.yB;   // one of this variant's scan lines
-    const int a0 = max(left[m], 0), b0 = min(right[m], xMax);
-    const bool some = on && b0 >= a0;
-    L.xa[m] = some ? a0 : 1; L.xb[m] = some ? b0 : 0;
-    tot[m] += some ? b0 - a0 + 1 : 0;
-    left[m] += on ? (y < g.ly ? g.fl : g.sl) : 0;
-    right[m] += on ? (y < g.ry ? g.fr : g.sr) : 0;
-    L.ua = some ? min(L.ua, a0) : L.ua; L.ub = some ? max(L.ub, b0) : L.ub;
-  }
-}
 __device__ __forceinline__ void lsd_var5_count(const LsdAlignTol& t, const LsdVar5Line& L, int x, float v, int alg[5]) {
   const float d = lsd_fold_deg(t.thDeg, v);
   bool r = d < t.lo;
@@ -325,26 +310,56 @@ __device__ __forceinline__ void lsd_var5_count(const LsdAlignTol& t, const LsdVa
 #pragma unroll
   for (int m = 0; m < 5; m++) alg[m] += (r && x >= L.xa[m] && x <= L.xb[m]) ? 1 : 0;
 }
-__device__ __forceinline__ void lsd_rect_counts_g8_var5(const RcFrame& f, const LsdScanGeom* gs, const LsdAlignTol& t, int j, int tot[5], int alg[5]) {
+// Round 6, second half: the BOUNDS of the five variants are walked by five lanes, one variant each -- lane m < 5 of the rectangle's
+// eight advances variant m's left / right bounds and counts its pixels (tot), and a scan line's span travels to the other lanes as one
+// packed word (xa | xb << 16) through a shuffle.  Before, every lane advanced all five variants itself: 70 of the ~ 95 instructions a
+// scan line of a steep rectangle cost were that bookkeeping, eight times over.  g0 = first lane of the rectangle's group.  The scan-line
+// loop is uniform over the wavefront (a group whose walk is over takes part with empty spans), so the shuffles are executed by all lanes;
+// a lane's result: tot[m] = ITS OWN variant's pixel count in every m (the caller reads tot[j] in lane j), alg[m] = its share of the
+// aligned pixels of variant m (the caller adds the eight up).  Image widths < 65535 (the spans are packed in 16 bits).
+__device__ __forceinline__ void lsd_rect_counts_g8_var5(const RcFrame& f, const LsdScanGeom* gs, const LsdAlignTol& t, int j, int g0, int tot[5], int alg[5]) {
   const int xMax = f.sw - 1;
-  int left[5], right[5];
   int yLo = 1 << 30, yHi = -1;
 #pragma unroll
   for (int m = 0; m < 5; m++) {
-    const LsdScanGeom g = gs[m];
-    left[m] = g.mx; right[m] = g.mx; tot[m] = 0; alg[m] = 0;
-    if (g.yA <= g.yB) { yLo = min(yLo, g.yA); yHi = max(yHi, g.yB); }
+    const int yA = gs[m].yA, yB = gs[m].yB;
+    alg[m] = 0;
+    if (yA <= yB) { yLo = min(yLo, yA); yHi = max(yHi, yB); }
   }
-#pragma clang loop unroll(disable) vectorize(disable)
-  for (int y = yLo; y <= yHi; y += 2) {   // two scan lines per trip to memory
-    LsdVar5Line L0, L1;
-    lsd_var5_line(gs, y, xMax, left, right, tot, L0);
-    L1.ua = 1 << 30; L1.ub = -1;
+  const LsdScanGeom g = gs[min(j, 4)];
+  const int gyA = j < 5 ? g.yA : 1, gyB = j < 5 ? g.yB : 0;   // (lanes 5 .. 7: no variant, never on a scan line)
+  int left = g.mx, right = g.mx, mytot = 0;
+  auto span = [&](int y) -> unsigned {   // this lane's variant on scan line y
+    const bool on = y >= gyA && y <= gyB;
+    const int a0 = max(left, 0), b0 = min(right, xMax);
+    const bool some = on && b0 >= a0;
+    mytot += some ? b0 - a0 + 1 : 0;
+    left += on ? (y < g.ly ? g.fl : g.sl) : 0;
+    right += on ? (y < g.ry ? g.fr : g.sr) : 0;
+    return some ? ((unsigned)a0 | ((unsigned)b0 << 16)) : 0xffffu;
+  };
+  auto spread = [&](unsigned s, LsdVar5Line& L) {
+    L.ua = 0xffff; L.ub = 0;
 #pragma unroll
-    for (int m = 0; m < 5; m++) { L1.xa[m] = 1; L1.xb[m] = 0; }
-    if (y + 1 <= yHi) lsd_var5_line(gs, y + 1, xMax, left, right, tot, L1);
-    const float* row0 = rc_row(f, y);
-    const float* row1 = rc_row(f, y + 1);   // (read only when the line y + 1 has a span: it exists then)
+    for (int m = 0; m < 5; m++) {
+      const unsigned w = (unsigned)__shfl((int)s, g0 + m);
+      L.xa[m] = (int)(w & 0xffffu); L.xb[m] = (int)(w >> 16);
+      L.ua = min(L.ua, L.xa[m]); L.ub = max(L.ub, L.xb[m]);
+    }
+  };
+#pragma clang loop unroll(disable) vectorize(disable)
+  for (int y = yLo; __any(y <= yHi); y += 2) {   // two scan lines per trip to memory
+    const bool live = y <= yHi;
+    unsigned s0 = 0xffffu, s1 = 0xffffu;
+    if (live) {
+      s0 = span(y);
+      if (y + 1 <= yHi) s1 = span(y + 1);
+    }
+    LsdVar5Line L0, L1;
+    spread(s0, L0);
+    spread(s1, L1);
+    const float* row0 = rc_row(f, live ? y : 0);
+    const float* row1 = rc_row(f, live ? y + 1 : 0);   // (read only when the line y + 1 has a span: it exists then)
     const int x0 = L0.ua + j, x1 = L1.ua + j;
     float v0 = -1024.f, v1 = -1024.f;   // NOTDEF
     if (x0 <= L0.ub) v0 = rc_at(row0, x0);
@@ -356,6 +371,8 @@ __device__ __forceinline__ void lsd_rect_counts_g8_var5(const RcFrame& f, const 
 #pragma clang loop unroll(disable) vectorize(disable)
     for (int x = x1 + 8; x <= L1.ub; x += 8) lsd_var5_count(t, L1, x, rc_at(row1, x), alg);
   }
+#pragma unroll
+  for (int m = 0; m < 5; m++) tot[m] = mytot;
 }
 
 // The same walk for the two "finer precision" stages of rect_improve(): their five variants share the rectangle and differ in

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) k_pyr_down(PyrLaunch p) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   struct { int w, h, pitch; } S = {p.sW, p.sH, p.sPitch}, D = {p.dW, p.dH, p.dPitch};
   int bx, by, b;   // (plh_xcd_decode_tiles: the source tiles of neighbouring blocks overlap -- a frame's blocks behind one L2)
-  if (!plh_xcd_decode_tiles(p.nbx, p.nby, p.batch, bx, by, b)) return;
+  if (!plh_xcd_decode_tiles(p.xg, bx, by, b)) return;
   const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
   const int xb = bx * 256, yb = by * 16;
   const uint8_t* src = p.src + (long long)b * p.srcStride;
@@ -262,14 +262,18 @@ __global__ void __launch_bounds__(256) k_pyr_down(PyrLaunch p) {
 //   dark = max_i min(d[i..i+8]),  bright = max_i min(-d[i..i+8]),  M = max(dark, bright)
 // pixel is a corner at threshold t  <=>  M > t ; cornerScore<16>() = M - 1 for any corner (the `threshold` floor inside
 // cornerScore only matters for non-corners).  A pixel cannot be a dark and a bright corner at once (9 + 9 > 16), so only
-// the side a pixel can be a corner on is ever measured: fast_arc_side(sv, ns, p) = max_i min_j (sv + ns * p[i+j]) with
+// the side a pixel can be a corner on is ever measured: fast_arc_side(v, bright, p) = max_i min_j (sv + ns * p[i+j]) with
 // (sv, ns) = (v, -1) for the dark side and (-v, +1) for the bright side.  The sliding 9-window minimum over the circular
 // 16-ring is built from windows of 3 (v_min3), the maximum over the 16 arcs is a v_max3 tree: 16 + 16 + 16 + 8 instructions.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_arc_side(int sv, int ns, const int p[16]) {
+// Round 6: the ring enters as p ^ m with m = 0 (bright side) or 255 (dark side: 255 - p), and v ^ m leaves at the end -- min / max commute
+// with the shift by v, so max_i min_j (p[j] - v) = (max_i min_j p[j]) - v and max_i min_j (v - p[j]) = (max_i min_j (255 - p[j])) - (255 - v):
+// sixteen v_xor_b32 (2.6 cycles per wave64 instruction on gfx950, profiles/r01_valu_issue_rate_gfx950.txt) instead of sixteen v_mad_i32_i24 (4.2).
+__device__ __forceinline__ int fast_arc_side(int v, bool bright, const int p[16]) {
   int x[16], lo3[16], lo9[16];
+  const int m = bright ? 0 : 255;
 #pragma unroll
-  for (int i = 0; i < 16; i++) x[i] = __mul24(ns, p[i]) + sv;      // v_mad_i32_i24
+  for (int i = 0; i < 16; i++) x[i] = p[i] ^ m;
 #pragma unroll
   for (int i = 0; i < 16; i++) lo3[i] = min(min(x[i], x[(i + 1) & 15]), x[(i + 2) & 15]);
 #pragma unroll
@@ -278,7 +282,7 @@ __device__ __forceinline__ int fast_arc_side(int sv, int ns, const int p[16]) {
 #pragma unroll
   for (int i = 0; i < 5; i++) a[i] = max(max(lo9[3 * i], lo9[3 * i + 1]), lo9[3 * i + 2]);
   a[5] = lo9[15];
-  return max(max(max(a[0], a[1]), a[2]), max(max(a[3], a[4]), a[5]));
+  return max(max(max(a[0], a[1]), a[2]), max(max(a[3], a[4]), a[5])) - (v ^ m);
 }
 
 // One block per (row of FAST cells, frame).  The rows of the level that the cell row covers are staged in LDS with
@@ -313,26 +317,23 @@ __device__ __forceinline__ void fast_score_entry(const uint8_t* tile, int TP, ui
   p[4] = t[3];            p[5] = t[-TP + 3];      p[6] = t[-2 * TP + 2];  p[7] = t[-3 * TP + 1];
   p[8] = t[-3 * TP];      p[9] = t[-3 * TP - 1];  p[10] = t[-2 * TP - 2]; p[11] = t[-TP - 3];
   p[12] = t[-3];          p[13] = t[TP - 3];      p[14] = t[2 * TP - 2];  p[15] = t[3 * TP - 1];
-  const int M = fast_arc_side(bright ? -v : v, bright ? 1 : -1, p);
+  const int M = fast_arc_side(v, bright, p);
   if (M > tlo) {
     sc[__mul24(r - 2, TP) + cx] = (uint8_t)(M - 1);   // score row rr = r - 3 is stored at sc row rr + 1
     atomicOr(&cmask[__mul24(r - 3, W32) + (cx >> 5)], 1u << (cx & 31));
   }
 }
 
-__global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a) {
+__global__ void __launch_bounds__(256) k_fast_strips(OrbDeviceArgs a, PlhXcdGrid xg) {
   HIP_DYNAMIC_SHARED(unsigned char, smem)
   __shared__ unsigned s_queue[4][FAST_QCAP];
   __shared__ int s_hi[64];
   __shared__ int s_total, s_listN;
 
-  // XCD-aware decode: block L runs on XCD (L % 8); keep all strips of a frame on one XCD so the overlapping halos
-  // and the level rows are served from that XCD's L2.
-  const int L = blockIdx.x;
-  const int xcd = L & 7, q = L >> 3;
-  const int strip = q % a.nStrips;
-  const int b = (q / a.nStrips) * 8 + xcd;
-  if (b >= a.batch) return;
+  // XCD-aware decode (plh_xcd.h): keep all strips of a frame on one XCD so the overlapping halos and the level rows are served from
+  // that XCD's L2.
+  int strip, b;
+  if (!plh_xcd_decode(xg, strip, b)) return;
 
   const OrbStrip st = a.strips[strip];
   const OrbLevel lv = a.levels[st.level];
@@ -911,7 +912,7 @@ __device__ __forceinline__ int reflect101(int p, int nn) {
 }
 
 __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoint* kps, uint8_t* desc, int* nOut,
-                                                     int cap) {
+                                                     int cap, PlhXcdGrid xg) {
   constexpr int PR = 21, PW = 43, PP = 48;   // patch radius / width / pitch (pitch 48 = 12 dwords)
   constexpr int BR = 18, BW = 37, BP = 40;   // blurred radius / width / pitch of the transposed blurred tile
   constexpr int HP = 50;                     // pitch (in u16) of the transposed row sums: rows 0..42 + the over-read of the last group (up to row 45);
@@ -929,7 +930,7 @@ __global__ void __launch_bounds__(64) k_orient_brief(OrbDeviceArgs a, plh_keypoi
   // every keypoint fetched its 43 rows x 1 - 2 sectors from HBM (4.9 MB per frame for 1.9 MB of patches, profiles/hbm_traffic.json
   // of build b6c019a1); behind one L2 the frame's level images are fetched once (1.0 MB).
   int slot, b;
-  if (!plh_xcd_decode(a.selPerFrame, a.batch, slot, b)) return;
+  if (!plh_xcd_decode(xg, slot, b)) return;
   const int lane = threadIdx.x;
   const int* selCount = a.selCount + (long long)b * a.nlevels;
 
@@ -1111,8 +1112,8 @@ void launch_pyr_down(const OrbDeviceArgs& a, int l, int pitch, int h, size_t lds
   dim3 grid((pitch / 4 + 63) / 64, (h + 4 * PYR_ROWS - 1) / (4 * PYR_ROWS), a.batch), block(64, 4);
   if (fast) {
     PyrLaunch pl = *fast;
-    pl.nbx = (int)grid.x; pl.nby = (int)grid.y; pl.batch = a.batch;
-    hipLaunchKernelGGL(k_pyr_down, dim3(plh_xcd_grid(pl.nbx * pl.nby, a.batch)), block, lds, s, pl);
+    pl.xg = plh_xcd_make((int)grid.x, (int)grid.y, a.batch);
+    hipLaunchKernelGGL(k_pyr_down, dim3(plh_xcd_grid(pl.xg)), block, lds, s, pl);
   } else {
     hipLaunchKernelGGL(k_pyr_down_gather, grid, block, lds, s, a, l);
   }
@@ -1123,9 +1124,9 @@ size_t fast_strip_lds_bytes(int width, int ch) {   // image tile + score tile + 
   return (((size_t)ch * TP + 15) & ~(size_t)15) + (((eh + 2) * TP + 15) & ~(size_t)15) + eh * W32 * 4 + 64;
 }
 void launch_fast_strips(const OrbDeviceArgs& a, size_t lds, hipStream_t s) {
-  const int groups = (a.batch + 7) / 8;
-  dim3 grid((unsigned)((long long)a.nStrips * groups * 8)), block(256);
-  hipLaunchKernelGGL(k_fast_strips, grid, block, lds, s, a);
+  const PlhXcdGrid xg = plh_xcd_make(a.nStrips, a.batch);
+  dim3 grid(plh_xcd_grid(xg)), block(256);
+  hipLaunchKernelGGL(k_fast_strips, grid, block, lds, s, a, xg);
 }
 size_t octree_lds_bytes(int nodeCap) { return (size_t)nodeCap * (4 * 7 + 2 * 10 + 1) + 64 + 64; }
 void launch_octree(const OrbDeviceArgs& a, int nodeCapMax, hipStream_t s) {
@@ -1133,8 +1134,9 @@ void launch_octree(const OrbDeviceArgs& a, int nodeCapMax, hipStream_t s) {
   hipLaunchKernelGGL(k_octree, grid, block, octree_lds_bytes(nodeCapMax), s, a, nodeCapMax);
 }
 void launch_orient_brief(const OrbDeviceArgs& a, plh_keypoint* kps, uint8_t* desc, int* nOut, int cap, hipStream_t s) {
-  dim3 grid(plh_xcd_grid(a.selPerFrame, a.batch)), block(64);
-  hipLaunchKernelGGL(k_orient_brief, grid, block, 0, s, a, kps, desc, nOut, cap);
+  const PlhXcdGrid xg = plh_xcd_make(a.selPerFrame, a.batch);
+  dim3 grid(plh_xcd_grid(xg)), block(64);
+  hipLaunchKernelGGL(k_orient_brief, grid, block, 0, s, a, kps, desc, nOut, cap, xg);
 }
 
 }  // namespace plh

@@ -4,6 +4,8 @@
 #pragma once
 #include <cstdint>
 
+#include "plh_xcd.h"
+
 namespace plh {
 
 constexpr int ORB_MAX_LEVELS = 16;
@@ -70,7 +72,7 @@ struct PyrLaunch {             // everything one k_pyr_down launch needs, by val
   const ResizeTap* xt;         // the level's x taps (padded), then its per-block-column tile entries at xt + xtile
   const ResizeTap* yt;
   int xtile, ytile;
-  int nbx, nby, batch;         // the launch's tiles per frame and frames (set by launch_pyr_down: the grid is plh_xcd_grid's)
+  PlhXcdGrid xg;               // the launch's tiles per frame and frames (set by launch_pyr_down: plh_xcd.h)
 };
 
 struct OrbDeviceArgs {         // kernel argument block (passed by value)

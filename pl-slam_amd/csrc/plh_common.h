@@ -9,6 +9,7 @@
 
 #include "../../include/plslam_hip.h"
 #include "plh_shims.h"
+#include "plh_xcd.h"
 
 #define PLH_WAVE 64
 
@@ -171,36 +172,35 @@ __device__ __forceinline__ int hamming256(const unsigned long long a[4], const u
   return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
 }
 
-// XCD-aware decode of a 1-D grid that stands for (blocks of a frame) x (frames).  Workgroups go to the eight XCDs round robin by
-// their linear id, and each XCD has an L2 of its own: a (x, frame) grid spreads the blocks of ONE frame over all eight, and whatever
-// those blocks share (the level images behind overlapping keypoint patches, the planes behind a frame's rectangles and line bands)
-// is fetched from HBM once per XCD that touches it.  Here block L runs on XCD (L % 8) and takes frame 8 (L / 8 / perFrame) + L % 8:
-// all blocks of a frame sit behind one L2 and are dispatched side by side.  Batches below PLH_XCD_MIN_BATCH frames keep the plain
-// order (a lone frame wants all 256 CUs, and nine frames would put two on one XCD and one on each of the others).  plh_xcd_grid() is
-// the matching grid size.
-#if defined(HIPEMU)
-constexpr int PLH_XCD_MIN_BATCH = 8;    // (the CPU emulator's small batches walk the decode too)
-#else
-constexpr int PLH_XCD_MIN_BATCH = 64;
-#endif
-__device__ __forceinline__ bool plh_xcd_decode(int perFrame, int batch, int& x, int& b) {
-  const int L = (int)blockIdx.x;
-  if (batch < PLH_XCD_MIN_BATCH) { x = L % perFrame; b = L / perFrame; return b < batch; }
-  const int q = L >> 3;
-  x = q % perFrame;
-  b = (q / perFrame) * 8 + (L & 7);
-  return b < batch;
+// XCD-aware block order: plh_xcd.h (PlhXcdGrid, built by the launcher).  q / d for a launch constant d with m = floor(2^32 / d): the
+// estimate (q m) >> 32 is the quotient or one below it for every q < 2^32.
+__device__ __forceinline__ unsigned plh_udiv_magic(unsigned q, unsigned d, unsigned m, unsigned& rem) {
+  unsigned b = (unsigned)(((unsigned long long)q * m) >> 32);
+  unsigned x = q - b * d;
+  if (x >= d) { b++; x -= d; }
+  rem = x;
+  return b;
+}
+__device__ __forceinline__ bool plh_xcd_decode(const PlhXcdGrid& g, int& x, int& b) {
+  const unsigned L = blockIdx.x;
+  unsigned r;
+  if (g.batch < PLH_XCD_MIN_BATCH) {
+    b = (int)plh_udiv_magic(L, (unsigned)g.perFrame, g.mPer, r);
+    x = (int)r;
+    return b < g.batch;
+  }
+  b = (int)(plh_udiv_magic(L >> 3, (unsigned)g.perFrame, g.mPer, r) * 8u + (L & 7u));
+  x = (int)r;
+  return b < g.batch;
 }
 // the same for a (tiles in x, tiles in y) x frames grid: neighbouring tiles of a stencil share their halo sectors behind one L2
-__device__ __forceinline__ bool plh_xcd_decode_tiles(int nx, int ny, int batch, int& bx, int& by, int& b) {
+__device__ __forceinline__ bool plh_xcd_decode_tiles(const PlhXcdGrid& g, int& bx, int& by, int& b) {
   int t;
-  if (!plh_xcd_decode(nx * ny, batch, t, b)) return false;
-  by = t / nx;
-  bx = t - by * nx;
+  if (!plh_xcd_decode(g, t, b)) return false;
+  unsigned r;
+  by = (int)plh_udiv_magic((unsigned)t, (unsigned)g.nx, g.mNx, r);
+  bx = (int)r;
   return true;
-}
-inline unsigned plh_xcd_grid(int perFrame, int batch) {
-  return batch < PLH_XCD_MIN_BATCH ? (unsigned)(perFrame * batch) : (unsigned)((long long)perFrame * ((batch + 7) / 8) * 8);
 }
 
 }  // namespace plh

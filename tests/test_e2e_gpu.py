@@ -194,3 +194,48 @@ def test_full_residency_replicas_are_identical(plslam, oracle, synth):
         lk, ldr, lfr, _ = _oracle_line(oracle, base[u], 200, 0.0, TUM1_K, TUM1_D)
         assert nl[u] == len(lk) and (r["ldesc"][u, :nl[u]] == ldr).all()
 
+
+
+def test_ragged_group_of_eight_xcd_block_order(plslam, oracle, synth):
+    """From 64 frames on the kernels that share bytes between a frame's blocks decode a one-dimensional grid the XCD-aware way
+    (plh_xcd_decode, plh_common.h: block L -> frame 8 (L / 8 / blocks per frame) + L % 8).  A handle planned for 80 frames is driven
+    with 67 -- the last group of eight holds three frames and five that do not exist -- and then with 64 (the smallest batch that
+    takes the order): every frame equals the oracle, frames beyond the call's batch are untouched."""
+    import torch
+    B = 80
+    frames = synth.make_frames(640, B, 480, 640)
+    d = torch.from_numpy(frames).cuda()
+    orb = plslam.ORBextractor(1000, 1.2, 8, 20, 7, rows=480, cols=640, max_batch=B)
+    le = plslam.LINEextractor(1, 1.2, 200, 0.0, rows=480, cols=640, max_batch=B, K=TUM1_K, D=TUM1_D)
+    ocap, lcap = orb.capacity, le.capacity
+    s = torch.cuda.current_stream().cuda_stream
+    ref = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    want = {}
+    for nb in (67, 64):
+        kps = torch.zeros((B, ocap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((B, ocap, 32), dtype=torch.uint8, device="cuda")
+        n = torch.full((B,), -5, dtype=torch.int32, device="cuda")
+        kl = torch.zeros((B, lcap, 17), dtype=torch.float32, device="cuda")
+        ld = torch.zeros((B, lcap, 32), dtype=torch.uint8, device="cuda")
+        fn = torch.zeros((B, lcap, 3), dtype=torch.float64, device="cuda")
+        nl = torch.full((B,), -5, dtype=torch.int32, device="cuda")
+        orb.extract_batch_dev(d, nb, 480 * 640, kps, desc, n, s)
+        le.extract_batch_dev(d, nb, 480 * 640, kl, ld, fn, nl, s)
+        torch.cuda.synchronize()
+        assert orb.status() == 0 and le.status() == 0
+        n_h, nl_h = n.cpu().numpy(), nl.cpu().numpy()
+        assert (n_h[nb:] == -5).all() and (nl_h[nb:] == -5).all()
+        k_h = kps.cpu().numpy().view(np.uint8).reshape(B, ocap, 28).copy().view(plslam.KP_DTYPE).reshape(B, ocap)
+        d_h = desc.cpu().numpy()
+        kl_h = kl.cpu().numpy().view(np.uint8).reshape(B, lcap, 68).copy().view(plslam.KL_DTYPE).reshape(B, lcap)
+        ld_h, fn_h = ld.cpu().numpy(), fn.cpu().numpy()
+        for b in range(nb):
+            if b not in want:
+                want[b] = (ref.extract(frames[b]), _oracle_line(oracle, frames[b], 200, 0.0, TUM1_K, TUM1_D)[:3])
+            (rk, rd), (lk, ldr, lfr) = want[b]
+            assert n_h[b] == len(rk) and (d_h[b, :n_h[b]] == rd).all(), (nb, b)
+            assert all((k_h[b, :n_h[b]][f] == rk[f]).all() for f in rk.dtype.names), (nb, b)
+            assert nl_h[b] == len(lk), (nb, b)
+            _match(kl_h[b, :nl_h[b]], ld_h[b, :nl_h[b]], fn_h[b, :nl_h[b]], lk, ldr, lfr, "batch %d frame %d" % (nb, b))
+    orb.close()
+    le.close()

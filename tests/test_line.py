@@ -589,3 +589,34 @@ def test_gpu_line_golden(plslam, synth):
         ex.close()
         assert gs.shape == g["segs"].shape and (gs == g["segs"]).all(), os.path.basename(path)
         _match(kl, desc, fn, g["keylines"], g["desc"], g["linefn"], os.path.basename(path))
+
+
+def test_emu_batch_of_ten_xcd_block_order(plslam, oracle, synth, emu_lib):
+    """Ten small frames in one call on the emulator build, where plh_xcd_decode (plh_common.h) switches to the XCD-aware block order
+    from eight frames on (the product build: from 64): block L -> frame 8 (L / 8 / blocks per frame) + L % 8, the last group of eight
+    ragged (frames 8, 9 + six that do not exist).  Every kernel that decodes its grid that way -- pyramid, orientation + rBRIEF, remap,
+    blur, Sobel, LBD, the LSD_REFINE_ADV walks -- must touch every frame exactly once: all records equal the oracle's."""
+    B, rows, cols = 10, 120, 160
+    frames = np.stack([synth.make_frame(30 + b, rows, cols, n_rect=40, n_line=20) for b in range(B)])
+    K, D = [150.0, 150.0, 80.0, 60.0], TUM1_D
+    ex = plslam.LINEextractor(1, 1.2, 40, 0.0, rows=rows, cols=cols, max_batch=B, lib=emu_lib, K=K, D=D)
+    ex.set_grow_waves(0)
+    cap = ex.capacity
+    kl = np.zeros((B, cap), plslam.KL_DTYPE)
+    desc = np.zeros((B, cap, 32), np.uint8)
+    fn = np.zeros((B, cap, 3), np.float64)
+    n = np.full(B, -7, np.int32)
+    ex.extract_batch_dev(frames, B, rows * cols, kl, desc, fn, n)   # (the emulator's device memory is host memory)
+    assert ex.status() == 0
+    for b in range(B):
+        rk, rd, rf, _ = _oracle_line(oracle, frames[b], 40, 0.0, K, D)
+        assert n[b] == len(rk) and _exact(kl[b, :n[b]], desc[b, :n[b]], fn[b, :n[b]], rk, rd, rf), b
+    ex.close()
+    orb = plslam.ORBextractor(200, 1.2, 3, 20, 7, rows=rows, cols=cols, max_batch=B, lib=emu_lib)
+    kps, od, on = orb.extract_batch(frames)
+    ref = oracle.OrbOracle(200, 1.2, 3, 20, 7)
+    for b in range(B):
+        rk, rd = ref.extract(frames[b])
+        assert on[b] == len(rk) and (od[b, :on[b]] == rd).all(), b
+        assert all((kps[b, :on[b]][f] == rk[f]).all() for f in rk.dtype.names), b
+    orb.close()

@@ -21,6 +21,9 @@ for k,v in sorted(d['kernels'].items(), key=lambda kv:-kv[1]['total']*kv[1].get(
 print('total %.2f MB per frame (was %.2f)' % (tot/1e6, toto/1e6), d['build'], o['build'])
 PY
 fi
+if [ "${INSTS:-0}" = 1 ]; then
+bash tools/pmc_insts.sh 1536 > $O/pmc_insts.txt 2>&1; head -16 $O/pmc_insts.txt
+fi
 show='import json,sys
 d=json.loads(sys.stdin.read()); k=d["kernel_ms_per_launch"]; print(d["value"], d["ms_per_step"], k)'
 for rep in 1 2; do
