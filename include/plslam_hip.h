@@ -492,6 +492,8 @@ PLH_API plh_status plh_line_search_by_projection_ml(const plh_keyline* kl, const
  *   plh_orb_search_by_projection_kf    ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) :1587-1716    Tracking::Relocalization
  *   plh_line_frame_bfmatch             LSDmatcher::FrameBFMatch(ldesc1, ldesc2, LineMatches, TH)   src/LSDmatcher.cpp:462-486       (SearchForTriangulation, isDouble = false)
  *   plh_line_fuse_search               the search inside LSDmatcher::Fuse(pKF, vpMapLines, th)           :860-1002                  LocalMapping.cc:1600, 1627
+ *   plh_line_frame_bfmatch_new         LSDmatcher::FrameBFMatchNew(ldesc1, ldesc2, LineMatches, kls1, kls2, kls2func, F, TH)   :488-625
+ *   plh_line_search_for_triangulation_new   LSDmatcher::SearchForTriangulationNew(pKF1, pKF2, vMatchedPairs, isDouble)         :780-832      (LocalMapping.cc:960, commented out)
  * (LSDmatcher::SearchForTriangulation's mutual forms, :672-778, are plh_line_search_double at TH_LOW / TH_HIGH.)
  * The adaptor overloads that keep the reference's signatures around them: pl-slam_amd/adaptor/HipORBmatcher.h, HipLSDmatcher.h. */
 PLH_API plh_status plh_orb_search_by_bow_kfkf(const plh_keypoint* kps1, const uint8_t* desc1, const int32_t* node1,
@@ -506,6 +508,23 @@ PLH_API plh_status plh_orb_search_for_triangulation(const plh_keypoint* kps1, co
                                                     int device);
 PLH_API plh_status plh_line_frame_bfmatch(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, float th, float nnratio,
                                           int32_t* matches12, int device);
+/* LSDmatcher::FrameBFMatchNew(ldesc1, ldesc2, LineMatches, kls1, kls2, kls2func, F, TH) (src/LSDmatcher.cpp:488-548, with
+ * mutualOverlap :550-625): the nearest LBD neighbour of every line of set 1, accepted if the segment carried over the fundamental
+ * matrix F (row-major 3 x 3; end point p of line 1 -> epipolar line F p, intersected with line 2's equation) overlaps line 2's own
+ * segment by more than 0.8, the distance is below th and the ratio test holds.  seg = (startPointX, startPointY, endPointX, endPointY)
+ * of every KeyLine, func2 = mvKeyLineFunctions of set 2 (3 doubles per line).  matches12[n1] = index in set 2 or -1. */
+PLH_API plh_status plh_line_frame_bfmatch_new(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, const float* seg1,
+                                              const float* seg2, const double* func2, const float F[9], float th, float nnratio,
+                                              int32_t* matches12, int device);
+/* LSDmatcher::SearchForTriangulationNew(pKF1, pKF2, vMatchedPairs, isDouble) (src/LSDmatcher.cpp:780-832; the reference's only call
+ * site, LocalMapping.cc:960, is commented out): FrameBFMatchNew both ways at th = TH_LOW -- F21 = ComputeF12(pKF2, pKF1) for 1 -> 2,
+ * F12 = ComputeF12(pKF1, pKF2) for 2 -> 1 (:834-858, the caller's) -- the mutual check if is_double, and only pairs of lines neither
+ * of which has a MapLine (has_ml = pKF->GetMapLine(i) != NULL).  matches12[n1], *nmatches = the method's return value. */
+PLH_API plh_status plh_line_search_for_triangulation_new(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, const float* seg1,
+                                                         const float* seg2, const double* func1, const double* func2,
+                                                         const float F21[9], const float F12[9], const uint8_t* has_ml1,
+                                                         const uint8_t* has_ml2, float th, float nnratio, int is_double,
+                                                         int32_t* matches12, int* nmatches, int device);
 PLH_API plh_status plh_line_fuse_search(const plh_keyline* kl, const uint8_t* cand_desc, int nl, const float* scale_factors_line,
                                         int nlevels, int nq, const uint8_t* q_valid, const float* q_seg, const int32_t* q_level,
                                         const uint8_t* q_desc, float th, float cos_th, int th_low, int32_t* best_idx, int* nfound,

@@ -123,6 +123,102 @@ int plo_line_search_double(const uint8_t* d1, int n1, const uint8_t* d2, int n2,
   return nmatches;
 }
 
+// LSDmatcher::mutualOverlap (reference src/LSDmatcher.cpp:550-625) for four points in homogeneous image coordinates (x, y, w):
+// the distance of the two inner points over the distance of the two outer ones.  Mat - Mat is a float subtraction per element,
+// cv::norm a double sum of squares in element order and a double sqrt, assigned to a float.
+static float plo_overlap_dist(const float a[3], const float b[3]) {
+  double s = 0;
+  for (int k = 0; k < 3; k++) { const float d = a[k] - b[k]; s += (double)d * d; }
+  return (float)std::sqrt(s);
+}
+static float plo_mutual_overlap(const float pts[4][3]) {
+  float max_dist = 0.0f;
+  int outer1 = 0, outer2 = 3, inner1 = 1, inner2 = 2;
+  for (int i = 0; i < 3; i++)
+    for (int j = i + 1; j < 4; j++) {
+      const float dist = plo_overlap_dist(pts[i], pts[j]);
+      if (dist > max_dist) { max_dist = dist; outer1 = i; outer2 = j; }
+    }
+  if (max_dist < 1.0f) return 0.0f;
+  if (outer1 == 0) {
+    if (outer2 == 1) { inner1 = 2; inner2 = 3; }
+    else if (outer2 == 2) { inner1 = 1; inner2 = 3; }
+    else { inner1 = 1; inner2 = 2; }
+  } else if (outer1 == 1) {
+    inner1 = 0;
+    inner2 = outer2 == 2 ? 3 : 2;
+  } else {
+    inner1 = 0; inner2 = 1;
+  }
+  double s = 0;
+  for (int k = 0; k < 3; k++) { const float d = pts[inner1][k] - pts[inner2][k]; s += (double)d * d; }
+  return (float)(std::sqrt(s) / max_dist);
+}
+
+// LSDmatcher::FrameBFMatchNew (reference src/LSDmatcher.cpp:488-548): knnMatch k = 2, then for the nearest neighbour of every
+// query (the loop over j runs to size() - 1 = 1) the end points of line 1 are carried over the fundamental matrix (epi = F p, a
+// 3 x 3 float product accumulated in element order), intersected with line 2's equation (l2.cross(epi), l2 = the float casts of
+// mvKeyLineFunctions), normalised by w (`Mat /= w`: a double division per element, back to float) and compared with line 2's own
+// end points by mutualOverlap; a match needs w of both > 1e-12 in magnitude, distance < TH, overlap > 0.8 and the ratio test.
+// seg = (startPointX, startPointY, endPointX, endPointY) per line; func2 = 3 doubles per line of set 2; F row-major.
+// Guard: the reference's `size() - 1` wraps when ldesc2 has no rows (unsigned); fewer than 2 train rows -> no matches.
+void plo_line_bfmatch_new(const uint8_t* d1, int n1, const uint8_t* d2, int n2, const float* seg1, const float* seg2,
+                          const double* func2, const float* F, float TH, float nnratio, int32_t* matches) {
+  for (int i = 0; i < n1; i++) matches[i] = -1;
+  if (n1 <= 0 || n2 < 2) return;
+  std::vector<int32_t> idx((size_t)n1 * 2), dist((size_t)n1 * 2);
+  plo_knn2(d1, n1, d2, n2, idx.data(), dist.data());
+  for (int q = 0; q < n1; q++) {
+    const int t = idx[q * 2];
+    const float m0 = (float)dist[q * 2], m1 = (float)dist[q * 2 + 1];
+    float pts[4][3];
+    bool ok = true;
+    const float l2[3] = {(float)func2[3 * t], (float)func2[3 * t + 1], (float)func2[3 * t + 2]};
+    for (int e = 0; e < 2; e++) {
+      const float p[3] = {seg1[4 * q + 2 * e], seg1[4 * q + 2 * e + 1], 1.0f};
+      float epi[3];
+      for (int r = 0; r < 3; r++) {
+        float acc = 0;
+        for (int k = 0; k < 3; k++) acc += F[3 * r + k] * p[k];
+        epi[r] = acc;
+      }
+      float c[3] = {l2[1] * epi[2] - l2[2] * epi[1], l2[2] * epi[0] - l2[0] * epi[2], l2[0] * epi[1] - l2[1] * epi[0]};
+      if (!(std::fabs(c[2]) > 1e-12)) ok = false;
+      const double w = c[2];
+      for (int k = 0; k < 3; k++) pts[e][k] = (float)(c[k] / w);
+    }
+    if (!ok) continue;   // (`continue` to j = 1, where the loop ends)
+    pts[2][0] = seg2[4 * t]; pts[2][1] = seg2[4 * t + 1]; pts[2][2] = 1.0f;
+    pts[3][0] = seg2[4 * t + 2]; pts[3][1] = seg2[4 * t + 3]; pts[3][2] = 1.0f;
+    const float score = plo_mutual_overlap(pts);
+    if (m0 < TH && score > 0.8 && m0 < nnratio * m1) matches[q] = t;
+  }
+}
+
+// LSDmatcher::SearchForTriangulationNew (reference src/LSDmatcher.cpp:780-832; its only call site, LocalMapping.cc:960, is commented
+// out): FrameBFMatchNew both ways at TH_LOW -- F21 = ComputeF12(pKF2, pKF1) carries set 1's end points into image 2, F12 the other
+// way -- the mutual check if isDouble, and only pairs of lines neither of which has a MapLine.  Returns nmatches.
+int plo_line_search_for_triangulation_new(const uint8_t* d1, int n1, const uint8_t* d2, int n2, const float* seg1, const float* seg2,
+                                          const double* func1, const double* func2, const float* F21, const float* F12,
+                                          const uint8_t* has_ml1, const uint8_t* has_ml2, float TH, float nnratio, int is_double,
+                                          int32_t* matches12) {
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n1 == 0 || n2 == 0) return 0;
+  std::vector<int32_t> m1(std::max(n1, 1)), m2(std::max(n2, 1));
+  plo_line_bfmatch_new(d1, n1, d2, n2, seg1, seg2, func2, F21, TH, nnratio, m1.data());
+  plo_line_bfmatch_new(d2, n2, d1, n1, seg2, seg1, func1, F12, TH, nnratio, m2.data());
+  int nmatches = 0;
+  for (int i = 0; i < n1; i++) {
+    const int j = m1[i];
+    if (j < 0) continue;
+    if (is_double && m2[j] != i) continue;
+    if (has_ml1[i] || has_ml2[j]) continue;
+    matches12[i] = j;
+    nmatches++;
+  }
+  return nmatches;
+}
+
 // ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches).
 // set 1 = KeyFrame (desc1, angle1 = mvKeysUn[].angle, node1 = FeatureVector node of each feature,
 // valid1 = feature has a non-bad MapPoint); set 2 = Frame.  matches21[j] = KeyFrame index whose MapPoint is

@@ -111,6 +111,13 @@ void plo_line_mad(const int32_t* dist, int nq, double* nn_mad, double* nn12_mad)
 void plo_line_bfmatch(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float th, float nnratio, int32_t* matches);
 int  plo_line_search_double(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float th, float nnratio,
                             int32_t* matches12);
+/* LSDmatcher::FrameBFMatchNew / SearchForTriangulationNew (src/LSDmatcher.cpp:488-548, 780-832; mutualOverlap :550-625) */
+void plo_line_bfmatch_new(const uint8_t* d1, int n1, const uint8_t* d2, int n2, const float* seg1, const float* seg2,
+                          const double* func2, const float* F, float th, float nnratio, int32_t* matches);
+int  plo_line_search_for_triangulation_new(const uint8_t* d1, int n1, const uint8_t* d2, int n2, const float* seg1,
+                                           const float* seg2, const double* func1, const double* func2, const float* F21,
+                                           const float* F12, const uint8_t* has_ml1, const uint8_t* has_ml2, float th,
+                                           float nnratio, int is_double, int32_t* matches12);
 int  plo_orb_search_by_bow(const uint8_t* desc1, const float* angle1, const int32_t* node1, const uint8_t* valid1, int n1,
                            const uint8_t* desc2, const float* angle2, const int32_t* node2, int n2,
                            int th_low, float nnratio, int check_ori, int32_t* matches21);

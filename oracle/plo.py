@@ -76,6 +76,8 @@ _SIGS = {
     "plo_line_mad": ([_V, _I, _V, _V], None),
     "plo_line_bfmatch": ([_V, _I, _V, _I, _F, _F, _V], None),
     "plo_line_search_double": ([_V, _I, _V, _I, _F, _F, _V], _I),
+    "plo_line_bfmatch_new": ([_V, _I, _V, _I, _V, _V, _V, _V, _F, _F, _V], None),
+    "plo_line_search_for_triangulation_new": ([_V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _F, _F, _I, _V], _I),
     "plo_orb_search_by_bow": ([_V, _V, _V, _V, _I, _V, _V, _V, _I, _I, _F, _I, _V], _I),
     "plo_lsd_detect": ([_V, _I, _I, _Z, _V, _I], _I),
     "plo_lsd_detect_ex": ([_V, _I, _I, _Z, _V, _I, _I], _I),

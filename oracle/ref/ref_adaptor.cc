@@ -433,7 +433,7 @@ int adx_local_mapping_triangulation(const char* voc_path, const void* kps1, cons
 namespace {
 // a KeyFrame that also holds nl keylines (68-byte KeyLine records) with their LBD descriptors; 8 line levels with factor `lscale`
 void build_kf_lines(BackScene& s, const void* kps28, const uint8_t* desc, int n, const void* kl68, const uint8_t* ldesc, int nl,
-                    const float gp[6], const float T16[16], const float K4[4], float lscale) {
+                    const float gp[6], const float T16[16], const float K4[4], float lscale, const double* linefn = nullptr) {
   Frame& f = s.f;
   f.NL = nl;
   f.mvKeylinesUn.resize(nl);
@@ -441,6 +441,8 @@ void build_kf_lines(BackScene& s, const void* kps28, const uint8_t* desc, int n,
   f.mLdesc = cv::Mat(nl > 0 ? nl : 0, 32, CV_8U);
   if (nl > 0) std::memcpy(f.mLdesc.data, ldesc, (size_t)nl * 32);
   f.mvKeyLineFunctions.assign(nl, Eigen::Vector3d(0, 0, 1));
+  if (linefn)
+    for (int i = 0; i < nl; i++) f.mvKeyLineFunctions[i] = Eigen::Vector3d(linefn[3 * i], linefn[3 * i + 1], linefn[3 * i + 2]);
   f.mvpMapLines.assign(nl, nullptr);
   f.mvbLineOutlier.assign(nl, false);
   f.mnScaleLevelsLine = 8;
@@ -503,6 +505,34 @@ int adx_local_mapping_line_triangulation(const void* kl1, const uint8_t* ld1, co
       if ((int)vec.size() != n1) return -4;
       for (int i = 0; i < n1; i++) out[i] = vec[i];
     }
+  }
+  *n_ref = res[0];
+  return res[1];
+}
+
+// LSDmatcher().SearchForTriangulationNew(pKF1, pKF2, vMatchedPairs, isDouble) (src/LSDmatcher.cpp:780-832; LocalMapping.cc:960) on two real
+// KeyFrames with poses T1 / T2 (4 x 4, row-major), their KeyLines (68-byte records), LBD rows and line equations (3 doubles per line);
+// has1 / has2: the line carries a MapLine.  The reference's side computes its fundamental matrices with its own ComputeF12, the drop-in
+// class with the same inherited method.  out_*[i] = line of KeyFrame 2 paired with line i, -1 none.
+int adx_local_mapping_line_triangulation_new(const void* kl1, const uint8_t* ld1, const double* fn1, const uint8_t* has1, int n1,
+                                             const void* kl2, const uint8_t* ld2, const double* fn2, const uint8_t* has2, int n2,
+                                             const float T1[16], const float T2[16], const float K4[4], int is_double, int32_t* out_ref,
+                                             int32_t* out_hip, int* n_ref) {
+  const float gp[6] = {0, 0, 640, 480, 0.1f, 0.1f}, z6[6] = {0, 0, 1, 0, 0, 2}, z3[3] = {0, 0, 1};
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    LineScene a, b;
+    build_kf_lines(a, nullptr, nullptr, 0, kl1, ld1, n1, gp, T1, K4, 1.2f, fn1);
+    build_kf_lines(b, nullptr, nullptr, 0, kl2, ld2, n2, gp, T2, K4, 1.2f, fn2);
+    for (int i = 0; i < n1; i++) if (has1[i]) a.kf->AddMapLine(add_line(a, z6, z3, 0, 1e9f, nullptr, 1, i), i);
+    for (int i = 0; i < n2; i++) if (has2[i]) b.kf->AddMapLine(add_line(b, z6, z3, 0, 1e9f, nullptr, 1, i), i);
+    int32_t* out = side == 0 ? out_ref : out_hip;
+    for (int i = 0; i < n1; i++) out[i] = -1;
+    std::vector<int> vec;
+    if (side == 0) { LSDmatcherCPU m; res[0] = m.SearchForTriangulationNew(a.kf, b.kf, vec, is_double != 0); }
+    else { LSDmatcher m; res[1] = m.SearchForTriangulationNew(a.kf, b.kf, vec, is_double != 0); }
+    if ((int)vec.size() != n1) return -4;
+    for (int i = 0; i < n1; i++) out[i] = vec[i];
   }
   *n_ref = res[0];
   return res[1];

@@ -6,6 +6,8 @@
 //   SearchDouble(Frame&, Frame&, LineMatches)        :427-460
 //   SearchByProjection(Cur, Last, th)                :72-176
 //   SearchByProjection(F, vpMapLines, th)            :221-338
+//   FrameBFMatchNew + mutualOverlap                  :488-625
+//   SearchForTriangulationNew (+ ComputeF12)         :780-858
 // TEST INFRASTRUCTURE ONLY.
 #include <cstdint>
 #include <cstring>
@@ -56,6 +58,8 @@ namespace {
 struct Matcher : LSDmatcher {   // FrameBFMatch / lineDescriptorMAD are protected members
   Matcher(float r) : LSDmatcher(r, true) {}
   using LSDmatcher::FrameBFMatch;
+  using LSDmatcher::FrameBFMatchNew;
+  using LSDmatcher::ComputeF12;
   using LSDmatcher::lineDescriptorMAD;
 };
 cv::Mat desc_mat(const uint8_t* d, int n) {
@@ -242,6 +246,70 @@ int ref_line_fuse(const plo_keyline* kl, const uint8_t* cand_desc, int nl, const
   for (const auto& e : kf.lineLog)
     if (e.first && (long)e.first->mnId >= 0) best_idx[e.first->mnId] = e.second;
   return nf;
+}
+
+// FrameBFMatchNew(ldesc1, ldesc2, LineMatches, kls1, kls2, kls2func, F, TH), src/LSDmatcher.cpp:488-548.  seg = (startPointX,
+// startPointY, endPointX, endPointY) per line, func2 = mvKeyLineFunctions of set 2 (3 doubles per line), F row-major CV_32F.
+static std::vector<KeyLine> seg_lines(const float* seg, int n) {
+  std::vector<KeyLine> k(n);
+  for (int i = 0; i < n; i++) {
+    std::memset(&k[i], 0, sizeof(KeyLine));
+    k[i].startPointX = seg[4 * i]; k[i].startPointY = seg[4 * i + 1]; k[i].endPointX = seg[4 * i + 2]; k[i].endPointY = seg[4 * i + 3];
+  }
+  return k;
+}
+static std::vector<Eigen::Vector3d> line_funcs(const double* fn, int n) {
+  std::vector<Eigen::Vector3d> f(n);
+  for (int i = 0; i < n; i++) { f[i](0) = fn[3 * i]; f[i](1) = fn[3 * i + 1]; f[i](2) = fn[3 * i + 2]; }
+  return f;
+}
+static cv::Mat mat_f32(const float* v, int r, int c) {
+  cv::Mat m(r, c, CV_32F);
+  for (int i = 0; i < r; i++)
+    for (int j = 0; j < c; j++) m.at<float>(i, j) = v[i * c + j];
+  return m;
+}
+void ref_line_bfmatch_new(const uint8_t* d1, int n1, const uint8_t* d2, int n2, const float* seg1, const float* seg2,
+                          const double* func2, const float* F, float th, float nnratio, int32_t* matches) {
+  Matcher m(nnratio);
+  std::vector<int> out;
+  m.FrameBFMatchNew(desc_mat(d1, n1), desc_mat(d2, n2), out, seg_lines(seg1, n1), seg_lines(seg2, n2), line_funcs(func2, n2),
+                    mat_f32(F, 3, 3), th);
+  for (int i = 0; i < n1; i++) matches[i] = out[i];
+}
+
+// SearchForTriangulationNew(pKF1, pKF2, vMatchedPairs, isDouble), src/LSDmatcher.cpp:780-832, on two stand-in KeyFrames: pose = (Rcw
+// row-major 3 x 3, tcw 3), K 3 x 3; has_ml = the line carries a MapLine.  F21_out / F12_out = what the reference's ComputeF12 (:834-858;
+// Mat::inv is the stand-in's 3 x 3 closed form) gave for (pKF2, pKF1) / (pKF1, pKF2): the matrices the test hands to the oracle and
+// to the library, whose C ABI takes them as inputs.
+int ref_line_search_for_triangulation_new(const uint8_t* d1, int n1, const uint8_t* d2, int n2, const float* seg1, const float* seg2,
+                                          const double* func1, const double* func2, const float* pose1, const float* pose2,
+                                          const float* K1, const float* K2, const uint8_t* has_ml1, const uint8_t* has_ml2,
+                                          float nnratio, int is_double, int32_t* matches12, float* F21_out, float* F12_out) {
+  Lines ls;
+  KeyFrame a, b;
+  struct { KeyFrame* kf; const uint8_t* d; int n; const float* seg; const double* fn; const float* pose; const float* K; const uint8_t* ml; } in[2] =
+      {{&a, d1, n1, seg1, func1, pose1, K1, has_ml1}, {&b, d2, n2, seg2, func2, pose2, K2, has_ml2}};
+  for (auto& e : in) {
+    e.kf->NL = e.n;
+    e.kf->mLineDescriptors = desc_mat(e.d, e.n);
+    e.kf->mvKeyLines = seg_lines(e.seg, e.n);
+    e.kf->mvKeyLineFunctions = line_funcs(e.fn, e.n);
+    e.kf->mvpMapLines.assign(e.n, nullptr);
+    for (int i = 0; i < e.n; i++)
+      if (e.ml[i]) e.kf->mvpMapLines[i] = ls.make(-1);
+    e.kf->Rcw = mat_f32(e.pose, 3, 3);
+    e.kf->tcw = mat_f32(e.pose + 9, 3, 1);
+    e.kf->mK = mat_f32(e.K, 3, 3);
+  }
+  Matcher m(nnratio);
+  KeyFrame *pa = &a, *pb = &b;
+  const cv::Mat F21 = m.ComputeF12(pb, pa), F12 = m.ComputeF12(pa, pb);
+  for (int i = 0; i < 9; i++) { F21_out[i] = F21.at<float>(i / 3, i % 3); F12_out[i] = F12.at<float>(i / 3, i % 3); }
+  std::vector<int> out;
+  const int n = m.SearchForTriangulationNew(&a, &b, out, is_double != 0);
+  for (int i = 0; i < n1; i++) matches12[i] = i < (int)out.size() ? out[i] : -1;
+  return n;
 }
 
 }  // extern "C"

@@ -223,7 +223,29 @@ class Mat {
     return m;
   }
   static Mat ones(int, int, int) { std::cerr << "oracle/ref stub: Mat::ones is compile-only" << std::endl; std::abort(); }
-  Mat inv(int = 0) const { std::cerr << "oracle/ref stub: Mat::inv is compile-only" << std::endl; std::abort(); }
+  // 3 x 3 CV_32F only (LSDmatcher::ComputeF12, src/LSDmatcher.cpp:857): the closed form with double products as cv::invert takes for
+  // n == 3 -- a stand-in that lets the harness produce a fundamental matrix; nothing derived from it is claimed to be pinned (the
+  // product takes F as an input)
+  Mat inv(int = 0) const {
+    if (!(type_ == CV_32F && rows == 3 && cols == 3)) { std::cerr << "oracle/ref stub: Mat::inv is 3 x 3 CV_32F only" << std::endl; std::abort(); }
+    const Mat& S = *this;
+    auto m = [&](int i, int j) { return (double)S.at<float>(i, j); };
+    double d = m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) - m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0)) +
+               m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
+    Mat r = Mat::zeros(3, 3, CV_32F);
+    if (d == 0.) return r;
+    d = 1. / d;
+    r.at<float>(0, 0) = (float)((m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) * d);
+    r.at<float>(0, 1) = (float)((m(0, 2) * m(2, 1) - m(0, 1) * m(2, 2)) * d);
+    r.at<float>(0, 2) = (float)((m(0, 1) * m(1, 2) - m(0, 2) * m(1, 1)) * d);
+    r.at<float>(1, 0) = (float)((m(1, 2) * m(2, 0) - m(1, 0) * m(2, 2)) * d);
+    r.at<float>(1, 1) = (float)((m(0, 0) * m(2, 2) - m(0, 2) * m(2, 0)) * d);
+    r.at<float>(1, 2) = (float)((m(0, 2) * m(1, 0) - m(0, 0) * m(1, 2)) * d);
+    r.at<float>(2, 0) = (float)((m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0)) * d);
+    r.at<float>(2, 1) = (float)((m(0, 1) * m(2, 0) - m(0, 0) * m(2, 1)) * d);
+    r.at<float>(2, 2) = (float)((m(0, 0) * m(1, 1) - m(0, 1) * m(1, 0)) * d);
+    return r;
+  }
   Mat cross(const Mat& o) const {
     Mat r(rows, cols, CV_32F);
     const float a0 = at<float>(0), a1 = at<float>(1), a2 = at<float>(2), b0 = o.at<float>(0), b1 = o.at<float>(1), b2 = o.at<float>(2);

@@ -120,6 +120,8 @@ _SIGS = {
     "plh_orb_search_by_bow_kfkf": ([_V, _V, _V, _V, _I, _V, _V, _V, _V, _I, _I, _F, _I, _V, _V, _I], _I),
     "plh_orb_search_for_triangulation": ([_V, _V, _V, _V, _I, _V, _V, _V, _V, _I, _V, _F, _F, _V, _V, _I, _I, _I, _V, _V, _I], _I),
     "plh_line_frame_bfmatch": ([_V, _I, _V, _I, _F, _F, _V, _I], _I),
+    "plh_line_frame_bfmatch_new": ([_V, _I, _V, _I, _V, _V, _V, _V, _F, _F, _V, _I], _I),
+    "plh_line_search_for_triangulation_new": ([_V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _F, _F, _I, _V, _V, _I], _I),
     "plh_line_fuse_search": ([_V, _V, _I, _V, _I, _I, _V, _V, _V, _V, _F, _F, _I, _V, _V, _I], _I),
     "plh_orb_search_by_sim3": ([_V, _V, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V, _V, _I], _I),
     "plh_orb_search_by_projection_kf": ([_V, _V, _I, _V, _V, _I, _V, _I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _I], _I),
@@ -825,6 +827,47 @@ class LSDmatcher:
         _check(L, L.plh_line_bfmatch_batch_dev(_p(di), _p(dd), _p(dna), _p(dnb), cap, 1,
                                                float(self.TH_LOW if TH is None else TH), self.mfNNratio, _p(dm), s), "bfmatch")
         return D.get(dm)[0, :n1].copy()
+
+
+    @staticmethod
+    def _line_args(ldesc, seg, func):
+        ldesc = np.ascontiguousarray(np.asarray(ldesc, np.uint8).reshape(-1, 32))
+        seg = np.ascontiguousarray(np.asarray(seg, np.float32).reshape(-1, 4))
+        func = np.ascontiguousarray(np.asarray(func, np.float64).reshape(-1, 3))
+        assert len(seg) == len(ldesc) and len(func) == len(ldesc)
+        return ldesc, seg, func
+
+    def FrameBFMatchNew(self, ldesc1, ldesc2, seg1, seg2, func2, F, TH=None):
+        """LSDmatcher::FrameBFMatchNew (LSDmatcher.cpp:488-548): LineMatches[NL1].  seg = (startPointX, startPointY, endPointX,
+        endPointY) per KeyLine, func2 = mvKeyLineFunctions of set 2, F the 3 x 3 fundamental matrix (CV_32F)."""
+        ldesc1, seg1, _ = self._line_args(ldesc1, seg1, np.zeros((len(np.asarray(seg1).reshape(-1, 4)), 3)))
+        ldesc2, seg2, func2 = self._line_args(ldesc2, seg2, func2)
+        F = np.ascontiguousarray(np.asarray(F, np.float32).reshape(9))
+        m = np.full(max(len(ldesc1), 1), -1, np.int32)
+        L = self.lib
+        _check(L, L.plh_line_frame_bfmatch_new(_p(ldesc1), len(ldesc1), _p(ldesc2), len(ldesc2), _p(seg1), _p(seg2), _p(func2), _p(F),
+                                               float(self.TH_LOW if TH is None else TH), self.mfNNratio, _p(m), self.D.device),
+               "plh_line_frame_bfmatch_new")
+        return m[:len(ldesc1)].copy()
+
+    def SearchForTriangulationNew(self, ldesc1, ldesc2, seg1, seg2, func1, func2, F21, F12, has_ml1, has_ml2, isDouble=False):
+        """LSDmatcher::SearchForTriangulationNew (LSDmatcher.cpp:780-832): (nmatches, vMatchedPairs[NL1]).  F21 = ComputeF12(pKF2, pKF1),
+        F12 = ComputeF12(pKF1, pKF2); has_ml = the line already carries a MapLine."""
+        ldesc1, seg1, func1 = self._line_args(ldesc1, seg1, func1)
+        ldesc2, seg2, func2 = self._line_args(ldesc2, seg2, func2)
+        F21 = np.ascontiguousarray(np.asarray(F21, np.float32).reshape(9))
+        F12 = np.ascontiguousarray(np.asarray(F12, np.float32).reshape(9))
+        ml1 = np.ascontiguousarray(np.asarray(has_ml1, np.uint8).reshape(-1))
+        ml2 = np.ascontiguousarray(np.asarray(has_ml2, np.uint8).reshape(-1))
+        assert len(ml1) == len(ldesc1) and len(ml2) == len(ldesc2)
+        m = np.full(max(len(ldesc1), 1), -1, np.int32)
+        c = C.c_int(0)
+        L = self.lib
+        _check(L, L.plh_line_search_for_triangulation_new(_p(ldesc1), len(ldesc1), _p(ldesc2), len(ldesc2), _p(seg1), _p(seg2), _p(func1),
+                                                          _p(func2), _p(F21), _p(F12), _p(ml1), _p(ml2), float(self.TH_LOW),
+                                                          self.mfNNratio, 1 if isDouble else 0, _p(m), C.byref(c), self.D.device),
+               "plh_line_search_for_triangulation_new")
+        return int(c.value), m[:len(ldesc1)].copy()
 
 
 class ORBmatcher:

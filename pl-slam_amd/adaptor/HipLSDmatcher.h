@@ -9,9 +9,10 @@
 // and the back end's (LocalMapping):
 //     LSDmatcher::SearchForTriangulation(pKF1, pKF2, vector<pair>&)         :672-725                     (LocalMapping.cc:679)
 //     LSDmatcher::SearchForTriangulation(pKF1, pKF2, vector<int>&, isDouble) :727-778                    (LocalMapping.cc:961)
+//     LSDmatcher::SearchForTriangulationNew(pKF1, pKF2, vector<int>&, isDouble) :780-832 (+ FrameBFMatchNew :488-625)  (LocalMapping.cc:960, commented out)
 //     LSDmatcher::Fuse(pKF, vpMapLines, th)                                 :860-1002                    (LocalMapping.cc:1600,1627)
 // Same construction as adaptor/HipORBmatcher.h: the reference's own class is read as LSDmatcherCPU, the class below derives
-// from it and inherits everything it does not re-declare (SearchForTriangulationNew, ...); the maintainer compiles
+// from it and inherits everything it does not re-declare (SerachForInitialize, ComputeF12, ...); the maintainer compiles
 // src/LSDmatcher.cpp with -DORBmatcher=ORBmatcherCPU -DLSDmatcher=LSDmatcherCPU.  The reference's debugging pictures
 // (matchResultTrack.jpg, :67 / :171 / :422; matchResultLocalMapping.jpg, :723 / :776) are not written.
 #ifndef PLSLAM_HIP_ADAPTOR_LSDMATCHER_H
@@ -164,6 +165,26 @@ class LSDmatcher : public LSDmatcherCPU {
       vMatchedPairs[i] = m12[i];
       nmatches++;
     }
+    return nmatches;
+  }
+
+  // LocalMapping.cc:960 (commented out in the reference): FrameBFMatchNew both ways -- nearest LBD neighbour, the segment carried over
+  // the fundamental matrix has to overlap the neighbour's by more than 0.8 (:488-625) -- at TH_LOW, the mutual check if isDouble, only
+  // lines without a MapLine (:780-832).  The fundamental matrices are the reference's own ComputeF12 (:834-858).
+  int SearchForTriangulationNew(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<int>& vMatchedPairs, bool isDouble = false) {
+    vMatchedPairs.clear();
+    vMatchedPairs.resize(pKF1->NL, -1);
+    if (pKF1->mLineDescriptors.rows == 0 || pKF2->mLineDescriptors.rows == 0) return 0;
+    const cv::Mat F21 = ComputeF12(pKF2, pKF1), F12 = ComputeF12(pKF1, pKF2);
+    const int n1 = pKF1->mLineDescriptors.rows, n2 = pKF2->mLineDescriptors.rows;
+    std::vector<unsigned char> ml1(n1), ml2(n2);
+    for (int i = 0; i < n1; i++) ml1[i] = pKF1->GetMapLine(i) ? 1 : 0;
+    for (int j = 0; j < n2; j++) ml2[j] = pKF2->GetMapLine(j) ? 1 : 0;
+    std::vector<int> m12;
+    const int nmatches = hip::SearchForTriangulationNew(pKF1->mLineDescriptors, pKF2->mLineDescriptors, pKF1->mvKeyLines, pKF2->mvKeyLines,
+                                                        pKF1->mvKeyLineFunctions, pKF2->mvKeyLineFunctions, F21, F12, ml1, ml2, mfNNratio,
+                                                        (float)TH_LOW, isDouble, m12);
+    for (size_t i = 0; i < m12.size() && i < vMatchedPairs.size(); i++) vMatchedPairs[i] = m12[i];
     return nmatches;
   }
 

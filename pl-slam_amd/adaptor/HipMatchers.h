@@ -89,6 +89,35 @@ inline void FrameBFMatch(const cv::Mat& ldesc1, const cv::Mat& ldesc2, std::vect
   check(plh_line_frame_bfmatch(d1.ptr<uchar>(), d1.rows, d2.ptr<uchar>(), d2.rows, TH, nnratio, LineMatches.data(), device));
 }
 
+// LSDmatcher::SearchForTriangulationNew's matching (LSDmatcher.cpp:780-832): FrameBFMatchNew both ways over the two fundamental
+// matrices, the mutual check, the MapLine gate -- one call.  F21 / F12: 3 x 3 CV_32F, the reference's ComputeF12 (pKF2, pKF1) / (pKF1, pKF2).
+template <class KL, class FN>
+inline int SearchForTriangulationNew(const cv::Mat& ldesc1, const cv::Mat& ldesc2, const std::vector<KL>& kls1, const std::vector<KL>& kls2,
+                                     const std::vector<FN>& func1, const std::vector<FN>& func2, const cv::Mat& F21, const cv::Mat& F12,
+                                     const std::vector<unsigned char>& hasML1, const std::vector<unsigned char>& hasML2, float nnratio,
+                                     float TH, bool isDouble, std::vector<int>& matches12, int device = 0) {
+  const int n1 = ldesc1.rows, n2 = ldesc2.rows;
+  matches12.assign(n1, -1);
+  if (n1 == 0 || n2 == 0) return 0;
+  cv::Mat d1 = ldesc1.isContinuous() ? ldesc1 : ldesc1.clone(), d2 = ldesc2.isContinuous() ? ldesc2 : ldesc2.clone();
+  std::vector<float> s1(4 * (size_t)n1), s2(4 * (size_t)n2), f21(9), f12(9);
+  std::vector<double> fn1(3 * (size_t)n1), fn2(3 * (size_t)n2);
+  for (int i = 0; i < n1; i++) {
+    s1[4 * i] = kls1[i].startPointX; s1[4 * i + 1] = kls1[i].startPointY; s1[4 * i + 2] = kls1[i].endPointX; s1[4 * i + 3] = kls1[i].endPointY;
+    for (int k = 0; k < 3; k++) fn1[3 * i + k] = func1[i](k);
+  }
+  for (int i = 0; i < n2; i++) {
+    s2[4 * i] = kls2[i].startPointX; s2[4 * i + 1] = kls2[i].startPointY; s2[4 * i + 2] = kls2[i].endPointX; s2[4 * i + 3] = kls2[i].endPointY;
+    for (int k = 0; k < 3; k++) fn2[3 * i + k] = func2[i](k);
+  }
+  for (int i = 0; i < 9; i++) { f21[i] = F21.at<float>(i / 3, i % 3); f12[i] = F12.at<float>(i / 3, i % 3); }
+  int nmatches = 0;
+  check(plh_line_search_for_triangulation_new(d1.ptr<uchar>(), n1, d2.ptr<uchar>(), n2, s1.data(), s2.data(), fn1.data(), fn2.data(),
+                                              f21.data(), f12.data(), hasML1.data(), hasML2.data(), TH, nnratio, isDouble ? 1 : 0,
+                                              matches12.data(), &nmatches, device));
+  return nmatches;
+}
+
 // cv::BFMatcher(NORM_HAMMING, false).knnMatch(q, t, matches, 2) (LSDmatcher.cpp:468-469, 494-495)
 inline void knnMatch2(const cv::Mat& q, const cv::Mat& t, std::vector<std::vector<cv::DMatch> >& matches, int device = 0) {
   matches.clear();

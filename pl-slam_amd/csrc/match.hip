@@ -942,6 +942,177 @@ plh_status plh_line_frame_bfmatch(const uint8_t* ldesc1, int n1, const uint8_t* 
   return st.download();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LSDmatcher::FrameBFMatchNew + mutualOverlap (LSDmatcher.cpp:488-625) and SearchForTriangulationNew (:780-832) on a knn2 table.
+// One lane per query: the nearest neighbour's line is intersected with the epipolar lines of the query's two end points and
+// the overlap of the carried-over segment with the neighbour's own decides, beside the distance and ratio tests.  The arithmetic
+// is the reference's, operation by operation (float products and sums in its element order, the normalisation `Mat /= w` as a double
+// division per element, cv::norm as a double sum of squares and a double sqrt assigned to a float); the build has no contraction.
+// ---------------------------------------------------------------------------------------------------------------------
+struct F33 { float m[9]; };
+
+__device__ __forceinline__ double bfnew_norm(const float* a, const float* b) {   // cv::norm(a - b), 3 x 1 CV_32F: a double
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const float d = a[k] - b[k]; s += (double)d * (double)d; }
+  return sqrt(s);
+}
+
+// mutualOverlap (:550-625): pts[0..1] = the carried-over end points, pts[2..3] = the neighbour's.  The reference finds the outer pair
+// (largest `float dist = norm(..)`, first wins) and divides the norm of the two others by it; the two others of pair k of the loop order
+// (0,1) (0,2) (0,3) (1,2) (1,3) (2,3) are pair 5 - k, lower index first as in the reference's inner1 / inner2: all six norms once, no
+// run-time index.
+__device__ __forceinline__ float bfnew_overlap(const float (*pts)[3]) {
+  const double n[6] = {bfnew_norm(pts[0], pts[1]), bfnew_norm(pts[0], pts[2]), bfnew_norm(pts[0], pts[3]),
+                       bfnew_norm(pts[1], pts[2]), bfnew_norm(pts[1], pts[3]), bfnew_norm(pts[2], pts[3])};
+  float maxDist = 0.0f;
+  double inner = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float d = (float)n[k];
+    if (d > maxDist) { maxDist = d; inner = n[5 - k]; }
+  }
+  if (maxDist < 1.0f) return 0.0f;
+  return (float)(inner / (double)maxDist);
+}
+
+__global__ void __launch_bounds__(256) k_line_bfmatch_new(const int32_t* idx, const int32_t* dist, int nq, int nt, const float* seg1,
+                                                          const float* seg2, const double* func2, F33 F, float TH, float nnratio,
+                                                          int32_t* M) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  int m = -1;
+  if (nt >= 2) {   // (the reference's loop bound size() - 1 leaves nothing to look at with one train row)
+    const int t = idx[q * 2];
+    const float m0 = (float)dist[q * 2], m1 = (float)dist[q * 2 + 1];
+    const float l2[3] = {(float)func2[3 * t], (float)func2[3 * t + 1], (float)func2[3 * t + 2]};
+    float pts[4][3];
+    bool ok = true;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const float p[3] = {seg1[4 * q + 2 * e], seg1[4 * q + 2 * e + 1], 1.0f};
+      float epi[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc += F.m[3 * r + k] * p[k];
+        epi[r] = acc;
+      }
+      const float c[3] = {l2[1] * epi[2] - l2[2] * epi[1], l2[2] * epi[0] - l2[0] * epi[2], l2[0] * epi[1] - l2[1] * epi[0]};
+      if (!((double)fabsf(c[2]) > 1e-12)) ok = false;
+      const double w = (double)c[2];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pts[e][k] = (float)((double)c[k] / w);
+    }
+    if (ok) {
+      pts[2][0] = seg2[4 * t]; pts[2][1] = seg2[4 * t + 1]; pts[2][2] = 1.0f;
+      pts[3][0] = seg2[4 * t + 2]; pts[3][1] = seg2[4 * t + 3]; pts[3][2] = 1.0f;
+      const float score = bfnew_overlap(pts);
+      if (m0 < TH && (double)score > 0.8 && m0 < nnratio * m1) m = t;
+    }
+  }
+  M[q] = m;
+}
+
+// SearchForTriangulationNew's loop (:812-820): the mutual check if isDouble, then only pairs neither line of which has a MapLine
+__global__ void __launch_bounds__(256) k_line_tri_new_resolve(const int32_t* m1, const int32_t* m2, int n1, const uint8_t* ml1,
+                                                              const uint8_t* ml2, int isDouble, int32_t* out, int32_t* nmatches) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n1) return;
+  int j = m1[i];
+  if (j >= 0 && ((isDouble && m2[j] != i) || ml1[i] || ml2[j])) j = -1;
+  out[i] = j;
+  if (j >= 0) atomicAdd(nmatches, 1);
+}
+
+// LSDmatcher::FrameBFMatchNew(ldesc1, ldesc2, LineMatches, kls1, kls2, kls2func, F, TH) (LSDmatcher.cpp:488-548) on host buffers.
+plh_status plh_line_frame_bfmatch_new(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, const float* seg1, const float* seg2,
+                                      const double* func2, const float F[9], float th, float nnratio, int32_t* matches12, int device) {
+  if (n1 < 0 || n2 < 0 || (n1 > 0 && (!ldesc1 || !matches12 || !seg1)) || (n2 > 0 && (!ldesc2 || !seg2 || !func2)) || !F) return PLH_ERR_INVALID;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  const int cap = std::max(n1, n2);
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  const uint8_t* d1 = st.in(ldesc1, (size_t)n1 * 32);
+  const uint8_t* d2 = st.in(ldesc2, (size_t)n2 * 32);
+  const float* s1 = st.in(seg1, (size_t)n1 * 4);
+  const float* s2 = st.in(seg2, (size_t)n2 * 4);
+  const double* f2 = st.in(func2, (size_t)n2 * 3);
+  const int32_t ns[2] = {n1, n2};
+  const int32_t* dn = st.in(ns, 2);
+  int32_t* di = st.scratch<int32_t>((size_t)cap * 2);
+  int32_t* dd = st.scratch<int32_t>((size_t)cap * 2);
+  int32_t* dm = st.out(matches12, (size_t)n1, (size_t)cap);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  rc = plh_hamming_knn2_batch_dev(d1, dn, cap, d2, dn + 1, cap, 1, di, dd, st.stream());
+  if (rc != PLH_OK) return rc;
+  F33 Fm;
+  for (int i = 0; i < 9; i++) Fm.m[i] = F[i];
+  hipLaunchKernelGGL(k_line_bfmatch_new, dim3((n1 + 255) / 256), dim3(256), 0, st.stream(), (const int32_t*)di, (const int32_t*)dd, n1, n2, s1,
+                     s2, f2, Fm, th, nnratio, dm);
+  PLH_LAUNCH_CHECK();
+  return st.download();
+}
+
+// LSDmatcher::SearchForTriangulationNew(pKF1, pKF2, vMatchedPairs, isDouble) (LSDmatcher.cpp:780-832) on host buffers: F21 =
+// ComputeF12(pKF2, pKF1) carries set 1's end points into image 2, F12 = ComputeF12(pKF1, pKF2) the other way; has_ml = GetMapLine(i) != 0.
+plh_status plh_line_search_for_triangulation_new(const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2, const float* seg1,
+                                                 const float* seg2, const double* func1, const double* func2, const float F21[9],
+                                                 const float F12[9], const uint8_t* has_ml1, const uint8_t* has_ml2, float th,
+                                                 float nnratio, int is_double, int32_t* matches12, int* nmatches, int device) {
+  if (n1 < 0 || n2 < 0 || !nmatches || (n1 > 0 && !matches12)) return PLH_ERR_INVALID;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  *nmatches = 0;
+  if (n1 == 0 || n2 == 0) return PLH_OK;
+  if (!ldesc1 || !ldesc2 || !seg1 || !seg2 || !func1 || !func2 || !F21 || !F12 || !has_ml1 || !has_ml2) return PLH_ERR_INVALID;
+  if (ensure_runtime() != PLH_OK) return PLH_ERR_NO_DEVICE;
+  const int cap = std::max(n1, n2);
+  Stager st;
+  plh_status rc = st.begin(device);
+  if (rc != PLH_OK) return rc;
+  const uint8_t* d1 = st.in(ldesc1, (size_t)n1 * 32);
+  const uint8_t* d2 = st.in(ldesc2, (size_t)n2 * 32);
+  const float* s1 = st.in(seg1, (size_t)n1 * 4);
+  const float* s2 = st.in(seg2, (size_t)n2 * 4);
+  const double* f1 = st.in(func1, (size_t)n1 * 3);
+  const double* f2 = st.in(func2, (size_t)n2 * 3);
+  const uint8_t* ml1 = st.in(has_ml1, (size_t)n1);
+  const uint8_t* ml2 = st.in(has_ml2, (size_t)n2);
+  const int32_t ns[2] = {n1, n2};
+  const int32_t* dn = st.in(ns, 2);
+  int32_t* i12 = st.scratch<int32_t>((size_t)cap * 2);
+  int32_t* e12 = st.scratch<int32_t>((size_t)cap * 2);
+  int32_t* i21 = st.scratch<int32_t>((size_t)cap * 2);
+  int32_t* e21 = st.scratch<int32_t>((size_t)cap * 2);
+  int32_t* m1 = st.scratch<int32_t>((size_t)cap);
+  int32_t* m2 = st.scratch<int32_t>((size_t)cap);
+  int32_t* dcnt = st.scratch_zero<int32_t>(1);
+  int32_t* dm = st.out(matches12, (size_t)n1, (size_t)cap);
+  if ((rc = st.upload()) != PLH_OK) return rc;
+  if ((rc = plh_hamming_knn2_batch_dev(d1, dn, cap, d2, dn + 1, cap, 1, i12, e12, st.stream())) != PLH_OK) return rc;
+  if ((rc = plh_hamming_knn2_batch_dev(d2, dn + 1, cap, d1, dn, cap, 1, i21, e21, st.stream())) != PLH_OK) return rc;
+  F33 Fa, Fb;
+  for (int i = 0; i < 9; i++) { Fa.m[i] = F21[i]; Fb.m[i] = F12[i]; }
+  hipLaunchKernelGGL(k_line_bfmatch_new, dim3((n1 + 255) / 256), dim3(256), 0, st.stream(), (const int32_t*)i12, (const int32_t*)e12, n1, n2,
+                     s1, s2, f2, Fa, th, nnratio, m1);
+  PLH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_line_bfmatch_new, dim3((n2 + 255) / 256), dim3(256), 0, st.stream(), (const int32_t*)i21, (const int32_t*)e21, n2, n1,
+                     s2, s1, f1, Fb, th, nnratio, m2);
+  PLH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_line_tri_new_resolve, dim3((n1 + 255) / 256), dim3(256), 0, st.stream(), (const int32_t*)m1, (const int32_t*)m2, n1,
+                     ml1, ml2, is_double, dm, dcnt);
+  PLH_LAUNCH_CHECK();
+  int32_t nm = 0;
+  st.fetch(&nm, (const int32_t*)dcnt, 1);
+  if ((rc = st.download()) != PLH_OK) return rc;
+  *nmatches = nm;
+  return PLH_OK;
+}
+
 // ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, false) on host buffers: see
 // plh_orb_search_for_triangulation_batch_dev.
 plh_status plh_orb_search_for_triangulation(const plh_keypoint* kps1, const uint8_t* desc1, const int32_t* node1, const uint8_t* has_mp1,

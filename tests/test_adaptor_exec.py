@@ -578,6 +578,28 @@ def _backend_calls(P, S, path, tmp_path):
                                                     C.byref(n_ref))
         assert nm == n_ref.value and nm > 30, (seed, mode, nm, n_ref.value)
         assert (o_ref == o_hip).all(), "LSDmatcher::SearchForTriangulation mode %d differs from the reference's" % mode
+    # ---- LocalMapping.cc:960 (commented out in the reference): LSDmatcher::SearchForTriangulationNew -- FrameBFMatchNew both ways over the
+    # reference's own ComputeF12, the overlap gate, the mutual check, the MapLine gate -- on two posed KeyFrames
+    G = _gen()
+    for seed, n1, n2, dbl in ((11, 300, 280, 0), (18, 900, 900, 1), (15, 37, 411, 1)):
+        x = G.lnew_inputs(S, seed, n1, n2, 0.1)
+        ks = []
+        for seg in (x["seg1"], x["seg2"]):
+            k = np.zeros(len(seg), P.KL_DTYPE)
+            k["startPointX"], k["startPointY"], k["endPointX"], k["endPointY"] = seg[:, 0], seg[:, 1], seg[:, 2], seg[:, 3]
+            k["class_id"] = np.arange(len(seg))
+            ks.append(k)
+        Ts = []
+        for pose in (x["pose1"], x["pose2"]):
+            T = np.eye(4, dtype=np.float32); T[:3, :3] = pose[:9].reshape(3, 3); T[:3, 3] = pose[9:]
+            Ts.append(np.ascontiguousarray(T))
+        K4 = np.array([517.3, 516.5, 318.6, 255.3], np.float32)
+        o_ref, o_hip = np.zeros(n1, np.int32), np.zeros(n1, np.int32)
+        R.adx_local_mapping_line_triangulation_new.argtypes = [V, V, V, V, I, V, V, V, V, I, V, V, V, I, V, V, V]
+        nm = R.adx_local_mapping_line_triangulation_new(p(ks[0]), p(x["d1"]), p(x["func1"]), p(x["ml1"]), n1, p(ks[1]), p(x["d2"]), p(x["func2"]),
+                                                        p(x["ml2"]), n2, p(Ts[0]), p(Ts[1]), p(K4), dbl, p(o_ref), p(o_hip), C.byref(n_ref))
+        assert nm == n_ref.value and (nm > 30 or n1 < 100), (seed, dbl, nm, n_ref.value)
+        assert (o_ref == o_hip).all(), "LSDmatcher::SearchForTriangulationNew seed %d differs from the reference's" % seed
     # ---- LocalMapping::SearchLineInNeighbors: LSDmatcher::Fuse(pKF, vpMapLines, th)
     for seed, th, behind in ((81, 3.0, None), (82, 6.0, 380)):
         sc = _line_fuse_scene(P, seed, behind_at=behind)

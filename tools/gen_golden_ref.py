@@ -528,6 +528,8 @@ def ref_lsdmatcher_lib():
     R.ref_line_search_by_projection_frame.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, F, V]
     R.ref_line_search_by_projection_ml.argtypes = [V, V, V, I, V, V, I, V, V, V, V, V, F, F, V]
     R.ref_line_fuse.argtypes = [V, V, I, V, I, V, V, I, V, V, V, V, V, V, V, V, V, F, V, V, V, V]
+    R.ref_line_bfmatch_new.argtypes = [V, I, V, I, V, V, V, V, F, F, V]
+    R.ref_line_search_for_triangulation_new.argtypes = [V, I, V, I, V, V, V, V, V, V, V, V, V, V, F, I, V, V, V]
     return R
 
 
@@ -1195,8 +1197,99 @@ def gen_computebow(S, out):
     np.savez_compressed(os.path.join(out, "ref_computebow.npz"), **g)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# LSDmatcher::FrameBFMatchNew / SearchForTriangulationNew (src/LSDmatcher.cpp:488-625, 780-858) -> ref_lsdmatcher_new.npz.
+# Two views of n random 3-D segments; set 2's rows are set 1's permuted (make_descriptor_sets), its segments shortened / shifted along
+# the line so that the overlap score spreads around the 0.8 gate.  The fundamental matrices come out of the reference's ComputeF12
+# through the harness and are part of the golden file: the oracle and the library take them as inputs.
+# ---------------------------------------------------------------------------------------------------------------
+LNEW_CASES = [(11, 300, 280, 0.06, 0.7), (12, 64, 80, 0.20, 0.9), (14, 500, 7, 0.10, 0.8), (15, 37, 411, 0.27, 0.75), (16, 2, 2, 0.05, 0.7),
+              (17, 3, 1, 0.05, 0.7), (18, 2000, 2000, 0.12, 0.8)]       # seed, n1, n2, bit-flip probability, nnratio
+LNEW_K = np.array([517.3, 0, 318.6, 0, 516.5, 255.3, 0, 0, 1], np.float32)
+LNEW_BF = [(50.0, 1.0), (80.0, 1.0), (50.0, 0.0), (50.0, -3.5)]     # TH, scale of F21 (0: the degenerate matrix, every w = 0)
+
+
+def lnew_inputs(S, seed, n1, n2, flip):
+    n = max(n1, n2)
+    a, b, perm = S.make_descriptor_sets(seed, n, flip)
+    rng = S.SplitMix64(7000 + seed)
+    u = lambda k: rng.uniform(k)
+    ay, ax = 0.04 + 0.1 * u(1)[0], 0.03 * (u(1)[0] - 0.5)
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    R2 = (Ry @ Rx).astype(np.float32)
+    t2 = np.array([-0.35, 0.02, 0.06], np.float32)
+    pose1 = np.r_[np.eye(3, dtype=np.float32).ravel(), np.zeros(3, np.float32)].astype(np.float32)
+    pose2 = np.r_[R2.ravel(), t2].astype(np.float32)
+    mid = np.c_[3.0 * (u(n) - 0.5), 2.0 * (u(n) - 0.5), 3.0 + 3.0 * u(n)]
+    d = np.c_[u(n) - 0.5, u(n) - 0.5, 0.4 * (u(n) - 0.5)]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hl = 0.2 + 0.4 * u(n)
+    P, Q = mid - d * hl[:, None], mid + d * hl[:, None]
+    K = LNEW_K.reshape(3, 3).astype(np.float64)
+
+    def proj(X, R, t):
+        x = (K @ (R.astype(np.float64) @ X.T + t.astype(np.float64)[:, None])).T
+        return x[:, :2] / x[:, 2:3]
+    s1 = np.c_[proj(P, np.eye(3), np.zeros(3)), proj(Q, np.eye(3), np.zeros(3))]
+    p2, q2 = proj(P, R2, t2)[perm], proj(Q, R2, t2)[perm]
+    cut0, cut1 = u(n) < 0.6, u(n) < 0.6
+    t0, t1 = 0.45 * u(n) * cut0, 1.0 - 0.45 * u(n) * cut1
+    sp, ep = p2 + t0[:, None] * (q2 - p2), p2 + t1[:, None] * (q2 - p2)
+    swap = u(n) < 0.3
+    sp2, ep2 = np.where(swap[:, None], ep, sp), np.where(swap[:, None], sp, ep)
+    perp = np.c_[-(q2 - p2)[:, 1], (q2 - p2)[:, 0]]
+    perp /= np.maximum(np.linalg.norm(perp, axis=1, keepdims=True), 1e-9)
+    off = 1.5 * (u(n) - 0.5)
+    s2 = np.c_[sp2 + off[:, None] * perp, ep2 + off[:, None] * perp]
+    seg1, seg2 = np.ascontiguousarray(s1[:n1], np.float32), np.ascontiguousarray(s2[:n2], np.float32)
+
+    def funcs(seg):
+        sg = seg.astype(np.float64)
+        l = np.cross(np.c_[sg[:, 0], sg[:, 1], np.ones(len(sg))], np.c_[sg[:, 2], sg[:, 3], np.ones(len(sg))])
+        return np.ascontiguousarray(l / np.maximum(np.hypot(l[:, 0], l[:, 1]), 1e-12)[:, None])
+    ml1, ml2 = (u(n) < 0.1).astype(np.uint8)[:n1], (u(n) < 0.1).astype(np.uint8)[:n2]
+    return dict(d1=np.ascontiguousarray(a[:n1]), d2=np.ascontiguousarray(b[:n2]), seg1=seg1, seg2=seg2, func1=funcs(seg1), func2=funcs(seg2),
+                pose1=pose1, pose2=pose2, K=LNEW_K.copy(), ml1=np.ascontiguousarray(ml1), ml2=np.ascontiguousarray(ml2))
+
+
+def reference_ltri_new(R, x, ratio, is_double):
+    n1, n2 = len(x["d1"]), len(x["d2"])
+    m, F21, F12 = np.full(max(n1, 1), -1, np.int32), np.zeros(9, np.float32), np.zeros(9, np.float32)
+    c = R.ref_line_search_for_triangulation_new(p(x["d1"]), n1, p(x["d2"]), n2, p(x["seg1"]), p(x["seg2"]), p(x["func1"]), p(x["func2"]),
+                                                p(x["pose1"]), p(x["pose2"]), p(x["K"]), p(x["K"]), p(x["ml1"]), p(x["ml2"]), ratio,
+                                                1 if is_double else 0, p(m), p(F21), p(F12))
+    return c, m[:n1], F21, F12
+
+
+def reference_lbf_new(R, x, F, th, ratio):
+    n1 = len(x["d1"])
+    m = np.full(max(n1, 1), -1, np.int32)
+    F = np.ascontiguousarray(F, np.float32)
+    R.ref_line_bfmatch_new(p(x["d1"]), n1, p(x["d2"]), len(x["d2"]), p(x["seg1"]), p(x["seg2"]), p(x["func2"]), p(F), th, ratio, p(m))
+    return m[:n1]
+
+
+def gen_lsdmatcher_new(S, out):
+    R = ref_lsdmatcher_lib()
+    g = {}
+    for seed, n1, n2, flip, ratio in LNEW_CASES:
+        x = lnew_inputs(S, seed, n1, n2, flip)
+        for dbl in (0, 1):
+            c, m, F21, F12 = reference_ltri_new(R, x, ratio, dbl)
+            g["tri_%d_%d_n" % (seed, dbl)], g["tri_%d_%d_m" % (seed, dbl)] = c, m
+        g["F21_%d" % seed], g["F12_%d" % seed] = F21, F12
+        for k, (th, sc) in enumerate(LNEW_BF):
+            g["bf_%d_%d" % (seed, k)] = reference_lbf_new(R, x, F21 * np.float32(sc), th, ratio)
+    np.savez_compressed(os.path.join(out, "ref_lsdmatcher_new.npz"), **g)
+    print("lsdmatcher New:", {k: int(v) for k, v in g.items() if k.endswith("_n")},
+          {k: int((v >= 0).sum()) for k, v in g.items() if k.startswith("bf_")})
+
+
 def main():
     S = _util.synth()
+    if "lnew" in sys.argv[1:]:   # only the file of LSDmatcher's New variants (the other files are not touched)
+        return gen_lsdmatcher_new(S, os.path.join(ROOT, "tests", "golden"))
     VM = _util._load("plslam_amd_vocab", os.path.join(ROOT, "pl-slam_amd", "vocab.py"))
     L = ref_lib()
     out = os.path.join(ROOT, "tests", "golden")
@@ -1217,6 +1310,7 @@ def main():
     gen_matchers(S, out)
     gen_keyframe_searches(S, out)
     gen_lsdmatcher(S, out)
+    gen_lsdmatcher_new(S, out)
     gen_distinctive(S, out)
     gen_framegrid(S, out)
     gen_frustum(S, out)
