@@ -133,6 +133,20 @@ int adx_search_double(void* h1, void* h2, float nnratio, int32_t* matches12) {
   return n;
 }
 
+// LSDmatcher(nnratio).SerachForInitialize(InitialFrame, CurrentFrame, LineMatches)  (Tracking.cc:710, commented out; src/LSDmatcher.cpp:340-373):
+// the reference's own method and the drop-in's on the same two Frames
+int adx_serach_for_initialize(void* h1, void* h2, float nnratio, int32_t* out_ref, int32_t* out_hip, int* n_ref) {
+  Frame &f1 = *(Frame*)h1, &f2 = *(Frame*)h2;
+  std::vector<int> a, b;
+  LSDmatcherCPU cpu(nnratio);
+  LSDmatcher hipm(nnratio);
+  *n_ref = cpu.SerachForInitialize(f1, f2, a);
+  const int n = hipm.SerachForInitialize(f1, f2, b);
+  if ((int)a.size() != f1.NL || (int)b.size() != f1.NL) return -4;
+  for (int i = 0; i < f1.NL; i++) { out_ref[i] = a[i]; out_hip[i] = b[i]; }
+  return n;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Back-end call sites on real KeyFrame / MapPoint objects: every function builds the scene TWICE and runs the reference's own
 // method (ORBmatcherCPU = src/ORBmatcher.cc) on one copy and the adaptor overload (ORBmatcher, GPU) on the other; the caller

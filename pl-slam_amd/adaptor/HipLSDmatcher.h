@@ -6,13 +6,14 @@
 //     LSDmatcher::SearchDouble(Frame&, Frame&, vector<int>&)                :427-460                     (Tracking.cc:711)
 //     LSDmatcher::SearchDouble(KeyFrame*, Frame&)                           :375-425                     (Tracking.cc:1159)
 //     LSDmatcher::DescriptorDistance                                        :654-670
+//     LSDmatcher::SerachForInitialize(Frame&, Frame&, vector<int>&)         :340-373                     (Tracking.cc:710, commented out)
 // and the back end's (LocalMapping):
 //     LSDmatcher::SearchForTriangulation(pKF1, pKF2, vector<pair>&)         :672-725                     (LocalMapping.cc:679)
 //     LSDmatcher::SearchForTriangulation(pKF1, pKF2, vector<int>&, isDouble) :727-778                    (LocalMapping.cc:961)
 //     LSDmatcher::SearchForTriangulationNew(pKF1, pKF2, vector<int>&, isDouble) :780-832 (+ FrameBFMatchNew :488-625)  (LocalMapping.cc:960, commented out)
 //     LSDmatcher::Fuse(pKF, vpMapLines, th)                                 :860-1002                    (LocalMapping.cc:1600,1627)
 // Same construction as adaptor/HipORBmatcher.h: the reference's own class is read as LSDmatcherCPU, the class below derives
-// from it and inherits everything it does not re-declare (SerachForInitialize, ComputeF12, ...); the maintainer compiles
+// from it and inherits everything it does not re-declare (ComputeF12, RadiusByViewingCos, ...); the maintainer compiles
 // src/LSDmatcher.cpp with -DORBmatcher=ORBmatcherCPU -DLSDmatcher=LSDmatcherCPU.  The reference's debugging pictures
 // (matchResultTrack.jpg, :67 / :171 / :422; matchResultLocalMapping.jpg, :723 / :776) are not written.
 #ifndef PLSLAM_HIP_ADAPTOR_LSDMATCHER_H
@@ -26,6 +27,8 @@
 #define LSDmatcher LSDmatcherCPU
 #include <LSDmatcher.h>   // the reference's include/LSDmatcher.h
 #undef LSDmatcher
+
+#include <limits>
 
 #include "HipMatchers.h"
 
@@ -127,6 +130,25 @@ class LSDmatcher : public LSDmatcherCPU {
       MapLine* pML = KF->GetMapLine(m21[i]);
       if (!pML) continue;
       CurrentFrame.mvpMapLines[i] = pML;
+      nmatches++;
+    }
+    return nmatches;
+  }
+
+  // Tracking.cc:710 (commented out in the reference; :340-373): the nearest LBD neighbour of every line of the initial frame, kept where
+  // the gap to the second nearest exceeds half the MAD of the gaps (Frame::lineDescriptorMAD, Frame.cc:519-544, is LSDmatcher's own,
+  // :627-652) -- FrameBFMatch without its distance and ratio tests, i.e. with both thresholds at infinity.
+  int SerachForInitialize(Frame& InitialFrame, Frame& CurrentFrame, std::vector<int>& LineMatches) {
+    LineMatches.clear();
+    LineMatches = std::vector<int>(InitialFrame.NL, -1);
+    if (InitialFrame.mLdesc.rows == 0 || CurrentFrame.mLdesc.rows == 0) return 0;
+    std::vector<int> m12;
+    const float inf = std::numeric_limits<float>::infinity();
+    hip::FrameBFMatch(InitialFrame.mLdesc, CurrentFrame.mLdesc, m12, inf, inf);
+    int nmatches = 0;
+    for (size_t i = 0; i < m12.size() && i < LineMatches.size(); i++) {
+      if (m12[i] < 0) continue;
+      LineMatches[i] = m12[i];
       nmatches++;
     }
     return nmatches;

@@ -305,6 +305,12 @@ def _initialization_matchers(P, S, O, path, rows, cols, nfeat):
         l1, l2 = np.ascontiguousarray(f1.ldesc), np.ascontiguousarray(f2.ldesc)
         rcl = O.lib().plo_line_search_double(O._p(l1), f1.NL, O._p(l2), f2.NL, 50.0, 0.7, O._p(rl))
         assert cl == rcl and (ml == rl).all() and rcl > 3, "SearchDouble (%d matches)" % rcl
+        # LSDmatcher(0.7).SerachForInitialize(InitialFrame, CurrentFrame, LineMatches)   (Tracking.cc:710, commented out): the reference's method
+        # and the drop-in's on the same Frames
+        o_ref, o_hip, n_ref = np.full(f1.NL, -7, np.int32), np.full(f1.NL, -9, np.int32), C.c_int(0)
+        R.adx_serach_for_initialize.argtypes = [V, V, F, V, V, V]
+        ci = R.adx_serach_for_initialize(f1.h, f2.h, 0.7, o_ref.ctypes.data_as(V), o_hip.ctypes.data_as(V), C.byref(n_ref))
+        assert ci == n_ref.value and (o_ref == o_hip).all() and ci >= rcl and ci > 3, "SerachForInitialize (%d / %d matches)" % (ci, n_ref.value)
         a, b = np.ascontiguousarray(d1[0]), np.ascontiguousarray(d2[0])
         dist = int(np.unpackbits(a ^ b).sum())
         assert R.adx_descriptor_distance(a.ctypes.data_as(V), b.ctypes.data_as(V)) == dist * 1001
