@@ -133,6 +133,30 @@ int adx_search_double(void* h1, void* h2, float nnratio, int32_t* matches12) {
   return n;
 }
 
+// LSDmatcher(nnratio).SearchByProjection(CurrentFrame, LastFrame) -- the two-argument overload, src/LSDmatcher.cpp:19-70, no caller in the
+// reference: the reference's method and the drop-in's on the same Frames.  has_ml[i]: line i of the last frame carries a MapLine (the
+// method only copies the pointer: a tag address stands for the object).  out_*[j] = the last frame's line whose MapLine line j of the
+// current frame received, -1 none.
+int adx_line_search_by_projection_two_arg(void* h_cur, void* h_last, const uint8_t* has_ml, float nnratio, int32_t* out_ref, int32_t* out_hip,
+                                          int* n_ref) {
+  Frame &cur = *(Frame*)h_cur, &last = *(Frame*)h_last;
+  char* const tag = reinterpret_cast<char*>(&last);
+  const std::vector<MapLine*> keepLast = last.mvpMapLines, keepCur = cur.mvpMapLines;
+  last.mvpMapLines.assign(last.NL, nullptr);
+  for (int i = 0; i < last.NL; i++) if (has_ml[i]) last.mvpMapLines[i] = reinterpret_cast<MapLine*>(tag + 1 + i);
+  int res[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    cur.mvpMapLines.assign(cur.NL, nullptr);
+    if (side == 0) { LSDmatcherCPU m(nnratio); res[0] = m.SearchByProjection(cur, last); }
+    else { LSDmatcher m(nnratio); res[1] = m.SearchByProjection(cur, last); }
+    int32_t* out = side == 0 ? out_ref : out_hip;
+    for (int j = 0; j < cur.NL; j++) out[j] = cur.mvpMapLines[j] ? (int32_t)(reinterpret_cast<char*>(cur.mvpMapLines[j]) - tag - 1) : -1;
+  }
+  last.mvpMapLines = keepLast; cur.mvpMapLines = keepCur;
+  *n_ref = res[0];
+  return res[1];
+}
+
 // LSDmatcher(nnratio).SerachForInitialize(InitialFrame, CurrentFrame, LineMatches)  (Tracking.cc:710, commented out; src/LSDmatcher.cpp:340-373):
 // the reference's own method and the drop-in's on the same two Frames
 int adx_serach_for_initialize(void* h1, void* h2, float nnratio, int32_t* out_ref, int32_t* out_hip, int* n_ref) {

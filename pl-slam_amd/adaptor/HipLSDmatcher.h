@@ -2,6 +2,7 @@
 // constructor and method signatures (include/LSDmatcher.h:22-76), whose tracking-path searches run on the GPU through the
 // C ABI of libplslam_hip.so:
 //     LSDmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th)     src/LSDmatcher.cpp:72-176    (Tracking.cc:1340-1357)
+//     LSDmatcher::SearchByProjection(Frame& Cur, const Frame& Last)         :19-70                       (no caller)
 //     LSDmatcher::SearchByProjection(Frame&, const vector<MapLine*>&, th)   :221-338                     (Tracking.cc:1849)
 //     LSDmatcher::SearchDouble(Frame&, Frame&, vector<int>&)                :427-460                     (Tracking.cc:711)
 //     LSDmatcher::SearchDouble(KeyFrame*, Frame&)                           :375-425                     (Tracking.cc:1159)
@@ -38,7 +39,22 @@ class LSDmatcher : public LSDmatcherCPU {
  public:
   LSDmatcher(float nnratio = 0.7, bool checkOri = true) : LSDmatcherCPU(nnratio, checkOri) {}
 
-  using LSDmatcherCPU::SearchByProjection;   // the two-argument overload (:178-219) stays the reference's
+  // The two-argument overload (src/LSDmatcher.cpp:19-70, no caller in the reference): mutual nearest LBD neighbours at TH_LOW between the
+  // last frame's lines and the current frame's, the last frame's MapLines carried over
+  int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame) {
+    if (LastFrame.mLdesc.rows == 0 || CurrentFrame.mLdesc.rows == 0) return 0;
+    std::vector<int> m12;
+    hip::SearchDouble(LastFrame.mLdesc, CurrentFrame.mLdesc, m12, mfNNratio, (float)TH_LOW);
+    int nmatches = 0;
+    for (size_t i = 0; i < m12.size() && i < LastFrame.mvpMapLines.size(); i++) {
+      if (m12[i] < 0) continue;
+      MapLine* mapLine = LastFrame.mvpMapLines[i];
+      if (!mapLine) continue;
+      CurrentFrame.mvpMapLines[m12[i]] = mapLine;
+      nmatches++;
+    }
+    return nmatches;
+  }
 
   static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return hip::DescriptorDistance(a, b); }
 

@@ -311,6 +311,14 @@ def _initialization_matchers(P, S, O, path, rows, cols, nfeat):
         R.adx_serach_for_initialize.argtypes = [V, V, F, V, V, V]
         ci = R.adx_serach_for_initialize(f1.h, f2.h, 0.7, o_ref.ctypes.data_as(V), o_hip.ctypes.data_as(V), C.byref(n_ref))
         assert ci == n_ref.value and (o_ref == o_hip).all() and ci >= rcl and ci > 3, "SerachForInitialize (%d / %d matches)" % (ci, n_ref.value)
+        # LSDmatcher(0.7).SearchByProjection(CurrentFrame, LastFrame) -- the two-argument overload (LSDmatcher.cpp:19-70, no caller): the
+        # reference's method and the drop-in's, the last frame's MapLines carried over to the same lines of the current frame
+        hm = (np.arange(f1.NL) % 4 != 1).astype(np.uint8)
+        o_ref, o_hip = np.full(f2.NL, -7, np.int32), np.full(f2.NL, -9, np.int32)
+        R.adx_line_search_by_projection_two_arg.argtypes = [V, V, V, F, V, V, V]
+        cp = R.adx_line_search_by_projection_two_arg(f2.h, f1.h, hm.ctypes.data_as(V), 0.7, o_ref.ctypes.data_as(V), o_hip.ctypes.data_as(V),
+                                                     C.byref(n_ref))
+        assert cp == n_ref.value and (o_ref == o_hip).all() and 0 < cp <= rcl and cp == int((o_hip >= 0).sum()), "SearchByProjection(Cur, Last) (%d / %d)" % (cp, n_ref.value)
         a, b = np.ascontiguousarray(d1[0]), np.ascontiguousarray(d2[0])
         dist = int(np.unpackbits(a ^ b).sum())
         assert R.adx_descriptor_distance(a.ctypes.data_as(V), b.ctypes.data_as(V)) == dist * 1001
