@@ -111,6 +111,41 @@ def _check_device(P, synth, lib):
     assert c == 0 and len(got) == 0
 
 
+def _check_errors(P, synth, lib):
+    """Error behaviour of the two entry points: negative counts and missing arrays are refused (PLH_ERR_INVALID = a non-zero status, nothing
+    written), empty sets are not an error."""
+    G = _gen()
+    L = P.load(lib)
+    x = G.lnew_inputs(synth, 12, 6, 7, 0.1)
+    p, F = P._p, np.ascontiguousarray(np.eye(3, dtype=np.float32).reshape(9))
+    m, c = np.full(6, 5, np.int32), C.c_int(-3)
+    assert L.plh_line_frame_bfmatch_new(p(x["d1"]), -1, p(x["d2"]), 7, p(x["seg1"]), p(x["seg2"]), p(x["func2"]), p(F), 50.0, 0.7, p(m), 0) != 0
+    assert L.plh_line_frame_bfmatch_new(p(x["d1"]), 6, p(x["d2"]), 7, None, p(x["seg2"]), p(x["func2"]), p(F), 50.0, 0.7, p(m), 0) != 0
+    assert L.plh_line_frame_bfmatch_new(p(x["d1"]), 6, p(x["d2"]), 7, p(x["seg1"]), p(x["seg2"]), None, p(F), 50.0, 0.7, p(m), 0) != 0
+    assert L.plh_line_frame_bfmatch_new(p(x["d1"]), 6, p(x["d2"]), 7, p(x["seg1"]), p(x["seg2"]), p(x["func2"]), None, 50.0, 0.7, p(m), 0) != 0
+    assert (m == 5).all()
+    assert L.plh_line_frame_bfmatch_new(p(x["d1"]), 6, None, 0, p(x["seg1"]), None, None, p(F), 50.0, 0.7, p(m), 0) == 0 and (m == -1).all()
+    m[:] = 5
+    args = [p(x["d1"]), 6, p(x["d2"]), 7, p(x["seg1"]), p(x["seg2"]), p(x["func1"]), p(x["func2"]), p(F), p(F), p(x["ml1"]), p(x["ml2"]), 50.0, 0.7, 1,
+            p(m), C.byref(c), 0]
+    for k in (4, 6, 8, 10, 11):      # seg1, func1, F21, has_ml1, has_ml2 missing
+        bad = list(args); bad[k] = None
+        assert L.plh_line_search_for_triangulation_new(*bad) != 0, k
+    bad = list(args); bad[16] = None
+    assert L.plh_line_search_for_triangulation_new(*bad) != 0
+    bad = list(args); bad[3] = -2
+    assert L.plh_line_search_for_triangulation_new(*bad) != 0
+
+
+def test_emu_lsdmatcher_new_error_behaviour(plslam, synth, emu_lib):
+    _check_errors(plslam, synth, emu_lib)
+
+
+@pytest.mark.gpu
+def test_gpu_lsdmatcher_new_error_behaviour(plslam, synth):
+    _check_errors(plslam, synth, None)
+
+
 def test_emu_reproduces_reference_lsdmatcher_new(plslam, synth, emu_lib):
     """The HIP sources compiled for the host emulator (tests/hipemu), through the C ABI."""
     _check_device(plslam, synth, emu_lib)
