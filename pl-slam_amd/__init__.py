@@ -808,7 +808,7 @@ class LSDmatcher:
         m, c = self.SearchDoubleBatch([ldesc1], [ldesc2])
         return int(c[0]), m[0, :len(ldesc1)].copy()
 
-    def FrameBFMatch(self, ldesc1, ldesc2, TH=None):
+    def FrameBFMatch(self, ldesc1, ldesc2, TH=None, nnratio=None):
         """LSDmatcher::FrameBFMatch (LSDmatcher.cpp:462-486): LineMatches[NL1]."""
         ldesc1 = np.asarray(ldesc1, np.uint8).reshape(-1, 32)
         ldesc2 = np.asarray(ldesc2, np.uint8).reshape(-1, 32)
@@ -825,8 +825,20 @@ class LSDmatcher:
         s = C.c_void_p(D.stream())
         _check(L, L.plh_hamming_knn2_batch_dev(_p(da), _p(dna), cap, _p(db), _p(dnb), cap, 1, _p(di), _p(dd), s), "knn2")
         _check(L, L.plh_line_bfmatch_batch_dev(_p(di), _p(dd), _p(dna), _p(dnb), cap, 1,
-                                               float(self.TH_LOW if TH is None else TH), self.mfNNratio, _p(dm), s), "bfmatch")
+                                               float(self.TH_LOW if TH is None else TH),
+                                               float(self.mfNNratio if nnratio is None else nnratio), _p(dm), s), "bfmatch")
         return D.get(dm)[0, :n1].copy()
+
+    def SerachForInitialize(self, ldesc1, ldesc2):
+        """LSDmatcher::SerachForInitialize (sic; LSDmatcher.cpp:340-373, call site Tracking.cc:710 commented out): the nearest neighbour of
+        every line of the initial frame, kept where the gap to the second nearest exceeds half the MAD of the gaps -- FrameBFMatch without
+        its distance and ratio tests.  Returns (nmatches, LineMatches[NL1])."""
+        ldesc1 = np.asarray(ldesc1, np.uint8).reshape(-1, 32)
+        ldesc2 = np.asarray(ldesc2, np.uint8).reshape(-1, 32)
+        if len(ldesc1) == 0 or len(ldesc2) == 0:
+            return 0, np.full(len(ldesc1), -1, np.int32)
+        m = self.FrameBFMatch(ldesc1, ldesc2, TH=float("inf"), nnratio=float("inf"))
+        return int((m >= 0).sum()), m
 
 
     @staticmethod

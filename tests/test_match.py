@@ -120,6 +120,10 @@ def test_emu_line_search_double(plslam, oracle, synth, emu_lib):
     ref = np.zeros(64, np.int32)
     oracle.lib().plo_line_bfmatch(oracle._p(a), 64, oracle._p(b), 80, 50.0, 0.7, oracle._p(ref))
     assert (m.FrameBFMatch(a, b) == ref).all()
+    # SerachForInitialize (LSDmatcher.cpp:340-373): only the gap test of FrameBFMatch -- both thresholds at infinity
+    oracle.lib().plo_line_bfmatch(oracle._p(a), 64, oracle._p(b), 80, float("inf"), float("inf"), oracle._p(ref))
+    c, got = m.SerachForInitialize(a, b)
+    assert (got == ref).all() and c == int((ref >= 0).sum()) and c >= int((m.FrameBFMatch(a, b) >= 0).sum())
 
 
 def test_emu_search_by_bow(plslam, oracle, synth, emu_lib):
