@@ -12,6 +12,7 @@
 // (SearchByProjection x3, SearchByBoW) are driven by ref_frame.cc's own harness functions, which in this build instantiate the
 // adaptor ORBmatcher / LSDmatcher.  TEST INFRASTRUCTURE ONLY.
 #include <cmath>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -552,6 +553,8 @@ int adx_local_mapping_line_triangulation(const void* kl1, const uint8_t* ld1, co
 // KeyFrames with poses T1 / T2 (4 x 4, row-major), their KeyLines (68-byte records), LBD rows and line equations (3 doubles per line);
 // has1 / has2: the line carries a MapLine.  The reference's side computes its fundamental matrices with its own ComputeF12, the drop-in
 // class with the same inherited method.  out_*[i] = line of KeyFrame 2 paired with line i, -1 none.
+static double g_tri_new_us[2] = {0, 0};   // wall microseconds of the last call's two method calls: [0] the reference's, [1] the drop-in's
+void adx_local_mapping_line_triangulation_new_us(double out[2]) { out[0] = g_tri_new_us[0]; out[1] = g_tri_new_us[1]; }
 int adx_local_mapping_line_triangulation_new(const void* kl1, const uint8_t* ld1, const double* fn1, const uint8_t* has1, int n1,
                                              const void* kl2, const uint8_t* ld2, const double* fn2, const uint8_t* has2, int n2,
                                              const float T1[16], const float T2[16], const float K4[4], int is_double, int32_t* out_ref,
@@ -567,8 +570,10 @@ int adx_local_mapping_line_triangulation_new(const void* kl1, const uint8_t* ld1
     int32_t* out = side == 0 ? out_ref : out_hip;
     for (int i = 0; i < n1; i++) out[i] = -1;
     std::vector<int> vec;
+    const auto t0 = std::chrono::steady_clock::now();
     if (side == 0) { LSDmatcherCPU m; res[0] = m.SearchForTriangulationNew(a.kf, b.kf, vec, is_double != 0); }
     else { LSDmatcher m; res[1] = m.SearchForTriangulationNew(a.kf, b.kf, vec, is_double != 0); }
+    g_tri_new_us[side] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     if ((int)vec.size() != n1) return -4;
     for (int i = 0; i < n1; i++) out[i] = vec[i];
   }
